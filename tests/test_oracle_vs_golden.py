@@ -1,0 +1,124 @@
+"""Pin the oracle restatement (oracle/*.c) to the REAL reference.
+
+Every expected value under tests/golden/ was produced by the reference itself
+(oracle/_ref/*, built by oracle/Makefile.ref, driven by tools/make_goldens.py).
+CPU only."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN
+import oracle_ctypes as oc
+
+
+def fnv(vals):
+    h = 1469598103934665603
+    for v in vals:
+        u = v & 0xFFFFFFFF
+        for i in range(4):
+            h ^= (u >> (8 * i)) & 0xFF
+            h = (h * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _pssm(lib, spec, rc, cache={}):
+    key = (spec, rc)
+    if key not in cache:
+        p = oc.Pssm()
+        if spec == "flat":
+            lib.ora_pssm_flat(C.byref(p))
+        else:
+            assert lib.ora_pssm_read(os.path.join(GOLDEN, spec).encode(), C.byref(p)) == 1
+        if rc:
+            q = oc.Pssm()
+            lib.ora_pssm_revcom(C.byref(p), C.byref(q))
+            p = q
+        cache[key] = p
+    return cache[key]
+
+
+def dp_cases():
+    with open(os.path.join(GOLDEN, "dp_vectors.txt")) as f:
+        lines = [l.rstrip("\n") for l in f if not l.startswith("#")]
+    return list(zip(lines[0::2], lines[1::2]))
+
+
+def test_dp_vectors(oracle):
+    """dyn_prog / max_sg_score / find_align_begin / populate_pwaln_to_begin:
+    full S and T matrices (hashed), end points and both gapped strings."""
+    cases = dp_cases()
+    assert len(cases) >= 400
+    for inp, exp in cases:
+        _, spec, rc, sg5, _sg3, s1, s2, mask = inp.split(" ")
+        e = exp.split(" ")
+        n1, n2 = len(s1), len(s2)
+        S = (C.c_int * (n1 * n2))()
+        T = (C.c_int * (n1 * n2))()
+        res = oc.Aln()
+        rg = C.create_string_buffer(520)
+        fg = C.create_string_buffer(520)
+        m = None if mask == "*" else bytes(1 if ch == "1" else 0 for ch in mask)
+        oracle.ora_align(s1.encode(), n1, s2.encode(), n2, m, C.byref(_pssm(oracle, spec, int(rc))), int(sg5),
+                         C.byref(res), rg, fg, S, T)
+        got = [res.best, res.aec, res.aer, res.abc, res.abr]
+        assert got == [int(x) for x in e[1:6]], inp[:80]
+        assert "%016x" % fnv(S) == e[6], inp[:80]
+        assert "%016x" % fnv(T) == e[7], inp[:80]
+        assert rg.value.decode() == e[8] and fg.value.decode() == e[9], inp[:80]
+
+
+def test_consensus_vectors(oracle):
+    with open(os.path.join(GOLDEN, "cons_vectors.txt")) as f:
+        lines = [l.rstrip("\n") for l in f]
+    for inp, exp in zip(lines[0::2], lines[1::2]):
+        v = [int(x) for x in inp.split()[1:]]
+        bc = oc.Counts(As=v[1], Cs=v[2], Gs=v[3], Ts=v[4], gaps=v[5], cov=v[6], scoreA=v[7], scoreC=v[8],
+                       scoreG=v[9], scoreT=v[10])
+        got = oracle.ora_find_consensus(C.byref(bc), v[0]).decode()
+        assert got == exp.split(" ")[1], inp
+
+
+def test_myers_vectors(oracle):
+    with open(os.path.join(GOLDEN, "myers_vectors.txt")) as f:
+        lines = [l.rstrip("\n") for l in f]
+    n = 0
+    for inp, exp in zip(lines[0::2], lines[1::2]):
+        mode, maxd, a, b = inp.split(" ")
+        d_exp, bt_exp = exp.split(" ")
+        bt = C.create_string_buffer(len(a) + len(b) + int(maxd) + 8)
+        d = oracle.ora_myers_diff(a.encode(), int(mode), b.encode(), int(maxd), bt)
+        assert d == int(d_exp), inp[:60]
+        if d != 0xFFFFFFFF:
+            assert bt.value.decode() == bt_exp, inp[:60]
+        n += 1
+    assert n >= 200
+
+
+def maln_cases():
+    with open(os.path.join(GOLDEN, "maln", "cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(maln_cases().keys()))
+def test_whole_run_maln(name, oracle_build, tmp_path):
+    """Run the oracle's mia front end on the committed inputs; every .maln it
+    writes must equal the reference's byte for byte (line 1 = timestamp excluded)."""
+    if name == "s150_full" and os.environ.get("MIA_SLOW", "0") != "1":
+        pytest.skip("unseeded pass 1 over 150 reads takes ~25 s on the CPU oracle (set MIA_SLOW=1)")
+    args = maln_cases()[name]
+    root = str(tmp_path / name)
+    subprocess.run([os.path.join(oracle_build, "ora_mia")] + args + ["-m", root], cwd=GOLDEN, check=True,
+                   stderr=subprocess.DEVNULL)
+    it = 1
+    while os.path.exists(os.path.join(GOLDEN, "maln", f"{name}.{it}")):
+        with open(os.path.join(GOLDEN, "maln", f"{name}.{it}")) as f:
+            exp = f.read()
+        with open(f"{root}.{it}") as f:
+            got = "".join(f.readlines()[1:])
+        assert got == exp, f"{name}.{it}"
+        it += 1
+    assert it > 1
+    assert not os.path.exists(f"{root}.{it}")

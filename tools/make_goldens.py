@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REAL reference (oracle/_ref/*, built
+by oracle/Makefile.ref from /root/reference).  Runs only in the build
+container; the outputs (data: inputs + expected outputs) are committed so that
+the GPU box, which has no /root/reference, can replay them.
+
+  tests/golden/mt311.fa              sequence data recovered from src/mt311.c
+  tests/golden/tr1.fna, tf.fna       the reference's own test fixtures (data)
+  tests/golden/ancient.submat.txt    the reference's PSSM table (data)
+  tests/golden/dp_vectors.txt        DP unit vectors  (ref_dp_driver)
+  tests/golden/cons_vectors.txt      find_consensus vectors (ref_dp_driver)
+  tests/golden/myers_vectors.txt     Myers vectors    (ref_myers_driver)
+  tests/golden/maln/<case>.<iter>    whole-run .maln files, line 1 (timestamp) removed
+  tests/golden/maln/cases.json       the command line of each case
+"""
+import json, os, random, shutil, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import gen_data  # noqa: E402
+
+REF = "/root/reference"
+RB = os.path.join(ROOT, "oracle", "_ref")
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def sh(cmd, **kw):
+    return subprocess.run(cmd, check=True, **kw)
+
+
+def dp_vectors():
+    rnd = random.Random(20261003)
+    anc = os.path.join(G, "ancient.submat.txt")
+    lines = []
+
+    def rseq(n, alphabet="ACGT"):
+        return "".join(rnd.choice(alphabet) for _ in range(n))
+
+    def mutate(s, p=0.1):
+        out = []
+        for ch in s:
+            u = rnd.random()
+            if u < p / 3:
+                continue
+            if u < 2 * p / 3:
+                out.append(rnd.choice("ACGT"))
+            if u < p:
+                out.append(rnd.choice("ACGT"))
+            else:
+                out.append(ch)
+        return "".join(out) or "A"
+
+    for i in range(400):
+        kind = i % 8
+        len2 = rnd.randint(1, 70) if i % 5 else rnd.randint(90, 256)
+        len1 = rnd.randint(max(2, len2 // 2), len2 + 140)
+        refalpha = "ACGT" if kind < 5 else "ACGTNRYacgt"
+        s1 = rseq(len1, refalpha)
+        if kind in (0, 1, 2, 5):           # read derived from the window
+            st = rnd.randint(0, max(0, len1 - len2))
+            s2 = mutate(s1[st:st + len2].upper().replace("R", "A").replace("Y", "C"), 0.08 if kind != 2 else 0.3)[:256]
+        elif kind == 3:                    # repeats -> ties
+            unit = rseq(rnd.randint(1, 4))
+            s1 = (unit * (len1 // len(unit) + 1))[:len1]
+            s2 = (unit * (len2 // len(unit) + 1))[:len2]
+        elif kind == 4:                    # homopolymers -> ties in gap placement
+            s1 = "".join(rnd.choice("AC") * rnd.randint(1, 6) for _ in range(len1))[:len1]
+            st = rnd.randint(0, max(0, len1 - len2))
+            s2 = mutate(s1[st:st + len2], 0.15)
+        else:                              # unrelated / N-rich read
+            s2 = rseq(len2, "ACGTN" if kind == 6 else "ACGT")
+        s2 = s2[:256] or "A"
+        matrix = ["flat", anc][i % 2]
+        rc = 1 if (i % 7 == 3) else 0
+        sg5 = 0 if (i % 11 == 5) else 1
+        if i % 3 == 0:
+            mask = "*"
+        else:                              # k-mer style column mask: a few open intervals
+            m = ["0"] * len(s1)
+            for _ in range(rnd.randint(1, 3)):
+                a = rnd.randint(0, len(s1) - 1)
+                b = min(len(s1), a + rnd.randint(1, len(s2) + 30))
+                for j in range(a, b):
+                    m[j] = "1"
+            mask = "".join(m)
+        lines.append(f"D {matrix} {rc} {sg5} 1 {s1} {s2} {mask}")
+    # long-gap cases (trace escape paths): read = left part + right part far apart
+    for g in (40, 70, 120, 200):
+        left, right = rseq(60), rseq(60)
+        s1 = rseq(20) + left + rseq(g) + right + rseq(20)
+        lines.append(f"D flat 0 1 1 {s1} {left + right} *")
+        s2 = left[:30] + rseq(g // 2) + left[30:]          # long insertion in the read
+        lines.append(f"D flat 0 1 1 {rseq(30) + left + rseq(30)} {s2[:256]} *")
+    inp = "\n".join(lines) + "\n"
+    out = subprocess.run([os.path.join(RB, "ref_dp_driver")], input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode()
+    outs = out.strip().split("\n")
+    assert len(outs) == len(lines)
+    with open(os.path.join(G, "dp_vectors.txt"), "w") as f:
+        f.write("# input line (see oracle/ref_dp_driver.c), then the reference's answer; matrix path is relative to tests/golden\n")
+        for a, b in zip(lines, outs):
+            f.write(a.replace(anc, "ancient.submat.txt") + "\n" + b + "\n")
+
+
+def cons_vectors():
+    rnd = random.Random(7)
+    lines = []
+    for i in range(300):
+        cc = 1 + (i % 2)
+        cov = rnd.choice([0, 1, 2, 3, 4, 7, 10, 100])
+        gaps = rnd.randint(0, cov) if cov else 0
+        if i % 9 == 0 and cov:
+            gaps = cov // 2
+        cnt = [rnd.randint(0, max(0, cov - gaps)) for _ in range(4)]
+        if i % 4 == 0:
+            base = rnd.randint(-3000, 3000)
+            sc = [base, base, rnd.randint(-3000, 3000), base][: 4]
+            rnd.shuffle(sc)
+        else:
+            sc = [rnd.randint(-5000, 5000) for _ in range(4)]
+        if i % 13 == 0:
+            sc = [-399, -400, -399, -5000]
+        if i % 17 == 0:
+            sc = [-1, -2401, -2402, -9000]
+        lines.append(f"C {cc} {cnt[0]} {cnt[1]} {cnt[2]} {cnt[3]} {gaps} {cov} {sc[0]} {sc[1]} {sc[2]} {sc[3]}")
+    inp = "\n".join(lines) + "\n"
+    out = subprocess.run([os.path.join(RB, "ref_dp_driver")], input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().strip().split("\n")
+    with open(os.path.join(G, "cons_vectors.txt"), "w") as f:
+        for a, b in zip(lines, out):
+            f.write(a + "\n" + b + "\n")
+
+
+def myers_vectors(mt311):
+    rnd = random.Random(99)
+    lines = []
+    iupac = "ACGTRYSWKMBDHVN"
+
+    def mut(s, nsub, nins, ndel):
+        s = list(s)
+        for _ in range(nsub):
+            p = rnd.randrange(len(s)); s[p] = rnd.choice("ACGT")
+        for _ in range(nins):
+            p = rnd.randrange(len(s)); s.insert(p, rnd.choice("ACGT"))
+        for _ in range(ndel):
+            if len(s) > 1:
+                del s[rnd.randrange(len(s))]
+        return "".join(s)
+
+    for i in range(220):
+        n = rnd.randint(1, 400)
+        alpha = "ACGT" if i % 3 else iupac
+        a = "".join(rnd.choice(alpha) for _ in range(n))
+        b = mut(a, rnd.randint(0, 6), rnd.randint(0, 3), rnd.randint(0, 3))
+        if i % 10 == 0:
+            b = b[: max(1, len(b) // 2)]
+        if i % 10 == 1:
+            a = a[: max(1, len(a) // 2)]
+        mode = i % 3
+        maxd = rnd.choice([1, 2, 5, 10, 20, 40])
+        maxd = min(maxd, len(a), len(b))     # stay inside the reference's defined domain
+        if maxd < 1:
+            maxd = 1
+        lines.append(f"{mode} {maxd} {a} {b}")
+    # the ccheck-shaped call: mt311 vs a mutated assembly, maxd = len/10 (src/ccheck.cc:477)
+    indiv = gen_data.resolve_individual(mt311)
+    asm = mut(indiv, 25, 4, 4)
+    lines.append(f"0 {max(len(mt311), len(asm)) // 10} {mt311} {asm}")
+    inp = "\n".join(lines) + "\n"
+    out = subprocess.run([os.path.join(RB, "ref_myers_driver")], input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode().strip().split("\n")
+    assert len(out) == len(lines)
+    with open(os.path.join(G, "myers_vectors.txt"), "w") as f:
+        for a, b in zip(lines, out):
+            f.write(a + "\n" + b + "\n")
+
+
+def maln_cases(mt311_path):
+    out_dir = os.path.join(G, "maln")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    tmp = tempfile.mkdtemp()
+    _, _, mt = gen_data.read_fasta_one(mt311_path)
+    indiv = gen_data.resolve_individual(mt)
+    sets = {
+        "s150": dict(n=150, seed=1, damage=False),
+        "d150": dict(n=150, seed=2, damage=True),
+    }
+    for name, kw in sets.items():
+        d = gen_data.make_reads(indiv, kw["n"], 100, kw["seed"], circular=True, damage=kw["damage"])
+        gen_data.write_fasta_reads(os.path.join(G, f"{name}.fa"), d["reads"])
+    # planted indels: consensus must change length across iterations
+    ind2 = indiv[:5000] + "ACG" + indiv[5000:9000] + indiv[9002:]
+    d = gen_data.make_reads(ind2, 1200, 100, 3, circular=True, damage=True)
+    # keep only reads near the planted events and the origin so the set stays small
+    keep = [i for i in range(1200) if (4800 <= d["start"][i] <= 5100) or (8800 <= d["start"][i] <= 9100) or d["start"][i] > 16480 or d["start"][i] < 60]
+    gen_data.write_fasta_reads(os.path.join(G, "indel.fa"), d["reads"][keep])
+    A = "ancient.submat.txt"
+    cases = {
+        "fix_c": ["-r", "tr1.fna", "-f", "tf.fna", "-c"],
+        "fix_c_n": ["-r", "tr1.fna", "-f", "tf.fna", "-c", "-n"],
+        "fix_lin": ["-r", "tr1.fna", "-f", "tf.fna"],
+        "fix_c_p2": ["-r", "tr1.fna", "-f", "tf.fna", "-c", "-p", "2"],
+        "fix_c_H": ["-r", "tr1.fna", "-f", "tf.fna", "-c", "-H", "4000"],
+        "fix_c_k8M": ["-r", "tr1.fna", "-f", "tf.fna", "-c", "-k", "8", "-M"],
+        "fix_c_anc": ["-r", "tr1.fna", "-f", "tf.fna", "-c", "-s", A],
+        "s150_k12": ["-r", "mt311.fa", "-f", "s150.fa", "-c", "-k", "12"],
+        "s150_full": ["-r", "mt311.fa", "-f", "s150.fa", "-c", "-n"],
+        "d150_anc_k12": ["-r", "mt311.fa", "-f", "d150.fa", "-c", "-k", "12", "-s", A],
+        "indel_anc_k12": ["-r", "mt311.fa", "-f", "indel.fa", "-c", "-k", "12", "-s", A],
+        "indel_anc_k12_SN": ["-r", "mt311.fa", "-f", "indel.fa", "-c", "-k", "12", "-s", A, "-S", "150", "-N", "100"],
+    }
+    for name, args in cases.items():
+        root = os.path.join(tmp, name)
+        sh([os.path.join(RB, "mia")] + args + ["-m", root], cwd=G, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        it = 1
+        while os.path.exists(f"{root}.{it}"):
+            with open(f"{root}.{it}") as f:
+                body = f.readlines()[1:]
+            with open(os.path.join(out_dir, f"{name}.{it}"), "w") as f:
+                f.writelines(body)
+            it += 1
+        print(f"{name}: {it - 1} iteration file(s)")
+    with open(os.path.join(out_dir, "cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    shutil.rmtree(tmp)
+
+
+def main():
+    os.makedirs(G, exist_ok=True)
+    sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
+    shutil.copy(os.path.join(RB, "mt311.fa"), os.path.join(G, "mt311.fa"))
+    shutil.copy(os.path.join(REF, "test", "tr1.fna"), os.path.join(G, "tr1.fna"))
+    shutil.copy(os.path.join(REF, "test", "tf.fna"), os.path.join(G, "tf.fna"))
+    shutil.copy(os.path.join(REF, "matrices", "ancient.submat.txt"), os.path.join(G, "ancient.submat.txt"))
+    _, _, mt = gen_data.read_fasta_one(os.path.join(G, "mt311.fa"))
+    dp_vectors()
+    cons_vectors()
+    myers_vectors(mt)
+    maln_cases(os.path.join(G, "mt311.fa"))
+
+
+if __name__ == "__main__":
+    main()
