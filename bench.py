@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- reads aligned per second per iteration on MI355X.
+
+One "step" = one MIA iteration over all stored reads (reference
+src/mia_main.c:931-963): reiterate_assembly + pop_smp_from_FSDB +
+cull_maln_from_fsdb + consensus_assembly_string, inputs resident in HBM.
+
+Workload (BASELINE.json configs[1]): 1 M synthetic 100 bp reads (1 % subs, 0.1 %
+indels, both strands) against the 16 619 bp mt311 reference, circular, flat
+matrix.  Pass-1 coordinates are the generator's true positions (the pass-1
+kernel is a later row of SURVEY.md section 8); each iteration re-aligns every read in its
++-50 window exactly as the reference does.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): reads are
+sharded in contiguous fsdb blocks; per iteration the int32 column tallies are
+all-reduced (sum) and the gap lengths (max) over RCCL, insert events are
+all-gathered.  Weak scaling: --reads is PER GPU.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BYTES_PER_READ = 182      # 50 B packed bases + 16 B meta in, 16 B result + 100 B script out
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+class DevArray:
+    """Wrap a raw device pointer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def make_workload(n_reads, seed, read_len=100):
+    import gen_data
+    _, _, mt = gen_data.read_fasta_one(os.path.join(ROOT, "tests", "golden", "mt311.fa"))
+    ref = mt.upper()                                    # make_ref_upper (src/mia.c:642-648)
+    indiv = gen_data.resolve_individual(mt)
+    d = gen_data.make_reads(indiv, n_reads, read_len, seed, circular=True, damage=False)
+    stored = gen_data.stored_orientation(d)
+    as_ = d["start"].astype(np.int32)
+    ae = (as_ + read_len - 1).astype(np.int32)
+    offsets = (np.arange(n_reads + 1, dtype=np.int64) * read_len)
+    return ref, stored, offsets, d["strand"].astype(np.uint8), as_, ae
+
+
+def cpu_baseline(ref, stored, rc, as_, ae, sample_per_proc=3000, iters=2):
+    """The reference's own per-iteration path (oracle/_ref/ref_iter_driver, built from
+    /root/reference by oracle/Makefile.ref) on the host cores, P independent processes."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_iter_driver")
+    P = max(1, min(os.cpu_count() or 1, 32))
+    n = stored.shape[0]
+    P = max(1, min(P, n // 500))
+    S = min(sample_per_proc, n // P)
+    tmp = tempfile.mkdtemp()
+    import gen_data
+    gen_data.write_fasta(os.path.join(tmp, "ref.fa"), "mt311", ref)
+    if os.path.exists(drv):
+        procs = []
+        for p in range(P):
+            path = os.path.join(tmp, f"reads{p}.txt")
+            with open(path, "w") as f:
+                for i in range(p * S, (p + 1) * S):
+                    f.write(f"{int(rc[i])} {int(as_[i])} {int(ae[i])} {stored[i].tobytes().decode()}\n")
+            procs.append(subprocess.Popen([drv, os.path.join(tmp, "ref.fa"), path, "1", "flat", str(iters)],
+                                          stdout=subprocess.PIPE))
+        secs = []
+        for pr in procs:
+            out = pr.communicate()[0].decode().split()
+            secs.append(float(out[out.index("seconds") + 1]))
+        rate = P * S * iters / max(secs)
+        return {"value": rate, "unit": "reads/s per iteration", "cores": P, "kind": "reference",
+                "sample": f"{P} processes x {S} reads x {iters} iterations of oracle/_ref/ref_iter_driver "
+                          f"(reference reiterate_assembly+pop_smp+cull+consensus), slowest process {max(secs):.2f} s"}
+    # the reference binary did not travel: fall back to timing the oracle port
+    import ctypes as C
+    import oracle_ctypes as oc
+    subprocess.run(["make", "-s", "-f", "oracle/Makefile"], cwd=ROOT, check=True)
+    return {"value": None, "unit": "reads/s per iteration", "cores": 0, "kind": "port", "sample": "oracle/_ref missing"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import mia_amd
+
+    n = a.reads
+    ref, stored, offsets, rc, as_, ae = make_workload(n, seed=1 + rank)
+    lens = (offsets[1:] - offsets[:-1]).astype(np.int32)
+    hip = mia_amd.MiaHip(local)
+    hip.set_pssm(mia_amd.flat_pssm())
+    hip.upload_reads(stored.reshape(-1), offsets, rc, np.ones(n, np.uint8), as_, ae)
+
+    def step(cur_ref):
+        hip.realign(cur_ref, True)
+        score, _, _ = hip.alignments()
+        slot_base = 0
+        if world > 1:
+            # the score-cut regression runs over ALL reads in fsdb order (src/fsdb.c:269-383)
+            t = torch.from_numpy(score).cuda()
+            g = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(g, t)
+            all_scores = torch.cat(g).cpu().numpy()
+            all_lens = np.tile(lens, world)
+            slope, intercept = hip.score_cut(all_scores, all_lens)
+            nrec = torch.tensor([hip.num_records()], dtype=torch.int64, device="cuda")
+            gr = [torch.empty_like(nrec) for _ in range(world)]
+            dist.all_gather(gr, nrec)
+            slot_base = int(sum(int(x.item()) for x in gr[:rank]))
+        else:
+            slope, intercept = hip.score_cut(score, lens)
+        if slope <= 0:
+            slope = 100.0
+        hip.cull(0, slope, intercept, slot_base)
+        hip.tally()
+        if world > 1:
+            pt, nt, pg, ng = hip.tally_buffers()
+            tt = torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda")
+            tg = torch.as_tensor(DevArray(pg, ng, "<i4"), device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            pe, ne = hip.ins_events()
+            cnt = torch.tensor([ne], dtype=torch.int64, device="cuda")
+            gc = [torch.empty_like(cnt) for _ in range(world)]
+            dist.all_gather(gc, cnt)
+            counts = [int(x.item()) for x in gc]
+            mx = max(max(counts), 1)
+            mine = torch.zeros(mx, dtype=torch.int64, device="cuda")
+            if ne:
+                mine[:ne] = torch.as_tensor(DevArray(pe, ne, "<i8"), device="cuda")
+            ge = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(ge, mine)
+            allev = torch.cat([ge[r][:counts[r]] for r in range(world)]).contiguous()
+            torch.cuda.synchronize()
+            hip.set_ins_events(allev.data_ptr() if allev.numel() else 0, int(allev.numel()))
+        return hip.consensus(1)
+
+    cur = ref
+    for _ in range(a.warmup):
+        cur = step(cur)
+    hip.kernel_time(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cur = step(cur)
+    hip.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    align_ms, launches = hip.kernel_time(reset=True)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        total_reads = n * world
+        value = total_reads * a.steps / dt
+        k_ms = align_ms / max(launches, 1)
+        reads_per_launch = n * a.steps / max(launches, 1)
+        achieved = BYTES_PER_READ * reads_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "reads aligned/sec per iteration (16.5kb mito ref, 100bp reads)",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic 100 bp reads per GPU vs mt311 (16619 bp, circular), flat matrix; "
+                                   "step = reiterate_assembly + cull + consensus; pass-1 coordinates = true positions" % n,
+                       "reads_per_gpu": n, "consensus_len": len(cur)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_align_window<4>", "kernel_ms": k_ms, "launches": launches,
+                         "note": "integer-VALU/LDS-bound DP: 182 algorithmic HBM bytes per read (SURVEY 8d); see DESIGN.md for GCUPS vs VALU peak",
+                         "gcups": reads_per_launch * 100 * 200 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ref, stored, rc, as_, ae)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

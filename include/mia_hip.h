@@ -1,0 +1,132 @@
+/* mia_hip.h -- C ABI of libmia_hip.so: the MI355X (gfx950) implementation of
+ * MIA's per-iteration align-and-consensus path.
+ *
+ * The reference (mpieva/mapping-iterative-assembler) has no plugin or FFI
+ * layer: the seam is ordinary C linkage inside one executable (SURVEY.md
+ * section 8(b)).  Each entry point below is the batch, device-resident equivalent of
+ * one of those C functions and cites the prototype it replaces.  Signatures
+ * carry only plain pointers and sizes; all pointers are HOST pointers unless
+ * the parameter name starts with d_ (device pointer, used for multi-GPU
+ * all-reduce of tallies by the caller).
+ *
+ * Threading: a context is not re-entrant (neither is the reference: all its
+ * scratch is shared mutable state).  One context per GPU per process.
+ * Errors: every function returns MIA_HIP_OK (0) or a negative code;
+ * mia_hip_last_error() gives the text.  Nothing falls back to the CPU: if the
+ * GPU or the code object is missing, creation fails.
+ */
+#ifndef MIA_HIP_H
+#define MIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIA_HIP_OK 0
+#define MIA_HIP_ERR_DEVICE (-1)   /* no gfx950 device / HIP runtime error */
+#define MIA_HIP_ERR_ARG (-2)      /* bad argument */
+#define MIA_HIP_ERR_RANGE (-3)    /* PSSM values outside the packed-score range */
+#define MIA_HIP_ERR_STATE (-4)    /* call order (e.g. realign before upload) */
+#define MIA_HIP_ERR_NOMEM (-5)
+
+#define MIA_HIP_PSSM_WORDS (31 * 5 * 5) /* PSSM.sm[31][5][5], src/types.h:155-158 */
+#define MIA_HIP_MAX_READ 256            /* INIT_ALN_SEQ_LEN, src/params.h:68 */
+#define MIA_HIP_TALLY_WORDS 12          /* per column: As,Cs,Gs,Ts,gaps,cov,scoreA,scoreC,scoreG,scoreT,span,pad */
+
+/* alignment script entry for read row r (see mia_hip_get_scripts) */
+#define MIA_HIP_COL_INSERT (-1) /* read base aligned to '-' (insert relative to the reference) */
+#define MIA_HIP_COL_CLIP (-2)   /* read base before the alignment start (5' soft clip) */
+
+typedef struct mia_hip_ctx mia_hip_ctx;
+
+/* ---- life cycle ------------------------------------------------------- */
+int mia_hip_create(mia_hip_ctx **ctx, int device_index);
+void mia_hip_destroy(mia_hip_ctx *ctx);
+const char *mia_hip_last_error(const mia_hip_ctx *ctx);
+int mia_hip_sync(mia_hip_ctx *ctx); /* wait for all queued work of this context */
+
+/* ---- inputs ----------------------------------------------------------- */
+
+/* The two PSSMs reiterate_assembly receives as `PSSMP ancsubmat, PSSMP
+ * rcancsubmat` (src/mia_main.c:29-30) and consensus_assembly_string reads as
+ * maln->fpsm / maln->rpsm (src/mia.c:584-589).  Layout sm[depth][ref][read]. */
+int mia_hip_set_pssm(mia_hip_ctx *ctx, const int32_t *fwd, const int32_t *rc);
+
+/* The read store: replaces `FSDB fsdb` (src/mia_main.c:26) -- the fields
+ * fss[i]->{seq, seq_len, rc, strand_known, as, ae} after pass 1 / clean_FSDB.
+ * bases: concatenated ASCII (already reverse-complemented for rc reads, as
+ * add_virgin_fs2fsdb leaves them, src/fsdb.c:209-227); offsets[n+1].
+ * Reads are uploaded once and stay resident (4-bit packed) for all iterations. */
+int mia_hip_upload_reads(mia_hip_ctx *ctx, int64_t n_reads, const char *bases, const int64_t *offsets,
+                         const uint8_t *rc, const uint8_t *strand_known, const int32_t *as, const int32_t *ae);
+
+/* ---- the per-iteration path ------------------------------------------- */
+
+/* void reiterate_assembly(char* new_ref_seq, int iter_num, MapAlignmentP, FSDB,
+ * AlignmentP, PWAlnFragP, PWAlnFragP, PSSMP, PSSMP)  -- src/mia_main.c:24-30.
+ * new_ref: the unwrapped consensus (ASCII, only upper-case ACGT are bases);
+ * circular != 0 appends the wrap as add_ref_wrap does (src/mia.c:657-689).
+ * Re-aligns every strand_known read in its window and updates as/ae/score. */
+int mia_hip_realign(mia_hip_ctx *ctx, const char *new_ref, int32_t ref_len, int circular);
+
+/* fs->{score, as, ae} after the call above (src/mia_main.c:254-257); any
+ * pointer may be NULL. */
+int mia_hip_get_alignments(mia_hip_ctx *ctx, int32_t *score, int32_t *as, int32_t *ae);
+
+/* The alignment itself, i.e. what populate_pwaln_to_begin (src/mia.c:1440-1497)
+ * hands to merge_pwaln_into_maln: for read i and read row r,
+ * cols[i*stride + r] = wrapped reference column aligned to that base minus
+ * ref_start[i], or MIA_HIP_COL_INSERT / MIA_HIP_COL_CLIP.  stride >= longest read. */
+int mia_hip_get_scripts(mia_hip_ctx *ctx, int16_t *cols, int32_t stride, int32_t *ref_start);
+
+/* cull_maln_from_fsdb (src/mia.c:418-506), device part: marks `dropped` for
+ * reads with score < hard_cut (hard_cut > 0) or score < intercept + slope*len
+ * (IEEE double, as the reference).  `dropped` is sticky per AlnSeq slot, like
+ * the reference's never-cleared bit field; slot_base = number of AlnSeq records
+ * that precede this context's reads (0 on a single GPU). */
+int mia_hip_cull(mia_hip_ctx *ctx, int32_t hard_cut, double slope, double intercept, int64_t slot_base);
+int mia_hip_get_dropped(mia_hip_ctx *ctx, uint8_t *front_dropped, uint8_t *back_dropped);
+/* Seed the sticky per-slot `dropped` bits, e.g. with the marks the pass-1 cull
+ * left on the AlnSeq slots (src/mia_main.c:848); slot s of this context is
+ * flags[s - slot_base]. */
+int mia_hip_set_slot_dropped(mia_hip_ctx *ctx, const uint8_t *flags, int64_t n_flags);
+
+/* find_fsdb_score_cut (src/fsdb.c:269-383) -- HOST helper, no device work: the
+ * reference's least-squares line through (seq_len, score) of all unique_best
+ * reads with score >= FIRST_ROUND_SCORE_CUTOFF, evaluated in IEEE double in fsdb
+ * order (the sums of products are order dependent, so this stays sequential).
+ * unique_best may be NULL (= all 1). */
+void mia_hip_score_cut(const int32_t *score, const int32_t *seq_len, const uint8_t *unique_best, int64_t n,
+                       double *slope, double *intercept);
+/* number of AlnSeq records (1 per read, 2 if split at the origin) of this context */
+int mia_hip_num_records(mia_hip_ctx *ctx, int64_t *n_records);
+
+/* pop_smp_from_FSDB (src/fsdb.c:542-619) + the add_base loop of
+ * consensus_assembly_string (src/mia.c:576-595) + ref->gaps (src/mia.c:486-504),
+ * as scatter-adds into  tally[(L+1)][MIA_HIP_TALLY_WORDS]  and  gaps[L+1];
+ * insert columns (find_ins_cons, src/map_align.c:444-510) go to an event list. */
+int mia_hip_tally(mia_hip_ctx *ctx);
+/* device views for the caller's RCCL all-reduce (sum on tally, max on gaps) */
+int mia_hip_tally_buffers(mia_hip_ctx *ctx, int32_t **d_tally, int64_t *n_tally_words, int32_t **d_gaps,
+                          int64_t *n_gaps_words);
+/* insert events (8 bytes each) for all-gather across GPUs */
+int mia_hip_ins_events(mia_hip_ctx *ctx, uint64_t **d_events, int64_t *n_events);
+int mia_hip_set_ins_events(mia_hip_ctx *ctx, const uint64_t *d_events, int64_t n_events);
+int mia_hip_get_tally(mia_hip_ctx *ctx, int32_t *tally, int32_t *gaps); /* host copies, (L+1)*12 and L+1 words */
+
+/* char* consensus_assembly_string(MapAlignmentP) -- src/mia.h:74, src/mia.c:515-603.
+ * Calls find_consensus / find_ins_cons per column on the (all-reduced) tallies.
+ * out must hold ref_len + sum(gaps) + 1 bytes; *out_len = strlen(out). */
+int mia_hip_consensus(mia_hip_ctx *ctx, int cons_code, char *out, int64_t out_cap, int64_t *out_len);
+
+/* ---- timing hooks for bench.py (HIP events on the context's stream) ------ */
+/* milliseconds spent in, and launches of, the windowed DP kernel since the last reset */
+int mia_hip_kernel_time(mia_hip_ctx *ctx, int reset, double *align_ms, int64_t *align_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

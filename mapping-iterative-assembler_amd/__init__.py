@@ -1,0 +1,242 @@
+"""mapping-iterative-assembler_amd -- MI355X-native per-iteration path of MIA.
+
+Python is plumbing only: this module is a ctypes binding of libmia_hip.so (the
+C ABI in include/mia_hip.h; HIP kernels in csrc/).  It fails loudly when the
+library or a GPU is missing -- there is no CPU fallback.  Import it as
+`mia_amd` (see mia_amd.py at the repository root; the directory name contains
+a hyphen).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmia_hip.so")
+
+PSSM_WORDS = 31 * 5 * 5
+TALLY_WORDS = 12
+COL_INSERT, COL_CLIP = -1, -2
+
+
+class MiaHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise MiaHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(LIB_PATH)
+    P, vp = C.POINTER, C.c_void_p
+    lib.mia_hip_create.argtypes = [P(vp), C.c_int]
+    lib.mia_hip_destroy.argtypes = [vp]
+    lib.mia_hip_destroy.restype = None
+    lib.mia_hip_last_error.argtypes = [vp]
+    lib.mia_hip_last_error.restype = C.c_char_p
+    lib.mia_hip_sync.argtypes = [vp]
+    lib.mia_hip_set_pssm.argtypes = [vp, vp, vp]
+    lib.mia_hip_upload_reads.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    lib.mia_hip_realign.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int]
+    lib.mia_hip_get_alignments.argtypes = [vp, vp, vp, vp]
+    lib.mia_hip_get_scripts.argtypes = [vp, vp, C.c_int32, vp]
+    lib.mia_hip_cull.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.c_int64]
+    lib.mia_hip_get_dropped.argtypes = [vp, vp, vp]
+    lib.mia_hip_set_slot_dropped.argtypes = [vp, vp, C.c_int64]
+    lib.mia_hip_score_cut.argtypes = [vp, vp, vp, C.c_int64, P(C.c_double), P(C.c_double)]
+    lib.mia_hip_score_cut.restype = None
+    lib.mia_hip_num_records.argtypes = [vp, P(C.c_int64)]
+    lib.mia_hip_tally.argtypes = [vp]
+    lib.mia_hip_tally_buffers.argtypes = [vp, P(vp), P(C.c_int64), P(vp), P(C.c_int64)]
+    lib.mia_hip_ins_events.argtypes = [vp, P(vp), P(C.c_int64)]
+    lib.mia_hip_set_ins_events.argtypes = [vp, vp, C.c_int64]
+    lib.mia_hip_get_tally.argtypes = [vp, vp, vp]
+    lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
+    lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def exported_symbols():
+    """Every entry point include/mia_hip.h declares (used by the CPU-side ABI test)."""
+    return ["mia_hip_create", "mia_hip_destroy", "mia_hip_last_error", "mia_hip_sync", "mia_hip_set_pssm",
+            "mia_hip_upload_reads", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
+            "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
+            "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_kernel_time"]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def flat_pssm():
+    """init_flatsubmat (reference src/pssm.c:96-126)."""
+    p = np.zeros((31, 5, 5), dtype=np.int32)
+    for i in range(5):
+        for j in range(4):
+            p[:, i, j] = 200 if i == j else -600
+        p[:, i, 4] = -100
+    p[:, 4, :] = -10
+    return p
+
+
+def revcom_pssm(p):
+    """revcom_submat (reference src/pssm.c:53-91): rc[30-d][3-i][3-j] = sm[d][i][j], index 4 fixed."""
+    idx = np.array([3, 2, 1, 0, 4])
+    return np.ascontiguousarray(p[::-1][:, idx][:, :, idx]).astype(np.int32)
+
+
+def read_pssm(path):
+    """read_pssm (reference src/io.c:408-503)."""
+    p = np.zeros((31, 5, 5), dtype=np.int32)
+    with open(path) as f:
+        lines = f.read().split("\n")
+    k = 0
+    for d in range(31):
+        if "# Matrix for position" not in lines[k]:
+            raise ValueError(f"Problem parsing matrix file: {path}")
+        for i in range(4):
+            p[d, i, :4] = [int(x) for x in lines[k + 1 + i].split("\t")[:4]]
+            p[d, i, 4] = -100
+        p[d, 4, :] = -10
+        k += 6
+    return p
+
+
+class MiaHip:
+    """One context = one GPU.  Mirrors the call order of the reference's main loop
+    (src/mia_main.c:931-963): realign -> cull -> tally -> consensus."""
+
+    def __init__(self, device=0):
+        self._l = lib()
+        self._h = C.c_void_p()
+        rc = self._l.mia_hip_create(C.byref(self._h), device)
+        if rc != 0:
+            raise MiaHipError(f"mia_hip_create failed ({rc}): no usable gfx950 device -- there is no CPU fallback")
+        self.n = 0
+        self.max_len = 0
+        self.L = 0
+
+    def close(self):
+        if self._h:
+            self._l.mia_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MiaHipError(f"libmia_hip error {rc}: {self._l.mia_hip_last_error(self._h).decode()}")
+
+    def set_pssm(self, fwd, rc=None):
+        fwd = np.ascontiguousarray(fwd, dtype=np.int32)
+        rc = np.ascontiguousarray(revcom_pssm(fwd) if rc is None else rc, dtype=np.int32)
+        self._chk(self._l.mia_hip_set_pssm(self._h, _ptr(fwd), _ptr(rc)))
+
+    def upload_reads(self, bases, offsets, rc, strand_known, as_, ae):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        rc = np.ascontiguousarray(rc, dtype=np.uint8)
+        sk = np.ascontiguousarray(strand_known, dtype=np.uint8)
+        as_ = np.ascontiguousarray(as_, dtype=np.int32)
+        ae = np.ascontiguousarray(ae, dtype=np.int32)
+        self.n = len(offsets) - 1
+        self.lens = (offsets[1:] - offsets[:-1]).astype(np.int32)
+        self.max_len = int(self.lens.max()) if self.n else 0
+        self._chk(self._l.mia_hip_upload_reads(self._h, self.n, _ptr(bases), _ptr(offsets), _ptr(rc), _ptr(sk), _ptr(as_), _ptr(ae)))
+
+    def realign(self, ref, circular):
+        if isinstance(ref, str):
+            ref = ref.encode()
+        self.L = len(ref)
+        self._chk(self._l.mia_hip_realign(self._h, ref, len(ref), 1 if circular else 0))
+
+    def alignments(self):
+        s = np.empty(self.n, dtype=np.int32)
+        a = np.empty(self.n, dtype=np.int32)
+        e = np.empty(self.n, dtype=np.int32)
+        self._chk(self._l.mia_hip_get_alignments(self._h, _ptr(s), _ptr(a), _ptr(e)))
+        return s, a, e
+
+    def scripts(self):
+        cols = np.empty((self.n, max(self.max_len, 1)), dtype=np.int16)
+        rs = np.empty(self.n, dtype=np.int32)
+        self._chk(self._l.mia_hip_get_scripts(self._h, _ptr(cols), cols.shape[1], _ptr(rs)))
+        return cols, rs
+
+    def score_cut(self, score, seq_len, unique_best=None):
+        score = np.ascontiguousarray(score, dtype=np.int32)
+        seq_len = np.ascontiguousarray(seq_len, dtype=np.int32)
+        ub = None if unique_best is None else np.ascontiguousarray(unique_best, dtype=np.uint8)
+        s, i = C.c_double(), C.c_double()
+        self._l.mia_hip_score_cut(_ptr(score), _ptr(seq_len), _ptr(ub), len(score), C.byref(s), C.byref(i))
+        return s.value, i.value
+
+    def cull(self, hard_cut=0, slope=0.0, intercept=0.0, slot_base=0):
+        self._chk(self._l.mia_hip_cull(self._h, hard_cut, slope, intercept, slot_base))
+
+    def dropped(self):
+        f = np.empty(self.n, dtype=np.uint8)
+        b = np.empty(self.n, dtype=np.uint8)
+        self._chk(self._l.mia_hip_get_dropped(self._h, _ptr(f), _ptr(b)))
+        return f, b
+
+    def set_slot_dropped(self, flags):
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._chk(self._l.mia_hip_set_slot_dropped(self._h, _ptr(flags), len(flags)))
+
+    def num_records(self):
+        n = C.c_int64()
+        self._chk(self._l.mia_hip_num_records(self._h, C.byref(n)))
+        return n.value
+
+    def tally(self):
+        self._chk(self._l.mia_hip_tally(self._h))
+
+    def tally_buffers(self):
+        """(device ptr, words) of the tally and gaps arrays, for an in-place RCCL all-reduce."""
+        pt, nt, pg, ng = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        self._chk(self._l.mia_hip_tally_buffers(self._h, C.byref(pt), C.byref(nt), C.byref(pg), C.byref(ng)))
+        return pt.value, nt.value, pg.value, ng.value
+
+    def ins_events(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._l.mia_hip_ins_events(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_ins_events(self, dptr, n):
+        self._chk(self._l.mia_hip_set_ins_events(self._h, C.c_void_p(dptr), n))
+
+    def get_tally(self):
+        t = np.empty((TALLY_WORDS, self.L + 1), dtype=np.int32)
+        g = np.empty(self.L + 1, dtype=np.int32)
+        self._chk(self._l.mia_hip_get_tally(self._h, _ptr(t), _ptr(g)))
+        return t, g
+
+    def consensus(self, cons_code=1):
+        cap = self.L * 2 + 1024 * 1024
+        buf = C.create_string_buffer(cap)
+        n = C.c_int64()
+        self._chk(self._l.mia_hip_consensus(self._h, cons_code, buf, cap, C.byref(n)))
+        return buf.raw[: n.value].decode()
+
+    def kernel_time(self, reset=False):
+        ms, k = C.c_double(), C.c_int64()
+        self._chk(self._l.mia_hip_kernel_time(self._h, 1 if reset else 0, C.byref(ms), C.byref(k)))
+        return ms.value, k.value
+
+    def sync(self):
+        self._chk(self._l.mia_hip_sync(self._h))

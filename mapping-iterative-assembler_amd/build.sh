@@ -1,0 +1,8 @@
+#!/bin/bash
+# Builds libmia_hip.so (HIP kernels + C ABI) for gfx950, in-tree.
+set -e
+here="$(cd "$(dirname "$0")" && pwd)"
+mkdir -p "$here/build"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function \
+  -save-temps=obj -o "$here/build/libmia_hip.so" "$here/csrc/mia_hip.hip" "$@"
+cp "$here/build/libmia_hip.so" "$here/libmia_hip.so"

@@ -1,0 +1,263 @@
+// mia_consensus_kernels.h -- cull, per-column tallies and consensus calls.
+//
+// The reference builds the consensus with an O(L * N) double loop over
+// (reference position, aligned record) (src/mia.c:551-599).  Here every read
+// scatter-adds its own columns into a [12][L+1] int32 tally (O(sum of read
+// lengths)); integer adds commute, so the result is bit-identical and can be
+// all-reduced across GPUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mia_kernels.h"
+#include "mia_layout.h"
+
+namespace mia {
+
+struct TallyBuf {
+  int32_t* tally;      // [TALLY_WORDS][Lp]
+  int32_t Lp;          // L + 1 (a record may end on column L, src/mia_main.c:259-263 uses '>')
+  int32_t* gaps;       // [Lp]  longest insert before each column (ref->gaps, src/mia.c:486-504)
+  uint64_t* events;    // insert bases: col | j<<32 | code<<42 | depth<<45 | rc<<50
+  int32_t* n_events;
+  int32_t cap_events;
+  uint32_t* flags;     // bit 0: event list overflow, bit 1: geometry the reference leaves undefined
+};
+
+// how a read's alignment maps onto AlnSeq records (src/mia_main.c:259-276, src/mia.c:1376-1438)
+struct RecGeom {
+  int start_w, end, split, ncols_f, ncols_b;
+};
+MIA_HD inline RecGeom rec_geom(int as, int ae, int L) {
+  RecGeom g;
+  g.start_w = as;
+  g.end = ae > L ? ae - L : ae;
+  g.split = as > g.end;
+  g.ncols_f = g.split ? (L - as) : (g.end - as + 1);
+  g.ncols_b = g.split ? g.end + 1 : 0;
+  return g;
+}
+
+// ---- records per read + exclusive scan -> AlnSeq slot of every read ---------------
+__global__ void k_scan_blocks(ReadSet rs, int32_t L, int64_t* partial) {
+  __shared__ int32_t sh[256];
+  const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  int32_t s = 0;
+  for (int k = 0; k < 16; k++) {
+    int64_t i = base + k;
+    if (i < rs.n && rs.sk[i]) s += rec_geom(rs.as[i], rs.ae[i], L).split ? 2 : 1;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ void k_scan_partials(int64_t* partial, int nb, int64_t base, int64_t* total) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int64_t run = base;
+  for (int b = 0; b < nb; b++) { int64_t v = partial[b]; partial[b] = run; run += v; }
+  *total = run - base;
+}
+__global__ void k_scan_apply(ReadSet rs, int32_t L, const int64_t* partial, int64_t* slot) {
+  __shared__ int32_t sh[256];
+  const int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  int32_t cnt[16], s = 0;
+  for (int k = 0; k < 16; k++) {
+    int64_t i = base + k;
+    cnt[k] = (i < rs.n && rs.sk[i]) ? (rec_geom(rs.as[i], rs.ae[i], L).split ? 2 : 1) : 0;
+    s += cnt[k];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  // exclusive scan of the 256 thread sums (Hillis-Steele; tiny)
+  for (int o = 1; o < 256; o <<= 1) {
+    int32_t v = ((int)threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int64_t run = partial[blockIdx.x] + sh[threadIdx.x] - s;
+  for (int k = 0; k < 16; k++) {
+    int64_t i = base + k;
+    if (i < rs.n) slot[i] = run;
+    run += cnt[k];
+  }
+}
+
+// ---- cull_maln_from_fsdb (src/mia.c:451-481): `dropped` is sticky per AlnSeq slot -----
+__global__ void k_cull(ReadSet rs, int32_t L, const int64_t* slot, uint8_t* slot_dropped, int64_t n_slots,
+                       int32_t hard_cut, double slope, double intercept, uint8_t* drop_front, uint8_t* drop_back) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rs.n) return;
+  uint8_t df = 0, db = 0;
+  if (rs.sk[i]) {
+    const bool split = rec_geom(rs.as[i], rs.ae[i], L).split;
+    const double min_score = hard_cut > 0 ? (double)hard_cut : (double)(intercept + (slope * (double)rs.len[i]));
+    const int64_t s = slot[i];
+    const bool low = (double)rs.score[i] < min_score;
+    if (s < n_slots) { if (low) slot_dropped[s] = 1; df = slot_dropped[s]; }
+    if (split && s + 1 < n_slots) { if (low) slot_dropped[s + 1] = 1; db = slot_dropped[s + 1]; }
+  }
+  drop_front[i] = df;
+  drop_back[i] = db;
+}
+
+// ---- tally: one read per wavefront, one read row per lane (4 passes for 256-base reads) ----
+__device__ __forceinline__ int depth_code(int dff, int dfb) {   // src/fsdb.c:572-582
+  return dff <= PSSM_DEPTH ? dff : (dfb < PSSM_DEPTH ? 2 * PSSM_DEPTH - dfb : PSSM_DEPTH);
+}
+
+__global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
+                                                const uint8_t* drop_back, TallyBuf tb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rs.n) return;
+  if (!rs.sk[i]) return;
+  if (rs.status[i] & ST_TOO_LONG) { if (lane == 0) atomicOr(tb.flags, 2u); return; }
+  const int L = ref.L, Lp = tb.Lp;
+  const int len2 = rs.len[i], abr = rs.abr[i];
+  const RecGeom g = rec_geom(rs.as[i], rs.ae[i], L);
+  const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
+  const int cbase = rs.refstart[i] - g.start_w;     // path offset of window column 0
+  const uint8_t* rp = rs.packed + rs.roff[i];
+  const int32_t* pm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);   // src/mia.c:584-589
+  const bool dF = drop_front[i], dB = drop_back[i];
+  if (g.split && g.start_w >= L) { if (lane == 0) atomicOr(tb.flags, 2u); return; }  // split_pwaln mis-places such a record
+  // pass A: inserted bases per record (asp_len, src/fsdb.c:518-530)
+  int nf = 0, nb = 0;
+  for (int r0 = abr; r0 < len2; r0 += 64) {
+    const int r = r0 + lane;
+    bool isF = false, isB = false;
+    if (r < len2 && cols[r] == COL_INSERT) {
+      int rn = r + 1;
+      while (rn < len2 && cols[rn] < 0) rn++;
+      const int o = cbase + cols[rn];
+      if (o < g.ncols_f) isF = true; else if (g.split && o - g.ncols_f < g.ncols_b) isB = true;
+    }
+    nf += __popcll(__ballot(isF));
+    nb += __popcll(__ballot(isB));
+  }
+  const int flen = g.ncols_f + nf, blen = g.split ? g.ncols_b + nb : 0;
+
+  auto emit = [&](int o, int act, int code /* 0..4, or 5 = '-' */) {
+    int p, gc, dff;
+    bool dropped;
+    if (o < g.ncols_f) { p = o; gc = g.start_w + o; dff = act; dropped = dF; }
+    else if (g.split && o - g.ncols_f < g.ncols_b) { p = o - g.ncols_f; gc = p; dff = flen + act; dropped = dB; }  // sic: src/fsdb.c:597
+    else return;
+    if (gc < 0 || gc >= Lp) { atomicOr(tb.flags, 2u); return; }
+    const int d = depth_code(dff, flen + blen - act - 1);
+    if (d < 0 || d > 2 * PSSM_DEPTH) { atomicOr(tb.flags, 2u); return; }
+    if (!dropped) {                                        // src/mia.c:580-582
+      atomicAdd(&tb.tally[T_COV * Lp + gc], 1);
+      if (code == 5) atomicAdd(&tb.tally[T_GAP * Lp + gc], 1);
+      else {
+        if (code < 4) atomicAdd(&tb.tally[(T_A + code) * Lp + gc], 1);
+        const int32_t* row = pm + d * 25 + code;           // sm[d][X][code], X = A,C,G,T (src/map_align.c:258-261)
+        atomicAdd(&tb.tally[T_SA * Lp + gc], row[0]);
+        atomicAdd(&tb.tally[T_SC * Lp + gc], row[5]);
+        atomicAdd(&tb.tally[T_SG * Lp + gc], row[10]);
+        atomicAdd(&tb.tally[T_ST * Lp + gc], row[15]);
+      }
+    }
+    if (p > 0) atomicAdd(&tb.tally[T_SPAN * Lp + gc], 1);  // start < pos <= end (src/map_align.c:466-469), dropped or not
+  };
+
+  for (int r0 = abr; r0 < len2; r0 += 64) {
+    const int r = r0 + lane;
+    if (r >= len2) continue;
+    const int cv = cols[r];
+    const int code = (rp[r >> 1] >> ((r & 1) * 4)) & 15;
+    if (cv >= 0) {
+      const int o = cbase + cv, act = r - abr;
+      if (r > abr && cols[r - 1] >= 0)
+        for (int o2 = cbase + cols[r - 1] + 1; o2 < o; o2++) emit(o2, act, 5);   // deleted reference columns: '-'
+      emit(o, act, code);
+    } else if (cv == COL_INSERT) {
+      int r1 = r;                       // first row of this insert run
+      while (r1 - 1 >= abr && cols[r1 - 1] == COL_INSERT) r1--;
+      int rn = r + 1;                   // aligned row that follows the run
+      while (rn < len2 && cols[rn] < 0) rn++;
+      const int o = cbase + cols[rn], act = rn - abr, j = r - r1, glen = rn - r1;
+      int p, gc, dff;
+      bool ok = true;
+      if (o < g.ncols_f) { p = o; gc = g.start_w + o; dff = act; }
+      else if (g.split && o - g.ncols_f < g.ncols_b) { p = o - g.ncols_f; gc = p; dff = flen + act; }
+      else ok = false;
+      if (ok && p > 0 && gc < Lp) {     // an insert in front of a record's first column is never counted (src/mia.c:492)
+        const int d = depth_code(dff, flen + blen - act - 1);
+        if (j == 0) atomicMax(&tb.gaps[gc], glen);
+        const int e = atomicAdd(tb.n_events, 1);
+        if (e < tb.cap_events)
+          tb.events[e] = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
+                         ((uint64_t)(rs.rc[i] ? 1 : 0) << 50);
+        else atomicOr(tb.flags, 1u);
+      }
+    }
+  }
+}
+
+// ---- insert columns (find_ins_cons, src/map_align.c:444-510) ----------------------
+// ins_off[pos] = sum of gaps[0..pos-1]; slot (pos, j) -> ins_off[pos] + j; 9 words per slot:
+// A,C,G,T counts, number of reads with a base there, scoreA..scoreT
+__global__ void k_gap_offsets(const int32_t* gaps, int32_t Lp, int32_t L, int32_t* ins_off, int32_t* total) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int32_t run = 0;
+  for (int p = 0; p < Lp; p++) { ins_off[p] = run; if (p > 0 && p < L) run += gaps[p]; }
+  *total = run;
+}
+__global__ void k_ins_tally(const uint64_t* events, int32_t n_events, const int32_t* pssm2, const int32_t* ins_off,
+                            const int32_t* gaps, int32_t L, int32_t* ins_tally) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_events) return;
+  const uint64_t ev = events[e];
+  const int gc = (int)(uint32_t)ev, j = (int)((ev >> 32) & 1023), code = (int)((ev >> 42) & 7), d = (int)((ev >> 45) & 31);
+  const int rc = (int)((ev >> 50) & 1);
+  if (gc <= 0 || gc >= L || j >= gaps[gc]) return;
+  int32_t* t = ins_tally + (int64_t)(ins_off[gc] + j) * 9;
+  const int32_t* row = pssm2 + (rc ? PSSM_WORDS : 0) + d * 25 + code;
+  if (code < 4) atomicAdd(&t[code], 1);
+  atomicAdd(&t[4], 1);
+  atomicAdd(&t[5], row[0]);
+  atomicAdd(&t[6], row[5]);
+  atomicAdd(&t[7], row[10]);
+  atomicAdd(&t[8], row[15]);
+}
+
+// find_consensus (src/map_align.c:294-391)
+__device__ __forceinline__ char call_base(int As, int Cs, int Gs, int Ts, int gapsn, int cov, int sA, int sC, int sG, int sT,
+                                          int cons_code) {
+  (void)As; (void)Cs; (void)Gs; (void)Ts;
+  if (cov == 0) return 'N';
+  if (((double)gapsn / (double)cov) >= (double)(50 / 100.0)) return '-';
+  int top = sA, second = INT32_MIN;
+  char base = 'A';
+  if (sC >= top) { second = top; top = sC; base = 'C'; } else second = sC;
+  if (sG >= top) { second = top; top = sG; base = 'G'; } else if (sG >= second) second = sG;
+  if (sT >= top) { second = top; top = sT; base = 'T'; } else if (sT >= second) second = sT;
+  if (cons_code == 2) return (top >= 0 || (top - 2400) > second) ? base : 'N';
+  return (top >= -399) ? base : 'N';
+}
+
+__global__ void k_call_columns(const int32_t* tally, int32_t Lp, int32_t L, int cons_code, char* calls) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= L) return;
+  calls[p] = call_base(tally[T_A * Lp + p], tally[T_C * Lp + p], tally[T_G * Lp + p], tally[T_T * Lp + p],
+                       tally[T_GAP * Lp + p], tally[T_COV * Lp + p], tally[T_SA * Lp + p], tally[T_SC * Lp + p],
+                       tally[T_SG * Lp + p], tally[T_ST * Lp + p], cons_code);
+}
+__global__ void k_call_inserts(const int32_t* tally, int32_t Lp, int32_t L, const int32_t* gaps, const int32_t* ins_off,
+                               const int32_t* ins_tally, int cons_code, char* ins_calls) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p <= 0 || p >= L) return;
+  const int span = tally[T_SPAN * Lp + p];
+  for (int j = 0; j < gaps[p]; j++) {
+    const int32_t* t = ins_tally + (int64_t)(ins_off[p] + j) * 9;
+    ins_calls[ins_off[p] + j] = call_base(t[0], t[1], t[2], t[3], span - t[4], span, t[5], t[6], t[7], t[8], cons_code);
+  }
+}
+
+}  // namespace mia

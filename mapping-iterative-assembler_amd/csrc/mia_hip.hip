@@ -1,0 +1,603 @@
+// mia_hip.hip -- libmia_hip.so: C ABI (include/mia_hip.h) over the gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mia_hip.h"
+#include "mia_consensus_kernels.h"
+#include "mia_kernels.h"
+
+using namespace mia;
+
+struct mia_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // PSSMs (fwd, rc)
+  int32_t* d_pssm = nullptr;
+  int max_abs = 0;
+  bool have_pssm = false;
+  PackSet packs;
+  // reads
+  ReadSet rs{};
+  uint8_t* d_packed = nullptr; uint32_t* d_roff = nullptr; uint16_t* d_len = nullptr;
+  uint8_t* d_rc = nullptr; uint8_t* d_sk = nullptr;
+  int32_t *d_as = nullptr, *d_ae = nullptr, *d_score = nullptr, *d_refstart = nullptr;
+  int16_t* d_abr = nullptr; uint32_t* d_status = nullptr; int16_t* d_cols = nullptr;
+  int max_len = 0;
+  // plan
+  int32_t *d_bin_of = nullptr, *d_list = nullptr, *d_wide_list = nullptr;
+  int32_t* d_bins = nullptr;  // [count N_BINS][off N_BINS][cursor N_BINS][wide_count 1]
+  // reference
+  uint8_t* d_ref = nullptr; int ref_cap = 0; int L = 0, wrap = 0; bool have_ref = false; bool aligned = false;
+  // cull
+  int64_t* d_slot = nullptr; int64_t* d_partial = nullptr; int64_t* d_total = nullptr;
+  uint8_t *d_slot_dropped = nullptr, *d_drop_f = nullptr, *d_drop_b = nullptr; int64_t n_slots = 0;
+  // tally
+  TallyBuf tb{}; int tally_cap = 0; int32_t* d_ins_off = nullptr; int32_t* d_ins_total = nullptr;
+  int32_t* d_ins_tally = nullptr; int64_t ins_tally_cap = 0; char* d_calls = nullptr; char* d_ins_calls = nullptr;
+  int64_t ins_calls_cap = 0; int32_t n_events_host = 0; bool tallied = false;
+  // wide scratch
+  int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
+  // timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+  double align_ms = 0; int64_t align_launches = 0;
+};
+
+#define HIPCHK(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                                    \
+      return MIA_HIP_ERR_DEVICE;                                                                       \
+    }                                                                                                  \
+  } while (0)
+
+template <class T>
+static int dev_alloc(mia_hip_ctx* ctx, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); *p = nullptr; return MIA_HIP_ERR_NOMEM; }
+  return MIA_HIP_OK;
+}
+
+extern "C" const char* mia_hip_last_error(const mia_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
+  if (!out) return MIA_HIP_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MIA_HIP_ERR_DEVICE;   // no CPU fallback, by design
+  if (device_index < 0 || device_index >= ndev) return MIA_HIP_ERR_ARG;
+  mia_hip_ctx* ctx = new mia_hip_ctx();
+  ctx->device = device_index;
+  if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return MIA_HIP_ERR_DEVICE;
+  }
+  // windows larger than 64 KiB of trace need the full 160 KiB LDS of a gfx950 CU
+  (void)hipFuncSetAttribute((const void*)k_align_window<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+  (void)hipFuncSetAttribute((const void*)k_align_window<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+  (void)hipFuncSetAttribute((const void*)k_align_window<12>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+  if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_bins, 3 * N_BINS + 1) ||
+      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1)) {
+    delete ctx;
+    return MIA_HIP_ERR_NOMEM;
+  }
+  *out = ctx;
+  return MIA_HIP_OK;
+}
+
+extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  void* ptrs[] = {ctx->d_pssm, ctx->d_packed, ctx->d_roff, ctx->d_len, ctx->d_rc, ctx->d_sk, ctx->d_as, ctx->d_ae, ctx->d_score,
+                  ctx->d_refstart, ctx->d_abr, ctx->d_status, ctx->d_cols, ctx->d_bin_of, ctx->d_list, ctx->d_wide_list,
+                  ctx->d_bins, ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
+                  ctx->d_drop_b, ctx->tb.tally, ctx->tb.gaps, ctx->tb.events, ctx->tb.n_events, ctx->tb.flags, ctx->d_ins_off,
+                  ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int mia_hip_sync(mia_hip_ctx* ctx) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_set_pssm(mia_hip_ctx* ctx, const int32_t* fwd, const int32_t* rc) {
+  if (!ctx || !fwd || !rc) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  int m = 0;
+  for (int i = 0; i < PSSM_WORDS; i++) {
+    int a = fwd[i] < 0 ? -fwd[i] : fwd[i], b = rc[i] < 0 ? -rc[i] : rc[i];
+    if (a > m) m = a;
+    if (b > m) m = b;
+  }
+  if (m > 32000) { ctx->err = "PSSM entries beyond +-32000 do not fit the int16 substitution table"; return MIA_HIP_ERR_RANGE; }
+  ctx->max_abs = m;
+  const int cpls[N_CPL] = {4, 8, 12};
+  for (int c = 0; c < N_CPL; c++) ctx->packs.ok[c] = make_pack_params(64 * cpls[c], m, &ctx->packs.p[c]) ? 1 : 0;
+  HIPCHK(hipMemcpyAsync(ctx->d_pssm, fwd, PSSM_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_pssm + PSSM_WORDS, rc, PSSM_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->have_pssm = true;
+  return MIA_HIP_OK;
+}
+
+static inline uint8_t base_code(char b) {   // src/map_align.c:16-29: only upper-case ACGT are bases
+  switch (b) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+}
+
+extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bases, const int64_t* offsets, const uint8_t* rc,
+                                    const uint8_t* strand_known, const int32_t* as, const int32_t* ae) {
+  if (!ctx || n < 0 || (n > 0 && (!bases || !offsets || !rc || !strand_known || !as || !ae))) return MIA_HIP_ERR_ARG;
+  if (n >= (int64_t)1 << 31) { ctx->err = "more than 2^31 reads per context"; return MIA_HIP_ERR_ARG; }
+  HIPCHK(hipSetDevice(ctx->device));
+  std::vector<uint32_t> roff((size_t)n);
+  std::vector<uint16_t> len((size_t)n);
+  uint64_t total = 0;
+  int max_len = 1;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t l = offsets[i + 1] - offsets[i];
+    if (l < 1 || l > MIA_HIP_MAX_READ) { ctx->err = "read length outside 1..256 (INIT_ALN_SEQ_LEN)"; return MIA_HIP_ERR_ARG; }
+    roff[i] = (uint32_t)total;
+    len[i] = (uint16_t)l;
+    if (l > max_len) max_len = (int)l;
+    total += (uint64_t)(((l + 1) / 2 + 3) & ~3);
+    if (total >= ((uint64_t)1 << 32)) { ctx->err = "packed read store exceeds 4 GiB per context"; return MIA_HIP_ERR_ARG; }
+  }
+  std::vector<uint8_t> packed((size_t)total + 8, 0);
+  for (int64_t i = 0; i < n; i++) {
+    const char* s = bases + offsets[i];
+    uint8_t* d = packed.data() + roff[i];
+    for (int k = 0; k < len[i]; k++) d[k >> 1] |= (uint8_t)(base_code(s[k]) << ((k & 1) * 4));
+  }
+  ctx->max_len = max_len;
+  const int stride = (max_len + 3) & ~3;
+  int rcx = 0;
+  rcx |= dev_alloc(ctx, &ctx->d_packed, packed.size());
+  rcx |= dev_alloc(ctx, &ctx->d_roff, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_len, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_rc, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_sk, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_as, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_ae, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_score, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_refstart, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_abr, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_status, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_cols, (size_t)n * stride);
+  rcx |= dev_alloc(ctx, &ctx->d_bin_of, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_list, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_wide_list, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_slot, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_partial, (size_t)(n / 4096 + 2));
+  rcx |= dev_alloc(ctx, &ctx->d_drop_f, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_drop_b, (size_t)n);
+  ctx->n_slots = 2 * n + 16;
+  rcx |= dev_alloc(ctx, &ctx->d_slot_dropped, (size_t)ctx->n_slots);
+  if (rcx) return MIA_HIP_ERR_NOMEM;
+  HIPCHK(hipMemcpyAsync(ctx->d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_roff, roff.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_len, len.data(), (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_rc, rc, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_sk, strand_known, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_as, as, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_ae, ae, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_score, 0, (size_t)n * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_status, 0, (size_t)n * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_slot_dropped, 0, (size_t)ctx->n_slots, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_drop_f, 0, (size_t)n, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_drop_b, 0, (size_t)n, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ReadSet& r = ctx->rs;
+  r.n = n; r.packed = ctx->d_packed; r.roff = ctx->d_roff; r.len = ctx->d_len; r.rc = ctx->d_rc; r.sk = ctx->d_sk;
+  r.as = ctx->d_as; r.ae = ctx->d_ae; r.score = ctx->d_score; r.refstart = ctx->d_refstart; r.abr = ctx->d_abr;
+  r.status = ctx->d_status; r.cols = ctx->d_cols; r.stride = stride;
+  ctx->aligned = false;
+  ctx->tallied = false;
+  return MIA_HIP_OK;
+}
+
+static int get_events(mia_hip_ctx* ctx, hipEvent_t* a, hipEvent_t* b) {
+  if (ctx->ev_free.empty()) {
+    hipEvent_t x, y;
+    if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return -1;
+    ctx->ev_free.push_back({x, y});
+  }
+  auto p = ctx->ev_free.back();
+  ctx->ev_free.pop_back();
+  ctx->ev_used.push_back(p);
+  *a = p.first; *b = p.second;
+  return 0;
+}
+
+static void drain_events(mia_hip_ctx* ctx) {
+  for (auto& e : ctx->ev_used) {
+    float ms = 0;
+    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+      ctx->align_ms += ms;
+      ctx->align_launches++;
+    }
+    ctx->ev_free.push_back(e);
+  }
+  ctx->ev_used.clear();
+}
+
+extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms, int64_t* launches) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  drain_events(ctx);
+  if (align_ms) *align_ms = ctx->align_ms;
+  if (launches) *launches = ctx->align_launches;
+  if (reset) { ctx->align_ms = 0; ctx->align_launches = 0; }
+  return MIA_HIP_OK;
+}
+
+template <int CPL>
+static hipError_t launch_window(mia_hip_ctx* ctx, int ci, int k, const int32_t* list, int count) {
+  const int lds = lds_for_occupancy(k);
+  hipEvent_t e0, e1;
+  if (get_events(ctx, &e0, &e1)) return hipErrorOutOfMemory;
+  RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
+  (void)hipEventRecord(e0, ctx->stream);
+  hipLaunchKernelGGL((k_align_window<CPL>), dim3(count), dim3(64), lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
+                     count, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS);
+  (void)hipEventRecord(e1, ctx->stream);
+  return hipGetLastError();
+}
+
+extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular) {
+  if (!ctx || !new_ref || ref_len <= 0) return MIA_HIP_ERR_ARG;
+  if (!ctx->have_pssm || !ctx->d_packed) { ctx->err = "set_pssm and upload_reads must precede realign"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  // add_ref_wrap (src/mia.c:657-689): first min(L,256) bases appended when circular
+  const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl;
+  std::vector<uint8_t> codes((size_t)wrap + 64, 4);
+  for (int i = 0; i < L; i++) codes[i] = base_code(new_ref[i]);
+  for (int i = 0; i < wl; i++) codes[L + i] = codes[i];
+  if ((int)codes.size() > ctx->ref_cap) {
+    if (dev_alloc(ctx, &ctx->d_ref, codes.size() * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->ref_cap = (int)codes.size() * 2;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_ref, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
+  ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true;
+  const int64_t n = ctx->rs.n;
+  if (n == 0) { ctx->aligned = true; return MIA_HIP_OK; }
+  RefInfo ref{ctx->d_ref, L, wrap};
+  int32_t* d_count = ctx->d_bins;
+  int32_t* d_off = ctx->d_bins + N_BINS;
+  int32_t* d_cursor = ctx->d_bins + 2 * N_BINS;
+  int32_t* d_wide_count = ctx->d_bins + 3 * N_BINS;
+  HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 1) * 4, ctx->stream));
+  const int tb = 256, gb = (int)((n + tb - 1) / tb);
+  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->d_bin_of, d_count);
+  int32_t h_count[N_BINS], h_off[N_BINS];
+  HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  int run = 0;
+  for (int b = 0; b < N_BINS; b++) { h_off[b] = run; run += h_count[b]; }
+  HIPCHK(hipMemcpyAsync(d_off, h_off, sizeof h_off, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
+  // reads that need the exact kernel from the start: copy their list to the head of wide_list
+  const int n_wide0 = h_count[BIN_WIDE];
+  if (n_wide0 > 0) {
+    HIPCHK(hipMemcpyAsync(ctx->d_wide_list, ctx->d_list + h_off[BIN_WIDE], (size_t)n_wide0 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_wide_count, &h_count[BIN_WIDE], 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  for (int ci = 0; ci < N_CPL; ci++)
+    for (int k = 1; k <= N_OCC; k++) {
+      const int b = ci * N_OCC + (k - 1);
+      if (h_count[b] == 0) continue;
+      hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, k, ctx->d_list + h_off[b], h_count[b])
+                   : ci == 1 ? launch_window<8>(ctx, ci, k, ctx->d_list + h_off[b], h_count[b])
+                             : launch_window<12>(ctx, ci, k, ctx->d_list + h_off[b], h_count[b]);
+      if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+    }
+  // exact kernel for whole-reference windows and escaped reads
+  int32_t n_wide = 0;
+  HIPCHK(hipMemcpyAsync(&n_wide, d_wide_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n_wide > 0) {
+    std::vector<int32_t> wl((size_t)n_wide), as((size_t)n_wide), ae((size_t)n_wide);
+    std::vector<uint16_t> ln((size_t)n_wide);
+    HIPCHK(hipMemcpy(wl.data(), ctx->d_wide_list, (size_t)n_wide * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> soff((size_t)n_wide);
+    int64_t total = 0;
+    for (int t = 0; t < n_wide; t++) {
+      HIPCHK(hipMemcpy(&as[t], ctx->d_as + wl[t], 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&ae[t], ctx->d_ae + wl[t], 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&ln[t], ctx->d_len + wl[t], 2, hipMemcpyDeviceToHost));
+      int s, n1;
+      realign_window(as[t], ae[t], ln[t], wrap, &s, &n1);
+      soff[t] = total;
+      total += (int64_t)ln[t] * n1 + 5 * (int64_t)n1 + 16;
+    }
+    if (total > ctx->scratch_cap) {
+      if (dev_alloc(ctx, &ctx->d_scratch, (size_t)total)) return MIA_HIP_ERR_NOMEM;
+      ctx->scratch_cap = total;
+    }
+    if (n_wide > ctx->scratch_off_cap) {
+      if (dev_alloc(ctx, &ctx->d_scratch_off, (size_t)n_wide)) return MIA_HIP_ERR_NOMEM;
+      ctx->scratch_off_cap = n_wide;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_scratch_off, soff.data(), (size_t)n_wide * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_align_wide, dim3((n_wide + 63) / 64), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_wide_list,
+                       n_wide, ctx->d_scratch_off, ctx->d_scratch);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  ctx->aligned = true;
+  ctx->tallied = false;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_get_alignments(mia_hip_ctx* ctx, int32_t* score, int32_t* as, int32_t* ae) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->rs.n;
+  if (score) HIPCHK(hipMemcpyAsync(score, ctx->d_score, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (as) HIPCHK(hipMemcpyAsync(as, ctx->d_as, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (ae) HIPCHK(hipMemcpyAsync(ae, ctx->d_ae, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_get_scripts(mia_hip_ctx* ctx, int16_t* cols, int32_t stride, int32_t* ref_start) {
+  if (!ctx || (cols && stride < ctx->max_len)) return MIA_HIP_ERR_ARG;
+  if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->rs.n;
+  if (cols) {
+    HIPCHK(hipMemcpy2DAsync(cols, (size_t)stride * 2, ctx->d_cols, (size_t)ctx->rs.stride * 2, (size_t)ctx->max_len * 2, n,
+                            hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (ref_start) HIPCHK(hipMemcpyAsync(ref_start, ctx->d_refstart, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+// ---- cull ----------------------------------------------------------------------
+extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, double intercept, int64_t slot_base) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->rs.n;
+  if (n == 0) return MIA_HIP_OK;
+  const int nb = (int)((n + 4095) / 4096);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(64), 0, ctx->stream, ctx->d_partial, nb, slot_base, ctx->d_total);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, ctx->d_slot);
+  if (slot_base + 2 * n + 16 > ctx->n_slots) {   // sharded runs: slots are global indices
+    uint8_t* nd = nullptr;
+    const int64_t ns = slot_base + 2 * n + 16;
+    if (hipMalloc((void**)&nd, (size_t)ns) != hipSuccess) return MIA_HIP_ERR_NOMEM;
+    HIPCHK(hipMemsetAsync(nd, 0, (size_t)ns, ctx->stream));
+    HIPCHK(hipMemcpyAsync(nd, ctx->d_slot_dropped, (size_t)ctx->n_slots, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_slot_dropped);
+    ctx->d_slot_dropped = nd;
+    ctx->n_slots = ns;
+  }
+  hipLaunchKernelGGL(k_cull, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
+                     ctx->n_slots, hard_cut, slope, intercept, ctx->d_drop_f, ctx->d_drop_b);
+  HIPCHK(hipGetLastError());
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_get_dropped(mia_hip_ctx* ctx, uint8_t* front, uint8_t* back) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->rs.n;
+  if (front) HIPCHK(hipMemcpyAsync(front, ctx->d_drop_f, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (back) HIPCHK(hipMemcpyAsync(back, ctx->d_drop_b, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_set_slot_dropped(mia_hip_ctx* ctx, const uint8_t* flags, int64_t n_flags) {
+  if (!ctx || !flags || n_flags < 0) return MIA_HIP_ERR_ARG;
+  if (!ctx->d_slot_dropped) { ctx->err = "upload_reads first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n_flags > ctx->n_slots) n_flags = ctx->n_slots;
+  HIPCHK(hipMemsetAsync(ctx->d_slot_dropped, 0, (size_t)ctx->n_slots, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_slot_dropped, flags, (size_t)n_flags, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+// find_fsdb_score_cut (src/fsdb.c:269-383): host-side, sequential IEEE double (built with -ffp-contract=off)
+extern "C" void mia_hip_score_cut(const int32_t* score, const int32_t* seq_len, const uint8_t* unique_best, int64_t n,
+                                  double* slope, double* intercept) {
+  double xbar = 0, ybar = 0, ssxy = 0, ssxx = 0, max_delta = 0;
+  size_t j = 0;
+  auto used = [&](int64_t i) { return (!unique_best || unique_best[i]) && score[i] >= 2000; };
+  for (int64_t i = 0; i < n; i++) if (used(i)) { xbar += seq_len[i]; ybar += score[i]; j++; }
+  xbar /= j;
+  ybar /= j;
+  for (int64_t i = 0; i < n; i++) if (used(i)) {
+    ssxy += (seq_len[i] - xbar) * (score[i] - ybar);
+    ssxx += (seq_len[i] - xbar) * (seq_len[i] - xbar);
+  }
+  const double slope_bf = ssxy / ssxx, intercept_bf = ybar - slope_bf * xbar;
+  for (int64_t i = 0; i < n; i++) if (used(i)) {
+    double d = (score[i] - ((slope_bf * seq_len[i]) + intercept_bf)) / seq_len[i];
+    if (d > max_delta) max_delta = d;
+  }
+  *intercept = intercept_bf;
+  if ((slope_bf - max_delta) > 0) *slope = slope_bf - (max_delta * 2.0);
+  else *slope = (double)(slope_bf * (80 / 100.0));
+}
+
+extern "C" int mia_hip_num_records(mia_hip_ctx* ctx, int64_t* n_records) {
+  if (!ctx || !n_records) return MIA_HIP_ERR_ARG;
+  if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->rs.n;
+  *n_records = 0;
+  if (n == 0) return MIA_HIP_OK;
+  const int nb = (int)((n + 4095) / 4096);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(64), 0, ctx->stream, ctx->d_partial, nb, (int64_t)0, ctx->d_total);
+  HIPCHK(hipMemcpyAsync(n_records, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+// ---- tally + consensus -------------------------------------------------------------
+static int ensure_tally(mia_hip_ctx* ctx) {
+  const int Lp = ctx->L + 1;
+  if (Lp > ctx->tally_cap) {
+    int rc = 0;
+    rc |= dev_alloc(ctx, &ctx->tb.tally, (size_t)TALLY_WORDS * Lp);
+    rc |= dev_alloc(ctx, &ctx->tb.gaps, (size_t)Lp);
+    rc |= dev_alloc(ctx, &ctx->d_ins_off, (size_t)Lp);
+    rc |= dev_alloc(ctx, &ctx->d_calls, (size_t)Lp);
+    if (rc) return MIA_HIP_ERR_NOMEM;
+    ctx->tally_cap = Lp;
+  }
+  if (!ctx->tb.events) {
+    // every inserted read base is one event; 1/8 of all bases is far beyond any real data,
+    // overflow is detected and reported
+    int64_t cap = ctx->rs.n * 32 + 4096;
+    if (cap > ((int64_t)1 << 30)) cap = (int64_t)1 << 30;
+    int rc = 0;
+    rc |= dev_alloc(ctx, &ctx->tb.events, (size_t)cap);
+    rc |= dev_alloc(ctx, &ctx->tb.n_events, 1);
+    rc |= dev_alloc(ctx, &ctx->tb.flags, 1);
+    if (rc) return MIA_HIP_ERR_NOMEM;
+    ctx->tb.cap_events = (int32_t)cap;
+  }
+  ctx->tb.Lp = Lp;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  int rc = ensure_tally(ctx);
+  if (rc) return rc;
+  const int Lp = ctx->tb.Lp;
+  HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, (size_t)TALLY_WORDS * Lp * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->tb.gaps, 0, (size_t)Lp * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->tb.n_events, 0, 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->tb.flags, 0, 4, ctx->stream));
+  const int64_t n = ctx->rs.n;
+  if (n > 0) {
+    RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
+    hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
+                       ctx->d_drop_b, ctx->tb);
+    HIPCHK(hipGetLastError());
+  }
+  uint32_t flags = 0;
+  HIPCHK(hipMemcpyAsync(&ctx->n_events_host, ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&flags, ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (flags & 1u) { ctx->err = "insert event list overflow"; return MIA_HIP_ERR_NOMEM; }
+  if (ctx->n_events_host > ctx->tb.cap_events) ctx->n_events_host = ctx->tb.cap_events;
+  ctx->tallied = true;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_tally_buffers(mia_hip_ctx* ctx, int32_t** d_tally, int64_t* n_tally_words, int32_t** d_gaps,
+                                     int64_t* n_gaps_words) {
+  if (!ctx || !ctx->tallied) return MIA_HIP_ERR_STATE;
+  if (d_tally) *d_tally = ctx->tb.tally;
+  if (n_tally_words) *n_tally_words = (int64_t)TALLY_WORDS * ctx->tb.Lp;
+  if (d_gaps) *d_gaps = ctx->tb.gaps;
+  if (n_gaps_words) *n_gaps_words = ctx->tb.Lp;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_ins_events(mia_hip_ctx* ctx, uint64_t** d_events, int64_t* n_events) {
+  if (!ctx || !ctx->tallied) return MIA_HIP_ERR_STATE;
+  if (d_events) *d_events = ctx->tb.events;
+  if (n_events) *n_events = ctx->n_events_host;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_set_ins_events(mia_hip_ctx* ctx, const uint64_t* d_events, int64_t n_events) {
+  if (!ctx || !ctx->tallied || n_events < 0) return MIA_HIP_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n_events > ctx->tb.cap_events) {
+    if (dev_alloc(ctx, &ctx->tb.events, (size_t)n_events)) return MIA_HIP_ERR_NOMEM;
+    ctx->tb.cap_events = (int32_t)n_events;
+  }
+  if (n_events > 0 && d_events != ctx->tb.events)
+    HIPCHK(hipMemcpyAsync(ctx->tb.events, d_events, (size_t)n_events * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_events_host = (int32_t)n_events;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_get_tally(mia_hip_ctx* ctx, int32_t* tally, int32_t* gaps) {
+  if (!ctx || !ctx->tallied) return MIA_HIP_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  const int Lp = ctx->tb.Lp;
+  if (tally) HIPCHK(hipMemcpyAsync(tally, ctx->tb.tally, (size_t)TALLY_WORDS * Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (gaps) HIPCHK(hipMemcpyAsync(gaps, ctx->tb.gaps, (size_t)Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int64_t out_cap, int64_t* out_len) {
+  if (!ctx || !out) return MIA_HIP_ERR_ARG;
+  if (!ctx->tallied) { ctx->err = "tally first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int L = ctx->L, Lp = ctx->tb.Lp;
+  int32_t total = 0;
+  hipLaunchKernelGGL(k_gap_offsets, dim3(1), dim3(64), 0, ctx->stream, ctx->tb.gaps, Lp, L, ctx->d_ins_off, ctx->d_ins_total);
+  HIPCHK(hipMemcpyAsync(&total, ctx->d_ins_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (total > ctx->ins_tally_cap) {
+    if (dev_alloc(ctx, &ctx->d_ins_tally, (size_t)total * 9) || dev_alloc(ctx, &ctx->d_ins_calls, (size_t)total)) return MIA_HIP_ERR_NOMEM;
+    ctx->ins_tally_cap = total;
+  }
+  if (total > 0) {
+    HIPCHK(hipMemsetAsync(ctx->d_ins_tally, 0, (size_t)total * 9 * 4, ctx->stream));
+    const int ne = ctx->n_events_host;
+    if (ne > 0)
+      hipLaunchKernelGGL(k_ins_tally, dim3((ne + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.events, ne, ctx->d_pssm, ctx->d_ins_off,
+                         ctx->tb.gaps, L, ctx->d_ins_tally);
+    hipLaunchKernelGGL(k_call_inserts, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, ctx->tb.gaps,
+                       ctx->d_ins_off, ctx->d_ins_tally, cons_code, ctx->d_ins_calls);
+  }
+  hipLaunchKernelGGL(k_call_columns, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, cons_code, ctx->d_calls);
+  HIPCHK(hipGetLastError());
+  std::vector<char> calls((size_t)L), ins((size_t)total + 1);
+  std::vector<int32_t> gaps((size_t)Lp), off((size_t)Lp);
+  HIPCHK(hipMemcpyAsync(calls.data(), ctx->d_calls, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+  if (total > 0) HIPCHK(hipMemcpyAsync(ins.data(), ctx->d_ins_calls, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(gaps.data(), ctx->tb.gaps, (size_t)Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(off.data(), ctx->d_ins_off, (size_t)Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // string assembly of consensus_assembly_string (src/mia.c:551-600): insert calls, then the column call; '-' is skipped
+  int64_t o = 0;
+  for (int p = 0; p < L; p++) {
+    if (p > 0)
+      for (int j = 0; j < gaps[p]; j++) {
+        char c = ins[off[p] + j];
+        if (c != '-' && c != ' ') { if (o + 1 >= out_cap) return MIA_HIP_ERR_ARG; out[o++] = c; }
+      }
+    char c = calls[p];
+    if (c != '-' && c != ' ') { if (o + 1 >= out_cap) return MIA_HIP_ERR_ARG; out[o++] = c; }
+  }
+  out[o] = 0;
+  if (out_len) *out_len = o;
+  return MIA_HIP_OK;
+}

@@ -1,0 +1,240 @@
+// mia_kernels.h -- gfx950 kernels of the per-iteration path.  Included once by
+// mia_hip.hip.  Device memory layout (all SoA, resident across iterations):
+//
+//   reads     packed[ ]  4-bit base codes, each read starts on a 4-byte boundary
+//             roff[n] (u32 byte offset), len[n] (u16), rc[n], sk[n] (strand_known)
+//   per read  as[n], ae[n] (wrapped coords, in/out), score[n], refstart[n], abr[n],
+//             status[n], cols[n][stride] (int16 alignment script)
+//   reference ref[wrap+pad] one code per byte (0..4), wrap = L + min(L,256) if circular
+//   consensus tally[12][L+1] int32 (word-major so that a wave's atomics are 256 B
+//             contiguous), gaps[L+1], insert events (u64 list)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "align_body.h"
+#include "mia_layout.h"
+#include "wave_dev.h"
+
+namespace mia {
+
+constexpr int LDS_TOTAL = 160 * 1024;
+constexpr int N_CPL = 3;                 // CPL 4, 8, 12
+constexpr int N_OCC = 8;                 // 1..8 waves per CU
+constexpr int BIN_WIDE = N_CPL * N_OCC;  // exact int32 kernel (whole-reference windows, escapes, overflow)
+constexpr int N_BINS = BIN_WIDE + 1;
+
+struct ReadSet {
+  int64_t n;
+  const uint8_t* packed;
+  const uint32_t* roff;
+  const uint16_t* len;
+  const uint8_t* rc;
+  const uint8_t* sk;
+  int32_t* as;
+  int32_t* ae;
+  int32_t* score;
+  int32_t* refstart;
+  int16_t* abr;
+  uint32_t* status;
+  int16_t* cols;
+  int32_t stride;
+};
+
+struct RefInfo {
+  const uint8_t* codes;
+  int32_t L, wrap;
+};
+
+MIA_HD inline int lds_need(int len2, int len1) { return ((len2 * 10 + 15) & ~15) + len2 * ((len1 + 3) & ~3); }
+
+// window of reiterate_assembly (src/mia_main.c:191-212)
+MIA_HD inline void realign_window(int as, int ae, int len2, int wrap, int* ref_start, int* len1) {
+  int rs = (as - REALIGN_BUFFER) < 0 ? 0 : as - REALIGN_BUFFER;
+  int re = (ae + REALIGN_BUFFER + 1) > wrap ? wrap : ae + REALIGN_BUFFER;
+  if (rs + len2 > re) { rs = 0; re = wrap; }
+  *ref_start = rs;
+  *len1 = re - rs;
+}
+
+struct PackSet { PackParams p[N_CPL]; int ok[N_CPL]; };
+
+// dynamic LDS bytes a workgroup (= one wave) gets when k of them share a CU; 512-byte allocation granule
+MIA_HD inline int lds_for_occupancy(int k) { return (LDS_TOTAL / k) & ~511; }
+
+MIA_HD inline int classify(int len2, int len1, const PackSet& ps) {
+  int ci = len1 <= 256 ? 0 : (len1 <= 512 ? 1 : (len1 <= 768 ? 2 : -1));
+  if (ci < 0 || !ps.ok[ci]) return BIN_WIDE;
+  const int need = lds_need(len2, len1);
+  for (int k = N_OCC; k >= 1; k--)
+    if (need <= lds_for_occupancy(k)) return ci * N_OCC + (k - 1);
+  return BIN_WIDE;
+}
+
+// ---- plan: bin every read by kernel variant and LDS footprint ----------------
+__global__ void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int32_t* bin_of, int32_t* bin_count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rs.n) return;
+  int b = -1;
+  if (rs.sk[i]) {
+    int s, l1;
+    realign_window(rs.as[i], rs.ae[i], rs.len[i], ref.wrap, &s, &l1);
+    b = classify(rs.len[i], l1, ps);
+    atomicAdd(&bin_count[b], 1);
+  } else {
+    rs.status[i] = ST_SKIPPED;
+  }
+  bin_of[i] = b;
+}
+
+__global__ void k_plan_fill(int64_t n, const int32_t* bin_of, const int32_t* bin_off, int32_t* bin_cursor, int32_t* list) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int b = bin_of[i];
+  if (b < 0) return;
+  int p = atomicAdd(&bin_cursor[b], 1);
+  list[bin_off[b] + p] = (int32_t)i;
+}
+
+// ---- the windowed DP: one read per 64-lane workgroup ---------------------------
+template <int CPL>
+__global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackParams pk,
+                                                      const int32_t* list, int32_t count, int32_t* wide_list,
+                                                      int32_t* wide_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int w = blockIdx.x;
+  if (w >= count) return;
+  const int i = list[w];
+  AlignArgs a;
+  int s, l1;
+  const int len2 = rs.len[i];
+  realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &l1);
+  a.ref_codes = ref.codes;
+  a.ref_start = s;
+  a.len1 = l1;
+  a.read_packed = rs.packed + rs.roff[i];
+  a.len2 = len2;
+  a.pssm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);   // src/mia_main.c:179-184
+  a.sg5 = 1;                                      // sg_align leaves sg5 = sg3 = 1 (src/mia.c:1535-1538)
+  a.pk = pk;
+  a.lds_sub = 0;
+  a.lds_trace = (uint32_t)((len2 * 10 + 15) & ~15);
+  a.trace_stride = (uint32_t)((l1 + 3) & ~3);
+  a.cols_out = rs.cols + (int64_t)i * rs.stride;
+  DevWave wave(lds_raw);
+  AlignResult r = WindowAligner<DevWave, CPL>::run(wave, a);
+  if (wave.lane() == 0) {
+    if (r.status & ST_ESCAPE) {
+      // a gap of >= 63 on the optimal path: the byte trace cannot represent it; hand the
+      // read to the exact kernel (as/ae are left untouched so that it sees the same window)
+      int p = atomicAdd(wide_count, 1);
+      wide_list[p] = i;
+    } else {
+      rs.score[i] = r.score;
+      rs.refstart[i] = s;
+      rs.abr[i] = (int16_t)r.abr;
+      rs.as[i] = r.abc + s;   // src/mia_main.c:254-255
+      rs.ae[i] = r.aec + s;
+    }
+    rs.status[i] = r.status;
+  }
+}
+
+// ---- exact wide kernel: one read per thread, int32 scores and trace in global scratch.
+// Handles whole-reference windows (src/mia_main.c:209-212), gaps >= 63 and anything the
+// packed kernel cannot represent.  Slow by design; it is the rare path.
+struct WideJob { int64_t scratch_off; };  // in int32 words
+
+__global__ void k_align_wide(ReadSet rs, RefInfo ref, const int32_t* pssm2, const int32_t* list, int32_t count,
+                             const int64_t* scratch_off, int32_t* scratch) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const int i = list[t];
+  const int len2 = rs.len[i];
+  int s, n1;
+  realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &n1);
+  const uint8_t* c1 = ref.codes + s;
+  const uint8_t* rp = rs.packed + rs.roff[i];
+  const int32_t* pm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);
+  int32_t* base = scratch + scratch_off[t];
+  int32_t* T = base;                               // [len2][n1]
+  int32_t* S0 = base + (int64_t)len2 * n1;         // three rotating score rows
+  int32_t* colkey = S0 + 3 * (int64_t)n1;
+  int32_t* colrow = colkey + n1;
+  auto rcode = [&](int r) { return (int)((rp[r >> 1] >> ((r & 1) * 4)) & 15); };
+  int32_t *prev2 = S0, *prev = S0 + n1, *cur = S0 + 2 * (int64_t)n1;
+  {
+    const int c2 = rcode(0);
+    for (int c = 0; c < n1; c++) {
+      cur[c] = pm[(0 * 5 + c1[c]) * 5 + c2];
+      T[c] = 0;
+      colkey[c] = cur[c];
+      colrow[c] = 0;
+    }
+  }
+  for (int r = 1; r < len2; r++) {
+    int32_t* tmp = prev2; prev2 = prev; prev = cur; cur = tmp;
+    const int d = sm_depth(r, len2), c2 = rcode(r);
+    const int fresh = -(GOP + GEP * (r + 1));
+    int32_t* tr = T + (int64_t)r * n1;
+    cur[0] = pm[(d * 5 + c1[0]) * 5 + c2] + fresh;
+    tr[0] = 0;
+    int rowkey = prev[0], rowcol = 0;
+    for (int c = 1; c < n1; c++) {
+      const int sub = pm[(d * 5 + c1[c]) * 5 + c2];
+      int gapc = -(1 << 30), gapr = -(1 << 30);
+      if (c >= 2) {
+        int k = prev[c - 2] + GEP * (c - 2);
+        if (k > rowkey) { rowkey = k; rowcol = c - 2; }
+        gapc = rowkey - GOP - GEP * (c - 1);
+      }
+      if (r >= 2) {
+        int k = prev2[c - 1] + GEP * (r - 2);
+        if (k > colkey[c - 1]) { colkey[c - 1] = k; colrow[c - 1] = r - 2; }
+        gapr = colkey[c - 1] - GOP - GEP * (r - 1);
+      }
+      const int diag = prev[c - 1];
+      if (fresh > diag && fresh > gapc && fresh > gapr) { cur[c] = fresh; tr[c] = c; }
+      else if (diag >= gapc && diag >= gapr) { cur[c] = sub + diag; tr[c] = 0; }
+      else if (gapc >= gapr) { cur[c] = sub + gapc; tr[c] = rowcol; }
+      else { cur[c] = sub + gapr; tr[c] = -colrow[c - 1]; }
+    }
+  }
+  int best = INT32_MIN, aec = 0;
+  for (int c = 0; c < n1; c++) if (cur[c] > best) { best = cur[c]; aec = c; }
+  // traceback (src/mia.c:612-637,1440-1497): first walk finds the alignment start so that the
+  // script can be stored relative to it (whole-reference windows exceed int16 otherwise)
+  int16_t* cols = rs.cols + (int64_t)i * rs.stride;
+  int r = len2 - 1, c = aec;
+  for (;;) {
+    const int t2 = T[(int64_t)r * n1 + c];
+    if (t2 == c || t2 == -r) break;
+    if (t2 == 0) { r--; c--; }
+    else if (t2 < 0) { r = -t2; c--; }
+    else { c = t2; r--; }
+  }
+  const int abr = r, abc = c;
+  int ncol = 0;
+  r = len2 - 1; c = aec;
+  for (;;) {
+    const int t2 = T[(int64_t)r * n1 + c];
+    const int rel = c - abc;
+    cols[r] = (int16_t)(rel > 32767 ? 32767 : rel);
+    ncol++;
+    if (t2 == c || t2 == -r) break;
+    if (t2 == 0) { r--; c--; }
+    else if (t2 < 0) { int nr = -t2; r--; c--; while (r > nr) { cols[r] = COL_INSERT; r--; ncol++; } }
+    else { ncol += c - 1 - t2; r--; c = t2; }
+  }
+  for (int q = 0; q < abr; q++) cols[q] = COL_CLIP;
+  uint32_t st = ST_OK;
+  if (ncol > 2 * MAX_READ) st |= ST_TOO_LONG;
+  rs.score[i] = best;
+  rs.refstart[i] = s + abc;   // script columns are relative to the alignment start here
+  rs.abr[i] = (int16_t)abr;
+  rs.as[i] = abc + s;         // src/mia_main.c:254-255
+  rs.ae[i] = aec + s;
+  rs.status[i] = st;
+}
+
+}  // namespace mia

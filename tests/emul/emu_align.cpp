@@ -1,0 +1,42 @@
+// emu_align.cpp -- TEST INFRASTRUCTURE: runs csrc/align_body.h (the exact source
+// the HIP kernel instantiates) on the CPU lock-step wave emulation, so the
+// packed-word DP and the ballot traceback can be checked against the oracle
+// without a GPU.  Built by tests/test_emul_align.py into oracle/_build/.
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#include "wave_emu.h"
+#include "align_body.h"
+
+using namespace mia;
+
+template <int CPL>
+static int run_one(const uint8_t* ref_codes, int ref_start, int len1, const uint8_t* read_codes, int len2,
+                   const int32_t* pssm, int sg5, int max_abs, int32_t* out5, int16_t* cols) {
+  PackParams pk;
+  if (!make_pack_params(64 * CPL, max_abs, &pk)) return -1;
+  std::vector<uint8_t> packed((len2 + 1) / 2 + 4, 0);
+  for (int i = 0; i < len2; i++) packed[i >> 1] |= (uint8_t)(read_codes[i] << ((i & 1) * 4));
+  AlignArgs a;
+  a.ref_codes = ref_codes; a.ref_start = ref_start; a.len1 = len1;
+  a.read_packed = packed.data(); a.len2 = len2; a.pssm = pssm; a.sg5 = sg5; a.pk = pk;
+  a.lds_sub = 0;
+  a.lds_trace = (uint32_t)((len2 * 10 + 15) & ~15);
+  a.trace_stride = (uint32_t)((len1 + 3) & ~3);
+  a.cols_out = cols;
+  EmuWave w(a.lds_trace + (size_t)len2 * a.trace_stride + 16);
+  AlignResult r = WindowAligner<EmuWave, CPL>::run(w, a);
+  out5[0] = r.score; out5[1] = r.abc; out5[2] = r.abr; out5[3] = r.aec; out5[4] = (int32_t)r.status;
+  return 0;
+}
+
+extern "C" int emu_align_window(int cpl, const uint8_t* ref_codes, int ref_start, int len1, const uint8_t* read_codes,
+                                int len2, const int32_t* pssm, int sg5, int max_abs, int32_t* out5, int16_t* cols) {
+  switch (cpl) {
+    case 4: return run_one<4>(ref_codes, ref_start, len1, read_codes, len2, pssm, sg5, max_abs, out5, cols);
+    case 8: return run_one<8>(ref_codes, ref_start, len1, read_codes, len2, pssm, sg5, max_abs, out5, cols);
+    case 12: return run_one<12>(ref_codes, ref_start, len1, read_codes, len2, pssm, sg5, max_abs, out5, cols);
+    default: return -2;
+  }
+}

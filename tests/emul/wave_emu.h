@@ -1,0 +1,76 @@
+// wave_emu.h -- TEST INFRASTRUCTURE: a CPU "wave policy" for csrc/align_body.h.
+// Every per-lane value is a 64-element array and every operation is applied to
+// all lanes before the next one starts (lock-step), so cross-lane operations
+// (shift, prefix max, ballot) see exactly what the GPU's DPP/LDS versions see.
+// Used only by tests/emul/emu_align.cpp to unit-test the kernel logic without
+// a GPU.  The product never links this.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include <vector>
+
+#include "mia_layout.h"
+
+namespace mia {
+
+struct EV {  // 64 x uint32
+  uint32_t a[64];
+  EV() { memset(a, 0, sizeof a); }
+  EV(uint32_t x) { for (int i = 0; i < 64; i++) a[i] = x; }
+};
+struct EM {  // 64 x bool
+  bool a[64];
+  EM() { memset(a, 0, sizeof a); }
+};
+
+#define EV_BIN(op)                                                                                      \
+  inline EV operator op(const EV& x, const EV& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] op y.a[i]; return r; } \
+  inline EV operator op(const EV& x, uint32_t y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] op y; return r; }       \
+  inline EV operator op(uint32_t x, const EV& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x op y.a[i]; return r; }
+EV_BIN(+) EV_BIN(-) EV_BIN(*) EV_BIN(&) EV_BIN(|) EV_BIN(^)
+#undef EV_BIN
+inline EV operator<<(const EV& x, int s) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] << s; return r; }
+inline EV operator>>(const EV& x, int s) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] >> s; return r; }
+inline EV operator<<(const EV& x, const EV& s) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] << s.a[i]; return r; }
+inline EV operator>>(const EV& x, const EV& s) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] >> s.a[i]; return r; }
+inline EV operator~(const EV& x) { EV r; for (int i = 0; i < 64; i++) r.a[i] = ~x.a[i]; return r; }
+#define EV_CMP(op)                                                                                      \
+  inline EM operator op(const EV& x, const EV& y) { EM r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] op y.a[i]; return r; } \
+  inline EM operator op(const EV& x, uint32_t y) { EM r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] op y; return r; }
+EV_CMP(==) EV_CMP(!=) EV_CMP(<) EV_CMP(<=) EV_CMP(>) EV_CMP(>=)
+#undef EV_CMP
+inline EM operator&(const EM& x, const EM& y) { EM r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] && y.a[i]; return r; }
+inline EM operator|(const EM& x, const EM& y) { EM r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] || y.a[i]; return r; }
+inline EM operator!(const EM& x) { EM r; for (int i = 0; i < 64; i++) r.a[i] = !x.a[i]; return r; }
+
+struct EmuWave {
+  typedef EV U;
+  typedef EM M;
+  std::vector<unsigned char> lds;
+  explicit EmuWave(size_t lds_bytes) : lds(lds_bytes + 64, 0) {}
+
+  U lane() const { EV r; for (int i = 0; i < 64; i++) r.a[i] = (uint32_t)i; return r; }
+  U shr1(const U& x, const U& fill) const { EV r; r.a[0] = fill.a[0]; for (int i = 1; i < 64; i++) r.a[i] = x.a[i - 1]; return r; }
+  static U umax(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] > y.a[i] ? x.a[i] : y.a[i]; return r; }
+  static U umin(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] < y.a[i] ? x.a[i] : y.a[i]; return r; }
+  static U umax3(const U& x, const U& y, const U& z) { return umax(umax(x, y), z); }
+  static U sel(const M& c, const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = c.a[i] ? x.a[i] : y.a[i]; return r; }
+  U scan_max(const U& v) const { EV r; uint32_t m = 0; for (int i = 0; i < 64; i++) { m = v.a[i] > m ? v.a[i] : m; r.a[i] = m; } return r; }
+  uint32_t reduce_max(const U& v) const { return scan_max(v).a[63]; }
+  uint32_t reduce_min(const U& v) const { return ~reduce_max(~v); }
+  uint64_t ballot(const M& m) const { uint64_t b = 0; for (int i = 0; i < 64; i++) if (m.a[i]) b |= 1ull << i; return b; }
+  uint32_t lane_val(const U& v, int l) const { return v.a[l]; }
+  bool lane_bit(const M& m, int l) const { return m.a[l]; }
+  static U udiv5(const U& e) { EV r; for (int i = 0; i < 64; i++) r.a[i] = e.a[i] / 5u; return r; }
+  static U depth(const U& row, uint32_t len) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (uint32_t)sm_depth((int)row.a[i], (int)len); return r; }
+  static U gload_u8(const uint8_t* p, const U& idx, const M& ok) { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? p[idx.a[i]] : 0u; return r; }
+  static U gload_i32(const int32_t* p, const U& idx, const M& ok) { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? (uint32_t)p[idx.a[i]] : 0u; return r; }
+  static void gstore_i16(int16_t* p, const U& idx, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) p[idx.a[i]] = (int16_t)(uint16_t)v.a[i]; }
+  void lds_w16(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { uint16_t x = (uint16_t)v.a[i]; memcpy(&lds.at(off.a[i]), &x, 2); } }
+  void lds_w32(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { lds.at(off.a[i] + 3); memcpy(&lds[off.a[i]], &v.a[i], 4); } }
+  U lds_ri16(const U& off) const { EV r; for (int i = 0; i < 64; i++) { int16_t x; lds.at(off.a[i] + 1); memcpy(&x, &lds[off.a[i]], 2); r.a[i] = (uint32_t)(int32_t)x; } return r; }
+  U lds_r8(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? lds.at(off.a[i]) : 0u; return r; }
+  void lds_fence() const {}
+};
+
+}  // namespace mia

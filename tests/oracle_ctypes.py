@@ -71,6 +71,8 @@ def load(path):
     lib.ora_num_culled.argtypes = [C.c_void_p]
     lib.ora_culled_at.argtypes = [C.c_void_p, C.c_int]
     lib.ora_culled_at.restype = P(AlnSeq)
+    lib.ora_slot_at.argtypes = [C.c_void_p, C.c_int]
+    lib.ora_slot_at.restype = P(AlnSeq)
     lib.ora_ref_len.argtypes = [C.c_void_p]
     lib.ora_ref_seq.argtypes = [C.c_void_p]
     lib.ora_ref_seq.restype = C.c_char_p

@@ -115,6 +115,14 @@ def make_reads(genome, n_reads, read_len=100, seed=1, circular=True, sub_rate=0.
     return {"reads": reads, "start": start.astype(np.int64), "strand": strand}
 
 
+def stored_orientation(d):
+    """Reads as MIA keeps them in its read store after pass 1: reverse-strand reads are
+    reverse-complemented once the strand is known (reference src/fsdb.c:209-227)."""
+    reads, strand = d["reads"], d["strand"]
+    flipped = _COMP[reads[:, ::-1]]
+    return np.where(strand[:, None] == 1, flipped, reads).astype(np.uint8)
+
+
 def write_fasta_reads(path, reads, prefix="r"):
     with open(path, "w") as f:
         for i in range(reads.shape[0]):
