@@ -17,7 +17,11 @@
 //     packed key words (lane-local chain + 6 DPP steps);
 //   * best_gap_row[c] (running arg-max down a column) -> one register per owned
 //     column, handed to the right neighbour with one DPP shift;
-//   * the trace is one byte per cell in LDS; the traceback follows diagonal
+//   * scores are carried biased (S + off) so that every packed word is built
+//     with one shift-add;
+//   * the trace is one byte per cell, written through the policy's tr_* hooks (a
+//     per-workgroup slab in global memory that stays in L2 / Infinity Cache on the
+//     GPU, so that LDS does not limit occupancy); the traceback follows diagonal
 //     runs 64 cells at a time with a ballot.
 #pragma once
 #include "mia_layout.h"
@@ -33,8 +37,7 @@ struct AlignArgs {            // everything here is wave-uniform
   const int32_t* pssm;        // sm[31][5][5] of this read's strand            [global]
   int32_t sg5;                // pay for unaligned 5' read bases (always 1 in mia)
   PackParams pk;
-  uint32_t lds_sub;           // LDS byte offset: int16 sub[len2][5]
-  uint32_t lds_trace;         // LDS byte offset: trace bytes [len2][trace_stride]
+  uint32_t lds_sub;           // LDS byte offset: int16 sub[5][rows padded to even]
   uint32_t trace_stride;      // bytes per trace row, multiple of 4, >= len1
   int16_t* cols_out;          // script: window column per read row            [global]
 };
@@ -44,20 +47,29 @@ struct AlignResult {          // wave-uniform
   uint32_t status;
 };
 
+template <int CPL>
+struct PackBits {
+  static constexpr int IB = (CPL == 4) ? 8 : 10;   // must agree with make_pack_params(64*CPL, ..)
+  static constexpr int SH = IB + 2;
+  static constexpr uint32_t IDXM = (1u << IB) - 1u;
+};
+
 template <class P, int CPL>
 struct WindowAligner {
   typedef typename P::U U;
   typedef typename P::M M;
+  static constexpr int IB = PackBits<CPL>::IB, SH = PackBits<CPL>::SH;
+  static constexpr uint32_t IDXM = PackBits<CPL>::IDXM;
 
   MIA_HD static inline __attribute__((always_inline)) AlignResult run(P& w, const AlignArgs& a) {
-    const int SH = a.pk.sh, IB = a.pk.ib;
-    const uint32_t IDXM = a.pk.idxm;
     const uint32_t OFF = (uint32_t)a.pk.off;
     const uint32_t UNAV = ((uint32_t)a.pk.unavail << SH) | IDXM;
     const U lane = w.lane();
     const int len1 = a.len1, len2 = a.len2;
+    const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;   // bytes per code row of the sub table
 
-    // ---- 1. substitution table sub[r][code1] = sm[depth(r)][code1][read[r]] (src/mia.c:792-795)
+    // ---- 1. substitution table sub[code1][r] = sm[depth(r)][code1][read[r]] (src/mia.c:792-795),
+    //         int16, rows r and r+1 adjacent so that one 32-bit LDS read serves two DP rows
     for (int e0 = 0; e0 < len2 * 5; e0 += WAVE) {
       U e = lane + (uint32_t)e0;
       M ok = e < (uint32_t)(len2 * 5);
@@ -67,7 +79,7 @@ struct WindowAligner {
       U c2 = (byte >> ((r & 1u) << 2)) & 15u;
       U d = w.depth(r, (uint32_t)len2);
       U v = w.gload_i32(a.pssm, (d * 5u + c1) * 5u + c2, ok);
-      w.lds_w16(U(a.lds_sub) + e * 2u, v, ok);
+      w.lds_w16(U(a.lds_sub) + c1 * RS2 + r * 2u, v, ok);
     }
     w.lds_fence();
 
@@ -77,96 +89,94 @@ struct WindowAligner {
       col[j] = lane * (uint32_t)CPL + (uint32_t)j;
       M in = col[j] < (uint32_t)len1;
       U code = w.sel(in, w.gload_u8(a.ref_codes, U((uint32_t)a.ref_start) + col[j], in), U(4u));
-      sub_addr[j] = U(a.lds_sub) + code * 2u;
+      sub_addr[j] = U(a.lds_sub) + code * RS2;
       // key -> column-gap candidate: value -= GOP + GEP*(c-1); prio = 2; idx -> len = c-1-k
-      KC[j] = (U(0u) - ((U((uint32_t)GOP) + (col[j] - 1u) * (uint32_t)GEP) << SH)) + (2u << IB) + (col[j] - 1u - IDXM);
-      // S -> key of this column for the next row: value = S + GEP*c + off, idx = IDXM - c
-      QC[j] = ((col[j] * (uint32_t)GEP + OFF) << SH) + (U(IDXM) - col[j]);
+      KC[j] = (U(0u) - ((U((uint32_t)GOP) + (col[j] - 1u) * (uint32_t)GEP) << SH)) + (TR_COLGAP << IB) + (col[j] - 1u - IDXM);
+      // biased S -> key of this column for the next row: value += GEP*c, idx = IDXM - c
+      QC[j] = ((col[j] * (uint32_t)GEP) << SH) + (U(IDXM) - col[j]);
     }
-    const uint32_t WDC = (OFF << SH) + (TR_DIAG << IB);
+    const uint32_t WDC = TR_DIAG << IB;
+    const U unav = U(UNAV);
 
-    // ---- 3. row 0 (src/mia.c:769-785): S = sub, T = 0
-    U S[CPL], q[CPL], rrun[CPL], pend[CPL];
+    // ---- 3. row 0 (src/mia.c:769-785): S = sub, T = 0.  Sb = S + off throughout.
+    U Sb[CPL], q[CPL], rrun[CPL], pend[CPL], pw[CPL];
     {
-      const uint32_t rk = ((0u * GEP + OFF) << SH) + (IDXM - 0u);
-      U tw = U(0u);
+      const uint32_t rk = IDXM;   // GEP*0, idx = IDXM - 0
       for (int j = 0; j < CPL; j++) {
-        S[j] = w.lds_ri16(sub_addr[j]);
-        q[j] = (S[j] << SH) + QC[j];
-        pend[j] = (S[j] << SH) + rk;
-        rrun[j] = U(UNAV);
-        tw = tw | (U(TR_DIAG << 6) << (8 * (j & 3)));
-        if ((j & 3) == 3 || j == CPL - 1) {
-          w.lds_w32(U(a.lds_trace) + col[j & ~3] , tw, col[j & ~3] < (uint32_t)a.trace_stride);
-          tw = U(0u);
-        }
+        pw[j] = w.lds_r32(sub_addr[j]);                 // rows 0 and 1
+        Sb[j] = w.sext_lo(pw[j]) + OFF;
+        q[j] = (Sb[j] << SH) + QC[j];
+        pend[j] = (Sb[j] << SH) + rk;
+        rrun[j] = unav;
       }
+      for (int j4 = 0; j4 < CPL; j4 += 4)
+        w.tr_w32(col[j4], U((TR_DIAG << 6) * 0x01010101u), col[j4] < (uint32_t)a.trace_stride);
     }
 
     // ---- 4. rows 1 .. len2-1
     for (int r = 1; r < len2; r++) {
       const int32_t fresh = a.sg5 ? -(GOP + GEP * (r + 1)) : 0;            // src/mia.c:877-880
-      const uint32_t WS = ((uint32_t)(fresh + (int32_t)OFF)) << SH;         // prio 0, len 0
+      const uint32_t freshb = (uint32_t)(fresh + (int32_t)OFF);
+      const uint32_t WS = freshb << SH;                                     // prio 0, len 0
       const uint32_t KR = (0u - ((uint32_t)(GOP + GEP * (r - 1)) << SH)) + (TR_ROWGAP << IB) + ((uint32_t)(r - 1) - IDXM);
-      const uint32_t RK = (((uint32_t)(GEP * r) + OFF) << SH) + (IDXM - (uint32_t)r);
-      const uint32_t row_sub = (uint32_t)r * 10u;
-      const uint32_t row_tr = a.lds_trace + (uint32_t)r * a.trace_stride;
+      const uint32_t RK = ((uint32_t)(GEP * r) << SH) + (IDXM - (uint32_t)r);
+      const uint32_t row_tr = (uint32_t)r * a.trace_stride;
+      const bool hi = (r & 1) != 0;
+      if (!hi)
+        for (int j = 0; j < CPL; j++) pw[j] = w.lds_r32(sub_addr[j] + (uint32_t)r * 2u);   // rows r, r+1
 
-      // neighbours: diag of the first owned column, its best_gap_row state, and the
-      // two keys left of the lane for the shifted prefix scan
-      U dleft = w.shr1(S[CPL - 1], U((uint32_t)fresh));   // column 0: "diag" = fresh  => S = sub + fresh, T = 0 (src/mia.c:805-822)
-      U rleft = w.shr1(rrun[CPL - 1], U(UNAV));
-      U u0 = w.shr1(q[CPL - 2 >= 0 ? CPL - 2 : 0], U(UNAV));
-      U u1 = w.shr1(q[CPL - 1], U(UNAV));
+      // neighbours: diag of the first owned column (column 0: "diag" = fresh, so S = sub + fresh
+      // and T = 0, src/mia.c:805-822), its best_gap_row state, and the two keys left of the
+      // lane for the shifted prefix scan.  Keys never go below UNAV, so max(., unav) is the fill.
+      U dleft = w.shr1(Sb[CPL - 1], U(freshb));
+      U rleft = w.shr1_max(rrun[CPL - 1], unav);
+      U u0 = w.shr1_max(q[CPL - 2], unav);
+      U u1 = w.shr1_max(q[CPL - 1], unav);
       // g[j] = max key over columns <= c_j - 2 inside {two left keys, own keys}
       U g[CPL];
       g[0] = u0;
       g[1] = w.umax(u0, u1);
       for (int j = 2; j < CPL; j++) g[j] = w.umax(g[j - 1], q[j - 2]);
-      U incl = w.scan_max(g[CPL - 1]);
-      U excl = w.shr1(incl, U(UNAV));
+      U excl = w.shr1_max(w.scan_max(g[CPL - 1]), unav);
 
-      U Snew[CPL];
-      U tw = U(0u);
+      U best[CPL], Snew[CPL];
       for (int j = 0; j < CPL; j++) {
-        U diag = (j == 0) ? dleft : S[j - 1];
+        U diag = (j == 0) ? dleft : Sb[j - 1];
         U rl = (j == 0) ? rleft : rrun[j - 1];
-        U cand = w.umax(excl, g[j]);
         U Wd = (diag << SH) + WDC;
-        U Wc = cand + KC[j];
+        U Wc = w.umax(excl, g[j]) + KC[j];
         U Wr = rl + KR;
-        U best = w.umax(w.umax3(Wd, Wc, Wr), U(WS));
-        U sub = w.lds_ri16(sub_addr[j] + row_sub);
-        M is_start = (best >> IB & 3u) == U(TR_START);
-        Snew[j] = (best >> SH) - OFF + w.sel(is_start, U(0u), sub);       // start drops the substitution score (src/mia.c:916-917)
-        U tb = ((best >> IB & 3u) << 6) | w.umin(best & IDXM, U(TR_LEN_SAT));
-        tw = tw | (tb << (8 * (j & 3)));
-        if ((j & 3) == 3 || j == CPL - 1) {
-          w.lds_w32(U(row_tr) + col[j & ~3], tw, col[j & ~3] < (uint32_t)a.trace_stride);
-          tw = U(0u);
-        }
+        U m3 = w.umax3(Wd, Wc, Wr);
+        best[j] = w.umax(m3, U(WS));
+        U sub = hi ? w.sext_hi(pw[j]) : w.sext_lo(pw[j]);
+        // start (only if strictly better than the other three) drops the substitution score (src/mia.c:910-917)
+        Snew[j] = (best[j] >> SH) + w.sel(m3 < WS, U(0u), sub);
       }
+      for (int j4 = 0; j4 < CPL; j4 += 4)
+        w.tr_w32(U(row_tr) + col[j4], w.template trace_pack4<IB>(best[j4], best[j4 + 1], best[j4 + 2], best[j4 + 3]),
+                 col[j4] < (uint32_t)a.trace_stride);
       for (int j = 0; j < CPL; j++) {
         rrun[j] = w.umax(rrun[j], pend[j]);       // rows <= r-1 become candidates for row r+1
         pend[j] = (Snew[j] << SH) + RK;
         q[j] = (Snew[j] << SH) + QC[j];
-        S[j] = Snew[j];
+        Sb[j] = Snew[j];
       }
     }
 
     // ---- 5. max_sg_score (src/mia.c:1278-1302): last row, first maximum
     AlignResult res;
+    res.abr = 0;
+    res.abc = 0;
     {
-      U m = U(0u);  // biased signed max
-      for (int j = 0; j < CPL; j++) m = w.umax(m, w.sel(col[j] < (uint32_t)len1, S[j] ^ 0x80000000u, U(0u)));
-      uint32_t bestb = w.reduce_max(m);
+      U m = U(0u);
+      for (int j = 0; j < CPL; j++) m = w.umax(m, w.sel(col[j] < (uint32_t)len1, Sb[j], U(0u)));
+      const uint32_t bestb = w.reduce_max(m);
       U cmin = U(0xFFFFFFFFu);
-      for (int j = CPL - 1; j >= 0; j--)
-        cmin = w.sel((col[j] < (uint32_t)len1) & ((S[j] ^ 0x80000000u) == U(bestb)), col[j], cmin);
-      res.score = (int32_t)(bestb ^ 0x80000000u);
+      for (int j = CPL - 1; j >= 0; j--) cmin = w.sel((col[j] < (uint32_t)len1) & (Sb[j] == bestb), col[j], cmin);
+      res.score = (int32_t)(bestb - OFF);
       res.aec = (int32_t)w.reduce_min(cmin);
     }
-    w.lds_fence();
+    w.tr_fence();
 
     // ---- 6. traceback (src/mia.c:612-637,1440-1497), diagonal runs of up to 64 cells per step.
     // cols_out[row] = window column aligned to that read base, COL_INSERT, or COL_CLIP.
@@ -177,7 +187,7 @@ struct WindowAligner {
       // lane i inspects cell (r-i, c-i)
       U ri = U((uint32_t)r) - lane, ci = U((uint32_t)c) - lane;
       M inside = (lane <= (uint32_t)r) & (lane <= (uint32_t)c);
-      U tb = w.lds_r8(U(a.lds_trace) + ri * a.trace_stride + ci, inside);
+      U tb = w.tr_r8(ri * a.trace_stride + ci, inside);
       U ty = tb >> 6, ln = tb & 63u;
       // the reference reads T==0 as a diagonal step even when it encodes a gap that
       // started in column/row 0 (src/mia.c:619,1460): gap source index 0 <=> len == c-1 / r-1

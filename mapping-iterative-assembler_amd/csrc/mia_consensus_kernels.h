@@ -203,11 +203,23 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
 // ---- insert columns (find_ins_cons, src/map_align.c:444-510) ----------------------
 // ins_off[pos] = sum of gaps[0..pos-1]; slot (pos, j) -> ins_off[pos] + j; 9 words per slot:
 // A,C,G,T counts, number of reads with a base there, scoreA..scoreT
-__global__ void k_gap_offsets(const int32_t* gaps, int32_t Lp, int32_t L, int32_t* ins_off, int32_t* total) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int32_t run = 0;
-  for (int p = 0; p < Lp; p++) { ins_off[p] = run; if (p > 0 && p < L) run += gaps[p]; }
-  *total = run;
+__global__ __launch_bounds__(1024) void k_gap_offsets(const int32_t* gaps, int32_t Lp, int32_t L, int32_t* ins_off, int32_t* total) {
+  // exclusive scan of gaps[1..L-1] by one 1024-thread block: each thread owns a contiguous chunk
+  __shared__ int32_t sh[1024];
+  const int t = threadIdx.x, chunk = (Lp + 1023) / 1024, lo = t * chunk, hi = min(lo + chunk, Lp);
+  int32_t s = 0;
+  for (int p = lo; p < hi; p++) if (p > 0 && p < L) s += gaps[p];
+  sh[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int32_t v = (t >= o) ? sh[t - o] : 0;
+    __syncthreads();
+    sh[t] += v;
+    __syncthreads();
+  }
+  int32_t run = sh[t] - s;
+  for (int p = lo; p < hi; p++) { ins_off[p] = run; if (p > 0 && p < L) run += gaps[p]; }
+  if (t == 1023) *total = sh[1023];
 }
 __global__ void k_ins_tally(const uint64_t* events, int32_t n_events, const int32_t* pssm2, const int32_t* ins_off,
                             const int32_t* gaps, int32_t L, int32_t* ins_tally) {

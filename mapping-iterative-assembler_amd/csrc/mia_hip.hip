@@ -42,6 +42,9 @@ struct mia_hip_ctx {
   TallyBuf tb{}; int tally_cap = 0; int32_t* d_ins_off = nullptr; int32_t* d_ins_total = nullptr;
   int32_t* d_ins_tally = nullptr; int64_t ins_tally_cap = 0; char* d_calls = nullptr; char* d_ins_calls = nullptr;
   int64_t ins_calls_cap = 0; int32_t n_events_host = 0; bool tallied = false;
+  // trace slabs of the persistent DP grid (one per workgroup, per CPL class)
+  unsigned char* d_slabs[N_CPL] = {nullptr, nullptr, nullptr};
+  int grid_wgs = 0;
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
@@ -81,10 +84,14 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     delete ctx;
     return MIA_HIP_ERR_DEVICE;
   }
-  // windows larger than 64 KiB of trace need the full 160 KiB LDS of a gfx950 CU
-  (void)hipFuncSetAttribute((const void*)k_align_window<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-  (void)hipFuncSetAttribute((const void*)k_align_window<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-  (void)hipFuncSetAttribute((const void*)k_align_window<12>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+  {
+    // persistent DP grid: one 64-lane workgroup per wave slot of the chip (8 waves/SIMD x 4 SIMDs x CUs)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
+    ctx->grid_wgs = prop.multiProcessorCount * 32;
+    const char* g = getenv("MIA_HIP_GRID_WAVES_PER_CU");
+    if (g && atoi(g) > 0) ctx->grid_wgs = prop.multiProcessorCount * atoi(g);
+  }
   if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_bins, 3 * N_BINS + 1) ||
       dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1)) {
     delete ctx;
@@ -102,7 +109,8 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_refstart, ctx->d_abr, ctx->d_status, ctx->d_cols, ctx->d_bin_of, ctx->d_list, ctx->d_wide_list,
                   ctx->d_bins, ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
                   ctx->d_drop_b, ctx->tb.tally, ctx->tb.gaps, ctx->tb.events, ctx->tb.n_events, ctx->tb.flags, ctx->d_ins_off,
-                  ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off};
+                  ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
+                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2]};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -248,14 +256,19 @@ extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms
 }
 
 template <int CPL>
-static hipError_t launch_window(mia_hip_ctx* ctx, int ci, int k, const int32_t* list, int count) {
-  const int lds = lds_for_occupancy(k);
+static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count) {
+  // slab = the largest trace of this class: 256 rows x 64*CPL columns, one byte per cell
+  const int64_t slab = (int64_t)MAX_READ * 64 * CPL;
+  const int grid = count < ctx->grid_wgs ? count : ctx->grid_wgs;
+  if (!ctx->d_slabs[ci]) {
+    if (hipMalloc((void**)&ctx->d_slabs[ci], (size_t)slab * ctx->grid_wgs) != hipSuccess) return hipErrorOutOfMemory;
+  }
   hipEvent_t e0, e1;
   if (get_events(ctx, &e0, &e1)) return hipErrorOutOfMemory;
   RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
   (void)hipEventRecord(e0, ctx->stream);
-  hipLaunchKernelGGL((k_align_window<CPL>), dim3(count), dim3(64), lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
-                     count, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS);
+  hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
+                     count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS);
   (void)hipEventRecord(e1, ctx->stream);
   return hipGetLastError();
 }
@@ -298,15 +311,13 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     HIPCHK(hipMemcpyAsync(ctx->d_wide_list, ctx->d_list + h_off[BIN_WIDE], (size_t)n_wide0 * 4, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_wide_count, &h_count[BIN_WIDE], 4, hipMemcpyHostToDevice, ctx->stream));
   }
-  for (int ci = 0; ci < N_CPL; ci++)
-    for (int k = 1; k <= N_OCC; k++) {
-      const int b = ci * N_OCC + (k - 1);
-      if (h_count[b] == 0) continue;
-      hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, k, ctx->d_list + h_off[b], h_count[b])
-                   : ci == 1 ? launch_window<8>(ctx, ci, k, ctx->d_list + h_off[b], h_count[b])
-                             : launch_window<12>(ctx, ci, k, ctx->d_list + h_off[b], h_count[b]);
-      if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
-    }
+  for (int ci = 0; ci < N_CPL; ci++) {
+    if (h_count[ci] == 0) continue;
+    hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, ctx->d_list + h_off[ci], h_count[ci])
+                 : ci == 1 ? launch_window<8>(ctx, ci, ctx->d_list + h_off[ci], h_count[ci])
+                           : launch_window<12>(ctx, ci, ctx->d_list + h_off[ci], h_count[ci]);
+    if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  }
   // exact kernel for whole-reference windows and escaped reads
   int32_t n_wide = 0;
   HIPCHK(hipMemcpyAsync(&n_wide, d_wide_count, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -561,7 +572,7 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   HIPCHK(hipSetDevice(ctx->device));
   const int L = ctx->L, Lp = ctx->tb.Lp;
   int32_t total = 0;
-  hipLaunchKernelGGL(k_gap_offsets, dim3(1), dim3(64), 0, ctx->stream, ctx->tb.gaps, Lp, L, ctx->d_ins_off, ctx->d_ins_total);
+  hipLaunchKernelGGL(k_gap_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->tb.gaps, Lp, L, ctx->d_ins_off, ctx->d_ins_total);
   HIPCHK(hipMemcpyAsync(&total, ctx->d_ins_total, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (total > ctx->ins_tally_cap) {

@@ -18,11 +18,10 @@
 
 namespace mia {
 
-constexpr int LDS_TOTAL = 160 * 1024;
-constexpr int N_CPL = 3;                 // CPL 4, 8, 12
-constexpr int N_OCC = 8;                 // 1..8 waves per CU
-constexpr int BIN_WIDE = N_CPL * N_OCC;  // exact int32 kernel (whole-reference windows, escapes, overflow)
+constexpr int N_CPL = 3;                 // CPL 4, 8, 12  -> windows of up to 256 / 512 / 768 columns
+constexpr int BIN_WIDE = N_CPL;          // exact int32 kernel (whole-reference windows, escapes, overflow)
 constexpr int N_BINS = BIN_WIDE + 1;
+constexpr int SUB_LDS_BYTES = MAX_READ * 10;   // int16 sub[len2][5]
 
 struct ReadSet {
   int64_t n;
@@ -46,8 +45,6 @@ struct RefInfo {
   int32_t L, wrap;
 };
 
-MIA_HD inline int lds_need(int len2, int len1) { return ((len2 * 10 + 15) & ~15) + len2 * ((len1 + 3) & ~3); }
-
 // window of reiterate_assembly (src/mia_main.c:191-212)
 MIA_HD inline void realign_window(int as, int ae, int len2, int wrap, int* ref_start, int* len1) {
   int rs = (as - REALIGN_BUFFER) < 0 ? 0 : as - REALIGN_BUFFER;
@@ -59,84 +56,95 @@ MIA_HD inline void realign_window(int as, int ae, int len2, int wrap, int* ref_s
 
 struct PackSet { PackParams p[N_CPL]; int ok[N_CPL]; };
 
-// dynamic LDS bytes a workgroup (= one wave) gets when k of them share a CU; 512-byte allocation granule
-MIA_HD inline int lds_for_occupancy(int k) { return (LDS_TOTAL / k) & ~511; }
-
 MIA_HD inline int classify(int len2, int len1, const PackSet& ps) {
+  (void)len2;
   int ci = len1 <= 256 ? 0 : (len1 <= 512 ? 1 : (len1 <= 768 ? 2 : -1));
   if (ci < 0 || !ps.ok[ci]) return BIN_WIDE;
-  const int need = lds_need(len2, len1);
-  for (int k = N_OCC; k >= 1; k--)
-    if (need <= lds_for_occupancy(k)) return ci * N_OCC + (k - 1);
-  return BIN_WIDE;
+  return ci;
 }
 
 // ---- plan: bin every read by kernel variant and LDS footprint ----------------
-__global__ void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int32_t* bin_of, int32_t* bin_count) {
+// Counts go through an LDS histogram per block, so global memory sees one atomic per
+// (block, non-empty bin) instead of one per read on a single hot address.
+__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int32_t* bin_of, int32_t* bin_count) {
+  __shared__ int32_t hist[N_BINS];
+  if (threadIdx.x < N_BINS) hist[threadIdx.x] = 0;
+  __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rs.n) return;
-  int b = -1;
-  if (rs.sk[i]) {
-    int s, l1;
-    realign_window(rs.as[i], rs.ae[i], rs.len[i], ref.wrap, &s, &l1);
-    b = classify(rs.len[i], l1, ps);
-    atomicAdd(&bin_count[b], 1);
-  } else {
-    rs.status[i] = ST_SKIPPED;
+  if (i < rs.n) {
+    int b = -1;
+    if (rs.sk[i]) {
+      int s, l1;
+      realign_window(rs.as[i], rs.ae[i], rs.len[i], ref.wrap, &s, &l1);
+      b = classify(rs.len[i], l1, ps);
+      atomicAdd(&hist[b], 1);
+    } else {
+      rs.status[i] = ST_SKIPPED;
+    }
+    bin_of[i] = b;
   }
-  bin_of[i] = b;
+  __syncthreads();
+  if (threadIdx.x < N_BINS && hist[threadIdx.x]) atomicAdd(&bin_count[threadIdx.x], hist[threadIdx.x]);
 }
 
-__global__ void k_plan_fill(int64_t n, const int32_t* bin_of, const int32_t* bin_off, int32_t* bin_cursor, int32_t* list) {
+__global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin_of, const int32_t* bin_off, int32_t* bin_cursor,
+                                                    int32_t* list) {
+  __shared__ int32_t hist[N_BINS], base[N_BINS];
+  if (threadIdx.x < N_BINS) hist[threadIdx.x] = 0;
+  __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int b = bin_of[i];
-  if (b < 0) return;
-  int p = atomicAdd(&bin_cursor[b], 1);
-  list[bin_off[b] + p] = (int32_t)i;
+  int b = -1, rank = 0;
+  if (i < n) { b = bin_of[i]; if (b >= 0) rank = atomicAdd(&hist[b], 1); }
+  __syncthreads();
+  if (threadIdx.x < N_BINS && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], hist[threadIdx.x]);
+  __syncthreads();
+  if (b >= 0) list[bin_off[b] + base[b] + rank] = (int32_t)i;
 }
 
-// ---- the windowed DP: one read per 64-lane workgroup ---------------------------
+// ---- the windowed DP: one read at a time per 64-lane workgroup, persistent grid -------------
+// The grid is sized to the machine (waves/CU x CUs); workgroup w takes reads w, w+G, w+2G ...
+// of its bin.  LDS holds only the 5-column substitution table, the byte trace goes to the
+// workgroup's private slab `trace_slabs + w*slab_bytes` which is re-used for every read.
 template <int CPL>
 __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackParams pk,
-                                                      const int32_t* list, int32_t count, int32_t* wide_list,
-                                                      int32_t* wide_count) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int w = blockIdx.x;
-  if (w >= count) return;
-  const int i = list[w];
-  AlignArgs a;
-  int s, l1;
-  const int len2 = rs.len[i];
-  realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &l1);
-  a.ref_codes = ref.codes;
-  a.ref_start = s;
-  a.len1 = l1;
-  a.read_packed = rs.packed + rs.roff[i];
-  a.len2 = len2;
-  a.pssm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);   // src/mia_main.c:179-184
-  a.sg5 = 1;                                      // sg_align leaves sg5 = sg3 = 1 (src/mia.c:1535-1538)
-  a.pk = pk;
-  a.lds_sub = 0;
-  a.lds_trace = (uint32_t)((len2 * 10 + 15) & ~15);
-  a.trace_stride = (uint32_t)((l1 + 3) & ~3);
-  a.cols_out = rs.cols + (int64_t)i * rs.stride;
-  DevWave wave(lds_raw);
-  AlignResult r = WindowAligner<DevWave, CPL>::run(wave, a);
-  if (wave.lane() == 0) {
-    if (r.status & ST_ESCAPE) {
-      // a gap of >= 63 on the optimal path: the byte trace cannot represent it; hand the
-      // read to the exact kernel (as/ae are left untouched so that it sees the same window)
-      int p = atomicAdd(wide_count, 1);
-      wide_list[p] = i;
-    } else {
-      rs.score[i] = r.score;
-      rs.refstart[i] = s;
-      rs.abr[i] = (int16_t)r.abr;
-      rs.as[i] = r.abc + s;   // src/mia_main.c:254-255
-      rs.ae[i] = r.aec + s;
+                                                      const int32_t* list, int32_t count, unsigned char* trace_slabs,
+                                                      int64_t slab_bytes, int32_t* wide_list, int32_t* wide_count) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SUB_LDS_BYTES];
+  DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
+  for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    const int i = list[w];
+    AlignArgs a;
+    int s, l1;
+    const int len2 = rs.len[i];
+    realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &l1);
+    a.ref_codes = ref.codes;
+    a.ref_start = s;
+    a.len1 = l1;
+    a.read_packed = rs.packed + rs.roff[i];
+    a.len2 = len2;
+    a.pssm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);   // src/mia_main.c:179-184
+    a.sg5 = 1;                                      // sg_align leaves sg5 = sg3 = 1 (src/mia.c:1535-1538)
+    a.pk = pk;
+    a.lds_sub = 0;
+    a.trace_stride = (uint32_t)((l1 + 3) & ~3);
+    a.cols_out = rs.cols + (int64_t)i * rs.stride;
+    AlignResult r = WindowAligner<DevWave, CPL>::run(wave, a);
+    if (wave.lane() == 0) {
+      if (r.status & ST_ESCAPE) {
+        // a gap of >= 63 on the optimal path: the byte trace cannot represent it; hand the
+        // read to the exact kernel (as/ae are left untouched so that it sees the same window)
+        int p = atomicAdd(wide_count, 1);
+        wide_list[p] = i;
+      } else {
+        rs.score[i] = r.score;
+        rs.refstart[i] = s;
+        rs.abr[i] = (int16_t)r.abr;
+        rs.as[i] = r.abc + s;   // src/mia_main.c:254-255
+        rs.ae[i] = r.aec + s;
+      }
+      rs.status[i] = r.status;
     }
-    rs.status[i] = r.status;
+    wave.lds_fence();   // the next read overwrites the substitution table
   }
 }
 

@@ -17,15 +17,43 @@ constexpr int DPP_ROW_BCAST31 = 0x143;
 struct DevWave {
   typedef uint32_t U;
   typedef bool M;
-  unsigned char* lds;  // this wave's LDS window
+  unsigned char* lds;    // this wave's LDS window (substitution table)
+  unsigned char* trace;  // this workgroup's trace slab in global memory
 
-  __device__ __forceinline__ explicit DevWave(unsigned char* l) : lds(l) {}
+  __device__ __forceinline__ DevWave(unsigned char* l, unsigned char* t) : lds(l), trace(t) {}
 
   __device__ __forceinline__ U lane() const { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
   // value of lane-1; lane 0 receives `fill`
   __device__ __forceinline__ U shr1(U x, U fill) const {
     return (U)__builtin_amdgcn_update_dpp((int)fill, (int)x, DPP_WAVE_SHR1, 0xF, 0xF, false);
+  }
+  // max(value of lane-1, unav); lane 0 receives unav (one v_max_u32_dpp with zero fill)
+  __device__ __forceinline__ U shr1_max(U x, U unav) const {
+    U s = (U)__builtin_amdgcn_update_dpp(0, (int)x, DPP_WAVE_SHR1, 0xF, 0xF, true);
+    return s > unav ? s : unav;
+  }
+  __device__ __forceinline__ static U sext_lo(U x) { return (U)(((int32_t)(x << 16)) >> 16); }
+  __device__ __forceinline__ static U sext_hi(U x) { return (U)(((int32_t)x) >> 16); }
+  // 4 packed score words -> 4 trace bytes [type:2][len:6, saturating at 63]
+  template <int IB>
+  __device__ __forceinline__ static U trace_pack4(U b0, U b1, U b2, U b3) {
+    if constexpr (IB == 8) {
+      // low 10 bits of each word = [type:2][len:8]; two words per dword, packed 16-bit min saturates len
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      const U d01 = __builtin_amdgcn_perm(b1, b0, 0x05040100u);   // {b1.lo16, b0.lo16}
+      const U d23 = __builtin_amdgcn_perm(b3, b2, 0x05040100u);
+      const us2 sat = {63, 63};
+      U x01 = d01 & 0x00FF00FFu, x23 = d23 & 0x00FF00FFu;
+      us2 y01 = __builtin_elementwise_min(__builtin_bit_cast(us2, x01), sat);
+      us2 y23 = __builtin_elementwise_min(__builtin_bit_cast(us2, x23), sat);
+      const U e01 = ((d01 >> 2) & 0x00C000C0u) | __builtin_bit_cast(U, y01);
+      const U e23 = ((d23 >> 2) & 0x00C000C0u) | __builtin_bit_cast(U, y23);
+      return __builtin_amdgcn_perm(e23, e01, 0x06040200u);        // byte 0 of each 16-bit half
+    } else {
+      auto one = [](U x) { U len = x & ((1u << IB) - 1u); return (((x >> IB) & 3u) << 6) | (len > 63u ? 63u : len); };
+      return one(b0) | (one(b1) << 8) | (one(b2) << 16) | (one(b3) << 24);
+    }
   }
   __device__ __forceinline__ static U umax(U a, U b) { return a > b ? a : b; }
   __device__ __forceinline__ static U umin(U a, U b) { return a < b ? a : b; }
@@ -60,7 +88,22 @@ struct DevWave {
   __device__ __forceinline__ void lds_w16(U off, U v, M ok) const { if (ok) *reinterpret_cast<uint16_t*>(lds + off) = (uint16_t)v; }
   __device__ __forceinline__ void lds_w32(U off, U v, M ok) const { if (ok) *reinterpret_cast<uint32_t*>(lds + off) = v; }
   __device__ __forceinline__ U lds_ri16(U off) const { return (U)(int32_t)*reinterpret_cast<const int16_t*>(lds + off); }
+  __device__ __forceinline__ U lds_r32(U off) const { return *reinterpret_cast<const uint32_t*>(lds + off); }
   __device__ __forceinline__ U lds_r8(U off, M ok) const { return ok ? (U)lds[off] : 0u; }
+  // trace slab: plain global stores / byte loads; the slab is private to the wave, re-used
+  // for every read it processes and small enough (<= 32 waves/CU x 256 CUs) to live in
+  // L2 / Infinity Cache, so the bytes rarely reach HBM
+  __device__ __forceinline__ void tr_w32(U off, U v, M ok) const { if (ok) *reinterpret_cast<uint32_t*>(trace + off) = v; }
+  // loads for the traceback are agent-scope relaxed (global_load_ubyte sc1): served by L2, never by a stale L1 line
+  __device__ __forceinline__ U tr_r8(U off, M ok) const {
+    return ok ? (U)__hip_atomic_load(trace + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  }
+  // this wave's own stores must be visible to its own loads: same CU, same L1 -> ordering only
+  __device__ __forceinline__ void tr_fence() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
   // order this wave's LDS writes before its later LDS reads (other lanes' data)
   __device__ __forceinline__ void lds_fence() const {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -22,10 +22,9 @@ static int run_one(const uint8_t* ref_codes, int ref_start, int len1, const uint
   a.ref_codes = ref_codes; a.ref_start = ref_start; a.len1 = len1;
   a.read_packed = packed.data(); a.len2 = len2; a.pssm = pssm; a.sg5 = sg5; a.pk = pk;
   a.lds_sub = 0;
-  a.lds_trace = (uint32_t)((len2 * 10 + 15) & ~15);
   a.trace_stride = (uint32_t)((len1 + 3) & ~3);
   a.cols_out = cols;
-  EmuWave w(a.lds_trace + (size_t)len2 * a.trace_stride + 16);
+  EmuWave w((size_t)len2 * 10 + 16, (size_t)len2 * a.trace_stride + 16);
   AlignResult r = WindowAligner<EmuWave, CPL>::run(w, a);
   out5[0] = r.score; out5[1] = r.abc; out5[2] = r.abr; out5[3] = r.aec; out5[4] = (int32_t)r.status;
   return 0;

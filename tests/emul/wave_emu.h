@@ -46,11 +46,29 @@ inline EM operator!(const EM& x) { EM r; for (int i = 0; i < 64; i++) r.a[i] = !
 struct EmuWave {
   typedef EV U;
   typedef EM M;
-  std::vector<unsigned char> lds;
-  explicit EmuWave(size_t lds_bytes) : lds(lds_bytes + 64, 0) {}
+  std::vector<unsigned char> lds, trace;
+  EmuWave(size_t lds_bytes, size_t trace_bytes) : lds(lds_bytes + 64, 0), trace(trace_bytes + 64, 0) {}
 
   U lane() const { EV r; for (int i = 0; i < 64; i++) r.a[i] = (uint32_t)i; return r; }
   U shr1(const U& x, const U& fill) const { EV r; r.a[0] = fill.a[0]; for (int i = 1; i < 64; i++) r.a[i] = x.a[i - 1]; return r; }
+  U shr1_max(const U& x, const U& unav) const { EV r; r.a[0] = unav.a[0]; for (int i = 1; i < 64; i++) r.a[i] = x.a[i - 1] > unav.a[i] ? x.a[i - 1] : unav.a[i]; return r; }
+  static U sext_lo(const U& x) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (uint32_t)(int32_t)(int16_t)(x.a[i] & 0xFFFFu); return r; }
+  static U sext_hi(const U& x) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (uint32_t)(int32_t)(int16_t)(x.a[i] >> 16); return r; }
+  // 4 packed score words -> 4 trace bytes [type:2][len:6, saturating at 63]
+  template <int IB>
+  static U trace_pack4(const U& b0, const U& b1, const U& b2, const U& b3) {
+    EV r;
+    const U* b[4] = {&b0, &b1, &b2, &b3};
+    for (int i = 0; i < 64; i++) {
+      uint32_t w = 0;
+      for (int k = 0; k < 4; k++) {
+        uint32_t x = b[k]->a[i], len = x & ((1u << IB) - 1u), ty = (x >> IB) & 3u;
+        w |= ((ty << 6) | (len > 63u ? 63u : len)) << (8 * k);
+      }
+      r.a[i] = w;
+    }
+    return r;
+  }
   static U umax(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] > y.a[i] ? x.a[i] : y.a[i]; return r; }
   static U umin(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] < y.a[i] ? x.a[i] : y.a[i]; return r; }
   static U umax3(const U& x, const U& y, const U& z) { return umax(umax(x, y), z); }
@@ -69,8 +87,12 @@ struct EmuWave {
   void lds_w16(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { uint16_t x = (uint16_t)v.a[i]; memcpy(&lds.at(off.a[i]), &x, 2); } }
   void lds_w32(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { lds.at(off.a[i] + 3); memcpy(&lds[off.a[i]], &v.a[i], 4); } }
   U lds_ri16(const U& off) const { EV r; for (int i = 0; i < 64; i++) { int16_t x; lds.at(off.a[i] + 1); memcpy(&x, &lds[off.a[i]], 2); r.a[i] = (uint32_t)(int32_t)x; } return r; }
+  U lds_r32(const U& off) const { EV r; for (int i = 0; i < 64; i++) { lds.at(off.a[i] + 3); memcpy(&r.a[i], &lds[off.a[i]], 4); } return r; }
   U lds_r8(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? lds.at(off.a[i]) : 0u; return r; }
   void lds_fence() const {}
+  void tr_w32(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { trace.at(off.a[i] + 3); memcpy(&trace[off.a[i]], &v.a[i], 4); } }
+  U tr_r8(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? trace.at(off.a[i]) : 0u; return r; }
+  void tr_fence() const {}
 };
 
 }  // namespace mia
