@@ -122,17 +122,11 @@ def main():
         score, _, _ = hip.alignments()
         slot_base = 0
         if world > 1:
+            from mia_amd import dist as mdist
             # the score-cut regression runs over ALL reads in fsdb order (src/fsdb.c:269-383)
-            t = torch.from_numpy(score).cuda()
-            g = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(g, t)
-            all_scores = torch.cat(g).cpu().numpy()
-            all_lens = np.tile(lens, world)
-            slope, intercept = hip.score_cut(all_scores, all_lens)
-            nrec = torch.tensor([hip.num_records()], dtype=torch.int64, device="cuda")
-            gr = [torch.empty_like(nrec) for _ in range(world)]
-            dist.all_gather(gr, nrec)
-            slot_base = int(sum(int(x.item()) for x in gr[:rank]))
+            all_scores = mdist.all_gather_concat(torch.from_numpy(score).cuda()).cpu().numpy()
+            slope, intercept = hip.score_cut(all_scores, np.tile(lens, world))
+            slot_base = mdist.exclusive_rank_sum(hip.num_records(), "cuda")
         else:
             slope, intercept = hip.score_cut(score, lens)
         if slope <= 0:
@@ -141,22 +135,11 @@ def main():
         hip.tally()
         if world > 1:
             pt, nt, pg, ng = hip.tally_buffers()
-            tt = torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda")
-            tg = torch.as_tensor(DevArray(pg, ng, "<i4"), device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            mdist.allreduce_tallies(torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda"),
+                                    torch.as_tensor(DevArray(pg, ng, "<i4"), device="cuda"))
             pe, ne = hip.ins_events()
-            cnt = torch.tensor([ne], dtype=torch.int64, device="cuda")
-            gc = [torch.empty_like(cnt) for _ in range(world)]
-            dist.all_gather(gc, cnt)
-            counts = [int(x.item()) for x in gc]
-            mx = max(max(counts), 1)
-            mine = torch.zeros(mx, dtype=torch.int64, device="cuda")
-            if ne:
-                mine[:ne] = torch.as_tensor(DevArray(pe, ne, "<i8"), device="cuda")
-            ge = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(ge, mine)
-            allev = torch.cat([ge[r][:counts[r]] for r in range(world)]).contiguous()
+            mine = torch.as_tensor(DevArray(pe, ne, "<i8"), device="cuda") if ne else torch.zeros(0, dtype=torch.int64, device="cuda")
+            allev = mdist.all_gather_ragged(mine)
             torch.cuda.synchronize()
             hip.set_ins_events(allev.data_ptr() if allev.numel() else 0, int(allev.numel()))
         return hip.consensus(1)

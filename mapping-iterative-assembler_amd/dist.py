@@ -1,0 +1,57 @@
+"""Host-side collectives of the sharded iteration, device agnostic:
+the same functions run on CUDA tensors over RCCL (bench.py, backend "nccl") and on CPU
+tensors over gloo (tests/test_dist_gloo.py).
+
+Reads are sharded in contiguous fsdb blocks, rank r owning block r, so "concatenate in
+rank order" == fsdb order."""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def all_gather_concat(t):
+    """Concatenate equally sized 1-D tensors of all ranks in rank (= fsdb) order: the
+    global score array the reference's score-cut regression runs over (src/fsdb.c:269-383)."""
+    if world() == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(world())]
+    dist.all_gather(parts, t)
+    return torch.cat(parts)
+
+
+def exclusive_rank_sum(value, device):
+    """Sum of `value` over all lower ranks: the AlnSeq slot index of this shard's first
+    record (records are numbered in merge order across the whole fsdb, src/map_align.c:882)."""
+    if world() == 1:
+        return 0
+    v = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    parts = [torch.empty_like(v) for _ in range(world())]
+    dist.all_gather(parts, v)
+    return int(sum(int(p.item()) for p in parts[: dist.get_rank()]))
+
+
+def allreduce_tallies(tally, gaps):
+    """In place: integer column tallies add up, ref->gaps is a maximum (src/mia.c:486-504)."""
+    if world() == 1:
+        return
+    dist.all_reduce(tally, op=dist.ReduceOp.SUM)
+    dist.all_reduce(gaps, op=dist.ReduceOp.MAX)
+
+
+def all_gather_ragged(t):
+    """Concatenate variable-length 1-D int64 tensors (insert events) of all ranks."""
+    if world() == 1:
+        return t
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    counts = [torch.empty_like(n) for _ in range(world())]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    mx = max(max(counts), 1)
+    mine = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    mine[: t.numel()] = t
+    parts = [torch.empty_like(mine) for _ in range(world())]
+    dist.all_gather(parts, mine)
+    return torch.cat([parts[r][: counts[r]] for r in range(world())]).contiguous()

@@ -1,0 +1,77 @@
+"""world_size-2 gloo test of the sharded iteration's host logic: reads
+sharded in contiguous fsdb blocks, column tallies all-reduced (sum), gaps (max), scores
+gathered in fsdb order.  The per-shard compute is done by the oracle here (no GPU in
+this container); the collectives are mapping-iterative-assembler_amd/dist.py, the same
+code bench.py runs over RCCL."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mia_amd
+from mia_amd import dist as mdist
+import oracle_ctypes as oc
+from mia_flow import oracle_after_pass1, fsdb_arrays
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+oracle = oc.load(os.path.join(ROOT, "oracle", "_build", "libmia_oracle.so"))
+
+def shard_file(path, lo, hi, out):
+    recs = open(path).read().split(">")[1:]
+    open(out, "w").write("".join(">" + r for r in recs[lo:hi]))
+    return len(recs)
+
+src = os.path.join(GOLDEN, "d150.fa")
+n_total = len(open(src).read().split(">")) - 1
+per = (n_total + world - 1) // world
+mine = os.path.join(TMP, f"shard{rank}.fa")
+shard_file(src, rank * per, min(n_total, (rank + 1) * per), mine)
+
+def run(reads):
+    st, o, anc = oracle_after_pass1(oracle, "mt311.fa", reads, True, 12, "ancient.submat.txt", hard_cut=17500)
+    L = oracle.ora_ref_len(st); ref = oracle.ora_ref_seq(st)[:L]
+    oracle.ora_iterate(st, ref, 1)
+    t = (C.c_int * (L * 10))(); oracle.ora_column_tallies(st, t)
+    gaps = np.ctypeslib.as_array(oracle.ora_ref_gaps(st), shape=(L,)).copy()
+    fs = fsdb_arrays(oracle, st)
+    return np.ctypeslib.as_array(t).reshape(L, 10).copy(), gaps, fs, oracle.ora_num_culled(st)
+
+tally, gaps, fs, nrec = run(mine)
+tt, tg = torch.from_numpy(tally.astype(np.int32)), torch.from_numpy(gaps.astype(np.int32))
+mdist.allreduce_tallies(tt, tg)
+scores = mdist.all_gather_concat(torch.from_numpy(np.pad(fs["score"], (0, per - fs["n"]), constant_values=-1)))
+base = mdist.exclusive_rank_sum(nrec, "cpu")
+ev = mdist.all_gather_ragged(torch.arange(rank * 100, rank * 100 + 3 + rank, dtype=torch.int64))
+if rank == 0:
+    full_t, full_g, full_fs, full_nrec = run("d150.fa")
+    assert np.array_equal(tt.numpy(), full_t), "summed shard tallies != unsharded tallies"
+    assert np.array_equal(tg.numpy(), full_g), "max of shard gaps != unsharded gaps"
+    got = scores.numpy(); got = got[got >= 0]
+    assert np.array_equal(got, full_fs["score"]), "gathered scores are not in fsdb order"
+    assert base == 0
+    assert ev.tolist() == [0, 1, 2, 100, 101, 102, 103]
+    print("DIST_OK")
+else:
+    assert base > 0
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharded_tallies(oracle_build, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\nGOLDEN = {GOLDEN!r}\nTMP = {str(tmp_path)!r}\n" + WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert "DIST_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
