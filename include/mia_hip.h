@@ -63,6 +63,25 @@ int mia_hip_set_pssm(mia_hip_ctx *ctx, const int32_t *fwd, const int32_t *rc);
 int mia_hip_upload_reads(mia_hip_ctx *ctx, int64_t n_reads, const char *bases, const int64_t *offsets,
                          const uint8_t *rc, const uint8_t *strand_known, const int32_t *as, const int32_t *ae);
 
+/* ---- pass 1 ------------------------------------------------------------ */
+
+#define MIA_HIP_P1_PASSED 1        /* new_kmer_filter returned non-zero (always set without -k) */
+#define MIA_HIP_P1_KEPT 2          /* score >= FIRST_ROUND_SCORE_CUTOFF: the read enters the fsdb (src/mia.c:1614) */
+#define MIA_HIP_P1_STRAND_KNOWN 4  /* score > cutoff (src/mia.c:1653) */
+#define MIA_HIP_P1_SPLIT 8         /* the alignment crosses the origin: front + back AlnSeq (src/mia.c:1619) */
+
+/* The body of main()'s read loop, src/mia_main.c:759-805, for a batch of reads:
+ *   int new_kmer_filter(FragSeqP, KPL*, KPL*, int, AlignmentP, AlignmentP)      -- src/kmer.h:83
+ *   int sg_align(MapAlignmentP, FragSeqP, FSDB, AlignmentP, AlignmentP, ...)    -- src/mia.h:212-215
+ * ref: reference sequence as read from the FASTA file (case kept: -M soft masking looks at it,
+ * populate_kpa runs before make_ref_upper, src/mia_main.c:659-676); circular as -c; kmer_len as -k
+ * (-1 = no filter); soft_mask as -M.  bases/offsets: reads as sequenced (upper-cased, <= 256).
+ * Uses the forward PSSM of mia_hip_set_pssm for both strands (src/mia_main.c:788-789).
+ * Outputs, n_reads each: fs->score, fs->rc, fs->as, fs->ae and MIA_HIP_P1_* flags. */
+int mia_hip_pass1(mia_hip_ctx *ctx, const char *ref, int32_t ref_len, int circular, int kmer_len, int soft_mask,
+                  int64_t n_reads, const char *bases, const int64_t *offsets, int32_t *score, uint8_t *rc, int32_t *as,
+                  int32_t *ae, uint8_t *flags);
+
 /* ---- the per-iteration path ------------------------------------------- */
 
 /* void reiterate_assembly(char* new_ref_seq, int iter_num, MapAlignmentP, FSDB,

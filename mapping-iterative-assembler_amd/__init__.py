@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmia_hip.so")
 PSSM_WORDS = 31 * 5 * 5
 TALLY_WORDS = 12
 COL_INSERT, COL_CLIP = -1, -2
+P1_PASSED, P1_KEPT, P1_STRAND_KNOWN, P1_SPLIT = 1, 2, 4, 8
 
 
 class MiaHipError(RuntimeError):
@@ -36,6 +37,7 @@ def _load():
     lib.mia_hip_sync.argtypes = [vp]
     lib.mia_hip_set_pssm.argtypes = [vp, vp, vp]
     lib.mia_hip_upload_reads.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    lib.mia_hip_pass1.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     lib.mia_hip_realign.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int]
     lib.mia_hip_get_alignments.argtypes = [vp, vp, vp, vp]
     lib.mia_hip_get_scripts.argtypes = [vp, vp, C.c_int32, vp]
@@ -68,7 +70,7 @@ def lib():
 def exported_symbols():
     """Every entry point include/mia_hip.h declares (used by the CPU-side ABI test)."""
     return ["mia_hip_create", "mia_hip_destroy", "mia_hip_last_error", "mia_hip_sync", "mia_hip_set_pssm",
-            "mia_hip_upload_reads", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
+            "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_kernel_time"]
@@ -157,6 +159,20 @@ class MiaHip:
         self.lens = (offsets[1:] - offsets[:-1]).astype(np.int32)
         self.max_len = int(self.lens.max()) if self.n else 0
         self._chk(self._l.mia_hip_upload_reads(self._h, self.n, _ptr(bases), _ptr(offsets), _ptr(rc), _ptr(sk), _ptr(as_), _ptr(ae)))
+
+    def pass1(self, ref, circular, bases, offsets, kmer_len=-1, soft_mask=False):
+        """new_kmer_filter + sg_align for a batch of reads (as sequenced, upper case).
+        Returns score, rc, as, ae, flags (P1_* bits)."""
+        if isinstance(ref, str):
+            ref = ref.encode()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        score = np.zeros(n, np.int32); as_ = np.zeros(n, np.int32); ae = np.zeros(n, np.int32)
+        rc = np.zeros(n, np.uint8); flags = np.zeros(n, np.uint8)
+        self._chk(self._l.mia_hip_pass1(self._h, ref, len(ref), 1 if circular else 0, kmer_len, 1 if soft_mask else 0, n,
+                                        _ptr(bases), _ptr(offsets), _ptr(score), _ptr(rc), _ptr(as_), _ptr(ae), _ptr(flags)))
+        return score, rc, as_, ae, flags
 
     def realign(self, ref, circular):
         if isinstance(ref, str):

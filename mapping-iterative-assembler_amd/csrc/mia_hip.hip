@@ -11,6 +11,7 @@
 #include "../../include/mia_hip.h"
 #include "mia_consensus_kernels.h"
 #include "mia_kernels.h"
+#include "mia_pass1_kernels.h"
 
 using namespace mia;
 
@@ -21,6 +22,7 @@ struct mia_hip_ctx {
   // PSSMs (fwd, rc)
   int32_t* d_pssm = nullptr;
   int max_abs = 0;
+  int max_pos = 0;   // largest positive PSSM entry: bounds any score by rows * max_pos
   bool have_pssm = false;
   PackSet packs;
   // reads
@@ -136,6 +138,8 @@ extern "C" int mia_hip_set_pssm(mia_hip_ctx* ctx, const int32_t* fwd, const int3
   }
   if (m > 32000) { ctx->err = "PSSM entries beyond +-32000 do not fit the int16 substitution table"; return MIA_HIP_ERR_RANGE; }
   ctx->max_abs = m;
+  ctx->max_pos = 0;
+  for (int i = 0; i < PSSM_WORDS; i++) { if (fwd[i] > ctx->max_pos) ctx->max_pos = fwd[i]; if (rc[i] > ctx->max_pos) ctx->max_pos = rc[i]; }
   const int cpls[N_CPL] = {4, 8, 12};
   for (int c = 0; c < N_CPL; c++) ctx->packs.ok[c] = make_pack_params(64 * cpls[c], m, &ctx->packs.p[c]) ? 1 : 0;
   HIPCHK(hipMemcpyAsync(ctx->d_pssm, fwd, PSSM_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -610,5 +614,143 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   }
   out[o] = 0;
   if (out_len) *out_len = o;
+  return MIA_HIP_OK;
+}
+
+// ---- pass 1 ----------------------------------------------------------------------------
+static char revcom_char_host(char b) {   // src/map_align.c:418-432
+  static const char tbl[] = "TVGH\0\0CD\0\0M\0KN\0\0\0YSAABWXR\0";
+  char r = 0;
+  if (b == '-') return '-';
+  if (b >= 'A' && b <= 'Z') r = tbl[b - 'A'];
+  else if (b >= 'a' && b <= 'z') r = (char)(tbl[b - 'a'] + 32);
+  return r ? r : 'N';
+}
+
+// populate_kpa + add_kmer (src/kmer.c:65-107,153-168) as a CSR table: ascending positions, at most 128 per k-mer
+static void build_kmer_csr(const std::string& seq, int k, int soft_mask, std::vector<int32_t>& off, std::vector<int32_t>& pos) {
+  const size_t nk = (size_t)1 << (2 * k);
+  off.assign(nk + 1, 0);
+  const int n = (int)seq.size();
+  std::vector<int64_t> inx((size_t)(n > 0 ? n : 1), -1);
+  for (int i = 0; i + k <= n; i++) {
+    bool ok = true;
+    uint64_t v = 0;
+    for (int t = 0; t < k && ok; t++) {
+      char c = seq[i + t];
+      if (soft_mask && (c >= 'a' && c <= 'z')) ok = false;
+      switch (c & ~32) { case 'A': v = v << 2; break; case 'C': v = (v << 2) | 1; break; case 'G': v = (v << 2) | 2; break;
+                         case 'T': v = (v << 2) | 3; break; default: ok = false; }
+    }
+    if (!ok) continue;
+    if (off[v + 1] < MAX_KMER_POS) { off[v + 1]++; inx[i] = (int64_t)v; }   // further positions are silently dropped (:75-77)
+  }
+  for (size_t v = 0; v < nk; v++) off[v + 1] += off[v];
+  pos.assign((size_t)off[nk] + 1, 0);
+  std::vector<int32_t> cur(off.begin(), off.end() - 1);
+  for (int i = 0; i < n; i++) if (inx[i] >= 0) pos[cur[inx[i]]++] = i;
+}
+
+extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len, int circular, int kmer_len, int soft_mask,
+                             int64_t n, const char* bases, const int64_t* offsets, int32_t* score, uint8_t* rc, int32_t* as,
+                             int32_t* ae, uint8_t* flags) {
+  if (!ctx || !ref || ref_len <= 0 || n < 0 || (n > 0 && (!bases || !offsets || !score || !rc || !as || !ae || !flags))) return MIA_HIP_ERR_ARG;
+  if (!ctx->have_pssm) { ctx->err = "set_pssm must precede pass1"; return MIA_HIP_ERR_STATE; }
+  if (kmer_len > 14) { ctx->err = "Cannot use kmer length greater than 14"; return MIA_HIP_ERR_ARG; }   // MAX_KMER_LEN
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n == 0) return MIA_HIP_OK;
+  PackParams pk;
+  if (!make_pack_params(1024, ctx->max_abs, &pk)) { ctx->err = "PSSM too large for the packed pass-1 kernel"; return MIA_HIP_ERR_RANGE; }
+  // dropping candidates further left than 768 columns is exact only if they can never beat a new start
+  // (a score is at most rows * max positive entry; a new start costs P(rows+1); a gap of >= 767 columns costs P(767))
+  if ((int64_t)MAX_READ * ctx->max_pos + (GOP + GEP * (MAX_READ + 1)) >= (int64_t)(GOP + GEP * (P1_REL - 1))) {
+    ctx->err = "PSSM too large for the pass-1 candidate horizon"; return MIA_HIP_ERR_RANGE;
+  }
+  // reference strands: make_reverse_complement, add_ref_wrap, (k-mer tables), make_ref_upper -- src/mia_main.c:637-676
+  const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl, len1 = circular ? wrap : L;
+  std::string fw(ref, ref + L), rcs((size_t)L, 'N');
+  for (int i = 0; i < L; i++) rcs[i] = revcom_char_host(ref[L - 1 - i]);
+  fw += fw.substr(0, wl);
+  rcs += rcs.substr(0, wl);
+  std::vector<uint8_t> cf((size_t)wrap + 64, 4), cr((size_t)wrap + 64, 4);
+  for (int i = 0; i < wrap; i++) { cf[i] = base_code((char)toupper((unsigned char)fw[i])); cr[i] = base_code((char)toupper((unsigned char)rcs[i])); }
+  uint8_t *d_cf = nullptr, *d_cr = nullptr;
+  int32_t *d_off[2] = {nullptr, nullptr}, *d_pos[2] = {nullptr, nullptr};
+  int rcx = dev_alloc(ctx, &d_cf, cf.size()) | dev_alloc(ctx, &d_cr, cr.size());
+  KmerIndex kx{};
+  kx.k = kmer_len > 0 ? kmer_len : -1;
+  if (kx.k > 0) {
+    for (int s = 0; s < 2; s++) {
+      std::vector<int32_t> off, pos;
+      build_kmer_csr(s ? rcs : fw, kx.k, soft_mask, off, pos);
+      rcx |= dev_alloc(ctx, &d_off[s], off.size()) | dev_alloc(ctx, &d_pos[s], pos.size());
+      if (rcx) break;
+      HIPCHK(hipMemcpy(d_off[s], off.data(), off.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_pos[s], pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
+      kx.off[s] = d_off[s];
+      kx.pos[s] = d_pos[s];
+    }
+  }
+  // reads (as sequenced)
+  std::vector<uint32_t> roff((size_t)n);
+  std::vector<uint16_t> len((size_t)n);
+  uint64_t total = 0;
+  int max_len = 1;
+  for (int64_t i = 0; i < n; i++) {
+    int64_t l = offsets[i + 1] - offsets[i];
+    if (l < 1 || l > MIA_HIP_MAX_READ) { ctx->err = "read length outside 1..256"; return MIA_HIP_ERR_ARG; }
+    roff[i] = (uint32_t)total; len[i] = (uint16_t)l;
+    if (l > max_len) max_len = (int)l;
+    total += (uint64_t)(((l + 1) / 2 + 3) & ~3);
+    if (total >= ((uint64_t)1 << 32)) { ctx->err = "packed read store exceeds 4 GiB per call"; return MIA_HIP_ERR_ARG; }
+  }
+  std::vector<uint8_t> packed((size_t)total + 8, 0);
+  for (int64_t i = 0; i < n; i++) {
+    const char* sq = bases + offsets[i];
+    uint8_t* d = packed.data() + roff[i];
+    for (int k = 0; k < len[i]; k++) d[k >> 1] |= (uint8_t)(base_code(sq[k]) << ((k & 1) * 4));
+  }
+  uint8_t *d_packed = nullptr, *d_rc = nullptr, *d_flags = nullptr;
+  uint32_t *d_roff = nullptr, *d_status = nullptr;
+  uint16_t* d_len = nullptr;
+  int32_t *d_score = nullptr, *d_as = nullptr, *d_ae = nullptr;
+  rcx |= dev_alloc(ctx, &d_packed, packed.size()) | dev_alloc(ctx, &d_roff, (size_t)n) | dev_alloc(ctx, &d_len, (size_t)n) |
+         dev_alloc(ctx, &d_rc, (size_t)n) | dev_alloc(ctx, &d_flags, (size_t)n) | dev_alloc(ctx, &d_status, (size_t)n) |
+         dev_alloc(ctx, &d_score, (size_t)n) | dev_alloc(ctx, &d_as, (size_t)n) | dev_alloc(ctx, &d_ae, (size_t)n);
+  // persistent grid; LDS: sub table + 5 carry arrays + 2 column masks
+  const int nch = (len1 + P1_CH - 1) / P1_CH, mask_words = nch * (P1_CH / 32) + 4;
+  const int lds = MAX_READ * 10 + 5 * MAX_READ * 4 + 2 * mask_words * 4;
+  const int rows_p = (max_len + 3) & ~3;
+  const int64_t trace_bytes = (int64_t)MAX_READ * P1_CH * 2, ckpt_words = (int64_t)2 * nch * 5 * rows_p;
+  int waves_cu = (160 * 1024) / ((lds + 511) & ~511);
+  if (waves_cu > 16) waves_cu = 16;
+  if (waves_cu < 1) { ctx->err = "reference too long for the pass-1 LDS masks"; return MIA_HIP_ERR_RANGE; }
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+  int64_t grid = (int64_t)prop.multiProcessorCount * waves_cu;
+  if (grid > n) grid = n;
+  unsigned char* d_trace = nullptr;
+  uint32_t* d_ckpt = nullptr;
+  rcx |= dev_alloc(ctx, &d_trace, (size_t)(trace_bytes * grid)) | dev_alloc(ctx, &d_ckpt, (size_t)(ckpt_words * grid));
+  void* tmp[] = {d_cf, d_cr, d_off[0], d_off[1], d_pos[0], d_pos[1], d_packed, d_roff, d_len, d_rc, d_flags, d_status, d_score, d_as, d_ae, d_trace, d_ckpt};
+  auto cleanup = [&]() { for (void* p : tmp) if (p) (void)hipFree(p); };
+  if (rcx) { cleanup(); return MIA_HIP_ERR_NOMEM; }
+  hipError_t e = hipSuccess;
+  auto cp = [&](void* d, const void* h, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
+  cp(d_cf, cf.data(), cf.size()); cp(d_cr, cr.data(), cr.size());
+  cp(d_packed, packed.data(), packed.size()); cp(d_roff, roff.data(), (size_t)n * 4); cp(d_len, len.data(), (size_t)n * 2);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) {
+    Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
+    hipLaunchKernelGGL(k_pass1, dim3((unsigned)grid), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
+                       trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words);
+    e = hipGetLastError();
+  }
+  auto back = [&](void* h, const void* d, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, ctx->stream); };
+  back(score, d_score, (size_t)n * 4); back(as, d_as, (size_t)n * 4); back(ae, d_ae, (size_t)n * 4);
+  back(rc, d_rc, (size_t)n); back(flags, d_flags, (size_t)n);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess) { ctx->err = std::string("pass1: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   return MIA_HIP_OK;
 }

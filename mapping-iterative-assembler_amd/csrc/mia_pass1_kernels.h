@@ -1,0 +1,144 @@
+// mia_pass1_kernels.h -- pass 1 on gfx950: the body of the read loop of main()
+// (/root/reference/src/mia_main.c:759-805): new_kmer_filter (src/kmer.c:239-331)
+// followed by sg_align (src/mia.c:1500-1665), one read per wavefront, persistent grid.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mia_layout.h"
+#include "pass1_body.h"
+#include "wave_dev.h"
+
+namespace mia {
+
+constexpr int MAX_KMER_POS = 128;   // src/params.h:75
+constexpr int KMER_SATURATE = 128;  // src/params.h:77
+constexpr int MASK_BUFFER = 10;     // src/params.h:78
+
+constexpr uint8_t P1_PASSED = 1, P1_KEPT = 2, P1_STRAND_KNOWN = 4, P1_SPLIT = 8;
+
+struct Pass1Reads {
+  int64_t n;
+  const uint8_t* packed;   // 4-bit codes, reads as sequenced
+  const uint32_t* roff;
+  const uint16_t* len;
+  int32_t* score;
+  int32_t* as;
+  int32_t* ae;
+  uint8_t* rc;
+  uint8_t* flags;
+  uint32_t* status;
+};
+
+struct KmerIndex {          // CSR over 4^k k-mers: positions (ascending, at most 128 each) on the wrapped reference
+  const int32_t* off[2];    // [0] forward strand, [1] reverse-complement strand
+  const int32_t* pos[2];
+  int32_t k;                // < 0: no filter
+};
+
+__device__ __forceinline__ void mask_or_range(uint32_t* m, int lo, int hi) {   // set bits lo..hi (inclusive) of an LDS bit mask
+  for (int w = lo >> 5; w <= (hi >> 5); w++) {
+    const int a = (w == (lo >> 5)) ? (lo & 31) : 0, b = (w == (hi >> 5)) ? (hi & 31) : 31;
+    const uint32_t bits = (b == 31 ? 0xFFFFFFFFu : ((1u << (b + 1)) - 1u)) & ~((1u << a) - 1u);
+    atomicOr(&m[w], bits);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_pass1(Pass1Reads rs, const uint8_t* ref_fw, const uint8_t* ref_rc, int32_t len1, int32_t L,
+                                               const int32_t* pssm_fwd, PackParams pk, KmerIndex kx, unsigned char* trace_slabs,
+                                               int64_t trace_bytes, uint32_t* ckpt_slabs, int64_t ckpt_words, int32_t rows_p,
+                                               int32_t mask_words) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * trace_bytes);
+  const int lane = (int)wave.lane();
+  Pass1Args a;
+  a.ref_codes[0] = ref_fw;
+  a.ref_codes[1] = ref_rc;
+  a.len1 = len1;
+  a.pssm = pssm_fwd;
+  a.pk = pk;
+  a.lds_sub = 0;
+  a.lds_carry = MAX_READ * 10;
+  a.lds_mask[0] = a.lds_carry + 5 * MAX_READ * 4;
+  a.lds_mask[1] = a.lds_mask[0] + (uint32_t)mask_words * 4;
+  a.masked = kx.k > 0;
+  a.ckpt = ckpt_slabs + (int64_t)blockIdx.x * ckpt_words;
+  a.rows_p = rows_p;
+  uint32_t* mask[2] = {reinterpret_cast<uint32_t*>(lds_raw + a.lds_mask[0]), reinterpret_cast<uint32_t*>(lds_raw + a.lds_mask[1])};
+
+  for (int64_t i = blockIdx.x; i < rs.n; i += gridDim.x) {
+    const int len2 = rs.len[i];
+    const uint8_t* rp = rs.packed + rs.roff[i];
+    bool pass = true;
+    if (kx.k > 0) {
+      // ---- new_kmer_filter (src/kmer.c:239-331)
+      for (int w = lane; w < 2 * mask_words; w += 64) mask[0][w] = 0;
+      wave.lds_fence();
+      int nf = 0, nr = 0;
+      for (int fp0 = 0; fp0 + kx.k <= len2; fp0 += 64) {
+        const int fp = fp0 + lane;
+        bool ok = fp + kx.k <= len2;
+        uint32_t inx = 0;
+        if (ok)
+          for (int t = 0; t < kx.k; t++) {
+            const int c = (rp[(fp + t) >> 1] >> (((fp + t) & 1) * 4)) & 15;
+            if (c > 3) { ok = false; break; }          // kmer2inx: anything but ACGT invalidates the k-mer (src/kmer.c:28-44)
+            inx = (inx << 2) | (uint32_t)c;
+          }
+        int cf = 0, cr = 0;
+        if (ok) {
+          const int f0 = kx.off[0][inx], f1 = kx.off[0][inx + 1], r0 = kx.off[1][inx], r1 = kx.off[1][inx + 1];
+          cf = f1 - f0; cr = r1 - r0;
+          for (int t = f0; t < f1; t++) {              // src/kmer.c:287-298
+            const int p = kx.pos[0][t];
+            int lo = p - fp - MASK_BUFFER, hi = p + (len2 - fp) + MASK_BUFFER;
+            if (lo < 0) lo = 0;
+            if (hi >= len1) hi = len1 - 1;
+            if (hi >= lo) mask_or_range(mask[0], lo, hi);
+          }
+          for (int t = r0; t < r1; t++) {              // src/kmer.c:311-323 (one column less than forward)
+            const int p = kx.pos[1][t];
+            int lo = p - fp - MASK_BUFFER, hi = p + len2 - fp - 1 + MASK_BUFFER;
+            if (lo < 0) lo = 0;
+            if (hi >= len1) hi = len1 - 1;
+            if (hi >= lo) mask_or_range(mask[1], lo, hi);
+          }
+        }
+        for (int o = 32; o > 0; o >>= 1) { cf += __shfl_xor(cf, o); cr += __shfl_xor(cr, o); }
+        nf += cf; nr += cr;
+      }
+      wave.lds_fence();
+      // >= 128 hits on a strand unmask it completely; the running count only grows, so the final count decides (src/kmer.c:283-285)
+      if (nf >= KMER_SATURATE) for (int w = lane; w < mask_words; w += 64) mask[0][w] = 0xFFFFFFFFu;
+      if (nr >= KMER_SATURATE) for (int w = lane; w < mask_words; w += 64) mask[1][w] = 0xFFFFFFFFu;
+      wave.lds_fence();
+      pass = (len2 >= kx.k) && (nf + nr) > 0;
+    }
+    if (!pass) {
+      if (lane == 0) { rs.flags[i] = 0; rs.score[i] = 0; rs.as[i] = 0; rs.ae[i] = 0; rs.rc[i] = 0; rs.status[i] = ST_SKIPPED; }
+      continue;
+    }
+    a.read_packed = rp;
+    a.len2 = len2;
+    Pass1Result r = Pass1Aligner<DevWave>::run(wave, a);
+    if (lane == 0) {
+      // sg_align, src/mia.c:1568-1610,1614,1619,1653
+      int start, end, as, ae;
+      if (r.strand) {
+        start = L - (r.aec % L) - 1;   // c2rcc (src/mia.c:26-30)
+        end = L - (r.abc % L) - 1;
+      } else { start = r.abc; end = r.aec; }
+      as = start; ae = end;
+      if (as > ae) ae = L + as;        // sic
+      if (end > L) end -= L;
+      uint8_t fl = P1_PASSED;
+      if (r.score >= 2000) fl |= P1_KEPT;
+      if (r.score > 2000) fl |= P1_STRAND_KNOWN;
+      if (start > end) fl |= P1_SPLIT;
+      rs.flags[i] = fl; rs.score[i] = r.score; rs.as[i] = as; rs.ae[i] = ae; rs.rc[i] = (uint8_t)r.strand; rs.status[i] = r.status;
+    }
+    wave.lds_fence();
+  }
+}
+
+}  // namespace mia

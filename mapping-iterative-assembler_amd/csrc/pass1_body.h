@@ -1,0 +1,343 @@
+// pass1_body.h -- pass 1 of MIA for ONE read on ONE wavefront: semi-global DP of the
+// read against the WHOLE wrapped reference on both strands, with the k-mer column
+// masks, strand choice and traceback -- sg_align of the reference
+// (/root/reference/src/mia.c:1500-1599, dyn_prog :740-981 with align_mask,
+// max_sg_score :1278-1302, find_align_begin :612-637).  Same policy scheme as
+// align_body.h: compiled for gfx950 (DevWave) and, for tests, for the CPU emulation.
+//
+// The reference fills a len2 x wrap matrix per strand (13.5 MB for mt311) and walks it
+// back.  Here the columns are swept in chunks of 256 (lane l owns 4 columns, as in the
+// window kernel) and only five words per row cross a chunk boundary:
+//     D  biased score of the chunk's last column (diagonal input of the next chunk)
+//     R  best_gap_row state of that column
+//     U0,U1  keys of its last two columns (the "k <= c-2" shift of best_gap_col)
+//     E  running best_gap_col key over everything further left
+// Phase A sweeps all chunks without a trace, records (best, first arg-max) of the last
+// row and checkpoints the five carry arrays of every chunk in global memory.  Phase B
+// picks the strand (forward only if strictly better, :1549).  Phase C recomputes just
+// the chunks the optimal path visits (1-3) from their checkpoints, now with a 16-bit
+// trace, and follows the path with the ballot walk.  Every cell value is identical to
+// the reference's; nothing is approximated.
+//
+// Masked columns (align_mask == 0, k-mer filter) hold HIM = INT_MIN/2 in the reference.
+// Anything derived from HIM loses against "start a new alignment" (>= -52 400), so such
+// cells are simply absent here: biased score 0, keys UNAV.  A column k is offered to
+// best_gap_col only while column k+2 is processed (src/mia.c:838-843), i.e. only if
+// mask[k+2] -- the `qen` flag.  Candidates further left than 768 columns can never beat
+// a new start (P(767) > len2*max_sub + P(len2+1), checked by the host) and are dropped,
+// which keeps column indices relative to the chunk in a 10-bit field.
+#pragma once
+#include "mia_layout.h"
+
+namespace mia {
+
+constexpr int P1_CH = 256;        // columns per chunk
+constexpr int P1_REL = 768;       // index offset: keys remember candidates up to 768 columns left of the chunk
+constexpr int P1_IB = 10, P1_SH = 12;
+constexpr uint32_t P1_IDXM = 1023u;
+
+struct Pass1Args {               // wave-uniform
+  const uint8_t* ref_codes[2];   // [0] forward wrapped reference, [1] reverse complement, wrapped   [global]
+  int32_t len1;                  // columns (wrap_seq_len, or seq_len when linear)
+  const uint8_t* read_packed;    // 4-bit codes                                                     [global]
+  int32_t len2;
+  const int32_t* pssm;           // ancsubmat for BOTH strands in pass 1 (src/mia_main.c:788-789)    [global]
+  PackParams pk;                 // from make_pack_params(1024, ...): ib = 10
+  uint32_t lds_sub;              // LDS: int16 sub[5][rows padded to even]
+  uint32_t lds_carry;            // LDS: 5 arrays [P1_ROWS] u32 : D, R, U0, U1, E
+  uint32_t lds_mask[2];          // LDS: column bit masks per strand (only if masked != 0)
+  int32_t masked;                // 0 = all columns open
+  uint32_t* ckpt;                // global: [2 strands][nchunks][5][rows_p] u32 checkpoints
+  int32_t rows_p;                // row stride of the checkpoint arrays (>= len2)
+};
+
+struct Pass1Result {             // wave-uniform
+  int32_t best[2];               // per strand; INT32_MIN/2 if the strand has no open column
+  int32_t strand, score, aec, abc, abr;
+  uint32_t status;
+};
+
+template <class P>
+struct Pass1Aligner {
+  typedef typename P::U U;
+  typedef typename P::M M;
+  static constexpr int CPL = 4, IB = P1_IB, SH = P1_SH;
+  static constexpr uint32_t IDXM = P1_IDXM;
+
+  // move a carried key to a chunk base that is `cols` columns further right
+  MIA_HD static inline U rebase(P& w, const U& e, uint32_t cols, uint32_t unav) {
+    U idx = (e & IDXM) + cols;
+    U moved = e - ((cols * (uint32_t)GEP) << SH) + cols;
+    return w.sel((idx > IDXM) | (e <= unav), U(unav), moved);
+  }
+
+  MIA_HD static inline M maskbit(P& w, const Pass1Args& a, int strand, const U& gcol) {
+    M in = gcol < (uint32_t)a.len1;
+    if (!a.masked) return in;
+    U word = w.lds_r32m(U(a.lds_mask[strand]) + (gcol >> 5) * 4u, in);
+    return in & (((word >> (gcol & 31u)) & 1u) != 0u);
+  }
+
+  // One chunk, all rows.  Carries are consumed from / produced into the LDS arrays in place.
+  // Returns through (cbest, ccol) the maximum biased score of the last row and its first column.
+  template <bool TRACE>
+  MIA_HD static inline void chunk(P& w, const Pass1Args& a, int strand, int ch, uint32_t& cbest, uint32_t& ccol) {
+    const uint32_t OFF = (uint32_t)a.pk.off;
+    const uint32_t UNAV = ((uint32_t)a.pk.unavail << SH) | IDXM;
+    const U unav = U(UNAV);
+    const U lane = w.lane();
+    const int len2 = a.len2;
+    const uint32_t base = (uint32_t)ch * P1_CH;
+    const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;
+    const uint32_t cD = a.lds_carry, cR = cD + MAX_READ * 4, cU0 = cR + MAX_READ * 4, cU1 = cU0 + MAX_READ * 4, cE = cU1 + MAX_READ * 4;
+    const M last_lane = lane == 63u;
+
+    U gcol[CPL], sub_addr[CPL], KC[CPL], QC[CPL];
+    M valid[CPL], qen[CPL];
+    for (int j = 0; j < CPL; j++) {
+      U crel = lane * (uint32_t)CPL + (uint32_t)j;
+      gcol[j] = crel + base;
+      valid[j] = maskbit(w, a, strand, gcol[j]);
+      qen[j] = valid[j] & ((gcol[j] == 0u) | maskbit(w, a, strand, gcol[j] + 2u));
+      U code = w.sel(gcol[j] < (uint32_t)a.len1, w.gload_u8(a.ref_codes[strand], gcol[j], gcol[j] < (uint32_t)a.len1), U(4u));
+      sub_addr[j] = U(a.lds_sub) + code * RS2;
+      U cp = crel + (uint32_t)P1_REL;   // shifted column index used inside keys
+      KC[j] = (U(0u) - ((U((uint32_t)GOP) + (cp - 1u) * (uint32_t)GEP) << SH)) + (TR_COLGAP << IB) + (cp - 1u - IDXM);
+      QC[j] = ((cp * (uint32_t)GEP) << SH) + (U(IDXM) - cp);
+    }
+    const uint32_t WDC = TR_DIAG << IB;
+
+    U Sb[CPL], q[CPL], rrun[CPL], pend[CPL], pw[CPL];
+    for (int j = 0; j < CPL; j++) {     // row 0 (src/mia.c:769-785)
+      pw[j] = w.lds_r32(sub_addr[j]);
+      Sb[j] = w.sel(valid[j], w.sext_lo(pw[j]) + OFF, U(0u));
+      q[j] = w.sel(qen[j], (Sb[j] << SH) + QC[j], unav);
+      pend[j] = w.sel(valid[j], (Sb[j] << SH) + IDXM, unav);
+      rrun[j] = unav;
+    }
+    if (TRACE) {
+      w.tr_w32(lane * 8u, U((TR_DIAG << IB) * 0x00010001u), lane < 64u);
+      w.tr_w32(lane * 8u + 4u, U((TR_DIAG << IB) * 0x00010001u), lane < 64u);
+    }
+
+    for (int r = 1; r < len2; r++) {
+      const int32_t fresh = -(GOP + GEP * (r + 1));                         // sg5 = 1 (src/mia.c:1535)
+      const uint32_t freshb = (uint32_t)(fresh + (int32_t)OFF);
+      const uint32_t WS = freshb << SH;
+      const uint32_t KR = (0u - ((uint32_t)(GOP + GEP * (r - 1)) << SH)) + (TR_ROWGAP << IB) + ((uint32_t)(r - 1) - IDXM);
+      const uint32_t RK = ((uint32_t)(GEP * r) << SH) + (IDXM - (uint32_t)r);
+      const bool hi = (r & 1) != 0;
+      if (!hi)
+        for (int j = 0; j < CPL; j++) pw[j] = w.lds_r32(sub_addr[j] + (uint32_t)r * 2u);
+
+      // carries of this row from the chunk on the left (same value in every lane) ...
+      const U inD = w.lds_r32(U(cD + (uint32_t)r * 4u)), inR = w.lds_r32(U(cR + (uint32_t)r * 4u));
+      const U inU0 = w.lds_r32(U(cU0 + (uint32_t)r * 4u)), inU1 = w.lds_r32(U(cU1 + (uint32_t)r * 4u));
+      const U inE = w.lds_r32(U(cE + (uint32_t)r * 4u));
+      // ... and ours for the chunk on the right (lane 63; state BEFORE this row is computed)
+      w.lds_w32(U(cD + (uint32_t)r * 4u), Sb[CPL - 1], last_lane);
+      w.lds_w32(U(cR + (uint32_t)r * 4u), rrun[CPL - 1], last_lane);
+      w.lds_w32(U(cU0 + (uint32_t)r * 4u), q[CPL - 2], last_lane);
+      w.lds_w32(U(cU1 + (uint32_t)r * 4u), q[CPL - 1], last_lane);
+
+      U dleft = w.shr1(Sb[CPL - 1], inD);
+      U rleft = w.shr1(rrun[CPL - 1], inR);
+      U u0 = w.shr1(q[CPL - 2], inU0);
+      U u1 = w.shr1(q[CPL - 1], inU1);
+      U g[CPL];
+      g[0] = u0;
+      g[1] = w.umax(u0, u1);
+      for (int j = 2; j < CPL; j++) g[j] = w.umax(g[j - 1], q[j - 2]);
+      U incl = w.scan_max(g[CPL - 1]);
+      U excl = w.umax(w.shr1_max(incl, unav), inE);
+      w.lds_w32(U(cE + (uint32_t)r * 4u), w.umax(incl, inE), last_lane);
+
+      U best[CPL], Snew[CPL];
+      for (int j = 0; j < CPL; j++) {
+        U diag = (j == 0) ? dleft : Sb[j - 1];
+        U rl = (j == 0) ? rleft : rrun[j - 1];
+        U Wd = (diag << SH) + WDC;
+        U Wc = w.umax(excl, g[j]) + KC[j];
+        U Wr = rl + KR;
+        U m3 = w.umax3(Wd, Wc, Wr);
+        best[j] = w.umax(m3, U(WS));
+        U sub = hi ? w.sext_hi(pw[j]) : w.sext_lo(pw[j]);
+        Snew[j] = w.sel(valid[j], (best[j] >> SH) + w.sel(m3 < WS, U(0u), sub), U(0u));
+      }
+      if (TRACE) {
+        const uint32_t row_tr = (uint32_t)r * (P1_CH * 2u);
+        w.tr_w32(U(row_tr) + lane * 8u, (best[0] & 0xFFFu) | ((best[1] & 0xFFFu) << 16), lane < 64u);
+        w.tr_w32(U(row_tr) + lane * 8u + 4u, (best[2] & 0xFFFu) | ((best[3] & 0xFFFu) << 16), lane < 64u);
+      }
+      for (int j = 0; j < CPL; j++) {
+        rrun[j] = w.umax(rrun[j], pend[j]);
+        pend[j] = w.sel(valid[j], (Snew[j] << SH) + RK, unav);
+        q[j] = w.sel(qen[j], (Snew[j] << SH) + QC[j], unav);
+        Sb[j] = Snew[j];
+      }
+    }
+    // last row: maximum and its first column inside this chunk
+    U m = U(0u);
+    for (int j = 0; j < CPL; j++) m = w.umax(m, Sb[j]);   // absent cells are 0
+    cbest = w.reduce_max(m);
+    U cmin = U(0xFFFFFFFFu);
+    for (int j = CPL - 1; j >= 0; j--) cmin = w.sel(valid[j] & (Sb[j] == cbest), gcol[j], cmin);
+    ccol = w.reduce_min(cmin);
+    w.lds_fence();
+  }
+
+  MIA_HD static inline bool chunk_open(P& w, const Pass1Args& a, int strand, int ch) {
+    if (!a.masked) return true;
+    const U lane = w.lane();
+    U widx = U((uint32_t)ch * (P1_CH / 32)) + lane;
+    M in = (lane < (uint32_t)(P1_CH / 32)) & (widx * 32u < (uint32_t)a.len1);
+    U word = w.lds_r32m(U(a.lds_mask[strand]) + widx * 4u, in);
+    return w.ballot(in & (word != 0u)) != 0;
+  }
+
+  MIA_HD static inline uint32_t* ckpt_of(const Pass1Args& a, int strand, int ch, int nch) {
+    return a.ckpt + ((size_t)strand * nch + ch) * 5u * (uint32_t)a.rows_p;
+  }
+
+  MIA_HD static inline Pass1Result run(P& w, const Pass1Args& a) {
+    const uint32_t OFF = (uint32_t)a.pk.off;
+    const uint32_t UNAV = ((uint32_t)a.pk.unavail << SH) | IDXM;
+    const U lane = w.lane();
+    const int len2 = a.len2, nch = (a.len1 + P1_CH - 1) / P1_CH;
+    const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;
+    const uint32_t cD = a.lds_carry;
+    Pass1Result res;
+    res.status = ST_OK;
+
+    // substitution table (as in the window kernel)
+    for (int e0 = 0; e0 < len2 * 5; e0 += WAVE) {
+      U e = lane + (uint32_t)e0;
+      M ok = e < (uint32_t)(len2 * 5);
+      U r = w.udiv5(e);
+      U c1 = e - r * 5u;
+      U byte = w.gload_u8(a.read_packed, r >> 1, ok);
+      U c2 = (byte >> ((r & 1u) << 2)) & 15u;
+      U d = w.depth(r, (uint32_t)len2);
+      U v = w.gload_i32(a.pssm, (d * 5u + c1) * 5u + c2, ok);
+      w.lds_w16(U(a.lds_sub) + c1 * RS2 + r * 2u, v, ok);
+    }
+    w.lds_fence();
+
+    // ---- phase A: score sweep of both strands
+    uint32_t sbest[2] = {0u, 0u}, scol[2] = {0u, 0u};
+    for (int strand = 0; strand < 2; strand++) {
+      int prev = -1;
+      for (int ch = 0; ch < nch; ch++) {
+        if (!chunk_open(w, a, strand, ch)) continue;
+        // carries entering this chunk
+        for (int r0 = 0; r0 < len2; r0 += WAVE) {
+          U r = lane + (uint32_t)r0;
+          M ok = r < (uint32_t)len2;
+          U d, rr, u0, u1, e;
+          if (prev < 0) {
+            // nothing to the left: global column 0 takes "diag" = fresh (src/mia.c:805-822), otherwise absent
+            U fr = U(OFF - (uint32_t)GOP) - (r + 1u) * (uint32_t)GEP;
+            d = (ch == 0) ? fr : U(0u);
+            rr = U(UNAV); u0 = U(UNAV); u1 = U(UNAV); e = U(UNAV);
+          } else {
+            const uint32_t adv = (uint32_t)(ch - prev) * P1_CH;
+            e = rebase(w, w.lds_r32m(U(cD + 4u * MAX_READ * 4u) + r * 4u, ok), adv, UNAV);
+            if (ch - prev == 1) {
+              d = w.lds_r32m(U(cD) + r * 4u, ok);
+              rr = w.lds_r32m(U(cD + 1u * MAX_READ * 4u) + r * 4u, ok);
+              u0 = rebase(w, w.lds_r32m(U(cD + 2u * MAX_READ * 4u) + r * 4u, ok), adv, UNAV);
+              u1 = rebase(w, w.lds_r32m(U(cD + 3u * MAX_READ * 4u) + r * 4u, ok), adv, UNAV);
+            } else {
+              // masked chunks in between: their columns are absent, but the two last keys of the
+              // previous open chunk are still candidates further left -> fold them into E
+              U pu0 = rebase(w, w.lds_r32m(U(cD + 2u * MAX_READ * 4u) + r * 4u, ok), adv, UNAV);
+              U pu1 = rebase(w, w.lds_r32m(U(cD + 3u * MAX_READ * 4u) + r * 4u, ok), adv, UNAV);
+              e = w.umax3(e, pu0, pu1);
+              d = U(0u); rr = U(UNAV); u0 = U(UNAV); u1 = U(UNAV);
+            }
+          }
+          w.lds_w32(U(cD) + r * 4u, d, ok);
+          w.lds_w32(U(cD + 1u * MAX_READ * 4u) + r * 4u, rr, ok);
+          w.lds_w32(U(cD + 2u * MAX_READ * 4u) + r * 4u, u0, ok);
+          w.lds_w32(U(cD + 3u * MAX_READ * 4u) + r * 4u, u1, ok);
+          w.lds_w32(U(cD + 4u * MAX_READ * 4u) + r * 4u, e, ok);
+          uint32_t* ck = ckpt_of(a, strand, ch, nch);
+          w.gstore_u32(ck, r, d, ok);
+          w.gstore_u32(ck + a.rows_p, r, rr, ok);
+          w.gstore_u32(ck + 2 * a.rows_p, r, u0, ok);
+          w.gstore_u32(ck + 3 * a.rows_p, r, u1, ok);
+          w.gstore_u32(ck + 4 * a.rows_p, r, e, ok);
+        }
+        w.lds_fence();
+        uint32_t cb, cc;
+        chunk<false>(w, a, strand, ch, cb, cc);
+        if (cb > sbest[strand]) { sbest[strand] = cb; scol[strand] = cc; }   // first maximum wins (src/mia.c:1293-1299)
+        prev = ch;
+      }
+    }
+    // note: U1 of the previous chunk enters E only with mask[k+2]; qen already encodes that.
+
+    // ---- phase B: strand choice (src/mia.c:1549-1554); an all-masked strand scores HIM, arg-max column 0
+    const int32_t HIM = INT32_MIN / 2;
+    res.best[0] = sbest[0] ? (int32_t)(sbest[0] - OFF) : HIM;
+    res.best[1] = sbest[1] ? (int32_t)(sbest[1] - OFF) : HIM;
+    res.strand = (res.best[0] > res.best[1]) ? 0 : 1;
+    const int st = res.strand;
+    res.score = res.best[st];
+    res.aec = sbest[st] ? (int32_t)scol[st] : 0;
+    res.abc = res.aec;
+    res.abr = len2 - 1;
+    if (!sbest[st]) {   // both strands fully masked cannot happen (the k-mer filter rejects the read first)
+      res.status |= ST_TOO_LONG;
+      return res;
+    }
+
+    // ---- phase C: traceback on the chosen strand, recomputing the visited chunks with a trace
+    int r = len2 - 1, c = res.aec, cur = -1, aln_cols = 0;
+    for (int guard = 0; guard < 8 * MAX_READ + 64; guard++) {
+      const int ch = c / P1_CH;
+      if (ch != cur) {
+        const uint32_t* ck = ckpt_of(a, st, ch, nch);
+        for (int r0 = 0; r0 < len2; r0 += WAVE) {
+          U rr = lane + (uint32_t)r0;
+          M ok = rr < (uint32_t)len2;
+          for (int k = 0; k < 5; k++) w.lds_w32(U(cD + (uint32_t)k * MAX_READ * 4u) + rr * 4u, w.gload_u32(ck + k * a.rows_p, rr, ok), ok);
+        }
+        w.lds_fence();
+        uint32_t cb, cc;
+        chunk<true>(w, a, st, ch, cb, cc);
+        w.tr_fence();
+        cur = ch;
+      }
+      const uint32_t base = (uint32_t)ch * P1_CH;
+      U ri = U((uint32_t)r) - lane, ci = U((uint32_t)c) - lane;
+      M inside = (lane <= (uint32_t)r) & (lane <= (uint32_t)c) & (ci >= base);
+      U tc = w.tr_r16(ri * (P1_CH * 2u) + (ci - base) * 2u, inside);
+      U ty = tc >> IB, ln = tc & IDXM;
+      M colgap0 = (ty == U(TR_COLGAP)) & (ln + 1u == ci);   // source column 0 -> T == 0 -> read as diagonal (src/mia.c:619)
+      M rowgap0 = (ty == U(TR_ROWGAP)) & (ln + 1u == ri);
+      M plain_diag = (ty == U(TR_DIAG)) | colgap0 | rowgap0;
+      M terminal = (ri == U(0u)) | (ci == U(0u)) | (ty == U(TR_START));
+      M stop_here = (!inside) | terminal | (!plain_diag);
+      uint64_t bal = w.ballot(stop_here);
+      int f = bal ? __builtin_ctzll(bal) : WAVE;
+      if (f == WAVE) { r -= WAVE; c -= WAVE; aln_cols += WAVE; continue; }
+      if (!w.lane_bit(inside, f)) {          // left the chunk (or the matrix edge is handled by `terminal` first)
+        if (f == 0) { res.status |= ST_TOO_LONG; break; }   // cannot happen: c / P1_CH == ch
+        r -= f; c -= f; aln_cols += f;
+        continue;
+      }
+      aln_cols += f + 1;
+      const uint32_t fty = w.lane_val(ty, f), fln = w.lane_val(ln, f);
+      const int fr = r - f, fc = c - f;
+      if (w.lane_bit(terminal, f)) { res.abr = fr; res.abc = fc; break; }
+      if (fty == TR_COLGAP) { r = fr - 1; c = fc - 1 - (int)fln; }
+      else { r = fr - 1 - (int)fln; c = fc - 1; }
+      aln_cols += (int)fln;
+    }
+    if (aln_cols > 2 * MAX_READ) res.status |= ST_TOO_LONG;
+    return res;
+  }
+};
+
+}  // namespace mia

@@ -89,6 +89,12 @@ struct DevWave {
   __device__ __forceinline__ void lds_w32(U off, U v, M ok) const { if (ok) *reinterpret_cast<uint32_t*>(lds + off) = v; }
   __device__ __forceinline__ U lds_ri16(U off) const { return (U)(int32_t)*reinterpret_cast<const int16_t*>(lds + off); }
   __device__ __forceinline__ U lds_r32(U off) const { return *reinterpret_cast<const uint32_t*>(lds + off); }
+  __device__ __forceinline__ U lds_r32m(U off, M ok) const { return ok ? *reinterpret_cast<const uint32_t*>(lds + off) : 0u; }
+  __device__ __forceinline__ static U gload_u32(const uint32_t* p, U i, M ok) { return ok ? p[i] : 0u; }
+  __device__ __forceinline__ static void gstore_u32(uint32_t* p, U i, U v, M ok) { if (ok) p[i] = v; }
+  __device__ __forceinline__ U tr_r16(U off, M ok) const {
+    return ok ? (U)__hip_atomic_load(reinterpret_cast<const uint16_t*>(trace + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  }
   __device__ __forceinline__ U lds_r8(U off, M ok) const { return ok ? (U)lds[off] : 0u; }
   // trace slab: plain global stores / byte loads; the slab is private to the wave, re-used
   // for every read it processes and small enough (<= 32 waves/CU x 256 CUs) to live in

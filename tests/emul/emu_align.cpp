@@ -8,6 +8,7 @@
 
 #include "wave_emu.h"
 #include "align_body.h"
+#include "pass1_body.h"
 
 using namespace mia;
 
@@ -38,4 +39,37 @@ extern "C" int emu_align_window(int cpl, const uint8_t* ref_codes, int ref_start
     case 12: return run_one<12>(ref_codes, ref_start, len1, read_codes, len2, pssm, sg5, max_abs, out5, cols);
     default: return -2;
   }
+}
+
+// pass 1 of one read: both strands vs the whole (wrapped) reference, optional column masks
+extern "C" int emu_pass1(const uint8_t* fw_codes, const uint8_t* rc_codes, int len1, const uint8_t* read_codes, int len2,
+                         const int32_t* pssm, int max_abs, const uint8_t* fw_mask, const uint8_t* rc_mask, int32_t* out8) {
+  PackParams pk;
+  if (!make_pack_params(1024, max_abs, &pk)) return -1;
+  std::vector<uint8_t> packed((len2 + 1) / 2 + 4, 0);
+  for (int i = 0; i < len2; i++) packed[i >> 1] |= (uint8_t)(read_codes[i] << ((i & 1) * 4));
+  const int nch = (len1 + P1_CH - 1) / P1_CH, words = nch * (P1_CH / 32) + 4;
+  Pass1Args a;
+  a.ref_codes[0] = fw_codes; a.ref_codes[1] = rc_codes; a.len1 = len1;
+  a.read_packed = packed.data(); a.len2 = len2; a.pssm = pssm; a.pk = pk;
+  a.lds_sub = 0;
+  a.lds_carry = MAX_READ * 10;
+  a.lds_mask[0] = a.lds_carry + 5 * MAX_READ * 4;
+  a.lds_mask[1] = a.lds_mask[0] + (uint32_t)words * 4;
+  a.masked = (fw_mask && rc_mask) ? 1 : 0;
+  a.rows_p = (len2 + 3) & ~3;
+  std::vector<uint32_t> ckpt((size_t)2 * nch * 5 * a.rows_p + 16, 0xDEADBEEFu);
+  a.ckpt = ckpt.data();
+  EmuWave w(a.lds_mask[1] + (size_t)words * 4 + 64, (size_t)MAX_READ * P1_CH * 2 + 64);
+  if (a.masked) {
+    for (int s = 0; s < 2; s++) {
+      const uint8_t* m = s ? rc_mask : fw_mask;
+      for (int c = 0; c < len1; c++)
+        if (m[c]) { uint32_t x; memcpy(&x, &w.lds[a.lds_mask[s] + (c >> 5) * 4], 4); x |= 1u << (c & 31); memcpy(&w.lds[a.lds_mask[s] + (c >> 5) * 4], &x, 4); }
+    }
+  }
+  Pass1Result r = Pass1Aligner<EmuWave>::run(w, a);
+  out8[0] = r.best[0]; out8[1] = r.best[1]; out8[2] = r.strand; out8[3] = r.score; out8[4] = r.aec; out8[5] = r.abc;
+  out8[6] = r.abr; out8[7] = (int32_t)r.status;
+  return 0;
 }

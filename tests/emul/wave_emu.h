@@ -88,6 +88,10 @@ struct EmuWave {
   void lds_w32(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { lds.at(off.a[i] + 3); memcpy(&lds[off.a[i]], &v.a[i], 4); } }
   U lds_ri16(const U& off) const { EV r; for (int i = 0; i < 64; i++) { int16_t x; lds.at(off.a[i] + 1); memcpy(&x, &lds[off.a[i]], 2); r.a[i] = (uint32_t)(int32_t)x; } return r; }
   U lds_r32(const U& off) const { EV r; for (int i = 0; i < 64; i++) { lds.at(off.a[i] + 3); memcpy(&r.a[i], &lds[off.a[i]], 4); } return r; }
+  U lds_r32m(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) if (ok.a[i]) { lds.at(off.a[i] + 3); memcpy(&r.a[i], &lds[off.a[i]], 4); } return r; }
+  static U gload_u32(const uint32_t* p, const U& idx, const M& ok) { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? p[idx.a[i]] : 0u; return r; }
+  static void gstore_u32(uint32_t* p, const U& idx, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) p[idx.a[i]] = v.a[i]; }
+  U tr_r16(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) if (ok.a[i]) { uint16_t x; trace.at(off.a[i] + 1); memcpy(&x, &trace[off.a[i]], 2); r.a[i] = x; } return r; }
   U lds_r8(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? lds.at(off.a[i]) : 0u; return r; }
   void lds_fence() const {}
   void tr_w32(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { trace.at(off.a[i] + 3); memcpy(&trace[off.a[i]], &v.a[i], 4); } }

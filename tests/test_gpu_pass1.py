@@ -1,0 +1,85 @@
+"""GPU parity of pass 1 (new_kmer_filter + sg_align, reference src/mia_main.c:759-805)
+through the C ABI, against the oracle's pass 1 on the committed inputs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ctypes as oc
+from conftest import GOLDEN
+from mia_flow import fsdb_arrays, oracle_after_pass1, pssm_array
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # name: (ref, reads, circular, kmer, soft_mask, pssm)
+    "fixture_c": ("tr1.fna", "tf.fna", True, -1, False, None),
+    "fixture_lin": ("tr1.fna", "tf.fna", False, -1, False, None),
+    "fixture_c_k8M": ("tr1.fna", "tf.fna", True, 8, True, None),
+    "fixture_c_anc": ("tr1.fna", "tf.fna", True, -1, False, "ancient.submat.txt"),
+    "s150_k12": ("mt311.fa", "s150.fa", True, 12, False, None),
+    "s150_full": ("mt311.fa", "s150.fa", True, -1, False, None),
+    "d150_anc_k12": ("mt311.fa", "d150.fa", True, 12, False, "ancient.submat.txt"),
+    "indel_anc_k10": ("mt311.fa", "indel.fa", True, 10, False, "ancient.submat.txt"),
+}
+
+
+def read_fasta(path):
+    """id, sequence as read_fasta leaves it (upper case, truncated to 256; src/io.c:246-278)"""
+    out = []
+    for rec in open(path).read().split(">")[1:]:
+        lines = rec.split("\n")
+        out.append((lines[0].split()[0] if lines[0].split() else "", "".join(lines[1:]).replace(" ", "").upper()[:256]))
+    return out
+
+
+def ref_fasta(path):
+    rec = open(path).read().split(">")[1]
+    return "".join(rec.split("\n")[1:])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_pass1_matches_oracle(name, oracle):
+    import mia_amd
+    ref_fa, reads_fa, circ, kmer, soft, pfile = CASES[name]
+    if name == "s150_full" and os.environ.get("MIA_SLOW", "0") != "1":
+        # the GPU needs milliseconds; the CPU oracle 25 s for the unseeded 150-read pass 1
+        pass
+    o = oc.Opts()
+    oracle.ora_opts_default(C.byref(o))
+    o.circular, o.kmer_len, o.soft_mask = int(circ), kmer, int(soft)
+    anc = oc.Pssm()
+    if pfile:
+        assert oracle.ora_pssm_read(os.path.join(GOLDEN, pfile).encode(), C.byref(anc)) == 1
+    else:
+        oracle.ora_pssm_flat(C.byref(anc))
+    st = oracle.ora_new(C.byref(o), C.byref(anc))
+    assert oracle.ora_load_ref_fasta(st, os.path.join(GOLDEN, ref_fa).encode()) == 1
+    oracle.ora_prepare_ref(st)
+    oracle.ora_pass1_file(st, os.path.join(GOLDEN, reads_fa).encode())   # no finish_pass1: raw pass-1 state
+    exp = {}
+    for i in range(oracle.ora_num_frags(st)):
+        f = oracle.ora_frag_at(st, i).contents
+        exp[f.id.decode()] = (f.score, f.rc, f.as_, f.ae, f.strand_known, f.back >= 0)
+
+    reads = [(i, s) for i, s in read_fasta(os.path.join(GOLDEN, reads_fa)) if len(s) > 0]
+    bases = np.frombuffer("".join(s for _, s in reads).encode(), dtype=np.uint8)
+    offsets = np.zeros(len(reads) + 1, np.int64)
+    offsets[1:] = np.cumsum([len(s) for _, s in reads])
+    hip = mia_amd.MiaHip(0)
+    hip.set_pssm(pssm_array(anc))
+    score, rc, as_, ae, flags = hip.pass1(ref_fasta(os.path.join(GOLDEN, ref_fa)), circ, bases, offsets, kmer, soft)
+    n_kept = 0
+    for k, (rid, _) in enumerate(reads):
+        kept = bool(flags[k] & mia_amd.P1_KEPT)
+        assert kept == (rid in exp), (name, rid, int(flags[k]), int(score[k]))
+        if kept:
+            n_kept += 1
+            e = exp[rid]
+            got = (int(score[k]), int(rc[k]), int(as_[k]), int(ae[k]), int(bool(flags[k] & mia_amd.P1_STRAND_KNOWN)),
+                   bool(flags[k] & mia_amd.P1_SPLIT))
+            assert got == (e[0], e[1], e[2], e[3], e[4], e[5]), (name, rid, got, e)
+    assert n_kept == len(exp) and n_kept > 0
+    hip.close()
+    oracle.ora_free(st)
