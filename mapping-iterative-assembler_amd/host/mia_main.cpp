@@ -1,0 +1,491 @@
+// mia_main.cpp -- `mia_hip`: the mia command line on top of libmia_hip.so.
+//
+// Host side of the boundary: same flags, same .maln text, same
+// read-store semantics as the reference's main() (/root/reference/src/mia_main.c:394-989),
+// but every alignment, tally and consensus call runs on the GPU through the C ABI of
+// include/mia_hip.h.  What stays here is what the reference also does on the host
+// around the hot path: option parsing, FASTA/FASTQ parsing (src/io.c:35-386), the
+// read store, and formatting the .maln (src/map_alignment.c:283-382).
+//
+// Options of the reference that are outside the accelerated path (SURVEY.md section 2,
+// "OUT OF SCOPE": -T -a -u -U -A -C -h -D -I -q) are rejected with a message
+// instead of being silently ignored.
+#include <ctype.h>
+#include <getopt.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/mia_hip.h"
+
+namespace {
+
+const int MAX_ID_LEN = 100, MAX_DESC_LEN = 128, MAX_READ = 256, PSSM_DEPTH = 15, MAX_ITER = 30;
+
+struct Pssm { int32_t sm[31][5][5]; };
+
+void flat_pssm(Pssm* p) {   // init_flatsubmat, src/pssm.c:96-126
+  for (int d = 0; d < 31; d++) {
+    for (int i = 0; i < 5; i++) {
+      for (int j = 0; j < 4; j++) p->sm[d][i][j] = (i == j) ? 200 : -600;
+      p->sm[d][i][4] = -100;
+    }
+    for (int j = 0; j < 5; j++) p->sm[d][4][j] = -10;
+  }
+}
+void revcom_pssm(const Pssm* in, Pssm* out) {   // revcom_submat, src/pssm.c:53-91
+  for (int d = 0; d < 31; d++)
+    for (int i = 0; i < 5; i++)
+      for (int j = 0; j < 5; j++) out->sm[30 - d][i][j] = in->sm[d][i < 4 ? 3 - i : 4][j < 4 ? 3 - j : 4];
+}
+bool read_pssm_file(const char* fn, Pssm* p) {   // read_pssm, src/io.c:408-503
+  FILE* f = fopen(fn, "r");
+  if (!f) return false;
+  char line[4096];
+  for (int d = 0; d < 31; d++) {
+    if (!fgets(line, sizeof line, f) || !strstr(line, "# Matrix for position")) { fclose(f); fprintf(stderr, "Problem parsing matrix file: %s\n", fn); exit(2); }
+    for (int i = 0; i < 4; i++) {
+      if (!fgets(line, sizeof line, f)) line[0] = 0;
+      sscanf(line, "%d\t%d\t%d\t%d", &p->sm[d][i][0], &p->sm[d][i][1], &p->sm[d][i][2], &p->sm[d][i][3]);
+      p->sm[d][i][4] = -100;
+    }
+    for (int j = 0; j < 5; j++) p->sm[d][4][j] = -10;
+    if (!fgets(line, sizeof line, f)) line[0] = 0;
+  }
+  fclose(f);
+  return true;
+}
+// find_read_pssm, src/mia_main.c:299-328: the path itself, then ./, then DATA_PATH/matrices/
+void find_read_pssm(const char* fn, Pssm* p) {
+  if (read_pssm_file(fn, p)) return;
+  const char* base = strrchr(fn, '/');
+  base = base ? base + 1 : fn;
+  std::string here = std::string("./") + base;
+  if (read_pssm_file(here.c_str(), p)) return;
+  const char* dp = getenv("MIA_DATA_PATH");
+  if (dp) {
+    std::string d = std::string(dp) + "/matrices/" + base;
+    if (read_pssm_file(d.c_str(), p)) return;
+  }
+  fprintf(stderr, "Sadly, the substitution matrix cannot be read. Bye bye.\n");
+  exit(10);
+}
+
+char revcom_char(char b) {   // src/map_align.c:418-432
+  static const char tbl[] = "TVGH\0\0CD\0\0M\0KN\0\0\0YSAABWXR\0";
+  char r = 0;
+  if (b == '-') return '-';
+  if (b >= 'A' && b <= 'Z') r = tbl[b - 'A'];
+  else if (b >= 'a' && b <= 'z') r = (char)(tbl[b - 'a'] + 32);
+  if (r) return r;
+  fprintf(stderr, "Do not know how to revcom \"%c\"\n", b);
+  return 'N';
+}
+
+struct Ref { std::string id, desc, seq; };
+
+bool read_fasta_ref(const char* fn, Ref* r) {   // src/io.c:287-386
+  FILE* f = fopen(fn, "r");
+  if (!f) return false;
+  int c = fgetc(f);
+  if (c != '>') { fclose(f); return false; }
+  bool done = false;
+  while (!isspace(c = fgetc(f)) && !done) {
+    if (c == EOF) { fclose(f); return false; }
+    r->id.push_back((char)c);
+    if ((int)r->id.size() == MAX_ID_LEN) done = true;
+  }
+  done = false;
+  if (c == '\n') done = true; else c = fgetc(f);
+  while (c != '\n' && !done) {
+    if (c == EOF) { fclose(f); return false; }
+    r->desc.push_back((char)c);
+    if ((int)r->desc.size() == MAX_DESC_LEN) done = true;
+    c = fgetc(f);
+  }
+  c = fgetc(f);
+  while (c != '>' && c != EOF) {
+    if (!isspace(c)) r->seq.push_back((char)c);
+    c = fgetc(f);
+  }
+  fclose(f);
+  return true;
+}
+
+struct Read { std::string id, desc, seq; };
+
+// read_fasta / read_fastq, src/io.c:35-281 (including the doubled first description character
+// of read_fasta, src/io.c:228-234, and the 256-base truncation)
+bool next_record(FILE* f, bool fastq, Read* r) {
+  r->id.clear(); r->desc.clear(); r->seq.clear();
+  int c = fgetc(f);
+  if (c == EOF) return false;
+  if (c != (fastq ? '@' : '>')) {
+    if (fastq) fprintf(stderr, "While reading fastq file, saw record not beginning with @\nMaybe badly formed input? Continuing, anyway...\n");
+    return false;
+  }
+  while (!isspace(c = fgetc(f)) && (int)r->id.size() < MAX_ID_LEN) {
+    if (c == EOF) return false;
+    r->id.push_back((char)c);
+  }
+  if (c != '\n') {
+    while (c != '\n' && isspace(c)) c = fgetc(f);
+    if (!fastq && c != '\n') r->desc.push_back((char)c);
+    while (c != '\n' && c != EOF && (int)r->desc.size() < MAX_DESC_LEN) { r->desc.push_back((char)c); c = fgetc(f); }
+  }
+  c = fgetc(f);
+  if (!fastq) {
+    while (c != '>' && c != EOF && (int)r->seq.size() < MAX_READ) {
+      if (!isspace(c)) r->seq.push_back((char)toupper(c));
+      c = fgetc(f);
+    }
+    if (c == '>') { ungetc('>', f); return true; }
+    if ((int)r->seq.size() == MAX_READ) {
+      while (c != '>' && c != EOF) c = fgetc(f);
+      if (c == '>') ungetc('>', f);
+      fprintf(stderr, "%s is longer than allowed length: %d\n", r->id.c_str(), MAX_READ);
+    }
+    return true;
+  }
+  while (c != '\n' && c != EOF && (int)r->seq.size() < MAX_READ) {
+    if (!isspace(c)) r->seq.push_back((char)toupper(c));
+    c = fgetc(f);
+  }
+  if ((int)r->seq.size() == MAX_READ) while (c != '\n' && c != EOF) c = fgetc(f);
+  c = fgetc(f);
+  if (c != '+') { fprintf(stderr, "Problem reading quality line for %s\n", r->id.c_str()); return true; }
+  c = fgetc(f);
+  while (c != '\n' && c != EOF) c = fgetc(f);
+  int q = 0;
+  c = fgetc(f);
+  while (c != '\n' && c != EOF && q < MAX_READ) { if (!isspace(c)) q++; c = fgetc(f); }
+  if (q == MAX_READ) while (c != '\n' && c != EOF) c = fgetc(f);
+  if (q != (int)r->seq.size()) { fprintf(stderr, "%s has unequal sequence and qual line lengths\n", r->id.c_str()); return false; }
+  return true;
+}
+
+// One fsdb entry (FragSeq, src/types.h:110-143) -- only what the path needs.
+struct Frag {
+  std::string id, desc, seq;   // seq already reverse-complemented when rc && strand_known (src/fsdb.c:209-227)
+  int rc, strand_known, as, ae, score;
+};
+
+// AlnSeq as it is printed (src/types.h:61-76)
+struct Record {
+  std::string id, desc, seq, smp;
+  std::vector<std::pair<int, std::string>> ins;
+  int start, end, score, rc, dropped;
+  char segment;
+};
+
+void die(mia_hip_ctx* g, const char* what) {
+  fprintf(stderr, "%s: %s\n", what, g ? mia_hip_last_error(g) : "no context");
+  exit(1);
+}
+
+void help() {
+  printf("\n\nMIA -- Mapping Iterativ Assembler V 1.0 (MI355X build, libmia_hip)\n"
+         "usage: mia_hip -r <reference fasta> -f <fasta/fastq reads> [-m maln root] [-s matrix] [-c] [-i|-n]\n"
+         "               [-p cons code] [-H hard score cut] [-S slope -N intercept] [-k kmer] [-M] [-F] [-g gpu]\n");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string maln_root = "assembly.maln.iter", ref_fn, frag_fn;
+  int hard_cut = 0, circular = 0, iterate = 1, final_only = 0, score_cut_set = 0, kmer = -1, soft_mask = 0, cc = 1, any = 0, gpu = 0;
+  double slope = 200.0, intercept = 0.0;
+  Pssm anc, rcanc;
+  flat_pssm(&anc);
+  int ich;
+  while ((ich = getopt(argc, argv, "s:r:f:m:a:p:H:I:S:N:k:q:g:FTcinuhDMUAC::")) != -1) {
+    switch (ich) {
+      case 'c': circular = 1; break;
+      case 'n': iterate = 0; break;
+      case 'i': iterate = 1; break;
+      case 'p': cc = atoi(optarg); any = 1; break;
+      case 'H':
+        hard_cut = atoi(optarg);
+        if (hard_cut <= 0) { fprintf(stderr, "Hard cutoff (-H) must be positive\n"); help(); exit(0); }
+        any = 1;
+        break;
+      case 'M': soft_mask = 1; break;
+      case 's': find_read_pssm(optarg, &anc); any = 1; break;
+      case 'r': ref_fn = optarg; any = 1; break;
+      case 'k': kmer = atoi(optarg); any = 1; break;
+      case 'f': frag_fn = optarg; any = 1; break;
+      case 'm': maln_root = optarg; any = 1; break;
+      case 'S': slope = atof(optarg); score_cut_set = 1; break;
+      case 'N': intercept = atof(optarg); score_cut_set = 1; break;
+      case 'F': final_only = 1; break;
+      case 'g': gpu = atoi(optarg); break;
+      case 'T': case 'a': case 'u': case 'U': case 'A': case 'C': case 'h': case 'D': case 'I': case 'q':
+        fprintf(stderr, "option -%c is outside the MI355X-accelerated path (see DESIGN.md, section 7) and is not supported by mia_hip\n", ich);
+        exit(2);
+      default: help(); exit(0);
+    }
+  }
+  if (!any) { help(); exit(0); }
+  if (optind != argc) { fprintf(stderr, "There seems to be some extra cruff on the command line that mia does not understand.\n"); exit(0); }
+  revcom_pssm(&anc, &rcanc);
+
+  time_t now = time(NULL);
+  fprintf(stderr, "Starting assembly of %s\nusing %s\nas reference at %s\n", frag_fn.c_str(), ref_fn.c_str(), asctime(localtime(&now)));
+
+  Ref ref;
+  if (!read_fasta_ref(ref_fn.c_str(), &ref)) { fprintf(stderr, "Problem reading reference sequence file %s\n", ref_fn.c_str()); exit(1); }
+
+  mia_hip_ctx* g = nullptr;
+  if (mia_hip_create(&g, gpu) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: no usable MI355X (gfx950) device %d; there is no CPU fallback\n", gpu); exit(1); }
+  if (mia_hip_set_pssm(g, &anc.sm[0][0][0], &rcanc.sm[0][0][0]) != MIA_HIP_OK) die(g, "set_pssm");
+
+  // ---- read the fragments (read_next_seq loop, src/mia_main.c:759)
+  FILE* ff = fopen(frag_fn.c_str(), "r");
+  if (!ff) { fprintf(stderr, "Cannot open %s\n", frag_fn.c_str()); exit(1); }
+  int c0 = fgetc(ff);
+  if (c0 != EOF) ungetc(c0, ff);
+  const bool fastq = (c0 == '@');   // find_input_type, src/io.c:11-26
+  std::vector<Read> reads;
+  {
+    Read r;
+    while (next_record(ff, fastq, &r)) reads.push_back(r);
+  }
+  fclose(ff);
+  fprintf(stderr, "Starting to align sequences to the reference...\n");
+
+  // ---- pass 1 on the GPU (new_kmer_filter + sg_align)
+  std::vector<int64_t> off;
+  std::string bases;
+  std::vector<size_t> src;   // reads with at least one base (an empty read cannot be aligned: src/mia.c:1283-1286)
+  off.push_back(0);
+  for (size_t i = 0; i < reads.size(); i++)
+    if (!reads[i].seq.empty()) { bases += reads[i].seq; off.push_back((int64_t)bases.size()); src.push_back(i); }
+  const int64_t n1 = (int64_t)src.size();
+  std::vector<int32_t> p_score((size_t)n1), p_as((size_t)n1), p_ae((size_t)n1);
+  std::vector<uint8_t> p_rc((size_t)n1), p_fl((size_t)n1);
+  if (n1 > 0 && mia_hip_pass1(g, ref.seq.c_str(), (int32_t)ref.seq.size(), circular, kmer, soft_mask, n1, bases.data(), off.data(),
+                              p_score.data(), p_rc.data(), p_as.data(), p_ae.data(), p_fl.data()) != MIA_HIP_OK) die(g, "pass1");
+  fprintf(stderr, "\n");
+
+  // ---- fsdb (add_virgin_fs2fsdb, src/fsdb.c:194-231) and the pass-1 AlnSeq slots
+  std::vector<Frag> fsdb;
+  std::vector<uint8_t> slot_dropped;   // pass-1 slots, merge order
+  std::vector<int> first_slot, n_slots;
+  int n_unknown = 0;
+  for (int64_t k = 0; k < n1; k++) {
+    if (!(p_fl[k] & MIA_HIP_P1_KEPT)) continue;
+    const Read& r = reads[src[(size_t)k]];
+    Frag f;
+    f.id = r.id; f.desc = r.desc; f.seq = r.seq;
+    f.rc = p_rc[k]; f.strand_known = (p_fl[k] & MIA_HIP_P1_STRAND_KNOWN) ? 1 : 0;
+    f.as = p_as[k]; f.ae = p_ae[k]; f.score = p_score[k];
+    if (f.rc && f.strand_known) {
+      std::string t(f.seq.size(), 'N');
+      for (size_t i = 0; i < f.seq.size(); i++) t[i] = revcom_char(f.seq[f.seq.size() - 1 - i]);
+      f.seq = t;
+    }
+    if (!f.strand_known) n_unknown++;
+    first_slot.push_back((int)slot_dropped.size());
+    slot_dropped.push_back(0);
+    if (p_fl[k] & MIA_HIP_P1_SPLIT) slot_dropped.push_back(0);
+    n_slots.push_back((p_fl[k] & MIA_HIP_P1_SPLIT) ? 2 : 1);
+    fsdb.push_back(f);
+  }
+  const int n = (int)fsdb.size();
+  const int pass1_records = (int)slot_dropped.size();   // culled_maln->size, frozen here (src/mia.c:54)
+  if (n == 0) { fprintf(stderr, "No sequence aligned to the reference with a score of at least 2000.\n"); mia_hip_destroy(g); exit(0); }
+  if (n_unknown)
+    fprintf(stderr, "mia_hip: %d read(s) scored exactly 2000 (strand unknown); the reference keeps stale records for such reads, "
+                    "mia_hip leaves them out (DESIGN.md, section 6)\n", n_unknown);
+  std::vector<int32_t> len((size_t)n), score((size_t)n), as((size_t)n), ae((size_t)n);
+  for (int i = 0; i < n; i++) { len[i] = (int32_t)fsdb[i].seq.size(); score[i] = fsdb[i].score; }
+
+  auto score_cut = [&](double* s, double* ic) {   // cull_maln_from_fsdb, src/mia.c:429-442
+    *s = slope; *ic = intercept;
+    if (hard_cut <= 0 && !score_cut_set) mia_hip_score_cut(score.data(), len.data(), NULL, n, s, ic);
+    if (*s <= 0) *s = 100.0;
+  };
+  // first cull on the pass-1 records: only its `dropped` marks survive (src/mia_main.c:848)
+  fprintf(stderr, "Repeat and score filtering\n");
+  {
+    double s, ic;
+    score_cut(&s, &ic);
+    for (int i = 0; i < n; i++) {
+      const double min_score = hard_cut > 0 ? (double)hard_cut : (double)(ic + (s * len[i]));
+      if (score[i] < min_score)
+        for (int k = 0; k < n_slots[i]; k++) slot_dropped[first_slot[i] + k] = 1;   // front_asp and back_asp (src/mia.c:471-478)
+    }
+  }
+  // clean_FSDB (src/mia.c:400-406) cannot remove anything: every kept read scores >= 2000
+
+  // ---- upload the read store
+  {
+    std::vector<int64_t> o2((size_t)n + 1, 0);
+    std::string b2;
+    std::vector<uint8_t> rc((size_t)n), sk((size_t)n);
+    for (int i = 0; i < n; i++) {
+      b2 += fsdb[i].seq; o2[i + 1] = (int64_t)b2.size();
+      rc[i] = (uint8_t)fsdb[i].rc; sk[i] = (uint8_t)fsdb[i].strand_known; as[i] = fsdb[i].as; ae[i] = fsdb[i].ae;
+    }
+    if (mia_hip_upload_reads(g, n, b2.data(), o2.data(), rc.data(), sk.data(), as.data(), ae.data()) != MIA_HIP_OK) die(g, "upload_reads");
+    if (mia_hip_set_slot_dropped(g, slot_dropped.data(), (int64_t)slot_dropped.size()) != MIA_HIP_OK) die(g, "set_slot_dropped");
+  }
+
+  // make_ref_upper (src/mia.c:642-648): iteration 1 aligns to the upper-cased input reference
+  std::string cons = ref.seq;
+  for (auto& ch : cons) ch = (char)toupper((unsigned char)ch);
+  std::string ref_id = ref.id, ref_desc = ref.desc;
+  const int stride = MAX_READ;
+  std::vector<int16_t> cols((size_t)n * stride);
+  std::vector<int32_t> rstart((size_t)n), gaps;
+  std::vector<uint8_t> dF((size_t)n), dB((size_t)n);
+
+  auto iteration = [&](int iter_num) {
+    // reiterate_assembly (src/mia_main.c:24-280)
+    if (mia_hip_realign(g, cons.c_str(), (int32_t)cons.size(), circular) != MIA_HIP_OK) die(g, "realign");
+    if (mia_hip_get_alignments(g, score.data(), as.data(), ae.data()) != MIA_HIP_OK) die(g, "get_alignments");
+    if (iter_num > 1) { ref_id = "ConsAssem." + std::to_string(iter_num); ref_desc = "iteration assembly"; }
+    fprintf(stderr, "Repeat and score filtering\n");
+    double s, ic;
+    score_cut(&s, &ic);
+    if (mia_hip_cull(g, hard_cut, s, ic, 0) != MIA_HIP_OK) die(g, "cull");
+    if (mia_hip_tally(g) != MIA_HIP_OK) die(g, "tally");
+  };
+
+  // write_ma (src/map_alignment.c:283-382) from the device results
+  auto write_maln = [&](const std::string& fn) {
+    const int L = (int)cons.size();
+    const int wl = circular ? std::min(L, MAX_READ) : 0;
+    std::string wrapped = cons + cons.substr(0, (size_t)wl);
+    if (mia_hip_get_scripts(g, cols.data(), stride, rstart.data()) != MIA_HIP_OK) die(g, "get_scripts");
+    if (mia_hip_get_dropped(g, dF.data(), dB.data()) != MIA_HIP_OK) die(g, "get_dropped");
+    gaps.assign((size_t)L + 1, 0);
+    if (mia_hip_get_tally(g, NULL, gaps.data()) != MIA_HIP_OK) die(g, "get_tally");
+    std::vector<Record> recs;
+    for (int i = 0; i < n; i++) {
+      const Frag& f = fsdb[i];
+      if (!f.strand_known) continue;
+      const int16_t* cs = &cols[(size_t)i * stride];
+      const int len2 = (int)f.seq.size();
+      // the two gapped strings of populate_pwaln_to_begin (src/mia.c:1440-1497)
+      std::string rg, fg;
+      int prev = -1;
+      for (int r = 0; r < len2; r++) {
+        if (cs[r] == MIA_HIP_COL_CLIP) continue;
+        if (cs[r] == MIA_HIP_COL_INSERT) { rg.push_back('-'); fg.push_back(f.seq[r]); continue; }
+        const int gc = rstart[i] + cs[r];
+        if (prev >= 0) for (int k = prev + 1; k < gc; k++) { rg.push_back(wrapped[(size_t)k]); fg.push_back('-'); }
+        rg.push_back(wrapped[(size_t)gc]); fg.push_back(f.seq[r]);
+        prev = gc;
+      }
+      int start = as[i], end = ae[i];
+      if (end > L) end -= L;                      // src/mia_main.c:259-263
+      auto build = [&](const std::string& r, const std::string& q, int st, int en, char seg, int dropped, const std::string& id) {
+        Record a;   // merge_pwaln_into_maln, src/map_align.c:866-954
+        a.id = id; a.desc = f.desc; a.start = st; a.end = en; a.score = score[i]; a.rc = f.rc; a.dropped = dropped; a.segment = seg;
+        std::string cur; bool in = false;
+        for (size_t k = 0; k < r.size(); k++) {
+          if (r[k] == '-') { cur.push_back(q[k]); in = true; }
+          else { if (in) { a.ins.push_back({(int)a.seq.size(), cur}); cur.clear(); in = false; } a.seq.push_back(q[k]); }
+        }
+        return a;
+      };
+      size_t first = recs.size();
+      if (start > end) {                          // split_pwaln, src/mia.c:1376-1438
+        int rp = start; size_t ap = 0;
+        while (rp < L && ap < rg.size()) { if (rg[ap] != '-') rp++; ap++; }
+        std::string idf = f.id.substr(0, (size_t)MAX_ID_LEN - 1) + "_f", idb = f.id.substr(0, (size_t)MAX_ID_LEN - 1) + "_b";
+        recs.push_back(build(rg.substr(0, ap), fg.substr(0, ap), start, L - 1, 'f', dF[i], idf));
+        recs.push_back(build(rg.substr(ap), fg.substr(ap), 0, end, 'b', dB[i], idb));
+      } else recs.push_back(build(rg, fg, start, end, 'a', dF[i], f.id));
+      // pop_smp_from_FSDB (src/fsdb.c:542-619) for this read's record(s)
+      auto total_len = [&](const Record& a) { int span = a.end - a.start + 1, t = span; for (auto& in : a.ins) if (in.first < span) t += (int)in.second.size(); return t; };
+      Record& fa = recs[first];
+      Record* ba = recs.size() - first == 2 ? &recs[first + 1] : nullptr;
+      const int flen = total_len(fa), blen = ba ? total_len(*ba) : 0;
+      int act = 0;
+      auto fill = [&](Record& a, bool back) {
+        const int span = a.end - a.start + 1;
+        size_t ii = 0;
+        for (int p = 0; p < span; p++) {
+          while (ii < a.ins.size() && a.ins[ii].first < p) ii++;
+          if (ii < a.ins.size() && a.ins[ii].first == p) act += (int)a.ins[ii].second.size();
+          const int dff = back ? flen + act : act, dfb = flen + blen - act - 1;
+          char code = dff <= PSSM_DEPTH ? (char)('A' + dff) : (dfb < PSSM_DEPTH ? (char)('A' + 2 * PSSM_DEPTH - dfb) : (char)('A' + PSSM_DEPTH));
+          a.smp.push_back(code);
+          if (p < (int)a.seq.size() && a.seq[(size_t)p] != '-') act++;
+        }
+      };
+      fill(fa, false);
+      if (ba) fill(*ba, true);
+    }
+    // sort_aln_frags: stable by (start, end) over cull order (src/map_align.c:393-414)
+    std::vector<int> order(recs.size());
+    for (size_t k = 0; k < recs.size(); k++) order[k] = (int)k;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      if (recs[x].start != recs[y].start) return recs[x].start < recs[y].start;
+      return recs[x].end < recs[y].end;
+    });
+    FILE* mf = fopen(fn.c_str(), "w");
+    if (!mf) { fprintf(stderr, "Cannot write %s\n", fn.c_str()); exit(1); }
+    time_t t = time(NULL);
+    fprintf(mf, "/* map_alignment [V%s] */ %s", "1.0", asctime(localtime(&t)));
+    int size = L + 1;                             // src/mia_main.c:66, src/mia.c:669-675
+    if (circular) while (L + wl >= size) size *= 2;
+    fprintf(mf, "MALN_NAS %d\nMALN_SIZ %d\nMALN_COC %d\n__REFERENCE__\nID %s\nDESC %s\nLEN %d\nSIZE %d\nSEQ %s\nGAPS", (int)recs.size(),
+            pass1_records, cc, ref_id.c_str(), ref_desc.c_str(), L, size, cons.c_str());
+    for (int p = 0; p < L; p++) fprintf(mf, " %d", gaps[(size_t)p]);
+    fprintf(mf, "\n__PSSM__\nDEPTH %d\nFPSM:\n", PSSM_DEPTH);
+    for (int d = 0; d < 31; d++) { for (int r = 0; r < 5; r++) fprintf(mf, "%d %d %d %d %d\n", anc.sm[d][r][0], anc.sm[d][r][1], anc.sm[d][r][2], anc.sm[d][r][3], anc.sm[d][r][4]); fprintf(mf, "\n"); }
+    fprintf(mf, "RPSM:\n");
+    for (int d = 0; d < 31; d++) { for (int r = 0; r < 5; r++) fprintf(mf, "%d %d %d %d %d\n", rcanc.sm[d][r][0], rcanc.sm[d][r][1], rcanc.sm[d][r][2], rcanc.sm[d][r][3], rcanc.sm[d][r][4]); fprintf(mf, "\n"); }
+    fprintf(mf, "__ALNSEQS__\n");
+    for (int k : order) {
+      const Record& a = recs[(size_t)k];
+      fprintf(mf, "ID %s\nDESC %s\nSCORE %d\nNUM_INPUTS 1\nSTART %d\nEND %d\nRC %d\nTR 0\nDR %d\nSEG %c\nSEQ %s\nSMP %s\nINS_POS", a.id.c_str(), a.desc.c_str(),
+              a.score, a.start, a.end, a.rc ? 1 : 0, a.dropped ? 1 : 0, a.segment, a.seq.c_str(), a.smp.c_str());
+      for (auto& in : a.ins) fprintf(mf, " %d %s", in.first, in.second.c_str());
+      fprintf(mf, "\n");
+    }
+    fclose(mf);
+  };
+
+  auto consensus = [&]() {
+    std::string out(cons.size() * 2 + (1 << 20), '\0');
+    int64_t clen = 0;
+    if (mia_hip_consensus(g, cc, &out[0], (int64_t)out.size(), &clen) != MIA_HIP_OK) die(g, "consensus");
+    out.resize((size_t)clen);
+    return out;
+  };
+
+  // ---- main loop (src/mia_main.c:878-976)
+  int iter_num = 1;
+  iteration(iter_num);
+  if (!iterate || !final_only) write_maln(maln_root + "." + std::to_string(iter_num));
+  if (iterate) {
+    fprintf(stderr, "Generating new assembly consensus\n");
+    std::string next = consensus();
+    while (next != cons && iter_num < MAX_ITER) {
+      iter_num++;
+      cons = next;
+      fprintf(stderr, "Starting assembly iteration %d\n", iter_num);
+      iteration(iter_num);
+      if (!final_only) { fprintf(stderr, "Writing maln file for iteration %d\n", iter_num); write_maln(maln_root + "." + std::to_string(iter_num)); }
+      next = consensus();
+    }
+    if (next == cons) fprintf(stderr, "Assembly convergence - writing final maln\n");
+    else fprintf(stderr, "Assembly did not converge after %d rounds, quitting\n", iter_num);
+    if (final_only) write_maln(maln_root + "." + std::to_string(iter_num));
+  }
+  now = time(NULL);
+  fprintf(stderr, "Assembly finished at %s\n", asctime(localtime(&now)));
+  mia_hip_destroy(g);
+  return 0;
+}
