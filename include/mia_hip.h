@@ -141,6 +141,17 @@ int mia_hip_get_tally(mia_hip_ctx *ctx, int32_t *tally, int32_t *gaps); /* host 
  * out must hold ref_len + sum(gaps) + 1 bytes; *out_len = strlen(out). */
 int mia_hip_consensus(mia_hip_ctx *ctx, int cons_code, char *out, int64_t out_cap, int64_t *out_len);
 
+/* ---- Myers edit distance -------------------------------------------------- */
+
+/* unsigned myers_diff(const char *seq_a, enum myers_align_mode mode, const char* seq_b, int maxd,
+ *                     char *bt_a, char *bt_b)                                -- src/myers_align.h:35
+ * for a batch of pairs: unit-cost edit distance with IUPAC-compatible matching, modes 0/1/2 as
+ * the enum (global / only seq_b must be consumed / only seq_a must be consumed, src/myers_align.c:39-40).
+ * dist[i] = distance, or 0xFFFFFFFF when it is >= maxd[i] (maxd clamped to len_a+len_b, :13).
+ * The backtrace strings of the reference are not produced.  seq_a up to 32768 characters. */
+int mia_hip_myers(mia_hip_ctx *ctx, int64_t n_pairs, const char *const *seq_a, const char *const *seq_b, const int32_t *mode,
+                  const int32_t *maxd, uint32_t *dist);
+
 /* ---- timing hooks for bench.py (HIP events on the context's stream) ------ */
 /* milliseconds spent in, and launches of, the windowed DP kernel since the last reset */
 int mia_hip_kernel_time(mia_hip_ctx *ctx, int reset, double *align_ms, int64_t *align_launches);

@@ -53,6 +53,7 @@ def _load():
     lib.mia_hip_set_ins_events.argtypes = [vp, vp, C.c_int64]
     lib.mia_hip_get_tally.argtypes = [vp, vp, vp]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
+    lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
     return lib
 
@@ -73,7 +74,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_kernel_time"]
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time"]
 
 
 def _ptr(a):
@@ -248,6 +249,17 @@ class MiaHip:
         n = C.c_int64()
         self._chk(self._l.mia_hip_consensus(self._h, cons_code, buf, cap, C.byref(n)))
         return buf.raw[: n.value].decode()
+
+    def myers(self, seq_a, seq_b, mode, maxd):
+        """Batch of myers_diff calls (reference src/myers_align.h:35): distances, 0xFFFFFFFF if >= maxd."""
+        n = len(seq_a)
+        A = (C.c_char_p * n)(*[s.encode() if isinstance(s, str) else s for s in seq_a])
+        B = (C.c_char_p * n)(*[s.encode() if isinstance(s, str) else s for s in seq_b])
+        mode = np.ascontiguousarray(mode, dtype=np.int32)
+        maxd = np.ascontiguousarray(maxd, dtype=np.int32)
+        out = np.zeros(n, dtype=np.uint32)
+        self._chk(self._l.mia_hip_myers(self._h, n, A, B, _ptr(mode), _ptr(maxd), _ptr(out)))
+        return out
 
     def kernel_time(self, reset=False):
         ms, k = C.c_double(), C.c_int64()

@@ -12,6 +12,7 @@
 #include "mia_consensus_kernels.h"
 #include "mia_kernels.h"
 #include "mia_pass1_kernels.h"
+#include "mia_myers_kernels.h"
 
 using namespace mia;
 
@@ -752,5 +753,45 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   cleanup();
   if (e != hipSuccess) { ctx->err = std::string("pass1: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  return MIA_HIP_OK;
+}
+
+// ---- Myers ------------------------------------------------------------------------------
+extern "C" int mia_hip_myers(mia_hip_ctx* ctx, int64_t n, const char* const* seq_a, const char* const* seq_b, const int32_t* mode,
+                             const int32_t* maxd, uint32_t* dist) {
+  if (!ctx || n < 0 || (n > 0 && (!seq_a || !seq_b || !mode || !maxd || !dist))) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n == 0) return MIA_HIP_OK;
+  std::vector<MyersPair> pairs((size_t)n);
+  std::string blob;
+  std::vector<size_t> oa((size_t)n), ob((size_t)n);
+  int max_blk = 1;
+  for (int64_t i = 0; i < n; i++) {
+    const size_t la = strlen(seq_a[i]), lb = strlen(seq_b[i]);
+    if (la > 64u * 64u * MYERS_MAX_K) { ctx->err = "seq_a longer than 32768 characters"; return MIA_HIP_ERR_ARG; }
+    oa[i] = blob.size(); blob.append(seq_a[i], la);
+    ob[i] = blob.size(); blob.append(seq_b[i], lb);
+    pairs[i].la = (int32_t)la; pairs[i].lb = (int32_t)lb; pairs[i].mode = mode[i]; pairs[i].maxd = maxd[i];
+    const int nb = (int)((la + 63) / 64);
+    if (nb > max_blk) max_blk = nb;
+  }
+  char* d_blob = nullptr;
+  MyersPair* d_pairs = nullptr;
+  uint32_t* d_out = nullptr;
+  if (dev_alloc(ctx, &d_blob, blob.size() + 1) || dev_alloc(ctx, &d_pairs, (size_t)n) || dev_alloc(ctx, &d_out, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+  for (int64_t i = 0; i < n; i++) { pairs[i].a = d_blob + oa[i]; pairs[i].b = d_blob + ob[i]; }
+  hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, pairs.data(), (size_t)n * sizeof(MyersPair), hipMemcpyHostToDevice, ctx->stream);
+  const int lds = 16 * max_blk * 8;
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_myers, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) {
+    const int grid = (int)(n < 8192 ? n : 8192);
+    hipLaunchKernelGGL(k_myers, dim3(grid), dim3(64), lds, ctx->stream, d_pairs, (int32_t)n, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_blob); (void)hipFree(d_pairs); (void)hipFree(d_out);
+  if (e != hipSuccess) { ctx->err = std::string("myers: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   return MIA_HIP_OK;
 }
