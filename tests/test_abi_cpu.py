@@ -23,7 +23,7 @@ def mia():
 
 def test_every_declared_symbol_is_exported(mia):
     hdr = open(os.path.join(ROOT, "include", "mia_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(mia_hip_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(mia_hip_[a-z_0-9]+)\s*\(", hdr)))
     assert len(declared) >= 20
     lib = mia.lib()
     missing = [s for s in declared if not hasattr(lib, s)]
