@@ -33,6 +33,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BYTES_PER_READ = 182      # 50 B packed bases + 16 B meta in, 16 B result + 100 B script out
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# memory-side bytes per read of k_align_window<4>, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two
+# separate passes (profiles/r01/pmc/summary_kb_per_launch.json: 5.60e6 KB + 19.78e6 KB per 1 M-read launch, counters as
+# reported, no width correction): almost all of it is the 20 KB/read byte trace going to the per-workgroup slabs
+TRAFFIC_BYTES_PER_READ = (5604250 + 19779321) * 1024 / 1_000_000
 
 
 class DevArray:
@@ -117,9 +121,20 @@ def main():
     hip.set_pssm(mia_amd.flat_pssm())
     hip.upload_reads(stored.reshape(-1), offsets, rc, np.ones(n, np.uint8), as_, ae)
 
+    phase = {}
+
+    def tick(name, t0):
+        if os.environ.get("MIA_BENCH_BREAKDOWN"):
+            hip.sync()
+            phase[name] = phase.get(name, 0.0) + (time.perf_counter() - t0)
+        return time.perf_counter()
+
     def step(cur_ref):
+        t0 = time.perf_counter()
         hip.realign(cur_ref, True)
+        t0 = tick("realign", t0)
         score, _, _ = hip.alignments()
+        t0 = tick("get_scores", t0)
         slot_base = 0
         if world > 1:
             from mia_amd import dist as mdist
@@ -129,10 +144,13 @@ def main():
             slot_base = mdist.exclusive_rank_sum(hip.num_records(), "cuda")
         else:
             slope, intercept = hip.score_cut(score, lens)
+        t0 = tick("score_cut", t0)
         if slope <= 0:
             slope = 100.0
         hip.cull(0, slope, intercept, slot_base)
+        t0 = tick("cull", t0)
         hip.tally()
+        t0 = tick("tally", t0)
         if world > 1:
             pt, nt, pg, ng = hip.tally_buffers()
             mdist.allreduce_tallies(torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda"),
@@ -142,7 +160,9 @@ def main():
             allev = mdist.all_gather_ragged(mine)
             torch.cuda.synchronize()
             hip.set_ins_events(allev.data_ptr() if allev.numel() else 0, int(allev.numel()))
-        return hip.consensus(1)
+        c = hip.consensus(1)
+        tick("consensus", t0)
+        return c
 
     cur = ref
     for _ in range(a.warmup):
@@ -180,11 +200,24 @@ def main():
                                    "step = reiterate_assembly + cull + consensus; pass-1 coordinates = true positions" % n,
                        "reads_per_gpu": n, "consensus_len": len(cur)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_READ * reads_per_launch,
                          "kernel": "k_align_window<4>", "kernel_ms": k_ms, "launches": launches,
                          "note": "integer-VALU/LDS-bound DP: 182 algorithmic HBM bytes per read (SURVEY 8d); see DESIGN.md for GCUPS vs VALU peak",
                          "gcups": reads_per_launch * 100 * 200 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
         }
+        # pass 1 (new_kmer_filter + sg_align over the whole wrapped reference, both strands), reported separately
+        import gen_data
+        m = min(n, 50_000)
+        seq = np.where(rc[:m, None] == 1, gen_data._COMP[stored[:m, ::-1]], stored[:m]).astype(np.uint8)   # as sequenced
+        p1 = {}
+        for label, k in (("k12", 12), ("no_kmer", -1)):
+            hip.pass1(ref, True, seq[:256].reshape(-1), offsets[:257], k)          # warm-up
+            t1 = time.perf_counter()
+            sc, _, _, _, fl = hip.pass1(ref, True, seq.reshape(-1), offsets[: m + 1], k)
+            p1[label] = {"reads_per_s": m / (time.perf_counter() - t1), "reads": m, "kept": int((fl & 2).astype(bool).sum())}
+        out["pass1"] = p1
+        if phase:
+            out["phase_ms_per_step"] = {k: v / (a.steps + a.warmup) * 1e3 for k, v in phase.items()}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, stored, rc, as_, ae)
         print(json.dumps(out))

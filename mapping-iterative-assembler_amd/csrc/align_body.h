@@ -40,6 +40,7 @@ struct AlignArgs {            // everything here is wave-uniform
   uint32_t lds_sub;           // LDS byte offset: int16 sub[5][rows padded to even]
   uint32_t trace_stride;      // bytes per trace row, multiple of 4, >= len1
   int16_t* cols_out;          // script: window column per read row            [global]
+  uint32_t dbg;               // timing experiments only (0 in production): 1 = no trace stores, 2 = no traceback, 4 = no row loop
 };
 
 struct AlignResult {          // wave-uniform
@@ -114,7 +115,7 @@ struct WindowAligner {
     }
 
     // ---- 4. rows 1 .. len2-1
-    for (int r = 1; r < len2; r++) {
+    for (int r = 1; r < ((a.dbg & 4u) ? 1 : len2); r++) {
       const int32_t fresh = a.sg5 ? -(GOP + GEP * (r + 1)) : 0;            // src/mia.c:877-880
       const uint32_t freshb = (uint32_t)(fresh + (int32_t)OFF);
       const uint32_t WS = freshb << SH;                                     // prio 0, len 0
@@ -152,7 +153,7 @@ struct WindowAligner {
         // start (only if strictly better than the other three) drops the substitution score (src/mia.c:910-917)
         Snew[j] = (best[j] >> SH) + w.sel(m3 < WS, U(0u), sub);
       }
-      for (int j4 = 0; j4 < CPL; j4 += 4)
+      if (!(a.dbg & 1u)) for (int j4 = 0; j4 < CPL; j4 += 4)
         w.tr_w32(U(row_tr) + col[j4], w.template trace_pack4<IB>(best[j4], best[j4 + 1], best[j4 + 2], best[j4 + 3]),
                  col[j4] < (uint32_t)a.trace_stride);
       for (int j = 0; j < CPL; j++) {
@@ -183,7 +184,7 @@ struct WindowAligner {
     int r = len2 - 1, c = res.aec;
     uint32_t status = ST_OK;
     int aln_cols = 0;
-    for (int guard = 0; guard < 4 * MAX_READ + 8; guard++) {
+    for (int guard = 0; guard < ((a.dbg & 2u) ? 0 : 4 * MAX_READ + 8); guard++) {
       // lane i inspects cell (r-i, c-i)
       U ri = U((uint32_t)r) - lane, ci = U((uint32_t)c) - lane;
       M inside = (lane <= (uint32_t)r) & (lane <= (uint32_t)c);

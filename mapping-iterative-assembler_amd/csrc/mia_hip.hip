@@ -48,6 +48,7 @@ struct mia_hip_ctx {
   // trace slabs of the persistent DP grid (one per workgroup, per CPL class)
   unsigned char* d_slabs[N_CPL] = {nullptr, nullptr, nullptr};
   int grid_wgs = 0;
+  uint32_t dbg = 0;   // MIA_HIP_DEBUG_SKIP: timing experiments only, results are wrong when set
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
@@ -92,6 +93,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
     ctx->grid_wgs = prop.multiProcessorCount * 32;
+    const char* dbg = getenv("MIA_HIP_DEBUG_SKIP");
+    if (dbg) ctx->dbg = (uint32_t)atoi(dbg);
     const char* g = getenv("MIA_HIP_GRID_WAVES_PER_CU");
     if (g && atoi(g) > 0) ctx->grid_wgs = prop.multiProcessorCount * atoi(g);
   }
@@ -273,7 +276,7 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
   RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
   (void)hipEventRecord(e0, ctx->stream);
   hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
-                     count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS);
+                     count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg);
   (void)hipEventRecord(e1, ctx->stream);
   return hipGetLastError();
 }

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin
 template <int CPL>
 __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackParams pk,
                                                       const int32_t* list, int32_t count, unsigned char* trace_slabs,
-                                                      int64_t slab_bytes, int32_t* wide_list, int32_t* wide_count) {
+                                                      int64_t slab_bytes, int32_t* wide_list, int32_t* wide_count, uint32_t dbg) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SUB_LDS_BYTES];
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
   for (int w = blockIdx.x; w < count; w += gridDim.x) {
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, co
     a.lds_sub = 0;
     a.trace_stride = (uint32_t)((l1 + 3) & ~3);
     a.cols_out = rs.cols + (int64_t)i * rs.stride;
+    a.dbg = dbg;
     AlignResult r = WindowAligner<DevWave, CPL>::run(wave, a);
     if (wave.lane() == 0) {
       if (r.status & ST_ESCAPE) {

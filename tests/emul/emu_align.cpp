@@ -25,6 +25,7 @@ static int run_one(const uint8_t* ref_codes, int ref_start, int len1, const uint
   a.lds_sub = 0;
   a.trace_stride = (uint32_t)((len1 + 3) & ~3);
   a.cols_out = cols;
+  a.dbg = 0;
   EmuWave w((size_t)len2 * 10 + 16, (size_t)len2 * a.trace_stride + 16);
   AlignResult r = WindowAligner<EmuWave, CPL>::run(w, a);
   out5[0] = r.score; out5[1] = r.abc; out5[2] = r.abr; out5[3] = r.aec; out5[4] = (int32_t)r.status;
