@@ -108,7 +108,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
-    if world > 1:
+    force_dist = os.environ.get("MIA_BENCH_FORCE_DIST") == "1"   # exercise the RCCL code path on one GPU
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -136,7 +142,8 @@ def main():
         score, _, _ = hip.alignments()
         t0 = tick("get_scores", t0)
         slot_base = 0
-        if world > 1:
+        sharded = world > 1 or force_dist
+        if sharded:
             from mia_amd import dist as mdist
             # the score-cut regression runs over ALL reads in fsdb order (src/fsdb.c:269-383)
             all_scores = mdist.all_gather_concat(torch.from_numpy(score).cuda()).cpu().numpy()
@@ -151,7 +158,8 @@ def main():
         t0 = tick("cull", t0)
         hip.tally()
         t0 = tick("tally", t0)
-        if world > 1:
+        if sharded:
+            from mia_amd import dist as mdist
             pt, nt, pg, ng = hip.tally_buffers()
             mdist.allreduce_tallies(torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda"),
                                     torch.as_tensor(DevArray(pg, ng, "<i4"), device="cuda"))
@@ -221,7 +229,7 @@ def main():
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ref, stored, rc, as_, ae)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

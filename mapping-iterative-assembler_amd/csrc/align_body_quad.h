@@ -1,0 +1,204 @@
+// align_body_quad.h -- the windowed DP of align_body.h for FOUR reads per wavefront.
+//
+// A 100 bp read has a 200-column window; on 64 lanes x 4 columns a quarter of the lanes
+// idle and the cross-lane work (prefix scan, neighbour shifts) is paid once per 4 cells.
+// Here each read gets one 16-lane DPP row and every lane owns 13 columns (208 per read):
+// 96 % of the lanes carry real columns, the row_shr DPP forms never leave a 16-lane row
+// (no masking needed between the four reads), the scan needs 4 steps instead of 6, and
+// its cost is spread over 13 cells.  The four reads of a quad must have the same length
+// (the planner pads each length bin to a multiple of four with empty slots); window
+// lengths, strands and positions are per read.  Arithmetic, packed words and tie rules
+// are exactly those of align_body.h (IB = 8: all indices < 256).
+#pragma once
+#include "align_body.h"
+#include "mia_layout.h"
+
+namespace mia {
+
+constexpr int Q_CPL = 13, Q_LPR = 16, Q_G = 4, Q_COLS = Q_CPL * Q_LPR;   // 208 columns per read
+constexpr int Q_TRACE_STRIDE = Q_LPR * 16;                               // 16 trace bytes per lane and row
+
+struct QuadArgs {                 // wave-uniform; [g] = read of lane row g, len1 == 0 marks an empty slot
+  const uint8_t* ref_codes;
+  const uint8_t* packed;          // base of the packed read store
+  const int32_t* pssm2;           // forward PSSM followed by the reverse-complemented one
+  int32_t len2;                   // common read length of the quad
+  int32_t ref_start[Q_G], len1[Q_G];
+  uint32_t roff[Q_G], rc[Q_G];
+  PackParams pk;                  // ib = 8
+  uint32_t lds_sub;               // LDS: 4 tables int16 sub[5][rows padded to even], Q_SUB_BYTES apart
+  uint32_t slab_group;            // bytes between the trace areas of two reads inside the workgroup slab
+  int16_t* cols_out[Q_G];
+  uint32_t dbg;
+};
+constexpr uint32_t Q_SUB_BYTES = MAX_READ * 10;
+
+template <class P>
+struct QuadAligner {
+  typedef typename P::U U;
+  typedef typename P::M M;
+  static constexpr int CPL = Q_CPL, IB = 8, SH = 10;
+  static constexpr uint32_t IDXM = 255u;
+
+  MIA_HD static inline __attribute__((always_inline)) void run(P& w, const QuadArgs& a, AlignResult* res /* [Q_G] */) {
+    const uint32_t OFF = (uint32_t)a.pk.off;
+    const uint32_t UNAV = ((uint32_t)a.pk.unavail << SH) | IDXM;
+    const U lane = w.lane();
+    const U grp = lane >> 4, gl = lane & 15u;
+    const int len2 = a.len2;
+    const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;
+    // per-lane copies of the per-read scalars
+    U len1v = U(0u), startv = U(0u), roffv = U(0u), pmoff = U(0u);
+    for (int g = 0; g < Q_G; g++) {
+      M mine = grp == (uint32_t)g;
+      len1v = w.sel(mine, U((uint32_t)a.len1[g]), len1v);
+      startv = w.sel(mine, U((uint32_t)a.ref_start[g]), startv);
+      roffv = w.sel(mine, U(a.roff[g]), roffv);
+      pmoff = w.sel(mine, U(a.rc[g] ? (uint32_t)PSSM_WORDS : 0u), pmoff);
+    }
+    const U subbase = U(a.lds_sub) + grp * Q_SUB_BYTES;
+    const U trbase = grp * a.slab_group + gl * 16u;
+
+    // ---- substitution tables, 16 lanes per read
+    for (int e0 = 0; e0 < len2 * 5; e0 += Q_LPR) {
+      U e = gl + (uint32_t)e0;
+      M ok = e < (uint32_t)(len2 * 5);
+      U r = w.udiv5(e);
+      U c1 = e - r * 5u;
+      U byte = w.gload_u8(a.packed, roffv + (r >> 1), ok);
+      U c2 = (byte >> ((r & 1u) << 2)) & 15u;
+      U d = w.depth(r, (uint32_t)len2);
+      U v = w.gload_i32(a.pssm2, pmoff + (d * 5u + c1) * 5u + c2, ok);
+      w.lds_w16(subbase + c1 * RS2 + r * 2u, v, ok);
+    }
+    w.lds_fence();
+
+    // Register diet (3 -> 4 waves per SIMD): the column-gap constant is affine in the column
+    // (KC[j] = KC0 + j*KCD), the best_gap_row key of row r-1 is rebuilt from the old score when
+    // it is needed, substitution scores are read as sign-extended 16-bit LDS loads, and the
+    // cells of a row are visited right to left so that every column is updated in place.
+    U col[CPL], sub_addr[CPL], QC[CPL];
+    for (int j = 0; j < CPL; j++) {
+      col[j] = gl * (uint32_t)CPL + (uint32_t)j;
+      M in = col[j] < len1v;
+      U code = w.sel(in, w.gload_u8(a.ref_codes, startv + col[j], in), U(4u));
+      sub_addr[j] = subbase + code * RS2;
+      QC[j] = ((col[j] * (uint32_t)GEP) << SH) + (U(IDXM) - col[j]);
+    }
+    // key -> column-gap candidate: value -= GOP + GEP*(c-1); prio = 2; idx -> len = c-1-k
+    const U KC0 = (U(0u) - ((U((uint32_t)GOP) + (col[0] - 1u) * (uint32_t)GEP) << SH)) + (TR_COLGAP << IB) + (col[0] - 1u - IDXM);
+    const uint32_t KCD = 1u - ((uint32_t)GEP << SH);
+    const uint32_t WDC = TR_DIAG << IB;
+    const U unav = U(UNAV);
+
+    U Sb[CPL], q[CPL], rrun[CPL];
+    for (int j = 0; j < CPL; j++) {
+      Sb[j] = w.lds_ri16(sub_addr[j]) + OFF;
+      q[j] = (Sb[j] << SH) + QC[j];
+      rrun[j] = unav;
+    }
+    {
+      const U d4 = U((TR_DIAG << 6) * 0x01010101u);
+      w.tr_w128(trbase, d4, d4, d4, d4);
+    }
+
+    for (int r = 1; r < ((a.dbg & 4u) ? 1 : len2); r++) {
+      const int32_t fresh = -(GOP + GEP * (r + 1));
+      const uint32_t freshb = (uint32_t)(fresh + (int32_t)OFF);
+      const uint32_t WS = freshb << SH;
+      const uint32_t KR = (0u - ((uint32_t)(GOP + GEP * (r - 1)) << SH)) + (TR_ROWGAP << IB) + ((uint32_t)(r - 1) - IDXM);
+      const uint32_t RKP = ((uint32_t)(GEP * (r - 1)) << SH) + (IDXM - (uint32_t)(r - 1));   // key constant of row r-1
+
+      U dleft = w.rshr1(Sb[CPL - 1], U(freshb));
+      U rleft = w.rshr1_max(rrun[CPL - 1], unav);
+      U u0 = w.rshr1_max(q[CPL - 2], unav);
+      U u1 = w.rshr1_max(q[CPL - 1], unav);
+      U g[CPL];
+      g[0] = u0;
+      g[1] = w.umax(u0, u1);
+      for (int j = 2; j < CPL; j++) g[j] = w.umax(g[j - 1], q[j - 2]);
+      U excl = w.rshr1_max(w.rscan_max(g[CPL - 1]), unav);
+
+      U bq[4], packed[4];
+      for (int j = CPL - 1; j >= 0; j--) {
+        U diag = (j == 0) ? dleft : Sb[j - 1];
+        U rl = (j == 0) ? rleft : rrun[j - 1];
+        U Wd = (diag << SH) + WDC;
+        U Wc = w.add3(w.umax(excl, g[j]), KC0, (uint32_t)j * KCD);
+        U Wr = rl + KR;
+        U m3 = w.umax3(Wd, Wc, Wr);
+        U best = w.umax(m3, U(WS));
+        U sub = w.lds_ri16(sub_addr[j] + (uint32_t)r * 2u);
+        U snew = (best >> SH) + w.sel(m3 < WS, U(0u), sub);
+        rrun[j] = w.umax(rrun[j], (Sb[j] << SH) + RKP);   // row r-1 becomes a best_gap_row candidate for row r+1
+        Sb[j] = snew;
+        q[j] = (snew << SH) + QC[j];
+        bq[j & 3] = best;
+        if (j == CPL - 1) packed[3] = w.template trace_pack4<IB>(best, best, best, best);
+        else if ((j & 3) == 0) packed[j >> 2] = w.template trace_pack4<IB>(bq[0], bq[1], bq[2], bq[3]);
+      }
+      if (!(a.dbg & 1u)) w.tr_w128(trbase + (uint32_t)r * Q_TRACE_STRIDE, packed[0], packed[1], packed[2], packed[3]);
+    }
+
+    // ---- max_sg_score per read (16-lane row)
+    U m = U(0u);
+    for (int j = 0; j < CPL; j++) m = w.umax(m, w.sel(col[j] < len1v, Sb[j], U(0u)));
+    const U bestv = w.row_last(w.rscan_max(m));
+    U cmin = U(0x7FFFFFFFu);
+    for (int j = CPL - 1; j >= 0; j--) cmin = w.sel((col[j] < len1v) & (Sb[j] == bestv), col[j], cmin);
+    const U aecv = ~w.row_last(w.rscan_max(~cmin));
+    w.tr_fence();
+
+    // ---- traceback, one read after the other with all 64 lanes (same walk as align_body.h;
+    //      trace rows here are [16 lanes][16 bytes], column c lives at (c/13)*16 + c%13)
+    for (int gi = 0; gi < Q_G; gi++) {
+      AlignResult& rs = res[gi];
+      rs.score = 0; rs.abc = 0; rs.abr = 0; rs.aec = 0; rs.status = ST_SKIPPED;
+      if (a.len1[gi] <= 0) continue;
+      rs.score = (int32_t)(w.lane_val(bestv, gi * Q_LPR) - OFF);
+      rs.aec = (int32_t)w.lane_val(aecv, gi * Q_LPR);
+      const uint32_t tb0 = (uint32_t)gi * a.slab_group;
+      int r = len2 - 1, c = rs.aec, aln_cols = 0;
+      uint32_t status = ST_OK;
+      for (int guard = 0; guard < ((a.dbg & 2u) ? 0 : 4 * MAX_READ + 8); guard++) {
+        U ri = U((uint32_t)r) - lane, ci = U((uint32_t)c) - lane;
+        M inside = (lane <= (uint32_t)r) & (lane <= (uint32_t)c);
+        U cl = w.udiv13(ci);
+        U tb = w.tr_r8(U(tb0) + ri * Q_TRACE_STRIDE + cl * 16u + (ci - cl * 13u), inside);
+        U ty = tb >> 6, ln = tb & 63u;
+        M colgap0 = (ty == U(TR_COLGAP)) & (ln + 1u == ci) & (ln < U(TR_LEN_SAT));
+        M rowgap0 = (ty == U(TR_ROWGAP)) & (ln + 1u == ri) & (ln < U(TR_LEN_SAT));
+        M plain_diag = (ty == U(TR_DIAG)) | colgap0 | rowgap0;
+        M terminal = (ri == U(0u)) | (ci == U(0u)) | (ty == U(TR_START));
+        M stop_here = (!inside) | terminal | (!plain_diag);
+        uint64_t bal = w.ballot(stop_here);
+        int f = bal ? __builtin_ctzll(bal) : WAVE;
+        int npairs = f < WAVE ? f + 1 : WAVE;
+        if (f < WAVE && !w.lane_bit(inside, f)) npairs = f;
+        w.gstore_i16(a.cols_out[gi], ri, ci, lane < (uint32_t)npairs);
+        aln_cols += npairs;
+        if (f == WAVE) { r -= WAVE; c -= WAVE; continue; }
+        const uint32_t fty = w.lane_val(ty, f), fln = w.lane_val(ln, f);
+        const bool fterm = w.lane_bit(terminal, f);
+        const int fr = r - f, fc = c - f;
+        if (fterm) { rs.abr = fr; rs.abc = fc; break; }
+        if (fln >= TR_LEN_SAT) { status |= ST_ESCAPE; rs.abr = fr; rs.abc = fc; break; }
+        if (fty == TR_COLGAP) { r = fr - 1; c = fc - 1 - (int)fln; aln_cols += (int)fln; }
+        else {
+          U rr = U((uint32_t)(fr - 1)) - lane;
+          w.gstore_i16(a.cols_out[gi], rr, U((uint32_t)(uint16_t)COL_INSERT), lane < fln);
+          r = fr - 1 - (int)fln; c = fc - 1;
+          aln_cols += (int)fln;
+        }
+      }
+      for (int r0 = 0; r0 < rs.abr; r0 += WAVE) {
+        U rr = lane + (uint32_t)r0;
+        w.gstore_i16(a.cols_out[gi], rr, U((uint32_t)(uint16_t)COL_CLIP), rr < (uint32_t)rs.abr);
+      }
+      if (aln_cols > 2 * MAX_READ) status |= ST_TOO_LONG;
+      rs.status = status;
+    }
+  }
+};
+
+}  // namespace mia

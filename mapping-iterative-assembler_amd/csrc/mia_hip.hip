@@ -47,6 +47,9 @@ struct mia_hip_ctx {
   int64_t ins_calls_cap = 0; int32_t n_events_host = 0; bool tallied = false;
   // trace slabs of the persistent DP grid (one per workgroup, per CPL class)
   unsigned char* d_slabs[N_CPL] = {nullptr, nullptr, nullptr};
+  unsigned char* d_quad_slabs = nullptr;
+  int quad_wgs = 0;
+  int use_quad = 1;   // MIA_HIP_NO_QUAD=1 routes everything through the one-read-per-wave kernels
   int grid_wgs = 0;
   uint32_t dbg = 0;   // MIA_HIP_DEBUG_SKIP: timing experiments only, results are wrong when set
   // wide scratch
@@ -93,6 +96,11 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
     ctx->grid_wgs = prop.multiProcessorCount * 32;
+    ctx->quad_wgs = prop.multiProcessorCount * 16;   // 128 VGPRs -> 4 waves per SIMD
+    const char* nq = getenv("MIA_HIP_NO_QUAD");
+    if (nq && atoi(nq)) ctx->use_quad = 0;
+    const char* qw = getenv("MIA_HIP_QUAD_WAVES_PER_CU");
+    if (qw && atoi(qw) > 0) ctx->quad_wgs = prop.multiProcessorCount * atoi(qw);
     const char* dbg = getenv("MIA_HIP_DEBUG_SKIP");
     if (dbg) ctx->dbg = (uint32_t)atoi(dbg);
     const char* g = getenv("MIA_HIP_GRID_WAVES_PER_CU");
@@ -116,7 +124,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_bins, ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
                   ctx->d_drop_b, ctx->tb.tally, ctx->tb.gaps, ctx->tb.events, ctx->tb.n_events, ctx->tb.flags, ctx->d_ins_off,
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
-                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2]};
+                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -197,7 +205,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_status, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_cols, (size_t)n * stride);
   rcx |= dev_alloc(ctx, &ctx->d_bin_of, (size_t)n);
-  rcx |= dev_alloc(ctx, &ctx->d_list, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_list, (size_t)n + 4 * N_BINS);   // quad bins are padded to multiples of four
   rcx |= dev_alloc(ctx, &ctx->d_wide_list, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_slot, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_partial, (size_t)(n / 4096 + 2));
@@ -305,12 +313,17 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   int32_t* d_wide_count = ctx->d_bins + 3 * N_BINS;
   HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 1) * 4, ctx->stream));
   const int tb = 256, gb = (int)((n + tb - 1) / tb);
-  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->d_bin_of, d_count);
+  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, ctx->d_bin_of, d_count);
   int32_t h_count[N_BINS], h_off[N_BINS];
   HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   int run = 0;
-  for (int b = 0; b < N_BINS; b++) { h_off[b] = run; run += h_count[b]; }
+  for (int b = 0; b < N_BINS; b++) {
+    h_off[b] = run;
+    run += b >= BIN_QUAD0 ? ((h_count[b] + 3) & ~3) : h_count[b];   // quad bins: every read length padded to whole quads
+  }
+  const int quad_begin = h_off[BIN_QUAD0], n_quads = (run - quad_begin) / 4;
+  if (n_quads > 0) HIPCHK(hipMemsetAsync(ctx->d_list + quad_begin, 0xFF, (size_t)(run - quad_begin) * 4, ctx->stream));   // -1 = empty slot
   HIPCHK(hipMemcpyAsync(d_off, h_off, sizeof h_off, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
   // reads that need the exact kernel from the start: copy their list to the head of wide_list
@@ -325,6 +338,18 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
                  : ci == 1 ? launch_window<8>(ctx, ci, ctx->d_list + h_off[ci], h_count[ci])
                            : launch_window<12>(ctx, ci, ctx->d_list + h_off[ci], h_count[ci]);
     if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  }
+  if (n_quads > 0) {
+    const int64_t slab = (int64_t)Q_G * MAX_READ * Q_TRACE_STRIDE;
+    const int grid = n_quads < ctx->quad_wgs ? n_quads : ctx->quad_wgs;
+    if (!ctx->d_quad_slabs && hipMalloc((void**)&ctx->d_quad_slabs, (size_t)slab * ctx->quad_wgs) != hipSuccess) return MIA_HIP_ERR_NOMEM;
+    hipEvent_t e0, e1;
+    if (get_events(ctx, &e0, &e1)) return MIA_HIP_ERR_NOMEM;
+    (void)hipEventRecord(e0, ctx->stream);
+    hipLaunchKernelGGL(k_align_quad, dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list + quad_begin,
+                       n_quads, ctx->d_quad_slabs, slab, ctx->d_wide_list, d_wide_count, ctx->dbg);
+    (void)hipEventRecord(e1, ctx->stream);
+    HIPCHK(hipGetLastError());
   }
   // exact kernel for whole-reference windows and escaped reads
   int32_t n_wide = 0;

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "align_body.h"
+#include "align_body_quad.h"
 #include "mia_layout.h"
 #include "wave_dev.h"
 
@@ -20,7 +21,8 @@ namespace mia {
 
 constexpr int N_CPL = 3;                 // CPL 4, 8, 12  -> windows of up to 256 / 512 / 768 columns
 constexpr int BIN_WIDE = N_CPL;          // exact int32 kernel (whole-reference windows, escapes, overflow)
-constexpr int N_BINS = BIN_WIDE + 1;
+constexpr int BIN_QUAD0 = BIN_WIDE + 1;  // + read length: windows <= 208 columns, four equally long reads per wavefront
+constexpr int N_BINS = BIN_QUAD0 + MAX_READ + 1;
 constexpr int SUB_LDS_BYTES = MAX_READ * 10;   // int16 sub[len2][5]
 
 struct ReadSet {
@@ -56,8 +58,8 @@ MIA_HD inline void realign_window(int as, int ae, int len2, int wrap, int* ref_s
 
 struct PackSet { PackParams p[N_CPL]; int ok[N_CPL]; };
 
-MIA_HD inline int classify(int len2, int len1, const PackSet& ps) {
-  (void)len2;
+MIA_HD inline int classify(int len2, int len1, const PackSet& ps, int use_quad) {
+  if (use_quad && len1 <= Q_COLS && ps.ok[0]) return BIN_QUAD0 + len2;
   int ci = len1 <= 256 ? 0 : (len1 <= 512 ? 1 : (len1 <= 768 ? 2 : -1));
   if (ci < 0 || !ps.ok[ci]) return BIN_WIDE;
   return ci;
@@ -66,9 +68,9 @@ MIA_HD inline int classify(int len2, int len1, const PackSet& ps) {
 // ---- plan: bin every read by kernel variant and LDS footprint ----------------
 // Counts go through an LDS histogram per block, so global memory sees one atomic per
 // (block, non-empty bin) instead of one per read on a single hot address.
-__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int32_t* bin_of, int32_t* bin_count) {
+__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int32_t* bin_of, int32_t* bin_count) {
   __shared__ int32_t hist[N_BINS];
-  if (threadIdx.x < N_BINS) hist[threadIdx.x] = 0;
+  for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < rs.n) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
     if (rs.sk[i]) {
       int s, l1;
       realign_window(rs.as[i], rs.ae[i], rs.len[i], ref.wrap, &s, &l1);
-      b = classify(rs.len[i], l1, ps);
+      b = classify(rs.len[i], l1, ps, use_quad);
       atomicAdd(&hist[b], 1);
     } else {
       rs.status[i] = ST_SKIPPED;
@@ -84,19 +86,19 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
     bin_of[i] = b;
   }
   __syncthreads();
-  if (threadIdx.x < N_BINS && hist[threadIdx.x]) atomicAdd(&bin_count[threadIdx.x], hist[threadIdx.x]);
+  for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
 }
 
 __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin_of, const int32_t* bin_off, int32_t* bin_cursor,
                                                     int32_t* list) {
   __shared__ int32_t hist[N_BINS], base[N_BINS];
-  if (threadIdx.x < N_BINS) hist[threadIdx.x] = 0;
+  for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int b = -1, rank = 0;
   if (i < n) { b = bin_of[i]; if (b >= 0) rank = atomicAdd(&hist[b], 1); }
   __syncthreads();
-  if (threadIdx.x < N_BINS && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], hist[threadIdx.x]);
+  for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) base[b] = atomicAdd(&bin_cursor[b], hist[b]);
   __syncthreads();
   if (b >= 0) list[bin_off[b] + base[b] + rank] = (int32_t)i;
 }
@@ -146,6 +148,59 @@ __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, co
       rs.status[i] = r.status;
     }
     wave.lds_fence();   // the next read overwrites the substitution table
+  }
+}
+
+// ---- four reads per wavefront (align_body_quad.h): windows <= 208 columns, equal read lengths ----
+__global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackParams pk, const int32_t* list,
+                                                    int32_t n_quads, unsigned char* trace_slabs, int64_t slab_bytes,
+                                                    int32_t* wide_list, int32_t* wide_count, uint32_t dbg) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[Q_G * Q_SUB_BYTES];
+  DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
+  for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
+    QuadArgs a;
+    int idx[Q_G];
+    a.ref_codes = ref.codes;
+    a.packed = rs.packed;
+    a.pssm2 = pssm2;
+    a.pk = pk;
+    a.lds_sub = 0;
+    a.slab_group = (uint32_t)(slab_bytes / Q_G);
+    a.dbg = dbg;
+    a.len2 = 1;
+    for (int g = 0; g < Q_G; g++) {
+      const int i = list[4 * qd + g];
+      idx[g] = i;
+      a.ref_start[g] = 0; a.len1[g] = 0; a.roff[g] = 0; a.rc[g] = 0; a.cols_out[g] = rs.cols;
+      if (i >= 0) {
+        int s, l1;
+        const int len2 = rs.len[i];
+        realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &l1);
+        a.len2 = len2;      // equal for the whole quad: the planner pads every length bin to a multiple of four
+        a.ref_start[g] = s; a.len1[g] = l1; a.roff[g] = rs.roff[i]; a.rc[g] = rs.rc[i];
+        a.cols_out[g] = rs.cols + (int64_t)i * rs.stride;
+      }
+    }
+    AlignResult res[Q_G];
+    QuadAligner<DevWave>::run(wave, a, res);
+    if (wave.lane() == 0) {
+      for (int g = 0; g < Q_G; g++) {
+        const int i = idx[g];
+        if (i < 0) continue;
+        if (res[g].status & ST_ESCAPE) {
+          int p = atomicAdd(wide_count, 1);
+          wide_list[p] = i;
+        } else {
+          rs.score[i] = res[g].score;
+          rs.refstart[i] = a.ref_start[g];
+          rs.abr[i] = (int16_t)res[g].abr;
+          rs.as[i] = res[g].abc + a.ref_start[g];
+          rs.ae[i] = res[g].aec + a.ref_start[g];
+        }
+        rs.status[i] = res[g].status;
+      }
+    }
+    wave.lds_fence();
   }
 }
 

@@ -55,6 +55,32 @@ struct DevWave {
       return one(b0) | (one(b1) << 8) | (one(b2) << 16) | (one(b3) << 24);
     }
   }
+  // 16-lane row forms (one read per DPP row in the quad kernel): row_shr never leaves its row
+  __device__ __forceinline__ U rshr1(U x, U fill) const {
+    return (U)__builtin_amdgcn_update_dpp((int)fill, (int)x, DPP_ROW_SHR + 1, 0xF, 0xF, false);
+  }
+  __device__ __forceinline__ U rshr1_max(U x, U unav) const {
+    U s = (U)__builtin_amdgcn_update_dpp(0, (int)x, DPP_ROW_SHR + 1, 0xF, 0xF, true);
+    return s > unav ? s : unav;
+  }
+  __device__ __forceinline__ U rscan_max(U v) const {
+    v = umax(v, (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 1, 0xF, 0xF, false));
+    v = umax(v, (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 2, 0xF, 0xF, false));
+    v = umax(v, (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 4, 0xF, 0xF, false));
+    v = umax(v, (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 8, 0xF, 0xF, false));
+    return v;
+  }
+  __device__ __forceinline__ U row_last(U v) const { return (U)__shfl((int)v, (int)((lane() & ~15u) | 15u)); }
+  __device__ __forceinline__ static U udiv13(U e) { return e / 13u; }
+  __device__ __forceinline__ void tr_w128(U off, U v0, U v1, U v2, U v3) const {
+    *reinterpret_cast<uint4*>(trace + off) = make_uint4(v0, v1, v2, v3);
+  }
+  // a + b + c with c wave-uniform, as ONE v_add3_u32 that the optimiser cannot hoist into a per-column register
+  __device__ __forceinline__ static U add3(U a, U b, uint32_t c) {
+    U r;
+    asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+  }
   __device__ __forceinline__ static U umax(U a, U b) { return a > b ? a : b; }
   __device__ __forceinline__ static U umin(U a, U b) { return a < b ? a : b; }
   __device__ __forceinline__ static U umax3(U a, U b, U c) { return umax(umax(a, b), c); }

@@ -12,10 +12,14 @@ def world():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def _active():
+    return dist.is_initialized()
+
+
 def all_gather_concat(t):
     """Concatenate equally sized 1-D tensors of all ranks in rank (= fsdb) order: the
     global score array the reference's score-cut regression runs over (src/fsdb.c:269-383)."""
-    if world() == 1:
+    if not _active():
         return t
     parts = [torch.empty_like(t) for _ in range(world())]
     dist.all_gather(parts, t)
@@ -25,7 +29,7 @@ def all_gather_concat(t):
 def exclusive_rank_sum(value, device):
     """Sum of `value` over all lower ranks: the AlnSeq slot index of this shard's first
     record (records are numbered in merge order across the whole fsdb, src/map_align.c:882)."""
-    if world() == 1:
+    if not _active():
         return 0
     v = torch.tensor([int(value)], dtype=torch.int64, device=device)
     parts = [torch.empty_like(v) for _ in range(world())]
@@ -35,7 +39,7 @@ def exclusive_rank_sum(value, device):
 
 def allreduce_tallies(tally, gaps):
     """In place: integer column tallies add up, ref->gaps is a maximum (src/mia.c:486-504)."""
-    if world() == 1:
+    if not _active():
         return
     dist.all_reduce(tally, op=dist.ReduceOp.SUM)
     dist.all_reduce(gaps, op=dist.ReduceOp.MAX)
@@ -43,7 +47,7 @@ def allreduce_tallies(tally, gaps):
 
 def all_gather_ragged(t):
     """Concatenate variable-length 1-D int64 tensors (insert events) of all ranks."""
-    if world() == 1:
+    if not _active():
         return t
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     counts = [torch.empty_like(n) for _ in range(world())]

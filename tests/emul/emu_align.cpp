@@ -9,6 +9,7 @@
 #include "wave_emu.h"
 #include "align_body.h"
 #include "pass1_body.h"
+#include "align_body_quad.h"
 
 using namespace mia;
 
@@ -72,5 +73,33 @@ extern "C" int emu_pass1(const uint8_t* fw_codes, const uint8_t* rc_codes, int l
   Pass1Result r = Pass1Aligner<EmuWave>::run(w, a);
   out8[0] = r.best[0]; out8[1] = r.best[1]; out8[2] = r.strand; out8[3] = r.score; out8[4] = r.aec; out8[5] = r.abc;
   out8[6] = r.abr; out8[7] = (int32_t)r.status;
+  return 0;
+}
+
+// quad kernel body: up to four reads of equal length, one per 16-lane row
+extern "C" int emu_align_quad(int ng, const uint8_t* ref_codes, const int32_t* ref_start, const int32_t* len1,
+                              const uint8_t* read_codes /* ng x len2 */, int len2, const int32_t* pssm2, const int32_t* rc,
+                              int max_abs, int32_t* out5 /* ng x 5 */, int16_t* cols /* ng x 256 */) {
+  PackParams pk;
+  if (!make_pack_params(256, max_abs, &pk)) return -1;
+  const uint32_t stride = (uint32_t)(((len2 + 1) / 2 + 3) & ~3);
+  std::vector<uint8_t> packed((size_t)stride * 4 + 8, 0);
+  QuadArgs a;
+  a.ref_codes = ref_codes; a.packed = packed.data(); a.pssm2 = pssm2; a.len2 = len2; a.pk = pk;
+  a.lds_sub = 0; a.slab_group = MAX_READ * Q_TRACE_STRIDE; a.dbg = 0;
+  for (int g = 0; g < Q_G; g++) {
+    a.ref_start[g] = 0; a.len1[g] = 0; a.roff[g] = 0; a.rc[g] = 0; a.cols_out[g] = cols + g * 256;
+    if (g < ng) {
+      a.ref_start[g] = ref_start[g]; a.len1[g] = len1[g]; a.roff[g] = (uint32_t)g * stride; a.rc[g] = (uint32_t)rc[g];
+      for (int i = 0; i < len2; i++) packed[a.roff[g] + (i >> 1)] |= (uint8_t)(read_codes[g * len2 + i] << ((i & 1) * 4));
+    }
+  }
+  EmuWave w(Q_G * Q_SUB_BYTES + 64, (size_t)Q_G * a.slab_group + 64);
+  AlignResult res[Q_G];
+  QuadAligner<EmuWave>::run(w, a, res);
+  for (int g = 0; g < ng; g++) {
+    out5[g * 5 + 0] = res[g].score; out5[g * 5 + 1] = res[g].abc; out5[g * 5 + 2] = res[g].abr; out5[g * 5 + 3] = res[g].aec;
+    out5[g * 5 + 4] = (int32_t)res[g].status;
+  }
   return 0;
 }

@@ -69,6 +69,17 @@ struct EmuWave {
     }
     return r;
   }
+  // 16-lane row forms (one read per DPP row in the quad kernel)
+  U rshr1(const U& x, const U& fill) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = (i & 15) ? x.a[i - 1] : fill.a[i]; return r; }
+  U rshr1_max(const U& x, const U& unav) const { EV r; for (int i = 0; i < 64; i++) { uint32_t s = (i & 15) ? x.a[i - 1] : 0u; r.a[i] = s > unav.a[i] ? s : unav.a[i]; } return r; }
+  U rscan_max(const U& v) const { EV r; uint32_t m = 0; for (int i = 0; i < 64; i++) { if ((i & 15) == 0) m = 0; m = v.a[i] > m ? v.a[i] : m; r.a[i] = m; } return r; }
+  U row_last(const U& v) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = v.a[(i & ~15) | 15]; return r; }
+  static U udiv13(const U& e) { EV r; for (int i = 0; i < 64; i++) r.a[i] = e.a[i] / 13u; return r; }
+  void tr_w128(const U& off, const U& v0, const U& v1, const U& v2, const U& v3) {
+    for (int i = 0; i < 64; i++) { trace.at(off.a[i] + 15); memcpy(&trace[off.a[i]], &v0.a[i], 4); memcpy(&trace[off.a[i] + 4], &v1.a[i], 4);
+                                   memcpy(&trace[off.a[i] + 8], &v2.a[i], 4); memcpy(&trace[off.a[i] + 12], &v3.a[i], 4); }
+  }
+  static U add3(const U& x, const U& y, uint32_t c) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] + y.a[i] + c; return r; }
   static U umax(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] > y.a[i] ? x.a[i] : y.a[i]; return r; }
   static U umin(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] < y.a[i] ? x.a[i] : y.a[i]; return r; }
   static U umax3(const U& x, const U& y, const U& z) { return umax(umax(x, y), z); }

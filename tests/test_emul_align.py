@@ -135,3 +135,53 @@ def test_emul_tie_heavy(emul, oracle):
                 s2[rnd.randrange(len(s2))] = rnd.choice("ACGT")
             s2 = "".join(s2)
         check(emul, oracle, s1, s2, flat, 1 if i % 5 else 0)
+
+
+def test_emul_quad_kernel(emul, oracle):
+    """four reads per wavefront (16 lanes x 13 columns each): every read must come out exactly as
+    the one-read-per-wave body / the oracle gives it, whatever its three neighbours are"""
+    rnd = random.Random(41)
+    flat = _pssm(oracle, "flat", 0)
+    anc = _pssm(oracle, "ancient.submat.txt", 0)
+    anc_rc = _pssm(oracle, "ancient.submat.txt", 1)
+    emul.emu_align_quad.restype = C.c_int
+    for it in range(40):
+        len2 = rnd.choice([1, 2, 17, 50, 100, 100, 100, 101, 150])
+        ng = rnd.choice([1, 2, 3, 4, 4, 4])
+        use_anc = it % 2
+        fwd = np.ctypeslib.as_array((anc if use_anc else flat).sm).reshape(-1)
+        rcm = np.ctypeslib.as_array((anc_rc if use_anc else flat).sm).reshape(-1)
+        pssm2 = np.concatenate([fwd, rcm]).astype(np.int32)
+        ref = "".join(rnd.choice("ACGT") for _ in range(600))
+        refc = codes(ref)
+        starts, len1s, reads, rcs = [], [], [], []
+        for g in range(ng):
+            st = rnd.randint(0, 300)
+            l1 = rnd.randint(max(len2, 2), 208) if len2 <= 150 else 208
+            l1 = max(l1, min(208, len2))
+            frag = list(ref[st + min(50, max(0, l1 - len2)):][:len2])
+            for _ in range(rnd.randint(0, 3)):
+                frag[rnd.randrange(len(frag))] = rnd.choice("ACGTN")
+            if len2 > 20 and rnd.random() < 0.4:
+                p = rnd.randrange(3, len2 - 3)
+                frag[p:p + rnd.randint(1, 2)] = []
+                frag += [rnd.choice("ACGT") for _ in range(len2 - len(frag))]
+            starts.append(st); len1s.append(l1); reads.append("".join(frag)[:len2].ljust(len2, "A")); rcs.append(rnd.randint(0, 1))
+        rd = np.concatenate([codes(r) for r in reads]).astype(np.uint8)
+        out = (C.c_int32 * (5 * ng))()
+        cols = np.full(4 * 256, -9, dtype=np.int16)
+        rcode = emul.emu_align_quad(ng, refc.ctypes.data_as(C.c_void_p), (C.c_int32 * ng)(*starts), (C.c_int32 * ng)(*len1s),
+                                    rd.ctypes.data_as(C.c_void_p), len2, pssm2.ctypes.data_as(C.c_void_p), (C.c_int32 * ng)(*rcs), 1100,
+                                    out, cols.ctypes.data_as(C.c_void_p))
+        assert rcode == 0
+        for g in range(ng):
+            s1 = ref[starts[g]:starts[g] + len1s[g]]
+            pm = (anc_rc if rcs[g] else anc) if use_anc else flat
+            res = oc.Aln(); rg = C.create_string_buffer(520); fg = C.create_string_buffer(520)
+            oracle.ora_align(s1.encode(), len(s1), reads[g].encode(), len2, None, C.byref(pm), 1, C.byref(res), rg, fg, None, None)
+            got = list(out[g * 5:(g + 1) * 5])
+            if got[4] & 1:
+                continue
+            assert (got[0], got[1], got[2], got[3]) == (res.best, res.abc, res.abr, res.aec), (it, g, got, res.best, res.abc, res.abr, res.aec)
+            r, f = script_to_strings(s1, reads[g], cols[g * 256:(g + 1) * 256], res.abr, res.aer)
+            assert r == rg.value.decode() and f == fg.value.decode(), (it, g)
