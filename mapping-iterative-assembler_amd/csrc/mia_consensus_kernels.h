@@ -110,11 +110,16 @@ __device__ __forceinline__ int depth_code(int dff, int dfb) {   // src/fsdb.c:57
   return dff <= PSSM_DEPTH ? dff : (dfb < PSSM_DEPTH ? 2 * PSSM_DEPTH - dfb : PSSM_DEPTH);
 }
 
-__global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
-                                                const uint8_t* drop_back, TallyBuf tb) {
-  const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= rs.n) return;
+// BINNED: the reads of one workgroup start inside one 256-column bucket of the reference
+// (k_bucket_* below), so their columns fall into a TALLY_WIN-column window that is tallied in
+// LDS and flushed once; anything outside the window (the back part of a read that wraps
+// around the origin) takes the global atomic.  Same integer sums either way.
+constexpr int TALLY_BUCKET = 256, TALLY_WIN = 768, TALLY_CHUNK = 1024;
+
+template <bool BINNED>
+__device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSet& rs, const RefInfo& ref, const int32_t* pssm2,
+                                               const uint8_t* drop_front, const uint8_t* drop_back, const TallyBuf& tb,
+                                               int32_t* lds, int win_base) {
   if (!rs.sk[i]) return;
   if (rs.status[i] & ST_TOO_LONG) { if (lane == 0) atomicOr(tb.flags, 2u); return; }
   const int L = ref.L, Lp = tb.Lp;
@@ -151,19 +156,23 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
     if (gc < 0 || gc >= Lp) { atomicOr(tb.flags, 2u); return; }
     const int d = depth_code(dff, flen + blen - act - 1);
     if (d < 0 || d > 2 * PSSM_DEPTH) { atomicOr(tb.flags, 2u); return; }
+    const int wc = gc - win_base;
+    const bool in_lds = BINNED && wc >= 0 && wc < TALLY_WIN;
+    int32_t* t = in_lds ? lds + wc : tb.tally + gc;
+    const int ws = in_lds ? TALLY_WIN : Lp;                // word stride
     if (!dropped) {                                        // src/mia.c:580-582
-      atomicAdd(&tb.tally[T_COV * Lp + gc], 1);
-      if (code == 5) atomicAdd(&tb.tally[T_GAP * Lp + gc], 1);
+      atomicAdd(&t[T_COV * ws], 1);
+      if (code == 5) atomicAdd(&t[T_GAP * ws], 1);
       else {
-        if (code < 4) atomicAdd(&tb.tally[(T_A + code) * Lp + gc], 1);
+        if (code < 4) atomicAdd(&t[(T_A + code) * ws], 1);
         const int32_t* row = pm + d * 25 + code;           // sm[d][X][code], X = A,C,G,T (src/map_align.c:258-261)
-        atomicAdd(&tb.tally[T_SA * Lp + gc], row[0]);
-        atomicAdd(&tb.tally[T_SC * Lp + gc], row[5]);
-        atomicAdd(&tb.tally[T_SG * Lp + gc], row[10]);
-        atomicAdd(&tb.tally[T_ST * Lp + gc], row[15]);
+        atomicAdd(&t[T_SA * ws], row[0]);
+        atomicAdd(&t[T_SC * ws], row[5]);
+        atomicAdd(&t[T_SG * ws], row[10]);
+        atomicAdd(&t[T_ST * ws], row[15]);
       }
     }
-    if (p > 0) atomicAdd(&tb.tally[T_SPAN * Lp + gc], 1);  // start < pos <= end (src/map_align.c:466-469), dropped or not
+    if (p > 0) atomicAdd(&t[T_SPAN * ws], 1);              // start < pos <= end (src/map_align.c:466-469), dropped or not
   };
 
   for (int r0 = abr; r0 < len2; r0 += 64) {
@@ -197,6 +206,71 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
         else atomicOr(tb.flags, 1u);
       }
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
+                                                const uint8_t* drop_back, TallyBuf tb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rs.n) return;
+  tally_one_read<false>(i, lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0);
+}
+
+// ---- bucketing of the reads by alignment start (counting sort, one pass per iteration) ----
+__global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count) {
+  extern __shared__ int32_t hist[];
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rs.n && rs.sk[i]) atomicAdd(&hist[min(rs.as[i] / TALLY_BUCKET, nb - 1)], 1);
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) if (hist[b]) atomicAdd(&count[b], hist[b]);
+}
+// off[b] = first read of bucket b in `order`, wgoff[b] = first workgroup of bucket b (TALLY_CHUNK reads each)
+__global__ void k_bucket_scan(const int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int run = 0, wg = 0;
+  for (int b = 0; b < nb; b++) { off[b] = run; wgoff[b] = wg; cursor[b] = 0; run += count[b]; wg += (count[b] + TALLY_CHUNK - 1) / TALLY_CHUNK; }
+  off[nb] = run;
+  wgoff[nb] = wg;
+}
+__global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order) {
+  extern __shared__ int32_t sh[];
+  int32_t* hist = sh;
+  int32_t* base = sh + nb;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b = -1, rank = 0;
+  if (i < rs.n && rs.sk[i]) { b = min(rs.as[i] / TALLY_BUCKET, nb - 1); rank = atomicAdd(&hist[b], 1); }
+  __syncthreads();
+  for (int k = threadIdx.x; k < nb; k += blockDim.x) if (hist[k]) base[k] = atomicAdd(&cursor[k], hist[k]);
+  __syncthreads();
+  if (b >= 0) order[off[b] + base[b] + rank] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
+                                                       const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
+                                                       const int32_t* wgoff, const int32_t* order) {
+  __shared__ int32_t lds[TALLY_WORDS * TALLY_WIN];
+  if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
+  // which bucket does this workgroup belong to?  (wgoff is ascending, nb <= a few hundred)
+  int lo = 0, hi = nb;
+  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (wgoff[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const int b = lo, chunk = (int)blockIdx.x - wgoff[b];
+  const int first = off[b] + chunk * TALLY_CHUNK, last = min(first + TALLY_CHUNK, off[b + 1]);
+  const int win_base = b * TALLY_BUCKET;
+  for (int k = threadIdx.x; k < TALLY_WORDS * TALLY_WIN; k += blockDim.x) lds[k] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = first + wv; k < last; k += 4) tally_one_read<true>(order[k], lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base);
+  __syncthreads();
+  const int Lp = tb.Lp;
+  for (int k = threadIdx.x; k < TALLY_WORDS * TALLY_WIN; k += blockDim.x) {
+    const int v = lds[k];
+    const int word = k / TALLY_WIN, gc = win_base + (k - word * TALLY_WIN);
+    if (v != 0 && gc < Lp) atomicAdd(&tb.tally[word * Lp + gc], v);
   }
 }
 

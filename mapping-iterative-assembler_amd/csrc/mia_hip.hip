@@ -52,6 +52,9 @@ struct mia_hip_ctx {
   int use_quad = 1;   // MIA_HIP_NO_QUAD=1 routes everything through the one-read-per-wave kernels
   int grid_wgs = 0;
   uint32_t dbg = 0;   // MIA_HIP_DEBUG_SKIP: timing experiments only, results are wrong when set
+  // read bucketing for the LDS-privatised tally
+  int32_t* d_bucket = nullptr; int bucket_cap = 0; int32_t* d_order = nullptr;
+  int use_binned_tally = 1;   // MIA_HIP_NO_BINNED_TALLY=1: plain global-atomic tally
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
@@ -97,6 +100,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
     ctx->grid_wgs = prop.multiProcessorCount * 32;
     ctx->quad_wgs = prop.multiProcessorCount * 16;   // 128 VGPRs -> 4 waves per SIMD
+    const char* nbt = getenv("MIA_HIP_NO_BINNED_TALLY");
+    if (nbt && atoi(nbt)) ctx->use_binned_tally = 0;
     const char* nq = getenv("MIA_HIP_NO_QUAD");
     if (nq && atoi(nq)) ctx->use_quad = 0;
     const char* qw = getenv("MIA_HIP_QUAD_WAVES_PER_CU");
@@ -124,7 +129,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_bins, ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
                   ctx->d_drop_b, ctx->tb.tally, ctx->tb.gaps, ctx->tb.events, ctx->tb.n_events, ctx->tb.flags, ctx->d_ins_off,
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
-                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs};
+                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -231,6 +236,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   r.n = n; r.packed = ctx->d_packed; r.roff = ctx->d_roff; r.len = ctx->d_len; r.rc = ctx->d_rc; r.sk = ctx->d_sk;
   r.as = ctx->d_as; r.ae = ctx->d_ae; r.score = ctx->d_score; r.refstart = ctx->d_refstart; r.abr = ctx->d_abr;
   r.status = ctx->d_status; r.cols = ctx->d_cols; r.stride = stride;
+  if (ctx->d_order) { (void)hipFree(ctx->d_order); ctx->d_order = nullptr; }
   ctx->aligned = false;
   ctx->tallied = false;
   return MIA_HIP_OK;
@@ -464,23 +470,48 @@ extern "C" int mia_hip_set_slot_dropped(mia_hip_ctx* ctx, const uint8_t* flags, 
   return MIA_HIP_OK;
 }
 
-// find_fsdb_score_cut (src/fsdb.c:269-383): host-side, sequential IEEE double (built with -ffp-contract=off)
+// find_fsdb_score_cut (src/fsdb.c:269-383): host-side IEEE double (built with -ffp-contract=off).
+// Bit-exactness argument per pass:
+//   1. xbar/ybar: every partial sum is an integer below 2^53, so each double addition is exact and
+//      the result does not depend on the order -> accumulate in int64.
+//   2. ssxy/ssxx: sums of inexact products, order dependent -> sequential, in fsdb order, exactly as
+//      the reference.  If all reads have the same length every (len - xbar) is exactly 0, both sums
+//      are exactly 0 and slope_bf = 0/0 = NaN: that case is answered without the pass.
+//   3. max slope delta: a maximum is order independent (NaN deltas never win, as in the reference).
 extern "C" void mia_hip_score_cut(const int32_t* score, const int32_t* seq_len, const uint8_t* unique_best, int64_t n,
                                   double* slope, double* intercept) {
-  double xbar = 0, ybar = 0, ssxy = 0, ssxx = 0, max_delta = 0;
-  size_t j = 0;
-  auto used = [&](int64_t i) { return (!unique_best || unique_best[i]) && score[i] >= 2000; };
-  for (int64_t i = 0; i < n; i++) if (used(i)) { xbar += seq_len[i]; ybar += score[i]; j++; }
-  xbar /= j;
-  ybar /= j;
-  for (int64_t i = 0; i < n; i++) if (used(i)) {
-    ssxy += (seq_len[i] - xbar) * (score[i] - ybar);
-    ssxx += (seq_len[i] - xbar) * (seq_len[i] - xbar);
+  int64_t sx = 0, sy = 0, j = 0;
+  int32_t lmin = INT32_MAX, lmax = INT32_MIN;
+  for (int64_t i = 0; i < n; i++) {
+    const bool u = (!unique_best || unique_best[i]) && score[i] >= 2000;
+    sx += u ? seq_len[i] : 0;
+    sy += u ? score[i] : 0;
+    j += u;
+    if (u) { lmin = seq_len[i] < lmin ? seq_len[i] : lmin; lmax = seq_len[i] > lmax ? seq_len[i] : lmax; }
   }
-  const double slope_bf = ssxy / ssxx, intercept_bf = ybar - slope_bf * xbar;
-  for (int64_t i = 0; i < n; i++) if (used(i)) {
-    double d = (score[i] - ((slope_bf * seq_len[i]) + intercept_bf)) / seq_len[i];
-    if (d > max_delta) max_delta = d;
+  double xbar = (double)sx, ybar = (double)sy;
+  xbar /= (double)(size_t)j;
+  ybar /= (double)(size_t)j;
+  double slope_bf, intercept_bf, max_delta = 0;
+  if (j > 0 && lmin == lmax) {
+    const double zero = 0.0;
+    slope_bf = zero / zero;                      // ssxy / ssxx with both sums exactly 0
+    intercept_bf = ybar - slope_bf * xbar;
+  } else {
+    double ssxy = 0, ssxx = 0;
+    auto used = [&](int64_t i) { return (!unique_best || unique_best[i]) && score[i] >= 2000; };
+    for (int64_t i = 0; i < n; i++) if (used(i)) {
+      ssxy += (seq_len[i] - xbar) * (score[i] - ybar);
+      ssxx += (seq_len[i] - xbar) * (seq_len[i] - xbar);
+    }
+    slope_bf = ssxy / ssxx;
+    intercept_bf = ybar - slope_bf * xbar;
+    double m4[4] = {0, 0, 0, 0};
+    for (int64_t i = 0; i < n; i++) if (used(i)) {
+      double d = (score[i] - ((slope_bf * seq_len[i]) + intercept_bf)) / seq_len[i];
+      if (d > m4[i & 3]) m4[i & 3] = d;
+    }
+    for (int k = 0; k < 4; k++) if (m4[k] > max_delta) max_delta = m4[k];
   }
   *intercept = intercept_bf;
   if ((slope_bf - max_delta) > 0) *slope = slope_bf - (max_delta * 2.0);
@@ -544,8 +575,27 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   if (n > 0) {
     RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
-    hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
-                       ctx->d_drop_b, ctx->tb);
+    const int nb = ctx->wrap / TALLY_BUCKET + 1;
+    if (ctx->use_binned_tally && nb <= 4096) {
+      // counting sort of the reads by alignment start, then one LDS tally window per workgroup
+      if (nb + 1 > ctx->bucket_cap) {
+        if (dev_alloc(ctx, &ctx->d_bucket, (size_t)4 * (nb + 1))) return MIA_HIP_ERR_NOMEM;
+        ctx->bucket_cap = nb + 1;
+      }
+      if (!ctx->d_order && dev_alloc(ctx, &ctx->d_order, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+      int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1);
+      HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, ctx->stream));
+      const int gb = (int)((n + 255) / 256);
+      hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, ctx->stream, ctx->rs, nb, d_cnt);
+      hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(64), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur);
+      hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, ctx->stream, ctx->rs, nb, d_off, d_cur, ctx->d_order);
+      const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
+      hipLaunchKernelGGL(k_tally_binned, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
+                         ctx->tb, nb, d_off, d_wgoff, ctx->d_order);
+    } else {
+      hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
+                         ctx->d_drop_b, ctx->tb);
+    }
     HIPCHK(hipGetLastError());
   }
   uint32_t flags = 0;
