@@ -33,10 +33,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BYTES_PER_READ = 182      # 50 B packed bases + 16 B meta in, 16 B result + 100 B script out
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# memory-side bytes per read of k_align_window<4>, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two
-# separate passes (profiles/r01/pmc/summary_kb_per_launch.json: 5.60e6 KB + 19.78e6 KB per 1 M-read launch, counters as
-# reported, no width correction): almost all of it is the 20 KB/read byte trace going to the per-workgroup slabs
-TRAFFIC_BYTES_PER_READ = (5604250 + 19779321) * 1024 / 1_000_000
+# memory-side bytes per read of k_align_quad, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate
+# passes (profiles/r01/pmc/quad_summary_kb_per_launch.json: 6.44e6 KB + 25.26e6 KB per 1 M-read launch, counters as
+# reported, no width correction): almost all of it is the 25.6 KB/read byte trace (16 B per lane and row) going to the
+# per-workgroup slabs
+TRAFFIC_BYTES_PER_READ = (6438078 + 25259702) * 1024 / 1_000_000
 
 
 class DevArray:
@@ -209,7 +210,7 @@ def main():
                        "reads_per_gpu": n, "consensus_len": len(cur)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_READ * reads_per_launch,
-                         "kernel": "k_align_window<4>", "kernel_ms": k_ms, "launches": launches,
+                         "kernel": "k_align_quad", "kernel_ms": k_ms, "launches": launches,
                          "note": "integer-VALU/LDS-bound DP: 182 algorithmic HBM bytes per read (SURVEY 8d); see DESIGN.md for GCUPS vs VALU peak",
                          "gcups": reads_per_launch * 100 * 200 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
         }
