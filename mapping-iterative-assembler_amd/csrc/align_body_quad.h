@@ -16,7 +16,8 @@
 namespace mia {
 
 constexpr int Q_CPL = 13, Q_LPR = 16, Q_G = 4, Q_COLS = Q_CPL * Q_LPR;   // 208 columns per read
-constexpr int Q_TRACE_STRIDE = Q_LPR * 16;                               // 16 trace bytes per lane and row
+constexpr int Q_TRACE_STRIDE = Q_LPR * 32;   // per row: 16 lanes x 32 bytes = 13 cells x 16 bit [prio:2][len:8] (+pad)
+constexpr int Q_BAND = 20;   // half width (columns) of the stored trace band around the expected diagonal
 
 struct QuadArgs {                 // wave-uniform; [g] = read of lane row g, len1 == 0 marks an empty slot
   const uint8_t* ref_codes;
@@ -29,6 +30,12 @@ struct QuadArgs {                 // wave-uniform; [g] = read of lane row g, len
   uint32_t lds_sub;               // LDS: 4 tables int16 sub[5][rows padded to even], Q_SUB_BYTES apart
   uint32_t slab_group;            // bytes between the trace areas of two reads inside the workgroup slab
   int16_t* cols_out[Q_G];
+  // Trace band: only lanes whose 13 columns come within Q_BAND columns of the diagonal the read followed in
+  // the previous iteration (column dexp + row) store their trace bytes; the live trace of all wavefronts then
+  // fits the Infinity Cache instead of streaming to HBM.  A path that leaves the band is detected in the
+  // traceback (ST_BAND) and the read is re-run by the one-read kernel with a full trace -- never guessed.
+  int32_t band;                   // 0 = store everything
+  int32_t dexp[Q_G];
   uint32_t dbg;
 };
 constexpr uint32_t Q_SUB_BYTES = MAX_READ * 10;
@@ -40,6 +47,13 @@ struct QuadAligner {
   static constexpr int CPL = Q_CPL, IB = 8, SH = 10;
   static constexpr uint32_t IDXM = 255u;
 
+  // does the 13-column block starting at column blk_lo come within Q_BAND columns of the expected diagonal in row r?
+  MIA_HD static inline M in_band(P& w, const QuadArgs& a, const U& dbias, const U& blk_lo, const U& r) {
+    if (!a.band) return w.lane() < 64u;
+    U dg = dbias + r;                                  // biased diagonal column of this row
+    return (blk_lo + 4096u <= dg + (uint32_t)Q_BAND) & (blk_lo + (4096u + (uint32_t)CPL - 1u + (uint32_t)Q_BAND) >= dg);
+  }
+
   MIA_HD static inline __attribute__((always_inline)) void run(P& w, const QuadArgs& a, AlignResult* res /* [Q_G] */) {
     const uint32_t OFF = (uint32_t)a.pk.off;
     const uint32_t UNAV = ((uint32_t)a.pk.unavail << SH) | IDXM;
@@ -48,16 +62,17 @@ struct QuadAligner {
     const int len2 = a.len2;
     const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;
     // per-lane copies of the per-read scalars
-    U len1v = U(0u), startv = U(0u), roffv = U(0u), pmoff = U(0u);
+    U len1v = U(0u), startv = U(0u), roffv = U(0u), pmoff = U(0u), dbias = U(4096u);
     for (int g = 0; g < Q_G; g++) {
       M mine = grp == (uint32_t)g;
       len1v = w.sel(mine, U((uint32_t)a.len1[g]), len1v);
       startv = w.sel(mine, U((uint32_t)a.ref_start[g]), startv);
       roffv = w.sel(mine, U(a.roff[g]), roffv);
       pmoff = w.sel(mine, U(a.rc[g] ? (uint32_t)PSSM_WORDS : 0u), pmoff);
+      dbias = w.sel(mine, U((uint32_t)(a.dexp[g] + 4096)), dbias);   // biased so that band arithmetic stays unsigned
     }
     const U subbase = U(a.lds_sub) + grp * Q_SUB_BYTES;
-    const U trbase = grp * a.slab_group + gl * 16u;
+    const U trbase = grp * a.slab_group + gl * 32u;
 
     // ---- substitution tables, 16 lanes per read
     for (int e0 = 0; e0 < len2 * 5; e0 += Q_LPR) {
@@ -91,15 +106,22 @@ struct QuadAligner {
     const uint32_t WDC = TR_DIAG << IB;
     const U unav = U(UNAV);
 
-    U Sb[CPL], q[CPL], rrun[CPL];
+    // The score state is kept SHIFTED and already carries the diagonal priority bits:
+    // Sd = ((S + off) << SH) | (TR_DIAG << IB) IS the diagonal candidate word of the cell below-right.  The two
+    // key words (next row's best_gap_col key, best_gap_row key of the previous row) are one add each, and the new
+    // state is rebuilt from the winning word with one AND-OR and one shift-add of the substitution score.
+    const uint32_t HI = ~((1u << SH) - 1u);
+    U Sd[CPL], q[CPL], rrun[CPL];
     for (int j = 0; j < CPL; j++) {
-      Sb[j] = w.lds_ri16(sub_addr[j]) + OFF;
-      q[j] = (Sb[j] << SH) + QC[j];
+      Sd[j] = ((w.lds_ri16(sub_addr[j]) + OFF) << SH) | WDC;
+      q[j] = Sd[j] + (QC[j] - WDC);
       rrun[j] = unav;
     }
     {
-      const U d4 = U((TR_DIAG << 6) * 0x01010101u);
-      w.tr_w128(trbase, d4, d4, d4, d4);
+      const U d4 = U((TR_DIAG << IB) * 0x00010001u);
+      const M ib0 = in_band(w, a, dbias, gl * (uint32_t)CPL, 0u);
+      w.tr_w128m(trbase, d4, d4, d4, d4, ib0);
+      w.tr_w128m(trbase + 16u, d4, d4, d4, d4, ib0);
     }
 
     for (int r = 1; r < ((a.dbg & 4u) ? 1 : len2); r++) {
@@ -107,9 +129,9 @@ struct QuadAligner {
       const uint32_t freshb = (uint32_t)(fresh + (int32_t)OFF);
       const uint32_t WS = freshb << SH;
       const uint32_t KR = (0u - ((uint32_t)(GOP + GEP * (r - 1)) << SH)) + (TR_ROWGAP << IB) + ((uint32_t)(r - 1) - IDXM);
-      const uint32_t RKP = ((uint32_t)(GEP * (r - 1)) << SH) + (IDXM - (uint32_t)(r - 1));   // key constant of row r-1
+      const uint32_t RKP = ((uint32_t)(GEP * (r - 1)) << SH) + (IDXM - (uint32_t)(r - 1)) - WDC;   // key constant of row r-1
 
-      U dleft = w.rshr1(Sb[CPL - 1], U(freshb));
+      U dleft = w.rshr1(Sd[CPL - 1], U(WS | WDC));
       U rleft = w.rshr1_max(rrun[CPL - 1], unav);
       U u0 = w.rshr1_max(q[CPL - 2], unav);
       U u1 = w.rshr1_max(q[CPL - 1], unav);
@@ -119,33 +141,39 @@ struct QuadAligner {
       for (int j = 2; j < CPL; j++) g[j] = w.umax(g[j - 1], q[j - 2]);
       U excl = w.rshr1_max(w.rscan_max(g[CPL - 1]), unav);
 
-      U bq[4], packed[4];
+      // trace cell = low 16 bits of the winning word ([..|prio:2|len:8]); two cells per dword, no saturation
+      U bodd = U(0u), packed[8];
+      packed[7] = U(0u);
       for (int j = CPL - 1; j >= 0; j--) {
-        U diag = (j == 0) ? dleft : Sb[j - 1];
+        U Wd = (j == 0) ? dleft : Sd[j - 1];
         U rl = (j == 0) ? rleft : rrun[j - 1];
-        U Wd = (diag << SH) + WDC;
         U Wc = w.add3(w.umax(excl, g[j]), KC0, (uint32_t)j * KCD);
         U Wr = rl + KR;
         U m3 = w.umax3(Wd, Wc, Wr);
         U best = w.umax(m3, U(WS));
         U sub = w.lds_ri16(sub_addr[j] + (uint32_t)r * 2u);
-        U snew = (best >> SH) + w.sel(m3 < WS, U(0u), sub);
-        rrun[j] = w.umax(rrun[j], (Sb[j] << SH) + RKP);   // row r-1 becomes a best_gap_row candidate for row r+1
-        Sb[j] = snew;
-        q[j] = (snew << SH) + QC[j];
-        bq[j & 3] = best;
-        if (j == CPL - 1) packed[3] = w.template trace_pack4<IB>(best, best, best, best);
-        else if ((j & 3) == 0) packed[j >> 2] = w.template trace_pack4<IB>(bq[0], bq[1], bq[2], bq[3]);
+        // start (only if strictly better than the other three) drops the substitution score (src/mia.c:910-917)
+        U snew = w.shl_add(w.sel(m3 < WS, U(0u), sub), SH, w.and_or(best, HI, WDC));
+        rrun[j] = w.umax(rrun[j], Sd[j] + RKP);   // row r-1 becomes a best_gap_row candidate for row r+1
+        Sd[j] = snew;
+        q[j] = snew + (QC[j] - WDC);
+        if (j == CPL - 1) packed[6] = best & 0xFFFFu;
+        else if (j & 1) bodd = best;
+        else packed[j >> 1] = w.pack16(best, bodd);
       }
-      if (!(a.dbg & 1u)) w.tr_w128(trbase + (uint32_t)r * Q_TRACE_STRIDE, packed[0], packed[1], packed[2], packed[3]);
+      if (!(a.dbg & 1u)) {
+        const M ib = in_band(w, a, dbias, gl * (uint32_t)CPL, (uint32_t)r);
+        w.tr_w128m(trbase + (uint32_t)r * Q_TRACE_STRIDE, packed[0], packed[1], packed[2], packed[3], ib);
+        w.tr_w128m(trbase + (uint32_t)r * Q_TRACE_STRIDE + 16u, packed[4], packed[5], packed[6], packed[7], ib);
+      }
     }
 
-    // ---- max_sg_score per read (16-lane row)
+    // ---- max_sg_score per read (16-lane row); the state words order like scores
     U m = U(0u);
-    for (int j = 0; j < CPL; j++) m = w.umax(m, w.sel(col[j] < len1v, Sb[j], U(0u)));
+    for (int j = 0; j < CPL; j++) m = w.umax(m, w.sel(col[j] < len1v, Sd[j], U(0u)));
     const U bestv = w.row_last(w.rscan_max(m));
     U cmin = U(0x7FFFFFFFu);
-    for (int j = CPL - 1; j >= 0; j--) cmin = w.sel((col[j] < len1v) & (Sb[j] == bestv), col[j], cmin);
+    for (int j = CPL - 1; j >= 0; j--) cmin = w.sel((col[j] < len1v) & (Sd[j] == bestv), col[j], cmin);
     const U aecv = ~w.row_last(w.rscan_max(~cmin));
     w.tr_fence();
 
@@ -155,7 +183,7 @@ struct QuadAligner {
       AlignResult& rs = res[gi];
       rs.score = 0; rs.abc = 0; rs.abr = 0; rs.aec = 0; rs.status = ST_SKIPPED;
       if (a.len1[gi] <= 0) continue;
-      rs.score = (int32_t)(w.lane_val(bestv, gi * Q_LPR) - OFF);
+      rs.score = (int32_t)((w.lane_val(bestv, gi * Q_LPR) >> SH) - OFF);
       rs.aec = (int32_t)w.lane_val(aecv, gi * Q_LPR);
       const uint32_t tb0 = (uint32_t)gi * a.slab_group;
       int r = len2 - 1, c = rs.aec, aln_cols = 0;
@@ -164,15 +192,18 @@ struct QuadAligner {
         U ri = U((uint32_t)r) - lane, ci = U((uint32_t)c) - lane;
         M inside = (lane <= (uint32_t)r) & (lane <= (uint32_t)c);
         U cl = w.udiv13(ci);
-        U tb = w.tr_r8(U(tb0) + ri * Q_TRACE_STRIDE + cl * 16u + (ci - cl * 13u), inside);
-        U ty = tb >> 6, ln = tb & 63u;
-        M colgap0 = (ty == U(TR_COLGAP)) & (ln + 1u == ci) & (ln < U(TR_LEN_SAT));
-        M rowgap0 = (ty == U(TR_ROWGAP)) & (ln + 1u == ri) & (ln < U(TR_LEN_SAT));
+        // a cell whose lane block lies outside the stored band has no trace byte
+        M covered = in_band(w, a, U(w.lane_val(dbias, gi * Q_LPR)), cl * (uint32_t)CPL, ri);
+        U tb = w.tr_r16(U(tb0) + ri * Q_TRACE_STRIDE + cl * 32u + (ci - cl * 13u) * 2u, inside & covered);
+        U ty = (tb >> IB) & 3u, ln = tb & IDXM;
+        M colgap0 = (ty == U(TR_COLGAP)) & (ln + 1u == ci);
+        M rowgap0 = (ty == U(TR_ROWGAP)) & (ln + 1u == ri);
         M plain_diag = (ty == U(TR_DIAG)) | colgap0 | rowgap0;
         M terminal = (ri == U(0u)) | (ci == U(0u)) | (ty == U(TR_START));
-        M stop_here = (!inside) | terminal | (!plain_diag);
+        M stop_here = (!inside) | (!covered) | terminal | (!plain_diag);
         uint64_t bal = w.ballot(stop_here);
         int f = bal ? __builtin_ctzll(bal) : WAVE;
+        if (f < WAVE && w.lane_bit(inside, f) && !w.lane_bit(covered, f)) { status |= ST_BAND; rs.abr = r - f; rs.abc = c - f; break; }
         int npairs = f < WAVE ? f + 1 : WAVE;
         if (f < WAVE && !w.lane_bit(inside, f)) npairs = f;
         w.gstore_i16(a.cols_out[gi], ri, ci, lane < (uint32_t)npairs);
@@ -182,11 +213,12 @@ struct QuadAligner {
         const bool fterm = w.lane_bit(terminal, f);
         const int fr = r - f, fc = c - f;
         if (fterm) { rs.abr = fr; rs.abc = fc; break; }
-        if (fln >= TR_LEN_SAT) { status |= ST_ESCAPE; rs.abr = fr; rs.abc = fc; break; }
         if (fty == TR_COLGAP) { r = fr - 1; c = fc - 1 - (int)fln; aln_cols += (int)fln; }
         else {
-          U rr = U((uint32_t)(fr - 1)) - lane;
-          w.gstore_i16(a.cols_out[gi], rr, U((uint32_t)(uint16_t)COL_INSERT), lane < fln);
+          for (int k0 = 0; k0 < (int)fln; k0 += WAVE) {   // lengths are exact here (no saturation): up to 255 rows
+            U rr = U((uint32_t)(fr - 1 - k0)) - lane;
+            w.gstore_i16(a.cols_out[gi], rr, U((uint32_t)(uint16_t)COL_INSERT), lane + (uint32_t)k0 < fln);
+          }
           r = fr - 1 - (int)fln; c = fc - 1;
           aln_cols += (int)fln;
         }

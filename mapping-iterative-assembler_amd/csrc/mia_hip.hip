@@ -34,7 +34,8 @@ struct mia_hip_ctx {
   int16_t* d_abr = nullptr; uint32_t* d_status = nullptr; int16_t* d_cols = nullptr;
   int max_len = 0;
   // plan
-  int32_t *d_bin_of = nullptr, *d_list = nullptr, *d_wide_list = nullptr;
+  int32_t *d_bin_of = nullptr, *d_list = nullptr, *d_wide_list = nullptr, *d_retry_list = nullptr;
+  int use_band = 1;   // MIA_HIP_NO_BAND=1: the quad kernel stores the full trace
   int32_t* d_bins = nullptr;  // [count N_BINS][off N_BINS][cursor N_BINS][wide_count 1]
   // reference
   uint8_t* d_ref = nullptr; int ref_cap = 0; int L = 0, wrap = 0; bool have_ref = false; bool aligned = false;
@@ -102,6 +103,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     ctx->quad_wgs = prop.multiProcessorCount * 16;   // 128 VGPRs -> 4 waves per SIMD
     const char* nbt = getenv("MIA_HIP_NO_BINNED_TALLY");
     if (nbt && atoi(nbt)) ctx->use_binned_tally = 0;
+    const char* nband = getenv("MIA_HIP_NO_BAND");
+    if (nband && atoi(nband)) ctx->use_band = 0;
     const char* nq = getenv("MIA_HIP_NO_QUAD");
     if (nq && atoi(nq)) ctx->use_quad = 0;
     const char* qw = getenv("MIA_HIP_QUAD_WAVES_PER_CU");
@@ -111,7 +114,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     const char* g = getenv("MIA_HIP_GRID_WAVES_PER_CU");
     if (g && atoi(g) > 0) ctx->grid_wgs = prop.multiProcessorCount * atoi(g);
   }
-  if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_bins, 3 * N_BINS + 1) ||
+  if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_bins, 3 * N_BINS + 2) ||
       dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1)) {
     delete ctx;
     return MIA_HIP_ERR_NOMEM;
@@ -125,7 +128,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   void* ptrs[] = {ctx->d_pssm, ctx->d_packed, ctx->d_roff, ctx->d_len, ctx->d_rc, ctx->d_sk, ctx->d_as, ctx->d_ae, ctx->d_score,
-                  ctx->d_refstart, ctx->d_abr, ctx->d_status, ctx->d_cols, ctx->d_bin_of, ctx->d_list, ctx->d_wide_list,
+                  ctx->d_refstart, ctx->d_abr, ctx->d_status, ctx->d_cols, ctx->d_bin_of, ctx->d_list, ctx->d_wide_list, ctx->d_retry_list,
                   ctx->d_bins, ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
                   ctx->d_drop_b, ctx->tb.tally, ctx->tb.gaps, ctx->tb.events, ctx->tb.n_events, ctx->tb.flags, ctx->d_ins_off,
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
@@ -212,6 +215,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_bin_of, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_list, (size_t)n + 4 * N_BINS);   // quad bins are padded to multiples of four
   rcx |= dev_alloc(ctx, &ctx->d_wide_list, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_retry_list, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_slot, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_partial, (size_t)(n / 4096 + 2));
   rcx |= dev_alloc(ctx, &ctx->d_drop_f, (size_t)n);
@@ -228,6 +232,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   HIPCHK(hipMemcpyAsync(ctx->d_ae, ae, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_score, 0, (size_t)n * 4, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_status, 0, (size_t)n * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_abr, 0, (size_t)n * 2, ctx->stream));   // no soft clip known after pass 1
   HIPCHK(hipMemsetAsync(ctx->d_slot_dropped, 0, (size_t)ctx->n_slots, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_drop_f, 0, (size_t)n, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_drop_b, 0, (size_t)n, ctx->stream));
@@ -317,7 +322,8 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   int32_t* d_off = ctx->d_bins + N_BINS;
   int32_t* d_cursor = ctx->d_bins + 2 * N_BINS;
   int32_t* d_wide_count = ctx->d_bins + 3 * N_BINS;
-  HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 1) * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 2) * 4, ctx->stream));
+  int32_t* d_retry_count = ctx->d_bins + 3 * N_BINS + 1;
   const int tb = 256, gb = (int)((n + tb - 1) / tb);
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, ctx->d_bin_of, d_count);
   int32_t h_count[N_BINS], h_off[N_BINS];
@@ -353,9 +359,20 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     if (get_events(ctx, &e0, &e1)) return MIA_HIP_ERR_NOMEM;
     (void)hipEventRecord(e0, ctx->stream);
     hipLaunchKernelGGL(k_align_quad, dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list + quad_begin,
-                       n_quads, ctx->d_quad_slabs, slab, ctx->d_wide_list, d_wide_count, ctx->dbg);
+                       n_quads, ctx->d_quad_slabs, slab, ctx->d_wide_list, d_wide_count, ctx->d_retry_list, d_retry_count, ctx->use_band,
+                       ctx->dbg);
     (void)hipEventRecord(e1, ctx->stream);
     HIPCHK(hipGetLastError());
+    if (ctx->use_band) {
+      // reads whose path left the stored trace band: one-read kernel with the full trace (windows <= 208 fit class 0)
+      int32_t n_retry = 0;
+      HIPCHK(hipMemcpyAsync(&n_retry, d_retry_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      if (n_retry > 0) {
+        hipError_t e = launch_window<4>(ctx, 0, ctx->d_retry_list, n_retry);
+        if (e != hipSuccess) { ctx->err = std::string("k_align_window retry launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+      }
+    }
   }
   // exact kernel for whole-reference windows and escaped reads
   int32_t n_wide = 0;

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, co
 // ---- four reads per wavefront (align_body_quad.h): windows <= 208 columns, equal read lengths ----
 __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackParams pk, const int32_t* list,
                                                     int32_t n_quads, unsigned char* trace_slabs, int64_t slab_bytes,
-                                                    int32_t* wide_list, int32_t* wide_count, uint32_t dbg) {
+                                                    int32_t* wide_list, int32_t* wide_count, int32_t* retry_list, int32_t* retry_count,
+                                                    int32_t band, uint32_t dbg) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[Q_G * Q_SUB_BYTES];
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
   for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
@@ -167,11 +168,12 @@ __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, c
     a.lds_sub = 0;
     a.slab_group = (uint32_t)(slab_bytes / Q_G);
     a.dbg = dbg;
+    a.band = band;
     a.len2 = 1;
     for (int g = 0; g < Q_G; g++) {
       const int i = list[4 * qd + g];
       idx[g] = i;
-      a.ref_start[g] = 0; a.len1[g] = 0; a.roff[g] = 0; a.rc[g] = 0; a.cols_out[g] = rs.cols;
+      a.ref_start[g] = 0; a.len1[g] = 0; a.roff[g] = 0; a.rc[g] = 0; a.cols_out[g] = rs.cols; a.dexp[g] = 0;
       if (i >= 0) {
         int s, l1;
         const int len2 = rs.len[i];
@@ -179,6 +181,8 @@ __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, c
         a.len2 = len2;      // equal for the whole quad: the planner pads every length bin to a multiple of four
         a.ref_start[g] = s; a.len1[g] = l1; a.roff[g] = rs.roff[i]; a.rc[g] = rs.rc[i];
         a.cols_out[g] = rs.cols + (int64_t)i * rs.stride;
+        // expected diagonal: where the read started last time, minus its soft-clipped rows (0 after pass 1)
+        a.dexp[g] = (rs.as[i] - s) - rs.abr[i];
       }
     }
     AlignResult res[Q_G];
@@ -187,7 +191,10 @@ __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, c
       for (int g = 0; g < Q_G; g++) {
         const int i = idx[g];
         if (i < 0) continue;
-        if (res[g].status & ST_ESCAPE) {
+        if (res[g].status & ST_BAND) {          // path outside the stored band: one-read kernel, full trace
+          int p = atomicAdd(retry_count, 1);
+          retry_list[p] = i;
+        } else if (res[g].status & ST_ESCAPE) {
           int p = atomicAdd(wide_count, 1);
           wide_list[p] = i;
         } else {

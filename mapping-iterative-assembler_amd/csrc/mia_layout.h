@@ -72,6 +72,7 @@ constexpr uint32_t ST_OK = 0;
 constexpr uint32_t ST_ESCAPE = 1;    // saturated gap length met on the path: needs the wide kernel
 constexpr uint32_t ST_TOO_LONG = 2;  // alignment longer than 512 columns (undefined in the reference, src/mia.c:1442-1450)
 constexpr uint32_t ST_SKIPPED = 4;   // strand_known == 0 (src/mia_main.c:178)
+constexpr uint32_t ST_BAND = 8;      // the path left the stored trace band of the quad kernel: re-run with a full trace
 
 constexpr int16_t COL_INSERT = -1;
 constexpr int16_t COL_CLIP = -2;

@@ -81,6 +81,17 @@ struct DevWave {
     asm volatile("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
     return r;
   }
+  __device__ __forceinline__ void tr_w128m(U off, U v0, U v1, U v2, U v3, M ok) const {
+    if (ok) *reinterpret_cast<uint4*>(trace + off) = make_uint4(v0, v1, v2, v3);
+  }
+  __device__ __forceinline__ static U shl_add(U x, int sh, U y) { return (x << sh) + y; }   // v_lshl_add_u32
+  __device__ __forceinline__ static U and_or(U x, uint32_t m, uint32_t o) { return (x & m) | o; }   // v_and_or_b32
+  // lane mask moved one lane up inside each 16-lane row; the first lane of a row gets false
+  __device__ __forceinline__ M mrshr1(M x) const {
+    return __builtin_amdgcn_update_dpp(0, x ? 1 : 0, DPP_ROW_SHR + 1, 0xF, 0xF, true) != 0;
+  }
+  __device__ __forceinline__ static M msel(M c, M x, M y) { return c ? x : y; }
+  __device__ __forceinline__ static U pack16(U lo, U hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }   // {hi.lo16, lo.lo16}
   __device__ __forceinline__ static U umax(U a, U b) { return a > b ? a : b; }
   __device__ __forceinline__ static U umin(U a, U b) { return a < b ? a : b; }
   __device__ __forceinline__ static U umax3(U a, U b, U c) { return umax(umax(a, b), c); }

@@ -79,16 +79,16 @@ extern "C" int emu_pass1(const uint8_t* fw_codes, const uint8_t* rc_codes, int l
 // quad kernel body: up to four reads of equal length, one per 16-lane row
 extern "C" int emu_align_quad(int ng, const uint8_t* ref_codes, const int32_t* ref_start, const int32_t* len1,
                               const uint8_t* read_codes /* ng x len2 */, int len2, const int32_t* pssm2, const int32_t* rc,
-                              int max_abs, int32_t* out5 /* ng x 5 */, int16_t* cols /* ng x 256 */) {
+                              int max_abs, int32_t* out5 /* ng x 5 */, int16_t* cols /* ng x 256 */, int band, const int32_t* dexp) {
   PackParams pk;
   if (!make_pack_params(256, max_abs, &pk)) return -1;
   const uint32_t stride = (uint32_t)(((len2 + 1) / 2 + 3) & ~3);
   std::vector<uint8_t> packed((size_t)stride * 4 + 8, 0);
   QuadArgs a;
   a.ref_codes = ref_codes; a.packed = packed.data(); a.pssm2 = pssm2; a.len2 = len2; a.pk = pk;
-  a.lds_sub = 0; a.slab_group = MAX_READ * Q_TRACE_STRIDE; a.dbg = 0;
+  a.lds_sub = 0; a.slab_group = MAX_READ * Q_TRACE_STRIDE; a.dbg = 0; a.band = band;
   for (int g = 0; g < Q_G; g++) {
-    a.ref_start[g] = 0; a.len1[g] = 0; a.roff[g] = 0; a.rc[g] = 0; a.cols_out[g] = cols + g * 256;
+    a.ref_start[g] = 0; a.len1[g] = 0; a.roff[g] = 0; a.rc[g] = 0; a.cols_out[g] = cols + g * 256; a.dexp[g] = (band && g < ng) ? dexp[g] : 0;
     if (g < ng) {
       a.ref_start[g] = ref_start[g]; a.len1[g] = len1[g]; a.roff[g] = (uint32_t)g * stride; a.rc[g] = (uint32_t)rc[g];
       for (int i = 0; i < len2; i++) packed[a.roff[g] + (i >> 1)] |= (uint8_t)(read_codes[g * len2 + i] << ((i & 1) * 4));

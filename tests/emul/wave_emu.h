@@ -80,6 +80,15 @@ struct EmuWave {
                                    memcpy(&trace[off.a[i] + 8], &v2.a[i], 4); memcpy(&trace[off.a[i] + 12], &v3.a[i], 4); }
   }
   static U add3(const U& x, const U& y, uint32_t c) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] + y.a[i] + c; return r; }
+  void tr_w128m(const U& off, const U& v0, const U& v1, const U& v2, const U& v3, const M& ok) {
+    for (int i = 0; i < 64; i++) if (ok.a[i]) { trace.at(off.a[i] + 15); memcpy(&trace[off.a[i]], &v0.a[i], 4); memcpy(&trace[off.a[i] + 4], &v1.a[i], 4);
+                                               memcpy(&trace[off.a[i] + 8], &v2.a[i], 4); memcpy(&trace[off.a[i] + 12], &v3.a[i], 4); }
+  }
+  static U shl_add(const U& x, int sh, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] << sh) + y.a[i]; return r; }
+  static U and_or(const U& x, uint32_t m, uint32_t o) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] & m) | o; return r; }
+  M mrshr1(const M& x) const { EM r; for (int i = 0; i < 64; i++) r.a[i] = (i & 15) ? x.a[i - 1] : false; return r; }
+  static M msel(const M& c, const M& x, const M& y) { EM r; for (int i = 0; i < 64; i++) r.a[i] = c.a[i] ? x.a[i] : y.a[i]; return r; }
+  static U pack16(const U& lo, const U& hi) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (lo.a[i] & 0xFFFFu) | (hi.a[i] << 16); return r; }
   static U umax(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] > y.a[i] ? x.a[i] : y.a[i]; return r; }
   static U umin(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] < y.a[i] ? x.a[i] : y.a[i]; return r; }
   static U umax3(const U& x, const U& y, const U& z) { return umax(umax(x, y), z); }

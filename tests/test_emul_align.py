@@ -145,7 +145,8 @@ def test_emul_quad_kernel(emul, oracle):
     anc = _pssm(oracle, "ancient.submat.txt", 0)
     anc_rc = _pssm(oracle, "ancient.submat.txt", 1)
     emul.emu_align_quad.restype = C.c_int
-    for it in range(40):
+    n_band_escapes = 0
+    for it in range(80):
         len2 = rnd.choice([1, 2, 17, 50, 100, 100, 100, 101, 150])
         ng = rnd.choice([1, 2, 3, 4, 4, 4])
         use_anc = it % 2
@@ -154,7 +155,7 @@ def test_emul_quad_kernel(emul, oracle):
         pssm2 = np.concatenate([fwd, rcm]).astype(np.int32)
         ref = "".join(rnd.choice("ACGT") for _ in range(600))
         refc = codes(ref)
-        starts, len1s, reads, rcs = [], [], [], []
+        starts, len1s, reads, rcs, dexps = [], [], [], [], []
         for g in range(ng):
             st = rnd.randint(0, 300)
             l1 = rnd.randint(max(len2, 2), 208) if len2 <= 150 else 208
@@ -167,14 +168,20 @@ def test_emul_quad_kernel(emul, oracle):
                 frag[p:p + rnd.randint(1, 2)] = []
                 frag += [rnd.choice("ACGT") for _ in range(len2 - len(frag))]
             starts.append(st); len1s.append(l1); reads.append("".join(frag)[:len2].ljust(len2, "A")); rcs.append(rnd.randint(0, 1))
+            dexps.append(min(50, max(0, l1 - len2)) + (rnd.choice([0, 0, 0, 40, -35]) if it % 5 == 4 else 0))
         rd = np.concatenate([codes(r) for r in reads]).astype(np.uint8)
         out = (C.c_int32 * (5 * ng))()
         cols = np.full(4 * 256, -9, dtype=np.int16)
+        band = it % 2          # odd rounds: only the trace band around the expected diagonal is stored
         rcode = emul.emu_align_quad(ng, refc.ctypes.data_as(C.c_void_p), (C.c_int32 * ng)(*starts), (C.c_int32 * ng)(*len1s),
                                     rd.ctypes.data_as(C.c_void_p), len2, pssm2.ctypes.data_as(C.c_void_p), (C.c_int32 * ng)(*rcs), 1100,
-                                    out, cols.ctypes.data_as(C.c_void_p))
+                                    out, cols.ctypes.data_as(C.c_void_p), band, (C.c_int32 * ng)(*dexps))
         assert rcode == 0
         for g in range(ng):
+            if out[g * 5 + 4] & 8:      # ST_BAND: the path left the stored band -> the read is re-run with a full trace
+                assert band
+                n_band_escapes += 1
+                continue
             s1 = ref[starts[g]:starts[g] + len1s[g]]
             pm = (anc_rc if rcs[g] else anc) if use_anc else flat
             res = oc.Aln(); rg = C.create_string_buffer(520); fg = C.create_string_buffer(520)
@@ -185,3 +192,4 @@ def test_emul_quad_kernel(emul, oracle):
             assert (got[0], got[1], got[2], got[3]) == (res.best, res.abc, res.abr, res.aec), (it, g, got, res.best, res.abc, res.abr, res.aec)
             r, f = script_to_strings(s1, reads[g], cols[g * 256:(g + 1) * 256], res.abr, res.aer)
             assert r == rg.value.decode() and f == fg.value.decode(), (it, g)
+    assert 0 < n_band_escapes < 40
