@@ -38,7 +38,23 @@ struct QuadArgs {                 // wave-uniform; [g] = read of lane row g, len
   int32_t dexp[Q_G];
   uint32_t dbg;
 };
-constexpr uint32_t Q_SUB_BYTES = MAX_READ * 10;
+// LDS substitution tables: sub[code][row] int16.  The row stride is padded so that the five code rows of a read
+// start >= 4 banks apart and consecutive reads are shifted by one bank: the 20 (read, code) rows of a quad then
+// hit 20 different banks (measured before: half of the LDS cycles were bank conflicts).
+MIA_HD inline uint32_t q_sub_stride(int len2) {
+  uint32_t dw = (uint32_t)((len2 + 1) / 2);
+  for (;; dw++) {
+    uint32_t k = dw & 31u, ok = 1;
+    for (uint32_t c1 = 0; c1 < 5 && ok; c1++)
+      for (uint32_t c2 = c1 + 1; c2 < 5; c2++) {
+        uint32_t d = (k * c2 - k * c1) & 31u;
+        if (d < 4u || d > 28u) { ok = 0; break; }
+      }
+    if (ok) return dw * 4u;
+  }
+}
+// bytes between the tables of two reads of a quad: the padded table plus one bank of shift
+MIA_HD inline uint32_t q_sub_bytes(int len2) { return 5u * q_sub_stride(len2) + 4u; }
 
 template <class P>
 struct QuadAligner {
@@ -60,7 +76,7 @@ struct QuadAligner {
     const U lane = w.lane();
     const U grp = lane >> 4, gl = lane & 15u;
     const int len2 = a.len2;
-    const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;
+    const uint32_t RS2 = q_sub_stride(len2);
     // per-lane copies of the per-read scalars
     U len1v = U(0u), startv = U(0u), roffv = U(0u), pmoff = U(0u), dbias = U(4096u);
     for (int g = 0; g < Q_G; g++) {
@@ -71,7 +87,7 @@ struct QuadAligner {
       pmoff = w.sel(mine, U(a.rc[g] ? (uint32_t)PSSM_WORDS : 0u), pmoff);
       dbias = w.sel(mine, U((uint32_t)(a.dexp[g] + 4096)), dbias);   // biased so that band arithmetic stays unsigned
     }
-    const U subbase = U(a.lds_sub) + grp * Q_SUB_BYTES;
+    const U subbase = U(a.lds_sub) + grp * q_sub_bytes(len2);
     const U trbase = grp * a.slab_group + gl * 32u;
 
     // ---- substitution tables, 16 lanes per read
@@ -112,6 +128,7 @@ struct QuadAligner {
     // state is rebuilt from the winning word with one AND-OR and one shift-add of the substitution score.
     const uint32_t HI = ~((1u << SH) - 1u);
     U Sd[CPL], q[CPL], rrun[CPL];
+    const U wdcv = U(WDC);
     for (int j = 0; j < CPL; j++) {
       Sd[j] = ((w.lds_ri16(sub_addr[j]) + OFF) << SH) | WDC;
       q[j] = Sd[j] + (QC[j] - WDC);
@@ -124,7 +141,8 @@ struct QuadAligner {
       w.tr_w128m(trbase + 16u, d4, d4, d4, d4, ib0);
     }
 
-    for (int r = 1; r < ((a.dbg & 4u) ? 1 : len2); r++) {
+    // one DP row; `off` (0 or 2) is the immediate LDS offset of this row inside the current row pair
+    auto do_row = [&](const int r, const uint32_t off) __attribute__((always_inline)) {
       const int32_t fresh = -(GOP + GEP * (r + 1));
       const uint32_t freshb = (uint32_t)(fresh + (int32_t)OFF);
       const uint32_t WS = freshb << SH;
@@ -135,37 +153,49 @@ struct QuadAligner {
       U rleft = w.rshr1_max(rrun[CPL - 1], unav);
       U u0 = w.rshr1_max(q[CPL - 2], unav);
       U u1 = w.rshr1_max(q[CPL - 1], unav);
-      U g[CPL];
-      g[0] = u0;
-      g[1] = w.umax(u0, u1);
-      for (int j = 2; j < CPL; j++) g[j] = w.umax(g[j - 1], q[j - 2]);
-      U excl = w.rshr1_max(w.rscan_max(g[CPL - 1]), unav);
+      // lane total by a max3 tree (6 ops), then -- with the prefix of the lanes to the left folded in --
+      // cand[j] = best key over all columns <= c_j - 2 as one running chain
+      U tot = w.umax3(w.umax3(u0, u1, q[0]), w.umax3(q[1], q[2], q[3]),
+                      w.umax3(w.umax3(q[4], q[5], q[6]), w.umax3(q[7], q[8], q[9]), q[10]));
+      U excl = w.rshr1_max(w.rscan_max(tot), unav);
+      U cand[CPL];
+      cand[0] = w.umax(excl, u0);
+      cand[1] = w.umax(cand[0], u1);
+      for (int j = 2; j < CPL; j++) cand[j] = w.umax(cand[j - 1], q[j - 2]);
 
-      // trace cell = low 16 bits of the winning word ([..|prio:2|len:8]); two cells per dword, no saturation
-      U bodd = U(0u), packed[8];
-      packed[7] = U(0u);
+      // trace cell = low 16 bits of the winning word ([..|prio:2|len:8]); two cells per dword, no saturation.
+      // Cells are visited right to left; each 16-byte half of the lane's trace row is stored as soon as it is complete.
+      const M ib = in_band(w, a, dbias, gl * (uint32_t)CPL, (uint32_t)r);
+      const U trrow = trbase + (uint32_t)r * Q_TRACE_STRIDE;
+      U bodd = U(0u), pk[4];
+      pk[3] = U(0u);
       for (int j = CPL - 1; j >= 0; j--) {
         U Wd = (j == 0) ? dleft : Sd[j - 1];
         U rl = (j == 0) ? rleft : rrun[j - 1];
-        U Wc = w.add3(w.umax(excl, g[j]), KC0, (uint32_t)j * KCD);
+        U Wc = w.add3(cand[j], KC0, (uint32_t)j * KCD);
         U Wr = rl + KR;
         U m3 = w.umax3(Wd, Wc, Wr);
         U best = w.umax(m3, U(WS));
-        U sub = w.lds_ri16(sub_addr[j] + (uint32_t)r * 2u);
+        U sub = w.lds_ri16o(sub_addr[j], off);
         // start (only if strictly better than the other three) drops the substitution score (src/mia.c:910-917)
-        U snew = w.shl_add(w.sel(m3 < WS, U(0u), sub), SH, w.and_or(best, HI, WDC));
+        U snew = w.shl_add(w.sel(m3 < WS, U(0u), sub), SH, w.bfi(HI, best, wdcv));
         rrun[j] = w.umax(rrun[j], Sd[j] + RKP);   // row r-1 becomes a best_gap_row candidate for row r+1
         Sd[j] = snew;
         q[j] = snew + (QC[j] - WDC);
-        if (j == CPL - 1) packed[6] = best & 0xFFFFu;
+        if (j == CPL - 1) pk[2] = best & 0xFFFFu;            // cell 12 (+ pad)
         else if (j & 1) bodd = best;
-        else packed[j >> 1] = w.pack16(best, bodd);
+        else pk[(j >> 1) & 3] = w.pack16(best, bodd);          // cells (j, j+1)
+        if (j == 8 && !(a.dbg & 1u)) w.tr_w128m(trrow + 16u, pk[0], pk[1], pk[2], pk[3], ib);   // cells 8..12
       }
-      if (!(a.dbg & 1u)) {
-        const M ib = in_band(w, a, dbias, gl * (uint32_t)CPL, (uint32_t)r);
-        w.tr_w128m(trbase + (uint32_t)r * Q_TRACE_STRIDE, packed[0], packed[1], packed[2], packed[3], ib);
-        w.tr_w128m(trbase + (uint32_t)r * Q_TRACE_STRIDE + 16u, packed[4], packed[5], packed[6], packed[7], ib);
-      }
+      if (!(a.dbg & 1u)) w.tr_w128m(trrow, pk[0], pk[1], pk[2], pk[3], ib);                      // cells 0..7
+    };
+    // rows are processed in pairs so that the substitution-table address of a column is bumped once per two rows
+    const int rows = (a.dbg & 4u) ? 1 : len2;
+    for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 2u;      // -> row 1
+    for (int r = 1; r < rows; r += 2) {
+      do_row(r, 0u);
+      if (r + 1 < rows) do_row(r + 1, 2u);
+      for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 4u;
     }
 
     // ---- max_sg_score per read (16-lane row); the state words order like scores

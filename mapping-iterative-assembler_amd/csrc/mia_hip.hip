@@ -358,7 +358,8 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     hipEvent_t e0, e1;
     if (get_events(ctx, &e0, &e1)) return MIA_HIP_ERR_NOMEM;
     (void)hipEventRecord(e0, ctx->stream);
-    hipLaunchKernelGGL(k_align_quad, dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list + quad_begin,
+    const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
+    hipLaunchKernelGGL(k_align_quad, dim3(grid), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list + quad_begin,
                        n_quads, ctx->d_quad_slabs, slab, ctx->d_wide_list, d_wide_count, ctx->d_retry_list, d_retry_count, ctx->use_band,
                        ctx->dbg);
     (void)hipEventRecord(e1, ctx->stream);

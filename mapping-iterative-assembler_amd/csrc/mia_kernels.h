@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, c
                                                     int32_t n_quads, unsigned char* trace_slabs, int64_t slab_bytes,
                                                     int32_t* wide_list, int32_t* wide_count, int32_t* retry_list, int32_t* retry_count,
                                                     int32_t band, uint32_t dbg) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[Q_G * Q_SUB_BYTES];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // Q_G * q_sub_bytes(longest read)
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
   for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
     QuadArgs a;

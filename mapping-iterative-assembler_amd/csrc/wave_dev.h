@@ -84,7 +84,20 @@ struct DevWave {
   __device__ __forceinline__ void tr_w128m(U off, U v0, U v1, U v2, U v3, M ok) const {
     if (ok) *reinterpret_cast<uint4*>(trace + off) = make_uint4(v0, v1, v2, v3);
   }
-  __device__ __forceinline__ static U shl_add(U x, int sh, U y) { return (x << sh) + y; }   // v_lshl_add_u32
+  // (x << sh) + y as ONE v_lshl_add_u32 (the optimiser otherwise splits it)
+  __device__ __forceinline__ static U shl_add(U x, int sh, U y) {
+    U r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(10), "v"(y));
+    (void)sh;
+    return r;
+  }
+  // (m & x) | (~m & y), m wave-uniform: one v_bfi_b32
+  __device__ __forceinline__ static U bfi(uint32_t m, U x, U y) {
+    U r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(m), "v"(x), "v"(y));
+    return r;
+  }
+  __device__ __forceinline__ U lds_ri16o(U off, uint32_t imm) const { return (U)(int32_t)*reinterpret_cast<const int16_t*>(lds + off + imm); }
   __device__ __forceinline__ static U and_or(U x, uint32_t m, uint32_t o) { return (x & m) | o; }   // v_and_or_b32
   // lane mask moved one lane up inside each 16-lane row; the first lane of a row gets false
   __device__ __forceinline__ M mrshr1(M x) const {

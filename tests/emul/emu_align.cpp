@@ -94,7 +94,7 @@ extern "C" int emu_align_quad(int ng, const uint8_t* ref_codes, const int32_t* r
       for (int i = 0; i < len2; i++) packed[a.roff[g] + (i >> 1)] |= (uint8_t)(read_codes[g * len2 + i] << ((i & 1) * 4));
     }
   }
-  EmuWave w(Q_G * Q_SUB_BYTES + 64, (size_t)Q_G * a.slab_group + 64);
+  EmuWave w(Q_G * q_sub_bytes(len2) + 64, (size_t)Q_G * a.slab_group + 64);
   AlignResult res[Q_G];
   QuadAligner<EmuWave>::run(w, a, res);
   for (int g = 0; g < ng; g++) {

@@ -89,6 +89,8 @@ struct EmuWave {
   M mrshr1(const M& x) const { EM r; for (int i = 0; i < 64; i++) r.a[i] = (i & 15) ? x.a[i - 1] : false; return r; }
   static M msel(const M& c, const M& x, const M& y) { EM r; for (int i = 0; i < 64; i++) r.a[i] = c.a[i] ? x.a[i] : y.a[i]; return r; }
   static U pack16(const U& lo, const U& hi) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (lo.a[i] & 0xFFFFu) | (hi.a[i] << 16); return r; }
+  static U bfi(uint32_t m, const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] & m) | (y.a[i] & ~m); return r; }
+  U lds_ri16o(const U& off, uint32_t imm) const { EV r; for (int i = 0; i < 64; i++) { int16_t x; lds.at(off.a[i] + imm + 1); memcpy(&x, &lds[off.a[i] + imm], 2); r.a[i] = (uint32_t)(int32_t)x; } return r; }
   static U umax(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] > y.a[i] ? x.a[i] : y.a[i]; return r; }
   static U umin(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] < y.a[i] ? x.a[i] : y.a[i]; return r; }
   static U umax3(const U& x, const U& y, const U& z) { return umax(umax(x, y), z); }
