@@ -34,10 +34,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 BYTES_PER_READ = 182      # 50 B packed bases + 16 B meta in, 16 B result + 100 B script out
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # memory-side bytes per read of k_align_quad, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate
-# passes (profiles/r01/pmc/quad_summary_kb_per_launch.json: 6.44e6 KB + 25.26e6 KB per 1 M-read launch, counters as
-# reported, no width correction): almost all of it is the 25.6 KB/read byte trace (16 B per lane and row) going to the
-# per-workgroup slabs
-TRAFFIC_BYTES_PER_READ = (6438078 + 25259702) * 1024 / 1_000_000
+# passes (profiles/r01/pmc/band_summary_kb_per_launch.json: 7.08e6 KB + 13.59e6 KB per 1 M-read launch, counters as
+# reported, no width correction): almost all of it is the trace band (16-bit cells, ~30 % of the lanes) going to the
+# per-workgroup slabs; the full byte trace cost 31.7e6 KB
+TRAFFIC_BYTES_PER_READ = (7078632 + 13590312) * 1024 / 1_000_000
+# SQ counters of the same kernel (profiles/r01/pmc/sq_counters_quad.json): the kernel is integer-VALU bound
+VALU_UTILISATION_PMC = 0.89
 
 
 class DevArray:
@@ -211,7 +213,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_READ * reads_per_launch,
                          "kernel": "k_align_quad", "kernel_ms": k_ms, "launches": launches,
-                         "note": "integer-VALU/LDS-bound DP: 182 algorithmic HBM bytes per read (SURVEY 8d); see DESIGN.md for GCUPS vs VALU peak",
+                         "note": "integer-VALU-bound DP (SQ_ACTIVE_INST_VALU = 89 % of SIMD capacity, profiles/r01/pmc): 182 algorithmic HBM bytes per read (SURVEY 8d) put it at a fraction of a percent of the HBM roof by construction; see DESIGN.md 3.1",
+                         "valu_utilisation": VALU_UTILISATION_PMC,
                          "gcups": reads_per_launch * 100 * 200 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
         }
         # pass 1 (new_kmer_filter + sg_align over the whole wrapped reference, both strands), reported separately
