@@ -155,6 +155,8 @@ int mia_hip_myers(mia_hip_ctx *ctx, int64_t n_pairs, const char *const *seq_a, c
 /* ---- timing hooks for bench.py (HIP events on the context's stream) ------ */
 /* milliseconds spent in, and launches of, the windowed DP kernel since the last reset */
 int mia_hip_kernel_time(mia_hip_ctx *ctx, int reset, double *align_ms, int64_t *align_launches);
+/* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
+int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ def _load():
     lib.mia_hip_get_tally.argtypes = [vp, vp, vp]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
     return lib
 
@@ -74,7 +75,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time"]
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time"]
 
 
 def _ptr(a):
@@ -265,6 +266,11 @@ class MiaHip:
         ms, k = C.c_double(), C.c_int64()
         self._chk(self._l.mia_hip_kernel_time(self._h, 1 if reset else 0, C.byref(ms), C.byref(k)))
         return ms.value, k.value
+
+    def pass1_time(self):
+        ms = C.c_double()
+        self._chk(self._l.mia_hip_pass1_time(self._h, C.byref(ms)))
+        return ms.value
 
     def sync(self):
         self._chk(self._l.mia_hip_sync(self._h))

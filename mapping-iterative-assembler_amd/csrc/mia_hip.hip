@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -52,6 +54,8 @@ struct mia_hip_ctx {
   int quad_wgs = 0;
   int use_quad = 1;   // MIA_HIP_NO_QUAD=1 routes everything through the one-read-per-wave kernels
   int grid_wgs = 0;
+  int window_wgs[N_CPL] = {0, 0, 0};
+  int cus = 1;
   uint32_t dbg = 0;   // MIA_HIP_DEBUG_SKIP: timing experiments only, results are wrong when set
   // read bucketing for the LDS-privatised tally
   int32_t* d_bucket = nullptr; int bucket_cap = 0; int32_t* d_order = nullptr;
@@ -61,6 +65,7 @@ struct mia_hip_ctx {
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
   double align_ms = 0; int64_t align_launches = 0;
+  double pass1_ms = 0;
 };
 
 #define HIPCHK(call)                                                                                   \
@@ -99,6 +104,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     // persistent DP grid: one 64-lane workgroup per wave slot of the chip (8 waves/SIMD x 4 SIMDs x CUs)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_index) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
+    ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
     ctx->grid_wgs = prop.multiProcessorCount * 32;
     ctx->quad_wgs = prop.multiProcessorCount * 16;   // 128 VGPRs -> 4 waves per SIMD
     const char* nbt = getenv("MIA_HIP_NO_BINNED_TALLY");
@@ -286,7 +292,16 @@ template <int CPL>
 static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count) {
   // slab = the largest trace of this class: 256 rows x 64*CPL columns, one byte per cell
   const int64_t slab = (int64_t)MAX_READ * 64 * CPL;
-  const int grid = count < ctx->grid_wgs ? count : ctx->grid_wgs;
+  // persistent grid: never more workgroups than are resident at once (a late starter would work through its whole
+  // share of the list on a drained GPU)
+  if (!ctx->window_wgs[ci]) {
+    int occ = 0;
+    const int cus = ctx->cus;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_align_window<CPL>, 64, 0) != hipSuccess || occ < 1) occ = 1;
+    const int per_cu = ctx->grid_wgs / cus;      // the configured ceiling (MIA_HIP_GRID_WAVES_PER_CU)
+    ctx->window_wgs[ci] = cus * (occ < per_cu ? occ : per_cu);
+  }
+  const int grid = count < ctx->window_wgs[ci] ? count : ctx->window_wgs[ci];
   if (!ctx->d_slabs[ci]) {
     if (hipMalloc((void**)&ctx->d_slabs[ci], (size_t)slab * ctx->grid_wgs) != hipSuccess) return hipErrorOutOfMemory;
   }
@@ -724,12 +739,14 @@ static char revcom_char_host(char b) {   // src/map_align.c:418-432
   return r ? r : 'N';
 }
 
-// populate_kpa + add_kmer (src/kmer.c:65-107,153-168) as a CSR table: ascending positions, at most 128 per k-mer
-static void build_kmer_csr(const std::string& seq, int k, int soft_mask, std::vector<int32_t>& off, std::vector<int32_t>& pos) {
-  const size_t nk = (size_t)1 << (2 * k);
-  off.assign(nk + 1, 0);
+// populate_kpa + add_kmer (src/kmer.c:65-107,153-168): the k-mers that occur in `seq`, each with its ascending
+// positions (at most 128; further ones are silently dropped, :75-77).  Only the occurring k-mers are listed -- the
+// dense 4^k table is zeroed and filled on the device.
+static void build_kmer_lists(const std::string& seq, int k, int soft_mask, std::vector<uint32_t>& kmer, std::vector<uint32_t>& entry,
+                             std::vector<int32_t>& pos) {
   const int n = (int)seq.size();
-  std::vector<int64_t> inx((size_t)(n > 0 ? n : 1), -1);
+  std::vector<uint64_t> kp;   // (k-mer << 32) | position: sorting keeps positions ascending inside a k-mer
+  kp.reserve((size_t)(n > 0 ? n : 1));
   for (int i = 0; i + k <= n; i++) {
     bool ok = true;
     uint64_t v = 0;
@@ -739,13 +756,20 @@ static void build_kmer_csr(const std::string& seq, int k, int soft_mask, std::ve
       switch (c & ~32) { case 'A': v = v << 2; break; case 'C': v = (v << 2) | 1; break; case 'G': v = (v << 2) | 2; break;
                          case 'T': v = (v << 2) | 3; break; default: ok = false; }
     }
-    if (!ok) continue;
-    if (off[v + 1] < MAX_KMER_POS) { off[v + 1]++; inx[i] = (int64_t)v; }   // further positions are silently dropped (:75-77)
+    if (ok) kp.push_back((v << 32) | (uint32_t)i);
   }
-  for (size_t v = 0; v < nk; v++) off[v + 1] += off[v];
-  pos.assign((size_t)off[nk] + 1, 0);
-  std::vector<int32_t> cur(off.begin(), off.end() - 1);
-  for (int i = 0; i < n; i++) if (inx[i] >= 0) pos[cur[inx[i]]++] = i;
+  std::sort(kp.begin(), kp.end());
+  kmer.clear(); entry.clear(); pos.clear();
+  for (size_t i = 0; i < kp.size();) {
+    size_t j = i;
+    while (j < kp.size() && (kp[j] >> 32) == (kp[i] >> 32)) j++;
+    const size_t cnt = (j - i) < (size_t)MAX_KMER_POS ? (j - i) : (size_t)MAX_KMER_POS;
+    kmer.push_back((uint32_t)(kp[i] >> 32));
+    entry.push_back((uint32_t)(pos.size() << 8) | (uint32_t)cnt);
+    for (size_t t = 0; t < cnt; t++) pos.push_back((int32_t)(uint32_t)kp[i + t]);
+    i = j;
+  }
+  pos.push_back(0);
 }
 
 extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len, int circular, int kmer_len, int soft_mask,
@@ -753,16 +777,19 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
                              int32_t* ae, uint8_t* flags) {
   if (!ctx || !ref || ref_len <= 0 || n < 0 || (n > 0 && (!bases || !offsets || !score || !rc || !as || !ae || !flags))) return MIA_HIP_ERR_ARG;
   if (!ctx->have_pssm) { ctx->err = "set_pssm must precede pass1"; return MIA_HIP_ERR_STATE; }
+  const bool timing = getenv("MIA_HIP_P1_TIMING") != nullptr;
+  auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mia_hip_pass1] %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_start).count());
+    t_start = t;
+  };
   if (kmer_len > 14) { ctx->err = "Cannot use kmer length greater than 14"; return MIA_HIP_ERR_ARG; }   // MAX_KMER_LEN
   HIPCHK(hipSetDevice(ctx->device));
   if (n == 0) return MIA_HIP_OK;
   PackParams pk;
   if (!make_pack_params(1024, ctx->max_abs, &pk)) { ctx->err = "PSSM too large for the packed pass-1 kernel"; return MIA_HIP_ERR_RANGE; }
-  // dropping candidates further left than 768 columns is exact only if they can never beat a new start
-  // (a score is at most rows * max positive entry; a new start costs P(rows+1); a gap of >= 767 columns costs P(767))
-  if ((int64_t)MAX_READ * ctx->max_pos + (GOP + GEP * (MAX_READ + 1)) >= (int64_t)(GOP + GEP * (P1_REL - 1))) {
-    ctx->err = "PSSM too large for the pass-1 candidate horizon"; return MIA_HIP_ERR_RANGE;
-  }
   // reference strands: make_reverse_complement, add_ref_wrap, (k-mer tables), make_ref_upper -- src/mia_main.c:637-676
   const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl, len1 = circular ? wrap : L;
   std::string fw(ref, ref + L), rcs((size_t)L, 'N');
@@ -771,24 +798,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   rcs += rcs.substr(0, wl);
   std::vector<uint8_t> cf((size_t)wrap + 64, 4), cr((size_t)wrap + 64, 4);
   for (int i = 0; i < wrap; i++) { cf[i] = base_code((char)toupper((unsigned char)fw[i])); cr[i] = base_code((char)toupper((unsigned char)rcs[i])); }
-  uint8_t *d_cf = nullptr, *d_cr = nullptr;
-  int32_t *d_off[2] = {nullptr, nullptr}, *d_pos[2] = {nullptr, nullptr};
-  int rcx = dev_alloc(ctx, &d_cf, cf.size()) | dev_alloc(ctx, &d_cr, cr.size());
-  KmerIndex kx{};
-  kx.k = kmer_len > 0 ? kmer_len : -1;
-  if (kx.k > 0) {
-    for (int s = 0; s < 2; s++) {
-      std::vector<int32_t> off, pos;
-      build_kmer_csr(s ? rcs : fw, kx.k, soft_mask, off, pos);
-      rcx |= dev_alloc(ctx, &d_off[s], off.size()) | dev_alloc(ctx, &d_pos[s], pos.size());
-      if (rcx) break;
-      HIPCHK(hipMemcpy(d_off[s], off.data(), off.size() * 4, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(d_pos[s], pos.data(), pos.size() * 4, hipMemcpyHostToDevice));
-      kx.off[s] = d_off[s];
-      kx.pos[s] = d_pos[s];
-    }
-  }
-  // reads (as sequenced)
+  // reads (as sequenced); validated before anything is allocated on the device
   std::vector<uint32_t> roff((size_t)n);
   std::vector<uint16_t> len((size_t)n);
   uint64_t total = 0;
@@ -801,11 +811,61 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
     total += (uint64_t)(((l + 1) / 2 + 3) & ~3);
     if (total >= ((uint64_t)1 << 32)) { ctx->err = "packed read store exceeds 4 GiB per call"; return MIA_HIP_ERR_ARG; }
   }
+  // Chunk width.  Dropping candidates further left than the horizon `rel` is exact only if they can never beat a
+  // new start: a score is at most rows * max positive entry, a new start costs P(rows+1), a gap of >= rel-1 columns
+  // costs P(rel-1).  Wide chunks (768 columns, horizon 256) for the unmasked sweep when that holds, else narrow
+  // ones (256 columns, horizon 768), which also skip masked stretches at a finer grain.
+  auto horizon_ok = [&](int rel) {
+    return (int64_t)max_len * ctx->max_pos + (GOP + GEP * (max_len + 1)) < (int64_t)(GOP + GEP * (rel - 1));
+  };
+  int cpl = (kmer_len <= 0 && horizon_ok(p1_rel(P1_CPL_WIDE))) ? P1_CPL_WIDE : P1_CPL_NARROW;
+  if (const char* ev = getenv("MIA_HIP_P1_CPL")) {
+    const int want = atoi(ev);
+    if ((want == P1_CPL_WIDE && horizon_ok(p1_rel(P1_CPL_WIDE))) || want == P1_CPL_NARROW) cpl = want;
+  }
+  if (!horizon_ok(p1_rel(cpl))) { ctx->err = "PSSM too large for the pass-1 candidate horizon"; return MIA_HIP_ERR_RANGE; }
+  const int P1_CH = p1_ch(cpl);
+  if (kmer_len > 0 && (size_t)wrap >= ((size_t)1 << 24)) { ctx->err = "reference too long for the k-mer table"; return MIA_HIP_ERR_RANGE; }
+  uint8_t *d_cf = nullptr, *d_cr = nullptr;
+  uint32_t *d_tab[2] = {nullptr, nullptr}, *d_kl[2] = {nullptr, nullptr}, *d_el[2] = {nullptr, nullptr};
+  int32_t* d_pos[2] = {nullptr, nullptr};
+  int rcx = dev_alloc(ctx, &d_cf, cf.size()) | dev_alloc(ctx, &d_cr, cr.size());
+  KmerIndex kx{};
+  kx.k = kmer_len > 0 ? kmer_len : -1;
+  if (kx.k > 0 && !rcx) {
+    const size_t nk = (size_t)1 << (2 * kx.k);
+    for (int s = 0; s < 2 && !rcx; s++) {
+      std::vector<uint32_t> kmer, entry;
+      std::vector<int32_t> pos;
+      build_kmer_lists(s ? rcs : fw, kx.k, soft_mask, kmer, entry, pos);
+      const size_t ne = kmer.size();
+      rcx |= dev_alloc(ctx, &d_tab[s], nk) | dev_alloc(ctx, &d_pos[s], pos.size()) | dev_alloc(ctx, &d_kl[s], ne + 1) |
+             dev_alloc(ctx, &d_el[s], ne + 1);
+      if (rcx) break;
+      hipError_t ke = hipMemsetAsync(d_tab[s], 0, nk * 4, ctx->stream);
+      if (ke == hipSuccess) ke = hipMemcpy(d_pos[s], pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
+      if (ke == hipSuccess && ne) ke = hipMemcpy(d_kl[s], kmer.data(), ne * 4, hipMemcpyHostToDevice);
+      if (ke == hipSuccess && ne) ke = hipMemcpy(d_el[s], entry.data(), ne * 4, hipMemcpyHostToDevice);
+      if (ke == hipSuccess && ne) {
+        hipLaunchKernelGGL(k_kmer_fill, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, (int32_t)ne, d_kl[s], d_el[s], d_tab[s]);
+        ke = hipGetLastError();
+      }
+      if (ke != hipSuccess) { ctx->err = std::string("pass1 k-mer table: ") + hipGetErrorString(ke); rcx = 2; }
+      kx.tab[s] = d_tab[s];
+      kx.pos[s] = d_pos[s];
+    }
+  }
+  lap("ref+kmer");
+  uint8_t code_lut[256];
+  for (int c = 0; c < 256; c++) code_lut[c] = base_code((char)c);
   std::vector<uint8_t> packed((size_t)total + 8, 0);
   for (int64_t i = 0; i < n; i++) {
     const char* sq = bases + offsets[i];
     uint8_t* d = packed.data() + roff[i];
-    for (int k = 0; k < len[i]; k++) d[k >> 1] |= (uint8_t)(base_code(sq[k]) << ((k & 1) * 4));
+    const int l = len[i];
+    int k = 0;
+    for (; k + 1 < l; k += 2) d[k >> 1] = (uint8_t)(code_lut[(uint8_t)sq[k]] | (code_lut[(uint8_t)sq[k + 1]] << 4));
+    if (k < l) d[k >> 1] = code_lut[(uint8_t)sq[k]];
   }
   uint8_t *d_packed = nullptr, *d_rc = nullptr, *d_flags = nullptr;
   uint32_t *d_roff = nullptr, *d_status = nullptr;
@@ -818,10 +878,15 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   const int nch = (len1 + P1_CH - 1) / P1_CH, mask_words = nch * (P1_CH / 32) + 4;
   const int lds = MAX_READ * 10 + 5 * MAX_READ * 4 + 2 * mask_words * 4;
   const int rows_p = (max_len + 3) & ~3;
-  const int64_t trace_bytes = (int64_t)MAX_READ * P1_CH * 2, ckpt_words = (int64_t)2 * nch * 5 * rows_p;
-  int waves_cu = (160 * 1024) / ((lds + 511) & ~511);
-  if (waves_cu > 16) waves_cu = 16;
-  if (waves_cu < 1) { ctx->err = "reference too long for the pass-1 LDS masks"; return MIA_HIP_ERR_RANGE; }
+  const int64_t trace_bytes = (int64_t)rows_p * P1_CH * 2, ckpt_words = (int64_t)2 * nch * 5 * rows_p;
+  if (lds > 160 * 1024) { ctx->err = "reference too long for the pass-1 LDS masks"; return MIA_HIP_ERR_RANGE; }
+  // persistent grid = exactly the waves that are resident at once (registers AND LDS): a wave that only starts
+  // when another has drained would run its whole share of the reads on a nearly idle GPU
+  auto kfn = (cpl == P1_CPL_WIDE) ? k_pass1<P1_CPL_WIDE> : k_pass1<P1_CPL_NARROW>;
+  HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  int waves_cu = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_cu, (const void*)kfn, 64, (size_t)lds));
+  if (waves_cu < 1) { ctx->err = "pass-1 kernel does not fit a compute unit"; return MIA_HIP_ERR_RANGE; }
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
   int64_t grid = (int64_t)prop.multiProcessorCount * waves_cu;
@@ -829,25 +894,37 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   unsigned char* d_trace = nullptr;
   uint32_t* d_ckpt = nullptr;
   rcx |= dev_alloc(ctx, &d_trace, (size_t)(trace_bytes * grid)) | dev_alloc(ctx, &d_ckpt, (size_t)(ckpt_words * grid));
-  void* tmp[] = {d_cf, d_cr, d_off[0], d_off[1], d_pos[0], d_pos[1], d_packed, d_roff, d_len, d_rc, d_flags, d_status, d_score, d_as, d_ae, d_trace, d_ckpt};
+  void* tmp[] = {d_cf, d_cr, d_tab[0], d_tab[1], d_kl[0], d_kl[1], d_el[0], d_el[1], d_pos[0], d_pos[1], d_packed, d_roff, d_len, d_rc, d_flags, d_status, d_score, d_as, d_ae, d_trace, d_ckpt};
   auto cleanup = [&]() { for (void* p : tmp) if (p) (void)hipFree(p); };
-  if (rcx) { cleanup(); return MIA_HIP_ERR_NOMEM; }
+  if (rcx) { cleanup(); return rcx == 2 ? MIA_HIP_ERR_DEVICE : MIA_HIP_ERR_NOMEM; }
+  lap("pack+alloc");
   hipError_t e = hipSuccess;
+  hipEvent_t pe0 = nullptr, pe1 = nullptr;
   auto cp = [&](void* d, const void* h, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
   cp(d_cf, cf.data(), cf.size()); cp(d_cr, cr.data(), cr.size());
   cp(d_packed, packed.data(), packed.size()); cp(d_roff, roff.data(), (size_t)n * 4); cp(d_len, len.data(), (size_t)n * 2);
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e == hipSuccess) {
     Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
-    hipLaunchKernelGGL(k_pass1, dim3((unsigned)grid), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
+    if (get_events(ctx, &pe0, &pe1) == 0) (void)hipEventRecord(pe0, ctx->stream);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
                        trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words);
+    if (pe1) (void)hipEventRecord(pe1, ctx->stream);
     e = hipGetLastError();
   }
   auto back = [&](void* h, const void* d, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, ctx->stream); };
   back(score, d_score, (size_t)n * 4); back(as, d_as, (size_t)n * 4); back(ae, d_ae, (size_t)n * 4);
   back(rc, d_rc, (size_t)n); back(flags, d_flags, (size_t)n);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  lap("h2d+kernel+d2h");
+  if (pe0 && pe1) {
+    float ms = 0;
+    if (e == hipSuccess && hipEventElapsedTime(&ms, pe0, pe1) == hipSuccess) ctx->pass1_ms = ms;
+    // the pair sits at the back of ev_used (pushed by get_events): hand it back without counting it as an align launch
+    ctx->ev_free.push_back(ctx->ev_used.back());
+    ctx->ev_used.pop_back();
+  }
   cleanup();
+  lap("free");
   if (e != hipSuccess) { ctx->err = std::string("pass1: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   return MIA_HIP_OK;
 }
@@ -889,5 +966,11 @@ extern "C" int mia_hip_myers(mia_hip_ctx* ctx, int64_t n, const char* const* seq
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_blob); (void)hipFree(d_pairs); (void)hipFree(d_out);
   if (e != hipSuccess) { ctx->err = std::string("myers: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_pass1_time(mia_hip_ctx* ctx, double* kernel_ms) {
+  if (!ctx || !kernel_ms) return MIA_HIP_ERR_ARG;
+  *kernel_ms = ctx->pass1_ms;
   return MIA_HIP_OK;
 }

@@ -30,11 +30,17 @@ struct Pass1Reads {
   uint32_t* status;
 };
 
-struct KmerIndex {          // CSR over 4^k k-mers: positions (ascending, at most 128 each) on the wrapped reference
-  const int32_t* off[2];    // [0] forward strand, [1] reverse-complement strand
-  const int32_t* pos[2];
+struct KmerIndex {          // dense table over the 4^k k-mers of each strand of the wrapped reference
+  const uint32_t* tab[2];   // [0] forward, [1] reverse complement: (first index into pos << 8) | number of positions (<= 128)
+  const int32_t* pos[2];    // positions, ascending per k-mer
   int32_t k;                // < 0: no filter
 };
+
+// the table is zeroed with a memset; only the k-mers that occur in the reference are written (at most one per position)
+__global__ void k_kmer_fill(int32_t n, const uint32_t* kmer, const uint32_t* entry, uint32_t* table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) table[kmer[i]] = entry[i];
+}
 
 __device__ __forceinline__ void mask_or_range(uint32_t* m, int lo, int hi) {   // set bits lo..hi (inclusive) of an LDS bit mask
   for (int w = lo >> 5; w <= (hi >> 5); w++) {
@@ -44,6 +50,7 @@ __device__ __forceinline__ void mask_or_range(uint32_t* m, int lo, int hi) {   /
   }
 }
 
+template <int CPL>
 __global__ __launch_bounds__(64) void k_pass1(Pass1Reads rs, const uint8_t* ref_fw, const uint8_t* ref_rc, int32_t len1, int32_t L,
                                                const int32_t* pssm_fwd, PackParams pk, KmerIndex kx, unsigned char* trace_slabs,
                                                int64_t trace_bytes, uint32_t* ckpt_slabs, int64_t ckpt_words, int32_t rows_p,
@@ -87,8 +94,9 @@ __global__ __launch_bounds__(64) void k_pass1(Pass1Reads rs, const uint8_t* ref_
           }
         int cf = 0, cr = 0;
         if (ok) {
-          const int f0 = kx.off[0][inx], f1 = kx.off[0][inx + 1], r0 = kx.off[1][inx], r1 = kx.off[1][inx + 1];
-          cf = f1 - f0; cr = r1 - r0;
+          const uint32_t ef = kx.tab[0][inx], er = kx.tab[1][inx];
+          cf = (int)(ef & 255u); cr = (int)(er & 255u);
+          const int f0 = (int)(ef >> 8), f1 = f0 + cf, r0 = (int)(er >> 8), r1 = r0 + cr;
           for (int t = f0; t < f1; t++) {              // src/kmer.c:287-298
             const int p = kx.pos[0][t];
             int lo = p - fp - MASK_BUFFER, hi = p + (len2 - fp) + MASK_BUFFER;
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(64) void k_pass1(Pass1Reads rs, const uint8_t* ref_
     }
     a.read_packed = rp;
     a.len2 = len2;
-    Pass1Result r = Pass1Aligner<DevWave>::run(wave, a);
+    Pass1Result r = Pass1Aligner<DevWave, CPL>::run(wave, a);
     if (lane == 0) {
       // sg_align, src/mia.c:1568-1610,1614,1619,1653
       int start, end, as, ae;

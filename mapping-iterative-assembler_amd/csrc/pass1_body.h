@@ -31,10 +31,16 @@
 
 namespace mia {
 
-constexpr int P1_CH = 256;        // columns per chunk
-constexpr int P1_REL = 768;       // index offset: keys remember candidates up to 768 columns left of the chunk
 constexpr int P1_IB = 10, P1_SH = 12;
 constexpr uint32_t P1_IDXM = 1023u;
+// A chunk is 64*CPL columns (lane l owns CPL adjacent ones).  Two widths are compiled:
+//   CPL = 4   256-column chunks, keys remember candidates up to 768 columns left of the chunk  (k-mer masks: fine skipping)
+//   CPL = 12  768-column chunks, horizon 256 columns                                           (unmasked sweep: 3x less per-row overhead)
+// chunk + horizon always fill the 10-bit index field.
+MIA_HD constexpr int p1_ch(int cpl) { return WAVE * cpl; }
+MIA_HD constexpr int p1_rel(int cpl) { return (int)P1_IDXM + 1 - WAVE * cpl; }
+constexpr int P1_CPL_NARROW = 4, P1_CPL_WIDE = 12;
+constexpr int P1_CH_MAX = WAVE * P1_CPL_WIDE;
 
 struct Pass1Args {               // wave-uniform
   const uint8_t* ref_codes[2];   // [0] forward wrapped reference, [1] reverse complement, wrapped   [global]
@@ -57,12 +63,13 @@ struct Pass1Result {             // wave-uniform
   uint32_t status;
 };
 
-template <class P>
+template <class P, int CPL_>
 struct Pass1Aligner {
   typedef typename P::U U;
   typedef typename P::M M;
-  static constexpr int CPL = 4, IB = P1_IB, SH = P1_SH;
+  static constexpr int CPL = CPL_, IB = P1_IB, SH = P1_SH, CH = WAVE * CPL_, REL = (int)P1_IDXM + 1 - CH;
   static constexpr uint32_t IDXM = P1_IDXM;
+  static constexpr uint32_t WDC = TR_DIAG << IB;
 
   // move a carried key to a chunk base that is `cols` columns further right
   MIA_HD static inline U rebase(P& w, const U& e, uint32_t cols, uint32_t unav) {
@@ -79,118 +86,164 @@ struct Pass1Aligner {
   }
 
   // One chunk, all rows.  Carries are consumed from / produced into the LDS arrays in place.
-  // Returns through (cbest, ccol) the maximum biased score of the last row and its first column.
-  template <bool TRACE>
+  // Returns through (cbest, ccol) the maximum state word of the last row and its first column.
+  //
+  // The score state is kept SHIFTED with the diagonal priority already in place, exactly as in
+  // align_body_quad.h: Sd = ((S + off) << SH) | (TR_DIAG << IB) is the diagonal candidate of the
+  // cell below-right; an absent (masked) cell holds 0, which loses against everything.
+  // MASKED = false is the fast path for chunks in which every column exists and is open.
+  template <bool TRACE, bool MASKED>
   MIA_HD static inline void chunk(P& w, const Pass1Args& a, int strand, int ch, uint32_t& cbest, uint32_t& ccol) {
     const uint32_t OFF = (uint32_t)a.pk.off;
     const uint32_t UNAV = ((uint32_t)a.pk.unavail << SH) | IDXM;
-    const U unav = U(UNAV);
+    const uint32_t HI = ~((1u << SH) - 1u);
+    const U unav = U(UNAV), wdcv = U(WDC);
     const U lane = w.lane();
     const int len2 = a.len2;
-    const uint32_t base = (uint32_t)ch * P1_CH;
+    const uint32_t base = (uint32_t)ch * CH;
     const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;
     const uint32_t cD = a.lds_carry, cR = cD + MAX_READ * 4, cU0 = cR + MAX_READ * 4, cU1 = cU0 + MAX_READ * 4, cE = cU1 + MAX_READ * 4;
     const M last_lane = lane == 63u;
+    const M all = lane < 64u;
 
-    U gcol[CPL], sub_addr[CPL], KC[CPL], QC[CPL];
+    U sub_addr[CPL];
     M valid[CPL], qen[CPL];
+    const U crel0 = lane * (uint32_t)CPL, cp0 = crel0 + (uint32_t)REL;   // cp: shifted column index used inside keys
     for (int j = 0; j < CPL; j++) {
-      U crel = lane * (uint32_t)CPL + (uint32_t)j;
-      gcol[j] = crel + base;
-      valid[j] = maskbit(w, a, strand, gcol[j]);
-      qen[j] = valid[j] & ((gcol[j] == 0u) | maskbit(w, a, strand, gcol[j] + 2u));
-      U code = w.sel(gcol[j] < (uint32_t)a.len1, w.gload_u8(a.ref_codes[strand], gcol[j], gcol[j] < (uint32_t)a.len1), U(4u));
+      U gcol = crel0 + (base + (uint32_t)j);
+      if (MASKED) {
+        valid[j] = maskbit(w, a, strand, gcol);
+        qen[j] = valid[j] & ((gcol == 0u) | maskbit(w, a, strand, gcol + 2u));
+      } else {
+        valid[j] = all; qen[j] = all;
+      }
+      M in = gcol < (uint32_t)a.len1;
+      U code = w.sel(in, w.gload_u8(a.ref_codes[strand], gcol, in), U(4u));
       sub_addr[j] = U(a.lds_sub) + code * RS2;
-      U cp = crel + (uint32_t)P1_REL;   // shifted column index used inside keys
-      KC[j] = (U(0u) - ((U((uint32_t)GOP) + (cp - 1u) * (uint32_t)GEP) << SH)) + (TR_COLGAP << IB) + (cp - 1u - IDXM);
-      QC[j] = ((cp * (uint32_t)GEP) << SH) + (U(IDXM) - cp);
     }
-    const uint32_t WDC = TR_DIAG << IB;
+    // key -> column-gap candidate: value -= GOP + GEP*(cp-1); prio = 2; idx -> len = cp-1-k.  Affine in the column.
+    const U KC0 = (U(0u) - ((U((uint32_t)GOP) + (cp0 - 1u) * (uint32_t)GEP) << SH)) + (TR_COLGAP << IB) + (cp0 - 1u - IDXM);
+    const uint32_t KCD = 1u - ((uint32_t)GEP << SH);
+    // state -> best_gap_col key of its column: value += GEP*cp, idx = IDXM - cp, diagonal bits removed.  Affine too.
+    const U QC0 = ((cp0 * (uint32_t)GEP) << SH) + (U(IDXM) - cp0) - WDC;
+    const uint32_t QCD = ((uint32_t)GEP << SH) - 1u;
 
-    U Sb[CPL], q[CPL], rrun[CPL], pend[CPL], pw[CPL];
+    U Sd[CPL], q[CPL], rrun[CPL];
     for (int j = 0; j < CPL; j++) {     // row 0 (src/mia.c:769-785)
-      pw[j] = w.lds_r32(sub_addr[j]);
-      Sb[j] = w.sel(valid[j], w.sext_lo(pw[j]) + OFF, U(0u));
-      q[j] = w.sel(qen[j], (Sb[j] << SH) + QC[j], unav);
-      pend[j] = w.sel(valid[j], (Sb[j] << SH) + IDXM, unav);
+      U s0 = ((w.lds_ri16o(sub_addr[j], 0u) + OFF) << SH) | WDC;
+      Sd[j] = MASKED ? w.sel(valid[j], s0, U(0u)) : s0;
+      U k0 = w.add3(s0, QC0, (uint32_t)j * QCD);
+      q[j] = MASKED ? w.sel(qen[j], k0, unav) : k0;
       rrun[j] = unav;
     }
     if (TRACE) {
-      w.tr_w32(lane * 8u, U((TR_DIAG << IB) * 0x00010001u), lane < 64u);
-      w.tr_w32(lane * 8u + 4u, U((TR_DIAG << IB) * 0x00010001u), lane < 64u);
+      const U d2 = U(WDC * 0x00010001u);
+      for (int j = 0; j < CPL; j += 2) w.tr_w32(lane * (uint32_t)(CPL * 2) + (uint32_t)(j * 2), d2, all);
     }
 
-    for (int r = 1; r < len2; r++) {
+    auto do_row = [&](const int r, const uint32_t off) __attribute__((always_inline)) {
       const int32_t fresh = -(GOP + GEP * (r + 1));                         // sg5 = 1 (src/mia.c:1535)
       const uint32_t freshb = (uint32_t)(fresh + (int32_t)OFF);
-      const uint32_t WS = freshb << SH;
-      const uint32_t KR = (0u - ((uint32_t)(GOP + GEP * (r - 1)) << SH)) + (TR_ROWGAP << IB) + ((uint32_t)(r - 1) - IDXM);
-      const uint32_t RK = ((uint32_t)(GEP * r) << SH) + (IDXM - (uint32_t)r);
-      const bool hi = (r & 1) != 0;
-      if (!hi)
-        for (int j = 0; j < CPL; j++) pw[j] = w.lds_r32(sub_addr[j] + (uint32_t)r * 2u);
+      const uint32_t WS = w.sconst(freshb << SH);
+      const uint32_t KR = w.sconst((0u - ((uint32_t)(GOP + GEP * (r - 1)) << SH)) + (TR_ROWGAP << IB) + ((uint32_t)(r - 1) - IDXM));
+      const uint32_t RKP = w.sconst(((uint32_t)(GEP * (r - 1)) << SH) + (IDXM - (uint32_t)(r - 1)) - WDC);   // key constant of row r-1
 
       // carries of this row from the chunk on the left (same value in every lane) ...
       const U inD = w.lds_r32(U(cD + (uint32_t)r * 4u)), inR = w.lds_r32(U(cR + (uint32_t)r * 4u));
       const U inU0 = w.lds_r32(U(cU0 + (uint32_t)r * 4u)), inU1 = w.lds_r32(U(cU1 + (uint32_t)r * 4u));
       const U inE = w.lds_r32(U(cE + (uint32_t)r * 4u));
       // ... and ours for the chunk on the right (lane 63; state BEFORE this row is computed)
-      w.lds_w32(U(cD + (uint32_t)r * 4u), Sb[CPL - 1], last_lane);
+      w.lds_w32(U(cD + (uint32_t)r * 4u), Sd[CPL - 1], last_lane);
       w.lds_w32(U(cR + (uint32_t)r * 4u), rrun[CPL - 1], last_lane);
       w.lds_w32(U(cU0 + (uint32_t)r * 4u), q[CPL - 2], last_lane);
       w.lds_w32(U(cU1 + (uint32_t)r * 4u), q[CPL - 1], last_lane);
 
-      U dleft = w.shr1(Sb[CPL - 1], inD);
+      U dleft = w.shr1(Sd[CPL - 1], inD);
       U rleft = w.shr1(rrun[CPL - 1], inR);
       U u0 = w.shr1(q[CPL - 2], inU0);
       U u1 = w.shr1(q[CPL - 1], inU1);
-      U g[CPL];
-      g[0] = u0;
-      g[1] = w.umax(u0, u1);
-      for (int j = 2; j < CPL; j++) g[j] = w.umax(g[j - 1], q[j - 2]);
-      U incl = w.scan_max(g[CPL - 1]);
+      // lane total of the keys it offers to the lanes on its right (columns <= own last column - 2 ... plus the two shifted in)
+      U tot = w.umax(u0, u1);
+      {
+        int j = 0;
+        for (; j + 1 < CPL - 2; j += 2) tot = w.umax3(tot, q[j], q[j + 1]);
+        if (j < CPL - 2) tot = w.umax(tot, q[j]);
+      }
+      U incl = w.scan_max(tot);
       U excl = w.umax(w.shr1_max(incl, unav), inE);
       w.lds_w32(U(cE + (uint32_t)r * 4u), w.umax(incl, inE), last_lane);
+      U subv[CPL];    // (loaded in the block that uses them: the sign extension then folds into ds_read_i16)
+      for (int j = 0; j < CPL; j++) subv[j] = w.lds_ri16o(sub_addr[j], off);
+      // cand[j] = best key over all columns <= c_j - 2, one running chain with the prefix folded in
+      U cand[CPL];
+      cand[0] = w.umax(excl, u0);
+      cand[1] = w.umax(cand[0], u1);
+      for (int j = 2; j < CPL; j++) cand[j] = w.umax(cand[j - 1], q[j - 2]);
 
-      U best[CPL], Snew[CPL];
-      for (int j = 0; j < CPL; j++) {
-        U diag = (j == 0) ? dleft : Sb[j - 1];
+      const U trrow = lane * (uint32_t)(CPL * 2) + (uint32_t)r * (uint32_t)(CH * 2);
+      U bodd = U(0u);
+      for (int j = CPL - 1; j >= 0; j--) {     // right to left: every column is updated in place
+        U Wd = (j == 0) ? dleft : Sd[j - 1];
         U rl = (j == 0) ? rleft : rrun[j - 1];
-        U Wd = (diag << SH) + WDC;
-        U Wc = w.umax(excl, g[j]) + KC[j];
+        U Wc = w.add3(cand[j], KC0, (uint32_t)j * KCD);
         U Wr = rl + KR;
         U m3 = w.umax3(Wd, Wc, Wr);
-        best[j] = w.umax(m3, U(WS));
-        U sub = hi ? w.sext_hi(pw[j]) : w.sext_lo(pw[j]);
-        Snew[j] = w.sel(valid[j], (best[j] >> SH) + w.sel(m3 < WS, U(0u), sub), U(0u));
+        U sub = subv[j];
+        // start (only if strictly better than the other three) drops the substitution score (src/mia.c:910-917)
+        U best, snew;
+        if (TRACE) {
+          best = w.umax(m3, U(WS));
+          snew = w.template shl_addc<SH>(w.sel(m3 < WS, U(0u), sub), w.bfi(HI, best, wdcv));
+        } else {   // one operation less when the winning word itself is not needed
+          best = U(0u);
+          snew = w.bfi(HI, w.sel(m3 < WS, U(WS), w.template shl_addc<SH>(sub, m3)), wdcv);
+        }
+        U rk = Sd[j] + RKP;                    // row r-1 becomes a best_gap_row candidate for row r+1
+        U qk = w.add3(snew, QC0, (uint32_t)j * QCD);
+        if (MASKED) {
+          snew = w.sel(valid[j], snew, U(0u));
+          rk = w.sel(valid[j], rk, unav);
+          qk = w.sel(qen[j], qk, unav);
+        }
+        rrun[j] = w.umax(rrun[j], rk);
+        Sd[j] = snew;
+        q[j] = qk;
+        if (TRACE) {
+          // trace cell = low 12 bits of the winning word ([prio:2|len:10]) in a 16-bit cell
+          if (j & 1) bodd = best & 0xFFFu;
+          else w.tr_w32(trrow + (uint32_t)(j * 2), (best & 0xFFFu) | (bodd << 16), all);
+        }
       }
-      if (TRACE) {
-        const uint32_t row_tr = (uint32_t)r * (P1_CH * 2u);
-        w.tr_w32(U(row_tr) + lane * 8u, (best[0] & 0xFFFu) | ((best[1] & 0xFFFu) << 16), lane < 64u);
-        w.tr_w32(U(row_tr) + lane * 8u + 4u, (best[2] & 0xFFFu) | ((best[3] & 0xFFFu) << 16), lane < 64u);
-      }
-      for (int j = 0; j < CPL; j++) {
-        rrun[j] = w.umax(rrun[j], pend[j]);
-        pend[j] = w.sel(valid[j], (Snew[j] << SH) + RK, unav);
-        q[j] = w.sel(qen[j], (Snew[j] << SH) + QC[j], unav);
-        Sb[j] = Snew[j];
-      }
+    };
+    // rows in pairs: the substitution-table address of a column is bumped once per two rows
+    for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 2u;      // -> row 1
+    for (int r = 1; r < len2; r += 2) {
+      do_row(r, 0u);
+      if (r + 1 < len2) do_row(r + 1, 2u);
+      for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 4u;
     }
-    // last row: maximum and its first column inside this chunk
+    // last row: maximum and its first column inside this chunk (state words order like scores; absent cells are 0)
     U m = U(0u);
-    for (int j = 0; j < CPL; j++) m = w.umax(m, Sb[j]);   // absent cells are 0
+    for (int j = 0; j < CPL; j++) m = w.umax(m, Sd[j]);
     cbest = w.reduce_max(m);
     U cmin = U(0xFFFFFFFFu);
-    for (int j = CPL - 1; j >= 0; j--) cmin = w.sel(valid[j] & (Sb[j] == cbest), gcol[j], cmin);
+    for (int j = CPL - 1; j >= 0; j--) cmin = w.sel(valid[j] & (Sd[j] == cbest), crel0 + (base + (uint32_t)j), cmin);
     ccol = w.reduce_min(cmin);
     w.lds_fence();
+  }
+
+  template <bool TRACE>
+  MIA_HD static inline void chunk_any(P& w, const Pass1Args& a, int strand, int ch, int nch, uint32_t& cbest, uint32_t& ccol) {
+    // the fast path needs every column of the chunk to exist: all but the last chunk of an unmasked strand
+    if (a.masked || ch == nch - 1) chunk<TRACE, true>(w, a, strand, ch, cbest, ccol);
+    else chunk<TRACE, false>(w, a, strand, ch, cbest, ccol);
   }
 
   MIA_HD static inline bool chunk_open(P& w, const Pass1Args& a, int strand, int ch) {
     if (!a.masked) return true;
     const U lane = w.lane();
-    U widx = U((uint32_t)ch * (P1_CH / 32)) + lane;
-    M in = (lane < (uint32_t)(P1_CH / 32)) & (widx * 32u < (uint32_t)a.len1);
+    U widx = U((uint32_t)ch * (CH / 32)) + lane;
+    M in = (lane < (uint32_t)(CH / 32)) & (widx * 32u < (uint32_t)a.len1);
     U word = w.lds_r32m(U(a.lds_mask[strand]) + widx * 4u, in);
     return w.ballot(in & (word != 0u)) != 0;
   }
@@ -203,7 +256,7 @@ struct Pass1Aligner {
     const uint32_t OFF = (uint32_t)a.pk.off;
     const uint32_t UNAV = ((uint32_t)a.pk.unavail << SH) | IDXM;
     const U lane = w.lane();
-    const int len2 = a.len2, nch = (a.len1 + P1_CH - 1) / P1_CH;
+    const int len2 = a.len2, nch = (a.len1 + CH - 1) / CH;
     const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;
     const uint32_t cD = a.lds_carry;
     Pass1Result res;
@@ -236,11 +289,11 @@ struct Pass1Aligner {
           U d, rr, u0, u1, e;
           if (prev < 0) {
             // nothing to the left: global column 0 takes "diag" = fresh (src/mia.c:805-822), otherwise absent
-            U fr = U(OFF - (uint32_t)GOP) - (r + 1u) * (uint32_t)GEP;
+            U fr = ((U(OFF - (uint32_t)GOP) - (r + 1u) * (uint32_t)GEP) << SH) | WDC;
             d = (ch == 0) ? fr : U(0u);
             rr = U(UNAV); u0 = U(UNAV); u1 = U(UNAV); e = U(UNAV);
           } else {
-            const uint32_t adv = (uint32_t)(ch - prev) * P1_CH;
+            const uint32_t adv = (uint32_t)(ch - prev) * CH;
             e = rebase(w, w.lds_r32m(U(cD + 4u * MAX_READ * 4u) + r * 4u, ok), adv, UNAV);
             if (ch - prev == 1) {
               d = w.lds_r32m(U(cD) + r * 4u, ok);
@@ -270,7 +323,7 @@ struct Pass1Aligner {
         }
         w.lds_fence();
         uint32_t cb, cc;
-        chunk<false>(w, a, strand, ch, cb, cc);
+        chunk_any<false>(w, a, strand, ch, nch, cb, cc);
         if (cb > sbest[strand]) { sbest[strand] = cb; scol[strand] = cc; }   // first maximum wins (src/mia.c:1293-1299)
         prev = ch;
       }
@@ -279,8 +332,8 @@ struct Pass1Aligner {
 
     // ---- phase B: strand choice (src/mia.c:1549-1554); an all-masked strand scores HIM, arg-max column 0
     const int32_t HIM = INT32_MIN / 2;
-    res.best[0] = sbest[0] ? (int32_t)(sbest[0] - OFF) : HIM;
-    res.best[1] = sbest[1] ? (int32_t)(sbest[1] - OFF) : HIM;
+    res.best[0] = sbest[0] ? (int32_t)((sbest[0] >> SH) - OFF) : HIM;
+    res.best[1] = sbest[1] ? (int32_t)((sbest[1] >> SH) - OFF) : HIM;
     res.strand = (res.best[0] > res.best[1]) ? 0 : 1;
     const int st = res.strand;
     res.score = res.best[st];
@@ -295,7 +348,7 @@ struct Pass1Aligner {
     // ---- phase C: traceback on the chosen strand, recomputing the visited chunks with a trace
     int r = len2 - 1, c = res.aec, cur = -1, aln_cols = 0;
     for (int guard = 0; guard < 8 * MAX_READ + 64; guard++) {
-      const int ch = c / P1_CH;
+      const int ch = c / CH;
       if (ch != cur) {
         const uint32_t* ck = ckpt_of(a, st, ch, nch);
         for (int r0 = 0; r0 < len2; r0 += WAVE) {
@@ -305,14 +358,14 @@ struct Pass1Aligner {
         }
         w.lds_fence();
         uint32_t cb, cc;
-        chunk<true>(w, a, st, ch, cb, cc);
+        chunk_any<true>(w, a, st, ch, nch, cb, cc);
         w.tr_fence();
         cur = ch;
       }
-      const uint32_t base = (uint32_t)ch * P1_CH;
+      const uint32_t base = (uint32_t)ch * CH;
       U ri = U((uint32_t)r) - lane, ci = U((uint32_t)c) - lane;
       M inside = (lane <= (uint32_t)r) & (lane <= (uint32_t)c) & (ci >= base);
-      U tc = w.tr_r16(ri * (P1_CH * 2u) + (ci - base) * 2u, inside);
+      U tc = w.tr_r16(ri * (uint32_t)(CH * 2) + (ci - base) * 2u, inside);
       U ty = tc >> IB, ln = tc & IDXM;
       M colgap0 = (ty == U(TR_COLGAP)) & (ln + 1u == ci);   // source column 0 -> T == 0 -> read as diagonal (src/mia.c:619)
       M rowgap0 = (ty == U(TR_ROWGAP)) & (ln + 1u == ri);
@@ -323,7 +376,7 @@ struct Pass1Aligner {
       int f = bal ? __builtin_ctzll(bal) : WAVE;
       if (f == WAVE) { r -= WAVE; c -= WAVE; aln_cols += WAVE; continue; }
       if (!w.lane_bit(inside, f)) {          // left the chunk (or the matrix edge is handled by `terminal` first)
-        if (f == 0) { res.status |= ST_TOO_LONG; break; }   // cannot happen: c / P1_CH == ch
+        if (f == 0) { res.status |= ST_TOO_LONG; break; }   // cannot happen: c / CH == ch
         r -= f; c -= f; aln_cols += f;
         continue;
       }

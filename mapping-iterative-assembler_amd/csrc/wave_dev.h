@@ -91,6 +91,19 @@ struct DevWave {
     (void)sh;
     return r;
   }
+  template <int S>
+  __device__ __forceinline__ static U shl_addc(U x, U y) {
+    U r;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(S), "v"(y));
+    return r;
+  }
+  // a wave-uniform constant the optimiser must keep in a scalar register (it otherwise re-derives per-row constants
+  // from the previous row's with an extra VECTOR add per cell)
+  __device__ __forceinline__ static uint32_t sconst(uint32_t c) {
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    asm("" : "+s"(c));
+    return c;
+  }
   // (m & x) | (~m & y), m wave-uniform: one v_bfi_b32
   __device__ __forceinline__ static U bfi(uint32_t m, U x, U y) {
     U r;

@@ -84,6 +84,9 @@ struct EmuWave {
     for (int i = 0; i < 64; i++) if (ok.a[i]) { trace.at(off.a[i] + 15); memcpy(&trace[off.a[i]], &v0.a[i], 4); memcpy(&trace[off.a[i] + 4], &v1.a[i], 4);
                                                memcpy(&trace[off.a[i] + 8], &v2.a[i], 4); memcpy(&trace[off.a[i] + 12], &v3.a[i], 4); }
   }
+  static uint32_t sconst(uint32_t c) { return c; }
+  template <int S>
+  static U shl_addc(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] << S) + y.a[i]; return r; }
   static U shl_add(const U& x, int sh, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] << sh) + y.a[i]; return r; }
   static U and_or(const U& x, uint32_t m, uint32_t o) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] & m) | o; return r; }
   M mrshr1(const M& x) const { EM r; for (int i = 0; i < 64; i++) r.a[i] = (i & 15) ? x.a[i - 1] : false; return r; }

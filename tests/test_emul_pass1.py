@@ -11,6 +11,7 @@ import oracle_ctypes as oc
 from test_emul_align import codes, emul  # noqa: F401  (fixture)
 from test_oracle_vs_golden import _pssm
 
+RUNS = {}
 COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
 
 
@@ -18,14 +19,14 @@ def revcomp(s):
     return "".join(COMP.get(ch, "N") for ch in reversed(s))
 
 
-def run_emul(emul, fw, rc, read, pssm, fmask, rmask, max_abs=1100):
+def run_emul(emul, fw, rc, read, pssm, fmask, rmask, max_abs=1100, cpl=4):
     out = (C.c_int32 * 8)()
     pm = np.ctypeslib.as_array(pssm.sm).reshape(-1).astype(np.int32)
     cf, cr, c2 = codes(fw), codes(rc), codes(read)
     fm = None if fmask is None else np.frombuffer(bytes(fmask), dtype=np.uint8).copy()
     rm = None if rmask is None else np.frombuffer(bytes(rmask), dtype=np.uint8).copy()
     emul.emu_pass1.restype = C.c_int
-    rcode = emul.emu_pass1(cf.ctypes.data_as(C.c_void_p), cr.ctypes.data_as(C.c_void_p), len(fw), c2.ctypes.data_as(C.c_void_p),
+    rcode = emul.emu_pass1(cpl, cf.ctypes.data_as(C.c_void_p), cr.ctypes.data_as(C.c_void_p), len(fw), c2.ctypes.data_as(C.c_void_p),
                            len(read), pm.ctypes.data_as(C.c_void_p), max_abs,
                            None if fm is None else fm.ctypes.data_as(C.c_void_p),
                            None if rm is None else rm.ctypes.data_as(C.c_void_p), out)
@@ -44,10 +45,20 @@ def oracle_pass1(oracle, fw, rc, read, pssm, fmask, rmask):
     return res, st
 
 
-def check(emul, oracle, fw, read, pssm, fmask=None, rmask=None):
+def check(emul, oracle, fw, read, pssm, fmask=None, rmask=None, cpls=(4, 12)):
     rc = revcomp(fw)
     exp, st = oracle_pass1(oracle, fw, rc, read, pssm, fmask, rmask)
-    got = run_emul(emul, fw, rc, read, pssm, fmask, rmask)
+    pm = np.ctypeslib.as_array(pssm.sm).reshape(-1)
+    n = len(read)
+    for cpl in cpls:
+        # the wide chunks keep a 256-column candidate horizon: exact only under the host's range check (mia_hip_pass1)
+        if cpl == 12 and n * int(pm.max()) + 1000 + 200 * (n + 1) >= 1000 + 200 * 255:
+            continue
+        RUNS[cpl] = RUNS.get(cpl, 0) + 1
+        _check_one(run_emul(emul, fw, rc, read, pssm, fmask, rmask, cpl=cpl), exp, st)
+
+
+def _check_one(got, exp, st):
     assert got[0] == exp[0].best and got[1] == exp[1].best, (got, exp[0].best, exp[1].best)
     assert got[2] == st
     e = exp[st]
@@ -73,7 +84,7 @@ def test_pass1_unmasked(emul, oracle):
     flat = _pssm(oracle, "flat", 0)
     anc = _pssm(oracle, "ancient.submat.txt", 0)
     for i in range(40):
-        L = rnd.choice([90, 255, 256, 257, 300, 511, 600, 1000, 1300])
+        L = rnd.choice([90, 255, 256, 257, 300, 511, 600, 767, 768, 1000, 1300, 1700, 2500])
         ref = "".join(rnd.choice("ACGT") for _ in range(L))
         wrap = ref + ref[: min(L, 256)]
         n = rnd.choice([20, 45, 100, 100, 150, 256])
@@ -85,6 +96,7 @@ def test_pass1_unmasked(emul, oracle):
         if i % 7 == 0:
             wrap = wrap[:50] + "N" + wrap[51:]
         check(emul, oracle, wrap, read, [flat, anc][i % 2])
+    assert RUNS.get(4, 0) >= 40 and RUNS.get(12, 0) >= 15, RUNS
 
 
 def test_pass1_masked(emul, oracle):
@@ -94,7 +106,7 @@ def test_pass1_masked(emul, oracle):
     flat = _pssm(oracle, "flat", 0)
     anc = _pssm(oracle, "ancient.submat.txt", 0)
     for i in range(60):
-        L = rnd.choice([300, 700, 1100, 1500])
+        L = rnd.choice([300, 700, 1100, 1500, 2400])
         ref = "".join(rnd.choice("ACGT") for _ in range(L))
         wrap = ref + ref[:256]
         n = rnd.choice([30, 60, 100, 140])
@@ -124,3 +136,4 @@ def test_pass1_masked(emul, oracle):
         if i % 9 == 0:
             fm = bytearray([1]) * W      # saturated (>=128 hits): everything open on one strand
         check(emul, oracle, wrap, read, [flat, anc][i % 2], fm, rm)
+    assert RUNS.get(12, 0) >= 30, RUNS
