@@ -825,6 +825,9 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   }
   if (!horizon_ok(p1_rel(cpl))) { ctx->err = "PSSM too large for the pass-1 candidate horizon"; return MIA_HIP_ERR_RANGE; }
   const int P1_CH = p1_ch(cpl);
+  // the wide unmasked sweep runs on plain keys (pass1_body.h, run_plain); MIA_HIP_P1_PLAIN=0 keeps the packed sweep
+  int plain = 1;
+  if (const char* ev = getenv("MIA_HIP_P1_PLAIN")) plain = atoi(ev) != 0;
   if (kmer_len > 0 && (size_t)wrap >= ((size_t)1 << 24)) { ctx->err = "reference too long for the k-mer table"; return MIA_HIP_ERR_RANGE; }
   uint8_t *d_cf = nullptr, *d_cr = nullptr;
   uint32_t *d_tab[2] = {nullptr, nullptr}, *d_kl[2] = {nullptr, nullptr}, *d_el[2] = {nullptr, nullptr};
@@ -875,7 +878,8 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
          dev_alloc(ctx, &d_rc, (size_t)n) | dev_alloc(ctx, &d_flags, (size_t)n) | dev_alloc(ctx, &d_status, (size_t)n) |
          dev_alloc(ctx, &d_score, (size_t)n) | dev_alloc(ctx, &d_as, (size_t)n) | dev_alloc(ctx, &d_ae, (size_t)n);
   // persistent grid; LDS: sub table + 5 carry arrays + 2 column masks
-  const int nch = (len1 + P1_CH - 1) / P1_CH, mask_words = nch * (P1_CH / 32) + 4;
+  // (the column masks are only read when the k-mer filter is on)
+  const int nch = (len1 + P1_CH - 1) / P1_CH, mask_words = kmer_len > 0 ? nch * (P1_CH / 32) + 4 : 0;
   const int lds = MAX_READ * 10 + 5 * MAX_READ * 4 + 2 * mask_words * 4;
   const int rows_p = (max_len + 3) & ~3;
   const int64_t trace_bytes = (int64_t)rows_p * P1_CH * 2, ckpt_words = (int64_t)2 * nch * 5 * rows_p;
@@ -887,6 +891,10 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   int waves_cu = 0;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_cu, (const void*)kfn, 64, (size_t)lds));
   if (waves_cu < 1) { ctx->err = "pass-1 kernel does not fit a compute unit"; return MIA_HIP_ERR_RANGE; }
+  // whole waves per SIMD only: an uneven remainder (13 = 4+3+3+3) measured slower than 12, the extra workgroups start late
+  if (waves_cu > 4) waves_cu &= ~3;
+  if (const char* ev = getenv("MIA_HIP_P1_WAVES_PER_CU")) { const int wv = atoi(ev); if (wv > 0 && wv < waves_cu) waves_cu = wv; }
+  if (timing) fprintf(stderr, "[mia_hip_pass1] cpl %d plain %d waves/CU %d lds %d\n", cpl, plain, waves_cu, lds);
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
   int64_t grid = (int64_t)prop.multiProcessorCount * waves_cu;
@@ -907,7 +915,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
     Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
     if (get_events(ctx, &pe0, &pe1) == 0) (void)hipEventRecord(pe0, ctx->stream);
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
-                       trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words);
+                       trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words, plain);
     if (pe1) (void)hipEventRecord(pe1, ctx->stream);
     e = hipGetLastError();
   }

@@ -51,10 +51,10 @@ __device__ __forceinline__ void mask_or_range(uint32_t* m, int lo, int hi) {   /
 }
 
 template <int CPL>
-__global__ __launch_bounds__(64) void k_pass1(Pass1Reads rs, const uint8_t* ref_fw, const uint8_t* ref_rc, int32_t len1, int32_t L,
+__global__ __launch_bounds__(64, 4) void k_pass1(Pass1Reads rs, const uint8_t* ref_fw, const uint8_t* ref_rc, int32_t len1, int32_t L,
                                                const int32_t* pssm_fwd, PackParams pk, KmerIndex kx, unsigned char* trace_slabs,
                                                int64_t trace_bytes, uint32_t* ckpt_slabs, int64_t ckpt_words, int32_t rows_p,
-                                               int32_t mask_words) {
+                                               int32_t mask_words, int32_t plain) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * trace_bytes);
   const int lane = (int)wave.lane();
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(64) void k_pass1(Pass1Reads rs, const uint8_t* ref_
   a.lds_mask[0] = a.lds_carry + 5 * MAX_READ * 4;
   a.lds_mask[1] = a.lds_mask[0] + (uint32_t)mask_words * 4;
   a.masked = kx.k > 0;
+  a.plain = (CPL == P1_CPL_WIDE && plain && !a.masked) ? 1 : 0;
   a.ckpt = ckpt_slabs + (int64_t)blockIdx.x * ckpt_words;
   a.rows_p = rows_p;
   uint32_t* mask[2] = {reinterpret_cast<uint32_t*>(lds_raw + a.lds_mask[0]), reinterpret_cast<uint32_t*>(lds_raw + a.lds_mask[1])};
@@ -128,7 +129,9 @@ __global__ __launch_bounds__(64) void k_pass1(Pass1Reads rs, const uint8_t* ref_
     }
     a.read_packed = rp;
     a.len2 = len2;
-    Pass1Result r = Pass1Aligner<DevWave, CPL>::run(wave, a);
+    Pass1Result r;
+    if (CPL == P1_CPL_WIDE && a.plain) r = Pass1Aligner<DevWave, CPL>::run_plain(wave, a);
+    else r = Pass1Aligner<DevWave, CPL>::run(wave, a);
     if (lane == 0) {
       // sg_align, src/mia.c:1568-1610,1614,1619,1653
       int start, end, as, ae;

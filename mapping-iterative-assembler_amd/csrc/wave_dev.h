@@ -111,6 +111,18 @@ struct DevWave {
     return r;
   }
   __device__ __forceinline__ U lds_ri16o(U off, uint32_t imm) const { return (U)(int32_t)*reinterpret_cast<const int16_t*>(lds + off + imm); }
+  // absolute LDS address of a byte offset, laundered so that the optimiser keeps it in a register instead of
+  // re-adding the (zero) base of the dynamic LDS block before every read
+  __device__ __forceinline__ U lds_abs(U off) const {
+    uint32_t p = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(lds + off);
+    asm("" : "+v"(p));
+    return p;
+  }
+  // keep a value in its register as it is (stops the optimiser from re-deriving loop-carried addresses per row)
+  __device__ __forceinline__ static void keep(U& x) { asm volatile("" : "+v"(x)); }
+  __device__ __forceinline__ static U lds_ri16a(U addr, uint32_t imm) {
+    return (U)(int32_t)*reinterpret_cast<const __attribute__((address_space(3))) int16_t*>((uintptr_t)(addr + imm));
+  }
   __device__ __forceinline__ static U and_or(U x, uint32_t m, uint32_t o) { return (x & m) | o; }   // v_and_or_b32
   // lane mask moved one lane up inside each 16-lane row; the first lane of a row gets false
   __device__ __forceinline__ M mrshr1(M x) const {

@@ -46,7 +46,7 @@ extern "C" int emu_align_window(int cpl, const uint8_t* ref_codes, int ref_start
 // pass 1 of one read: both strands vs the whole (wrapped) reference, optional column masks
 template <int CPL>
 static int emu_pass1_t(const uint8_t* fw_codes, const uint8_t* rc_codes, int len1, const uint8_t* read_codes, int len2,
-                       const int32_t* pssm, int max_abs, const uint8_t* fw_mask, const uint8_t* rc_mask, int32_t* out8) {
+                       const int32_t* pssm, int max_abs, const uint8_t* fw_mask, const uint8_t* rc_mask, int32_t* out8, int plain) {
   constexpr int P1_CH = p1_ch(CPL);
   PackParams pk;
   if (!make_pack_params(1024, max_abs, &pk)) return -1;
@@ -72,16 +72,19 @@ static int emu_pass1_t(const uint8_t* fw_codes, const uint8_t* rc_codes, int len
         if (m[c]) { uint32_t x; memcpy(&x, &w.lds[a.lds_mask[s] + (c >> 5) * 4], 4); x |= 1u << (c & 31); memcpy(&w.lds[a.lds_mask[s] + (c >> 5) * 4], &x, 4); }
     }
   }
-  Pass1Result r = Pass1Aligner<EmuWave, CPL>::run(w, a);
+  a.plain = (plain && !a.masked) ? 1 : 0;
+  Pass1Result r = a.plain ? Pass1Aligner<EmuWave, CPL>::run_plain(w, a) : Pass1Aligner<EmuWave, CPL>::run(w, a);
   out8[0] = r.best[0]; out8[1] = r.best[1]; out8[2] = r.strand; out8[3] = r.score; out8[4] = r.aec; out8[5] = r.abc;
   out8[6] = r.abr; out8[7] = (int32_t)r.status;
   return 0;
 }
 
+// cpl: 4 or 12; cpl = 112 selects the plain-key sweep on 768-column chunks (unmasked only)
 extern "C" int emu_pass1(int cpl, const uint8_t* fw_codes, const uint8_t* rc_codes, int len1, const uint8_t* read_codes, int len2,
                          const int32_t* pssm, int max_abs, const uint8_t* fw_mask, const uint8_t* rc_mask, int32_t* out8) {
-  if (cpl == P1_CPL_NARROW) return emu_pass1_t<P1_CPL_NARROW>(fw_codes, rc_codes, len1, read_codes, len2, pssm, max_abs, fw_mask, rc_mask, out8);
-  if (cpl == P1_CPL_WIDE) return emu_pass1_t<P1_CPL_WIDE>(fw_codes, rc_codes, len1, read_codes, len2, pssm, max_abs, fw_mask, rc_mask, out8);
+  if (cpl == P1_CPL_NARROW) return emu_pass1_t<P1_CPL_NARROW>(fw_codes, rc_codes, len1, read_codes, len2, pssm, max_abs, fw_mask, rc_mask, out8, 0);
+  if (cpl == P1_CPL_WIDE || cpl == 100 + P1_CPL_WIDE)
+    return emu_pass1_t<P1_CPL_WIDE>(fw_codes, rc_codes, len1, read_codes, len2, pssm, max_abs, fw_mask, rc_mask, out8, cpl >= 100);
   return -2;
 }
 

@@ -85,6 +85,9 @@ struct EmuWave {
                                                memcpy(&trace[off.a[i] + 8], &v2.a[i], 4); memcpy(&trace[off.a[i] + 12], &v3.a[i], 4); }
   }
   static uint32_t sconst(uint32_t c) { return c; }
+  static void keep(U&) {}
+  U lds_abs(const U& off) const { return off; }
+  U lds_ri16a(const U& addr, uint32_t imm) const { return lds_ri16o(addr, imm); }
   template <int S>
   static U shl_addc(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] << S) + y.a[i]; return r; }
   static U shl_add(const U& x, int sh, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] << sh) + y.a[i]; return r; }

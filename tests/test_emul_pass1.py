@@ -45,14 +45,16 @@ def oracle_pass1(oracle, fw, rc, read, pssm, fmask, rmask):
     return res, st
 
 
-def check(emul, oracle, fw, read, pssm, fmask=None, rmask=None, cpls=(4, 12)):
+def check(emul, oracle, fw, read, pssm, fmask=None, rmask=None, cpls=(4, 12, 112)):
     rc = revcomp(fw)
     exp, st = oracle_pass1(oracle, fw, rc, read, pssm, fmask, rmask)
     pm = np.ctypeslib.as_array(pssm.sm).reshape(-1)
     n = len(read)
     for cpl in cpls:
         # the wide chunks keep a 256-column candidate horizon: exact only under the host's range check (mia_hip_pass1)
-        if cpl == 12 and n * int(pm.max()) + 1000 + 200 * (n + 1) >= 1000 + 200 * 255:
+        if cpl == 112 and fmask is not None:
+            continue
+        if cpl in (12, 112) and n * int(pm.max()) + 1000 + 200 * (n + 1) >= 1000 + 200 * 255:
             continue
         RUNS[cpl] = RUNS.get(cpl, 0) + 1
         _check_one(run_emul(emul, fw, rc, read, pssm, fmask, rmask, cpl=cpl), exp, st)
@@ -83,8 +85,8 @@ def test_pass1_unmasked(emul, oracle):
     rnd = random.Random(17)
     flat = _pssm(oracle, "flat", 0)
     anc = _pssm(oracle, "ancient.submat.txt", 0)
-    for i in range(40):
-        L = rnd.choice([90, 255, 256, 257, 300, 511, 600, 767, 768, 1000, 1300, 1700, 2500])
+    for i in range(60):
+        L = rnd.choice([90, 255, 256, 257, 300, 511, 600, 767, 768, 1000, 1300, 1700, 2500, 4000])
         ref = "".join(rnd.choice("ACGT") for _ in range(L))
         wrap = ref + ref[: min(L, 256)]
         n = rnd.choice([20, 45, 100, 100, 150, 256])
@@ -96,7 +98,30 @@ def test_pass1_unmasked(emul, oracle):
         if i % 7 == 0:
             wrap = wrap[:50] + "N" + wrap[51:]
         check(emul, oracle, wrap, read, [flat, anc][i % 2])
-    assert RUNS.get(4, 0) >= 40 and RUNS.get(12, 0) >= 15, RUNS
+    assert RUNS.get(4, 0) >= 40 and RUNS.get(12, 0) >= 15 and RUNS.get(112, 0) >= 15, RUNS
+
+
+def test_pass1_chunk_boundaries(emul, oracle):
+    """reads (with indels) straddling the 256- and 768-column chunk boundaries, both strands: the retrace has to
+    cross into the chunk on the left, and the plain sweep's placeholder carries must never surface"""
+    rnd = random.Random(99)
+    flat = _pssm(oracle, "flat", 0)
+    anc = _pssm(oracle, "ancient.submat.txt", 0)
+    before = dict(RUNS)
+    L = 3300
+    for i in range(36):
+        ref = "".join(rnd.choice("ACGT") for _ in range(L))
+        wrap = ref + ref[:256]
+        n = rnd.choice([40, 80, 100, 120])
+        edge = rnd.choice([256, 512, 768, 1536, 2304, 3072])
+        p = max(0, edge - rnd.randint(1, n - 1))
+        frag = ref[p:p + n]
+        if i % 2:                       # reverse strand: the alignment sits at L - p - n on the reverse complement
+            p2 = max(0, L - edge - rnd.randint(1, n - 1))
+            frag = revcomp(ref[p2:p2 + n])
+        read = mutate(rnd, frag, rnd.randint(0, 2), i % 3 != 2)
+        check(emul, oracle, wrap, read, [flat, anc][i % 2])
+    assert RUNS.get(112, 0) - before.get(112, 0) >= 20, RUNS
 
 
 def test_pass1_masked(emul, oracle):
