@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Whole-run comparison: the reference's own `mia` binary (oracle/_ref/mia, built in place from
+/root/reference by oracle/Makefile.ref) against the mia_hip command line on the same synthetic FASTA.
+Checks that every .maln iteration is byte-identical from line 2 and reports both wall times as JSON.
+
+usage: python tools/whole_run.py [-n READS] [--kmer K] [--keep DIR]
+Needs a GPU (mia_hip) and the prebuilt reference binary; reads nothing under /root/reference at run time."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-n", type=int, default=20000)
+    ap.add_argument("--kmer", type=int, default=0)
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("--skip-reference", action="store_true")
+    a = ap.parse_args()
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "mia")
+    hip_bin = os.path.join(ROOT, "mapping-iterative-assembler_amd", "mia_hip")
+    work = a.keep or tempfile.mkdtemp(prefix="mia_whole_")
+    os.makedirs(work, exist_ok=True)
+    reads = os.path.join(work, "reads.fa")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_data.py"), "--ref", os.path.join(GOLDEN, "mt311.fa"),
+                    "--out", reads, "-n", str(a.n), "--len", "100", "--seed", "7"], check=True)
+    args = ["-r", os.path.join(GOLDEN, "mt311.fa"), "-f", reads, "-c"]
+    if a.kmer > 0:
+        args += ["-k", str(a.kmer)]
+    env = dict(os.environ, MIA_DATA_PATH=GOLDEN)
+    out = {"reads": a.n, "kmer": a.kmer}
+    runs = [("mia_hip", hip_bin)] + ([] if a.skip_reference else [("reference", ref_bin)])
+    for label, exe in runs:
+        root = os.path.join(work, label)
+        t0 = time.perf_counter()
+        subprocess.run([exe] + args + ["-m", root], check=True, env=env, cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out[label + "_s"] = round(time.perf_counter() - t0, 3)
+        it = 0
+        while os.path.exists("%s.%d" % (root, it + 1)):
+            it += 1
+        out[label + "_iterations"] = it
+    if not a.skip_reference:
+        same = out["mia_hip_iterations"] == out["reference_iterations"] and out["reference_iterations"] > 0
+        for it in range(1, out["reference_iterations"] + 1):
+            if not same:
+                break
+            x = open(os.path.join(work, "reference.%d" % it)).readlines()[1:]
+            y = open(os.path.join(work, "mia_hip.%d" % it)).readlines()[1:]
+            same = x == y
+        out["maln_identical"] = bool(same)
+        out["speedup"] = round(out["reference_s"] / out["mia_hip_s"], 1)
+    print(json.dumps(out))
+    return 0 if out.get("maln_identical", True) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
