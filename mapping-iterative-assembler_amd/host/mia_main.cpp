@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -236,6 +237,15 @@ int main(int argc, char** argv) {
   if (optind != argc) { fprintf(stderr, "There seems to be some extra cruff on the command line that mia does not understand.\n"); exit(0); }
   revcom_pssm(&anc, &rcanc);
 
+  // MIA_HIP_TIMING=1: wall time of each phase on stderr
+  const bool timing = getenv("MIA_HIP_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!timing) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mia_hip timing] %-22s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+    t_last = t;
+  };
   time_t now = time(NULL);
   fprintf(stderr, "Starting assembly of %s\nusing %s\nas reference at %s\n", frag_fn.c_str(), ref_fn.c_str(), asctime(localtime(&now)));
 
@@ -258,6 +268,7 @@ int main(int argc, char** argv) {
     while (next_record(ff, fastq, &r)) reads.push_back(r);
   }
   fclose(ff);
+  lap("init + read input");
   fprintf(stderr, "Starting to align sequences to the reference...\n");
 
   // ---- pass 1 on the GPU (new_kmer_filter + sg_align)
@@ -272,6 +283,7 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> p_rc((size_t)n1), p_fl((size_t)n1);
   if (n1 > 0 && mia_hip_pass1(g, ref.seq.c_str(), (int32_t)ref.seq.size(), circular, kmer, soft_mask, n1, bases.data(), off.data(),
                               p_score.data(), p_rc.data(), p_as.data(), p_ae.data(), p_fl.data()) != MIA_HIP_OK) die(g, "pass1");
+  lap("pass 1");
   fprintf(stderr, "\n");
 
   // ---- fsdb (add_virgin_fs2fsdb, src/fsdb.c:194-231) and the pass-1 AlnSeq slots
@@ -357,6 +369,7 @@ int main(int argc, char** argv) {
     score_cut(&s, &ic);
     if (mia_hip_cull(g, hard_cut, s, ic, 0) != MIA_HIP_OK) die(g, "cull");
     if (mia_hip_tally(g) != MIA_HIP_OK) die(g, "tally");
+    lap("iteration (device)");
   };
 
   // write_ma (src/map_alignment.c:283-382) from the device results
@@ -455,6 +468,7 @@ int main(int argc, char** argv) {
       fprintf(mf, "\n");
     }
     fclose(mf);
+    lap("write .maln");
   };
 
   auto consensus = [&]() {

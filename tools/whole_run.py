@@ -40,7 +40,8 @@ def main():
     for label, exe in runs:
         root = os.path.join(work, label)
         t0 = time.perf_counter()
-        subprocess.run([exe] + args + ["-m", root], check=True, env=env, cwd=work, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([exe] + args + ["-m", root], check=True, env=env, cwd=work, stdout=subprocess.DEVNULL,
+                       stderr=(None if (label == "mia_hip" and os.environ.get("MIA_HIP_TIMING")) else subprocess.DEVNULL))
         out[label + "_s"] = round(time.perf_counter() - t0, 3)
         it = 0
         while os.path.exists("%s.%d" % (root, it + 1)):
