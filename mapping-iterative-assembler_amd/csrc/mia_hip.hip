@@ -179,6 +179,20 @@ static inline uint8_t base_code(char b) {   // src/map_align.c:16-29: only upper
   switch (b) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
 }
 
+// 4-bit base codes, two per byte, each read starting on a 4-byte boundary of `packed` (zero-filled by the caller)
+static void pack_reads(int64_t n, const char* bases, const int64_t* offsets, const uint32_t* roff, const uint16_t* len, uint8_t* packed) {
+  uint8_t lut[256];
+  for (int c = 0; c < 256; c++) lut[c] = base_code((char)c);
+  for (int64_t i = 0; i < n; i++) {
+    const unsigned char* s = reinterpret_cast<const unsigned char*>(bases) + offsets[i];
+    uint8_t* d = packed + roff[i];
+    const int l = len[i];
+    int k = 0;
+    for (; k + 1 < l; k += 2) d[k >> 1] = (uint8_t)(lut[s[k]] | (lut[s[k + 1]] << 4));
+    if (k < l) d[k >> 1] = lut[s[k]];
+  }
+}
+
 extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bases, const int64_t* offsets, const uint8_t* rc,
                                     const uint8_t* strand_known, const int32_t* as, const int32_t* ae) {
   if (!ctx || n < 0 || (n > 0 && (!bases || !offsets || !rc || !strand_known || !as || !ae))) return MIA_HIP_ERR_ARG;
@@ -198,11 +212,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
     if (total >= ((uint64_t)1 << 32)) { ctx->err = "packed read store exceeds 4 GiB per context"; return MIA_HIP_ERR_ARG; }
   }
   std::vector<uint8_t> packed((size_t)total + 8, 0);
-  for (int64_t i = 0; i < n; i++) {
-    const char* s = bases + offsets[i];
-    uint8_t* d = packed.data() + roff[i];
-    for (int k = 0; k < len[i]; k++) d[k >> 1] |= (uint8_t)(base_code(s[k]) << ((k & 1) * 4));
-  }
+  pack_reads(n, bases, offsets, roff.data(), len.data(), packed.data());
   ctx->max_len = max_len;
   const int stride = (max_len + 3) & ~3;
   int rcx = 0;
@@ -859,17 +869,8 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
     }
   }
   lap("ref+kmer");
-  uint8_t code_lut[256];
-  for (int c = 0; c < 256; c++) code_lut[c] = base_code((char)c);
   std::vector<uint8_t> packed((size_t)total + 8, 0);
-  for (int64_t i = 0; i < n; i++) {
-    const char* sq = bases + offsets[i];
-    uint8_t* d = packed.data() + roff[i];
-    const int l = len[i];
-    int k = 0;
-    for (; k + 1 < l; k += 2) d[k >> 1] = (uint8_t)(code_lut[(uint8_t)sq[k]] | (code_lut[(uint8_t)sq[k + 1]] << 4));
-    if (k < l) d[k >> 1] = code_lut[(uint8_t)sq[k]];
-  }
+  pack_reads(n, bases, offsets, roff.data(), len.data(), packed.data());
   uint8_t *d_packed = nullptr, *d_rc = nullptr, *d_flags = nullptr;
   uint32_t *d_roff = nullptr, *d_status = nullptr;
   uint16_t* d_len = nullptr;

@@ -20,8 +20,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <charconv>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mia_hip.h"
@@ -126,30 +128,30 @@ struct Read { std::string id, desc, seq; };
 // of read_fasta, src/io.c:228-234, and the 256-base truncation)
 bool next_record(FILE* f, bool fastq, Read* r) {
   r->id.clear(); r->desc.clear(); r->seq.clear();
-  int c = fgetc(f);
+  int c = getc_unlocked(f);
   if (c == EOF) return false;
   if (c != (fastq ? '@' : '>')) {
     if (fastq) fprintf(stderr, "While reading fastq file, saw record not beginning with @\nMaybe badly formed input? Continuing, anyway...\n");
     return false;
   }
-  while (!isspace(c = fgetc(f)) && (int)r->id.size() < MAX_ID_LEN) {
+  while (!isspace(c = getc_unlocked(f)) && (int)r->id.size() < MAX_ID_LEN) {
     if (c == EOF) return false;
     r->id.push_back((char)c);
   }
   if (c != '\n') {
-    while (c != '\n' && isspace(c)) c = fgetc(f);
+    while (c != '\n' && isspace(c)) c = getc_unlocked(f);
     if (!fastq && c != '\n') r->desc.push_back((char)c);
-    while (c != '\n' && c != EOF && (int)r->desc.size() < MAX_DESC_LEN) { r->desc.push_back((char)c); c = fgetc(f); }
+    while (c != '\n' && c != EOF && (int)r->desc.size() < MAX_DESC_LEN) { r->desc.push_back((char)c); c = getc_unlocked(f); }
   }
-  c = fgetc(f);
+  c = getc_unlocked(f);
   if (!fastq) {
     while (c != '>' && c != EOF && (int)r->seq.size() < MAX_READ) {
       if (!isspace(c)) r->seq.push_back((char)toupper(c));
-      c = fgetc(f);
+      c = getc_unlocked(f);
     }
     if (c == '>') { ungetc('>', f); return true; }
     if ((int)r->seq.size() == MAX_READ) {
-      while (c != '>' && c != EOF) c = fgetc(f);
+      while (c != '>' && c != EOF) c = getc_unlocked(f);
       if (c == '>') ungetc('>', f);
       fprintf(stderr, "%s is longer than allowed length: %d\n", r->id.c_str(), MAX_READ);
     }
@@ -157,17 +159,17 @@ bool next_record(FILE* f, bool fastq, Read* r) {
   }
   while (c != '\n' && c != EOF && (int)r->seq.size() < MAX_READ) {
     if (!isspace(c)) r->seq.push_back((char)toupper(c));
-    c = fgetc(f);
+    c = getc_unlocked(f);
   }
-  if ((int)r->seq.size() == MAX_READ) while (c != '\n' && c != EOF) c = fgetc(f);
-  c = fgetc(f);
+  if ((int)r->seq.size() == MAX_READ) while (c != '\n' && c != EOF) c = getc_unlocked(f);
+  c = getc_unlocked(f);
   if (c != '+') { fprintf(stderr, "Problem reading quality line for %s\n", r->id.c_str()); return true; }
-  c = fgetc(f);
-  while (c != '\n' && c != EOF) c = fgetc(f);
+  c = getc_unlocked(f);
+  while (c != '\n' && c != EOF) c = getc_unlocked(f);
   int q = 0;
-  c = fgetc(f);
-  while (c != '\n' && c != EOF && q < MAX_READ) { if (!isspace(c)) q++; c = fgetc(f); }
-  if (q == MAX_READ) while (c != '\n' && c != EOF) c = fgetc(f);
+  c = getc_unlocked(f);
+  while (c != '\n' && c != EOF && q < MAX_READ) { if (!isspace(c)) q++; c = getc_unlocked(f); }
+  if (q == MAX_READ) while (c != '\n' && c != EOF) c = getc_unlocked(f);
   if (q != (int)r->seq.size()) { fprintf(stderr, "%s has unequal sequence and qual line lengths\n", r->id.c_str()); return false; }
   return true;
 }
@@ -185,6 +187,24 @@ struct Record {
   int start, end, score, rc, dropped;
   char segment;
 };
+
+// host-side fan-out for the per-read text work (.maln records); MIA_HIP_THREADS overrides
+int worker_threads(int items) {
+  int t = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("MIA_HIP_THREADS")) t = atoi(e);
+  if (t > 64) t = 64;
+  if (t > items / 2048) t = items / 2048;
+  return t < 1 ? 1 : t;
+}
+
+template <class F>
+void run_parallel(int T, F&& fn) {
+  if (T <= 1) { fn(0); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back([&fn, t] { fn(t); });
+  fn(0);
+  for (auto& x : th) x.join();
+}
 
 void die(mia_hip_ctx* g, const char* what) {
   fprintf(stderr, "%s: %s\n", what, g ? mia_hip_last_error(g) : "no context");
@@ -262,13 +282,17 @@ int main(int argc, char** argv) {
   int c0 = fgetc(ff);
   if (c0 != EOF) ungetc(c0, ff);
   const bool fastq = (c0 == '@');   // find_input_type, src/io.c:11-26
+  lap("init");
   std::vector<Read> reads;
   {
+    // same character-level state machine as the reference's reader, on an 8 MB unlocked stdio buffer
+    std::vector<char> iobuf((size_t)8 << 20);
+    setvbuf(ff, iobuf.data(), _IOFBF, iobuf.size());
     Read r;
-    while (next_record(ff, fastq, &r)) reads.push_back(r);
+    while (next_record(ff, fastq, &r)) { reads.emplace_back(); std::swap(reads.back(), r); }
+    fclose(ff);
   }
-  fclose(ff);
-  lap("init + read input");
+  lap("read input");
   fprintf(stderr, "Starting to align sequences to the reference...\n");
 
   // ---- pass 1 on the GPU (new_kmer_filter + sg_align)
@@ -293,22 +317,21 @@ int main(int argc, char** argv) {
   int n_unknown = 0;
   for (int64_t k = 0; k < n1; k++) {
     if (!(p_fl[k] & MIA_HIP_P1_KEPT)) continue;
-    const Read& r = reads[src[(size_t)k]];
+    Read& r = reads[src[(size_t)k]];      // each input read is looked at once: move its strings into the store
     Frag f;
-    f.id = r.id; f.desc = r.desc; f.seq = r.seq;
+    f.id = std::move(r.id); f.desc = std::move(r.desc); f.seq = std::move(r.seq);
     f.rc = p_rc[k]; f.strand_known = (p_fl[k] & MIA_HIP_P1_STRAND_KNOWN) ? 1 : 0;
     f.as = p_as[k]; f.ae = p_ae[k]; f.score = p_score[k];
     if (f.rc && f.strand_known) {
-      std::string t(f.seq.size(), 'N');
-      for (size_t i = 0; i < f.seq.size(); i++) t[i] = revcom_char(f.seq[f.seq.size() - 1 - i]);
-      f.seq = t;
+      std::reverse(f.seq.begin(), f.seq.end());
+      for (auto& ch : f.seq) ch = revcom_char(ch);
     }
     if (!f.strand_known) n_unknown++;
     first_slot.push_back((int)slot_dropped.size());
     slot_dropped.push_back(0);
     if (p_fl[k] & MIA_HIP_P1_SPLIT) slot_dropped.push_back(0);
     n_slots.push_back((p_fl[k] & MIA_HIP_P1_SPLIT) ? 2 : 1);
-    fsdb.push_back(f);
+    fsdb.push_back(std::move(f));
   }
   const int n = (int)fsdb.size();
   const int pass1_records = (int)slot_dropped.size();   // culled_maln->size, frozen here (src/mia.c:54)
@@ -337,6 +360,7 @@ int main(int argc, char** argv) {
   }
   // clean_FSDB (src/mia.c:400-406) cannot remove anything: every kept read scores >= 2000
 
+  lap("read store");
   // ---- upload the read store
   {
     std::vector<int64_t> o2((size_t)n + 1, 0);
@@ -349,12 +373,14 @@ int main(int argc, char** argv) {
     if (mia_hip_upload_reads(g, n, b2.data(), o2.data(), rc.data(), sk.data(), as.data(), ae.data()) != MIA_HIP_OK) die(g, "upload_reads");
     if (mia_hip_set_slot_dropped(g, slot_dropped.data(), (int64_t)slot_dropped.size()) != MIA_HIP_OK) die(g, "set_slot_dropped");
   }
+  lap("upload");
 
   // make_ref_upper (src/mia.c:642-648): iteration 1 aligns to the upper-cased input reference
   std::string cons = ref.seq;
   for (auto& ch : cons) ch = (char)toupper((unsigned char)ch);
   std::string ref_id = ref.id, ref_desc = ref.desc;
-  const int stride = MAX_READ;
+  int stride = 4;                        // columns of the script table: longest stored read, rounded up
+  for (int i = 0; i < n; i++) stride = std::max(stride, (len[i] + 3) & ~3);
   std::vector<int16_t> cols((size_t)n * stride);
   std::vector<int32_t> rstart((size_t)n), gaps;
   std::vector<uint8_t> dF((size_t)n), dB((size_t)n);
@@ -381,8 +407,9 @@ int main(int argc, char** argv) {
     if (mia_hip_get_dropped(g, dF.data(), dB.data()) != MIA_HIP_OK) die(g, "get_dropped");
     gaps.assign((size_t)L + 1, 0);
     if (mia_hip_get_tally(g, NULL, gaps.data()) != MIA_HIP_OK) die(g, "get_tally");
-    std::vector<Record> recs;
-    for (int i = 0; i < n; i++) {
+    // records of reads [lo, hi), in cull order (front record, then back record)
+    auto build_range = [&](int lo, int hi, std::vector<Record>& recs) {
+    for (int i = lo; i < hi; i++) {
       const Frag& f = fsdb[i];
       if (!f.strand_known) continue;
       const int16_t* cs = &cols[(size_t)i * stride];
@@ -439,6 +466,18 @@ int main(int argc, char** argv) {
       fill(fa, false);
       if (ba) fill(*ba, true);
     }
+    };
+    // reads are independent: build on all host threads, keep the order
+    const int T = worker_threads(n);
+    std::vector<std::vector<Record>> part((size_t)T);
+    run_parallel(T, [&](int t) { build_range((int)((int64_t)n * t / T), (int)((int64_t)n * (t + 1) / T), part[(size_t)t]); });
+    std::vector<Record> recs;
+    {
+      size_t tot = 0;
+      for (auto& v : part) tot += v.size();
+      recs.reserve(tot);
+      for (auto& v : part) { for (auto& a : v) recs.push_back(std::move(a)); std::vector<Record>().swap(v); }
+    }
     // sort_aln_frags: stable by (start, end) over cull order (src/map_align.c:393-414)
     std::vector<int> order(recs.size());
     for (size_t k = 0; k < recs.size(); k++) order[k] = (int)k;
@@ -460,12 +499,27 @@ int main(int argc, char** argv) {
     fprintf(mf, "RPSM:\n");
     for (int d = 0; d < 31; d++) { for (int r = 0; r < 5; r++) fprintf(mf, "%d %d %d %d %d\n", rcanc.sm[d][r][0], rcanc.sm[d][r][1], rcanc.sm[d][r][2], rcanc.sm[d][r][3], rcanc.sm[d][r][4]); fprintf(mf, "\n"); }
     fprintf(mf, "__ALNSEQS__\n");
-    for (int k : order) {
-      const Record& a = recs[(size_t)k];
-      fprintf(mf, "ID %s\nDESC %s\nSCORE %d\nNUM_INPUTS 1\nSTART %d\nEND %d\nRC %d\nTR 0\nDR %d\nSEG %c\nSEQ %s\nSMP %s\nINS_POS", a.id.c_str(), a.desc.c_str(),
-              a.score, a.start, a.end, a.rc ? 1 : 0, a.dropped ? 1 : 0, a.segment, a.seq.c_str(), a.smp.c_str());
-      for (auto& in : a.ins) fprintf(mf, " %d %s", in.first, in.second.c_str());
-      fprintf(mf, "\n");
+    {
+      // the record texts are formatted in parallel (contiguous runs of the sorted order), written in order
+      const size_t nr = order.size();
+      const int TF = worker_threads((int)std::min<size_t>(nr, (size_t)INT32_MAX));
+      std::vector<std::string> text((size_t)TF);
+      run_parallel(TF, [&](int t) {
+        std::string& o = text[(size_t)t];
+        const size_t lo = nr * (size_t)t / (size_t)TF, hi = nr * (size_t)(t + 1) / (size_t)TF;
+        o.reserve((hi - lo) * 420);
+        auto num = [&](int v) { char b[16]; auto r = std::to_chars(b, b + sizeof b, v); o.append(b, r.ptr); };
+        for (size_t q = lo; q < hi; q++) {
+          const Record& a = recs[(size_t)order[q]];
+          o += "ID "; o += a.id; o += "\nDESC "; o += a.desc; o += "\nSCORE "; num(a.score);
+          o += "\nNUM_INPUTS 1\nSTART "; num(a.start); o += "\nEND "; num(a.end);
+          o += a.rc ? "\nRC 1\nTR 0\nDR " : "\nRC 0\nTR 0\nDR "; o += a.dropped ? '1' : '0';
+          o += "\nSEG "; o += a.segment; o += "\nSEQ "; o += a.seq; o += "\nSMP "; o += a.smp; o += "\nINS_POS";
+          for (auto& in : a.ins) { o += ' '; num(in.first); o += ' '; o += in.second; }
+          o += '\n';
+        }
+      });
+      for (auto& o : text) fwrite(o.data(), 1, o.size(), mf);
     }
     fclose(mf);
     lap("write .maln");
