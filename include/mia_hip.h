@@ -141,6 +141,27 @@ int mia_hip_get_tally(mia_hip_ctx *ctx, int32_t *tally, int32_t *gaps); /* host 
  * out must hold ref_len + sum(gaps) + 1 bytes; *out_len = strlen(out). */
 int mia_hip_consensus(mia_hip_ctx *ctx, int cons_code, char *out, int64_t out_cap, int64_t *out_len);
 
+/* ---- ma: reports from a .maln ------------------------------------------ */
+
+/* The tally loop of show_consensus / get_consensus (src/map_alignment.c:107-170,222-262) and of
+ * find_ins_cons (src/map_align.c:444-510) over the AlnSeq records of a .maln file as read_ma
+ * (src/map_alignment.c:384-607) leaves them -- EVERY record counts here, dropped or not, unlike
+ * consensus_assembly_string.  Uses the matrices of mia_hip_set_pssm (the file's FPSM / RPSM).
+ *   gaps[ref_len]                         ref->gaps from the file's GAPS line
+ *   start[n], revcom[n]                   per record
+ *   col_off[n+1], seq, smp                record r owns seq/smp[col_off[r] .. col_off[r+1]) = columns start..end
+ *   ins_record/ins_pos[n_ins], ins_off[n_ins+1], ins_bases   the INS_POS pairs: inserted bases before column
+ *                                         start+ins_pos of that record
+ * Afterwards mia_hip_get_tally, mia_hip_consensus (the sequence -f 5 prints) and mia_hip_get_ins_tally work. */
+int mia_hip_ma_tally(mia_hip_ctx *ctx, int32_t ref_len, const int32_t *gaps, int64_t n_records, const int32_t *start,
+                     const uint8_t *revcom, const int64_t *col_off, const char *seq, const char *smp, int64_t n_ins,
+                     const int32_t *ins_record, const int32_t *ins_pos, const int64_t *ins_off, const char *ins_bases);
+
+/* BaseCounts of the insert columns (find_ins_cons), valid after mia_hip_consensus: ins_off[ref_len+1] = index of
+ * the first insert column before each reference column, ins_tally[slot*9 + {A,C,G,T,bases,scoreA,scoreC,scoreG,scoreT}]
+ * (bases = records with a base in that column; cov = T_SPAN word of the column, gaps = cov - bases). */
+int mia_hip_get_ins_tally(mia_hip_ctx *ctx, int32_t *ins_off, int32_t *ins_tally, int64_t cap_slots, int64_t *n_slots);
+
 /* ---- Myers edit distance -------------------------------------------------- */
 
 /* unsigned myers_diff(const char *seq_a, enum myers_align_mode mode, const char* seq_b, int maxd,

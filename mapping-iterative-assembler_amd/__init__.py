@@ -55,6 +55,8 @@ def _load():
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
+    lib.mia_hip_ma_tally.argtypes = [vp, C.c_int32, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
+    lib.mia_hip_get_ins_tally.argtypes = [vp, vp, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
     return lib
 
@@ -75,7 +77,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time"]
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally"]
 
 
 def _ptr(a):
@@ -266,6 +268,34 @@ class MiaHip:
         ms, k = C.c_double(), C.c_int64()
         self._chk(self._l.mia_hip_kernel_time(self._h, 1 if reset else 0, C.byref(ms), C.byref(k)))
         return ms.value, k.value
+
+    def ma_tally(self, ref_len, gaps, start, revcom, col_off, seq, smp, ins_record=(), ins_pos=(), ins_off=(0,), ins_bases=b""):
+        """show_consensus / find_ins_cons tallies over stored AlnSeq records (reference src/map_alignment.c:107-170)."""
+        gaps = np.ascontiguousarray(gaps, dtype=np.int32)
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        revcom = np.ascontiguousarray(revcom, dtype=np.uint8)
+        col_off = np.ascontiguousarray(col_off, dtype=np.int64)
+        seq = np.frombuffer(bytes(seq), dtype=np.uint8) if not isinstance(seq, np.ndarray) else seq
+        smp = np.frombuffer(bytes(smp), dtype=np.uint8) if not isinstance(smp, np.ndarray) else smp
+        ir = np.ascontiguousarray(ins_record, dtype=np.int32)
+        ip = np.ascontiguousarray(ins_pos, dtype=np.int32)
+        io = np.ascontiguousarray(ins_off, dtype=np.int64)
+        ib = np.frombuffer(bytes(ins_bases), dtype=np.uint8) if not isinstance(ins_bases, np.ndarray) else ins_bases
+        self.L = int(ref_len)
+        self._chk(self._l.mia_hip_ma_tally(self._h, int(ref_len), _ptr(gaps), len(start), _ptr(start), _ptr(revcom), _ptr(col_off),
+                                           _ptr(seq) if len(seq) else None, _ptr(smp) if len(smp) else None, len(ir),
+                                           _ptr(ir) if len(ir) else None, _ptr(ip) if len(ip) else None, _ptr(io),
+                                           _ptr(ib) if len(ib) else None))
+
+    def ins_tally(self):
+        """(ins_off[L+1], ins_tally[slots][9]) of the insert columns, after consensus()."""
+        n = C.c_int64()
+        off = np.empty(self.L + 1, dtype=np.int32)
+        self._chk(self._l.mia_hip_get_ins_tally(self._h, _ptr(off), None, 0, C.byref(n)))
+        t = np.zeros((max(n.value, 1), 9), dtype=np.int32)
+        if n.value:
+            self._chk(self._l.mia_hip_get_ins_tally(self._h, None, _ptr(t), n.value, None))
+        return off, t[: n.value]
 
     def pass1_time(self):
         ms = C.c_double()

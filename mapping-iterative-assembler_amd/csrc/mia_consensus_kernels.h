@@ -274,6 +274,67 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   }
 }
 
+// ---- ma: tally of stored AlnSeq records (show_consensus, src/map_alignment.c:139-170) -------------
+// One record per wavefront, one column per lane.  No `dropped` test: ma counts every record.
+struct MaRecords {
+  int64_t n;
+  const int32_t* start;
+  const uint8_t* revcom;
+  const int64_t* col_off;   // [n+1]
+  const char* seq;
+  const char* smp;
+};
+__device__ __forceinline__ int ma_code(char b) {   // add_base / base2inx (src/map_align.c:16-29,229-263)
+  return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : b == '-' ? 5 : 4;
+}
+__global__ __launch_bounds__(256) void k_ma_tally(MaRecords mr, const int32_t* pssm2, TallyBuf tb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= mr.n) return;
+  const int64_t o0 = mr.col_off[r];
+  const int ncols = (int)(mr.col_off[r + 1] - o0), start = mr.start[r], Lp = tb.Lp;
+  const int32_t* pm = pssm2 + (mr.revcom[r] ? PSSM_WORDS : 0);
+  for (int p = lane; p < ncols; p += 64) {
+    const int gc = start + p;
+    if (gc < 0 || gc >= Lp) { atomicOr(tb.flags, 2u); continue; }
+    const int code = ma_code(mr.seq[o0 + p]), d = (int)mr.smp[o0 + p] - 'A';
+    int32_t* t = tb.tally + gc;
+    atomicAdd(&t[T_COV * Lp], 1);
+    if (code == 5) atomicAdd(&t[T_GAP * Lp], 1);
+    else {
+      if (d < 0 || d > 2 * PSSM_DEPTH) { atomicOr(tb.flags, 2u); continue; }
+      if (code < 4) atomicAdd(&t[(T_A + code) * Lp], 1);
+      const int32_t* row = pm + d * 25 + code;
+      atomicAdd(&t[T_SA * Lp], row[0]);
+      atomicAdd(&t[T_SC * Lp], row[5]);
+      atomicAdd(&t[T_SG * Lp], row[10]);
+      atomicAdd(&t[T_ST * Lp], row[15]);
+    }
+    if (p > 0) atomicAdd(&t[T_SPAN * Lp], 1);              // start < pos <= end (src/map_align.c:466-469)
+  }
+}
+// INS_POS pairs -> the event list k_ins_tally consumes; one pair per thread (inserts are short)
+__global__ void k_ma_ins_events(MaRecords mr, int64_t n_ins, const int32_t* ins_record, const int32_t* ins_pos, const int64_t* ins_off,
+                                const char* ins_bases, TallyBuf tb) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ins) return;
+  const int r = ins_record[e], p = ins_pos[e];
+  const int64_t o0 = mr.col_off[r];
+  const int ncols = (int)(mr.col_off[r + 1] - o0);
+  if (p <= 0 || p >= ncols) return;                        // not "start < pos <= end": never looked at
+  const int gc = mr.start[r] + p, d = (int)mr.smp[o0 + p] - 'A';
+  if (gc >= tb.Lp || d < 0 || d > 2 * PSSM_DEPTH) { atomicOr(tb.flags, 2u); return; }
+  const int len = (int)(ins_off[e + 1] - ins_off[e]);
+  for (int j = 0; j < len && j < 1024; j++) {
+    const int code = ma_code(ins_bases[ins_off[e] + j]);
+    const int slot = atomicAdd(tb.n_events, 1);
+    if (slot < tb.cap_events)
+      tb.events[slot] = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)(code == 5 ? 4 : code) << 42) | ((uint64_t)(d & 31) << 45) |
+                        ((uint64_t)(mr.revcom[r] ? 1 : 0) << 50);
+    else atomicOr(tb.flags, 1u);
+  }
+}
+
 // ---- insert columns (find_ins_cons, src/map_align.c:444-510) ----------------------
 // ins_off[pos] = sum of gaps[0..pos-1]; slot (pos, j) -> ins_off[pos] + j; 9 words per slot:
 // A,C,G,T counts, number of reads with a base there, scoreA..scoreT

@@ -66,6 +66,8 @@ struct mia_hip_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
   double align_ms = 0; int64_t align_launches = 0;
   double pass1_ms = 0;
+  bool consensus_done = false;
+  int64_t ins_total_host = 0;
 };
 
 #define HIPCHK(call)                                                                                   \
@@ -648,6 +650,7 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
   if (flags & 1u) { ctx->err = "insert event list overflow"; return MIA_HIP_ERR_NOMEM; }
   if (ctx->n_events_host > ctx->tb.cap_events) ctx->n_events_host = ctx->tb.cap_events;
   ctx->tallied = true;
+  ctx->consensus_done = false;
   return MIA_HIP_OK;
 }
 
@@ -736,6 +739,96 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   }
   out[o] = 0;
   if (out_len) *out_len = o;
+  ctx->consensus_done = true;
+  ctx->ins_total_host = total;
+  return MIA_HIP_OK;
+}
+
+// ---- ma -------------------------------------------------------------------------------------
+extern "C" int mia_hip_ma_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_t* gaps, int64_t n, const int32_t* start,
+                                const uint8_t* revcom, const int64_t* col_off, const char* seq, const char* smp, int64_t n_ins,
+                                const int32_t* ins_record, const int32_t* ins_pos, const int64_t* ins_off, const char* ins_bases) {
+  if (!ctx || ref_len <= 0 || !gaps || n < 0 || n_ins < 0 || (n > 0 && (!start || !revcom || !col_off || !seq || !smp)) ||
+      (n_ins > 0 && (!ins_record || !ins_pos || !ins_off || !ins_bases)))
+    return MIA_HIP_ERR_ARG;
+  if (!ctx->have_pssm) { ctx->err = "set_pssm must precede ma_tally"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  for (int64_t r = 0; r < n; r++)
+    if (col_off[r + 1] < col_off[r] || start[r] < 0) { ctx->err = "malformed record geometry"; return MIA_HIP_ERR_ARG; }
+  for (int64_t e = 0; e < n_ins; e++)
+    if (ins_record[e] < 0 || ins_record[e] >= n || ins_off[e + 1] < ins_off[e]) { ctx->err = "malformed insert list"; return MIA_HIP_ERR_ARG; }
+  ctx->L = ref_len;
+  ctx->wrap = ref_len;
+  const int64_t ins_chars = n_ins ? ins_off[n_ins] : 0;
+  if (ctx->tb.events && ctx->tb.cap_events < ins_chars + 16) {   // the list was sized for another job
+    (void)hipFree(ctx->tb.events); ctx->tb.events = nullptr;
+    if (dev_alloc(ctx, &ctx->tb.events, (size_t)ins_chars + 4096)) return MIA_HIP_ERR_NOMEM;
+    ctx->tb.cap_events = (int32_t)std::min<int64_t>(ins_chars + 4096, INT32_MAX);
+  }
+  if (!ctx->tb.events) {
+    int rc0 = dev_alloc(ctx, &ctx->tb.events, (size_t)ins_chars + 4096) | dev_alloc(ctx, &ctx->tb.n_events, 1) | dev_alloc(ctx, &ctx->tb.flags, 1);
+    if (rc0) return MIA_HIP_ERR_NOMEM;
+    ctx->tb.cap_events = (int32_t)std::min<int64_t>(ins_chars + 4096, INT32_MAX);
+  }
+  int rc = ensure_tally(ctx);
+  if (rc) return rc;
+  const int Lp = ctx->tb.Lp;
+  const int64_t chars = n ? col_off[n] : 0;
+  int32_t *d_start = nullptr, *d_irec = nullptr, *d_ipos = nullptr;
+  uint8_t* d_rev = nullptr;
+  int64_t *d_coff = nullptr, *d_ioff = nullptr;
+  char *d_seq = nullptr, *d_smp = nullptr, *d_ib = nullptr;
+  int rcx = dev_alloc(ctx, &d_start, (size_t)n + 1) | dev_alloc(ctx, &d_rev, (size_t)n + 1) | dev_alloc(ctx, &d_coff, (size_t)n + 1) |
+            dev_alloc(ctx, &d_seq, (size_t)chars + 1) | dev_alloc(ctx, &d_smp, (size_t)chars + 1) | dev_alloc(ctx, &d_irec, (size_t)n_ins + 1) |
+            dev_alloc(ctx, &d_ipos, (size_t)n_ins + 1) | dev_alloc(ctx, &d_ioff, (size_t)n_ins + 1) | dev_alloc(ctx, &d_ib, (size_t)ins_chars + 1);
+  void* tmp[] = {d_start, d_rev, d_coff, d_seq, d_smp, d_irec, d_ipos, d_ioff, d_ib};
+  auto cleanup = [&]() { for (void* p : tmp) if (p) (void)hipFree(p); };
+  if (rcx) { cleanup(); return MIA_HIP_ERR_NOMEM; }
+  hipError_t e = hipSuccess;
+  auto up = [&](void* d, const void* h, size_t b) { if (e == hipSuccess && b) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
+  auto zero = [&](void* d, size_t b) { if (e == hipSuccess) e = hipMemsetAsync(d, 0, b, ctx->stream); };
+  zero(ctx->tb.tally, (size_t)TALLY_WORDS * Lp * 4);
+  zero(ctx->tb.gaps, (size_t)Lp * 4);
+  zero(ctx->tb.n_events, 4);
+  zero(ctx->tb.flags, 4);
+  up(ctx->tb.gaps, gaps, (size_t)ref_len * 4);
+  up(d_start, start, (size_t)n * 4); up(d_rev, revcom, (size_t)n); up(d_coff, col_off, (size_t)(n + 1) * 8);
+  up(d_seq, seq, (size_t)chars); up(d_smp, smp, (size_t)chars);
+  if (n_ins) { up(d_irec, ins_record, (size_t)n_ins * 4); up(d_ipos, ins_pos, (size_t)n_ins * 4); up(d_ioff, ins_off, (size_t)(n_ins + 1) * 8); up(d_ib, ins_bases, (size_t)ins_chars); }
+  if (e == hipSuccess && n > 0) {
+    MaRecords mr{n, d_start, d_rev, d_coff, d_seq, d_smp};
+    hipLaunchKernelGGL(k_ma_tally, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, mr, ctx->d_pssm, ctx->tb);
+    if (n_ins > 0)
+      hipLaunchKernelGGL(k_ma_ins_events, dim3((unsigned)((n_ins + 255) / 256)), dim3(256), 0, ctx->stream, mr, n_ins, d_irec, d_ipos, d_ioff,
+                         d_ib, ctx->tb);
+    e = hipGetLastError();
+  }
+  uint32_t flags = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&ctx->n_events_host, ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&flags, ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess) { ctx->err = std::string("ma_tally: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  if (flags & 1u) { ctx->err = "insert event list overflow"; return MIA_HIP_ERR_NOMEM; }
+  if (flags & 2u) { ctx->err = "a record reaches past the reference or carries a depth code outside A.._"; return MIA_HIP_ERR_ARG; }
+  if (ctx->n_events_host > ctx->tb.cap_events) ctx->n_events_host = ctx->tb.cap_events;
+  ctx->tallied = true;
+  ctx->consensus_done = false;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_get_ins_tally(mia_hip_ctx* ctx, int32_t* ins_off, int32_t* ins_tally, int64_t cap_slots, int64_t* n_slots) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (!ctx->tallied || !ctx->consensus_done) { ctx->err = "consensus first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t total = ctx->ins_total_host;
+  if (n_slots) *n_slots = total;
+  if (ins_off) HIPCHK(hipMemcpyAsync(ins_off, ctx->d_ins_off, (size_t)ctx->tb.Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (ins_tally && total > 0) {
+    if (cap_slots < total) { ctx->err = "ins_tally buffer too small"; return MIA_HIP_ERR_ARG; }
+    HIPCHK(hipMemcpyAsync(ins_tally, ctx->d_ins_tally, (size_t)total * 9 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return MIA_HIP_OK;
 }
 

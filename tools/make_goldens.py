@@ -223,8 +223,52 @@ def maln_cases(mt311_path):
     shutil.rmtree(tmp)
 
 
+MA_HEADER = "/* map_alignment [V1.0] */ golden\n"   # line 1 of a .maln carries a timestamp and is not stored
+MA_RUNS = [(5, 1), (5, 2), (41, 1), (41, 2), (4, 1)]
+
+
+def ma_cases():
+    """Reports of the reference's own `ma` on every committed .maln: -f 5 (FASTA), -f 41 / -f 4 (column table),
+    consensus codes 1 and 2.  Outputs above 40 KB are pinned by sha256 (tests/golden/ma/hashes.json)."""
+    import glob
+    import hashlib
+    out_dir = os.path.join(G, "ma")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    tmp = tempfile.mkdtemp()
+    hashes = {}
+    for path in sorted(glob.glob(os.path.join(G, "maln", "*.[0-9]"))):
+        name = os.path.basename(path)
+        full = os.path.join(tmp, name)
+        with open(full, "w") as f:
+            f.write(MA_HEADER + open(path).read())
+        for fmt, code in MA_RUNS:
+            out = subprocess.run([os.path.join(RB, "ma"), "-M", full, "-f", str(fmt), "-c", str(code)], check=True,
+                                 stdout=subprocess.PIPE).stdout
+            key = f"{name}.f{fmt}c{code}"
+            if len(out) <= 40 * 1024:
+                with open(os.path.join(out_dir, key), "wb") as f:
+                    f.write(out)
+            else:
+                hashes[key] = {"sha256": hashlib.sha256(out).hexdigest(), "bytes": len(out)}
+    # -I: a user-assigned id for the FASTA header
+    name = "fix_c.2"
+    out = subprocess.run([os.path.join(RB, "ma"), "-M", os.path.join(tmp, name), "-f", "5", "-I", "my_assembly"], check=True,
+                         stdout=subprocess.PIPE).stdout
+    with open(os.path.join(out_dir, name + ".f5c1.I"), "wb") as f:
+        f.write(out)
+    with open(os.path.join(out_dir, "hashes.json"), "w") as f:
+        json.dump(hashes, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp)
+    print("ma goldens:", len(os.listdir(out_dir)) - 1, "files,", len(hashes), "hashed")
+
+
 def main():
     os.makedirs(G, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "ma":          # only the ma reports (the .maln files stay as they are)
+        sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
+        ma_cases()
+        return
     sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
     shutil.copy(os.path.join(RB, "mt311.fa"), os.path.join(G, "mt311.fa"))
     shutil.copy(os.path.join(REF, "test", "tr1.fna"), os.path.join(G, "tr1.fna"))
@@ -235,6 +279,7 @@ def main():
     cons_vectors()
     myers_vectors(mt)
     maln_cases(os.path.join(G, "mt311.fa"))
+    ma_cases()
 
 
 if __name__ == "__main__":
