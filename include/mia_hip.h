@@ -141,6 +141,19 @@ int mia_hip_get_tally(mia_hip_ctx *ctx, int32_t *tally, int32_t *gaps); /* host 
  * out must hold ref_len + sum(gaps) + 1 bytes; *out_len = strlen(out). */
 int mia_hip_consensus(mia_hip_ctx *ctx, int cons_code, char *out, int64_t out_cap, int64_t *out_len);
 
+/* ---- adapter trimming ---------------------------------------------------- */
+
+/* void trim_frag(FragSeqP, char* adapter, AlignmentP) -- src/mia.h, src/mia.c:1318-1368, as main() sets it up for -T
+ * (src/mia_main.c:694-717,771-775): flat matrix, adapter (ASCII, 1..127 bases) = rows with sg5 = 1, read = columns,
+ * best score over the last column.  bases/offsets: reads as sequenced (1..256 bases each).
+ * Out: trimmed[n] = fs->trimmed, trim_point[n] = fs->trim_point (0 when not trimmed). */
+int mia_hip_trim(mia_hip_ctx *ctx, const char *adapter, int64_t n_reads, const char *bases, const int64_t *offsets,
+                 uint8_t *trimmed, int32_t *trim_point);
+
+/* reads of the most recent mia_hip_trim call whose best path held a gap of 63 or more and that were therefore
+ * re-run by the exact scalar kernel (diagnostic; results are identical either way) */
+int mia_hip_trim_stats(mia_hip_ctx *ctx, int64_t *exact_reruns);
+
 /* ---- ma: reports from a .maln ------------------------------------------ */
 
 /* The tally loop of show_consensus / get_consensus (src/map_alignment.c:107-170,222-262) and of

@@ -56,6 +56,8 @@ def _load():
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
     lib.mia_hip_ma_tally.argtypes = [vp, C.c_int32, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
+    lib.mia_hip_trim.argtypes = [vp, C.c_char_p, C.c_int64, vp, vp, vp, vp]
+    lib.mia_hip_trim_stats.argtypes = [vp, P(C.c_int64)]
     lib.mia_hip_get_ins_tally.argtypes = [vp, vp, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
     return lib
@@ -77,7 +79,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally"]
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats"]
 
 
 def _ptr(a):
@@ -296,6 +298,23 @@ class MiaHip:
         if n.value:
             self._chk(self._l.mia_hip_get_ins_tally(self._h, None, _ptr(t), n.value, None))
         return off, t[: n.value]
+
+    def trim(self, adapter, bases, offsets):
+        """trim_frag for a batch (reference src/mia.c:1318-1368): returns trimmed[n], trim_point[n]."""
+        if isinstance(adapter, str):
+            adapter = adapter.encode()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        trimmed = np.zeros(n, np.uint8)
+        point = np.zeros(n, np.int32)
+        self._chk(self._l.mia_hip_trim(self._h, adapter, n, _ptr(bases), _ptr(offsets), _ptr(trimmed), _ptr(point)))
+        return trimmed, point
+
+    def trim_exact_reruns(self):
+        n = C.c_int64()
+        self._chk(self._l.mia_hip_trim_stats(self._h, C.byref(n)))
+        return n.value
 
     def pass1_time(self):
         ms = C.c_double()

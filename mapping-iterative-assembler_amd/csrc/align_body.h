@@ -46,6 +46,7 @@ struct AlignArgs {            // everything here is wave-uniform
 struct AlignResult {          // wave-uniform
   int32_t score, abc, abr, aec;
   uint32_t status;
+  int32_t aer;                // last row of the alignment: len2-1, or the arg-max row of the last column (LASTCOL)
 };
 
 template <int CPL>
@@ -55,7 +56,9 @@ struct PackBits {
   static constexpr uint32_t IDXM = (1u << IB) - 1u;
 };
 
-template <class P, int CPL>
+// LASTCOL = the end condition of trim_frag (src/mia.c:1346-1353): best score over the LAST COLUMN (all rows,
+// first maximum) instead of max_sg_score's last row; everything else is the same DP.
+template <class P, int CPL, bool LASTCOL = false>
 struct WindowAligner {
   typedef typename P::U U;
   typedef typename P::M M;
@@ -113,6 +116,16 @@ struct WindowAligner {
       for (int j4 = 0; j4 < CPL; j4 += 4)
         w.tr_w32(col[j4], U((TR_DIAG << 6) * 0x01010101u), col[j4] < (uint32_t)a.trace_stride);
     }
+    // LASTCOL: running (first) maximum of column len1-1 over the rows, kept in the lane that owns that column
+    U colbest = U(0u), colrow = U(0u);
+    auto last_col_update = [&](int r) __attribute__((always_inline)) {
+      U v = U(0u);
+      for (int j = 0; j < CPL; j++) v = w.sel(col[j] == (uint32_t)(len1 - 1), Sb[j], v);
+      M up = v > colbest;                       // biased scores are >= 1: the first row always enters
+      colbest = w.sel(up, v, colbest);
+      colrow = w.sel(up, U((uint32_t)r), colrow);
+    };
+    if (LASTCOL) last_col_update(0);
 
     // ---- 4. rows 1 .. len2-1
     for (int r = 1; r < ((a.dbg & 4u) ? 1 : len2); r++) {
@@ -162,13 +175,20 @@ struct WindowAligner {
         q[j] = (Snew[j] << SH) + QC[j];
         Sb[j] = Snew[j];
       }
+      if (LASTCOL) last_col_update(r);
     }
 
     // ---- 5. max_sg_score (src/mia.c:1278-1302): last row, first maximum
     AlignResult res;
     res.abr = 0;
     res.abc = 0;
-    {
+    res.aer = len2 - 1;
+    if (LASTCOL) {
+      const int owner = (len1 - 1) / CPL;
+      res.score = (int32_t)(w.lane_val(colbest, owner) - OFF);
+      res.aer = (int32_t)w.lane_val(colrow, owner);
+      res.aec = len1 - 1;
+    } else {
       U m = U(0u);
       for (int j = 0; j < CPL; j++) m = w.umax(m, w.sel(col[j] < (uint32_t)len1, Sb[j], U(0u)));
       const uint32_t bestb = w.reduce_max(m);
@@ -181,7 +201,7 @@ struct WindowAligner {
 
     // ---- 6. traceback (src/mia.c:612-637,1440-1497), diagonal runs of up to 64 cells per step.
     // cols_out[row] = window column aligned to that read base, COL_INSERT, or COL_CLIP.
-    int r = len2 - 1, c = res.aec;
+    int r = res.aer, c = res.aec;
     uint32_t status = ST_OK;
     int aln_cols = 0;
     for (int guard = 0; guard < ((a.dbg & 2u) ? 0 : 4 * MAX_READ + 8); guard++) {

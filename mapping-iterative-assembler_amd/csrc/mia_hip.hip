@@ -15,6 +15,7 @@
 #include "mia_kernels.h"
 #include "mia_pass1_kernels.h"
 #include "mia_myers_kernels.h"
+#include "mia_trim_kernels.h"
 
 using namespace mia;
 
@@ -67,6 +68,7 @@ struct mia_hip_ctx {
   double align_ms = 0; int64_t align_launches = 0;
   double pass1_ms = 0;
   bool consensus_done = false;
+  int64_t trim_escapes = 0;   // reads of the last mia_hip_trim call that took the exact scalar path
   int64_t ins_total_host = 0;
 };
 
@@ -741,6 +743,97 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   if (out_len) *out_len = o;
   ctx->consensus_done = true;
   ctx->ins_total_host = total;
+  return MIA_HIP_OK;
+}
+
+// ---- adapter trimming ---------------------------------------------------------------------------
+extern "C" int mia_hip_trim(mia_hip_ctx* ctx, const char* adapter, int64_t n, const char* bases, const int64_t* offsets,
+                            uint8_t* trimmed, int32_t* trim_point) {
+  if (!ctx || !adapter || n < 0 || (n > 0 && (!bases || !offsets || !trimmed || !trim_point))) return MIA_HIP_ERR_ARG;
+  const int len2 = (int)strlen(adapter);
+  if (len2 < 1 || len2 > MAX_ADAPTER) { ctx->err = "adapter length outside 1..127"; return MIA_HIP_ERR_ARG; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n == 0) return MIA_HIP_OK;
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t l = offsets[i + 1] - offsets[i];
+    if (l < 1 || l > MIA_HIP_MAX_READ) { ctx->err = "read length outside 1..256"; return MIA_HIP_ERR_ARG; }
+  }
+  // init_flatsubmat (src/pssm.c:96-126)
+  std::vector<int32_t> flat((size_t)PSSM_WORDS);
+  for (int d = 0; d < 31; d++)
+    for (int i = 0; i < 5; i++)
+      for (int j = 0; j < 5; j++)
+        flat[(size_t)(d * 5 + i) * 5 + j] = i == 4 ? -10 : (j == 4 ? -100 : (i == j ? 200 : -600));
+  PackParams pk;
+  if (!make_pack_params(256, 600, &pk)) return MIA_HIP_ERR_RANGE;
+  const int64_t chars = offsets[n] - offsets[0];
+  std::vector<uint8_t> codes((size_t)chars), acodes((size_t)len2), apacked((size_t)(len2 + 1) / 2 + 4, 0);
+  for (int64_t k = 0; k < chars; k++) codes[(size_t)k] = base_code(bases[offsets[0] + k]);
+  for (int k = 0; k < len2; k++) { acodes[(size_t)k] = base_code(adapter[k]); apacked[(size_t)k >> 1] |= (uint8_t)(acodes[(size_t)k] << ((k & 1) * 4)); }
+  std::vector<int64_t> off0((size_t)n + 1);
+  for (int64_t i = 0; i <= n; i++) off0[(size_t)i] = offsets[i] - offsets[0];
+  int occ = 0;
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_trim, 64, 0));
+  if (occ < 1) occ = 1;
+  if (occ > 32) occ = 32;
+  if (occ > 4) occ &= ~3;
+  int64_t grid = (int64_t)ctx->cus * occ;
+  if (grid > n) grid = n;
+  const int64_t slab = (int64_t)(MAX_ADAPTER + 1) * MAX_READ;
+  uint8_t *d_codes = nullptr, *d_ap = nullptr, *d_ac = nullptr, *d_trimmed = nullptr;
+  int64_t* d_off = nullptr;
+  int32_t *d_flat = nullptr, *d_tp = nullptr, *d_list = nullptr, *d_scratch = nullptr;
+  uint32_t* d_status = nullptr;
+  unsigned char* d_slabs = nullptr;
+  int16_t* d_cols = nullptr;
+  int rcx = dev_alloc(ctx, &d_codes, (size_t)chars + 8) | dev_alloc(ctx, &d_ap, apacked.size()) | dev_alloc(ctx, &d_ac, (size_t)len2) |
+            dev_alloc(ctx, &d_trimmed, (size_t)n) | dev_alloc(ctx, &d_off, (size_t)n + 1) | dev_alloc(ctx, &d_flat, (size_t)PSSM_WORDS) |
+            dev_alloc(ctx, &d_tp, (size_t)n) | dev_alloc(ctx, &d_status, (size_t)n) | dev_alloc(ctx, &d_slabs, (size_t)(slab * grid)) |
+            dev_alloc(ctx, &d_cols, (size_t)(grid * MAX_READ));
+  std::vector<void*> tmp = {d_codes, d_ap, d_ac, d_trimmed, d_off, d_flat, d_tp, d_status, d_slabs, d_cols};
+  auto cleanup = [&]() { for (void* p : tmp) if (p) (void)hipFree(p); };
+  if (rcx) { cleanup(); return MIA_HIP_ERR_NOMEM; }
+  hipError_t e = hipSuccess;
+  auto up = [&](void* d, const void* h, size_t b) { if (e == hipSuccess && b) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
+  up(d_codes, codes.data(), (size_t)chars); up(d_ap, apacked.data(), apacked.size()); up(d_ac, acodes.data(), (size_t)len2);
+  up(d_off, off0.data(), (size_t)(n + 1) * 8); up(d_flat, flat.data(), (size_t)PSSM_WORDS * 4);
+  TrimReads tr{n, d_codes, d_off, d_trimmed, d_tp, d_status};
+  std::vector<uint32_t> status((size_t)n);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_trim, dim3((unsigned)grid), dim3(64), 0, ctx->stream, tr, d_ap, len2, d_flat, pk, d_slabs, slab, d_cols);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(status.data(), d_status, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  // gaps of 63 or more on the optimal path: exact scalar re-run of those reads
+  std::vector<int32_t> esc;
+  if (e == hipSuccess)
+    for (int64_t i = 0; i < n; i++) if (status[(size_t)i] != ST_OK) esc.push_back((int32_t)i);
+  if (e == hipSuccess && !esc.empty()) {
+    const int64_t words = (int64_t)len2 * MAX_READ + 5 * (int64_t)MAX_READ;
+    if (dev_alloc(ctx, &d_list, esc.size()) || dev_alloc(ctx, &d_scratch, (size_t)(words * (int64_t)esc.size()))) {
+      tmp.push_back(d_list); tmp.push_back(d_scratch); cleanup(); return MIA_HIP_ERR_NOMEM;
+    }
+    tmp.push_back(d_list); tmp.push_back(d_scratch);
+    up(d_list, esc.data(), esc.size() * 4);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_trim_wide, dim3((unsigned)((esc.size() + 63) / 64)), dim3(64), 0, ctx->stream, tr, d_ac, len2, d_flat, d_list,
+                         (int32_t)esc.size(), d_scratch, words);
+      e = hipGetLastError();
+    }
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(trimmed, d_trimmed, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(trim_point, d_tp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  cleanup();
+  if (e != hipSuccess) { ctx->err = std::string("trim: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  ctx->trim_escapes = (int64_t)esc.size();
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_trim_stats(mia_hip_ctx* ctx, int64_t* exact_reruns) {
+  if (!ctx || !exact_reruns) return MIA_HIP_ERR_ARG;
+  *exact_reruns = ctx->trim_escapes;
   return MIA_HIP_OK;
 }
 

@@ -182,6 +182,42 @@ static void dp_fill(const unsigned char *c1, int n1, const unsigned char *c2, in
   free(colrow);
 }
 
+/* trim_frag, src/mia.c:1318-1368 */
+void ora_trim(const char *read, int read_len, const char *adapter, int *trimmed, int *trim_point, ora_aln *res) {
+  ora_pssm flat;
+  int len1 = read_len, len2 = (int)strlen(adapter), i, r, c, best = INT_MIN, aer = 0, aec, abr, abc;
+  unsigned char *c1, *c2;
+  int *S, *T;
+  *trimmed = 0;
+  *trim_point = 0;
+  if (len1 <= 0 || len2 <= 0) return;
+  ora_pssm_flat(&flat);
+  c1 = (unsigned char *)malloc((size_t)len1);
+  c2 = (unsigned char *)malloc((size_t)len2);
+  for (i = 0; i < len1; i++) c1[i] = (unsigned char)ora_base_code(read[i]);
+  for (i = 0; i < len2; i++) c2[i] = (unsigned char)ora_base_code(adapter[i]);
+  S = (int *)malloc(sizeof(int) * (size_t)len1 * len2);
+  T = (int *)malloc(sizeof(int) * (size_t)len1 * len2);
+  dp_fill(c1, len1, c2, len2, NULL, &flat, 1, S, T);
+  /* last column, all rows, first maximum (src/mia.c:1346-1353) */
+  aec = len1 - 1;
+  for (r = 0; r < len2; r++)
+    if (S[(size_t)r * len1 + aec] > best) { best = S[(size_t)r * len1 + aec]; aer = r; }
+  /* find_align_begin, src/mia.c:612-637 */
+  r = aer; c = aec;
+  for (;;) {
+    int t = T[(size_t)r * len1 + c];
+    if (t == c || t == -r) break;
+    if (t == 0) { r--; c--; }
+    else if (t < 0) { r = -t; c--; }
+    else { c = t; r--; }
+  }
+  abr = r; abc = c;
+  if (best >= 1000 || best >= (aer - abr + 1) * 200) { *trimmed = 1; *trim_point = abc - 1; }
+  if (res) { res->best = best; res->aec = aec; res->aer = aer; res->abc = abc; res->abr = abr; }
+  free(S); free(T); free(c1); free(c2);
+}
+
 int ora_align(const char *seq1, int len1, const char *seq2, int len2, const unsigned char *mask,
               const ora_pssm *pm, int sg5, ora_aln *res, char *ref_gapped, char *frag_gapped,
               int *S_out, int *T_out) {

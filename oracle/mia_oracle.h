@@ -62,6 +62,12 @@ int ora_align(const char *seq1, int len1, const char *seq2, int len2,
               ora_aln *res, char *ref_gapped, char *frag_gapped,
               int *S_out, int *T_out);
 
+/* ---- adapter trimming: trim_frag (src/mia.c:1318-1368) as main() sets it up (src/mia_main.c:694-717):
+ *      read = seq1 (columns), adapter = seq2 (rows), flat matrix, sg5 = 1, sg3 = 0; best score over the LAST COLUMN
+ *      (first maximum), walk back to the alignment start; trimmed iff best >= TRIM_SCORE_CUT (1000) or
+ *      best >= (aer - abr + 1) * FLAT_MATCH (200); trim_point = abc - 1.  res may be NULL. */
+void ora_trim(const char *read, int read_len, const char *adapter, int *trimmed, int *trim_point, ora_aln *res);
+
 /* ---- consensus primitives (src/map_align.c:229-391) */
 typedef struct {
   int As, scoreA, Cs, scoreC, Gs, scoreG, Ts, scoreT, gaps, cov;

@@ -15,6 +15,10 @@
  *     -> "D best aec aer abc abr hashS hashT ref_gapped frag_gapped"
  *   C <cons_code> As Cs Gs Ts gaps cov scoreA scoreC scoreG scoreT
  *     -> "C <char>"
+ *   T <adapter> <read>
+ *       trim_frag (src/mia.c:1318-1368) set up as main() does (src/mia_main.c:694-717):
+ *       flat matrix, adapter = seq2 (rows), sg5 = 1, sg3 = 0
+ *     -> "T trimmed trim_point aec aer abc abr"   (trim_point is -999 when not trimmed)
  */
 #include "mia.h"
 #include <stdint.h>
@@ -40,6 +44,17 @@ int main(void) {
              &bc.gaps, &bc.cov, &bc.scoreA, &bc.scoreC, &bc.scoreG, &bc.scoreT);
       ch = find_consensus(&bc, cc);
       printf("C %c\n", ch);
+      continue;
+    }
+    if (line[0] == 'T') {
+      static char ad[256]; static FragSeq fsq; static AlignmentP ta = NULL;
+      if (sscanf(line + 1, "%255s %300s", ad, fsq.seq) != 2) { fprintf(stderr, "bad T line\n"); return 1; }
+      if (!ta) ta = init_alignment(INIT_ALN_SEQ_LEN, INIT_ALN_SEQ_LEN, 0, 0);
+      ta->submat = flat; ta->seq2 = ad; ta->len2 = strlen(ad); pop_s2c_in_a(ta);
+      ta->sg5 = 1; ta->sg3 = 0;
+      fsq.trimmed = 0; fsq.trim_point = -999;
+      trim_frag(&fsq, ad, ta);
+      printf("T %d %d %d %d %d %d\n", fsq.trimmed, fsq.trimmed ? fsq.trim_point : -999, ta->aec, ta->aer, ta->abc, ta->abr);
       continue;
     }
     if (line[0] != 'D') continue;

@@ -33,6 +33,27 @@ static int run_one(const uint8_t* ref_codes, int ref_start, int len1, const uint
   return 0;
 }
 
+// trim_frag (src/mia.c:1318-1368): the read is the "reference" (columns), the adapter the "read" (rows), last-column end
+extern "C" int emu_trim(const uint8_t* read_codes, int len1, const uint8_t* adapter_codes, int len2, const int32_t* flat_pssm,
+                        int max_abs, int32_t* out6) {
+  PackParams pk;
+  if (!make_pack_params(256, max_abs, &pk)) return -1;
+  std::vector<uint8_t> packed((len2 + 1) / 2 + 4, 0);
+  for (int i = 0; i < len2; i++) packed[i >> 1] |= (uint8_t)(adapter_codes[i] << ((i & 1) * 4));
+  std::vector<int16_t> cols(MAX_READ + 8);
+  AlignArgs a;
+  a.ref_codes = read_codes; a.ref_start = 0; a.len1 = len1;
+  a.read_packed = packed.data(); a.len2 = len2; a.pssm = flat_pssm; a.sg5 = 1; a.pk = pk;
+  a.lds_sub = 0;
+  a.trace_stride = (uint32_t)((len1 + 3) & ~3);
+  a.cols_out = cols.data();
+  a.dbg = 0;
+  EmuWave w((size_t)len2 * 10 + 16, (size_t)len2 * a.trace_stride + 16);
+  AlignResult r = WindowAligner<EmuWave, 4, true>::run(w, a);
+  out6[0] = r.score; out6[1] = r.aec; out6[2] = r.aer; out6[3] = r.abc; out6[4] = r.abr; out6[5] = (int32_t)r.status;
+  return 0;
+}
+
 extern "C" int emu_align_window(int cpl, const uint8_t* ref_codes, int ref_start, int len1, const uint8_t* read_codes,
                                 int len2, const int32_t* pssm, int sg5, int max_abs, int32_t* out5, int16_t* cols) {
   switch (cpl) {

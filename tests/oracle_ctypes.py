@@ -46,6 +46,8 @@ def load(path):
     lib.ora_align.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p, P(Pssm), C.c_int, P(Aln),
                               C.c_char_p, C.c_char_p, P(C.c_int), P(C.c_int)]
     lib.ora_align.restype = C.c_int
+    lib.ora_trim.argtypes = [C.c_char_p, C.c_int, C.c_char_p, P(C.c_int), P(C.c_int), P(Aln)]
+    lib.ora_trim.restype = None
     lib.ora_find_consensus.argtypes = [P(Counts), C.c_int]
     lib.ora_find_consensus.restype = C.c_char
     lib.ora_myers_diff.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p]

@@ -193,3 +193,30 @@ def test_emul_quad_kernel(emul, oracle):
             r, f = script_to_strings(s1, reads[g], cols[g * 256:(g + 1) * 256], res.abr, res.aer)
             assert r == rg.value.decode() and f == fg.value.decode(), (it, g)
     assert 0 < n_band_escapes < 40
+
+
+def test_trim_lastcol_mode(emul, oracle):
+    """the LASTCOL end condition of the window aligner (trim_frag) on the reference's own trim vectors and on
+    random pairs against the oracle; reads whose path holds a gap of 63 or more report ST_ESCAPE (the GPU then
+    re-runs them in the exact scalar kernel)"""
+    import mia_amd
+    from test_oracle_vs_golden import trim_vectors
+    flat = mia_amd.flat_pssm().reshape(-1).astype(np.int32)
+    out = (C.c_int32 * 6)()
+    n_ok = n_esc = 0
+    for ad, read, exp in trim_vectors():
+        cr, ca = codes(read), codes(ad)
+        assert emul.emu_trim(cr.ctypes.data_as(C.c_void_p), len(read), ca.ctypes.data_as(C.c_void_p), len(ad),
+                             flat.ctypes.data_as(C.c_void_p), 600, out) == 0
+        score, aec, aer, abc, abr, st = list(out)
+        tr, tp, a = C.c_int(), C.c_int(), oc.Aln()
+        oracle.ora_trim(read.encode(), len(read), ad.encode(), C.byref(tr), C.byref(tp), C.byref(a))
+        assert (score, aec, aer) == (a.best, a.aec, a.aer), (ad, read)
+        if st & 1:            # ST_ESCAPE
+            n_esc += 1
+            continue
+        assert st == 0 and (abc, abr) == (a.abc, a.abr), (ad, read, list(out), exp)
+        trimmed = int(score >= 1000 or score >= (aer - abr + 1) * 200)
+        assert [trimmed, abc - 1 if trimmed else -999] == exp[:2]
+        n_ok += 1
+    assert n_ok > 450

@@ -122,3 +122,25 @@ def test_whole_run_maln(name, oracle_build, tmp_path):
         it += 1
     assert it > 1
     assert not os.path.exists(f"{root}.{it}")
+
+
+def trim_vectors():
+    lines = open(os.path.join(GOLDEN, "trim_vectors.txt")).read().splitlines()
+    out = []
+    for k in range(0, len(lines), 2):
+        ad, read = lines[k].split()
+        f = lines[k + 1].split()
+        assert f[0] == "T"
+        out.append((ad, read, [int(x) for x in f[1:]]))   # trimmed trim_point aec aer abc abr
+    return out
+
+
+def test_trim_vectors(oracle):
+    """ora_trim against trim_frag of the real reference (oracle/ref_dp_driver.c, `T` lines)"""
+    vecs = trim_vectors()
+    assert len(vecs) >= 400 and sum(v[2][0] for v in vecs) > 100 and sum(1 - v[2][0] for v in vecs) > 30
+    for ad, read, exp in vecs:
+        tr, tp, a = C.c_int(), C.c_int(), oc.Aln()
+        oracle.ora_trim(read.encode(), len(read), ad.encode(), C.byref(tr), C.byref(tp), C.byref(a))
+        got = [tr.value, tp.value if tr.value else -999, a.aec, a.aer, a.abc, a.abr]
+        assert got == exp, (ad, read, got, exp)

@@ -223,6 +223,68 @@ def maln_cases(mt311_path):
     shutil.rmtree(tmp)
 
 
+NEAND_ADAPT = "GTCAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG"     # src/mia_main.c:462-463 (data, quoted for the inputs)
+STAND_ADAPT = "CTGAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG"
+
+
+def trim_inputs(n=500, seed=77):
+    """(adapter, read) pairs: no adapter, whole / partial / mutated / gapped adapter at the 3' end, adapter in the
+    middle followed by junk, one-base matches at the very end, reads with N, user-defined adapters."""
+    rnd = random.Random(seed)
+
+    def rseq(k, alphabet="ACGT"):
+        return "".join(rnd.choice(alphabet) for _ in range(k))
+
+    def mut(s, p):
+        out = []
+        for ch in s:
+            u = rnd.random()
+            if u < p / 3:
+                continue
+            if u < 2 * p / 3:
+                out.append(rnd.choice("ACGT"))
+            out.append(rnd.choice("ACGT") if u < p else ch)
+        return "".join(out)
+
+    pairs = []
+    for i in range(n):
+        ad = [NEAND_ADAPT, STAND_ADAPT, rseq(rnd.randint(2, 127)), rseq(rnd.randint(8, 30))][i % 4]
+        kind = i % 10
+        body = rseq(rnd.randint(1, 200), "ACGTN" if kind == 9 else "ACGT")
+        if kind == 0:
+            read = body
+        elif kind in (1, 2):
+            read = body + ad[: rnd.randint(1, len(ad))]
+        elif kind == 3:
+            read = body + (mut(ad, 0.1) or "A")[: rnd.randint(min(3, len(ad)), len(ad))]
+        elif kind == 4:                                    # adapter, then unrelated sequence
+            read = body + ad[: rnd.randint(min(5, len(ad)), len(ad))] + rseq(rnd.randint(1, 90))
+        elif kind == 5:                                    # adapter prefix early, long junk, adapter continues
+            k = rnd.randint(min(4, len(ad)), max(min(4, len(ad)), len(ad) // 2))
+            read = body[:40] + ad[:k] + rseq(rnd.randint(20, 120)) + ad[k:]
+        elif kind == 6:                                    # starts inside the adapter
+            read = body + ad[rnd.randint(1, max(1, len(ad) - 2)):]
+        elif kind == 7:                                    # the read IS adapter
+            read = ad[: rnd.randint(1, len(ad))]
+        elif kind == 8:                                    # single-base coincidences at the end
+            read = body + ad[0]
+        else:
+            read = body + mut(ad, 0.05)
+        pairs.append((ad, read[:256] or "A"))
+    return pairs
+
+
+def trim_vectors():
+    pairs = trim_inputs()
+    out = subprocess.run([os.path.join(RB, "ref_dp_driver")], input="".join(f"T {a} {r}\n" for a, r in pairs).encode(), check=True,
+                         stdout=subprocess.PIPE).stdout.decode().splitlines()
+    assert len(out) == len(pairs)
+    with open(os.path.join(G, "trim_vectors.txt"), "w") as f:
+        for (a, r), o in zip(pairs, out):
+            f.write(f"{a} {r}\n{o}\n")
+    print("trim vectors:", len(pairs), "trimmed:", sum(1 for o in out if o.split()[1] == "1"))
+
+
 MA_HEADER = "/* map_alignment [V1.0] */ golden\n"   # line 1 of a .maln carries a timestamp and is not stored
 MA_RUNS = [(5, 1), (5, 2), (41, 1), (41, 2), (4, 1)]
 
@@ -265,6 +327,10 @@ def ma_cases():
 
 def main():
     os.makedirs(G, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "trim":        # only the trim_frag vectors
+        sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
+        trim_vectors()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "ma":          # only the ma reports (the .maln files stay as they are)
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
         ma_cases()
@@ -280,6 +346,7 @@ def main():
     myers_vectors(mt)
     maln_cases(os.path.join(G, "mt311.fa"))
     ma_cases()
+    trim_vectors()
 
 
 if __name__ == "__main__":
