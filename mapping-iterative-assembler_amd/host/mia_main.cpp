@@ -122,7 +122,7 @@ bool read_fasta_ref(const char* fn, Ref* r) {   // src/io.c:287-386
   return true;
 }
 
-struct Read { std::string id, desc, seq; };
+struct Read { std::string id, desc, seq; int trimmed = 0; };
 
 // read_fasta / read_fastq, src/io.c:35-281 (including the doubled first description character
 // of read_fasta, src/io.c:228-234, and the 256-base truncation)
@@ -178,6 +178,7 @@ bool next_record(FILE* f, bool fastq, Read* r) {
 struct Frag {
   std::string id, desc, seq;   // seq already reverse-complemented when rc && strand_known (src/fsdb.c:209-227)
   int rc, strand_known, as, ae, score;
+  int trimmed = 0;             // adapter found by trim_frag: seq is already cut at the trim point (src/fsdb.c:199-203)
 };
 
 // AlnSeq as it is printed (src/types.h:61-76)
@@ -185,6 +186,7 @@ struct Record {
   std::string id, desc, seq, smp;
   std::vector<std::pair<int, std::string>> ins;
   int start, end, score, rc, dropped;
+  int trimmed = 0;
   char segment;
 };
 
@@ -223,6 +225,10 @@ int main(int argc, char** argv) {
   std::string maln_root = "assembly.maln.iter", ref_fn, frag_fn;
   int hard_cut = 0, circular = 0, iterate = 1, final_only = 0, score_cut_set = 0, kmer = -1, soft_mask = 0, cc = 1, any = 0, gpu = 0;
   double slope = 200.0, intercept = 0.0;
+  int do_adapter_trimming = 0;
+  // src/mia_main.c:462-466: the two built-in adapters, Neandertal by default
+  const std::string neand_adapt = "GTCAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG", stand_adapt = "CTGAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG";
+  std::string adapter = neand_adapt;
   Pssm anc, rcanc;
   flat_pssm(&anc);
   int ich;
@@ -247,7 +253,13 @@ int main(int argc, char** argv) {
       case 'N': intercept = atof(optarg); score_cut_set = 1; break;
       case 'F': final_only = 1; break;
       case 'g': gpu = atoi(optarg); break;
-      case 'T': case 'a': case 'u': case 'U': case 'A': case 'C': case 'h': case 'D': case 'I': case 'q':
+      case 'T': do_adapter_trimming = 1; break;
+      case 'a':                                        // src/mia_main.c:558-578
+        if (strlen(optarg) > 127) { fprintf(stderr, "That adapter is too big!\nMIA will use the standard adapter.\n"); adapter = stand_adapt; }
+        else if (strlen(optarg) > 1) adapter = optarg;
+        else adapter = (optarg[0] == 'n' || optarg[0] == 'N') ? neand_adapt : stand_adapt;
+        break;
+      case 'u': case 'U': case 'A': case 'C': case 'h': case 'D': case 'I': case 'q':
         fprintf(stderr, "option -%c is outside the MI355X-accelerated path (see DESIGN.md, section 7) and is not supported by mia_hip\n", ich);
         exit(2);
       default: help(); exit(0);
@@ -295,6 +307,29 @@ int main(int argc, char** argv) {
   lap("read input");
   fprintf(stderr, "Starting to align sequences to the reference...\n");
 
+  // ---- adapter trimming (trim_frag, src/mia_main.c:771-775): the read ends at the trim point from here on
+  if (do_adapter_trimming && !reads.empty()) {
+    std::vector<int64_t> toff;
+    std::string tb;
+    std::vector<size_t> tsrc;
+    toff.push_back(0);
+    for (size_t i = 0; i < reads.size(); i++)
+      if (!reads[i].seq.empty()) { tb += reads[i].seq; toff.push_back((int64_t)tb.size()); tsrc.push_back(i); }
+    std::vector<uint8_t> tr(tsrc.size());
+    std::vector<int32_t> tp(tsrc.size());
+    if (!tsrc.empty() && mia_hip_trim(g, adapter.c_str(), (int64_t)tsrc.size(), tb.data(), toff.data(), tr.data(), tp.data()) != MIA_HIP_OK) die(g, "trim");
+    int emptied = 0;
+    for (size_t k = 0; k < tsrc.size(); k++) {
+      if (!tr[k]) continue;
+      Read& r = reads[tsrc[k]];
+      r.trimmed = 1;
+      if (tp[k] + 1 <= 0) { r.seq.clear(); emptied++; }    // nothing but adapter: the reference's len2 = 0 case is undefined, the read is left out
+      else r.seq.resize((size_t)tp[k] + 1);
+    }
+    if (emptied) fprintf(stderr, "mia_hip: %d read(s) consist of adapter only and are left out\n", emptied);
+    lap("adapter trimming");
+  }
+
   // ---- pass 1 on the GPU (new_kmer_filter + sg_align)
   std::vector<int64_t> off;
   std::string bases;
@@ -319,7 +354,7 @@ int main(int argc, char** argv) {
     if (!(p_fl[k] & MIA_HIP_P1_KEPT)) continue;
     Read& r = reads[src[(size_t)k]];      // each input read is looked at once: move its strings into the store
     Frag f;
-    f.id = std::move(r.id); f.desc = std::move(r.desc); f.seq = std::move(r.seq);
+    f.id = std::move(r.id); f.desc = std::move(r.desc); f.seq = std::move(r.seq); f.trimmed = r.trimmed;
     f.rc = p_rc[k]; f.strand_known = (p_fl[k] & MIA_HIP_P1_STRAND_KNOWN) ? 1 : 0;
     f.as = p_as[k]; f.ae = p_ae[k]; f.score = p_score[k];
     if (f.rc && f.strand_known) {
@@ -429,7 +464,7 @@ int main(int argc, char** argv) {
       if (end > L) end -= L;                      // src/mia_main.c:259-263
       auto build = [&](const std::string& r, const std::string& q, int st, int en, char seg, int dropped, const std::string& id) {
         Record a;   // merge_pwaln_into_maln, src/map_align.c:866-954
-        a.id = id; a.desc = f.desc; a.start = st; a.end = en; a.score = score[i]; a.rc = f.rc; a.dropped = dropped; a.segment = seg;
+        a.id = id; a.desc = f.desc; a.start = st; a.end = en; a.score = score[i]; a.rc = f.rc; a.dropped = dropped; a.segment = seg; a.trimmed = f.trimmed;
         std::string cur; bool in = false;
         for (size_t k = 0; k < r.size(); k++) {
           if (r[k] == '-') { cur.push_back(q[k]); in = true; }
@@ -513,7 +548,7 @@ int main(int argc, char** argv) {
           const Record& a = recs[(size_t)order[q]];
           o += "ID "; o += a.id; o += "\nDESC "; o += a.desc; o += "\nSCORE "; num(a.score);
           o += "\nNUM_INPUTS 1\nSTART "; num(a.start); o += "\nEND "; num(a.end);
-          o += a.rc ? "\nRC 1\nTR 0\nDR " : "\nRC 0\nTR 0\nDR "; o += a.dropped ? '1' : '0';
+          o += a.rc ? "\nRC 1\nTR " : "\nRC 0\nTR "; o += a.trimmed ? '1' : '0'; o += "\nDR "; o += a.dropped ? '1' : '0';
           o += "\nSEG "; o += a.segment; o += "\nSEQ "; o += a.seq; o += "\nSMP "; o += a.smp; o += "\nINS_POS";
           for (auto& in : a.ins) { o += ' '; num(in.first); o += ' '; o += in.second; }
           o += '\n';

@@ -116,6 +116,8 @@ typedef struct {
   int kmer_len;        /* -k, -1 = off */
   int soft_mask;       /* -M */
   int final_only;      /* -F */
+  int do_trim;         /* -T: trim_frag every read before the k-mer filter (src/mia_main.c:771-775) */
+  char adapter[128];   /* -a (src/mia_main.c:558-578); default = the Neandertal adapter (:462,466) */
 } ora_opts;
 
 void ora_opts_default(ora_opts *o);

@@ -51,6 +51,7 @@ void ora_opts_default(ora_opts *o) {
   o->slope = 200.0;   /* DEF_S */
   o->intercept = 0.0; /* DEF_N */
   o->kmer_len = -1;
+  strcpy(o->adapter, "GTCAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG");   /* neand_adapt, src/mia_main.c:462,466 */
 }
 
 ora_state *ora_new(const ora_opts *o, const ora_pssm *anc) {
@@ -383,10 +384,20 @@ void ora_pass1_read(ora_state *st, const char *id, const char *desc, const char 
   char rg_f[ORA_MAX_ALN + 1], fg_f[ORA_MAX_ALN + 1], rg_r[ORA_MAX_ALN + 1], fg_r[ORA_MAX_ALN + 1];
   ora_aln fw, rc, *best;
   pwaln front, back;
-  int n = 0, is_rc, as, ae, score, L = st->seq_len, front_slot, back_slot = -1;
+  int n = 0, is_rc, as, ae, score, L = st->seq_len, front_slot, back_slot = -1, trimmed = 0, trim_point = 0;
   ora_frag *fs;
   while (seq_in[n] && n < ORA_MAX_READ) { seq[n] = (char)toupper((unsigned char)seq_in[n]); n++; }
   seq[n] = 0;
+  if (st->opt.do_trim && n > 0) {
+    /* trim_frag (src/mia.c:1318-1368); from here on the read ends at the trim point: the k-mer filter and sg_align
+     * use trim_point + 1 bases (src/kmer.c:262-263, src/mia.c:1514-1516), add_virgin_fs2fsdb cuts the string (src/fsdb.c:199-203) */
+    ora_trim(seq, n, st->opt.adapter, &trimmed, &trim_point, NULL);
+    if (trimmed) {
+      if (trim_point + 1 <= 0) return;   /* adapter only: len2 = 0 is undefined in the reference (see the n == 0 note below) */
+      n = trim_point + 1;
+      seq[n] = 0;
+    }
+  }
   if (!kmer_filter(st, seq, n)) return;
   if (n == 0) {
     /* dyn_prog on an empty read leaves both scores INT_MIN; sg_align then reads
@@ -404,7 +415,7 @@ void ora_pass1_read(ora_state *st, const char *id, const char *desc, const char 
   strcpy(front.ref_seq, is_rc ? rg_r : rg_f);
   strcpy(front.frag_seq, is_rc ? fg_r : fg_f);
   front.start = best->abc; front.end = best->aec;
-  front.trimmed = 0; front.segment = 'a'; front.score = best->best;
+  front.trimmed = trimmed; front.segment = 'a'; front.score = best->best;
   front.num_inputs = 0; /* PWAlnFrag.num_inputs is never set in pass 1; malloc'd memory (0 in practice) */
   score = best->best;
   if (is_rc) {
@@ -433,6 +444,7 @@ void ora_pass1_read(ora_state *st, const char *id, const char *desc, const char 
   strncpy(fs->desc, desc, ORA_MAX_DESC);
   strcpy(fs->seq, seq);
   fs->seq_len = n;
+  fs->trimmed = trimmed; fs->trim_point = trim_point;
   fs->rc = is_rc; fs->as = as; fs->ae = ae; fs->score = score;
   fs->front = front_slot; fs->back = back_slot;
   fs->unique_best = 1; fs->num_inputs = 1;

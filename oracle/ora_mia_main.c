@@ -16,7 +16,7 @@ int main(int argc, char **argv) {
   int ch, iters;
   ora_opts_default(&o);
   ora_pssm_flat(&anc);
-  while ((ch = getopt(argc, argv, "s:r:f:m:p:H:S:N:k:FcinM")) != -1) {
+  while ((ch = getopt(argc, argv, "s:r:f:m:p:H:S:N:k:a:FcinMT")) != -1) {
     switch (ch) {
       case 'c': o.circular = 1; break;
       case 'n': o.iterate = 0; break;
@@ -32,6 +32,12 @@ int main(int argc, char **argv) {
       case 'S': o.slope = atof(optarg); o.score_cut_set = 1; break;
       case 'N': o.intercept = atof(optarg); o.score_cut_set = 1; break;
       case 'F': o.final_only = 1; break;
+      case 'T': o.do_trim = 1; break;
+      case 'a':   /* src/mia_main.c:558-578 */
+        if (strlen(optarg) > 127) strcpy(o.adapter, "CTGAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG");
+        else if (strlen(optarg) > 1) strcpy(o.adapter, optarg);
+        else if (!(optarg[0] == 'n' || optarg[0] == 'N')) strcpy(o.adapter, "CTGAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG");
+        break;
       default: return 2;
     }
   }

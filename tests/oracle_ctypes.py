@@ -18,7 +18,8 @@ class Counts(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("circular", C.c_int), ("iterate", C.c_int), ("cons_code", C.c_int), ("hard_cut", C.c_int),
                 ("score_cut_set", C.c_int), ("slope", C.c_double), ("intercept", C.c_double),
-                ("kmer_len", C.c_int), ("soft_mask", C.c_int), ("final_only", C.c_int)]
+                ("kmer_len", C.c_int), ("soft_mask", C.c_int), ("final_only", C.c_int), ("do_trim", C.c_int),
+                ("adapter", C.c_char * 128)]
 
 
 class AlnSeq(C.Structure):

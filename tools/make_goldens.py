@@ -192,8 +192,21 @@ def maln_cases(mt311_path):
     # keep only reads near the planted events and the origin so the set stays small
     keep = [i for i in range(1200) if (4800 <= d["start"][i] <= 5100) or (8800 <= d["start"][i] <= 9100) or d["start"][i] > 16480 or d["start"][i] < 60]
     gen_data.write_fasta_reads(os.path.join(G, "indel.fa"), d["reads"][keep])
+    # reads that run into the sequencing adapter (-T): 40-90 genome bases, then none / part / all of the adapter
+    rnd = random.Random(515)
+    d = gen_data.make_reads(indiv, 140, 100, 4, circular=True, damage=False)
+    with open(os.path.join(G, "adapt.fa"), "w") as f:
+        for i in range(140):
+            body = d["reads"][i].tobytes().decode()[: rnd.randint(40, 90)]
+            ad = [NEAND_ADAPT, STAND_ADAPT][i % 2]
+            tail = ["", ad[: rnd.randint(1, 12)], ad[: rnd.randint(13, len(ad))], ad][i % 4]
+            f.write(f">a{i}\n{body + tail}\n")
     A = "ancient.submat.txt"
     cases = {
+        "adapt_T_k12": ["-r", "mt311.fa", "-f", "adapt.fa", "-c", "-k", "12", "-T"],
+        "adapt_T_aS_k12": ["-r", "mt311.fa", "-f", "adapt.fa", "-c", "-k", "12", "-T", "-a", "S"],
+        "adapt_T_user_k12": ["-r", "mt311.fa", "-f", "adapt.fa", "-c", "-k", "12", "-T", "-a", "GTCAGACACGCAACAGG"],
+        "fix_c_T": ["-r", "tr1.fna", "-f", "tf.fna", "-c", "-T"],
         "fix_c": ["-r", "tr1.fna", "-f", "tf.fna", "-c"],
         "fix_c_n": ["-r", "tr1.fna", "-f", "tf.fna", "-c", "-n"],
         "fix_lin": ["-r", "tr1.fna", "-f", "tf.fna"],
@@ -207,6 +220,7 @@ def maln_cases(mt311_path):
         "indel_anc_k12": ["-r", "mt311.fa", "-f", "indel.fa", "-c", "-k", "12", "-s", A],
         "indel_anc_k12_SN": ["-r", "mt311.fa", "-f", "indel.fa", "-c", "-k", "12", "-s", A, "-S", "150", "-N", "100"],
     }
+    hashes = {}
     for name, args in cases.items():
         root = os.path.join(tmp, name)
         sh([os.path.join(RB, "mia")] + args + ["-m", root], cwd=G, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -214,12 +228,18 @@ def maln_cases(mt311_path):
         while os.path.exists(f"{root}.{it}"):
             with open(f"{root}.{it}") as f:
                 body = f.readlines()[1:]
-            with open(os.path.join(out_dir, f"{name}.{it}"), "w") as f:
-                f.writelines(body)
+            if it <= 4:
+                with open(os.path.join(out_dir, f"{name}.{it}"), "w") as f:
+                    f.writelines(body)
+            else:       # long runs (a case that oscillates until MAX_ITER): later iterations are pinned by hash
+                import hashlib
+                hashes[f"{name}.{it}"] = hashlib.sha256("".join(body).encode()).hexdigest()
             it += 1
         print(f"{name}: {it - 1} iteration file(s)")
     with open(os.path.join(out_dir, "cases.json"), "w") as f:
         json.dump(cases, f, indent=1)
+    with open(os.path.join(out_dir, "hashes.json"), "w") as f:
+        json.dump(hashes, f, indent=1, sort_keys=True)
     shutil.rmtree(tmp)
 
 
