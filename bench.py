@@ -129,6 +129,8 @@ def main():
     hip = mia_amd.MiaHip(local)
     hip.set_pssm(mia_amd.flat_pssm())
     hip.upload_reads(stored.reshape(-1), offsets, rc, np.ones(n, np.uint8), as_, ae)
+    if world > 1:
+        hip.set_read_base(rank * n)          # contiguous fsdb blocks: global index of this rank's first read
 
     phase = {}
 
@@ -158,6 +160,8 @@ def main():
         if slope <= 0:
             slope = 100.0
         hip.cull(0, slope, intercept, slot_base)
+        if sharded:
+            mdist.exchange_links(hip, lambda ptr, n, ts: torch.as_tensor(DevArray(ptr, n, ts), device="cuda"))
         t0 = tick("cull", t0)
         hip.tally()
         t0 = tick("tally", t0)

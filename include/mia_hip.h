@@ -113,6 +113,28 @@ int mia_hip_get_dropped(mia_hip_ctx *ctx, uint8_t *front_dropped, uint8_t *back_
  * flags[s - slot_base]. */
 int mia_hip_set_slot_dropped(mia_hip_ctx *ctx, const uint8_t *flags, int64_t n_flags);
 
+/* fs->back_asp is set when a read is split at the origin and never cleared (src/mia_main.c:259-276): a read that
+ * is no longer split keeps pointing at its old AlnSeq slot, and cull_maln_from_fsdb / pop_smp_from_FSDB /
+ * consensus_assembly_string see the record that now sits there a second time through it.  mia_hip_cull reproduces
+ * this (duplicate listing, dropped mark by the reader's score, depth codes overwritten by later readers).
+ * back_slot[n]: slot index of each read's back record after pass 1, -1 if it was not split (global slot numbers,
+ * as fs->back_asp would address them). */
+int mia_hip_set_back_slots(mia_hip_ctx *ctx, const int64_t *back_slot);
+/* After mia_hip_cull: per read  params[i*8 + {0..3}] = front record {dffBase, actOffset, total, multiplicity},
+ * params[i*8 + {4..7}] = back record: the depth code of a column reached after `a` bases of that record is
+ * depth(dffBase + actOffset + a, total - (actOffset + a) - 1) (src/fsdb.c:568-581,597-610); multiplicity = how often
+ * cull_maln_from_fsdb lists the record.  back_slot[i] = fs->back_asp as a slot index (-1 = NULL). */
+int mia_hip_get_record_params(mia_hip_ctx *ctx, int32_t *params, int64_t *back_slot);
+/* Sharded runs (one context per GPU): global index of this context's first read, and the exchange of the links
+ * between mia_hip_cull and mia_hip_tally:  all-gather the buffers of mia_hip_links (4 int64 per link), hand the
+ * concatenation to mia_hip_set_links on every rank, all-reduce(max) the buffer of mia_hip_link_lengths, then
+ * mia_hip_finish_links.  Not needed on a single GPU. */
+int mia_hip_set_read_base(mia_hip_ctx *ctx, int64_t read_base);
+int mia_hip_links(mia_hip_ctx *ctx, int64_t **d_links, int64_t *n_links);
+int mia_hip_set_links(mia_hip_ctx *ctx, const int64_t *d_links_all, int64_t n_all);
+int mia_hip_link_lengths(mia_hip_ctx *ctx, int32_t **d_len, int64_t *n);
+int mia_hip_finish_links(mia_hip_ctx *ctx);
+
 /* find_fsdb_score_cut (src/fsdb.c:269-383) -- HOST helper, no device work: the
  * reference's least-squares line through (seq_len, score) of all unique_best
  * reads with score >= FIRST_ROUND_SCORE_CUTOFF, evaluated in IEEE double in fsdb

@@ -57,6 +57,13 @@ def _load():
     lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
     lib.mia_hip_ma_tally.argtypes = [vp, C.c_int32, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.mia_hip_trim.argtypes = [vp, C.c_char_p, C.c_int64, vp, vp, vp, vp]
+    lib.mia_hip_set_back_slots.argtypes = [vp, vp]
+    lib.mia_hip_get_record_params.argtypes = [vp, vp, vp]
+    lib.mia_hip_set_read_base.argtypes = [vp, C.c_int64]
+    lib.mia_hip_links.argtypes = [vp, P(vp), P(C.c_int64)]
+    lib.mia_hip_set_links.argtypes = [vp, vp, C.c_int64]
+    lib.mia_hip_link_lengths.argtypes = [vp, P(vp), P(C.c_int64)]
+    lib.mia_hip_finish_links.argtypes = [vp]
     lib.mia_hip_trim_stats.argtypes = [vp, P(C.c_int64)]
     lib.mia_hip_get_ins_tally.argtypes = [vp, vp, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
@@ -79,7 +86,9 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats"]
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots",
+            "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
+            "mia_hip_finish_links"]
 
 
 def _ptr(a):
@@ -310,6 +319,37 @@ class MiaHip:
         point = np.zeros(n, np.int32)
         self._chk(self._l.mia_hip_trim(self._h, adapter, n, _ptr(bases), _ptr(offsets), _ptr(trimmed), _ptr(point)))
         return trimmed, point
+
+    def set_back_slots(self, back_slot):
+        b = np.ascontiguousarray(back_slot, dtype=np.int64)
+        assert len(b) == self.n
+        self._chk(self._l.mia_hip_set_back_slots(self._h, _ptr(b)))
+
+    def record_params(self):
+        """(params[n][8], back_slot[n]) after cull(): see mia_hip_get_record_params."""
+        p = np.empty((self.n, 8), dtype=np.int32)
+        b = np.empty(self.n, dtype=np.int64)
+        self._chk(self._l.mia_hip_get_record_params(self._h, _ptr(p), _ptr(b)))
+        return p, b
+
+    def set_read_base(self, base):
+        self._chk(self._l.mia_hip_set_read_base(self._h, int(base)))
+
+    def links(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._l.mia_hip_links(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_links(self, dptr, n):
+        self._chk(self._l.mia_hip_set_links(self._h, C.c_void_p(dptr), int(n)))
+
+    def link_lengths(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._l.mia_hip_link_lengths(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def finish_links(self):
+        self._chk(self._l.mia_hip_finish_links(self._h))
 
     def trim_exact_reruns(self):
         n = C.c_int64()

@@ -88,18 +88,151 @@ __global__ void k_scan_apply(ReadSet rs, int32_t L, const int64_t* partial, int6
 }
 
 // ---- cull_maln_from_fsdb (src/mia.c:451-481): `dropped` is sticky per AlnSeq slot -----
-__global__ void k_cull(ReadSet rs, int32_t L, const int64_t* slot, uint8_t* slot_dropped, int64_t n_slots,
-                       int32_t hard_cut, double slope, double intercept, uint8_t* drop_front, uint8_t* drop_back) {
+//
+// The reference addresses AlnSeq records through fs->front_asp / fs->back_asp.  reiterate_assembly sets back_asp only
+// when the read is split at the origin and NEVER clears it (src/mia_main.c:259-276): a read that was split in an
+// earlier iteration and is not any more keeps pointing at its old slot, which by now holds the record of whichever
+// read was merged into that position this time.  Everything that walks the fsdb then sees that record through the
+// stale pointer as well (a "link" below):
+//   * cull_maln_from_fsdb lists it a second time (it is counted twice by every consensus loop and printed twice) and
+//     marks it dropped when the READER's score is low (src/mia.c:469-480);
+//   * pop_smp_from_FSDB treats it as the reader's back segment: the reader's own depth codes are computed with its
+//     length added, and its depth codes are overwritten with the reader's geometry -- the overwrite survives iff the
+//     reader comes later in the fsdb than the record's owner (src/fsdb.c:542-619 runs in fsdb order).
+// All of this is reproduced: per read a persistent back slot, per iteration the list of links, per slot the last
+// writer of its depth codes and the number of times it is listed.
+struct RecInfo {              // per read, rebuilt every iteration by k_rec_geom
+  int32_t* flen;              // asp_len of the front record (columns + inserted bases, src/fsdb.c:518-530)
+  int32_t* blen;              // same for the read's own back record (0 if not split)
+  int32_t* actf;              // read bases in the front record
+  int32_t* params;            // [n][8]: front {dffBase, actOff, B, mult}, back {dffBase, actOff, B, mult}
+};
+struct SlotInfo {             // per local AlnSeq slot (global slot - slot_base)
+  int64_t base;               // first global slot of this context
+  int64_t n_local;            // slots owned by this context in this iteration
+  int32_t* reclen;            // asp_len of the record in the slot
+  unsigned long long* writer; // (global read index << 20 | link index) of the last pop_smp writer; owner: link index 0xFFFFF
+  int32_t* mult;              // times the slot is listed in the culled maln
+};
+constexpr unsigned long long LINK_NONE = 0xFFFFFull;
+struct Links {                // [cap][4] int64: reader (global read index), slot (global), flen << 32 | actf, low score flag
+  int64_t* rec;
+  int32_t* n;
+  int32_t cap;
+};
+
+// inserted bases per record and bases in the front: one read per wavefront (the script walk of the tally's pass A)
+__global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const int64_t* slot, RecInfo ri, SlotInfo si, int64_t read_base,
+                                                    uint32_t* flags) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rs.n) return;
+  if (!rs.sk[i]) { if (lane == 0) { ri.flen[i] = 0; ri.blen[i] = 0; ri.actf[i] = 0; } return; }
+  const int len2 = rs.len[i], abr = rs.abr[i];
+  const RecGeom g = rec_geom(rs.as[i], rs.ae[i], L);
+  const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
+  const int cbase = rs.refstart[i] - g.start_w;
+  int nf = 0, nb = 0, af = 0;
+  for (int r0 = abr; r0 < len2; r0 += 64) {
+    const int r = r0 + lane;
+    bool isF = false, isB = false, alF = false;
+    if (r < len2) {
+      if (cols[r] == COL_INSERT) {
+        int rn = r + 1;
+        while (rn < len2 && cols[rn] < 0) rn++;
+        const int o = cbase + cols[rn];
+        if (o < g.ncols_f) isF = true; else if (g.split && o - g.ncols_f < g.ncols_b) isB = true;
+      } else if (cols[r] >= 0) {
+        alF = (cbase + cols[r]) < g.ncols_f;
+      }
+    }
+    nf += __popcll(__ballot(isF));
+    nb += __popcll(__ballot(isB));
+    af += __popcll(__ballot(alF));
+  }
+  if (lane == 0) {
+    const int flen = g.ncols_f + nf, blen = g.split ? g.ncols_b + nb : 0;
+    ri.flen[i] = flen; ri.blen[i] = blen; ri.actf[i] = af + nf;
+    const int64_t ls = slot[i] - si.base;
+    if (ls >= 0 && ls + (g.split ? 1 : 0) < si.n_local) {
+      si.reclen[ls] = flen; si.mult[ls] = 1; si.writer[ls] = ((unsigned long long)(read_base + i) << 20) | LINK_NONE;
+      if (g.split) { si.reclen[ls + 1] = blen; si.mult[ls + 1] = 1; si.writer[ls + 1] = ((unsigned long long)(read_base + i) << 20) | LINK_NONE; }
+    } else atomicOr(flags, 4u);
+  }
+}
+
+// own dropped marks, the persistent back slot, and the links of formerly split reads
+__global__ void k_cull_mark(ReadSet rs, int32_t L, const int64_t* slot, uint8_t* slot_dropped, int64_t n_slots, int32_t hard_cut, double slope,
+                            double intercept, int64_t* back_slot, RecInfo ri, Links lk, int64_t read_base, uint32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rs.n || !rs.sk[i]) return;
+  const bool split = rec_geom(rs.as[i], rs.ae[i], L).split;
+  const double min_score = hard_cut > 0 ? (double)hard_cut : (double)(intercept + (slope * (double)rs.len[i]));
+  const int64_t s = slot[i];
+  const bool low = (double)rs.score[i] < min_score;
+  if (low && s < n_slots) slot_dropped[s] = 1;
+  if (split) {
+    if (low && s + 1 < n_slots) slot_dropped[s + 1] = 1;
+    back_slot[i] = s + 1;                                      // fs->back_asp (src/mia_main.c:266-267)
+  } else if (back_slot[i] >= 0) {                              // stale back_asp
+    const int e = atomicAdd(lk.n, 1);
+    if (e < lk.cap) {
+      int64_t* r = lk.rec + (int64_t)e * 4;
+      r[0] = read_base + i; r[1] = back_slot[i];
+      r[2] = ((int64_t)ri.flen[i] << 32) | (uint32_t)ri.actf[i];
+      r[3] = low ? 1 : 0;
+    } else atomicOr(flags, 8u);
+  }
+}
+
+// every link (of this context or gathered from the others): effects on the slot it points at, if that slot is ours
+__global__ void k_links_apply(const int64_t* links, int32_t n_links, SlotInfo si, uint8_t* slot_dropped, int64_t n_slots, int32_t* link_len,
+                              uint32_t* flags) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_links) return;
+  const int64_t* r = links + (int64_t)e * 4;
+  const int64_t ls = r[1] - si.base;
+  if (ls < 0 || ls >= si.n_local) return;                      // another context's slot (or none: see k_links_check)
+  atomicMax(&si.writer[ls], ((unsigned long long)r[0] << 20) | (unsigned long long)e);
+  atomicAdd(&si.mult[ls], 1);
+  if (r[3] && r[1] < n_slots) slot_dropped[r[1]] = 1;
+  link_len[e] = si.reclen[ls];
+}
+
+// depth-code parameters and multiplicities of every read's records + its dropped bits, after all links are in
+__global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const uint8_t* slot_dropped, int64_t n_slots, const int64_t* back_slot,
+                             RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, int32_t n_links, int64_t read_base,
+                             uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rs.n) return;
   uint8_t df = 0, db = 0;
+  int32_t* p = ri.params + i * 8;
+  for (int k = 0; k < 8; k++) p[k] = 0;
   if (rs.sk[i]) {
     const bool split = rec_geom(rs.as[i], rs.ae[i], L).split;
-    const double min_score = hard_cut > 0 ? (double)hard_cut : (double)(intercept + (slope * (double)rs.len[i]));
-    const int64_t s = slot[i];
-    const bool low = (double)rs.score[i] < min_score;
-    if (s < n_slots) { if (low) slot_dropped[s] = 1; df = slot_dropped[s]; }
-    if (split && s + 1 < n_slots) { if (low) slot_dropped[s + 1] = 1; db = slot_dropped[s + 1]; }
+    const int64_t s = slot[i], ls = s - si.base;
+    if (s < n_slots) df = slot_dropped[s];
+    if (split && s + 1 < n_slots) db = slot_dropped[s + 1];
+    const int flen = ri.flen[i], blen = ri.blen[i], actf = ri.actf[i];
+    int back_len = blen;                                       // what pop_smp adds to the front as "the back segment"
+    if (!split && back_slot[i] >= 0) {
+      back_len = -1;
+      for (int e = 0; e < n_links; e++)                        // (a handful of links; only formerly split reads get here)
+        if (links[(int64_t)e * 4] == read_base + i) { back_len = link_len[e]; break; }
+      if (back_len < 0) { atomicOr(flags, 4u); back_len = 0; }
+    }
+    auto fill = [&](int32_t* q, int64_t lsl, int own_base, int own_off, int own_B, int own_len) {
+      const unsigned long long w = si.writer[lsl];
+      if ((w & LINK_NONE) == LINK_NONE) { q[0] = own_base; q[1] = own_off; q[2] = own_B; }
+      else {                                                   // overwritten by a later reader through its stale pointer
+        const int64_t* r = links + (int64_t)(w & LINK_NONE) * 4;
+        const int rf = (int)(r[2] >> 32), ra = (int)(uint32_t)r[2];
+        q[0] = rf; q[1] = ra; q[2] = rf + own_len;
+      }
+      q[3] = si.mult[lsl];
+    };
+    if (ls >= 0 && ls < si.n_local) fill(p, ls, 0, 0, flen + back_len, flen);
+    if (split && ls + 1 < si.n_local) fill(p + 4, ls + 1, flen, actf, flen + blen, blen);
   }
   drop_front[i] = df;
   drop_back[i] = db;
@@ -119,7 +252,7 @@ constexpr int TALLY_BUCKET = 256, TALLY_WIN = 768, TALLY_CHUNK = 1024;
 template <bool BINNED>
 __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSet& rs, const RefInfo& ref, const int32_t* pssm2,
                                                const uint8_t* drop_front, const uint8_t* drop_back, const TallyBuf& tb,
-                                               int32_t* lds, int win_base) {
+                                               int32_t* lds, int win_base, const int32_t* rec_params, const int32_t* rec_actf) {
   if (!rs.sk[i]) return;
   if (rs.status[i] & ST_TOO_LONG) { if (lane == 0) atomicOr(tb.flags, 2u); return; }
   const int L = ref.L, Lp = tb.Lp;
@@ -131,48 +264,43 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
   const int32_t* pm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);   // src/mia.c:584-589
   const bool dF = drop_front[i], dB = drop_back[i];
   if (g.split && g.start_w >= L) { if (lane == 0) atomicOr(tb.flags, 2u); return; }  // split_pwaln mis-places such a record
-  // pass A: inserted bases per record (asp_len, src/fsdb.c:518-530)
-  int nf = 0, nb = 0;
-  for (int r0 = abr; r0 < len2; r0 += 64) {
-    const int r = r0 + lane;
-    bool isF = false, isB = false;
-    if (r < len2 && cols[r] == COL_INSERT) {
-      int rn = r + 1;
-      while (rn < len2 && cols[rn] < 0) rn++;
-      const int o = cbase + cols[rn];
-      if (o < g.ncols_f) isF = true; else if (g.split && o - g.ncols_f < g.ncols_b) isB = true;
-    }
-    nf += __popcll(__ballot(isF));
-    nb += __popcll(__ballot(isB));
-  }
-  const int flen = g.ncols_f + nf, blen = g.split ? g.ncols_b + nb : 0;
-
+  // depth-code parameters and multiplicity of the two records (k_rec_params): normally {0, 0, flen+blen, 1} for the
+  // front and {flen, bases in the front, flen+blen, 1} for the back (src/fsdb.c:568-581,597-610)
+  const int32_t* prm = rec_params + i * 8;
+  const int fBase = prm[0], fOff = prm[1], fB = prm[2], fMult = prm[3], bBase = prm[4], bOff = prm[5], bB = prm[6], bMult = prm[7];
+  const int actF = rec_actf[i];                            // read bases in the front record
+  // code of a column reached after `act` read bases, front or back record
+  auto dcode = [&](bool back, int act) {
+    const int a = back ? bOff + (act - actF) : fOff + act;
+    return depth_code((back ? bBase : fBase) + a, (back ? bB : fB) - a - 1);
+  };
   auto emit = [&](int o, int act, int code /* 0..4, or 5 = '-' */) {
-    int p, gc, dff;
-    bool dropped;
-    if (o < g.ncols_f) { p = o; gc = g.start_w + o; dff = act; dropped = dF; }
-    else if (g.split && o - g.ncols_f < g.ncols_b) { p = o - g.ncols_f; gc = p; dff = flen + act; dropped = dB; }  // sic: src/fsdb.c:597
+    int p, gc, mult;
+    bool dropped, back;
+    if (o < g.ncols_f) { p = o; gc = g.start_w + o; back = false; dropped = dF; mult = fMult; }
+    else if (g.split && o - g.ncols_f < g.ncols_b) { p = o - g.ncols_f; gc = p; back = true; dropped = dB; mult = bMult; }  // dff = flen + act, sic: src/fsdb.c:597
     else return;
     if (gc < 0 || gc >= Lp) { atomicOr(tb.flags, 2u); return; }
-    const int d = depth_code(dff, flen + blen - act - 1);
+    const int d = dcode(back, act);
     if (d < 0 || d > 2 * PSSM_DEPTH) { atomicOr(tb.flags, 2u); return; }
     const int wc = gc - win_base;
     const bool in_lds = BINNED && wc >= 0 && wc < TALLY_WIN;
     int32_t* t = in_lds ? lds + wc : tb.tally + gc;
     const int ws = in_lds ? TALLY_WIN : Lp;                // word stride
+    // mult > 1: the record is listed again through the stale back_asp of formerly split reads (see k_cull_mark)
     if (!dropped) {                                        // src/mia.c:580-582
-      atomicAdd(&t[T_COV * ws], 1);
-      if (code == 5) atomicAdd(&t[T_GAP * ws], 1);
+      atomicAdd(&t[T_COV * ws], mult);
+      if (code == 5) atomicAdd(&t[T_GAP * ws], mult);
       else {
-        if (code < 4) atomicAdd(&t[(T_A + code) * ws], 1);
+        if (code < 4) atomicAdd(&t[(T_A + code) * ws], mult);
         const int32_t* row = pm + d * 25 + code;           // sm[d][X][code], X = A,C,G,T (src/map_align.c:258-261)
-        atomicAdd(&t[T_SA * ws], row[0]);
-        atomicAdd(&t[T_SC * ws], row[5]);
-        atomicAdd(&t[T_SG * ws], row[10]);
-        atomicAdd(&t[T_ST * ws], row[15]);
+        atomicAdd(&t[T_SA * ws], mult * row[0]);
+        atomicAdd(&t[T_SC * ws], mult * row[5]);
+        atomicAdd(&t[T_SG * ws], mult * row[10]);
+        atomicAdd(&t[T_ST * ws], mult * row[15]);
       }
     }
-    if (p > 0) atomicAdd(&t[T_SPAN * ws], 1);              // start < pos <= end (src/map_align.c:466-469), dropped or not
+    if (p > 0) atomicAdd(&t[T_SPAN * ws], mult);           // start < pos <= end (src/map_align.c:466-469), dropped or not
   };
 
   for (int r0 = abr; r0 < len2; r0 += 64) {
@@ -191,30 +319,32 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
       int rn = r + 1;                   // aligned row that follows the run
       while (rn < len2 && cols[rn] < 0) rn++;
       const int o = cbase + cols[rn], act = rn - abr, j = r - r1, glen = rn - r1;
-      int p, gc, dff;
-      bool ok = true;
-      if (o < g.ncols_f) { p = o; gc = g.start_w + o; dff = act; }
-      else if (g.split && o - g.ncols_f < g.ncols_b) { p = o - g.ncols_f; gc = p; dff = flen + act; }
+      int p, gc, mult;
+      bool ok = true, back = false;
+      if (o < g.ncols_f) { p = o; gc = g.start_w + o; mult = fMult; }
+      else if (g.split && o - g.ncols_f < g.ncols_b) { p = o - g.ncols_f; gc = p; back = true; mult = bMult; }
       else ok = false;
       if (ok && p > 0 && gc < Lp) {     // an insert in front of a record's first column is never counted (src/mia.c:492)
-        const int d = depth_code(dff, flen + blen - act - 1);
+        const int d = dcode(back, act);
         if (j == 0) atomicMax(&tb.gaps[gc], glen);
-        const int e = atomicAdd(tb.n_events, 1);
-        if (e < tb.cap_events)
-          tb.events[e] = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
-                         ((uint64_t)(rs.rc[i] ? 1 : 0) << 50);
-        else atomicOr(tb.flags, 1u);
+        for (int m = 0; m < mult; m++) {
+          const int e = atomicAdd(tb.n_events, 1);
+          if (e < tb.cap_events)
+            tb.events[e] = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
+                           ((uint64_t)(rs.rc[i] ? 1 : 0) << 50);
+          else atomicOr(tb.flags, 1u);
+        }
       }
     }
   }
 }
 
 __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
-                                                const uint8_t* drop_back, TallyBuf tb) {
+                                                const uint8_t* drop_back, TallyBuf tb, const int32_t* rec_params, const int32_t* rec_actf) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= rs.n) return;
-  tally_one_read<false>(i, lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0);
+  tally_one_read<false>(i, lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0, rec_params, rec_actf);
 }
 
 // ---- bucketing of the reads by alignment start (counting sort, one pass per iteration) ----
@@ -252,7 +382,8 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
 
 __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
-                                                       const int32_t* wgoff, const int32_t* order) {
+                                                       const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
+                                                       const int32_t* rec_actf) {
   __shared__ int32_t lds[TALLY_WORDS * TALLY_WIN];
   if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
   // which bucket does this workgroup belong to?  (wgoff is ascending, nb <= a few hundred)
@@ -264,7 +395,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   for (int k = threadIdx.x; k < TALLY_WORDS * TALLY_WIN; k += blockDim.x) lds[k] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = first + wv; k < last; k += 4) tally_one_read<true>(order[k], lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base);
+  for (int k = first + wv; k < last; k += 4) tally_one_read<true>(order[k], lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base, rec_params, rec_actf);
   __syncthreads();
   const int Lp = tb.Lp;
   for (int k = threadIdx.x; k < TALLY_WORDS * TALLY_WIN; k += blockDim.x) {

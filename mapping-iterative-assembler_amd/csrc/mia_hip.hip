@@ -45,6 +45,19 @@ struct mia_hip_ctx {
   // cull
   int64_t* d_slot = nullptr; int64_t* d_partial = nullptr; int64_t* d_total = nullptr;
   uint8_t *d_slot_dropped = nullptr, *d_drop_f = nullptr, *d_drop_b = nullptr; int64_t n_slots = 0;
+  // stale back_asp emulation (mia_consensus_kernels.h, k_cull_mark)
+  int64_t* d_back_slot = nullptr;          // per read, persistent across iterations
+  RecInfo ri{};                            // per read, per iteration
+  SlotInfo si{};                           // per local slot, per iteration
+  int64_t slot_cap = 0;
+  Links lk{};                              // links produced by this context in the last cull
+  int64_t* d_links_all = nullptr; int32_t n_links_all = 0; int64_t links_all_cap = 0;   // links to apply (own, or gathered from all ranks)
+  int32_t* d_link_len = nullptr; int64_t link_len_cap = 0;
+  uint32_t* d_cull_flags = nullptr;
+  int64_t read_base = 0;                   // global index of this context's first read (sharded runs)
+  int64_t slot_base = 0;
+  bool culled = false, links_applied = false;
+  std::vector<int64_t*> owned_links;       // gathered link buffers (mia_hip_set_links)
   // tally
   TallyBuf tb{}; int tally_cap = 0; int32_t* d_ins_off = nullptr; int32_t* d_ins_total = nullptr;
   int32_t* d_ins_tally = nullptr; int64_t ins_tally_cap = 0; char* d_calls = nullptr; char* d_ins_calls = nullptr;
@@ -142,8 +155,11 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_bins, ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
                   ctx->d_drop_b, ctx->tb.tally, ctx->tb.gaps, ctx->tb.events, ctx->tb.n_events, ctx->tb.flags, ctx->d_ins_off,
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
-                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order};
+                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
+                  ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
@@ -242,6 +258,15 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_drop_b, (size_t)n);
   ctx->n_slots = 2 * n + 16;
   rcx |= dev_alloc(ctx, &ctx->d_slot_dropped, (size_t)ctx->n_slots);
+  rcx |= dev_alloc(ctx, &ctx->d_back_slot, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->ri.flen, (size_t)n) | dev_alloc(ctx, &ctx->ri.blen, (size_t)n) | dev_alloc(ctx, &ctx->ri.actf, (size_t)n) |
+         dev_alloc(ctx, &ctx->ri.params, (size_t)n * 8);
+  ctx->slot_cap = 2 * n + 16;
+  rcx |= dev_alloc(ctx, &ctx->si.reclen, (size_t)ctx->slot_cap) | dev_alloc(ctx, &ctx->si.writer, (size_t)ctx->slot_cap) |
+         dev_alloc(ctx, &ctx->si.mult, (size_t)ctx->slot_cap);
+  ctx->lk.cap = (int32_t)std::min<int64_t>(n + 16, (int64_t)1 << 20);     // link index field of SlotInfo::writer: 20 bits
+  if (ctx->lk.cap > (int32_t)LINK_NONE - 1) ctx->lk.cap = (int32_t)LINK_NONE - 1;
+  rcx |= dev_alloc(ctx, &ctx->lk.rec, (size_t)ctx->lk.cap * 4) | dev_alloc(ctx, &ctx->lk.n, 1) | dev_alloc(ctx, &ctx->d_cull_flags, 1);
   if (rcx) return MIA_HIP_ERR_NOMEM;
   HIPCHK(hipMemcpyAsync(ctx->d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_roff, roff.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -254,6 +279,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   HIPCHK(hipMemsetAsync(ctx->d_status, 0, (size_t)n * 4, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_abr, 0, (size_t)n * 2, ctx->stream));   // no soft clip known after pass 1
   HIPCHK(hipMemsetAsync(ctx->d_slot_dropped, 0, (size_t)ctx->n_slots, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_back_slot, 0xFF, (size_t)n * 8, ctx->stream));   // -1: never split
   HIPCHK(hipMemsetAsync(ctx->d_drop_f, 0, (size_t)n, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_drop_b, 0, (size_t)n, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -264,6 +290,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   if (ctx->d_order) { (void)hipFree(ctx->d_order); ctx->d_order = nullptr; }
   ctx->aligned = false;
   ctx->tallied = false;
+  ctx->culled = false;
   return MIA_HIP_OK;
 }
 
@@ -438,6 +465,7 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   ctx->aligned = true;
+  ctx->culled = false;
   ctx->tallied = false;
   return MIA_HIP_OK;
 }
@@ -469,6 +497,41 @@ extern "C" int mia_hip_get_scripts(mia_hip_ctx* ctx, int16_t* cols, int32_t stri
 }
 
 // ---- cull ----------------------------------------------------------------------
+static int finish_params(mia_hip_ctx* ctx);
+// second half of the cull: every link (own or gathered) acts on the slot it points at, then each read's dropped bits,
+// depth-code parameters and multiplicities are final.  Runs at the end of mia_hip_cull and again after mia_hip_set_links.
+static int finish_cull(mia_hip_ctx* ctx) {
+  const int32_t nl = ctx->n_links_all;
+  if (nl > ctx->link_len_cap) {
+    if (dev_alloc(ctx, &ctx->d_link_len, (size_t)nl + 64)) return MIA_HIP_ERR_NOMEM;
+    ctx->link_len_cap = nl + 64;
+  }
+  if (nl > 0) {
+    HIPCHK(hipMemsetAsync(ctx->d_link_len, 0xFF, (size_t)nl * 4, ctx->stream));   // -1: the slot is not ours
+    hipLaunchKernelGGL(k_links_apply, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_links_all, nl, ctx->si,
+                       ctx->d_slot_dropped, ctx->n_slots, ctx->d_link_len, ctx->d_cull_flags);
+  }
+  ctx->links_applied = true;
+  return finish_params(ctx);
+}
+
+static int finish_params(mia_hip_ctx* ctx) {
+  const int64_t n = ctx->rs.n;
+  hipLaunchKernelGGL(k_rec_params, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
+                     ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->n_links_all, ctx->read_base,
+                     ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags);
+  HIPCHK(hipGetLastError());
+  uint32_t fl = 0;
+  HIPCHK(hipMemcpyAsync(&fl, ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (fl & 4u) {
+    ctx->err = "a formerly split read points at an AlnSeq slot that holds no record of this iteration (the reference would show "
+               "the slot's content from an earlier iteration); not reproduced";
+    return MIA_HIP_ERR_RANGE;
+  }
+  return MIA_HIP_OK;
+}
+
 extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, double intercept, int64_t slot_base) {
   if (!ctx) return MIA_HIP_ERR_ARG;
   if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
@@ -490,9 +553,105 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
     ctx->d_slot_dropped = nd;
     ctx->n_slots = ns;
   }
-  hipLaunchKernelGGL(k_cull, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
-                     ctx->n_slots, hard_cut, slope, intercept, ctx->d_drop_f, ctx->d_drop_b);
+  // records per read and per slot, the reads' own dropped marks, and the links of formerly split reads
+  int64_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->slot_base = slot_base;
+  ctx->si.base = slot_base;
+  ctx->si.n_local = total;
+  HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_cull_flags, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
+                     ctx->read_base, ctx->d_cull_flags);
+  hipLaunchKernelGGL(k_cull_mark, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
+                     ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot, ctx->ri, ctx->lk, ctx->read_base, ctx->d_cull_flags);
   HIPCHK(hipGetLastError());
+  int32_t nl = 0;
+  uint32_t fl = 0;
+  HIPCHK(hipMemcpyAsync(&nl, ctx->lk.n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&fl, ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (fl & 8u) { ctx->err = "more formerly split reads than the link list holds"; return MIA_HIP_ERR_RANGE; }
+  // by default the links to apply are this context's own; a sharded run replaces them with the gathered list (mia_hip_set_links)
+  ctx->d_links_all = ctx->lk.rec;
+  ctx->n_links_all = nl;
+  ctx->culled = true;
+  ctx->links_applied = false;
+  return finish_cull(ctx);
+}
+
+extern "C" int mia_hip_set_back_slots(mia_hip_ctx* ctx, const int64_t* back_slot) {
+  if (!ctx || !back_slot) return MIA_HIP_ERR_ARG;
+  if (!ctx->d_back_slot) { ctx->err = "upload_reads first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(ctx->d_back_slot, back_slot, (size_t)ctx->rs.n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_set_read_base(mia_hip_ctx* ctx, int64_t read_base) {
+  if (!ctx || read_base < 0) return MIA_HIP_ERR_ARG;
+  ctx->read_base = read_base;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_links(mia_hip_ctx* ctx, int64_t** d_links, int64_t* n_links) {
+  if (!ctx || !ctx->culled) return MIA_HIP_ERR_STATE;
+  int32_t nl = 0;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpy(&nl, ctx->lk.n, 4, hipMemcpyDeviceToHost));
+  if (d_links) *d_links = ctx->lk.rec;
+  if (n_links) *n_links = nl;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_set_links(mia_hip_ctx* ctx, const int64_t* d_links_all, int64_t n_all) {
+  if (!ctx || n_all < 0 || (n_all > 0 && !d_links_all)) return MIA_HIP_ERR_ARG;
+  if (!ctx->culled) { ctx->err = "cull first"; return MIA_HIP_ERR_STATE; }
+  if (n_all >= (int64_t)LINK_NONE) { ctx->err = "too many links"; return MIA_HIP_ERR_RANGE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  // own copy of the gathered list (the caller's buffer may be a temporary of the collective)
+  if (n_all > ctx->links_all_cap) {
+    int64_t* nb = nullptr;
+    if (hipMalloc((void**)&nb, (size_t)(n_all + 64) * 32) != hipSuccess) return MIA_HIP_ERR_NOMEM;
+    ctx->links_all_cap = n_all + 64;
+    ctx->d_links_all = nb;          // (the previous gathered buffer, if any, is released with the context)
+    ctx->owned_links.push_back(nb);
+  } else if (!ctx->owned_links.empty()) ctx->d_links_all = ctx->owned_links.back();
+  if (n_all > 0) HIPCHK(hipMemcpyAsync(ctx->d_links_all, d_links_all, (size_t)n_all * 32, hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->n_links_all = (int32_t)n_all;
+  // slot state back to "owners only", then every link once
+  const int64_t n = ctx->rs.n;
+  HIPCHK(hipMemsetAsync(ctx->d_cull_flags, 0, 4, ctx->stream));
+  hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
+                     ctx->read_base, ctx->d_cull_flags);
+  HIPCHK(hipGetLastError());
+  return finish_cull(ctx);
+}
+
+extern "C" int mia_hip_link_lengths(mia_hip_ctx* ctx, int32_t** d_len, int64_t* n) {
+  if (!ctx || !ctx->links_applied) return MIA_HIP_ERR_STATE;
+  if (d_len) *d_len = ctx->d_link_len;
+  if (n) *n = ctx->n_links_all;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_finish_links(mia_hip_ctx* ctx) {
+  if (!ctx || !ctx->links_applied) return MIA_HIP_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemsetAsync(ctx->d_cull_flags, 0, 4, ctx->stream));
+  return finish_params(ctx);
+}
+
+extern "C" int mia_hip_get_record_params(mia_hip_ctx* ctx, int32_t* params, int64_t* back_slot) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (!ctx->culled) { ctx->err = "cull first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->rs.n;
+  if (params) HIPCHK(hipMemcpyAsync(params, ctx->ri.params, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (back_slot) HIPCHK(hipMemcpyAsync(back_slot, ctx->d_back_slot, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return MIA_HIP_OK;
 }
 
@@ -611,6 +770,7 @@ static int ensure_tally(mia_hip_ctx* ctx) {
 extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
   if (!ctx) return MIA_HIP_ERR_ARG;
   if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
+  if (!ctx->culled) { ctx->err = "cull first (the dropped bits and record parameters are its output)"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
   int rc = ensure_tally(ctx);
   if (rc) return rc;
@@ -638,10 +798,10 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
       hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, ctx->stream, ctx->rs, nb, d_off, d_cur, ctx->d_order);
       const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
       hipLaunchKernelGGL(k_tally_binned, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
-                         ctx->tb, nb, d_off, d_wgoff, ctx->d_order);
+                         ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.params, ctx->ri.actf);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
-                         ctx->d_drop_b, ctx->tb);
+                         ctx->d_drop_b, ctx->tb, ctx->ri.params, ctx->ri.actf);
     }
     HIPCHK(hipGetLastError());
   }

@@ -59,3 +59,34 @@ def all_gather_ragged(t):
     parts = [torch.empty_like(mine) for _ in range(world())]
     dist.all_gather(parts, mine)
     return torch.cat([parts[r][: counts[r]] for r in range(world())]).contiguous()
+
+
+def exchange_links(hip, as_tensor):
+    """Between cull() and tally() of a sharded iteration: the links of formerly split reads (stale fs->back_asp,
+    include/mia_hip.h) may point at AlnSeq slots of another rank.  Every rank gets all links, applies those that hit
+    its own slots, and the record lengths the readers need come back with a max-reduce.
+    as_tensor(ptr, n, typestr) wraps a device pointer of the library as a tensor (bench.DevArray on CUDA)."""
+    if not _active():
+        return
+    ptr, n = hip.links()
+    mine = as_tensor(ptr, 4 * n, "<i8") if n else torch.zeros(0, dtype=torch.int64, device=_device())
+    alll = all_gather_ragged(mine)
+    total = int(alll.numel()) // 4
+    if total == 0:
+        return
+    _sync(alll)
+    hip.set_links(alll.data_ptr(), total)
+    lp, ln = hip.link_lengths()
+    lens = as_tensor(lp, ln, "<i4")
+    dist.all_reduce(lens, op=dist.ReduceOp.MAX)
+    _sync(lens)
+    hip.finish_links()
+
+
+def _device():
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
+def _sync(t):
+    if t.is_cuda:
+        torch.cuda.synchronize()

@@ -407,6 +407,9 @@ int main(int argc, char** argv) {
     }
     if (mia_hip_upload_reads(g, n, b2.data(), o2.data(), rc.data(), sk.data(), as.data(), ae.data()) != MIA_HIP_OK) die(g, "upload_reads");
     if (mia_hip_set_slot_dropped(g, slot_dropped.data(), (int64_t)slot_dropped.size()) != MIA_HIP_OK) die(g, "set_slot_dropped");
+    std::vector<int64_t> b0((size_t)n, -1);                     // fs->back_asp after pass 1 (src/mia.c:1619-1650)
+    for (int i = 0; i < n; i++) if (n_slots[i] == 2) b0[(size_t)i] = (int64_t)first_slot[i] + 1;
+    if (mia_hip_set_back_slots(g, b0.data()) != MIA_HIP_OK) die(g, "set_back_slots");
   }
   lap("upload");
 
@@ -419,6 +422,8 @@ int main(int argc, char** argv) {
   std::vector<int16_t> cols((size_t)n * stride);
   std::vector<int32_t> rstart((size_t)n), gaps;
   std::vector<uint8_t> dF((size_t)n), dB((size_t)n);
+  std::vector<int32_t> rparams((size_t)n * 8);
+  std::vector<int64_t> back_slot((size_t)n);
 
   auto iteration = [&](int iter_num) {
     // reiterate_assembly (src/mia_main.c:24-280)
@@ -440,6 +445,7 @@ int main(int argc, char** argv) {
     std::string wrapped = cons + cons.substr(0, (size_t)wl);
     if (mia_hip_get_scripts(g, cols.data(), stride, rstart.data()) != MIA_HIP_OK) die(g, "get_scripts");
     if (mia_hip_get_dropped(g, dF.data(), dB.data()) != MIA_HIP_OK) die(g, "get_dropped");
+    if (mia_hip_get_record_params(g, rparams.data(), back_slot.data()) != MIA_HIP_OK) die(g, "get_record_params");
     gaps.assign((size_t)L + 1, 0);
     if (mia_hip_get_tally(g, NULL, gaps.data()) != MIA_HIP_OK) die(g, "get_tally");
     // records of reads [lo, hi), in cull order (front record, then back record)
@@ -480,26 +486,27 @@ int main(int argc, char** argv) {
         recs.push_back(build(rg.substr(0, ap), fg.substr(0, ap), start, L - 1, 'f', dF[i], idf));
         recs.push_back(build(rg.substr(ap), fg.substr(ap), 0, end, 'b', dB[i], idb));
       } else recs.push_back(build(rg, fg, start, end, 'a', dF[i], f.id));
-      // pop_smp_from_FSDB (src/fsdb.c:542-619) for this read's record(s)
-      auto total_len = [&](const Record& a) { int span = a.end - a.start + 1, t = span; for (auto& in : a.ins) if (in.first < span) t += (int)in.second.size(); return t; };
+      // pop_smp_from_FSDB (src/fsdb.c:542-619) for this read's record(s).  The depth code of a column reached after
+      // `a` bases of its record is depth(q[0] + q[1] + a, q[2] - (q[1] + a) - 1); q = {0, 0, flen+blen} for a front
+      // record and {flen, bases in the front, flen+blen} for a back record, unless a formerly split read further
+      // down the fsdb overwrote the codes through its stale back_asp (mia_hip_get_record_params).
       Record& fa = recs[first];
       Record* ba = recs.size() - first == 2 ? &recs[first + 1] : nullptr;
-      const int flen = total_len(fa), blen = ba ? total_len(*ba) : 0;
-      int act = 0;
-      auto fill = [&](Record& a, bool back) {
+      auto fill = [&](Record& a, const int32_t* q) {
         const int span = a.end - a.start + 1;
         size_t ii = 0;
+        int act = 0;
         for (int p = 0; p < span; p++) {
           while (ii < a.ins.size() && a.ins[ii].first < p) ii++;
           if (ii < a.ins.size() && a.ins[ii].first == p) act += (int)a.ins[ii].second.size();
-          const int dff = back ? flen + act : act, dfb = flen + blen - act - 1;
+          const int dff = q[0] + q[1] + act, dfb = q[2] - (q[1] + act) - 1;
           char code = dff <= PSSM_DEPTH ? (char)('A' + dff) : (dfb < PSSM_DEPTH ? (char)('A' + 2 * PSSM_DEPTH - dfb) : (char)('A' + PSSM_DEPTH));
           a.smp.push_back(code);
           if (p < (int)a.seq.size() && a.seq[(size_t)p] != '-') act++;
         }
       };
-      fill(fa, false);
-      if (ba) fill(*ba, true);
+      fill(fa, &rparams[(size_t)i * 8]);
+      if (ba) fill(*ba, &rparams[(size_t)i * 8 + 4]);
     }
     };
     // reads are independent: build on all host threads, keep the order
@@ -513,9 +520,29 @@ int main(int argc, char** argv) {
       recs.reserve(tot);
       for (auto& v : part) { for (auto& a : v) recs.push_back(std::move(a)); std::vector<Record>().swap(v); }
     }
+    // cull_maln_from_fsdb (src/mia.c:451-481): front_asp of every read, then back_asp if it is not NULL.  back_asp is
+    // never cleared (src/mia_main.c:259-276): for a read that is not split any more it addresses the record that
+    // sits in that slot NOW, which is thereby listed twice.
+    std::vector<int> order;
+    {
+      std::vector<int> slot_rec;                 // AlnSeq slot -> record
+      slot_rec.reserve(recs.size());
+      for (size_t k = 0; k < recs.size(); k++) slot_rec.push_back((int)k);   // records are in merge (= slot) order
+      size_t k = 0;
+      order.reserve(recs.size() + 16);
+      for (int i = 0; i < n; i++) {
+        if (!fsdb[i].strand_known) continue;
+        const bool split = recs[k].segment == 'f';
+        order.push_back((int)k);
+        if (split) order.push_back((int)k + 1);
+        else if (back_slot[(size_t)i] >= 0) {
+          const int64_t sl = back_slot[(size_t)i];
+          if (sl < (int64_t)slot_rec.size()) order.push_back(slot_rec[(size_t)sl]);
+        }
+        k += split ? 2 : 1;
+      }
+    }
     // sort_aln_frags: stable by (start, end) over cull order (src/map_align.c:393-414)
-    std::vector<int> order(recs.size());
-    for (size_t k = 0; k < recs.size(); k++) order[k] = (int)k;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
       if (recs[x].start != recs[y].start) return recs[x].start < recs[y].start;
       return recs[x].end < recs[y].end;
@@ -526,7 +553,7 @@ int main(int argc, char** argv) {
     fprintf(mf, "/* map_alignment [V%s] */ %s", "1.0", asctime(localtime(&t)));
     int size = L + 1;                             // src/mia_main.c:66, src/mia.c:669-675
     if (circular) while (L + wl >= size) size *= 2;
-    fprintf(mf, "MALN_NAS %d\nMALN_SIZ %d\nMALN_COC %d\n__REFERENCE__\nID %s\nDESC %s\nLEN %d\nSIZE %d\nSEQ %s\nGAPS", (int)recs.size(),
+    fprintf(mf, "MALN_NAS %d\nMALN_SIZ %d\nMALN_COC %d\n__REFERENCE__\nID %s\nDESC %s\nLEN %d\nSIZE %d\nSEQ %s\nGAPS", (int)order.size(),
             pass1_records, cc, ref_id.c_str(), ref_desc.c_str(), L, size, cons.c_str());
     for (int p = 0; p < L; p++) fprintf(mf, " %d", gaps[(size_t)p]);
     fprintf(mf, "\n__PSSM__\nDEPTH %d\nFPSM:\n", PSSM_DEPTH);

@@ -11,7 +11,7 @@ from conftest import GOLDEN
 
 
 def oracle_after_pass1(oracle, ref_fa, reads_fa, circular=True, kmer=12, pssm_file=None, hard_cut=0, cons_code=1,
-                       slope=None, intercept=None):
+                       slope=None, intercept=None, adapter=None):
     """ora_new + load ref + pass 1 over a FASTA + finish_pass1; returns (state, opts, anc pssm)."""
     o = oc.Opts()
     oracle.ora_opts_default(C.byref(o))
@@ -21,6 +21,9 @@ def oracle_after_pass1(oracle, ref_fa, reads_fa, circular=True, kmer=12, pssm_fi
     o.cons_code = cons_code
     if slope is not None:
         o.score_cut_set, o.slope, o.intercept = 1, slope, intercept
+    if adapter is not None:         # -T -a <adapter>
+        o.do_trim = 1
+        o.adapter = adapter.encode()
     anc = oc.Pssm()
     if pssm_file:
         assert oracle.ora_pssm_read(os.path.join(GOLDEN, pssm_file).encode(), C.byref(anc)) == 1

@@ -52,6 +52,33 @@ mdist.allreduce_tallies(tt, tg)
 scores = mdist.all_gather_concat(torch.from_numpy(np.pad(fs["score"], (0, per - fs["n"]), constant_values=-1)))
 base = mdist.exclusive_rank_sum(nrec, "cpu")
 ev = mdist.all_gather_ragged(torch.arange(rank * 100, rank * 100 + 3 + rank, dtype=torch.int64))
+
+# the link exchange of formerly split reads (stale back_asp): rank 0 has two links, rank 1 one; a link is 4 int64
+# {reader, slot, flen<<32|actf, low}.  A stand-in with the library's five calls checks the protocol of exchange_links.
+class FakeHip:
+    def __init__(self):
+        n = 2 - rank
+        self.own = torch.tensor([[1000 * rank + k, 7 + 10 * k + rank, (50 << 32) | 40, k & 1] for k in range(n)], dtype=torch.int64).reshape(-1)
+        self.done = False
+    def links(self):
+        return self.own.data_ptr(), self.own.numel() // 4
+    def set_links(self, ptr, n):
+        self.all = np.ctypeslib.as_array((C.c_int64 * (4 * n)).from_address(ptr)).reshape(n, 4).copy()
+        # "my" slots are those with slot % 2 == rank: their record length is known here, the others are -1
+        self.lens = torch.tensor([200 + int(s) if int(s) % 2 == rank else -1 for s in self.all[:, 1]], dtype=torch.int32)
+    def link_lengths(self):
+        return self.lens.data_ptr(), self.lens.numel()
+    def finish_links(self):
+        self.done = True
+
+def cpu_tensor(ptr, n, ts):
+    ct = {"<i8": C.c_int64, "<i4": C.c_int32}[ts]
+    return torch.from_numpy(np.ctypeslib.as_array((ct * n).from_address(ptr)))
+
+fh = FakeHip()
+mdist.exchange_links(fh, cpu_tensor)
+assert fh.done and fh.all[:, 0].tolist() == [0, 1, 1000], fh.all          # all links, rank order
+assert fh.lens.tolist() == [200 + int(s) for s in fh.all[:, 1]], fh.lens     # every length resolved by its owner
 if rank == 0:
     full_t, full_g, full_fs, full_nrec = run("d150.fa")
     assert np.array_equal(tt.numpy(), full_t), "summed shard tallies != unsharded tallies"

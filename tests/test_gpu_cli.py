@@ -23,17 +23,12 @@ def cases():
 # fix_lin contains tf11-adapt, whose pass-1 score is exactly 2000 (strand unknown): the reference
 # then follows a stale AlnSeq pointer; documented divergence
 SKIP = {"fix_lin": "strand-unknown read (score == 2000): stale-pointer behaviour of the reference is not reproduced"}
-# reads that were split at the origin in one iteration and are not in a later one keep a stale back_asp in the reference
-# (src/mia_main.c:269-276 never clears it): the record that now sits in that slot is emitted a second time
-XFAIL = {"adapt_T_user_k12": "stale back_asp of a formerly split read (duplicate record in the culled maln)"}
 
 
 @pytest.mark.parametrize("name", sorted(cases().keys()))
 def test_cli_maln_identical(name, tmp_path):
     if name in SKIP:
         pytest.skip(SKIP[name])
-    if name in XFAIL:
-        pytest.xfail(XFAIL[name])
     args = cases()[name]
     root = str(tmp_path / name)
     env = dict(os.environ, MIA_DATA_PATH=GOLDEN)

@@ -24,6 +24,9 @@ CASES = {
     # carries a stale AlnSeq pointer for it ("strand-unknown reads"); excluded from this case
     "fixture_lin": ("tr1.fna", "tf.fna:-tf11-adapt", False, None, 0, 1, None),
     "fixture_c_anc_H": ("tr1.fna", "tf.fna", True, "ancient.submat.txt", 4000, 1, None),
+    # adapter-trimmed reads (-T -a GTCAGACACGCAACAGG); two reads that are split at the origin after pass 1 are not
+    # in iteration 2: their stale back_asp makes the reference list two unrelated records twice
+    "adapt_T_user": ("mt311.fa", "adapt.fa", True, None, 0, 1, None, "GTCAGACACGCAACAGG"),
 }
 
 
@@ -35,7 +38,8 @@ def hipmod():
 
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_iterations_match_oracle(name, oracle, hipmod, tmp_path):
-    ref_fa, reads_fa, circ, pfile, hard, cc, sn = CASES[name]
+    ref_fa, reads_fa, circ, pfile, hard, cc, sn = CASES[name][:7]
+    adapter = CASES[name][7] if len(CASES[name]) > 7 else None
     if ":-" in reads_fa:            # drop one record from a committed FASTA
         src, drop = reads_fa.split(":-")
         recs = open(os.path.join(GOLDEN, src)).read().split(">")[1:]
@@ -44,7 +48,7 @@ def test_iterations_match_oracle(name, oracle, hipmod, tmp_path):
             f.write("".join(">" + r for r in recs if r.split()[0] != drop))
     kmer = 12 if ref_fa == "mt311.fa" else -1
     st, opts, anc = oracle_after_pass1(oracle, ref_fa, reads_fa, circ, kmer, pfile, hard, cc,
-                                       sn[0] if sn else None, sn[1] if sn else None)
+                                       sn[0] if sn else None, sn[1] if sn else None, adapter)
     fs = fsdb_arrays(oracle, st)
     assert fs["n"] > 0 and fs["sk"].all()
     hip = hipmod.MiaHip(0)
@@ -52,13 +56,17 @@ def test_iterations_match_oracle(name, oracle, hipmod, tmp_path):
     hip.upload_reads(fs["bases"], fs["offsets"], fs["rc"], fs["sk"], fs["as_"], fs["ae"])
     n_slots1 = oracle.ora_num_culled(st)
     hip.set_slot_dropped(np.array([oracle.ora_slot_at(st, i).contents.dropped for i in range(n_slots1)], np.uint8))
+    hip.set_back_slots(fs["back"])          # fs->back_asp after pass 1 (-1 = NULL)
     lens = (fs["offsets"][1:] - fs["offsets"][:-1]).astype(np.int32)
 
     L0 = oracle.ora_ref_len(st)
     ref = oracle.ora_ref_seq(st)[:L0].decode()
+    max_mult = 1
     for it in range(1, 8):
         oracle.ora_iterate(st, ref.encode(), it)
         score, as_, ae, cons = hip_iteration(hip, ref, circ, lens, hard, sn, cc)
+        prm, _ = hip.record_params()
+        max_mult = max(max_mult, int(prm[:, 3].max()), int(prm[:, 7].max()))
         L = len(ref)
         wrapped = ref + (ref[: min(L, 256)] if circ else "")
         cols, rstart = hip.scripts()
@@ -92,5 +100,7 @@ def test_iterations_match_oracle(name, oracle, hipmod, tmp_path):
         if cons == ref:
             break
         ref = cons
+    if name == "adapt_T_user":
+        assert max_mult == 2      # the stale back_asp path was taken: some record was listed twice
     hip.close()
     oracle.ora_free(st)
