@@ -120,6 +120,11 @@ int mia_hip_set_slot_dropped(mia_hip_ctx *ctx, const uint8_t *flags, int64_t n_f
  * back_slot[n]: slot index of each read's back record after pass 1, -1 if it was not split (global slot numbers,
  * as fs->back_asp would address them). */
 int mia_hip_set_back_slots(mia_hip_ctx *ctx, const int64_t *back_slot);
+/* The same plus what a strand-unknown read (pass-1 score exactly FIRST_ROUND_SCORE_CUTOFF, src/mia.c:1653) keeps for
+ * ever because reiterate_assembly skips it (src/mia_main.c:178): its pass-1 front_asp slot and its pass-1 score (which
+ * find_fsdb_score_cut and cull_maln_from_fsdb keep using).  front_slot / back_slot / score: n entries each, any may be
+ * NULL; front_slot is only looked at for reads uploaded with strand_known == 0. */
+int mia_hip_set_pass1_state(mia_hip_ctx *ctx, const int64_t *front_slot, const int64_t *back_slot, const int32_t *score);
 /* After mia_hip_cull: per read  params[i*8 + {0..3}] = front record {dffBase, actOffset, total, multiplicity},
  * params[i*8 + {4..7}] = back record: the depth code of a column reached after `a` bases of that record is
  * depth(dffBase + actOffset + a, total - (actOffset + a) - 1) (src/fsdb.c:568-581,597-610); multiplicity = how often
@@ -127,12 +132,13 @@ int mia_hip_set_back_slots(mia_hip_ctx *ctx, const int64_t *back_slot);
 int mia_hip_get_record_params(mia_hip_ctx *ctx, int32_t *params, int64_t *back_slot);
 /* Sharded runs (one context per GPU): global index of this context's first read, and the exchange of the links
  * between mia_hip_cull and mia_hip_tally:  all-gather the buffers of mia_hip_links (4 int64 per link), hand the
- * concatenation to mia_hip_set_links on every rank, all-reduce(max) the buffer of mia_hip_link_lengths, then
+ * concatenation to mia_hip_set_links on every rank, all-reduce(max) the two buffers of mia_hip_link_lengths (record length and
+ * read bases of the addressed record, -1 where the slot belongs to another rank), then
  * mia_hip_finish_links.  Not needed on a single GPU. */
 int mia_hip_set_read_base(mia_hip_ctx *ctx, int64_t read_base);
 int mia_hip_links(mia_hip_ctx *ctx, int64_t **d_links, int64_t *n_links);
 int mia_hip_set_links(mia_hip_ctx *ctx, const int64_t *d_links_all, int64_t n_all);
-int mia_hip_link_lengths(mia_hip_ctx *ctx, int32_t **d_len, int64_t *n);
+int mia_hip_link_lengths(mia_hip_ctx *ctx, int32_t **d_len, int32_t **d_act, int64_t *n);
 int mia_hip_finish_links(mia_hip_ctx *ctx);
 
 /* find_fsdb_score_cut (src/fsdb.c:269-383) -- HOST helper, no device work: the

@@ -58,11 +58,12 @@ def _load():
     lib.mia_hip_ma_tally.argtypes = [vp, C.c_int32, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.mia_hip_trim.argtypes = [vp, C.c_char_p, C.c_int64, vp, vp, vp, vp]
     lib.mia_hip_set_back_slots.argtypes = [vp, vp]
+    lib.mia_hip_set_pass1_state.argtypes = [vp, vp, vp, vp]
     lib.mia_hip_get_record_params.argtypes = [vp, vp, vp]
     lib.mia_hip_set_read_base.argtypes = [vp, C.c_int64]
     lib.mia_hip_links.argtypes = [vp, P(vp), P(C.c_int64)]
     lib.mia_hip_set_links.argtypes = [vp, vp, C.c_int64]
-    lib.mia_hip_link_lengths.argtypes = [vp, P(vp), P(C.c_int64)]
+    lib.mia_hip_link_lengths.argtypes = [vp, P(vp), P(vp), P(C.c_int64)]
     lib.mia_hip_finish_links.argtypes = [vp]
     lib.mia_hip_trim_stats.argtypes = [vp, P(C.c_int64)]
     lib.mia_hip_get_ins_tally.argtypes = [vp, vp, vp, C.c_int64, P(C.c_int64)]
@@ -86,7 +87,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots",
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links"]
 
@@ -325,6 +326,12 @@ class MiaHip:
         assert len(b) == self.n
         self._chk(self._l.mia_hip_set_back_slots(self._h, _ptr(b)))
 
+    def set_pass1_state(self, front_slot=None, back_slot=None, score=None):
+        f = None if front_slot is None else np.ascontiguousarray(front_slot, dtype=np.int64)
+        b = None if back_slot is None else np.ascontiguousarray(back_slot, dtype=np.int64)
+        sc = None if score is None else np.ascontiguousarray(score, dtype=np.int32)
+        self._chk(self._l.mia_hip_set_pass1_state(self._h, _ptr(f), _ptr(b), _ptr(sc)))
+
     def record_params(self):
         """(params[n][8], back_slot[n]) after cull(): see mia_hip_get_record_params."""
         p = np.empty((self.n, 8), dtype=np.int32)
@@ -344,9 +351,9 @@ class MiaHip:
         self._chk(self._l.mia_hip_set_links(self._h, C.c_void_p(dptr), int(n)))
 
     def link_lengths(self):
-        p, n = C.c_void_p(), C.c_int64()
-        self._chk(self._l.mia_hip_link_lengths(self._h, C.byref(p), C.byref(n)))
-        return p.value, n.value
+        p, q, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        self._chk(self._l.mia_hip_link_lengths(self._h, C.byref(p), C.byref(q), C.byref(n)))
+        return p.value, q.value, n.value
 
     def finish_links(self):
         self._chk(self._l.mia_hip_finish_links(self._h))

@@ -111,11 +111,15 @@ struct SlotInfo {             // per local AlnSeq slot (global slot - slot_base)
   int64_t base;               // first global slot of this context
   int64_t n_local;            // slots owned by this context in this iteration
   int32_t* reclen;            // asp_len of the record in the slot
+  int32_t* recact;            // read bases in that record
   unsigned long long* writer; // (global read index << 20 | link index) of the last pop_smp writer; owner: link index 0xFFFFF
   int32_t* mult;              // times the slot is listed in the culled maln
 };
 constexpr unsigned long long LINK_NONE = 0xFFFFFull;
-struct Links {                // [cap][4] int64: reader (global read index), slot (global), flen << 32 | actf, low score flag
+// kinds of link: 0 = back_asp of a read that is no longer split; 1 / 2 = front_asp / back_asp of a read whose strand is
+// unknown (pass-1 score exactly 2000): reiterate_assembly skips it (src/mia_main.c:178), so BOTH its pointers stay on the
+// pass-1 slots for good
+struct Links {                // [cap][4] int64: reader (global read index), slot (global), flen << 32 | actf, low score flag | kind << 8
   int64_t* rec;
   int32_t* n;
   int32_t cap;
@@ -155,39 +159,46 @@ __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const i
     ri.flen[i] = flen; ri.blen[i] = blen; ri.actf[i] = af + nf;
     const int64_t ls = slot[i] - si.base;
     if (ls >= 0 && ls + (g.split ? 1 : 0) < si.n_local) {
-      si.reclen[ls] = flen; si.mult[ls] = 1; si.writer[ls] = ((unsigned long long)(read_base + i) << 20) | LINK_NONE;
-      if (g.split) { si.reclen[ls + 1] = blen; si.mult[ls + 1] = 1; si.writer[ls + 1] = ((unsigned long long)(read_base + i) << 20) | LINK_NONE; }
+      si.reclen[ls] = flen; si.recact[ls] = af + nf; si.mult[ls] = 1; si.writer[ls] = ((unsigned long long)(read_base + i) << 20) | LINK_NONE;
+      if (g.split) { si.reclen[ls + 1] = blen; si.recact[ls + 1] = (len2 - abr) - (af + nf); si.mult[ls + 1] = 1; si.writer[ls + 1] = ((unsigned long long)(read_base + i) << 20) | LINK_NONE; }
     } else atomicOr(flags, 4u);
   }
 }
 
 // own dropped marks, the persistent back slot, and the links of formerly split reads
 __global__ void k_cull_mark(ReadSet rs, int32_t L, const int64_t* slot, uint8_t* slot_dropped, int64_t n_slots, int32_t hard_cut, double slope,
-                            double intercept, int64_t* back_slot, RecInfo ri, Links lk, int64_t read_base, uint32_t* flags) {
+                            double intercept, int64_t* back_slot, const int64_t* front_slot0, RecInfo ri, Links lk, int64_t read_base,
+                            uint32_t* flags) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rs.n || !rs.sk[i]) return;
-  const bool split = rec_geom(rs.as[i], rs.ae[i], L).split;
+  if (i >= rs.n) return;
   const double min_score = hard_cut > 0 ? (double)hard_cut : (double)(intercept + (slope * (double)rs.len[i]));
-  const int64_t s = slot[i];
   const bool low = (double)rs.score[i] < min_score;
+  auto add_link = [&](int64_t target, int kind, int fl, int ac) {
+    const int e = atomicAdd(lk.n, 1);
+    if (e < lk.cap) {
+      int64_t* r = lk.rec + (int64_t)e * 4;
+      r[0] = read_base + i; r[1] = target;
+      r[2] = ((int64_t)fl << 32) | (uint32_t)ac;
+      r[3] = (low ? 1 : 0) | (kind << 8);
+    } else atomicOr(flags, 8u);
+  };
+  if (!rs.sk[i]) {                                             // strand unknown: both pointers are the pass-1 ones
+    if (front_slot0[i] >= 0) add_link(front_slot0[i], 1, 0, 0);
+    if (back_slot[i] >= 0) add_link(back_slot[i], 2, 0, 0);
+    return;
+  }
+  const bool split = rec_geom(rs.as[i], rs.ae[i], L).split;
+  const int64_t s = slot[i];
   if (low && s < n_slots) slot_dropped[s] = 1;
   if (split) {
     if (low && s + 1 < n_slots) slot_dropped[s + 1] = 1;
     back_slot[i] = s + 1;                                      // fs->back_asp (src/mia_main.c:266-267)
-  } else if (back_slot[i] >= 0) {                              // stale back_asp
-    const int e = atomicAdd(lk.n, 1);
-    if (e < lk.cap) {
-      int64_t* r = lk.rec + (int64_t)e * 4;
-      r[0] = read_base + i; r[1] = back_slot[i];
-      r[2] = ((int64_t)ri.flen[i] << 32) | (uint32_t)ri.actf[i];
-      r[3] = low ? 1 : 0;
-    } else atomicOr(flags, 8u);
-  }
+  } else if (back_slot[i] >= 0) add_link(back_slot[i], 0, ri.flen[i], ri.actf[i]);   // stale back_asp
 }
 
 // every link (of this context or gathered from the others): effects on the slot it points at, if that slot is ours
 __global__ void k_links_apply(const int64_t* links, int32_t n_links, SlotInfo si, uint8_t* slot_dropped, int64_t n_slots, int32_t* link_len,
-                              uint32_t* flags) {
+                              int32_t* link_act, uint32_t* flags) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_links) return;
   const int64_t* r = links + (int64_t)e * 4;
@@ -195,13 +206,15 @@ __global__ void k_links_apply(const int64_t* links, int32_t n_links, SlotInfo si
   if (ls < 0 || ls >= si.n_local) return;                      // another context's slot (or none: see k_links_check)
   atomicMax(&si.writer[ls], ((unsigned long long)r[0] << 20) | (unsigned long long)e);
   atomicAdd(&si.mult[ls], 1);
-  if (r[3] && r[1] < n_slots) slot_dropped[r[1]] = 1;
+  if ((r[3] & 1) && r[1] < n_slots) slot_dropped[r[1]] = 1;
   link_len[e] = si.reclen[ls];
+  link_act[e] = si.recact[ls];
 }
 
 // depth-code parameters and multiplicities of every read's records + its dropped bits, after all links are in
 __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const uint8_t* slot_dropped, int64_t n_slots, const int64_t* back_slot,
-                             RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, int32_t n_links, int64_t read_base,
+                             RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, const int32_t* link_act, int32_t n_links,
+                             int64_t read_base,
                              uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rs.n) return;
@@ -218,16 +231,30 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
     if (!split && back_slot[i] >= 0) {
       back_len = -1;
       for (int e = 0; e < n_links; e++)                        // (a handful of links; only formerly split reads get here)
-        if (links[(int64_t)e * 4] == read_base + i) { back_len = link_len[e]; break; }
+        if (links[(int64_t)e * 4] == read_base + i && (links[(int64_t)e * 4 + 3] >> 8) == 0) { back_len = link_len[e]; break; }
       if (back_len < 0) { atomicOr(flags, 4u); back_len = 0; }
     }
     auto fill = [&](int32_t* q, int64_t lsl, int own_base, int own_off, int own_B, int own_len) {
       const unsigned long long w = si.writer[lsl];
       if ((w & LINK_NONE) == LINK_NONE) { q[0] = own_base; q[1] = own_off; q[2] = own_B; }
       else {                                                   // overwritten by a later reader through its stale pointer
-        const int64_t* r = links + (int64_t)(w & LINK_NONE) * 4;
-        const int rf = (int)(r[2] >> 32), ra = (int)(uint32_t)r[2];
-        q[0] = rf; q[1] = ra; q[2] = rf + own_len;
+        const int we = (int)(w & LINK_NONE);
+        const int64_t* r = links + (int64_t)we * 4;
+        const int kind = (int)(r[3] >> 8);
+        if (kind == 0) {                                       // back segment of a formerly split read
+          const int rf = (int)(r[2] >> 32), ra = (int)(uint32_t)r[2];
+          q[0] = rf; q[1] = ra; q[2] = rf + own_len;
+        } else {                                               // front / back segment of a strand-unknown read: its other
+          int sib_len = 0, sib_act = 0;                        // segment is whatever its other pointer addresses
+          for (int e = 0; e < n_links; e++)
+            if (links[(int64_t)e * 4] == r[0] && (links[(int64_t)e * 4 + 3] >> 8) == 3 - kind) {
+              sib_len = link_len[e]; sib_act = link_act[e];
+              if (sib_len < 0) { atomicOr(flags, 4u); sib_len = 0; sib_act = 0; }
+              break;
+            }
+          if (kind == 1) { q[0] = 0; q[1] = 0; q[2] = own_len + sib_len; }
+          else { q[0] = sib_len; q[1] = sib_act; q[2] = sib_len + own_len; }
+        }
       }
       q[3] = si.mult[lsl];
     };

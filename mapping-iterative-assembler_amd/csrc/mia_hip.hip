@@ -47,6 +47,8 @@ struct mia_hip_ctx {
   uint8_t *d_slot_dropped = nullptr, *d_drop_f = nullptr, *d_drop_b = nullptr; int64_t n_slots = 0;
   // stale back_asp emulation (mia_consensus_kernels.h, k_cull_mark)
   int64_t* d_back_slot = nullptr;          // per read, persistent across iterations
+  int64_t* d_front_slot0 = nullptr;        // per read: pass-1 front slot (followed for strand-unknown reads only)
+  int32_t* d_link_act = nullptr;
   RecInfo ri{};                            // per read, per iteration
   SlotInfo si{};                           // per local slot, per iteration
   int64_t slot_cap = 0;
@@ -157,7 +159,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len};
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -258,11 +260,11 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_drop_b, (size_t)n);
   ctx->n_slots = 2 * n + 16;
   rcx |= dev_alloc(ctx, &ctx->d_slot_dropped, (size_t)ctx->n_slots);
-  rcx |= dev_alloc(ctx, &ctx->d_back_slot, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_back_slot, (size_t)n) | dev_alloc(ctx, &ctx->d_front_slot0, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->ri.flen, (size_t)n) | dev_alloc(ctx, &ctx->ri.blen, (size_t)n) | dev_alloc(ctx, &ctx->ri.actf, (size_t)n) |
          dev_alloc(ctx, &ctx->ri.params, (size_t)n * 8);
   ctx->slot_cap = 2 * n + 16;
-  rcx |= dev_alloc(ctx, &ctx->si.reclen, (size_t)ctx->slot_cap) | dev_alloc(ctx, &ctx->si.writer, (size_t)ctx->slot_cap) |
+  rcx |= dev_alloc(ctx, &ctx->si.reclen, (size_t)ctx->slot_cap) | dev_alloc(ctx, &ctx->si.recact, (size_t)ctx->slot_cap) | dev_alloc(ctx, &ctx->si.writer, (size_t)ctx->slot_cap) |
          dev_alloc(ctx, &ctx->si.mult, (size_t)ctx->slot_cap);
   ctx->lk.cap = (int32_t)std::min<int64_t>(n + 16, (int64_t)1 << 20);     // link index field of SlotInfo::writer: 20 bits
   if (ctx->lk.cap > (int32_t)LINK_NONE - 1) ctx->lk.cap = (int32_t)LINK_NONE - 1;
@@ -280,6 +282,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   HIPCHK(hipMemsetAsync(ctx->d_abr, 0, (size_t)n * 2, ctx->stream));   // no soft clip known after pass 1
   HIPCHK(hipMemsetAsync(ctx->d_slot_dropped, 0, (size_t)ctx->n_slots, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_back_slot, 0xFF, (size_t)n * 8, ctx->stream));   // -1: never split
+  HIPCHK(hipMemsetAsync(ctx->d_front_slot0, 0xFF, (size_t)n * 8, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_drop_f, 0, (size_t)n, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_drop_b, 0, (size_t)n, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -503,13 +506,14 @@ static int finish_params(mia_hip_ctx* ctx);
 static int finish_cull(mia_hip_ctx* ctx) {
   const int32_t nl = ctx->n_links_all;
   if (nl > ctx->link_len_cap) {
-    if (dev_alloc(ctx, &ctx->d_link_len, (size_t)nl + 64)) return MIA_HIP_ERR_NOMEM;
+    if (dev_alloc(ctx, &ctx->d_link_len, (size_t)nl + 64) || dev_alloc(ctx, &ctx->d_link_act, (size_t)nl + 64)) return MIA_HIP_ERR_NOMEM;
     ctx->link_len_cap = nl + 64;
   }
   if (nl > 0) {
     HIPCHK(hipMemsetAsync(ctx->d_link_len, 0xFF, (size_t)nl * 4, ctx->stream));   // -1: the slot is not ours
+    HIPCHK(hipMemsetAsync(ctx->d_link_act, 0xFF, (size_t)nl * 4, ctx->stream));
     hipLaunchKernelGGL(k_links_apply, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_links_all, nl, ctx->si,
-                       ctx->d_slot_dropped, ctx->n_slots, ctx->d_link_len, ctx->d_cull_flags);
+                       ctx->d_slot_dropped, ctx->n_slots, ctx->d_link_len, ctx->d_link_act, ctx->d_cull_flags);
   }
   ctx->links_applied = true;
   return finish_params(ctx);
@@ -518,7 +522,8 @@ static int finish_cull(mia_hip_ctx* ctx) {
 static int finish_params(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   hipLaunchKernelGGL(k_rec_params, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
-                     ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->n_links_all, ctx->read_base,
+                     ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->d_link_act, ctx->n_links_all,
+                     ctx->read_base,
                      ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags);
   HIPCHK(hipGetLastError());
   uint32_t fl = 0;
@@ -565,7 +570,8 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
                      ctx->read_base, ctx->d_cull_flags);
   hipLaunchKernelGGL(k_cull_mark, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
-                     ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot, ctx->ri, ctx->lk, ctx->read_base, ctx->d_cull_flags);
+                     ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot, ctx->d_front_slot0, ctx->ri, ctx->lk, ctx->read_base,
+                     ctx->d_cull_flags);
   HIPCHK(hipGetLastError());
   int32_t nl = 0;
   uint32_t fl = 0;
@@ -586,6 +592,18 @@ extern "C" int mia_hip_set_back_slots(mia_hip_ctx* ctx, const int64_t* back_slot
   if (!ctx->d_back_slot) { ctx->err = "upload_reads first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemcpyAsync(ctx->d_back_slot, back_slot, (size_t)ctx->rs.n * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_set_pass1_state(mia_hip_ctx* ctx, const int64_t* front_slot, const int64_t* back_slot, const int32_t* score) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (!ctx->d_back_slot) { ctx->err = "upload_reads first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->rs.n;
+  if (front_slot) HIPCHK(hipMemcpyAsync(ctx->d_front_slot0, front_slot, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (back_slot) HIPCHK(hipMemcpyAsync(ctx->d_back_slot, back_slot, n * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (score) HIPCHK(hipMemcpyAsync(ctx->d_score, score, n * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return MIA_HIP_OK;
 }
@@ -630,9 +648,10 @@ extern "C" int mia_hip_set_links(mia_hip_ctx* ctx, const int64_t* d_links_all, i
   return finish_cull(ctx);
 }
 
-extern "C" int mia_hip_link_lengths(mia_hip_ctx* ctx, int32_t** d_len, int64_t* n) {
+extern "C" int mia_hip_link_lengths(mia_hip_ctx* ctx, int32_t** d_len, int32_t** d_act, int64_t* n) {
   if (!ctx || !ctx->links_applied) return MIA_HIP_ERR_STATE;
   if (d_len) *d_len = ctx->d_link_len;
+  if (d_act) *d_act = ctx->d_link_act;
   if (n) *n = ctx->n_links_all;
   return MIA_HIP_OK;
 }

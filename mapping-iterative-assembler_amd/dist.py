@@ -76,10 +76,11 @@ def exchange_links(hip, as_tensor):
         return
     _sync(alll)
     hip.set_links(alll.data_ptr(), total)
-    lp, ln = hip.link_lengths()
-    lens = as_tensor(lp, ln, "<i4")
-    dist.all_reduce(lens, op=dist.ReduceOp.MAX)
-    _sync(lens)
+    lp, ap, ln = hip.link_lengths()
+    for ptr in (lp, ap):
+        t = as_tensor(ptr, ln, "<i4")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        _sync(t)
     hip.finish_links()
 
 

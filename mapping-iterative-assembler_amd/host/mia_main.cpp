@@ -371,10 +371,9 @@ int main(int argc, char** argv) {
   const int n = (int)fsdb.size();
   const int pass1_records = (int)slot_dropped.size();   // culled_maln->size, frozen here (src/mia.c:54)
   if (n == 0) { fprintf(stderr, "No sequence aligned to the reference with a score of at least 2000.\n"); mia_hip_destroy(g); exit(0); }
-  if (n_unknown)
-    fprintf(stderr, "mia_hip: %d read(s) scored exactly 2000 (strand unknown); the reference keeps stale records for such reads, "
-                    "mia_hip leaves them out (DESIGN.md, section 6)\n", n_unknown);
+  (void)n_unknown;   // strand-unknown reads (score exactly 2000) stay in the fsdb: their stale pointers are followed as the reference does
   std::vector<int32_t> len((size_t)n), score((size_t)n), as((size_t)n), ae((size_t)n);
+  std::vector<int64_t> f0((size_t)n, -1);     // pass-1 front slot of every read
   for (int i = 0; i < n; i++) { len[i] = (int32_t)fsdb[i].seq.size(); score[i] = fsdb[i].score; }
 
   auto score_cut = [&](double* s, double* ic) {   // cull_maln_from_fsdb, src/mia.c:429-442
@@ -407,9 +406,11 @@ int main(int argc, char** argv) {
     }
     if (mia_hip_upload_reads(g, n, b2.data(), o2.data(), rc.data(), sk.data(), as.data(), ae.data()) != MIA_HIP_OK) die(g, "upload_reads");
     if (mia_hip_set_slot_dropped(g, slot_dropped.data(), (int64_t)slot_dropped.size()) != MIA_HIP_OK) die(g, "set_slot_dropped");
-    std::vector<int64_t> b0((size_t)n, -1);                     // fs->back_asp after pass 1 (src/mia.c:1619-1650)
-    for (int i = 0; i < n; i++) if (n_slots[i] == 2) b0[(size_t)i] = (int64_t)first_slot[i] + 1;
-    if (mia_hip_set_back_slots(g, b0.data()) != MIA_HIP_OK) die(g, "set_back_slots");
+    // fs->front_asp / back_asp and fs->score after pass 1 (src/mia.c:1619-1653): the back slot of every split read, and
+    // for strand-unknown reads (never re-aligned, src/mia_main.c:178) also the front slot and the score
+    std::vector<int64_t> b0((size_t)n, -1);
+    for (int i = 0; i < n; i++) { f0[(size_t)i] = first_slot[i]; if (n_slots[i] == 2) b0[(size_t)i] = (int64_t)first_slot[i] + 1; }
+    if (mia_hip_set_pass1_state(g, f0.data(), b0.data(), score.data()) != MIA_HIP_OK) die(g, "set_pass1_state");
   }
   lap("upload");
 
@@ -531,7 +532,11 @@ int main(int argc, char** argv) {
       size_t k = 0;
       order.reserve(recs.size() + 16);
       for (int i = 0; i < n; i++) {
-        if (!fsdb[i].strand_known) continue;
+        if (!fsdb[i].strand_known) {             // both pointers still address the pass-1 slots (src/mia_main.c:178)
+          if (f0[(size_t)i] >= 0 && f0[(size_t)i] < (int64_t)slot_rec.size()) order.push_back(slot_rec[(size_t)f0[(size_t)i]]);
+          if (back_slot[(size_t)i] >= 0 && back_slot[(size_t)i] < (int64_t)slot_rec.size()) order.push_back(slot_rec[(size_t)back_slot[(size_t)i]]);
+          continue;
+        }
         const bool split = recs[k].segment == 'f';
         order.push_back((int)k);
         if (split) order.push_back((int)k + 1);

@@ -66,8 +66,9 @@ class FakeHip:
         self.all = np.ctypeslib.as_array((C.c_int64 * (4 * n)).from_address(ptr)).reshape(n, 4).copy()
         # "my" slots are those with slot % 2 == rank: their record length is known here, the others are -1
         self.lens = torch.tensor([200 + int(s) if int(s) % 2 == rank else -1 for s in self.all[:, 1]], dtype=torch.int32)
+        self.acts = self.lens.clone()
     def link_lengths(self):
-        return self.lens.data_ptr(), self.lens.numel()
+        return self.lens.data_ptr(), self.acts.data_ptr(), self.lens.numel()
     def finish_links(self):
         self.done = True
 
@@ -79,6 +80,7 @@ fh = FakeHip()
 mdist.exchange_links(fh, cpu_tensor)
 assert fh.done and fh.all[:, 0].tolist() == [0, 1, 1000], fh.all          # all links, rank order
 assert fh.lens.tolist() == [200 + int(s) for s in fh.all[:, 1]], fh.lens     # every length resolved by its owner
+assert fh.acts.tolist() == fh.lens.tolist()
 if rank == 0:
     full_t, full_g, full_fs, full_nrec = run("d150.fa")
     assert np.array_equal(tt.numpy(), full_t), "summed shard tallies != unsharded tallies"

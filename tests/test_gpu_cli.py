@@ -20,9 +20,7 @@ def cases():
         return json.load(f)
 
 
-# fix_lin contains tf11-adapt, whose pass-1 score is exactly 2000 (strand unknown): the reference
-# then follows a stale AlnSeq pointer; documented divergence
-SKIP = {"fix_lin": "strand-unknown read (score == 2000): stale-pointer behaviour of the reference is not reproduced"}
+SKIP = {}
 
 
 @pytest.mark.parametrize("name", sorted(cases().keys()))
