@@ -38,6 +38,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # reported, no width correction): almost all of it is the trace band (16-bit cells, ~30 % of the lanes) going to the
 # per-workgroup slabs; the full byte trace cost 31.7e6 KB
 TRAFFIC_BYTES_PER_READ = (7078632 + 13590312) * 1024 / 1_000_000
+# the values-only first pass stores no trace: PMC traffic per read, filled in once measured (None = not measured yet)
+PLAIN_TRAFFIC_BYTES_PER_READ = None
 # SQ counters of the same kernel (profiles/r01/pmc/sq_counters_quad.json): the kernel is integer-VALU bound
 VALU_UTILISATION_PMC = 0.89
 
@@ -183,6 +185,7 @@ def main():
     for _ in range(a.warmup):
         cur = step(cur)
     hip.kernel_time(reset=True)
+    hip.plain_stats(reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -195,6 +198,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     align_ms, launches = hip.kernel_time(reset=True)
+    plain_ms, plain_launches, plain_in, plain_retried = hip.plain_stats(reset=True)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -203,8 +207,16 @@ def main():
     if rank == 0:
         total_reads = n * world
         value = total_reads * a.steps / dt
-        k_ms = align_ms / max(launches, 1)
-        reads_per_launch = n * a.steps / max(launches, 1)
+        # dominant kernel: the values-only first pass over all reads (k_align_quad_plain); reads whose alignment is not
+        # provably the pure diagonal go on to the trace kernel k_align_quad (reported beside it).  MIA_HIP_NO_PLAIN=1
+        # restores the single-kernel path.
+        plain_on = plain_launches > 0
+        if plain_on:
+            dom_name, k_ms, dom_launches = "k_align_quad_plain", plain_ms / plain_launches, plain_launches
+            reads_per_launch = plain_in / plain_launches
+        else:
+            dom_name, k_ms, dom_launches = "k_align_quad", align_ms / max(launches, 1), launches
+            reads_per_launch = n * a.steps / max(launches, 1)
         achieved = BYTES_PER_READ * reads_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "reads aligned/sec per iteration (16.5kb mito ref, 100bp reads)",
@@ -215,8 +227,12 @@ def main():
                                    "step = reiterate_assembly + cull + consensus; pass-1 coordinates = true positions" % n,
                        "reads_per_gpu": n, "consensus_len": len(cur)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_READ * reads_per_launch,
-                         "kernel": "k_align_quad", "kernel_ms": k_ms, "launches": launches,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (PLAIN_TRAFFIC_BYTES_PER_READ * reads_per_launch if PLAIN_TRAFFIC_BYTES_PER_READ else None) if plain_on
+                         else TRAFFIC_BYTES_PER_READ * reads_per_launch,
+                         "kernel": dom_name, "kernel_ms": k_ms, "launches": dom_launches,
+                         "trace_kernel": {"kernel": "k_align_quad", "ms_per_step": align_ms / a.steps, "launches": launches,
+                                          "reads_frac": (plain_retried / plain_in) if plain_on and plain_in else 1.0},
                          "note": "integer-VALU-bound DP (SQ_ACTIVE_INST_VALU = 89 % of SIMD capacity, profiles/r01/pmc): 182 algorithmic HBM bytes per read (SURVEY 8d) put it at a fraction of a percent of the HBM roof by construction; see DESIGN.md 3.1",
                          "valu_utilisation": VALU_UTILISATION_PMC,
                          "gcups": reads_per_launch * 100 * 200 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},

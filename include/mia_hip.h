@@ -217,6 +217,11 @@ int mia_hip_myers(mia_hip_ctx *ctx, int64_t n_pairs, const char *const *seq_a, c
 /* ---- timing hooks for bench.py (HIP events on the context's stream) ------ */
 /* milliseconds spent in, and launches of, the windowed DP kernel since the last reset */
 int mia_hip_kernel_time(mia_hip_ctx *ctx, int reset, double *align_ms, int64_t *align_launches);
+/* The values-only first pass of mia_hip_realign (k_align_quad_plain: score and end column of every read, plus the proof
+ * that its alignment is the pure diagonal; the rest goes on to the trace kernel that mia_hip_kernel_time reports):
+ * accumulated kernel time, launches, reads that entered and reads that had to be re-run with a trace. */
+int mia_hip_plain_stats(mia_hip_ctx *ctx, int reset, double *plain_ms, int64_t *plain_launches, int64_t *reads_in,
+                        int64_t *reads_retried);
 /* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
 int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 

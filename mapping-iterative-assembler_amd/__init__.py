@@ -65,6 +65,7 @@ def _load():
     lib.mia_hip_set_links.argtypes = [vp, vp, C.c_int64]
     lib.mia_hip_link_lengths.argtypes = [vp, P(vp), P(vp), P(C.c_int64)]
     lib.mia_hip_finish_links.argtypes = [vp]
+    lib.mia_hip_plain_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64), P(C.c_int64), P(C.c_int64)]
     lib.mia_hip_trim_stats.argtypes = [vp, P(C.c_int64)]
     lib.mia_hip_get_ins_tally.argtypes = [vp, vp, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
@@ -89,7 +90,7 @@ def exported_symbols():
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
-            "mia_hip_finish_links"]
+            "mia_hip_finish_links", "mia_hip_plain_stats"]
 
 
 def _ptr(a):
@@ -357,6 +358,12 @@ class MiaHip:
 
     def finish_links(self):
         self._chk(self._l.mia_hip_finish_links(self._h))
+
+    def plain_stats(self, reset=False):
+        """(ms, launches, reads in, reads re-run with a trace) of the values-only first pass."""
+        ms, a, b, c = C.c_double(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self._l.mia_hip_plain_stats(self._h, 1 if reset else 0, C.byref(ms), C.byref(a), C.byref(b), C.byref(c)))
+        return ms.value, a.value, b.value, c.value
 
     def trim_exact_reruns(self):
         n = C.c_int64()

@@ -69,6 +69,8 @@ struct mia_hip_ctx {
   unsigned char* d_quad_slabs = nullptr;
   int quad_wgs = 0;
   int use_quad = 1;   // MIA_HIP_NO_QUAD=1 routes everything through the one-read-per-wave kernels
+  int use_plain = 1;  // MIA_HIP_NO_PLAIN=1: no values-only first pass, every quad goes straight to the trace kernel
+  double plain_ms = 0; int64_t plain_launches = 0; int64_t plain_retried = 0, plain_total = 0;
   int grid_wgs = 0;
   int window_wgs[N_CPL] = {0, 0, 0};
   int cus = 1;
@@ -79,7 +81,7 @@ struct mia_hip_ctx {
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free, ev_plain;
   double align_ms = 0; int64_t align_launches = 0;
   double pass1_ms = 0;
   bool consensus_done = false;
@@ -130,6 +132,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nbt && atoi(nbt)) ctx->use_binned_tally = 0;
     const char* nband = getenv("MIA_HIP_NO_BAND");
     if (nband && atoi(nband)) ctx->use_band = 0;
+    const char* npl = getenv("MIA_HIP_NO_PLAIN");
+    if (npl && atoi(npl)) ctx->use_plain = 0;
     const char* nq = getenv("MIA_HIP_NO_QUAD");
     if (nq && atoi(nq)) ctx->use_quad = 0;
     const char* qw = getenv("MIA_HIP_QUAD_WAVES_PER_CU");
@@ -164,6 +168,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : ctx->ev_plain) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -320,6 +325,15 @@ static void drain_events(mia_hip_ctx* ctx) {
     ctx->ev_free.push_back(e);
   }
   ctx->ev_used.clear();
+  for (auto& e : ctx->ev_plain) {
+    float ms = 0;
+    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+      ctx->plain_ms += ms;
+      ctx->plain_launches++;
+    }
+    ctx->ev_free.push_back(e);
+  }
+  ctx->ev_plain.clear();
 }
 
 extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms, int64_t* launches) {
@@ -329,6 +343,18 @@ extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms
   if (align_ms) *align_ms = ctx->align_ms;
   if (launches) *launches = ctx->align_launches;
   if (reset) { ctx->align_ms = 0; ctx->align_launches = 0; }
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_plain_stats(mia_hip_ctx* ctx, int reset, double* plain_ms, int64_t* plain_launches, int64_t* reads_in, int64_t* reads_retried) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  drain_events(ctx);
+  if (plain_ms) *plain_ms = ctx->plain_ms;
+  if (plain_launches) *plain_launches = ctx->plain_launches;
+  if (reads_in) *reads_in = ctx->plain_total;
+  if (reads_retried) *reads_retried = ctx->plain_retried;
+  if (reset) { ctx->plain_ms = 0; ctx->plain_launches = 0; ctx->plain_total = 0; ctx->plain_retried = 0; }
   return MIA_HIP_OK;
 }
 
@@ -410,7 +436,41 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
                            : launch_window<12>(ctx, ci, ctx->d_list + h_off[ci], h_count[ci]);
     if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   }
-  if (n_quads > 0) {
+  int n_quads_trace = n_quads, quad_begin_trace = quad_begin;
+  if (n_quads > 0 && ctx->use_plain) {
+    // first pass: values only; reads whose alignment is provably the pure diagonal are finished there
+    const int grid = n_quads < ctx->quad_wgs ? n_quads : ctx->quad_wgs;
+    const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
+    hipEvent_t p0, p1;
+    if (get_events(ctx, &p0, &p1)) return MIA_HIP_ERR_NOMEM;
+    ctx->ev_plain.push_back(ctx->ev_used.back());
+    ctx->ev_used.pop_back();
+    (void)hipEventRecord(p0, ctx->stream);
+    hipLaunchKernelGGL(k_align_quad_plain, dim3(grid), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_list + quad_begin,
+                       n_quads, ctx->d_bin_of);
+    (void)hipEventRecord(p1, ctx->stream);
+    HIPCHK(hipGetLastError());
+    // re-plan what is left into quads of equal read length
+    HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ctx->stream));
+    hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_count);
+    int32_t h_count2[N_BINS], h_off2[N_BINS];
+    HIPCHK(hipMemcpyAsync(h_count2, d_count, sizeof h_count2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int run2 = 0;
+    for (int b = 0; b < N_BINS; b++) { h_off2[b] = run2; run2 += b >= BIN_QUAD0 ? ((h_count2[b] + 3) & ~3) : 0; }
+    n_quads_trace = run2 / 4;
+    quad_begin_trace = 0;
+    ctx->plain_total += (int64_t)n_quads * 4;
+    for (int b = BIN_QUAD0; b < N_BINS; b++) ctx->plain_retried += h_count2[b];
+    if (n_quads_trace > 0) {
+      HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, (size_t)run2 * 4, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d_off, h_off2, sizeof h_off2, hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
+    }
+  }
+  if (n_quads_trace > 0) {
+    const int n_quads = n_quads_trace, quad_begin = quad_begin_trace;
     const int64_t slab = (int64_t)Q_G * MAX_READ * Q_TRACE_STRIDE;
     const int grid = n_quads < ctx->quad_wgs ? n_quads : ctx->quad_wgs;
     if (!ctx->d_quad_slabs && hipMalloc((void**)&ctx->d_quad_slabs, (size_t)slab * ctx->quad_wgs) != hipSuccess) return MIA_HIP_ERR_NOMEM;

@@ -14,6 +14,7 @@
 
 #include "align_body.h"
 #include "align_body_quad.h"
+#include "align_body_quad_plain.h"
 #include "mia_layout.h"
 #include "wave_dev.h"
 
@@ -209,6 +210,67 @@ __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, c
     }
     wave.lds_fence();
   }
+}
+
+// ---- first pass over the quad bins: values only + the diagonal proof (align_body_quad_plain.h).  A proven read is
+// finished here and leaves its bin (bin_of = -1); the others keep their bin and are re-planned into quads for k_align_quad.
+__global__ __launch_bounds__(64, 4) void k_align_quad_plain(ReadSet rs, RefInfo ref, const int32_t* pssm2, const int32_t* list,
+                                                          int32_t n_quads, int32_t* bin_of) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // Q_G * q_sub_bytes(longest read)
+  DevWave wave(lds_raw, nullptr);
+  for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
+    QuadPlainArgs a;
+    int idx[Q_G];
+    a.ref_codes = ref.codes;
+    a.packed = rs.packed;
+    a.pssm2 = pssm2;
+    a.lds_sub = 0;
+    a.len2 = 1;
+    for (int g = 0; g < Q_G; g++) {
+      const int i = list[4 * qd + g];
+      idx[g] = i;
+      a.ref_start[g] = 0; a.len1[g] = 0; a.roff[g] = 0; a.rc[g] = 0; a.cols_out[g] = rs.cols;
+      if (i >= 0) {
+        int s, l1;
+        const int len2 = rs.len[i];
+        realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &l1);
+        a.len2 = len2;
+        a.ref_start[g] = s; a.len1[g] = l1; a.roff[g] = rs.roff[i]; a.rc[g] = rs.rc[i];
+        a.cols_out[g] = rs.cols + (int64_t)i * rs.stride;
+      }
+    }
+    QuadPlainResult res[Q_G];
+    QuadPlainAligner<DevWave>::run(wave, a, res);
+    if (wave.lane() == 0) {
+      for (int g = 0; g < Q_G; g++) {
+        const int i = idx[g];
+        if (i < 0 || !res[g].proven) continue;               // unproven: as/ae untouched, the trace kernel sees the same window
+        rs.score[i] = res[g].score;
+        rs.refstart[i] = a.ref_start[g];
+        rs.abr[i] = (int16_t)res[g].abr;
+        rs.as[i] = res[g].abc + a.ref_start[g];               // src/mia_main.c:254-255
+        rs.ae[i] = res[g].aec + a.ref_start[g];
+        rs.status[i] = ST_OK;
+        bin_of[i] = -1;
+      }
+    }
+    wave.lds_fence();
+  }
+}
+
+// reads still in a quad bin after the first pass (everything else is done): counts per bin
+__global__ __launch_bounds__(256) void k_plan_recount(int64_t n, int32_t* bin_of, int32_t* bin_count) {
+  __shared__ int32_t hist[N_BINS];
+  for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
+  __syncthreads();
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    int b = bin_of[i];
+    if (b >= BIN_QUAD0) atomicAdd(&hist[b], 1);
+    else if (b >= 0) bin_of[i] = -1;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
 }
 
 // ---- exact wide kernel: one read per thread, int32 scores and trace in global scratch.

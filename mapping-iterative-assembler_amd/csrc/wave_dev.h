@@ -145,6 +145,16 @@ struct DevWave {
     v = umax(v, (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false));
     return v;
   }
+  // inclusive prefix sum across the 64 lanes (same DPP ladder as scan_max; invalid sources contribute 0)
+  __device__ __forceinline__ U scan_add(U v) const {
+    v += (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 1, 0xF, 0xF, false);
+    v += (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 2, 0xF, 0xF, false);
+    v += (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 4, 0xF, 0xF, false);
+    v += (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_SHR + 8, 0xF, 0xF, false);
+    v += (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST15, 0xA, 0xF, false);
+    v += (U)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_BCAST31, 0xC, 0xF, false);
+    return v;
+  }
   __device__ __forceinline__ uint32_t reduce_max(U v) const { return (uint32_t)__builtin_amdgcn_readlane((int)scan_max(v), 63); }
   __device__ __forceinline__ uint32_t reduce_min(U v) const { return ~reduce_max(~v); }
   __device__ __forceinline__ uint64_t ballot(M m) const { return __builtin_amdgcn_ballot_w64(m); }

@@ -10,6 +10,7 @@
 #include "align_body.h"
 #include "pass1_body.h"
 #include "align_body_quad.h"
+#include "align_body_quad_plain.h"
 
 using namespace mia;
 
@@ -133,6 +134,31 @@ extern "C" int emu_align_quad(int ng, const uint8_t* ref_codes, const int32_t* r
   for (int g = 0; g < ng; g++) {
     out5[g * 5 + 0] = res[g].score; out5[g * 5 + 1] = res[g].abc; out5[g * 5 + 2] = res[g].abr; out5[g * 5 + 3] = res[g].aec;
     out5[g * 5 + 4] = (int32_t)res[g].status;
+  }
+  return 0;
+}
+
+// values-only quad body with the diagonal proof: out6 per read = score, abc, abr, aec, proven, 0
+extern "C" int emu_align_quad_plain(int ng, const uint8_t* ref_codes, const int32_t* ref_start, const int32_t* len1,
+                                    const uint8_t* read_codes /* ng x len2 */, int len2, const int32_t* pssm2, const int32_t* rc,
+                                    int32_t* out6 /* ng x 6 */, int16_t* cols /* ng x 256 */) {
+  const uint32_t stride = (uint32_t)(((len2 + 1) / 2 + 3) & ~3);
+  std::vector<uint8_t> packed((size_t)stride * 4 + 8, 0);
+  QuadPlainArgs a;
+  a.ref_codes = ref_codes; a.packed = packed.data(); a.pssm2 = pssm2; a.len2 = len2; a.lds_sub = 0;
+  for (int g = 0; g < Q_G; g++) {
+    a.ref_start[g] = 0; a.len1[g] = 0; a.roff[g] = 0; a.rc[g] = 0; a.cols_out[g] = cols + g * 256;
+    if (g < ng) {
+      a.ref_start[g] = ref_start[g]; a.len1[g] = len1[g]; a.roff[g] = (uint32_t)g * stride; a.rc[g] = (uint32_t)rc[g];
+      for (int i = 0; i < len2; i++) packed[a.roff[g] + (i >> 1)] |= (uint8_t)(read_codes[g * len2 + i] << ((i & 1) * 4));
+    }
+  }
+  EmuWave w(Q_G * q_sub_bytes(len2) + 64, 64);
+  QuadPlainResult res[Q_G];
+  QuadPlainAligner<EmuWave>::run(w, a, res);
+  for (int g = 0; g < ng; g++) {
+    out6[g * 6 + 0] = res[g].score; out6[g * 6 + 1] = res[g].abc; out6[g * 6 + 2] = res[g].abr; out6[g * 6 + 3] = res[g].aec;
+    out6[g * 6 + 4] = res[g].proven; out6[g * 6 + 5] = 0;
   }
   return 0;
 }

@@ -102,6 +102,7 @@ struct EmuWave {
   static U umax3(const U& x, const U& y, const U& z) { return umax(umax(x, y), z); }
   static U sel(const M& c, const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = c.a[i] ? x.a[i] : y.a[i]; return r; }
   U scan_max(const U& v) const { EV r; uint32_t m = 0; for (int i = 0; i < 64; i++) { m = v.a[i] > m ? v.a[i] : m; r.a[i] = m; } return r; }
+  U scan_add(const U& v) const { EV r; uint32_t m = 0; for (int i = 0; i < 64; i++) { m += v.a[i]; r.a[i] = m; } return r; }
   uint32_t reduce_max(const U& v) const { return scan_max(v).a[63]; }
   uint32_t reduce_min(const U& v) const { return ~reduce_max(~v); }
   uint64_t ballot(const M& m) const { uint64_t b = 0; for (int i = 0; i < 64; i++) if (m.a[i]) b |= 1ull << i; return b; }

@@ -195,6 +195,90 @@ def test_emul_quad_kernel(emul, oracle):
     assert 0 < n_band_escapes < 40
 
 
+def test_emul_quad_plain_kernel(emul, oracle):
+    """values-only quad body (align_body_quad_plain.h): score and end column always equal the oracle's; whenever it
+    claims the diagonal proof, begin point and script equal the oracle's too, and a gap-free, clip-free oracle
+    alignment whose diagonal prefix never drops to the start level must be proven"""
+    rnd = random.Random(77)
+    flat = _pssm(oracle, "flat", 0)
+    anc = _pssm(oracle, "ancient.submat.txt", 0)
+    anc_rc = _pssm(oracle, "ancient.submat.txt", 1)
+    emul.emu_align_quad_plain.restype = C.c_int
+    n_proven = n_gapped = n_clip = n_quirk = 0
+    for it in range(140):
+        len2 = rnd.choice([1, 2, 17, 50, 100, 100, 100, 101, 150, 200])
+        ng = rnd.choice([1, 2, 3, 4, 4, 4])
+        use_anc = it % 2
+        fwd = np.ctypeslib.as_array((anc if use_anc else flat).sm).reshape(-1)
+        rcm = np.ctypeslib.as_array((anc_rc if use_anc else flat).sm).reshape(-1)
+        pssm2 = np.concatenate([fwd, rcm]).astype(np.int32)
+        ref = "".join(rnd.choice("ACGT") for _ in range(1000))
+        if it % 9 == 0:
+            ref = ref[:200] + "N" + ref[201:330] + "R" + ref[331:]
+        refc = codes(ref)
+        starts, len1s, reads, rcs = [], [], [], []
+        for g in range(ng):
+            st = rnd.randint(0, 300)
+            l1 = min(208, max(len2, rnd.randint(max(len2, 2), 208)))
+            lead = rnd.choice([min(50, max(0, l1 - len2)), 0, rnd.randint(0, max(0, l1 - len2))])
+            frag = list(ref[st + lead:][:len2])
+            kind = rnd.random()
+            for _ in range(rnd.randint(0, 3)):
+                frag[rnd.randrange(len(frag))] = rnd.choice("ACGTN")
+            if len2 > 20 and kind < 0.25:                        # indel
+                p = rnd.randrange(3, len2 - 3)
+                if rnd.random() < 0.5:
+                    frag[p:p + rnd.randint(1, 2)] = []
+                    frag += [rnd.choice("ACGT") for _ in range(len2 - len(frag))]
+                else:
+                    frag[p:p] = [rnd.choice("ACGT") for _ in range(rnd.randint(1, 3))]
+                    frag = frag[:len2]
+            elif len2 > 30 and kind < 0.4:                       # junk at the 5' end: soft clip / bad prefix
+                k = rnd.randint(3, 15)
+                frag[:k] = [rnd.choice("ACGT") for _ in range(k)]
+            starts.append(st); len1s.append(l1); reads.append("".join(frag)[:len2].ljust(len2, "A")); rcs.append(rnd.randint(0, 1))
+        rd = np.concatenate([codes(r) for r in reads]).astype(np.uint8)
+        out = (C.c_int32 * (6 * ng))()
+        cols = np.full(4 * 256, -9, dtype=np.int16)
+        assert emul.emu_align_quad_plain(ng, refc.ctypes.data_as(C.c_void_p), (C.c_int32 * ng)(*starts), (C.c_int32 * ng)(*len1s),
+                                         rd.ctypes.data_as(C.c_void_p), len2, pssm2.ctypes.data_as(C.c_void_p), (C.c_int32 * ng)(*rcs),
+                                         out, cols.ctypes.data_as(C.c_void_p)) == 0
+        for g in range(ng):
+            s1 = ref[starts[g]:starts[g] + len1s[g]]
+            pm = (anc_rc if rcs[g] else anc) if use_anc else flat
+            res = oc.Aln(); rg = C.create_string_buffer(520); fg = C.create_string_buffer(520)
+            oracle.ora_align(s1.encode(), len(s1), reads[g].encode(), len2, None, C.byref(pm), 1, C.byref(res), rg, fg, None, None)
+            score, abc, abr, aec, proven, _ = list(out[g * 6:(g + 1) * 6])
+            assert (score, aec) == (res.best, res.aec), (it, g)
+            gapped = b"-" in rg.value or b"-" in fg.value
+            n_gapped += gapped
+            n_clip += res.abr > 0 and res.abc > 0
+            if proven:
+                n_proven += 1
+                assert not gapped and (abc, abr) == (res.abc, res.abr), (it, g)
+                c = cols[g * 256: g * 256 + len2]
+                assert (c[:abr] == -2).all() and np.array_equal(c[abr:], np.arange(abr, len2) + (aec - (len2 - 1))), (it, g)
+            elif not gapped and not (res.abr > 0 and res.abc > 0):
+                # unproven although the oracle's path LOOKS like a pure diagonal: allowed only if the diagonal prefix sank
+                # below the level of a new start somewhere (condition (ii) of the proof), or if the score is not the
+                # diagonal's own sum -- a gap whose source index is 0 has T == 0 and is read back as a diagonal step
+                # (src/mia.c:619), so the reported path can be gap-free while the score came through the gap
+                d = res.aec - (len2 - 1)
+                r0 = max(0, -d)
+                sm = np.ctypeslib.as_array(pm.sm).reshape(31, 5, 5)
+                c1, c2 = codes(s1), codes(reads[g])
+                D = 0
+                sank = False
+                for r in range(r0, len2):
+                    dep = r if r < 15 else (30 - (len2 - r - 1) if len2 - (r + 1) < 15 else 15)
+                    D += int(sm[dep][c1[r + d]][c2[r]]) + (-(1000 + 200 * (r0 + 1)) if (r == r0 and d < 0) else 0)
+                    if r < len2 - 1 and D < -(1000 + 200 * (r + 2)):
+                        sank = True
+                n_quirk += D != res.best
+                assert sank or D != res.best, (it, g, s1, reads[g])
+    assert n_proven > 150 and n_gapped > 40 and n_clip > 5, (n_proven, n_gapped, n_clip)
+
+
 def test_trim_lastcol_mode(emul, oracle):
     """the LASTCOL end condition of the window aligner (trim_frag) on the reference's own trim vectors and on
     random pairs against the oracle; reads whose path holds a gap of 63 or more report ST_ESCAPE (the GPU then
