@@ -146,7 +146,7 @@ def main():
         t0 = time.perf_counter()
         hip.realign(cur_ref, True)
         t0 = tick("realign", t0)
-        score, _, _ = hip.alignments()
+        score = hip.scores()
         t0 = tick("get_scores", t0)
         slot_base = 0
         sharded = world > 1 or force_dist

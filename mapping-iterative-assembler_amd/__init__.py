@@ -204,6 +204,12 @@ class MiaHip:
         self._chk(self._l.mia_hip_get_alignments(self._h, _ptr(s), _ptr(a), _ptr(e)))
         return s, a, e
 
+    def scores(self):
+        """fs->score only (4 bytes per read over PCIe instead of 12)."""
+        s = np.empty(self.n, dtype=np.int32)
+        self._chk(self._l.mia_hip_get_alignments(self._h, _ptr(s), None, None))
+        return s
+
     def scripts(self):
         cols = np.empty((self.n, max(self.max_len, 1)), dtype=np.int16)
         rs = np.empty(self.n, dtype=np.int32)

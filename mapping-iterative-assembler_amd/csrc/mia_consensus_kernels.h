@@ -137,6 +137,10 @@ __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const i
   const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
   const int cbase = rs.refstart[i] - g.start_w;
   int nf = 0, nb = 0, af = 0;
+  if (rs.status[i] & ST_DIAG) {
+    // one column per read base from the alignment start on: nothing to count in the script
+    af = (len2 - abr) < g.ncols_f ? (len2 - abr) : g.ncols_f;
+  } else
   for (int r0 = abr; r0 < len2; r0 += 64) {
     const int r = r0 + lane;
     bool isF = false, isB = false, alF = false;
@@ -279,7 +283,8 @@ constexpr int TALLY_BUCKET = 256, TALLY_WIN = 768, TALLY_CHUNK = 1024;
 template <bool BINNED>
 __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSet& rs, const RefInfo& ref, const int32_t* pssm2,
                                                const uint8_t* drop_front, const uint8_t* drop_back, const TallyBuf& tb,
-                                               int32_t* lds, int win_base, const int32_t* rec_params, const int32_t* rec_actf) {
+                                               int32_t* lds, int win_base, const int32_t* rec_params, const int32_t* rec_actf,
+                                               const int16_t* pssm_lds) {
   if (!rs.sk[i]) return;
   if (rs.status[i] & ST_TOO_LONG) { if (lane == 0) atomicOr(tb.flags, 2u); return; }
   const int L = ref.L, Lp = tb.Lp;
@@ -288,8 +293,10 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
   const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
   const int cbase = rs.refstart[i] - g.start_w;     // path offset of window column 0
   const uint8_t* rp = rs.packed + rs.roff[i];
-  const int32_t* pm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);   // src/mia.c:584-589
+  const int pmo = rs.rc[i] ? PSSM_WORDS : 0;                // src/mia.c:584-589
+  const int32_t* pm = pssm2 + pmo;
   const bool dF = drop_front[i], dB = drop_back[i];
+  const bool diag = (rs.status[i] & ST_DIAG) != 0;           // proven pure diagonal: the script is not needed
   if (g.split && g.start_w >= L) { if (lane == 0) atomicOr(tb.flags, 2u); return; }  // split_pwaln mis-places such a record
   // depth-code parameters and multiplicity of the two records (k_rec_params): normally {0, 0, flen+blen, 1} for the
   // front and {flen, bases in the front, flen+blen, 1} for the back (src/fsdb.c:568-581,597-610)
@@ -320,11 +327,13 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
       if (code == 5) atomicAdd(&t[T_GAP * ws], mult);
       else {
         if (code < 4) atomicAdd(&t[(T_A + code) * ws], mult);
-        const int32_t* row = pm + d * 25 + code;           // sm[d][X][code], X = A,C,G,T (src/map_align.c:258-261)
-        atomicAdd(&t[T_SA * ws], mult * row[0]);
-        atomicAdd(&t[T_SC * ws], mult * row[5]);
-        atomicAdd(&t[T_SG * ws], mult * row[10]);
-        atomicAdd(&t[T_ST * ws], mult * row[15]);
+        int s0, s1, s2, s3;                                // sm[d][X][code], X = A,C,G,T (src/map_align.c:258-261)
+        if (BINNED) { const int16_t* row = pssm_lds + pmo + d * 25 + code; s0 = row[0]; s1 = row[5]; s2 = row[10]; s3 = row[15]; }
+        else { const int32_t* row = pm + d * 25 + code; s0 = row[0]; s1 = row[5]; s2 = row[10]; s3 = row[15]; }
+        atomicAdd(&t[T_SA * ws], mult * s0);
+        atomicAdd(&t[T_SC * ws], mult * s1);
+        atomicAdd(&t[T_SG * ws], mult * s2);
+        atomicAdd(&t[T_ST * ws], mult * s3);
       }
     }
     if (p > 0) atomicAdd(&t[T_SPAN * ws], mult);           // start < pos <= end (src/map_align.c:466-469), dropped or not
@@ -333,8 +342,9 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
   for (int r0 = abr; r0 < len2; r0 += 64) {
     const int r = r0 + lane;
     if (r >= len2) continue;
-    const int cv = cols[r];
     const int code = (rp[r >> 1] >> ((r & 1) * 4)) & 15;
+    if (diag) { emit(r - abr, r - abr, code); continue; }   // column offset == bases before it
+    const int cv = cols[r];
     if (cv >= 0) {
       const int o = cbase + cv, act = r - abr;
       if (r > abr && cols[r - 1] >= 0)
@@ -371,7 +381,7 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= rs.n) return;
-  tally_one_read<false>(i, lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0, rec_params, rec_actf);
+  tally_one_read<false>(i, lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0, rec_params, rec_actf, nullptr);
 }
 
 // ---- bucketing of the reads by alignment start (counting sort, one pass per iteration) ----
@@ -411,7 +421,8 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
                                                        const int32_t* rec_actf) {
-  __shared__ int32_t lds[TALLY_WORDS * TALLY_WIN];
+  __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
+  __shared__ int16_t pssm_lds[2 * PSSM_WORDS];               // both matrices: every aligned base looks four entries up
   if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
   // which bucket does this workgroup belong to?  (wgoff is ascending, nb <= a few hundred)
   int lo = 0, hi = nb;
@@ -419,13 +430,14 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   const int b = lo, chunk = (int)blockIdx.x - wgoff[b];
   const int first = off[b] + chunk * TALLY_CHUNK, last = min(first + TALLY_CHUNK, off[b + 1]);
   const int win_base = b * TALLY_BUCKET;
-  for (int k = threadIdx.x; k < TALLY_WORDS * TALLY_WIN; k += blockDim.x) lds[k] = 0;
+  for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) lds[k] = 0;
+  for (int k = threadIdx.x; k < 2 * PSSM_WORDS; k += blockDim.x) pssm_lds[k] = (int16_t)pssm2[k];
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = first + wv; k < last; k += 4) tally_one_read<true>(order[k], lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base, rec_params, rec_actf);
+  for (int k = first + wv; k < last; k += 4) tally_one_read<true>(order[k], lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base, rec_params, rec_actf, pssm_lds);
   __syncthreads();
   const int Lp = tb.Lp;
-  for (int k = threadIdx.x; k < TALLY_WORDS * TALLY_WIN; k += blockDim.x) {
+  for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) {
     const int v = lds[k];
     const int word = k / TALLY_WIN, gc = win_base + (k - word * TALLY_WIN);
     if (v != 0 && gc < Lp) atomicAdd(&tb.tally[word * Lp + gc], v);

@@ -862,7 +862,7 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
   if (n > 0) {
     RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
     const int nb = ctx->wrap / TALLY_BUCKET + 1;
-    if (ctx->use_binned_tally && nb <= 4096) {
+    if (ctx->use_binned_tally && nb <= 4096 && ctx->max_abs <= 32767) {   // (the LDS copy of the matrices is int16)
       // counting sort of the reads by alignment start, then one LDS tally window per workgroup
       if (nb + 1 > ctx->bucket_cap) {
         if (dev_alloc(ctx, &ctx->d_bucket, (size_t)4 * (nb + 1))) return MIA_HIP_ERR_NOMEM;

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64, 4) void k_align_quad_plain(ReadSet rs, RefInfo 
         rs.abr[i] = (int16_t)res[g].abr;
         rs.as[i] = res[g].abc + a.ref_start[g];               // src/mia_main.c:254-255
         rs.ae[i] = res[g].aec + a.ref_start[g];
-        rs.status[i] = ST_OK;
+        rs.status[i] = ST_DIAG;
         bin_of[i] = -1;
       }
     }
