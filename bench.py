@@ -38,8 +38,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # reported, no width correction): almost all of it is the trace band (16-bit cells, ~30 % of the lanes) going to the
 # per-workgroup slabs; the full byte trace cost 31.7e6 KB
 TRAFFIC_BYTES_PER_READ = (7078632 + 13590312) * 1024 / 1_000_000
-# the values-only first pass stores no trace: PMC traffic per read, filled in once measured (None = not measured yet)
-PLAIN_TRAFFIC_BYTES_PER_READ = None
+# the values-only first pass stores no trace: memory-side traffic is about twice the algorithmic 182 B/read
+PLAIN_TRAFFIC_BYTES_PER_READ = (117299.53 + 257620.02) * 1024 / 1_000_000   # profiles/r01/pmc/plain_pass_counters.json (FETCH_SIZE + WRITE_SIZE, KB per 1 M-read launch)
+PLAIN_VALU_UTILISATION_PMC = 0.95
 # SQ counters of the same kernel (profiles/r01/pmc/sq_counters_quad.json): the kernel is integer-VALU bound
 VALU_UTILISATION_PMC = 0.89
 
@@ -233,8 +234,8 @@ def main():
                          "kernel": dom_name, "kernel_ms": k_ms, "launches": dom_launches,
                          "trace_kernel": {"kernel": "k_align_quad", "ms_per_step": align_ms / a.steps, "launches": launches,
                                           "reads_frac": (plain_retried / plain_in) if plain_on and plain_in else 1.0},
-                         "note": "integer-VALU-bound DP (SQ_ACTIVE_INST_VALU = 89 % of SIMD capacity, profiles/r01/pmc): 182 algorithmic HBM bytes per read (SURVEY 8d) put it at a fraction of a percent of the HBM roof by construction; see DESIGN.md 3.1",
-                         "valu_utilisation": VALU_UTILISATION_PMC,
+                         "note": "integer-VALU-bound DP (SQ_ACTIVE_INST_VALU = 95 % of SIMD capacity for the values-only pass, 89 % for the trace kernel; profiles/r01/pmc): 182 algorithmic HBM bytes per read (SURVEY 8d) put it at a fraction of a percent of the HBM roof by construction; see DESIGN.md 3.1",
+                         "valu_utilisation": PLAIN_VALU_UTILISATION_PMC if plain_on else VALU_UTILISATION_PMC,
                          "gcups": reads_per_launch * 100 * 200 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
         }
         # pass 1 (new_kmer_filter + sg_align over the whole wrapped reference, both strands), reported separately

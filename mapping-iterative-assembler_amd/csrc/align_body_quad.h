@@ -192,10 +192,14 @@ struct QuadAligner {
     // rows are processed in pairs so that the substitution-table address of a column is bumped once per two rows
     const int rows = (a.dbg & 4u) ? 1 : len2;
     for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 2u;      // -> row 1
-    for (int r = 1; r < rows; r += 2) {
-      do_row(r, 0u);
-      if (r + 1 < rows) do_row(r + 1, 2u);
-      for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 4u;
+    {
+      int r = 1;
+      for (; r + 1 < rows; r += 2) {        // straight-line row pairs (no copies of the column state between rows)
+        do_row(r, 0u);
+        do_row(r + 1, 2u);
+        for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 4u;
+      }
+      if (r < rows) do_row(r, 0u);
     }
 
     // ---- max_sg_score per read (16-lane row); the state words order like scores

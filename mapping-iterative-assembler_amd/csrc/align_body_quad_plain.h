@@ -127,10 +127,14 @@ struct QuadPlainAligner {
       }
     };
     for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 2u;      // -> row 1
-    for (int r = 1; r < len2; r += 2) {
-      do_row(0u);
-      if (r + 1 < len2) do_row(2u);
-      for (int j = 0; j < CPL; j++) { sub_addr[j] = sub_addr[j] + 4u; w.keep(sub_addr[j]); }
+    {
+      int r = 1;
+      for (; r + 1 < len2; r += 2) {        // straight-line row pairs: every column is updated in place, no copies between rows
+        do_row(0u);
+        do_row(2u);
+        for (int j = 0; j < CPL; j++) { sub_addr[j] = sub_addr[j] + 4u; w.keep(sub_addr[j]); }
+      }
+      if (r < len2) do_row(0u);
     }
 
     // ---- max_sg_score (src/mia.c:1278-1302): last row, first maximum.  S + PB = kk - GEP*(len2-1) - GEP*c

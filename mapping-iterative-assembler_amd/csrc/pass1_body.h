@@ -218,10 +218,14 @@ struct Pass1Aligner {
     };
     // rows in pairs: the substitution-table address of a column is bumped once per two rows
     for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 2u;      // -> row 1
-    for (int r = 1; r < len2; r += 2) {
-      do_row(r, 0u);
-      if (r + 1 < len2) do_row(r + 1, 2u);
-      for (int j = 0; j < CPL; j++) { sub_addr[j] = sub_addr[j] + 4u; w.keep(sub_addr[j]); }
+    {
+      int r = 1;
+      for (; r + 1 < len2; r += 2) {        // straight-line row pairs (no copies of the column state between rows)
+        do_row(r, 0u);
+        do_row(r + 1, 2u);
+        for (int j = 0; j < CPL; j++) { sub_addr[j] = sub_addr[j] + 4u; w.keep(sub_addr[j]); }
+      }
+      if (r < len2) do_row(r, 0u);
     }
     // last row: maximum and its first column inside this chunk (state words order like scores; absent cells are 0)
     U m = U(0u);
@@ -509,10 +513,14 @@ struct Pass1Aligner {
       }
     };
     for (int j = 0; j < CPL; j++) sub_addr[j] = sub_addr[j] + 2u;
-    for (int r = 1; r < len2; r += 2) {
-      do_row(r, 0u);
-      if (r + 1 < len2) do_row(r + 1, 2u);
-      for (int j = 0; j < CPL; j++) { sub_addr[j] = sub_addr[j] + 4u; w.keep(sub_addr[j]); }
+    {
+      int r = 1;
+      for (; r + 1 < len2; r += 2) {        // straight-line row pairs (no copies of the column state between rows)
+        do_row(r, 0u);
+        do_row(r + 1, 2u);
+        for (int j = 0; j < CPL; j++) { sub_addr[j] = sub_addr[j] + 4u; w.keep(sub_addr[j]); }
+      }
+      if (r < len2) do_row(r, 0u);
     }
     // last row: back to scores (still biased by PB): S = kk - GEP*(len2-1) - GEP*c
     U m = zero, sc[CPL];
