@@ -126,46 +126,63 @@ struct Links {                // [cap][4] int64: reader (global read index), slo
 };
 
 // inserted bases per record and bases in the front: one read per wavefront (the script walk of the tally's pass A)
+// A block takes 256 reads.  Proven-diagonal reads (ST_DIAG, the large majority) need no script: one thread each.  The
+// others are walked by the block's four wavefronts, 64 script rows at a time (ballot counts).
+__device__ __forceinline__ void rec_store(int64_t i, const RecGeom& g, int nf, int nb, int af, int bases, const int64_t* slot, RecInfo& ri,
+                                          SlotInfo& si, int64_t read_base, uint32_t* flags) {
+  const int flen = g.ncols_f + nf, blen = g.split ? g.ncols_b + nb : 0;
+  ri.flen[i] = flen; ri.blen[i] = blen; ri.actf[i] = af + nf;
+  const int64_t ls = slot[i] - si.base;
+  if (ls >= 0 && ls + (g.split ? 1 : 0) < si.n_local) {
+    const unsigned long long me = ((unsigned long long)(read_base + i) << 20) | LINK_NONE;
+    si.reclen[ls] = flen; si.recact[ls] = af + nf; si.mult[ls] = 1; si.writer[ls] = me;
+    if (g.split) { si.reclen[ls + 1] = blen; si.recact[ls + 1] = bases - (af + nf); si.mult[ls + 1] = 1; si.writer[ls + 1] = me; }
+  } else atomicOr(flags, 4u);
+}
+
 __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const int64_t* slot, RecInfo ri, SlotInfo si, int64_t read_base,
                                                     uint32_t* flags) {
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= rs.n) return;
-  if (!rs.sk[i]) { if (lane == 0) { ri.flen[i] = 0; ri.blen[i] = 0; ri.actf[i] = 0; } return; }
-  const int len2 = rs.len[i], abr = rs.abr[i];
-  const RecGeom g = rec_geom(rs.as[i], rs.ae[i], L);
-  const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
-  const int cbase = rs.refstart[i] - g.start_w;
-  int nf = 0, nb = 0, af = 0;
-  if (rs.status[i] & ST_DIAG) {
-    // one column per read base from the alignment start on: nothing to count in the script
-    af = (len2 - abr) < g.ncols_f ? (len2 - abr) : g.ncols_f;
-  } else
-  for (int r0 = abr; r0 < len2; r0 += 64) {
-    const int r = r0 + lane;
-    bool isF = false, isB = false, alF = false;
-    if (r < len2) {
-      if (cols[r] == COL_INSERT) {
-        int rn = r + 1;
-        while (rn < len2 && cols[rn] < 0) rn++;
-        const int o = cbase + cols[rn];
-        if (o < g.ncols_f) isF = true; else if (g.split && o - g.ncols_f < g.ncols_b) isB = true;
-      } else if (cols[r] >= 0) {
-        alF = (cbase + cols[r]) < g.ncols_f;
-      }
-    }
-    nf += __popcll(__ballot(isF));
-    nb += __popcll(__ballot(isB));
-    af += __popcll(__ballot(alF));
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);     // first read of this wavefront
+  const int64_t me = i0 + lane;
+  bool walk = false;
+  if (me < rs.n) {
+    if (!rs.sk[me]) { ri.flen[me] = 0; ri.blen[me] = 0; ri.actf[me] = 0; }
+    else if (rs.status[me] & ST_DIAG) {
+      // one column per read base from the alignment start on: nothing to count in the script
+      const int len2 = rs.len[me], abr = rs.abr[me];
+      const RecGeom g = rec_geom(rs.as[me], rs.ae[me], L);
+      const int af = (len2 - abr) < g.ncols_f ? (len2 - abr) : g.ncols_f;
+      rec_store(me, g, 0, 0, af, len2 - abr, slot, ri, si, read_base, flags);
+    } else walk = true;
   }
-  if (lane == 0) {
-    const int flen = g.ncols_f + nf, blen = g.split ? g.ncols_b + nb : 0;
-    ri.flen[i] = flen; ri.blen[i] = blen; ri.actf[i] = af + nf;
-    const int64_t ls = slot[i] - si.base;
-    if (ls >= 0 && ls + (g.split ? 1 : 0) < si.n_local) {
-      si.reclen[ls] = flen; si.recact[ls] = af + nf; si.mult[ls] = 1; si.writer[ls] = ((unsigned long long)(read_base + i) << 20) | LINK_NONE;
-      if (g.split) { si.reclen[ls + 1] = blen; si.recact[ls + 1] = (len2 - abr) - (af + nf); si.mult[ls + 1] = 1; si.writer[ls + 1] = ((unsigned long long)(read_base + i) << 20) | LINK_NONE; }
-    } else atomicOr(flags, 4u);
+  unsigned long long todo = __ballot(walk);
+  while (todo) {
+    const int64_t i = i0 + __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const int len2 = rs.len[i], abr = rs.abr[i];
+    const RecGeom g = rec_geom(rs.as[i], rs.ae[i], L);
+    const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
+    const int cbase = rs.refstart[i] - g.start_w;
+    int nf = 0, nb = 0, af = 0;
+    for (int r0 = abr; r0 < len2; r0 += 64) {
+      const int r = r0 + lane;
+      bool isF = false, isB = false, alF = false;
+      if (r < len2) {
+        if (cols[r] == COL_INSERT) {
+          int rn = r + 1;
+          while (rn < len2 && cols[rn] < 0) rn++;
+          const int o = cbase + cols[rn];
+          if (o < g.ncols_f) isF = true; else if (g.split && o - g.ncols_f < g.ncols_b) isB = true;
+        } else if (cols[r] >= 0) {
+          alF = (cbase + cols[r]) < g.ncols_f;
+        }
+      }
+      nf += __popcll(__ballot(isF));
+      nb += __popcll(__ballot(isB));
+      af += __popcll(__ballot(alF));
+    }
+    if (lane == 0) rec_store(i, g, nf, nb, af, len2 - abr, slot, ri, si, read_base, flags);
   }
 }
 

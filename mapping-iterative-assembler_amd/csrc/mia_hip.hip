@@ -627,7 +627,7 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   ctx->si.n_local = total;
   HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 4, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_cull_flags, 0, 4, ctx->stream));
-  hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
+  hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
                      ctx->read_base, ctx->d_cull_flags);
   hipLaunchKernelGGL(k_cull_mark, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
                      ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot, ctx->d_front_slot0, ctx->ri, ctx->lk, ctx->read_base,
@@ -702,7 +702,7 @@ extern "C" int mia_hip_set_links(mia_hip_ctx* ctx, const int64_t* d_links_all, i
   // slot state back to "owners only", then every link once
   const int64_t n = ctx->rs.n;
   HIPCHK(hipMemsetAsync(ctx->d_cull_flags, 0, 4, ctx->stream));
-  hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
+  hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
                      ctx->read_base, ctx->d_cull_flags);
   HIPCHK(hipGetLastError());
   return finish_cull(ctx);
