@@ -147,18 +147,26 @@ def main():
         t0 = time.perf_counter()
         hip.realign(cur_ref, True)
         t0 = tick("realign", t0)
-        score = hip.scores()
-        t0 = tick("get_scores", t0)
         slot_base = 0
         sharded = world > 1 or force_dist
+        # find_fsdb_score_cut: pass 1 (integer sums, length range) on the device; with equally long reads that is the
+        # whole regression.  Only reads of different lengths need the sequential double sums over the scores on the host.
+        sums = hip.score_sums()
         if sharded:
             from mia_amd import dist as mdist
-            # the score-cut regression runs over ALL reads in fsdb order (src/fsdb.c:269-383)
-            all_scores = mdist.all_gather_concat(torch.from_numpy(score).cuda()).cpu().numpy()
-            slope, intercept = hip.score_cut(all_scores, np.tile(lens, world))
+            sums = mdist.allreduce_score_sums(sums, "cuda")
             slot_base = mdist.exclusive_rank_sum(hip.num_records(), "cuda")
-        else:
-            slope, intercept = hip.score_cut(score, lens)
+        t0 = tick("score_sums", t0)
+        cut = hip.score_cut_from_sums(sums)
+        if cut is None:
+            score = hip.scores()
+            if sharded:
+                # the regression runs over ALL reads in fsdb order (src/fsdb.c:269-383)
+                all_scores = mdist.all_gather_concat(torch.from_numpy(score).cuda()).cpu().numpy()
+                cut = hip.score_cut(all_scores, np.tile(lens, world))
+            else:
+                cut = hip.score_cut(score, lens)
+        slope, intercept = cut
         t0 = tick("score_cut", t0)
         if slope <= 0:
             slope = 100.0

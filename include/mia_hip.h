@@ -148,6 +148,13 @@ int mia_hip_finish_links(mia_hip_ctx *ctx);
  * unique_best may be NULL (= all 1). */
 void mia_hip_score_cut(const int32_t *score, const int32_t *seq_len, const uint8_t *unique_best, int64_t n,
                        double *slope, double *intercept);
+/* Pass 1 of find_fsdb_score_cut on the device: sums5 = {sum of seq_len, sum of score, count, min seq_len, max seq_len}
+ * over the reads with score >= FIRST_ROUND_SCORE_CUTOFF (integers: exact, all-reducible).  When all those reads have the
+ * same length the whole regression follows from the sums (slope_bf = 0/0): mia_hip_score_cut_from_sums (host helper)
+ * returns 0 and fills slope/intercept exactly as the reference's arithmetic would; it returns 1 when the lengths
+ * differ and the sequential double sums need the scores on the host (mia_hip_get_alignments + mia_hip_score_cut). */
+int mia_hip_score_sums(mia_hip_ctx *ctx, int64_t *sums5);
+int mia_hip_score_cut_from_sums(const int64_t *sums5, double *slope, double *intercept);
 /* number of AlnSeq records (1 per read, 2 if split at the origin) of this context */
 int mia_hip_num_records(mia_hip_ctx *ctx, int64_t *n_records);
 

@@ -66,6 +66,9 @@ def _load():
     lib.mia_hip_link_lengths.argtypes = [vp, P(vp), P(vp), P(C.c_int64)]
     lib.mia_hip_finish_links.argtypes = [vp]
     lib.mia_hip_plain_stats.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64), P(C.c_int64), P(C.c_int64)]
+    lib.mia_hip_score_sums.argtypes = [vp, vp]
+    lib.mia_hip_score_cut_from_sums.argtypes = [vp, P(C.c_double), P(C.c_double)]
+    lib.mia_hip_score_cut_from_sums.restype = C.c_int
     lib.mia_hip_trim_stats.argtypes = [vp, P(C.c_int64)]
     lib.mia_hip_get_ins_tally.argtypes = [vp, vp, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
@@ -90,7 +93,8 @@ def exported_symbols():
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
-            "mia_hip_finish_links", "mia_hip_plain_stats"]
+            "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
+            "mia_hip_score_cut_from_sums"]
 
 
 def _ptr(a):
@@ -222,6 +226,20 @@ class MiaHip:
         ub = None if unique_best is None else np.ascontiguousarray(unique_best, dtype=np.uint8)
         s, i = C.c_double(), C.c_double()
         self._l.mia_hip_score_cut(_ptr(score), _ptr(seq_len), _ptr(ub), len(score), C.byref(s), C.byref(i))
+        return s.value, i.value
+
+    def score_sums(self):
+        """{sum len, sum score, count, min len, max len} of the reads the score-cut regression uses, reduced on the device."""
+        s5 = np.zeros(5, dtype=np.int64)
+        self._chk(self._l.mia_hip_score_sums(self._h, _ptr(s5)))
+        return s5
+
+    def score_cut_from_sums(self, sums5):
+        """(slope, intercept) if the regression follows from the sums alone (all used reads equally long), else None."""
+        s5 = np.ascontiguousarray(sums5, dtype=np.int64)
+        s, i = C.c_double(), C.c_double()
+        if self._l.mia_hip_score_cut_from_sums(_ptr(s5), C.byref(s), C.byref(i)) != 0:
+            return None
         return s.value, i.value
 
     def cull(self, hard_cut=0, slope=0.0, intercept=0.0, slot_base=0):

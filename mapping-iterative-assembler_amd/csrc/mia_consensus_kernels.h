@@ -87,6 +87,35 @@ __global__ void k_scan_apply(ReadSet rs, int32_t L, const int64_t* partial, int6
   }
 }
 
+// ---- first pass of find_fsdb_score_cut (src/fsdb.c:269-383) on the device: the sums of length and score over the reads
+// the regression uses (unique_best, score >= 2000) are sums of integers -- exact in any order -- plus the length range.
+// out: {sum len, sum score, count, min len, max len}
+__global__ __launch_bounds__(256) void k_score_sums(ReadSet rs, unsigned long long* out) {
+  __shared__ unsigned long long sh[3][256];
+  __shared__ int shl[2][256];
+  unsigned long long sx = 0, sy = 0, j = 0;
+  int lmin = INT32_MAX, lmax = INT32_MIN;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rs.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int sc = rs.score[i], ln = rs.len[i];
+    if (sc >= 2000) { sx += (unsigned long long)ln; sy += (unsigned long long)sc; j++; lmin = ln < lmin ? ln : lmin; lmax = ln > lmax ? ln : lmax; }
+  }
+  sh[0][threadIdx.x] = sx; sh[1][threadIdx.x] = sy; sh[2][threadIdx.x] = j; shl[0][threadIdx.x] = lmin; shl[1][threadIdx.x] = lmax;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+      shl[0][threadIdx.x] = min(shl[0][threadIdx.x], shl[0][threadIdx.x + o]);
+      shl[1][threadIdx.x] = max(shl[1][threadIdx.x], shl[1][threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&out[0], sh[0][0]); atomicAdd(&out[1], sh[1][0]); atomicAdd(&out[2], sh[2][0]);
+    atomicMin(reinterpret_cast<long long*>(&out[3]), (long long)shl[0][0]);
+    atomicMax(reinterpret_cast<long long*>(&out[4]), (long long)shl[1][0]);
+  }
+}
+
 // ---- cull_maln_from_fsdb (src/mia.c:451-481): `dropped` is sticky per AlnSeq slot -----
 //
 // The reference addresses AlnSeq records through fs->front_asp / fs->back_asp.  reiterate_assembly sets back_asp only

@@ -56,6 +56,7 @@ struct mia_hip_ctx {
   int64_t* d_links_all = nullptr; int32_t n_links_all = 0; int64_t links_all_cap = 0;   // links to apply (own, or gathered from all ranks)
   int32_t* d_link_len = nullptr; int64_t link_len_cap = 0;
   uint32_t* d_cull_flags = nullptr;
+  unsigned long long* d_sums = nullptr;
   int64_t read_base = 0;                   // global index of this context's first read (sharded runs)
   int64_t slot_base = 0;
   bool culled = false, links_applied = false;
@@ -163,7 +164,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact};
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -801,6 +802,43 @@ extern "C" void mia_hip_score_cut(const int32_t* score, const int32_t* seq_len, 
   *intercept = intercept_bf;
   if ((slope_bf - max_delta) > 0) *slope = slope_bf - (max_delta * 2.0);
   else *slope = (double)(slope_bf * (80 / 100.0));
+}
+
+extern "C" int mia_hip_score_sums(mia_hip_ctx* ctx, int64_t* sums5) {
+  if (!ctx || !sums5) return MIA_HIP_ERR_ARG;
+  if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->d_sums && dev_alloc(ctx, &ctx->d_sums, 8)) return MIA_HIP_ERR_NOMEM;
+  const long long init[5] = {0, 0, 0, INT32_MAX, INT32_MIN};
+  HIPCHK(hipMemcpyAsync(ctx->d_sums, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+  const int64_t n = ctx->rs.n;
+  if (n > 0) {
+    int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus * 8);
+    hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(sums5, ctx->d_sums, 40, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+// HOST helper: what find_fsdb_score_cut returns when every used read has the same length -- both regression sums
+// are exactly 0, slope_bf = 0/0 -- from the (possibly all-reduced) sums alone.  Returns 1 if the lengths differ: the
+// order-dependent double sums of passes 2 and 3 then need the scores on the host (mia_hip_score_cut).
+extern "C" int mia_hip_score_cut_from_sums(const int64_t* sums5, double* slope, double* intercept) {
+  const int64_t sx = sums5[0], sy = sums5[1], j = sums5[2];
+  if (!(j > 0 && sums5[3] == sums5[4])) return 1;
+  double xbar = (double)sx, ybar = (double)sy;
+  xbar /= (double)(size_t)j;
+  ybar /= (double)(size_t)j;
+  const double zero = 0.0;
+  const double slope_bf = zero / zero;
+  const double intercept_bf = ybar - slope_bf * xbar;
+  const double max_delta = 0;
+  *intercept = intercept_bf;
+  if ((slope_bf - max_delta) > 0) *slope = slope_bf - (max_delta * 2.0);
+  else *slope = (double)(slope_bf * (80 / 100.0));
+  return 0;
 }
 
 extern "C" int mia_hip_num_records(mia_hip_ctx* ctx, int64_t* n_records) {

@@ -45,6 +45,18 @@ def allreduce_tallies(tally, gaps):
     dist.all_reduce(gaps, op=dist.ReduceOp.MAX)
 
 
+def allreduce_score_sums(sums5, device):
+    """{sum len, sum score, count, min len, max len} of mia_hip_score_sums over all ranks (integers: exact)."""
+    if not _active():
+        return sums5
+    t = torch.as_tensor(sums5, dtype=torch.int64).to(device)
+    add, lo, hi = t[:3].clone(), t[3:4].clone(), t[4:5].clone()
+    dist.all_reduce(add, op=dist.ReduceOp.SUM)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return torch.cat([add, lo, hi]).cpu().numpy()
+
+
 def all_gather_ragged(t):
     """Concatenate variable-length 1-D int64 tensors (insert events) of all ranks."""
     if not _active():

@@ -53,6 +53,9 @@ scores = mdist.all_gather_concat(torch.from_numpy(np.pad(fs["score"], (0, per - 
 base = mdist.exclusive_rank_sum(nrec, "cpu")
 ev = mdist.all_gather_ragged(torch.arange(rank * 100, rank * 100 + 3 + rank, dtype=torch.int64))
 
+s5 = mdist.allreduce_score_sums(np.array([10 + rank, 100 * (rank + 1), 3, 50 - rank, 60 + rank], dtype=np.int64), "cpu")
+assert s5.tolist() == [21, 300, 6, 49, 61], s5
+
 # the link exchange of formerly split reads (stale back_asp): rank 0 has two links, rank 1 one; a link is 4 int64
 # {reader, slot, flen<<32|actf, low}.  A stand-in with the library's five calls checks the protocol of exchange_links.
 class FakeHip:

@@ -136,6 +136,21 @@ def test_unfiltered_pass1_sample(full, oracle):
     oracle.ora_free(st)
 
 
+def test_score_sums_on_device(full):
+    """pass 1 of find_fsdb_score_cut reduced on the device equals numpy's sums, and with equally long reads the
+    regression from the sums equals the host regression over the downloaded scores (NaN pattern included)"""
+    f = full
+    sc = f.hip.scores()
+    used = sc >= 2000
+    s5 = f.hip.score_sums()
+    assert s5.tolist() == [int(f.lens[used].sum()), int(sc[used].astype(np.int64).sum()), int(used.sum()), 100, 100]
+    a = f.hip.score_cut_from_sums(s5)
+    b = f.hip.score_cut(sc, f.lens)
+    assert a is not None and all((x == y) or (np.isnan(x) and np.isnan(y)) for x, y in zip(a, b)), (a, b)
+    s5[4] += 1                       # reads of different lengths: the host regression is needed
+    assert f.hip.score_cut_from_sums(s5) is None
+
+
 def test_realign_idempotent(full):
     f = full
     f.hip.realign(f.ref, True)
