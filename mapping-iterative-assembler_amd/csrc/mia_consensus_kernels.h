@@ -138,7 +138,7 @@ struct RecInfo {              // per read, rebuilt every iteration by k_rec_geom
 };
 struct SlotInfo {             // per local AlnSeq slot (global slot - slot_base)
   int64_t base;               // first global slot of this context
-  int64_t n_local;            // slots owned by this context in this iteration
+  const int64_t* n_local_p;   // slots owned by this context in this iteration (device: the scan's total)
   int32_t* reclen;            // asp_len of the record in the slot
   int32_t* recact;            // read bases in that record
   unsigned long long* writer; // (global read index << 20 | link index) of the last pop_smp writer; owner: link index 0xFFFFF
@@ -162,7 +162,7 @@ __device__ __forceinline__ void rec_store(int64_t i, const RecGeom& g, int nf, i
   const int flen = g.ncols_f + nf, blen = g.split ? g.ncols_b + nb : 0;
   ri.flen[i] = flen; ri.blen[i] = blen; ri.actf[i] = af + nf;
   const int64_t ls = slot[i] - si.base;
-  if (ls >= 0 && ls + (g.split ? 1 : 0) < si.n_local) {
+  if (ls >= 0 && ls + (g.split ? 1 : 0) < (*si.n_local_p)) {
     const unsigned long long me = ((unsigned long long)(read_base + i) << 20) | LINK_NONE;
     si.reclen[ls] = flen; si.recact[ls] = af + nf; si.mult[ls] = 1; si.writer[ls] = me;
     if (g.split) { si.reclen[ls + 1] = blen; si.recact[ls + 1] = bases - (af + nf); si.mult[ls + 1] = 1; si.writer[ls + 1] = me; }
@@ -247,27 +247,31 @@ __global__ void k_cull_mark(ReadSet rs, int32_t L, const int64_t* slot, uint8_t*
 }
 
 // every link (of this context or gathered from the others): effects on the slot it points at, if that slot is ours
-__global__ void k_links_apply(const int64_t* links, int32_t n_links, SlotInfo si, uint8_t* slot_dropped, int64_t n_slots, int32_t* link_len,
-                              int32_t* link_act, uint32_t* flags) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_links) return;
-  const int64_t* r = links + (int64_t)e * 4;
-  const int64_t ls = r[1] - si.base;
-  if (ls < 0 || ls >= si.n_local) return;                      // another context's slot (or none: see k_links_check)
-  atomicMax(&si.writer[ls], ((unsigned long long)r[0] << 20) | (unsigned long long)e);
-  atomicAdd(&si.mult[ls], 1);
-  if ((r[3] & 1) && r[1] < n_slots) slot_dropped[r[1]] = 1;
-  link_len[e] = si.reclen[ls];
-  link_act[e] = si.recact[ls];
+__global__ void k_links_apply(const int64_t* links, const int32_t* n_links_p, int32_t cap, SlotInfo si, uint8_t* slot_dropped, int64_t n_slots,
+                              int32_t* link_len, int32_t* link_act, uint32_t* flags) {
+  const int n_links = min(*n_links_p, cap);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_links; e += gridDim.x * blockDim.x) {
+    const int64_t* r = links + (int64_t)e * 4;
+    const int64_t ls = r[1] - si.base;
+    link_len[e] = -1;                                            // -1: the slot is not ours
+    link_act[e] = -1;
+    if (ls < 0 || ls >= (*si.n_local_p)) continue;                // another context's slot (or none: flagged by k_rec_params)
+    atomicMax(&si.writer[ls], ((unsigned long long)r[0] << 20) | (unsigned long long)e);
+    atomicAdd(&si.mult[ls], 1);
+    if ((r[3] & 1) && r[1] < n_slots) slot_dropped[r[1]] = 1;
+    link_len[e] = si.reclen[ls];
+    link_act[e] = si.recact[ls];
+  }
 }
 
 // depth-code parameters and multiplicities of every read's records + its dropped bits, after all links are in
 __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const uint8_t* slot_dropped, int64_t n_slots, const int64_t* back_slot,
-                             RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, const int32_t* link_act, int32_t n_links,
-                             int64_t read_base,
+                             RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, const int32_t* link_act, const int32_t* n_links_p,
+                             int32_t cap, int64_t read_base,
                              uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rs.n) return;
+  const int n_links = min(*n_links_p, cap);
   uint8_t df = 0, db = 0;
   int32_t* p = ri.params + i * 8;
   for (int k = 0; k < 8; k++) p[k] = 0;
@@ -308,8 +312,8 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
       }
       q[3] = si.mult[lsl];
     };
-    if (ls >= 0 && ls < si.n_local) fill(p, ls, 0, 0, flen + back_len, flen);
-    if (split && ls + 1 < si.n_local) fill(p + 4, ls + 1, flen, actf, flen + blen, blen);
+    if (ls >= 0 && ls < (*si.n_local_p)) fill(p, ls, 0, 0, flen + back_len, flen);
+    if (split && ls + 1 < (*si.n_local_p)) fill(p + 4, ls + 1, flen, actf, flen + blen, blen);
   }
   drop_front[i] = df;
   drop_back[i] = db;

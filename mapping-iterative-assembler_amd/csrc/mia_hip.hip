@@ -54,6 +54,7 @@ struct mia_hip_ctx {
   int64_t slot_cap = 0;
   Links lk{};                              // links produced by this context in the last cull
   int64_t* d_links_all = nullptr; int32_t n_links_all = 0; int64_t links_all_cap = 0;   // links to apply (own, or gathered from all ranks)
+  int32_t* d_n_links_all = nullptr; int64_t links_cap_all = 0; int32_t* d_n_links_gathered = nullptr;
   int32_t* d_link_len = nullptr; int64_t link_len_cap = 0;
   uint32_t* d_cull_flags = nullptr;
   unsigned long long* d_sums = nullptr;
@@ -164,7 +165,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums};
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -565,17 +566,13 @@ static int finish_params(mia_hip_ctx* ctx);
 // second half of the cull: every link (own or gathered) acts on the slot it points at, then each read's dropped bits,
 // depth-code parameters and multiplicities are final.  Runs at the end of mia_hip_cull and again after mia_hip_set_links.
 static int finish_cull(mia_hip_ctx* ctx) {
-  const int32_t nl = ctx->n_links_all;
-  if (nl > ctx->link_len_cap) {
-    if (dev_alloc(ctx, &ctx->d_link_len, (size_t)nl + 64) || dev_alloc(ctx, &ctx->d_link_act, (size_t)nl + 64)) return MIA_HIP_ERR_NOMEM;
-    ctx->link_len_cap = nl + 64;
+  if (ctx->links_cap_all > ctx->link_len_cap) {
+    if (dev_alloc(ctx, &ctx->d_link_len, (size_t)ctx->links_cap_all + 64) || dev_alloc(ctx, &ctx->d_link_act, (size_t)ctx->links_cap_all + 64))
+      return MIA_HIP_ERR_NOMEM;
+    ctx->link_len_cap = ctx->links_cap_all + 64;
   }
-  if (nl > 0) {
-    HIPCHK(hipMemsetAsync(ctx->d_link_len, 0xFF, (size_t)nl * 4, ctx->stream));   // -1: the slot is not ours
-    HIPCHK(hipMemsetAsync(ctx->d_link_act, 0xFF, (size_t)nl * 4, ctx->stream));
-    hipLaunchKernelGGL(k_links_apply, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_links_all, nl, ctx->si,
-                       ctx->d_slot_dropped, ctx->n_slots, ctx->d_link_len, ctx->d_link_act, ctx->d_cull_flags);
-  }
+  hipLaunchKernelGGL(k_links_apply, dim3(32), dim3(256), 0, ctx->stream, ctx->d_links_all, ctx->d_n_links_all, (int32_t)ctx->links_cap_all, ctx->si,
+                     ctx->d_slot_dropped, ctx->n_slots, ctx->d_link_len, ctx->d_link_act, ctx->d_cull_flags);
   ctx->links_applied = true;
   return finish_params(ctx);
 }
@@ -583,13 +580,15 @@ static int finish_cull(mia_hip_ctx* ctx) {
 static int finish_params(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   hipLaunchKernelGGL(k_rec_params, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
-                     ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->d_link_act, ctx->n_links_all,
-                     ctx->read_base,
-                     ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags);
+                     ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->d_link_act, ctx->d_n_links_all,
+                     (int32_t)ctx->links_cap_all, ctx->read_base, ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags);
   HIPCHK(hipGetLastError());
-  uint32_t fl = 0;
-  HIPCHK(hipMemcpyAsync(&fl, ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
+}
+
+// the error flags of the cull kernels, checked where the stream is synchronised anyway
+static int check_cull_flags(mia_hip_ctx* ctx, uint32_t fl) {
+  if (fl & 8u) { ctx->err = "more formerly split reads than the link list holds"; return MIA_HIP_ERR_RANGE; }
   if (fl & 4u) {
     ctx->err = "a formerly split read points at an AlnSeq slot that holds no record of this iteration (the reference would show "
                "the slot's content from an earlier iteration); not reproduced";
@@ -619,13 +618,11 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
     ctx->d_slot_dropped = nd;
     ctx->n_slots = ns;
   }
-  // records per read and per slot, the reads' own dropped marks, and the links of formerly split reads
-  int64_t total = 0;
-  HIPCHK(hipMemcpyAsync(&total, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // records per read and per slot, the reads' own dropped marks, and the links of formerly split reads -- all without a
+  // host round trip: the record total and the link count stay on the device, the error flags are read by mia_hip_tally
   ctx->slot_base = slot_base;
   ctx->si.base = slot_base;
-  ctx->si.n_local = total;
+  ctx->si.n_local_p = ctx->d_total;
   HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 4, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->d_cull_flags, 0, 4, ctx->stream));
   hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
@@ -634,15 +631,10 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
                      ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot, ctx->d_front_slot0, ctx->ri, ctx->lk, ctx->read_base,
                      ctx->d_cull_flags);
   HIPCHK(hipGetLastError());
-  int32_t nl = 0;
-  uint32_t fl = 0;
-  HIPCHK(hipMemcpyAsync(&nl, ctx->lk.n, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&fl, ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (fl & 8u) { ctx->err = "more formerly split reads than the link list holds"; return MIA_HIP_ERR_RANGE; }
   // by default the links to apply are this context's own; a sharded run replaces them with the gathered list (mia_hip_set_links)
   ctx->d_links_all = ctx->lk.rec;
-  ctx->n_links_all = nl;
+  ctx->d_n_links_all = ctx->lk.n;
+  ctx->links_cap_all = ctx->lk.cap;
   ctx->culled = true;
   ctx->links_applied = false;
   return finish_cull(ctx);
@@ -700,6 +692,11 @@ extern "C" int mia_hip_set_links(mia_hip_ctx* ctx, const int64_t* d_links_all, i
   } else if (!ctx->owned_links.empty()) ctx->d_links_all = ctx->owned_links.back();
   if (n_all > 0) HIPCHK(hipMemcpyAsync(ctx->d_links_all, d_links_all, (size_t)n_all * 32, hipMemcpyDeviceToDevice, ctx->stream));
   ctx->n_links_all = (int32_t)n_all;
+  if (!ctx->d_n_links_gathered && dev_alloc(ctx, &ctx->d_n_links_gathered, 1)) return MIA_HIP_ERR_NOMEM;
+  const int32_t n32 = (int32_t)n_all;
+  HIPCHK(hipMemcpyAsync(ctx->d_n_links_gathered, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
+  ctx->d_n_links_all = ctx->d_n_links_gathered;
+  ctx->links_cap_all = n_all;
   // slot state back to "owners only", then every link once
   const int64_t n = ctx->rs.n;
   HIPCHK(hipMemsetAsync(ctx->d_cull_flags, 0, 4, ctx->stream));
@@ -741,8 +738,10 @@ extern "C" int mia_hip_get_dropped(mia_hip_ctx* ctx, uint8_t* front, uint8_t* ba
   const size_t n = (size_t)ctx->rs.n;
   if (front) HIPCHK(hipMemcpyAsync(front, ctx->d_drop_f, n, hipMemcpyDeviceToHost, ctx->stream));
   if (back) HIPCHK(hipMemcpyAsync(back, ctx->d_drop_b, n, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t cflags = 0;
+  if (ctx->culled) HIPCHK(hipMemcpyAsync(&cflags, ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  return MIA_HIP_OK;
+  return check_cull_flags(ctx, cflags);
 }
 
 extern "C" int mia_hip_set_slot_dropped(mia_hip_ctx* ctx, const uint8_t* flags, int64_t n_flags) {
@@ -813,7 +812,7 @@ extern "C" int mia_hip_score_sums(mia_hip_ctx* ctx, int64_t* sums5) {
   HIPCHK(hipMemcpyAsync(ctx->d_sums, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
   const int64_t n = ctx->rs.n;
   if (n > 0) {
-    int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus * 8);
+    int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus);   // few blocks: five same-address atomics per block
     hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums);
     HIPCHK(hipGetLastError());
   }
@@ -922,10 +921,12 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
     }
     HIPCHK(hipGetLastError());
   }
-  uint32_t flags = 0;
+  uint32_t flags = 0, cflags = 0;
   HIPCHK(hipMemcpyAsync(&ctx->n_events_host, ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(&flags, ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&cflags, ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (int rcf = check_cull_flags(ctx, cflags)) return rcf;
   if (flags & 1u) { ctx->err = "insert event list overflow"; return MIA_HIP_ERR_NOMEM; }
   if (ctx->n_events_host > ctx->tb.cap_events) ctx->n_events_host = ctx->tb.cap_events;
   ctx->tallied = true;

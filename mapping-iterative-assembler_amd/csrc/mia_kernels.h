@@ -66,6 +66,25 @@ MIA_HD inline int classify(int len2, int len1, const PackSet& ps, int use_quad) 
   return ci;
 }
 
+// Histogram update with one LDS atomic per (wavefront, distinct bin): the reads of a wavefront almost always share
+// their bin (same kernel class, same read length), so 64 same-address atomics collapse into one.  Returns the rank of
+// the lane among the lanes of its wavefront with the same bin plus the old bin count (as atomicAdd would).
+__device__ __forceinline__ int hist_add_aggregated(int32_t* hist, int b) {
+  int rank = 0;
+  unsigned long long todo = __ballot(b >= 0);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const int b0 = __shfl(b, leader);
+    const unsigned long long same = __ballot(b == b0);
+    int base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&hist[b0], (int)__popcll(same));
+    base = __shfl(base, leader);
+    if (b == b0) rank = base + (int)__popcll(same & ((1ull << (threadIdx.x & 63)) - 1ull));
+    todo &= ~same;
+  }
+  return rank;
+}
+
 // ---- plan: bin every read by kernel variant and LDS footprint ----------------
 // Counts go through an LDS histogram per block, so global memory sees one atomic per
 // (block, non-empty bin) instead of one per read on a single hot address.
@@ -74,18 +93,18 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b = -1;
   if (i < rs.n) {
-    int b = -1;
     if (rs.sk[i]) {
       int s, l1;
       realign_window(rs.as[i], rs.ae[i], rs.len[i], ref.wrap, &s, &l1);
       b = classify(rs.len[i], l1, ps, use_quad);
-      atomicAdd(&hist[b], 1);
     } else {
       rs.status[i] = ST_SKIPPED;
     }
     bin_of[i] = b;
   }
+  hist_add_aggregated(hist, b);
   __syncthreads();
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
 }
@@ -96,8 +115,9 @@ __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int b = -1, rank = 0;
-  if (i < n) { b = bin_of[i]; if (b >= 0) rank = atomicAdd(&hist[b], 1); }
+  int b = -1;
+  if (i < n) b = bin_of[i];
+  const int rank = hist_add_aggregated(hist, b);
   __syncthreads();
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) base[b] = atomicAdd(&bin_cursor[b], hist[b]);
   __syncthreads();
@@ -264,11 +284,12 @@ __global__ __launch_bounds__(256) void k_plan_recount(int64_t n, int32_t* bin_of
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b = -1;
   if (i < n) {
-    int b = bin_of[i];
-    if (b >= BIN_QUAD0) atomicAdd(&hist[b], 1);
-    else if (b >= 0) bin_of[i] = -1;
+    b = bin_of[i];
+    if (b >= 0 && b < BIN_QUAD0) { bin_of[i] = -1; b = -1; }
   }
+  hist_add_aggregated(hist, b);
   __syncthreads();
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
 }
