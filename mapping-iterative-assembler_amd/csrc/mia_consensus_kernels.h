@@ -435,12 +435,15 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
 }
 
 // ---- bucketing of the reads by alignment start (counting sort, one pass per iteration) ----
+constexpr int BUCKET_PER = 8;   // reads per thread of the bucketing kernels
 __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count) {
   extern __shared__ int32_t hist[];
   for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < rs.n && rs.sk[i]) atomicAdd(&hist[min(rs.as[i] / TALLY_BUCKET, nb - 1)], 1);
+  for (int k = 0; k < BUCKET_PER; k++) {
+    const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
+    if (i < rs.n && rs.sk[i]) atomicAdd(&hist[min(rs.as[i] / TALLY_BUCKET, nb - 1)], 1);
+  }
   __syncthreads();
   for (int b = threadIdx.x; b < nb; b += blockDim.x) if (hist[b]) atomicAdd(&count[b], hist[b]);
 }
@@ -458,13 +461,19 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
   int32_t* base = sh + nb;
   for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int b = -1, rank = 0;
-  if (i < rs.n && rs.sk[i]) { b = min(rs.as[i] / TALLY_BUCKET, nb - 1); rank = atomicAdd(&hist[b], 1); }
+  int bb[BUCKET_PER], rank[BUCKET_PER];
+  for (int k = 0; k < BUCKET_PER; k++) {
+    const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
+    bb[k] = -1; rank[k] = 0;
+    if (i < rs.n && rs.sk[i]) { bb[k] = min(rs.as[i] / TALLY_BUCKET, nb - 1); rank[k] = atomicAdd(&hist[bb[k]], 1); }
+  }
   __syncthreads();
   for (int k = threadIdx.x; k < nb; k += blockDim.x) if (hist[k]) base[k] = atomicAdd(&cursor[k], hist[k]);
   __syncthreads();
-  if (b >= 0) order[off[b] + base[b] + rank] = (int32_t)i;
+  for (int k = 0; k < BUCKET_PER; k++) {
+    const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
+    if (bb[k] >= 0) order[off[bb[k]] + base[bb[k]] + rank[k]] = (int32_t)i;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,

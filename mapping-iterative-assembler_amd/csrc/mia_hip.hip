@@ -411,7 +411,7 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   int32_t* d_wide_count = ctx->d_bins + 3 * N_BINS;
   HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 2) * 4, ctx->stream));
   int32_t* d_retry_count = ctx->d_bins + 3 * N_BINS + 1;
-  const int tb = 256, gb = (int)((n + tb - 1) / tb);
+  const int tb = 256, gb = (int)((n + (int64_t)tb * PLAN_PER - 1) / ((int64_t)tb * PLAN_PER));
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, ctx->d_bin_of, d_count);
   int32_t h_count[N_BINS], h_off[N_BINS];
   HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, ctx->stream));
@@ -908,7 +908,7 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
       if (!ctx->d_order && dev_alloc(ctx, &ctx->d_order, (size_t)n)) return MIA_HIP_ERR_NOMEM;
       int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1);
       HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, ctx->stream));
-      const int gb = (int)((n + 255) / 256);
+      const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
       hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, ctx->stream, ctx->rs, nb, d_cnt);
       hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(64), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur);
       hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, ctx->stream, ctx->rs, nb, d_off, d_cur, ctx->d_order);

@@ -88,23 +88,27 @@ __device__ __forceinline__ int hist_add_aggregated(int32_t* hist, int b) {
 // ---- plan: bin every read by kernel variant and LDS footprint ----------------
 // Counts go through an LDS histogram per block, so global memory sees one atomic per
 // (block, non-empty bin) instead of one per read on a single hot address.
+constexpr int PLAN_PER = 8;   // reads per thread of the planner kernels: a block bins 2048 reads per LDS histogram
+
 __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int32_t* bin_of, int32_t* bin_count) {
   __shared__ int32_t hist[N_BINS];
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int b = -1;
-  if (i < rs.n) {
-    if (rs.sk[i]) {
-      int s, l1;
-      realign_window(rs.as[i], rs.ae[i], rs.len[i], ref.wrap, &s, &l1);
-      b = classify(rs.len[i], l1, ps, use_quad);
-    } else {
-      rs.status[i] = ST_SKIPPED;
+  for (int k = 0; k < PLAN_PER; k++) {
+    const int64_t i = ((int64_t)blockIdx.x * PLAN_PER + k) * 256 + threadIdx.x;
+    int b = -1;
+    if (i < rs.n) {
+      if (rs.sk[i]) {
+        int s, l1;
+        realign_window(rs.as[i], rs.ae[i], rs.len[i], ref.wrap, &s, &l1);
+        b = classify(rs.len[i], l1, ps, use_quad);
+      } else {
+        rs.status[i] = ST_SKIPPED;
+      }
+      bin_of[i] = b;
     }
-    bin_of[i] = b;
+    hist_add_aggregated(hist, b);
   }
-  hist_add_aggregated(hist, b);
   __syncthreads();
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
 }
@@ -114,14 +118,19 @@ __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin
   __shared__ int32_t hist[N_BINS], base[N_BINS];
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int b = -1;
-  if (i < n) b = bin_of[i];
-  const int rank = hist_add_aggregated(hist, b);
+  int bb[PLAN_PER], rank[PLAN_PER];
+  for (int k = 0; k < PLAN_PER; k++) {
+    const int64_t i = ((int64_t)blockIdx.x * PLAN_PER + k) * 256 + threadIdx.x;
+    bb[k] = i < n ? bin_of[i] : -1;
+    rank[k] = hist_add_aggregated(hist, bb[k]);
+  }
   __syncthreads();
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) base[b] = atomicAdd(&bin_cursor[b], hist[b]);
   __syncthreads();
-  if (b >= 0) list[bin_off[b] + base[b] + rank] = (int32_t)i;
+  for (int k = 0; k < PLAN_PER; k++) {
+    const int64_t i = ((int64_t)blockIdx.x * PLAN_PER + k) * 256 + threadIdx.x;
+    if (bb[k] >= 0) list[bin_off[bb[k]] + base[bb[k]] + rank[k]] = (int32_t)i;
+  }
 }
 
 // ---- the windowed DP: one read at a time per 64-lane workgroup, persistent grid -------------
@@ -283,13 +292,15 @@ __global__ __launch_bounds__(256) void k_plan_recount(int64_t n, int32_t* bin_of
   __shared__ int32_t hist[N_BINS];
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int b = -1;
-  if (i < n) {
-    b = bin_of[i];
-    if (b >= 0 && b < BIN_QUAD0) { bin_of[i] = -1; b = -1; }
+  for (int k = 0; k < PLAN_PER; k++) {
+    const int64_t i = ((int64_t)blockIdx.x * PLAN_PER + k) * 256 + threadIdx.x;
+    int b = -1;
+    if (i < n) {
+      b = bin_of[i];
+      if (b >= 0 && b < BIN_QUAD0) { bin_of[i] = -1; b = -1; }
+    }
+    hist_add_aggregated(hist, b);
   }
-  hist_add_aggregated(hist, b);
   __syncthreads();
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
 }
