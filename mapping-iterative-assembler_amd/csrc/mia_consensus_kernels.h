@@ -135,7 +135,12 @@ struct RecInfo {              // per read, rebuilt every iteration by k_rec_geom
   int32_t* blen;              // same for the read's own back record (0 if not split)
   int32_t* actf;              // read bases in the front record
   int32_t* params;            // [n][8]: front {dffBase, actOff, B, mult}, back {dffBase, actOff, B, mult}
+  int32_t* trec;              // [n][16]: everything the tally needs about a read in ONE 64-byte line (see TREC_*)
 };
+// The tally visits the reads in bucket order, i.e. at random with respect to the per-read arrays: gathering a dozen
+// fields costs a dozen cache lines per read (1.8 GB per 1 M reads).  k_rec_params writes them side by side instead.
+enum { TREC_AS = 0, TREC_AE, TREC_LEN_ABR, TREC_FLAGS, TREC_REFSTART, TREC_ROFF, TREC_ACTF, TREC_SPARE, TREC_PARAMS = 8 };
+constexpr int TRF_RC = 1, TRF_DF = 2, TRF_DB = 4, TRF_DIAG = 8, TRF_TOO_LONG = 16, TRF_SK = 32;
 struct SlotInfo {             // per local AlnSeq slot (global slot - slot_base)
   int64_t base;               // first global slot of this context
   const int64_t* n_local_p;   // slots owned by this context in this iteration (device: the scan's total)
@@ -317,6 +322,14 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
   }
   drop_front[i] = df;
   drop_back[i] = db;
+  int32_t* t = ri.trec + i * 16;
+  const uint32_t st = rs.status[i];
+  t[TREC_AS] = rs.as[i]; t[TREC_AE] = rs.ae[i];
+  t[TREC_LEN_ABR] = (int32_t)((uint32_t)rs.len[i] | ((uint32_t)(uint16_t)rs.abr[i] << 16));
+  t[TREC_FLAGS] = (rs.rc[i] ? TRF_RC : 0) | (df ? TRF_DF : 0) | (db ? TRF_DB : 0) | ((st & ST_DIAG) ? TRF_DIAG : 0) |
+                  ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0);
+  t[TREC_REFSTART] = rs.refstart[i]; t[TREC_ROFF] = (int32_t)rs.roff[i]; t[TREC_ACTF] = ri.actf[i]; t[TREC_SPARE] = 0;
+  for (int k = 0; k < 8; k++) t[TREC_PARAMS + k] = p[k];
 }
 
 // ---- tally: one read per wavefront, one read row per lane (4 passes for 256-base reads) ----
@@ -328,31 +341,36 @@ __device__ __forceinline__ int depth_code(int dff, int dfb) {   // src/fsdb.c:57
 // (k_bucket_* below), so their columns fall into a TALLY_WIN-column window that is tallied in
 // LDS and flushed once; anything outside the window (the back part of a read that wraps
 // around the origin) takes the global atomic.  Same integer sums either way.
-constexpr int TALLY_BUCKET = 256, TALLY_WIN = 768, TALLY_CHUNK = 1024;
+constexpr int TALLY_EV_CAP = 256;    // insert events a workgroup buffers in LDS
+constexpr int TALLY_BUCKET = 128, TALLY_WIN = 384, TALLY_CHUNK = 512;   // 20 KB of LDS per workgroup: 8 workgroups (32 waves) per CU
 
 template <bool BINNED>
 __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSet& rs, const RefInfo& ref, const int32_t* pssm2,
                                                const uint8_t* drop_front, const uint8_t* drop_back, const TallyBuf& tb,
                                                int32_t* lds, int win_base, const int32_t* rec_params, const int32_t* rec_actf,
-                                               const int16_t* pssm_lds) {
-  if (!rs.sk[i]) return;
-  if (rs.status[i] & ST_TOO_LONG) { if (lane == 0) atomicOr(tb.flags, 2u); return; }
+                                               const int16_t* pssm_lds, unsigned long long* ev_buf, int* ev_cnt) {
+  // one 64-byte record per read (wave-uniform address: scalar loads)
+  const int32_t* tr = rec_params + i * 16;
+  const int flags = tr[TREC_FLAGS];
+  if (!(flags & TRF_SK)) return;
+  if (flags & TRF_TOO_LONG) { if (lane == 0) atomicOr(tb.flags, 2u); return; }
   const int L = ref.L, Lp = tb.Lp;
-  const int len2 = rs.len[i], abr = rs.abr[i];
-  const RecGeom g = rec_geom(rs.as[i], rs.ae[i], L);
+  const int len2 = tr[TREC_LEN_ABR] & 0xFFFF, abr = (int)(int16_t)((uint32_t)tr[TREC_LEN_ABR] >> 16);
+  const RecGeom g = rec_geom(tr[TREC_AS], tr[TREC_AE], L);
   const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
-  const int cbase = rs.refstart[i] - g.start_w;     // path offset of window column 0
-  const uint8_t* rp = rs.packed + rs.roff[i];
-  const int pmo = rs.rc[i] ? PSSM_WORDS : 0;                // src/mia.c:584-589
+  const int cbase = tr[TREC_REFSTART] - g.start_w;     // path offset of window column 0
+  const uint8_t* rp = rs.packed + (uint32_t)tr[TREC_ROFF];
+  const bool is_rc = (flags & TRF_RC) != 0;
+  const int pmo = is_rc ? PSSM_WORDS : 0;                   // src/mia.c:584-589
   const int32_t* pm = pssm2 + pmo;
-  const bool dF = drop_front[i], dB = drop_back[i];
-  const bool diag = (rs.status[i] & ST_DIAG) != 0;           // proven pure diagonal: the script is not needed
+  const bool dF = (flags & TRF_DF) != 0, dB = (flags & TRF_DB) != 0;
+  const bool diag = (flags & TRF_DIAG) != 0;                 // proven pure diagonal: the script is not needed
   if (g.split && g.start_w >= L) { if (lane == 0) atomicOr(tb.flags, 2u); return; }  // split_pwaln mis-places such a record
   // depth-code parameters and multiplicity of the two records (k_rec_params): normally {0, 0, flen+blen, 1} for the
   // front and {flen, bases in the front, flen+blen, 1} for the back (src/fsdb.c:568-581,597-610)
-  const int32_t* prm = rec_params + i * 8;
+  const int32_t* prm = tr + TREC_PARAMS;
   const int fBase = prm[0], fOff = prm[1], fB = prm[2], fMult = prm[3], bBase = prm[4], bOff = prm[5], bB = prm[6], bMult = prm[7];
-  const int actF = rec_actf[i];                            // read bases in the front record
+  const int actF = tr[TREC_ACTF];                          // read bases in the front record
   // code of a column reached after `act` read bases, front or back record
   auto dcode = [&](bool back, int act) {
     const int a = back ? bOff + (act - actF) : fOff + act;
@@ -369,24 +387,31 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
     if (d < 0 || d > 2 * PSSM_DEPTH) { atomicOr(tb.flags, 2u); return; }
     const int wc = gc - win_base;
     const bool in_lds = BINNED && wc >= 0 && wc < TALLY_WIN;
-    int32_t* t = in_lds ? lds + wc : tb.tally + gc;
-    const int ws = in_lds ? TALLY_WIN : Lp;                // word stride
-    // mult > 1: the record is listed again through the stale back_asp of formerly split reads (see k_cull_mark)
-    if (!dropped) {                                        // src/mia.c:580-582
-      atomicAdd(&t[T_COV * ws], mult);
-      if (code == 5) atomicAdd(&t[T_GAP * ws], mult);
-      else {
-        if (code < 4) atomicAdd(&t[(T_A + code) * ws], mult);
-        int s0, s1, s2, s3;                                // sm[d][X][code], X = A,C,G,T (src/map_align.c:258-261)
-        if (BINNED) { const int16_t* row = pssm_lds + pmo + d * 25 + code; s0 = row[0]; s1 = row[5]; s2 = row[10]; s3 = row[15]; }
-        else { const int32_t* row = pm + d * 25 + code; s0 = row[0]; s1 = row[5]; s2 = row[10]; s3 = row[15]; }
-        atomicAdd(&t[T_SA * ws], mult * s0);
-        atomicAdd(&t[T_SC * ws], mult * s1);
-        atomicAdd(&t[T_SG * ws], mult * s2);
-        atomicAdd(&t[T_ST * ws], mult * s3);
-      }
+    int s0 = 0, s1 = 0, s2 = 0, s3 = 0;                    // sm[d][X][code], X = A,C,G,T (src/map_align.c:258-261)
+    if (!dropped && code != 5) {
+      if (BINNED) { const int16_t* row = pssm_lds + pmo + d * 25 + code; s0 = row[0]; s1 = row[5]; s2 = row[10]; s3 = row[15]; }
+      else { const int32_t* row = pm + d * 25 + code; s0 = row[0]; s1 = row[5]; s2 = row[10]; s3 = row[15]; }
     }
-    if (p > 0) atomicAdd(&t[T_SPAN * ws], mult);           // start < pos <= end (src/map_align.c:466-469), dropped or not
+    // mult > 1: the record is listed again through the stale back_asp of formerly split reads (see k_cull_mark).
+    // Two copies of the same adds, one per address space: a pointer chosen at run time would turn every one of them
+    // into a FLAT atomic, which is several times slower on LDS than ds_add.
+    auto aadd = [](auto* q, int v) { (void)__hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto add_all = [&](auto* t, const int ws) {
+      if (!dropped) {                                      // src/mia.c:580-582
+        aadd(&t[T_COV * ws], mult);
+        if (code == 5) aadd(&t[T_GAP * ws], mult);
+        else {
+          if (code < 4) aadd(&t[(T_A + code) * ws], mult);
+          aadd(&t[T_SA * ws], mult * s0);
+          aadd(&t[T_SC * ws], mult * s1);
+          aadd(&t[T_SG * ws], mult * s2);
+          aadd(&t[T_ST * ws], mult * s3);
+        }
+      }
+      if (p > 0) aadd(&t[T_SPAN * ws], mult);         // start < pos <= end (src/map_align.c:466-469), dropped or not
+    };
+    if (in_lds) add_all((__attribute__((address_space(3))) int32_t*)lds + wc, TALLY_WIN);
+    else add_all(tb.tally + gc, Lp);
   };
 
   for (int r0 = abr; r0 < len2; r0 += 64) {
@@ -414,12 +439,17 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
       if (ok && p > 0 && gc < Lp) {     // an insert in front of a record's first column is never counted (src/mia.c:492)
         const int d = dcode(back, act);
         if (j == 0) atomicMax(&tb.gaps[gc], glen);
+        const uint64_t ev = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
+                            ((uint64_t)(is_rc ? 1 : 0) << 50);
         for (int m = 0; m < mult; m++) {
-          const int e = atomicAdd(tb.n_events, 1);
-          if (e < tb.cap_events)
-            tb.events[e] = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
-                           ((uint64_t)(rs.rc[i] ? 1 : 0) << 50);
-          else atomicOr(tb.flags, 1u);
+          // the event list has ONE global counter: a hundred thousand same-address atomics cost a millisecond.  A
+          // binned workgroup collects its events in LDS and reserves their slots with one atomic at the end.
+          int slot = BINNED ? atomicAdd(ev_cnt, 1) : TALLY_EV_CAP;
+          if (slot < TALLY_EV_CAP) ev_buf[slot] = ev;
+          else {
+            const int e = atomicAdd(tb.n_events, 1);
+            if (e < tb.cap_events) tb.events[e] = ev; else atomicOr(tb.flags, 1u);
+          }
         }
       }
     }
@@ -431,7 +461,7 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= rs.n) return;
-  tally_one_read<false>(i, lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0, rec_params, rec_actf, nullptr);
+  tally_one_read<false>(__builtin_amdgcn_readfirstlane((int)i), lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0, rec_params, rec_actf, nullptr, nullptr, nullptr);
 }
 
 // ---- bucketing of the reads by alignment start (counting sort, one pass per iteration) ----
@@ -479,9 +509,15 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
 __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
-                                                       const int32_t* rec_actf) {
+                                                       const int32_t* rec_actf, int32_t* slabs, uint32_t dbg) {
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
   __shared__ int16_t pssm_lds[2 * PSSM_WORDS];               // both matrices: every aligned base looks four entries up
+  // LDS atomics are the limit of this kernel (~1.4 lane-atomics per cycle and CU, whatever the addresses).  Coverage
+  // and span of a gap-free record are range counts: +1 / -1 at the two ends of a difference array instead of one
+  // atomic per column; the prefix sums are taken when the window is flushed.
+  __shared__ int32_t cov_diff[TALLY_WIN], span_diff[TALLY_WIN];
+  __shared__ unsigned long long ev_buf[TALLY_EV_CAP];
+  __shared__ int ev_cnt, ev_base;
   if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
   // which bucket does this workgroup belong to?  (wgoff is ascending, nb <= a few hundred)
   int lo = 0, hi = nb;
@@ -491,16 +527,115 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   const int win_base = b * TALLY_BUCKET;
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) lds[k] = 0;
   for (int k = threadIdx.x; k < 2 * PSSM_WORDS; k += blockDim.x) pssm_lds[k] = (int16_t)pssm2[k];
+  for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { cov_diff[k] = 0; span_diff[k] = 0; }
+  if (threadIdx.x == 0) ev_cnt = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int k = first + wv; k < last; k += 4) tally_one_read<true>(order[k], lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base, rec_params, rec_actf, pssm_lds);
-  __syncthreads();
-  const int Lp = tb.Lp;
-  for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) {
-    const int v = lds[k];
-    const int word = k / TALLY_WIN, gc = win_base + (k - word * TALLY_WIN);
-    if (v != 0 && gc < Lp) atomicAdd(&tb.tally[word * Lp + gc], v);
+  (void)wv;
+  // The common case by far -- proven diagonal, one record, listed once, its own depth codes, every column inside the LDS
+  // window -- goes ONE READ PER LANE: 64 independent chains of (order -> record -> bases) loads per wavefront instead of
+  // one, which is what the kernel was waiting on (80 % of the wave cycles in SQ_WAIT_ANY).  Everything else takes the
+  // general one-read-per-wavefront path.  Same integer sums either way.
+  typedef __attribute__((address_space(3))) int32_t lds_i32;
+  auto aadd = [](lds_i32* q, int v) { (void)__hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const int L = ref.L, Lp = tb.Lp;
+  for (int k0 = first; k0 < last; k0 += 256) {
+    const int k = k0 + (int)threadIdx.x;
+    const bool have = k < last;
+    const int i = have ? order[k] : -1;
+    bool fast = false;
+    if (have) {
+      const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16);
+      const int4 a = tr4[0], b4 = tr4[1], c4 = tr4[2];
+      const int flags = a.w;
+      const int len2 = a.z & 0xFFFF, abr = (int)(int16_t)((uint32_t)a.z >> 16);
+      const RecGeom g = rec_geom(a.x, a.y, L);
+      const int n_al = len2 - abr, w0 = g.start_w - win_base;
+      const int fBase = c4.x, fOff = c4.y, fB = c4.z, fMult = c4.w;
+      fast = (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && (flags & TRF_DIAG) && !g.split && fMult == 1 && fBase == 0 && fOff == 0 && w0 >= 0 &&
+             w0 + n_al <= TALLY_WIN && g.start_w + n_al <= Lp && n_al <= g.ncols_f && n_al > 0;
+      if (fast && !(dbg & 8u)) {
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);    // reads start on 4-byte boundaries
+        const int16_t* pmat = pssm_lds + ((flags & TRF_RC) ? PSSM_WORDS : 0);
+        const bool dF = (flags & TRF_DF) != 0;
+        lds_i32* t = (lds_i32*)lds + w0;
+        uint32_t word = 0;
+        int bad = 0;
+        for (int act = 0; act < n_al; act++) {
+          const int r = abr + act;
+          if (act == 0 || (r & 7) == 0) word = rp[r >> 3];
+          const int code = (int)((word >> ((r & 7) * 4)) & 15u);
+          const int d = depth_code(act, fB - act - 1);
+          bad |= (d < 0) | (d > 2 * PSSM_DEPTH);
+          const int dd = d < 0 ? 0 : (d > 2 * PSSM_DEPTH ? 2 * PSSM_DEPTH : d);
+          if (!dF && !(dbg & 16u)) {
+            const int16_t* row = pmat + dd * 25 + code;
+            if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1);
+            aadd(&t[T_SA * TALLY_WIN], (int)row[0]);
+            aadd(&t[T_SC * TALLY_WIN], (int)row[5]);
+            aadd(&t[T_SG * TALLY_WIN], (int)row[10]);
+            aadd(&t[T_ST * TALLY_WIN], (int)row[15]);
+          }
+          t++;
+        }
+        // coverage (not dropped): columns w0 .. w0+n_al-1; span (start < pos <= end, dropped or not): w0+1 .. w0+n_al-1
+        if (!dF) { aadd((lds_i32*)cov_diff + w0, 1); if (w0 + n_al < TALLY_WIN) aadd((lds_i32*)cov_diff + w0 + n_al, -1); }
+        if (n_al > 1) { aadd((lds_i32*)span_diff + w0 + 1, 1); if (w0 + n_al < TALLY_WIN) aadd((lds_i32*)span_diff + w0 + n_al, -1); }
+        if (bad | (int)(word & (dbg & 16u ? 0x40000000u : 0u))) atomicOr(tb.flags, 2u);
+      }
+    }
+    unsigned long long todo = __ballot(have && !fast);
+    while (todo) {
+      const int l = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int ii = __shfl(i, l);
+      tally_one_read<true>(__builtin_amdgcn_readfirstlane(ii), lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base, rec_params, rec_actf, pssm_lds, ev_buf, &ev_cnt);
+    }
   }
+  __syncthreads();
+  // The window goes to this workgroup's slab with plain stores; k_tally_reduce adds the slabs up.  (Flushing with
+  // global atomics cost more than the tally itself: ~9 M device-scope atomics per 1 M reads, and the eight XCDs
+  // share no L2, so every one of them is resolved at the memory side.)
+  {   // the buffered insert events: one reservation for all of them
+    const int ne = ev_cnt < TALLY_EV_CAP ? ev_cnt : TALLY_EV_CAP;
+    if (threadIdx.x == 0 && ne > 0) ev_base = atomicAdd(tb.n_events, ne);
+    __syncthreads();
+    for (int k = threadIdx.x; k < ne; k += blockDim.x) {
+      if (ev_base + k < tb.cap_events) tb.events[ev_base + k] = ev_buf[k]; else atomicOr(tb.flags, 1u);
+    }
+  }
+  // prefix sums of the two difference arrays (Hillis-Steele over TALLY_WIN entries), folded into the cov / span rows
+  for (int o = 1; o < TALLY_WIN; o <<= 1) {
+    int c[(TALLY_WIN + 255) / 256], sp[(TALLY_WIN + 255) / 256];
+    for (int q = 0, k = threadIdx.x; k < TALLY_WIN; k += blockDim.x, q++) { c[q] = k >= o ? cov_diff[k - o] : 0; sp[q] = k >= o ? span_diff[k - o] : 0; }
+    __syncthreads();
+    for (int q = 0, k = threadIdx.x; k < TALLY_WIN; k += blockDim.x, q++) { cov_diff[k] += c[q]; span_diff[k] += sp[q]; }
+    __syncthreads();
+  }
+  for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { lds[T_COV * TALLY_WIN + k] += cov_diff[k]; lds[T_SPAN * TALLY_WIN + k] += span_diff[k]; }
+  __syncthreads();
+  int32_t* slab = slabs + (int64_t)blockIdx.x * ((TALLY_WORDS - 1) * TALLY_WIN);
+  for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) slab[k] = lds[k];
+}
+
+// tally[word][gc] += sum of the windows that cover column gc: buckets floor(gc/128)-2 .. floor(gc/128), all their chunks.
+// Runs after k_tally_binned; nothing else writes the tally then, so plain read-modify-write.
+__global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs) {
+  const int gc = blockIdx.x * blockDim.x + threadIdx.x;
+  const int Lp = tb.Lp;
+  if (gc >= Lp) return;
+  int acc[TALLY_WORDS - 1];
+  for (int w = 0; w < TALLY_WORDS - 1; w++) acc[w] = 0;
+  const int bhi = min(gc / TALLY_BUCKET, nb - 1);
+  for (int b = max(0, gc / TALLY_BUCKET - (TALLY_WIN / TALLY_BUCKET - 1)); b <= bhi; b++) {
+    const int wc = gc - b * TALLY_BUCKET;
+    if (wc < 0 || wc >= TALLY_WIN) continue;
+    for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) {
+      const int32_t* slab = slabs + (int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + wc;
+      for (int w = 0; w < TALLY_WORDS - 1; w++) acc[w] += slab[w * TALLY_WIN];
+    }
+  }
+  for (int w = 0; w < TALLY_WORDS - 1; w++) if (acc[w]) tb.tally[w * Lp + gc] += acc[w];
 }
 
 // ---- ma: tally of stored AlnSeq records (show_consensus, src/map_alignment.c:139-170) -------------

@@ -80,6 +80,7 @@ struct mia_hip_ctx {
   // read bucketing for the LDS-privatised tally
   int32_t* d_bucket = nullptr; int bucket_cap = 0; int32_t* d_order = nullptr;
   int use_binned_tally = 1;   // MIA_HIP_NO_BINNED_TALLY=1: plain global-atomic tally
+  int32_t* d_tally_slabs = nullptr; int64_t tally_slab_cap = 0;   // one LDS window per tally workgroup, summed by k_tally_reduce
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
@@ -164,8 +165,8 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_drop_b, ctx->tb.tally, ctx->tb.gaps, ctx->tb.events, ctx->tb.n_events, ctx->tb.flags, ctx->d_ins_off,
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
-                  ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered};
+                  ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -269,7 +270,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_slot_dropped, (size_t)ctx->n_slots);
   rcx |= dev_alloc(ctx, &ctx->d_back_slot, (size_t)n) | dev_alloc(ctx, &ctx->d_front_slot0, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->ri.flen, (size_t)n) | dev_alloc(ctx, &ctx->ri.blen, (size_t)n) | dev_alloc(ctx, &ctx->ri.actf, (size_t)n) |
-         dev_alloc(ctx, &ctx->ri.params, (size_t)n * 8);
+         dev_alloc(ctx, &ctx->ri.params, (size_t)n * 8) | dev_alloc(ctx, &ctx->ri.trec, (size_t)n * 16);
   ctx->slot_cap = 2 * n + 16;
   rcx |= dev_alloc(ctx, &ctx->si.reclen, (size_t)ctx->slot_cap) | dev_alloc(ctx, &ctx->si.recact, (size_t)ctx->slot_cap) | dev_alloc(ctx, &ctx->si.writer, (size_t)ctx->slot_cap) |
          dev_alloc(ctx, &ctx->si.mult, (size_t)ctx->slot_cap);
@@ -913,11 +914,17 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
       hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(64), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur);
       hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, ctx->stream, ctx->rs, nb, d_off, d_cur, ctx->d_order);
       const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
+      const int64_t slab_words = (int64_t)grid * (TALLY_WORDS - 1) * TALLY_WIN;
+      if (slab_words > ctx->tally_slab_cap) {
+        if (dev_alloc(ctx, &ctx->d_tally_slabs, (size_t)slab_words)) return MIA_HIP_ERR_NOMEM;
+        ctx->tally_slab_cap = slab_words;
+      }
       hipLaunchKernelGGL(k_tally_binned, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
-                         ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.params, ctx->ri.actf);
+                         ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg);
+      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
-                         ctx->d_drop_b, ctx->tb, ctx->ri.params, ctx->ri.actf);
+                         ctx->d_drop_b, ctx->tb, ctx->ri.trec, ctx->ri.actf);
     }
     HIPCHK(hipGetLastError());
   }
