@@ -154,8 +154,7 @@ def main():
         sums = hip.score_sums()
         if sharded:
             from mia_amd import dist as mdist
-            sums = mdist.allreduce_score_sums(sums, "cuda")
-            slot_base = mdist.exclusive_rank_sum(hip.num_records(), "cuda")
+            sums, slot_base = mdist.gather_pre_cull(sums, hip.num_records(), "cuda")
         t0 = tick("score_sums", t0)
         cut = hip.score_cut_from_sums(sums)
         if cut is None:

@@ -45,6 +45,20 @@ def allreduce_tallies(tally, gaps):
     dist.all_reduce(gaps, op=dist.ReduceOp.MAX)
 
 
+def gather_pre_cull(sums5, n_records, device):
+    """One small all-gather before the cull instead of four collectives: every rank's score sums (mia_hip_score_sums)
+    and record count.  Returns (global sums5, slot_base, read counts are not needed: reads are sharded evenly)."""
+    if not _active():
+        return sums5, 0
+    mine = torch.tensor(list(map(int, sums5)) + [int(n_records)], dtype=torch.int64, device=device)
+    allt = torch.empty(6 * world(), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allt, mine)
+    allv = allt.cpu().numpy().reshape(world(), 6)
+    import numpy as np
+    g = np.array([allv[:, 0].sum(), allv[:, 1].sum(), allv[:, 2].sum(), allv[:, 3].min(), allv[:, 4].max()], dtype=np.int64)
+    return g, int(allv[: dist.get_rank(), 5].sum())
+
+
 def allreduce_score_sums(sums5, device):
     """{sum len, sum score, count, min len, max len} of mia_hip_score_sums over all ranks (integers: exact)."""
     if not _active():
@@ -57,20 +71,28 @@ def allreduce_score_sums(sums5, device):
     return torch.cat([add, lo, hi]).cpu().numpy()
 
 
-def all_gather_ragged(t):
-    """Concatenate variable-length 1-D int64 tensors (insert events) of all ranks."""
+def _gather_counts(n, device):
+    """every rank's n as a python list, one collective and one device-to-host copy"""
+    mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
+    allc = torch.empty(world(), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(allc, mine)
+    return allc.cpu().tolist()
+
+
+def all_gather_ragged(t, counts=None):
+    """Concatenate variable-length 1-D int64 tensors (insert events, links) of all ranks in rank order."""
     if not _active():
         return t
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    counts = [torch.empty_like(n) for _ in range(world())]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    if counts is None:
+        counts = _gather_counts(t.numel(), t.device)
     mx = max(max(counts), 1)
     mine = torch.zeros(mx, dtype=t.dtype, device=t.device)
     mine[: t.numel()] = t
-    parts = [torch.empty_like(mine) for _ in range(world())]
-    dist.all_gather(parts, mine)
-    return torch.cat([parts[r][: counts[r]] for r in range(world())]).contiguous()
+    allt = torch.empty(mx * world(), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(allt, mine)
+    if all(c == mx for c in counts):
+        return allt
+    return torch.cat([allt[r * mx: r * mx + counts[r]] for r in range(world())]).contiguous()
 
 
 def exchange_links(hip, as_tensor):
@@ -81,8 +103,12 @@ def exchange_links(hip, as_tensor):
     if not _active():
         return
     ptr, n = hip.links()
+    # almost always no rank has a link: find that out with one tiny all-gather before moving any list
+    counts = _gather_counts(4 * n, _device())
+    if sum(counts) == 0:
+        return
     mine = as_tensor(ptr, 4 * n, "<i8") if n else torch.zeros(0, dtype=torch.int64, device=_device())
-    alll = all_gather_ragged(mine)
+    alll = all_gather_ragged(mine, counts)
     total = int(alll.numel()) // 4
     if total == 0:
         return

@@ -56,6 +56,9 @@ ev = mdist.all_gather_ragged(torch.arange(rank * 100, rank * 100 + 3 + rank, dty
 s5 = mdist.allreduce_score_sums(np.array([10 + rank, 100 * (rank + 1), 3, 50 - rank, 60 + rank], dtype=np.int64), "cpu")
 assert s5.tolist() == [21, 300, 6, 49, 61], s5
 
+g5, sb = mdist.gather_pre_cull(np.array([10 + rank, 100 * (rank + 1), 3, 50 - rank, 60 + rank], dtype=np.int64), 7 + rank, "cpu")
+assert g5.tolist() == [21, 300, 6, 49, 61] and sb == (0 if rank == 0 else 7), (g5, sb)
+
 # the link exchange of formerly split reads (stale back_asp): rank 0 has two links, rank 1 one; a link is 4 int64
 # {reader, slot, flen<<32|actf, low}.  A stand-in with the library's five calls checks the protocol of exchange_links.
 class FakeHip:
