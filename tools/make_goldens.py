@@ -201,8 +201,21 @@ def maln_cases(mt311_path):
             ad = [NEAND_ADAPT, STAND_ADAPT][i % 2]
             tail = ["", ad[: rnd.randint(1, 12)], ad[: rnd.randint(13, len(ad))], ad][i % 4]
             f.write(f">a{i}\n{body + tail}\n")
+    # the fixture reads as FASTQ (read_fastq, src/io.c:35-175): same bases, dummy qualities, one over-long record and
+    # one record with a description
+    recs = open(os.path.join(G, "tf.fna")).read().split(">")[1:]
+    with open(os.path.join(G, "tf.fq"), "w") as f:
+        for k, r in enumerate(recs):
+            head, seq = r.split("\n", 1)
+            seq = seq.replace("\n", "")
+            if k == 3:
+                head = head.split()[0] + " a description"
+            f.write(f"@{head}\n{seq}\n+\n{'I' * len(seq)}\n")
+        long_seq = (recs[0].split("\n", 1)[1].replace("\n", "") * 4)[:300]
+        f.write(f"@toolong\n{long_seq}\n+\n{'#' * len(long_seq)}\n")
     A = "ancient.submat.txt"
     cases = {
+        "fix_c_fq": ["-r", "tr1.fna", "-f", "tf.fq", "-c"],
         "adapt_T_k12": ["-r", "mt311.fa", "-f", "adapt.fa", "-c", "-k", "12", "-T"],
         "adapt_T_aS_k12": ["-r", "mt311.fa", "-f", "adapt.fa", "-c", "-k", "12", "-T", "-a", "S"],
         "adapt_T_user_k12": ["-r", "mt311.fa", "-f", "adapt.fa", "-c", "-k", "12", "-T", "-a", "GTCAGACACGCAACAGG"],
