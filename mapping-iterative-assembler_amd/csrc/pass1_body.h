@@ -622,6 +622,33 @@ struct Pass1Aligner {
     const bool open[2] = {true, true};
     choose_strand(best, open, scol, len2, res);
     const int st = res.strand;
+    // Most alignments are gap-free: the proof of align_body_quad_plain.h -- (i) best == D(R), (ii) D(r-1) >= -P(r+1) on the
+    // diagonal through the end cell -- then gives the begin point without recomputing any chunk with a trace.
+    {
+      const U lane = w.lane();
+      const int R = len2 - 1, d = res.aec - R, r0 = d < 0 ? -d : 0;
+      const uint32_t RS2 = (uint32_t)((len2 + 1) & ~1) * 2u;
+      int32_t carry = 0;
+      bool ok = true;
+      for (int rb = r0; rb <= R && ok; rb += WAVE) {
+        U r = lane + (uint32_t)rb;
+        M in = r <= (uint32_t)R;
+        U c = r + (uint32_t)d;
+        U code = w.gload_u8(a.ref_codes[st], c, in);
+        U sv = w.sel(in, w.lds_ri16o(U(a.lds_sub) + code * RS2 + r * 2u, 0u), U(0u));
+        if (rb == r0 && d < 0) sv = sv + w.sel(lane == 0u, U((uint32_t)(-(GOP + GEP * (r0 + 1)))), U(0u));   // column 0: sub - P(r+1)
+        U D = w.scan_add(sv) + (uint32_t)carry;
+        M bad = in & (r < (uint32_t)R) & ((D + 0x80000000u) < (U((uint32_t)(-(GOP + 2 * GEP))) - r * (uint32_t)GEP + 0x80000000u));
+        if (w.ballot(bad)) ok = false;
+        const int last = (R - rb) < (WAVE - 1) ? (R - rb) : (WAVE - 1);
+        carry = (int32_t)w.lane_val(D, last);
+      }
+      if (ok && carry == res.score) {
+        res.abr = r0;
+        res.abc = d < 0 ? 0 : d;
+        return res;
+      }
+    }
     walk_back(w, a, res, [&](int ch) {
       uint32_t cb, cc;
       if (ch == 0) {
