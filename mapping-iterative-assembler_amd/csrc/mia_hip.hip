@@ -101,6 +101,13 @@ struct mia_hip_ctx {
     }                                                                                                  \
   } while (0)
 
+// frees the watched temporaries when the scope is left, whichever way (every early return of a long entry point)
+struct ScopeFree {
+  std::vector<void**> w;
+  void watch(void** pp) { w.push_back(pp); }
+  ~ScopeFree() { for (void** pp : w) if (*pp) { (void)hipFree(*pp); *pp = nullptr; } }
+};
+
 template <class T>
 static int dev_alloc(mia_hip_ctx* ctx, T** p, size_t n) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -1313,6 +1320,17 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   uint8_t *d_cf = nullptr, *d_cr = nullptr;
   uint32_t *d_tab[2] = {nullptr, nullptr}, *d_kl[2] = {nullptr, nullptr}, *d_el[2] = {nullptr, nullptr};
   int32_t* d_pos[2] = {nullptr, nullptr};
+  uint8_t *d_packed = nullptr, *d_rc = nullptr, *d_flags = nullptr;
+  uint32_t *d_roff = nullptr, *d_status = nullptr;
+  uint16_t* d_len = nullptr;
+  int32_t *d_score = nullptr, *d_as = nullptr, *d_ae = nullptr;
+  unsigned char* d_trace = nullptr;
+  uint32_t* d_ckpt = nullptr;
+  ScopeFree guard;   // every temporary below is released on any return
+  for (void** pp : {(void**)&d_cf, (void**)&d_cr, (void**)&d_tab[0], (void**)&d_tab[1], (void**)&d_kl[0], (void**)&d_kl[1], (void**)&d_el[0],
+                    (void**)&d_el[1], (void**)&d_pos[0], (void**)&d_pos[1], (void**)&d_packed, (void**)&d_rc, (void**)&d_flags, (void**)&d_roff,
+                    (void**)&d_status, (void**)&d_len, (void**)&d_score, (void**)&d_as, (void**)&d_ae, (void**)&d_trace, (void**)&d_ckpt})
+    guard.watch(pp);
   int rcx = dev_alloc(ctx, &d_cf, cf.size()) | dev_alloc(ctx, &d_cr, cr.size());
   KmerIndex kx{};
   kx.k = kmer_len > 0 ? kmer_len : -1;
@@ -1342,10 +1360,6 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   lap("ref+kmer");
   std::vector<uint8_t> packed((size_t)total + 8, 0);
   pack_reads(n, bases, offsets, roff.data(), len.data(), packed.data());
-  uint8_t *d_packed = nullptr, *d_rc = nullptr, *d_flags = nullptr;
-  uint32_t *d_roff = nullptr, *d_status = nullptr;
-  uint16_t* d_len = nullptr;
-  int32_t *d_score = nullptr, *d_as = nullptr, *d_ae = nullptr;
   rcx |= dev_alloc(ctx, &d_packed, packed.size()) | dev_alloc(ctx, &d_roff, (size_t)n) | dev_alloc(ctx, &d_len, (size_t)n) |
          dev_alloc(ctx, &d_rc, (size_t)n) | dev_alloc(ctx, &d_flags, (size_t)n) | dev_alloc(ctx, &d_status, (size_t)n) |
          dev_alloc(ctx, &d_score, (size_t)n) | dev_alloc(ctx, &d_as, (size_t)n) | dev_alloc(ctx, &d_ae, (size_t)n);
@@ -1371,12 +1385,8 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
   int64_t grid = (int64_t)prop.multiProcessorCount * waves_cu;
   if (grid > n) grid = n;
-  unsigned char* d_trace = nullptr;
-  uint32_t* d_ckpt = nullptr;
   rcx |= dev_alloc(ctx, &d_trace, (size_t)(trace_bytes * grid)) | dev_alloc(ctx, &d_ckpt, (size_t)(ckpt_words * grid));
-  void* tmp[] = {d_cf, d_cr, d_tab[0], d_tab[1], d_kl[0], d_kl[1], d_el[0], d_el[1], d_pos[0], d_pos[1], d_packed, d_roff, d_len, d_rc, d_flags, d_status, d_score, d_as, d_ae, d_trace, d_ckpt};
-  auto cleanup = [&]() { for (void* p : tmp) if (p) (void)hipFree(p); };
-  if (rcx) { cleanup(); return rcx == 2 ? MIA_HIP_ERR_DEVICE : MIA_HIP_ERR_NOMEM; }
+  if (rcx) return rcx == 2 ? MIA_HIP_ERR_DEVICE : MIA_HIP_ERR_NOMEM;
   lap("pack+alloc");
   hipError_t e = hipSuccess;
   hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -1403,8 +1413,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
     ctx->ev_free.push_back(ctx->ev_used.back());
     ctx->ev_used.pop_back();
   }
-  cleanup();
-  lap("free");
+  lap("done");
   if (e != hipSuccess) { ctx->err = std::string("pass1: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   return MIA_HIP_OK;
 }

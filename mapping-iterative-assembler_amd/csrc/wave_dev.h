@@ -72,9 +72,6 @@ struct DevWave {
   }
   __device__ __forceinline__ U row_last(U v) const { return (U)__shfl((int)v, (int)((lane() & ~15u) | 15u)); }
   __device__ __forceinline__ static U udiv13(U e) { return e / 13u; }
-  __device__ __forceinline__ void tr_w128(U off, U v0, U v1, U v2, U v3) const {
-    *reinterpret_cast<uint4*>(trace + off) = make_uint4(v0, v1, v2, v3);
-  }
   // a + b + c with c wave-uniform, as ONE v_add3_u32 that the optimiser cannot hoist into a per-column register
   __device__ __forceinline__ static U add3(U a, U b, uint32_t c) {
     U r;
@@ -123,12 +120,6 @@ struct DevWave {
   __device__ __forceinline__ static U lds_ri16a(U addr, uint32_t imm) {
     return (U)(int32_t)*reinterpret_cast<const __attribute__((address_space(3))) int16_t*>((uintptr_t)(addr + imm));
   }
-  __device__ __forceinline__ static U and_or(U x, uint32_t m, uint32_t o) { return (x & m) | o; }   // v_and_or_b32
-  // lane mask moved one lane up inside each 16-lane row; the first lane of a row gets false
-  __device__ __forceinline__ M mrshr1(M x) const {
-    return __builtin_amdgcn_update_dpp(0, x ? 1 : 0, DPP_ROW_SHR + 1, 0xF, 0xF, true) != 0;
-  }
-  __device__ __forceinline__ static M msel(M c, M x, M y) { return c ? x : y; }
   __device__ __forceinline__ static U pack16(U lo, U hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }   // {hi.lo16, lo.lo16}
   __device__ __forceinline__ static U umax(U a, U b) { return a > b ? a : b; }
   __device__ __forceinline__ static U umin(U a, U b) { return a < b ? a : b; }
@@ -180,7 +171,6 @@ struct DevWave {
   __device__ __forceinline__ U tr_r16(U off, M ok) const {
     return ok ? (U)__hip_atomic_load(reinterpret_cast<const uint16_t*>(trace + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   }
-  __device__ __forceinline__ U lds_r8(U off, M ok) const { return ok ? (U)lds[off] : 0u; }
   // trace slab: plain global stores / byte loads; the slab is private to the wave, re-used
   // for every read it processes and small enough (<= 32 waves/CU x 256 CUs) to live in
   // L2 / Infinity Cache, so the bytes rarely reach HBM

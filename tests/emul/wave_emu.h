@@ -75,10 +75,6 @@ struct EmuWave {
   U rscan_max(const U& v) const { EV r; uint32_t m = 0; for (int i = 0; i < 64; i++) { if ((i & 15) == 0) m = 0; m = v.a[i] > m ? v.a[i] : m; r.a[i] = m; } return r; }
   U row_last(const U& v) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = v.a[(i & ~15) | 15]; return r; }
   static U udiv13(const U& e) { EV r; for (int i = 0; i < 64; i++) r.a[i] = e.a[i] / 13u; return r; }
-  void tr_w128(const U& off, const U& v0, const U& v1, const U& v2, const U& v3) {
-    for (int i = 0; i < 64; i++) { trace.at(off.a[i] + 15); memcpy(&trace[off.a[i]], &v0.a[i], 4); memcpy(&trace[off.a[i] + 4], &v1.a[i], 4);
-                                   memcpy(&trace[off.a[i] + 8], &v2.a[i], 4); memcpy(&trace[off.a[i] + 12], &v3.a[i], 4); }
-  }
   static U add3(const U& x, const U& y, uint32_t c) { EV r; for (int i = 0; i < 64; i++) r.a[i] = x.a[i] + y.a[i] + c; return r; }
   void tr_w128m(const U& off, const U& v0, const U& v1, const U& v2, const U& v3, const M& ok) {
     for (int i = 0; i < 64; i++) if (ok.a[i]) { trace.at(off.a[i] + 15); memcpy(&trace[off.a[i]], &v0.a[i], 4); memcpy(&trace[off.a[i] + 4], &v1.a[i], 4);
@@ -91,9 +87,6 @@ struct EmuWave {
   template <int S>
   static U shl_addc(const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] << S) + y.a[i]; return r; }
   static U shl_add(const U& x, int sh, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] << sh) + y.a[i]; return r; }
-  static U and_or(const U& x, uint32_t m, uint32_t o) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] & m) | o; return r; }
-  M mrshr1(const M& x) const { EM r; for (int i = 0; i < 64; i++) r.a[i] = (i & 15) ? x.a[i - 1] : false; return r; }
-  static M msel(const M& c, const M& x, const M& y) { EM r; for (int i = 0; i < 64; i++) r.a[i] = c.a[i] ? x.a[i] : y.a[i]; return r; }
   static U pack16(const U& lo, const U& hi) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (lo.a[i] & 0xFFFFu) | (hi.a[i] << 16); return r; }
   static U bfi(uint32_t m, const U& x, const U& y) { EV r; for (int i = 0; i < 64; i++) r.a[i] = (x.a[i] & m) | (y.a[i] & ~m); return r; }
   U lds_ri16o(const U& off, uint32_t imm) const { EV r; for (int i = 0; i < 64; i++) { int16_t x; lds.at(off.a[i] + imm + 1); memcpy(&x, &lds[off.a[i] + imm], 2); r.a[i] = (uint32_t)(int32_t)x; } return r; }
@@ -121,7 +114,6 @@ struct EmuWave {
   static U gload_u32(const uint32_t* p, const U& idx, const M& ok) { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? p[idx.a[i]] : 0u; return r; }
   static void gstore_u32(uint32_t* p, const U& idx, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) p[idx.a[i]] = v.a[i]; }
   U tr_r16(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) if (ok.a[i]) { uint16_t x; trace.at(off.a[i] + 1); memcpy(&x, &trace[off.a[i]], 2); r.a[i] = x; } return r; }
-  U lds_r8(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? lds.at(off.a[i]) : 0u; return r; }
   void lds_fence() const {}
   void tr_w32(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { trace.at(off.a[i] + 3); memcpy(&trace[off.a[i]], &v.a[i], 4); } }
   U tr_r8(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? trace.at(off.a[i]) : 0u; return r; }
