@@ -95,6 +95,15 @@ int mia_hip_realign(mia_hip_ctx *ctx, const char *new_ref, int32_t ref_len, int 
  * pointer may be NULL. */
 int mia_hip_get_alignments(mia_hip_ctx *ctx, int32_t *score, int32_t *as, int32_t *ae);
 
+/* ccheck's per-read re-alignment (src/ccheck.cc:569-604: init_alignment, pop_s1c_in_a/pop_s2c_in_a, dyn_prog,
+ * max_sg_score, find_align_begin, populate_pwaln_to_begin per AlnSeq): read i of the store against ITS OWN
+ * reference string windows[win_off[i] .. win_off[i+1]) -- ASCII, only upper-case ACGT are bases -- with
+ * sg5 = sg3 = 1, no margin around the window and no whole-reference fallback; rc[i] of the upload selects the
+ * matrix as in mia_hip_realign.  win_off[n_reads+1]; empty windows are an argument error.  Results come back
+ * through mia_hip_get_alignments (as/ae = win_off[i] - win_off[0] + abc/aec) and mia_hip_get_scripts.  The
+ * consensus path (cull, tally) needs a mia_hip_realign again afterwards. */
+int mia_hip_align_windows(mia_hip_ctx *ctx, const char *windows, const int64_t *win_off);
+
 /* The alignment itself, i.e. what populate_pwaln_to_begin (src/mia.c:1440-1497)
  * hands to merge_pwaln_into_maln: for read i and read row r,
  * cols[i*stride + r] = wrapped reference column aligned to that base minus

@@ -39,6 +39,7 @@ def _load():
     lib.mia_hip_upload_reads.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     lib.mia_hip_pass1.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     lib.mia_hip_realign.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int]
+    lib.mia_hip_align_windows.argtypes = [vp, vp, vp]
     lib.mia_hip_get_alignments.argtypes = [vp, vp, vp, vp]
     lib.mia_hip_get_scripts.argtypes = [vp, vp, C.c_int32, vp]
     lib.mia_hip_cull.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.c_int64]
@@ -88,7 +89,7 @@ def lib():
 def exported_symbols():
     """Every entry point include/mia_hip.h declares (used by the CPU-side ABI test)."""
     return ["mia_hip_create", "mia_hip_destroy", "mia_hip_last_error", "mia_hip_sync", "mia_hip_set_pssm",
-            "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
+            "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_align_windows", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
@@ -200,6 +201,15 @@ class MiaHip:
             ref = ref.encode()
         self.L = len(ref)
         self._chk(self._l.mia_hip_realign(self._h, ref, len(ref), 1 if circular else 0))
+
+    def align_windows(self, windows, win_off):
+        """ccheck's per-read re-alignment (reference src/ccheck.cc:569-604): read i against its own reference string
+        windows[win_off[i]:win_off[i+1]], no margin; results through alignments() / scripts(), columns counted from
+        win_off[i] - win_off[0]."""
+        w = np.frombuffer(windows.encode() if isinstance(windows, str) else bytes(windows), dtype=np.uint8)
+        off = np.ascontiguousarray(win_off, dtype=np.int64)
+        assert len(off) == self.n + 1 and off[-1] <= len(w)
+        self._chk(self._l.mia_hip_align_windows(self._h, _ptr(w), _ptr(off)))
 
     def alignments(self):
         s = np.empty(self.n, dtype=np.int32)

@@ -41,7 +41,7 @@ struct mia_hip_ctx {
   int use_band = 1;   // MIA_HIP_NO_BAND=1: the quad kernel stores the full trace
   int32_t* d_bins = nullptr;  // [count N_BINS][off N_BINS][cursor N_BINS][wide_count 1]
   // reference
-  uint8_t* d_ref = nullptr; int ref_cap = 0; int L = 0, wrap = 0; bool have_ref = false; bool aligned = false;
+  uint8_t* d_ref = nullptr; int ref_cap = 0; int L = 0, wrap = 0; int explicit_win = 0; bool have_ref = false; bool aligned = false;
   // cull
   int64_t* d_slot = nullptr; int64_t* d_partial = nullptr; int64_t* d_total = nullptr;
   uint8_t *d_slot_dropped = nullptr, *d_drop_f = nullptr, *d_drop_b = nullptr; int64_t n_slots = 0;
@@ -387,13 +387,15 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
   }
   hipEvent_t e0, e1;
   if (get_events(ctx, &e0, &e1)) return hipErrorOutOfMemory;
-  RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
+  RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
   (void)hipEventRecord(e0, ctx->stream);
   hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
                      count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg);
   (void)hipEventRecord(e1, ctx->stream);
   return hipGetLastError();
 }
+
+static int align_all(mia_hip_ctx* ctx);
 
 extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular) {
   if (!ctx || !new_ref || ref_len <= 0) return MIA_HIP_ERR_ARG;
@@ -409,10 +411,16 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     ctx->ref_cap = (int)codes.size() * 2;
   }
   HIPCHK(hipMemcpyAsync(ctx->d_ref, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
-  ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true;
+  ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true; ctx->explicit_win = 0;
+  return align_all(ctx);
+}
+
+// every strand_known read against its window of ctx->d_ref: plan, values-only pass, trace kernels, exact kernel
+static int align_all(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
+  const int wrap = ctx->wrap;
   if (n == 0) { ctx->aligned = true; return MIA_HIP_OK; }
-  RefInfo ref{ctx->d_ref, L, wrap};
+  RefInfo ref{ctx->d_ref, ctx->L, wrap, ctx->explicit_win};
   int32_t* d_count = ctx->d_bins;
   int32_t* d_off = ctx->d_bins + N_BINS;
   int32_t* d_cursor = ctx->d_bins + 2 * N_BINS;
@@ -519,7 +527,7 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
       HIPCHK(hipMemcpy(&ae[t], ctx->d_ae + wl[t], 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(&ln[t], ctx->d_len + wl[t], 2, hipMemcpyDeviceToHost));
       int s, n1;
-      realign_window(as[t], ae[t], ln[t], wrap, &s, &n1);
+      read_window(ref, as[t], ae[t], ln[t], &s, &n1);
       soff[t] = total;
       total += (int64_t)ln[t] * n1 + 5 * (int64_t)n1 + 16;
     }
@@ -541,6 +549,38 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   ctx->culled = false;
   ctx->tallied = false;
   return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_align_windows(mia_hip_ctx* ctx, const char* windows, const int64_t* win_off) {
+  if (!ctx || !windows || !win_off) return MIA_HIP_ERR_ARG;
+  if (!ctx->have_pssm || !ctx->d_packed) { ctx->err = "set_pssm and upload_reads must precede align_windows"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int64_t n = ctx->rs.n;
+  const int64_t total = n ? win_off[n] - win_off[0] : 0;
+  if (total < 0 || total > INT32_MAX - 128) { ctx->err = "align_windows: the windows of one call must stay below 2^31 characters"; return MIA_HIP_ERR_ARG; }
+  std::vector<int32_t> as((size_t)n), ae((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    if (win_off[i + 1] <= win_off[i]) { ctx->err = "align_windows: empty window"; return MIA_HIP_ERR_ARG; }
+    as[(size_t)i] = (int32_t)(win_off[i] - win_off[0]);
+    ae[(size_t)i] = (int32_t)(win_off[i + 1] - win_off[0] - 1);
+  }
+  std::vector<uint8_t> codes((size_t)total + 64, 4);
+  const char* w = windows + (n ? win_off[0] : 0);
+  for (int64_t i = 0; i < total; i++) codes[(size_t)i] = base_code(w[i]);
+  if ((int64_t)codes.size() > ctx->ref_cap) {
+    if (dev_alloc(ctx, &ctx->d_ref, codes.size())) return MIA_HIP_ERR_NOMEM;
+    ctx->ref_cap = (int)codes.size();
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_ref, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
+  if (n) {
+    HIPCHK(hipMemcpyAsync(ctx->d_as, as.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_ae, ae.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  // not a reference the consensus path can use: cull / tally need a realign first
+  ctx->L = (int)total; ctx->wrap = (int)total; ctx->have_ref = false; ctx->explicit_win = 1;
+  const int rcode = align_all(ctx);
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // as/ae/codes are stack-owned host buffers
+  return rcode;
 }
 
 extern "C" int mia_hip_get_alignments(mia_hip_ctx* ctx, int32_t* score, int32_t* as, int32_t* ae) {
@@ -608,6 +648,7 @@ static int check_cull_flags(mia_hip_ctx* ctx, uint32_t fl) {
 extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, double intercept, int64_t slot_base) {
   if (!ctx) return MIA_HIP_ERR_ARG;
   if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
+  if (ctx->explicit_win) { ctx->err = "the last alignment ran on caller-supplied windows (align_windows): realign first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n = ctx->rs.n;
   if (n == 0) return MIA_HIP_OK;

@@ -46,6 +46,7 @@ struct ReadSet {
 struct RefInfo {
   const uint8_t* codes;
   int32_t L, wrap;
+  int32_t explicit_win;   // mia_hip_align_windows: read i is aligned to codes[as[i] .. ae[i]] as it stands
 };
 
 // window of reiterate_assembly (src/mia_main.c:191-212)
@@ -55,6 +56,12 @@ MIA_HD inline void realign_window(int as, int ae, int len2, int wrap, int* ref_s
   if (rs + len2 > re) { rs = 0; re = wrap; }
   *ref_start = rs;
   *len1 = re - rs;
+}
+
+// the window of read i: reiterate_assembly's, or the caller's own (src/ccheck.cc:556,589-592: no margin, no fallback)
+MIA_HD inline void read_window(const RefInfo& ref, int as, int ae, int len2, int* ref_start, int* len1) {
+  if (ref.explicit_win) { *ref_start = as; *len1 = ae - as + 1; return; }
+  realign_window(as, ae, len2, ref.wrap, ref_start, len1);
 }
 
 struct PackSet { PackParams p[N_CPL]; int ok[N_CPL]; };
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
     if (i < rs.n) {
       if (rs.sk[i]) {
         int s, l1;
-        realign_window(rs.as[i], rs.ae[i], rs.len[i], ref.wrap, &s, &l1);
+        read_window(ref, rs.as[i], rs.ae[i], rs.len[i], &s, &l1);
         b = classify(rs.len[i], l1, ps, use_quad);
       } else {
         rs.status[i] = ST_SKIPPED;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, co
     AlignArgs a;
     int s, l1;
     const int len2 = rs.len[i];
-    realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &l1);
+    read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
     a.ref_codes = ref.codes;
     a.ref_start = s;
     a.len1 = l1;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, c
       if (i >= 0) {
         int s, l1;
         const int len2 = rs.len[i];
-        realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &l1);
+        read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
         a.len2 = len2;      // equal for the whole quad: the planner pads every length bin to a multiple of four
         a.ref_start[g] = s; a.len1[g] = l1; a.roff[g] = rs.roff[i]; a.rc[g] = rs.rc[i];
         a.cols_out[g] = rs.cols + (int64_t)i * rs.stride;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64, 4) void k_align_quad_plain(ReadSet rs, RefInfo 
       if (i >= 0) {
         int s, l1;
         const int len2 = rs.len[i];
-        realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &l1);
+        read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
         a.len2 = len2;
         a.ref_start[g] = s; a.len1[g] = l1; a.roff[g] = rs.roff[i]; a.rc[g] = rs.rc[i];
         a.cols_out[g] = rs.cols + (int64_t)i * rs.stride;
@@ -317,7 +324,7 @@ __global__ void k_align_wide(ReadSet rs, RefInfo ref, const int32_t* pssm2, cons
   const int i = list[t];
   const int len2 = rs.len[i];
   int s, n1;
-  realign_window(rs.as[i], rs.ae[i], len2, ref.wrap, &s, &n1);
+  read_window(ref, rs.as[i], rs.ae[i], len2, &s, &n1);
   const uint8_t* c1 = ref.codes + s;
   const uint8_t* rp = rs.packed + rs.roff[i];
   const int32_t* pm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);
