@@ -97,12 +97,13 @@ int mia_hip_get_alignments(mia_hip_ctx *ctx, int32_t *score, int32_t *as, int32_
 
 /* ccheck's per-read re-alignment (src/ccheck.cc:569-604: init_alignment, pop_s1c_in_a/pop_s2c_in_a, dyn_prog,
  * max_sg_score, find_align_begin, populate_pwaln_to_begin per AlnSeq): read i of the store against ITS OWN
- * reference string windows[win_off[i] .. win_off[i+1]) -- ASCII, only upper-case ACGT are bases -- with
- * sg5 = sg3 = 1, no margin around the window and no whole-reference fallback; rc[i] of the upload selects the
- * matrix as in mia_hip_realign.  win_off[n_reads+1]; empty windows are an argument error.  Results come back
- * through mia_hip_get_alignments (as/ae = win_off[i] - win_off[0] + abc/aec) and mia_hip_get_scripts.  The
- * consensus path (cull, tally) needs a mia_hip_realign again afterwards. */
-int mia_hip_align_windows(mia_hip_ctx *ctx, const char *windows, const int64_t *win_off);
+ * window ref[win_start[i] .. win_start[i] + win_len[i]) of a caller-supplied string (ASCII, only upper-case ACGT
+ * are bases; for ccheck the contaminant consensus, whose lifted-over stretch is the window) with sg5 = sg3 = 1,
+ * no margin around the window and no whole-reference fallback; windows may be shorter than the read and may
+ * overlap.  rc[i] of the upload selects the matrix as in mia_hip_realign.  Empty windows are an argument error.
+ * Results come back through mia_hip_get_alignments (as/ae = win_start[i] + abc/aec) and mia_hip_get_scripts
+ * (columns relative to ref_start[i]).  The consensus path (cull, tally) needs a mia_hip_realign afterwards. */
+int mia_hip_align_windows(mia_hip_ctx *ctx, const char *ref, int64_t ref_len, const int64_t *win_start, const int32_t *win_len);
 
 /* The alignment itself, i.e. what populate_pwaln_to_begin (src/mia.c:1440-1497)
  * hands to merge_pwaln_into_maln: for read i and read row r,
@@ -229,6 +230,15 @@ int mia_hip_get_ins_tally(mia_hip_ctx *ctx, int32_t *ins_off, int32_t *ins_tally
  * The backtrace strings of the reference are not produced.  seq_a up to 32768 characters. */
 int mia_hip_myers(mia_hip_ctx *ctx, int64_t n_pairs, const char *const *seq_a, const char *const *seq_b, const int32_t *mode,
                   const int32_t *maxd, uint32_t *dist);
+
+/* One myers_diff call with its backtrace (what ccheck asks for, src/ccheck.cc:478-480): the distance comes from the
+ * bit-vector kernel above; the two rows of the alignment (bt_a over seq_a, bt_b over seq_b, '-' for a gap) are
+ * rebuilt on the host from the furthest-reaching D-paths with the reference's preferences (src/myers_align.c:47-83).
+ * Buffers of len + dist + 2 bytes each, as the reference wants them (len_a + maxd + 2 is enough).  BOTH rows are
+ * NUL-terminated (the reference leaves bt_b without its terminator, src/myers_align.c:44-45).  dist = 0xFFFFFFFF and
+ * untouched buffers when the distance is >= maxd.  bt_a / bt_b may be NULL. */
+int mia_hip_myers_align(mia_hip_ctx *ctx, const char *seq_a, int32_t mode, const char *seq_b, int32_t maxd, uint32_t *dist,
+                        char *bt_a, char *bt_b);
 
 /* ---- timing hooks for bench.py (HIP events on the context's stream) ------ */
 /* milliseconds spent in, and launches of, the windowed DP kernel since the last reset */

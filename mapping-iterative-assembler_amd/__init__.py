@@ -39,7 +39,7 @@ def _load():
     lib.mia_hip_upload_reads.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     lib.mia_hip_pass1.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     lib.mia_hip_realign.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int]
-    lib.mia_hip_align_windows.argtypes = [vp, vp, vp]
+    lib.mia_hip_align_windows.argtypes = [vp, vp, C.c_int64, vp, vp]
     lib.mia_hip_get_alignments.argtypes = [vp, vp, vp, vp]
     lib.mia_hip_get_scripts.argtypes = [vp, vp, C.c_int32, vp]
     lib.mia_hip_cull.argtypes = [vp, C.c_int32, C.c_double, C.c_double, C.c_int64]
@@ -55,6 +55,7 @@ def _load():
     lib.mia_hip_get_tally.argtypes = [vp, vp, vp]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.mia_hip_myers_align.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, vp, vp, vp]
     lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
     lib.mia_hip_ma_tally.argtypes = [vp, C.c_int32, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.mia_hip_trim.argtypes = [vp, C.c_char_p, C.c_int64, vp, vp, vp, vp]
@@ -92,7 +93,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_align_windows", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
             "mia_hip_score_cut_from_sums"]
@@ -202,14 +203,14 @@ class MiaHip:
         self.L = len(ref)
         self._chk(self._l.mia_hip_realign(self._h, ref, len(ref), 1 if circular else 0))
 
-    def align_windows(self, windows, win_off):
-        """ccheck's per-read re-alignment (reference src/ccheck.cc:569-604): read i against its own reference string
-        windows[win_off[i]:win_off[i+1]], no margin; results through alignments() / scripts(), columns counted from
-        win_off[i] - win_off[0]."""
-        w = np.frombuffer(windows.encode() if isinstance(windows, str) else bytes(windows), dtype=np.uint8)
-        off = np.ascontiguousarray(win_off, dtype=np.int64)
-        assert len(off) == self.n + 1 and off[-1] <= len(w)
-        self._chk(self._l.mia_hip_align_windows(self._h, _ptr(w), _ptr(off)))
+    def align_windows(self, ref, win_start, win_len):
+        """ccheck's per-read re-alignment (reference src/ccheck.cc:569-604): read i against its own window
+        ref[win_start[i] : win_start[i] + win_len[i]], no margin; results through alignments() / scripts()."""
+        w = np.frombuffer(ref.encode() if isinstance(ref, str) else bytes(ref), dtype=np.uint8)
+        st = np.ascontiguousarray(win_start, dtype=np.int64)
+        ln = np.ascontiguousarray(win_len, dtype=np.int32)
+        assert len(st) == self.n and len(ln) == self.n
+        self._chk(self._l.mia_hip_align_windows(self._h, _ptr(w), len(w), _ptr(st), _ptr(ln)))
 
     def alignments(self):
         s = np.empty(self.n, dtype=np.int32)
@@ -299,6 +300,18 @@ class MiaHip:
         n = C.c_int64()
         self._chk(self._l.mia_hip_consensus(self._h, cons_code, buf, cap, C.byref(n)))
         return buf.raw[: n.value].decode()
+
+    def myers_align(self, seq_a, mode, seq_b, maxd):
+        """myers_diff with its backtrace (reference src/myers_align.h:35): (distance or None, row over seq_a, row over seq_b)"""
+        a = seq_a.encode() if isinstance(seq_a, str) else seq_a
+        b = seq_b.encode() if isinstance(seq_b, str) else seq_b
+        d = C.c_uint32(0)
+        cap = len(a) + len(b) + 4
+        ra, rb = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        self._chk(self._l.mia_hip_myers_align(self._h, a, mode, b, maxd, C.byref(d), ra, rb))
+        if d.value == 0xFFFFFFFF:
+            return None, None, None
+        return d.value, ra.value.decode(), rb.value.decode()
 
     def myers(self, seq_a, seq_b, mode, maxd):
         """Batch of myers_diff calls (reference src/myers_align.h:35): distances, 0xFFFFFFFF if >= maxd."""

@@ -9,3 +9,4 @@ cp "$here/build/libmia_hip.so" "$here/libmia_hip.so"
 # host program (mia command line on top of the C ABI)
 g++ -O2 -std=c++17 -Wall -pthread -o "$here/mia_hip" "$here/host/mia_main.cpp" -L"$here" -lmia_hip -Wl,-rpath,'$ORIGIN'
 g++ -O2 -std=c++17 -Wall -pthread -o "$here/ma_hip" "$here/host/ma_main.cpp" -L"$here" -lmia_hip -Wl,-rpath,'$ORIGIN'
+g++ -O2 -std=c++17 -Wall -pthread -o "$here/ccheck_hip" "$here/host/ccheck_main.cpp" -L"$here" -lmia_hip -Wl,-rpath,'$ORIGIN'

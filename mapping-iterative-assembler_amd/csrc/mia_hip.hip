@@ -551,22 +551,23 @@ static int align_all(mia_hip_ctx* ctx) {
   return MIA_HIP_OK;
 }
 
-extern "C" int mia_hip_align_windows(mia_hip_ctx* ctx, const char* windows, const int64_t* win_off) {
-  if (!ctx || !windows || !win_off) return MIA_HIP_ERR_ARG;
+extern "C" int mia_hip_align_windows(mia_hip_ctx* ctx, const char* ref, int64_t ref_len, const int64_t* win_start, const int32_t* win_len) {
+  if (!ctx || !ref || !win_start || !win_len || ref_len <= 0) return MIA_HIP_ERR_ARG;
   if (!ctx->have_pssm || !ctx->d_packed) { ctx->err = "set_pssm and upload_reads must precede align_windows"; return MIA_HIP_ERR_STATE; }
+  if (ref_len > INT32_MAX - 128) { ctx->err = "align_windows: the reference string must stay below 2^31 characters"; return MIA_HIP_ERR_ARG; }
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n = ctx->rs.n;
-  const int64_t total = n ? win_off[n] - win_off[0] : 0;
-  if (total < 0 || total > INT32_MAX - 128) { ctx->err = "align_windows: the windows of one call must stay below 2^31 characters"; return MIA_HIP_ERR_ARG; }
   std::vector<int32_t> as((size_t)n), ae((size_t)n);
   for (int64_t i = 0; i < n; i++) {
-    if (win_off[i + 1] <= win_off[i]) { ctx->err = "align_windows: empty window"; return MIA_HIP_ERR_ARG; }
-    as[(size_t)i] = (int32_t)(win_off[i] - win_off[0]);
-    ae[(size_t)i] = (int32_t)(win_off[i + 1] - win_off[0] - 1);
+    if (win_len[i] <= 0 || win_start[i] < 0 || win_start[i] + win_len[i] > ref_len) {
+      ctx->err = "align_windows: window " + std::to_string(i) + " is empty or leaves the reference string";
+      return MIA_HIP_ERR_ARG;
+    }
+    as[(size_t)i] = (int32_t)win_start[i];
+    ae[(size_t)i] = (int32_t)(win_start[i] + win_len[i] - 1);
   }
-  std::vector<uint8_t> codes((size_t)total + 64, 4);
-  const char* w = windows + (n ? win_off[0] : 0);
-  for (int64_t i = 0; i < total; i++) codes[(size_t)i] = base_code(w[i]);
+  std::vector<uint8_t> codes((size_t)ref_len + 64, 4);
+  for (int64_t i = 0; i < ref_len; i++) codes[(size_t)i] = base_code(ref[i]);
   if ((int64_t)codes.size() > ctx->ref_cap) {
     if (dev_alloc(ctx, &ctx->d_ref, codes.size())) return MIA_HIP_ERR_NOMEM;
     ctx->ref_cap = (int)codes.size();
@@ -577,9 +578,9 @@ extern "C" int mia_hip_align_windows(mia_hip_ctx* ctx, const char* windows, cons
     HIPCHK(hipMemcpyAsync(ctx->d_ae, ae.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   }
   // not a reference the consensus path can use: cull / tally need a realign first
-  ctx->L = (int)total; ctx->wrap = (int)total; ctx->have_ref = false; ctx->explicit_win = 1;
+  ctx->L = (int)ref_len; ctx->wrap = (int)ref_len; ctx->have_ref = false; ctx->explicit_win = 1;
   const int rcode = align_all(ctx);
-  HIPCHK(hipStreamSynchronize(ctx->stream));   // as/ae/codes are stack-owned host buffers
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // as / ae / codes are host buffers of this call
   return rcode;
 }
 
@@ -1496,6 +1497,69 @@ extern "C" int mia_hip_myers(mia_hip_ctx* ctx, int64_t n, const char* const* seq
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_blob); (void)hipFree(d_pairs); (void)hipFree(d_out);
   if (e != hipSuccess) { ctx->err = std::string("myers: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  return MIA_HIP_OK;
+}
+
+// The alignment behind a distance the device has already established: Myers' furthest-reaching D-paths (1986) for
+// D = 0 .. dist, then the walk back with the reference's preferences (mismatch, then a seq_b-only column, then a
+// seq_a-only column, else one step down the snake; src/myers_align.c:47-83).  Host code: the table has (dist+1)^2
+// cells and is walked once; the O(len * dist / 64) search for `dist` itself ran on the GPU.
+static bool ond_backtrace(const char* a, int la, const char* b, int lb, int mode, int dist, std::string* row_a, std::string* row_b) {
+  const int NONE = INT32_MIN / 2;
+  auto bits = [](char c) { return (int)iupac_bits(c); };
+  std::vector<int> v((size_t)(dist + 1) * (size_t)(dist + 1), NONE);   // row d starts at d*d, diagonal k at index k+d
+  auto at = [&](int d, int k) -> int { return (k < -d || k > d) ? NONE : v[(size_t)d * d + (size_t)(k + d)]; };
+  int end_k = 0;
+  bool found = false;
+  for (int d = 0; d <= dist && !found; d++) {
+    const int klo = -d > -la ? -d : -la, khi = d < lb ? d : lb;
+    for (int k = klo; k <= khi; k++) {
+      int x = 0;
+      if (d > 0) {
+        const int keep = at(d - 1, k), from_left = at(d - 1, k - 1), from_right = at(d - 1, k + 1);
+        x = keep == NONE ? NONE : keep + 1;
+        if (from_left != NONE && from_left + 1 > x) x = from_left + 1;
+        if (from_right != NONE && from_right > x) x = from_right;
+        if (x == NONE) continue;
+      }
+      int y = x - k;
+      while (x < lb && y < la && x >= 0 && y >= 0 && (bits(b[x]) & bits(a[y]))) { x++; y++; }
+      v[(size_t)d * d + (size_t)(k + d)] = x;
+      if ((mode == 1 || y == la) && (mode == 2 || x == lb)) {
+        if (d != dist) return false;
+        end_k = k; found = true;
+        break;
+      }
+    }
+  }
+  if (!found) return false;
+  std::string ra, rb;   // built back to front
+  int k = end_k, x = at(dist, k), y = x - k;
+  for (int d = dist; d != 0;) {
+    if (k != -d && k != d && x == at(d - 1, k) + 1) { d--; x--; y--; rb.push_back(b[x]); ra.push_back(a[y]); }
+    else if (k > -d + 1 && x == at(d - 1, k - 1) + 1) { x--; k--; d--; rb.push_back(b[x]); ra.push_back('-'); }
+    else if (k < d - 1 && x == at(d - 1, k + 1)) { k++; y--; d--; rb.push_back('-'); ra.push_back(a[y]); }
+    else { x--; y--; rb.push_back(b[x]); ra.push_back(a[y]); }
+    if (x < 0 || y < 0) return false;
+  }
+  while (x > 0) { x--; rb.push_back(b[x]); ra.push_back(a[x]); }
+  row_a->assign(ra.rbegin(), ra.rend());
+  row_b->assign(rb.rbegin(), rb.rend());
+  return true;
+}
+
+extern "C" int mia_hip_myers_align(mia_hip_ctx* ctx, const char* seq_a, int32_t mode, const char* seq_b, int32_t maxd, uint32_t* dist,
+                                   char* bt_a, char* bt_b) {
+  if (!ctx || !seq_a || !seq_b || !dist || mode < 0 || mode > 2) return MIA_HIP_ERR_ARG;
+  const int rc = mia_hip_myers(ctx, 1, &seq_a, &seq_b, &mode, &maxd, dist);
+  if (rc != MIA_HIP_OK || *dist == 0xFFFFFFFFu || (!bt_a && !bt_b)) return rc;
+  std::string ra, rb;
+  if (!ond_backtrace(seq_a, (int)strlen(seq_a), seq_b, (int)strlen(seq_b), mode, (int)*dist, &ra, &rb)) {
+    ctx->err = "myers_align: the D-path table does not end at the distance the device computed";
+    return MIA_HIP_ERR_DEVICE;
+  }
+  if (bt_a) memcpy(bt_a, ra.c_str(), ra.size() + 1);
+  if (bt_b) memcpy(bt_b, rb.c_str(), rb.size() + 1);
   return MIA_HIP_OK;
 }
 

@@ -23,7 +23,7 @@ namespace mia {
 
 constexpr int MYERS_MAX_K = 8;   // blocks per lane -> seq_a up to 64*64*8 = 32768 characters
 
-__device__ __forceinline__ uint32_t iupac_bits(char x) {   // src/myers_align.h:40-67
+__host__ __device__ __forceinline__ uint32_t iupac_bits(char x) {   // src/myers_align.h:40-67
   switch (x & ~32) {
     case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': case 'U': return 8;
     case 'S': return 6; case 'W': return 9; case 'R': return 5; case 'Y': return 10; case 'K': return 12; case 'M': return 3;

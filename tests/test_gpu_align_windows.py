@@ -30,7 +30,7 @@ def run_batch(mod, pssm_words, pairs):
     woff = np.concatenate([[0], np.cumsum([len(w) for w, _ in pairs])]).astype(np.int64)
     h.upload_reads(np.frombuffer(reads.encode(), dtype=np.uint8), roff, np.zeros(n, np.uint8), np.ones(n, np.uint8),
                    np.zeros(n, np.int32), np.zeros(n, np.int32))
-    h.align_windows("".join(w for w, _ in pairs), woff)
+    h.align_windows("".join(w for w, _ in pairs), woff[:-1], np.diff(woff))
     score, as_, ae = h.alignments()
     cols, rstart = h.scripts()
     out = []

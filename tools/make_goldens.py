@@ -12,6 +12,7 @@ the GPU box, which has no /root/reference, can replay them.
   tests/golden/myers_vectors.txt     Myers vectors    (ref_myers_driver)
   tests/golden/maln/<case>.<iter>    whole-run .maln files, line 1 (timestamp) removed
   tests/golden/maln/cases.json       the command line of each case
+  tests/golden/ccheck/*              ccheck inputs (.maln.gz) and the reference's reports on them
 """
 import json, os, random, shutil, subprocess, sys, tempfile
 
@@ -358,11 +359,121 @@ def ma_cases():
     print("ma goldens:", len(os.listdir(out_dir)) - 1, "files,", len(hashes), "hashed")
 
 
+CCHECK_RUNS = {
+    # name -> (arguments in front of the file names, file names)
+    "plain": ([], ["cc_flat.maln"]),
+    "ancient": (["-a"], ["cc_anc.maln"]),
+    "anc_plain": ([], ["cc_anc.maln"]),
+    "tv": (["-t"], ["cc_flat.maln"]),
+    "span": (["-s", "2000-9000"], ["cc_flat.maln"]),
+    "n2": (["-n", "2"], ["cc_flat.maln"]),
+    "table": (["-T"], ["cc_flat.maln"]),
+    "table_a_two_files": (["-T", "-a"], ["cc_anc.maln", "cc_flat.maln"]),
+    "two_files": ([], ["cc_flat.maln", "cc_anc.maln"]),
+    "v1": (["-v"], ["cc_flat.maln"]),
+    "v2": (["-vv"], ["cc_flat.maln"]),
+    "v3": (["-vvv"], ["cc_flat.maln"]),
+    "v4": (["-vvvv", "-a"], ["cc_anc.maln"]),
+    "v5": (["-vvvvv"], ["cc_small.maln"]),
+    "v6": (["-vvvvvv", "-F"], ["cc_small.maln"]),
+    "maxd_too_small": (["-d", "20"], ["cc_flat.maln"]),
+    "maxd_large": (["-d", "4000"], ["cc_flat.maln"]),
+    "other_ref": (["-r", "cc_contam.fa"], ["cc_flat.maln"]),
+    "few_positions": ([], ["cc_small.maln"]),
+    "few_positions_F": (["-F"], ["cc_small.maln"]),
+    "few_positions_F_table": (["-F", "-T", "-a", "-n", "2"], ["cc_small.maln"]),
+}
+
+
+def ccheck_cases(mt311_path):
+    """The reference's own ccheck (oracle/_ref/ccheck) on assemblies made by the reference's own mia:
+       cc_flat   an individual 170 substitutions + 3 indels away from mt311, 2 750 reads of 100 and 60 bases,
+                 13 % of them from a second (contaminating) human, flat matrix
+       cc_anc    the same with deaminated reads and the ancient matrix
+       cc_small  the 150-read set of the maln goldens (too few diagnostic positions: needs -F)
+    Committed: the final .maln of each (gzip, line 1 replaced by a fixed header), cc_contam.fa, and for every run of
+    CCHECK_RUNS stdout / stderr / exit code (streams above 64 KB as sha256)."""
+    import gzip
+    import hashlib
+    out_dir = os.path.join(G, "ccheck")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    tmp = tempfile.mkdtemp()
+    _, _, mt = gen_data.read_fasta_one(mt311_path)
+    rnd = random.Random(909)
+    endo = list(gen_data.resolve_individual(mt, seed=311))
+    for p in rnd.sample(range(len(endo)), 170):
+        endo[p] = rnd.choice([b for b in "ACGT" if b != endo[p]])
+    endo = "".join(endo)
+    endo = endo[:3000] + endo[3002:9000] + "TT" + endo[9000:12000] + endo[12001:]
+    contam = gen_data.resolve_individual(mt, seed=77)
+    gen_data.write_fasta(os.path.join(out_dir, "cc_contam.fa"), "contaminant one resolved human", contam)
+    for name, damage in (("cc_flat", False), ("cc_anc", True)):
+        parts = [(endo, 1500, 100, 21), (endo, 900, 60, 22), (contam, 250, 100, 23), (contam, 100, 60, 24)]
+        recs = []
+        for k, (genome, n, ln, seed) in enumerate(parts):
+            d = gen_data.make_reads(genome, n, ln, seed + (10 if damage else 0), circular=True, damage=damage and k < 2)
+            recs += [(f"{'e' if k < 2 else 'c'}{k}_{i}", d["reads"][i].tobytes().decode()) for i in range(n)]
+        rnd.shuffle(recs)
+        with open(os.path.join(tmp, name + ".fa"), "w") as f:
+            for rid, seq in recs:
+                f.write(f">{rid}\n{seq}\n")
+        args = ["-r", mt311_path, "-f", name + ".fa", "-c", "-k", "12", "-i"]
+        if damage:
+            args += ["-s", os.path.join(G, "ancient.submat.txt")]
+        sh([os.path.join(RB, "mia")] + args + ["-m", name], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        it = 1
+        while os.path.exists(os.path.join(tmp, f"{name}.{it + 1}")):
+            it += 1
+        body = open(os.path.join(tmp, f"{name}.{it}")).readlines()[1:]
+        with open(os.path.join(tmp, name + ".maln"), "w") as f:
+            f.write(MA_HEADER + "".join(body))
+        print(f"{name}: iteration {it}")
+    with open(os.path.join(tmp, "cc_small.maln"), "w") as f:
+        f.write(MA_HEADER + open(os.path.join(G, "maln", "s150_k12.2")).read())
+    shutil.copy(os.path.join(out_dir, "cc_contam.fa"), tmp)
+    for name in ("cc_flat", "cc_anc"):
+        with open(os.path.join(tmp, name + ".maln"), "rb") as f, gzip.GzipFile(os.path.join(out_dir, name + ".maln.gz"), "wb", mtime=0) as g:
+            g.write(f.read())
+    # find_maln (src/ccheck.cc:206-236): without -f the highest-numbered sibling is read
+    shutil.copy(os.path.join(tmp, "cc_small.maln"), os.path.join(tmp, "sib.1"))
+    shutil.copy(os.path.join(tmp, "cc_flat.maln"), os.path.join(tmp, "sib.3"))
+    runs = dict(CCHECK_RUNS)
+    hashes = {}
+    for key, (args, files) in list(runs.items()) + [("find_maln", (None, ["sib.1"]))]:
+        argv = [os.path.join(RB, "ccheck")] + (["-f"] + args if args is not None else []) + files
+        r = subprocess.run(argv, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        for ext, data in (("out", r.stdout), ("err", r.stderr)):
+            if len(data) <= 64 * 1024:
+                with open(os.path.join(out_dir, f"{key}.{ext}"), "wb") as f:
+                    f.write(data)
+            elif f"{key}.{ext}" == "v6.err":
+                # print_aln prints the assembly row of myers_diff, which the reference leaves without its terminator
+                # (src/myers_align.c:44-45): the bytes after it are heap remains.  Kept in full so that the test can
+                # compare everything but that tail.
+                with gzip.GzipFile(os.path.join(out_dir, f"{key}.{ext}.gz"), "wb", mtime=0) as g:
+                    g.write(data)
+            else:
+                hashes[f"{key}.{ext}"] = {"sha256": hashlib.sha256(data).hexdigest(), "bytes": len(data)}
+        with open(os.path.join(out_dir, f"{key}.rc"), "w") as f:
+            f.write(f"{r.returncode}\n")
+        print(f"ccheck {key}: rc {r.returncode}, {len(r.stdout)} B out, {len(r.stderr)} B err")
+    with open(os.path.join(out_dir, "runs.json"), "w") as f:
+        json.dump(runs, f, indent=1)
+    with open(os.path.join(out_dir, "hashes.json"), "w") as f:
+        json.dump(hashes, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp)
+
+
 def main():
     os.makedirs(G, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "trim":        # only the trim_frag vectors
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
         trim_vectors()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "ccheck":      # only the ccheck inputs and reports
+        sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
+        ccheck_cases(os.path.join(G, "mt311.fa"))
         return
     if len(sys.argv) > 1 and sys.argv[1] == "ma":          # only the ma reports (the .maln files stay as they are)
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
@@ -380,6 +491,7 @@ def main():
     maln_cases(os.path.join(G, "mt311.fa"))
     ma_cases()
     trim_vectors()
+    ccheck_cases(os.path.join(G, "mt311.fa"))
 
 
 if __name__ == "__main__":

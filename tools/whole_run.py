@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--kmer", type=int, default=0)
     ap.add_argument("--keep", default=None)
     ap.add_argument("--skip-reference", action="store_true")
+    ap.add_argument("--ccheck", action="store_true", help="also run ccheck (reference and ccheck_hip) on the final .maln")
     a = ap.parse_args()
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mia")
     hip_bin = os.path.join(ROOT, "mapping-iterative-assembler_amd", "mia_hip")
@@ -57,8 +58,25 @@ def main():
             same = x == y
         out["maln_identical"] = bool(same)
         out["speedup"] = round(out["reference_s"] / out["mia_hip_s"], 1)
+    ok = out.get("maln_identical", True)
+    if a.ccheck:
+        # the contamination check of the final assembly: the reference's ccheck against ccheck_hip, same file
+        final = os.path.join(work, "mia_hip.%d" % out["mia_hip_iterations"])
+        reports = {}
+        for label, exe in (("ccheck_hip", os.path.join(ROOT, "mapping-iterative-assembler_amd", "ccheck_hip")),
+                           ("ccheck_reference", os.path.join(ROOT, "oracle", "_ref", "ccheck"))):
+            if label == "ccheck_reference" and a.skip_reference:
+                continue
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "-f", "-F", "-a", os.path.basename(final)], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            out[label + "_s"] = round(time.perf_counter() - t0, 3)
+            reports[label] = (r.returncode, r.stdout, r.stderr)
+        if len(reports) == 2:
+            out["ccheck_identical"] = reports["ccheck_hip"] == reports["ccheck_reference"]
+            out["ccheck_speedup"] = round(out["ccheck_reference_s"] / out["ccheck_hip_s"], 1)
+            ok = ok and out["ccheck_identical"]
     print(json.dumps(out))
-    return 0 if out.get("maln_identical", True) else 1
+    return 0 if ok else 1
 
 
 if __name__ == "__main__":
