@@ -1534,15 +1534,20 @@ static bool ond_backtrace(const char* a, int la, const char* b, int lb, int mode
   }
   if (!found) return false;
   std::string ra, rb;   // built back to front
+  // In the prefix modes a D-path may run past the end of the sequence that need not be consumed (the recurrence has no
+  // bound there, src/myers_align.c:26-32): the reference then copies that sequence's terminator into the row, which
+  // ends the C string early.  Same here, without reading past the terminator.
+  auto ca = [&](int y) { return y < la ? a[y] : '\0'; };
+  auto cb = [&](int x) { return x < lb ? b[x] : '\0'; };
   int k = end_k, x = at(dist, k), y = x - k;
   for (int d = dist; d != 0;) {
-    if (k != -d && k != d && x == at(d - 1, k) + 1) { d--; x--; y--; rb.push_back(b[x]); ra.push_back(a[y]); }
-    else if (k > -d + 1 && x == at(d - 1, k - 1) + 1) { x--; k--; d--; rb.push_back(b[x]); ra.push_back('-'); }
-    else if (k < d - 1 && x == at(d - 1, k + 1)) { k++; y--; d--; rb.push_back('-'); ra.push_back(a[y]); }
-    else { x--; y--; rb.push_back(b[x]); ra.push_back(a[y]); }
+    if (k != -d && k != d && x == at(d - 1, k) + 1) { d--; x--; y--; rb.push_back(cb(x)); ra.push_back(ca(y)); }
+    else if (k > -d + 1 && x == at(d - 1, k - 1) + 1) { x--; k--; d--; rb.push_back(cb(x)); ra.push_back('-'); }
+    else if (k < d - 1 && x == at(d - 1, k + 1)) { k++; y--; d--; rb.push_back('-'); ra.push_back(ca(y)); }
+    else { x--; y--; rb.push_back(cb(x)); ra.push_back(ca(y)); }
     if (x < 0 || y < 0) return false;
   }
-  while (x > 0) { x--; rb.push_back(b[x]); ra.push_back(a[x]); }
+  while (x > 0) { x--; rb.push_back(cb(x)); ra.push_back(ca(x)); }
   row_a->assign(ra.rbegin(), ra.rend());
   row_b->assign(rb.rbegin(), rb.rend());
   return true;
