@@ -248,6 +248,11 @@ int mia_hip_kernel_time(mia_hip_ctx *ctx, int reset, double *align_ms, int64_t *
  * accumulated kernel time, launches, reads that entered and reads that had to be re-run with a trace. */
 int mia_hip_plain_stats(mia_hip_ctx *ctx, int reset, double *plain_ms, int64_t *plain_launches, int64_t *reads_in,
                         int64_t *reads_retried);
+
+/* The diagonal filter in front of the DP kernels of mia_hip_realign / mia_hip_align_windows (csrc/diag_filter.h: flat
+ * matrix only; a read whose alignment is provably one gap-free diagonal with at most two mismatches is finished by
+ * bit-parallel comparison and never reaches the DP): reads examined and reads finished there since the last reset. */
+int mia_hip_filter_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_seen, int64_t *reads_finished);
 /* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
 int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 

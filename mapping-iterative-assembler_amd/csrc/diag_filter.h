@@ -1,0 +1,245 @@
+// diag_filter.h -- decides, WITHOUT running the DP, that the alignment dyn_prog / max_sg_score / find_align_begin
+// (/root/reference/src/mia.c:740-981,1278-1302,612-637) would produce for a read in its window is one gap-free
+// diagonal, and which.  Bit-parallel: read and reference are 2-bit planes, one shift of the read against the window
+// costs a few 64-bit XOR / AND / popcount operations instead of len2 DP cells.  Only for the FLAT matrix
+// (src/pssm.c:96-126: match 200, mismatch -600 at every depth) and reads without N; everything else goes to the DP
+// kernels.  Shared by the gfx950 kernel (mia_kernels.h: k_diag_filter) and the CPU tests (tests/emul).
+//
+// Why the verdict is exact.  Write R = len2-1, P(g) = GOP + GEP*g = 1000 + 200 g.  Every cell value S(r,c) of the
+// recurrence is the value of a PATH: rows aligned to columns (each scoring 200 / -600 / the N score <= 200), joined
+// by events -- a column gap or a row gap of g >= 1 (cost P(g); skipped rows score nothing), or a late start at row
+// r > 0 (cost P(r+1), rows before it skipped; src/mia.c:905-948).  A path that starts in row 0 and has no event is a
+// diagonal.  Define loss = 200*len2 - value >= 0: 800 per definite mismatch (both ACGT, different), >= 0 per N
+// column, 200 per skipped row, P(g) >= 1200 per event.  Let D be the diagonal at offset delta with K definite
+// mismatches and no N under it: loss(D) = 800 K.  Checked here:
+//   (a) every other diagonal that fits the window has >= K+1 definite mismatches        -> loss >= 800(K+1) > loss(D)
+//   (b) K <= 2.  Paths with one event and >= 1 definite mismatch lose >= 1200 + 800 = 2000 > 1600 >= loss(D); paths
+//       with >= 2 events lose >= 2400.  With K <= 1 one event alone (1200) already exceeds loss(D) <= 800.
+//   (c) K == 2: a path with ONE event and NO definite mismatch loses 1000 + 200 g (+ 200 per skipped ordinary row),
+//       which is <= 1600 only for g <= 3.  It is a mismatch-free prefix of the read on one diagonal followed by a
+//       mismatch-free suffix on another (or nothing but a suffix after a late start), together covering all but
+//       <= 3 rows.  LP = longest mismatch-free prefix over ALL diagonals, LS = longest mismatch-free suffix; the test
+//       LP + LS <= R - 3 rules every such path out.  N columns, columns outside the window and positions outside
+//       the reference are treated as matching anything, which can only make LP / LS larger (more fall-backs, never
+//       a wrong verdict).
+// Hence every path other than D ends in row R with a value STRICTLY below D's: max_sg_score's first maximum of the
+// last row is D's end cell (ties impossible), and by extending any better path to a diagonal cell along D one sees
+// that at every cell of D the diagonal candidate is >= both gap candidates, and D(r-1) >= -600 > -P(r+1), so the
+// "start a new alignment" branch (strictly greater only) never fires: trace 0 all the way, find_align_begin stops
+// at row 0.  Result: score 200 len2 - 800 K, abc = delta, aec = delta + R, abr = 0, script = consecutive columns --
+// exactly what k_align_quad_plain's proof or the trace kernels would deliver.
+#pragma once
+#include <stdint.h>
+
+#include "mia_layout.h"
+
+namespace mia {
+
+constexpr int PLANE_LEAD = 320;      // wild-card bits in front of reference position 0 (multiple of 64, >= MAX_READ)
+constexpr int PLANE_TAIL = 704;      // ... and behind the last code (>= 2*MAX_READ + 3*64)
+constexpr int DF_MAX_LEN1 = 768;     // windows wider than the widest DP class are not examined
+
+MIA_HD inline int64_t plane_words(int64_t n_codes) { return (PLANE_LEAD + n_codes + PLANE_TAIL) / 64 + 1; }
+
+struct RefPlanes {
+  const uint64_t* lo;   // bit p + PLANE_LEAD: low bit of the code at reference position p
+  const uint64_t* hi;   //                     high bit
+  const uint64_t* ok;   //                     1 iff the code is A, C, G or T (0: N, or outside the reference)
+};
+
+// one word of the three planes from 64 consecutive reference codes (0..3 bases, anything else N)
+MIA_HD inline void plane_word(const uint8_t* codes, int64_t n_codes, int64_t word, uint64_t* lo, uint64_t* hi, uint64_t* ok) {
+  uint64_t l = 0, h = 0, k = 0;
+  for (int b = 0; b < 64; b++) {
+    const int64_t p = word * 64 + b - PLANE_LEAD;
+    if (p < 0 || p >= n_codes) continue;
+    const uint32_t c = codes[p];
+    if (c > 3) continue;
+    l |= (uint64_t)(c & 1) << b;
+    h |= (uint64_t)(c >> 1) << b;
+    k |= 1ull << b;
+  }
+  *lo = l; *hi = h; *ok = k;
+}
+
+MIA_HD inline int df_popc(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popcll(x);
+#else
+  return __builtin_popcountll(x);
+#endif
+}
+MIA_HD inline int df_ctz(uint64_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ffsll((long long)x) - 1;
+#else
+  return __builtin_ctzll(x);
+#endif
+}
+MIA_HD inline int df_clz(uint64_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clzll((long long)x);
+#else
+  return __builtin_clzll(x);
+#endif
+}
+
+// The read against every diagonal of a range: planes of the window slide past the read one bit per step.  NW = 64-bit
+// words per read plane, a template parameter so that every array index is static (registers, not scratch).
+template <int NW>
+struct DiagScan {
+  uint64_t rlo[NW], rhi[NW], rows[NW];         // read planes, valid-row mask
+  uint64_t clo[NW + 1], chi[NW + 1], cok[NW + 1];
+  int len2, left;                              // bits left in the top word before a refill
+
+  // false if the read holds an N (such reads are left to the DP)
+  MIA_HD bool load_read(const uint8_t* packed, int n) {
+    len2 = n;
+    bool acgt = true;
+    const uint32_t* pw = (const uint32_t*)packed;        // reads start on 4-byte boundaries, 8 codes per word
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      uint64_t l = 0, h = 0, m = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int r0 = j * 64 + q * 8;
+        const int cnt = n - r0 < 8 ? n - r0 : 8;
+        if (cnt <= 0) continue;
+        uint32_t x = pw[r0 >> 3];
+        if (cnt < 8) x &= (1u << (4 * cnt)) - 1u;
+        if (x & 0xCCCCCCCCu) acgt = false;               // a code above 3
+        // gather bit 0 (bit 1) of each nibble into one byte
+        uint32_t a = x & 0x11111111u, b = (x >> 1) & 0x11111111u;
+        a = (a | (a >> 3)) & 0x03030303u; a = (a | (a >> 6)) & 0x000F000Fu; a = (a | (a >> 12)) & 0xFFu;
+        b = (b | (b >> 3)) & 0x03030303u; b = (b | (b >> 6)) & 0x000F000Fu; b = (b | (b >> 12)) & 0xFFu;
+        l |= (uint64_t)a << (q * 8);
+        h |= (uint64_t)b << (q * 8);
+        m |= (uint64_t)((1u << cnt) - 1u) << (q * 8);
+      }
+      rlo[j] = l; rhi[j] = h; rows[j] = m;
+    }
+    return acgt;
+  }
+
+  // planes of reference positions [pos, pos + 64 (NW+1)); pos >= -PLANE_LEAD
+  MIA_HD void seek(const RefPlanes& rp, int64_t pos) {
+    const int64_t bit = pos + PLANE_LEAD;
+    const int64_t q = bit >> 6;
+    const int b = (int)(bit & 63);
+    uint64_t l0 = rp.lo[q], h0 = rp.hi[q], k0 = rp.ok[q];
+#pragma unroll
+    for (int j = 0; j <= NW; j++) {
+      const uint64_t l1 = rp.lo[q + j + 1], h1 = rp.hi[q + j + 1], k1 = rp.ok[q + j + 1];
+      // (x << 1) << (63 - b) == x << (64 - b) for b in 1..63 and 0 for b == 0, without a 64-bit shift by 64
+      clo[j] = (l0 >> b) | ((l1 << 1) << (63 - b));
+      chi[j] = (h0 >> b) | ((h1 << 1) << (63 - b));
+      cok[j] = (k0 >> b) | ((k1 << 1) << (63 - b));
+      l0 = l1; h0 = h1; k0 = k1;
+    }
+    left = 64;
+  }
+  // one reference position further
+  MIA_HD void advance(const RefPlanes& rp, int64_t next_pos) {
+    if (--left == 0) { seek(rp, next_pos); return; }
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      clo[j] = (clo[j] >> 1) | (clo[j + 1] << 63);
+      chi[j] = (chi[j] >> 1) | (chi[j + 1] << 63);
+      cok[j] = (cok[j] >> 1) | (cok[j + 1] << 63);
+    }
+    clo[NW] >>= 1; chi[NW] >>= 1; cok[NW] >>= 1;
+  }
+  // definite mismatches of the rows in word j on the current diagonal
+  MIA_HD uint64_t mis(int j) const { return ((rlo[j] ^ clo[j]) | (rhi[j] ^ chi[j])) & cok[j] & rows[j]; }
+  MIA_HD int mismatches() const {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) n += df_popc(mis(j));
+    return n;
+  }
+  MIA_HD bool all_acgt() const {   // no N (and nothing outside the reference) under the read
+    bool full = true;
+#pragma unroll
+    for (int j = 0; j < NW; j++) full = full && ((cok[j] & rows[j]) == rows[j]);
+    return full;
+  }
+  MIA_HD int clean_prefix() const {   // rows 0 .. without a definite mismatch
+    int p = len2;
+#pragma unroll
+    for (int j = NW - 1; j >= 0; j--) {
+      const uint64_t m = mis(j);
+      if (m) p = j * 64 + df_ctz(m);
+    }
+    return p;
+  }
+  MIA_HD int clean_suffix() const {   // rows .. R without a definite mismatch
+    int q = len2;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      const uint64_t m = mis(j);
+      if (m) q = len2 - 1 - (j * 64 + 63 - df_clz(m));
+    }
+    return q;
+  }
+};
+
+struct DiagVerdict { int delta, mismatches; };
+
+template <int NW>
+MIA_HD inline bool diag_filter_w(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, DiagVerdict* out) {
+  DiagScan<NW> sc;
+  if (!sc.load_read(read_packed, len2)) return false;
+  const int R = len2 - 1, fit = len1 - len2;          // diagonals 0 .. fit hold the whole read
+  int best = 1 << 20, second = 1 << 20, delta = -1;
+  bool clean = false;
+  sc.seek(rp, s);
+  for (int d = 0; d <= fit; d++) {
+    const int m = sc.mismatches();
+    if (m < best) { second = best; best = m; delta = d; clean = sc.all_acgt(); }
+    else if (m < second) second = m;
+    if (d < fit) sc.advance(rp, (int64_t)s + d + 1);
+  }
+  if (best > 2 || second <= best || !clean) return false;     // (b), (a), no N under the diagonal
+  if (best == 2) {
+    // (c): prefixes start in row 0 at a window column, diagonals 0 .. len1-1; suffixes end in row R at a window
+    // column, diagonals -R .. fit
+    int lp = 0, ls = 0;
+    sc.seek(rp, (int64_t)s - R);
+    for (int d = -R; d <= len1 - 1; d++) {
+      if (d >= 0) { const int p = sc.clean_prefix(); lp = p > lp ? p : lp; }
+      if (d <= fit) { const int q = sc.clean_suffix(); ls = q > ls ? q : ls; }
+      if (d < len1 - 1) sc.advance(rp, (int64_t)s + d + 1);
+    }
+    if (lp + ls > R - 3) return false;
+  }
+  out->delta = delta;
+  out->mismatches = best;
+  return true;
+}
+
+// Window = reference positions [s, s + len1).  True iff the alignment is provably the diagonal out->delta (offset
+// inside the window) with out->mismatches definite mismatches.  The caller has established the flat matrix.
+MIA_HD inline bool diag_filter(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, DiagVerdict* out) {
+  if (len2 < 1 || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1) return false;
+  switch ((len2 + 63) >> 6) {
+    case 1: return diag_filter_w<1>(rp, s, len1, read_packed, len2, out);
+    case 2: return diag_filter_w<2>(rp, s, len1, read_packed, len2, out);
+    case 3: return diag_filter_w<3>(rp, s, len1, read_packed, len2, out);
+    default: return diag_filter_w<4>(rp, s, len1, read_packed, len2, out);
+  }
+}
+
+// the flat matrix, both strands, every depth; N columns may score anything up to a match (src/pssm.c:96-126)
+inline bool pssm_is_flat(const int32_t* fwd, const int32_t* rc) {
+  const int32_t* tabs[2] = {fwd, rc};
+  for (const int32_t* t : tabs)
+    for (int d = 0; d < 2 * PSSM_DEPTH + 1; d++)
+      for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 4; b++) {
+          const int32_t v = t[(d * 5 + a) * 5 + b];
+          if (a < 4 ? v != (a == b ? FLAT_MATCH : FLAT_MISMATCH) : v > FLAT_MATCH) return false;
+        }
+  return true;
+}
+
+}  // namespace mia

@@ -73,6 +73,10 @@ struct mia_hip_ctx {
   int use_quad = 1;   // MIA_HIP_NO_QUAD=1 routes everything through the one-read-per-wave kernels
   int use_plain = 1;  // MIA_HIP_NO_PLAIN=1: no values-only first pass, every quad goes straight to the trace kernel
   double plain_ms = 0; int64_t plain_launches = 0; int64_t plain_retried = 0, plain_total = 0;
+  // the diagonal filter (diag_filter.h): flat matrix only
+  bool flat = false; int use_filter = 1;   // MIA_HIP_NO_DIAG_FILTER=1 sends every read to the DP kernels
+  uint64_t* d_planes = nullptr; int64_t plane_cap = 0;   // lo | hi | ok, plane_cap words each
+  uint32_t* d_filter_n = nullptr; int64_t filter_proven = 0, filter_seen = 0;
   int grid_wgs = 0;
   int window_wgs[N_CPL] = {0, 0, 0};
   int cus = 1;
@@ -144,6 +148,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nband && atoi(nband)) ctx->use_band = 0;
     const char* npl = getenv("MIA_HIP_NO_PLAIN");
     if (npl && atoi(npl)) ctx->use_plain = 0;
+    const char* nf = getenv("MIA_HIP_NO_DIAG_FILTER");
+    if (nf && atoi(nf)) ctx->use_filter = 0;
     const char* nq = getenv("MIA_HIP_NO_QUAD");
     if (nq && atoi(nq)) ctx->use_quad = 0;
     const char* qw = getenv("MIA_HIP_QUAD_WAVES_PER_CU");
@@ -154,7 +160,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (g && atoi(g) > 0) ctx->grid_wgs = prop.multiProcessorCount * atoi(g);
   }
   if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_bins, 3 * N_BINS + 2) ||
-      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1)) {
+      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1) || dev_alloc(ctx, &ctx->d_filter_n, 1)) {
     delete ctx;
     return MIA_HIP_ERR_NOMEM;
   }
@@ -173,7 +179,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs};
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -209,6 +215,7 @@ extern "C" int mia_hip_set_pssm(mia_hip_ctx* ctx, const int32_t* fwd, const int3
   HIPCHK(hipMemcpyAsync(ctx->d_pssm + PSSM_WORDS, rc, PSSM_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->have_pssm = true;
+  ctx->flat = pssm_is_flat(fwd, rc);
   return MIA_HIP_OK;
 }
 
@@ -356,6 +363,14 @@ extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms
   return MIA_HIP_OK;
 }
 
+extern "C" int mia_hip_filter_stats(mia_hip_ctx* ctx, int reset, int64_t* reads_seen, int64_t* reads_finished) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (reads_seen) *reads_seen = ctx->filter_seen;
+  if (reads_finished) *reads_finished = ctx->filter_proven;
+  if (reset) { ctx->filter_seen = 0; ctx->filter_proven = 0; }
+  return MIA_HIP_OK;
+}
+
 extern "C" int mia_hip_plain_stats(mia_hip_ctx* ctx, int reset, double* plain_ms, int64_t* plain_launches, int64_t* reads_in, int64_t* reads_retried) {
   if (!ctx) return MIA_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
@@ -428,10 +443,29 @@ static int align_all(mia_hip_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 2) * 4, ctx->stream));
   int32_t* d_retry_count = ctx->d_bins + 3 * N_BINS + 1;
   const int tb = 256, gb = (int)((n + (int64_t)tb * PLAN_PER - 1) / ((int64_t)tb * PLAN_PER));
-  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, ctx->d_bin_of, d_count);
+  const int filtered = ctx->flat && ctx->use_filter;
+  uint32_t h_filter_n = 0;
+  if (filtered) {
+    // reads whose alignment is provably one gap-free diagonal never reach the DP kernels (diag_filter.h)
+    const int64_t words = plane_words((int64_t)wrap + 64);
+    if (words > ctx->plane_cap) {
+      if (dev_alloc(ctx, &ctx->d_planes, (size_t)words * 3)) return MIA_HIP_ERR_NOMEM;
+      ctx->plane_cap = words;
+    }
+    RefPlanes rp{ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap};
+    hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
+                       ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
+    HIPCHK(hipMemsetAsync(ctx->d_filter_n, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ctx->d_bin_of, ctx->d_filter_n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&h_filter_n, ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, ctx->d_bin_of, d_count);
   int32_t h_count[N_BINS], h_off[N_BINS];
   HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->filter_proven += h_filter_n;
+  ctx->filter_seen += n;
   int run = 0;
   for (int b = 0; b < N_BINS; b++) {
     h_off[b] = run;

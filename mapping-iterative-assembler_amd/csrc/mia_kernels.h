@@ -15,6 +15,7 @@
 #include "align_body.h"
 #include "align_body_quad.h"
 #include "align_body_quad_plain.h"
+#include "diag_filter.h"
 #include "mia_layout.h"
 #include "wave_dev.h"
 
@@ -97,7 +98,61 @@ __device__ __forceinline__ int hist_add_aggregated(int32_t* hist, int b) {
 // (block, non-empty bin) instead of one per read on a single hot address.
 constexpr int PLAN_PER = 8;   // reads per thread of the planner kernels: a block bins 2048 reads per LDS histogram
 
-__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int32_t* bin_of, int32_t* bin_count) {
+// ---- the diagonal filter (diag_filter.h), ahead of everything else: one read per thread.  A read whose alignment
+// is provably one gap-free diagonal is finished here (score, end points, script, ST_DIAG) and marked bin_of = -2 so
+// that the planner leaves it out; all others are marked 0.  Flat matrix only (the host checks).
+__global__ __launch_bounds__(256) void k_ref_planes(const uint8_t* codes, int64_t n_codes, int64_t words, uint64_t* lo, uint64_t* hi, uint64_t* ok) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w < words) plane_word(codes, n_codes, w, &lo[w], &hi[w], &ok[w]);
+}
+
+__global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, RefPlanes rp, int32_t* bin_of, uint32_t* n_proven) {
+  __shared__ int16_t verdict[256];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int delta = -1;
+  if (i < rs.n) {
+    int mark = 0;
+    if (rs.sk[i]) {
+      int s, l1;
+      const int len2 = rs.len[i];
+      read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
+      DiagVerdict v;
+      if (diag_filter(rp, s, l1, rs.packed + rs.roff[i], len2, &v)) {
+        delta = v.delta;
+        rs.score[i] = FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * v.mismatches;
+        rs.refstart[i] = s;
+        rs.abr[i] = 0;
+        rs.as[i] = s + delta;                 // src/mia_main.c:254-255
+        rs.ae[i] = s + delta + len2 - 1;
+        rs.status[i] = ST_DIAG;
+        mark = -2;
+      }
+    }
+    bin_of[i] = mark;
+  }
+  verdict[threadIdx.x] = (int16_t)delta;
+  const unsigned long long won = __ballot(delta >= 0);
+  if ((threadIdx.x & 63) == 0 && won) atomicAdd(n_proven, (uint32_t)__popcll(won));
+  __syncthreads();
+  // the scripts of the finished reads: eight threads per read, four consecutive columns (8 bytes) per store
+  for (int k = 0; k < 8; k++) {
+    const int t = k * 32 + (int)(threadIdx.x >> 3);
+    const int d = verdict[t];
+    if (d < 0) continue;
+    const int64_t j = (int64_t)blockIdx.x * 256 + t;
+    const int len2 = rs.len[j];
+    int16_t* cols = rs.cols + j * rs.stride;        // stride is a multiple of 4 and >= len2
+    for (int base = (int)(threadIdx.x & 7) * 4; base < len2; base += 32) {
+      const uint32_t c0 = (uint32_t)(d + base);
+      uint2 v;
+      v.x = (c0 & 0xFFFFu) | ((c0 + 1u) << 16);
+      v.y = ((c0 + 2u) & 0xFFFFu) | ((c0 + 3u) << 16);
+      *reinterpret_cast<uint2*>(cols + base) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int filtered, int32_t* bin_of, int32_t* bin_count) {
   __shared__ int32_t hist[N_BINS];
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
@@ -105,7 +160,9 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
     const int64_t i = ((int64_t)blockIdx.x * PLAN_PER + k) * 256 + threadIdx.x;
     int b = -1;
     if (i < rs.n) {
-      if (rs.sk[i]) {
+      if (filtered && bin_of[i] == -2) {
+        // finished by k_diag_filter
+      } else if (rs.sk[i]) {
         int s, l1;
         read_window(ref, rs.as[i], rs.ae[i], rs.len[i], &s, &l1);
         b = classify(rs.len[i], l1, ps, use_quad);

@@ -16,6 +16,8 @@ namespace mia {
 constexpr int GOP = 1000;           // gap open   (src/params.h:26)
 constexpr int GEP = 200;            // gap extend (src/params.h:27)
 constexpr int PSSM_DEPTH = 15;      // src/params.h:22
+constexpr int FLAT_MATCH = 200;     // src/params.h:28
+constexpr int FLAT_MISMATCH = -600; // src/params.h:29
 constexpr int MAX_READ = 256;       // INIT_ALN_SEQ_LEN (src/params.h:68)
 constexpr int REALIGN_BUFFER = 50;  // src/params.h:36
 constexpr int PSSM_WORDS = 31 * 25;

@@ -15,7 +15,6 @@
 namespace mia {
 
 constexpr int TRIM_SCORE_CUT = 1000;   // src/params.h:32
-constexpr int FLAT_MATCH = 200;        // src/params.h:28
 constexpr int MAX_ADAPTER = 127;       // src/mia_main.c:559
 
 struct TrimReads {

@@ -11,6 +11,7 @@
 #include "pass1_body.h"
 #include "align_body_quad.h"
 #include "align_body_quad_plain.h"
+#include "diag_filter.h"
 
 using namespace mia;
 
@@ -161,4 +162,23 @@ extern "C" int emu_align_quad_plain(int ng, const uint8_t* ref_codes, const int3
     out6[g * 6 + 4] = res[g].proven; out6[g * 6 + 5] = 0;
   }
   return 0;
+}
+
+// The diagonal filter (csrc/diag_filter.h) as the kernel runs it: planes of the whole reference, the read as 4-bit codes
+// on a 4-byte boundary.  Returns 1 if the read's alignment in [ref_start, ref_start+len1) is proven to be the gap-free
+// diagonal *delta with *mismatches mismatches, 0 if the read is left to the DP.
+extern "C" int emu_diag_filter(const uint8_t* ref_codes, int64_t n_codes, int ref_start, int len1, const uint8_t* read_codes, int len2,
+                               int* delta, int* mismatches) {
+  using namespace mia;
+  const int64_t words = plane_words(n_codes);
+  std::vector<uint64_t> lo((size_t)words), hi((size_t)words), ok((size_t)words);
+  for (int64_t w = 0; w < words; w++) plane_word(ref_codes, n_codes, w, &lo[(size_t)w], &hi[(size_t)w], &ok[(size_t)w]);
+  std::vector<uint32_t> packed((size_t)(len2 / 8 + 2), 0);
+  uint8_t* pb = (uint8_t*)packed.data();
+  for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
+  RefPlanes rp{lo.data(), hi.data(), ok.data()};
+  DiagVerdict v{0, 0};
+  const bool won = diag_filter(rp, ref_start, len1, pb, len2, &v);
+  *delta = v.delta; *mismatches = v.mismatches;
+  return won ? 1 : 0;
 }

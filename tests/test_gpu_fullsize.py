@@ -202,3 +202,53 @@ def test_iteration_reaches_fixed_point(full):
         rounds += 1
     assert cons == ref, rounds
     assert rounds >= 2 and abs(len(cons) - len(f.ref)) < 50
+
+
+def test_diag_filter_changes_nothing(full):
+    """the diagonal filter (csrc/diag_filter.h) finishes most reads before any DP runs; a context with the filter
+    switched off must deliver the same scores, end points and scripts for every read of the full-size batch, and for
+    a second batch whose reads carry more substitutions and sit in a reference with planted tandem repeats"""
+    f = full
+
+    def both(ref, stored, soff, rc, sk, as0, ae0, min_share):
+        out = []
+        for off in (False, True):
+            if off:
+                os.environ["MIA_HIP_NO_DIAG_FILTER"] = "1"
+            try:
+                hip = f.mod.MiaHip(0)
+            finally:
+                os.environ.pop("MIA_HIP_NO_DIAG_FILTER", None)
+            hip.set_pssm(f.mod.flat_pssm())
+            hip.upload_reads(stored.reshape(-1), soff, rc, sk, as0, ae0)
+            hip.realign(ref, True)
+            sc, a, e = hip.alignments()
+            cols, rstart = hip.scripts()
+            st = hip.filter_stats()
+            assert st[1] == 0 if off else st[1] >= min_share * len(rc), st
+            out.append((sc, a, e, absolute(cols, rstart)))
+            hip.close()
+        for x, y in zip(out[0], out[1]):
+            assert np.array_equal(x, y)
+
+    # mt311 itself: half of its columns carry ambiguity codes (N for the aligner), few reads can be decided early
+    both(f.ref, f.stored, f.soff, f.rc, f.sk, f.as0, f.ae0, 0.0)
+    # the usual case, a consensus of plain bases: the filter must take the bulk
+    both(gen_data.resolve_individual(f.ref), f.stored, f.soff, f.rc, f.sk, f.as0, f.ae0, 0.6)
+    # a harder batch: 1.5 % substitutions, 0.3 % indels, reference with tandem repeats and homopolymer runs
+    rng = np.random.default_rng(77)
+    g = list(gen_data.resolve_individual(f.ref))
+    for _ in range(60):
+        p = int(rng.integers(0, len(g) - 200))
+        unit = "".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 7))))
+        run = (unit * 100)[: int(rng.integers(12, 90))]
+        g[p:p + len(run)] = list(run)
+    ref2 = "".join(g)
+    m = 300_000
+    d = gen_data.make_reads(ref2, m, 100, seed=12, circular=True, sub_rate=0.015, indel_rate=0.003)
+    start, strand = d["start"], d["strand"]
+    stored = gen_data.stored_orientation(d)
+    soff = np.arange(m + 1, dtype=np.int64) * 100
+    as0 = start.astype(np.int32)
+    ae0 = (start + 99).astype(np.int32)
+    both(ref2, stored, soff, strand.astype(np.uint8), np.ones(m, np.uint8), as0, ae0, 0.3)
