@@ -183,13 +183,14 @@ struct DiagScan {
   }
 };
 
-struct DiagVerdict { int delta, mismatches; };
-
+// Step 1, rules (a) and (b): the best diagonal among those that hold the whole read.  Returns its mismatch count K
+// (0..2) if it is the only diagonal that good and has no N under it, -1 if the read has to go to the DP.  K <= 1 settles
+// the read; K == 2 needs step 2.
 template <int NW>
-MIA_HD inline bool diag_filter_w(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, DiagVerdict* out) {
+MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out) {
   DiagScan<NW> sc;
-  if (!sc.load_read(read_packed, len2)) return false;
-  const int R = len2 - 1, fit = len1 - len2;          // diagonals 0 .. fit hold the whole read
+  if (!sc.load_read(read_packed, len2)) return -1;
+  const int fit = len1 - len2;                        // diagonals 0 .. fit hold the whole read
   int best = 1 << 20, second = 1 << 20, delta = -1;
   bool clean = false;
   sc.seek(rp, s);
@@ -199,34 +200,59 @@ MIA_HD inline bool diag_filter_w(const RefPlanes& rp, int s, int len1, const uin
     else if (m < second) second = m;
     if (d < fit) sc.advance(rp, (int64_t)s + d + 1);
   }
-  if (best > 2 || second <= best || !clean) return false;     // (b), (a), no N under the diagonal
-  if (best == 2) {
-    // (c): prefixes start in row 0 at a window column, diagonals 0 .. len1-1; suffixes end in row R at a window
-    // column, diagonals -R .. fit
-    int lp = 0, ls = 0;
-    sc.seek(rp, (int64_t)s - R);
-    for (int d = -R; d <= len1 - 1; d++) {
-      if (d >= 0) { const int p = sc.clean_prefix(); lp = p > lp ? p : lp; }
-      if (d <= fit) { const int q = sc.clean_suffix(); ls = q > ls ? q : ls; }
-      if (d < len1 - 1) sc.advance(rp, (int64_t)s + d + 1);
-    }
-    if (lp + ls > R - 3) return false;
-  }
-  out->delta = delta;
-  out->mismatches = best;
-  return true;
+  if (best > 2 || second <= best || !clean) return -1;
+  *delta_out = delta;
+  return best;
 }
+
+// Step 2, rule (c), for K == 2: prefixes start in row 0 at a window column (diagonals 0 .. len1-1), suffixes end in row
+// R at a window column (diagonals -R .. len1-len2).
+template <int NW>
+MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2) {
+  DiagScan<NW> sc;
+  sc.load_read(read_packed, len2);
+  const int R = len2 - 1, fit = len1 - len2;
+  int lp = 0, ls = 0;
+  sc.seek(rp, (int64_t)s - R);
+  for (int d = -R; d <= len1 - 1; d++) {
+    if (d >= 0) { const int p = sc.clean_prefix(); lp = p > lp ? p : lp; }
+    if (d <= fit) { const int q = sc.clean_suffix(); ls = q > ls ? q : ls; }
+    if (d < len1 - 1) sc.advance(rp, (int64_t)s + d + 1);
+  }
+  return lp + ls <= R - 3;
+}
+
+MIA_HD inline bool diag_examined(int len1, int len2) { return len2 >= 1 && len2 <= MAX_READ && len1 >= len2 && len1 <= DF_MAX_LEN1; }
+
+MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out) {
+  if (!diag_examined(len1, len2)) return -1;
+  switch ((len2 + 63) >> 6) {
+    case 1: return diag_step1<1>(rp, s, len1, read_packed, len2, delta_out);
+    case 2: return diag_step1<2>(rp, s, len1, read_packed, len2, delta_out);
+    case 3: return diag_step1<3>(rp, s, len1, read_packed, len2, delta_out);
+    default: return diag_step1<4>(rp, s, len1, read_packed, len2, delta_out);
+  }
+}
+MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2) {
+  switch ((len2 + 63) >> 6) {
+    case 1: return diag_step2<1>(rp, s, len1, read_packed, len2);
+    case 2: return diag_step2<2>(rp, s, len1, read_packed, len2);
+    case 3: return diag_step2<3>(rp, s, len1, read_packed, len2);
+    default: return diag_step2<4>(rp, s, len1, read_packed, len2);
+  }
+}
+
+struct DiagVerdict { int delta, mismatches; };
 
 // Window = reference positions [s, s + len1).  True iff the alignment is provably the diagonal out->delta (offset
 // inside the window) with out->mismatches definite mismatches.  The caller has established the flat matrix.
 MIA_HD inline bool diag_filter(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, DiagVerdict* out) {
-  if (len2 < 1 || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1) return false;
-  switch ((len2 + 63) >> 6) {
-    case 1: return diag_filter_w<1>(rp, s, len1, read_packed, len2, out);
-    case 2: return diag_filter_w<2>(rp, s, len1, read_packed, len2, out);
-    case 3: return diag_filter_w<3>(rp, s, len1, read_packed, len2, out);
-    default: return diag_filter_w<4>(rp, s, len1, read_packed, len2, out);
-  }
+  int delta = 0;
+  const int k = diag_step1(rp, s, len1, read_packed, len2, &delta);
+  if (k < 0 || (k == 2 && !diag_step2(rp, s, len1, read_packed, len2))) return false;
+  out->delta = delta;
+  out->mismatches = k;
+  return true;
 }
 
 // the flat matrix, both strands, every depth; N columns may score anything up to a match (src/pssm.c:96-126)

@@ -456,11 +456,11 @@ static int align_all(mia_hip_ctx* ctx) {
     hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
                        ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
     HIPCHK(hipMemsetAsync(ctx->d_filter_n, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ctx->d_bin_of, ctx->d_filter_n);
+    hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ctx->d_bin_of);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&h_filter_n, ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
   }
-  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, ctx->d_bin_of, d_count);
+  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, ctx->d_bin_of, d_count, ctx->d_filter_n);
+  if (filtered) HIPCHK(hipMemcpyAsync(&h_filter_n, ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
   int32_t h_count[N_BINS], h_off[N_BINS];
   HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));

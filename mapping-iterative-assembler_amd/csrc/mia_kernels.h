@@ -106,40 +106,68 @@ __global__ __launch_bounds__(256) void k_ref_planes(const uint8_t* codes, int64_
   if (w < words) plane_word(codes, n_codes, w, &lo[w], &hi[w], &ok[w]);
 }
 
-__global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, RefPlanes rp, int32_t* bin_of, uint32_t* n_proven) {
-  __shared__ int16_t verdict[256];
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int delta = -1;
-  if (i < rs.n) {
-    int mark = 0;
-    if (rs.sk[i]) {
-      int s, l1;
+__global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, RefPlanes rp, int32_t* bin_of) {
+  __shared__ int16_t verdict[256];      // per read of the block: diagonal of a finished read, -1 otherwise
+  __shared__ int16_t cand[256];         // reads with exactly two mismatches on their diagonal: rule (c) is still open
+  __shared__ int16_t cand_delta[256];
+  __shared__ int32_t n_cand;
+  if (threadIdx.x == 0) n_cand = 0;
+  verdict[threadIdx.x] = -1;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * 256;
+  auto finish = [&](int64_t i, int s, int len2, int delta, int k) {
+    rs.score[i] = FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * k;
+    rs.refstart[i] = s;
+    rs.abr[i] = 0;
+    rs.as[i] = s + delta;                   // src/mia_main.c:254-255
+    rs.ae[i] = s + delta + len2 - 1;
+    rs.status[i] = ST_DIAG;
+    bin_of[i] = -2;
+  };
+  {
+    const int64_t i = i0 + threadIdx.x;
+    if (i < rs.n) {
+      int k = -1, delta = 0, s = 0, l1 = 0;
       const int len2 = rs.len[i];
-      read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
-      DiagVerdict v;
-      if (diag_filter(rp, s, l1, rs.packed + rs.roff[i], len2, &v)) {
-        delta = v.delta;
-        rs.score[i] = FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * v.mismatches;
-        rs.refstart[i] = s;
-        rs.abr[i] = 0;
-        rs.as[i] = s + delta;                 // src/mia_main.c:254-255
-        rs.ae[i] = s + delta + len2 - 1;
-        rs.status[i] = ST_DIAG;
-        mark = -2;
+      if (rs.sk[i]) {
+        read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
+        k = diag_step1(rp, s, l1, rs.packed + rs.roff[i], len2, &delta);
+      }
+      if (k == 2) {                         // one of the block's later threads takes it through step 2
+        const int slot = atomicAdd(&n_cand, 1);
+        cand[slot] = (int16_t)threadIdx.x;
+        cand_delta[slot] = (int16_t)delta;
+      } else if (k >= 0) {
+        finish(i, s, len2, delta, k);
+        verdict[threadIdx.x] = (int16_t)delta;
+      } else {
+        bin_of[i] = 0;
       }
     }
-    bin_of[i] = mark;
   }
-  verdict[threadIdx.x] = (int16_t)delta;
-  const unsigned long long won = __ballot(delta >= 0);
-  if ((threadIdx.x & 63) == 0 && won) atomicAdd(n_proven, (uint32_t)__popcll(won));
+  __syncthreads();
+  // step 2 is three times as long as step 1 and concerns one read in five: run it on the candidates packed into the
+  // block's first threads instead of leaving four in five lanes idle
+  if ((int)threadIdx.x < n_cand) {
+    const int t = cand[threadIdx.x], delta = cand_delta[threadIdx.x];
+    const int64_t i = i0 + t;
+    int s, l1;
+    const int len2 = rs.len[i];
+    read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);       // as / ae of a candidate are still untouched
+    if (diag_step2(rp, s, l1, rs.packed + rs.roff[i], len2)) {
+      finish(i, s, len2, delta, 2);
+      verdict[t] = (int16_t)delta;
+    } else {
+      bin_of[i] = 0;
+    }
+  }
   __syncthreads();
   // the scripts of the finished reads: eight threads per read, four consecutive columns (8 bytes) per store
   for (int k = 0; k < 8; k++) {
     const int t = k * 32 + (int)(threadIdx.x >> 3);
     const int d = verdict[t];
     if (d < 0) continue;
-    const int64_t j = (int64_t)blockIdx.x * 256 + t;
+    const int64_t j = i0 + t;
     const int len2 = rs.len[j];
     int16_t* cols = rs.cols + j * rs.stride;        // stride is a multiple of 4 and >= len2
     for (int base = (int)(threadIdx.x & 7) * 4; base < len2; base += 32) {
@@ -152,16 +180,20 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
   }
 }
 
-__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int filtered, int32_t* bin_of, int32_t* bin_count) {
+__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int filtered, int32_t* bin_of, int32_t* bin_count,
+                                                     uint32_t* n_filtered) {
   __shared__ int32_t hist[N_BINS];
+  __shared__ uint32_t done;     // reads of this block that k_diag_filter finished (one global atomic per block, not per wave)
+  if (threadIdx.x == 0) done = 0;
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) hist[b] = 0;
   __syncthreads();
   for (int k = 0; k < PLAN_PER; k++) {
     const int64_t i = ((int64_t)blockIdx.x * PLAN_PER + k) * 256 + threadIdx.x;
     int b = -1;
+    bool was_done = false;
     if (i < rs.n) {
       if (filtered && bin_of[i] == -2) {
-        // finished by k_diag_filter
+        was_done = true;
       } else if (rs.sk[i]) {
         int s, l1;
         read_window(ref, rs.as[i], rs.ae[i], rs.len[i], &s, &l1);
@@ -172,9 +204,12 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
       bin_of[i] = b;
     }
     hist_add_aggregated(hist, b);
+    const unsigned long long dm = __ballot(was_done);
+    if ((threadIdx.x & 63) == 0 && dm) atomicAdd(&done, (uint32_t)__popcll(dm));
   }
   __syncthreads();
   for (int b = threadIdx.x; b < N_BINS; b += blockDim.x) if (hist[b]) atomicAdd(&bin_count[b], hist[b]);
+  if (threadIdx.x == 0 && done) atomicAdd(n_filtered, done);
 }
 
 __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin_of, const int32_t* bin_off, int32_t* bin_cursor,
