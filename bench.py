@@ -194,6 +194,7 @@ def main():
         cur = step(cur)
     hip.kernel_time(reset=True)
     hip.plain_stats(reset=True)
+    hip.filter_stats(reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -207,6 +208,7 @@ def main():
     dt = time.perf_counter() - t0
     align_ms, launches = hip.kernel_time(reset=True)
     plain_ms, plain_launches, plain_in, plain_retried = hip.plain_stats(reset=True)
+    filt_seen, filt_done, filt_ms, filt_launches = hip.filter_stats(reset=True)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -215,9 +217,10 @@ def main():
     if rank == 0:
         total_reads = n * world
         value = total_reads * a.steps / dt
-        # dominant kernel: the values-only first pass over all reads (k_align_quad_plain); reads whose alignment is not
-        # provably the pure diagonal go on to the trace kernel k_align_quad (reported beside it).  MIA_HIP_NO_PLAIN=1
-        # restores the single-kernel path.
+        # Three stages share the realignment: the diagonal filter (k_diag_filter, bit-parallel, finishes the reads whose
+        # alignment is provably one gap-free diagonal), the values-only DP over the rest (k_align_quad_plain, the
+        # largest single kernel and the one the roofline object describes) and the trace kernel k_align_quad for the
+        # reads that really carry a gap.  MIA_HIP_NO_DIAG_FILTER=1 / MIA_HIP_NO_PLAIN=1 switch the first two off.
         plain_on = plain_launches > 0
         if plain_on:
             dom_name, k_ms, dom_launches = "k_align_quad_plain", plain_ms / plain_launches, plain_launches
@@ -240,7 +243,12 @@ def main():
                          else TRAFFIC_BYTES_PER_READ * reads_per_launch,
                          "kernel": dom_name, "kernel_ms": k_ms, "launches": dom_launches,
                          "trace_kernel": {"kernel": "k_align_quad", "ms_per_step": align_ms / a.steps, "launches": launches,
-                                          "reads_frac": (plain_retried / plain_in) if plain_on and plain_in else 1.0},
+                                          "reads_frac_of_all": (plain_retried / (n * a.steps)) if plain_on else 1.0},
+                         "filter_kernel": {"kernel": "k_diag_filter", "kernel_ms": filt_ms / filt_launches, "launches": filt_launches,
+                                           "reads_finished_frac": filt_done / filt_seen if filt_seen else 0.0,
+                                           "achieved_GBs": BYTES_PER_READ * (filt_seen / filt_launches) / (filt_ms / filt_launches * 1e-3) / 1e9,
+                                           "frac_of_hbm_peak": BYTES_PER_READ * (filt_seen / filt_launches) / (filt_ms / filt_launches * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                         if filt_launches else None,
                          "note": "integer-VALU-bound DP (SQ_ACTIVE_INST_VALU = 95 % of SIMD capacity for the values-only pass, 89 % for the trace kernel; profiles/r01/pmc): 182 algorithmic HBM bytes per read (SURVEY 8d) put it at a fraction of a percent of the HBM roof by construction; see DESIGN.md 3.1",
                          "valu_utilisation": PLAIN_VALU_UTILISATION_PMC if plain_on else VALU_UTILISATION_PMC,
                          "gcups": reads_per_launch * 100 * 200 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},

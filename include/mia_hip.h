@@ -251,8 +251,9 @@ int mia_hip_plain_stats(mia_hip_ctx *ctx, int reset, double *plain_ms, int64_t *
 
 /* The diagonal filter in front of the DP kernels of mia_hip_realign / mia_hip_align_windows (csrc/diag_filter.h: flat
  * matrix only; a read whose alignment is provably one gap-free diagonal with at most two mismatches is finished by
- * bit-parallel comparison and never reaches the DP): reads examined and reads finished there since the last reset. */
-int mia_hip_filter_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_seen, int64_t *reads_finished);
+ * bit-parallel comparison and never reaches the DP): reads examined and reads finished there since the last reset;
+ * kernel_ms / launches: accumulated time of k_diag_filter (HIP events on the context's stream).  Any pointer may be NULL. */
+int mia_hip_filter_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_seen, int64_t *reads_finished, double *kernel_ms, int64_t *launches);
 /* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
 int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 

@@ -55,7 +55,7 @@ def _load():
     lib.mia_hip_get_tally.argtypes = [vp, vp, vp]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
-    lib.mia_hip_filter_stats.argtypes = [vp, C.c_int, vp, vp]
+    lib.mia_hip_filter_stats.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.mia_hip_myers_align.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, vp, vp, vp]
     lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
     lib.mia_hip_ma_tally.argtypes = [vp, C.c_int32, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
@@ -303,10 +303,10 @@ class MiaHip:
         return buf.raw[: n.value].decode()
 
     def filter_stats(self, reset=False):
-        """reads examined / finished by the diagonal filter in front of the DP kernels (flat matrix only)"""
-        a, b = C.c_int64(0), C.c_int64(0)
-        self._chk(self._l.mia_hip_filter_stats(self._h, 1 if reset else 0, C.byref(a), C.byref(b)))
-        return a.value, b.value
+        """(reads examined, reads finished, kernel ms, launches) of the diagonal filter in front of the DP kernels (flat matrix only)"""
+        a, b, ms, k = C.c_int64(0), C.c_int64(0), C.c_double(0), C.c_int64(0)
+        self._chk(self._l.mia_hip_filter_stats(self._h, 1 if reset else 0, C.byref(a), C.byref(b), C.byref(ms), C.byref(k)))
+        return a.value, b.value, ms.value, k.value
 
     def myers_align(self, seq_a, mode, seq_b, maxd):
         """myers_diff with its backtrace (reference src/myers_align.h:35): (distance or None, row over seq_a, row over seq_b)"""

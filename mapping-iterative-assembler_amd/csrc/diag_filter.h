@@ -38,6 +38,7 @@ namespace mia {
 constexpr int PLANE_LEAD = 320;      // wild-card bits in front of reference position 0 (multiple of 64, >= MAX_READ)
 constexpr int PLANE_TAIL = 704;      // ... and behind the last code (>= 2*MAX_READ + 3*64)
 constexpr int DF_MAX_LEN1 = 768;     // windows wider than the widest DP class are not examined
+constexpr int DF_GAP_HINT = 6;       // this many mismatches on the best gap-free diagonal: the read almost surely carries a gap
 
 MIA_HD inline int64_t plane_words(int64_t n_codes) { return (PLANE_LEAD + n_codes + PLANE_TAIL) / 64 + 1; }
 
@@ -187,8 +188,9 @@ struct DiagScan {
 // (0..2) if it is the only diagonal that good and has no N under it, -1 if the read has to go to the DP.  K <= 1 settles
 // the read; K == 2 needs step 2.
 template <int NW>
-MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out) {
+MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out, int* best_out) {
   DiagScan<NW> sc;
+  *best_out = -1;
   if (!sc.load_read(read_packed, len2)) return -1;
   const int fit = len1 - len2;                        // diagonals 0 .. fit hold the whole read
   int best = 1 << 20, second = 1 << 20, delta = -1;
@@ -200,6 +202,7 @@ MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t
     else if (m < second) second = m;
     if (d < fit) sc.advance(rp, (int64_t)s + d + 1);
   }
+  *best_out = best;                                   // a hint for the planner: many mismatches on the best diagonal = a gap
   if (best > 2 || second <= best || !clean) return -1;
   *delta_out = delta;
   return best;
@@ -224,13 +227,14 @@ MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_
 
 MIA_HD inline bool diag_examined(int len1, int len2) { return len2 >= 1 && len2 <= MAX_READ && len1 >= len2 && len1 <= DF_MAX_LEN1; }
 
-MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out) {
+MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out, int* best_out) {
+  *best_out = -1;
   if (!diag_examined(len1, len2)) return -1;
   switch ((len2 + 63) >> 6) {
-    case 1: return diag_step1<1>(rp, s, len1, read_packed, len2, delta_out);
-    case 2: return diag_step1<2>(rp, s, len1, read_packed, len2, delta_out);
-    case 3: return diag_step1<3>(rp, s, len1, read_packed, len2, delta_out);
-    default: return diag_step1<4>(rp, s, len1, read_packed, len2, delta_out);
+    case 1: return diag_step1<1>(rp, s, len1, read_packed, len2, delta_out, best_out);
+    case 2: return diag_step1<2>(rp, s, len1, read_packed, len2, delta_out, best_out);
+    case 3: return diag_step1<3>(rp, s, len1, read_packed, len2, delta_out, best_out);
+    default: return diag_step1<4>(rp, s, len1, read_packed, len2, delta_out, best_out);
   }
 }
 MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2) {
@@ -247,8 +251,8 @@ struct DiagVerdict { int delta, mismatches; };
 // Window = reference positions [s, s + len1).  True iff the alignment is provably the diagonal out->delta (offset
 // inside the window) with out->mismatches definite mismatches.  The caller has established the flat matrix.
 MIA_HD inline bool diag_filter(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, DiagVerdict* out) {
-  int delta = 0;
-  const int k = diag_step1(rp, s, len1, read_packed, len2, &delta);
+  int delta = 0, best = 0;
+  const int k = diag_step1(rp, s, len1, read_packed, len2, &delta, &best);
   if (k < 0 || (k == 2 && !diag_step2(rp, s, len1, read_packed, len2))) return false;
   out->delta = delta;
   out->mismatches = k;

@@ -88,7 +88,8 @@ struct mia_hip_ctx {
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free, ev_plain;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free, ev_plain, ev_filter;
+  double filter_ms = 0; int64_t filter_launches = 0;
   double align_ms = 0; int64_t align_launches = 0;
   double pass1_ms = 0;
   bool consensus_done = false;
@@ -185,6 +186,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_plain) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : ctx->ev_filter) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -351,6 +353,15 @@ static void drain_events(mia_hip_ctx* ctx) {
     ctx->ev_free.push_back(e);
   }
   ctx->ev_plain.clear();
+  for (auto& e : ctx->ev_filter) {
+    float ms = 0;
+    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+      ctx->filter_ms += ms;
+      ctx->filter_launches++;
+    }
+    ctx->ev_free.push_back(e);
+  }
+  ctx->ev_filter.clear();
 }
 
 extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms, int64_t* launches) {
@@ -363,11 +374,15 @@ extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms
   return MIA_HIP_OK;
 }
 
-extern "C" int mia_hip_filter_stats(mia_hip_ctx* ctx, int reset, int64_t* reads_seen, int64_t* reads_finished) {
+extern "C" int mia_hip_filter_stats(mia_hip_ctx* ctx, int reset, int64_t* reads_seen, int64_t* reads_finished, double* kernel_ms, int64_t* launches) {
   if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  drain_events(ctx);
   if (reads_seen) *reads_seen = ctx->filter_seen;
   if (reads_finished) *reads_finished = ctx->filter_proven;
-  if (reset) { ctx->filter_seen = 0; ctx->filter_proven = 0; }
+  if (kernel_ms) *kernel_ms = ctx->filter_ms;
+  if (launches) *launches = ctx->filter_launches;
+  if (reset) { ctx->filter_seen = 0; ctx->filter_proven = 0; ctx->filter_ms = 0; ctx->filter_launches = 0; }
   return MIA_HIP_OK;
 }
 
@@ -456,10 +471,16 @@ static int align_all(mia_hip_ctx* ctx) {
     hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
                        ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
     HIPCHK(hipMemsetAsync(ctx->d_filter_n, 0, 4, ctx->stream));
+    hipEvent_t f0, f1;
+    if (get_events(ctx, &f0, &f1)) return MIA_HIP_ERR_NOMEM;
+    ctx->ev_filter.push_back(ctx->ev_used.back());
+    ctx->ev_used.pop_back();
+    (void)hipEventRecord(f0, ctx->stream);
     hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ctx->d_bin_of);
+    (void)hipEventRecord(f1, ctx->stream);
     HIPCHK(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, ctx->d_bin_of, d_count, ctx->d_filter_n);
+  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && ctx->use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   if (filtered) HIPCHK(hipMemcpyAsync(&h_filter_n, ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
   int32_t h_count[N_BINS], h_off[N_BINS];
   HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, ctx->stream));
@@ -489,8 +510,9 @@ static int align_all(mia_hip_ctx* ctx) {
     if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   }
   int n_quads_trace = n_quads, quad_begin_trace = quad_begin;
-  if (n_quads > 0 && ctx->use_plain) {
+  if ((n_quads > 0 || filtered) && ctx->use_plain) {
     // first pass: values only; reads whose alignment is provably the pure diagonal are finished there
+    if (n_quads > 0) {
     const int grid = n_quads < ctx->quad_wgs ? n_quads : ctx->quad_wgs;
     const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
     hipEvent_t p0, p1;
@@ -502,7 +524,8 @@ static int align_all(mia_hip_ctx* ctx) {
                        n_quads, ctx->d_bin_of);
     (void)hipEventRecord(p1, ctx->stream);
     HIPCHK(hipGetLastError());
-    // re-plan what is left into quads of equal read length
+    }
+    // re-plan what is left (and what the filter's gap hint kept out of the first pass) into quads of equal read length
     HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ctx->stream));
     hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_count);

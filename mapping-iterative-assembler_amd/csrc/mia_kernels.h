@@ -96,6 +96,7 @@ __device__ __forceinline__ int hist_add_aggregated(int32_t* hist, int b) {
 // ---- plan: bin every read by kernel variant and LDS footprint ----------------
 // Counts go through an LDS histogram per block, so global memory sees one atomic per
 // (block, non-empty bin) instead of one per read on a single hot address.
+constexpr int PLAN_DEFERRED = -1000;   // bin_of = PLAN_DEFERRED - bin: a quad-class read that waits for the trace stage
 constexpr int PLAN_PER = 8;   // reads per thread of the planner kernels: a block bins 2048 reads per LDS histogram
 
 // ---- the diagonal filter (diag_filter.h), ahead of everything else: one read per thread.  A read whose alignment
@@ -127,11 +128,11 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
   {
     const int64_t i = i0 + threadIdx.x;
     if (i < rs.n) {
-      int k = -1, delta = 0, s = 0, l1 = 0;
+      int k = -1, delta = 0, s = 0, l1 = 0, best = -1;
       const int len2 = rs.len[i];
       if (rs.sk[i]) {
         read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
-        k = diag_step1(rp, s, l1, rs.packed + rs.roff[i], len2, &delta);
+        k = diag_step1(rp, s, l1, rs.packed + rs.roff[i], len2, &delta, &best);
       }
       if (k == 2) {                         // one of the block's later threads takes it through step 2
         const int slot = atomicAdd(&n_cand, 1);
@@ -141,7 +142,9 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
         finish(i, s, len2, delta, k);
         verdict[threadIdx.x] = (int16_t)delta;
       } else {
-        bin_of[i] = 0;
+        // not decided here.  With DF_GAP_HINT or more mismatches on its best gap-free diagonal the values-only DP pass
+        // would only find out that the read needs a trace: the planner sends it to the trace kernel directly (-3).
+        bin_of[i] = best >= DF_GAP_HINT ? -3 : 0;
       }
     }
   }
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
   }
 }
 
-__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int filtered, int32_t* bin_of, int32_t* bin_count,
+__global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int filtered, int defer, int32_t* bin_of, int32_t* bin_count,
                                                      uint32_t* n_filtered) {
   __shared__ int32_t hist[N_BINS];
   __shared__ uint32_t done;     // reads of this block that k_diag_filter finished (one global atomic per block, not per wave)
@@ -192,12 +195,15 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
     int b = -1;
     bool was_done = false;
     if (i < rs.n) {
-      if (filtered && bin_of[i] == -2) {
+      const int mark = filtered ? bin_of[i] : 0;
+      if (mark == -2) {
         was_done = true;
       } else if (rs.sk[i]) {
         int s, l1;
         read_window(ref, rs.as[i], rs.ae[i], rs.len[i], &s, &l1);
         b = classify(rs.len[i], l1, ps, use_quad);
+        // gap hint of the filter: skip the values-only pass; k_plan_recount brings the read back for the trace kernel
+        if (mark == -3 && defer && b >= BIN_QUAD0) b = PLAN_DEFERRED - b;
       } else {
         rs.status[i] = ST_SKIPPED;
       }
@@ -396,7 +402,8 @@ __global__ __launch_bounds__(256) void k_plan_recount(int64_t n, int32_t* bin_of
     int b = -1;
     if (i < n) {
       b = bin_of[i];
-      if (b >= 0 && b < BIN_QUAD0) { bin_of[i] = -1; b = -1; }
+      if (b <= PLAN_DEFERRED) { b = PLAN_DEFERRED - b; bin_of[i] = b; }
+      else if (b >= 0 && b < BIN_QUAD0) { bin_of[i] = -1; b = -1; }
     }
     hist_add_aggregated(hist, b);
   }
