@@ -184,9 +184,36 @@ struct DiagScan {
   }
 };
 
+// 64 reference positions of the three planes, sliding one position per step (a second word feeds the first)
+struct Slide {
+  uint64_t lo0, lo1, hi0, hi1, ok0, ok1;
+  int left;
+  MIA_HD void seek(const RefPlanes& rp, int64_t pos) {
+    const int64_t bit = pos + PLANE_LEAD;
+    const int64_t q = bit >> 6;
+    const int b = (int)(bit & 63);
+    const uint64_t l0 = rp.lo[q], l1 = rp.lo[q + 1], l2 = rp.lo[q + 2];
+    const uint64_t h0 = rp.hi[q], h1 = rp.hi[q + 1], h2 = rp.hi[q + 2];
+    const uint64_t k0 = rp.ok[q], k1 = rp.ok[q + 1], k2 = rp.ok[q + 2];
+    lo0 = (l0 >> b) | ((l1 << 1) << (63 - b)); lo1 = (l1 >> b) | ((l2 << 1) << (63 - b));
+    hi0 = (h0 >> b) | ((h1 << 1) << (63 - b)); hi1 = (h1 >> b) | ((h2 << 1) << (63 - b));
+    ok0 = (k0 >> b) | ((k1 << 1) << (63 - b)); ok1 = (k1 >> b) | ((k2 << 1) << (63 - b));
+    left = 64;
+  }
+  MIA_HD void advance(const RefPlanes& rp, int64_t next_pos) {
+    if (--left == 0) { seek(rp, next_pos); return; }
+    lo0 = (lo0 >> 1) | (lo1 << 63); lo1 >>= 1;
+    hi0 = (hi0 >> 1) | (hi1 << 63); hi1 >>= 1;
+    ok0 = (ok0 >> 1) | (ok1 << 63); ok1 >>= 1;
+  }
+  MIA_HD uint64_t mis(uint64_t rlo, uint64_t rhi, uint64_t rows) const { return ((rlo ^ lo0) | (rhi ^ hi0)) & ok0 & rows; }
+};
+
 // Step 1, rules (a) and (b): the best diagonal among those that hold the whole read.  Returns its mismatch count K
 // (0..2) if it is the only diagonal that good and has no N under it, -1 if the read has to go to the DP.  K <= 1 settles
-// the read; K == 2 needs step 2.
+// the read; K == 2 needs step 2.  Only the first 64 rows are compared on every diagonal: three mismatches there already
+// put a diagonal out of the race (all that is asked of the others is ">= K+1", K <= 2), the few diagonals that pass
+// are compared in full.  *best_out: a lower bound of the mismatches on the best diagonal, exact when it is below 3.
 template <int NW>
 MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out, int* best_out) {
   DiagScan<NW> sc;
@@ -195,12 +222,19 @@ MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t
   const int fit = len1 - len2;                        // diagonals 0 .. fit hold the whole read
   int best = 1 << 20, second = 1 << 20, delta = -1;
   bool clean = false;
-  sc.seek(rp, s);
+  Slide head;
+  head.seek(rp, s);
   for (int d = 0; d <= fit; d++) {
-    const int m = sc.mismatches();
-    if (m < best) { second = best; best = m; delta = d; clean = sc.all_acgt(); }
+    int m = df_popc(head.mis(sc.rlo[0], sc.rhi[0], sc.rows[0]));
+    bool acgt = (head.ok0 & sc.rows[0]) == sc.rows[0];
+    if (NW > 1 && m < 3) {                            // a contender: all rows
+      sc.seek(rp, (int64_t)s + d);
+      m = sc.mismatches();
+      acgt = sc.all_acgt();
+    }
+    if (m < best) { second = best; best = m; delta = d; clean = acgt; }
     else if (m < second) second = m;
-    if (d < fit) sc.advance(rp, (int64_t)s + d + 1);
+    if (d < fit) head.advance(rp, (int64_t)s + d + 1);
   }
   *best_out = best;                                   // a hint for the planner: many mismatches on the best diagonal = a gap
   if (best > 2 || second <= best || !clean) return -1;
@@ -209,18 +243,36 @@ MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t
 }
 
 // Step 2, rule (c), for K == 2: prefixes start in row 0 at a window column (diagonals 0 .. len1-1), suffixes end in row
-// R at a window column (diagonals -R .. len1-len2).
+// R at a window column (diagonals -R .. len1-len2).  A prefix is almost always cut within the first 64 rows and a suffix
+// within the last word of rows: two sliding words; the full planes are fetched only when one of them shows no mismatch.
 template <int NW>
 MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2) {
   DiagScan<NW> sc;
   sc.load_read(read_packed, len2);
   const int R = len2 - 1, fit = len1 - len2;
+  constexpr int TOP = 64 * (NW - 1);                  // first row of the last word
   int lp = 0, ls = 0;
-  sc.seek(rp, (int64_t)s - R);
+  Slide head, tail;
+  head.seek(rp, (int64_t)s - R);
+  if (NW > 1) tail.seek(rp, (int64_t)s - R + TOP);
   for (int d = -R; d <= len1 - 1; d++) {
-    if (d >= 0) { const int p = sc.clean_prefix(); lp = p > lp ? p : lp; }
-    if (d <= fit) { const int q = sc.clean_suffix(); ls = q > ls ? q : ls; }
-    if (d < len1 - 1) sc.advance(rp, (int64_t)s + d + 1);
+    const uint64_t m0 = head.mis(sc.rlo[0], sc.rhi[0], sc.rows[0]);
+    const uint64_t mt = NW > 1 ? tail.mis(sc.rlo[NW - 1], sc.rhi[NW - 1], sc.rows[NW - 1]) : m0;
+    int p, q;
+    if (NW > 1 && (m0 == 0 || mt == 0)) {             // a long clean stretch: all rows
+      sc.seek(rp, (int64_t)s + d);
+      p = sc.clean_prefix();
+      q = sc.clean_suffix();
+    } else {
+      p = m0 ? df_ctz(m0) : len2;
+      q = mt ? len2 - 1 - (TOP + 63 - df_clz(mt)) : len2;
+    }
+    if (d >= 0 && p > lp) lp = p;
+    if (d <= fit && q > ls) ls = q;
+    if (d < len1 - 1) {
+      head.advance(rp, (int64_t)s + d + 1);
+      if (NW > 1) tail.advance(rp, (int64_t)s + d + 1 + TOP);
+    }
   }
   return lp + ls <= R - 3;
 }
