@@ -256,6 +256,9 @@ int mia_hip_plain_stats(mia_hip_ctx *ctx, int reset, double *plain_ms, int64_t *
 int mia_hip_filter_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_seen, int64_t *reads_finished, double *kernel_ms, int64_t *launches);
 /* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
 int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
+/* reads of the last mia_hip_pass1 call decided by the diagonal filter (csrc/diag_filter.h: flat matrix, no k-mer mask)
+ * instead of the whole-reference DP */
+int mia_hip_pass1_filtered(mia_hip_ctx *ctx, int64_t *reads);
 
 #ifdef __cplusplus
 }

@@ -19,9 +19,9 @@
 //       which is <= 1600 only for g <= 3.  It is a mismatch-free prefix of the read on one diagonal followed by a
 //       mismatch-free suffix on another (or nothing but a suffix after a late start), together covering all but
 //       <= 3 rows.  LP = longest mismatch-free prefix over ALL diagonals, LS = longest mismatch-free suffix; the test
-//       LP + LS <= R - 3 rules every such path out.  N columns, columns outside the window and positions outside
-//       the reference are treated as matching anything, which can only make LP / LS larger (more fall-backs, never
-//       a wrong verdict).
+//       LP + LS <= R - 3 rules every such path out.  A prefix (suffix) counts only as far as its diagonal stays
+//       inside the window; N columns and positions outside the reference are treated as matching anything, which
+//       can only make LP / LS larger (more fall-backs, never a wrong verdict).
 // Hence every path other than D ends in row R with a value STRICTLY below D's: max_sg_score's first maximum of the
 // last row is D's end cell (ties impossible), and by extending any better path to a diagonal cell along D one sees
 // that at every cell of D the diagonal candidate is >= both gap candidates, and D(r-1) >= -600 > -P(r+1), so the
@@ -214,7 +214,13 @@ struct Slide {
 // the read; K == 2 needs step 2.  Only the first 64 rows are compared on every diagonal: three mismatches there already
 // put a diagonal out of the race (all that is asked of the others is ">= K+1", K <= 2), the few diagonals that pass
 // are compared in full.  *best_out: a lower bound of the mismatches on the best diagonal, exact when it is below 3.
-template <int NW>
+//
+// RIGHT_TIES: diagonals to the RIGHT of the best one may be equally good (pass 1 on a circular reference sees every
+// read near the origin twice, L columns apart).  Such a diagonal ends in a later column of the last row with the same
+// value, and max_sg_score keeps the FIRST maximum; nothing else in the argument needs strictness on that side.  The
+// scan runs left to right and replaces the best only by a strictly better diagonal, so everything left of the final
+// best is strictly worse by construction.
+template <int NW, bool RIGHT_TIES>
 MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out, int* best_out) {
   DiagScan<NW> sc;
   *best_out = -1;
@@ -237,7 +243,7 @@ MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t
     if (d < fit) head.advance(rp, (int64_t)s + d + 1);
   }
   *best_out = best;                                   // a hint for the planner: many mismatches on the best diagonal = a gap
-  if (best > 2 || second <= best || !clean) return -1;
+  if (best > 2 || (!RIGHT_TIES && second <= best) || !clean) return -1;
   *delta_out = delta;
   return best;
 }
@@ -267,6 +273,9 @@ MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_
       p = m0 ? df_ctz(m0) : len2;
       q = mt ? len2 - 1 - (TOP + 63 - df_clz(mt)) : len2;
     }
+    // a prefix on diagonal d cannot run past the last window column, a suffix cannot begin before the first one
+    if (p > len1 - d) p = len1 - d;
+    if (d < 0 && q > len2 + d) q = len2 + d;
     if (d >= 0 && p > lp) lp = p;
     if (d <= fit && q > ls) ls = q;
     if (d < len1 - 1) {
@@ -283,11 +292,45 @@ MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t
   *best_out = -1;
   if (!diag_examined(len1, len2)) return -1;
   switch ((len2 + 63) >> 6) {
-    case 1: return diag_step1<1>(rp, s, len1, read_packed, len2, delta_out, best_out);
-    case 2: return diag_step1<2>(rp, s, len1, read_packed, len2, delta_out, best_out);
-    case 3: return diag_step1<3>(rp, s, len1, read_packed, len2, delta_out, best_out);
-    default: return diag_step1<4>(rp, s, len1, read_packed, len2, delta_out, best_out);
+    case 1: return diag_step1<1, false>(rp, s, len1, read_packed, len2, delta_out, best_out);
+    case 2: return diag_step1<2, false>(rp, s, len1, read_packed, len2, delta_out, best_out);
+    case 3: return diag_step1<3, false>(rp, s, len1, read_packed, len2, delta_out, best_out);
+    default: return diag_step1<4, false>(rp, s, len1, read_packed, len2, delta_out, best_out);
   }
+}
+// the same against a whole strand of the (wrapped) reference, columns 0 .. len1-1: pass 1
+MIA_HD inline int strand_step1(const RefPlanes& rp, int len1, const uint8_t* read_packed, int len2, int* delta_out, int* best_out) {
+  *best_out = -1;
+  if (len2 < 1 || len2 > MAX_READ || len1 < len2) return -1;
+  switch ((len2 + 63) >> 6) {
+    case 1: return diag_step1<1, true>(rp, 0, len1, read_packed, len2, delta_out, best_out);
+    case 2: return diag_step1<2, true>(rp, 0, len1, read_packed, len2, delta_out, best_out);
+    case 3: return diag_step1<3, true>(rp, 0, len1, read_packed, len2, delta_out, best_out);
+    default: return diag_step1<4, true>(rp, 0, len1, read_packed, len2, delta_out, best_out);
+  }
+}
+
+// Pass 1 (sg_align, src/mia.c:1500-1665: both strands of the whole reference, the better one wins, the reverse strand
+// on a tie, :1549) for a read that the flat matrix aligns gap-free.  fw / rc: planes of the two strands, len1 columns
+// each.  Step 1 of both strands: *strand = the strand whose best diagonal has fewer mismatches, K of them (returned;
+// -1 = leave the read to the DP).  The loser's best diagonal must have >= K+1 mismatches: every path there then loses
+// more than 800 K (a diagonal >= 800 (K+1); anything with an event >= 1200, and for K == 2 pass1_step2 on the loser
+// excludes the event paths that lose <= 1600), so the winner's score 200 len - 800 K is strictly the larger one.
+MIA_HD inline int pass1_step1(const RefPlanes& fw, const RefPlanes& rc, int len1, const uint8_t* read_packed, int len2, int* strand, int* delta) {
+  int d[2] = {0, 0}, best[2], k[2];
+  k[0] = strand_step1(fw, len1, read_packed, len2, &d[0], &best[0]);
+  if (best[0] < 0) return -1;                            // a read with N
+  k[1] = strand_step1(rc, len1, read_packed, len2, &d[1], &best[1]);
+  const int x = best[0] < best[1] ? 0 : 1, y = 1 - x;     // best[] below 3 is exact, from 3 on a lower bound
+  if (k[x] < 0 || best[y] <= k[x]) return -1;
+  *strand = x;
+  *delta = d[x];
+  return k[x];
+}
+MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2);
+// K == 2: rule (c) on both strands
+MIA_HD inline bool pass1_step2(const RefPlanes& fw, const RefPlanes& rc, int len1, const uint8_t* read_packed, int len2) {
+  return diag_step2(fw, 0, len1, read_packed, len2) && diag_step2(rc, 0, len1, read_packed, len2);
 }
 MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2) {
   switch ((len2 + 63) >> 6) {

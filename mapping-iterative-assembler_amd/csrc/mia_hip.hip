@@ -91,7 +91,7 @@ struct mia_hip_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free, ev_plain, ev_filter;
   double filter_ms = 0; int64_t filter_launches = 0;
   double align_ms = 0; int64_t align_launches = 0;
-  double pass1_ms = 0;
+  double pass1_ms = 0; int64_t pass1_filtered = 0;   // reads of the last pass-1 call that the diagonal filter decided
   bool consensus_done = false;
   int64_t trim_escapes = 0;   // reads of the last mia_hip_trim call that took the exact scalar path
   int64_t ins_total_host = 0;
@@ -1425,7 +1425,11 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   int32_t *d_score = nullptr, *d_as = nullptr, *d_ae = nullptr;
   unsigned char* d_trace = nullptr;
   uint32_t* d_ckpt = nullptr;
+  uint64_t* d_p1planes = nullptr;
+  int32_t* d_todo = nullptr;
+  uint32_t* d_ntodo = nullptr;
   ScopeFree guard;   // every temporary below is released on any return
+  guard.watch((void**)&d_p1planes); guard.watch((void**)&d_todo); guard.watch((void**)&d_ntodo);
   for (void** pp : {(void**)&d_cf, (void**)&d_cr, (void**)&d_tab[0], (void**)&d_tab[1], (void**)&d_kl[0], (void**)&d_kl[1], (void**)&d_el[0],
                     (void**)&d_el[1], (void**)&d_pos[0], (void**)&d_pos[1], (void**)&d_packed, (void**)&d_rc, (void**)&d_flags, (void**)&d_roff,
                     (void**)&d_status, (void**)&d_len, (void**)&d_score, (void**)&d_as, (void**)&d_ae, (void**)&d_trace, (void**)&d_ckpt})
@@ -1492,13 +1496,39 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   auto cp = [&](void* d, const void* h, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
   cp(d_cf, cf.data(), cf.size()); cp(d_cr, cr.data(), cr.size());
   cp(d_packed, packed.data(), packed.size()); cp(d_roff, roff.data(), (size_t)n * 4); cp(d_len, len.data(), (size_t)n * 2);
+  // The diagonal filter (diag_filter.h) first, when its premises hold: flat matrix and no k-mer mask (a masked DP is a
+  // different recurrence).  It decides most reads by bit-parallel comparison against every diagonal of both strands;
+  // the whole-reference DP then runs on what is left.
+  const bool filtered = ctx->flat && ctx->use_filter && kmer_len <= 0 && len1 >= max_len;
+  int64_t n_dp = n;
+  ctx->pass1_filtered = 0;
   if (e == hipSuccess) {
     Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
     if (get_events(ctx, &pe0, &pe1) == 0) (void)hipEventRecord(pe0, ctx->stream);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
-                       trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words, plain);
+    if (filtered) {
+      const int64_t words = plane_words(len1);
+      if (dev_alloc(ctx, &d_p1planes, (size_t)words * 6) || dev_alloc(ctx, &d_todo, (size_t)n) || dev_alloc(ctx, &d_ntodo, 1)) return MIA_HIP_ERR_NOMEM;
+      uint64_t* pl = d_p1planes;
+      hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, words, pl, pl + words, pl + 2 * words);
+      hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, words, pl + 3 * words, pl + 4 * words, pl + 5 * words);
+      e = hipMemsetAsync(d_ntodo, 0, 4, ctx->stream);
+      RefPlanes pf{pl, pl + words, pl + 2 * words}, prc{pl + 3 * words, pl + 4 * words, pl + 5 * words};
+      hipLaunchKernelGGL(k_pass1_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pr, pf, prc, len1, L, d_todo, d_ntodo);
+      if (e == hipSuccess) e = hipGetLastError();
+      uint32_t h_ntodo = 0;
+      if (e == hipSuccess) e = hipMemcpyAsync(&h_ntodo, d_ntodo, 4, hipMemcpyDeviceToHost, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      n_dp = h_ntodo;
+      ctx->pass1_filtered = n - n_dp;
+      if (timing) fprintf(stderr, "[mia_hip_pass1] diagonal filter: %lld of %lld reads decided\n", (long long)(n - n_dp), (long long)n);
+    }
+    if (e == hipSuccess && n_dp > 0) {
+      const int64_t g = grid < n_dp ? grid : n_dp;
+      hipLaunchKernelGGL(kfn, dim3((unsigned)g), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
+                         trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words, plain, filtered ? d_todo : nullptr, n_dp);
+      e = hipGetLastError();
+    }
     if (pe1) (void)hipEventRecord(pe1, ctx->stream);
-    e = hipGetLastError();
   }
   auto back = [&](void* h, const void* d, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, ctx->stream); };
   back(score, d_score, (size_t)n * 4); back(as, d_as, (size_t)n * 4); back(ae, d_ae, (size_t)n * 4);
@@ -1628,5 +1658,11 @@ extern "C" int mia_hip_myers_align(mia_hip_ctx* ctx, const char* seq_a, int32_t 
 extern "C" int mia_hip_pass1_time(mia_hip_ctx* ctx, double* kernel_ms) {
   if (!ctx || !kernel_ms) return MIA_HIP_ERR_ARG;
   *kernel_ms = ctx->pass1_ms;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_pass1_filtered(mia_hip_ctx* ctx, int64_t* reads) {
+  if (!ctx || !reads) return MIA_HIP_ERR_ARG;
+  *reads = ctx->pass1_filtered;
   return MIA_HIP_OK;
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "diag_filter.h"
 #include "mia_layout.h"
 #include "pass1_body.h"
 #include "wave_dev.h"
@@ -50,11 +51,74 @@ __device__ __forceinline__ void mask_or_range(uint32_t* m, int lo, int hi) {   /
   }
 }
 
+// what sg_align leaves in the FragSeq for the winning strand's alignment (src/mia.c:1568-1610,1614,1619,1653)
+__device__ __forceinline__ void pass1_store(const Pass1Reads& rs, int64_t i, int32_t L, int strand, int32_t score, int32_t abc, int32_t aec,
+                                            uint32_t status) {
+  int start, end, as, ae;
+  if (strand) {
+    start = L - (aec % L) - 1;   // c2rcc (src/mia.c:26-30)
+    end = L - (abc % L) - 1;
+  } else { start = abc; end = aec; }
+  as = start; ae = end;
+  if (as > ae) ae = L + as;        // sic
+  if (end > L) end -= L;
+  uint8_t fl = P1_PASSED;
+  if (score >= 2000) fl |= P1_KEPT;
+  if (score > 2000) fl |= P1_STRAND_KNOWN;
+  if (start > end) fl |= P1_SPLIT;
+  rs.flags[i] = fl; rs.score[i] = score; rs.as[i] = as; rs.ae[i] = ae; rs.rc[i] = (uint8_t)strand; rs.status[i] = status;
+}
+
+// ---- the diagonal filter in front of the whole-reference DP (diag_filter.h; flat matrix, no k-mer mask): one read per
+// thread against every diagonal of both strands.  Reads it cannot decide are collected in `todo` for k_pass1.
+__global__ __launch_bounds__(256) void k_pass1_filter(Pass1Reads rs, RefPlanes fw, RefPlanes rc, int32_t len1, int32_t L, int32_t* todo,
+                                                      uint32_t* n_todo) {
+  __shared__ int16_t cand[256];
+  __shared__ int32_t cand_delta[256];
+  __shared__ uint8_t cand_strand[256];
+  __shared__ int16_t left[256];
+  __shared__ int32_t n_cand, n_left;
+  __shared__ uint32_t base;
+  if (threadIdx.x == 0) { n_cand = 0; n_left = 0; }
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * 256;
+  {
+    const int64_t i = i0 + threadIdx.x;
+    if (i < rs.n) {
+      const int len2 = rs.len[i];
+      int strand = 0, delta = 0;
+      const int k = pass1_step1(fw, rc, len1, rs.packed + rs.roff[i], len2, &strand, &delta);
+      if (k == 2) {
+        const int slot = atomicAdd(&n_cand, 1);
+        cand[slot] = (int16_t)threadIdx.x; cand_delta[slot] = delta; cand_strand[slot] = (uint8_t)strand;
+      } else if (k >= 0) {
+        pass1_store(rs, i, L, strand, FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * k, delta, delta + len2 - 1, ST_DIAG);
+      } else {
+        left[atomicAdd(&n_left, 1)] = (int16_t)threadIdx.x;
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_cand) {               // rule (c) for the reads with two mismatches, packed into the first threads
+    const int t = cand[threadIdx.x], strand = cand_strand[threadIdx.x];
+    const int64_t i = i0 + t;
+    const int len2 = rs.len[i], delta = cand_delta[threadIdx.x];
+    if (pass1_step2(fw, rc, len1, rs.packed + rs.roff[i], len2))
+      pass1_store(rs, i, L, strand, FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * 2, delta, delta + len2 - 1, ST_DIAG);
+    else
+      left[atomicAdd(&n_left, 1)] = (int16_t)t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && n_left) base = atomicAdd(n_todo, (uint32_t)n_left);
+  __syncthreads();
+  if ((int)threadIdx.x < n_left) todo[base + threadIdx.x] = (int32_t)(i0 + left[threadIdx.x]);
+}
+
 template <int CPL>
 __global__ __launch_bounds__(64, 4) void k_pass1(Pass1Reads rs, const uint8_t* ref_fw, const uint8_t* ref_rc, int32_t len1, int32_t L,
                                                const int32_t* pssm_fwd, PackParams pk, KmerIndex kx, unsigned char* trace_slabs,
                                                int64_t trace_bytes, uint32_t* ckpt_slabs, int64_t ckpt_words, int32_t rows_p,
-                                               int32_t mask_words, int32_t plain) {
+                                               int32_t mask_words, int32_t plain, const int32_t* todo, int64_t n_todo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * trace_bytes);
   const int lane = (int)wave.lane();
@@ -74,7 +138,9 @@ __global__ __launch_bounds__(64, 4) void k_pass1(Pass1Reads rs, const uint8_t* r
   a.rows_p = rows_p;
   uint32_t* mask[2] = {reinterpret_cast<uint32_t*>(lds_raw + a.lds_mask[0]), reinterpret_cast<uint32_t*>(lds_raw + a.lds_mask[1])};
 
-  for (int64_t i = blockIdx.x; i < rs.n; i += gridDim.x) {
+  const int64_t n_work = todo ? n_todo : rs.n;     // todo: the reads the diagonal filter left over
+  for (int64_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+    const int64_t i = todo ? (int64_t)todo[w] : w;
     const int len2 = rs.len[i];
     const uint8_t* rp = rs.packed + rs.roff[i];
     bool pass = true;
@@ -132,22 +198,7 @@ __global__ __launch_bounds__(64, 4) void k_pass1(Pass1Reads rs, const uint8_t* r
     Pass1Result r;
     if (CPL == P1_CPL_WIDE && a.plain) r = Pass1Aligner<DevWave, CPL>::run_plain(wave, a);
     else r = Pass1Aligner<DevWave, CPL>::run(wave, a);
-    if (lane == 0) {
-      // sg_align, src/mia.c:1568-1610,1614,1619,1653
-      int start, end, as, ae;
-      if (r.strand) {
-        start = L - (r.aec % L) - 1;   // c2rcc (src/mia.c:26-30)
-        end = L - (r.abc % L) - 1;
-      } else { start = r.abc; end = r.aec; }
-      as = start; ae = end;
-      if (as > ae) ae = L + as;        // sic
-      if (end > L) end -= L;
-      uint8_t fl = P1_PASSED;
-      if (r.score >= 2000) fl |= P1_KEPT;
-      if (r.score > 2000) fl |= P1_STRAND_KNOWN;
-      if (start > end) fl |= P1_SPLIT;
-      rs.flags[i] = fl; rs.score[i] = r.score; rs.as[i] = as; rs.ae[i] = ae; rs.rc[i] = (uint8_t)r.strand; rs.status[i] = r.status;
-    }
+    if (lane == 0) pass1_store(rs, i, L, r.strand, r.score, r.abc, r.aec, r.status);
     wave.lds_fence();
   }
 }

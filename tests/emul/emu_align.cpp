@@ -182,3 +182,23 @@ extern "C" int emu_diag_filter(const uint8_t* ref_codes, int64_t n_codes, int re
   *delta = v.delta; *mismatches = v.mismatches;
   return won ? 1 : 0;
 }
+
+// The pass-1 form of the filter (both strands of the whole reference): returns K (0..2) with *strand / *delta when the
+// read is decided, -1 when it is left to the DP.
+extern "C" int emu_pass1_filter(const uint8_t* fw_codes, const uint8_t* rc_codes, int len1, const uint8_t* read_codes, int len2, int* strand,
+                                int* delta) {
+  using namespace mia;
+  const int64_t words = plane_words(len1);
+  std::vector<uint64_t> pl((size_t)words * 6);
+  for (int64_t w = 0; w < words; w++) {
+    plane_word(fw_codes, len1, w, &pl[(size_t)w], &pl[(size_t)(words + w)], &pl[(size_t)(2 * words + w)]);
+    plane_word(rc_codes, len1, w, &pl[(size_t)(3 * words + w)], &pl[(size_t)(4 * words + w)], &pl[(size_t)(5 * words + w)]);
+  }
+  std::vector<uint32_t> packed((size_t)(len2 / 8 + 2), 0);
+  uint8_t* pb = (uint8_t*)packed.data();
+  for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
+  RefPlanes fw{pl.data(), pl.data() + words, pl.data() + 2 * words}, rc{pl.data() + 3 * words, pl.data() + 4 * words, pl.data() + 5 * words};
+  const int k = pass1_step1(fw, rc, len1, pb, len2, strand, delta);
+  if (k == 2 && !pass1_step2(fw, rc, len1, pb, len2)) return -1;
+  return k;
+}

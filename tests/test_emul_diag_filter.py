@@ -147,3 +147,50 @@ def test_n_and_window_edges(emul, oracle, flat):
             continue
         check(emul, oracle, flat, ref, s, len1, read, stats)
     assert stats[1] > 150 and n_read_n > 100, stats
+
+
+def test_pass1_form_both_strands(emul, oracle, flat):
+    """pass 1: the read against every diagonal of both strands of a circular (wrapped) reference.  Whenever the filter
+    decides, the strand choice of sg_align (reverse on a tie), score and end points of the full DP must agree -- reads
+    from either strand, reads across the origin (seen twice, L columns apart: the first copy must win), palindromic
+    stretches (both strands equally good: never decided), repeats."""
+    from test_emul_pass1 import oracle_pass1, revcomp
+    rnd = random.Random(59)
+    decided = total = near_origin = 0
+    for rep in range(6):
+        L = rnd.choice([700, 900, 1300])
+        genome = "".join(rnd.choice("ACGT") for _ in range(L))
+        if rep % 2:
+            p = rnd.randrange(100, L - 200)          # a reverse-complement palindrome and a tandem repeat
+            half = genome[p:p + 40]
+            genome = genome[:p + 40] + revcomp(half) + genome[p + 80:]
+            q = rnd.randrange(0, 60)
+            genome = genome[:q] + ("ACG" * 30)[:70] + genome[q + 70:]
+        fw = genome + genome[:256]                   # add_ref_wrap
+        rc = revcomp(fw)
+        cf, cr = codes(fw), codes(rc)
+        for i in range(160):
+            len2 = rnd.choice([30, 50, 64, 65, 100, 130])
+            st = rnd.randrange(0, L) if i % 5 else rnd.choice([0, 1, 5, L - 40, L - 10, L - 1])
+            src = (genome + genome)[st:st + len2]
+            if i % 2:
+                src = revcomp(src)
+            k = rnd.choice([0, 0, 1, 2, 2, 3])
+            read = mutate(rnd, src, sorted(rnd.sample(range(len2), k)))
+            if i % 9 == 0:
+                p = rnd.randrange(5, len2 - 5)
+                read = read[:p] + read[p + 2:]        # a deletion: never decidable
+            c2 = codes(read)
+            strand, delta = C.c_int(0), C.c_int(0)
+            kk = emul.emu_pass1_filter(cf.ctypes.data_as(C.c_void_p), cr.ctypes.data_as(C.c_void_p), len(fw), c2.ctypes.data_as(C.c_void_p),
+                                       len(read), C.byref(strand), C.byref(delta))
+            total += 1
+            if kk < 0:
+                continue
+            decided += 1
+            near_origin += st < 256 or st > L - 130
+            exp, want_strand = oracle_pass1(oracle, fw, rc, read, flat, None, None)
+            e = exp[want_strand]
+            got = (strand.value, 200 * len(read) - 800 * kk, delta.value, delta.value + len(read) - 1, 0)
+            assert got == (want_strand, e.best, e.abc, e.aec, e.abr), (L, st, i, got, (want_strand, e.best, e.abc, e.aec, e.abr))
+    assert decided > 0.5 * total and near_origin > 30, (decided, total, near_origin)

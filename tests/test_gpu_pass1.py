@@ -83,3 +83,37 @@ def test_pass1_matches_oracle(name, oracle):
     assert n_kept == len(exp) and n_kept > 0
     hip.close()
     oracle.ora_free(st)
+
+
+def test_pass1_diag_filter_changes_nothing():
+    """unfiltered pass 1 (no k-mer mask, flat matrix): the diagonal filter decides most reads without the whole-reference
+    DP; a context with the filter switched off must return the same score / strand / as / ae / flags for every read --
+    reads from both strands, reads across the origin of the circular reference, reads with indels, reads with N, and a
+    reference with ambiguity codes (mt311) as well as a resolved one"""
+    import gen_data
+    import mia_amd
+    _, _, mt = gen_data.read_fasta_one(os.path.join(GOLDEN, "mt311.fa"))
+    indiv = gen_data.resolve_individual(mt)
+    n = 40_000
+    d = gen_data.make_reads(indiv, n, 100, seed=31, circular=True, sub_rate=0.012, indel_rate=0.002)
+    seq = d["reads"].copy()
+    rng = np.random.default_rng(5)
+    seq[rng.integers(0, n, 300), rng.integers(0, 100, 300)] = ord("N")
+    seq[:200] = gen_data.make_reads(indiv[-150:] + indiv[:150], 200, 100, seed=32, circular=False)["reads"]   # across the origin
+    offsets = np.arange(n + 1, dtype=np.int64) * 100
+    for ref, min_share in ((indiv, 0.6), (mt.upper(), 0.0)):
+        out = []
+        for off in (False, True):
+            if off:
+                os.environ["MIA_HIP_NO_DIAG_FILTER"] = "1"
+            try:
+                hip = mia_amd.MiaHip(0)
+            finally:
+                os.environ.pop("MIA_HIP_NO_DIAG_FILTER", None)
+            hip.set_pssm(mia_amd.flat_pssm())
+            out.append(hip.pass1(ref, True, seq.reshape(-1), offsets, -1))
+            decided = hip.pass1_filtered()
+            assert decided == 0 if off else decided >= min_share * n, decided
+            hip.close()
+        for x, y in zip(out[0], out[1]):
+            assert np.array_equal(x, y)
