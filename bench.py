@@ -33,16 +33,18 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BYTES_PER_READ = 182      # 50 B packed bases + 16 B meta in, 16 B result + 100 B script out
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# memory-side bytes per read of k_align_quad, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate
-# passes (profiles/r01/pmc/band_summary_kb_per_launch.json: 7.08e6 KB + 13.59e6 KB per 1 M-read launch, counters as
-# reported, no width correction): almost all of it is the trace band (16-bit cells, ~30 % of the lanes) going to the
-# per-workgroup slabs; the full byte trace cost 31.7e6 KB
-TRAFFIC_BYTES_PER_READ = (7078632 + 13590312) * 1024 / 1_000_000
-# the values-only first pass stores no trace: memory-side traffic is about twice the algorithmic 182 B/read
-PLAIN_TRAFFIC_BYTES_PER_READ = (117299.53 + 257620.02) * 1024 / 1_000_000   # profiles/r01/pmc/plain_pass_counters.json (FETCH_SIZE + WRITE_SIZE, KB per 1 M-read launch)
-PLAIN_VALU_UTILISATION_PMC = 0.95
-# SQ counters of the same kernel (profiles/r01/pmc/sq_counters_quad.json): the kernel is integer-VALU bound
-VALU_UTILISATION_PMC = 0.89
+# Memory-side bytes per read and VALU utilisation of the three realignment kernels, measured with rocprofv3 --pmc in
+# separate passes for FETCH_SIZE, WRITE_SIZE and the SQ set (profiles/r01/pmc/v14_summary.json; counters as reported, no
+# width correction; utilisation = SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 / 4)):
+#   k_align_quad        661 749 KB + 1 279 506 KB per launch of 95.4 k reads: the 16-bit trace band written to the
+#                       per-workgroup slabs and read back along the path
+#   k_align_quad_plain  111 680 KB + 252 604 KB per 1 M reads: no trace, about twice the algorithmic 182 B/read
+#   k_diag_filter       38 373 KB + 209 485 KB per 1 M reads: packed reads in, results and scripts out
+PMC = {
+    "k_align_quad": {"traffic_per_read": (661749.34 + 1279506.11) * 1024 / 95_407, "valu_utilisation": 0.79},
+    "k_align_quad_plain": {"traffic_per_read": (111680.25 + 252603.66) * 1024 / 1_000_000, "valu_utilisation": 0.90},
+    "k_diag_filter": {"traffic_per_read": (38372.81 + 209485.37) * 1024 / 1_000_000, "valu_utilisation": 0.51},
+}
 
 
 class DevArray:
@@ -217,18 +219,28 @@ def main():
     if rank == 0:
         total_reads = n * world
         value = total_reads * a.steps / dt
-        # Three stages share the realignment: the diagonal filter (k_diag_filter, bit-parallel, finishes the reads whose
-        # alignment is provably one gap-free diagonal), the values-only DP over the rest (k_align_quad_plain, the
-        # largest single kernel and the one the roofline object describes) and the trace kernel k_align_quad for the
-        # reads that really carry a gap.  MIA_HIP_NO_DIAG_FILTER=1 / MIA_HIP_NO_PLAIN=1 switch the first two off.
+        # Three kernels share the realignment: the diagonal filter (k_diag_filter, bit-parallel, finishes the reads whose
+        # alignment is provably one gap-free diagonal), the values-only DP (k_align_quad_plain) over the reads it left
+        # undecided, and the trace kernel k_align_quad for the reads that really carry a gap.  The roofline object describes
+        # whichever takes the most time per step; all three are listed under "stages".  MIA_HIP_NO_DIAG_FILTER=1 /
+        # MIA_HIP_NO_PLAIN=1 switch the first two off.
+        stages = []
+
+        def stage(name, ms_total, k_launches, reads_total):
+            if k_launches <= 0 or ms_total <= 0:
+                return
+            k_ms, rpl = ms_total / k_launches, reads_total / k_launches
+            ach = BYTES_PER_READ * rpl / (k_ms * 1e-3) / 1e9
+            stages.append({"kernel": name, "kernel_ms": k_ms, "ms_per_step": ms_total / a.steps, "launches": k_launches,
+                           "reads_per_launch": rpl, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                           "traffic": PMC[name]["traffic_per_read"] * rpl, "valu_utilisation": PMC[name]["valu_utilisation"],
+                           "gcups": rpl * 100 * 200 / (k_ms * 1e-3) / 1e9 if name != "k_diag_filter" else None})
+
         plain_on = plain_launches > 0
-        if plain_on:
-            dom_name, k_ms, dom_launches = "k_align_quad_plain", plain_ms / plain_launches, plain_launches
-            reads_per_launch = plain_in / plain_launches
-        else:
-            dom_name, k_ms, dom_launches = "k_align_quad", align_ms / max(launches, 1), launches
-            reads_per_launch = n * a.steps / max(launches, 1)
-        achieved = BYTES_PER_READ * reads_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        stage("k_diag_filter", filt_ms, filt_launches, filt_seen)
+        stage("k_align_quad_plain", plain_ms, plain_launches, plain_in)
+        stage("k_align_quad", align_ms, launches, plain_retried if plain_on else n * a.steps)
+        dom = max(stages, key=lambda st: st["ms_per_step"])
         out = {
             "metric": "reads aligned/sec per iteration (16.5kb mito ref, 100bp reads)",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -237,21 +249,15 @@ def main():
             "config": {"workload": "configs[1]: %d synthetic 100 bp reads per GPU vs mt311 (16619 bp, circular), flat matrix; "
                                    "step = reiterate_assembly + cull + consensus; pass-1 coordinates = true positions" % n,
                        "reads_per_gpu": n, "consensus_len": len(cur)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (PLAIN_TRAFFIC_BYTES_PER_READ * reads_per_launch if PLAIN_TRAFFIC_BYTES_PER_READ else None) if plain_on
-                         else TRAFFIC_BYTES_PER_READ * reads_per_launch,
-                         "kernel": dom_name, "kernel_ms": k_ms, "launches": dom_launches,
-                         "trace_kernel": {"kernel": "k_align_quad", "ms_per_step": align_ms / a.steps, "launches": launches,
-                                          "reads_frac_of_all": (plain_retried / (n * a.steps)) if plain_on else 1.0},
-                         "filter_kernel": {"kernel": "k_diag_filter", "kernel_ms": filt_ms / filt_launches, "launches": filt_launches,
-                                           "reads_finished_frac": filt_done / filt_seen if filt_seen else 0.0,
-                                           "achieved_GBs": BYTES_PER_READ * (filt_seen / filt_launches) / (filt_ms / filt_launches * 1e-3) / 1e9,
-                                           "frac_of_hbm_peak": BYTES_PER_READ * (filt_seen / filt_launches) / (filt_ms / filt_launches * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                         if filt_launches else None,
-                         "note": "integer-VALU-bound DP (SQ_ACTIVE_INST_VALU = 95 % of SIMD capacity for the values-only pass, 89 % for the trace kernel; profiles/r01/pmc): 182 algorithmic HBM bytes per read (SURVEY 8d) put it at a fraction of a percent of the HBM roof by construction; see DESIGN.md 3.1",
-                         "valu_utilisation": PLAIN_VALU_UTILISATION_PMC if plain_on else VALU_UTILISATION_PMC,
-                         "gcups": reads_per_launch * 100 * 200 / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0},
+            "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
+                         "traffic": dom["traffic"], "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "launches": dom["launches"],
+                         "valu_utilisation": dom["valu_utilisation"],
+                         "stages": stages,
+                         "reads_finished_by_filter_frac": filt_done / filt_seen if filt_seen else 0.0,
+                         "reads_to_trace_kernel_frac": (plain_retried / (n * a.steps)) if plain_on else 1.0,
+                         "note": "the DP kernels are integer-VALU bound (SQ_ACTIVE_INST_VALU 79-90 % of SIMD capacity, profiles/r01/pmc): "
+                                 "182 algorithmic HBM bytes per read (SURVEY 8d) put them at a fraction of a percent of the HBM roof "
+                                 "by construction; the trace kernel moves ~21 KB/read of trace band on top; see DESIGN.md 3.0-3.1"},
         }
         # pass 1 (new_kmer_filter + sg_align over the whole wrapped reference, both strands), reported separately
         import gen_data
