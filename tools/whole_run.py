@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--kmer", type=int, default=0)
     ap.add_argument("--keep", default=None)
     ap.add_argument("--skip-reference", action="store_true")
+    ap.add_argument("--plain-ref", action="store_true", help="reference = mt311 with its ambiguity codes resolved (the usual kind of "
+                    "reference; lets the diagonal filter of pass 1 work)")
     ap.add_argument("--ccheck", action="store_true", help="also run ccheck (reference and ccheck_hip) on the final .maln")
     a = ap.parse_args()
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mia")
@@ -32,11 +34,18 @@ def main():
     reads = os.path.join(work, "reads.fa")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_data.py"), "--ref", os.path.join(GOLDEN, "mt311.fa"),
                     "--out", reads, "-n", str(a.n), "--len", "100", "--seed", "7"], check=True)
-    args = ["-r", os.path.join(GOLDEN, "mt311.fa"), "-f", reads, "-c"]
+    ref_fa = os.path.join(GOLDEN, "mt311.fa")
+    if a.plain_ref:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import gen_data
+        _, _, mt = gen_data.read_fasta_one(ref_fa)
+        ref_fa = os.path.join(work, "plain_ref.fa")
+        gen_data.write_fasta(ref_fa, "mt311_resolved", gen_data.resolve_individual(mt, seed=99))   # not the reads' own individual
+    args = ["-r", ref_fa, "-f", reads, "-c"]
     if a.kmer > 0:
         args += ["-k", str(a.kmer)]
     env = dict(os.environ, MIA_DATA_PATH=GOLDEN)
-    out = {"reads": a.n, "kmer": a.kmer}
+    out = {"reads": a.n, "kmer": a.kmer, "plain_ref": bool(a.plain_ref)}
     runs = [("mia_hip", hip_bin)] + ([] if a.skip_reference else [("reference", ref_bin)])
     for label, exe in runs:
         root = os.path.join(work, label)
