@@ -1177,13 +1177,15 @@ extern "C" int mia_hip_trim(mia_hip_ctx* ctx, const char* adapter, int64_t n, co
   uint32_t* d_status = nullptr;
   unsigned char* d_slabs = nullptr;
   int16_t* d_cols = nullptr;
+  ScopeFree guard;   // every temporary is released on any return
+  for (void** pp : {(void**)&d_codes, (void**)&d_ap, (void**)&d_ac, (void**)&d_trimmed, (void**)&d_off, (void**)&d_flat, (void**)&d_tp,
+                    (void**)&d_list, (void**)&d_scratch, (void**)&d_status, (void**)&d_slabs, (void**)&d_cols})
+    guard.watch(pp);
   int rcx = dev_alloc(ctx, &d_codes, (size_t)chars + 8) | dev_alloc(ctx, &d_ap, apacked.size()) | dev_alloc(ctx, &d_ac, (size_t)len2) |
             dev_alloc(ctx, &d_trimmed, (size_t)n) | dev_alloc(ctx, &d_off, (size_t)n + 1) | dev_alloc(ctx, &d_flat, (size_t)PSSM_WORDS) |
             dev_alloc(ctx, &d_tp, (size_t)n) | dev_alloc(ctx, &d_status, (size_t)n) | dev_alloc(ctx, &d_slabs, (size_t)(slab * grid)) |
             dev_alloc(ctx, &d_cols, (size_t)(grid * MAX_READ));
-  std::vector<void*> tmp = {d_codes, d_ap, d_ac, d_trimmed, d_off, d_flat, d_tp, d_status, d_slabs, d_cols};
-  auto cleanup = [&]() { for (void* p : tmp) if (p) (void)hipFree(p); };
-  if (rcx) { cleanup(); return MIA_HIP_ERR_NOMEM; }
+  if (rcx) return MIA_HIP_ERR_NOMEM;
   hipError_t e = hipSuccess;
   auto up = [&](void* d, const void* h, size_t b) { if (e == hipSuccess && b) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
   up(d_codes, codes.data(), (size_t)chars); up(d_ap, apacked.data(), apacked.size()); up(d_ac, acodes.data(), (size_t)len2);
@@ -1202,10 +1204,7 @@ extern "C" int mia_hip_trim(mia_hip_ctx* ctx, const char* adapter, int64_t n, co
     for (int64_t i = 0; i < n; i++) if (status[(size_t)i] != ST_OK) esc.push_back((int32_t)i);
   if (e == hipSuccess && !esc.empty()) {
     const int64_t words = (int64_t)len2 * MAX_READ + 5 * (int64_t)MAX_READ;
-    if (dev_alloc(ctx, &d_list, esc.size()) || dev_alloc(ctx, &d_scratch, (size_t)(words * (int64_t)esc.size()))) {
-      tmp.push_back(d_list); tmp.push_back(d_scratch); cleanup(); return MIA_HIP_ERR_NOMEM;
-    }
-    tmp.push_back(d_list); tmp.push_back(d_scratch);
+    if (dev_alloc(ctx, &d_list, esc.size()) || dev_alloc(ctx, &d_scratch, (size_t)(words * (int64_t)esc.size()))) return MIA_HIP_ERR_NOMEM;
     up(d_list, esc.data(), esc.size() * 4);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_trim_wide, dim3((unsigned)((esc.size() + 63) / 64)), dim3(64), 0, ctx->stream, tr, d_ac, len2, d_flat, d_list,
@@ -1216,7 +1215,6 @@ extern "C" int mia_hip_trim(mia_hip_ctx* ctx, const char* adapter, int64_t n, co
   if (e == hipSuccess) e = hipMemcpyAsync(trimmed, d_trimmed, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(trim_point, d_tp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  cleanup();
   if (e != hipSuccess) { ctx->err = std::string("trim: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   ctx->trim_escapes = (int64_t)esc.size();
   return MIA_HIP_OK;
@@ -1262,12 +1260,14 @@ extern "C" int mia_hip_ma_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_t
   uint8_t* d_rev = nullptr;
   int64_t *d_coff = nullptr, *d_ioff = nullptr;
   char *d_seq = nullptr, *d_smp = nullptr, *d_ib = nullptr;
+  ScopeFree guard;   // every temporary is released on any return
+  for (void** pp : {(void**)&d_start, (void**)&d_rev, (void**)&d_coff, (void**)&d_seq, (void**)&d_smp, (void**)&d_irec, (void**)&d_ipos,
+                    (void**)&d_ioff, (void**)&d_ib})
+    guard.watch(pp);
   int rcx = dev_alloc(ctx, &d_start, (size_t)n + 1) | dev_alloc(ctx, &d_rev, (size_t)n + 1) | dev_alloc(ctx, &d_coff, (size_t)n + 1) |
             dev_alloc(ctx, &d_seq, (size_t)chars + 1) | dev_alloc(ctx, &d_smp, (size_t)chars + 1) | dev_alloc(ctx, &d_irec, (size_t)n_ins + 1) |
             dev_alloc(ctx, &d_ipos, (size_t)n_ins + 1) | dev_alloc(ctx, &d_ioff, (size_t)n_ins + 1) | dev_alloc(ctx, &d_ib, (size_t)ins_chars + 1);
-  void* tmp[] = {d_start, d_rev, d_coff, d_seq, d_smp, d_irec, d_ipos, d_ioff, d_ib};
-  auto cleanup = [&]() { for (void* p : tmp) if (p) (void)hipFree(p); };
-  if (rcx) { cleanup(); return MIA_HIP_ERR_NOMEM; }
+  if (rcx) return MIA_HIP_ERR_NOMEM;
   hipError_t e = hipSuccess;
   auto up = [&](void* d, const void* h, size_t b) { if (e == hipSuccess && b) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
   auto zero = [&](void* d, size_t b) { if (e == hipSuccess) e = hipMemsetAsync(d, 0, b, ctx->stream); };
@@ -1291,7 +1291,6 @@ extern "C" int mia_hip_ma_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_t
   if (e == hipSuccess) e = hipMemcpyAsync(&ctx->n_events_host, ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(&flags, ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  cleanup();
   if (e != hipSuccess) { ctx->err = std::string("ma_tally: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   if (flags & 1u) { ctx->err = "insert event list overflow"; return MIA_HIP_ERR_NOMEM; }
   if (flags & 2u) { ctx->err = "a record reaches past the reference or carries a depth code outside A.._"; return MIA_HIP_ERR_ARG; }
