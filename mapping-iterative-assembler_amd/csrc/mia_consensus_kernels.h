@@ -348,9 +348,13 @@ template <bool BINNED>
 __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSet& rs, const RefInfo& ref, const int32_t* pssm2,
                                                const uint8_t* drop_front, const uint8_t* drop_back, const TallyBuf& tb,
                                                int32_t* lds, int win_base, const int32_t* rec_params, const int32_t* rec_actf,
-                                               const int16_t* pssm_lds, unsigned long long* ev_buf, int* ev_cnt) {
-  // one 64-byte record per read (wave-uniform address: scalar loads)
-  const int32_t* tr = rec_params + i * 16;
+                                               const int16_t* pssm_lds, unsigned long long* ev_buf, int* ev_cnt, int32_t* n_cnt = nullptr,
+                                               const int32_t* rec_lds = nullptr) {
+  // n_cnt != nullptr (binned tally, matrix independent of depth and strand): the four score words of a column are a
+  // linear function of its base counts; the LDS window then only counts (N in n_cnt) and the flush derives the scores.
+  // rec_lds != nullptr: the read's 64-byte record, staged in LDS by the lane that already holds it (a scalar load
+  // from global memory here costs a microsecond per read, and these reads are taken one after the other).
+  const int32_t* tr = rec_lds ? rec_lds : rec_params + i * 16;
   const int flags = tr[TREC_FLAGS];
   if (!(flags & TRF_SK)) return;
   if (flags & TRF_TOO_LONG) { if (lane == 0) atomicOr(tb.flags, 2u); return; }
@@ -396,22 +400,26 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
     // Two copies of the same adds, one per address space: a pointer chosen at run time would turn every one of them
     // into a FLAT atomic, which is several times slower on LDS than ds_add.
     auto aadd = [](auto* q, int v) { (void)__hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto add_all = [&](auto* t, const int ws) {
+    auto add_all = [&](auto* t, const int ws, auto* ncount) {
       if (!dropped) {                                      // src/mia.c:580-582
         aadd(&t[T_COV * ws], mult);
         if (code == 5) aadd(&t[T_GAP * ws], mult);
         else {
           if (code < 4) aadd(&t[(T_A + code) * ws], mult);
-          aadd(&t[T_SA * ws], mult * s0);
-          aadd(&t[T_SC * ws], mult * s1);
-          aadd(&t[T_SG * ws], mult * s2);
-          aadd(&t[T_ST * ws], mult * s3);
+          else if (ncount) aadd(ncount, mult);
+          if (!ncount) {
+            aadd(&t[T_SA * ws], mult * s0);
+            aadd(&t[T_SC * ws], mult * s1);
+            aadd(&t[T_SG * ws], mult * s2);
+            aadd(&t[T_ST * ws], mult * s3);
+          }
         }
       }
       if (p > 0) aadd(&t[T_SPAN * ws], mult);         // start < pos <= end (src/map_align.c:466-469), dropped or not
     };
-    if (in_lds) add_all((__attribute__((address_space(3))) int32_t*)lds + wc, TALLY_WIN);
-    else add_all(tb.tally + gc, Lp);
+    typedef __attribute__((address_space(3))) int32_t lds_word;
+    if (in_lds) add_all((lds_word*)lds + wc, TALLY_WIN, n_cnt ? (lds_word*)n_cnt + wc : (lds_word*)nullptr);
+    else add_all(tb.tally + gc, Lp, (int32_t*)nullptr);
   };
 
   for (int r0 = abr; r0 < len2; r0 += 64) {
@@ -509,8 +517,13 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
 __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
-                                                       const int32_t* rec_actf, int32_t* slabs, uint32_t dbg) {
+                                                       const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, int32_t linear) {
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
+  // linear: the matrix does not depend on depth or strand (the flat matrix), so scoreX(column) = sum_b count_b * sm[X][b].
+  // The window then takes ONE LDS atomic per base (its count; N in n_cnt) instead of five, and the four score rows are
+  // filled in from the counts when the window is flushed.  Same integer sums.
+  __shared__ int32_t n_cnt[TALLY_WIN];
+  __shared__ int32_t rec_stage[4][16];                       // one 64-byte read record per wavefront (see tally_one_read)
   __shared__ int16_t pssm_lds[2 * PSSM_WORDS];               // both matrices: every aligned base looks four entries up
   // LDS atomics are the limit of this kernel (~1.4 lane-atomics per cycle and CU, whatever the addresses).  Coverage
   // and span of a gap-free record are range counts: +1 / -1 at the two ends of a difference array instead of one
@@ -527,7 +540,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   const int win_base = b * TALLY_BUCKET;
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) lds[k] = 0;
   for (int k = threadIdx.x; k < 2 * PSSM_WORDS; k += blockDim.x) pssm_lds[k] = (int16_t)pssm2[k];
-  for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { cov_diff[k] = 0; span_diff[k] = 0; }
+  for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { cov_diff[k] = 0; span_diff[k] = 0; n_cnt[k] = 0; }
   if (threadIdx.x == 0) ev_cnt = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -539,6 +552,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   typedef __attribute__((address_space(3))) int32_t lds_i32;
   auto aadd = [](lds_i32* q, int v) { (void)__hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   const int L = ref.L, Lp = tb.Lp;
+  int warm = 0;
   for (int k0 = first; k0 < last; k0 += 256) {
     const int k = k0 + (int)threadIdx.x;
     const bool have = k < last;
@@ -561,6 +575,21 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
         lds_i32* t = (lds_i32*)lds + w0;
         uint32_t word = 0;
         int bad = 0;
+        if (linear) {
+          // depth codes are not needed for the sums; they only have to be valid: act <= 15 always is, beyond that
+          // dfb = fB - act - 1 must not be negative (depth_code above)
+          bad = n_al > PSSM_DEPTH + 1 && fB < n_al;
+          if (!dF) {
+            lds_i32* nc = (lds_i32*)n_cnt + w0;
+            for (int act = 0; act < n_al; act++) {
+              const int r = abr + act;
+              if (act == 0 || (r & 7) == 0) word = rp[r >> 3];
+              const int code = (int)((word >> ((r & 7) * 4)) & 15u);
+              if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1); else aadd(nc, 1);
+              t++; nc++;
+            }
+          }
+        } else
         for (int act = 0; act < n_al; act++) {
           const int r = abr + act;
           if (act == 0 || (r & 7) == 0) word = rp[r >> 3];
@@ -584,14 +613,37 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
         if (bad | (int)(word & (dbg & 16u ? 0x40000000u : 0u))) atomicOr(tb.flags, 2u);
       }
     }
-    unsigned long long todo = __ballot(have && !fast);
+    // The reads left over are taken one per wavefront and one after the other; each begins with loads of its record,
+    // script and bases.  The record is already in the registers of the lane that owns the read and is handed over
+    // through LDS; script and bases are touched by all owning lanes first, side by side, so that the serial part finds
+    // them in L2.
+    int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+    if (have && !fast) {
+      const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16);
+      r0 = tr4[0]; r1 = tr4[1]; r2 = tr4[2]; r3 = tr4[3];
+      const int16_t* cl = rs.cols + (int64_t)i * rs.stride;
+      const uint32_t* rp0 = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)r1.y);
+      const int n2 = r0.z & 0xFFFF;
+      warm += (int)cl[0] + (int)cl[n2 > 64 ? 64 : 0] + (int)cl[n2 > 128 ? 128 : 0] + (int)cl[n2 > 192 ? 192 : 0] + (int)rp0[0] +
+              (int)rp0[n2 > 128 ? 16 : 0];
+    }
+    unsigned long long todo = __ballot(have && !fast && !(dbg & 32u));
     while (todo) {
       const int l = __builtin_ctzll(todo);
       todo &= todo - 1;
       const int ii = __shfl(i, l);
-      tally_one_read<true>(__builtin_amdgcn_readfirstlane(ii), lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base, rec_params, rec_actf, pssm_lds, ev_buf, &ev_cnt);
+      if (lane == l) {
+        int4* st = reinterpret_cast<int4*>(rec_stage[wv]);
+        st[0] = r0; st[1] = r1; st[2] = r2; st[3] = r3;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the record is in LDS before anyone reads it (one wavefront)
+      __builtin_amdgcn_wave_barrier();
+      tally_one_read<true>(__builtin_amdgcn_readfirstlane(ii), lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base, rec_params, rec_actf, pssm_lds, ev_buf, &ev_cnt,
+                           linear ? n_cnt : nullptr, rec_stage[wv]);
+      __builtin_amdgcn_wave_barrier();
     }
   }
+  if (warm == 0x7FFFFFF1) atomicOr(tb.flags, 4u);   // keeps the warming loads alive; never true for real data
   __syncthreads();
   // The window goes to this workgroup's slab with plain stores; k_tally_reduce adds the slabs up.  (Flushing with
   // global atomics cost more than the tally itself: ~9 M device-scope atomics per 1 M reads, and the eight XCDs
@@ -613,6 +665,20 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
     __syncthreads();
   }
   for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { lds[T_COV * TALLY_WIN + k] += cov_diff[k]; lds[T_SPAN * TALLY_WIN + k] += span_diff[k]; }
+  if (linear) {
+    // the score rows from the counts: sm[X][b] of depth 0, forward table (src/map_align.c:258-261 adds sm[d][X][b] per base)
+    for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) {
+      int c[5];
+      for (int b5 = 0; b5 < 4; b5++) c[b5] = lds[(T_A + b5) * TALLY_WIN + k];
+      c[4] = n_cnt[k];
+      const int rows[4] = {T_SA, T_SC, T_SG, T_ST};
+      for (int x = 0; x < 4; x++) {
+        int acc = 0;
+        for (int b5 = 0; b5 < 5; b5++) acc += c[b5] * (int)pssm_lds[x * 5 + b5];
+        lds[rows[x] * TALLY_WIN + k] += acc;
+      }
+    }
+  }
   __syncthreads();
   int32_t* slab = slabs + (int64_t)blockIdx.x * ((TALLY_WORDS - 1) * TALLY_WIN);
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) slab[k] = lds[k];

@@ -74,6 +74,7 @@ struct mia_hip_ctx {
   int use_plain = 1;  // MIA_HIP_NO_PLAIN=1: no values-only first pass, every quad goes straight to the trace kernel
   double plain_ms = 0; int64_t plain_launches = 0; int64_t plain_retried = 0, plain_total = 0;
   // the diagonal filter (diag_filter.h): flat matrix only
+  bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
   bool flat = false; int use_filter = 1;   // MIA_HIP_NO_DIAG_FILTER=1 sends every read to the DP kernels
   uint64_t* d_planes = nullptr; int64_t plane_cap = 0;   // lo | hi | ok, plane_cap words each
   uint32_t* d_filter_n = nullptr; int64_t filter_proven = 0, filter_seen = 0;
@@ -218,6 +219,14 @@ extern "C" int mia_hip_set_pssm(mia_hip_ctx* ctx, const int32_t* fwd, const int3
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->have_pssm = true;
   ctx->flat = pssm_is_flat(fwd, rc);
+  // the score words of a column are linear in its base counts iff sm[d][X][b] (X = A,C,G,T; src/map_align.c:258-261)
+  // depends neither on the depth nor on the strand: k_tally_binned then counts only and derives the scores
+  ctx->tally_linear = true;
+  for (int d = 0; d < 2 * PSSM_DEPTH + 1; d++)
+    for (int x = 0; x < 4; x++)
+      for (int b = 0; b < 5; b++)
+        if (fwd[(d * 5 + x) * 5 + b] != fwd[x * 5 + b] || rc[(d * 5 + x) * 5 + b] != fwd[x * 5 + b]) ctx->tally_linear = false;
+  if (const char* nl = getenv("MIA_HIP_NO_LINEAR_TALLY")) if (atoi(nl)) ctx->tally_linear = false;
   return MIA_HIP_OK;
 }
 
@@ -1026,7 +1035,7 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
         ctx->tally_slab_cap = slab_words;
       }
       hipLaunchKernelGGL(k_tally_binned, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
-                         ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg);
+                         ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg, ctx->tally_linear ? 1 : 0);
       hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
