@@ -88,8 +88,8 @@ def test_pass1_matches_oracle(name, oracle):
 def test_pass1_diag_filter_changes_nothing():
     """unfiltered pass 1 (no k-mer mask, flat matrix): the diagonal filter decides most reads without the whole-reference
     DP; a context with the filter switched off must return the same score / strand / as / ae / flags for every read --
-    reads from both strands, reads across the origin of the circular reference, reads with indels, reads with N, and a
-    reference with ambiguity codes (mt311) as well as a resolved one"""
+    reads from both strands, reads across the origin of the circular reference, reads with indels, reads with N, a
+    reference with ambiguity codes (mt311) as well as a resolved one, and a linear reference that holds only half of the reads"""
     import gen_data
     import mia_amd
     _, _, mt = gen_data.read_fasta_one(os.path.join(GOLDEN, "mt311.fa"))
@@ -101,7 +101,7 @@ def test_pass1_diag_filter_changes_nothing():
     seq[rng.integers(0, n, 300), rng.integers(0, 100, 300)] = ord("N")
     seq[:200] = gen_data.make_reads(indiv[-150:] + indiv[:150], 200, 100, seed=32, circular=False)["reads"]   # across the origin
     offsets = np.arange(n + 1, dtype=np.int64) * 100
-    for ref, min_share in ((indiv, 0.6), (mt.upper(), 0.0)):
+    for ref, circular, min_share in ((indiv, True, 0.6), (mt.upper(), True, 0.0), (indiv[:9000], False, 0.25)):
         out = []
         for off in (False, True):
             if off:
@@ -111,7 +111,7 @@ def test_pass1_diag_filter_changes_nothing():
             finally:
                 os.environ.pop("MIA_HIP_NO_DIAG_FILTER", None)
             hip.set_pssm(mia_amd.flat_pssm())
-            out.append(hip.pass1(ref, True, seq.reshape(-1), offsets, -1))
+            out.append(hip.pass1(ref, circular, seq.reshape(-1), offsets, -1))
             decided = hip.pass1_filtered()
             assert decided == 0 if off else decided >= min_share * n, decided
             hip.close()
