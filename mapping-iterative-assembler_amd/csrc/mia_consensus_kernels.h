@@ -87,6 +87,10 @@ __global__ void k_scan_apply(ReadSet rs, int32_t L, const int64_t* partial, int6
   }
 }
 
+__global__ void k_score_sums_init(unsigned long long* sums) {   // the neutral element of k_score_sums' five accumulators
+  if (threadIdx.x == 0) { sums[0] = 0; sums[1] = 0; sums[2] = 0; sums[3] = (unsigned long long)(long long)INT32_MAX; sums[4] = (unsigned long long)(long long)INT32_MIN; }
+}
+
 // ---- first pass of find_fsdb_score_cut (src/fsdb.c:269-383) on the device: the sums of length and score over the reads
 // the regression uses (unique_best, score >= 2000) are sums of integers -- exact in any order -- plus the length range.
 // out: {sum len, sum score, count, min len, max len}
@@ -786,14 +790,16 @@ __global__ __launch_bounds__(1024) void k_gap_offsets(const int32_t* gaps, int32
   for (int p = lo; p < hi; p++) { ins_off[p] = run; if (p > 0 && p < L) run += gaps[p]; }
   if (t == 1023) *total = sh[1023];
 }
+// cap: slots the insert buffers hold.  The host launches with the capacity left from the last call and reads the real total
+// back with the results; only if the total outgrew the capacity does it enlarge the buffers and run the insert part again.
 __global__ void k_ins_tally(const uint64_t* events, int32_t n_events, const int32_t* pssm2, const int32_t* ins_off,
-                            const int32_t* gaps, int32_t L, int32_t* ins_tally) {
+                            const int32_t* gaps, int32_t L, int32_t* ins_tally, int32_t cap) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_events) return;
   const uint64_t ev = events[e];
   const int gc = (int)(uint32_t)ev, j = (int)((ev >> 32) & 1023), code = (int)((ev >> 42) & 7), d = (int)((ev >> 45) & 31);
   const int rc = (int)((ev >> 50) & 1);
-  if (gc <= 0 || gc >= L || j >= gaps[gc]) return;
+  if (gc <= 0 || gc >= L || j >= gaps[gc] || ins_off[gc] + j >= cap) return;
   int32_t* t = ins_tally + (int64_t)(ins_off[gc] + j) * 9;
   const int32_t* row = pssm2 + (rc ? PSSM_WORDS : 0) + d * 25 + code;
   if (code < 4) atomicAdd(&t[code], 1);
@@ -827,11 +833,11 @@ __global__ void k_call_columns(const int32_t* tally, int32_t Lp, int32_t L, int 
                        tally[T_SG * Lp + p], tally[T_ST * Lp + p], cons_code);
 }
 __global__ void k_call_inserts(const int32_t* tally, int32_t Lp, int32_t L, const int32_t* gaps, const int32_t* ins_off,
-                               const int32_t* ins_tally, int cons_code, char* ins_calls) {
+                               const int32_t* ins_tally, int cons_code, char* ins_calls, int32_t cap) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p <= 0 || p >= L) return;
   const int span = tally[T_SPAN * Lp + p];
-  for (int j = 0; j < gaps[p]; j++) {
+  for (int j = 0; j < gaps[p] && ins_off[p] + j < cap; j++) {
     const int32_t* t = ins_tally + (int64_t)(ins_off[p] + j) * 9;
     ins_calls[ins_off[p] + j] = call_base(t[0], t[1], t[2], t[3], span - t[4], span, t[5], t[6], t[7], t[8], cons_code);
   }

@@ -91,6 +91,8 @@ struct mia_hip_ctx {
   // timing
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free, ev_plain, ev_filter;
   double filter_ms = 0; int64_t filter_launches = 0;
+  // pinned staging: small copies to and from pageable memory wait for the stream, pinned ones do not
+  unsigned char* h_pin = nullptr; static constexpr size_t PIN_BYTES = 1 << 20, PIN_MISC = 64 << 10;
   double align_ms = 0; int64_t align_launches = 0;
   double pass1_ms = 0; int64_t pass1_filtered = 0;   // reads of the last pass-1 call that the diagonal filter decided
   bool consensus_done = false;
@@ -166,6 +168,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     delete ctx;
     return MIA_HIP_ERR_NOMEM;
   }
+  if (hipHostMalloc((void**)&ctx->h_pin, mia_hip_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
   *out = ctx;
   return MIA_HIP_OK;
 }
@@ -184,6 +187,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
+  if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_plain) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -449,7 +453,13 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     if (dev_alloc(ctx, &ctx->d_ref, codes.size() * 2)) return MIA_HIP_ERR_NOMEM;
     ctx->ref_cap = (int)codes.size() * 2;
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_ref, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->h_pin && codes.size() <= mia_hip_ctx::PIN_BYTES - mia_hip_ctx::PIN_MISC) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));             // the staging area may still feed an earlier copy
+    memcpy(ctx->h_pin + mia_hip_ctx::PIN_MISC, codes.data(), codes.size());
+    HIPCHK(hipMemcpyAsync(ctx->d_ref, ctx->h_pin + mia_hip_ctx::PIN_MISC, codes.size(), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->d_ref, codes.data(), codes.size(), hipMemcpyHostToDevice, ctx->stream));
+  }
   ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true; ctx->explicit_win = 0;
   return align_all(ctx);
 }
@@ -490,10 +500,16 @@ static int align_all(mia_hip_ctx* ctx) {
     HIPCHK(hipGetLastError());
   }
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && ctx->use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
-  if (filtered) HIPCHK(hipMemcpyAsync(&h_filter_n, ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
-  int32_t h_count[N_BINS], h_off[N_BINS];
-  HIPCHK(hipMemcpyAsync(h_count, d_count, sizeof h_count, hipMemcpyDeviceToHost, ctx->stream));
+  // host copies of the counters live in pinned memory when there is some: a copy to or from pageable memory makes the
+  // host wait for the stream even when it is called "async"
+  int32_t local_buf[4 * N_BINS + 16];
+  int32_t* hb = ctx->h_pin ? reinterpret_cast<int32_t*>(ctx->h_pin) : local_buf;
+  int32_t *h_count = hb, *h_off = hb + N_BINS, *h_count2 = hb + 2 * N_BINS, *h_off2 = hb + 3 * N_BINS, *h_misc = hb + 4 * N_BINS;
+  h_misc[0] = 0;
+  if (filtered) HIPCHK(hipMemcpyAsync(&h_misc[0], ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(h_count, d_count, (size_t)N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  h_filter_n = (uint32_t)h_misc[0];
   ctx->filter_proven += h_filter_n;
   ctx->filter_seen += n;
   int run = 0;
@@ -503,7 +519,7 @@ static int align_all(mia_hip_ctx* ctx) {
   }
   const int quad_begin = h_off[BIN_QUAD0], n_quads = (run - quad_begin) / 4;
   if (n_quads > 0) HIPCHK(hipMemsetAsync(ctx->d_list + quad_begin, 0xFF, (size_t)(run - quad_begin) * 4, ctx->stream));   // -1 = empty slot
-  HIPCHK(hipMemcpyAsync(d_off, h_off, sizeof h_off, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(d_off, h_off, (size_t)N_BINS * 4, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
   // reads that need the exact kernel from the start: copy their list to the head of wide_list
   const int n_wide0 = h_count[BIN_WIDE];
@@ -519,6 +535,7 @@ static int align_all(mia_hip_ctx* ctx) {
     if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   }
   int n_quads_trace = n_quads, quad_begin_trace = quad_begin;
+  bool wide_known = false;
   if ((n_quads > 0 || filtered) && ctx->use_plain) {
     // first pass: values only; reads whose alignment is provably the pure diagonal are finished there
     if (n_quads > 0) {
@@ -538,8 +555,7 @@ static int align_all(mia_hip_ctx* ctx) {
     HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ctx->stream));
     hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_count);
-    int32_t h_count2[N_BINS], h_off2[N_BINS];
-    HIPCHK(hipMemcpyAsync(h_count2, d_count, sizeof h_count2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_count2, d_count, (size_t)N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     int run2 = 0;
     for (int b = 0; b < N_BINS; b++) { h_off2[b] = run2; run2 += b >= BIN_QUAD0 ? ((h_count2[b] + 3) & ~3) : 0; }
@@ -549,7 +565,7 @@ static int align_all(mia_hip_ctx* ctx) {
     for (int b = BIN_QUAD0; b < N_BINS; b++) ctx->plain_retried += h_count2[b];
     if (n_quads_trace > 0) {
       HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, (size_t)run2 * 4, ctx->stream));
-      HIPCHK(hipMemcpyAsync(d_off, h_off2, sizeof h_off2, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d_off, h_off2, (size_t)N_BINS * 4, hipMemcpyHostToDevice, ctx->stream));
       hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
     }
   }
@@ -569,19 +585,24 @@ static int align_all(mia_hip_ctx* ctx) {
     HIPCHK(hipGetLastError());
     if (ctx->use_band) {
       // reads whose path left the stored trace band: one-read kernel with the full trace (windows <= 208 fit class 0)
-      int32_t n_retry = 0;
-      HIPCHK(hipMemcpyAsync(&n_retry, d_retry_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+      // (the two counters sit side by side: one copy, one wait; the wide count is final unless the retry kernel runs)
+      HIPCHK(hipMemcpyAsync(&h_misc[2], d_wide_count, 8, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
+      const int32_t n_retry = h_misc[3];
       if (n_retry > 0) {
         hipError_t e = launch_window<4>(ctx, 0, ctx->d_retry_list, n_retry);
         if (e != hipSuccess) { ctx->err = std::string("k_align_window retry launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+      } else {
+        wide_known = true;
       }
     }
   }
   // exact kernel for whole-reference windows and escaped reads
-  int32_t n_wide = 0;
-  HIPCHK(hipMemcpyAsync(&n_wide, d_wide_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (!wide_known) {
+    HIPCHK(hipMemcpyAsync(&h_misc[2], d_wide_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  const int32_t n_wide = h_misc[2];
   if (n_wide > 0) {
     std::vector<int32_t> wl((size_t)n_wide), as((size_t)n_wide), ae((size_t)n_wide);
     std::vector<uint16_t> ln((size_t)n_wide);
@@ -924,16 +945,17 @@ extern "C" int mia_hip_score_sums(mia_hip_ctx* ctx, int64_t* sums5) {
   if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->d_sums && dev_alloc(ctx, &ctx->d_sums, 8)) return MIA_HIP_ERR_NOMEM;
-  const long long init[5] = {0, 0, 0, INT32_MAX, INT32_MIN};
-  HIPCHK(hipMemcpyAsync(ctx->d_sums, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_score_sums_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_sums);
   const int64_t n = ctx->rs.n;
   if (n > 0) {
     int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus);   // few blocks: five same-address atomics per block
     hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums);
     HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipMemcpyAsync(sums5, ctx->d_sums, 40, hipMemcpyDeviceToHost, ctx->stream));
+  int64_t* stage = ctx->h_pin ? reinterpret_cast<int64_t*>(ctx->h_pin + (16 << 10)) : sums5;   // pinned: the copy does not block by itself
+  HIPCHK(hipMemcpyAsync(stage, ctx->d_sums, 40, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (stage != sums5) memcpy(sums5, stage, 40);
   return MIA_HIP_OK;
 }
 
@@ -1043,11 +1065,14 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
     }
     HIPCHK(hipGetLastError());
   }
-  uint32_t flags = 0, cflags = 0;
-  HIPCHK(hipMemcpyAsync(&ctx->n_events_host, ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&flags, ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&cflags, ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t local3[3] = {0, 0, 0};
+  uint32_t* h3 = ctx->h_pin ? reinterpret_cast<uint32_t*>(ctx->h_pin + (17 << 10)) : local3;   // pinned: three copies, one wait
+  HIPCHK(hipMemcpyAsync(&h3[0], ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&h3[1], ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&h3[2], ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_events_host = (int32_t)h3[0];
+  const uint32_t flags = h3[1], cflags = h3[2];
   if (int rcf = check_cull_flags(ctx, cflags)) return rcf;
   if (flags & 1u) { ctx->err = "insert event list overflow"; return MIA_HIP_ERR_NOMEM; }
   if (ctx->n_events_host > ctx->tb.cap_events) ctx->n_events_host = ctx->tb.cap_events;
@@ -1102,32 +1127,56 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   if (!ctx->tallied) { ctx->err = "tally first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
   const int L = ctx->L, Lp = ctx->tb.Lp;
-  int32_t total = 0;
   hipLaunchKernelGGL(k_gap_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->tb.gaps, Lp, L, ctx->d_ins_off, ctx->d_ins_total);
-  HIPCHK(hipMemcpyAsync(&total, ctx->d_ins_total, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (total > ctx->ins_tally_cap) {
-    if (dev_alloc(ctx, &ctx->d_ins_tally, (size_t)total * 9) || dev_alloc(ctx, &ctx->d_ins_calls, (size_t)total)) return MIA_HIP_ERR_NOMEM;
-    ctx->ins_tally_cap = total;
-  }
-  if (total > 0) {
-    HIPCHK(hipMemsetAsync(ctx->d_ins_tally, 0, (size_t)total * 9 * 4, ctx->stream));
+  hipLaunchKernelGGL(k_call_columns, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, cons_code, ctx->d_calls);
+  // The insert columns are tallied and called into buffers of the capacity the last call left behind, and their total
+  // comes back with the results: one wait for the stream instead of two.  Only when the total has outgrown the buffers
+  // are they enlarged and the insert part run again.
+  auto insert_part = [&](int64_t cap) -> int {
+    if (cap <= 0) return MIA_HIP_OK;
+    HIPCHK(hipMemsetAsync(ctx->d_ins_tally, 0, (size_t)cap * 9 * 4, ctx->stream));
     const int ne = ctx->n_events_host;
     if (ne > 0)
       hipLaunchKernelGGL(k_ins_tally, dim3((ne + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.events, ne, ctx->d_pssm, ctx->d_ins_off,
-                         ctx->tb.gaps, L, ctx->d_ins_tally);
+                         ctx->tb.gaps, L, ctx->d_ins_tally, (int32_t)cap);
     hipLaunchKernelGGL(k_call_inserts, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, ctx->tb.gaps,
-                       ctx->d_ins_off, ctx->d_ins_tally, cons_code, ctx->d_ins_calls);
-  }
-  hipLaunchKernelGGL(k_call_columns, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, cons_code, ctx->d_calls);
+                       ctx->d_ins_off, ctx->d_ins_tally, cons_code, ctx->d_ins_calls, (int32_t)cap);
+    return MIA_HIP_OK;
+  };
+  int rc0 = insert_part(ctx->ins_tally_cap);
+  if (rc0) return rc0;
   HIPCHK(hipGetLastError());
-  std::vector<char> calls((size_t)L), ins((size_t)total + 1);
-  std::vector<int32_t> gaps((size_t)Lp), off((size_t)Lp);
-  HIPCHK(hipMemcpyAsync(calls.data(), ctx->d_calls, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
-  if (total > 0) HIPCHK(hipMemcpyAsync(ins.data(), ctx->d_ins_calls, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(gaps.data(), ctx->tb.gaps, (size_t)Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(off.data(), ctx->d_ins_off, (size_t)Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  // results through the pinned staging area when they fit (copies into pageable memory make the host wait one by one)
+  const size_t need = 16 + (size_t)L + 2 * (size_t)Lp * 4 + (size_t)ctx->ins_tally_cap + 64;
+  std::vector<unsigned char> pageable;
+  unsigned char* base;
+  if (ctx->h_pin && need <= mia_hip_ctx::PIN_BYTES - mia_hip_ctx::PIN_MISC) base = ctx->h_pin + mia_hip_ctx::PIN_MISC;
+  else { pageable.resize(need); base = pageable.data(); }
+  int32_t* h_total = reinterpret_cast<int32_t*>(base);
+  int32_t* gaps = reinterpret_cast<int32_t*>(base + 16);
+  int32_t* off = gaps + Lp;
+  char* calls = reinterpret_cast<char*>(off + Lp);
+  char* ins = calls + L;
+  HIPCHK(hipMemcpyAsync(h_total, ctx->d_ins_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(calls, ctx->d_calls, (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(gaps, ctx->tb.gaps, (size_t)Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(off, ctx->d_ins_off, (size_t)Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->ins_tally_cap > 0) HIPCHK(hipMemcpyAsync(ins, ctx->d_ins_calls, (size_t)ctx->ins_tally_cap, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  const int32_t total = *h_total;
+  std::vector<char> ins_big;
+  if (total > ctx->ins_tally_cap) {
+    const int64_t cap = (int64_t)total + total / 4 + 1024;
+    if (dev_alloc(ctx, &ctx->d_ins_tally, (size_t)cap * 9) || dev_alloc(ctx, &ctx->d_ins_calls, (size_t)cap)) return MIA_HIP_ERR_NOMEM;
+    ctx->ins_tally_cap = cap;
+    rc0 = insert_part(cap);
+    if (rc0) return rc0;
+    HIPCHK(hipGetLastError());
+    ins_big.resize((size_t)total + 1);
+    HIPCHK(hipMemcpyAsync(ins_big.data(), ctx->d_ins_calls, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ins = ins_big.data();
+  }
   // string assembly of consensus_assembly_string (src/mia.c:551-600): insert calls, then the column call; '-' is skipped
   int64_t o = 0;
   for (int p = 0; p < L; p++) {
