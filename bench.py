@@ -156,7 +156,8 @@ def main():
         sums = hip.score_sums()
         if sharded:
             from mia_amd import dist as mdist
-            sums, slot_base = mdist.gather_pre_cull(sums, hip.num_records(), "cuda")
+            n_rec, n_lnk = hip.pre_cull_counts()           # by-products of score_sums: no further round trip
+            sums, slot_base, link_counts = mdist.gather_pre_cull(sums, n_rec, "cuda", n_lnk)
         t0 = tick("score_sums", t0)
         cut = hip.score_cut_from_sums(sums)
         if cut is None:
@@ -173,18 +174,18 @@ def main():
             slope = 100.0
         hip.cull(0, slope, intercept, slot_base)
         if sharded:
-            mdist.exchange_links(hip, lambda ptr, n, ts: torch.as_tensor(DevArray(ptr, n, ts), device="cuda"))
+            mdist.exchange_links(hip, lambda ptr, n, ts: torch.as_tensor(DevArray(ptr, n, ts), device="cuda"), link_counts)
         t0 = tick("cull", t0)
         hip.tally()
         t0 = tick("tally", t0)
         if sharded:
             from mia_amd import dist as mdist
             pt, nt, pg, ng = hip.tally_buffers()
-            mdist.allreduce_tallies(torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda"),
-                                    torch.as_tensor(DevArray(pg, ng, "<i4"), device="cuda"))
             pe, ne = hip.ins_events()
+            counts = mdist.allreduce_tallies_with_counts(torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda"),
+                                                         torch.as_tensor(DevArray(pg, ng, "<i4"), device="cuda"), ne)
             mine = torch.as_tensor(DevArray(pe, ne, "<i8"), device="cuda") if ne else torch.zeros(0, dtype=torch.int64, device="cuda")
-            allev = mdist.all_gather_ragged(mine)
+            allev = mdist.all_gather_ragged(mine, counts)
             torch.cuda.synchronize()
             hip.set_ins_events(allev.data_ptr() if allev.numel() else 0, int(allev.numel()))
         c = hip.consensus(1)

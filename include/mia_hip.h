@@ -158,6 +158,12 @@ int mia_hip_finish_links(mia_hip_ctx *ctx);
  * unique_best may be NULL (= all 1). */
 void mia_hip_score_cut(const int32_t *score, const int32_t *seq_len, const uint8_t *unique_best, int64_t n,
                        double *slope, double *intercept);
+/* By-products of the last mia_hip_score_sums call (same sweep over the reads, no further device round trip), for a
+ * sharded run: the number of AlnSeq records this context will hold (what mia_hip_num_records returns) and the number
+ * of links mia_hip_cull will emit (mia_hip_links).  With both known on every rank BEFORE the cull, one small
+ * all-gather settles the slot bases and whether any links have to be exchanged at all. */
+int mia_hip_pre_cull_counts(mia_hip_ctx *ctx, int64_t *n_records, int64_t *n_links);
+
 /* Pass 1 of find_fsdb_score_cut on the device: sums5 = {sum of seq_len, sum of score, count, min seq_len, max seq_len}
  * over the reads with score >= FIRST_ROUND_SCORE_CUTOFF (integers: exact, all-reducible).  When all those reads have the
  * same length the whole regression follows from the sums (slope_bf = 0/0): mia_hip_score_cut_from_sums (host helper)

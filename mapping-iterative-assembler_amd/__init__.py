@@ -55,6 +55,7 @@ def _load():
     lib.mia_hip_get_tally.argtypes = [vp, vp, vp]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.mia_hip_pre_cull_counts.argtypes = [vp, vp, vp]
     lib.mia_hip_filter_stats.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.mia_hip_myers_align.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, vp, vp, vp]
     lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
@@ -94,7 +95,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_align_windows", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
             "mia_hip_score_cut_from_sums"]
@@ -301,6 +302,12 @@ class MiaHip:
         n = C.c_int64()
         self._chk(self._l.mia_hip_consensus(self._h, cons_code, buf, cap, C.byref(n)))
         return buf.raw[: n.value].decode()
+
+    def pre_cull_counts(self):
+        """(AlnSeq records of this context, links the cull will emit): by-products of the last score_sums() call"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self._l.mia_hip_pre_cull_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def pass1_filtered(self):
         """reads of the last pass1() call decided by the diagonal filter instead of the whole-reference DP"""

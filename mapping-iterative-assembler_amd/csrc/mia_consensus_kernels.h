@@ -88,26 +88,39 @@ __global__ void k_scan_apply(ReadSet rs, int32_t L, const int64_t* partial, int6
 }
 
 __global__ void k_score_sums_init(unsigned long long* sums) {   // the neutral element of k_score_sums' five accumulators
-  if (threadIdx.x == 0) { sums[0] = 0; sums[1] = 0; sums[2] = 0; sums[3] = (unsigned long long)(long long)INT32_MAX; sums[4] = (unsigned long long)(long long)INT32_MIN; }
+  if (threadIdx.x == 0) { sums[0] = 0; sums[1] = 0; sums[2] = 0; sums[3] = (unsigned long long)(long long)INT32_MAX; sums[4] = (unsigned long long)(long long)INT32_MIN; sums[5] = 0; sums[6] = 0; }
 }
 
 // ---- first pass of find_fsdb_score_cut (src/fsdb.c:269-383) on the device: the sums of length and score over the reads
 // the regression uses (unique_best, score >= 2000) are sums of integers -- exact in any order -- plus the length range.
 // out: {sum len, sum score, count, min len, max len}
-__global__ __launch_bounds__(256) void k_score_sums(ReadSet rs, unsigned long long* out) {
-  __shared__ unsigned long long sh[3][256];
+// Two more counts a sharded run needs before the cull, taken in the same sweep: out[5] = AlnSeq records of this context
+// (one per strand-known read, two if it is split at the origin: what k_scan_* will number), out[6] = links k_cull_mark
+// will emit (same conditions as there: a strand-unknown read with pass-1 slots, or a read that was split once and is not
+// now) -- so that the ranks can agree in ONE small all-gather that there is nothing to exchange.
+__global__ __launch_bounds__(256) void k_score_sums(ReadSet rs, unsigned long long* out, int32_t L, const int64_t* back_slot,
+                                                     const int64_t* front_slot0) {
+  __shared__ unsigned long long sh[5][256];
   __shared__ int shl[2][256];
-  unsigned long long sx = 0, sy = 0, j = 0;
+  unsigned long long sx = 0, sy = 0, j = 0, nrec = 0, nlink = 0;
   int lmin = INT32_MAX, lmax = INT32_MIN;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rs.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int sc = rs.score[i], ln = rs.len[i];
     if (sc >= 2000) { sx += (unsigned long long)ln; sy += (unsigned long long)sc; j++; lmin = ln < lmin ? ln : lmin; lmax = ln > lmax ? ln : lmax; }
+    if (rs.sk[i]) {
+      const bool split = rec_geom(rs.as[i], rs.ae[i], L).split;
+      nrec += split ? 2 : 1;
+      if (!split && back_slot[i] >= 0) nlink++;
+    } else {
+      nlink += (front_slot0[i] >= 0) + (back_slot[i] >= 0);
+    }
   }
-  sh[0][threadIdx.x] = sx; sh[1][threadIdx.x] = sy; sh[2][threadIdx.x] = j; shl[0][threadIdx.x] = lmin; shl[1][threadIdx.x] = lmax;
+  sh[0][threadIdx.x] = sx; sh[1][threadIdx.x] = sy; sh[2][threadIdx.x] = j; sh[3][threadIdx.x] = nrec; sh[4][threadIdx.x] = nlink;
+  shl[0][threadIdx.x] = lmin; shl[1][threadIdx.x] = lmax;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) {
-      for (int k = 0; k < 3; k++) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+      for (int k = 0; k < 5; k++) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
       shl[0][threadIdx.x] = min(shl[0][threadIdx.x], shl[0][threadIdx.x + o]);
       shl[1][threadIdx.x] = max(shl[1][threadIdx.x], shl[1][threadIdx.x + o]);
     }
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(256) void k_score_sums(ReadSet rs, unsigned long lo
   }
   if (threadIdx.x == 0) {
     atomicAdd(&out[0], sh[0][0]); atomicAdd(&out[1], sh[1][0]); atomicAdd(&out[2], sh[2][0]);
+    atomicAdd(&out[5], sh[3][0]); atomicAdd(&out[6], sh[4][0]);
     atomicMin(reinterpret_cast<long long*>(&out[3]), (long long)shl[0][0]);
     atomicMax(reinterpret_cast<long long*>(&out[4]), (long long)shl[1][0]);
   }

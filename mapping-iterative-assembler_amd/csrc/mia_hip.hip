@@ -76,6 +76,7 @@ struct mia_hip_ctx {
   // the diagonal filter (diag_filter.h): flat matrix only
   bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
   bool flat = false; int use_filter = 1;   // MIA_HIP_NO_DIAG_FILTER=1 sends every read to the DP kernels
+  int64_t pre_cull_records = 0, pre_cull_links = 0; bool pre_cull_valid = false;   // mia_hip_score_sums' by-products
   uint64_t* d_planes = nullptr; int64_t plane_cap = 0;   // lo | hi | ok, plane_cap words each
   uint32_t* d_filter_n = nullptr; int64_t filter_proven = 0, filter_seen = 0;
   int grid_wgs = 0;
@@ -635,6 +636,7 @@ static int align_all(mia_hip_ctx* ctx) {
   ctx->aligned = true;
   ctx->culled = false;
   ctx->tallied = false;
+  ctx->pre_cull_valid = false;
   return MIA_HIP_OK;
 }
 
@@ -778,6 +780,7 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
 }
 
 extern "C" int mia_hip_set_back_slots(mia_hip_ctx* ctx, const int64_t* back_slot) {
+  if (ctx) ctx->pre_cull_valid = false;
   if (!ctx || !back_slot) return MIA_HIP_ERR_ARG;
   if (!ctx->d_back_slot) { ctx->err = "upload_reads first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
@@ -787,6 +790,7 @@ extern "C" int mia_hip_set_back_slots(mia_hip_ctx* ctx, const int64_t* back_slot
 }
 
 extern "C" int mia_hip_set_pass1_state(mia_hip_ctx* ctx, const int64_t* front_slot, const int64_t* back_slot, const int32_t* score) {
+  if (ctx) ctx->pre_cull_valid = false;
   if (!ctx) return MIA_HIP_ERR_ARG;
   if (!ctx->d_back_slot) { ctx->err = "upload_reads first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
@@ -945,17 +949,30 @@ extern "C" int mia_hip_score_sums(mia_hip_ctx* ctx, int64_t* sums5) {
   if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->d_sums && dev_alloc(ctx, &ctx->d_sums, 8)) return MIA_HIP_ERR_NOMEM;
+  ctx->pre_cull_valid = false;
   hipLaunchKernelGGL(k_score_sums_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_sums);
   const int64_t n = ctx->rs.n;
   if (n > 0) {
     int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus);   // few blocks: five same-address atomics per block
-    hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums);
+    hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums, ctx->L, ctx->d_back_slot, ctx->d_front_slot0);
     HIPCHK(hipGetLastError());
   }
-  int64_t* stage = ctx->h_pin ? reinterpret_cast<int64_t*>(ctx->h_pin + (16 << 10)) : sums5;   // pinned: the copy does not block by itself
-  HIPCHK(hipMemcpyAsync(stage, ctx->d_sums, 40, hipMemcpyDeviceToHost, ctx->stream));
+  int64_t local7[7];
+  int64_t* stage = ctx->h_pin ? reinterpret_cast<int64_t*>(ctx->h_pin + (16 << 10)) : local7;   // pinned: the copy does not block by itself
+  HIPCHK(hipMemcpyAsync(stage, ctx->d_sums, 56, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (stage != sums5) memcpy(sums5, stage, 40);
+  memcpy(sums5, stage, 40);
+  ctx->pre_cull_records = stage[5];
+  ctx->pre_cull_links = stage[6];
+  ctx->pre_cull_valid = true;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_pre_cull_counts(mia_hip_ctx* ctx, int64_t* n_records, int64_t* n_links) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (!ctx->pre_cull_valid) { ctx->err = "score_sums (after the last realign) first"; return MIA_HIP_ERR_STATE; }
+  if (n_records) *n_records = ctx->pre_cull_records;
+  if (n_links) *n_links = ctx->pre_cull_links;
   return MIA_HIP_OK;
 }
 

@@ -45,18 +45,36 @@ def allreduce_tallies(tally, gaps):
     dist.all_reduce(gaps, op=dist.ReduceOp.MAX)
 
 
-def gather_pre_cull(sums5, n_records, device):
-    """One small all-gather before the cull instead of four collectives: every rank's score sums (mia_hip_score_sums)
-    and record count.  Returns (global sums5, slot_base, read counts are not needed: reads are sharded evenly)."""
+def allreduce_tallies_with_counts(tally, gaps, n_mine):
+    """allreduce_tallies plus every rank's n_mine (its number of insert events) WITHOUT a collective of its own: the
+    counts ride on the MAX all-reduce of the gaps in `world` extra slots, rank r filling slot r.  Returns the list of
+    counts in rank order (what all_gather_ragged wants)."""
     if not _active():
-        return sums5, 0
-    mine = torch.tensor(list(map(int, sums5)) + [int(n_records)], dtype=torch.int64, device=device)
-    allt = torch.empty(6 * world(), dtype=torch.int64, device=device)
+        return [int(n_mine)]
+    w, r = world(), dist.get_rank()
+    dist.all_reduce(tally, op=dist.ReduceOp.SUM)
+    ext = torch.zeros(gaps.numel() + w, dtype=gaps.dtype, device=gaps.device)
+    ext[: gaps.numel()] = gaps
+    ext[gaps.numel() + r] = int(n_mine)
+    dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+    gaps.copy_(ext[: gaps.numel()])
+    return ext[gaps.numel():].cpu().tolist()
+
+
+def gather_pre_cull(sums5, n_records, device, n_links=None):
+    """One small all-gather before the cull instead of four collectives: every rank's score sums (mia_hip_score_sums),
+    record count and -- if given -- the number of links its cull will emit (mia_hip_pre_cull_counts).  Returns
+    (global sums5, slot_base) or, with n_links, (global sums5, slot_base, every rank's link count)."""
+    if not _active():
+        return (sums5, 0) if n_links is None else (sums5, 0, [int(n_links)])
+    mine = torch.tensor(list(map(int, sums5)) + [int(n_records), int(n_links or 0)], dtype=torch.int64, device=device)
+    allt = torch.empty(7 * world(), dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(allt, mine)
-    allv = allt.cpu().numpy().reshape(world(), 6)
+    allv = allt.cpu().numpy().reshape(world(), 7)
     import numpy as np
     g = np.array([allv[:, 0].sum(), allv[:, 1].sum(), allv[:, 2].sum(), allv[:, 3].min(), allv[:, 4].max()], dtype=np.int64)
-    return g, int(allv[: dist.get_rank(), 5].sum())
+    base = int(allv[: dist.get_rank(), 5].sum())
+    return (g, base) if n_links is None else (g, base, [int(x) for x in allv[:, 6]])
 
 
 def allreduce_score_sums(sums5, device):
@@ -95,16 +113,20 @@ def all_gather_ragged(t, counts=None):
     return torch.cat([allt[r * mx: r * mx + counts[r]] for r in range(world())]).contiguous()
 
 
-def exchange_links(hip, as_tensor):
+def exchange_links(hip, as_tensor, link_counts=None):
     """Between cull() and tally() of a sharded iteration: the links of formerly split reads (stale fs->back_asp,
     include/mia_hip.h) may point at AlnSeq slots of another rank.  Every rank gets all links, applies those that hit
     its own slots, and the record lengths the readers need come back with a max-reduce.
-    as_tensor(ptr, n, typestr) wraps a device pointer of the library as a tensor (bench.DevArray on CUDA)."""
+    as_tensor(ptr, n, typestr) wraps a device pointer of the library as a tensor (bench.DevArray on CUDA).
+    link_counts: see below."""
     if not _active():
         return
+    # almost always no rank has a link.  link_counts (every rank's number of links, known before the cull from
+    # gather_pre_cull) settles that without a collective or a device round trip; otherwise one tiny all-gather does.
+    if link_counts is not None and sum(link_counts) == 0:
+        return
     ptr, n = hip.links()
-    # almost always no rank has a link: find that out with one tiny all-gather before moving any list
-    counts = _gather_counts(4 * n, _device())
+    counts = [4 * c for c in link_counts] if link_counts is not None else _gather_counts(4 * n, _device())
     if sum(counts) == 0:
         return
     mine = as_tensor(ptr, 4 * n, "<i8") if n else torch.zeros(0, dtype=torch.int64, device=_device())

@@ -52,12 +52,21 @@ mdist.allreduce_tallies(tt, tg)
 scores = mdist.all_gather_concat(torch.from_numpy(np.pad(fs["score"], (0, per - fs["n"]), constant_values=-1)))
 base = mdist.exclusive_rank_sum(nrec, "cpu")
 ev = mdist.all_gather_ragged(torch.arange(rank * 100, rank * 100 + 3 + rank, dtype=torch.int64))
+# the same with the counts riding on the gaps all-reduce (no collective of their own)
+tt2, tg2 = torch.from_numpy(tally.astype(np.int32)), torch.from_numpy(gaps.astype(np.int32))
+cnts = mdist.allreduce_tallies_with_counts(tt2, tg2, 3 + rank)
+assert cnts == [3 + r for r in range(world)], cnts
+assert torch.equal(tt2, tt) and torch.equal(tg2, tg)
+ev2 = mdist.all_gather_ragged(torch.arange(rank * 100, rank * 100 + 3 + rank, dtype=torch.int64), cnts)
+assert torch.equal(ev2, ev)
 
 s5 = mdist.allreduce_score_sums(np.array([10 + rank, 100 * (rank + 1), 3, 50 - rank, 60 + rank], dtype=np.int64), "cpu")
 assert s5.tolist() == [21, 300, 6, 49, 61], s5
 
 g5, sb = mdist.gather_pre_cull(np.array([10 + rank, 100 * (rank + 1), 3, 50 - rank, 60 + rank], dtype=np.int64), 7 + rank, "cpu")
 assert g5.tolist() == [21, 300, 6, 49, 61] and sb == (0 if rank == 0 else 7), (g5, sb)
+g5, sb, lc = mdist.gather_pre_cull(np.array([10 + rank, 100 * (rank + 1), 3, 50 - rank, 60 + rank], dtype=np.int64), 7 + rank, "cpu", 2 - rank)
+assert g5.tolist() == [21, 300, 6, 49, 61] and sb == (0 if rank == 0 else 7) and lc == [2, 1], (g5, sb, lc)
 
 # the link exchange of formerly split reads (stale back_asp): rank 0 has two links, rank 1 one; a link is 4 int64
 # {reader, slot, flen<<32|actf, low}.  A stand-in with the library's five calls checks the protocol of exchange_links.
@@ -87,6 +96,15 @@ mdist.exchange_links(fh, cpu_tensor)
 assert fh.done and fh.all[:, 0].tolist() == [0, 1, 1000], fh.all          # all links, rank order
 assert fh.lens.tolist() == [200 + int(s) for s in fh.all[:, 1]], fh.lens     # every length resolved by its owner
 assert fh.acts.tolist() == fh.lens.tolist()
+# with the link counts known beforehand (mia_hip_pre_cull_counts through gather_pre_cull): same result without the count
+# gather; and when nobody has a link nothing is called at all
+fh2 = FakeHip()
+mdist.exchange_links(fh2, cpu_tensor, [2, 1])
+assert fh2.done and np.array_equal(fh2.all, fh.all) and fh2.lens.tolist() == fh.lens.tolist()
+class NoLinks:
+    def links(self):
+        raise AssertionError("links() must not be called when every rank reported zero links")
+mdist.exchange_links(NoLinks(), cpu_tensor, [0, 0])
 if rank == 0:
     full_t, full_g, full_fs, full_nrec = run("d150.fa")
     assert np.array_equal(tt.numpy(), full_t), "summed shard tallies != unsharded tallies"

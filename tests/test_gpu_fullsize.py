@@ -149,6 +149,11 @@ def test_score_sums_on_device(full):
     assert a is not None and all((x == y) or (np.isnan(x) and np.isnan(y)) for x, y in zip(a, b)), (a, b)
     s5[4] += 1                       # reads of different lengths: the host regression is needed
     assert f.hip.score_cut_from_sums(s5) is None
+    # by-products of the same sweep: the record count and the number of links the next cull emits
+    n_rec, n_lnk = f.hip.pre_cull_counts()
+    assert n_rec == f.hip.num_records()
+    f.hip.cull(0, f.cut[0] if f.cut[0] > 0 else 100.0, f.cut[1], 0)
+    assert f.hip.links()[1] == n_lnk
 
 
 def test_realign_idempotent(full):
