@@ -48,6 +48,30 @@ struct RefPlanes {
   const uint64_t* ok;   //                     1 iff the code is A, C, G or T (0: N, or outside the reference)
 };
 
+// Where each 10-mer of the reference starts (first DF_KCAP occurrences; cnt beyond that = "too many, ask the planes").
+// Rule (c) only cares about clean prefixes / suffixes that are LONG; a clean stretch of 10 or more rows on a diagonal
+// means the read's first (last) 10-mer occurs there, so the few diagonals the table names are the only ones that can
+// exceed 9 -- no need to slide over all of them.  Sound only where the reference stretch has no N (a wild card is not
+// in the table): the caller checks the ok plane.
+constexpr int DF_K = 10, DF_KCAP = 4;
+constexpr int64_t DF_KTAB = (int64_t)1 << (2 * DF_K);
+struct KmerOcc {
+  const int32_t* cnt;   // [4^10] occurrences of the 10-mer in the reference
+  const int32_t* pos;   // [4^10][DF_KCAP] start positions of the first DF_KCAP of them
+};
+
+// position p of the reference: its 10-mer index (code of p+t in bits 2t, 2t+1), or -1 if it holds an N / runs off the end
+MIA_HD inline int64_t kmer_at(const uint8_t* codes, int64_t n_codes, int64_t p) {
+  if (p < 0 || p + DF_K > n_codes) return -1;
+  int64_t idx = 0;
+  for (int t = 0; t < DF_K; t++) {
+    const uint32_t c = codes[p + t];
+    if (c > 3) return -1;
+    idx |= (int64_t)c << (2 * t);
+  }
+  return idx;
+}
+
 // one word of the three planes from 64 consecutive reference codes (0..3 bases, anything else N)
 MIA_HD inline void plane_word(const uint8_t* codes, int64_t n_codes, int64_t word, uint64_t* lo, uint64_t* hi, uint64_t* ok) {
   uint64_t l = 0, h = 0, k = 0;
@@ -284,6 +308,77 @@ MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_
     }
   }
   return lp + ls <= R - 3;
+}
+
+// are reference positions [lo, hi) all A/C/G/T?  (positions outside the reference count as "not": their ok bits are 0)
+MIA_HD inline bool all_bases(const RefPlanes& rp, int64_t lo, int64_t hi) {
+  for (int64_t b = lo + PLANE_LEAD; b < hi + PLANE_LEAD;) {
+    const int64_t w = b >> 6;
+    const int o = (int)(b & 63);
+    const int64_t room = 64 - o, left = hi + PLANE_LEAD - b;
+    const int n = (int)(left < room ? left : room);
+    const uint64_t mask = (n == 64 ? ~0ull : ((1ull << n) - 1ull)) << o;
+    if ((rp.ok[w] & mask) != mask) return false;
+    b += n;
+  }
+  return true;
+}
+
+// Rule (c) through the 10-mer table: 1 = proven (LP + LS <= R - 3 with every diagonal the table does not name counted
+// as 9); 0 = not proven -- the read then simply goes to the DP (sliding over all diagonals would settle a few more of
+// these, but one such read per wavefront would cost the whole wavefront the slide); -1 = the table cannot be used here
+// (N in reach, a 10-mer with too many occurrences, a short read, no table): the caller slides.  n_ref = reference positions.
+template <int NW>
+MIA_HD inline int diag_step2_kmer(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2) {
+  if (!ko.cnt || len2 < 2 * DF_K + 4) return -1;
+  const int R = len2 - 1, fit = len1 - len2;
+  // every position a prefix or suffix inside the window can touch must be a plain base
+  int64_t lo = (int64_t)s - R, hi = (int64_t)s + len1 + R;
+  if (lo < 0) lo = 0;
+  if (hi > n_ref) hi = n_ref;
+  if (!all_bases(rp, lo, hi)) return -1;
+  DiagScan<NW> sc;
+  sc.load_read(read_packed, len2);
+  // the read's first and last 10-mer
+  int64_t first = 0, last = 0;
+  for (int t = 0; t < DF_K; t++) {
+    first |= (int64_t)(((sc.rlo[0] >> t) & 1ull) | (((sc.rhi[0] >> t) & 1ull) << 1)) << (2 * t);
+    const int r = R - DF_K + 1 + t;
+    const int c = (read_packed[r >> 1] >> ((r & 1) * 4)) & 3;
+    last |= (int64_t)c << (2 * t);
+  }
+  const int nf = ko.cnt[first], nl = ko.cnt[last];
+  if (nf > DF_KCAP || nl > DF_KCAP) return -1;
+  int lp = DF_K - 1, ls = DF_K - 1;
+  for (int k = 0; k < DF_KCAP; k++) {
+    if (k < nf) {
+      const int d = ko.pos[first * DF_KCAP + k] - s;            // the prefix starts in window column d
+      if (d >= 0 && d <= len1 - 1) {
+        sc.seek(rp, (int64_t)s + d);
+        int p = sc.clean_prefix();
+        if (p > len1 - d) p = len1 - d;
+        if (p > lp) lp = p;
+      }
+    }
+    if (k < nl) {
+      const int d = ko.pos[last * DF_KCAP + k] + DF_K - 1 - R - s;   // row R sits in window column d + R
+      if (d >= -R && d <= fit) {
+        sc.seek(rp, (int64_t)s + d);
+        int q = sc.clean_suffix();
+        if (d < 0 && q > len2 + d) q = len2 + d;
+        if (q > ls) ls = q;
+      }
+    }
+  }
+  return lp + ls <= R - 3 ? 1 : 0;
+}
+MIA_HD inline int diag_step2_kmer(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2) {
+  switch ((len2 + 63) >> 6) {
+    case 1: return diag_step2_kmer<1>(rp, ko, n_ref, s, len1, read_packed, len2);
+    case 2: return diag_step2_kmer<2>(rp, ko, n_ref, s, len1, read_packed, len2);
+    case 3: return diag_step2_kmer<3>(rp, ko, n_ref, s, len1, read_packed, len2);
+    default: return diag_step2_kmer<4>(rp, ko, n_ref, s, len1, read_packed, len2);
+  }
 }
 
 MIA_HD inline bool diag_examined(int len1, int len2) { return len2 >= 1 && len2 <= MAX_READ && len1 >= len2 && len1 <= DF_MAX_LEN1; }

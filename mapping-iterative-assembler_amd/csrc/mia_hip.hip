@@ -77,6 +77,7 @@ struct mia_hip_ctx {
   bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
   bool flat = false; int use_filter = 1;   // MIA_HIP_NO_DIAG_FILTER=1 sends every read to the DP kernels
   int64_t pre_cull_records = 0, pre_cull_links = 0; bool pre_cull_valid = false;   // mia_hip_score_sums' by-products
+  int32_t *d_kocc_cnt = nullptr, *d_kocc_pos = nullptr;   // 10-mer table of the reference (diag_filter.h: KmerOcc)
   uint64_t* d_planes = nullptr; int64_t plane_cap = 0;   // lo | hi | ok, plane_cap words each
   uint32_t* d_filter_n = nullptr; int64_t filter_proven = 0, filter_seen = 0;
   int grid_wgs = 0;
@@ -185,7 +186,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n};
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n, ctx->d_kocc_cnt, ctx->d_kocc_pos};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -491,12 +492,22 @@ static int align_all(mia_hip_ctx* ctx) {
     hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
                        ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
     HIPCHK(hipMemsetAsync(ctx->d_filter_n, 0, 4, ctx->stream));
+    // the 10-mer table of this reference (rule (c) looks long clean stretches up instead of sliding over every diagonal);
+    // not for the very long concatenated strings mia_hip_align_windows may be given
+    KmerOcc ko{nullptr, nullptr};
+    if (wrap <= (1 << 22)) {
+      if (!ctx->d_kocc_cnt && (dev_alloc(ctx, &ctx->d_kocc_cnt, (size_t)DF_KTAB) || dev_alloc(ctx, &ctx->d_kocc_pos, (size_t)DF_KTAB * DF_KCAP)))
+        return MIA_HIP_ERR_NOMEM;
+      HIPCHK(hipMemsetAsync(ctx->d_kocc_cnt, 0, (size_t)DF_KTAB * 4, ctx->stream));
+      hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_kocc_cnt, ctx->d_kocc_pos);
+      ko.cnt = ctx->d_kocc_cnt; ko.pos = ctx->d_kocc_pos;
+    }
     hipEvent_t f0, f1;
     if (get_events(ctx, &f0, &f1)) return MIA_HIP_ERR_NOMEM;
     ctx->ev_filter.push_back(ctx->ev_used.back());
     ctx->ev_used.pop_back();
     (void)hipEventRecord(f0, ctx->stream);
-    hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ctx->d_bin_of);
+    hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_bin_of, ctx->dbg);
     (void)hipEventRecord(f1, ctx->stream);
     HIPCHK(hipGetLastError());
   }

@@ -107,7 +107,16 @@ __global__ __launch_bounds__(256) void k_ref_planes(const uint8_t* codes, int64_
   if (w < words) plane_word(codes, n_codes, w, &lo[w], &hi[w], &ok[w]);
 }
 
-__global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, RefPlanes rp, int32_t* bin_of) {
+// the 10-mer table of the reference for rule (c) (diag_filter.h: KmerOcc); cnt is zeroed before
+__global__ __launch_bounds__(256) void k_kmer_occ(const uint8_t* codes, int64_t n_codes, int32_t* cnt, int32_t* pos) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t idx = kmer_at(codes, n_codes, p);
+  if (idx < 0) return;
+  const int c = atomicAdd(&cnt[idx], 1);
+  if (c < DF_KCAP) pos[idx * DF_KCAP + c] = (int32_t)p;
+}
+
+__global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, RefPlanes rp, KmerOcc ko, int64_t n_ref, int32_t* bin_of, uint32_t dbg) {
   __shared__ int16_t verdict[256];      // per read of the block: diagonal of a finished read, -1 otherwise
   __shared__ int16_t cand[256];         // reads with exactly two mismatches on their diagonal: rule (c) is still open
   __shared__ int16_t cand_delta[256];
@@ -157,7 +166,8 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
     int s, l1;
     const int len2 = rs.len[i];
     read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);       // as / ae of a candidate are still untouched
-    if (diag_step2(rp, s, l1, rs.packed + rs.roff[i], len2)) {
+    const int via_table = (dbg & 64u) ? 0 : diag_step2_kmer(rp, ko, n_ref, s, l1, rs.packed + rs.roff[i], len2);
+    if (via_table > 0 || (via_table < 0 && diag_step2(rp, s, l1, rs.packed + rs.roff[i], len2))) {
       finish(i, s, len2, delta, 2);
       verdict[t] = (int16_t)delta;
     } else {

@@ -202,3 +202,33 @@ extern "C" int emu_pass1_filter(const uint8_t* fw_codes, const uint8_t* rc_codes
   if (k == 2 && !pass1_step2(fw, rc, len1, pb, len2)) return -1;
   return k;
 }
+
+// Rule (c) of the filter both ways for one read: bit 0 = verdict of the slide over all diagonals (diag_step2), bit 1 =
+// verdict of the 10-mer table route (diag_step2_kmer).  The table route counts every diagonal it does not look at as 9,
+// so it may only say yes where the slide says yes.  -1: step 1 does not make the read a K = 2 candidate.
+extern "C" int emu_step2_both(const uint8_t* ref_codes, int64_t n_codes, int ref_start, int len1, const uint8_t* read_codes, int len2) {
+  using namespace mia;
+  const int64_t words = plane_words(n_codes);
+  std::vector<uint64_t> lo((size_t)words), hi((size_t)words), ok((size_t)words);
+  for (int64_t w = 0; w < words; w++) plane_word(ref_codes, n_codes, w, &lo[(size_t)w], &hi[(size_t)w], &ok[(size_t)w]);
+  std::vector<uint32_t> packed((size_t)(len2 / 8 + 2), 0);
+  uint8_t* pb = (uint8_t*)packed.data();
+  for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
+  RefPlanes rp{lo.data(), hi.data(), ok.data()};
+  int delta = 0, best = 0;
+  if (diag_step1(rp, ref_start, len1, pb, len2, &delta, &best) != 2) return -1;
+  static std::vector<int32_t> cnt((size_t)DF_KTAB, 0), pos((size_t)DF_KTAB * DF_KCAP, 0);
+  std::vector<int64_t> touched;
+  for (int64_t p = 0; p < n_codes; p++) {
+    const int64_t idx = kmer_at(ref_codes, n_codes, p);
+    if (idx < 0) continue;
+    const int c = cnt[(size_t)idx]++;
+    if (c < DF_KCAP) pos[(size_t)(idx * DF_KCAP + c)] = (int32_t)p;
+    touched.push_back(idx);
+  }
+  KmerOcc ko{cnt.data(), pos.data()};
+  const int scan = diag_step2(rp, ref_start, len1, pb, len2) ? 1 : 0;
+  const int km = diag_step2_kmer(rp, ko, n_codes, ref_start, len1, pb, len2) > 0 ? 2 : 0;
+  for (int64_t idx : touched) cnt[(size_t)idx] = 0;
+  return scan | km;
+}

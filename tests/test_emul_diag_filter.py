@@ -194,3 +194,45 @@ def test_pass1_form_both_strands(emul, oracle, flat):
             got = (strand.value, 200 * len(read) - 800 * kk, delta.value, delta.value + len(read) - 1, 0)
             assert got == (want_strand, e.best, e.abc, e.aec, e.abr), (L, st, i, got, (want_strand, e.best, e.abc, e.aec, e.abr))
     assert decided > 0.5 * total and near_origin > 30, (decided, total, near_origin)
+
+
+def test_kmer_route_of_rule_c_never_says_more_than_the_slide(emul):
+    """rule (c) has a shortcut: long clean prefixes / suffixes are looked up in a 10-mer table of the reference instead of
+    sliding over every diagonal, all diagonals the table does not name counting as 9.  That bound is conservative, so the
+    shortcut may only prove what the slide proves -- on random, repetitive and N-holding references, clipped windows,
+    second copies of the read's ends nearby -- and it must prove most of them (or it would not be worth having)."""
+    rnd = random.Random(61)
+    both = only_scan = cand = 0
+    for i in range(2500):
+        kind = i % 4
+        if kind == 0:
+            ref = "".join(rnd.choice("ACGT") for _ in range(700))
+        elif kind == 1:
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([2, 3, 5, 9, 12, 21])))
+            ref = "".join(rnd.choice("ACGT") for _ in range(200)) + (unit * 100)[:250] + "".join(rnd.choice("ACGT") for _ in range(250))
+        elif kind == 2:
+            ref = list("".join(rnd.choice("ACGT") for _ in range(700)))
+            for p in rnd.sample(range(700), 6):
+                ref[p] = "N"
+            ref = "".join(ref)
+        else:
+            body = "".join(rnd.choice("ACGT") for _ in range(300))
+            ref = body + "".join(rnd.choice("ACGT") for _ in range(rnd.randint(0, 40))) + body[: rnd.randint(20, 200)] + \
+                "".join(rnd.choice("ACGT") for _ in range(120))
+        len2 = rnd.choice([24, 30, 50, 64, 65, 100, 128, 140])
+        st = rnd.randrange(0, len(ref) - len2)
+        s = max(0, st - rnd.choice([0, 3, 50]))
+        len1 = min(len(ref), st + len2 + rnd.choice([0, 3, 50])) - s
+        src = ref[st:st + len2].replace("N", "A")
+        gap = rnd.choice([1, 2, 3, 4, 8, 20, 40])
+        p0 = rnd.randrange(0, max(1, len2 - gap))
+        read = mutate(rnd, src, sorted({p0, min(len2 - 1, p0 + gap)}))
+        rc, c2 = codes(ref), codes(read)
+        v = emul.emu_step2_both(rc.ctypes.data_as(C.c_void_p), C.c_int64(len(ref)), s, len1, c2.ctypes.data_as(C.c_void_p), len(read))
+        if v < 0:
+            continue
+        cand += 1
+        assert v != 2, (ref, s, len1, read)         # table route yes, slide no: the bound would be unsound
+        both += v == 3
+        only_scan += v == 1
+    assert cand > 800 and both > 0.6 * (both + only_scan), (cand, both, only_scan)
