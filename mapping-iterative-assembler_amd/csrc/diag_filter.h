@@ -423,9 +423,14 @@ MIA_HD inline int pass1_step1(const RefPlanes& fw, const RefPlanes& rc, int len1
   return k[x];
 }
 MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2);
-// K == 2: rule (c) on both strands
-MIA_HD inline bool pass1_step2(const RefPlanes& fw, const RefPlanes& rc, int len1, const uint8_t* read_packed, int len2) {
-  return diag_step2(fw, 0, len1, read_packed, len2) && diag_step2(rc, 0, len1, read_packed, len2);
+MIA_HD inline int diag_step2_kmer(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2);
+// K == 2: rule (c) on both strands, each through its 10-mer table where that can be used
+MIA_HD inline bool pass1_step2(const RefPlanes& fw, const RefPlanes& rc, const KmerOcc& kf, const KmerOcc& kr, int len1, const uint8_t* read_packed,
+                               int len2) {
+  const int a = diag_step2_kmer(fw, kf, len1, 0, len1, read_packed, len2);
+  if (a == 0 || (a < 0 && !diag_step2(fw, 0, len1, read_packed, len2))) return false;
+  const int b = diag_step2_kmer(rc, kr, len1, 0, len1, read_packed, len2);
+  return b > 0 || (b < 0 && diag_step2(rc, 0, len1, read_packed, len2));
 }
 MIA_HD inline bool diag_step2(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2) {
   switch ((len2 + 63) >> 6) {

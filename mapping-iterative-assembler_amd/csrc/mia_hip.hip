@@ -1511,10 +1511,11 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   unsigned char* d_trace = nullptr;
   uint32_t* d_ckpt = nullptr;
   uint64_t* d_p1planes = nullptr;
+  int32_t *d_p1kcnt = nullptr, *d_p1kpos = nullptr;
   int32_t* d_todo = nullptr;
   uint32_t* d_ntodo = nullptr;
   ScopeFree guard;   // every temporary below is released on any return
-  guard.watch((void**)&d_p1planes); guard.watch((void**)&d_todo); guard.watch((void**)&d_ntodo);
+  guard.watch((void**)&d_p1planes); guard.watch((void**)&d_todo); guard.watch((void**)&d_ntodo); guard.watch((void**)&d_p1kcnt); guard.watch((void**)&d_p1kpos);
   for (void** pp : {(void**)&d_cf, (void**)&d_cr, (void**)&d_tab[0], (void**)&d_tab[1], (void**)&d_kl[0], (void**)&d_kl[1], (void**)&d_el[0],
                     (void**)&d_el[1], (void**)&d_pos[0], (void**)&d_pos[1], (void**)&d_packed, (void**)&d_rc, (void**)&d_flags, (void**)&d_roff,
                     (void**)&d_status, (void**)&d_len, (void**)&d_score, (void**)&d_as, (void**)&d_ae, (void**)&d_trace, (void**)&d_ckpt})
@@ -1598,7 +1599,17 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, words, pl + 3 * words, pl + 4 * words, pl + 5 * words);
       e = hipMemsetAsync(d_ntodo, 0, 4, ctx->stream);
       RefPlanes pf{pl, pl + words, pl + 2 * words}, prc{pl + 3 * words, pl + 4 * words, pl + 5 * words};
-      hipLaunchKernelGGL(k_pass1_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pr, pf, prc, len1, L, d_todo, d_ntodo);
+      // 10-mer tables of both strands for rule (c) (diag_filter.h: KmerOcc)
+      KmerOcc kf{nullptr, nullptr}, kr{nullptr, nullptr};
+      if (len1 <= (1 << 22)) {
+        if (dev_alloc(ctx, &d_p1kcnt, (size_t)DF_KTAB * 2) || dev_alloc(ctx, &d_p1kpos, (size_t)DF_KTAB * DF_KCAP * 2)) return MIA_HIP_ERR_NOMEM;
+        if (e == hipSuccess) e = hipMemsetAsync(d_p1kcnt, 0, (size_t)DF_KTAB * 2 * 4, ctx->stream);
+        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, d_p1kcnt, d_p1kpos);
+        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, d_p1kcnt + DF_KTAB,
+                           d_p1kpos + DF_KTAB * DF_KCAP);
+        kf.cnt = d_p1kcnt; kf.pos = d_p1kpos; kr.cnt = d_p1kcnt + DF_KTAB; kr.pos = d_p1kpos + DF_KTAB * DF_KCAP;
+      }
+      hipLaunchKernelGGL(k_pass1_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pr, pf, prc, kf, kr, len1, L, d_todo, d_ntodo);
       if (e == hipSuccess) e = hipGetLastError();
       uint32_t h_ntodo = 0;
       if (e == hipSuccess) e = hipMemcpyAsync(&h_ntodo, d_ntodo, 4, hipMemcpyDeviceToHost, ctx->stream);

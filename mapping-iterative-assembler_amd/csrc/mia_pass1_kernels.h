@@ -71,8 +71,8 @@ __device__ __forceinline__ void pass1_store(const Pass1Reads& rs, int64_t i, int
 
 // ---- the diagonal filter in front of the whole-reference DP (diag_filter.h; flat matrix, no k-mer mask): one read per
 // thread against every diagonal of both strands.  Reads it cannot decide are collected in `todo` for k_pass1.
-__global__ __launch_bounds__(256) void k_pass1_filter(Pass1Reads rs, RefPlanes fw, RefPlanes rc, int32_t len1, int32_t L, int32_t* todo,
-                                                      uint32_t* n_todo) {
+__global__ __launch_bounds__(256) void k_pass1_filter(Pass1Reads rs, RefPlanes fw, RefPlanes rc, KmerOcc kf, KmerOcc kr, int32_t len1, int32_t L,
+                                                      int32_t* todo, uint32_t* n_todo) {
   __shared__ int16_t cand[256];
   __shared__ int32_t cand_delta[256];
   __shared__ uint8_t cand_strand[256];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_pass1_filter(Pass1Reads rs, RefPlanes f
     const int t = cand[threadIdx.x], strand = cand_strand[threadIdx.x];
     const int64_t i = i0 + t;
     const int len2 = rs.len[i], delta = cand_delta[threadIdx.x];
-    if (pass1_step2(fw, rc, len1, rs.packed + rs.roff[i], len2))
+    if (pass1_step2(fw, rc, kf, kr, len1, rs.packed + rs.roff[i], len2))
       pass1_store(rs, i, L, strand, FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * 2, delta, delta + len2 - 1, ST_DIAG);
     else
       left[atomicAdd(&n_left, 1)] = (int16_t)t;

@@ -199,7 +199,22 @@ extern "C" int emu_pass1_filter(const uint8_t* fw_codes, const uint8_t* rc_codes
   for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
   RefPlanes fw{pl.data(), pl.data() + words, pl.data() + 2 * words}, rc{pl.data() + 3 * words, pl.data() + 4 * words, pl.data() + 5 * words};
   const int k = pass1_step1(fw, rc, len1, pb, len2, strand, delta);
-  if (k == 2 && !pass1_step2(fw, rc, len1, pb, len2)) return -1;
+  if (k == 2) {
+    // the two 10-mer tables, as mia_hip_pass1 builds them
+    static std::vector<int32_t> cf((size_t)DF_KTAB, 0), pf((size_t)DF_KTAB * DF_KCAP, 0), cr((size_t)DF_KTAB, 0), pr((size_t)DF_KTAB * DF_KCAP, 0);
+    std::vector<int64_t> tf, tr;
+    for (int64_t p = 0; p < len1; p++) {
+      int64_t idx = kmer_at(fw_codes, len1, p);
+      if (idx >= 0) { const int c = cf[(size_t)idx]++; if (c < DF_KCAP) pf[(size_t)(idx * DF_KCAP + c)] = (int32_t)p; tf.push_back(idx); }
+      idx = kmer_at(rc_codes, len1, p);
+      if (idx >= 0) { const int c = cr[(size_t)idx]++; if (c < DF_KCAP) pr[(size_t)(idx * DF_KCAP + c)] = (int32_t)p; tr.push_back(idx); }
+    }
+    KmerOcc kf{cf.data(), pf.data()}, kr{cr.data(), pr.data()};
+    const bool ok = pass1_step2(fw, rc, kf, kr, len1, pb, len2);
+    for (int64_t idx : tf) cf[(size_t)idx] = 0;
+    for (int64_t idx : tr) cr[(size_t)idx] = 0;
+    if (!ok) return -1;
+  }
   return k;
 }
 
