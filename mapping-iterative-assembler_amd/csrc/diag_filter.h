@@ -21,7 +21,11 @@
 //       <= 3 rows.  LP = longest mismatch-free prefix over ALL diagonals, LS = longest mismatch-free suffix; the test
 //       LP + LS <= R - 3 rules every such path out.  A prefix (suffix) counts only as far as its diagonal stays
 //       inside the window; N columns and positions outside the reference are treated as matching anything, which
-//       can only make LP / LS larger (more fall-backs, never a wrong verdict).
+//       can only make LP / LS larger (more fall-backs, never a wrong verdict).  LP and LS need not be exact either,
+//       only not too small: where the reference stretch holds no N, a clean prefix (suffix) of 10 or more rows on a
+//       diagonal means that the read's first (last) 10-mer occurs there, so a table of the reference's 10-mers names
+//       the only diagonals that can exceed 9 and all others are counted as 9 (diag_step2_kmer) -- a look-up instead
+//       of a slide over every diagonal.
 // Hence every path other than D ends in row R with a value STRICTLY below D's: max_sg_score's first maximum of the
 // last row is D's end cell (ties impossible), and by extending any better path to a diagonal cell along D one sees
 // that at every cell of D the diagonal candidate is >= both gap candidates, and D(r-1) >= -600 > -P(r+1), so the
@@ -381,8 +385,56 @@ MIA_HD inline int diag_step2_kmer(const RefPlanes& rp, const KmerOcc& ko, int64_
   }
 }
 
+// Step 1 through the 10-mer table.  Pigeonhole: cut B disjoint 10-mers out of the read; a diagonal with fewer than B
+// mismatches leaves at least one of them intact, i.e. that 10-mer occurs in the reference at the matching place.  So the
+// occurrences the table lists for the B blocks name every diagonal that can have fewer than B mismatches; those few are
+// compared in full, all others have >= B.  B = 6 where the read is long enough (the gap hint wants "best >= 6"), at
+// least 3 (rules (a), (b) ask for ">= K+1", K <= 2).  Returns K / -1 like diag_step1, or -2 if the table cannot be used
+// for this read (N in the window, a block whose 10-mer has more occurrences than the table keeps, a short read, no
+// table): the caller slides.  n_ref = reference positions; the window is [s, s + len1).
+constexpr int DF_BLOCKS = 6;
+template <int NW, bool RIGHT_TIES>
+MIA_HD inline int diag_step1_kmer(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2,
+                                  int* delta_out, int* best_out) {
+  *best_out = -1;
+  const int nblk = len2 / DF_K < DF_BLOCKS ? len2 / DF_K : DF_BLOCKS;
+  if (!ko.cnt || nblk < 3 || s < 0 || (int64_t)s + len1 > n_ref) return -2;
+  if (!all_bases(rp, s, (int64_t)s + len1)) return -2;
+  DiagScan<NW> sc;
+  if (!sc.load_read(read_packed, len2)) return -1;
+  const int fit = len1 - len2;
+  int best = 1 << 20, second = nblk, delta = -1;        // diagonals the table does not name: >= nblk mismatches
+  for (int b = 0; b < DF_BLOCKS; b++) {
+    if (b >= nblk) break;
+    const int o = (int)((int64_t)b * (len2 - DF_K) / (nblk - 1));       // first row of block b; blocks do not overlap (len2 >= 10 nblk)
+    int64_t idx = 0;
+    for (int t = 0; t < DF_K; t++) {
+      const int r = o + t;
+      idx |= (int64_t)((read_packed[r >> 1] >> ((r & 1) * 4)) & 3) << (2 * t);
+    }
+    const int n = ko.cnt[idx];
+    if (n > DF_KCAP) return -2;
+    for (int k = 0; k < DF_KCAP; k++) {
+      if (k >= n) break;
+      const int d = ko.pos[idx * DF_KCAP + k] - o - s;
+      if (d < 0 || d > fit || d == delta) continue;
+      sc.seek(rp, (int64_t)s + d);
+      const int m = sc.mismatches();
+      if (m < best || (m == best && d < delta)) { if (best < second) second = best; best = m; delta = d; }
+      else if (m < second) second = m;
+    }
+  }
+  *best_out = best < nblk ? best : nblk;               // a lower bound of the fewest mismatches on any diagonal, exact below nblk
+  if (best > 2 || (!RIGHT_TIES && second <= best)) return -1;
+  *delta_out = delta;
+  return best;
+}
+
 MIA_HD inline bool diag_examined(int len1, int len2) { return len2 >= 1 && len2 <= MAX_READ && len1 >= len2 && len1 <= DF_MAX_LEN1; }
 
+// the table first, the slide where the table cannot be used
+MIA_HD inline int diag_step1(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2,
+                             int* delta_out, int* best_out);
 MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, int* delta_out, int* best_out) {
   *best_out = -1;
   if (!diag_examined(len1, len2)) return -1;
@@ -393,10 +445,31 @@ MIA_HD inline int diag_step1(const RefPlanes& rp, int s, int len1, const uint8_t
     default: return diag_step1<4, false>(rp, s, len1, read_packed, len2, delta_out, best_out);
   }
 }
+MIA_HD inline int diag_step1(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2,
+                             int* delta_out, int* best_out) {
+  *best_out = -1;
+  if (!diag_examined(len1, len2)) return -1;
+  int k;
+  switch ((len2 + 63) >> 6) {
+    case 1: k = diag_step1_kmer<1, false>(rp, ko, n_ref, s, len1, read_packed, len2, delta_out, best_out); break;
+    case 2: k = diag_step1_kmer<2, false>(rp, ko, n_ref, s, len1, read_packed, len2, delta_out, best_out); break;
+    case 3: k = diag_step1_kmer<3, false>(rp, ko, n_ref, s, len1, read_packed, len2, delta_out, best_out); break;
+    default: k = diag_step1_kmer<4, false>(rp, ko, n_ref, s, len1, read_packed, len2, delta_out, best_out); break;
+  }
+  return k != -2 ? k : diag_step1(rp, s, len1, read_packed, len2, delta_out, best_out);
+}
 // the same against a whole strand of the (wrapped) reference, columns 0 .. len1-1: pass 1
-MIA_HD inline int strand_step1(const RefPlanes& rp, int len1, const uint8_t* read_packed, int len2, int* delta_out, int* best_out) {
+MIA_HD inline int strand_step1(const RefPlanes& rp, const KmerOcc& ko, int len1, const uint8_t* read_packed, int len2, int* delta_out, int* best_out) {
   *best_out = -1;
   if (len2 < 1 || len2 > MAX_READ || len1 < len2) return -1;
+  int k;
+  switch ((len2 + 63) >> 6) {
+    case 1: k = diag_step1_kmer<1, true>(rp, ko, len1, 0, len1, read_packed, len2, delta_out, best_out); break;
+    case 2: k = diag_step1_kmer<2, true>(rp, ko, len1, 0, len1, read_packed, len2, delta_out, best_out); break;
+    case 3: k = diag_step1_kmer<3, true>(rp, ko, len1, 0, len1, read_packed, len2, delta_out, best_out); break;
+    default: k = diag_step1_kmer<4, true>(rp, ko, len1, 0, len1, read_packed, len2, delta_out, best_out); break;
+  }
+  if (k != -2) return k;
   switch ((len2 + 63) >> 6) {
     case 1: return diag_step1<1, true>(rp, 0, len1, read_packed, len2, delta_out, best_out);
     case 2: return diag_step1<2, true>(rp, 0, len1, read_packed, len2, delta_out, best_out);
@@ -411,11 +484,12 @@ MIA_HD inline int strand_step1(const RefPlanes& rp, int len1, const uint8_t* rea
 // -1 = leave the read to the DP).  The loser's best diagonal must have >= K+1 mismatches: every path there then loses
 // more than 800 K (a diagonal >= 800 (K+1); anything with an event >= 1200, and for K == 2 pass1_step2 on the loser
 // excludes the event paths that lose <= 1600), so the winner's score 200 len - 800 K is strictly the larger one.
-MIA_HD inline int pass1_step1(const RefPlanes& fw, const RefPlanes& rc, int len1, const uint8_t* read_packed, int len2, int* strand, int* delta) {
+MIA_HD inline int pass1_step1(const RefPlanes& fw, const RefPlanes& rc, const KmerOcc& kf, const KmerOcc& kr, int len1, const uint8_t* read_packed,
+                              int len2, int* strand, int* delta) {
   int d[2] = {0, 0}, best[2], k[2];
-  k[0] = strand_step1(fw, len1, read_packed, len2, &d[0], &best[0]);
+  k[0] = strand_step1(fw, kf, len1, read_packed, len2, &d[0], &best[0]);
   if (best[0] < 0) return -1;                            // a read with N
-  k[1] = strand_step1(rc, len1, read_packed, len2, &d[1], &best[1]);
+  k[1] = strand_step1(rc, kr, len1, read_packed, len2, &d[1], &best[1]);
   const int x = best[0] < best[1] ? 0 : 1, y = 1 - x;     // best[] below 3 is exact, from 3 on a lower bound
   if (k[x] < 0 || best[y] <= k[x]) return -1;
   *strand = x;
@@ -449,6 +523,20 @@ MIA_HD inline bool diag_filter(const RefPlanes& rp, int s, int len1, const uint8
   int delta = 0, best = 0;
   const int k = diag_step1(rp, s, len1, read_packed, len2, &delta, &best);
   if (k < 0 || (k == 2 && !diag_step2(rp, s, len1, read_packed, len2))) return false;
+  out->delta = delta;
+  out->mismatches = k;
+  return true;
+}
+// the same with the reference's 10-mer table at hand (what k_diag_filter does)
+MIA_HD inline bool diag_filter(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2,
+                               DiagVerdict* out) {
+  int delta = 0, best = 0;
+  const int k = diag_step1(rp, ko, n_ref, s, len1, read_packed, len2, &delta, &best);
+  if (k < 0) return false;
+  if (k == 2) {
+    const int via_table = diag_step2_kmer(rp, ko, n_ref, s, len1, read_packed, len2);
+    if (via_table == 0 || (via_table < 0 && !diag_step2(rp, s, len1, read_packed, len2))) return false;
+  }
   out->delta = delta;
   out->mismatches = k;
   return true;

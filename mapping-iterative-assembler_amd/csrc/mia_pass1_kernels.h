@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_pass1_filter(Pass1Reads rs, RefPlanes f
     if (i < rs.n) {
       const int len2 = rs.len[i];
       int strand = 0, delta = 0;
-      const int k = pass1_step1(fw, rc, len1, rs.packed + rs.roff[i], len2, &strand, &delta);
+      const int k = pass1_step1(fw, rc, kf, kr, len1, rs.packed + rs.roff[i], len2, &strand, &delta);
       if (k == 2) {
         const int slot = atomicAdd(&n_cand, 1);
         cand[slot] = (int16_t)threadIdx.x; cand_delta[slot] = delta; cand_strand[slot] = (uint8_t)strand;

@@ -164,6 +164,26 @@ extern "C" int emu_align_quad_plain(int ng, const uint8_t* ref_codes, const int3
   return 0;
 }
 
+// 10-mer table of a code string in static buffers (sparse reset: a table is 20 MB, the tests call this thousands of times)
+struct EmuTable {
+  std::vector<int32_t> cnt, pos;
+  std::vector<int64_t> touched;
+  EmuTable() : cnt((size_t)mia::DF_KTAB, 0), pos((size_t)mia::DF_KTAB * mia::DF_KCAP, 0) {}
+  mia::KmerOcc build(const uint8_t* codes, int64_t n) {
+    for (int64_t idx : touched) cnt[(size_t)idx] = 0;
+    touched.clear();
+    for (int64_t p = 0; p < n; p++) {
+      const int64_t idx = mia::kmer_at(codes, n, p);
+      if (idx < 0) continue;
+      const int c = cnt[(size_t)idx]++;
+      if (c < mia::DF_KCAP) pos[(size_t)(idx * mia::DF_KCAP + c)] = (int32_t)p;
+      touched.push_back(idx);
+    }
+    return mia::KmerOcc{cnt.data(), pos.data()};
+  }
+};
+static EmuTable g_tab_a, g_tab_b;
+
 // The diagonal filter (csrc/diag_filter.h) as the kernel runs it: planes of the whole reference, the read as 4-bit codes
 // on a 4-byte boundary.  Returns 1 if the read's alignment in [ref_start, ref_start+len1) is proven to be the gap-free
 // diagonal *delta with *mismatches mismatches, 0 if the read is left to the DP.
@@ -178,8 +198,14 @@ extern "C" int emu_diag_filter(const uint8_t* ref_codes, int64_t n_codes, int re
   for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
   RefPlanes rp{lo.data(), hi.data(), ok.data()};
   DiagVerdict v{0, 0};
-  const bool won = diag_filter(rp, ref_start, len1, pb, len2, &v);
+  const KmerOcc ko = g_tab_a.build(ref_codes, n_codes);
+  const bool won = diag_filter(rp, ko, n_codes, ref_start, len1, pb, len2, &v);
   *delta = v.delta; *mismatches = v.mismatches;
+  // where the table applies, step 1 through it must see what the slide over all diagonals sees
+  int d1 = 0, b1 = 0, d2 = 0, b2 = 0;
+  const int k_table = diag_step1(rp, ko, n_codes, ref_start, len1, pb, len2, &d1, &b1);
+  const int k_slide = diag_step1(rp, ref_start, len1, pb, len2, &d2, &b2);
+  if (k_table != k_slide || (k_table >= 0 && d1 != d2)) return -7;
   return won ? 1 : 0;
 }
 
@@ -198,23 +224,9 @@ extern "C" int emu_pass1_filter(const uint8_t* fw_codes, const uint8_t* rc_codes
   uint8_t* pb = (uint8_t*)packed.data();
   for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
   RefPlanes fw{pl.data(), pl.data() + words, pl.data() + 2 * words}, rc{pl.data() + 3 * words, pl.data() + 4 * words, pl.data() + 5 * words};
-  const int k = pass1_step1(fw, rc, len1, pb, len2, strand, delta);
-  if (k == 2) {
-    // the two 10-mer tables, as mia_hip_pass1 builds them
-    static std::vector<int32_t> cf((size_t)DF_KTAB, 0), pf((size_t)DF_KTAB * DF_KCAP, 0), cr((size_t)DF_KTAB, 0), pr((size_t)DF_KTAB * DF_KCAP, 0);
-    std::vector<int64_t> tf, tr;
-    for (int64_t p = 0; p < len1; p++) {
-      int64_t idx = kmer_at(fw_codes, len1, p);
-      if (idx >= 0) { const int c = cf[(size_t)idx]++; if (c < DF_KCAP) pf[(size_t)(idx * DF_KCAP + c)] = (int32_t)p; tf.push_back(idx); }
-      idx = kmer_at(rc_codes, len1, p);
-      if (idx >= 0) { const int c = cr[(size_t)idx]++; if (c < DF_KCAP) pr[(size_t)(idx * DF_KCAP + c)] = (int32_t)p; tr.push_back(idx); }
-    }
-    KmerOcc kf{cf.data(), pf.data()}, kr{cr.data(), pr.data()};
-    const bool ok = pass1_step2(fw, rc, kf, kr, len1, pb, len2);
-    for (int64_t idx : tf) cf[(size_t)idx] = 0;
-    for (int64_t idx : tr) cr[(size_t)idx] = 0;
-    if (!ok) return -1;
-  }
+  const KmerOcc kf0 = g_tab_a.build(fw_codes, len1), kr0 = g_tab_b.build(rc_codes, len1);
+  const int k = pass1_step1(fw, rc, kf0, kr0, len1, pb, len2, strand, delta);
+  if (k == 2 && !pass1_step2(fw, rc, kf0, kr0, len1, pb, len2)) return -1;
   return k;
 }
 

@@ -21,6 +21,7 @@ def run_filter(emul, ref, s, len1, read):
     d, k = C.c_int(0), C.c_int(0)
     won = emul.emu_diag_filter(rc.ctypes.data_as(C.c_void_p), C.c_int64(len(ref)), s, len1, c2.ctypes.data_as(C.c_void_p), len(read),
                                C.byref(d), C.byref(k))
+    assert won in (0, 1), "step 1 through the 10-mer table and step 1 by sliding disagree"
     return won, d.value, k.value
 
 
