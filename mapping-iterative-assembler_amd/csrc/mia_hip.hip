@@ -75,6 +75,7 @@ struct mia_hip_ctx {
   double plain_ms = 0; int64_t plain_launches = 0; int64_t plain_retried = 0, plain_total = 0;
   // the diagonal filter (diag_filter.h): flat matrix only
   bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
+  bool ref_mostly_bases = true;            // fewer than 2 % of the reference columns are N
   bool flat = false; int use_filter = 1;   // MIA_HIP_NO_DIAG_FILTER=1 sends every read to the DP kernels
   int64_t pre_cull_records = 0, pre_cull_links = 0; bool pre_cull_valid = false;   // mia_hip_score_sums' by-products
   int32_t *d_kocc_cnt = nullptr, *d_kocc_pos = nullptr;   // 10-mer table of the reference (diag_filter.h: KmerOcc)
@@ -449,8 +450,11 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   // add_ref_wrap (src/mia.c:657-689): first min(L,256) bases appended when circular
   const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl;
   std::vector<uint8_t> codes((size_t)wrap + 64, 4);
-  for (int i = 0; i < L; i++) codes[i] = base_code(new_ref[i]);
+  int64_t n_other = 0;
+  for (int i = 0; i < L; i++) { codes[i] = base_code(new_ref[i]); n_other += codes[i] > 3; }
   for (int i = 0; i < wl; i++) codes[L + i] = codes[i];
+  // a reference full of ambiguity codes (mt311 itself: every other column) leaves the diagonal filter nothing to decide
+  ctx->ref_mostly_bases = n_other * 50 <= L;
   if ((int)codes.size() > ctx->ref_cap) {
     if (dev_alloc(ctx, &ctx->d_ref, codes.size() * 2)) return MIA_HIP_ERR_NOMEM;
     ctx->ref_cap = (int)codes.size() * 2;
@@ -479,7 +483,7 @@ static int align_all(mia_hip_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 2) * 4, ctx->stream));
   int32_t* d_retry_count = ctx->d_bins + 3 * N_BINS + 1;
   const int tb = 256, gb = (int)((n + (int64_t)tb * PLAN_PER - 1) / ((int64_t)tb * PLAN_PER));
-  const int filtered = ctx->flat && ctx->use_filter;
+  const int filtered = ctx->flat && ctx->use_filter && ctx->ref_mostly_bases;
   uint32_t h_filter_n = 0;
   if (filtered) {
     // reads whose alignment is provably one gap-free diagonal never reach the DP kernels (diag_filter.h)
@@ -678,7 +682,7 @@ extern "C" int mia_hip_align_windows(mia_hip_ctx* ctx, const char* ref, int64_t 
     HIPCHK(hipMemcpyAsync(ctx->d_ae, ae.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   }
   // not a reference the consensus path can use: cull / tally need a realign first
-  ctx->L = (int)ref_len; ctx->wrap = (int)ref_len; ctx->have_ref = false; ctx->explicit_win = 1;
+  ctx->L = (int)ref_len; ctx->wrap = (int)ref_len; ctx->have_ref = false; ctx->explicit_win = 1; ctx->ref_mostly_bases = true;
   const int rcode = align_all(ctx);
   HIPCHK(hipStreamSynchronize(ctx->stream));   // as / ae / codes are host buffers of this call
   return rcode;
@@ -1585,7 +1589,9 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   // The diagonal filter (diag_filter.h) first, when its premises hold: flat matrix and no k-mer mask (a masked DP is a
   // different recurrence).  It decides most reads by bit-parallel comparison against every diagonal of both strands;
   // the whole-reference DP then runs on what is left.
-  const bool filtered = ctx->flat && ctx->use_filter && kmer_len <= 0 && len1 >= max_len;
+  int64_t p1_other = 0;
+  for (int i = 0; i < L; i++) p1_other += cf[(size_t)i] > 3;
+  const bool filtered = ctx->flat && ctx->use_filter && kmer_len <= 0 && len1 >= max_len && p1_other * 50 <= L;
   int64_t n_dp = n;
   ctx->pass1_filtered = 0;
   if (e == hipSuccess) {
