@@ -34,16 +34,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 BYTES_PER_READ = 182      # 50 B packed bases + 16 B meta in, 16 B result + 100 B script out
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # Memory-side bytes per read and VALU utilisation of the three realignment kernels, measured with rocprofv3 --pmc in
-# separate passes for FETCH_SIZE, WRITE_SIZE and the SQ set (profiles/r01/pmc/v14_summary.json; counters as reported, no
+# separate passes for FETCH_SIZE, WRITE_SIZE and the SQ set (profiles/r01/pmc/v14_summary.json, v17_summary.json for the
+# filter; counters as reported, no
 # width correction; utilisation = SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 / 4)):
 #   k_align_quad        661 749 KB + 1 279 506 KB per launch of 95.4 k reads: the 16-bit trace band written to the
 #                       per-workgroup slabs and read back along the path
 #   k_align_quad_plain  111 680 KB + 252 604 KB per 1 M reads: no trace, about twice the algorithmic 182 B/read
-#   k_diag_filter       38 373 KB + 209 485 KB per 1 M reads: packed reads in, results and scripts out
+#   k_diag_filter       77 281 KB + 204 036 KB per 1 M reads: packed reads and 10-mer table look-ups in, results and scripts out
 PMC = {
     "k_align_quad": {"traffic_per_read": (661749.34 + 1279506.11) * 1024 / 95_407, "valu_utilisation": 0.79},
     "k_align_quad_plain": {"traffic_per_read": (111680.25 + 252603.66) * 1024 / 1_000_000, "valu_utilisation": 0.90},
-    "k_diag_filter": {"traffic_per_read": (38372.81 + 209485.37) * 1024 / 1_000_000, "valu_utilisation": 0.51},
+    "k_diag_filter": {"traffic_per_read": (77280.98 + 204036.09) * 1024 / 1_000_000, "valu_utilisation": 0.69},
 }
 
 
