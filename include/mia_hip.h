@@ -265,6 +265,8 @@ int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 /* reads of the last mia_hip_pass1 call decided by the diagonal filter (csrc/diag_filter.h: flat matrix, no k-mer mask)
  * instead of the whole-reference DP */
 int mia_hip_pass1_filtered(mia_hip_ctx *ctx, int64_t *reads);
+/* ... and those decided by windowed alignment around their 10-mer anchors (csrc/mia_pass1_kernels.h: k_pass1_anchor) */
+int mia_hip_pass1_anchored(mia_hip_ctx *ctx, int64_t *reads);
 
 #ifdef __cplusplus
 }

@@ -97,7 +97,7 @@ struct mia_hip_ctx {
   // pinned staging: small copies to and from pageable memory wait for the stream, pinned ones do not
   unsigned char* h_pin = nullptr; static constexpr size_t PIN_BYTES = 1 << 20, PIN_MISC = 64 << 10;
   double align_ms = 0; int64_t align_launches = 0;
-  double pass1_ms = 0; int64_t pass1_filtered = 0;   // reads of the last pass-1 call that the diagonal filter decided
+  double pass1_ms = 0; int64_t pass1_filtered = 0, pass1_anchored = 0;   // reads of the last pass-1 call that the diagonal filter decided
   bool consensus_done = false;
   int64_t trim_escapes = 0;   // reads of the last mia_hip_trim call that took the exact scalar path
   int64_t ins_total_host = 0;
@@ -626,9 +626,9 @@ static int align_all(mia_hip_ctx* ctx) {
     std::vector<int64_t> soff((size_t)n_wide);
     int64_t total = 0;
     for (int t = 0; t < n_wide; t++) {
-      HIPCHK(hipMemcpy(&as[t], ctx->d_as + wl[t], 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&ae[t], ctx->d_ae + wl[t], 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&ln[t], ctx->d_len + wl[t], 2, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&as[t], ctx->rs.as + wl[t], 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&ae[t], ctx->rs.ae + wl[t], 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&ln[t], ctx->rs.len + wl[t], 2, hipMemcpyDeviceToHost));
       int s, n1;
       read_window(ref, as[t], ae[t], ln[t], &s, &n1);
       soff[t] = total;
@@ -1448,6 +1448,25 @@ static void build_kmer_lists(const std::string& seq, int k, int soft_mask, std::
   pos.push_back(0);
 }
 
+// Lets align_all run on a borrowed read set and reference (the anchored part of pass 1) and puts the context back as it was.
+struct AlignBorrow {
+  mia_hip_ctx* c;
+  ReadSet rs; int32_t *bin_of, *list, *wide, *retry; int max_len; uint8_t* d_ref; int L, wrap, explicit_win, use_filter;
+  bool aligned, culled, tallied, pre_cull_valid, ref_mostly_bases;
+  int64_t plain_total, plain_retried, filter_seen, filter_proven;
+  explicit AlignBorrow(mia_hip_ctx* ctx)
+      : c(ctx), rs(ctx->rs), bin_of(ctx->d_bin_of), list(ctx->d_list), wide(ctx->d_wide_list), retry(ctx->d_retry_list), max_len(ctx->max_len),
+        d_ref(ctx->d_ref), L(ctx->L), wrap(ctx->wrap), explicit_win(ctx->explicit_win), use_filter(ctx->use_filter), aligned(ctx->aligned),
+        culled(ctx->culled), tallied(ctx->tallied), pre_cull_valid(ctx->pre_cull_valid), ref_mostly_bases(ctx->ref_mostly_bases),
+        plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven) {}
+  ~AlignBorrow() {
+    c->rs = rs; c->d_bin_of = bin_of; c->d_list = list; c->d_wide_list = wide; c->d_retry_list = retry; c->max_len = max_len; c->d_ref = d_ref;
+    c->L = L; c->wrap = wrap; c->explicit_win = explicit_win; c->use_filter = use_filter; c->aligned = aligned; c->culled = culled;
+    c->tallied = tallied; c->pre_cull_valid = pre_cull_valid; c->ref_mostly_bases = ref_mostly_bases; c->plain_total = plain_total;
+    c->plain_retried = plain_retried; c->filter_seen = filter_seen; c->filter_proven = filter_proven;
+  }
+};
+
 extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len, int circular, int kmer_len, int soft_mask,
                              int64_t n, const char* bases, const int64_t* offsets, int32_t* score, uint8_t* rc, int32_t* as,
                              int32_t* ae, uint8_t* flags) {
@@ -1594,6 +1613,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   const bool filtered = ctx->flat && ctx->use_filter && kmer_len <= 0 && len1 >= max_len && p1_other * 50 <= L;
   int64_t n_dp = n;
   ctx->pass1_filtered = 0;
+  ctx->pass1_anchored = 0;
   if (e == hipSuccess) {
     Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
     if (get_events(ctx, &pe0, &pe1) == 0) (void)hipEventRecord(pe0, ctx->stream);
@@ -1624,6 +1644,69 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       ctx->pass1_filtered = n - n_dp;
       if (timing) fprintf(stderr, "[mia_hip_pass1] diagonal filter: %lld of %lld reads decided\n", (long long)(n - n_dp), (long long)n);
     }
+    // Anchored stage (mia_pass1_kernels.h): what the filter left over is aligned in +-50 windows around the places where
+    // six 10-mers of the read occur -- provably the same result as the whole-strand DP when the budget check of
+    // k_pass1_select holds; everything else goes on to k_pass1.  Needs both strands free of N (a 10-mer with an N is not
+    // in the table and an N column costs less than a mismatch).
+    const int32_t* dp_list = filtered ? d_todo : nullptr;
+    if (e == hipSuccess && filtered && n_dp > 0 && p1_other == 0 && d_p1kcnt && !getenv("MIA_HIP_NO_ANCHOR")) {
+      const int64_t m = n_dp * P1A_SLOTS;
+      const int stride = (max_len + 3) & ~3;
+      uint32_t *w_roff = nullptr, *w_status = nullptr, *d_nrest = nullptr;
+      uint16_t* w_len = nullptr;
+      uint8_t *w_rc = nullptr, *w_sk = nullptr, *d_ref2 = nullptr;
+      int32_t *w_as = nullptr, *w_ae = nullptr, *w_score = nullptr, *w_refstart = nullptr, *w_bin = nullptr, *w_list = nullptr, *w_wide = nullptr,
+              *w_retry = nullptr, *d_rest = nullptr, *w_bound = nullptr, *w_budget = nullptr;
+      int16_t *w_abr = nullptr, *w_cols = nullptr;
+      ScopeFree g2;
+      for (void** pp : {(void**)&w_roff, (void**)&w_status, (void**)&d_nrest, (void**)&w_len, (void**)&w_rc, (void**)&w_sk, (void**)&d_ref2, (void**)&w_as,
+                        (void**)&w_ae, (void**)&w_score, (void**)&w_refstart, (void**)&w_bin, (void**)&w_list, (void**)&w_wide, (void**)&w_retry,
+                        (void**)&d_rest, (void**)&w_abr, (void**)&w_cols, (void**)&w_bound, (void**)&w_budget})
+        g2.watch(pp);
+      if (dev_alloc(ctx, &w_roff, (size_t)m) || dev_alloc(ctx, &w_status, (size_t)m) || dev_alloc(ctx, &d_nrest, 1) || dev_alloc(ctx, &w_len, (size_t)m) ||
+          dev_alloc(ctx, &w_rc, (size_t)m) || dev_alloc(ctx, &w_sk, (size_t)m) || dev_alloc(ctx, &d_ref2, (size_t)2 * len1 + 64) ||
+          dev_alloc(ctx, &w_as, (size_t)m) || dev_alloc(ctx, &w_ae, (size_t)m) || dev_alloc(ctx, &w_score, (size_t)m) ||
+          dev_alloc(ctx, &w_refstart, (size_t)m) || dev_alloc(ctx, &w_bin, (size_t)m) || dev_alloc(ctx, &w_list, (size_t)m + 4 * N_BINS) ||
+          dev_alloc(ctx, &w_wide, (size_t)m) || dev_alloc(ctx, &w_retry, (size_t)m) || dev_alloc(ctx, &d_rest, (size_t)n_dp) ||
+          dev_alloc(ctx, &w_abr, (size_t)m) || dev_alloc(ctx, &w_cols, (size_t)m * stride) || dev_alloc(ctx, &w_bound, (size_t)n_dp) ||
+          dev_alloc(ctx, &w_budget, (size_t)n_dp))
+        return MIA_HIP_ERR_NOMEM;
+      HIPCHK(hipMemsetAsync(w_rc, 0, (size_t)m, ctx->stream));
+      HIPCHK(hipMemsetAsync(w_abr, 0, (size_t)m * 2, ctx->stream));
+      HIPCHK(hipMemsetAsync(w_status, 0, (size_t)m * 4, ctx->stream));
+      HIPCHK(hipMemsetAsync(w_score, 0, (size_t)m * 4, ctx->stream));
+      HIPCHK(hipMemsetAsync(d_nrest, 0, 4, ctx->stream));
+      HIPCHK(hipMemsetAsync(d_ref2, 4, (size_t)2 * len1 + 64, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d_ref2, d_cf, (size_t)len1, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d_ref2 + len1, d_cr, (size_t)len1, hipMemcpyDeviceToDevice, ctx->stream));
+      KmerOcc kf{d_p1kcnt, d_p1kpos}, kr{d_p1kcnt + DF_KTAB, d_p1kpos + DF_KTAB * DF_KCAP};
+      hipLaunchKernelGGL(k_pass1_anchor, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, kf, kr, len1, w_roff, w_len,
+                         w_sk, w_as, w_ae, w_bound, w_budget);
+      HIPCHK(hipGetLastError());
+      int rc_inner;
+      {
+        AlignBorrow borrow(ctx);
+        ReadSet& r = ctx->rs;
+        r.n = m; r.packed = d_packed; r.roff = w_roff; r.len = w_len; r.rc = w_rc; r.sk = w_sk; r.as = w_as; r.ae = w_ae; r.score = w_score;
+        r.refstart = w_refstart; r.abr = w_abr; r.status = w_status; r.cols = w_cols; r.stride = stride;
+        ctx->d_bin_of = w_bin; ctx->d_list = w_list; ctx->d_wide_list = w_wide; ctx->d_retry_list = w_retry; ctx->max_len = max_len;
+        ctx->d_ref = d_ref2; ctx->L = 2 * len1; ctx->wrap = 2 * len1; ctx->explicit_win = 1; ctx->use_filter = 0;
+        rc_inner = align_all(ctx);
+      }
+      if (rc_inner != MIA_HIP_OK) return rc_inner;
+      hipLaunchKernelGGL(k_pass1_select, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, len1, L, w_sk, w_score, w_as,
+                         w_ae, w_abr, w_status, w_bound, w_budget, d_rest, d_nrest);
+      HIPCHK(hipGetLastError());
+      uint32_t h_nrest = 0;
+      HIPCHK(hipMemcpyAsync(&h_nrest, d_nrest, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      // the survivors' list replaces the filter's (d_todo is at least as long)
+      HIPCHK(hipMemcpyAsync(d_todo, d_rest, (size_t)h_nrest * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      ctx->pass1_anchored = n_dp - h_nrest;
+      if (timing) fprintf(stderr, "[mia_hip_pass1] anchored windows: %lld of %lld left-over reads decided\n", (long long)(n_dp - h_nrest), (long long)n_dp);
+      n_dp = h_nrest;
+    }
+    (void)dp_list;
     if (e == hipSuccess && n_dp > 0) {
       const int64_t g = grid < n_dp ? grid : n_dp;
       hipLaunchKernelGGL(kfn, dim3((unsigned)g), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
@@ -1766,5 +1849,11 @@ extern "C" int mia_hip_pass1_time(mia_hip_ctx* ctx, double* kernel_ms) {
 extern "C" int mia_hip_pass1_filtered(mia_hip_ctx* ctx, int64_t* reads) {
   if (!ctx || !reads) return MIA_HIP_ERR_ARG;
   *reads = ctx->pass1_filtered;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_pass1_anchored(mia_hip_ctx* ctx, int64_t* reads) {
+  if (!ctx || !reads) return MIA_HIP_ERR_ARG;
+  *reads = ctx->pass1_anchored;
   return MIA_HIP_OK;
 }

@@ -114,6 +114,123 @@ __global__ __launch_bounds__(256) void k_pass1_filter(Pass1Reads rs, RefPlanes f
   if ((int)threadIdx.x < n_left) todo[base + threadIdx.x] = (int32_t)(i0 + left[threadIdx.x]);
 }
 
+// ---- anchored pass 1 for the reads the filter left over (flat matrix, both strands free of N, no k-mer mask) -----------
+// Pigeonhole again, now for ALIGNMENTS: a path through the DP matrix that loses no more than B against 200 x len has at
+// most B/800 defects (a mismatch costs 800; a gap at least 1200 and 200 + 200 per skipped row), so if the read is cut into
+// six 10-mers and B < 4600 at least one 10-mer is crossed without any defect -- the path runs through a place where that
+// 10-mer occurs in the reference, and the table lists all of those ("anchors").  From an anchor on diagonal d the path
+// cannot stray further than (B - 1000) / 200 < 18 diagonals.  So every alignment that can compete with one of score
+// 200 len - B lies inside a +-50 window around a cluster of anchors, and the best over those few windows IS the best
+// over the whole strand: the windowed kernels (mia_hip_align_windows' pipeline) do in ~10 ns what k_pass1 does in 900.
+// k_pass1_anchor finds at most two clusters per read and writes their windows (absolute positions in the string
+// [forward strand | reverse strand]); k_pass1_select checks the budget on the result, applies max_sg_score's first
+// maximum and sg_align's strand rule (src/mia.c:1549) and hands everything it cannot vouch for to k_pass1.
+constexpr int P1A_SLOTS = 2;       // windows per read that are aligned
+constexpr int P1A_CLUSTERS = 8;    // clusters of anchors a read may have (most of them one stray 10-mer)
+constexpr int P1A_BLOCKS = 9;      // 10-mers cut out of the read (fewer for reads under 90 bases, at least 6)
+constexpr int P1A_JOIN = 20;       // anchors this close (in diagonals) share a window
+constexpr int P1A_MARGIN = 50;     // columns around a cluster, as reiterate_assembly's REALIGN_BUFFER
+// With nb blocks the budget is 800 nb - 400: fewer than nb defects, and 200 in hand because the first column of a window
+// may give a late start its substitution score back (src/mia.c: column 0 against the "new start" branch elsewhere).  A path
+// that loses no more strays at most (800*9 - 400 - 1000) / 200 = 29 diagonals from its anchor: inside the margin.
+// Clusters in which a single block occurs are not aligned: a path through them alone keeps at most as many blocks intact
+// as occur in such clusters, which bounds it by 200 len - 800 (nb - that many) + 200; k_pass1_select wants more (w_bound).
+
+__global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32_t* todo, int64_t n_todo, KmerOcc kf, KmerOcc kr, int32_t len1,
+                                                      uint32_t* w_roff, uint16_t* w_len, uint8_t* w_sk, int32_t* w_as, int32_t* w_ae,
+                                                      int32_t* w_bound, int32_t* w_budget) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_todo) return;
+  const int64_t i = todo[t];
+  const int len2 = rs.len[i];
+  const uint8_t* rp = rs.packed + rs.roff[i];
+  const int nb = len2 / DF_K < P1A_BLOCKS ? len2 / DF_K : P1A_BLOCKS;
+  int n_cl = 0, c_strand[P1A_CLUSTERS], c_lo[P1A_CLUSTERS], c_hi[P1A_CLUSTERS], c_mask[P1A_CLUSTERS];
+  bool usable = nb >= 6;
+  for (int r = 0; usable && r < len2; r++) if (((rp[r >> 1] >> ((r & 1) * 4)) & 15) > 3) usable = false;     // a read with N
+  for (int st = 0; usable && st < 2; st++) {
+    const KmerOcc& ko = st ? kr : kf;
+    for (int b = 0; usable && b < nb; b++) {
+      const int o = (int)((int64_t)b * (len2 - DF_K) / (nb - 1));
+      int64_t idx = 0;
+      for (int q = 0; q < DF_K; q++) { const int r = o + q; idx |= (int64_t)((rp[r >> 1] >> ((r & 1) * 4)) & 3) << (2 * q); }
+      const int n = ko.cnt[idx];
+      if (n > DF_KCAP) { usable = false; break; }
+      for (int k = 0; k < n; k++) {
+        const int d = ko.pos[idx * DF_KCAP + k] - o;          // diagonal of this anchor (may hang over either end of the strand)
+        int hit = -1;
+        for (int c = 0; c < n_cl; c++) if (c_strand[c] == st && d >= c_lo[c] - P1A_JOIN && d <= c_hi[c] + P1A_JOIN) hit = c;
+        if (hit >= 0) {
+          if (d < c_lo[hit]) c_lo[hit] = d;
+          if (d > c_hi[hit]) c_hi[hit] = d;
+          c_mask[hit] |= 1 << b;
+          if (c_hi[hit] - c_lo[hit] > 100) usable = false;
+        } else if (n_cl < P1A_CLUSTERS) { c_strand[n_cl] = st; c_lo[n_cl] = d; c_hi[n_cl] = d; c_mask[n_cl] = 1 << b; n_cl++; }
+        else usable = false;
+      }
+    }
+  }
+  // (two clusters that grew towards each other stay two overlapping windows: harmless)
+  int n_slot = 0, weak = 0;
+  int s_strand[P1A_SLOTS] = {0, 0}, s_lo[P1A_SLOTS] = {0, 0}, s_hi[P1A_SLOTS] = {0, 0};
+  for (int c = 0; usable && c < n_cl; c++) {
+    if (__popc((unsigned)c_mask[c]) >= 2) {
+      if (n_slot < P1A_SLOTS) { s_strand[n_slot] = c_strand[c]; s_lo[n_slot] = c_lo[c]; s_hi[n_slot] = c_hi[c]; n_slot++; }
+      else usable = false;
+    } else weak |= c_mask[c];
+  }
+  // A path that runs through no aligned cluster keeps intact only blocks that occur in the weak clusters (it may visit
+  // several of them): at most popc(weak) of the nb, every other block costs it 800.
+  const int bound = weak ? FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * (nb - __popc((unsigned)weak)) + FLAT_MATCH : INT32_MIN;
+  if (n_slot == 0) usable = false;                             // nothing strong to align: nothing bounds the optimum from below
+  for (int c = 0; c < P1A_SLOTS; c++) {
+    const int64_t slot = t * P1A_SLOTS + c;
+    w_roff[slot] = rs.roff[i];
+    w_len[slot] = (uint16_t)len2;
+    int ws = 0, we = 0;
+    if (usable && c < n_slot) {
+      ws = s_lo[c] - P1A_MARGIN; if (ws < 0) ws = 0;
+      we = s_hi[c] + len2 + P1A_MARGIN; if (we > len1) we = len1;     // exclusive
+      if (we - ws < len2) usable = false;                            // the read does not fit: leave it to k_pass1
+    }
+    w_as[slot] = (c < n_slot && s_strand[c] ? len1 : 0) + ws;        // the reverse strand follows the forward one
+    w_ae[slot] = (c < n_slot && s_strand[c] ? len1 : 0) + we - 1;
+  }
+  for (int c = 0; c < P1A_SLOTS; c++) w_sk[t * P1A_SLOTS + c] = (uint8_t)(usable && c < n_slot);
+  w_bound[t] = bound;
+  w_budget[t] = (FLAT_MATCH - FLAT_MISMATCH) * nb - 2 * FLAT_MATCH;
+}
+
+// after the windowed alignment of the slots: the read's result, or its place in the list of k_pass1
+__global__ __launch_bounds__(256) void k_pass1_select(Pass1Reads rs, const int32_t* todo, int64_t n_todo, int32_t len1, int32_t L, const uint8_t* w_sk,
+                                                      const int32_t* w_score, const int32_t* w_as, const int32_t* w_ae, const int16_t* w_abr,
+                                                      const uint32_t* w_status, const int32_t* w_bound, const int32_t* w_budget, int32_t* rest,
+                                                      uint32_t* n_rest) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_todo) return;
+  const int64_t i = todo[t];
+  const int len2 = rs.len[i];
+  int best[2] = {INT32_MIN, INT32_MIN}, abc[2] = {0, 0}, aec[2] = {0, 0};
+  bool good = false, bad = false;
+  for (int c = 0; c < P1A_SLOTS; c++) {
+    const int64_t slot = t * P1A_SLOTS + c;
+    if (!w_sk[slot]) continue;
+    good = true;
+    const uint32_t stt = w_status[slot];
+    if ((stt & (ST_TOO_LONG | ST_ESCAPE | ST_BAND)) || w_abr[slot] != 0) bad = true;   // (a clipped start is left to the whole-strand DP)
+    const int st = w_as[slot] >= len1 ? 1 : 0, base = st ? len1 : 0;
+    const int sc = w_score[slot], a = w_as[slot] - base, e = w_ae[slot] - base;
+    if (sc > best[st] || (sc == best[st] && e < aec[st])) { best[st] = sc; abc[st] = a; aec[st] = e; }     // first maximum of the last row
+  }
+  const int st = best[0] > best[1] ? 0 : 1;                        // src/mia.c:1549: the reverse strand on a tie
+  // within the budget of its blocks, and better than anything the clusters that were not aligned could hold
+  if (good && !bad && FLAT_MATCH * len2 - best[st] <= w_budget[t] && best[st] > w_bound[t]) {
+    pass1_store(rs, i, L, st, best[st], abc[st], aec[st], ST_OK);
+  } else {
+    rest[atomicAdd(n_rest, 1u)] = (int32_t)i;
+  }
+}
+
 template <int CPL>
 __global__ __launch_bounds__(64, 4) void k_pass1(Pass1Reads rs, const uint8_t* ref_fw, const uint8_t* ref_rc, int32_t len1, int32_t L,
                                                const int32_t* pssm_fwd, PackParams pk, KmerIndex kx, unsigned char* trace_slabs,
