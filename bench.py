@@ -274,7 +274,8 @@ def main():
             t1 = time.perf_counter()
             sc, _, _, _, fl = hip.pass1(r1, True, seq.reshape(-1), offsets[: m + 1], k)
             p1[label] = {"reads_per_s": m / (time.perf_counter() - t1), "kernel_reads_per_s": m / (hip.pass1_time() * 1e-3),
-                         "reads": m, "kept": int((fl & 2).astype(bool).sum()), "decided_by_diag_filter": hip.pass1_filtered()}
+                         "reads": m, "kept": int((fl & 2).astype(bool).sum()), "decided_by_diag_filter": hip.pass1_filtered(),
+                         "decided_by_anchored_windows": hip.pass1_anchored()}
         out["pass1"] = p1
         if phase:
             out["phase_ms_per_step"] = {k: v / (a.steps + a.warmup) * 1e3 for k, v in phase.items()}

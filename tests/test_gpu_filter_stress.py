@@ -149,3 +149,57 @@ def test_pass1_on_adversarial_references(seed):
         assert decided == 0 if is_off else decided >= 0, decided
     for x, y in zip(out[0], out[1]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("seed,read_len,circular", [(21, 100, True), (22, 64, True), (23, 150, False), (24, 90, True)])
+def test_pass1_anchored_windows_at_their_limits(seed, read_len, circular):
+    """anchored pass 1 (k_pass1_anchor / k_pass1_select): reads with 0..9 substitutions (the budget of nine 10-mer blocks
+    ends at eight defects), deletions and insertions of 1..40 bases (a path may stray 29 diagonals from its anchor),
+    reads that hang over the ends of a linear reference, reads across the origin of a circular one, a reference with
+    repeated blocks (several anchor clusters, stray 10-mers on the other strand).  Same answers as the whole-strand DP."""
+    import mia_amd
+    rng = np.random.default_rng(seed)
+    L = 6000
+    base = rng.choice(np.frombuffer(b"ACGT", np.uint8), L).astype(np.uint8)
+    # repeated blocks, some reverse-complemented: anchors in several places and on both strands
+    for _ in range(12):
+        ln = int(rng.integers(15, 140))
+        src, dst = int(rng.integers(0, L - ln)), int(rng.integers(0, L - ln))
+        blk = base[src:src + ln].copy()
+        if rng.random() < 0.4:
+            blk = COMP[blk[::-1]]
+        hit = rng.random(ln) < 0.03
+        blk[hit] = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(hit.sum()))
+        base[dst:dst + ln] = blk
+    n = 40_000
+    ext = np.concatenate([base, base]) if circular else np.concatenate([rng.choice(np.frombuffer(b"ACGT", np.uint8), 60), base,
+                                                                        rng.choice(np.frombuffer(b"ACGT", np.uint8), 160)]).astype(np.uint8)
+    start = rng.integers(0, L if circular else L + 120 - read_len, n)
+    reads = np.empty((n, read_len), np.uint8)
+    for i in range(n):
+        t = ext[start[i]: start[i] + read_len + 45].copy()
+        kind = i % 5
+        if kind == 1:                                   # deletion from the read's point of view
+            p, g = int(rng.integers(5, read_len - 5)), int(rng.choice([1, 2, 3, 5, 10, 17, 28, 29, 30, 40]))
+            t = np.concatenate([t[:p], t[p + g:]])
+        elif kind == 2:                                 # insertion
+            p, g = int(rng.integers(5, read_len - 5)), int(rng.choice([1, 2, 3, 5, 10, 17, 28, 29, 30]))
+            t = np.concatenate([t[:p], rng.choice(np.frombuffer(b"ACGT", np.uint8), g), t[p:]])
+        r = t[:read_len].copy()
+        k = int(rng.integers(0, 10)) if kind != 4 else int(rng.integers(0, 3))
+        for p in rng.choice(read_len, k, replace=False):
+            r[p] = rng.choice([b for b in b"ACGT" if b != r[p]])
+        reads[i] = r
+    flip = rng.random(n) < 0.5
+    reads[flip] = COMP[reads[flip][:, ::-1]]
+    off = np.arange(n + 1, dtype=np.int64) * read_len
+    refs = base.tobytes().decode()
+    out = []
+    for is_off, hip in contexts(mia_amd):
+        out.append(hip.pass1(refs, circular, reads.reshape(-1), off, -1))
+        if not is_off:
+            assert hip.pass1_anchored() > 0.15 * n, (hip.pass1_filtered(), hip.pass1_anchored())
+    names = ("score", "rc", "as", "ae", "flags")
+    for nm, x, y in zip(names, out[0], out[1]):
+        bad = np.nonzero(x != y)[0]
+        assert len(bad) == 0, (nm, bad[:5], x[bad[:5]], y[bad[:5]])

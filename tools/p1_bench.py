@@ -41,9 +41,9 @@ def main():
     wall = time.perf_counter() - t0
     ms = hip.pass1_time()
     print("reads %d k %d: kernel %.2f ms (%.0f reads/s), wall %.1f ms (%.0f reads/s), kept %d, mean score %.1f, strand agreement %.4f, "
-          "decided by the diagonal filter %d"
+          "decided by the diagonal filter %d, by anchored windows %d"
           % (n, k, ms, n / ms * 1e3, wall * 1e3, n / wall, int(((fl & 2) != 0).sum()), float(sc.mean()), float((rcs.astype(bool) == rc).mean()),
-             hip.pass1_filtered()))
+             hip.pass1_filtered(), hip.pass1_anchored()))
 
 
 if __name__ == "__main__":
