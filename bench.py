@@ -261,25 +261,26 @@ def main():
                                  "182 algorithmic HBM bytes per read (SURVEY 8d) put them at a fraction of a percent of the HBM roof "
                                  "by construction; the trace kernel moves ~21 KB/read of trace band on top; see DESIGN.md 3.0-3.1"},
         }
-        # pass 1 (new_kmer_filter + sg_align over the whole wrapped reference, both strands), reported separately
-        import gen_data
-        m = min(n, 200_000)
-        seq = np.where(rc[:m, None] == 1, gen_data._COMP[stored[:m, ::-1]], stored[:m]).astype(np.uint8)   # as sequenced
-        p1 = {}
-        # mt311 itself carries an ambiguity code in every other column (N for the aligner); "plain_ref" is the same
-        # sequence with those resolved, the usual kind of reference, where the diagonal filter decides most reads
-        plain_ref = gen_data.resolve_individual(ref)
-        for label, k, r1 in (("k12", 12, ref), ("no_kmer", -1, ref), ("no_kmer_plain_ref", -1, plain_ref)):
-            hip.pass1(r1, True, seq[:256].reshape(-1), offsets[:257], k)          # warm-up
-            t1 = time.perf_counter()
-            sc, _, _, _, fl = hip.pass1(r1, True, seq.reshape(-1), offsets[: m + 1], k)
-            p1[label] = {"reads_per_s": m / (time.perf_counter() - t1), "kernel_reads_per_s": m / (hip.pass1_time() * 1e-3),
-                         "reads": m, "kept": int((fl & 2).astype(bool).sum()), "decided_by_diag_filter": hip.pass1_filtered(),
-                         "decided_by_anchored_windows": hip.pass1_anchored()}
-        out["pass1"] = p1
+        if world == 1:      # single-GPU line only: the other ranks of a sharded run would sit waiting
+            # pass 1 (new_kmer_filter + sg_align over the whole wrapped reference, both strands), reported separately
+            import gen_data
+            m = min(n, 200_000)
+            seq = np.where(rc[:m, None] == 1, gen_data._COMP[stored[:m, ::-1]], stored[:m]).astype(np.uint8)   # as sequenced
+            p1 = {}
+            # mt311 itself carries an ambiguity code in every other column (N for the aligner); "plain_ref" is the same
+            # sequence with those resolved, the usual kind of reference, where the diagonal filter decides most reads
+            plain_ref = gen_data.resolve_individual(ref)
+            for label, k, r1 in (("k12", 12, ref), ("no_kmer", -1, ref), ("no_kmer_plain_ref", -1, plain_ref)):
+                hip.pass1(r1, True, seq[:256].reshape(-1), offsets[:257], k)          # warm-up
+                t1 = time.perf_counter()
+                sc, _, _, _, fl = hip.pass1(r1, True, seq.reshape(-1), offsets[: m + 1], k)
+                p1[label] = {"reads_per_s": m / (time.perf_counter() - t1), "kernel_reads_per_s": m / (hip.pass1_time() * 1e-3),
+                             "reads": m, "kept": int((fl & 2).astype(bool).sum()), "decided_by_diag_filter": hip.pass1_filtered(),
+                             "decided_by_anchored_windows": hip.pass1_anchored()}
+            out["pass1"] = p1
         if phase:
             out["phase_ms_per_step"] = {k: v / (a.steps + a.warmup) * 1e3 for k, v in phase.items()}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the CPU comparator is timed beside the single-GPU line only
             out["cpu_baseline"] = cpu_baseline(ref, stored, rc, as_, ae)
         print(json.dumps(out))
     if world > 1 or force_dist:
