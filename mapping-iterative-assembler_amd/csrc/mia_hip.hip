@@ -1652,25 +1652,27 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
     if (e == hipSuccess && filtered && n_dp > 0 && p1_other == 0 && d_p1kcnt && !getenv("MIA_HIP_NO_ANCHOR")) {
       const int64_t m = n_dp * P1A_SLOTS;
       const int stride = (max_len + 3) & ~3;
-      uint32_t *w_roff = nullptr, *w_status = nullptr, *d_nrest = nullptr;
-      uint16_t* w_len = nullptr;
-      uint8_t *w_rc = nullptr, *w_sk = nullptr, *d_ref2 = nullptr;
-      int32_t *w_as = nullptr, *w_ae = nullptr, *w_score = nullptr, *w_refstart = nullptr, *w_bin = nullptr, *w_list = nullptr, *w_wide = nullptr,
-              *w_retry = nullptr, *d_rest = nullptr, *w_bound = nullptr, *w_budget = nullptr;
-      int16_t *w_abr = nullptr, *w_cols = nullptr;
+      // one allocation for all the temporaries of this stage (twenty separate ones cost more than the stage)
+      unsigned char* arena = nullptr;
       ScopeFree g2;
-      for (void** pp : {(void**)&w_roff, (void**)&w_status, (void**)&d_nrest, (void**)&w_len, (void**)&w_rc, (void**)&w_sk, (void**)&d_ref2, (void**)&w_as,
-                        (void**)&w_ae, (void**)&w_score, (void**)&w_refstart, (void**)&w_bin, (void**)&w_list, (void**)&w_wide, (void**)&w_retry,
-                        (void**)&d_rest, (void**)&w_abr, (void**)&w_cols, (void**)&w_bound, (void**)&w_budget})
-        g2.watch(pp);
-      if (dev_alloc(ctx, &w_roff, (size_t)m) || dev_alloc(ctx, &w_status, (size_t)m) || dev_alloc(ctx, &d_nrest, 1) || dev_alloc(ctx, &w_len, (size_t)m) ||
-          dev_alloc(ctx, &w_rc, (size_t)m) || dev_alloc(ctx, &w_sk, (size_t)m) || dev_alloc(ctx, &d_ref2, (size_t)2 * len1 + 64) ||
-          dev_alloc(ctx, &w_as, (size_t)m) || dev_alloc(ctx, &w_ae, (size_t)m) || dev_alloc(ctx, &w_score, (size_t)m) ||
-          dev_alloc(ctx, &w_refstart, (size_t)m) || dev_alloc(ctx, &w_bin, (size_t)m) || dev_alloc(ctx, &w_list, (size_t)m + 4 * N_BINS) ||
-          dev_alloc(ctx, &w_wide, (size_t)m) || dev_alloc(ctx, &w_retry, (size_t)m) || dev_alloc(ctx, &d_rest, (size_t)n_dp) ||
-          dev_alloc(ctx, &w_abr, (size_t)m) || dev_alloc(ctx, &w_cols, (size_t)m * stride) || dev_alloc(ctx, &w_bound, (size_t)n_dp) ||
-          dev_alloc(ctx, &w_budget, (size_t)n_dp))
-        return MIA_HIP_ERR_NOMEM;
+      g2.watch((void**)&arena);
+      size_t top = 0;
+      auto carve = [&](size_t bytes) { const size_t at = top; top += (bytes + 255) & ~(size_t)255; return at; };
+      const size_t o_roff = carve((size_t)m * 4), o_status = carve((size_t)m * 4), o_nrest = carve(4), o_len = carve((size_t)m * 2),
+                   o_rc = carve((size_t)m), o_sk = carve((size_t)m), o_ref2 = carve((size_t)2 * len1 + 64), o_as = carve((size_t)m * 4),
+                   o_ae = carve((size_t)m * 4), o_score = carve((size_t)m * 4), o_refstart = carve((size_t)m * 4), o_bin = carve((size_t)m * 4),
+                   o_list = carve(((size_t)m + 4 * N_BINS) * 4), o_wide = carve((size_t)m * 4), o_retry = carve((size_t)m * 4),
+                   o_rest = carve((size_t)n_dp * 4), o_abr = carve((size_t)m * 2), o_cols = carve((size_t)m * stride * 2),
+                   o_bound = carve((size_t)n_dp * 4), o_budget = carve((size_t)n_dp * 4);
+      if (dev_alloc(ctx, &arena, top)) return MIA_HIP_ERR_NOMEM;
+      uint32_t *w_roff = (uint32_t*)(arena + o_roff), *w_status = (uint32_t*)(arena + o_status), *d_nrest = (uint32_t*)(arena + o_nrest);
+      uint16_t* w_len = (uint16_t*)(arena + o_len);
+      uint8_t *w_rc = arena + o_rc, *w_sk = arena + o_sk, *d_ref2 = arena + o_ref2;
+      int32_t *w_as = (int32_t*)(arena + o_as), *w_ae = (int32_t*)(arena + o_ae), *w_score = (int32_t*)(arena + o_score),
+              *w_refstart = (int32_t*)(arena + o_refstart), *w_bin = (int32_t*)(arena + o_bin), *w_list = (int32_t*)(arena + o_list),
+              *w_wide = (int32_t*)(arena + o_wide), *w_retry = (int32_t*)(arena + o_retry), *d_rest = (int32_t*)(arena + o_rest),
+              *w_bound = (int32_t*)(arena + o_bound), *w_budget = (int32_t*)(arena + o_budget);
+      int16_t *w_abr = (int16_t*)(arena + o_abr), *w_cols = (int16_t*)(arena + o_cols);
       HIPCHK(hipMemsetAsync(w_rc, 0, (size_t)m, ctx->stream));
       HIPCHK(hipMemsetAsync(w_abr, 0, (size_t)m * 2, ctx->stream));
       HIPCHK(hipMemsetAsync(w_status, 0, (size_t)m * 4, ctx->stream));

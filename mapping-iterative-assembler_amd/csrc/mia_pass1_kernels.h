@@ -144,18 +144,30 @@ __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32
   const int64_t i = todo[t];
   const int len2 = rs.len[i];
   const uint8_t* rp = rs.packed + rs.roff[i];
-  const int nb = len2 / DF_K < P1A_BLOCKS ? len2 / DF_K : P1A_BLOCKS;
+  const int nb_cut = len2 / DF_K < P1A_BLOCKS ? len2 / DF_K : P1A_BLOCKS;
   int n_cl = 0, c_strand[P1A_CLUSTERS], c_lo[P1A_CLUSTERS], c_hi[P1A_CLUSTERS], c_mask[P1A_CLUSTERS];
-  bool usable = nb >= 6;
+  bool usable = nb_cut >= 6;
   for (int r = 0; usable && r < len2; r++) if (((rp[r >> 1] >> ((r & 1) * 4)) & 15) > 3) usable = false;     // a read with N
+  // A block whose 10-mer has more occurrences (on either strand) than the table keeps cannot be used -- the pigeonhole
+  // then runs over the nb blocks that can: still "fewer than nb defects leave one of them intact".
+  int blocks = 0;
+  if (usable)
+    for (int b = 0; b < nb_cut; b++) {
+      const int o = (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1));
+      int64_t idx = 0;
+      for (int q = 0; q < DF_K; q++) { const int r = o + q; idx |= (int64_t)((rp[r >> 1] >> ((r & 1) * 4)) & 3) << (2 * q); }
+      if (kf.cnt[idx] <= DF_KCAP && kr.cnt[idx] <= DF_KCAP) blocks |= 1 << b;
+    }
+  const int nb = __popc((unsigned)blocks);
+  if (nb < 6) usable = false;
   for (int st = 0; usable && st < 2; st++) {
     const KmerOcc& ko = st ? kr : kf;
-    for (int b = 0; usable && b < nb; b++) {
-      const int o = (int)((int64_t)b * (len2 - DF_K) / (nb - 1));
+    for (int b = 0; usable && b < nb_cut; b++) {
+      if (!((blocks >> b) & 1)) continue;
+      const int o = (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1));
       int64_t idx = 0;
       for (int q = 0; q < DF_K; q++) { const int r = o + q; idx |= (int64_t)((rp[r >> 1] >> ((r & 1) * 4)) & 3) << (2 * q); }
       const int n = ko.cnt[idx];
-      if (n > DF_KCAP) { usable = false; break; }
       for (int k = 0; k < n; k++) {
         const int d = ko.pos[idx * DF_KCAP + k] - o;          // diagonal of this anchor (may hang over either end of the strand)
         int hit = -1;
