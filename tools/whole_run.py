@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--plain-ref", action="store_true", help="reference = mt311 with its ambiguity codes resolved (the usual kind of "
                     "reference; lets the diagonal filter of pass 1 work)")
     ap.add_argument("--ccheck", action="store_true", help="also run ccheck (reference and ccheck_hip) on the final .maln")
+    ap.add_argument("--ccheck-reference", action="store_true", help="with --skip-reference: still time the reference's ccheck on mia_hip's .maln")
     a = ap.parse_args()
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "mia")
     hip_bin = os.path.join(ROOT, "mapping-iterative-assembler_amd", "mia_hip")
@@ -74,7 +75,7 @@ def main():
         reports = {}
         for label, exe in (("ccheck_hip", os.path.join(ROOT, "mapping-iterative-assembler_amd", "ccheck_hip")),
                            ("ccheck_reference", os.path.join(ROOT, "oracle", "_ref", "ccheck"))):
-            if label == "ccheck_reference" and a.skip_reference:
+            if label == "ccheck_reference" and a.skip_reference and not a.ccheck_reference:
                 continue
             t0 = time.perf_counter()
             r = subprocess.run([exe, "-f", "-F", "-a", os.path.basename(final)], cwd=work, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
