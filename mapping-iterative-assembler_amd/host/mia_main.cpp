@@ -376,9 +376,15 @@ int main(int argc, char** argv) {
   std::vector<int64_t> f0((size_t)n, -1);     // pass-1 front slot of every read
   for (int i = 0; i < n; i++) { len[i] = (int32_t)fsdb[i].seq.size(); score[i] = fsdb[i].score; }
 
+  bool on_device = false;    // true once the read store is resident and re-aligned (the first cull runs on pass-1 scores)
   auto score_cut = [&](double* s, double* ic) {   // cull_maln_from_fsdb, src/mia.c:429-442
     *s = slope; *ic = intercept;
-    if (hard_cut <= 0 && !score_cut_set) mia_hip_score_cut(score.data(), len.data(), NULL, n, s, ic);
+    if (hard_cut <= 0 && !score_cut_set) {
+      // the regression's first pass (integer sums) runs on the device; with equally long reads that is all of it
+      int64_t sums5[5];
+      if (!on_device || mia_hip_score_sums(g, sums5) != MIA_HIP_OK || mia_hip_score_cut_from_sums(sums5, s, ic) != 0)
+        mia_hip_score_cut(score.data(), len.data(), NULL, n, s, ic);
+    }
     if (*s <= 0) *s = 100.0;
   };
   // first cull on the pass-1 records: only its `dropped` marks survive (src/mia_main.c:848)
@@ -429,14 +435,18 @@ int main(int argc, char** argv) {
   auto iteration = [&](int iter_num) {
     // reiterate_assembly (src/mia_main.c:24-280)
     if (mia_hip_realign(g, cons.c_str(), (int32_t)cons.size(), circular) != MIA_HIP_OK) die(g, "realign");
+    lap("  realign");
     if (mia_hip_get_alignments(g, score.data(), as.data(), ae.data()) != MIA_HIP_OK) die(g, "get_alignments");
+    lap("  get_alignments");
+    on_device = true;
     if (iter_num > 1) { ref_id = "ConsAssem." + std::to_string(iter_num); ref_desc = "iteration assembly"; }
     fprintf(stderr, "Repeat and score filtering\n");
     double s, ic;
     score_cut(&s, &ic);
+    lap("  score cut");
     if (mia_hip_cull(g, hard_cut, s, ic, 0) != MIA_HIP_OK) die(g, "cull");
     if (mia_hip_tally(g) != MIA_HIP_OK) die(g, "tally");
-    lap("iteration (device)");
+    lap("  cull + tally");
   };
 
   // write_ma (src/map_alignment.c:283-382) from the device results
@@ -589,6 +599,16 @@ int main(int argc, char** argv) {
       for (auto& o : text) fwrite(o.data(), 1, o.size(), mf);
     }
     fclose(mf);
+    {
+      // a million records own several strings each: giving them back on one thread when the vector dies costs as much as
+      // formatting them did
+      const size_t nrec = recs.size();
+      const int TD = worker_threads((int)std::min<size_t>(nrec, (size_t)INT32_MAX));
+      run_parallel(TD, [&](int t) {
+        for (size_t q = nrec * (size_t)t / (size_t)TD, hi = nrec * (size_t)(t + 1) / (size_t)TD; q < hi; q++) recs[q] = Record();
+      });
+      std::vector<Record>().swap(recs);
+    }
     lap("write .maln");
   };
 
