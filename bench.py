@@ -45,6 +45,7 @@ PMC = {
     "k_align_quad": {"traffic_per_read": (661749.34 + 1279506.11) * 1024 / 95_407, "valu_utilisation": 0.79},
     "k_align_quad_plain": {"traffic_per_read": (111680.25 + 252603.66) * 1024 / 1_000_000, "valu_utilisation": 0.90},
     "k_diag_filter": {"traffic_per_read": (77280.98 + 204036.09) * 1024 / 1_000_000, "valu_utilisation": 0.69},
+    "k_band_align": {"traffic_per_read": None, "valu_utilisation": None},      # not yet profiled with counters
 }
 
 
@@ -199,6 +200,7 @@ def main():
     hip.kernel_time(reset=True)
     hip.plain_stats(reset=True)
     hip.filter_stats(reset=True)
+    hip.band_stats(reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -213,6 +215,7 @@ def main():
     align_ms, launches = hip.kernel_time(reset=True)
     plain_ms, plain_launches, plain_in, plain_retried = hip.plain_stats(reset=True)
     filt_seen, filt_done, filt_ms, filt_launches = hip.filter_stats(reset=True)
+    band_done, band_ms, band_launches = hip.band_stats(reset=True)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -235,11 +238,12 @@ def main():
             ach = BYTES_PER_READ * rpl / (k_ms * 1e-3) / 1e9
             stages.append({"kernel": name, "kernel_ms": k_ms, "ms_per_step": ms_total / a.steps, "launches": k_launches,
                            "reads_per_launch": rpl, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                           "traffic": PMC[name]["traffic_per_read"] * rpl, "valu_utilisation": PMC[name]["valu_utilisation"],
+                           "traffic": PMC[name]["traffic_per_read"] * rpl if PMC[name]["traffic_per_read"] else None, "valu_utilisation": PMC[name]["valu_utilisation"],
                            "gcups": rpl * 100 * 200 / (k_ms * 1e-3) / 1e9 if name != "k_diag_filter" else None})
 
         plain_on = plain_launches > 0
         stage("k_diag_filter", filt_ms, filt_launches, filt_seen)
+        stage("k_band_align", band_ms, band_launches, filt_seen - filt_done)
         stage("k_align_quad_plain", plain_ms, plain_launches, plain_in)
         stage("k_align_quad", align_ms, launches, plain_retried if plain_on else n * a.steps)
         dom = max(stages, key=lambda st: st["ms_per_step"])
@@ -256,6 +260,7 @@ def main():
                          "valu_utilisation": dom["valu_utilisation"],
                          "stages": stages,
                          "reads_finished_by_filter_frac": filt_done / filt_seen if filt_seen else 0.0,
+                         "reads_finished_by_banded_dp_frac": band_done / filt_seen if filt_seen else 0.0,
                          "reads_to_trace_kernel_frac": (plain_retried / (n * a.steps)) if plain_on else 1.0,
                          "note": "the DP kernels are integer-VALU bound (SQ_ACTIVE_INST_VALU 79-90 % of SIMD capacity, profiles/r01/pmc): "
                                  "182 algorithmic HBM bytes per read (SURVEY 8d) put them at a fraction of a percent of the HBM roof "

@@ -260,6 +260,12 @@ int mia_hip_plain_stats(mia_hip_ctx *ctx, int reset, double *plain_ms, int64_t *
  * bit-parallel comparison and never reaches the DP): reads examined and reads finished there since the last reset;
  * kernel_ms / launches: accumulated time of k_diag_filter (HIP events on the context's stream).  Any pointer may be NULL. */
 int mia_hip_filter_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_seen, int64_t *reads_finished, double *kernel_ms, int64_t *launches);
+/* The banded DP behind the filter (csrc/band_body.h: flat matrix, windows without N).  A left-over read whose ten-mer
+ * anchors confine every alignment that can win to at most 32 diagonals is aligned inside that band, one read per thread,
+ * with the same recurrence, tie rules and traceback as dyn_prog / find_align_begin / populate_pwaln_to_begin
+ * (reference src/mia.c:740-981, 612-637, 1440-1497); the rest goes on to the full-window kernels.  reads_finished /
+ * kernel_ms / launches of k_band_align since the last reset.  Any pointer may be NULL. */
+int mia_hip_band_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_finished, double *kernel_ms, int64_t *launches);
 /* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
 int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 /* reads of the last mia_hip_pass1 call decided by the diagonal filter (csrc/diag_filter.h: flat matrix, no k-mer mask)

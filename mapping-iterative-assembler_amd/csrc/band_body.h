@@ -1,0 +1,240 @@
+// band_body.h -- the windowed DP of dyn_prog / max_sg_score / find_align_begin / populate_pwaln_to_begin
+// (/root/reference/src/mia.c:740-981,1278-1302,612-637,1440-1497) confined to a BAND of diagonals that provably holds
+// every alignment that matters, one read per thread.  Flat matrix, read and window free of N (diag_filter.h's premises).
+//
+// Which band.  Cut the read into nb 10-mers (diag_filter.h: pigeonhole).  Some valid path is cheap to write down -- the
+// read on the diagonal of its first anchor up to a switch row, one gap, the rest on the diagonal of its last anchor -- and
+// its loss B0 (against 200 x len) bounds the optimum's.  If B0 <= 800 nb - 400, every path that loses no more than B0 runs
+// through an anchor and strays at most g = (B0 - 1000) / 200 diagonals from it (0 if B0 < 1200), so all of them, ties
+// included, lie on diagonals [lowest anchor - g, highest anchor + g]: W of them, not the window's hundred.
+//
+// Why the band is enough.  Run the recurrence with every cell outside the band "absent".  A cell ON an optimal path has the
+// same value as in the full matrix (its best path is an optimal prefix, inside the band), and the candidates that lose
+// against the chosen one in the full matrix are not larger here; a candidate that ties is itself optimal, hence inside
+// with its full value, and the running maxima keep the earliest index among equals in both.  So values, choices and gap
+// sources agree on every cell the traceback visits, and the first maximum of the last row is the same cell.  The one
+// thing that can lead the reference's traceback OFF the optimal cells is its own quirk -- a gap whose source index is 0
+// reads back as a diagonal step (src/mia.c:619) -- so a traceback that meets such a gap gives up and the read goes to the
+// full-window kernels, as does any read whose band would be wider than BAND_W.
+#pragma once
+#include <stdint.h>
+
+#include "diag_filter.h"
+#include "mia_layout.h"
+
+namespace mia {
+
+constexpr int BAND_W = 32;            // diagonals a thread keeps in registers
+constexpr int BAND_BLOCKS = 9;        // 10-mers cut out of the read (at least 6)
+constexpr int BAND_NEG = -(1 << 22);  // "no such cell": far below any score a read of 256 bases can have, small enough to pack
+
+struct BandPlan { int d0, w, budget, b0; };   // diagonals d0 .. d0 + w - 1 (column minus row, window coordinates)
+
+// the band of a read, or false if the read is left to the full-window kernels
+MIA_HD inline bool band_plan(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2, BandPlan* out) {
+  if (!ko.cnt || len2 < 6 * DF_K || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1 || s < 0 || (int64_t)s + len1 > n_ref) return false;
+  if (!all_bases(rp, s, (int64_t)s + len1)) return false;
+  const int R = len2 - 1, nb_cut = len2 / DF_K < BAND_BLOCKS ? len2 / DF_K : BAND_BLOCKS;
+  int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0;
+  bool any = false;
+  for (int r = 0; r < len2; r++) if (((read_packed[r >> 1] >> ((r & 1) * 4)) & 15) > 3) return false;      // a read with N
+  for (int b = 0; b < nb_cut; b++) {
+    const int o = (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1));
+    int64_t idx = 0;
+    for (int q = 0; q < DF_K; q++) { const int r = o + q; idx |= (int64_t)((read_packed[r >> 1] >> ((r & 1) * 4)) & 3) << (2 * q); }
+    const int n = ko.cnt[idx];
+    if (n > DF_KCAP) continue;                       // an overloaded 10-mer is not part of the pigeonhole
+    nb++;
+    for (int k = 0; k < n; k++) {
+      const int d = ko.pos[idx * DF_KCAP + k] - o - s;        // diagonal in window coordinates
+      if (d < -R || d > len1 - 1) continue;                   // not a place inside this window
+      if (!any) { d_first = d; any = true; }
+      d_last = d;
+      if (d < a_lo) a_lo = d;
+      if (d > a_hi) a_hi = d;
+    }
+  }
+  if (nb < 6 || !any) return false;
+  // the loss of one valid path: rows [0, t) on d_first, one gap, the rest on d_last (or the plain diagonal if they agree)
+  if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) return false;   // keep the written-down path inside the window
+  int b0;
+  {
+    auto mis = [&](int d, int r) {                 // 1 iff read row r mismatches on diagonal d (window coordinates)
+      const int c = (read_packed[r >> 1] >> ((r & 1) * 4)) & 3;
+      const int64_t p = (int64_t)s + d + r + PLANE_LEAD;
+      const int x = (int)((rp.lo[p >> 6] >> (p & 63)) & 1) | ((int)((rp.hi[p >> 6] >> (p & 63)) & 1) << 1);
+      return c != x ? 1 : 0;
+    };
+    if (d_first == d_last) {
+      int k = 0;
+      for (int r = 0; r < len2; r++) k += mis(d_first, r);
+      b0 = 800 * k;
+    } else {
+      // column gap (d_last > d_first: the rows from t on continue d_last - d_first columns further right) or row gap (the read
+      // skips d_first - d_last rows): prefix mismatches on d_first plus suffix mismatches on d_last, best switch row t
+      const int shift = d_last - d_first, skip = shift < 0 ? -shift : 0;
+      int prefix = 0, suffix = 0, best = 1 << 20;
+      for (int r = skip; r < len2; r++) suffix += mis(d_last, r);
+      // rows [0, t) on d_first, `skip` rows inserted, rows [t + skip, len2) on d_last; both stretches non-empty
+      for (int t = 1; t + skip <= R; t++) {
+        prefix += mis(d_first, t - 1);
+        suffix -= mis(d_last, t - 1 + skip);
+        if (prefix + suffix < best) best = prefix + suffix;
+      }
+      if (best == (1 << 20)) return false;
+      b0 = 800 * best + (shift > 0 ? GOP + GEP * shift : GOP + GEP * skip + FLAT_MATCH * skip);
+    }
+  }
+  const int budget = 800 * nb - 400;
+  if (b0 > budget) return false;
+  // (one diagonal more than (b0 - 1000) / 200: a path that starts late in the window's first column gets its substitution
+  // score back, src/mia.c:838-846, and may spend those 200 on one more gap column)
+  const int g = b0 < GOP ? 0 : (b0 - GOP + GEP) / GEP;
+  const int d0 = a_lo - g, w = a_hi - a_lo + 2 * g + 1;
+  if (w > BAND_W) return false;
+  out->d0 = d0; out->w = w; out->budget = budget; out->b0 = b0;
+  return true;
+}
+
+struct BandResult { int score, abc, aec, abr, gaps; };
+
+// 32 bits of a plane from bit position `bit` on
+MIA_HD inline uint64_t band_bits(const uint64_t* plane, int64_t bit) {
+  const int64_t q = bit >> 6;
+  const int o = (int)(bit & 63);
+  return o ? (plane[q] >> o) | (plane[q + 1] << (64 - o)) : plane[q];
+}
+
+// true if no cell of the band [d0, d0 + wmax) leaves the window in any row and none but row 0's touches column 0: the
+// plain form of band_align applies
+MIA_HD inline bool band_interior(const BandPlan& bp, int wmax, int len1, int len2) { return bp.d0 >= 0 && len2 - 1 + bp.d0 + wmax <= len1; }
+
+// The DP over the band [d0, d0 + wmax), wmax >= the plan's width (a wavefront uses the widest of its 64 reads: a scalar
+// loop bound).  trace: 8 words (BAND_W bytes) per row, row r at trace + r * row_words -- private to the thread (the
+// kernel interleaves the rows of a wavefront's 64 reads so that its stores coalesce).  cols_out: the script (window column
+// per read row, COL_INSERT, COL_CLIP) as the other kernels write it.  false: the traceback met the reference's index-0
+// quirk -- the caller sends the read to the full-window kernels.  EDGE: the band may leave the window (see band_interior).
+//
+// Everything a cell compares is packed value * 256 + code, so that one integer maximum applies the reference's tie rules:
+//   diagonal   S(r-1, c-1) * 256 + 0xFF                wins ties against both gaps          (src/mia.c:848-935)
+//   column gap (best - GOP - GEP n) * 256 + 0x40 + n   n = gap length; beats the row gap on ties
+//   row gap    (best - GOP - GEP n) * 256 + n
+// and within one kind the LARGER n among equal values, i.e. the earliest source, as the reference's running maxima keep
+// the first of equals.  The winning code byte is the trace.  A new start (code 0x80) needs fresh > all three, strictly.
+template <bool EDGE>
+MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, const BandPlan& bp, int wmax, uint32_t* trace,
+                              int64_t row_words, int16_t* cols_out, BandResult* res) {
+  const int R = len2 - 1, d0 = bp.d0;
+  constexpr int DEAD = BAND_NEG * 256;
+  constexpr int STEP = 1 - GEP * 256;                 // a running maximum ages by one position: value - GEP, length + 1
+  constexpr int CAND = -GOP * 256 + STEP;             // a cell becomes a gap source: value - GOP - GEP, length 1
+  // P[j]: S(r-1, c-1) for the cell on diagonal d0 + j of the current row (its diagonal predecessor).
+  // H[j]: the packed row-gap candidate of that cell (best over rows <= r-2 of its left-hand column).
+  int32_t P[BAND_W], H[BAND_W];
+  const uint32_t* rwords = reinterpret_cast<const uint32_t*>(read_packed);     // reads start on 4-byte boundaries
+  uint64_t wl, wh;
+  uint32_t rw = rwords[0];
+  {
+    // row 0: every column may start the alignment (src/mia.c:781-800)
+    const int64_t bit = (int64_t)s + d0 + PLANE_LEAD;
+    wl = band_bits(rp.lo, bit); wh = band_bits(rp.hi, bit);
+    const int c2 = (int)(rw & 3u);
+    const uint32_t match = ~((((uint32_t)wl) ^ ((c2 & 1) ? ~0u : 0u)) | (((uint32_t)wh) ^ ((c2 & 2) ? ~0u : 0u)));
+    wl >>= 1; wh >>= 1;
+    const int jlo = d0 < 0 ? -d0 : 0, jhi = (len1 - d0) < wmax ? (len1 - d0) : wmax;
+    const uint32_t live = jhi > jlo ? ((jhi >= 32 ? ~0u : ((1u << jhi) - 1u)) & ~((1u << jlo) - 1u)) : 0u;
+#pragma unroll
+    for (int j = 0; j < BAND_W; j++) {
+      H[j] = DEAD;
+      P[j] = ((live >> j) & 1u) ? (((match >> j) & 1u) ? FLAT_MATCH : FLAT_MISMATCH) : BAND_NEG;
+    }
+#pragma unroll
+    for (int k = 0; k < BAND_W / 4; k++) trace[k] = 0xFFFFFFFFu;
+  }
+  for (int r = 1; r < len2; r++) {
+    const int c0 = r + d0;                        // column of j = 0
+    if ((r & 31) == 0) {                          // 64 plane bits serve 32 rows (the band slides one column per row)
+      const int64_t bit = (int64_t)s + c0 + PLANE_LEAD;
+      wl = band_bits(rp.lo, bit); wh = band_bits(rp.hi, bit);
+    }
+    if ((r & 7) == 0) rw = rwords[r >> 3];
+    const int c2 = (int)((rw >> (4 * (r & 7))) & 3u);
+    const uint32_t match = ~((((uint32_t)wl) ^ ((c2 & 1) ? ~0u : 0u)) | (((uint32_t)wh) ^ ((c2 & 2) ? ~0u : 0u)));
+    wl >>= 1; wh >>= 1;
+    uint32_t live = ~0u, col0 = 0u;
+    if (EDGE) {
+      const int jlo = c0 < 0 ? -c0 : 0, jhi = (len1 - c0) < wmax ? (len1 - c0) : wmax;      // cells jlo .. jhi-1 are inside the window
+      live = jhi > jlo ? ((jhi >= 32 ? ~0u : ((1u << jhi) - 1u)) & ~((1u << jlo) - 1u)) : 0u;
+      col0 = (c0 <= 0 && c0 > -BAND_W) ? (1u << (-c0)) : 0u;                               // the cell in the window's first column
+    }
+    const int fresh = -(GOP + GEP * (r + 1));
+    const int f0 = fresh * 256;
+    int G = DEAD;                                 // the packed column-gap candidate of the cell about to be computed
+    uint32_t tw[BAND_W / 4];
+#pragma unroll
+    for (int k = 0; k < BAND_W / 4; k++) tw[k] = 0;
+#pragma unroll
+    for (int j = 0; j < BAND_W; j++) {
+      if (j < wmax) {                             // (the same for all reads of a wavefront: a scalar branch)
+        const int p = P[j], h = H[j];
+        const int sub = ((match >> j) & 1u) ? FLAT_MATCH : FLAT_MISMATCH;
+        const int pd = p * 256 + 0xFF, gc = G | 0x40;
+        const int x = pd > gc ? (pd > h ? pd : h) : (gc > h ? gc : h);
+        const bool start = f0 > x;                                                   // fresh beats all three, strictly
+        int cur = ((start ? f0 : x) >> 8) + (start ? 0 : sub);
+        int code = start ? 0x80 : (x & 0xFF);
+        if (EDGE) {
+          if ((col0 >> j) & 1u) { cur = sub + fresh; code = 0xFF; }                  // src/mia.c:838-846
+          if (!((live >> j) & 1u)) { cur = BAND_NEG; code = 0; }
+        }
+        tw[j >> 2] |= (uint32_t)code << (8 * (j & 3));
+        // S(r-1, c-1) = P[j] becomes a gap source: for this row's cells further right, and for column c-1 (which the
+        // next row reaches from index j-1)
+        const int cand = p * 256 + CAND;
+        G = G + STEP > cand ? G + STEP : cand;
+        if (j >= 1) H[j - 1] = h + STEP > cand ? h + STEP : cand;
+        P[j] = cur;
+      } else if (j == wmax) {
+        H[j - 1] = DEAD;                          // (wmax >= 1)
+      }
+    }
+    if (wmax == BAND_W) H[BAND_W - 1] = DEAD;
+    uint32_t* tr = trace + (int64_t)r * row_words;
+#pragma unroll
+    for (int k = 0; k < BAND_W / 4; k++) tr[k] = tw[k];
+  }
+  // max_sg_score: first maximum of the last row (src/mia.c:1278-1302)
+  int best = BAND_NEG, bj = -1;
+#pragma unroll
+  for (int j = 0; j < BAND_W; j++) if (j < wmax && P[j] > best) { best = P[j]; bj = j; }
+  if (bj < 0 || best <= BAND_NEG / 2) return false;
+  // find_align_begin + populate_pwaln_to_begin (src/mia.c:612-637, 1440-1497)
+  int r = R, c = R + d0 + bj, gaps = 0;
+  const int aec = c;
+  for (;;) {
+    cols_out[r] = (int16_t)c;
+    if (r == 0 || c == 0) break;
+    const int j = c - r - d0;
+    if (j < 0 || j >= wmax) return false;
+    const int code = (int)((trace[(int64_t)r * row_words + (j >> 2)] >> (8 * (j & 3))) & 255u);
+    if (code == 0x80) break;
+    if (code == 0xFF) { r--; c--; }
+    else if (code & 0x40) {
+      const int sc = c - 1 - (code & 63);
+      if (sc <= 0) return false;             // a gap from column 0 reads back as a diagonal step in the reference: not followed here
+      gaps++;
+      r--; c = sc;
+    } else {
+      const int sr = r - 1 - code;
+      if (sr <= 0) return false;             // a gap from row 0: the same quirk
+      for (int q = r - 1; q > sr; q--) cols_out[q] = COL_INSERT;
+      gaps++;
+      r = sr; c--;
+    }
+  }
+  for (int q = 0; q < r; q++) cols_out[q] = COL_CLIP;
+  res->score = best; res->abc = c; res->aec = aec; res->abr = r; res->gaps = gaps;
+  return true;
+}
+
+}  // namespace mia

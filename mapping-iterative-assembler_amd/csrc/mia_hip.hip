@@ -80,7 +80,11 @@ struct mia_hip_ctx {
   int64_t pre_cull_records = 0, pre_cull_links = 0; bool pre_cull_valid = false;   // mia_hip_score_sums' by-products
   int32_t *d_kocc_cnt = nullptr, *d_kocc_pos = nullptr;   // 10-mer table of the reference (diag_filter.h: KmerOcc)
   uint64_t* d_planes = nullptr; int64_t plane_cap = 0;   // lo | hi | ok, plane_cap words each
-  uint32_t* d_filter_n = nullptr; int64_t filter_proven = 0, filter_seen = 0;
+  uint32_t* d_filter_n = nullptr; int64_t filter_proven = 0, filter_seen = 0;   // device: {finished by the filter, left over, finished by the banded DP}
+  int use_banddp = 1;                       // MIA_HIP_NO_BAND_DP=1: the filter's left-overs go straight to the full-window kernels
+  int32_t* d_left_list = nullptr; int64_t left_cap = 0;
+  uint32_t* d_band_slabs = nullptr; int64_t band_slab_cap = 0;
+  int64_t band_done = 0; double band_ms = 0; int64_t band_launches = 0;
   int grid_wgs = 0;
   int window_wgs[N_CPL] = {0, 0, 0};
   int cus = 1;
@@ -92,7 +96,7 @@ struct mia_hip_ctx {
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free, ev_plain, ev_filter;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free, ev_plain, ev_filter, ev_band;
   double filter_ms = 0; int64_t filter_launches = 0;
   // pinned staging: small copies to and from pageable memory wait for the stream, pinned ones do not
   unsigned char* h_pin = nullptr; static constexpr size_t PIN_BYTES = 1 << 20, PIN_MISC = 64 << 10;
@@ -157,6 +161,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (npl && atoi(npl)) ctx->use_plain = 0;
     const char* nf = getenv("MIA_HIP_NO_DIAG_FILTER");
     if (nf && atoi(nf)) ctx->use_filter = 0;
+    const char* nbd = getenv("MIA_HIP_NO_BAND_DP");
+    if (nbd && atoi(nbd)) ctx->use_banddp = 0;
     const char* nq = getenv("MIA_HIP_NO_QUAD");
     if (nq && atoi(nq)) ctx->use_quad = 0;
     const char* qw = getenv("MIA_HIP_QUAD_WAVES_PER_CU");
@@ -167,7 +173,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (g && atoi(g) > 0) ctx->grid_wgs = prop.multiProcessorCount * atoi(g);
   }
   if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_bins, 3 * N_BINS + 2) ||
-      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1) || dev_alloc(ctx, &ctx->d_filter_n, 1)) {
+      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1) || dev_alloc(ctx, &ctx->d_filter_n, 4)) {
     delete ctx;
     return MIA_HIP_ERR_NOMEM;
   }
@@ -187,7 +193,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n, ctx->d_kocc_cnt, ctx->d_kocc_pos};
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -195,6 +201,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_plain) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_filter) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : ctx->ev_band) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -378,6 +385,15 @@ static void drain_events(mia_hip_ctx* ctx) {
     ctx->ev_free.push_back(e);
   }
   ctx->ev_filter.clear();
+  for (auto& e : ctx->ev_band) {
+    float ms = 0;
+    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+      ctx->band_ms += ms;
+      ctx->band_launches++;
+    }
+    ctx->ev_free.push_back(e);
+  }
+  ctx->ev_band.clear();
 }
 
 extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms, int64_t* launches) {
@@ -399,6 +415,17 @@ extern "C" int mia_hip_filter_stats(mia_hip_ctx* ctx, int reset, int64_t* reads_
   if (kernel_ms) *kernel_ms = ctx->filter_ms;
   if (launches) *launches = ctx->filter_launches;
   if (reset) { ctx->filter_seen = 0; ctx->filter_proven = 0; ctx->filter_ms = 0; ctx->filter_launches = 0; }
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_band_stats(mia_hip_ctx* ctx, int reset, int64_t* reads_finished, double* kernel_ms, int64_t* launches) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  drain_events(ctx);
+  if (reads_finished) *reads_finished = ctx->band_done;
+  if (kernel_ms) *kernel_ms = ctx->band_ms;
+  if (launches) *launches = ctx->band_launches;
+  if (reset) { ctx->band_done = 0; ctx->band_ms = 0; ctx->band_launches = 0; }
   return MIA_HIP_OK;
 }
 
@@ -495,7 +522,7 @@ static int align_all(mia_hip_ctx* ctx) {
     RefPlanes rp{ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap};
     hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
                        ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
-    HIPCHK(hipMemsetAsync(ctx->d_filter_n, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_filter_n, 0, 16, ctx->stream));
     // the 10-mer table of this reference (rule (c) looks long clean stretches up instead of sliding over every diagonal);
     // not for the very long concatenated strings mia_hip_align_windows may be given
     KmerOcc ko{nullptr, nullptr};
@@ -511,9 +538,35 @@ static int align_all(mia_hip_ctx* ctx) {
     ctx->ev_filter.push_back(ctx->ev_used.back());
     ctx->ev_used.pop_back();
     (void)hipEventRecord(f0, ctx->stream);
-    hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_bin_of, ctx->dbg);
+    // what the filter leaves over goes through the banded DP first (band_body.h); it needs the table
+    const bool banded = ctx->use_banddp && ko.cnt && !(ctx->dbg & 128u);
+    if (banded && n > ctx->left_cap) {
+      if (dev_alloc(ctx, &ctx->d_left_list, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+      ctx->left_cap = n;
+    }
+    hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_bin_of, ctx->dbg,
+                       banded ? ctx->d_left_list : nullptr, ctx->d_filter_n + 1);
     (void)hipEventRecord(f1, ctx->stream);
     HIPCHK(hipGetLastError());
+    if (banded) {
+      // a persistent grid of wavefronts, each with its own trace slab (the number of left-over reads stays on the device)
+      const int64_t chunks = (n + 63) / 64;
+      const int grid = (int)(chunks < 2048 ? chunks : 2048);
+      const int64_t slab_words = (int64_t)ctx->max_len * BAND_ROW_WORDS;
+      if (slab_words * grid > ctx->band_slab_cap) {
+        if (dev_alloc(ctx, &ctx->d_band_slabs, (size_t)(slab_words * grid))) return MIA_HIP_ERR_NOMEM;
+        ctx->band_slab_cap = slab_words * grid;
+      }
+      hipEvent_t b0, b1;
+      if (get_events(ctx, &b0, &b1)) return MIA_HIP_ERR_NOMEM;
+      ctx->ev_band.push_back(ctx->ev_used.back());
+      ctx->ev_used.pop_back();
+      (void)hipEventRecord(b0, ctx->stream);
+      hipLaunchKernelGGL(k_band_align, dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_left_list, ctx->d_filter_n + 1,
+                         ctx->d_band_slabs, slab_words, ctx->d_bin_of, ctx->d_filter_n + 2);
+      (void)hipEventRecord(b1, ctx->stream);
+      HIPCHK(hipGetLastError());
+    }
   }
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && ctx->use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   // host copies of the counters live in pinned memory when there is some: a copy to or from pageable memory makes the
@@ -522,11 +575,16 @@ static int align_all(mia_hip_ctx* ctx) {
   int32_t* hb = ctx->h_pin ? reinterpret_cast<int32_t*>(ctx->h_pin) : local_buf;
   int32_t *h_count = hb, *h_off = hb + N_BINS, *h_count2 = hb + 2 * N_BINS, *h_off2 = hb + 3 * N_BINS, *h_misc = hb + 4 * N_BINS;
   h_misc[0] = 0;
-  if (filtered) HIPCHK(hipMemcpyAsync(&h_misc[0], ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  h_misc[6] = 0;
+  if (filtered) {
+    HIPCHK(hipMemcpyAsync(&h_misc[0], ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&h_misc[6], ctx->d_filter_n + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIPCHK(hipMemcpyAsync(h_count, d_count, (size_t)N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   h_filter_n = (uint32_t)h_misc[0];
   ctx->filter_proven += h_filter_n;
+  ctx->band_done += (uint32_t)h_misc[6];
   ctx->filter_seen += n;
   int run = 0;
   for (int b = 0; b < N_BINS; b++) {

@@ -16,6 +16,7 @@
 #include "align_body_quad.h"
 #include "align_body_quad_plain.h"
 #include "diag_filter.h"
+#include "band_body.h"
 #include "mia_layout.h"
 #include "wave_dev.h"
 
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(256) void k_kmer_occ(const uint8_t* codes, int64_t 
   if (c < DF_KCAP) pos[idx * DF_KCAP + c] = (int32_t)p;
 }
 
-__global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, RefPlanes rp, KmerOcc ko, int64_t n_ref, int32_t* bin_of, uint32_t dbg) {
+__global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, RefPlanes rp, KmerOcc ko, int64_t n_ref, int32_t* bin_of, uint32_t dbg,
+                                                      int32_t* left_list, uint32_t* n_left) {
   __shared__ int16_t verdict[256];      // per read of the block: diagonal of a finished read, -1 otherwise
   __shared__ int16_t cand[256];         // reads with exactly two mismatches on their diagonal: rule (c) is still open
   __shared__ int16_t cand_delta[256];
@@ -177,6 +179,16 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
     }
   }
   __syncthreads();
+  // the reads left over, as a list for the banded DP (k_band_align): one atomic per wavefront
+  if (left_list) {
+    const int64_t i = i0 + threadIdx.x;
+    const bool left = i < rs.n && rs.sk[i] && verdict[threadIdx.x] < 0;
+    const unsigned long long m = __ballot(left);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(n_left, (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    if (left) left_list[base + (uint32_t)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int32_t)i;
+  }
   // the scripts of the finished reads: eight threads per read, four consecutive columns (8 bytes) per store
   for (int k = 0; k < 8; k++) {
     const int t = k * 32 + (int)(threadIdx.x >> 3);
@@ -195,6 +207,51 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
   }
 }
 
+// ---- the banded DP (band_body.h) for the reads the filter left over: one read per thread, persistent grid of
+// wavefronts, each with a private trace slab [row][lane][BAND_W bytes] so that a row's 64 stores are one 2 KB stretch.
+// A finished read is marked bin_of = -4 (the planner leaves it out); every other read keeps its mark and its window.
+constexpr int BAND_ROW_WORDS = 64 * (BAND_W / 4);
+__global__ __launch_bounds__(64) void k_band_align(ReadSet rs, RefInfo ref, RefPlanes rp, KmerOcc ko, int64_t n_ref, const int32_t* left_list,
+                                                   const uint32_t* n_left, uint32_t* trace_slabs, int64_t slab_words, int32_t* bin_of,
+                                                   uint32_t* n_done) {
+  const uint32_t total = *n_left;
+  uint32_t* trace = trace_slabs + (int64_t)blockIdx.x * slab_words + threadIdx.x * (BAND_W / 4);
+  uint32_t done = 0;
+  for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 64 < total; chunk += gridDim.x) {
+    const uint32_t t = chunk * 64 + threadIdx.x;
+    const bool live = t < total;
+    const int64_t i = live ? left_list[t] : 0;
+    const int len2 = live ? rs.len[i] : 0;
+    int s = 0, l1 = 0;
+    if (live) read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
+    const uint8_t* rd = rs.packed + (live ? rs.roff[i] : 0);
+    BandPlan bp;
+    const bool ok = live && band_plan(rp, ko, n_ref, s, l1, rd, len2, &bp);
+    // the whole wavefront runs the widest band among its reads (a scalar loop bound), and the plain form of the
+    // recurrence only if no read's band leaves its window
+    int w = ok ? bp.w : 0;
+    for (int o = 32; o; o >>= 1) { const int v = __shfl_xor(w, o); w = v > w ? v : w; }
+    const int wmax = __builtin_amdgcn_readfirstlane(w);
+    if (wmax == 0) continue;
+    const bool edge = __ballot(ok && !band_interior(bp, wmax, l1, len2)) != 0ull;
+    if (!ok) continue;
+    BandResult res;
+    const bool got = edge ? band_align<true>(rp, s, l1, rd, len2, bp, wmax, trace, BAND_ROW_WORDS, rs.cols + i * rs.stride, &res)
+                          : band_align<false>(rp, s, l1, rd, len2, bp, wmax, trace, BAND_ROW_WORDS, rs.cols + i * rs.stride, &res);
+    if (!got) continue;
+    rs.score[i] = res.score;
+    rs.refstart[i] = s;
+    rs.abr[i] = (int16_t)res.abr;
+    rs.as[i] = res.abc + s;                   // src/mia_main.c:254-255
+    rs.ae[i] = res.aec + s;
+    rs.status[i] = res.gaps ? ST_OK : ST_DIAG;
+    bin_of[i] = -4;
+    done++;
+  }
+  for (int o = 32; o; o >>= 1) done += __shfl_xor(done, o);
+  if (threadIdx.x == 0 && done) atomicAdd(n_done, done);
+}
+
 __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, PackSet ps, int use_quad, int filtered, int defer, int32_t* bin_of, int32_t* bin_count,
                                                      uint32_t* n_filtered) {
   __shared__ int32_t hist[N_BINS];
@@ -210,6 +267,7 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
       const int mark = filtered ? bin_of[i] : 0;
       if (mark == -2) {
         was_done = true;
+      } else if (mark == -4) {                 // finished by k_band_align (counted there)
       } else if (rs.sk[i]) {
         int s, l1;
         read_window(ref, rs.as[i], rs.ae[i], rs.len[i], &s, &l1);

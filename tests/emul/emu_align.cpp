@@ -12,6 +12,7 @@
 #include "align_body_quad.h"
 #include "align_body_quad_plain.h"
 #include "diag_filter.h"
+#include "band_body.h"
 
 using namespace mia;
 
@@ -258,4 +259,33 @@ extern "C" int emu_step2_both(const uint8_t* ref_codes, int64_t n_codes, int ref
   const int km = diag_step2_kmer(rp, ko, n_codes, ref_start, len1, pb, len2) > 0 ? 2 : 0;
   for (int64_t idx : touched) cnt[(size_t)idx] = 0;
   return scan | km;
+}
+
+// The banded DP (csrc/band_body.h) for one read: returns 1 with out5 = {score, abc, aec, abr, gaps} and the script in cols
+// (window columns), 0 if the read is left to the full-window kernels.  out_plan = {d0, w, b0, budget}.  widen: extra
+// diagonals on the band's right-hand side.
+extern "C" int emu_band(const uint8_t* ref_codes, int64_t n_codes, int ref_start, int len1, const uint8_t* read_codes, int len2, int32_t* out5,
+                        int16_t* cols, int32_t* out_plan, int widen) {
+  using namespace mia;
+  const int64_t words = plane_words(n_codes);
+  std::vector<uint64_t> lo((size_t)words), hi((size_t)words), ok((size_t)words);
+  for (int64_t w = 0; w < words; w++) plane_word(ref_codes, n_codes, w, &lo[(size_t)w], &hi[(size_t)w], &ok[(size_t)w]);
+  std::vector<uint32_t> packed((size_t)(len2 / 8 + 2), 0);
+  uint8_t* pb = (uint8_t*)packed.data();
+  for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
+  RefPlanes rp{lo.data(), hi.data(), ok.data()};
+  const KmerOcc ko = g_tab_a.build(ref_codes, n_codes);
+  BandPlan bp;
+  if (!band_plan(rp, ko, n_codes, ref_start, len1, pb, len2, &bp)) return 0;
+  out_plan[0] = bp.d0; out_plan[1] = bp.w; out_plan[2] = bp.b0; out_plan[3] = bp.budget;
+  std::vector<uint32_t> trace((size_t)len2 * (BAND_W / 4));
+  BandResult res;
+  // the kernel runs every read of a wavefront with the widest band among them: any width from the plan's up must do
+  const int wmax = bp.w + widen > BAND_W ? BAND_W : bp.w + widen;
+  const bool got = (band_interior(bp, wmax, len1, len2) && !(widen & 1))   // (odd widen: the edge form on interior reads too)
+                      ? band_align<false>(rp, ref_start, len1, pb, len2, bp, wmax, trace.data(), BAND_W / 4, cols, &res)
+                      : band_align<true>(rp, ref_start, len1, pb, len2, bp, wmax, trace.data(), BAND_W / 4, cols, &res);
+  if (!got) return 0;
+  out5[0] = res.score; out5[1] = res.abc; out5[2] = res.aec; out5[3] = res.abr; out5[4] = res.gaps;
+  return 1;
 }
