@@ -87,9 +87,11 @@ MIA_HD inline bool band_plan(const RefPlanes& rp, const KmerOcc& ko, int64_t n_r
   }
   const int budget = 800 * nb - 400;
   if (b0 > budget) return false;
-  // (one diagonal more than (b0 - 1000) / 200: a path that starts late in the window's first column gets its substitution
-  // score back, src/mia.c:838-846, and may spend those 200 on one more gap column)
-  const int g = b0 < GOP ? 0 : (b0 - GOP + GEP) / GEP;
+  // One diagonal more only where the window's first column is within reach: a path that starts late THERE gets its
+  // substitution score back (src/mia.c:838-846) and may spend those 200 on one more gap column; it starts on a
+  // negative diagonal, so with a_lo - g - 1 >= 0 no such path can come near an anchor.
+  int g = b0 < GOP + GEP ? 0 : (b0 - GOP) / GEP;
+  if (a_lo - g - 1 < 0) g++;
   const int d0 = a_lo - g, w = a_hi - a_lo + 2 * g + 1;
   if (w > BAND_W) return false;
   out->d0 = d0; out->w = w; out->budget = budget; out->b0 = b0;
@@ -109,8 +111,8 @@ MIA_HD inline uint64_t band_bits(const uint64_t* plane, int64_t bit) {
 // plain form of band_align applies
 MIA_HD inline bool band_interior(const BandPlan& bp, int wmax, int len1, int len2) { return bp.d0 >= 0 && len2 - 1 + bp.d0 + wmax <= len1; }
 
-// The DP over the band [d0, d0 + wmax), wmax >= the plan's width (a wavefront uses the widest of its 64 reads: a scalar
-// loop bound).  trace: 8 words (BAND_W bytes) per row, row r at trace + r * row_words -- private to the thread (the
+// The DP over the band [d0, d0 + wmax), wmax >= the plan's width and a multiple of 4 (a wavefront uses the widest of its
+// 64 reads: a scalar loop bound).  trace: 8 words (BAND_W bytes) per row, row r at trace + r * row_words -- private to the thread (the
 // kernel interleaves the rows of a wavefront's 64 reads so that its stores coalesce).  cols_out: the script (window column
 // per read row, COL_INSERT, COL_CLIP) as the other kernels write it.  false: the traceback met the reference's index-0
 // quirk -- the caller sends the read to the full-window kernels.  EDGE: the band may leave the window (see band_interior).
@@ -121,15 +123,25 @@ MIA_HD inline bool band_interior(const BandPlan& bp, int wmax, int len1, int len
 //   row gap    (best - GOP - GEP n) * 256 + n
 // and within one kind the LARGER n among equal values, i.e. the earliest source, as the reference's running maxima keep
 // the first of equals.  The winning code byte is the trace.  A new start (code 0x80) needs fresh > all three, strictly.
+// byte k of word w := the low byte of v
+MIA_HD inline uint32_t band_put(uint32_t w, uint32_t v, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_perm(v, w, 0x03020100u ^ ((uint32_t)(4 ^ k) << (8 * k)));
+#else
+  return (w & ~(0xFFu << (8 * k))) | ((v & 0xFFu) << (8 * k));
+#endif
+}
+
 template <bool EDGE>
 MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, const BandPlan& bp, int wmax, uint32_t* trace,
                               int64_t row_words, int16_t* cols_out, BandResult* res) {
   const int R = len2 - 1, d0 = bp.d0;
   constexpr int DEAD = BAND_NEG * 256;
   constexpr int STEP = 1 - GEP * 256;                 // a running maximum ages by one position: value - GEP, length + 1
-  constexpr int CAND = -GOP * 256 + STEP;             // a cell becomes a gap source: value - GOP - GEP, length 1
-  // P[j]: S(r-1, c-1) for the cell on diagonal d0 + j of the current row (its diagonal predecessor).
+  constexpr int CAND = -GOP * 256 + STEP - 0xFF;      // a cell (packed as a diagonal source) becomes a gap source: value - GOP - GEP, length 1
+  // P[j]: S(r-1, c-1) * 256 + (its trace code) for the cell on diagonal d0 + j of the current row (its diagonal predecessor).
   // H[j]: the packed row-gap candidate of that cell (best over rows <= r-2 of its left-hand column).
+  // wmax is a multiple of 4 here: cells are computed in groups of four behind one scalar branch.
   int32_t P[BAND_W], H[BAND_W];
   const uint32_t* rwords = reinterpret_cast<const uint32_t*>(read_packed);     // reads start on 4-byte boundaries
   uint64_t wl, wh;
@@ -146,7 +158,7 @@ MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_
 #pragma unroll
     for (int j = 0; j < BAND_W; j++) {
       H[j] = DEAD;
-      P[j] = ((live >> j) & 1u) ? (((match >> j) & 1u) ? FLAT_MATCH : FLAT_MISMATCH) : BAND_NEG;
+      P[j] = ((live >> j) & 1u) ? (((match >> j) & 1u) ? FLAT_MATCH : FLAT_MISMATCH) * 256 + 0xFF : DEAD;
     }
 #pragma unroll
     for (int k = 0; k < BAND_W / 4; k++) trace[k] = 0xFFFFFFFFu;
@@ -168,34 +180,35 @@ MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_
       col0 = (c0 <= 0 && c0 > -BAND_W) ? (1u << (-c0)) : 0u;                               // the cell in the window's first column
     }
     const int fresh = -(GOP + GEP * (r + 1));
-    const int f0 = fresh * 256;
+    const int f0 = fresh * 256, f0s = f0 | 0x80;
     int G = DEAD;                                 // the packed column-gap candidate of the cell about to be computed
     uint32_t tw[BAND_W / 4];
 #pragma unroll
     for (int k = 0; k < BAND_W / 4; k++) tw[k] = 0;
 #pragma unroll
-    for (int j = 0; j < BAND_W; j++) {
-      if (j < wmax) {                             // (the same for all reads of a wavefront: a scalar branch)
-        const int p = P[j], h = H[j];
-        const int sub = ((match >> j) & 1u) ? FLAT_MATCH : FLAT_MISMATCH;
-        const int pd = p * 256 + 0xFF, gc = G | 0x40;
-        const int x = pd > gc ? (pd > h ? pd : h) : (gc > h ? gc : h);
-        const bool start = f0 > x;                                                   // fresh beats all three, strictly
-        int cur = ((start ? f0 : x) >> 8) + (start ? 0 : sub);
-        int code = start ? 0x80 : (x & 0xFF);
-        if (EDGE) {
-          if ((col0 >> j) & 1u) { cur = sub + fresh; code = 0xFF; }                  // src/mia.c:838-846
-          if (!((live >> j) & 1u)) { cur = BAND_NEG; code = 0; }
+    for (int j0 = 0; j0 < BAND_W; j0 += 4) {
+      if (j0 < wmax) {                            // (the same for all reads of a wavefront: a scalar branch)
+#pragma unroll
+        for (int j = j0; j < j0 + 4; j++) {
+          const int pd = P[j] | 0xFF, h = H[j], gc = G | 0x40;
+          const int x = pd > gc ? (pd > h ? pd : h) : (gc > h ? gc : h);
+          const int sub256 = (int)((match >> j) & 1u) * ((FLAT_MATCH - FLAT_MISMATCH) * 256) + FLAT_MISMATCH * 256;
+          // value and trace code of the cell in one word; fresh must beat all three strictly (its code byte is 0 in f0)
+          int cur = f0 > x ? f0s : x + sub256;
+          if (EDGE) {
+            if ((col0 >> j) & 1u) cur = (sub256 + f0) | 0xFF;                          // src/mia.c:838-846
+            if (!((live >> j) & 1u)) cur = DEAD;
+          }
+          tw[j >> 2] = band_put(tw[j >> 2], (uint32_t)cur, j & 3);
+          // S(r-1, c-1) = P[j] becomes a gap source: for this row's cells further right, and for column c-1 (which the
+          // next row reaches from index j-1)
+          const int cand = pd + CAND;
+          G = G + STEP > cand ? G + STEP : cand;
+          if (j >= 1) H[j - 1] = h + STEP > cand ? h + STEP : cand;
+          P[j] = cur;
         }
-        tw[j >> 2] |= (uint32_t)code << (8 * (j & 3));
-        // S(r-1, c-1) = P[j] becomes a gap source: for this row's cells further right, and for column c-1 (which the
-        // next row reaches from index j-1)
-        const int cand = p * 256 + CAND;
-        G = G + STEP > cand ? G + STEP : cand;
-        if (j >= 1) H[j - 1] = h + STEP > cand ? h + STEP : cand;
-        P[j] = cur;
-      } else if (j == wmax) {
-        H[j - 1] = DEAD;                          // (wmax >= 1)
+      } else if (j0 == wmax) {
+        H[j0 - 1] = DEAD;                         // (wmax >= 4)
       }
     }
     if (wmax == BAND_W) H[BAND_W - 1] = DEAD;
@@ -206,30 +219,41 @@ MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_
   // max_sg_score: first maximum of the last row (src/mia.c:1278-1302)
   int best = BAND_NEG, bj = -1;
 #pragma unroll
-  for (int j = 0; j < BAND_W; j++) if (j < wmax && P[j] > best) { best = P[j]; bj = j; }
+  for (int j = 0; j < BAND_W; j++) if (j < wmax && (P[j] >> 8) > best) { best = P[j] >> 8; bj = j; }
   if (bj < 0 || best <= BAND_NEG / 2) return false;
-  // find_align_begin + populate_pwaln_to_begin (src/mia.c:612-637, 1440-1497)
+  // find_align_begin + populate_pwaln_to_begin (src/mia.c:612-637, 1440-1497).  Nearly every step is a diagonal one and
+  // stays on band index j: the trace bytes of eight rows are fetched at once, so that the walk waits for memory once per
+  // eight rows (and once per gap) instead of once per row.
   int r = R, c = R + d0 + bj, gaps = 0;
   const int aec = c;
-  for (;;) {
-    cols_out[r] = (int16_t)c;
-    if (r == 0 || c == 0) break;
+  bool stop = false;
+  while (!stop) {
     const int j = c - r - d0;
     if (j < 0 || j >= wmax) return false;
-    const int code = (int)((trace[(int64_t)r * row_words + (j >> 2)] >> (8 * (j & 3))) & 255u);
-    if (code == 0x80) break;
-    if (code == 0xFF) { r--; c--; }
-    else if (code & 0x40) {
-      const int sc = c - 1 - (code & 63);
-      if (sc <= 0) return false;             // a gap from column 0 reads back as a diagonal step in the reference: not followed here
+    uint32_t wv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) wv[k] = trace[(int64_t)(r - k > 0 ? r - k : 0) * row_words + (j >> 2)];
+    bool moved = false;                      // left index j: fetch again
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (stop || moved) continue;
+      cols_out[r] = (int16_t)c;
+      if (r == 0 || c == 0) { stop = true; continue; }
+      const int code = (int)((wv[k] >> (8 * (j & 3))) & 255u);
+      if (code == 0x80) { stop = true; continue; }
+      if (code == 0xFF) { r--; c--; continue; }
+      moved = true;
       gaps++;
-      r--; c = sc;
-    } else {
-      const int sr = r - 1 - code;
-      if (sr <= 0) return false;             // a gap from row 0: the same quirk
-      for (int q = r - 1; q > sr; q--) cols_out[q] = COL_INSERT;
-      gaps++;
-      r = sr; c--;
+      if (code & 0x40) {
+        const int sc = c - 1 - (code & 63);
+        if (sc <= 0) return false;           // a gap from column 0 reads back as a diagonal step in the reference: not followed here
+        r--; c = sc;
+      } else {
+        const int sr = r - 1 - code;
+        if (sr <= 0) return false;           // a gap from row 0: the same quirk
+        for (int q = r - 1; q > sr; q--) cols_out[q] = COL_INSERT;
+        r = sr; c--;
+      }
     }
   }
   for (int q = 0; q < r; q++) cols_out[q] = COL_CLIP;

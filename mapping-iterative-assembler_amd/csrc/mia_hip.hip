@@ -551,7 +551,7 @@ static int align_all(mia_hip_ctx* ctx) {
     if (banded) {
       // a persistent grid of wavefronts, each with its own trace slab (the number of left-over reads stays on the device)
       const int64_t chunks = (n + 63) / 64;
-      const int grid = (int)(chunks < 2048 ? chunks : 2048);
+      const int grid = (int)(chunks < 3072 ? chunks : 3072);          // three wavefronts per SIMD
       const int64_t slab_words = (int64_t)ctx->max_len * BAND_ROW_WORDS;
       if (slab_words * grid > ctx->band_slab_cap) {
         if (dev_alloc(ctx, &ctx->d_band_slabs, (size_t)(slab_words * grid))) return MIA_HIP_ERR_NOMEM;
@@ -563,7 +563,7 @@ static int align_all(mia_hip_ctx* ctx) {
       ctx->ev_used.pop_back();
       (void)hipEventRecord(b0, ctx->stream);
       hipLaunchKernelGGL(k_band_align, dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_left_list, ctx->d_filter_n + 1,
-                         ctx->d_band_slabs, slab_words, ctx->d_bin_of, ctx->d_filter_n + 2);
+                         ctx->d_band_slabs, slab_words, ctx->d_bin_of, ctx->d_filter_n + 2, ctx->d_filter_n + 3);
       (void)hipEventRecord(b1, ctx->stream);
       HIPCHK(hipGetLastError());
     }

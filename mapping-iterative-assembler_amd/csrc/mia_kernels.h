@@ -213,11 +213,16 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
 constexpr int BAND_ROW_WORDS = 64 * (BAND_W / 4);
 __global__ __launch_bounds__(64) void k_band_align(ReadSet rs, RefInfo ref, RefPlanes rp, KmerOcc ko, int64_t n_ref, const int32_t* left_list,
                                                    const uint32_t* n_left, uint32_t* trace_slabs, int64_t slab_words, int32_t* bin_of,
-                                                   uint32_t* n_done) {
+                                                   uint32_t* n_done, uint32_t* next_chunk) {
   const uint32_t total = *n_left;
   uint32_t* trace = trace_slabs + (int64_t)blockIdx.x * slab_words + threadIdx.x * (BAND_W / 4);
   uint32_t done = 0;
-  for (uint32_t chunk = blockIdx.x; (uint64_t)chunk * 64 < total; chunk += gridDim.x) {
+  for (;;) {
+    // chunks of 64 reads are handed out as wavefronts come free: their cost differs by the width of their bands
+    uint32_t chunk = 0;
+    if (threadIdx.x == 0) chunk = atomicAdd(next_chunk, 1u);
+    chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+    if ((uint64_t)chunk * 64 >= total) break;
     const uint32_t t = chunk * 64 + threadIdx.x;
     const bool live = t < total;
     const int64_t i = live ? left_list[t] : 0;
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(64) void k_band_align(ReadSet rs, RefInfo ref, RefP
     // recurrence only if no read's band leaves its window
     int w = ok ? bp.w : 0;
     for (int o = 32; o; o >>= 1) { const int v = __shfl_xor(w, o); w = v > w ? v : w; }
-    const int wmax = __builtin_amdgcn_readfirstlane(w);
+    const int wmax = (__builtin_amdgcn_readfirstlane(w) + 3) & ~3;
     if (wmax == 0) continue;
     const bool edge = __ballot(ok && !band_interior(bp, wmax, l1, len2)) != 0ull;
     if (!ok) continue;

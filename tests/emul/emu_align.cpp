@@ -281,7 +281,7 @@ extern "C" int emu_band(const uint8_t* ref_codes, int64_t n_codes, int ref_start
   std::vector<uint32_t> trace((size_t)len2 * (BAND_W / 4));
   BandResult res;
   // the kernel runs every read of a wavefront with the widest band among them: any width from the plan's up must do
-  const int wmax = bp.w + widen > BAND_W ? BAND_W : bp.w + widen;
+  const int wmax = ((bp.w + widen > BAND_W ? BAND_W : bp.w + widen) + 3) & ~3;
   const bool got = (band_interior(bp, wmax, len1, len2) && !(widen & 1))   // (odd widen: the edge form on interior reads too)
                       ? band_align<false>(rp, ref_start, len1, pb, len2, bp, wmax, trace.data(), BAND_W / 4, cols, &res)
                       : band_align<true>(rp, ref_start, len1, pb, len2, bp, wmax, trace.data(), BAND_W / 4, cols, &res);
