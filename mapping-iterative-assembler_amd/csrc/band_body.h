@@ -30,23 +30,50 @@ constexpr int BAND_NEG = -(1 << 22);  // "no such cell": far below any score a r
 
 struct BandPlan { int d0, w, budget, b0; };   // diagonals d0 .. d0 + w - 1 (column minus row, window coordinates)
 
+// 10-mer index (diag_filter.h: kmer_at's packing) of read rows o .. o+9, from the packed nibbles
+MIA_HD inline int64_t band_kmer(const uint32_t* pw, int len2, int o) {
+  const int w = o >> 3, last = (len2 - 1) >> 3;
+  const uint64_t w0 = pw[w], w1 = w + 1 <= last ? pw[w + 1] : 0u, w2 = w + 2 <= last ? pw[w + 2] : 0u;
+  const int sh = 4 * (o & 7);
+  uint64_t y = ((w0 | (w1 << 32)) >> sh) | (sh ? (w2 << 32) << (32 - sh) : 0ull);          // 40 bits: ten nibbles
+  y &= 0x3333333333ull;
+  y = (y | (y >> 2)) & 0x0F0F0F0F0Full;
+  y = (y | (y >> 4)) & 0x00FF00FF00FFull;
+  y = (y | (y >> 8)) & 0x0000FFFF0000FFFFull;
+  return (int64_t)((y & 0xFFFFull) | ((y >> 16) & 0xF0000ull));
+}
+
 // the band of a read, or false if the read is left to the full-window kernels
 MIA_HD inline bool band_plan(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2, BandPlan* out) {
   if (!ko.cnt || len2 < 6 * DF_K || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1 || s < 0 || (int64_t)s + len1 > n_ref) return false;
   if (!all_bases(rp, s, (int64_t)s + len1)) return false;
+  DiagScan<4> sc;
+  if (!sc.load_read(read_packed, len2)) return false;             // a read with N
   const int R = len2 - 1, nb_cut = len2 / DF_K < BAND_BLOCKS ? len2 / DF_K : BAND_BLOCKS;
+  const uint32_t* pw = reinterpret_cast<const uint32_t*>(read_packed);
+  // all look-ups first, then their use: nine independent loads in flight instead of nine round trips
+  int32_t cn[BAND_BLOCKS], ps[BAND_BLOCKS][DF_KCAP];
+#pragma unroll
+  for (int b = 0; b < BAND_BLOCKS; b++) {
+    cn[b] = DF_KCAP + 1;
+    if (b < nb_cut) {
+      const int64_t idx = band_kmer(pw, len2, (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1)));
+      cn[b] = ko.cnt[idx];
+#pragma unroll
+      for (int k = 0; k < DF_KCAP; k++) ps[b][k] = ko.pos[idx * DF_KCAP + k];
+    }
+  }
   int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0;
   bool any = false;
-  for (int r = 0; r < len2; r++) if (((read_packed[r >> 1] >> ((r & 1) * 4)) & 15) > 3) return false;      // a read with N
-  for (int b = 0; b < nb_cut; b++) {
-    const int o = (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1));
-    int64_t idx = 0;
-    for (int q = 0; q < DF_K; q++) { const int r = o + q; idx |= (int64_t)((read_packed[r >> 1] >> ((r & 1) * 4)) & 3) << (2 * q); }
-    const int n = ko.cnt[idx];
-    if (n > DF_KCAP) continue;                       // an overloaded 10-mer is not part of the pigeonhole
+#pragma unroll
+  for (int b = 0; b < BAND_BLOCKS; b++) {
+    if (cn[b] > DF_KCAP) continue;                   // no such block, or an overloaded 10-mer: not part of the pigeonhole
     nb++;
-    for (int k = 0; k < n; k++) {
-      const int d = ko.pos[idx * DF_KCAP + k] - o - s;        // diagonal in window coordinates
+    const int o = (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1));
+#pragma unroll
+    for (int k = 0; k < DF_KCAP; k++) {
+      if (k >= cn[b]) continue;
+      const int d = ps[b][k] - o - s;                         // diagonal in window coordinates
       if (d < -R || d > len1 - 1) continue;                   // not a place inside this window
       if (!any) { d_first = d; any = true; }
       d_last = d;
@@ -54,32 +81,40 @@ MIA_HD inline bool band_plan(const RefPlanes& rp, const KmerOcc& ko, int64_t n_r
       if (d > a_hi) a_hi = d;
     }
   }
-  if (nb < 6 || !any) return false;
+  if (nb < 6 || !any || a_hi - a_lo >= BAND_W) return false;
   // the loss of one valid path: rows [0, t) on d_first, one gap, the rest on d_last (or the plain diagonal if they agree)
   if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) return false;   // keep the written-down path inside the window
   int b0;
   {
-    auto mis = [&](int d, int r) {                 // 1 iff read row r mismatches on diagonal d (window coordinates)
-      const int c = (read_packed[r >> 1] >> ((r & 1) * 4)) & 3;
-      const int64_t p = (int64_t)s + d + r + PLANE_LEAD;
-      const int x = (int)((rp.lo[p >> 6] >> (p & 63)) & 1) | ((int)((rp.hi[p >> 6] >> (p & 63)) & 1) << 1);
-      return c != x ? 1 : 0;
-    };
+    uint64_t m1[4], m2[5];                           // mismatch masks of the read on the two diagonals
+    sc.seek(rp, (int64_t)s + d_first);
+#pragma unroll
+    for (int j = 0; j < 4; j++) m1[j] = sc.mis(j);
     if (d_first == d_last) {
-      int k = 0;
-      for (int r = 0; r < len2; r++) k += mis(d_first, r);
-      b0 = 800 * k;
+      b0 = 800 * (df_popc(m1[0]) + df_popc(m1[1]) + df_popc(m1[2]) + df_popc(m1[3]));
     } else {
+      sc.seek(rp, (int64_t)s + d_last);
+#pragma unroll
+      for (int j = 0; j < 4; j++) m2[j] = sc.mis(j);
+      m2[4] = 0;
       // column gap (d_last > d_first: the rows from t on continue d_last - d_first columns further right) or row gap (the read
       // skips d_first - d_last rows): prefix mismatches on d_first plus suffix mismatches on d_last, best switch row t
-      const int shift = d_last - d_first, skip = shift < 0 ? -shift : 0;
-      int prefix = 0, suffix = 0, best = 1 << 20;
-      for (int r = skip; r < len2; r++) suffix += mis(d_last, r);
+      const int shift = d_last - d_first, skip = shift < 0 ? -shift : 0;            // |shift| < BAND_W
+      if (skip) {                                    // bit t of m2 := its row t + skip
+#pragma unroll
+        for (int j = 0; j < 4; j++) m2[j] = (m2[j] >> skip) | (m2[j + 1] << (64 - skip));
+      }
+      int prefix = 0, suffix = df_popc(m2[0]) + df_popc(m2[1]) + df_popc(m2[2]) + df_popc(m2[3]), best = 1 << 20;
       // rows [0, t) on d_first, `skip` rows inserted, rows [t + skip, len2) on d_last; both stretches non-empty
-      for (int t = 1; t + skip <= R; t++) {
-        prefix += mis(d_first, t - 1);
-        suffix -= mis(d_last, t - 1 + skip);
-        if (prefix + suffix < best) best = prefix + suffix;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        for (int q = 0; q < 64; q++) {
+          const int t = j * 64 + q + 1;
+          if (t + skip > R) break;
+          prefix += (int)((m1[j] >> q) & 1);
+          suffix -= (int)((m2[j] >> q) & 1);
+          if (prefix + suffix < best) best = prefix + suffix;
+        }
       }
       if (best == (1 << 20)) return false;
       b0 = 800 * best + (shift > 0 ? GOP + GEP * shift : GOP + GEP * skip + FLAT_MATCH * skip);
@@ -134,7 +169,7 @@ MIA_HD inline uint32_t band_put(uint32_t w, uint32_t v, int k) {
 
 template <bool EDGE>
 MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_t* read_packed, int len2, const BandPlan& bp, int wmax, uint32_t* trace,
-                              int64_t row_words, int16_t* cols_out, BandResult* res) {
+                              int64_t row_words, int16_t* cols_out, BandResult* res, bool no_walk = false) {
   const int R = len2 - 1, d0 = bp.d0;
   constexpr int DEAD = BAND_NEG * 256;
   constexpr int STEP = 1 - GEP * 256;                 // a running maximum ages by one position: value - GEP, length + 1
@@ -220,7 +255,7 @@ MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_
   int best = BAND_NEG, bj = -1;
 #pragma unroll
   for (int j = 0; j < BAND_W; j++) if (j < wmax && (P[j] >> 8) > best) { best = P[j] >> 8; bj = j; }
-  if (bj < 0 || best <= BAND_NEG / 2) return false;
+  if (bj < 0 || best <= BAND_NEG / 2 || no_walk) return false;
   // find_align_begin + populate_pwaln_to_begin (src/mia.c:612-637, 1440-1497).  Nearly every step is a diagonal one and
   // stays on band index j: the trace bytes of eight rows are fetched at once, so that the walk waits for memory once per
   // eight rows (and once per gap) instead of once per row.

@@ -563,7 +563,7 @@ static int align_all(mia_hip_ctx* ctx) {
       ctx->ev_used.pop_back();
       (void)hipEventRecord(b0, ctx->stream);
       hipLaunchKernelGGL(k_band_align, dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_left_list, ctx->d_filter_n + 1,
-                         ctx->d_band_slabs, slab_words, ctx->d_bin_of, ctx->d_filter_n + 2, ctx->d_filter_n + 3);
+                         ctx->d_band_slabs, slab_words, ctx->d_bin_of, ctx->d_filter_n + 2, ctx->d_filter_n + 3, ctx->dbg);
       (void)hipEventRecord(b1, ctx->stream);
       HIPCHK(hipGetLastError());
     }

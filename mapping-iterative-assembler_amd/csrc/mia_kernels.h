@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, Re
 constexpr int BAND_ROW_WORDS = 64 * (BAND_W / 4);
 __global__ __launch_bounds__(64) void k_band_align(ReadSet rs, RefInfo ref, RefPlanes rp, KmerOcc ko, int64_t n_ref, const int32_t* left_list,
                                                    const uint32_t* n_left, uint32_t* trace_slabs, int64_t slab_words, int32_t* bin_of,
-                                                   uint32_t* n_done, uint32_t* next_chunk) {
+                                                   uint32_t* n_done, uint32_t* next_chunk, uint32_t dbg) {
   const uint32_t total = *n_left;
   uint32_t* trace = trace_slabs + (int64_t)blockIdx.x * slab_words + threadIdx.x * (BAND_W / 4);
   uint32_t done = 0;
@@ -237,12 +237,12 @@ __global__ __launch_bounds__(64) void k_band_align(ReadSet rs, RefInfo ref, RefP
     int w = ok ? bp.w : 0;
     for (int o = 32; o; o >>= 1) { const int v = __shfl_xor(w, o); w = v > w ? v : w; }
     const int wmax = (__builtin_amdgcn_readfirstlane(w) + 3) & ~3;
-    if (wmax == 0) continue;
+    if (wmax == 0 || (dbg & 256u)) continue;
     const bool edge = __ballot(ok && !band_interior(bp, wmax, l1, len2)) != 0ull;
     if (!ok) continue;
     BandResult res;
-    const bool got = edge ? band_align<true>(rp, s, l1, rd, len2, bp, wmax, trace, BAND_ROW_WORDS, rs.cols + i * rs.stride, &res)
-                          : band_align<false>(rp, s, l1, rd, len2, bp, wmax, trace, BAND_ROW_WORDS, rs.cols + i * rs.stride, &res);
+    const bool got = edge ? band_align<true>(rp, s, l1, rd, len2, bp, wmax, trace, BAND_ROW_WORDS, rs.cols + i * rs.stride, &res, (dbg & 512u) != 0)
+                          : band_align<false>(rp, s, l1, rd, len2, bp, wmax, trace, BAND_ROW_WORDS, rs.cols + i * rs.stride, &res, (dbg & 512u) != 0);
     if (!got) continue;
     rs.score[i] = res.score;
     rs.refstart[i] = s;
