@@ -45,7 +45,7 @@ PMC = {
     "k_align_quad": {"traffic_per_read": (661749.34 + 1279506.11) * 1024 / 95_407, "valu_utilisation": 0.79},
     "k_align_quad_plain": {"traffic_per_read": (111680.25 + 252603.66) * 1024 / 1_000_000, "valu_utilisation": 0.90},
     "k_diag_filter": {"traffic_per_read": (77280.98 + 204036.09) * 1024 / 1_000_000, "valu_utilisation": 0.69},
-    "k_band_align": {"traffic_per_read": None, "valu_utilisation": None},      # not yet profiled with counters
+    "k_band_align": {"traffic_per_read": (541971.03 + 637559.77) * 1024 / 176_751, "valu_utilisation": 0.46},
 }
 
 
@@ -224,11 +224,11 @@ def main():
     if rank == 0:
         total_reads = n * world
         value = total_reads * a.steps / dt
-        # Three kernels share the realignment: the diagonal filter (k_diag_filter, bit-parallel, finishes the reads whose
-        # alignment is provably one gap-free diagonal), the values-only DP (k_align_quad_plain) over the reads it left
-        # undecided, and the trace kernel k_align_quad for the reads that really carry a gap.  The roofline object describes
-        # whichever takes the most time per step; all three are listed under "stages".  MIA_HIP_NO_DIAG_FILTER=1 /
-        # MIA_HIP_NO_PLAIN=1 switch the first two off.
+        # Four kernels share the realignment: the diagonal filter (k_diag_filter, bit-parallel, finishes the reads whose
+        # alignment is provably one gap-free diagonal), the banded DP (k_band_align: exact band from ten-mer anchors, one read
+        # per thread) over what it leaves, and for the reads without a usable band the values-only DP (k_align_quad_plain)
+        # and the trace kernel k_align_quad.  The roofline object describes whichever takes the most time per step; all are
+        # listed under "stages".  MIA_HIP_NO_DIAG_FILTER=1 / MIA_HIP_NO_BAND_DP=1 / MIA_HIP_NO_PLAIN=1 switch the first three off.
         stages = []
 
         def stage(name, ms_total, k_launches, reads_total):
@@ -262,9 +262,10 @@ def main():
                          "reads_finished_by_filter_frac": filt_done / filt_seen if filt_seen else 0.0,
                          "reads_finished_by_banded_dp_frac": band_done / filt_seen if filt_seen else 0.0,
                          "reads_to_trace_kernel_frac": (plain_retried / (n * a.steps)) if plain_on else 1.0,
-                         "note": "the DP kernels are integer-VALU bound (SQ_ACTIVE_INST_VALU 79-90 % of SIMD capacity, profiles/r01/pmc): "
+                         "note": "the DP kernels are integer-VALU bound (SQ_ACTIVE_INST_VALU 46-90 % of SIMD capacity, profiles/r01/pmc): "
                                  "182 algorithmic HBM bytes per read (SURVEY 8d) put them at a fraction of a percent of the HBM roof "
-                                 "by construction; the trace kernel moves ~21 KB/read of trace band on top; see DESIGN.md 3.0-3.1"},
+                                 "by construction; the banded DP moves 6.8 KB/read (its 32-byte-per-row trace), the full-window trace "
+                                 "kernel ~21 KB/read; see DESIGN.md 3.0-3.1"},
         }
         if world == 1:      # single-GPU line only: the other ranks of a sharded run would sit waiting
             # pass 1 (new_kmer_filter + sg_align over the whole wrapped reference, both strands), reported separately
