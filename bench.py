@@ -245,7 +245,8 @@ def main():
         stage("k_diag_filter", filt_ms, filt_launches, filt_seen)
         stage("k_band_align", band_ms, band_launches, filt_seen - filt_done)
         stage("k_align_quad_plain", plain_ms, plain_launches, plain_in)
-        stage("k_align_quad", align_ms, launches, plain_retried if plain_on else n * a.steps)
+        to_trace = plain_retried if plain_on else (filt_seen - filt_done - band_done if filt_launches else n * a.steps)
+        stage("k_align_quad", align_ms, launches, to_trace)
         dom = max(stages, key=lambda st: st["ms_per_step"])
         out = {
             "metric": "reads aligned/sec per iteration (16.5kb mito ref, 100bp reads)",
@@ -261,7 +262,7 @@ def main():
                          "stages": stages,
                          "reads_finished_by_filter_frac": filt_done / filt_seen if filt_seen else 0.0,
                          "reads_finished_by_banded_dp_frac": band_done / filt_seen if filt_seen else 0.0,
-                         "reads_to_trace_kernel_frac": (plain_retried / (n * a.steps)) if plain_on else 1.0,
+                         "reads_to_trace_kernel_frac": to_trace / (n * a.steps),
                          "note": "the DP kernels are integer-VALU bound (SQ_ACTIVE_INST_VALU 46-90 % of SIMD capacity, profiles/r01/pmc): "
                                  "182 algorithmic HBM bytes per read (SURVEY 8d) put them at a fraction of a percent of the HBM roof "
                                  "by construction; the banded DP moves 6.8 KB/read (its 32-byte-per-row trace), the full-window trace "

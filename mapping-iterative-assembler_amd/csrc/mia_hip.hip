@@ -512,6 +512,7 @@ static int align_all(mia_hip_ctx* ctx) {
   const int tb = 256, gb = (int)((n + (int64_t)tb * PLAN_PER - 1) / ((int64_t)tb * PLAN_PER));
   const int filtered = ctx->flat && ctx->use_filter && ctx->ref_mostly_bases;
   uint32_t h_filter_n = 0;
+  bool banded = false;
   if (filtered) {
     // reads whose alignment is provably one gap-free diagonal never reach the DP kernels (diag_filter.h)
     const int64_t words = plane_words((int64_t)wrap + 64);
@@ -539,7 +540,7 @@ static int align_all(mia_hip_ctx* ctx) {
     ctx->ev_used.pop_back();
     (void)hipEventRecord(f0, ctx->stream);
     // what the filter leaves over goes through the banded DP first (band_body.h); it needs the table
-    const bool banded = ctx->use_banddp && ko.cnt && !(ctx->dbg & 128u);
+    banded = ctx->use_banddp && ko.cnt && !(ctx->dbg & 128u);
     if (banded && n > ctx->left_cap) {
       if (dev_alloc(ctx, &ctx->d_left_list, (size_t)n)) return MIA_HIP_ERR_NOMEM;
       ctx->left_cap = n;
@@ -568,7 +569,9 @@ static int align_all(mia_hip_ctx* ctx) {
       HIPCHK(hipGetLastError());
     }
   }
-  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && ctx->use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
+  // behind the banded DP the values-only pass has nothing left to prove: what the band could not take nearly always needs a trace
+  const bool use_plain = ctx->use_plain && !banded;
+  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   // host copies of the counters live in pinned memory when there is some: a copy to or from pageable memory makes the
   // host wait for the stream even when it is called "async"
   int32_t local_buf[4 * N_BINS + 16];
@@ -610,7 +613,7 @@ static int align_all(mia_hip_ctx* ctx) {
   }
   int n_quads_trace = n_quads, quad_begin_trace = quad_begin;
   bool wide_known = false;
-  if ((n_quads > 0 || filtered) && ctx->use_plain) {
+  if ((n_quads > 0 || filtered) && use_plain) {
     // first pass: values only; reads whose alignment is provably the pure diagonal are finished there
     if (n_quads > 0) {
     const int grid = n_quads < ctx->quad_wgs ? n_quads : ctx->quad_wgs;
