@@ -2,7 +2,9 @@
 // (/root/reference/src/mia.c:740-981,1278-1302,612-637,1440-1497) confined to a BAND of diagonals that provably holds
 // every alignment that matters, one read per thread.  Flat matrix, read and window free of N (diag_filter.h's premises).
 //
-// Which band.  Cut the read into nb 10-mers (diag_filter.h: pigeonhole).  Some valid path is cheap to write down -- the
+// Which band.  Cut the read into nb = min(9, len / 10) >= 3 disjoint 10-mers (diag_filter.h: pigeonhole; a substitution
+// costs 800 and breaks one of them, a gap of n columns 1000 + 200 n and breaks at most one, n inserted or clipped rows at
+// least 1000 + 400 n and touch at most n / 10 + 2: never less than 800 per 10-mer broken).  Some valid path is cheap to write down -- the
 // read on the diagonal of its first anchor up to a switch row, one gap, the rest on the diagonal of its last anchor -- and
 // its loss B0 (against 200 x len) bounds the optimum's.  If B0 <= 800 nb - 400, every path that loses no more than B0 runs
 // through an anchor and strays at most g = (B0 - 1000) / 200 diagonals from it (0 if B0 < 1200), so all of them, ties
@@ -25,7 +27,8 @@
 namespace mia {
 
 constexpr int BAND_W = 32;            // diagonals a thread keeps in registers
-constexpr int BAND_BLOCKS = 9;        // 10-mers cut out of the read (at least 6)
+constexpr int BAND_BLOCKS = 9;        // 10-mers cut out of the read: len / 10 of them, at most 9
+constexpr int BAND_MIN_BLOCKS = 3;    // ... and at least 3 (budget 2000: two substitutions, or one short indel and one substitution)
 constexpr int BAND_NEG = -(1 << 22);  // "no such cell": far below any score a read of 256 bases can have, small enough to pack
 
 struct BandPlan { int d0, w, budget, b0; };   // diagonals d0 .. d0 + w - 1 (column minus row, window coordinates)
@@ -45,7 +48,7 @@ MIA_HD inline int64_t band_kmer(const uint32_t* pw, int len2, int o) {
 
 // the band of a read, or false if the read is left to the full-window kernels
 MIA_HD inline bool band_plan(const RefPlanes& rp, const KmerOcc& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2, BandPlan* out) {
-  if (!ko.cnt || len2 < 6 * DF_K || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1 || s < 0 || (int64_t)s + len1 > n_ref) return false;
+  if (!ko.cnt || len2 < BAND_MIN_BLOCKS * DF_K || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1 || s < 0 || (int64_t)s + len1 > n_ref) return false;
   if (!all_bases(rp, s, (int64_t)s + len1)) return false;
   DiagScan<4> sc;
   if (!sc.load_read(read_packed, len2)) return false;             // a read with N
@@ -81,7 +84,7 @@ MIA_HD inline bool band_plan(const RefPlanes& rp, const KmerOcc& ko, int64_t n_r
       if (d > a_hi) a_hi = d;
     }
   }
-  if (nb < 6 || !any || a_hi - a_lo >= BAND_W) return false;
+  if (nb < BAND_MIN_BLOCKS || !any || a_hi - a_lo >= BAND_W) return false;
   // the loss of one valid path: rows [0, t) on d_first, one gap, the rest on d_last (or the plain diagonal if they agree)
   if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) return false;   // keep the written-down path inside the window
   int b0;

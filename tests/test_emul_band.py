@@ -62,7 +62,7 @@ def test_single_indels_everywhere(emul, oracle, flat):
     ref = "".join(rnd.choice("ACGT") for _ in range(4000))
     stats = [0, 0]
     for i in range(600):
-        n = rnd.randint(60, 180)
+        n = rnd.randint(30, 180)
         pos = rnd.randint(0, len(ref) - n - 40)
         src = ref[pos:pos + n + 30]
         at = rnd.choice([1, 2, 3, 5, 9, 10, 11, n // 2, n - 12, n - 10, n - 3, n - 2, rnd.randint(1, n - 2)])
@@ -127,13 +127,13 @@ def test_clipped_windows_and_late_starts(emul, oracle, flat):
     ref = "".join(rnd.choice("ACGT") for _ in range(1500))
     stats = [0, 0]
     for i in range(400):
-        n = rnd.randint(60, 150)
+        n = rnd.randint(32, 150)
         pos = rnd.choice([0, 0, 1, 2, 5, len(ref) - n, len(ref) - n - 1, rnd.randint(0, 30)])
         read = ref[pos:pos + n]
         junk = rnd.choice([0, 0, 3, 6, 12])                       # a junk head: the alignment starts late
         read = "".join(rnd.choice("ACGT") for _ in range(junk)) + read[junk:]
         if i % 3 == 0:
-            at = rnd.randint(12, n - 12)
+            at = rnd.randint(8, n - 8)
             read = read[:at] + read[at + 1:]
         read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([0, 1, 3])))
         s, l1 = window(ref, pos, len(read), margin=rnd.choice([50, 50, 10, 0]))
