@@ -136,7 +136,7 @@ MIA_HD inline bool band_plan(const RefPlanes& rp, const KmerOcc& ko, int64_t n_r
   return true;
 }
 
-struct BandResult { int score, abc, aec, abr, gaps; };
+struct BandResult { int score, abc, aec, abr, gaps; uint32_t gap_desc; };   // gap_desc: the last gap met by the traceback, as ST_ONEGAP's upper bits >> 8
 
 // 32 bits of a plane from bit position `bit` on
 MIA_HD inline uint64_t band_bits(const uint64_t* plane, int64_t bit) {
@@ -263,6 +263,7 @@ MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_
   // stays on band index j: the trace bytes of eight rows are fetched at once, so that the walk waits for memory once per
   // eight rows (and once per gap) instead of once per row.
   int r = R, c = R + d0 + bj, gaps = 0;
+  uint32_t gap_desc = 0;
   const int aec = c;
   bool stop = false;
   while (!stop) {
@@ -285,17 +286,19 @@ MIA_HD inline bool band_align(const RefPlanes& rp, int s, int len1, const uint8_
       if (code & 0x40) {
         const int sc = c - 1 - (code & 63);
         if (sc <= 0) return false;           // a gap from column 0 reads back as a diagonal step in the reference: not followed here
+        gap_desc = 0u | ((uint32_t)r << 1) | ((uint32_t)(code & 63) << 10);
         r--; c = sc;
       } else {
         const int sr = r - 1 - code;
         if (sr <= 0) return false;           // a gap from row 0: the same quirk
         for (int q = r - 1; q > sr; q--) cols_out[q] = COL_INSERT;
+        gap_desc = 1u | ((uint32_t)(sr + 1) << 1) | ((uint32_t)code << 10);
         r = sr; c--;
       }
     }
   }
   for (int q = 0; q < r; q++) cols_out[q] = COL_CLIP;
-  res->score = best; res->abc = c; res->aec = aec; res->abr = r; res->gaps = gaps;
+  res->score = best; res->abc = c; res->aec = aec; res->abr = r; res->gaps = gaps; res->gap_desc = gap_desc;
   return true;
 }
 

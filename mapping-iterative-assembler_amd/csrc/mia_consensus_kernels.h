@@ -158,7 +158,7 @@ struct RecInfo {              // per read, rebuilt every iteration by k_rec_geom
 // The tally visits the reads in bucket order, i.e. at random with respect to the per-read arrays: gathering a dozen
 // fields costs a dozen cache lines per read (1.8 GB per 1 M reads).  k_rec_params writes them side by side instead.
 enum { TREC_AS = 0, TREC_AE, TREC_LEN_ABR, TREC_FLAGS, TREC_REFSTART, TREC_ROFF, TREC_ACTF, TREC_SPARE, TREC_PARAMS = 8 };
-constexpr int TRF_RC = 1, TRF_DF = 2, TRF_DB = 4, TRF_DIAG = 8, TRF_TOO_LONG = 16, TRF_SK = 32;
+constexpr int TRF_RC = 1, TRF_DF = 2, TRF_DB = 4, TRF_DIAG = 8, TRF_TOO_LONG = 16, TRF_SK = 32, TRF_ONEGAP = 64;   // ONEGAP: TREC_SPARE describes the gap
 struct SlotInfo {             // per local AlnSeq slot (global slot - slot_base)
   int64_t base;               // first global slot of this context
   const int64_t* n_local_p;   // slots owned by this context in this iteration (device: the scan's total)
@@ -217,22 +217,49 @@ __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const i
     const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
     const int cbase = rs.refstart[i] - g.start_w;
     int nf = 0, nb = 0, af = 0;
+    // on the way: does the script hold exactly one gap?  (One run of inserted rows, or one jump over reference columns
+    // between two aligned rows.)  Then the tally can take the read without walking the script again (ST_ONEGAP).
+    int n_ev = 0, ins_rows = 0, ev_row = 0, ev_len = 0, ev_kind = 0;
     for (int r0 = abr; r0 < len2; r0 += 64) {
       const int r = r0 + lane;
-      bool isF = false, isB = false, alF = false;
+      bool isF = false, isB = false, alF = false, ins_row = false, ins_start = false, jump = false;
+      int jump_len = 0;
       if (r < len2) {
+        const int cp = r > abr ? (int)cols[r - 1] : -3;
         if (cols[r] == COL_INSERT) {
           int rn = r + 1;
           while (rn < len2 && cols[rn] < 0) rn++;
           const int o = cbase + cols[rn];
           if (o < g.ncols_f) isF = true; else if (g.split && o - g.ncols_f < g.ncols_b) isB = true;
+          ins_row = true;
+          ins_start = cp != COL_INSERT;
         } else if (cols[r] >= 0) {
           alF = (cbase + cols[r]) < g.ncols_f;
+          if (cp >= 0 && cols[r] - cp > 1) { jump = true; jump_len = cols[r] - cp - 1; }
         }
       }
       nf += __popcll(__ballot(isF));
       nb += __popcll(__ballot(isB));
       af += __popcll(__ballot(alF));
+      const unsigned long long m_ins = __ballot(ins_start), m_del = __ballot(jump);
+      ins_rows += __popcll(__ballot(ins_row));
+      if (n_ev == 0 && (m_ins | m_del)) {
+        const int l = __builtin_ctzll(m_ins | m_del);
+        ev_row = r0 + l;
+        ev_kind = (int)((m_ins >> l) & 1ull);
+        ev_len = __shfl(jump_len, l);
+      }
+      n_ev += __popcll(m_ins) + __popcll(m_del);
+    }
+    if (lane == 0) {
+      const uint32_t st = rs.status[i];
+      if (!(st & (ST_ESCAPE | ST_TOO_LONG | ST_SKIPPED | ST_BAND | ST_DIAG))) {
+        const int gn = ev_kind ? ins_rows : ev_len, n_al = len2 - abr;
+        // (the columns must be what one gap explains: an insert followed by a jump is left to the script walk)
+        const bool one = n_ev == 1 && !g.split && gn > 0 && gn < 64 && ev_row < 512 && g.ncols_f == (ev_kind ? n_al - gn : n_al + gn);
+        const uint32_t want = one ? (ST_ONEGAP | (((uint32_t)ev_kind | ((uint32_t)ev_row << 1) | ((uint32_t)gn << 10)) << 8)) : ST_OK;
+        if (st != want) rs.status[i] = want;        // (k_band_align's own description of its one gap is the same word)
+      }
     }
     if (lane == 0) rec_store(i, g, nf, nb, af, len2 - abr, slot, ri, si, read_base, flags);
   }
@@ -345,8 +372,8 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
   t[TREC_AS] = rs.as[i]; t[TREC_AE] = rs.ae[i];
   t[TREC_LEN_ABR] = (int32_t)((uint32_t)rs.len[i] | ((uint32_t)(uint16_t)rs.abr[i] << 16));
   t[TREC_FLAGS] = (rs.rc[i] ? TRF_RC : 0) | (df ? TRF_DF : 0) | (db ? TRF_DB : 0) | ((st & ST_DIAG) ? TRF_DIAG : 0) |
-                  ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0);
-  t[TREC_REFSTART] = rs.refstart[i]; t[TREC_ROFF] = (int32_t)rs.roff[i]; t[TREC_ACTF] = ri.actf[i]; t[TREC_SPARE] = 0;
+                  ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0) | ((st & ST_ONEGAP) ? TRF_ONEGAP : 0);
+  t[TREC_REFSTART] = rs.refstart[i]; t[TREC_ROFF] = (int32_t)rs.roff[i]; t[TREC_ACTF] = ri.actf[i]; t[TREC_SPARE] = (int32_t)(st >> 8);
   for (int k = 0; k < 8; k++) t[TREC_PARAMS + k] = p[k];
 }
 
@@ -361,6 +388,13 @@ __device__ __forceinline__ int depth_code(int dff, int dfb) {   // src/fsdb.c:57
 // around the origin) takes the global atomic.  Same integer sums either way.
 constexpr int TALLY_EV_CAP = 256;    // insert events a workgroup buffers in LDS
 constexpr int TALLY_BUCKET = 128, TALLY_WIN = 384, TALLY_CHUNK = 512;   // 20 KB of LDS per workgroup: 8 workgroups (32 waves) per CU
+
+// The LDS window of a workgroup is circular: slot k holds column win_base + k, and past the end of the reference the
+// columns 0, 1, ... (the back records of reads over the origin, which all start in the last bucket).
+__device__ __forceinline__ int tally_slot(int gc, int win_base, int Lp) {
+  const int wc = gc - win_base;
+  return wc < 0 ? wc + Lp : wc;
+}
 
 template <bool BINNED>
 __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSet& rs, const RefInfo& ref, const int32_t* pssm2,
@@ -407,7 +441,7 @@ __device__ __forceinline__ void tally_one_read(int64_t i, int lane, const ReadSe
     if (gc < 0 || gc >= Lp) { atomicOr(tb.flags, 2u); return; }
     const int d = dcode(back, act);
     if (d < 0 || d > 2 * PSSM_DEPTH) { atomicOr(tb.flags, 2u); return; }
-    const int wc = gc - win_base;
+    const int wc = tally_slot(gc, win_base, Lp);
     const bool in_lds = BINNED && wc >= 0 && wc < TALLY_WIN;
     int s0 = 0, s1 = 0, s2 = 0, s3 = 0;                    // sm[d][X][code], X = A,C,G,T (src/map_align.c:258-261)
     if (!dropped && code != 5) {
@@ -631,6 +665,129 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
         if (bad | (int)(word & (dbg & 16u ? 0x40000000u : 0u))) atomicOr(tb.flags, 2u);
       }
     }
+    // Proven-diagonal reads that run over the origin (two records: front in this window, back at the start of the
+    // reference) all start in the last bucket, where nine reads in ten are of this kind: one per lane as well, every base
+    // through the general path's rules (tally_one_read's emit: record, depth-code validity, dropped flags, multiplicity;
+    // outside the LDS window the scores are added explicitly).
+    if (have && !fast && !(dbg & 8u)) {
+      const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16);
+      const int4 a = tr4[0], b4 = tr4[1], c4 = tr4[2], d4 = tr4[3];
+      const int flags = a.w;
+      const int len2 = a.z & 0xFFFF, abr = (int)(int16_t)((uint32_t)a.z >> 16);
+      const RecGeom g = rec_geom(a.x, a.y, L);
+      const int n_al = len2 - abr, w0 = g.start_w - win_base, actF = b4.z;
+      const bool wrap2 = linear && (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && (flags & TRF_DIAG) && g.split && g.start_w < L && w0 >= 0 &&
+                         w0 + g.ncols_f <= TALLY_WIN && n_al == g.ncols_f + g.ncols_b && n_al > 0 && actF == g.ncols_f;
+      if (wrap2) {
+        fast = true;
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);
+        const bool dF = (flags & TRF_DF) != 0, dB = (flags & TRF_DB) != 0;
+        const int fBase = c4.x, fOff = c4.y, fB = c4.z, fMult = c4.w, bBase = d4.x, bOff = d4.y, bB = d4.z, bMult = d4.w;
+        uint32_t word = 0;
+        int bad = 0;
+        // coverage and span of the two records as range counts (see cov_diff) when both are listed once and the back
+        // record fits the window's circular part; per column otherwise
+        const int sb = tally_slot(0, win_base, Lp);
+        const bool ranges = fMult == 1 && bMult == 1 && sb >= 0 && sb + g.ncols_b <= TALLY_WIN;
+        for (int act = 0; act < n_al; act++) {
+          const int r = abr + act;
+          if (act == 0 || (r & 7) == 0) word = rp[r >> 3];
+          const int code = (int)((word >> ((r & 7) * 4)) & 15u);
+          const bool back = act >= g.ncols_f;
+          const int p = back ? act - g.ncols_f : act, gc = back ? p : g.start_w + act, mult = back ? bMult : fMult;
+          const bool dropped = back ? dB : dF;
+          const int aa = back ? bOff + (act - actF) : fOff + act;
+          const int d = depth_code((back ? bBase : fBase) + aa, (back ? bB : fB) - aa - 1);
+          if (gc < 0 || gc >= Lp || d < 0 || d > 2 * PSSM_DEPTH) { bad = 1; continue; }
+          const int wc = tally_slot(gc, win_base, Lp);
+          if (wc >= 0 && wc < TALLY_WIN) {
+            lds_i32* t = (lds_i32*)lds + wc;
+            if (!dropped) {
+              if (!ranges) aadd(&t[T_COV * TALLY_WIN], mult);
+              if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], mult); else aadd((lds_i32*)n_cnt + wc, mult);
+            }
+            if (!ranges && p > 0) aadd(&t[T_SPAN * TALLY_WIN], mult);
+          } else {
+            int32_t* t = tb.tally + gc;
+            if (!dropped) {
+              atomicAdd(&t[T_COV * Lp], mult);
+              if (code < 4) atomicAdd(&t[(T_A + code) * Lp], mult);
+              atomicAdd(&t[T_SA * Lp], mult * (int)pssm_lds[0 * 5 + code]);
+              atomicAdd(&t[T_SC * Lp], mult * (int)pssm_lds[1 * 5 + code]);
+              atomicAdd(&t[T_SG * Lp], mult * (int)pssm_lds[2 * 5 + code]);
+              atomicAdd(&t[T_ST * Lp], mult * (int)pssm_lds[3 * 5 + code]);
+            }
+            if (p > 0) atomicAdd(&t[T_SPAN * Lp], mult);
+          }
+        }
+        if (ranges) {
+          auto range = [&](lds_i32* diff, int from, int to) {          // +1 on slots from .. to-1
+            if (to <= from) return;
+            aadd(diff + from, 1);
+            if (to < TALLY_WIN) aadd(diff + to, -1);
+          };
+          if (!dF) range((lds_i32*)cov_diff, w0, w0 + g.ncols_f);
+          if (!dB) range((lds_i32*)cov_diff, sb, sb + g.ncols_b);
+          range((lds_i32*)span_diff, w0 + 1, w0 + g.ncols_f);            // start < pos <= end of each record, dropped or not
+          range((lds_i32*)span_diff, sb + 1, sb + g.ncols_b);
+        }
+        if (bad) atomicOr(tb.flags, 2u);
+      }
+    }
+    // Second most common: one gap (k_band_align says where), otherwise as above, counts only (linear).  Also one read per
+    // lane: the bases before the gap, the gap -- deleted reference columns count as '-', inserted read rows become insert
+    // events (src/map_align.c:444-510 through the general path's event format) --, the bases after it.
+    if (have && !fast && linear && !(dbg & 8u)) {
+      const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16);
+      const int4 a = tr4[0], b4 = tr4[1], c4 = tr4[2];
+      const int flags = a.w;
+      const int len2 = a.z & 0xFFFF, abr = (int)(int16_t)((uint32_t)a.z >> 16);
+      const RecGeom g = rec_geom(a.x, a.y, L);
+      const uint32_t desc = (uint32_t)b4.w;
+      const int ins = (int)(desc & 1u), grow = (int)((desc >> 1) & 511u), gn = (int)((desc >> 10) & 63u);
+      const int n_al = len2 - abr, ncol = ins ? n_al - gn : n_al + gn, w0 = g.start_w - win_base;
+      const int fBase = c4.x, fOff = c4.y, fB = c4.z, fMult = c4.w;
+      const bool one = (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && (flags & TRF_ONEGAP) && !(flags & TRF_DIAG) && !g.split && fMult == 1 &&
+                       fBase == 0 && fOff == 0 && w0 >= 0 && ncol > 0 && w0 + ncol <= TALLY_WIN && g.start_w + ncol <= Lp && ncol == g.ncols_f &&
+                       gn > 0 && grow > abr && grow + (ins ? gn : 0) < len2;
+      if (one) {
+        fast = true;
+        if (!(dbg & 2048u)) {
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);
+        const bool dF = (flags & TRF_DF) != 0;
+        lds_i32* t = (lds_i32*)lds + w0;
+        lds_i32* nc = (lds_i32*)n_cnt + w0;
+        const int bad = n_al > PSSM_DEPTH + 1 && fB < n_al;            // (depth codes only have to be valid, see above)
+        uint32_t word = 0;
+        for (int r = abr; r < len2; r++) {
+          if (r == abr || (r & 7) == 0) word = rp[r >> 3];
+          const int code = (int)((word >> ((r & 7) * 4)) & 15u);
+          if (r == grow && !ins) {                                     // deleted reference columns: '-' (covered, not a base)
+            for (int q = 0; q < gn; q++) { if (!dF) aadd(&t[T_GAP * TALLY_WIN], 1); t++; nc++; }
+          }
+          if (ins && r >= grow && r < grow + gn) {                     // an inserted base: an event at the column that follows
+            const int o = grow - abr, gc = g.start_w + o, act = grow + gn - abr, j = r - grow;
+            if (j == 0) atomicMax(&tb.gaps[gc], gn);
+            const int d = depth_code(act, fB - act - 1);
+            const uint64_t ev = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
+                                ((uint64_t)((flags & TRF_RC) ? 1 : 0) << 50);
+            const int slot = atomicAdd(&ev_cnt, 1);
+            if (slot < TALLY_EV_CAP) ev_buf[slot] = ev;
+            else {
+              const int e = atomicAdd(tb.n_events, 1);
+              if (e < tb.cap_events) tb.events[e] = ev; else atomicOr(tb.flags, 1u);
+            }
+            continue;
+          }
+          if (!dF) { if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1); else aadd(nc, 1); }
+          t++; nc++;
+        }
+        if (!dF) { aadd((lds_i32*)cov_diff + w0, 1); if (w0 + ncol < TALLY_WIN) aadd((lds_i32*)cov_diff + w0 + ncol, -1); }
+        if (ncol > 1) { aadd((lds_i32*)span_diff + w0 + 1, 1); if (w0 + ncol < TALLY_WIN) aadd((lds_i32*)span_diff + w0 + ncol, -1); }
+        if (bad) atomicOr(tb.flags, 2u);
+        }
+      }
+    }
     // The reads left over are taken one per wavefront and one after the other; each begins with loads of its record,
     // script and bases.  The record is already in the registers of the lane that owns the read and is handed over
     // through LDS; script and bases are touched by all owning lanes first, side by side, so that the serial part finds
@@ -702,7 +859,8 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) slab[k] = lds[k];
 }
 
-// tally[word][gc] += sum of the windows that cover column gc: buckets floor(gc/128)-2 .. floor(gc/128), all their chunks.
+// tally[word][gc] += sum of the windows that cover column gc: buckets floor(gc/128)-2 .. floor(gc/128), all their chunks,
+// and the last buckets' windows where they wrap around to the start of the reference.
 // Runs after k_tally_binned; nothing else writes the tally then, so plain read-modify-write.
 __global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs) {
   const int gc = blockIdx.x * blockDim.x + threadIdx.x;
@@ -714,6 +872,15 @@ __global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, c
   for (int b = max(0, gc / TALLY_BUCKET - (TALLY_WIN / TALLY_BUCKET - 1)); b <= bhi; b++) {
     const int wc = gc - b * TALLY_BUCKET;
     if (wc < 0 || wc >= TALLY_WIN) continue;
+    for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) {
+      const int32_t* slab = slabs + (int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + wc;
+      for (int w = 0; w < TALLY_WORDS - 1; w++) acc[w] += slab[w * TALLY_WIN];
+    }
+  }
+  // ... and the circular part of the last buckets' windows (tally_slot): slot gc + Lp - b * TALLY_BUCKET
+  for (int b = max(0, (Lp + gc - TALLY_WIN) / TALLY_BUCKET); b < nb; b++) {
+    const int wc = gc + Lp - b * TALLY_BUCKET;
+    if (wc < 0 || wc >= TALLY_WIN || gc >= b * TALLY_BUCKET) continue;     // (columns from win_base on sit in their direct slot)
     for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) {
       const int32_t* slab = slabs + (int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + wc;
       for (int w = 0; w < TALLY_WORDS - 1; w++) acc[w] += slab[w * TALLY_WIN];

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void k_band_align(ReadSet rs, RefInfo ref, RefP
     rs.abr[i] = (int16_t)res.abr;
     rs.as[i] = res.abc + s;                   // src/mia_main.c:254-255
     rs.ae[i] = res.aec + s;
-    rs.status[i] = res.gaps ? ST_OK : ST_DIAG;
+    rs.status[i] = res.gaps == 0 ? ST_DIAG : (res.gaps == 1 ? (ST_ONEGAP | (res.gap_desc << 8)) : ST_OK);
     bin_of[i] = -4;
     done++;
   }

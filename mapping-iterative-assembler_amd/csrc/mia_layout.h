@@ -76,6 +76,9 @@ constexpr uint32_t ST_TOO_LONG = 2;  // alignment longer than 512 columns (undef
 constexpr uint32_t ST_SKIPPED = 4;   // strand_known == 0 (src/mia_main.c:178)
 constexpr uint32_t ST_BAND = 8;      // the path left the stored trace band of the quad kernel: re-run with a full trace
 
+// exactly one gap, described in the upper bits (k_band_align): bit 8 = 1 for inserted read rows / 0 for deleted reference
+// columns, bits 9-17 = first inserted row / first row after the deletion, bits 18-23 = length of the gap
+constexpr uint32_t ST_ONEGAP = 32;
 constexpr uint32_t ST_DIAG = 16;     // proven pure diagonal (k_align_quad_plain): no insert, no deletion, script = consecutive columns
 
 constexpr int16_t COL_INSERT = -1;

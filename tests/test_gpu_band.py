@@ -119,3 +119,54 @@ def test_reads_at_the_origin_of_a_circular_reference():
     as0 = start.astype(np.int32)
     ae0 = (as0 + 89).astype(np.int32)
     run_both(mia_amd, ref.tobytes().decode(), reads, 90, as0, ae0, 0.0)
+
+
+@pytest.mark.parametrize("seed,read_len", [(51, 100), (52, 70), (53, 140)])
+def test_tally_of_one_gap_reads(seed, read_len):
+    """k_band_align tells the tally where the single gap of a read is (ST_ONEGAP), and the binned tally then takes such
+    reads one per lane instead of one per wavefront.  Column tallies, ref->gaps, the consensus (with its inserts) and the
+    insert tallies must be what the script-walking path gives with the banded DP switched off: reads with one deletion,
+    one insertion, at all distances from the ends, both strands, dropped and kept, reads over the origin."""
+    import mia_amd
+    rng = np.random.default_rng(seed)
+    L = 9000
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), L)
+    n = 200_000
+    reads, start = damaged_reads(rng, ref, n, read_len, 0.6, 5, 3, two_share=0.1, junk_share=0.02)
+    # some inserts shared by many reads, so that the consensus calls them
+    for p in rng.integers(200, L - 200, 12):
+        ins = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(1, 4)))
+        hit = np.nonzero((start < p - 15) & (start + read_len > p + 15 + len(ins)))[0]
+        for i in hit[: len(hit) * 3 // 4]:
+            o = int(p - start[i])
+            reads[i] = np.concatenate([ref[start[i]: start[i] + o], ins, ref[start[i] + o: start[i] + read_len]])[:read_len]
+    strand = (rng.random(n) < 0.5).astype(np.uint8)
+    off = np.arange(n + 1, dtype=np.int64) * read_len
+    as0 = (start % L).astype(np.int32)
+    ae0 = (as0 + read_len - 1).astype(np.int32)
+    refs = ref.tobytes().decode()
+    out = []
+    for band_off in (False, True):
+        if band_off:
+            os.environ["MIA_HIP_NO_BAND_DP"] = "1"
+        try:
+            hip = mia_amd.MiaHip(0)
+        finally:
+            os.environ.pop("MIA_HIP_NO_BAND_DP", None)
+        hip.set_pssm(mia_amd.flat_pssm())
+        hip.upload_reads(reads.reshape(-1), off, strand, np.ones(n, np.uint8), as0, ae0)
+        hip.realign(refs, True)
+        sc, a, e = hip.alignments()
+        cut = hip.score_cut(sc, np.full(n, read_len, np.int32))
+        hip.cull(0, cut[0] if cut[0] > 0 else 100.0, cut[1], 0)
+        hip.tally()
+        t, g = hip.get_tally()
+        cons = hip.consensus(1)
+        it = hip.ins_tally()
+        out.append((t, g, cons, it, hip.band_stats()[0]))
+        hip.close()
+    assert out[0][4] > 0.2 * n and out[1][4] == 0
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2] and out[0][1].max() > 0          # (the same consensus; insert events did reach ref->gaps)
+    for x, y in zip(out[0][3], out[1][3]):
+        assert np.array_equal(x, y)
