@@ -206,6 +206,12 @@ __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const i
       const RecGeom g = rec_geom(rs.as[me], rs.ae[me], L);
       const int af = (len2 - abr) < g.ncols_f ? (len2 - abr) : g.ncols_f;
       rec_store(me, g, 0, 0, af, len2 - abr, slot, ri, si, read_base, flags);
+    } else if ((rs.status[me] & ST_ONEGAP) && !rec_geom(rs.as[me], rs.ae[me], L).split) {
+      // k_band_align's reads with one gap, one record: inserted bases and aligned bases follow from the gap's description
+      const uint32_t desc = rs.status[me] >> 8;
+      const int len2 = rs.len[me], abr = rs.abr[me], gn = (int)((desc >> 10) & 63u), ins = (int)(desc & 1u);
+      const RecGeom g = rec_geom(rs.as[me], rs.ae[me], L);
+      rec_store(me, g, ins ? gn : 0, 0, len2 - abr - (ins ? gn : 0), len2 - abr, slot, ri, si, read_base, flags);
     } else walk = true;
   }
   unsigned long long todo = __ballot(walk);
@@ -367,14 +373,15 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
   }
   drop_front[i] = df;
   drop_back[i] = db;
-  int32_t* t = ri.trec + i * 16;
   const uint32_t st = rs.status[i];
-  t[TREC_AS] = rs.as[i]; t[TREC_AE] = rs.ae[i];
-  t[TREC_LEN_ABR] = (int32_t)((uint32_t)rs.len[i] | ((uint32_t)(uint16_t)rs.abr[i] << 16));
-  t[TREC_FLAGS] = (rs.rc[i] ? TRF_RC : 0) | (df ? TRF_DF : 0) | (db ? TRF_DB : 0) | ((st & ST_DIAG) ? TRF_DIAG : 0) |
-                  ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0) | ((st & ST_ONEGAP) ? TRF_ONEGAP : 0);
-  t[TREC_REFSTART] = rs.refstart[i]; t[TREC_ROFF] = (int32_t)rs.roff[i]; t[TREC_ACTF] = ri.actf[i]; t[TREC_SPARE] = (int32_t)(st >> 8);
-  for (int k = 0; k < 8; k++) t[TREC_PARAMS + k] = p[k];
+  // the 64-byte record in four 16-byte stores (sixteen 4-byte ones, 64 bytes apart across the lanes, took twice as long)
+  int4* t4 = reinterpret_cast<int4*>(ri.trec + i * 16);
+  const int fl = (rs.rc[i] ? TRF_RC : 0) | (df ? TRF_DF : 0) | (db ? TRF_DB : 0) | ((st & ST_DIAG) ? TRF_DIAG : 0) |
+                 ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0) | ((st & ST_ONEGAP) ? TRF_ONEGAP : 0);
+  t4[0] = make_int4(rs.as[i], rs.ae[i], (int32_t)((uint32_t)rs.len[i] | ((uint32_t)(uint16_t)rs.abr[i] << 16)), fl);   // TREC_AS, _AE, _LEN_ABR, _FLAGS
+  t4[1] = make_int4(rs.refstart[i], (int32_t)rs.roff[i], ri.actf[i], (int32_t)(st >> 8));                                // TREC_REFSTART, _ROFF, _ACTF, _SPARE
+  t4[2] = make_int4(p[0], p[1], p[2], p[3]);                                                                              // TREC_PARAMS ..
+  t4[3] = make_int4(p[4], p[5], p[6], p[7]);
 }
 
 // ---- tally: one read per wavefront, one read row per lane (4 passes for 256-base reads) ----
