@@ -55,11 +55,23 @@ __global__ void k_scan_blocks(ReadSet rs, int32_t L, int64_t* partial) {
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
-__global__ void k_scan_partials(int64_t* partial, int nb, int64_t base, int64_t* total) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int64_t run = base;
-  for (int b = 0; b < nb; b++) { int64_t v = partial[b]; partial[b] = run; run += v; }
-  *total = run - base;
+__global__ __launch_bounds__(256) void k_scan_partials(int64_t* partial, int nb, int64_t base, int64_t* total) {
+  // one workgroup of 256 threads: every thread a stretch of the partial sums, a scan over the 256 stretch sums in LDS
+  __shared__ int64_t s_run[256];
+  const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
+  int64_t mine = 0;
+  for (int b = b0; b < b1; b++) mine += partial[b];
+  s_run[t] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int64_t a = t >= o ? s_run[t - o] : 0;
+    __syncthreads();
+    s_run[t] += a;
+    __syncthreads();
+  }
+  int64_t run = base + s_run[t] - mine;
+  for (int b = b0; b < b1; b++) { const int64_t v = partial[b]; partial[b] = run; run += v; }
+  if (t == 255) *total = s_run[255];
 }
 __global__ void k_scan_apply(ReadSet rs, int32_t L, const int64_t* partial, int64_t* slot) {
   __shared__ int32_t sh[256];
@@ -545,12 +557,23 @@ __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, in
   for (int b = threadIdx.x; b < nb; b += blockDim.x) if (hist[b]) atomicAdd(&count[b], hist[b]);
 }
 // off[b] = first read of bucket b in `order`, wgoff[b] = first workgroup of bucket b (TALLY_CHUNK reads each)
-__global__ void k_bucket_scan(const int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void k_bucket_scan(const int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor) {
+  // one workgroup of 256 threads: every thread a stretch of buckets, a scan over the 256 partial sums in LDS
+  __shared__ int32_t s_run[256], s_wg[256];
+  const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
   int run = 0, wg = 0;
-  for (int b = 0; b < nb; b++) { off[b] = run; wgoff[b] = wg; cursor[b] = 0; run += count[b]; wg += (count[b] + TALLY_CHUNK - 1) / TALLY_CHUNK; }
-  off[nb] = run;
-  wgoff[nb] = wg;
+  for (int b = b0; b < b1; b++) { run += count[b]; wg += (count[b] + TALLY_CHUNK - 1) / TALLY_CHUNK; }
+  s_run[t] = run; s_wg[t] = wg;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int a = t >= o ? s_run[t - o] : 0, c = t >= o ? s_wg[t - o] : 0;
+    __syncthreads();
+    s_run[t] += a; s_wg[t] += c;
+    __syncthreads();
+  }
+  int r = s_run[t] - run, w = s_wg[t] - wg;
+  for (int b = b0; b < b1; b++) { off[b] = r; wgoff[b] = w; cursor[b] = 0; r += count[b]; w += (count[b] + TALLY_CHUNK - 1) / TALLY_CHUNK; }
+  if (t == 255) { off[nb] = s_run[255]; wgoff[nb] = s_wg[255]; }
 }
 __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order) {
   extern __shared__ int32_t sh[];

@@ -820,7 +820,7 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   if (n == 0) return MIA_HIP_OK;
   const int nb = (int)((n + 4095) / 4096);
   hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial);
-  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(64), 0, ctx->stream, ctx->d_partial, nb, slot_base, ctx->d_total);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partial, nb, slot_base, ctx->d_total);
   hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, ctx->d_slot);
   if (slot_base + 2 * n + 16 > ctx->n_slots) {   // sharded runs: slots are global indices
     uint8_t* nd = nullptr;
@@ -1080,7 +1080,7 @@ extern "C" int mia_hip_num_records(mia_hip_ctx* ctx, int64_t* n_records) {
   if (n == 0) return MIA_HIP_OK;
   const int nb = (int)((n + 4095) / 4096);
   hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial);
-  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(64), 0, ctx->stream, ctx->d_partial, nb, (int64_t)0, ctx->d_total);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partial, nb, (int64_t)0, ctx->d_total);
   HIPCHK(hipMemcpyAsync(n_records, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return MIA_HIP_OK;
@@ -1141,7 +1141,7 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
       HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, ctx->stream));
       const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
       hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, ctx->stream, ctx->rs, nb, d_cnt);
-      hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(64), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur);
+      hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur);
       hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, ctx->stream, ctx->rs, nb, d_off, d_cur, ctx->d_order);
       const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
       const int64_t slab_words = (int64_t)grid * (TALLY_WORDS - 1) * TALLY_WIN;
