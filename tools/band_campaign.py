@@ -1,0 +1,36 @@
+"""A longer differential campaign for the banded DP than the test suite has time for: many seeds of
+tests/test_gpu_band.py's generators (random and adversarial references, read lengths 30-250, indels up to 12, jittered
+pass-1 coordinates), banded DP on against off, every read's score, end points and script.  usage: band_campaign.py [rounds [first seed]]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mia_amd  # noqa: E402
+from test_gpu_band import damaged_reads, run_both  # noqa: E402
+from test_gpu_filter_stress import adversarial_reference  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+t0 = time.time()
+reads_total = 0
+for k in range(rounds):
+    seed = seed0 + k
+    rng = np.random.default_rng(seed)
+    read_len = int(rng.choice([30, 33, 41, 50, 59, 60, 64, 77, 90, 100, 101, 128, 150, 200, 250]))
+    L = int(rng.integers(2000, 20000))
+    ref = adversarial_reference(rng, L) if k % 3 == 0 else rng.choice(np.frombuffer(b"ACGT", np.uint8), L)
+    n = 100_000
+    reads, start = damaged_reads(rng, ref, n, read_len, float(rng.choice([0.2, 0.5, 0.8])), int(rng.integers(1, min(13, read_len // 4))),
+                                 int(rng.integers(1, 8)), two_share=float(rng.choice([0.0, 0.1, 0.4])), junk_share=float(rng.choice([0.0, 0.05, 0.2])))
+    jitter = rng.integers(-10, 11, n) * (rng.random(n) < 0.3)
+    as0 = ((start + jitter) % L).astype(np.int32)
+    ae0 = (as0 + read_len - 1).astype(np.int32)
+    run_both(mia_amd, ref.tobytes().decode(), reads, read_len, as0, ae0, 0.0)
+    reads_total += n
+    print("round", k, "seed", seed, "len", read_len, "L", L, "ok", round(time.time() - t0, 1), "s", flush=True)
+print("campaign done:", reads_total, "reads, no difference")
