@@ -146,13 +146,16 @@ def test_tally_of_one_gap_reads(seed, read_len):
     ae0 = (as0 + read_len - 1).astype(np.int32)
     refs = ref.tobytes().decode()
     out = []
-    for band_off in (False, True):
-        if band_off:
-            os.environ["MIA_HIP_NO_BAND_DP"] = "1"
+    # the one-read-per-lane paths for one-gap and over-the-origin reads exist for the count-only ("linear") tally; with
+    # MIA_HIP_NO_LINEAR_TALLY=1 those reads walk their scripts one per wavefront and every base adds its four score words
+    for env in (None, "MIA_HIP_NO_BAND_DP", "MIA_HIP_NO_LINEAR_TALLY"):
+        if env:
+            os.environ[env] = "1"
         try:
             hip = mia_amd.MiaHip(0)
         finally:
-            os.environ.pop("MIA_HIP_NO_BAND_DP", None)
+            if env:
+                os.environ.pop(env, None)
         hip.set_pssm(mia_amd.flat_pssm())
         hip.upload_reads(reads.reshape(-1), off, strand, np.ones(n, np.uint8), as0, ae0)
         hip.realign(refs, True)
@@ -166,7 +169,8 @@ def test_tally_of_one_gap_reads(seed, read_len):
         out.append((t, g, cons, it, hip.band_stats()[0]))
         hip.close()
     assert out[0][4] > 0.2 * n and out[1][4] == 0
-    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    assert out[0][2] == out[1][2] and out[0][1].max() > 0          # (the same consensus; insert events did reach ref->gaps)
-    for x, y in zip(out[0][3], out[1][3]):
-        assert np.array_equal(x, y)
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1])
+        assert out[0][2] == other[2] and out[0][1].max() > 0          # (the same consensus; insert events did reach ref->gaps)
+        for x, y in zip(out[0][3], other[3]):
+            assert np.array_equal(x, y)
