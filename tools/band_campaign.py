@@ -1,6 +1,8 @@
 """A longer differential campaign for the banded DP than the test suite has time for: many seeds of
 tests/test_gpu_band.py's generators (random and adversarial references, read lengths 30-250, indels up to 12, jittered
-pass-1 coordinates), banded DP on against off, every read's score, end points and script.  usage: band_campaign.py [rounds [first seed]]"""
+pass-1 coordinates), banded DP on against off, every read's score, end points and script.
+usage: band_campaign.py [rounds [first seed [MIA_HIP_NO_DIAG_FILTER]]]   (third argument: the switch that defines "off";
+MIA_HIP_NO_DIAG_FILTER takes filter AND banded DP out, i.e. compares both shortcuts with the full-window DP kernels)"""
 import os
 import sys
 import time
@@ -16,6 +18,29 @@ from test_gpu_filter_stress import adversarial_reference  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+switch = sys.argv[3] if len(sys.argv) > 3 else "MIA_HIP_NO_BAND_DP"
+
+
+def compare(refs, reads, read_len, as0, ae0):
+    n = len(reads)
+    off = np.arange(n + 1, dtype=np.int64) * read_len
+    out = []
+    for env in (None, switch):
+        if env:
+            os.environ[env] = "1"
+        hip = mia_amd.MiaHip(0)
+        if env:
+            os.environ.pop(env)
+        hip.set_pssm(mia_amd.flat_pssm())
+        hip.upload_reads(reads.reshape(-1), off, np.zeros(n, np.uint8), np.ones(n, np.uint8), as0, ae0)
+        hip.realign(refs, True)
+        sc, a, e = hip.alignments()
+        cols, rstart = hip.scripts()
+        out.append((sc, a, e, np.where(cols >= 0, cols.astype(np.int32) + rstart[:, None], cols.astype(np.int32))))
+        hip.close()
+    for name, x, y in zip(("score", "start", "end", "script"), out[0], out[1]):
+        assert np.array_equal(x, y), name
+
 t0 = time.time()
 reads_total = 0
 for k in range(rounds):
@@ -30,7 +55,10 @@ for k in range(rounds):
     jitter = rng.integers(-10, 11, n) * (rng.random(n) < 0.3)
     as0 = ((start + jitter) % L).astype(np.int32)
     ae0 = (as0 + read_len - 1).astype(np.int32)
-    run_both(mia_amd, ref.tobytes().decode(), reads, read_len, as0, ae0, 0.0)
+    if switch == "MIA_HIP_NO_BAND_DP":
+        run_both(mia_amd, ref.tobytes().decode(), reads, read_len, as0, ae0, 0.0)
+    else:
+        compare(ref.tobytes().decode(), reads, read_len, as0, ae0)
     reads_total += n
     print("round", k, "seed", seed, "len", read_len, "L", L, "ok", round(time.time() - t0, 1), "s", flush=True)
 print("campaign done:", reads_total, "reads, no difference")
