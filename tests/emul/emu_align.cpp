@@ -289,3 +289,114 @@ extern "C" int emu_band(const uint8_t* ref_codes, int64_t n_codes, int ref_start
   out5[0] = res.score; out5[1] = res.abc; out5[2] = res.aec; out5[3] = res.abr; out5[4] = res.gaps;
   return 1;
 }
+
+// The matrix-agnostic band pipeline (csrc/bandx_body.h) as k_bx_plan / k_bx_values / k_bx_trace run it.
+//   opts bit 0: run the trace DP even where the values-only check (or the plan alone) would finish the read
+//   opts bit 1: use the EDGE form of the recurrence even for interior bands
+//   opts >> 4 : widen the band class (0..3 classes up)
+// Returns the plan's mode (0 = not planned), negated if the stages disagree among themselves; out6 = score, abc, aec,
+// abr, gaps, how the read was finished (1 plan, 2 values, 3 trace, 0 not finished); plan5 = d0, w, dstar, b0, edge.
+#include "bandx_body.h"
+template <int W>
+static int emu_bandx_w(const uint32_t* nib, int s, int len1, const uint32_t* rw, int len2, const mia::BxPlan& bp, bool edge, const int32_t* sub,
+                       const int32_t* sub256, bool want_values, bool want_trace, int expect, int32_t* out6, int16_t* cols) {
+  using namespace mia;
+  int how = 0;
+  if (want_values) {
+    int best, bj;
+    if (edge) bx_values<W, true>(nib, s, len1, rw, len2, bp.d0, sub, &best, &bj);
+    else bx_values<W, false>(nib, s, len1, rw, len2, bp.d0, sub, &best, &bj);
+    if (bj >= 0 && best == expect && bj == bp.dstar - bp.d0) {
+      how = 2;
+      out6[0] = best; out6[1] = bp.dstar; out6[2] = bp.dstar + len2 - 1; out6[3] = 0; out6[4] = 0;
+      for (int r = 0; r < len2; r++) cols[r] = (int16_t)(bp.dstar + r);
+    }
+  }
+  if (want_trace || (want_values && !how)) {
+    std::vector<uint32_t> trace((size_t)len2 * (W / 4));
+    std::vector<int16_t> c2((size_t)len2 + 8, -9);
+    BxResult res;
+    const bool got = edge ? bx_trace<W, true>(nib, s, len1, rw, len2, bp.d0, sub256, trace.data(), W / 4, c2.data(), &res)
+                          : bx_trace<W, false>(nib, s, len1, rw, len2, bp.d0, sub256, trace.data(), W / 4, c2.data(), &res);
+    if (got) {
+      if (how) {      // both stages finished the read: they must agree
+        if (res.score != out6[0] || res.abc != out6[1] || res.aec != out6[2] || res.abr != out6[3] || res.gaps != 0) return -100;
+        for (int r = 0; r < len2; r++) if (c2[r] != cols[r]) return -101;
+      } else {
+        how = 3;
+        out6[0] = res.score; out6[1] = res.abc; out6[2] = res.aec; out6[3] = res.abr; out6[4] = res.gaps;
+        for (int r = 0; r < len2; r++) cols[r] = c2[r];
+      }
+    } else if (how) return -102;     // the values stage proved a pure diagonal the traceback could not walk
+  }
+  return how;
+}
+
+extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_start, int len1, const uint8_t* read_codes, int len2, const int32_t* fwd,
+                         const int32_t* rc, int strand, int opts, int32_t* out6, int16_t* cols, int32_t* plan5) {
+  using namespace mia;
+  const int64_t words = plane_words(n_codes);
+  std::vector<uint64_t> lo((size_t)words), hi((size_t)words), ok((size_t)words);
+  for (int64_t w = 0; w < words; w++) plane_word(ref_codes, n_codes, w, &lo[(size_t)w], &hi[(size_t)w], &ok[(size_t)w]);
+  std::vector<uint32_t> packed((size_t)(len2 / 8 + 2), 0);
+  uint8_t* pb = (uint8_t*)packed.data();
+  for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
+  RefPlanes rp{lo.data(), hi.data(), ok.data()};
+  const KmerOcc ko = g_tab_a.build(ref_codes, n_codes);
+  std::vector<int32_t> sub(BX_SUB_WORDS, 0), sub256(BX_SUB_WORDS, 0), mrow(2 * 31 * 4), delta(2 * 31);
+  BxTab T{sub.data(), mrow.data(), delta.data(), 0, 0, 0};
+  if (!bx_make_tables(fwd, rc, sub.data(), mrow.data(), delta.data(), &T.ev_block, &T.min_m, &T.max_m)) return 0;
+  for (int k = 0; k < BX_SUB_WORDS; k++) sub256[(size_t)k] = sub[(size_t)k] * 256;
+  std::vector<uint32_t> nib((size_t)bx_nib_words(n_codes), 0x44444444u);
+  for (int64_t p = 0; p < n_codes; p++) {
+    const int64_t q = p + BX_NIB_LEAD;
+    nib[(size_t)(q >> 3)] = (nib[(size_t)(q >> 3)] & ~(0xFu << (4 * (q & 7)))) | ((uint32_t)(ref_codes[p] > 4 ? 4 : ref_codes[p]) << (4 * (q & 7)));
+  }
+  BxPlan bp;
+  bx_plan(rp, ko, ref_codes, n_codes, ref_start, len1, pb, len2, strand, T, &bp);
+  out6[5] = 0;
+  if (bp.mode == BX_NONE) return 0;
+  plan5[0] = bp.d0; plan5[1] = bp.w; plan5[2] = bp.dstar; plan5[3] = bp.b0; plan5[4] = bp.edge;
+  const int u = bx_umax(mrow.data(), pb, len2, strand);
+  const int expect = u - bp.b0;
+  int how = 0;
+  if (bp.mode == BX_DONE) {
+    how = 1;
+    out6[0] = expect; out6[1] = bp.dstar; out6[2] = bp.dstar + len2 - 1; out6[3] = 0; out6[4] = 0;
+    for (int r = 0; r < len2; r++) cols[r] = (int16_t)(bp.dstar + r);
+  }
+  int cls = bx_class_of(bp.w) + (opts >> 4);
+  if (cls > 3) cls = 3;
+  const int wc = 8 * (cls + 1);
+  const bool interior = bp.d0 >= 0 && len2 - 1 + bp.d0 + wc <= len1;
+  const bool edge = !interior || (opts & 2);
+  const bool force_trace = (opts & 1) != 0;
+  if (bp.mode == BX_DONE && !force_trace) { out6[5] = 1; return bp.mode; }
+  const int32_t* st_sub = sub.data() + strand * 31 * 4 * BX_SUB_ROW;
+  const int32_t* st_sub256 = sub256.data() + strand * 31 * 4 * BX_SUB_ROW;
+  int32_t o2[6] = {0, 0, 0, 0, 0, 0};
+  std::vector<int16_t> c2((size_t)len2 + 8, -9);
+  const bool want_values = bp.mode == BX_VALUES || bp.mode == BX_DONE;
+  const bool want_trace = bp.mode == BX_TRACE || force_trace;
+  const uint32_t* rw = packed.data();
+  int h2;
+  switch (cls) {
+    case 0: h2 = emu_bandx_w<8>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
+    case 1: h2 = emu_bandx_w<16>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
+    case 2: h2 = emu_bandx_w<24>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
+    default: h2 = emu_bandx_w<32>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
+  }
+  if (h2 < 0) return h2;
+  if (how == 1) {
+    // the plan finished the read; whatever the DP stages found must be the same alignment
+    if (h2 == 0) return -103;
+    if (o2[0] != out6[0] || o2[1] != out6[1] || o2[2] != out6[2] || o2[3] != out6[3] || o2[4] != 0) return -104;
+    for (int r = 0; r < len2; r++) if (c2[r] != cols[r]) return -105;
+  } else {
+    how = h2;
+    for (int k = 0; k < 5; k++) out6[k] = o2[k];
+    for (int r = 0; r < len2; r++) cols[r] = c2[r];
+  }
+  out6[5] = how;
+  return bp.mode;
+}

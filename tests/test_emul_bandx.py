@@ -1,0 +1,209 @@
+"""The matrix-agnostic band pipeline (csrc/bandx_body.h -- the source hipcc compiles into k_bx_plan / k_bx_values /
+k_bx_trace) on the CPU against the oracle's full-window DP, for the flat matrix and both strands of the two aDNA
+matrices.  Whenever a stage finishes a read -- the plan alone (one-diagonal band), the values-only DP with the plan's
+diagonal check, or the trace DP -- score, end points, begin row and the whole gapped alignment must be what dyn_prog /
+max_sg_score / find_align_begin / populate_pwaln_to_begin give over the whole window, and the stages must agree with
+each other wherever more than one of them can finish the read (the harness returns a negative code if not)."""
+import ctypes as C
+import math
+import random
+
+import numpy as np
+import pytest
+
+import oracle_ctypes as oc
+from test_emul_align import codes, emul, script_to_strings  # noqa: F401  (fixture)
+from test_emul_diag_filter import mutate
+from test_oracle_vs_golden import _pssm
+
+MATS = [("flat", 0), ("ancient.submat.txt", 0), ("ancient.submat.txt", 1), ("ancient.submat.solexa.pe.txt", 0),
+        ("ancient.submat.solexa.pe.txt", 1)]
+
+
+def pssm_pair(oracle, spec):
+    f, r = _pssm(oracle, spec, 0), _pssm(oracle, spec, 1)
+    return (np.ctypeslib.as_array(f.sm).astype(np.int32).reshape(-1).copy(), np.ctypeslib.as_array(r.sm).astype(np.int32).reshape(-1).copy())
+
+
+def run_bandx(emul, oracle, spec, strand, ref, s, len1, read, opts=0):
+    fwd, rc = pssm_pair(oracle, spec)
+    rcd, c2 = codes(ref), codes(read)
+    out6 = (C.c_int32 * 6)()
+    plan = (C.c_int32 * 5)()
+    cols = np.full(len(read) + 8, -9, dtype=np.int16)
+    emul.emu_bandx.restype = C.c_int
+    mode = emul.emu_bandx(rcd.ctypes.data_as(C.c_void_p), C.c_int64(len(ref)), s, len1, c2.ctypes.data_as(C.c_void_p), len(read),
+                          fwd.ctypes.data_as(C.c_void_p), rc.ctypes.data_as(C.c_void_p), strand, opts, out6, cols.ctypes.data_as(C.c_void_p), plan)
+    assert mode >= 0, (mode, ref[s:s + len1], read, list(plan))
+    return mode, list(out6), cols, list(plan)
+
+
+def check(emul, oracle, spec, strand, ref, s, len1, read, stats, opts=None):
+    if opts is None:
+        k = stats["n"]
+        opts = (k & 3) | (((k >> 2) % 3) << 4)          # trace forced or not, edge form or not, class widened by 0..2
+    stats["n"] += 1
+    mode, out6, cols, plan = run_bandx(emul, oracle, spec, strand, ref, s, len1, read, opts)
+    stats["mode%d" % mode] = stats.get("mode%d" % mode, 0) + 1
+    if out6[5] == 0:
+        return False
+    stats["how%d" % out6[5]] = stats.get("how%d" % out6[5], 0) + 1
+    win = ref[s:s + len1]
+    res = oc.Aln()
+    rg = C.create_string_buffer(1100)
+    fg = C.create_string_buffer(1100)
+    assert oracle.ora_align(win.encode(), len(win), read.encode(), len(read), None, C.byref(_pssm(oracle, spec, strand)), 1, C.byref(res), rg, fg,
+                            None, None) == 0
+    ctx = (spec, strand, win, read, plan, out6, (res.best, res.abc, res.aec, res.abr))
+    assert (out6[0], out6[1], out6[2], out6[3]) == (res.best, res.abc, res.aec, res.abr), ctx
+    r, f = script_to_strings(win, read, cols, res.abr, res.aer)
+    assert r == rg.value.decode() and f == fg.value.decode(), ctx
+    assert all(int(cols[i]) == -2 for i in range(res.abr)) or out6[5] != 3, ctx
+    assert out6[4] == len([x for x in rg.value.split(b"-") if x]) - 1 + len([x for x in fg.value.split(b"-") if x]) - 1, ctx
+    return True
+
+
+def window(ref, pos, length, margin=50):
+    s = max(0, pos - margin)
+    e = min(len(ref), pos + length + margin)
+    return s, e - s
+
+
+def damage(rnd, read, p0=0.30, lam=0.35):
+    """C->T near the 5' end, G->A near the 3' end."""
+    r = list(read)
+    n = len(r)
+    for i in range(min(n, 25)):
+        if r[i] == "C" and rnd.random() < p0 * math.exp(-lam * i):
+            r[i] = "T"
+        j = n - 1 - i
+        if r[j] == "G" and rnd.random() < p0 * math.exp(-lam * i):
+            r[j] = "A"
+    return "".join(r)
+
+
+@pytest.mark.parametrize("spec,strand", MATS)
+def test_damaged_reads_with_substitutions(emul, oracle, spec, strand):
+    rnd = random.Random(21 + strand)
+    ref = "".join(rnd.choice("ACGT") for _ in range(5000))
+    stats = {"n": 0}
+    for i in range(500):
+        n = rnd.choice([100, 100, 100, 150, rnd.randint(30, 250)])
+        pos = rnd.randint(0, len(ref) - n)
+        read = damage(rnd, ref[pos:pos + n], p0=0.6)
+        read = mutate(rnd, read, rnd.sample(range(n), rnd.choice([0, 0, 1, 1, 2, 3, 4, 6])))
+        s, l1 = window(ref, pos + rnd.randint(-3, 3) if 3 <= pos < len(ref) - n - 3 else pos, n)
+        check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+    assert stats.get("how1", 0) > 60 and stats.get("how2", 0) + stats.get("how3", 0) > 60, stats
+
+
+@pytest.mark.parametrize("spec,strand", MATS)
+def test_single_indels_everywhere(emul, oracle, spec, strand):
+    rnd = random.Random(7 + strand)
+    ref = "".join(rnd.choice("ACGT") for _ in range(4000))
+    stats = {"n": 0}
+    for i in range(400):
+        n = rnd.randint(30, 180)
+        pos = rnd.randint(0, len(ref) - n - 40)
+        src = ref[pos:pos + n + 30]
+        at = rnd.choice([1, 2, 3, 5, 9, 10, 11, n // 2, n - 12, n - 10, n - 3, n - 2, rnd.randint(1, n - 2)])
+        k = rnd.choice([1, 1, 1, 2, 3, 5, 8])
+        if i % 2:
+            read = src[:at] + src[at + k:][:n - at]
+        else:
+            ins = "".join(rnd.choice("ACGT") for _ in range(k))
+            read = (src[:at] + ins + src[at:])[:n]
+        read = damage(rnd, read)
+        read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([0, 0, 1, 2, 3])))
+        s, l1 = window(ref, pos, len(read))
+        check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+    assert stats.get("how3", 0) > 100, stats
+
+
+@pytest.mark.parametrize("spec,strand", MATS[:3])
+def test_two_indels_and_heavy_damage(emul, oracle, spec, strand):
+    rnd = random.Random(8 + strand)
+    ref = "".join(rnd.choice("ACGT") for _ in range(4000))
+    stats = {"n": 0}
+    for i in range(350):
+        n = rnd.randint(70, 200)
+        pos = rnd.randint(0, len(ref) - n - 60)
+        read = ref[pos:pos + n + 40]
+        for _ in range(2):
+            at = rnd.randint(1, len(read) - 30)
+            k = rnd.randint(1, 4)
+            if rnd.random() < 0.5:
+                read = read[:at] + read[at + k:]
+            else:
+                read = read[:at] + "".join(rnd.choice("ACGT") for _ in range(k)) + read[at:]
+        read = damage(rnd, read[:n], p0=0.5)
+        read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([0, 1, 3, 5, 8])))
+        s, l1 = window(ref, pos, len(read))
+        check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+    assert stats.get("how3", 0) > 5, stats
+
+
+@pytest.mark.parametrize("spec,strand", MATS[:3])
+def test_repeats_where_gap_placements_tie(emul, oracle, spec, strand):
+    rnd = random.Random(9 + strand)
+    stats = {"n": 0}
+    for i in range(300):
+        unit = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([1, 2, 3, 4, 7])))
+        reps = rnd.randint(3, 12)
+        left = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(150, 300)))
+        right = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(150, 300)))
+        ref = left + unit * reps + right
+        a = rnd.randint(40, 110)
+        b = rnd.randint(40, 110)
+        delta = rnd.choice([-2, -1, 0, 1, 2])                    # the read has more / fewer copies of the unit
+        read = left[-a:] + unit * max(0, reps + delta) + right[:b]
+        if len(read) > 250:
+            continue
+        read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([0, 0, 1, 2])))
+        pos = len(left) - a
+        s, l1 = window(ref, pos, a + len(unit) * reps + b)
+        check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+    assert stats.get("how3", 0) + stats.get("how2", 0) + stats.get("how1", 0) > 80, stats
+
+
+@pytest.mark.parametrize("spec,strand", MATS[:3])
+def test_clipped_windows_and_late_starts(emul, oracle, spec, strand):
+    rnd = random.Random(10 + strand)
+    ref = "".join(rnd.choice("ACGT") for _ in range(1500))
+    stats = {"n": 0}
+    for i in range(400):
+        n = rnd.randint(32, 150)
+        pos = rnd.choice([0, 0, 1, 2, 5, len(ref) - n, len(ref) - n - 1, rnd.randint(0, 30)])
+        read = ref[pos:pos + n]
+        junk = rnd.choice([0, 0, 3, 6, 12])                       # a junk head: the alignment starts late
+        read = "".join(rnd.choice("ACGT") for _ in range(junk)) + read[junk:]
+        if i % 3 == 0:
+            at = rnd.randint(8, n - 8)
+            read = read[:at] + read[at + 1:]
+        read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([0, 1, 3])))
+        s, l1 = window(ref, pos, len(read), margin=rnd.choice([50, 50, 10, 0]))
+        if l1 < len(read):
+            continue
+        check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+    assert stats.get("how3", 0) + stats.get("how2", 0) + stats.get("how1", 0) > 100, stats
+
+
+def test_second_copies_compete(emul, oracle):
+    """A second, slightly worse copy of the read's target a few columns away: anchors on two diagonals, ties between
+    diagonals, the first maximum of the last row."""
+    rnd = random.Random(12)
+    stats = {"n": 0}
+    for spec, strand in MATS[:3]:
+        for i in range(150):
+            n = rnd.randint(60, 120)
+            core = "".join(rnd.choice("ACGT") for _ in range(n))
+            gap = rnd.randint(0, 25)
+            copy2 = mutate(rnd, core, rnd.sample(range(n), rnd.choice([0, 0, 1, 2])))
+            left = "".join(rnd.choice("ACGT") for _ in range(200))
+            ref = left + core + "".join(rnd.choice("ACGT") for _ in range(gap)) + copy2 + left[::-1]
+            read = mutate(rnd, core, rnd.sample(range(n), rnd.choice([0, 1, 2])))
+            s, l1 = window(ref, 200, n, margin=rnd.choice([50, 50 + gap + n]))
+            if l1 > 760:
+                continue
+            check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+    assert stats["n"] > 300, stats
