@@ -257,7 +257,8 @@ int mia_hip_plain_stats(mia_hip_ctx *ctx, int reset, double *plain_ms, int64_t *
 
 /* The diagonal filter in front of the DP kernels of mia_hip_realign / mia_hip_align_windows (csrc/diag_filter.h: flat
  * matrix only; a read whose alignment is provably one gap-free diagonal with at most two mismatches is finished by
- * bit-parallel comparison and never reaches the DP): reads examined and reads finished there since the last reset;
+ * bit-parallel comparison and never reaches the DP): reads examined and reads finished WITHOUT any DP since the last reset
+ * (by this filter, or by the plan of the band pipeline below when its band is a single diagonal -- mia_hip_bx_stats);
  * kernel_ms / launches: accumulated time of k_diag_filter (HIP events on the context's stream).  Any pointer may be NULL. */
 int mia_hip_filter_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_seen, int64_t *reads_finished, double *kernel_ms, int64_t *launches);
 /* The banded DP behind the filter (csrc/band_body.h: flat matrix, windows without N).  A left-over read whose ten-mer
@@ -266,6 +267,21 @@ int mia_hip_filter_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_seen, int64
  * (reference src/mia.c:740-981, 612-637, 1440-1497); the rest goes on to the full-window kernels.  reads_finished /
  * kernel_ms / launches of k_band_align since the last reset.  Any pointer may be NULL. */
 int mia_hip_band_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_finished, double *kernel_ms, int64_t *launches);
+/* The band pipeline of mia_hip_realign / mia_hip_align_windows for ANY substitution matrix (csrc/bandx_body.h: the
+ * position-specific matrices of src/pssm.c:6-46 included).  Per read: a band of diagonals from the 10-mer anchors that
+ * provably holds every alignment that can win or tie (pigeonhole over the losses against the best score each row can
+ * have); reads whose band is one diagonal are finished by the plan itself, the others by a values-only banded DP plus the
+ * diagonal proof, the rest by a banded DP with trace and the reference's traceback (src/mia.c:740-981, 612-637,
+ * 1440-1497).  What none of them can take (N in read or window, too many defects, the trace-0 quirk) goes on to the
+ * full-window kernels.  reads4 = {reads planned on, finished by the plan, by the values DP, by the trace DP};
+ * kernel_ms3 = accumulated time of k_bx_plan, k_bx_values, k_bx_trace (HIP events on the context's stream);
+ * launches = realign calls that used the pipeline.  Any pointer may be NULL. */
+int mia_hip_bx_stats(mia_hip_ctx *ctx, int reset, int64_t *reads4, double *kernel_ms3, int64_t *launches);
+/* Diagnostic: the 32 device counters of the band pipeline after the last realign -- [0..3] reads sent to the values DP by
+ * band class (8, 16, 24, 32 diagonals), [4..7] to the trace DP, [10..12] finished by plan / values / trace, [13] reads
+ * planned on, [17..23] reads not planned, by reason (N in the read, window, too few anchored blocks, anchors too far
+ * apart, written-down path outside the window, loss over the pigeonhole budget, band wider than 32). */
+int mia_hip_bx_counters(mia_hip_ctx *ctx, uint32_t *out32);
 /* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
 int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 /* reads of the last mia_hip_pass1 call decided by the diagonal filter (csrc/diag_filter.h: flat matrix, no k-mer mask)

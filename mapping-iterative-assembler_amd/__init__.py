@@ -58,6 +58,8 @@ def _load():
     lib.mia_hip_pre_cull_counts.argtypes = [vp, vp, vp]
     lib.mia_hip_filter_stats.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.mia_hip_band_stats.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.mia_hip_bx_stats.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.mia_hip_bx_counters.argtypes = [vp, vp]
     lib.mia_hip_myers_align.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, vp, vp, vp]
     lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
     lib.mia_hip_ma_tally.argtypes = [vp, C.c_int32, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
@@ -96,7 +98,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_align_windows", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
             "mia_hip_score_cut_from_sums"]
@@ -333,6 +335,21 @@ class MiaHip:
         b, ms, k = C.c_int64(0), C.c_double(0), C.c_int64(0)
         self._chk(self._l.mia_hip_band_stats(self._h, 1 if reset else 0, C.byref(b), C.byref(ms), C.byref(k)))
         return b.value, ms.value, k.value
+
+    def bx_stats(self, reset=False):
+        """((reads planned on, finished by the plan, by the values DP, by the trace DP), (ms of k_bx_plan, k_bx_values,
+        k_bx_trace), launches) of the band pipeline for any matrix (csrc/bandx_body.h)"""
+        r = (C.c_int64 * 4)()
+        ms = (C.c_double * 3)()
+        k = C.c_int64(0)
+        self._chk(self._l.mia_hip_bx_stats(self._h, 1 if reset else 0, r, ms, C.byref(k)))
+        return tuple(r), tuple(ms), k.value
+
+    def bx_counters(self):
+        """the 32 device counters of the band pipeline after the last realign (include/mia_hip.h)"""
+        out = (C.c_uint32 * 32)()
+        self._chk(self._l.mia_hip_bx_counters(self._h, out))
+        return list(out)
 
     def myers_align(self, seq_a, mode, seq_b, maxd):
         """myers_diff with its backtrace (reference src/myers_align.h:35): (distance or None, row over seq_a, row over seq_b)"""

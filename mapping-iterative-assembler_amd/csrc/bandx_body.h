@@ -51,21 +51,26 @@ MIA_HD inline int bx_class_of(int w) { return w <= 8 ? 0 : (w <= 16 ? 1 : (w <= 
 struct BxTab {
   const int32_t* sub;      // [2][31][4][8]: sm[strand][depth][ref code 0..4][read base], read base major
   const int32_t* mrow;     // [2][31][4]:    M
-  const int32_t* delta;    // [2][31]:       least loss of a non-identical base at that depth
-  int32_t ev_block;        // E
+  const int16_t* loss;     // [2][31][4][4]: M - sm, by (strand, depth, read base, reference base)
+  const int16_t* dl;       // [2][MAX_READ+1][BX_BLOCKS]: what breaking block b of a read of that length costs at least
   int32_t min_m, max_m;
 };
+constexpr int BX_LOSS_WORDS = 2 * 31 * 4 * 4;
+constexpr int BX_DL_WORDS = 2 * (MAX_READ + 1) * BX_BLOCKS;
 
 MIA_HD inline int64_t bx_nib_words(int64_t n_codes) { return (BX_NIB_LEAD + n_codes + BX_NIB_TAIL) / 8 + 2; }
+// first row of block b of a read of len2 bases cut into nb_cut blocks
+MIA_HD inline int bx_block_row(int b, int len2, int nb_cut) { return (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1)); }
+MIA_HD inline int bx_blocks_of(int len2) { return len2 / DF_K < BX_BLOCKS ? len2 / DF_K : BX_BLOCKS; }
 
 // host side of BxTab; false: the band pipeline cannot be used with these matrices
-inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, int32_t* mrow, int32_t* delta, int32_t* ev_block, int32_t* min_m,
-                           int32_t* max_m) {
+inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, int32_t* mrow, int16_t* loss, int16_t* dl, int32_t* min_m, int32_t* max_m) {
   const int32_t* tabs[2] = {fwd, rc};
   int mn = 1 << 30, mx = -(1 << 30);
+  int delta[2][31];
   for (int st = 0; st < 2; st++)
     for (int d = 0; d < 31; d++) {
-      int dl = 1 << 30;
+      int dmin = 1 << 30;
       for (int b = 0; b < 4; b++) {
         int32_t* row = sub + ((st * 31 + d) * 4 + b) * BX_SUB_ROW;
         for (int i = 0; i < BX_SUB_ROW; i++) row[i] = tabs[st][(d * 5 + (i < 5 ? i : 4)) * 5 + b];
@@ -74,20 +79,36 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
         if (row[b] != m || m <= 0 || row[4] > m) return false;      // identity is the best base; skipping a row never pays; N is no better
         for (int i = 0; i < 5; i++) if (row[i] > 4000 || row[i] < -4000) return false;   // (value * 256 + code must fit a word, with room)
         mrow[(st * 31 + d) * 4 + b] = m;
-        for (int i = 0; i < 4; i++) if (i != b && m - row[i] < dl) dl = m - row[i];
+        for (int i = 0; i < 4; i++) {
+          loss[((st * 31 + d) * 4 + b) * 4 + i] = (int16_t)(m - row[i]);
+          if (i != b && m - row[i] < dmin) dmin = m - row[i];
+        }
         if (m < mn) mn = m;
         if (m > mx) mx = m;
       }
-      delta[st * 31 + d] = dl;
+      delta[st][d] = dmin;
     }
-  int e = 1 << 30;
+  // skipped rows (an insert, a soft clip): n of them touch at most ceil((n-1)/10)+1 blocks and cost at least GOP + (GEP + min M) n
+  int e = GOP + GEP;                    // (a column gap inside a block)
   for (int n = 1; n <= 2 * MAX_READ; n++) {
     const int q = (GOP + (GEP + mn) * n) / ((n - 1 + 9) / 10 + 1);
     if (q < e) e = q;
   }
-  if (e > GOP + GEP) e = GOP + GEP;
-  *ev_block = e; *min_m = mn; *max_m = mx;
-  return e > 0;
+  if (e <= 0) return false;
+  for (int st = 0; st < 2; st++)
+    for (int len2 = 0; len2 <= MAX_READ; len2++)
+      for (int b = 0; b < BX_BLOCKS; b++) {
+        int v = 0;
+        const int nb_cut = bx_blocks_of(len2);
+        if (nb_cut >= BX_MIN_BLOCKS && b < nb_cut) {
+          const int o = bx_block_row(b, len2, nb_cut);
+          v = e;
+          for (int r = o; r < o + DF_K; r++) { const int dd = delta[st][sm_depth(r, len2)]; if (dd < v) v = dd; }
+        }
+        dl[(st * (MAX_READ + 1) + len2) * BX_BLOCKS + b] = (int16_t)v;
+      }
+  *min_m = mn; *max_m = mx;
+  return true;
 }
 
 // 10-mer index (diag_filter.h: kmer_at's packing) of read rows o .. o+9, from the packed nibbles
@@ -103,152 +124,257 @@ MIA_HD inline int64_t bx_kmer(const uint32_t* pw, int len2, int o) {
   return (int64_t)((y & 0xFFFFull) | ((y >> 16) & 0xF0000ull));
 }
 
+// The reference's 10-mers as a compact hash table (open addressing, 16-byte slots {key, pos0, count - 1, pos1}, load <= 1/4):
+// a megabyte for a mitochondrion, so that the nine look-ups of a read stay in the L2 (the direct-addressed table of
+// diag_filter.h is 20 MB and every look-up a trip to memory).  Positions 3 and 4 of a repeated 10-mer sit in `ovf`.
+struct KmerHash {
+  const uint32_t* slot;    // [4 * (mask + 1)], all ones = empty
+  const int32_t* ovf;      // [2 * (mask + 1)]
+  uint32_t mask;
+  int32_t shift;           // 32 - log2(slots)
+};
+constexpr uint32_t KH_EMPTY = 0xFFFFFFFFu;
+MIA_HD inline uint32_t kh_slots_for(int64_t n_codes) { uint32_t s = 1024; while ((int64_t)s < 4 * n_codes) s <<= 1; return s; }
+MIA_HD inline int kh_shift_for(uint32_t slots) { int b = 0; while ((1u << b) < slots) b++; return 32 - b; }
+MIA_HD inline uint32_t kh_home(const KmerHash& kh, uint32_t idx) { return (idx * 2654435761u) >> kh.shift; }
+// occurrences of 10-mer idx (DF_KCAP + 1 = more than the table keeps), the first DF_KCAP positions in ps; e = its home slot, already loaded
+MIA_HD inline int kh_resolve(const KmerHash& kh, uint32_t idx, uint32_t h, uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, int32_t* ps) {
+  for (int probe = 0; probe < 32; probe++) {
+    if (e0 == KH_EMPTY) return 0;
+    if (e0 == idx) {
+      const int cnt = (int)(e2 + 1u);
+      ps[0] = (int32_t)e1; ps[1] = (int32_t)e3;
+      if (cnt > 2) { ps[2] = kh.ovf[2 * h]; ps[3] = kh.ovf[2 * h + 1]; }
+      return cnt > DF_KCAP ? DF_KCAP + 1 : cnt;
+    }
+    h = (h + 1) & kh.mask;
+    const uint32_t* e = kh.slot + 4 * (size_t)h;
+    e0 = e[0]; e1 = e[1]; e2 = e[2]; e3 = e[3];
+  }
+  return DF_KCAP + 1;                                // a crowded neighbourhood: not part of the pigeonhole
+}
+// host-side insert (the tests); the device inserts with atomics (k_kmer_hash)
+inline void kh_insert_host(uint32_t* slot, int32_t* ovf, uint32_t mask, int shift, uint32_t idx, int32_t p) {
+  uint32_t h = (idx * 2654435761u) >> shift;
+  while (slot[4 * (size_t)h] != KH_EMPTY && slot[4 * (size_t)h] != idx) h = (h + 1) & mask;
+  uint32_t* e = slot + 4 * (size_t)h;
+  e[0] = idx;
+  const uint32_t c = ++e[2];                        // (starts at all ones)
+  if (c == 0) e[1] = (uint32_t)p; else if (c == 1) e[3] = (uint32_t)p; else if (c < 4) ovf[2 * (size_t)h + c - 2] = p;
+}
+
 // mode of a planned read
 constexpr int BX_NONE = 0;     // not planned: the full-window kernels take it
 constexpr int BX_DONE = 1;     // finished by the plan: pure diagonal dstar, score = U - b0
 constexpr int BX_VALUES = 2;   // values-only DP, then the check  best == U - b0 at diagonal dstar
 constexpr int BX_TRACE = 3;    // straight to the trace DP
 struct BxPlan { int mode, d0, w, dstar, b0, edge; };
+// why a read was not planned (statistics only)
+enum { BXF_READ = 1, BXF_WINDOW, BXF_BLOCKS, BXF_SPAN, BXF_PATH, BXF_BUDGET, BXF_WIDTH, BXF_KINDS };
 
-// loss of read row r (base b, depth d) aligned to reference code i
-MIA_HD inline int bx_loss(const BxTab& T, int st, int d, int b, int i) {
-  return T.mrow[(st * 31 + d) * 4 + b] - T.sub[((st * 31 + d) * 4 + b) * BX_SUB_ROW + i];
-}
+// the anchors of a read and what they imply, before any loss is summed
+struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi; };
 
+// Where the read's blocks occur inside the window.  sc holds the read's planes.
 template <int NW>
-MIA_HD inline void bx_plan_nw(const RefPlanes& rp, const KmerOcc& ko, const uint8_t* codes, int64_t n_ref, int s, int len1, const uint8_t* read_packed,
-                              int len2, int st, const BxTab& T, BxPlan* out) {
-  out->mode = BX_NONE;
-  DiagScan<NW> sc;
-  if (!sc.load_read(read_packed, len2)) return;              // a read with N
-  const int R = len2 - 1, nb_cut = len2 / DF_K < BX_BLOCKS ? len2 / DF_K : BX_BLOCKS;
-  const uint32_t* pw = reinterpret_cast<const uint32_t*>(read_packed);
-  // all look-ups first, then their use: nine independent loads in flight instead of nine round trips
+MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const uint32_t* pw, int s, int len1, int len2, int st, const BxTab& T, BxAnchors* an) {
+  const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
+  // the home slots of all blocks first, then their use: nine independent loads in flight instead of nine round trips
   int32_t cn[BX_BLOCKS], ps[BX_BLOCKS][DF_KCAP];
+  uint32_t kidx[BX_BLOCKS], kh0[BX_BLOCKS], ke[BX_BLOCKS][4];
+#pragma unroll
+  for (int b = 0; b < BX_BLOCKS; b++) {
+    if (b < nb_cut) {
+      kidx[b] = (uint32_t)bx_kmer(pw, len2, bx_block_row(b, len2, nb_cut));
+      kh0[b] = kh_home(kh, kidx[b]);
+      const uint32_t* e = kh.slot + 4 * (size_t)kh0[b];
+#pragma unroll
+      for (int k = 0; k < 4; k++) ke[b][k] = e[k];
+    }
+  }
 #pragma unroll
   for (int b = 0; b < BX_BLOCKS; b++) {
     cn[b] = DF_KCAP + 1;
-    if (b < nb_cut) {
-      const int64_t idx = bx_kmer(pw, len2, (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1)));
-      cn[b] = ko.cnt[idx];
 #pragma unroll
-      for (int k = 0; k < DF_KCAP; k++) ps[b][k] = ko.pos[idx * DF_KCAP + k];
-    }
+    for (int k = 0; k < DF_KCAP; k++) ps[b][k] = 0;
+    if (b < nb_cut) cn[b] = kh_resolve(kh, kidx[b], kh0[b], ke[b][0], ke[b][1], ke[b][2], ke[b][3], ps[b]);
   }
-  int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0, budget = -1;
+  int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0, budget = -1, b_first = 0;
   bool any = false;
+  const int16_t* dl = T.dl + (st * (MAX_READ + 1) + len2) * BX_BLOCKS;
 #pragma unroll
   for (int b = 0; b < BX_BLOCKS; b++) {
     if (cn[b] > DF_KCAP) continue;                   // no such block, or an overloaded 10-mer: not part of the pigeonhole
     nb++;
-    const int o = (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1));
-    // what breaking this block costs at least (depths are monotone along the read: the ends of the block bound them)
-    {
-      const int dlo = sm_depth(o, len2), dhi = sm_depth(o + DF_K - 1, len2);
-      int dl = T.ev_block;
-      for (int d = dlo; d <= dhi; d++) { const int v = T.delta[st * 31 + d]; if (v < dl) dl = v; }
-      budget += dl;
-    }
+    budget += dl[b];
+    const int o = bx_block_row(b, len2, nb_cut);
 #pragma unroll
     for (int k = 0; k < DF_KCAP; k++) {
       if (k >= cn[b]) continue;
       const int d = ps[b][k] - o - s;                         // diagonal in window coordinates
       if (d < -R || d > len1 - 1) continue;                   // not a place inside this window
       if (!any) { d_first = d; any = true; }
+      if (d == d_first) b_first = b;                          // (the last block that has an anchor on d_first)
       d_last = d;
       if (d < a_lo) a_lo = d;
       if (d > a_hi) a_hi = d;
     }
   }
-  if (nb < BX_MIN_BLOCKS || !any || a_hi - a_lo >= BX_MAXW) return;
-  if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) return;   // keep the written-down path inside the window
-  // the loss of one valid path: rows [0, t) on d_first, one gap, the rest on d_last (or the plain diagonal if they agree),
-  // row by row from the mismatch masks (identical bases lose nothing)
-  auto row_loss = [&](int r, int dg) {
-    const int b = (int)((read_packed[r >> 1] >> ((r & 1) * 4)) & 3u), i = codes[(int64_t)s + dg + r];
-    return bx_loss(T, st, sm_depth(r, len2), b, i);
-  };
+  an->fail = 0;
+  if (nb < BX_MIN_BLOCKS || !any) { an->fail = BXF_BLOCKS; return; }
+  if (a_hi - a_lo >= BX_MAXW) { an->fail = BXF_SPAN; return; }
+  // keep the written-down path inside the window
+  if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) { an->fail = BXF_PATH; return; }
+  an->a_lo = a_lo; an->a_hi = a_hi; an->d_first = d_first; an->d_last = d_last; an->budget = budget;
+  an->t_lo = 1; an->t_hi = R;
+  if (d_first != d_last) {
+    // the switch row is looked for between the last block anchored on d_first and the first one after it anchored on d_last
+    int b_last = nb_cut - 1;
+    bool found = false;
+#pragma unroll
+    for (int b = 0; b < BX_BLOCKS; b++) {
+      if (cn[b] > DF_KCAP || b <= b_first || found) continue;
+      const int o = bx_block_row(b, len2, nb_cut);
+#pragma unroll
+      for (int k = 0; k < DF_KCAP; k++)
+        if (k < cn[b] && ps[b][k] - o - s == d_last) { b_last = b; found = true; }
+    }
+    an->t_lo = bx_block_row(b_first, len2, nb_cut) + DF_K;
+    an->t_hi = found ? bx_block_row(b_last, len2, nb_cut) : R;
+    if (an->t_lo < 1) an->t_lo = 1;
+  }
+}
+
+// bit q of a multiword mask
+template <int NW>
+MIA_HD inline int bx_bit(const uint64_t* m, int q) {
+  uint64_t w = m[0];
+#pragma unroll
+  for (int j = 1; j < NW; j++) if ((q >> 6) == j) w = m[j];
+  return (int)((w >> (q & 63)) & 1ull);
+}
+// mismatches in rows [from, to) of a mask
+template <int NW>
+MIA_HD inline int bx_count(const uint64_t* m, int from, int to) {
+  int n = 0;
+#pragma unroll
+  for (int j = 0; j < NW; j++) {
+    const int lo = from - 64 * j, hi = to - 64 * j;
+    if (hi <= 0 || lo >= 64) continue;
+    uint64_t w = m[j];
+    if (lo > 0) w &= ~0ull << lo;
+    if (hi < 64) w &= (1ull << hi) - 1ull;
+    n += df_popc(w);
+  }
+  return n;
+}
+
+// loss of the rows in [from, to) that mismatch on the diagonal sc is on (m = its mismatch words); *proof (if given):
+// D(q) >= -P(q+2) after every mismatch row q, with D(q) >= (q+1) min M - loss so far
+template <int NW>
+MIA_HD inline int bx_rows_loss(const DiagScan<NW>& sc, const uint64_t* m, int from, int to, int len2, int st, const BxTab& T, int b0, bool* proof) {
+#pragma unroll
+  for (int j = 0; j < NW; j++) {
+    uint64_t w = m[j];
+    const int lo = from - 64 * j, hi = to - 64 * j;
+    if (hi <= 0 || lo >= 64) continue;
+    if (lo > 0) w &= ~0ull << lo;
+    if (hi < 64) w &= (1ull << hi) - 1ull;
+    while (w) {
+      const int k = df_ctz(w), q = j * 64 + k;
+      w &= w - 1;
+      const int b = (int)(((sc.rlo[j] >> k) & 1ull) | (((sc.rhi[j] >> k) & 1ull) << 1));
+      const int i = (int)(((sc.clo[j] >> k) & 1ull) | (((sc.chi[j] >> k) & 1ull) << 1));
+      b0 += T.loss[((st * 31 + sm_depth(q, len2)) * 4 + b) * 4 + i];
+      if (proof && b0 > (q + 1) * T.min_m + GOP + GEP * (q + 2)) *proof = false;
+    }
+  }
+  return b0;
+}
+
+// B0 (the loss of one valid path) and what follows from it
+// PATHS: 0 = whatever the anchors say, 1 = the caller knows d_first == d_last, 2 = the caller knows they differ
+template <int NW, int PATHS = 0>
+MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnchors& an, int s, int len1, int len2, int st, const BxTab& T, BxPlan* out) {
+  out->mode = BX_NONE;
+  const int R = len2 - 1, d_first = an.d_first, d_last = PATHS == 1 ? an.d_first : an.d_last;
   uint64_t m1[NW];
   sc.seek(rp, (int64_t)s + d_first);
 #pragma unroll
   for (int j = 0; j < NW; j++) m1[j] = sc.mis(j);
   int b0 = 0;
-  bool proof = true;      // D(r-1) >= -P(r+1) for every row r >= 1 of the pure diagonal (only asked for when d_first == d_last)
-  if (d_first == d_last) {
-#pragma unroll
-    for (int j = 0; j < NW; j++) {
-      uint64_t m = m1[j];
-      while (m) {
-        const int q = j * 64 + df_ctz(m);
-        m &= m - 1;
-        b0 += row_loss(q, d_first);
-        // D(q) >= (q+1) min M - loss so far; the bound -P(q+2) falls with q while D only drops at mismatches
-        if (b0 > (q + 1) * T.min_m + GOP + GEP * (q + 2)) proof = false;
-      }
-    }
+  bool proof = true;
+  if (PATHS == 1 || (PATHS == 0 && d_first == d_last)) {
+    b0 = bx_rows_loss<NW>(sc, m1, 0, len2, len2, st, T, 0, &proof);
   } else {
-    uint64_t m2[NW + 1];
-    sc.seek(rp, (int64_t)s + d_last);
-#pragma unroll
-    for (int j = 0; j < NW; j++) m2[j] = sc.mis(j);
-    m2[NW] = 0;
-    // column gap (d_last > d_first: the rows from t on continue d_last - d_first columns further right) or row gap (the read
-    // skips d_first - d_last rows): the switch row t with the fewest mismatches, then that path's loss
+    // rows [0, t) on d_first, one gap, the rest on d_last: a column gap (d_last > d_first) or `skip` inserted rows
     const int shift = d_last - d_first, skip = shift < 0 ? -shift : 0;            // |shift| < BX_MAXW
-    uint64_t m2s[NW + 1];
+    int t_lo = an.t_lo, t_hi = an.t_hi - skip;
+    if (t_hi > R - skip) t_hi = R - skip;
+    if (t_lo > t_hi) t_lo = t_hi;
+    if (t_lo < 1) { out->b0 = BXF_PATH; return; }
+    uint64_t m2[NW];
+    DiagScan<NW> s2 = sc;
+    s2.seek(rp, (int64_t)s + d_last);
 #pragma unroll
-    for (int j = 0; j <= NW; j++) m2s[j] = m2[j];
-    if (skip) {                                    // bit t of m2s := row t + skip
-#pragma unroll
-      for (int j = 0; j < NW; j++) m2s[j] = (m2[j] >> skip) | (m2[j + 1] << (64 - skip));
+    for (int j = 0; j < NW; j++) m2[j] = s2.mis(j);
+    // the switch row with the fewest mismatches in [t_lo, t_hi]
+    int cur = bx_count<NW>(m1, 0, t_lo) + bx_count<NW>(m2, t_lo + skip, len2), best = cur, tbest = t_lo;
+    for (int t = t_lo + 1; t <= t_hi; t++) {
+      cur += bx_bit<NW>(m1, t - 1) - bx_bit<NW>(m2, t - 1 + skip);
+      if (cur < best) { best = cur; tbest = t; }
     }
-    int prefix = 0, suffix = 0, best = 1 << 20, tbest = -1;
-#pragma unroll
-    for (int j = 0; j < NW; j++) suffix += df_popc(m2s[j]);
-#pragma unroll
-    for (int j = 0; j < NW; j++) {
-      for (int q = 0; q < 64; q++) {
-        const int t = j * 64 + q + 1;
-        if (t + skip > R) break;
-        prefix += (int)((m1[j] >> q) & 1);
-        suffix -= (int)((m2s[j] >> q) & 1);
-        if (prefix + suffix < best) { best = prefix + suffix; tbest = t; }
-      }
-    }
-    if (tbest < 0) return;
     b0 = shift > 0 ? GOP + GEP * shift : GOP + (GEP + T.max_m) * skip;
-#pragma unroll
-    for (int j = 0; j < NW; j++) {
-      uint64_t m = m1[j];
-      while (m) { const int q = j * 64 + df_ctz(m); m &= m - 1; if (q < tbest) b0 += row_loss(q, d_first); }
-      m = m2[j];
-      while (m) { const int q = j * 64 + df_ctz(m); m &= m - 1; if (q >= tbest + skip) b0 += row_loss(q, d_last); }
-    }
+    b0 = bx_rows_loss<NW>(sc, m1, 0, tbest, len2, st, T, b0, nullptr);
+    b0 = bx_rows_loss<NW>(s2, m2, tbest + skip, len2, len2, st, T, b0, nullptr);
   }
-  if (b0 > budget) return;
+  out->b0 = BXF_BUDGET;
+  if (b0 > an.budget) return;
   // (one diagonal more where the window's first column is within reach, as band_body.h)
   int g = b0 < GOP + GEP ? 0 : (b0 - GOP) / GEP;
-  if (a_lo - g - 1 < 0) g++;
-  const int d0 = a_lo - g, w = a_hi - a_lo + 2 * g + 1;
+  if (an.a_lo - g - 1 < 0) g++;
+  const int d0 = an.a_lo - g, w = an.a_hi - an.a_lo + 2 * g + 1;
+  out->b0 = BXF_WIDTH;
   if (w > BX_MAXW) return;
   out->d0 = d0; out->w = w; out->b0 = b0; out->dstar = d_first;
-  if (d_first != d_last || !proof) { out->mode = BX_TRACE; }
+  if (d_first != d_last || !proof) out->mode = BX_TRACE;
   else out->mode = w == 1 ? BX_DONE : BX_VALUES;
   // the widest band of the read's class must not leave the window anywhere for the plain form of the recurrence
   const int wc = 8 * (bx_class_of(w) + 1);
   out->edge = !(d0 >= 0 && len2 - 1 + d0 + wc <= len1);
 }
 
-MIA_HD inline void bx_plan(const RefPlanes& rp, const KmerOcc& ko, const uint8_t* codes, int64_t n_ref, int s, int len1, const uint8_t* read_packed,
-                           int len2, int st, const BxTab& T, BxPlan* out) {
+MIA_HD inline bool bx_plannable(const RefPlanes& rp, const KmerHash& ko, int64_t n_ref, int s, int len1, int len2) {
+  if (!ko.slot || len2 < BX_MIN_BLOCKS * DF_K || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1 || s < 0 || (int64_t)s + len1 > n_ref) return false;
+  return all_bases(rp, s, (int64_t)s + len1);
+}
+
+// everything in one go (the kernel does the same in two phases: reads with anchors on two diagonals are collected and
+// finished by the block's first threads).  out->mode == BX_NONE: out->b0 holds the reason (BXF_*).
+template <int NW>
+MIA_HD inline void bx_plan_nw(const RefPlanes& rp, const KmerHash& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2, int st,
+                              const BxTab& T, BxPlan* out) {
   out->mode = BX_NONE;
-  if (!ko.cnt || len2 < BX_MIN_BLOCKS * DF_K || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1 || s < 0 || (int64_t)s + len1 > n_ref) return;
-  if (!all_bases(rp, s, (int64_t)s + len1)) return;
+  DiagScan<NW> sc;
+  out->b0 = BXF_READ;
+  if (!sc.load_read(read_packed, len2)) return;              // a read with N
+  BxAnchors an;
+  bx_anchors<NW>(sc, ko, reinterpret_cast<const uint32_t*>(read_packed), s, len1, len2, st, T, &an);
+  out->b0 = an.fail;
+  if (an.fail) return;
+  bx_finish<NW>(sc, rp, an, s, len1, len2, st, T, out);
+}
+
+MIA_HD inline void bx_plan(const RefPlanes& rp, const KmerHash& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2, int st,
+                           const BxTab& T, BxPlan* out) {
+  out->mode = BX_NONE;
+  out->b0 = BXF_WINDOW;
+  if (!bx_plannable(rp, ko, n_ref, s, len1, len2)) return;
   switch ((len2 + 63) >> 6) {
-    case 1: bx_plan_nw<1>(rp, ko, codes, n_ref, s, len1, read_packed, len2, st, T, out); break;
-    case 2: bx_plan_nw<2>(rp, ko, codes, n_ref, s, len1, read_packed, len2, st, T, out); break;
-    case 3: bx_plan_nw<3>(rp, ko, codes, n_ref, s, len1, read_packed, len2, st, T, out); break;
-    default: bx_plan_nw<4>(rp, ko, codes, n_ref, s, len1, read_packed, len2, st, T, out); break;
+    case 1: bx_plan_nw<1>(rp, ko, n_ref, s, len1, read_packed, len2, st, T, out); break;
+    case 2: bx_plan_nw<2>(rp, ko, n_ref, s, len1, read_packed, len2, st, T, out); break;
+    case 3: bx_plan_nw<3>(rp, ko, n_ref, s, len1, read_packed, len2, st, T, out); break;
+    default: bx_plan_nw<4>(rp, ko, n_ref, s, len1, read_packed, len2, st, T, out); break;
   }
 }
 

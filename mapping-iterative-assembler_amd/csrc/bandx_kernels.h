@@ -1,0 +1,382 @@
+// bandx_kernels.h -- gfx950 kernels around bandx_body.h: the re-alignment of every stored read in its window
+// (reiterate_assembly, /root/reference/src/mia_main.c:24-280: dyn_prog, max_sg_score, find_align_begin,
+// populate_pwaln_to_begin per read) for any substitution matrix.
+//
+//   k_ref_nibbles  the reference as 4-bit codes (the DP looks the substitution score of a cell up by this code)
+//   k_bx_umax      U of every read (once per read set and matrix)
+//   k_bx_plan      one read per thread: band from the 10-mer anchors; one-diagonal bands are finished here; the rest is
+//                  appended to one of eight lists (values / trace x band class)
+//   k_bx_values    persistent wavefronts take chunks of 64 reads of one class: values-only DP in registers, substitution
+//                  table in LDS; a read whose best score is the plan's diagonal's is finished, the others go on to the trace lists
+//   k_bx_trace     the same with a byte trace in a private slab and the reference's traceback
+// Nothing here waits for the host: list lengths and chunk cursors stay on the device.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bandx_body.h"
+#include "mia_kernels.h"
+
+namespace mia {
+
+// counters of the pipeline; each on a cache line of its own (BXC_STRIDE words apart): thousands of wavefronts add to them,
+// and atomics on one line are served one after the other
+enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_COUNTERS = 32 };
+constexpr int BXC_STRIDE = 64;
+constexpr int BXC_WORDS = BXC_COUNTERS * BXC_STRIDE;
+__device__ __forceinline__ uint32_t* bxc(const uint32_t* ctr, int k) { return const_cast<uint32_t*>(ctr) + (size_t)k * BXC_STRIDE; }
+
+struct BxDev {
+  BxTab tab;               // tables in global memory
+  const int32_t* sub256;   // tab.sub times 256 (the trace DP's packed words)
+  const uint32_t* refnib;
+  const int32_t* umax;     // [n] U of every read, -1 for a read with N; nullptr: a borrowed read set, U is summed where it is needed
+  const uint64_t* rplanes; // [n][2 * rplane_words] bit planes of the reads (k_read_planes), or nullptr
+  int32_t rplane_words;
+  uint32_t* plan;          // [n] packed BxPlan of a read on a list
+  int32_t* expect;         // [n] U - b0: the score of the plan's diagonal
+  int32_t* lists;          // [2 * BX_NCLS][list_stride] read indices
+  int64_t list_stride;
+  uint32_t* ctr;           // BXC_*
+};
+
+__device__ __forceinline__ uint32_t bx_pack(const BxPlan& p) {
+  return (uint32_t)(p.d0 + 512) | ((uint32_t)(p.dstar - p.d0) << 11) | ((uint32_t)p.edge << 16) | ((uint32_t)p.w << 17);
+}
+
+__global__ __launch_bounds__(256) void k_ref_nibbles(const uint8_t* codes, int64_t n_codes, int64_t words, uint32_t* out) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= words) return;
+  uint32_t v = 0;
+  for (int k = 0; k < 8; k++) {
+    const int64_t p = w * 8 + k - BX_NIB_LEAD;
+    const uint32_t c = (p >= 0 && p < n_codes) ? codes[p] : 4u;
+    v |= (c > 4u ? 4u : c) << (4 * k);
+  }
+  out[w] = v;
+}
+
+__global__ __launch_bounds__(256) void k_bx_umax(ReadSet rs, const int32_t* mrow, int32_t* umax) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < rs.n) umax[i] = bx_umax(mrow, rs.packed + rs.roff[i], rs.len[i], rs.rc[i] ? 1 : 0);
+}
+
+// append `i` to list `which` for the lanes with want == true: one atomic per wavefront and list
+__device__ __forceinline__ void bx_append(const BxDev& bx, int which, bool want, int32_t i) {
+  const unsigned long long m = __ballot(want);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == __builtin_ctzll(m)) base = atomicAdd(bxc(bx.ctr, BXC_LIST0 + which), (uint32_t)__popcll(m));
+  base = __shfl(base, __builtin_ctzll(m));
+  if (want) bx.lists[(int64_t)which * bx.list_stride + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+// the script of a pure diagonal (consecutive columns from c0 on) for the lanes in `mask`: the wavefront writes one read
+// per step, four columns (8 bytes) per lane
+__device__ __forceinline__ void bx_diag_scripts(const ReadSet& rs, unsigned long long mask, int32_t i, int c0, int len2) {
+  const int lane = threadIdx.x & 63;
+  while (mask) {
+    const int l = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const int64_t j = __shfl(i, l);
+    const int d = __shfl(c0, l), n = __shfl(len2, l);
+    int16_t* cols = rs.cols + j * rs.stride;        // stride is a multiple of 4 and >= len2
+    const int base = lane * 4;
+    if (base < n) {
+      const uint32_t c = (uint32_t)(d + base);
+      uint2 v;
+      v.x = (c & 0xFFFFu) | ((c + 1u) << 16);
+      v.y = ((c + 2u) & 0xFFFFu) | ((c + 3u) << 16);
+      *reinterpret_cast<uint2*>(cols + base) = v;
+    }
+  }
+}
+
+// the reference's 10-mers into the hash table (bandx_body.h: KmerHash); slots and ovf are all ones / anything before
+__global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t n_codes, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t idx64 = kmer_at(codes, n_codes, p);
+  if (idx64 < 0) return;
+  const uint32_t idx = (uint32_t)idx64;
+  uint32_t h = (idx * 2654435761u) >> shift;
+  for (;;) {
+    uint32_t* e = slot + 4 * (size_t)h;
+    const uint32_t prev = atomicCAS(&e[0], KH_EMPTY, idx);
+    if (prev == KH_EMPTY || prev == idx) {
+      const uint32_t c = atomicAdd(&e[2], 1u) + 1u;           // (starts at all ones)
+      if (c == 0) e[1] = (uint32_t)p; else if (c == 1) e[3] = (uint32_t)p; else if (c < 4) ovf[2 * (size_t)h + c - 2] = (int32_t)p;
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+
+// bit planes of every read (diag_filter.h: DiagScan::load_read), once per read set: words lo words, then words hi words
+__global__ __launch_bounds__(256) void k_read_planes(ReadSet rs, int32_t words, uint64_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rs.n) return;
+  DiagScan<4> sc;
+  sc.load_read(rs.packed + rs.roff[i], rs.len[i]);
+  uint64_t* o = out + i * 2 * words;
+  for (int j = 0; j < words; j++) { o[j] = sc.rlo[j]; o[words + j] = sc.rhi[j]; }
+}
+
+// in_list / n_in_p: the reads to look at (what the diagonal filter left over), or nullptr: all n_all reads, and then
+// every read gets its mark in bin_of (0 = open, -4 = finished here or later by the band kernels).
+// NW: 64-row words of the longest read of the set.  Two phases: every thread takes its read through the anchors and, if
+// they lie on one diagonal (nine reads in ten), through the rest; the others are collected and finished by the block's
+// first threads, so that their longer way (two diagonals, the switch row between them) is not walked by whole wavefronts
+// for the sake of a few lanes.
+template <int NW>
+__global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPlanes rp, KmerHash ko, int64_t n_ref, BxDev bx, const int32_t* in_list,
+                                                  const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of) {
+  __shared__ int16_t loss_lds[BX_LOSS_WORDS];
+  __shared__ BxAnchors cand_an[256];
+  __shared__ uint8_t cand_tid[256];
+  __shared__ int32_t n_cand;
+  __shared__ uint32_t blk_cnt[2 * BX_NCLS + 2 + BXF_KINDS], blk_base[2 * BX_NCLS];   // per block: list appends, finished, seen, reasons
+  for (int k = threadIdx.x; k < BX_LOSS_WORDS; k += 256) loss_lds[k] = bx.tab.loss[k];
+  if (threadIdx.x == 0) n_cand = 0;
+  if (threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS) blk_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  BxTab T = bx.tab;
+  T.loss = loss_lds;
+  const int64_t total = in_list ? (int64_t)*n_in_p : n_all;
+  const int64_t t0 = (int64_t)blockIdx.x * 256;
+
+  struct Rd { int32_t i; int len2, s, l1, st; bool ok; };
+  auto fetch = [&](int tid, DiagScan<NW>& sc) -> Rd {
+    Rd r{0, 0, 0, 0, 0, false};
+    const int64_t t = t0 + tid;
+    if (t >= total) return r;
+    r.i = in_list ? in_list[t] : (int32_t)t;
+    if (!rs.sk[r.i]) return r;
+    r.len2 = rs.len[r.i];
+    r.st = rs.rc[r.i] ? 1 : 0;
+    read_window(ref, rs.as[r.i], rs.ae[r.i], r.len2, &r.s, &r.l1);
+    r.ok = true;
+    return r;
+  };
+  auto load_planes = [&](const Rd& r, DiagScan<NW>& sc) -> bool {
+    if (bx.rplanes) {
+      if (bx.umax[r.i] < 0) return false;                       // a read with N
+      const uint64_t* pl = bx.rplanes + (int64_t)r.i * 2 * bx.rplane_words;
+      sc.set_read(pl, pl + bx.rplane_words, r.len2);
+      return true;
+    }
+    return sc.load_read(rs.packed + rs.roff[r.i], r.len2);
+  };
+  // results of a planned read: finished (scripts follow), or on to a list
+  auto emit = [&](const Rd& r, const BxPlan& bp, bool mark_open) {
+    if (r.ok || mark_open) {
+      if (bp.mode == BX_DONE || bp.mode == BX_VALUES) {
+        const int u = bx.umax ? bx.umax[r.i] : bx_umax(bx.tab.mrow, rs.packed + rs.roff[r.i], r.len2, r.st);
+        const int expect = u - bp.b0;
+        if (bp.mode == BX_DONE) {
+          rs.score[r.i] = expect;
+          rs.refstart[r.i] = r.s;
+          rs.abr[r.i] = 0;
+          rs.as[r.i] = r.s + bp.dstar;                   // src/mia_main.c:254-255
+          rs.ae[r.i] = r.s + bp.dstar + r.len2 - 1;
+          rs.status[r.i] = ST_DIAG;
+          bin_of[r.i] = -4;
+        } else bx.expect[r.i] = expect;
+      }
+      if (bp.mode == BX_VALUES || bp.mode == BX_TRACE) bx.plan[r.i] = bx_pack(bp);
+      if (mark_open && bp.mode != BX_DONE) bin_of[r.i] = 0;
+    }
+    // list appends and counters go through the block: one global atomic per block and list instead of one per wavefront
+    const int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? BX_NCLS + bx_class_of(bp.w) : -1);
+    uint32_t rank = 0;
+    if (which >= 0) rank = atomicAdd(&blk_cnt[which], 1u);
+    if (bp.mode == BX_DONE) atomicAdd(&blk_cnt[2 * BX_NCLS], 1u);
+    if (r.ok && bp.mode == BX_NONE && bp.b0 > 0 && bp.b0 < BXF_KINDS) atomicAdd(&blk_cnt[2 * BX_NCLS + 2 + bp.b0], 1u);
+    __syncthreads();
+    if (threadIdx.x < 2 * BX_NCLS && blk_cnt[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(bxc(bx.ctr, BXC_LIST0 + threadIdx.x), blk_cnt[threadIdx.x]);
+    if (threadIdx.x == 2 * BX_NCLS && blk_cnt[2 * BX_NCLS]) atomicAdd(bxc(bx.ctr, BXC_DONE_PLAN), blk_cnt[2 * BX_NCLS]);
+    if (threadIdx.x == 2 * BX_NCLS + 1 && blk_cnt[2 * BX_NCLS + 1]) atomicAdd(bxc(bx.ctr, BXC_SEEN), blk_cnt[2 * BX_NCLS + 1]);
+    if (threadIdx.x > 2 * BX_NCLS + 2 && threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS && blk_cnt[threadIdx.x])
+      atomicAdd(bxc(bx.ctr, BXC_FAIL0 + (int)threadIdx.x - 2 * BX_NCLS - 2), blk_cnt[threadIdx.x]);
+    __syncthreads();
+    if (which >= 0) bx.lists[(int64_t)which * bx.list_stride + blk_base[which] + rank] = r.i;
+    bx_diag_scripts(rs, __ballot(bp.mode == BX_DONE), r.i, bp.dstar, r.len2);
+    __syncthreads();
+    if (threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS) blk_cnt[threadIdx.x] = 0;
+    __syncthreads();
+  };
+  {
+    DiagScan<NW> sc;
+    Rd r = fetch((int)threadIdx.x, sc);
+    BxPlan bp;
+    bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
+    bool waits = false;
+    if (r.ok) {
+      bp.b0 = BXF_WINDOW;
+      if (bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2)) {
+        bp.b0 = BXF_READ;
+        if (load_planes(r, sc)) {
+          BxAnchors an;
+          bx_anchors<NW>(sc, ko, reinterpret_cast<const uint32_t*>(rs.packed + rs.roff[r.i]), r.s, r.l1, r.len2, r.st, T, &an);
+          bp.b0 = an.fail;
+          if (!an.fail) {
+            if (an.d_first == an.d_last) bx_finish<NW, 1>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
+            else {
+              const int slot = atomicAdd(&n_cand, 1);
+              cand_an[slot] = an;
+              cand_tid[slot] = (uint8_t)threadIdx.x;
+              waits = true;
+              bp.b0 = 0;
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long sm = __ballot(r.ok);
+    if ((threadIdx.x & 63) == 0 && sm) atomicAdd(&blk_cnt[2 * BX_NCLS + 1], (uint32_t)__popcll(sm));
+    // (a waiting read's mark is written in the second phase)
+    Rd rr = r;
+    if (waits) rr.ok = false;
+    emit(rr, bp, !in_list && t0 + threadIdx.x < total && !waits);
+  }
+  __syncthreads();
+  if (n_cand == 0) return;
+  {                                                 // (every thread: emit has barriers)
+    DiagScan<NW> sc;
+    Rd r{0, 0, 0, 0, 0, false};
+    BxPlan bp;
+    bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
+    if ((int)threadIdx.x < n_cand) {
+      r = fetch(cand_tid[threadIdx.x], sc);
+      load_planes(r, sc);
+      const BxAnchors an = cand_an[threadIdx.x];
+      bx_finish<NW, 2>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
+    }
+    emit(r, bp, !in_list && r.ok);
+  }
+}
+
+// the chunk a wavefront takes next: classes in descending width (the long chunks first), 64 reads each
+struct BxChunk { int cls; uint32_t first, count; };
+__device__ __forceinline__ bool bx_next_chunk(const BxDev& bx, int list0, int cursor, BxChunk* out) {
+  uint32_t chunk = 0;
+  if ((threadIdx.x & 63) == 0) chunk = atomicAdd(bxc(bx.ctr, cursor), 1u);
+  chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+  for (int c = BX_NCLS - 1; c >= 0; c--) {
+    const uint32_t cnt = *bxc(bx.ctr, BXC_LIST0 + list0 + c), nch = (cnt + 63u) >> 6;
+    if (chunk < nch) { out->cls = c; out->first = chunk * 64u; out->count = cnt; return true; }
+    chunk -= nch;
+  }
+  return false;
+}
+
+struct BxRead { int32_t i; int len2, s, l1, d0, jstar, st; bool edge; const uint32_t* rw; };
+__device__ __forceinline__ BxRead bx_load(const ReadSet& rs, const RefInfo& ref, const BxDev& bx, int32_t i) {
+  BxRead r;
+  r.i = i;
+  r.len2 = rs.len[i];
+  read_window(ref, rs.as[i], rs.ae[i], r.len2, &r.s, &r.l1);
+  const uint32_t w = bx.plan[i];
+  r.d0 = (int)(w & 0x7FFu) - 512;
+  r.jstar = (int)((w >> 11) & 31u);
+  r.edge = ((w >> 16) & 1u) != 0;
+  r.st = rs.rc[i] ? 1 : 0;
+  r.rw = reinterpret_cast<const uint32_t*>(rs.packed + rs.roff[i]);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_bx_values(ReadSet rs, RefInfo ref, BxDev bx, int32_t* bin_of) {
+  __shared__ int32_t sub_lds[BX_SUB_WORDS];
+  for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.tab.sub[k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  uint32_t done = 0;
+  BxChunk ch;
+  while (bx_next_chunk(bx, 0, BXC_CUR_VALUES, &ch)) {
+    const uint32_t t = ch.first + lane;
+    const bool live = t < ch.count;
+    int best = BX_NEG, bj = -1;
+    BxRead r{};
+    if (live) r = bx_load(rs, ref, bx, bx.lists[(int64_t)ch.cls * bx.list_stride + t]);
+    const bool edge = __ballot(live && r.edge) != 0ull;       // one form of the recurrence per wavefront
+    if (live) {
+      const int32_t* sub = sub_lds + r.st * (31 * 4 * BX_SUB_ROW);
+#define BXV(W)                                                                                                \
+  if (edge) bx_values<W, true>(bx.refnib, r.s, r.l1, r.rw, r.len2, r.d0, sub, &best, &bj);                  \
+  else bx_values<W, false>(bx.refnib, r.s, r.l1, r.rw, r.len2, r.d0, sub, &best, &bj)
+      switch (ch.cls) {
+        case 0: BXV(8); break;
+        case 1: BXV(16); break;
+        case 2: BXV(24); break;
+        default: BXV(32); break;
+      }
+#undef BXV
+    }
+    const bool ok = live && bj >= 0 && bj == r.jstar && best == bx.expect[r.i];
+    if (ok) {
+      const int dstar = r.d0 + r.jstar;
+      rs.score[r.i] = best;
+      rs.refstart[r.i] = r.s;
+      rs.abr[r.i] = 0;
+      rs.as[r.i] = r.s + dstar;                   // src/mia_main.c:254-255
+      rs.ae[r.i] = r.s + dstar + r.len2 - 1;
+      rs.status[r.i] = ST_DIAG;
+      bin_of[r.i] = -4;
+      done++;
+    }
+    bx_append(bx, BX_NCLS + ch.cls, live && !ok, r.i);
+    bx_diag_scripts(rs, __ballot(ok), r.i, r.d0 + r.jstar, r.len2);
+  }
+  for (int o = 32; o; o >>= 1) done += __shfl_xor(done, o);
+  if (lane == 0 && done) atomicAdd(bxc(bx.ctr, BXC_DONE_VALUES), done);
+}
+
+// trace slab of a wavefront: [row][lane][BX_MAXW bytes], so that the 64 stores of a row are one stretch
+// trace slab of a wavefront: [row][lane][W bytes], so that the 64 stores of a row are one stretch
+constexpr int BX_SLAB_ROW_WORDS = 64 * (BX_MAXW / 4);
+__global__ __launch_bounds__(256) void k_bx_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
+  __shared__ int32_t sub_lds[BX_SUB_WORDS];
+  for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.sub256[k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  uint32_t* slab = slabs + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * slab_words;
+  uint32_t done = 0;
+  BxChunk ch;
+  while (bx_next_chunk(bx, BX_NCLS, BXC_CUR_TRACE, &ch)) {
+    const uint32_t t = ch.first + lane;
+    const bool live = t < ch.count;
+    BxRead r{};
+    if (live) r = bx_load(rs, ref, bx, bx.lists[(int64_t)(BX_NCLS + ch.cls) * bx.list_stride + t]);
+    const bool edge = __ballot(live && r.edge) != 0ull;
+    bool got = false;
+    BxResult res{};
+    if (live) {
+      const int32_t* sub = sub_lds + r.st * (31 * 4 * BX_SUB_ROW);
+      int16_t* cols = rs.cols + (int64_t)r.i * rs.stride;
+#define BXT(W)                                                                                                                              \
+  got = edge ? bx_trace<W, true>(bx.refnib, r.s, r.l1, r.rw, r.len2, r.d0, sub, slab + lane * (W / 4), 64 * (W / 4), cols, &res)          \
+             : bx_trace<W, false>(bx.refnib, r.s, r.l1, r.rw, r.len2, r.d0, sub, slab + lane * (W / 4), 64 * (W / 4), cols, &res)
+      switch (ch.cls) {
+        case 0: BXT(8); break;
+        case 1: BXT(16); break;
+        case 2: BXT(24); break;
+        default: BXT(32); break;
+      }
+#undef BXT
+    }
+    if (got) {                                   // (not got: the reference's index-0 quirk -- the full-window kernels take the read)
+      rs.score[r.i] = res.score;
+      rs.refstart[r.i] = r.s;
+      rs.abr[r.i] = (int16_t)res.abr;
+      rs.as[r.i] = res.abc + r.s;                // src/mia_main.c:254-255
+      rs.ae[r.i] = res.aec + r.s;
+      rs.status[r.i] = res.gaps == 0 ? ST_DIAG : (res.gaps == 1 ? (ST_ONEGAP | (res.gap_desc << 8)) : ST_OK);
+      bin_of[r.i] = -4;
+      done++;
+    }
+  }
+  for (int o = 32; o; o >>= 1) done += __shfl_xor(done, o);
+  if (lane == 0 && done) atomicAdd(bxc(bx.ctr, BXC_DONE_TRACE), done);
+}
+
+}  // namespace mia

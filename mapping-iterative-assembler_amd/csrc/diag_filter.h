@@ -150,6 +150,17 @@ struct DiagScan {
     return acgt;
   }
 
+  // the same from planes made earlier (k_read_planes: NWP words of lo, then NWP of hi); the caller knows there is no N
+  MIA_HD void set_read(const uint64_t* lo, const uint64_t* hi, int n) {
+    len2 = n;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      const int left = n - 64 * j;
+      rlo[j] = lo[j]; rhi[j] = hi[j];
+      rows[j] = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
+    }
+  }
+
   // planes of reference positions [pos, pos + 64 (NW+1)); pos >= -PLANE_LEAD
   MIA_HD void seek(const RefPlanes& rp, int64_t pos) {
     const int64_t bit = pos + PLANE_LEAD;

@@ -13,6 +13,7 @@
 #include "../../include/mia_hip.h"
 #include "mia_consensus_kernels.h"
 #include "mia_kernels.h"
+#include "bandx_kernels.h"
 #include "mia_pass1_kernels.h"
 #include "mia_myers_kernels.h"
 #include "mia_trim_kernels.h"
@@ -85,6 +86,24 @@ struct mia_hip_ctx {
   int32_t* d_left_list = nullptr; int64_t left_cap = 0;
   uint32_t* d_band_slabs = nullptr; int64_t band_slab_cap = 0;
   int64_t band_done = 0; double band_ms = 0; int64_t band_launches = 0;
+  // the matrix-agnostic band pipeline (bandx_kernels.h): plan -> values-only DP -> trace DP, for any PSSM
+  bool bx_ok = false;                       // the matrices allow it (bx_make_tables)
+  int use_bx = 1;                           // MIA_HIP_NO_BANDX=1: the round-1 path (flat: filter + k_band_align; PSSM: full-window kernels)
+  int bx_filter_first = 0;                  // MIA_HIP_BX_FILTER=1 (flat matrix): k_diag_filter runs ahead of the plan
+  int32_t *d_bx_sub = nullptr, *d_bx_mrow = nullptr; int16_t *d_bx_loss = nullptr, *d_bx_dl = nullptr;   // sub | sub * 256; M; losses; block costs
+  int32_t bx_min_m = 0, bx_max_m = 0;
+  uint64_t* d_rplanes = nullptr; int rplane_words = 0;   // bit planes of the stored reads (k_read_planes)
+  uint32_t* d_refnib = nullptr; int64_t refnib_cap = 0;
+  uint32_t* d_khash = nullptr; int32_t* d_khash_ovf = nullptr; uint32_t khash_cap = 0;   // 10-mers of the reference (bandx_body.h: KmerHash)
+  int32_t* d_umax = nullptr; bool umax_valid = false;
+  uint32_t* d_bx_plan = nullptr; int32_t* d_bx_expect = nullptr; int32_t* d_bx_lists = nullptr; int64_t bx_cap = 0;
+  uint32_t* d_bx_ctr = nullptr;
+  uint32_t* d_bx_slabs = nullptr; int64_t bx_slab_cap = 0;
+  int bx_values_wgs = 0, bx_trace_wgs = 0;
+  int64_t bx_seen = 0, bx_done[3] = {0, 0, 0};   // reads planned on; finished by the plan / the values DP / the trace DP
+  double bx_ms[3] = {0, 0, 0}; int64_t bx_launches = 0;
+  uint32_t bx_last[BXC_COUNTERS] = {0};     // counters of the last call (list lengths, reasons a read was not planned)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_bx[3];
   int grid_wgs = 0;
   int window_wgs[N_CPL] = {0, 0, 0};
   int cus = 1;
@@ -160,9 +179,13 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     const char* npl = getenv("MIA_HIP_NO_PLAIN");
     if (npl && atoi(npl)) ctx->use_plain = 0;
     const char* nf = getenv("MIA_HIP_NO_DIAG_FILTER");
-    if (nf && atoi(nf)) ctx->use_filter = 0;
+    if (nf && atoi(nf)) { ctx->use_filter = 0; ctx->use_bx = 0; }      // every shortcut off: the full-window DP kernels only
     const char* nbd = getenv("MIA_HIP_NO_BAND_DP");
-    if (nbd && atoi(nbd)) ctx->use_banddp = 0;
+    if (nbd && atoi(nbd)) { ctx->use_banddp = 0; ctx->use_bx = 0; }
+    const char* nbx = getenv("MIA_HIP_NO_BANDX");
+    if (nbx && atoi(nbx)) ctx->use_bx = 0;
+    const char* bxf = getenv("MIA_HIP_BX_FILTER");
+    if (bxf && atoi(bxf)) ctx->bx_filter_first = 1;
     const char* nq = getenv("MIA_HIP_NO_QUAD");
     if (nq && atoi(nq)) ctx->use_quad = 0;
     const char* qw = getenv("MIA_HIP_QUAD_WAVES_PER_CU");
@@ -173,7 +196,10 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (g && atoi(g) > 0) ctx->grid_wgs = prop.multiProcessorCount * atoi(g);
   }
   if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_bins, 3 * N_BINS + 2) ||
-      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1) || dev_alloc(ctx, &ctx->d_filter_n, 4)) {
+      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1) || dev_alloc(ctx, &ctx->d_filter_n, 4) ||
+      dev_alloc(ctx, &ctx->d_bx_sub, 2 * BX_SUB_WORDS) || dev_alloc(ctx, &ctx->d_bx_mrow, 2 * 31 * 4) || dev_alloc(ctx, &ctx->d_bx_loss, BX_LOSS_WORDS) ||
+      dev_alloc(ctx, &ctx->d_bx_dl, BX_DL_WORDS) ||
+      dev_alloc(ctx, &ctx->d_bx_ctr, BXC_WORDS)) {
     delete ctx;
     return MIA_HIP_ERR_NOMEM;
   }
@@ -193,7 +219,9 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs};
+                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs,
+                  ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_ctr,
+                  ctx->d_bx_slabs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -202,6 +230,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   for (auto& e : ctx->ev_plain) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_filter) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_band) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& v : ctx->ev_bx) for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -241,6 +270,27 @@ extern "C" int mia_hip_set_pssm(mia_hip_ctx* ctx, const int32_t* fwd, const int3
       for (int b = 0; b < 5; b++)
         if (fwd[(d * 5 + x) * 5 + b] != fwd[x * 5 + b] || rc[(d * 5 + x) * 5 + b] != fwd[x * 5 + b]) ctx->tally_linear = false;
   if (const char* nl = getenv("MIA_HIP_NO_LINEAR_TALLY")) if (atoi(nl)) ctx->tally_linear = false;
+  // tables of the band pipeline (bandx_body.h): substitution scores by (strand, depth, read base, reference code), the best
+  // score of every row kind, and what a non-identical base costs at least
+  {
+    std::vector<int32_t> sub(2 * BX_SUB_WORDS, 0), mrow(2 * 31 * 4, 0);
+    std::vector<int16_t> loss(BX_LOSS_WORDS, 0), dl(BX_DL_WORDS, 0);
+    ctx->bx_ok = bx_make_tables(fwd, rc, sub.data(), mrow.data(), loss.data(), dl.data(), &ctx->bx_min_m, &ctx->bx_max_m);
+    if (ctx->bx_ok) {
+      for (int k = 0; k < BX_SUB_WORDS; k++) sub[(size_t)BX_SUB_WORDS + k] = sub[(size_t)k] * 256;
+      HIPCHK(hipMemcpyAsync(ctx->d_bx_sub, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ctx->d_bx_mrow, mrow.data(), mrow.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ctx->d_bx_loss, loss.data(), loss.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ctx->d_bx_dl, dl.data(), dl.size() * 2, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->umax_valid = false;
+    if (ctx->bx_ok && ctx->d_umax && ctx->rs.n > 0) {
+      hipLaunchKernelGGL(k_bx_umax, dim3((unsigned)((ctx->rs.n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_bx_mrow, ctx->d_umax);
+      HIPCHK(hipGetLastError());
+      ctx->umax_valid = true;
+    }
+  }
   return MIA_HIP_OK;
 }
 
@@ -298,6 +348,9 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_status, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_cols, (size_t)n * stride);
   rcx |= dev_alloc(ctx, &ctx->d_bin_of, (size_t)n);
+  rcx |= dev_alloc(ctx, &ctx->d_umax, (size_t)n);
+  ctx->rplane_words = (max_len + 63) >> 6;
+  rcx |= dev_alloc(ctx, &ctx->d_rplanes, (size_t)n * 2 * ctx->rplane_words);
   rcx |= dev_alloc(ctx, &ctx->d_list, (size_t)n + 4 * N_BINS);   // quad bins are padded to multiples of four
   rcx |= dev_alloc(ctx, &ctx->d_wide_list, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_retry_list, (size_t)n);
@@ -338,6 +391,13 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   r.as = ctx->d_as; r.ae = ctx->d_ae; r.score = ctx->d_score; r.refstart = ctx->d_refstart; r.abr = ctx->d_abr;
   r.status = ctx->d_status; r.cols = ctx->d_cols; r.stride = stride;
   if (ctx->d_order) { (void)hipFree(ctx->d_order); ctx->d_order = nullptr; }
+  ctx->umax_valid = false;
+  if (n > 0) hipLaunchKernelGGL(k_read_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->rplane_words, ctx->d_rplanes);
+  if (ctx->have_pssm && ctx->bx_ok && n > 0) {
+    hipLaunchKernelGGL(k_bx_umax, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_bx_mrow, ctx->d_umax);
+    HIPCHK(hipGetLastError());
+    ctx->umax_valid = true;
+  }
   ctx->aligned = false;
   ctx->tallied = false;
   ctx->culled = false;
@@ -394,6 +454,14 @@ static void drain_events(mia_hip_ctx* ctx) {
     ctx->ev_free.push_back(e);
   }
   ctx->ev_band.clear();
+  for (int k = 0; k < 3; k++) {
+    for (auto& e : ctx->ev_bx[k]) {
+      float ms = 0;
+      if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) ctx->bx_ms[k] += ms;
+      ctx->ev_free.push_back(e);
+    }
+    ctx->ev_bx[k].clear();
+  }
 }
 
 extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms, int64_t* launches) {
@@ -426,6 +494,23 @@ extern "C" int mia_hip_band_stats(mia_hip_ctx* ctx, int reset, int64_t* reads_fi
   if (kernel_ms) *kernel_ms = ctx->band_ms;
   if (launches) *launches = ctx->band_launches;
   if (reset) { ctx->band_done = 0; ctx->band_ms = 0; ctx->band_launches = 0; }
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_bx_stats(mia_hip_ctx* ctx, int reset, int64_t* reads4, double* kernel_ms3, int64_t* launches) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  drain_events(ctx);
+  if (reads4) { reads4[0] = ctx->bx_seen; reads4[1] = ctx->bx_done[0]; reads4[2] = ctx->bx_done[1]; reads4[3] = ctx->bx_done[2]; }
+  if (kernel_ms3) for (int k = 0; k < 3; k++) kernel_ms3[k] = ctx->bx_ms[k];
+  if (launches) *launches = ctx->bx_launches;
+  if (reset) { ctx->bx_seen = 0; for (int k = 0; k < 3; k++) { ctx->bx_done[k] = 0; ctx->bx_ms[k] = 0; } ctx->bx_launches = 0; }
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_bx_counters(mia_hip_ctx* ctx, uint32_t* out32) {
+  if (!ctx || !out32) return MIA_HIP_ERR_ARG;
+  for (int k = 0; k < BXC_COUNTERS; k++) out32[k] = ctx->bx_last[k];
   return MIA_HIP_OK;
 }
 
@@ -510,7 +595,11 @@ static int align_all(mia_hip_ctx* ctx) {
   HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 2) * 4, ctx->stream));
   int32_t* d_retry_count = ctx->d_bins + 3 * N_BINS + 1;
   const int tb = 256, gb = (int)((n + (int64_t)tb * PLAN_PER - 1) / ((int64_t)tb * PLAN_PER));
-  const int filtered = ctx->flat && ctx->use_filter && ctx->ref_mostly_bases;
+  const int filter_ok = ctx->flat && ctx->use_filter && ctx->ref_mostly_bases;
+  // the band pipeline for any matrix (bandx_kernels.h); it needs the 10-mer table and windows free of N
+  const bool bx = ctx->bx_ok && ctx->use_bx && ctx->ref_mostly_bases && wrap <= (1 << 22) && !(ctx->dbg & 128u);
+  const bool run_filter = filter_ok && (!bx || ctx->bx_filter_first);
+  const int filtered = run_filter || bx;            // bin_of carries marks for the planner
   uint32_t h_filter_n = 0;
   bool banded = false;
   if (filtered) {
@@ -524,32 +613,110 @@ static int align_all(mia_hip_ctx* ctx) {
     hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
                        ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
     HIPCHK(hipMemsetAsync(ctx->d_filter_n, 0, 16, ctx->stream));
-    // the 10-mer table of this reference (rule (c) looks long clean stretches up instead of sliding over every diagonal);
-    // not for the very long concatenated strings mia_hip_align_windows may be given
+    // the 10-mer table of this reference (rule (c) looks long clean stretches up instead of sliding over every diagonal;
+    // the band plans are made of its anchors); not for the very long concatenated strings mia_hip_align_windows may be given
     KmerOcc ko{nullptr, nullptr};
-    if (wrap <= (1 << 22)) {
+    if (wrap <= (1 << 22) && (run_filter || !bx)) {
       if (!ctx->d_kocc_cnt && (dev_alloc(ctx, &ctx->d_kocc_cnt, (size_t)DF_KTAB) || dev_alloc(ctx, &ctx->d_kocc_pos, (size_t)DF_KTAB * DF_KCAP)))
         return MIA_HIP_ERR_NOMEM;
       HIPCHK(hipMemsetAsync(ctx->d_kocc_cnt, 0, (size_t)DF_KTAB * 4, ctx->stream));
       hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_kocc_cnt, ctx->d_kocc_pos);
       ko.cnt = ctx->d_kocc_cnt; ko.pos = ctx->d_kocc_pos;
     }
-    hipEvent_t f0, f1;
-    if (get_events(ctx, &f0, &f1)) return MIA_HIP_ERR_NOMEM;
-    ctx->ev_filter.push_back(ctx->ev_used.back());
-    ctx->ev_used.pop_back();
-    (void)hipEventRecord(f0, ctx->stream);
-    // what the filter leaves over goes through the banded DP first (band_body.h); it needs the table
-    banded = ctx->use_banddp && ko.cnt && !(ctx->dbg & 128u);
-    if (banded && n > ctx->left_cap) {
-      if (dev_alloc(ctx, &ctx->d_left_list, (size_t)n)) return MIA_HIP_ERR_NOMEM;
-      ctx->left_cap = n;
+    // what the filter leaves over goes through a banded DP first (bandx_kernels.h, or round 1's band_body.h); both need the table
+    banded = bx || (ctx->use_banddp && ko.cnt && !(ctx->dbg & 128u));
+    if (run_filter) {
+      hipEvent_t f0, f1;
+      if (get_events(ctx, &f0, &f1)) return MIA_HIP_ERR_NOMEM;
+      ctx->ev_filter.push_back(ctx->ev_used.back());
+      ctx->ev_used.pop_back();
+      (void)hipEventRecord(f0, ctx->stream);
+      if (banded && n > ctx->left_cap) {
+        if (dev_alloc(ctx, &ctx->d_left_list, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+        ctx->left_cap = n;
+      }
+      hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_bin_of, ctx->dbg,
+                         banded ? ctx->d_left_list : nullptr, ctx->d_filter_n + 1);
+      (void)hipEventRecord(f1, ctx->stream);
+      HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_bin_of, ctx->dbg,
-                       banded ? ctx->d_left_list : nullptr, ctx->d_filter_n + 1);
-    (void)hipEventRecord(f1, ctx->stream);
-    HIPCHK(hipGetLastError());
-    if (banded) {
+    if (bx) {
+      // the reference as 4-bit codes, the lists, one slab per wavefront of the trace kernel's persistent grid
+      const int64_t nw = bx_nib_words((int64_t)wrap + 64);
+      if (nw > ctx->refnib_cap) {
+        if (dev_alloc(ctx, &ctx->d_refnib, (size_t)nw * 2)) return MIA_HIP_ERR_NOMEM;
+        ctx->refnib_cap = nw * 2;
+      }
+      hipLaunchKernelGGL(k_ref_nibbles, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, nw, ctx->d_refnib);
+      const uint32_t kslots = kh_slots_for(wrap);
+      if (kslots > ctx->khash_cap) {
+        if (dev_alloc(ctx, &ctx->d_khash, (size_t)kslots * 4) || dev_alloc(ctx, &ctx->d_khash_ovf, (size_t)kslots * 2)) return MIA_HIP_ERR_NOMEM;
+        ctx->khash_cap = kslots;
+      }
+      HIPCHK(hipMemsetAsync(ctx->d_khash, 0xFF, (size_t)kslots * 16, ctx->stream));
+      const KmerHash kh{ctx->d_khash, ctx->d_khash_ovf, kslots - 1, kh_shift_for(kslots)};
+      hipLaunchKernelGGL(k_kmer_hash, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_khash, ctx->d_khash_ovf,
+                         kh.mask, kh.shift);
+      if (n > ctx->bx_cap) {
+        if (dev_alloc(ctx, &ctx->d_bx_plan, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_expect, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_lists, (size_t)n * 2 * BX_NCLS))
+          return MIA_HIP_ERR_NOMEM;
+        ctx->bx_cap = n;
+      }
+      if (!ctx->bx_values_wgs) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_bx_values, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        ctx->bx_values_wgs = ctx->cus * occ;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_bx_trace, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        ctx->bx_trace_wgs = ctx->cus * occ;
+      }
+      const int64_t slab_words = (int64_t)ctx->max_len * BX_SLAB_ROW_WORDS;
+      if (slab_words * ctx->bx_trace_wgs * 4 > ctx->bx_slab_cap) {
+        if (dev_alloc(ctx, &ctx->d_bx_slabs, (size_t)(slab_words * ctx->bx_trace_wgs * 4))) return MIA_HIP_ERR_NOMEM;
+        ctx->bx_slab_cap = slab_words * ctx->bx_trace_wgs * 4;
+      }
+      HIPCHK(hipMemsetAsync(ctx->d_bx_ctr, 0, BXC_WORDS * 4, ctx->stream));
+      BxDev bd;
+      bd.tab.sub = ctx->d_bx_sub; bd.tab.mrow = ctx->d_bx_mrow; bd.tab.loss = ctx->d_bx_loss; bd.tab.dl = ctx->d_bx_dl;
+      bd.tab.min_m = ctx->bx_min_m; bd.tab.max_m = ctx->bx_max_m;
+      bd.sub256 = ctx->d_bx_sub + BX_SUB_WORDS;
+      bd.refnib = ctx->d_refnib;
+      bd.umax = (ctx->umax_valid && ctx->rs.roff == ctx->d_roff) ? ctx->d_umax : nullptr;    // (a borrowed read set has none)
+      bd.rplanes = bd.umax ? ctx->d_rplanes : nullptr;
+      bd.rplane_words = ctx->rplane_words;
+      bd.plan = ctx->d_bx_plan; bd.expect = ctx->d_bx_expect; bd.lists = ctx->d_bx_lists; bd.list_stride = ctx->bx_cap; bd.ctr = ctx->d_bx_ctr;
+      hipEvent_t e0[3], e1[3];
+      for (int k = 0; k < 3; k++) {
+        if (get_events(ctx, &e0[k], &e1[k])) return MIA_HIP_ERR_NOMEM;
+        ctx->ev_bx[k].push_back(ctx->ev_used.back());
+        ctx->ev_used.pop_back();
+      }
+      (void)hipEventRecord(e0[0], ctx->stream);
+      {
+        const int32_t* in_list = run_filter ? ctx->d_left_list : nullptr;
+        const dim3 pg((unsigned)((n + 255) / 256)), pb(256);
+        switch ((ctx->max_len + 63) >> 6) {       // 64-row words of the longest read
+          case 1: hipLaunchKernelGGL(k_bx_plan<1>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
+          case 2: hipLaunchKernelGGL(k_bx_plan<2>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
+          case 3: hipLaunchKernelGGL(k_bx_plan<3>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
+          default: hipLaunchKernelGGL(k_bx_plan<4>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
+        }
+      }
+      (void)hipEventRecord(e1[0], ctx->stream);
+      HIPCHK(hipGetLastError());
+      if (!(ctx->dbg & 256u)) {
+        (void)hipEventRecord(e0[1], ctx->stream);
+        hipLaunchKernelGGL(k_bx_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
+        (void)hipEventRecord(e1[1], ctx->stream);
+        (void)hipEventRecord(e0[2], ctx->stream);
+        hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
+        (void)hipEventRecord(e1[2], ctx->stream);
+        HIPCHK(hipGetLastError());
+      } else {
+        (void)hipEventRecord(e0[1], ctx->stream); (void)hipEventRecord(e1[1], ctx->stream);
+        (void)hipEventRecord(e0[2], ctx->stream); (void)hipEventRecord(e1[2], ctx->stream);
+      }
+      ctx->bx_launches++;
+    } else if (banded) {
       // a persistent grid of wavefronts, each with its own trace slab (the number of left-over reads stays on the device)
       const int64_t chunks = (n + 63) / 64;
       const int grid = (int)(chunks < 3072 ? chunks : 3072);          // three wavefronts per SIMD
@@ -579,9 +746,15 @@ static int align_all(mia_hip_ctx* ctx) {
   int32_t *h_count = hb, *h_off = hb + N_BINS, *h_count2 = hb + 2 * N_BINS, *h_off2 = hb + 3 * N_BINS, *h_misc = hb + 4 * N_BINS;
   h_misc[0] = 0;
   h_misc[6] = 0;
+  std::vector<uint32_t> bxc_pageable;
+  uint32_t* h_bxc;                                  // all counters of the band pipeline (8 KB), read once the stream is waited for anyway
+  if (ctx->h_pin) h_bxc = reinterpret_cast<uint32_t*>(ctx->h_pin + (24 << 10));
+  else { bxc_pageable.resize(BXC_WORDS); h_bxc = bxc_pageable.data(); }
+  for (int k = 0; k < BXC_COUNTERS; k++) h_bxc[k * BXC_STRIDE] = 0;
   if (filtered) {
     HIPCHK(hipMemcpyAsync(&h_misc[0], ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(&h_misc[6], ctx->d_filter_n + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (bx) HIPCHK(hipMemcpyAsync(h_bxc, ctx->d_bx_ctr, BXC_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
   }
   HIPCHK(hipMemcpyAsync(h_count, d_count, (size_t)N_BINS * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -589,6 +762,10 @@ static int align_all(mia_hip_ctx* ctx) {
   ctx->filter_proven += h_filter_n;
   ctx->band_done += (uint32_t)h_misc[6];
   ctx->filter_seen += n;
+  ctx->filter_proven += h_bxc[BXC_DONE_PLAN * BXC_STRIDE];          // finished without any DP: by the diagonal filter or by the band plan
+  for (int k = 0; k < 3; k++) ctx->bx_done[k] += h_bxc[(BXC_DONE_PLAN + k) * BXC_STRIDE];
+  ctx->bx_seen += h_bxc[BXC_SEEN * BXC_STRIDE];
+  for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = h_bxc[k * BXC_STRIDE];
   int run = 0;
   for (int b = 0; b < N_BINS; b++) {
     h_off[b] = run;
@@ -1514,17 +1691,19 @@ struct AlignBorrow {
   mia_hip_ctx* c;
   ReadSet rs; int32_t *bin_of, *list, *wide, *retry; int max_len; uint8_t* d_ref; int L, wrap, explicit_win, use_filter;
   bool aligned, culled, tallied, pre_cull_valid, ref_mostly_bases;
-  int64_t plain_total, plain_retried, filter_seen, filter_proven;
+  int64_t plain_total, plain_retried, filter_seen, filter_proven, bx_seen, bx_done0, bx_done1, bx_done2;
   explicit AlignBorrow(mia_hip_ctx* ctx)
       : c(ctx), rs(ctx->rs), bin_of(ctx->d_bin_of), list(ctx->d_list), wide(ctx->d_wide_list), retry(ctx->d_retry_list), max_len(ctx->max_len),
         d_ref(ctx->d_ref), L(ctx->L), wrap(ctx->wrap), explicit_win(ctx->explicit_win), use_filter(ctx->use_filter), aligned(ctx->aligned),
         culled(ctx->culled), tallied(ctx->tallied), pre_cull_valid(ctx->pre_cull_valid), ref_mostly_bases(ctx->ref_mostly_bases),
-        plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven) {}
+        plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven),
+        bx_seen(ctx->bx_seen), bx_done0(ctx->bx_done[0]), bx_done1(ctx->bx_done[1]), bx_done2(ctx->bx_done[2]) {}
   ~AlignBorrow() {
     c->rs = rs; c->d_bin_of = bin_of; c->d_list = list; c->d_wide_list = wide; c->d_retry_list = retry; c->max_len = max_len; c->d_ref = d_ref;
     c->L = L; c->wrap = wrap; c->explicit_win = explicit_win; c->use_filter = use_filter; c->aligned = aligned; c->culled = culled;
     c->tallied = tallied; c->pre_cull_valid = pre_cull_valid; c->ref_mostly_bases = ref_mostly_bases; c->plain_total = plain_total;
     c->plain_retried = plain_retried; c->filter_seen = filter_seen; c->filter_proven = filter_proven;
+    c->bx_seen = bx_seen; c->bx_done[0] = bx_done0; c->bx_done[1] = bx_done1; c->bx_done[2] = bx_done2;
   }
 };
 

@@ -342,10 +342,18 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
   uint8_t* pb = (uint8_t*)packed.data();
   for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
   RefPlanes rp{lo.data(), hi.data(), ok.data()};
-  const KmerOcc ko = g_tab_a.build(ref_codes, n_codes);
-  std::vector<int32_t> sub(BX_SUB_WORDS, 0), sub256(BX_SUB_WORDS, 0), mrow(2 * 31 * 4), delta(2 * 31);
-  BxTab T{sub.data(), mrow.data(), delta.data(), 0, 0, 0};
-  if (!bx_make_tables(fwd, rc, sub.data(), mrow.data(), delta.data(), &T.ev_block, &T.min_m, &T.max_m)) return 0;
+  const uint32_t kslots = kh_slots_for(n_codes);
+  std::vector<uint32_t> kslot((size_t)kslots * 4, KH_EMPTY);
+  std::vector<int32_t> kovf((size_t)kslots * 2, 0);
+  const KmerHash ko{kslot.data(), kovf.data(), kslots - 1, kh_shift_for(kslots)};
+  for (int64_t p = 0; p < n_codes; p++) {
+    const int64_t idx = kmer_at(ref_codes, n_codes, p);
+    if (idx >= 0) kh_insert_host(kslot.data(), kovf.data(), kslots - 1, ko.shift, (uint32_t)idx, (int32_t)p);
+  }
+  std::vector<int32_t> sub(BX_SUB_WORDS, 0), sub256(BX_SUB_WORDS, 0), mrow(2 * 31 * 4);
+  std::vector<int16_t> loss(BX_LOSS_WORDS), dl(BX_DL_WORDS);
+  BxTab T{sub.data(), mrow.data(), loss.data(), dl.data(), 0, 0};
+  if (!bx_make_tables(fwd, rc, sub.data(), mrow.data(), loss.data(), dl.data(), &T.min_m, &T.max_m)) return 0;
   for (int k = 0; k < BX_SUB_WORDS; k++) sub256[(size_t)k] = sub[(size_t)k] * 256;
   std::vector<uint32_t> nib((size_t)bx_nib_words(n_codes), 0x44444444u);
   for (int64_t p = 0; p < n_codes; p++) {
@@ -353,7 +361,7 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
     nib[(size_t)(q >> 3)] = (nib[(size_t)(q >> 3)] & ~(0xFu << (4 * (q & 7)))) | ((uint32_t)(ref_codes[p] > 4 ? 4 : ref_codes[p]) << (4 * (q & 7)));
   }
   BxPlan bp;
-  bx_plan(rp, ko, ref_codes, n_codes, ref_start, len1, pb, len2, strand, T, &bp);
+  bx_plan(rp, ko, n_codes, ref_start, len1, pb, len2, strand, T, &bp);
   out6[5] = 0;
   if (bp.mode == BX_NONE) return 0;
   plan5[0] = bp.d0; plan5[1] = bp.w; plan5[2] = bp.dstar; plan5[3] = bp.b0; plan5[4] = bp.edge;
