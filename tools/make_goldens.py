@@ -257,6 +257,53 @@ def maln_cases(mt311_path):
     shutil.rmtree(tmp)
 
 
+def g2_sets():
+    """2 000 seeded reads against mt311 -- whole runs, no k-mer filter, iterated to convergence.  The
+    read files are regenerated from the seed where they are needed (gen_data), only their hash is committed."""
+    return {
+        "g2_flat": dict(seed=21, damage=False, args=["-c", "-i"]),
+        "g2_anc": dict(seed=22, damage=True, args=["-c", "-i", "-s", "ancient.submat.txt"]),
+        "g2_pe": dict(seed=23, damage=True, args=["-c", "-i", "-s", "ancient.submat.solexa.pe.txt"]),
+    }
+
+
+def g2_reads(name, out_path):
+    kw = g2_sets()[name]
+    _, _, mt = gen_data.read_fasta_one(os.path.join(G, "mt311.fa"))
+    d = gen_data.make_reads(gen_data.resolve_individual(mt), 2000, 100, kw["seed"], circular=True, damage=kw["damage"])
+    gen_data.write_fasta_reads(out_path, d["reads"])
+    import hashlib
+    return hashlib.sha256(open(out_path, "rb").read()).hexdigest()
+
+
+def g2_cases():
+    """The reference's own mia on the G2 sets (two minutes of CPU each: pass 1 is the whole-reference DP).  Every .maln of
+    a run is pinned by the sha256 of its text from line 2 on; the SEQ line of each iteration's reference is kept readable."""
+    import hashlib
+    shutil.copy(os.path.join(REF, "matrices", "ancient.submat.solexa.pe.txt"), os.path.join(G, "ancient.submat.solexa.pe.txt"))
+    tmp = tempfile.mkdtemp()
+    out = {}
+    procs = {}
+    for name, kw in g2_sets().items():
+        fa = os.path.join(tmp, name + ".fa")
+        out[name] = {"reads_sha256": g2_reads(name, fa), "args": kw["args"], "maln_sha256": [], "ref_seq": []}
+        procs[name] = subprocess.Popen([os.path.join(RB, "mia"), "-r", "mt311.fa", "-f", fa] + kw["args"] + ["-m", os.path.join(tmp, name)], cwd=G,
+                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for name, pr in procs.items():
+        assert pr.wait() == 0, name
+        it = 1
+        while os.path.exists(os.path.join(tmp, f"{name}.{it}")):
+            with open(os.path.join(tmp, f"{name}.{it}")) as f:
+                body = f.readlines()[1:]
+            out[name]["maln_sha256"].append(hashlib.sha256("".join(body).encode()).hexdigest())
+            out[name]["ref_seq"].append(hashlib.sha256(next(l for l in body if l.startswith("SEQ ")).encode()).hexdigest()[:16])
+            it += 1
+        print(f"{name}: {it - 1} iteration file(s)")
+    with open(os.path.join(G, "g2_runs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp)
+
+
 NEAND_ADAPT = "GTCAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG"     # src/mia_main.c:462-463 (data, quoted for the inputs)
 STAND_ADAPT = "CTGAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG"
 
@@ -475,6 +522,10 @@ def main():
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
         ccheck_cases(os.path.join(G, "mt311.fa"))
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g2":          # only the 2 000-read whole runs
+        sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
+        g2_cases()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "ma":          # only the ma reports (the .maln files stay as they are)
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
         ma_cases()
@@ -489,6 +540,7 @@ def main():
     cons_vectors()
     myers_vectors(mt)
     maln_cases(os.path.join(G, "mt311.fa"))
+    g2_cases()
     ma_cases()
     trim_vectors()
     ccheck_cases(os.path.join(G, "mt311.fa"))
