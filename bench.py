@@ -5,18 +5,22 @@ One "step" = one MIA iteration over all stored reads (reference
 src/mia_main.c:931-963): reiterate_assembly + pop_smp_from_FSDB +
 cull_maln_from_fsdb + consensus_assembly_string, inputs resident in HBM.
 
-Workload (BASELINE.json configs[1]): 1 M synthetic 100 bp reads (1 % subs, 0.1 %
-indels, both strands) against the 16 619 bp mt311 reference, circular, flat
-matrix.  Pass-1 coordinates are the generator's true positions (the pass-1
-kernel is a later row of SURVEY.md section 8); each iteration re-aligns every read in its
-+-50 window exactly as the reference does.
+Headline (`value`): BASELINE.json configs[1] -- 1 M synthetic 100 bp reads (1 % subs, 0.1 % indels, both strands)
+against the 16 619 bp mt311 reference, circular, flat matrix.  Pass-1 coordinates are the generator's true positions
+(pass 1 is reported separately under "pass1"); every iteration re-aligns every read in its +-50 window exactly as the
+reference does.  At N = 1 the same JSON line also carries
+  "configs2"  configs[2]: 1 M aDNA-damaged reads, matrices/ancient.submat.txt, iterated from mt311 itself to convergence
+  "configs4"  configs[4]'s shape on one GPU: 150 bp reads against a 100 kb linear reference, ancient matrix
+  "peaks"     the two ceilings measured on this device: streaming-copy GB/s and int32 VALU wave-instructions/s
+  "myers"     the bit-vector edit distance (reference src/myers_align.c) on a batch of pairs
+  "cpu_baseline"  the reference's own loop (oracle/_ref/ref_iter_driver) on the host cores, flat and ancient matrix
 
-N > 1 (one process per GPU, launched by torch.distributed.run): reads are
-sharded in contiguous fsdb blocks; per iteration the int32 column tallies are
-all-reduced (sum) and the gap lengths (max) over RCCL, insert events are
-all-gathered.  Weak scaling: --reads is PER GPU.
+N > 1 (one process per GPU, launched by torch.distributed.run): reads are sharded in contiguous fsdb blocks; per
+iteration the int32 column tallies are all-reduced (sum) and the gap lengths (max), insert events are all-gathered.
+--scaling weak (default): --reads is PER GPU.  --scaling strong: --reads is the whole job, split over the ranks.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -31,22 +35,42 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-BYTES_PER_READ = 182      # 50 B packed bases + 16 B meta in, 16 B result + 100 B script out
-HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# Memory-side bytes per read and VALU utilisation of the three realignment kernels, measured with rocprofv3 --pmc in
-# separate passes for FETCH_SIZE, WRITE_SIZE and the SQ set (profiles/r01/pmc/v14_summary.json, v17_summary.json for the
-# filter; counters as reported, no
-# width correction; utilisation = SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE/8 / 4)):
-#   k_align_quad        661 749 KB + 1 279 506 KB per launch of 95.4 k reads: the 16-bit trace band written to the
-#                       per-workgroup slabs and read back along the path
-#   k_align_quad_plain  111 680 KB + 252 604 KB per 1 M reads: no trace, about twice the algorithmic 182 B/read
-#   k_diag_filter       77 281 KB + 204 036 KB per 1 M reads: packed reads and 10-mer table look-ups in, results and scripts out
-PMC = {
-    "k_align_quad": {"traffic_per_read": (661749.34 + 1279506.11) * 1024 / 95_407, "valu_utilisation": 0.79},
-    "k_align_quad_plain": {"traffic_per_read": (111680.25 + 252603.66) * 1024 / 1_000_000, "valu_utilisation": 0.90},
-    "k_diag_filter": {"traffic_per_read": (77280.98 + 204036.09) * 1024 / 1_000_000, "valu_utilisation": 0.69},
-    "k_band_align": {"traffic_per_read": (541971.03 + 637559.77) * 1024 / 176_751, "valu_utilisation": 0.46},
-}
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s nominal (about 6.3 TB/s achievable)
+# SURVEY.md section 8(d), algorithmic HBM bytes per read per iteration: ceil(len/2) packed bases + 16 B meta in,
+# 16 B result + len bytes of edit script out -> 182 B at 100 bp, 257 B at 150 bp
+def bytes_per_read(read_len):
+    return (read_len + 1) // 2 + 16 + 16 + read_len
+
+
+PMC_DIR = os.path.join(ROOT, "profiles", "r02", "pmc")
+CSRC = os.path.join(ROOT, "mapping-iterative-assembler_amd", "csrc")
+STAGES = ["k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_trace", "k_align_quad_plain", "k_align_quad", "k_tally_binned"]
+
+
+def source_hash():
+    """what the kernels were built from: the PMC summaries name the build they were collected on"""
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(tag):
+    """profiles/r02/pmc/<tag>.json, written by tools/pmc_summary.py from the three rocprofv3 --pmc passes of
+    `bench.py --pmc-run <tag>`.  Returns (per-kernel counters, stale?) -- counters of another build are not replayed:
+    the caller then reports traffic and VALU fractions as null.  A summary that lacks a kernel this run timed is an error."""
+    path = os.path.join(PMC_DIR, tag + ".json")
+    if not os.path.exists(path):
+        return None, True
+    with open(path) as f:
+        d = json.load(f)
+    return d, d.get("_meta", {}).get("source_hash") != source_hash()
+
+
+def pmc_usable(pmc, stale, reads_per_gpu):
+    return pmc is not None and not stale and pmc.get("_meta", {}).get("reads_per_gpu") == reads_per_gpu
 
 
 class DevArray:
@@ -56,52 +80,291 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def make_workload(n_reads, seed, read_len=100):
+# ---- workloads (SURVEY.md section 8(d) recipe; tools/gen_data.py) -------------------------------------------------
+def make_workload(cfg, n_reads, seed):
     import gen_data
-    _, _, mt = gen_data.read_fasta_one(os.path.join(ROOT, "tests", "golden", "mt311.fa"))
-    ref = mt.upper()                                    # make_ref_upper (src/mia.c:642-648)
-    indiv = gen_data.resolve_individual(mt)
-    d = gen_data.make_reads(indiv, n_reads, read_len, seed, circular=True, damage=False)
-    stored = gen_data.stored_orientation(d)
-    as_ = d["start"].astype(np.int32)
-    ae = (as_ + read_len - 1).astype(np.int32)
-    offsets = (np.arange(n_reads + 1, dtype=np.int64) * read_len)
-    return ref, stored, offsets, d["strand"].astype(np.uint8), as_, ae
+    import mia_amd
+    w = {"cfg": cfg, "n": n_reads}
+    if cfg == 4:
+        w["read_len"], w["circular"] = 150, False
+        indiv = gen_data.random_reference(100_000, seed=5)
+        w["ref"] = indiv
+        w["ref_name"] = "100 kb synthetic region (seed 5), linear"
+    else:
+        w["read_len"], w["circular"] = 100, True
+        _, _, mt = gen_data.read_fasta_one(os.path.join(GOLDEN, "mt311.fa"))
+        w["ref"] = mt.upper()                              # make_ref_upper (src/mia.c:642-648)
+        indiv = gen_data.resolve_individual(mt)
+        w["ref_name"] = "mt311 (16619 bp, circular)"
+    w["plain_ref"] = indiv
+    w["matrix_file"] = {1: None, 2: "ancient.submat.txt", 3: "ancient.submat.solexa.pe.txt", 4: "ancient.submat.txt"}[cfg]
+    w["pssm"] = mia_amd.flat_pssm() if w["matrix_file"] is None else mia_amd.read_pssm(os.path.join(GOLDEN, w["matrix_file"]))
+    L = w["read_len"]
+    d = gen_data.make_reads(indiv, n_reads, L, seed, circular=w["circular"], damage=cfg != 1)
+    w["stored"] = gen_data.stored_orientation(d)
+    w["rc"] = d["strand"].astype(np.uint8)
+    w["as_"] = d["start"].astype(np.int32)
+    w["ae"] = (w["as_"] + L - 1).astype(np.int32)
+    w["offsets"] = np.arange(n_reads + 1, dtype=np.int64) * L
+    w["lens"] = np.full(n_reads, L, np.int32)
+    w["bytes_per_read"] = bytes_per_read(L)
+    return w
 
 
-def cpu_baseline(ref, stored, rc, as_, ae, sample_per_proc=3000, iters=2):
-    """The reference's own per-iteration path (oracle/_ref/ref_iter_driver, built from
-    /root/reference by oracle/Makefile.ref) on the host cores, P independent processes."""
+def cpu_baseline(w, sample_per_proc=3000, iters=2):
+    """The reference's own per-iteration path (oracle/_ref/ref_iter_driver, built from /root/reference by
+    oracle/Makefile.ref) on the host cores, P independent processes on disjoint samples of the same workload."""
+    import gen_data
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_iter_driver")
+    if not os.path.exists(drv):
+        return {"value": None, "unit": "reads/s per iteration", "cores": 0, "kind": "reference", "sample": "oracle/_ref/ref_iter_driver missing"}
     P = max(1, min(os.cpu_count() or 1, 32))
-    n = stored.shape[0]
+    n = w["n"]
     P = max(1, min(P, n // 500))
     S = min(sample_per_proc, n // P)
     tmp = tempfile.mkdtemp()
-    import gen_data
-    gen_data.write_fasta(os.path.join(tmp, "ref.fa"), "mt311", ref)
-    if os.path.exists(drv):
-        procs = []
-        for p in range(P):
-            path = os.path.join(tmp, f"reads{p}.txt")
-            with open(path, "w") as f:
-                for i in range(p * S, (p + 1) * S):
-                    f.write(f"{int(rc[i])} {int(as_[i])} {int(ae[i])} {stored[i].tobytes().decode()}\n")
-            procs.append(subprocess.Popen([drv, os.path.join(tmp, "ref.fa"), path, "1", "flat", str(iters)],
-                                          stdout=subprocess.PIPE))
-        secs = []
-        for pr in procs:
-            out = pr.communicate()[0].decode().split()
-            secs.append(float(out[out.index("seconds") + 1]))
-        rate = P * S * iters / max(secs)
-        return {"value": rate, "unit": "reads/s per iteration", "cores": P, "kind": "reference",
-                "sample": f"{P} processes x {S} reads x {iters} iterations of oracle/_ref/ref_iter_driver "
-                          f"(reference reiterate_assembly+pop_smp+cull+consensus), slowest process {max(secs):.2f} s"}
-    # the reference binary did not travel: fall back to timing the oracle port
-    import ctypes as C
-    import oracle_ctypes as oc
-    subprocess.run(["make", "-s", "-f", "oracle/Makefile"], cwd=ROOT, check=True)
-    return {"value": None, "unit": "reads/s per iteration", "cores": 0, "kind": "port", "sample": "oracle/_ref missing"}
+    gen_data.write_fasta(os.path.join(tmp, "ref.fa"), "ref", w["ref"])
+    matrix = os.path.join(GOLDEN, w["matrix_file"]) if w["matrix_file"] else "flat"
+    procs = []
+    for p in range(P):
+        path = os.path.join(tmp, f"reads{p}.txt")
+        with open(path, "w") as f:
+            for i in range(p * S, (p + 1) * S):
+                f.write(f"{int(w['rc'][i])} {int(w['as_'][i])} {int(w['ae'][i])} {w['stored'][i].tobytes().decode()}\n")
+        procs.append(subprocess.Popen([drv, os.path.join(tmp, "ref.fa"), path, "1" if w["circular"] else "0", matrix, str(iters)], stdout=subprocess.PIPE))
+    secs = []
+    for pr in procs:
+        out = pr.communicate()[0].decode().split()
+        secs.append(float(out[out.index("seconds") + 1]))
+    return {"value": P * S * iters / max(secs), "unit": "reads/s per iteration", "cores": P, "kind": "reference",
+            "sample": f"{P} processes x {S} reads x {iters} iterations of oracle/_ref/ref_iter_driver (reference reiterate_assembly+"
+                      f"pop_smp+cull+consensus, matrix {w['matrix_file'] or 'flat'}), slowest process {max(secs):.2f} s"}
+
+
+# ---- one iteration ------------------------------------------------------------------------------------------------
+class Pipeline:
+    def __init__(self, hip, w, world=1, rank=0, force_dist=False, breakdown=False):
+        self.hip, self.w, self.world, self.rank = hip, w, world, rank
+        self.sharded = world > 1 or force_dist
+        self.phase = {} if breakdown else None
+        hip.set_pssm(w["pssm"])
+        hip.upload_reads(w["stored"].reshape(-1), w["offsets"], w["rc"], np.ones(w["n"], np.uint8), w["as_"], w["ae"])
+        if world > 1:
+            hip.set_read_base(w["read_base"])       # contiguous fsdb blocks: global index of this rank's first read
+
+    def _tick(self, name, t0):
+        if self.phase is not None:
+            self.hip.sync()
+            self.phase[name] = self.phase.get(name, 0.0) + (time.perf_counter() - t0)
+        return time.perf_counter()
+
+    def step(self, cur_ref):
+        hip, w = self.hip, self.w
+        t0 = time.perf_counter()
+        hip.realign(cur_ref, w["circular"])
+        t0 = self._tick("realign", t0)
+        slot_base = 0
+        # find_fsdb_score_cut: pass 1 (integer sums, length range) on the device; with equally long reads that is the
+        # whole regression.  Only reads of different lengths need the sequential double sums over the scores on the host.
+        sums = hip.score_sums()
+        if self.sharded:
+            import torch
+            from mia_amd import dist as mdist
+            n_rec, n_lnk = hip.pre_cull_counts()           # by-products of score_sums: no further round trip
+            sums, slot_base, link_counts = mdist.gather_pre_cull(sums, n_rec, "cuda", n_lnk)
+        t0 = self._tick("score_sums", t0)
+        cut = hip.score_cut_from_sums(sums)
+        if cut is None:
+            score = hip.scores()
+            if self.sharded:
+                # the regression runs over ALL reads in fsdb order (src/fsdb.c:269-383): scores and lengths in rank order
+                all_scores = mdist.all_gather_concat(torch.from_numpy(score).cuda()).cpu().numpy()
+                all_lens = mdist.all_gather_concat(torch.from_numpy(w["lens"]).cuda()).cpu().numpy()
+                cut = hip.score_cut(all_scores, all_lens)
+            else:
+                cut = hip.score_cut(score, w["lens"])
+        slope, intercept = cut
+        t0 = self._tick("score_cut", t0)
+        if slope <= 0:
+            slope = 100.0
+        hip.cull(0, slope, intercept, slot_base)
+        if self.sharded:
+            mdist.exchange_links(hip, lambda ptr, n, ts: torch.as_tensor(DevArray(ptr, n, ts), device="cuda"), link_counts)
+        t0 = self._tick("cull", t0)
+        hip.tally()
+        t0 = self._tick("tally", t0)
+        if self.sharded:
+            pt, nt, pg, ng = hip.tally_buffers()
+            pe, ne = hip.ins_events()
+            counts = mdist.allreduce_tallies_with_counts(torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda"),
+                                                         torch.as_tensor(DevArray(pg, ng, "<i4"), device="cuda"), ne)
+            mine = torch.as_tensor(DevArray(pe, ne, "<i8"), device="cuda") if ne else torch.zeros(0, dtype=torch.int64, device="cuda")
+            allev = mdist.all_gather_ragged(mine, counts)
+            torch.cuda.synchronize()
+            hip.set_ins_events(allev.data_ptr() if allev.numel() else 0, int(allev.numel()))
+        c = hip.consensus(1)
+        self._tick("consensus", t0)
+        return c
+
+    def reset_stats(self):
+        h = self.hip
+        h.stage_stats(reset=True)
+        h.plain_stats(reset=True)
+        h.filter_stats(reset=True)
+        h.band_stats(reset=True)
+        h.bx_stats(reset=True)
+
+    def stages(self, steps, peaks, pmc, pmc_stale):
+        """Per kernel of the realignment and the tally: HIP-event time over the steps just run, the reads it worked on,
+        algorithmic GB/s against the HBM roof, cells actually evaluated, and -- from the PMC summary of THIS build, if
+        there is one -- memory-side traffic and VALU issue against the measured issue peak."""
+        h, w = self.hip, self.w
+        st = h.stage_stats()
+        (seen, by_plan, by_values, by_trace), _, bx_launches = h.bx_stats()
+        f_seen, f_done, _, f_launches = h.filter_stats()
+        band_done, _, _ = h.band_stats()
+        _, _, plain_in, plain_retried = h.plain_stats()
+        ctr = h.bx_counters()                      # of the last realign: list lengths by band class
+        widths = (8, 16, 24, 32)
+        n, L2 = w["n"], w["read_len"]
+        win = L2 + 100                             # +-50 window (src/mia_main.c:190-212)
+        per_launch = {
+            "k_diag_filter": (n if f_launches else 0, None),
+            "k_band_align": ((f_seen - f_done) / max(st["k_band_align"][1], 1), 32 * L2),
+            "k_bx_plan": (seen / max(bx_launches, 1), None),
+            "k_bx_values": (sum(ctr[0:4]), sum(c * wd for c, wd in zip(ctr[0:4], widths)) * L2),
+            "k_bx_trace": (sum(ctr[4:8]), sum(c * wd for c, wd in zip(ctr[4:8], widths)) * L2),
+            "k_align_quad_plain": (plain_in / max(st["k_align_quad_plain"][1], 1), win * L2),
+            "k_tally_binned": (n, None),
+        }
+        left = f_seen - f_done - band_done - by_values - by_trace if (f_launches or bx_launches) else n * steps
+        per_launch["k_align_quad"] = ((plain_retried if st["k_align_quad_plain"][1] else left) / max(st["k_align_quad"][1], 1), win * L2)
+        out = []
+        for name in STAGES:
+            ms, k = st[name]
+            if k <= 0 or ms <= 0:
+                continue
+            reads, cells = per_launch[name]
+            if cells is not None and name in ("k_band_align", "k_align_quad_plain", "k_align_quad"):
+                cells = cells * reads              # per read -> per launch
+            k_ms = ms / k
+            ach = w["bytes_per_read"] * reads / (k_ms * 1e-3) / 1e9
+            s = {"kernel": name, "kernel_ms": k_ms, "ms_per_step": ms / steps, "launches": k, "reads_per_launch": reads,
+                 "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                 "gcups": cells / (k_ms * 1e-3) / 1e9 if cells else None, "traffic": None, "valu_frac": None}
+            if pmc_usable(pmc, pmc_stale, n):
+                if name not in pmc or not all(k in pmc[name] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")):
+                    raise RuntimeError(f"PMC summary has no entry for {name}: re-run tools/pmc_collect.sh for this build")
+                c = pmc[name]
+                # MI355X_MICROARCH.md, HBM: FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE counts 128-byte read
+                # requests as 64 bytes for wide streaming reads -> doubled (calibrated on k_peak_copy in the same passes,
+                # see _meta.fetch_calibration); per launch, like `achieved`
+                s["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+                if peaks and peaks.get("valu_ginst_s"):
+                    s["valu_insts"] = c["SQ_INSTS_VALU"]
+                    s["valu_frac"] = c["SQ_INSTS_VALU"] / (k_ms * 1e-3) / (peaks["valu_ginst_s"] * 1e9)
+            out.append(s)
+        return out, {"reads_seen": seen or f_seen, "finished_by_plan_or_filter": f_done, "finished_by_values_dp": by_values,
+                     "finished_by_trace_dp": by_trace + band_done, "to_full_window_kernels": max(left, 0)}
+
+
+def roofline(stages, peaks, pmc_tag, pmc_stale):
+    dom = max(stages, key=lambda s: s["ms_per_step"])
+    r = {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+         "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "launches": dom["launches"], "reads_per_launch": dom["reads_per_launch"],
+         "primary_bound": "valu",
+         "valu": {"bound": "valu", "achieved": (dom["valu_insts"] / (dom["kernel_ms"] * 1e-3) / 1e9) if dom.get("valu_insts") else None,
+                  "peak": peaks.get("valu_ginst_s") if peaks else None, "unit": "1e9 wave64 instructions/s", "frac": dom["valu_frac"]},
+         "peak_measured_copy": peaks.get("hbm_copy_gbs") if peaks else None,
+         "frac_of_measured_copy": dom["achieved"] / peaks["hbm_copy_gbs"] if peaks and peaks.get("hbm_copy_gbs") else None,
+         "pmc": {"summary": f"profiles/r02/pmc/{pmc_tag}.json", "from_this_build": not pmc_stale},
+         "stages": stages,
+         "note": "integer DP: the kernels are bound by VALU issue, not HBM -- `frac` prices the SURVEY 8(d) algorithmic bytes of the "
+                 "kernel with the most time per step against the nominal 8 TB/s as the contract asks; `valu.frac` = its VALU "
+                 "instructions (rocprofv3 SQ_INSTS_VALU of this build) over its live HIP-event time, against the issue rate "
+                 "measured by k_peak_valu in this run; traffic/valu are null when the committed PMC summary is from another build"}
+    return r
+
+
+def run_steps(pipe, cur, steps):
+    for _ in range(steps):
+        cur = pipe.step(cur)
+    pipe.hip.sync()
+    return cur
+
+
+def section_converge(hip_mod, device, cfg, n, seed, peaks, no_cpu, max_iters=12):
+    """configs[2] / configs[4]: from the starting reference to convergence, every iteration timed on its own (the first
+    one runs against the reference itself -- mt311 carries an ambiguity code in every tenth column --, the later ones
+    against consensus sequences); then the converged state is stepped a few times for the stage table."""
+    w = make_workload(cfg, n, seed)
+    hip = hip_mod.MiaHip(device)
+    pipe = Pipeline(hip, w)
+    cur, it_ms, rounds = w["ref"], [], 0
+    while rounds < max_iters:
+        hip.sync()
+        t0 = time.perf_counter()
+        nxt = pipe.step(cur)
+        hip.sync()
+        it_ms.append((time.perf_counter() - t0) * 1e3)
+        rounds += 1
+        if nxt == cur:                              # src/mia_main.c:905-940: stop when the consensus repeats
+            break
+        cur = nxt
+    converged = nxt == cur
+    K = 6
+    pipe.reset_stats()
+    hip.sync()
+    t0 = time.perf_counter()
+    cur = run_steps(pipe, cur, K)
+    steady_ms = (time.perf_counter() - t0) * 1e3 / K
+    tag = f"cfg{cfg}"
+    pmc, stale = load_pmc(tag)
+    stages, counts = pipe.stages(K, peaks, pmc, stale)
+    out = {"workload": f"configs[{cfg}]: {n} synthetic {w['read_len']} bp aDNA-damaged reads vs {w['ref_name']}, matrix {w['matrix_file']}; "
+                       "pass-1 coordinates = true positions",
+           "iterations_to_convergence": rounds, "converged": converged, "ms_per_iteration": it_ms,
+           "reads_per_s_per_iteration": n * rounds / (sum(it_ms) * 1e-3),
+           "steady_state_ms_per_iteration": steady_ms, "steady_state_reads_per_s": n / (steady_ms * 1e-3),
+           "bytes_per_read": w["bytes_per_read"], "consensus_len": len(cur), "read_fate": counts,
+           "roofline": roofline(stages, peaks, tag, stale)}
+    if not no_cpu:
+        out["cpu_baseline"] = cpu_baseline(w, sample_per_proc=3000 if cfg != 4 else 1500)
+    hip.close()
+    return out
+
+
+def section_myers(hip):
+    """myers_diff (reference src/myers_align.c:10-99) as a batch: 10 000 pairs of 100-300 characters with ~3 % edits, and
+    the ccheck-sized pair (16.6 kb, maxd = len/10 as src/ccheck.cc:477)."""
+    rng = np.random.default_rng(7)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    A, B = [], []
+    for _ in range(10_000):
+        n = int(rng.integers(100, 301))
+        a = bases[rng.integers(0, 4, n)].copy()
+        b = a.copy()
+        for p in rng.integers(0, n, max(1, n // 33)):
+            b[p] = bases[rng.integers(0, 4)]
+        A.append(a.tobytes())
+        B.append(b.tobytes())
+    mode = np.zeros(len(A), np.int32)
+    maxd = np.full(len(A), 64, np.int32)
+    hip.myers(A[:64], B[:64], mode[:64], maxd[:64])
+    t0 = time.perf_counter()
+    d = hip.myers(A, B, mode, maxd)
+    dt = time.perf_counter() - t0
+    cells = sum(len(a) * len(b) for a, b in zip(A, B))
+    big = bases[rng.integers(0, 4, 16_600)].copy()
+    big2 = big.copy()
+    for p in rng.integers(0, len(big), 160):
+        big2[p] = bases[rng.integers(0, 4)]
+    t1 = time.perf_counter()
+    dbig = hip.myers([big.tobytes()], [big2.tobytes()], np.zeros(1, np.int32), np.full(1, 1660, np.int32))
+    dt_big = time.perf_counter() - t1
+    return {"pairs": len(A), "pairs_per_s": len(A) / dt, "gcups": cells / dt / 1e9, "mean_distance": float(d[d != 0xFFFFFFFF].mean()),
+            "pair_16k6_ms": dt_big * 1e3, "pair_16k6_distance": int(dbig[0]),
+            "note": "wall time of mia_hip_myers including packing and PCIe; one pair per wavefront, 64-bit lanes"}
 
 
 def main():
@@ -109,8 +372,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (weak) or in the whole job (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4), help="BASELINE.json configs[k] for the timed steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="the headline line only (no configs2/configs4/pass1/myers sections)")
+    ap.add_argument("--pmc-run", default=None, help="reduced run under rocprofv3 --pmc: only the timed steps of this config, plus k_peak_copy for the FETCH_SIZE calibration")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,165 +397,95 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import mia_amd
 
-    n = a.reads
-    ref, stored, offsets, rc, as_, ae = make_workload(n, seed=1 + rank)
-    lens = (offsets[1:] - offsets[:-1]).astype(np.int32)
+    if a.pmc_run:
+        a.no_cpu_baseline = a.no_extras = True
+    n = a.reads if a.scaling == "weak" else (a.reads // world + (1 if rank < a.reads % world else 0))
+    w = make_workload(a.config, n, seed=1 + rank)
+    if a.scaling == "strong":
+        w["read_base"] = rank * (a.reads // world) + min(rank, a.reads % world)
+    else:
+        w["read_base"] = rank * n
     hip = mia_amd.MiaHip(local)
-    hip.set_pssm(mia_amd.flat_pssm())
-    hip.upload_reads(stored.reshape(-1), offsets, rc, np.ones(n, np.uint8), as_, ae)
-    if world > 1:
-        hip.set_read_base(rank * n)          # contiguous fsdb blocks: global index of this rank's first read
+    peaks = None
+    if rank == 0 and world == 1 and not a.pmc_run:
+        gbs, ginst = hip.measure_peaks(1 << 30)
+        peaks = {"hbm_copy_gbs": gbs, "valu_ginst_s": ginst,
+                 "note": "k_peak_copy: 1 GiB streamed in and out, best of 5; k_peak_valu: v_max3_i32/v_add_u32 chains, 8 waves per SIMD, "
+                         "wave64 instructions per second over the whole chip (csrc/mia_peak_kernels.h)"}
+    pipe = Pipeline(hip, w, world, rank, force_dist, breakdown=bool(os.environ.get("MIA_BENCH_BREAKDOWN")))
 
-    phase = {}
-
-    def tick(name, t0):
-        if os.environ.get("MIA_BENCH_BREAKDOWN"):
-            hip.sync()
-            phase[name] = phase.get(name, 0.0) + (time.perf_counter() - t0)
-        return time.perf_counter()
-
-    def step(cur_ref):
-        t0 = time.perf_counter()
-        hip.realign(cur_ref, True)
-        t0 = tick("realign", t0)
-        slot_base = 0
-        sharded = world > 1 or force_dist
-        # find_fsdb_score_cut: pass 1 (integer sums, length range) on the device; with equally long reads that is the
-        # whole regression.  Only reads of different lengths need the sequential double sums over the scores on the host.
-        sums = hip.score_sums()
-        if sharded:
-            from mia_amd import dist as mdist
-            n_rec, n_lnk = hip.pre_cull_counts()           # by-products of score_sums: no further round trip
-            sums, slot_base, link_counts = mdist.gather_pre_cull(sums, n_rec, "cuda", n_lnk)
-        t0 = tick("score_sums", t0)
-        cut = hip.score_cut_from_sums(sums)
-        if cut is None:
-            score = hip.scores()
-            if sharded:
-                # the regression runs over ALL reads in fsdb order (src/fsdb.c:269-383)
-                all_scores = mdist.all_gather_concat(torch.from_numpy(score).cuda()).cpu().numpy()
-                cut = hip.score_cut(all_scores, np.tile(lens, world))
-            else:
-                cut = hip.score_cut(score, lens)
-        slope, intercept = cut
-        t0 = tick("score_cut", t0)
-        if slope <= 0:
-            slope = 100.0
-        hip.cull(0, slope, intercept, slot_base)
-        if sharded:
-            mdist.exchange_links(hip, lambda ptr, n, ts: torch.as_tensor(DevArray(ptr, n, ts), device="cuda"), link_counts)
-        t0 = tick("cull", t0)
-        hip.tally()
-        t0 = tick("tally", t0)
-        if sharded:
-            from mia_amd import dist as mdist
-            pt, nt, pg, ng = hip.tally_buffers()
-            pe, ne = hip.ins_events()
-            counts = mdist.allreduce_tallies_with_counts(torch.as_tensor(DevArray(pt, nt, "<i4"), device="cuda"),
-                                                         torch.as_tensor(DevArray(pg, ng, "<i4"), device="cuda"), ne)
-            mine = torch.as_tensor(DevArray(pe, ne, "<i8"), device="cuda") if ne else torch.zeros(0, dtype=torch.int64, device="cuda")
-            allev = mdist.all_gather_ragged(mine, counts)
-            torch.cuda.synchronize()
-            hip.set_ins_events(allev.data_ptr() if allev.numel() else 0, int(allev.numel()))
-        c = hip.consensus(1)
-        tick("consensus", t0)
-        return c
-
-    cur = ref
+    cur = w["ref"]
     for _ in range(a.warmup):
-        cur = step(cur)
-    hip.kernel_time(reset=True)
-    hip.plain_stats(reset=True)
-    hip.filter_stats(reset=True)
-    hip.band_stats(reset=True)
+        cur = pipe.step(cur)
+    pipe.reset_stats()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        cur = step(cur)
+        cur = pipe.step(cur)
     hip.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    align_ms, launches = hip.kernel_time(reset=True)
-    plain_ms, plain_launches, plain_in, plain_retried = hip.plain_stats(reset=True)
-    filt_seen, filt_done, filt_ms, filt_launches = hip.filter_stats(reset=True)
-    band_done, band_ms, band_launches = hip.band_stats(reset=True)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        tot = torch.tensor([n], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_reads = int(tot.item())
+    else:
+        total_reads = n
 
     if rank == 0:
-        total_reads = n * world
-        value = total_reads * a.steps / dt
-        # Four kernels share the realignment: the diagonal filter (k_diag_filter, bit-parallel, finishes the reads whose
-        # alignment is provably one gap-free diagonal), the banded DP (k_band_align: exact band from ten-mer anchors, one read
-        # per thread) over what it leaves, and for the reads without a usable band the values-only DP (k_align_quad_plain)
-        # and the trace kernel k_align_quad.  The roofline object describes whichever takes the most time per step; all are
-        # listed under "stages".  MIA_HIP_NO_DIAG_FILTER=1 / MIA_HIP_NO_BAND_DP=1 / MIA_HIP_NO_PLAIN=1 switch the first three off.
-        stages = []
-
-        def stage(name, ms_total, k_launches, reads_total):
-            if k_launches <= 0 or ms_total <= 0:
-                return
-            k_ms, rpl = ms_total / k_launches, reads_total / k_launches
-            ach = BYTES_PER_READ * rpl / (k_ms * 1e-3) / 1e9
-            stages.append({"kernel": name, "kernel_ms": k_ms, "ms_per_step": ms_total / a.steps, "launches": k_launches,
-                           "reads_per_launch": rpl, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-                           "traffic": PMC[name]["traffic_per_read"] * rpl if PMC[name]["traffic_per_read"] else None, "valu_utilisation": PMC[name]["valu_utilisation"],
-                           "gcups": rpl * 100 * 200 / (k_ms * 1e-3) / 1e9 if name != "k_diag_filter" else None})
-
-        plain_on = plain_launches > 0
-        stage("k_diag_filter", filt_ms, filt_launches, filt_seen)
-        stage("k_band_align", band_ms, band_launches, filt_seen - filt_done)
-        stage("k_align_quad_plain", plain_ms, plain_launches, plain_in)
-        to_trace = plain_retried if plain_on else (filt_seen - filt_done - band_done if filt_launches else n * a.steps)
-        stage("k_align_quad", align_ms, launches, to_trace)
-        dom = max(stages, key=lambda st: st["ms_per_step"])
+        tag = f"cfg{a.config}"
+        pmc, stale = load_pmc(tag)
+        stages, counts = pipe.stages(a.steps, peaks, pmc, stale)
         out = {
             "metric": "reads aligned/sec per iteration (16.5kb mito ref, 100bp reads)",
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": total_reads * a.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": a.scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic 100 bp reads per GPU vs mt311 (16619 bp, circular), flat matrix; "
-                                   "step = reiterate_assembly + cull + consensus; pass-1 coordinates = true positions" % n,
-                       "reads_per_gpu": n, "consensus_len": len(cur)},
-            "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
-                         "traffic": dom["traffic"], "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "launches": dom["launches"],
-                         "valu_utilisation": dom["valu_utilisation"],
-                         "stages": stages,
-                         "reads_finished_by_filter_frac": filt_done / filt_seen if filt_seen else 0.0,
-                         "reads_finished_by_banded_dp_frac": band_done / filt_seen if filt_seen else 0.0,
-                         "reads_to_trace_kernel_frac": to_trace / (n * a.steps),
-                         "note": "the DP kernels are integer-VALU bound (SQ_ACTIVE_INST_VALU 46-90 % of SIMD capacity, profiles/r01/pmc): "
-                                 "182 algorithmic HBM bytes per read (SURVEY 8d) put them at a fraction of a percent of the HBM roof "
-                                 "by construction; the banded DP moves 6.8 KB/read (its 32-byte-per-row trace), the full-window trace "
-                                 "kernel ~21 KB/read; see DESIGN.md 3.0-3.1"},
+            "config": {"workload": "configs[%d]: %d synthetic %d bp reads %s vs %s, matrix %s; step = reiterate_assembly + pop_smp + cull + "
+                                   "consensus; pass-1 coordinates = true positions"
+                                   % (a.config, a.reads, w["read_len"], "per GPU" if a.scaling == "weak" else "in total, split over the GPUs",
+                                      w["ref_name"], w["matrix_file"] or "flat"),
+                       "reads_per_gpu": n, "total_reads": total_reads, "consensus_len": len(cur), "bytes_per_read": w["bytes_per_read"]},
+            "roofline": roofline(stages, peaks, tag, stale),
+            "read_fate": counts,
         }
-        if world == 1:      # single-GPU line only: the other ranks of a sharded run would sit waiting
+        if peaks:
+            out["peaks"] = peaks
+        if pipe.phase:
+            out["phase_ms_per_step"] = {k: v / (a.steps + a.warmup) * 1e3 for k, v in pipe.phase.items()}
+        if world == 1 and not a.no_extras:      # single-GPU line only: the other ranks of a sharded run would sit waiting
             # pass 1 (new_kmer_filter + sg_align over the whole wrapped reference, both strands), reported separately
             import gen_data
             m = min(n, 200_000)
+            stored, rc, offsets = w["stored"], w["rc"], w["offsets"]
             seq = np.where(rc[:m, None] == 1, gen_data._COMP[stored[:m, ::-1]], stored[:m]).astype(np.uint8)   # as sequenced
             p1 = {}
-            # mt311 itself carries an ambiguity code in every other column (N for the aligner); "plain_ref" is the same
+            # mt311 itself carries an ambiguity code in every tenth column (N for the aligner); "plain_ref" is the same
             # sequence with those resolved, the usual kind of reference, where the diagonal filter decides most reads
-            plain_ref = gen_data.resolve_individual(ref)
-            for label, k, r1 in (("k12", 12, ref), ("no_kmer", -1, ref), ("no_kmer_plain_ref", -1, plain_ref)):
-                hip.pass1(r1, True, seq[:256].reshape(-1), offsets[:257], k)          # warm-up
+            for label, k, r1 in (("k12", 12, w["ref"]), ("no_kmer", -1, w["ref"]), ("no_kmer_plain_ref", -1, w["plain_ref"])):
+                hip.pass1(r1, w["circular"], seq[:256].reshape(-1), offsets[:257], k)          # warm-up
                 t1 = time.perf_counter()
-                sc, _, _, _, fl = hip.pass1(r1, True, seq.reshape(-1), offsets[: m + 1], k)
+                sc, _, _, _, fl = hip.pass1(r1, w["circular"], seq.reshape(-1), offsets[: m + 1], k)
                 p1[label] = {"reads_per_s": m / (time.perf_counter() - t1), "kernel_reads_per_s": m / (hip.pass1_time() * 1e-3),
                              "reads": m, "kept": int((fl & 2).astype(bool).sum()), "decided_by_diag_filter": hip.pass1_filtered(),
                              "decided_by_anchored_windows": hip.pass1_anchored()}
             out["pass1"] = p1
-        if phase:
-            out["phase_ms_per_step"] = {k: v / (a.steps + a.warmup) * 1e3 for k, v in phase.items()}
+            out["myers"] = section_myers(hip)
+        if a.pmc_run:
+            hip.measure_peaks(1 << 28)           # k_peak_copy in the counter passes: the FETCH_SIZE calibration
         if not a.no_cpu_baseline and world == 1:      # the CPU comparator is timed beside the single-GPU line only
-            out["cpu_baseline"] = cpu_baseline(ref, stored, rc, as_, ae)
+            out["cpu_baseline"] = cpu_baseline(w)
+        hip.close()
+        if world == 1 and not a.no_extras and a.config == 1:
+            out["configs2"] = section_converge(mia_amd, local, 2, 1_000_000, 3, peaks, a.no_cpu_baseline)
+            out["configs4"] = section_converge(mia_amd, local, 4, 500_000, 5, peaks, a.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

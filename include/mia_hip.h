@@ -186,6 +186,11 @@ int mia_hip_tally_buffers(mia_hip_ctx *ctx, int32_t **d_tally, int64_t *n_tally_
 int mia_hip_ins_events(mia_hip_ctx *ctx, uint64_t **d_events, int64_t *n_events);
 int mia_hip_set_ins_events(mia_hip_ctx *ctx, const uint64_t *d_events, int64_t n_events);
 int mia_hip_get_tally(mia_hip_ctx *ctx, int32_t *tally, int32_t *gaps); /* host copies, (L+1)*12 and L+1 words */
+/* The reverse: BaseCounts of every column handed in by the caller (same layout: tally[word][L+1], word = As, Cs, Gs, Ts,
+ * gaps, cov, scoreA, scoreC, scoreG, scoreT, span, pad; gaps[L+1] = ref->gaps or NULL for none), no insert events --
+ * e.g. tallies reduced outside the library, or find_consensus (src/map_align.c:294-391) on its own.  mia_hip_consensus
+ * may follow. */
+int mia_hip_set_tally(mia_hip_ctx *ctx, int32_t ref_len, const int32_t *tally, const int32_t *gaps);
 
 /* char* consensus_assembly_string(MapAlignmentP) -- src/mia.h:74, src/mia.c:515-603.
  * Calls find_consensus / find_ins_cons per column on the (all-reduced) tallies.
@@ -282,6 +287,14 @@ int mia_hip_bx_stats(mia_hip_ctx *ctx, int reset, int64_t *reads4, double *kerne
  * planned on, [17..23] reads not planned, by reason (N in the read, window, too few anchored blocks, anchors too far
  * apart, written-down path outside the window, loss over the pigeonhole budget, band wider than 32). */
 int mia_hip_bx_counters(mia_hip_ctx *ctx, uint32_t *out32);
+/* Every timed stage at once: names[k] (static strings: k_align_quad, k_align_quad_plain, k_diag_filter, k_band_align,
+ * k_bx_plan, k_bx_values, k_bx_trace, k_tally_binned, k_pass1), accumulated milliseconds and launches since the last
+ * reset; *n_stages = how many there are, at most cap are written.  Any pointer may be NULL. */
+int mia_hip_stage_stats(mia_hip_ctx *ctx, int reset, int32_t cap, const char **names, double *ms, int64_t *launches, int32_t *n_stages);
+/* The two ceilings the roofline is priced against, measured on this device: a streaming copy of
+ * copy_bytes (read + written bytes per second, GB/s) and the issue rate of the DP kernels' own instruction mix
+ * (v_max3_i32 / v_add_u32 chains, 10^9 wave64 instructions per second over the whole chip).  Either may be NULL. */
+int mia_hip_measure_peaks(mia_hip_ctx *ctx, int64_t copy_bytes, double *hbm_copy_gbs, double *valu_ginst_s);
 /* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
 int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 /* reads of the last mia_hip_pass1 call decided by the diagonal filter (csrc/diag_filter.h: flat matrix, no k-mer mask)

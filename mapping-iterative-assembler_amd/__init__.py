@@ -53,6 +53,7 @@ def _load():
     lib.mia_hip_ins_events.argtypes = [vp, P(vp), P(C.c_int64)]
     lib.mia_hip_set_ins_events.argtypes = [vp, vp, C.c_int64]
     lib.mia_hip_get_tally.argtypes = [vp, vp, vp]
+    lib.mia_hip_set_tally.argtypes = [vp, C.c_int32, vp, vp]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     lib.mia_hip_pre_cull_counts.argtypes = [vp, vp, vp]
@@ -79,6 +80,8 @@ def _load():
     lib.mia_hip_trim_stats.argtypes = [vp, P(C.c_int64)]
     lib.mia_hip_get_ins_tally.argtypes = [vp, vp, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
+    lib.mia_hip_stage_stats.argtypes = [vp, C.c_int, C.c_int32, vp, vp, vp, P(C.c_int32)]
+    lib.mia_hip_measure_peaks.argtypes = [vp, C.c_int64, P(C.c_double), P(C.c_double)]
     return lib
 
 
@@ -101,7 +104,7 @@ def exported_symbols():
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
-            "mia_hip_score_cut_from_sums"]
+            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally"]
 
 
 def _ptr(a):
@@ -299,6 +302,14 @@ class MiaHip:
         self._chk(self._l.mia_hip_get_tally(self._h, _ptr(t), _ptr(g)))
         return t, g
 
+    def set_tally(self, tally, gaps=None):
+        """BaseCounts of every column from the caller: tally[12][L+1] (word-major, see include/mia_hip.h), gaps[L+1] or None"""
+        t = np.ascontiguousarray(tally, dtype=np.int32)
+        assert t.ndim == 2 and t.shape[0] == TALLY_WORDS
+        self.L = t.shape[1] - 1
+        g = None if gaps is None else np.ascontiguousarray(gaps, dtype=np.int32)
+        self._chk(self._l.mia_hip_set_tally(self._h, self.L, _ptr(t), _ptr(g)))
+
     def consensus(self, cons_code=1):
         cap = self.L * 2 + 1024 * 1024
         buf = C.create_string_buffer(cap)
@@ -378,6 +389,22 @@ class MiaHip:
         ms, k = C.c_double(), C.c_int64()
         self._chk(self._l.mia_hip_kernel_time(self._h, 1 if reset else 0, C.byref(ms), C.byref(k)))
         return ms.value, k.value
+
+    def stage_stats(self, reset=False):
+        """{stage name: (milliseconds, launches)} of every timed kernel since the last reset (HIP events on the context's stream)"""
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        k = (C.c_int64 * cap)()
+        n = C.c_int32(0)
+        self._chk(self._l.mia_hip_stage_stats(self._h, 1 if reset else 0, cap, names, ms, k, C.byref(n)))
+        return {names[i].decode(): (ms[i], k[i]) for i in range(min(n.value, cap))}
+
+    def measure_peaks(self, copy_bytes=1 << 30):
+        """(HBM copy GB/s, 10^9 wave64 VALU instructions/s) measured on this device"""
+        a, b = C.c_double(0), C.c_double(0)
+        self._chk(self._l.mia_hip_measure_peaks(self._h, copy_bytes, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def ma_tally(self, ref_len, gaps, start, revcom, col_off, seq, smp, ins_record=(), ins_pos=(), ins_off=(0,), ins_bases=b""):
         """show_consensus / find_ins_cons tallies over stored AlnSeq records (reference src/map_alignment.c:107-170)."""

@@ -17,8 +17,14 @@
 #include "mia_pass1_kernels.h"
 #include "mia_myers_kernels.h"
 #include "mia_trim_kernels.h"
+#include "mia_peak_kernels.h"
 
 using namespace mia;
+
+// timed stages (HIP events on the context's stream around the kernel launches of that kind)
+enum Stage { STG_TRACE = 0, STG_PLAIN, STG_FILTER, STG_BAND, STG_BX_PLAN, STG_BX_VALUES, STG_BX_TRACE, STG_TALLY, STG_PASS1, STG_COUNT };
+static const char* const STAGE_NAMES[STG_COUNT] = {"k_align_quad", "k_align_quad_plain", "k_diag_filter", "k_band_align", "k_bx_plan",
+                                                   "k_bx_values", "k_bx_trace", "k_tally_binned", "k_pass1"};
 
 struct mia_hip_ctx {
   int device = 0;
@@ -72,8 +78,9 @@ struct mia_hip_ctx {
   unsigned char* d_quad_slabs = nullptr;
   int quad_wgs = 0;
   int use_quad = 1;   // MIA_HIP_NO_QUAD=1 routes everything through the one-read-per-wave kernels
+  int plain_behind_band = 0;
   int use_plain = 1;  // MIA_HIP_NO_PLAIN=1: no values-only first pass, every quad goes straight to the trace kernel
-  double plain_ms = 0; int64_t plain_launches = 0; int64_t plain_retried = 0, plain_total = 0;
+  int64_t plain_retried = 0, plain_total = 0;
   // the diagonal filter (diag_filter.h): flat matrix only
   bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
   bool ref_mostly_bases = true;            // fewer than 2 % of the reference columns are N
@@ -85,7 +92,7 @@ struct mia_hip_ctx {
   int use_banddp = 1;                       // MIA_HIP_NO_BAND_DP=1: the filter's left-overs go straight to the full-window kernels
   int32_t* d_left_list = nullptr; int64_t left_cap = 0;
   uint32_t* d_band_slabs = nullptr; int64_t band_slab_cap = 0;
-  int64_t band_done = 0; double band_ms = 0; int64_t band_launches = 0;
+  int64_t band_done = 0;
   // the matrix-agnostic band pipeline (bandx_kernels.h): plan -> values-only DP -> trace DP, for any PSSM
   bool bx_ok = false;                       // the matrices allow it (bx_make_tables)
   int use_bx = 1;                           // MIA_HIP_NO_BANDX=1: the round-1 path (flat: filter + k_band_align; PSSM: full-window kernels)
@@ -101,9 +108,8 @@ struct mia_hip_ctx {
   uint32_t* d_bx_slabs = nullptr; int64_t bx_slab_cap = 0;
   int bx_values_wgs = 0, bx_trace_wgs = 0;
   int64_t bx_seen = 0, bx_done[3] = {0, 0, 0};   // reads planned on; finished by the plan / the values DP / the trace DP
-  double bx_ms[3] = {0, 0, 0}; int64_t bx_launches = 0;
+  int64_t bx_launches = 0;
   uint32_t bx_last[BXC_COUNTERS] = {0};     // counters of the last call (list lengths, reasons a read was not planned)
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_bx[3];
   int grid_wgs = 0;
   int window_wgs[N_CPL] = {0, 0, 0};
   int cus = 1;
@@ -115,11 +121,12 @@ struct mia_hip_ctx {
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free, ev_plain, ev_filter, ev_band;
-  double filter_ms = 0; int64_t filter_launches = 0;
+  // HIP-event timers of the kernels bench.py reports, one per stage (mia_hip_stage_stats); pairs are recycled through ev_free
+  struct StageTimer { std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; double ms = 0; int64_t launches = 0; };
+  StageTimer stg[STG_COUNT];
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
   // pinned staging: small copies to and from pageable memory wait for the stream, pinned ones do not
   unsigned char* h_pin = nullptr; static constexpr size_t PIN_BYTES = 1 << 20, PIN_MISC = 64 << 10;
-  double align_ms = 0; int64_t align_launches = 0;
   double pass1_ms = 0; int64_t pass1_filtered = 0, pass1_anchored = 0;   // reads of the last pass-1 call that the diagonal filter decided
   bool consensus_done = false;
   int64_t trim_escapes = 0;   // reads of the last mia_hip_trim call that took the exact scalar path
@@ -178,6 +185,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nband && atoi(nband)) ctx->use_band = 0;
     const char* npl = getenv("MIA_HIP_NO_PLAIN");
     if (npl && atoi(npl)) ctx->use_plain = 0;
+    const char* pbb = getenv("MIA_HIP_PLAIN_BEHIND_BAND");
+    if (pbb && atoi(pbb)) ctx->plain_behind_band = 1;
     const char* nf = getenv("MIA_HIP_NO_DIAG_FILTER");
     if (nf && atoi(nf)) { ctx->use_filter = 0; ctx->use_bx = 0; }      // every shortcut off: the full-window DP kernels only
     const char* nbd = getenv("MIA_HIP_NO_BAND_DP");
@@ -225,12 +234,8 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-  for (auto& e : ctx->ev_used) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  for (auto& e : ctx->ev_plain) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  for (auto& e : ctx->ev_filter) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  for (auto& e : ctx->ev_band) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  for (auto& v : ctx->ev_bx) for (auto& e : v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& t : ctx->stg) for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -404,7 +409,8 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   return MIA_HIP_OK;
 }
 
-static int get_events(mia_hip_ctx* ctx, hipEvent_t* a, hipEvent_t* b) {
+// an event pair for one launch of stage `st`; the start event is recorded here, the end event by stage_end
+static int stage_begin(mia_hip_ctx* ctx, Stage st) {
   if (ctx->ev_free.empty()) {
     hipEvent_t x, y;
     if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return -1;
@@ -412,65 +418,47 @@ static int get_events(mia_hip_ctx* ctx, hipEvent_t* a, hipEvent_t* b) {
   }
   auto p = ctx->ev_free.back();
   ctx->ev_free.pop_back();
-  ctx->ev_used.push_back(p);
-  *a = p.first; *b = p.second;
+  ctx->stg[st].pending.push_back(p);
+  (void)hipEventRecord(p.first, ctx->stream);
   return 0;
 }
+static void stage_end(mia_hip_ctx* ctx, Stage st) { (void)hipEventRecord(ctx->stg[st].pending.back().second, ctx->stream); }
 
 static void drain_events(mia_hip_ctx* ctx) {
-  for (auto& e : ctx->ev_used) {
-    float ms = 0;
-    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
-      ctx->align_ms += ms;
-      ctx->align_launches++;
-    }
-    ctx->ev_free.push_back(e);
-  }
-  ctx->ev_used.clear();
-  for (auto& e : ctx->ev_plain) {
-    float ms = 0;
-    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
-      ctx->plain_ms += ms;
-      ctx->plain_launches++;
-    }
-    ctx->ev_free.push_back(e);
-  }
-  ctx->ev_plain.clear();
-  for (auto& e : ctx->ev_filter) {
-    float ms = 0;
-    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
-      ctx->filter_ms += ms;
-      ctx->filter_launches++;
-    }
-    ctx->ev_free.push_back(e);
-  }
-  ctx->ev_filter.clear();
-  for (auto& e : ctx->ev_band) {
-    float ms = 0;
-    if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
-      ctx->band_ms += ms;
-      ctx->band_launches++;
-    }
-    ctx->ev_free.push_back(e);
-  }
-  ctx->ev_band.clear();
-  for (int k = 0; k < 3; k++) {
-    for (auto& e : ctx->ev_bx[k]) {
+  for (auto& t : ctx->stg) {
+    for (auto& e : t.pending) {
       float ms = 0;
-      if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) ctx->bx_ms[k] += ms;
+      if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+        t.ms += ms;
+        t.launches++;
+      }
       ctx->ev_free.push_back(e);
     }
-    ctx->ev_bx[k].clear();
+    t.pending.clear();
   }
+}
+
+extern "C" int mia_hip_stage_stats(mia_hip_ctx* ctx, int reset, int32_t cap, const char** names, double* ms, int64_t* launches, int32_t* n_stages) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  drain_events(ctx);
+  if (n_stages) *n_stages = STG_COUNT;
+  for (int k = 0; k < STG_COUNT && k < cap; k++) {
+    if (names) names[k] = STAGE_NAMES[k];
+    if (ms) ms[k] = ctx->stg[k].ms;
+    if (launches) launches[k] = ctx->stg[k].launches;
+  }
+  if (reset) for (auto& t : ctx->stg) { t.ms = 0; t.launches = 0; }
+  return MIA_HIP_OK;
 }
 
 extern "C" int mia_hip_kernel_time(mia_hip_ctx* ctx, int reset, double* align_ms, int64_t* launches) {
   if (!ctx) return MIA_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   drain_events(ctx);
-  if (align_ms) *align_ms = ctx->align_ms;
-  if (launches) *launches = ctx->align_launches;
-  if (reset) { ctx->align_ms = 0; ctx->align_launches = 0; }
+  if (align_ms) *align_ms = ctx->stg[STG_TRACE].ms;
+  if (launches) *launches = ctx->stg[STG_TRACE].launches;
+  if (reset) { ctx->stg[STG_TRACE].ms = 0; ctx->stg[STG_TRACE].launches = 0; }
   return MIA_HIP_OK;
 }
 
@@ -480,9 +468,9 @@ extern "C" int mia_hip_filter_stats(mia_hip_ctx* ctx, int reset, int64_t* reads_
   drain_events(ctx);
   if (reads_seen) *reads_seen = ctx->filter_seen;
   if (reads_finished) *reads_finished = ctx->filter_proven;
-  if (kernel_ms) *kernel_ms = ctx->filter_ms;
-  if (launches) *launches = ctx->filter_launches;
-  if (reset) { ctx->filter_seen = 0; ctx->filter_proven = 0; ctx->filter_ms = 0; ctx->filter_launches = 0; }
+  if (kernel_ms) *kernel_ms = ctx->stg[STG_FILTER].ms;
+  if (launches) *launches = ctx->stg[STG_FILTER].launches;
+  if (reset) { ctx->filter_seen = 0; ctx->filter_proven = 0; ctx->stg[STG_FILTER].ms = 0; ctx->stg[STG_FILTER].launches = 0; }
   return MIA_HIP_OK;
 }
 
@@ -491,9 +479,9 @@ extern "C" int mia_hip_band_stats(mia_hip_ctx* ctx, int reset, int64_t* reads_fi
   HIPCHK(hipSetDevice(ctx->device));
   drain_events(ctx);
   if (reads_finished) *reads_finished = ctx->band_done;
-  if (kernel_ms) *kernel_ms = ctx->band_ms;
-  if (launches) *launches = ctx->band_launches;
-  if (reset) { ctx->band_done = 0; ctx->band_ms = 0; ctx->band_launches = 0; }
+  if (kernel_ms) *kernel_ms = ctx->stg[STG_BAND].ms;
+  if (launches) *launches = ctx->stg[STG_BAND].launches;
+  if (reset) { ctx->band_done = 0; ctx->stg[STG_BAND].ms = 0; ctx->stg[STG_BAND].launches = 0; }
   return MIA_HIP_OK;
 }
 
@@ -502,9 +490,9 @@ extern "C" int mia_hip_bx_stats(mia_hip_ctx* ctx, int reset, int64_t* reads4, do
   HIPCHK(hipSetDevice(ctx->device));
   drain_events(ctx);
   if (reads4) { reads4[0] = ctx->bx_seen; reads4[1] = ctx->bx_done[0]; reads4[2] = ctx->bx_done[1]; reads4[3] = ctx->bx_done[2]; }
-  if (kernel_ms3) for (int k = 0; k < 3; k++) kernel_ms3[k] = ctx->bx_ms[k];
+  if (kernel_ms3) for (int k = 0; k < 3; k++) kernel_ms3[k] = ctx->stg[STG_BX_PLAN + k].ms;
   if (launches) *launches = ctx->bx_launches;
-  if (reset) { ctx->bx_seen = 0; for (int k = 0; k < 3; k++) { ctx->bx_done[k] = 0; ctx->bx_ms[k] = 0; } ctx->bx_launches = 0; }
+  if (reset) { ctx->bx_seen = 0; for (int k = 0; k < 3; k++) { ctx->bx_done[k] = 0; ctx->stg[STG_BX_PLAN + k].ms = 0; ctx->stg[STG_BX_PLAN + k].launches = 0; } ctx->bx_launches = 0; }
   return MIA_HIP_OK;
 }
 
@@ -518,11 +506,11 @@ extern "C" int mia_hip_plain_stats(mia_hip_ctx* ctx, int reset, double* plain_ms
   if (!ctx) return MIA_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   drain_events(ctx);
-  if (plain_ms) *plain_ms = ctx->plain_ms;
-  if (plain_launches) *plain_launches = ctx->plain_launches;
+  if (plain_ms) *plain_ms = ctx->stg[STG_PLAIN].ms;
+  if (plain_launches) *plain_launches = ctx->stg[STG_PLAIN].launches;
   if (reads_in) *reads_in = ctx->plain_total;
   if (reads_retried) *reads_retried = ctx->plain_retried;
-  if (reset) { ctx->plain_ms = 0; ctx->plain_launches = 0; ctx->plain_total = 0; ctx->plain_retried = 0; }
+  if (reset) { ctx->stg[STG_PLAIN].ms = 0; ctx->stg[STG_PLAIN].launches = 0; ctx->plain_total = 0; ctx->plain_retried = 0; }
   return MIA_HIP_OK;
 }
 
@@ -543,13 +531,11 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
   if (!ctx->d_slabs[ci]) {
     if (hipMalloc((void**)&ctx->d_slabs[ci], (size_t)slab * ctx->grid_wgs) != hipSuccess) return hipErrorOutOfMemory;
   }
-  hipEvent_t e0, e1;
-  if (get_events(ctx, &e0, &e1)) return hipErrorOutOfMemory;
   RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
-  (void)hipEventRecord(e0, ctx->stream);
+  if (stage_begin(ctx, STG_TRACE)) return hipErrorOutOfMemory;
   hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
                      count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg);
-  (void)hipEventRecord(e1, ctx->stream);
+  stage_end(ctx, STG_TRACE);
   return hipGetLastError();
 }
 
@@ -626,18 +612,14 @@ static int align_all(mia_hip_ctx* ctx) {
     // what the filter leaves over goes through a banded DP first (bandx_kernels.h, or round 1's band_body.h); both need the table
     banded = bx || (ctx->use_banddp && ko.cnt && !(ctx->dbg & 128u));
     if (run_filter) {
-      hipEvent_t f0, f1;
-      if (get_events(ctx, &f0, &f1)) return MIA_HIP_ERR_NOMEM;
-      ctx->ev_filter.push_back(ctx->ev_used.back());
-      ctx->ev_used.pop_back();
-      (void)hipEventRecord(f0, ctx->stream);
       if (banded && n > ctx->left_cap) {
         if (dev_alloc(ctx, &ctx->d_left_list, (size_t)n)) return MIA_HIP_ERR_NOMEM;
         ctx->left_cap = n;
       }
+      if (stage_begin(ctx, STG_FILTER)) return MIA_HIP_ERR_NOMEM;
       hipLaunchKernelGGL(k_diag_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_bin_of, ctx->dbg,
                          banded ? ctx->d_left_list : nullptr, ctx->d_filter_n + 1);
-      (void)hipEventRecord(f1, ctx->stream);
+      stage_end(ctx, STG_FILTER);
       HIPCHK(hipGetLastError());
     }
     if (bx) {
@@ -684,13 +666,7 @@ static int align_all(mia_hip_ctx* ctx) {
       bd.rplanes = bd.umax ? ctx->d_rplanes : nullptr;
       bd.rplane_words = ctx->rplane_words;
       bd.plan = ctx->d_bx_plan; bd.expect = ctx->d_bx_expect; bd.lists = ctx->d_bx_lists; bd.list_stride = ctx->bx_cap; bd.ctr = ctx->d_bx_ctr;
-      hipEvent_t e0[3], e1[3];
-      for (int k = 0; k < 3; k++) {
-        if (get_events(ctx, &e0[k], &e1[k])) return MIA_HIP_ERR_NOMEM;
-        ctx->ev_bx[k].push_back(ctx->ev_used.back());
-        ctx->ev_used.pop_back();
-      }
-      (void)hipEventRecord(e0[0], ctx->stream);
+      if (stage_begin(ctx, STG_BX_PLAN)) return MIA_HIP_ERR_NOMEM;
       {
         const int32_t* in_list = run_filter ? ctx->d_left_list : nullptr;
         const dim3 pg((unsigned)((n + 255) / 256)), pb(256);
@@ -701,19 +677,16 @@ static int align_all(mia_hip_ctx* ctx) {
           default: hipLaunchKernelGGL(k_bx_plan<4>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
         }
       }
-      (void)hipEventRecord(e1[0], ctx->stream);
+      stage_end(ctx, STG_BX_PLAN);
       HIPCHK(hipGetLastError());
       if (!(ctx->dbg & 256u)) {
-        (void)hipEventRecord(e0[1], ctx->stream);
+        if (stage_begin(ctx, STG_BX_VALUES)) return MIA_HIP_ERR_NOMEM;
         hipLaunchKernelGGL(k_bx_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
-        (void)hipEventRecord(e1[1], ctx->stream);
-        (void)hipEventRecord(e0[2], ctx->stream);
+        stage_end(ctx, STG_BX_VALUES);
+        if (stage_begin(ctx, STG_BX_TRACE)) return MIA_HIP_ERR_NOMEM;
         hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
-        (void)hipEventRecord(e1[2], ctx->stream);
+        stage_end(ctx, STG_BX_TRACE);
         HIPCHK(hipGetLastError());
-      } else {
-        (void)hipEventRecord(e0[1], ctx->stream); (void)hipEventRecord(e1[1], ctx->stream);
-        (void)hipEventRecord(e0[2], ctx->stream); (void)hipEventRecord(e1[2], ctx->stream);
       }
       ctx->bx_launches++;
     } else if (banded) {
@@ -725,19 +698,17 @@ static int align_all(mia_hip_ctx* ctx) {
         if (dev_alloc(ctx, &ctx->d_band_slabs, (size_t)(slab_words * grid))) return MIA_HIP_ERR_NOMEM;
         ctx->band_slab_cap = slab_words * grid;
       }
-      hipEvent_t b0, b1;
-      if (get_events(ctx, &b0, &b1)) return MIA_HIP_ERR_NOMEM;
-      ctx->ev_band.push_back(ctx->ev_used.back());
-      ctx->ev_used.pop_back();
-      (void)hipEventRecord(b0, ctx->stream);
+      if (stage_begin(ctx, STG_BAND)) return MIA_HIP_ERR_NOMEM;
       hipLaunchKernelGGL(k_band_align, dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, rp, ko, (int64_t)wrap, ctx->d_left_list, ctx->d_filter_n + 1,
                          ctx->d_band_slabs, slab_words, ctx->d_bin_of, ctx->d_filter_n + 2, ctx->d_filter_n + 3, ctx->dbg);
-      (void)hipEventRecord(b1, ctx->stream);
+      stage_end(ctx, STG_BAND);
       HIPCHK(hipGetLastError());
     }
   }
   // behind the banded DP the values-only pass has nothing left to prove: what the band could not take nearly always needs a trace
-  const bool use_plain = ctx->use_plain && !banded;
+  // (MIA_HIP_PLAIN_BEHIND_BAND=1: values-only pass over the band pipeline's left-overs all the same -- with a position-specific
+  // matrix most of them are gap-free reads with many substitutions, which it finishes at half the trace kernel's price)
+  const bool use_plain = ctx->use_plain && (!banded || ctx->plain_behind_band);
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   // host copies of the counters live in pinned memory when there is some: a copy to or from pageable memory makes the
   // host wait for the stream even when it is called "async"
@@ -795,14 +766,10 @@ static int align_all(mia_hip_ctx* ctx) {
     if (n_quads > 0) {
     const int grid = n_quads < ctx->quad_wgs ? n_quads : ctx->quad_wgs;
     const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
-    hipEvent_t p0, p1;
-    if (get_events(ctx, &p0, &p1)) return MIA_HIP_ERR_NOMEM;
-    ctx->ev_plain.push_back(ctx->ev_used.back());
-    ctx->ev_used.pop_back();
-    (void)hipEventRecord(p0, ctx->stream);
+    if (stage_begin(ctx, STG_PLAIN)) return MIA_HIP_ERR_NOMEM;
     hipLaunchKernelGGL(k_align_quad_plain, dim3(grid), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_list + quad_begin,
                        n_quads, ctx->d_bin_of);
-    (void)hipEventRecord(p1, ctx->stream);
+    stage_end(ctx, STG_PLAIN);
     HIPCHK(hipGetLastError());
     }
     // re-plan what is left (and what the filter's gap hint kept out of the first pass) into quads of equal read length
@@ -828,14 +795,12 @@ static int align_all(mia_hip_ctx* ctx) {
     const int64_t slab = (int64_t)Q_G * MAX_READ * Q_TRACE_STRIDE;
     const int grid = n_quads < ctx->quad_wgs ? n_quads : ctx->quad_wgs;
     if (!ctx->d_quad_slabs && hipMalloc((void**)&ctx->d_quad_slabs, (size_t)slab * ctx->quad_wgs) != hipSuccess) return MIA_HIP_ERR_NOMEM;
-    hipEvent_t e0, e1;
-    if (get_events(ctx, &e0, &e1)) return MIA_HIP_ERR_NOMEM;
-    (void)hipEventRecord(e0, ctx->stream);
     const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
+    if (stage_begin(ctx, STG_TRACE)) return MIA_HIP_ERR_NOMEM;
     hipLaunchKernelGGL(k_align_quad, dim3(grid), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list + quad_begin,
                        n_quads, ctx->d_quad_slabs, slab, ctx->d_wide_list, d_wide_count, ctx->d_retry_list, d_retry_count, ctx->use_band,
                        ctx->dbg);
-    (void)hipEventRecord(e1, ctx->stream);
+    stage_end(ctx, STG_TRACE);
     HIPCHK(hipGetLastError());
     if (ctx->use_band) {
       // reads whose path left the stored trace band: one-read kernel with the full trace (windows <= 208 fit class 0)
@@ -1065,7 +1030,10 @@ extern "C" int mia_hip_links(mia_hip_ctx* ctx, int64_t** d_links, int64_t* n_lin
   if (!ctx || !ctx->culled) return MIA_HIP_ERR_STATE;
   int32_t nl = 0;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpy(&nl, ctx->lk.n, 4, hipMemcpyDeviceToHost));
+  // on the context's own (non-blocking) stream, behind the k_cull_mark that counts the links; once it has been waited for,
+  // the list itself is complete too and the caller's collective may read it from any stream
+  HIPCHK(hipMemcpyAsync(&nl, ctx->lk.n, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   if (d_links) *d_links = ctx->lk.rec;
   if (n_links) *n_links = nl;
   return MIA_HIP_OK;
@@ -1097,11 +1065,15 @@ extern "C" int mia_hip_set_links(mia_hip_ctx* ctx, const int64_t* d_links_all, i
   hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
                      ctx->read_base, ctx->d_cull_flags);
   HIPCHK(hipGetLastError());
-  return finish_cull(ctx);
+  const int rc_fc = finish_cull(ctx);
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // n32 above is a stack local; the caller's buffer may be a temporary
+  return rc_fc;
 }
 
 extern "C" int mia_hip_link_lengths(mia_hip_ctx* ctx, int32_t** d_len, int32_t** d_act, int64_t* n) {
   if (!ctx || !ctx->links_applied) return MIA_HIP_ERR_STATE;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));   // k_links_apply fills both buffers; the caller reduces them on a stream of its own
   if (d_len) *d_len = ctx->d_link_len;
   if (d_act) *d_act = ctx->d_link_act;
   if (n) *n = ctx->n_links_all;
@@ -1326,8 +1298,10 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
         if (dev_alloc(ctx, &ctx->d_tally_slabs, (size_t)slab_words)) return MIA_HIP_ERR_NOMEM;
         ctx->tally_slab_cap = slab_words;
       }
+      if (stage_begin(ctx, STG_TALLY)) return MIA_HIP_ERR_NOMEM;
       hipLaunchKernelGGL(k_tally_binned, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                          ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg, ctx->tally_linear ? 1 : 0);
+      stage_end(ctx, STG_TALLY);
       hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
@@ -1392,6 +1366,24 @@ extern "C" int mia_hip_get_tally(mia_hip_ctx* ctx, int32_t* tally, int32_t* gaps
   return MIA_HIP_OK;
 }
 
+extern "C" int mia_hip_set_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_t* tally, const int32_t* gaps) {
+  if (!ctx || ref_len <= 0 || !tally) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  ctx->L = ref_len;
+  int rc = ensure_tally(ctx);
+  if (rc) return rc;
+  const int Lp = ctx->tb.Lp;
+  HIPCHK(hipMemcpyAsync(ctx->tb.tally, tally, (size_t)TALLY_WORDS * Lp * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (gaps) HIPCHK(hipMemcpyAsync(ctx->tb.gaps, gaps, (size_t)Lp * 4, hipMemcpyHostToDevice, ctx->stream));
+  else HIPCHK(hipMemsetAsync(ctx->tb.gaps, 0, (size_t)Lp * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->tb.n_events, 0, 4, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_events_host = 0;
+  ctx->tallied = true;
+  ctx->consensus_done = false;
+  return MIA_HIP_OK;
+}
+
 extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int64_t out_cap, int64_t* out_len) {
   if (!ctx || !out) return MIA_HIP_ERR_ARG;
   if (!ctx->tallied) { ctx->err = "tally first"; return MIA_HIP_ERR_STATE; }
@@ -1453,10 +1445,10 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
     if (p > 0)
       for (int j = 0; j < gaps[p]; j++) {
         char c = ins[off[p] + j];
-        if (c != '-' && c != ' ') { if (o + 1 >= out_cap) return MIA_HIP_ERR_ARG; out[o++] = c; }
+        if (c != '-' && c != ' ') { if (o + 1 >= out_cap) { ctx->err = "consensus buffer too small"; return MIA_HIP_ERR_ARG; } out[o++] = c; }
       }
     char c = calls[p];
-    if (c != '-' && c != ' ') { if (o + 1 >= out_cap) return MIA_HIP_ERR_ARG; out[o++] = c; }
+    if (c != '-' && c != ' ') { if (o + 1 >= out_cap) { ctx->err = "consensus buffer too small"; return MIA_HIP_ERR_ARG; } out[o++] = c; }
   }
   out[o] = 0;
   if (out_len) *out_len = o;
@@ -1692,13 +1684,32 @@ struct AlignBorrow {
   ReadSet rs; int32_t *bin_of, *list, *wide, *retry; int max_len; uint8_t* d_ref; int L, wrap, explicit_win, use_filter;
   bool aligned, culled, tallied, pre_cull_valid, ref_mostly_bases;
   int64_t plain_total, plain_retried, filter_seen, filter_proven, bx_seen, bx_done0, bx_done1, bx_done2;
+  double stg_ms[STG_COUNT]; int64_t stg_launches[STG_COUNT];
   explicit AlignBorrow(mia_hip_ctx* ctx)
       : c(ctx), rs(ctx->rs), bin_of(ctx->d_bin_of), list(ctx->d_list), wide(ctx->d_wide_list), retry(ctx->d_retry_list), max_len(ctx->max_len),
         d_ref(ctx->d_ref), L(ctx->L), wrap(ctx->wrap), explicit_win(ctx->explicit_win), use_filter(ctx->use_filter), aligned(ctx->aligned),
         culled(ctx->culled), tallied(ctx->tallied), pre_cull_valid(ctx->pre_cull_valid), ref_mostly_bases(ctx->ref_mostly_bases),
         plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven),
-        bx_seen(ctx->bx_seen), bx_done0(ctx->bx_done[0]), bx_done1(ctx->bx_done[1]), bx_done2(ctx->bx_done[2]) {}
+        bx_seen(ctx->bx_seen), bx_done0(ctx->bx_done[0]), bx_done1(ctx->bx_done[1]), bx_done2(ctx->bx_done[2]) {
+    // the stage timers of the iteration path must not see what the borrowed runs add (bench.py's roofline reads them)
+    for (int k = 0; k < STG_COUNT; k++) {
+      if (k == STG_PASS1) continue;
+      float ms = 0;
+      for (auto& e : ctx->stg[k].pending) {
+        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { ctx->stg[k].ms += ms; ctx->stg[k].launches++; }
+        ctx->ev_free.push_back(e);
+      }
+      ctx->stg[k].pending.clear();
+      stg_ms[k] = ctx->stg[k].ms; stg_launches[k] = ctx->stg[k].launches;
+    }
+  }
   ~AlignBorrow() {
+    for (int k = 0; k < STG_COUNT; k++) {
+      if (k == STG_PASS1) continue;
+      for (auto& e : c->stg[k].pending) { (void)hipEventSynchronize(e.second); c->ev_free.push_back(e); }
+      c->stg[k].pending.clear();
+      c->stg[k].ms = stg_ms[k]; c->stg[k].launches = stg_launches[k];
+    }
     c->rs = rs; c->d_bin_of = bin_of; c->d_list = list; c->d_wide_list = wide; c->d_retry_list = retry; c->max_len = max_len; c->d_ref = d_ref;
     c->L = L; c->wrap = wrap; c->explicit_win = explicit_win; c->use_filter = use_filter; c->aligned = aligned; c->culled = culled;
     c->tallied = tallied; c->pre_cull_valid = pre_cull_valid; c->ref_mostly_bases = ref_mostly_bases; c->plain_total = plain_total;
@@ -1841,7 +1852,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   if (rcx) return rcx == 2 ? MIA_HIP_ERR_DEVICE : MIA_HIP_ERR_NOMEM;
   lap("pack+alloc");
   hipError_t e = hipSuccess;
-  hipEvent_t pe0 = nullptr, pe1 = nullptr;
+  bool p1_timed = false;
   auto cp = [&](void* d, const void* h, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
   cp(d_cf, cf.data(), cf.size()); cp(d_cr, cr.data(), cr.size());
   cp(d_packed, packed.data(), packed.size()); cp(d_roff, roff.data(), (size_t)n * 4); cp(d_len, len.data(), (size_t)n * 2);
@@ -1856,7 +1867,8 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   ctx->pass1_anchored = 0;
   if (e == hipSuccess) {
     Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
-    if (get_events(ctx, &pe0, &pe1) == 0) (void)hipEventRecord(pe0, ctx->stream);
+    drain_events(ctx);                       // (nothing of an earlier call may sit in the pass-1 timer)
+    p1_timed = stage_begin(ctx, STG_PASS1) == 0;
     if (filtered) {
       const int64_t words = plane_words(len1);
       if (dev_alloc(ctx, &d_p1planes, (size_t)words * 6) || dev_alloc(ctx, &d_todo, (size_t)n) || dev_alloc(ctx, &d_ntodo, 1)) return MIA_HIP_ERR_NOMEM;
@@ -1955,19 +1967,18 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
                          trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words, plain, filtered ? d_todo : nullptr, n_dp);
       e = hipGetLastError();
     }
-    if (pe1) (void)hipEventRecord(pe1, ctx->stream);
+    if (p1_timed) stage_end(ctx, STG_PASS1);
   }
   auto back = [&](void* h, const void* d, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, ctx->stream); };
   back(score, d_score, (size_t)n * 4); back(as, d_as, (size_t)n * 4); back(ae, d_ae, (size_t)n * 4);
   back(rc, d_rc, (size_t)n); back(flags, d_flags, (size_t)n);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   lap("h2d+kernel+d2h");
-  if (pe0 && pe1) {
+  if (p1_timed && !ctx->stg[STG_PASS1].pending.empty()) {
+    // the whole call's device time (filter, anchored windows and DP), measured on the pair taken above
+    const auto pr = ctx->stg[STG_PASS1].pending.back();
     float ms = 0;
-    if (e == hipSuccess && hipEventElapsedTime(&ms, pe0, pe1) == hipSuccess) ctx->pass1_ms = ms;
-    // the pair sits at the back of ev_used (pushed by get_events): hand it back without counting it as an align launch
-    ctx->ev_free.push_back(ctx->ev_used.back());
-    ctx->ev_used.pop_back();
+    if (e == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ctx->pass1_ms = ms;
   }
   lap("done");
   if (e != hipSuccess) { ctx->err = std::string("pass1: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
@@ -2080,6 +2091,58 @@ extern "C" int mia_hip_myers_align(mia_hip_ctx* ctx, const char* seq_a, int32_t 
   if (bt_a) memcpy(bt_a, ra.c_str(), ra.size() + 1);
   if (bt_b) memcpy(bt_b, rb.c_str(), rb.size() + 1);
   return MIA_HIP_OK;
+}
+
+// ---- measured ceilings (bench.py's roofline) -----------------------------------------------
+extern "C" int mia_hip_measure_peaks(mia_hip_ctx* ctx, int64_t copy_bytes, double* hbm_copy_gbs, double* valu_ginst_s) {
+  if (!ctx || copy_bytes < (1 << 20)) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  void *a = nullptr, *b = nullptr;
+  ScopeFree sf; sf.watch(&a); sf.watch(&b);
+  int rc = MIA_HIP_OK;
+  if (hbm_copy_gbs) {
+    const int64_t n16 = copy_bytes / 16;
+    if (hipMalloc(&a, (size_t)n16 * 16) != hipSuccess || hipMalloc(&b, (size_t)n16 * 16) != hipSuccess) { ctx->err = "measure_peaks: hipMalloc"; rc = MIA_HIP_ERR_NOMEM; }
+    else {
+      HIPCHK(hipMemsetAsync(a, 1, (size_t)n16 * 16, ctx->stream));
+      const int grid = ctx->cus * 16;
+      float best = 1e30f;
+      for (int rep = 0; rep < 6; rep++) {                     // the first repetition warms the TLBs
+        (void)hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(k_peak_copy, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16);
+        (void)hipEventRecord(e1, ctx->stream);
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best) best = ms;
+      }
+      *hbm_copy_gbs = 2.0 * (double)n16 * 16 / (best * 1e-3) / 1e9;      // bytes read + bytes written
+    }
+  }
+  if (valu_ginst_s && rc == MIA_HIP_OK) {
+    int32_t* out = nullptr;
+    const int wgs = ctx->cus * 8, iters = 4096;               // 8 waves per SIMD: enough to cover the issue latency
+    if (hipMalloc((void**)&out, (size_t)wgs * 256 * 4) != hipSuccess) { ctx->err = "measure_peaks: hipMalloc"; rc = MIA_HIP_ERR_NOMEM; }
+    else {
+      float best = 1e30f;
+      for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(k_peak_valu, dim3(wgs), dim3(256), 0, ctx->stream, out, iters, 12345 + rep);
+        (void)hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && ms < best) best = ms;
+      }
+      (void)hipFree(out);
+      *valu_ginst_s = (double)wgs * 4 * iters * PEAK_VALU_OPS_PER_ITER / (best * 1e-3) / 1e9;   // wave instructions per second
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
 }
 
 extern "C" int mia_hip_pass1_time(mia_hip_ctx* ctx, double* kernel_ms) {

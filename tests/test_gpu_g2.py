@@ -1,5 +1,7 @@
 """whole runs of 2 000 seeded 100 bp reads against mt311 -- flat matrix, matrices/ancient.submat.txt and
-matrices/ancient.submat.solexa.pe.txt (aDNA-damaged reads), no k-mer filter, iterated to convergence.  mia_hip must write
+matrices/ancient.submat.solexa.pe.txt (aDNA-damaged reads), no k-mer filter, iterated to convergence -- and, as g2_c4,
+BASELINE.json configs[4]'s shape: 2 000 damaged 150 bp reads against a 100 kb linear region (seed 5), ancient matrix,
+-k 12, no -c (src/mia_main.c:645: no wrap; src/kmer.c:239-331 over 100 kb; windows of 250 columns, src/mia_main.c:190-217).  mia_hip must write
 the .maln files the reference's own mia wrote (tools/make_goldens.py g2, oracle/_ref/mia), byte for byte from line 2:
 each is pinned by the sha256 of that text (tests/golden/g2_runs.json); the reads are regenerated from their seed."""
 import hashlib
@@ -31,7 +33,8 @@ def test_g2_whole_run_identical(name, tmp_path):
     assert make_goldens.g2_reads(name, fa) == want["reads_sha256"]          # the same reads the reference saw
     root = str(tmp_path / name)
     env = dict(os.environ, MIA_DATA_PATH=GOLDEN)
-    subprocess.run([CLI, "-r", "mt311.fa", "-f", fa] + want["args"] + ["-m", root], cwd=GOLDEN, check=True, stderr=subprocess.DEVNULL, env=env, timeout=900)
+    ref_arg, _ = make_goldens.g2_ref(name, fa + ".ref.fa")
+    subprocess.run([CLI, "-r", ref_arg, "-f", fa] + want["args"] + ["-m", root], cwd=GOLDEN, check=True, stderr=subprocess.DEVNULL, env=env, timeout=900)
     assert len(want["maln_sha256"]) >= 2
     for it, (h, hs) in enumerate(zip(want["maln_sha256"], want["ref_seq"]), 1):
         body = open(f"{root}.{it}").readlines()[1:]

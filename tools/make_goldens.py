@@ -264,30 +264,50 @@ def g2_sets():
         "g2_flat": dict(seed=21, damage=False, args=["-c", "-i"]),
         "g2_anc": dict(seed=22, damage=True, args=["-c", "-i", "-s", "ancient.submat.txt"]),
         "g2_pe": dict(seed=23, damage=True, args=["-c", "-i", "-s", "ancient.submat.solexa.pe.txt"]),
+        # BASELINE.json configs[4]'s shape: 150 bp damaged reads against a 100 kb linear region (seed 5), ancient matrix, -k 12
+        "g2_c4": dict(seed=24, damage=True, args=["-i", "-s", "ancient.submat.txt", "-k", "12"], read_len=150, ref="rand100k"),
     }
+
+
+def g2_ref(name, out_path):
+    """the reference FASTA of a G2 set: mt311 (committed) or the seeded 100 kb region; returns (path to hand to -r, genome the reads come from)"""
+    kw = g2_sets()[name]
+    if kw.get("ref") == "rand100k":
+        g = gen_data.random_reference(100_000, seed=5)
+        gen_data.write_fasta(out_path, "region100k synthetic", g)
+        return out_path, g
+    _, _, mt = gen_data.read_fasta_one(os.path.join(G, "mt311.fa"))
+    return "mt311.fa", gen_data.resolve_individual(mt)
 
 
 def g2_reads(name, out_path):
     kw = g2_sets()[name]
-    _, _, mt = gen_data.read_fasta_one(os.path.join(G, "mt311.fa"))
-    d = gen_data.make_reads(gen_data.resolve_individual(mt), 2000, 100, kw["seed"], circular=True, damage=kw["damage"])
+    _, genome = g2_ref(name, out_path + ".ref.fa")
+    d = gen_data.make_reads(genome, 2000, kw.get("read_len", 100), kw["seed"], circular="-c" in kw["args"], damage=kw["damage"])
     gen_data.write_fasta_reads(out_path, d["reads"])
     import hashlib
     return hashlib.sha256(open(out_path, "rb").read()).hexdigest()
 
 
-def g2_cases():
+def g2_cases(only=None):
     """The reference's own mia on the G2 sets (two minutes of CPU each: pass 1 is the whole-reference DP).  Every .maln of
-    a run is pinned by the sha256 of its text from line 2 on; the SEQ line of each iteration's reference is kept readable."""
+    a run is pinned by the sha256 of its text from line 2 on; the SEQ line of each iteration's reference is kept readable.
+    only: names to (re)generate, the others keep their committed entries."""
     import hashlib
     shutil.copy(os.path.join(REF, "matrices", "ancient.submat.solexa.pe.txt"), os.path.join(G, "ancient.submat.solexa.pe.txt"))
     tmp = tempfile.mkdtemp()
     out = {}
+    if only and os.path.exists(os.path.join(G, "g2_runs.json")):
+        with open(os.path.join(G, "g2_runs.json")) as f:
+            out = json.load(f)
     procs = {}
     for name, kw in g2_sets().items():
+        if only and name not in only:
+            continue
         fa = os.path.join(tmp, name + ".fa")
         out[name] = {"reads_sha256": g2_reads(name, fa), "args": kw["args"], "maln_sha256": [], "ref_seq": []}
-        procs[name] = subprocess.Popen([os.path.join(RB, "mia"), "-r", "mt311.fa", "-f", fa] + kw["args"] + ["-m", os.path.join(tmp, name)], cwd=G,
+        ref_arg, _ = g2_ref(name, fa + ".ref.fa")
+        procs[name] = subprocess.Popen([os.path.join(RB, "mia"), "-r", ref_arg, "-f", fa] + kw["args"] + ["-m", os.path.join(tmp, name)], cwd=G,
                                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for name, pr in procs.items():
         assert pr.wait() == 0, name
@@ -524,7 +544,7 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g2":          # only the 2 000-read whole runs
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
-        g2_cases()
+        g2_cases(sys.argv[2:] or None)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "ma":          # only the ma reports (the .maln files stay as they are)
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)

@@ -1,21 +1,35 @@
 #!/usr/bin/env python3
 """Per-kernel averages of rocprofv3 --pmc counter_collection.csv files (one file per counter pass; FETCH_SIZE and
-WRITE_SIZE need separate passes on gfx950).  usage: pmc_summary.py out.json pass1_counter_collection.csv [...]
-Values are per dispatch, averaged over the dispatches of the kernel that processed at least half as much as the largest
-one (the timed steps; warm-up and tiny launches are left out).  FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports them."""
+WRITE_SIZE need separate passes on gfx950).
+usage: pmc_summary.py out.json reads_per_gpu pass1_counter_collection.csv [...]
+Values are per dispatch, averaged over the dispatches of the kernel whose counter came to at least half of the largest
+one (the timed steps; warm-up and tiny launches are left out).  FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports
+them, uncorrected; bench.py applies the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE x 2) and this file records
+what k_peak_copy -- a streaming copy of a known size in the same passes -- showed, as the calibration of that factor.
+_meta.source_hash names the build (sha256 over csrc/): bench.py does not replay counters of another build."""
 import csv
 import json
+import os
+import re
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def short(name):
+    name = name.split("(")[0].replace("void ", "").strip()
+    name = re.sub(r"<.*>", "", name)
+    return name.split("::")[-1]
 
 
 def main():
     out = defaultdict(dict)
-    for path in sys.argv[2:]:
+    for path in sys.argv[3:]:
         per = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(path)):
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            per[name][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            per[short(r["Kernel_Name"])][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for name, ctrs in per.items():
             for c, vals in ctrs.items():
                 big = max(v for v, _ in vals)
@@ -23,10 +37,21 @@ def main():
                 out[name][c] = sum(v for v, _ in keep) / len(keep)
                 out[name]["dispatches_" + c] = len(keep)
                 out[name]["kernel_ms_under_" + c] = sum(t for _, t in keep) / len(keep) / 1e6
+    import bench
+    meta = {"source_hash": bench.source_hash(), "reads_per_gpu": int(sys.argv[2]),
+            "command": "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --pmc-run <tag> --config <k> (tools/pmc_collect.sh)"}
+    pc = out.get("k_peak_copy")
+    if pc and "FETCH_SIZE" in pc:
+        copied = float(1 << 28)                  # bench.py --pmc-run: measure_peaks(1 << 28), bytes read = bytes written
+        meta["fetch_calibration"] = {"k_peak_copy_bytes_read": copied, "FETCH_SIZE_bytes": pc["FETCH_SIZE"] * 1024,
+                                     "ratio": pc["FETCH_SIZE"] * 1024 / copied,
+                                     "WRITE_SIZE_bytes": pc.get("WRITE_SIZE", 0) * 1024, "write_ratio": pc.get("WRITE_SIZE", 0) * 1024 / copied}
+    out["_meta"] = meta
     with open(sys.argv[1], "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    for name in sorted(out, key=lambda k: -out[k].get("kernel_ms_under_FETCH_SIZE", 0))[:12]:
+    for name in sorted((k for k in out if k != "_meta"), key=lambda k: -out[k].get("kernel_ms_under_FETCH_SIZE", 0))[:14]:
         print(name, {k: round(v, 2) for k, v in out[name].items() if not k.startswith("dispatches")})
+    print(meta)
 
 
 if __name__ == "__main__":
