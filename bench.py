@@ -160,6 +160,9 @@ class Pipeline:
 
     def step(self, cur_ref):
         hip, w = self.hip, self.w
+        if not self.sharded and self.phase is None and not os.environ.get("MIA_BENCH_STEPWISE"):
+            # the product's own iteration call (mia_hip_iterate): planner, cut line and insert-event count stay on the device
+            return hip.iterate(cur_ref, w["circular"])
         t0 = time.perf_counter()
         hip.realign(cur_ref, w["circular"])
         t0 = self._tick("realign", t0)

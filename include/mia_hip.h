@@ -197,6 +197,20 @@ int mia_hip_set_tally(mia_hip_ctx *ctx, int32_t ref_len, const int32_t *tally, c
  * out must hold ref_len + sum(gaps) + 1 bytes; *out_len = strlen(out). */
 int mia_hip_consensus(mia_hip_ctx *ctx, int cons_code, char *out, int64_t out_cap, int64_t *out_len);
 
+/* One whole iteration of the main loop, src/mia_main.c:931-963 -- reiterate_assembly, pop_smp_from_FSDB,
+ * cull_maln_from_fsdb (with find_fsdb_score_cut unless hard_cut > 0 or a line is given) and consensus_assembly_string --
+ * as one call.  Same kernels and same results as mia_hip_realign + mia_hip_cull + mia_hip_tally + mia_hip_consensus, but
+ * the numbers those calls pass through the host in between (planner bins, cut line, insert-event count, result arrays)
+ * stay on the device; the host waits once behind the alignment and once for the consensus string.
+ *   new_ref/ref_len/circular   as mia_hip_realign
+ *   hard_cut                   -H (> 0), else
+ *   slope_intercept            -S / -N as {slope, intercept}, or NULL: the regression of find_fsdb_score_cut
+ *   cons_code, out, out_cap, out_len   as mia_hip_consensus
+ * Afterwards every getter (mia_hip_get_alignments, _scripts, _dropped, _record_params, _tally, _ins_tally) answers as
+ * after the four separate calls.  Single context; a sharded run uses the separate calls with its collectives between. */
+int mia_hip_iterate(mia_hip_ctx *ctx, const char *new_ref, int32_t ref_len, int circular, int32_t hard_cut,
+                    const double *slope_intercept, int cons_code, char *out, int64_t out_cap, int64_t *out_len);
+
 /* ---- adapter trimming ---------------------------------------------------- */
 
 /* void trim_frag(FragSeqP, char* adapter, AlignmentP) -- src/mia.h, src/mia.c:1318-1368, as main() sets it up for -T

@@ -54,6 +54,7 @@ def _load():
     lib.mia_hip_set_ins_events.argtypes = [vp, vp, C.c_int64]
     lib.mia_hip_get_tally.argtypes = [vp, vp, vp]
     lib.mia_hip_set_tally.argtypes = [vp, C.c_int32, vp, vp]
+    lib.mia_hip_iterate.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int, C.c_int32, vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
     lib.mia_hip_pre_cull_counts.argtypes = [vp, vp, vp]
@@ -104,7 +105,7 @@ def exported_symbols():
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
-            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally"]
+            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate"]
 
 
 def _ptr(a):
@@ -316,6 +317,22 @@ class MiaHip:
         n = C.c_int64()
         self._chk(self._l.mia_hip_consensus(self._h, cons_code, buf, cap, C.byref(n)))
         return buf.raw[: n.value].decode()
+
+    def iterate(self, ref, circular, hard_cut=0, score_cut=None, cons_code=1):
+        """One whole iteration (reference src/mia_main.c:931-963) as one call: realign + score cut + cull + tally +
+        consensus without host round trips in between.  score_cut: (slope, intercept) of -S/-N, or None for the
+        regression of find_fsdb_score_cut.  Returns the consensus string."""
+        if isinstance(ref, str):
+            ref = ref.encode()
+        self.L = len(ref)
+        cap = len(ref) * 2 + 65536
+        if getattr(self, "_cons_buf_cap", 0) < cap:
+            self._cons_buf, self._cons_buf_cap = C.create_string_buffer(cap), cap
+        n = C.c_int64()
+        sc = None if score_cut is None else np.ascontiguousarray(score_cut, dtype=np.float64)
+        self._chk(self._l.mia_hip_iterate(self._h, ref, len(ref), 1 if circular else 0, hard_cut, _ptr(sc), cons_code, self._cons_buf,
+                                          self._cons_buf_cap, C.byref(n)))
+        return self._cons_buf.raw[: n.value].decode()
 
     def pass1_anchored(self):
         """reads of the last pass1() call decided by windowed alignment around their 10-mer anchors"""

@@ -286,9 +286,10 @@ __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const i
 // own dropped marks, the persistent back slot, and the links of formerly split reads
 __global__ void k_cull_mark(ReadSet rs, int32_t L, const int64_t* slot, uint8_t* slot_dropped, int64_t n_slots, int32_t hard_cut, double slope,
                             double intercept, int64_t* back_slot, const int64_t* front_slot0, RecInfo ri, Links lk, int64_t read_base,
-                            uint32_t* flags) {
+                            uint32_t* flags, const double* dev_cut) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rs.n) return;
+  if (dev_cut) { slope = dev_cut[0]; intercept = dev_cut[1]; }   // the line of find_fsdb_score_cut, left on the device
   const double min_score = hard_cut > 0 ? (double)hard_cut : (double)(intercept + (slope * (double)rs.len[i]));
   const bool low = (double)rs.score[i] < min_score;
   auto add_link = [&](int64_t target, int kind, int fl, int ac) {
@@ -1011,13 +1012,13 @@ __global__ __launch_bounds__(1024) void k_gap_offsets(const int32_t* gaps, int32
 // cap: slots the insert buffers hold.  The host launches with the capacity left from the last call and reads the real total
 // back with the results; only if the total outgrew the capacity does it enlarge the buffers and run the insert part again.
 __global__ void k_ins_tally(const uint64_t* events, int32_t n_events, const int32_t* pssm2, const int32_t* ins_off,
-                            const int32_t* gaps, int32_t L, int32_t* ins_tally, int32_t cap) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_events) return;
+                            const int32_t* gaps, int32_t L, int32_t* ins_tally, int32_t cap, const int32_t* n_events_dev, int32_t cap_events) {
+  if (n_events_dev) n_events = min(*n_events_dev, cap_events);      // the count stayed on the device: a grid-stride sweep
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_events; e += gridDim.x * blockDim.x) {
   const uint64_t ev = events[e];
   const int gc = (int)(uint32_t)ev, j = (int)((ev >> 32) & 1023), code = (int)((ev >> 42) & 7), d = (int)((ev >> 45) & 31);
   const int rc = (int)((ev >> 50) & 1);
-  if (gc <= 0 || gc >= L || j >= gaps[gc] || ins_off[gc] + j >= cap) return;
+  if (gc <= 0 || gc >= L || j >= gaps[gc] || ins_off[gc] + j >= cap) continue;
   int32_t* t = ins_tally + (int64_t)(ins_off[gc] + j) * 9;
   const int32_t* row = pssm2 + (rc ? PSSM_WORDS : 0) + d * 25 + code;
   if (code < 4) atomicAdd(&t[code], 1);
@@ -1026,6 +1027,7 @@ __global__ void k_ins_tally(const uint64_t* events, int32_t n_events, const int3
   atomicAdd(&t[6], row[5]);
   atomicAdd(&t[7], row[10]);
   atomicAdd(&t[8], row[15]);
+  }
 }
 
 // find_consensus (src/map_align.c:294-391)

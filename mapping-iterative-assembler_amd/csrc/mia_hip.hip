@@ -18,6 +18,7 @@
 #include "mia_myers_kernels.h"
 #include "mia_trim_kernels.h"
 #include "mia_peak_kernels.h"
+#include "mia_iter_kernels.h"
 
 using namespace mia;
 
@@ -129,6 +130,16 @@ struct mia_hip_ctx {
   unsigned char* h_pin = nullptr; static constexpr size_t PIN_BYTES = 1 << 20, PIN_MISC = 64 << 10;
   double pass1_ms = 0; int64_t pass1_filtered = 0, pass1_anchored = 0;   // reads of the last pass-1 call that the diagonal filter decided
   bool consensus_done = false;
+  // mia_hip_iterate: one iteration with the planner's answers, the cut line and the insert-event count left on the device
+  bool deferred = false;                    // align_all: no host round trip before its end
+  int32_t* d_plan_hdr = nullptr;            // PH_* (k_plan_scan)
+  const double* dev_cut = nullptr; double* d_cut_buf = nullptr;
+  int min_len = 0;                          // shortest stored read
+  std::vector<int32_t> h_len;               // read lengths on the host (the score-cut regression of reads of different lengths)
+  char* d_ascii = nullptr; int64_t ascii_cap = 0;
+  char* d_cons = nullptr; int64_t cons_cap = 0; int32_t* d_cons_pos = nullptr; int64_t cons_pos_cap = 0; int32_t* d_cons_hdr = nullptr;
+  unsigned char* h_pin2 = nullptr; size_t pin2_bytes = 0;   // results of an iteration (header + consensus string)
+  int64_t iter_fallbacks = 0;
   int64_t trim_escapes = 0;   // reads of the last mia_hip_trim call that took the exact scalar path
   int64_t ins_total_host = 0;
 };
@@ -208,7 +219,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
       dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1) || dev_alloc(ctx, &ctx->d_filter_n, 4) ||
       dev_alloc(ctx, &ctx->d_bx_sub, 2 * BX_SUB_WORDS) || dev_alloc(ctx, &ctx->d_bx_mrow, 2 * 31 * 4) || dev_alloc(ctx, &ctx->d_bx_loss, BX_LOSS_WORDS) ||
       dev_alloc(ctx, &ctx->d_bx_dl, BX_DL_WORDS) ||
-      dev_alloc(ctx, &ctx->d_bx_ctr, BXC_WORDS)) {
+      dev_alloc(ctx, &ctx->d_bx_ctr, BXC_WORDS) || dev_alloc(ctx, &ctx->d_plan_hdr, PH_WORDS) || dev_alloc(ctx, &ctx->d_cut_buf, 2) ||
+      dev_alloc(ctx, &ctx->d_cons_hdr, CH_WORDS)) {
     delete ctx;
     return MIA_HIP_ERR_NOMEM;
   }
@@ -230,10 +242,11 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
                   ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs,
                   ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_ctr,
-                  ctx->d_bx_slabs};
+                  ctx->d_bx_slabs, ctx->d_plan_hdr, ctx->d_cut_buf, ctx->d_ascii, ctx->d_cons, ctx->d_cons_pos, ctx->d_cons_hdr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+  if (ctx->h_pin2) (void)hipHostFree(ctx->h_pin2);
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& t : ctx->stg) for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
@@ -338,6 +351,9 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   std::vector<uint8_t> packed((size_t)total + 8, 0);
   pack_reads(n, bases, offsets, roff.data(), len.data(), packed.data());
   ctx->max_len = max_len;
+  ctx->min_len = max_len;
+  ctx->h_len.assign(len.begin(), len.end());
+  for (int64_t i = 0; i < n; i++) if ((int)len[(size_t)i] < ctx->min_len) ctx->min_len = len[(size_t)i];
   const int stride = (max_len + 3) & ~3;
   int rcx = 0;
   rcx |= dev_alloc(ctx, &ctx->d_packed, packed.size());
@@ -515,7 +531,7 @@ extern "C" int mia_hip_plain_stats(mia_hip_ctx* ctx, int reset, double* plain_ms
 }
 
 template <int CPL>
-static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count) {
+static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count, const int32_t* dev_range = nullptr) {
   // slab = the largest trace of this class: 256 rows x 64*CPL columns, one byte per cell
   const int64_t slab = (int64_t)MAX_READ * 64 * CPL;
   // persistent grid: never more workgroups than are resident at once (a late starter would work through its whole
@@ -527,14 +543,14 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
     const int per_cu = ctx->grid_wgs / cus;      // the configured ceiling (MIA_HIP_GRID_WAVES_PER_CU)
     ctx->window_wgs[ci] = cus * (occ < per_cu ? occ : per_cu);
   }
-  const int grid = count < ctx->window_wgs[ci] ? count : ctx->window_wgs[ci];
+  const int grid = (dev_range || count >= ctx->window_wgs[ci]) ? ctx->window_wgs[ci] : count;   // (a count on the device: the whole persistent grid)
   if (!ctx->d_slabs[ci]) {
     if (hipMalloc((void**)&ctx->d_slabs[ci], (size_t)slab * ctx->grid_wgs) != hipSuccess) return hipErrorOutOfMemory;
   }
   RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
   if (stage_begin(ctx, STG_TRACE)) return hipErrorOutOfMemory;
   hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
-                     count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg);
+                     count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg, dev_range);
   stage_end(ctx, STG_TRACE);
   return hipGetLastError();
 }
@@ -566,6 +582,38 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   }
   ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true; ctx->explicit_win = 0;
   return align_all(ctx);
+}
+
+// exact kernel for whole-reference windows and escaped reads (rare): one read per thread, int32 scores and trace in scratch
+static int run_wide(mia_hip_ctx* ctx, const RefInfo& ref, int32_t n_wide) {
+    std::vector<int32_t> wl((size_t)n_wide), as((size_t)n_wide), ae((size_t)n_wide);
+    std::vector<uint16_t> ln((size_t)n_wide);
+    HIPCHK(hipMemcpy(wl.data(), ctx->d_wide_list, (size_t)n_wide * 4, hipMemcpyDeviceToHost));
+    std::vector<int64_t> soff((size_t)n_wide);
+    int64_t total = 0;
+    for (int t = 0; t < n_wide; t++) {
+      HIPCHK(hipMemcpy(&as[t], ctx->rs.as + wl[t], 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&ae[t], ctx->rs.ae + wl[t], 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&ln[t], ctx->rs.len + wl[t], 2, hipMemcpyDeviceToHost));
+      int s, n1;
+      read_window(ref, as[t], ae[t], ln[t], &s, &n1);
+      soff[t] = total;
+      total += (int64_t)ln[t] * n1 + 5 * (int64_t)n1 + 16;
+    }
+    if (total > ctx->scratch_cap) {
+      if (dev_alloc(ctx, &ctx->d_scratch, (size_t)total)) return MIA_HIP_ERR_NOMEM;
+      ctx->scratch_cap = total;
+    }
+    if (n_wide > ctx->scratch_off_cap) {
+      if (dev_alloc(ctx, &ctx->d_scratch_off, (size_t)n_wide)) return MIA_HIP_ERR_NOMEM;
+      ctx->scratch_off_cap = n_wide;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_scratch_off, soff.data(), (size_t)n_wide * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_align_wide, dim3((n_wide + 63) / 64), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_wide_list,
+                       n_wide, ctx->d_scratch_off, ctx->d_scratch);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  return MIA_HIP_OK;
 }
 
 // every strand_known read against its window of ctx->d_ref: plan, values-only pass, trace kernels, exact kernel
@@ -710,6 +758,100 @@ static int align_all(mia_hip_ctx* ctx) {
   // matrix most of them are gap-free reads with many substitutions, which it finishes at half the trace kernel's price)
   const bool use_plain = ctx->use_plain && (!banded || ctx->plain_behind_band);
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
+  if (ctx->deferred) {
+    // ---- mia_hip_iterate: the same plan, but its numbers stay on the device (k_plan_scan) and every DP kernel reads its own
+    // range; the host looks at the counters once, when everything has been queued --------------------------------------
+    int32_t* hdr = ctx->d_plan_hdr;
+    const bool dbg_steps = getenv("MIA_HIP_ITER_DEBUG") != nullptr;
+    auto ck = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[align_all deferred] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
+    ck("plan_count");
+    int32_t* d_retry_cnt = hdr + PH_RETRY + 1;
+    HIPCHK(hipMemsetAsync(hdr, 0, PH_WORDS * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ctx->stream));           // -1 = empty slot (quad padding)
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(64), 0, ctx->stream, d_count, d_off, hdr, 0);
+    hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
+    ck("memsets");
+    hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ctx->stream, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count);
+    ck("scan fill seed");
+    // every window class reads its own range from the header (the list is rewritten by the re-plan below, so they all go
+    // first; a class without reads costs an empty launch)
+    for (int ci = 0; ci < N_CPL; ci++) {
+      hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci)
+                   : ci == 1 ? launch_window<8>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci)
+                             : launch_window<12>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci);
+      if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+    }
+    ck("window classes");
+    const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
+    if (ctx->use_quad) {
+      if (use_plain) {
+        if (stage_begin(ctx, STG_PLAIN)) return MIA_HIP_ERR_NOMEM;
+        hipLaunchKernelGGL(k_align_quad_plain, dim3(ctx->quad_wgs), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_list, 0, ctx->d_bin_of,
+                           (const int32_t*)(hdr + PH_QUAD));
+        stage_end(ctx, STG_PLAIN);
+        ck("quad plain");
+        // what it could not finish (and what the filter's gap hint kept out of it), re-planned into quads
+        HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ctx->stream));
+        hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_count);
+        HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(64), 0, ctx->stream, d_count, d_off, hdr, 1);
+        hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
+        ck("replan");
+      }
+      const int64_t slab = (int64_t)Q_G * MAX_READ * Q_TRACE_STRIDE;
+      if (!ctx->d_quad_slabs && hipMalloc((void**)&ctx->d_quad_slabs, (size_t)slab * ctx->quad_wgs) != hipSuccess) return MIA_HIP_ERR_NOMEM;
+      const int qgrid = ctx->quad_wgs;
+      if (dbg_steps) {
+        int32_t hh[PH_WORDS];
+        (void)hipMemcpy(hh, hdr, sizeof hh, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[align_all deferred] hdr:");
+        for (int k = 0; k < PH_WORDS; k++) fprintf(stderr, " %d", hh[k]);
+        fprintf(stderr, "  n=%lld max_len=%d quad_lds=%zu\n", (long long)n, ctx->max_len, quad_lds);
+      }
+      if (stage_begin(ctx, STG_TRACE)) return MIA_HIP_ERR_NOMEM;
+      hipLaunchKernelGGL(k_align_quad, dim3(qgrid), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list, 0,
+                         ctx->d_quad_slabs, slab, ctx->d_wide_list, d_wide_count, ctx->d_retry_list, d_retry_cnt, ctx->use_band, ctx->dbg,
+                         (const int32_t*)(hdr + PH_QUAD));
+      stage_end(ctx, STG_TRACE);
+      HIPCHK(hipGetLastError());
+      ck("quad trace");
+      if (ctx->use_band) {
+        hipError_t e = launch_window<4>(ctx, 0, ctx->d_retry_list, 0, hdr + PH_RETRY);
+        if (e != hipSuccess) { ctx->err = std::string("k_align_window retry launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+      }
+    }
+    ck("retry");
+    // the one look at the counters
+    std::vector<int32_t> pageable;
+    int32_t* hb;
+    if (ctx->h_pin) hb = reinterpret_cast<int32_t*>(ctx->h_pin);
+    else { pageable.resize(PH_WORDS + 8 + BXC_WORDS); hb = pageable.data(); }
+    int32_t *h_hdr = hb, *h_misc = hb + PH_WORDS;
+    uint32_t* h_bxc = reinterpret_cast<uint32_t*>(hb + PH_WORDS + 8);
+    for (int k = 0; k < BXC_COUNTERS; k++) h_bxc[k * BXC_STRIDE] = 0;
+    h_misc[0] = h_misc[1] = h_misc[2] = 0;
+    HIPCHK(hipMemcpyAsync(h_hdr, hdr, PH_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&h_misc[2], d_wide_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (filtered) {
+      HIPCHK(hipMemcpyAsync(&h_misc[0], ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(&h_misc[1], ctx->d_filter_n + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (bx) HIPCHK(hipMemcpyAsync(h_bxc, ctx->d_bx_ctr, BXC_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->filter_proven += (uint32_t)h_misc[0];
+    ctx->band_done += (uint32_t)h_misc[1];
+    ctx->filter_seen += n;
+    ctx->filter_proven += h_bxc[BXC_DONE_PLAN * BXC_STRIDE];
+    for (int k = 0; k < 3; k++) ctx->bx_done[k] += h_bxc[(BXC_DONE_PLAN + k) * BXC_STRIDE];
+    ctx->bx_seen += h_bxc[BXC_SEEN * BXC_STRIDE];
+    for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = h_bxc[k * BXC_STRIDE];
+    if (use_plain && ctx->use_quad) { ctx->plain_retried += h_hdr[PH_RETRIED_PLAIN]; }
+    const int32_t n_wide = h_misc[2];
+    if (n_wide > 0) { if (int rcw = run_wide(ctx, ref, n_wide)) return rcw; }
+    ctx->aligned = true; ctx->culled = false; ctx->tallied = false; ctx->pre_cull_valid = false;
+    return MIA_HIP_OK;
+  }
   // host copies of the counters live in pinned memory when there is some: a copy to or from pageable memory makes the
   // host wait for the stream even when it is called "async"
   int32_t local_buf[4 * N_BINS + 16];
@@ -768,7 +910,7 @@ static int align_all(mia_hip_ctx* ctx) {
     const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
     if (stage_begin(ctx, STG_PLAIN)) return MIA_HIP_ERR_NOMEM;
     hipLaunchKernelGGL(k_align_quad_plain, dim3(grid), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_list + quad_begin,
-                       n_quads, ctx->d_bin_of);
+                       n_quads, ctx->d_bin_of, (const int32_t*)nullptr);
     stage_end(ctx, STG_PLAIN);
     HIPCHK(hipGetLastError());
     }
@@ -799,7 +941,7 @@ static int align_all(mia_hip_ctx* ctx) {
     if (stage_begin(ctx, STG_TRACE)) return MIA_HIP_ERR_NOMEM;
     hipLaunchKernelGGL(k_align_quad, dim3(grid), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list + quad_begin,
                        n_quads, ctx->d_quad_slabs, slab, ctx->d_wide_list, d_wide_count, ctx->d_retry_list, d_retry_count, ctx->use_band,
-                       ctx->dbg);
+                       ctx->dbg, (const int32_t*)nullptr);
     stage_end(ctx, STG_TRACE);
     HIPCHK(hipGetLastError());
     if (ctx->use_band) {
@@ -822,35 +964,7 @@ static int align_all(mia_hip_ctx* ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
   const int32_t n_wide = h_misc[2];
-  if (n_wide > 0) {
-    std::vector<int32_t> wl((size_t)n_wide), as((size_t)n_wide), ae((size_t)n_wide);
-    std::vector<uint16_t> ln((size_t)n_wide);
-    HIPCHK(hipMemcpy(wl.data(), ctx->d_wide_list, (size_t)n_wide * 4, hipMemcpyDeviceToHost));
-    std::vector<int64_t> soff((size_t)n_wide);
-    int64_t total = 0;
-    for (int t = 0; t < n_wide; t++) {
-      HIPCHK(hipMemcpy(&as[t], ctx->rs.as + wl[t], 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&ae[t], ctx->rs.ae + wl[t], 4, hipMemcpyDeviceToHost));
-      HIPCHK(hipMemcpy(&ln[t], ctx->rs.len + wl[t], 2, hipMemcpyDeviceToHost));
-      int s, n1;
-      read_window(ref, as[t], ae[t], ln[t], &s, &n1);
-      soff[t] = total;
-      total += (int64_t)ln[t] * n1 + 5 * (int64_t)n1 + 16;
-    }
-    if (total > ctx->scratch_cap) {
-      if (dev_alloc(ctx, &ctx->d_scratch, (size_t)total)) return MIA_HIP_ERR_NOMEM;
-      ctx->scratch_cap = total;
-    }
-    if (n_wide > ctx->scratch_off_cap) {
-      if (dev_alloc(ctx, &ctx->d_scratch_off, (size_t)n_wide)) return MIA_HIP_ERR_NOMEM;
-      ctx->scratch_off_cap = n_wide;
-    }
-    HIPCHK(hipMemcpyAsync(ctx->d_scratch_off, soff.data(), (size_t)n_wide * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_align_wide, dim3((n_wide + 63) / 64), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_wide_list,
-                       n_wide, ctx->d_scratch_off, ctx->d_scratch);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-  }
+  if (n_wide > 0) { if (int rcw = run_wide(ctx, ref, n_wide)) return rcw; }
   ctx->aligned = true;
   ctx->culled = false;
   ctx->tallied = false;
@@ -986,7 +1100,7 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
                      ctx->read_base, ctx->d_cull_flags);
   hipLaunchKernelGGL(k_cull_mark, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
                      ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot, ctx->d_front_slot0, ctx->ri, ctx->lk, ctx->read_base,
-                     ctx->d_cull_flags);
+                     ctx->d_cull_flags, ctx->dev_cut);
   HIPCHK(hipGetLastError());
   // by default the links to apply are this context's own; a sharded run replaces them with the gathered list (mia_hip_set_links)
   ctx->d_links_all = ctx->lk.rec;
@@ -1263,8 +1377,8 @@ static int ensure_tally(mia_hip_ctx* ctx) {
   return MIA_HIP_OK;
 }
 
-extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
-  if (!ctx) return MIA_HIP_ERR_ARG;
+// everything of mia_hip_tally that is queued on the stream; the event count and the error flags are read afterwards
+static int tally_launch(mia_hip_ctx* ctx) {
   if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
   if (!ctx->culled) { ctx->err = "cull first (the dropped bits and record parameters are its output)"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
@@ -1309,20 +1423,30 @@ extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
     }
     HIPCHK(hipGetLastError());
   }
-  uint32_t local3[3] = {0, 0, 0};
-  uint32_t* h3 = ctx->h_pin ? reinterpret_cast<uint32_t*>(ctx->h_pin + (17 << 10)) : local3;   // pinned: three copies, one wait
-  HIPCHK(hipMemcpyAsync(&h3[0], ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&h3[1], ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(&h3[2], ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->n_events_host = (int32_t)h3[0];
-  const uint32_t flags = h3[1], cflags = h3[2];
+  return MIA_HIP_OK;
+}
+
+// what the tally kernels left in their counters (event count, overflow and geometry flags, the cull's flags)
+static int tally_finish(mia_hip_ctx* ctx, uint32_t n_events, uint32_t flags, uint32_t cflags) {
+  ctx->n_events_host = (int32_t)n_events;
   if (int rcf = check_cull_flags(ctx, cflags)) return rcf;
   if (flags & 1u) { ctx->err = "insert event list overflow"; return MIA_HIP_ERR_NOMEM; }
   if (ctx->n_events_host > ctx->tb.cap_events) ctx->n_events_host = ctx->tb.cap_events;
   ctx->tallied = true;
   ctx->consensus_done = false;
   return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_tally(mia_hip_ctx* ctx) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (int rc = tally_launch(ctx)) return rc;
+  uint32_t local3[3] = {0, 0, 0};
+  uint32_t* h3 = ctx->h_pin ? reinterpret_cast<uint32_t*>(ctx->h_pin + (17 << 10)) : local3;   // pinned: three copies, one wait
+  HIPCHK(hipMemcpyAsync(&h3[0], ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&h3[1], ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&h3[2], ctx->d_cull_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return tally_finish(ctx, h3[0], h3[1], h3[2]);
 }
 
 extern "C" int mia_hip_tally_buffers(mia_hip_ctx* ctx, int32_t** d_tally, int64_t* n_tally_words, int32_t** d_gaps,
@@ -1384,27 +1508,38 @@ extern "C" int mia_hip_set_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_
   return MIA_HIP_OK;
 }
 
+// the kernels of mia_hip_consensus: column calls, then the insert columns tallied and called into buffers of `cap` slots.
+// events_on_device: the insert-event count is read by k_ins_tally itself (mia_hip_iterate has not seen it yet)
+static int consensus_launch(mia_hip_ctx* ctx, int cons_code, int64_t cap, bool columns, bool events_on_device) {
+  const int L = ctx->L, Lp = ctx->tb.Lp;
+  if (columns) {
+    hipLaunchKernelGGL(k_gap_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->tb.gaps, Lp, L, ctx->d_ins_off, ctx->d_ins_total);
+    hipLaunchKernelGGL(k_call_columns, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, cons_code, ctx->d_calls);
+  }
+  if (cap <= 0) return MIA_HIP_OK;
+  HIPCHK(hipMemsetAsync(ctx->d_ins_tally, 0, (size_t)cap * 9 * 4, ctx->stream));
+  const int ne = ctx->n_events_host;
+  if (events_on_device)
+    hipLaunchKernelGGL(k_ins_tally, dim3(256), dim3(256), 0, ctx->stream, ctx->tb.events, 0, ctx->d_pssm, ctx->d_ins_off, ctx->tb.gaps, L, ctx->d_ins_tally,
+                       (int32_t)cap, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events);
+  else if (ne > 0)
+    hipLaunchKernelGGL(k_ins_tally, dim3((ne + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.events, ne, ctx->d_pssm, ctx->d_ins_off,
+                       ctx->tb.gaps, L, ctx->d_ins_tally, (int32_t)cap, (const int32_t*)nullptr, 0);
+  hipLaunchKernelGGL(k_call_inserts, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, ctx->tb.gaps,
+                     ctx->d_ins_off, ctx->d_ins_tally, cons_code, ctx->d_ins_calls, (int32_t)cap);
+  return MIA_HIP_OK;
+}
+
 extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int64_t out_cap, int64_t* out_len) {
   if (!ctx || !out) return MIA_HIP_ERR_ARG;
   if (!ctx->tallied) { ctx->err = "tally first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
   const int L = ctx->L, Lp = ctx->tb.Lp;
-  hipLaunchKernelGGL(k_gap_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->tb.gaps, Lp, L, ctx->d_ins_off, ctx->d_ins_total);
-  hipLaunchKernelGGL(k_call_columns, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, cons_code, ctx->d_calls);
   // The insert columns are tallied and called into buffers of the capacity the last call left behind, and their total
   // comes back with the results: one wait for the stream instead of two.  Only when the total has outgrown the buffers
   // are they enlarged and the insert part run again.
-  auto insert_part = [&](int64_t cap) -> int {
-    if (cap <= 0) return MIA_HIP_OK;
-    HIPCHK(hipMemsetAsync(ctx->d_ins_tally, 0, (size_t)cap * 9 * 4, ctx->stream));
-    const int ne = ctx->n_events_host;
-    if (ne > 0)
-      hipLaunchKernelGGL(k_ins_tally, dim3((ne + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.events, ne, ctx->d_pssm, ctx->d_ins_off,
-                         ctx->tb.gaps, L, ctx->d_ins_tally, (int32_t)cap);
-    hipLaunchKernelGGL(k_call_inserts, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, ctx->tb.gaps,
-                       ctx->d_ins_off, ctx->d_ins_tally, cons_code, ctx->d_ins_calls, (int32_t)cap);
-    return MIA_HIP_OK;
-  };
+  auto insert_part = [&](int64_t cap) -> int { return consensus_launch(ctx, cons_code, cap, false, false); };
+  if (int rcc = consensus_launch(ctx, cons_code, 0, true, false)) return rcc;
   int rc0 = insert_part(ctx->ins_tally_cap);
   if (rc0) return rc0;
   HIPCHK(hipGetLastError());
@@ -1454,6 +1589,120 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   if (out_len) *out_len = o;
   ctx->consensus_done = true;
   ctx->ins_total_host = total;
+  return MIA_HIP_OK;
+}
+
+// ---- one whole iteration -------------------------------------------------------------------------
+// reiterate_assembly + pop_smp_from_FSDB + cull_maln_from_fsdb + consensus_assembly_string (src/mia_main.c:931-963) as
+// one call: the same kernels as mia_hip_realign / _cull / _tally / _consensus, but what those entry points hand back to
+// the host between the kernels -- the planner's bin sizes, the cut line, the insert-event count, five result arrays --
+// stays on the device.  The host waits twice: once behind the alignment (reads that need the exact scalar kernel must be
+// known before anything is culled) and once for the consensus string.
+extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular, int32_t hard_cut, const double* slope_intercept,
+                               int cons_code, char* out, int64_t out_cap, int64_t* out_len) {
+  if (!ctx || !new_ref || ref_len <= 0 || !out || out_cap < 1) return MIA_HIP_ERR_ARG;
+  if (!ctx->have_pssm || !ctx->d_packed) { ctx->err = "set_pssm and upload_reads must precede iterate"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  // -- the new reference: ASCII up, codes and wrap made on the device (make_ref_upper / add_ref_wrap, src/mia.c:642-689)
+  const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl, total = wrap + 64;
+  int64_t n_other = 0;
+  for (int i = 0; i < L; i++) n_other += base_code(new_ref[i]) > 3;
+  ctx->ref_mostly_bases = n_other * 50 <= L;
+  if (total > ctx->ref_cap) {
+    if (dev_alloc(ctx, &ctx->d_ref, (size_t)total * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->ref_cap = total * 2;
+  }
+  if (L > ctx->ascii_cap) {
+    if (dev_alloc(ctx, &ctx->d_ascii, (size_t)L * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->ascii_cap = (int64_t)L * 2;
+  }
+  if (ctx->h_pin && (size_t)L <= mia_hip_ctx::PIN_BYTES - mia_hip_ctx::PIN_MISC) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));             // the staging area may still feed an earlier copy
+    memcpy(ctx->h_pin + mia_hip_ctx::PIN_MISC, new_ref, (size_t)L);
+    HIPCHK(hipMemcpyAsync(ctx->d_ascii, ctx->h_pin + mia_hip_ctx::PIN_MISC, (size_t)L, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->d_ascii, new_ref, (size_t)L, hipMemcpyHostToDevice, ctx->stream));
+  }
+  hipLaunchKernelGGL(k_ref_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_ascii, L, wl, ctx->d_ref, total);
+  HIPCHK(hipGetLastError());
+  const bool dbg_steps = getenv("MIA_HIP_ITER_DEBUG") != nullptr;      // diagnostic: wait and report after every stage
+  auto checkpoint = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[mia_hip_iterate] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
+  checkpoint("reference");
+  ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true; ctx->explicit_win = 0;
+  // -- re-alignment (one wait, at its end)
+  ctx->deferred = true;
+  const int rca = align_all(ctx);
+  ctx->deferred = false;
+  if (rca) return rca;
+  checkpoint("realign");
+  const int64_t n = ctx->rs.n;
+  // -- the cut line of find_fsdb_score_cut (src/fsdb.c:269-383)
+  double slope = 0, intercept = 0;
+  if (hard_cut > 0) {
+  } else if (slope_intercept) {
+    slope = slope_intercept[0]; intercept = slope_intercept[1];
+  } else if (ctx->min_len == ctx->max_len || n == 0) {
+    // reads of one length: both regression sums are exactly 0, slope_bf = 0/0, and every derived quantity is that NaN
+    // whatever the scores (mia_hip_score_cut_from_sums spells the arithmetic out) -- nothing to compute
+    const double zero = 0.0;
+    slope = intercept = zero / zero;
+  } else {
+    // sums of products in IEEE double are order dependent: the reference's sequential order over the scores, on the host
+    std::vector<int32_t> score((size_t)n);
+    HIPCHK(hipMemcpyAsync(score.data(), ctx->d_score, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    mia_hip_score_cut(score.data(), ctx->h_len.data(), nullptr, n, &slope, &intercept);
+  }
+  if (!(hard_cut > 0) && slope <= 0) slope = 100.0;         // src/mia.c:440-442
+  if (int rcc = mia_hip_cull(ctx, hard_cut, slope, intercept, 0)) return rcc;
+  checkpoint("cull");
+  if (n == 0) { out[0] = 0; if (out_len) *out_len = 0; return MIA_HIP_OK; }
+  // -- tally and consensus, queued back to back
+  if (int rct = tally_launch(ctx)) return rct;
+  checkpoint("tally");
+  const int Lp = ctx->tb.Lp;
+  ctx->n_events_host = 0;
+  if (int rcc = consensus_launch(ctx, cons_code, ctx->ins_tally_cap, true, true)) return rcc;
+  checkpoint("consensus kernels");
+  const int64_t cons_cap = (int64_t)L + ctx->ins_tally_cap + 64;
+  if (cons_cap > ctx->cons_cap) {
+    if (dev_alloc(ctx, &ctx->d_cons, (size_t)cons_cap * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->cons_cap = cons_cap * 2;
+  }
+  if (Lp > ctx->cons_pos_cap) {
+    if (dev_alloc(ctx, &ctx->d_cons_pos, (size_t)Lp * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->cons_pos_cap = (int64_t)Lp * 2;
+  }
+  hipLaunchKernelGGL(k_cons_assemble, dim3(1), dim3(1024), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls, (const int32_t*)ctx->tb.gaps,
+                     (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos, ctx->d_cons, (int32_t)cons_cap,
+                     ctx->d_cons_hdr, (const int32_t*)ctx->tb.n_events, (const uint32_t*)ctx->tb.flags, (const uint32_t*)ctx->d_cull_flags);
+  HIPCHK(hipGetLastError());
+  checkpoint("assemble");
+  const size_t need = (size_t)CH_WORDS * 4 + (size_t)cons_cap;
+  if (need > ctx->pin2_bytes) {
+    if (ctx->h_pin2) (void)hipHostFree(ctx->h_pin2);
+    ctx->h_pin2 = nullptr; ctx->pin2_bytes = 0;
+    if (hipHostMalloc((void**)&ctx->h_pin2, need * 2, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc"; return MIA_HIP_ERR_NOMEM; }
+    ctx->pin2_bytes = need * 2;
+  }
+  int32_t* h_hdr = reinterpret_cast<int32_t*>(ctx->h_pin2);
+  char* h_str = reinterpret_cast<char*>(ctx->h_pin2) + CH_WORDS * 4;
+  HIPCHK(hipMemcpyAsync(h_hdr, ctx->d_cons_hdr, CH_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(h_str, ctx->d_cons, (size_t)cons_cap, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (int rcf = tally_finish(ctx, (uint32_t)h_hdr[CH_N_EVENTS], (uint32_t)h_hdr[CH_TALLY_FLAGS], (uint32_t)h_hdr[CH_CULL_FLAGS])) return rcf;
+  if (h_hdr[CH_OVERFLOW]) {
+    // more insert columns than the buffers of the last call hold: the step-wise entry point enlarges them and calls again
+    ctx->iter_fallbacks++;
+    return mia_hip_consensus(ctx, cons_code, out, out_cap, out_len);
+  }
+  const int64_t len = h_hdr[CH_LEN];
+  if (len + 1 > out_cap) { ctx->err = "consensus buffer too small"; return MIA_HIP_ERR_ARG; }
+  memcpy(out, h_str, (size_t)len);
+  out[len] = 0;
+  if (out_len) *out_len = len;
+  ctx->consensus_done = true;
+  ctx->ins_total_host = h_hdr[CH_INS_TOTAL];
   return MIA_HIP_OK;
 }
 

@@ -313,6 +313,35 @@ __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin
   }
 }
 
+// ---- the planner's answer without a host round trip (mia_hip_iterate) ---------------------------------------------
+// What the host computes between k_plan_count and k_plan_fill in mia_hip_realign -- bin offsets with every quad bin padded
+// to whole quads -- by one wavefront, and the ranges the DP kernels then read themselves (their dev_range argument):
+//   hdr[PH_WIN + 2 ci] = {offset, count} of window class ci,  hdr[PH_QUAD] = {offset, quads},  hdr[PH_WIDE0] = {offset, count}
+//   hdr[PH_RETRY] = {0, reads whose path left the quad kernel's trace band} (k_align_quad counts into the second word)
+//   hdr[PH_TOTAL] = list entries in use (padding included)
+enum { PH_WIN = 0, PH_QUAD = 2 * N_CPL, PH_WIDE0 = PH_QUAD + 2, PH_RETRY = PH_WIDE0 + 2, PH_TOTAL = PH_RETRY + 2, PH_RETRIED_PLAIN, PH_WORDS = 16 };
+__global__ __launch_bounds__(64) void k_plan_scan(const int32_t* count, int32_t* off, int32_t* hdr, int32_t quads_only) {
+  if (threadIdx.x != 0) return;
+  int run = 0, retried = 0;
+  for (int b = 0; b < N_BINS; b++) {
+    off[b] = run;
+    run += b >= BIN_QUAD0 ? ((count[b] + 3) & ~3) : (quads_only ? 0 : count[b]);
+    if (b >= BIN_QUAD0) retried += count[b];
+  }
+  if (!quads_only) {
+    for (int ci = 0; ci < N_CPL; ci++) { hdr[PH_WIN + 2 * ci] = off[ci]; hdr[PH_WIN + 2 * ci + 1] = count[ci]; }
+    hdr[PH_WIDE0] = off[BIN_WIDE]; hdr[PH_WIDE0 + 1] = count[BIN_WIDE];
+  } else hdr[PH_RETRIED_PLAIN] = retried;
+  hdr[PH_QUAD] = off[BIN_QUAD0]; hdr[PH_QUAD + 1] = (run - off[BIN_QUAD0]) / 4;
+  hdr[PH_TOTAL] = run;
+}
+// reads that need the exact kernel from the start: the head of wide_list (the DP kernels append their escapes behind)
+__global__ __launch_bounds__(256) void k_wide_seed(const int32_t* list, const int32_t* hdr, int32_t* wide_list, int32_t* wide_count) {
+  const int off = hdr[PH_WIDE0], n = hdr[PH_WIDE0 + 1];
+  for (int t = threadIdx.x; t < n; t += 256) wide_list[t] = list[off + t];
+  if (threadIdx.x == 0) *wide_count = n;
+}
+
 // ---- the windowed DP: one read at a time per 64-lane workgroup, persistent grid -------------
 // The grid is sized to the machine (waves/CU x CUs); workgroup w takes reads w, w+G, w+2G ...
 // of its bin.  LDS holds only the 5-column substitution table, the byte trace goes to the
@@ -320,8 +349,10 @@ __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin
 template <int CPL>
 __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackParams pk,
                                                       const int32_t* list, int32_t count, unsigned char* trace_slabs,
-                                                      int64_t slab_bytes, int32_t* wide_list, int32_t* wide_count, uint32_t dbg) {
+                                                      int64_t slab_bytes, int32_t* wide_list, int32_t* wide_count, uint32_t dbg,
+                                                      const int32_t* dev_range) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SUB_LDS_BYTES];
+  if (dev_range) { list += dev_range[0]; count = dev_range[1]; }     // the planner's answer stayed on the device (k_plan_scan)
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
   for (int w = blockIdx.x; w < count; w += gridDim.x) {
     const int i = list[w];
@@ -365,8 +396,9 @@ __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, co
 __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackParams pk, const int32_t* list,
                                                     int32_t n_quads, unsigned char* trace_slabs, int64_t slab_bytes,
                                                     int32_t* wide_list, int32_t* wide_count, int32_t* retry_list, int32_t* retry_count,
-                                                    int32_t band, uint32_t dbg) {
+                                                    int32_t band, uint32_t dbg, const int32_t* dev_range) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // Q_G * q_sub_bytes(longest read)
+  if (dev_range) { list += dev_range[0]; n_quads = dev_range[1]; }
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
   for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
     QuadArgs a;
@@ -424,8 +456,9 @@ __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, c
 // ---- first pass over the quad bins: values only + the diagonal proof (align_body_quad_plain.h).  A proven read is
 // finished here and leaves its bin (bin_of = -1); the others keep their bin and are re-planned into quads for k_align_quad.
 __global__ __launch_bounds__(64, 4) void k_align_quad_plain(ReadSet rs, RefInfo ref, const int32_t* pssm2, const int32_t* list,
-                                                          int32_t n_quads, int32_t* bin_of) {
+                                                          int32_t n_quads, int32_t* bin_of, const int32_t* dev_range) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // Q_G * q_sub_bytes(longest read)
+  if (dev_range) { list += dev_range[0]; n_quads = dev_range[1]; }
   DevWave wave(lds_raw, nullptr);
   for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
     QuadPlainArgs a;

@@ -57,8 +57,13 @@ def pssm_array(p):
     return np.ctypeslib.as_array(p.sm).reshape(31, 5, 5).astype(np.int32).copy()
 
 
-def hip_iteration(hip, ref_seq, circular, lens, hard_cut=0, score_cut=None, cons_code=1, slot_base=0):
-    """One pass of the per-iteration path on the GPU: reiterate_assembly + cull + tally + consensus."""
+def hip_iteration(hip, ref_seq, circular, lens, hard_cut=0, score_cut=None, cons_code=1, slot_base=0, fused=False):
+    """One pass of the per-iteration path on the GPU: reiterate_assembly + cull + tally + consensus.
+    fused: through mia_hip_iterate (one call, no host round trips between the stages) instead of the four entry points."""
+    if fused:
+        cons = hip.iterate(ref_seq, circular, hard_cut, score_cut, cons_code)
+        score, as_, ae = hip.alignments()
+        return score, as_, ae, cons
     hip.realign(ref_seq, circular)
     score, as_, ae = hip.alignments()
     if hard_cut > 0:

@@ -186,3 +186,24 @@ def test_idempotent_linear_and_convergent(full):
         rounds += 1
     assert cons == ref, rounds
     assert abs(len(cons) - len(f.ref)) < 50
+
+
+def test_fused_iteration_identical(full):
+    """mia_hip_iterate (one call per iteration) from the same starting point: alignments, scripts, tallies, gaps and the
+    consensus of both iterations equal what the four separate entry points gave"""
+    f = full
+    hip = f.mod.MiaHip(0)
+    hip.set_pssm(f.pssm)
+    hip.upload_reads(f.stored.reshape(-1), f.soff, f.rc, f.sk, f.as0, f.ae0)
+    assert hip.iterate(f.ref, True) == f.cons1
+    for x, y in zip(hip.alignments(), f.al1):
+        assert np.array_equal(x, y)
+    assert hip.iterate(f.cons1, True) == f.cons2
+    for x, y in zip(hip.alignments(), f.al2):
+        assert np.array_equal(x, y)
+    cols, rstart = hip.scripts()
+    sk = f.sk.astype(bool)
+    assert np.array_equal(absolute(cols, rstart)[sk], absolute(f.cols2, f.rstart2)[sk])
+    t, g = hip.get_tally()
+    assert np.array_equal(t, f.tally2) and np.array_equal(g, f.gaps2)
+    hip.close()

@@ -37,8 +37,11 @@ def hipmod():
     return mia_amd
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["stepwise", "iterate"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_iterations_match_oracle(name, oracle, hipmod, tmp_path):
+def test_iterations_match_oracle(name, fused, oracle, hipmod, tmp_path):
+    """fused: the whole iteration through mia_hip_iterate (planner, cut line and event count stay on the device) instead of
+    mia_hip_realign + _cull + _tally + _consensus; everything below is checked the same way after either."""
     ref_fa, reads_fa, circ, pfile, hard, cc, sn = CASES[name][:7]
     adapter = CASES[name][7] if len(CASES[name]) > 7 else None
     if ":-" in reads_fa:            # drop one record from a committed FASTA
@@ -67,7 +70,7 @@ def test_iterations_match_oracle(name, oracle, hipmod, tmp_path):
     max_mult = 1
     for it in range(1, 8):
         oracle.ora_iterate(st, ref.encode(), it)
-        score, as_, ae, cons = hip_iteration(hip, ref, circ, lens, hard, sn, cc)
+        score, as_, ae, cons = hip_iteration(hip, ref, circ, lens, hard, sn, cc, fused=fused)
         prm, _ = hip.record_params()
         max_mult = max(max_mult, int(prm[:, 3].max()), int(prm[:, 7].max()))
         L = len(ref)
