@@ -305,6 +305,9 @@ int mia_hip_bx_counters(mia_hip_ctx *ctx, uint32_t *out32);
  * k_bx_plan, k_bx_values, k_bx_trace, k_tally_binned, k_pass1), accumulated milliseconds and launches since the last
  * reset; *n_stages = how many there are, at most cap are written.  Any pointer may be NULL. */
 int mia_hip_stage_stats(mia_hip_ctx *ctx, int reset, int32_t cap, const char **names, double *ms, int64_t *launches, int32_t *n_stages);
+/* Which stages are timed: bit k = stage k of mia_hip_stage_stats (default: all).  An event pair costs the stream a few
+ * microseconds of idle time; a caller that wants the duration of one kernel over a timed region switches the others off. */
+int mia_hip_set_stage_mask(mia_hip_ctx *ctx, uint32_t mask);
 /* The two ceilings the roofline is priced against, measured on this device: a streaming copy of
  * copy_bytes (read + written bytes per second, GB/s) and the issue rate of the DP kernels' own instruction mix
  * (v_max3_i32 / v_add_u32 chains, 10^9 wave64 instructions per second over the whole chip).  Either may be NULL. */

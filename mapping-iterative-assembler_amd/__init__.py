@@ -82,6 +82,7 @@ def _load():
     lib.mia_hip_get_ins_tally.argtypes = [vp, vp, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
     lib.mia_hip_stage_stats.argtypes = [vp, C.c_int, C.c_int32, vp, vp, vp, P(C.c_int32)]
+    lib.mia_hip_set_stage_mask.argtypes = [vp, C.c_uint32]
     lib.mia_hip_measure_peaks.argtypes = [vp, C.c_int64, P(C.c_double), P(C.c_double)]
     return lib
 
@@ -105,7 +106,7 @@ def exported_symbols():
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
-            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate"]
+            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask"]
 
 
 def _ptr(a):
@@ -416,6 +417,13 @@ class MiaHip:
         n = C.c_int32(0)
         self._chk(self._l.mia_hip_stage_stats(self._h, 1 if reset else 0, cap, names, ms, k, C.byref(n)))
         return {names[i].decode(): (ms[i], k[i]) for i in range(min(n.value, cap))}
+
+    STAGES = ["k_align_quad", "k_align_quad_plain", "k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_trace", "k_tally_binned", "k_pass1"]
+
+    def set_timed_stages(self, names=None):
+        """time only these stages (None: all); see mia_hip_set_stage_mask"""
+        mask = 0xFFFFFFFF if names is None else sum(1 << self.STAGES.index(n) for n in names)
+        self._chk(self._l.mia_hip_set_stage_mask(self._h, mask))
 
     def measure_peaks(self, copy_bytes=1 << 30):
         """(HBM copy GB/s, 10^9 wave64 VALU instructions/s) measured on this device"""

@@ -984,31 +984,6 @@ __global__ void k_ma_ins_events(MaRecords mr, int64_t n_ins, const int32_t* ins_
 // ---- insert columns (find_ins_cons, src/map_align.c:444-510) ----------------------
 // ins_off[pos] = sum of gaps[0..pos-1]; slot (pos, j) -> ins_off[pos] + j; 9 words per slot:
 // A,C,G,T counts, number of reads with a base there, scoreA..scoreT
-__global__ __launch_bounds__(1024) void k_gap_offsets(const int32_t* gaps, int32_t Lp, int32_t L, int32_t* ins_off, int32_t* total) {
-  // exclusive scan of gaps[1..L-1] by one 1024-thread block: each of the 16 wavefronts owns a contiguous region and walks
-  // it 64 columns at a time (coalesced loads, a wave prefix sum per step); the regions are joined through LDS.  (One
-  // thread per contiguous chunk, as this kernel began, is a serial chain of strided loads: 0.19 ms at 100 000 columns.)
-  __shared__ int32_t wsum[16];
-  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int per = ((Lp + 15) / 16 + 63) & ~63;
-  const int lo = w * per, hi = min(lo + per, Lp);
-  int32_t carry = 0;
-  for (int base = lo; base < hi; base += 64) {
-    const int p = base + lane;
-    const int32_t v = (p < hi && p > 0 && p < L) ? gaps[p] : 0;
-    int32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-    if (p < hi) ins_off[p] = carry + inc - v;
-    carry += __shfl(inc, 63);
-  }
-  if (lane == 0) wsum[w] = carry;
-  __syncthreads();
-  int32_t off = 0;
-  for (int k = 0; k < w; k++) off += wsum[k];
-  if (off) for (int p = lo + lane; p < hi; p += 64) ins_off[p] += off;
-  if (t == 1023) *total = off + wsum[15];
-}
 // cap: slots the insert buffers hold.  The host launches with the capacity left from the last call and reads the real total
 // back with the results; only if the total outgrew the capacity does it enlarge the buffers and run the insert part again.
 __global__ void k_ins_tally(const uint64_t* events, int32_t n_events, const int32_t* pssm2, const int32_t* ins_off,

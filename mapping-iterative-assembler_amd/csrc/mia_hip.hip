@@ -27,8 +27,20 @@ enum Stage { STG_TRACE = 0, STG_PLAIN, STG_FILTER, STG_BAND, STG_BX_PLAN, STG_BX
 static const char* const STAGE_NAMES[STG_COUNT] = {"k_align_quad", "k_align_quad_plain", "k_diag_filter", "k_band_align", "k_bx_plan",
                                                    "k_bx_values", "k_bx_trace", "k_tally_binned", "k_pass1"};
 
+// One device block for every small counter of an iteration (planner bins and header, filter / band-pipeline counters, link
+// count, cull and tally flags, insert-event count): one memset at the start of the alignment clears them all, and one copy
+// brings back what the host wants to see.  Offsets in 32-bit words.
+constexpr int CTRL_BINS = 0;                                   // [count N_BINS][off N_BINS][cursor N_BINS][wide_count][retry_count]
+constexpr int CTRL_HDR = (3 * N_BINS + 2 + 1) & ~1;            // PH_* (8-byte aligned: the DP kernels fetch their range as a pair)
+constexpr int CTRL_FILTER = CTRL_HDR + PH_WORDS;               // 4 words (k_diag_filter / k_band_align)
+constexpr int CTRL_LKN = CTRL_FILTER + 4, CTRL_CULLF = CTRL_LKN + 1, CTRL_NEV = CTRL_CULLF + 1, CTRL_TFLAGS = CTRL_NEV + 1;
+constexpr int CTRL_BXC = (CTRL_TFLAGS + 1 + 63) & ~63;         // BXC_* counters, a cache line each
+constexpr int CTRL_WORDS = CTRL_BXC + BXC_WORDS;
+
 struct mia_hip_ctx {
   int device = 0;
+  int32_t* d_ctrl = nullptr;
+  uint32_t stage_mask = ~0u;               // timed stages (mia_hip_set_stage_mask): an event pair costs the stream a few microseconds
   hipStream_t stream = nullptr;
   std::string err;
   // PSSMs (fwd, rc)
@@ -132,12 +144,14 @@ struct mia_hip_ctx {
   bool consensus_done = false;
   // mia_hip_iterate: one iteration with the planner's answers, the cut line and the insert-event count left on the device
   bool deferred = false;                    // align_all: no host round trip before its end
+  bool in_iterate = false;                  // the control block was cleared as a whole by the alignment's one memset
   int32_t* d_plan_hdr = nullptr;            // PH_* (k_plan_scan)
   const double* dev_cut = nullptr; double* d_cut_buf = nullptr;
   int min_len = 0;                          // shortest stored read
   std::vector<int32_t> h_len;               // read lengths on the host (the score-cut regression of reads of different lengths)
   char* d_ascii = nullptr; int64_t ascii_cap = 0;
-  char* d_cons = nullptr; int64_t cons_cap = 0; int32_t* d_cons_pos = nullptr; int64_t cons_pos_cap = 0; int32_t* d_cons_hdr = nullptr;
+  char* d_cons = nullptr; int64_t cons_cap = 0;              // result of an iteration: [CH_WORDS header][consensus string]
+  int32_t* d_cons_pos = nullptr; int64_t cons_pos_cap = 0;
   unsigned char* h_pin2 = nullptr; size_t pin2_bytes = 0;   // results of an iteration (header + consensus string)
   int64_t iter_fallbacks = 0;
   int64_t trim_escapes = 0;   // reads of the last mia_hip_trim call that took the exact scalar path
@@ -215,15 +229,23 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     const char* g = getenv("MIA_HIP_GRID_WAVES_PER_CU");
     if (g && atoi(g) > 0) ctx->grid_wgs = prop.multiProcessorCount * atoi(g);
   }
-  if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_bins, 3 * N_BINS + 2) ||
-      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1) || dev_alloc(ctx, &ctx->d_filter_n, 4) ||
+  if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_ctrl, CTRL_WORDS) ||
+      dev_alloc(ctx, &ctx->d_total, 1) || dev_alloc(ctx, &ctx->d_ins_total, 1) ||
       dev_alloc(ctx, &ctx->d_bx_sub, 2 * BX_SUB_WORDS) || dev_alloc(ctx, &ctx->d_bx_mrow, 2 * 31 * 4) || dev_alloc(ctx, &ctx->d_bx_loss, BX_LOSS_WORDS) ||
       dev_alloc(ctx, &ctx->d_bx_dl, BX_DL_WORDS) ||
-      dev_alloc(ctx, &ctx->d_bx_ctr, BXC_WORDS) || dev_alloc(ctx, &ctx->d_plan_hdr, PH_WORDS) || dev_alloc(ctx, &ctx->d_cut_buf, 2) ||
-      dev_alloc(ctx, &ctx->d_cons_hdr, CH_WORDS)) {
+      dev_alloc(ctx, &ctx->d_cut_buf, 2)) {
     delete ctx;
     return MIA_HIP_ERR_NOMEM;
   }
+  ctx->d_bins = ctx->d_ctrl + CTRL_BINS;
+  ctx->d_plan_hdr = ctx->d_ctrl + CTRL_HDR;
+  ctx->d_filter_n = reinterpret_cast<uint32_t*>(ctx->d_ctrl + CTRL_FILTER);
+  ctx->lk.n = ctx->d_ctrl + CTRL_LKN;
+  ctx->d_cull_flags = reinterpret_cast<uint32_t*>(ctx->d_ctrl + CTRL_CULLF);
+  ctx->tb.n_events = ctx->d_ctrl + CTRL_NEV;
+  ctx->tb.flags = reinterpret_cast<uint32_t*>(ctx->d_ctrl + CTRL_TFLAGS);
+  ctx->d_bx_ctr = reinterpret_cast<uint32_t*>(ctx->d_ctrl + CTRL_BXC);
+  if (hipMemset(ctx->d_ctrl, 0, CTRL_WORDS * 4) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
   if (hipHostMalloc((void**)&ctx->h_pin, mia_hip_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
   *out = ctx;
   return MIA_HIP_OK;
@@ -233,16 +255,15 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  void* ptrs[] = {ctx->d_pssm, ctx->d_packed, ctx->d_roff, ctx->d_len, ctx->d_rc, ctx->d_sk, ctx->d_as, ctx->d_ae, ctx->d_score,
+  void* ptrs[] = {ctx->d_ctrl, ctx->d_pssm, ctx->d_packed, ctx->d_roff, ctx->d_len, ctx->d_rc, ctx->d_sk, ctx->d_as, ctx->d_ae, ctx->d_score,
                   ctx->d_refstart, ctx->d_abr, ctx->d_status, ctx->d_cols, ctx->d_bin_of, ctx->d_list, ctx->d_wide_list, ctx->d_retry_list,
-                  ctx->d_bins, ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
-                  ctx->d_drop_b, ctx->tb.tally, ctx->tb.gaps, ctx->tb.events, ctx->tb.n_events, ctx->tb.flags, ctx->d_ins_off,
+                  ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
+                  ctx->d_drop_b, ctx->tb.tally, ctx->tb.events, ctx->d_ins_off,
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
-                  ctx->lk.rec, ctx->lk.n, ctx->d_cull_flags, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_filter_n, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs,
-                  ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_ctr,
-                  ctx->d_bx_slabs, ctx->d_plan_hdr, ctx->d_cut_buf, ctx->d_ascii, ctx->d_cons, ctx->d_cons_pos, ctx->d_cons_hdr};
+                  ctx->lk.rec, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs,
+                  ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_slabs, ctx->d_cut_buf, ctx->d_ascii, ctx->d_cons, ctx->d_cons_pos};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -389,7 +410,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
          dev_alloc(ctx, &ctx->si.mult, (size_t)ctx->slot_cap);
   ctx->lk.cap = (int32_t)std::min<int64_t>(n + 16, (int64_t)1 << 20);     // link index field of SlotInfo::writer: 20 bits
   if (ctx->lk.cap > (int32_t)LINK_NONE - 1) ctx->lk.cap = (int32_t)LINK_NONE - 1;
-  rcx |= dev_alloc(ctx, &ctx->lk.rec, (size_t)ctx->lk.cap * 4) | dev_alloc(ctx, &ctx->lk.n, 1) | dev_alloc(ctx, &ctx->d_cull_flags, 1);
+  rcx |= dev_alloc(ctx, &ctx->lk.rec, (size_t)ctx->lk.cap * 4);
   if (rcx) return MIA_HIP_ERR_NOMEM;
   HIPCHK(hipMemcpyAsync(ctx->d_packed, packed.data(), packed.size(), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_roff, roff.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -427,6 +448,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
 
 // an event pair for one launch of stage `st`; the start event is recorded here, the end event by stage_end
 static int stage_begin(mia_hip_ctx* ctx, Stage st) {
+  if (!((ctx->stage_mask >> st) & 1u)) return 0;
   if (ctx->ev_free.empty()) {
     hipEvent_t x, y;
     if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return -1;
@@ -438,7 +460,9 @@ static int stage_begin(mia_hip_ctx* ctx, Stage st) {
   (void)hipEventRecord(p.first, ctx->stream);
   return 0;
 }
-static void stage_end(mia_hip_ctx* ctx, Stage st) { (void)hipEventRecord(ctx->stg[st].pending.back().second, ctx->stream); }
+static void stage_end(mia_hip_ctx* ctx, Stage st) {
+  if (((ctx->stage_mask >> st) & 1u) && !ctx->stg[st].pending.empty()) (void)hipEventRecord(ctx->stg[st].pending.back().second, ctx->stream);
+}
 
 static void drain_events(mia_hip_ctx* ctx) {
   for (auto& t : ctx->stg) {
@@ -452,6 +476,14 @@ static void drain_events(mia_hip_ctx* ctx) {
     }
     t.pending.clear();
   }
+}
+
+extern "C" int mia_hip_set_stage_mask(mia_hip_ctx* ctx, uint32_t mask) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  drain_events(ctx);
+  ctx->stage_mask = mask;
+  return MIA_HIP_OK;
 }
 
 extern "C" int mia_hip_stage_stats(mia_hip_ctx* ctx, int reset, int32_t cap, const char** names, double* ms, int64_t* launches, int32_t* n_stages) {
@@ -626,7 +658,7 @@ static int align_all(mia_hip_ctx* ctx) {
   int32_t* d_off = ctx->d_bins + N_BINS;
   int32_t* d_cursor = ctx->d_bins + 2 * N_BINS;
   int32_t* d_wide_count = ctx->d_bins + 3 * N_BINS;
-  HIPCHK(hipMemsetAsync(ctx->d_bins, 0, (3 * N_BINS + 2) * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_ctrl, 0, (size_t)CTRL_WORDS * 4, ctx->stream));       // every counter of the iteration at once
   int32_t* d_retry_count = ctx->d_bins + 3 * N_BINS + 1;
   const int tb = 256, gb = (int)((n + (int64_t)tb * PLAN_PER - 1) / ((int64_t)tb * PLAN_PER));
   const int filter_ok = ctx->flat && ctx->use_filter && ctx->ref_mostly_bases;
@@ -646,7 +678,6 @@ static int align_all(mia_hip_ctx* ctx) {
     RefPlanes rp{ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap};
     hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
                        ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
-    HIPCHK(hipMemsetAsync(ctx->d_filter_n, 0, 16, ctx->stream));
     // the 10-mer table of this reference (rule (c) looks long clean stretches up instead of sliding over every diagonal;
     // the band plans are made of its anchors); not for the very long concatenated strings mia_hip_align_windows may be given
     KmerOcc ko{nullptr, nullptr};
@@ -704,7 +735,6 @@ static int align_all(mia_hip_ctx* ctx) {
         if (dev_alloc(ctx, &ctx->d_bx_slabs, (size_t)(slab_words * ctx->bx_trace_wgs * 4))) return MIA_HIP_ERR_NOMEM;
         ctx->bx_slab_cap = slab_words * ctx->bx_trace_wgs * 4;
       }
-      HIPCHK(hipMemsetAsync(ctx->d_bx_ctr, 0, BXC_WORDS * 4, ctx->stream));
       BxDev bd;
       bd.tab.sub = ctx->d_bx_sub; bd.tab.mrow = ctx->d_bx_mrow; bd.tab.loss = ctx->d_bx_loss; bd.tab.dl = ctx->d_bx_dl;
       bd.tab.min_m = ctx->bx_min_m; bd.tab.max_m = ctx->bx_max_m;
@@ -766,9 +796,8 @@ static int align_all(mia_hip_ctx* ctx) {
     auto ck = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[align_all deferred] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
     ck("plan_count");
     int32_t* d_retry_cnt = hdr + PH_RETRY + 1;
-    HIPCHK(hipMemsetAsync(hdr, 0, PH_WORDS * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ctx->stream));           // -1 = empty slot (quad padding)
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(64), 0, ctx->stream, d_count, d_off, hdr, 0);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ctx->stream, d_count, d_off, hdr, 0);
     hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
     ck("memsets");
     hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ctx->stream, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count);
@@ -795,7 +824,7 @@ static int align_all(mia_hip_ctx* ctx) {
         HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ctx->stream));
         hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_count);
         HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ctx->stream));
-        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(64), 0, ctx->stream, d_count, d_off, hdr, 1);
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ctx->stream, d_count, d_off, hdr, 1);
         hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
         ck("replan");
       }
@@ -822,32 +851,31 @@ static int align_all(mia_hip_ctx* ctx) {
       }
     }
     ck("retry");
-    // the one look at the counters
+    // the one look at the counters: wide / retry counts, the planner's header, filter and band-pipeline counters lie side by
+    // side in the control block
+    constexpr int C0 = CTRL_BINS + 3 * N_BINS, CN = CTRL_WORDS - C0;
     std::vector<int32_t> pageable;
     int32_t* hb;
     if (ctx->h_pin) hb = reinterpret_cast<int32_t*>(ctx->h_pin);
-    else { pageable.resize(PH_WORDS + 8 + BXC_WORDS); hb = pageable.data(); }
-    int32_t *h_hdr = hb, *h_misc = hb + PH_WORDS;
-    uint32_t* h_bxc = reinterpret_cast<uint32_t*>(hb + PH_WORDS + 8);
-    for (int k = 0; k < BXC_COUNTERS; k++) h_bxc[k * BXC_STRIDE] = 0;
-    h_misc[0] = h_misc[1] = h_misc[2] = 0;
-    HIPCHK(hipMemcpyAsync(h_hdr, hdr, PH_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(&h_misc[2], d_wide_count, 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (filtered) {
-      HIPCHK(hipMemcpyAsync(&h_misc[0], ctx->d_filter_n, 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipMemcpyAsync(&h_misc[1], ctx->d_filter_n + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
-      if (bx) HIPCHK(hipMemcpyAsync(h_bxc, ctx->d_bx_ctr, BXC_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    else { pageable.resize(CN); hb = pageable.data(); }
+    HIPCHK(hipMemcpyAsync(hb, ctx->d_ctrl + C0, (size_t)CN * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    ctx->filter_proven += (uint32_t)h_misc[0];
-    ctx->band_done += (uint32_t)h_misc[1];
+    const int32_t* h_hdr = hb + (CTRL_HDR - C0);
+    const uint32_t* h_filter = reinterpret_cast<const uint32_t*>(hb + (CTRL_FILTER - C0));
+    const uint32_t* h_bxc = reinterpret_cast<const uint32_t*>(hb + (CTRL_BXC - C0));
     ctx->filter_seen += n;
-    ctx->filter_proven += h_bxc[BXC_DONE_PLAN * BXC_STRIDE];
-    for (int k = 0; k < 3; k++) ctx->bx_done[k] += h_bxc[(BXC_DONE_PLAN + k) * BXC_STRIDE];
-    ctx->bx_seen += h_bxc[BXC_SEEN * BXC_STRIDE];
-    for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = h_bxc[k * BXC_STRIDE];
-    if (use_plain && ctx->use_quad) { ctx->plain_retried += h_hdr[PH_RETRIED_PLAIN]; }
-    const int32_t n_wide = h_misc[2];
+    if (filtered) {
+      ctx->filter_proven += h_filter[0];
+      ctx->band_done += h_filter[2];
+      if (bx) {
+        ctx->filter_proven += h_bxc[BXC_DONE_PLAN * BXC_STRIDE];
+        for (int k = 0; k < 3; k++) ctx->bx_done[k] += h_bxc[(BXC_DONE_PLAN + k) * BXC_STRIDE];
+        ctx->bx_seen += h_bxc[BXC_SEEN * BXC_STRIDE];
+      }
+    }
+    for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = bx ? h_bxc[k * BXC_STRIDE] : 0;
+    if (use_plain && ctx->use_quad) ctx->plain_retried += h_hdr[PH_RETRIED_PLAIN];
+    const int32_t n_wide = hb[0];
     if (n_wide > 0) { if (int rcw = run_wide(ctx, ref, n_wide)) return rcw; }
     ctx->aligned = true; ctx->culled = false; ctx->tallied = false; ctx->pre_cull_valid = false;
     return MIA_HIP_OK;
@@ -1094,8 +1122,7 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   ctx->slot_base = slot_base;
   ctx->si.base = slot_base;
   ctx->si.n_local_p = ctx->d_total;
-  HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_cull_flags, 0, 4, ctx->stream));
+  if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 8, ctx->stream));                     // link count, cull flags (neighbours in the control block)
   hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
                      ctx->read_base, ctx->d_cull_flags);
   hipLaunchKernelGGL(k_cull_mark, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
@@ -1354,8 +1381,7 @@ static int ensure_tally(mia_hip_ctx* ctx) {
   const int Lp = ctx->L + 1;
   if (Lp > ctx->tally_cap) {
     int rc = 0;
-    rc |= dev_alloc(ctx, &ctx->tb.tally, (size_t)TALLY_WORDS * Lp);
-    rc |= dev_alloc(ctx, &ctx->tb.gaps, (size_t)Lp);
+    rc |= dev_alloc(ctx, &ctx->tb.tally, (size_t)(TALLY_WORDS + 1) * Lp);      // tally[12][Lp], then gaps[Lp]: one memset clears both
     rc |= dev_alloc(ctx, &ctx->d_ins_off, (size_t)Lp);
     rc |= dev_alloc(ctx, &ctx->d_calls, (size_t)Lp);
     if (rc) return MIA_HIP_ERR_NOMEM;
@@ -1368,12 +1394,11 @@ static int ensure_tally(mia_hip_ctx* ctx) {
     if (cap > ((int64_t)1 << 30)) cap = (int64_t)1 << 30;
     int rc = 0;
     rc |= dev_alloc(ctx, &ctx->tb.events, (size_t)cap);
-    rc |= dev_alloc(ctx, &ctx->tb.n_events, 1);
-    rc |= dev_alloc(ctx, &ctx->tb.flags, 1);
     if (rc) return MIA_HIP_ERR_NOMEM;
     ctx->tb.cap_events = (int32_t)cap;
   }
   ctx->tb.Lp = Lp;
+  ctx->tb.gaps = ctx->tb.tally + (size_t)TALLY_WORDS * Lp;      // right behind the tally of THIS reference length
   return MIA_HIP_OK;
 }
 
@@ -1385,10 +1410,8 @@ static int tally_launch(mia_hip_ctx* ctx) {
   int rc = ensure_tally(ctx);
   if (rc) return rc;
   const int Lp = ctx->tb.Lp;
-  HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, (size_t)TALLY_WORDS * Lp * 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->tb.gaps, 0, (size_t)Lp * 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->tb.n_events, 0, 4, ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->tb.flags, 0, 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, (size_t)(TALLY_WORDS + 1) * Lp * 4, ctx->stream));      // tally and gaps
+  if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->tb.n_events, 0, 8, ctx->stream));              // event count, flags (neighbours in the control block)
   const int64_t n = ctx->rs.n;
   if (n > 0) {
     RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
@@ -1513,7 +1536,7 @@ extern "C" int mia_hip_set_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_
 static int consensus_launch(mia_hip_ctx* ctx, int cons_code, int64_t cap, bool columns, bool events_on_device) {
   const int L = ctx->L, Lp = ctx->tb.Lp;
   if (columns) {
-    hipLaunchKernelGGL(k_gap_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->tb.gaps, Lp, L, ctx->d_ins_off, ctx->d_ins_total);
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->tb.gaps, Lp, 1, L, ctx->d_ins_off, ctx->d_ins_total);   // ins_off[p] = gaps[1] + .. + gaps[p-1]
     hipLaunchKernelGGL(k_call_columns, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, cons_code, ctx->d_calls);
   }
   if (cap <= 0) return MIA_HIP_OK;
@@ -1630,6 +1653,8 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   checkpoint("reference");
   ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true; ctx->explicit_win = 0;
   // -- re-alignment (one wait, at its end)
+  struct IterScope { mia_hip_ctx* c; ~IterScope() { c->in_iterate = false; c->deferred = false; } } iter_scope{ctx};
+  ctx->in_iterate = true;
   ctx->deferred = true;
   const int rca = align_all(ctx);
   ctx->deferred = false;
@@ -1664,21 +1689,29 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   ctx->n_events_host = 0;
   if (int rcc = consensus_launch(ctx, cons_code, ctx->ins_tally_cap, true, true)) return rcc;
   checkpoint("consensus kernels");
-  const int64_t cons_cap = (int64_t)L + ctx->ins_tally_cap + 64;
-  if (cons_cap > ctx->cons_cap) {
-    if (dev_alloc(ctx, &ctx->d_cons, (size_t)cons_cap * 2)) return MIA_HIP_ERR_NOMEM;
-    ctx->cons_cap = cons_cap * 2;
+  const int64_t cons_cap = (int64_t)L + ctx->ins_tally_cap + 64;          // string bytes
+  const int64_t res_bytes = (int64_t)CH_WORDS * 4 + cons_cap;
+  if (res_bytes > ctx->cons_cap) {
+    if (dev_alloc(ctx, &ctx->d_cons, (size_t)res_bytes * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->cons_cap = res_bytes * 2;
   }
   if (Lp > ctx->cons_pos_cap) {
     if (dev_alloc(ctx, &ctx->d_cons_pos, (size_t)Lp * 2)) return MIA_HIP_ERR_NOMEM;
     ctx->cons_pos_cap = (int64_t)Lp * 2;
   }
-  hipLaunchKernelGGL(k_cons_assemble, dim3(1), dim3(1024), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls, (const int32_t*)ctx->tb.gaps,
-                     (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos, ctx->d_cons, (int32_t)cons_cap,
-                     ctx->d_cons_hdr, (const int32_t*)ctx->tb.n_events, (const uint32_t*)ctx->tb.flags, (const uint32_t*)ctx->d_cull_flags);
+  // the string consensus_assembly_string returns, put together on the device: characters per column, their prefix sums,
+  // a scatter; header and string come back in one copy
+  int32_t* d_res = reinterpret_cast<int32_t*>(ctx->d_cons);
+  hipLaunchKernelGGL(k_cons_count, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
+                     (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos);
+  hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->d_cons_pos, L, 0, L, ctx->d_cons_pos, d_res + CH_LEN);
+  hipLaunchKernelGGL(k_cons_scatter, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
+                     (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total,
+                     (const int32_t*)ctx->d_cons_pos, d_res, (int32_t)cons_cap, (const int32_t*)ctx->tb.n_events, (const uint32_t*)ctx->tb.flags,
+                     (const uint32_t*)ctx->d_cull_flags);
   HIPCHK(hipGetLastError());
   checkpoint("assemble");
-  const size_t need = (size_t)CH_WORDS * 4 + (size_t)cons_cap;
+  const size_t need = (size_t)res_bytes;
   if (need > ctx->pin2_bytes) {
     if (ctx->h_pin2) (void)hipHostFree(ctx->h_pin2);
     ctx->h_pin2 = nullptr; ctx->pin2_bytes = 0;
@@ -1687,9 +1720,9 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   }
   int32_t* h_hdr = reinterpret_cast<int32_t*>(ctx->h_pin2);
   char* h_str = reinterpret_cast<char*>(ctx->h_pin2) + CH_WORDS * 4;
-  HIPCHK(hipMemcpyAsync(h_hdr, ctx->d_cons_hdr, CH_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(h_str, ctx->d_cons, (size_t)cons_cap, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->h_pin2, ctx->d_cons, need, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->in_iterate = false;
   if (int rcf = tally_finish(ctx, (uint32_t)h_hdr[CH_N_EVENTS], (uint32_t)h_hdr[CH_TALLY_FLAGS], (uint32_t)h_hdr[CH_CULL_FLAGS])) return rcf;
   if (h_hdr[CH_OVERFLOW]) {
     // more insert columns than the buffers of the last call hold: the step-wise entry point enlarges them and calls again
@@ -1817,7 +1850,7 @@ extern "C" int mia_hip_ma_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_t
     ctx->tb.cap_events = (int32_t)std::min<int64_t>(ins_chars + 4096, INT32_MAX);
   }
   if (!ctx->tb.events) {
-    int rc0 = dev_alloc(ctx, &ctx->tb.events, (size_t)ins_chars + 4096) | dev_alloc(ctx, &ctx->tb.n_events, 1) | dev_alloc(ctx, &ctx->tb.flags, 1);
+    int rc0 = dev_alloc(ctx, &ctx->tb.events, (size_t)ins_chars + 4096);
     if (rc0) return MIA_HIP_ERR_NOMEM;
     ctx->tb.cap_events = (int32_t)std::min<int64_t>(ins_chars + 4096, INT32_MAX);
   }
@@ -2117,7 +2150,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   if (e == hipSuccess) {
     Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
     drain_events(ctx);                       // (nothing of an earlier call may sit in the pass-1 timer)
-    p1_timed = stage_begin(ctx, STG_PASS1) == 0;
+    p1_timed = ((ctx->stage_mask >> STG_PASS1) & 1u) && stage_begin(ctx, STG_PASS1) == 0;
     if (filtered) {
       const int64_t words = plane_words(len1);
       if (dev_alloc(ctx, &d_p1planes, (size_t)words * 6) || dev_alloc(ctx, &d_todo, (size_t)n) || dev_alloc(ctx, &d_ntodo, 1)) return MIA_HIP_ERR_NOMEM;

@@ -2,8 +2,9 @@
 // /root/reference/src/mia_main.c:915-964) run without the host in between (mia_hip_iterate):
 //   k_ref_encode      the new reference as the aligner sees it: base codes of the ASCII string, wrap appended
 //                     (make_ref_upper / add_ref_wrap / base2inx: src/mia.c:642-689, src/map_align.c:16-29)
-//   k_cons_assemble   the string consensus_assembly_string returns (src/mia.c:551-600): insert-column calls, then the
-//                     column's own call, '-' left out -- from the per-column calls, by one workgroup
+//   k_excl_scan       exclusive prefix sums by one workgroup (insert-column offsets from ref->gaps; string positions)
+//   k_cons_count / k_cons_scatter   the string consensus_assembly_string returns (src/mia.c:551-600): insert-column
+//                     calls, then the column's own call, '-' left out -- put together from the per-column calls
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,52 +24,71 @@ __global__ __launch_bounds__(256) void k_ref_encode(const char* ascii, int32_t L
 
 enum { CH_LEN = 0, CH_INS_TOTAL, CH_OVERFLOW, CH_N_EVENTS, CH_TALLY_FLAGS, CH_CULL_FLAGS, CH_WORDS = 8 };
 
-// One 1024-thread workgroup; each of its 16 wavefronts owns a contiguous stretch of columns and walks it 64 at a time.
-// pos[Lp]: scratch (where each column's characters start).  hdr[CH_LEN] = strlen, hdr[CH_INS_TOTAL] = insert columns in
-// all, hdr[CH_OVERFLOW] = 1 if the insert buffers (ins_cap slots) or `out` (out_cap bytes incl. the terminator) were too
-// small: the host then repeats the consensus with larger buffers.
-__global__ __launch_bounds__(1024) void k_cons_assemble(const char* calls, const char* ins_calls, const int32_t* gaps, const int32_t* ins_off, int32_t L,
-                                                         int32_t ins_cap, const int32_t* ins_total, int32_t* pos, char* out, int32_t out_cap, int32_t* hdr,
-                                                         const int32_t* n_events, const uint32_t* tally_flags, const uint32_t* cull_flags) {
+// Exclusive prefix sum of in[0..n) by ONE 1024-thread workgroup (in place is fine): each of the 16 wavefronts owns a
+// contiguous stretch and walks it 256 elements at a time (four per lane, a wave prefix sum per step); the stretches are
+// joined through LDS.  Elements outside [lo_valid, hi_valid) count as 0.  *total = the sum of everything.
+__global__ __launch_bounds__(1024) void k_excl_scan(const int32_t* in, int32_t n, int32_t lo_valid, int32_t hi_valid, int32_t* out, int32_t* total) {
   __shared__ int32_t wsum[16];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int per = ((L + 15) / 16 + 63) & ~63;
-  const int lo = w * per, hi = min(lo + per, L);
-  const int total = *ins_total;
-  const bool ins_ok = total <= ins_cap;
-  auto emits = [](char c) { return c != '-' && c != ' '; };
+  const int per = ((n + 15) / 16 + 255) & ~255;
+  const int lo = w * per, hi = min(lo + per, n);
   int32_t carry = 0;
-  for (int base = lo; base < hi; base += 64) {
-    const int p = base + lane;
-    int32_t v = 0;
-    if (p < hi) {
-      if (p > 0 && ins_ok) for (int j = 0; j < gaps[p]; j++) v += emits(ins_calls[ins_off[p] + j]) ? 1 : 0;
-      v += emits(calls[p]) ? 1 : 0;
-    }
-    int32_t inc = v;
+  for (int base = lo; base < hi; base += 256) {
+    const int p = base + lane * 4;
+    int32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int q = p + k; v[k] = (q < hi && q >= lo_valid && q < hi_valid) ? in[q] : 0; }
+    const int32_t s4 = v[0] + v[1] + v[2] + v[3];
+    int32_t inc = s4;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-    if (p < hi) pos[p] = carry + inc - v;
+    int32_t run = carry + inc - s4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (p + k < hi) out[p + k] = run; run += v[k]; }
     carry += __shfl(inc, 63);
   }
   if (lane == 0) wsum[w] = carry;
   __syncthreads();
-  int32_t off = 0, len = 0;
-  for (int k = 0; k < 16; k++) { if (k < w) off += wsum[k]; len += wsum[k]; }
-  const bool fits = len + 1 <= out_cap;
-  if (fits)
-    for (int p = lo + lane; p < hi; p += 64) {
-      int32_t o = pos[p] + off;
-      if (p > 0 && ins_ok) for (int j = 0; j < gaps[p]; j++) { const char c = ins_calls[ins_off[p] + j]; if (emits(c)) out[o++] = c; }
-      const char c = calls[p];
-      if (emits(c)) out[o++] = c;
-    }
-  if (t == 0) {
+  int32_t off = 0;
+  for (int k = 0; k < w; k++) off += wsum[k];
+  if (off) for (int p = lo + lane; p < hi; p += 64) out[p] += off;
+  if (t == 1023) *total = off + wsum[15];
+}
+
+__device__ __forceinline__ bool cons_emits(char c) { return c != '-' && c != ' '; }
+
+// characters column p contributes to the consensus string (src/mia.c:551-600): the calls of the insert columns before it,
+// then its own, '-' left out.  ins_total > ins_cap: the insert buffers are too small (the host repeats the call) -- then
+// only the columns' own calls are counted here.
+__global__ __launch_bounds__(256) void k_cons_count(const char* calls, const char* ins_calls, const int32_t* gaps, const int32_t* ins_off, int32_t L,
+                                                      int32_t ins_cap, const int32_t* ins_total, int32_t* cnt) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= L) return;
+  int32_t v = cons_emits(calls[p]) ? 1 : 0;
+  if (p > 0 && *ins_total <= ins_cap) for (int j = 0; j < gaps[p]; j++) v += cons_emits(ins_calls[ins_off[p] + j]) ? 1 : 0;
+  cnt[p] = v;
+}
+
+// res = [CH_WORDS header words][string]; pos = exclusive scan of k_cons_count's output, res[CH_LEN] = its total
+__global__ __launch_bounds__(256) void k_cons_scatter(const char* calls, const char* ins_calls, const int32_t* gaps, const int32_t* ins_off, int32_t L,
+                                                        int32_t ins_cap, const int32_t* ins_total, const int32_t* pos, int32_t* res, int32_t out_cap,
+                                                        const int32_t* n_events, const uint32_t* tally_flags, const uint32_t* cull_flags) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int total = *ins_total, len = res[CH_LEN];
+  const bool ins_ok = total <= ins_cap, fits = len + 1 <= out_cap;
+  char* out = reinterpret_cast<char*>(res + CH_WORDS);
+  if (p < L && fits) {
+    int32_t o = pos[p];
+    if (p > 0 && ins_ok) for (int j = 0; j < gaps[p]; j++) { const char c = ins_calls[ins_off[p] + j]; if (cons_emits(c)) out[o++] = c; }
+    const char c = calls[p];
+    if (cons_emits(c)) out[o++] = c;
+  }
+  if (p == 0) {
     if (fits) out[len] = 0;
-    hdr[CH_LEN] = len; hdr[CH_INS_TOTAL] = total; hdr[CH_OVERFLOW] = (ins_ok && fits) ? 0 : 1;
-    hdr[CH_N_EVENTS] = n_events ? *n_events : 0;
-    hdr[CH_TALLY_FLAGS] = tally_flags ? (int32_t)*tally_flags : 0;
-    hdr[CH_CULL_FLAGS] = cull_flags ? (int32_t)*cull_flags : 0;
+    res[CH_INS_TOTAL] = total; res[CH_OVERFLOW] = (ins_ok && fits) ? 0 : 1;
+    res[CH_N_EVENTS] = n_events ? *n_events : 0;
+    res[CH_TALLY_FLAGS] = tally_flags ? (int32_t)*tally_flags : 0;
+    res[CH_CULL_FLAGS] = cull_flags ? (int32_t)*cull_flags : 0;
   }
 }
 

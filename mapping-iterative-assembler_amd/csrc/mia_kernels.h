@@ -320,20 +320,33 @@ __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin
 //   hdr[PH_RETRY] = {0, reads whose path left the quad kernel's trace band} (k_align_quad counts into the second word)
 //   hdr[PH_TOTAL] = list entries in use (padding included)
 enum { PH_WIN = 0, PH_QUAD = 2 * N_CPL, PH_WIDE0 = PH_QUAD + 2, PH_RETRY = PH_WIDE0 + 2, PH_TOTAL = PH_RETRY + 2, PH_RETRIED_PLAIN, PH_WORDS = 16 };
-__global__ __launch_bounds__(64) void k_plan_scan(const int32_t* count, int32_t* off, int32_t* hdr, int32_t quads_only) {
-  if (threadIdx.x != 0) return;
-  int run = 0, retried = 0;
-  for (int b = 0; b < N_BINS; b++) {
-    off[b] = run;
-    run += b >= BIN_QUAD0 ? ((count[b] + 3) & ~3) : (quads_only ? 0 : count[b]);
-    if (b >= BIN_QUAD0) retried += count[b];
+__global__ __launch_bounds__(512) void k_plan_scan(const int32_t* count, int32_t* off, int32_t* hdr, int32_t quads_only) {
+  __shared__ int32_t sh[512];
+  const int b = threadIdx.x;
+  const int c = b < N_BINS ? count[b] : 0;
+  const int take = b >= N_BINS ? 0 : (b >= BIN_QUAD0 ? ((c + 3) & ~3) : (quads_only ? 0 : c));
+  sh[b] = take;
+  __syncthreads();
+  for (int o = 1; o < 512; o <<= 1) {
+    const int v = b >= o ? sh[b - o] : 0;
+    __syncthreads();
+    sh[b] += v;
+    __syncthreads();
   }
+  const int excl = sh[b] - take, run = sh[511];
+  if (b < N_BINS) off[b] = excl;
   if (!quads_only) {
-    for (int ci = 0; ci < N_CPL; ci++) { hdr[PH_WIN + 2 * ci] = off[ci]; hdr[PH_WIN + 2 * ci + 1] = count[ci]; }
-    hdr[PH_WIDE0] = off[BIN_WIDE]; hdr[PH_WIDE0 + 1] = count[BIN_WIDE];
-  } else hdr[PH_RETRIED_PLAIN] = retried;
-  hdr[PH_QUAD] = off[BIN_QUAD0]; hdr[PH_QUAD + 1] = (run - off[BIN_QUAD0]) / 4;
-  hdr[PH_TOTAL] = run;
+    if (b < N_CPL) { hdr[PH_WIN + 2 * b] = excl; hdr[PH_WIN + 2 * b + 1] = c; }
+    if (b == BIN_WIDE) { hdr[PH_WIDE0] = excl; hdr[PH_WIDE0 + 1] = c; }
+  }
+  if (b == BIN_QUAD0) { hdr[PH_QUAD] = excl; hdr[PH_QUAD + 1] = (run - excl) / 4; hdr[PH_TOTAL] = run; }
+  if (quads_only) {      // reads the values-only pass handed on: everything still in a quad bin
+    __syncthreads();
+    sh[b] = (b >= BIN_QUAD0 && b < N_BINS) ? c : 0;
+    __syncthreads();
+    for (int o = 256; o > 0; o >>= 1) { if (b < o) sh[b] += sh[b + o]; __syncthreads(); }
+    if (b == 0) hdr[PH_RETRIED_PLAIN] = sh[0];
+  }
 }
 // reads that need the exact kernel from the start: the head of wide_list (the DP kernels append their escapes behind)
 __global__ __launch_bounds__(256) void k_wide_seed(const int32_t* list, const int32_t* hdr, int32_t* wide_list, int32_t* wide_count) {
