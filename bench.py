@@ -143,9 +143,10 @@ def cpu_baseline(w, sample_per_proc=3000, iters=2):
 
 # ---- one iteration ------------------------------------------------------------------------------------------------
 class Pipeline:
-    def __init__(self, hip, w, world=1, rank=0, force_dist=False, breakdown=False):
+    def __init__(self, hip, w, world=1, rank=0, force_dist=False, breakdown=False, c_comm=False):
         self.hip, self.w, self.world, self.rank = hip, w, world, rank
         self.sharded = world > 1 or force_dist
+        self.c_comm = c_comm                    # the library's own RCCL communicator: iterate() does the exchanges itself
         self.phase = {} if breakdown else None
         hip.set_pssm(w["pssm"])
         hip.upload_reads(w["stored"].reshape(-1), w["offsets"], w["rc"], np.ones(w["n"], np.uint8), w["as_"], w["ae"])
@@ -160,7 +161,7 @@ class Pipeline:
 
     def step(self, cur_ref):
         hip, w = self.hip, self.w
-        if not self.sharded and self.phase is None and not os.environ.get("MIA_BENCH_STEPWISE"):
+        if (not self.sharded or self.c_comm) and self.phase is None and not os.environ.get("MIA_BENCH_STEPWISE"):
             # the product's own iteration call (mia_hip_iterate): planner, cut line and insert-event count stay on the device
             return hip.iterate(cur_ref, w["circular"])
         t0 = time.perf_counter()
@@ -396,10 +397,17 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (weak) or in the whole job (strong)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4), help="BASELINE.json configs[k] for the timed steps")
+    ap.add_argument("--coll", choices=("rccl", "torch"), default="rccl", help="N > 1: exchanges inside libmia_hip (RCCL) or in Python over torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="the headline line only (no configs2/configs4/pass1/myers sections)")
     ap.add_argument("--pmc-run", default=None, help="reduced run under rocprofv3 --pmc: only the timed steps of this config, plus k_peak_copy for the FETCH_SIZE calibration")
     a = ap.parse_args()
+
+    # stdout carries ONE line, the JSON of rank 0: whatever libraries print while they start up (RCCL's version banner ...)
+    # goes to stderr -- file descriptor 1 points there until the line is written
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -433,7 +441,18 @@ def main():
         peaks = {"hbm_copy_gbs": gbs, "valu_ginst_s": ginst,
                  "note": "k_peak_copy: 1 GiB streamed in and out, best of 5; k_peak_valu: v_max3_i32/v_add_u32 chains, 8 waves per SIMD, "
                          "wave64 instructions per second over the whole chip (csrc/mia_peak_kernels.h)"}
-    pipe = Pipeline(hip, w, world, rank, force_dist, breakdown=bool(os.environ.get("MIA_BENCH_BREAKDOWN")))
+    # several GPUs: the exchanges of a sharded iteration run inside the library (RCCL communicator made from an id that rank 0
+    # hands out through torch.distributed); --coll torch keeps them in Python over torch.distributed (dist.py) instead
+    c_comm, coll_note = False, None
+    if (world > 1 or force_dist) and a.coll == "rccl":
+        try:
+            box = [mia_amd.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            hip.comm_init(box[0], world, rank)
+            c_comm = True
+        except Exception as e:              # noqa: BLE001 -- a second way to run beats no number at all; the line says which one ran
+            coll_note = "library communicator failed (%s): collectives through torch.distributed" % e
+    pipe = Pipeline(hip, w, world, rank, force_dist, breakdown=bool(os.environ.get("MIA_BENCH_BREAKDOWN")), c_comm=c_comm)
 
     cur = w["ref"]
     dominant = None
@@ -503,6 +522,10 @@ def main():
             "roofline": roofline(stages, peaks, tag, stale),
             "read_fate": counts,
         }
+        if world > 1 or force_dist:
+            out["collectives"] = "libmia_hip (RCCL communicator, mia_hip_iterate)" if c_comm else "torch.distributed (mapping-iterative-assembler_amd/dist.py)"
+            if coll_note:
+                out["collectives_note"] = coll_note
         if peaks:
             out["peaks"] = peaks
         if pipe.phase:
@@ -533,7 +556,12 @@ def main():
         if world == 1 and not a.no_extras and a.config == 1:
             out["configs2"] = section_converge(mia_amd, local, 2, 1_000_000, 3, peaks, a.no_cpu_baseline)
             out["configs4"] = section_converge(mia_amd, local, 4, 500_000, 5, peaks, a.no_cpu_baseline)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    if c_comm and rank != 0:
+        hip.close()                         # (rank 0 closed its context above; the communicator goes with the context)
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

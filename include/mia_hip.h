@@ -207,9 +207,23 @@ int mia_hip_consensus(mia_hip_ctx *ctx, int cons_code, char *out, int64_t out_ca
  *   slope_intercept            -S / -N as {slope, intercept}, or NULL: the regression of find_fsdb_score_cut
  *   cons_code, out, out_cap, out_len   as mia_hip_consensus
  * Afterwards every getter (mia_hip_get_alignments, _scripts, _dropped, _record_params, _tally, _ins_tally) answers as
- * after the four separate calls.  Single context; a sharded run uses the separate calls with its collectives between. */
+ * after the four separate calls.
+ * SHARDED (a communicator attached by mia_hip_comm_init, the read store split in contiguous fsdb blocks, this context's
+ * first read announced by mia_hip_set_read_base): the call also does the exchanges between the GPUs, on its own stream --
+ * one all-gather of seven integers per rank before the cull (score sums, AlnSeq records, links), the link exchange if any
+ * rank has links, all-reduce(sum) of the tallies, all-reduce(max) of ref->gaps with the ranks' insert-event counts riding
+ * on it, all-gather of the insert events -- and every rank returns the same consensus.  Every rank must call it. */
 int mia_hip_iterate(mia_hip_ctx *ctx, const char *new_ref, int32_t ref_len, int circular, int32_t hard_cut,
                     const double *slope_intercept, int cons_code, char *out, int64_t out_cap, int64_t *out_len);
+
+/* ---- several GPUs: RCCL over xGMI -------------------------------------------
+ * One context per GPU (one process or one host thread each).  Rank 0 makes an id, hands the 128 bytes to the others by
+ * whatever channel the host program has (a pipe, MPI, a file, an in-process variable), and every rank calls
+ * mia_hip_comm_init -- together, as ncclCommInitRank wants.  librccl is opened at that moment (dlopen), not before. */
+#define MIA_HIP_COMM_ID_BYTES 128
+int mia_hip_comm_unique_id(void *id128);
+int mia_hip_comm_init(mia_hip_ctx *ctx, const void *id128, int32_t n_ranks, int32_t rank);
+int mia_hip_comm_destroy(mia_hip_ctx *ctx);
 
 /* ---- adapter trimming ---------------------------------------------------- */
 

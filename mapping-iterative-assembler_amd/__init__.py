@@ -83,6 +83,9 @@ def _load():
     lib.mia_hip_kernel_time.argtypes = [vp, C.c_int, P(C.c_double), P(C.c_int64)]
     lib.mia_hip_stage_stats.argtypes = [vp, C.c_int, C.c_int32, vp, vp, vp, P(C.c_int32)]
     lib.mia_hip_set_stage_mask.argtypes = [vp, C.c_uint32]
+    lib.mia_hip_comm_unique_id.argtypes = [vp]
+    lib.mia_hip_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    lib.mia_hip_comm_destroy.argtypes = [vp]
     lib.mia_hip_measure_peaks.argtypes = [vp, C.c_int64, P(C.c_double), P(C.c_double)]
     return lib
 
@@ -106,7 +109,7 @@ def exported_symbols():
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
-            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask"]
+            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask", "mia_hip_comm_unique_id", "mia_hip_comm_init", "mia_hip_comm_destroy"]
 
 
 def _ptr(a):
@@ -145,6 +148,14 @@ def read_pssm(path):
         p[d, 4, :] = -10
         k += 6
     return p
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0 calls it and passes the 128 bytes to the other ranks)"""
+    buf = C.create_string_buffer(128)
+    if lib().mia_hip_comm_unique_id(buf) != 0:
+        raise MiaHipError("mia_hip_comm_unique_id failed: librccl could not be opened")
+    return buf.raw
 
 
 class MiaHip:
@@ -419,6 +430,15 @@ class MiaHip:
         return {names[i].decode(): (ms[i], k[i]) for i in range(min(n.value, cap))}
 
     STAGES = ["k_align_quad", "k_align_quad_plain", "k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_trace", "k_tally_binned", "k_pass1"]
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        """attach an RCCL communicator (ncclCommInitRank on this context's GPU); unique_id: the 128 bytes of comm_unique_id()
+        of rank 0.  iterate() then does the exchanges of a sharded run itself."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._l.mia_hip_comm_init(self._h, buf, n_ranks, rank))
+
+    def comm_destroy(self):
+        self._chk(self._l.mia_hip_comm_destroy(self._h))
 
     def set_timed_stages(self, names=None):
         """time only these stages (None: all); see mia_hip_set_stage_mask"""

@@ -1,6 +1,8 @@
 // mia_hip.hip -- libmia_hip.so: C ABI (include/mia_hip.h) over the gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: librccl is opened at run time by mia_hip_comm_init (single-GPU runs never load it)
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -154,6 +156,13 @@ struct mia_hip_ctx {
   int32_t* d_cons_pos = nullptr; int64_t cons_pos_cap = 0;
   unsigned char* h_pin2 = nullptr; size_t pin2_bytes = 0;   // results of an iteration (header + consensus string)
   int64_t iter_fallbacks = 0;
+  // sharded runs: one context per GPU, RCCL over xGMI on the context's own stream (mia_hip_comm_init)
+  ncclComm_t comm = nullptr; int comm_ranks = 1, comm_rank = 0;
+  unsigned long long* d_gather = nullptr;   // [7 * ranks] score sums, record and link counts of every rank
+  int64_t* d_lstage = nullptr; int64_t lstage_cap = 0;       // links / insert events of all ranks, padded to the longest
+  int64_t* d_lmine = nullptr; int64_t lmine_cap = 0;
+  int64_t* d_lall = nullptr; int64_t lall_cap = 0;
+  int32_t* d_scores_all = nullptr; int64_t scores_all_cap = 0;
   int64_t trim_escapes = 0;   // reads of the last mia_hip_trim call that took the exact scalar path
   int64_t ins_total_host = 0;
 };
@@ -251,10 +260,12 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
   return MIA_HIP_OK;
 }
 
+extern "C" int mia_hip_comm_destroy(mia_hip_ctx* ctx);
 extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)mia_hip_comm_destroy(ctx);
   void* ptrs[] = {ctx->d_ctrl, ctx->d_pssm, ctx->d_packed, ctx->d_roff, ctx->d_len, ctx->d_rc, ctx->d_sk, ctx->d_as, ctx->d_ae, ctx->d_score,
                   ctx->d_refstart, ctx->d_abr, ctx->d_status, ctx->d_cols, ctx->d_bin_of, ctx->d_list, ctx->d_wide_list, ctx->d_retry_list,
                   ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
@@ -263,7 +274,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
                   ctx->lk.rec, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs,
-                  ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_slabs, ctx->d_cut_buf, ctx->d_ascii, ctx->d_cons, ctx->d_cons_pos};
+                  ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_slabs, ctx->d_cut_buf, ctx->d_ascii, ctx->d_cons, ctx->d_cons_pos, ctx->d_gather, ctx->d_lstage, ctx->d_lmine, ctx->d_lall, ctx->d_scores_all};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -1255,7 +1266,10 @@ extern "C" int mia_hip_set_slot_dropped(mia_hip_ctx* ctx, const uint8_t* flags, 
   if (!ctx || !flags || n_flags < 0) return MIA_HIP_ERR_ARG;
   if (!ctx->d_slot_dropped) { ctx->err = "upload_reads first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
-  if (n_flags > ctx->n_slots) n_flags = ctx->n_slots;
+  if (n_flags > ctx->n_slots) {            // a shard is handed the marks of ALL slots: its own lie behind the other ranks'
+    if (dev_alloc(ctx, &ctx->d_slot_dropped, (size_t)n_flags + 16)) return MIA_HIP_ERR_NOMEM;
+    ctx->n_slots = n_flags + 16;
+  }
   HIPCHK(hipMemsetAsync(ctx->d_slot_dropped, 0, (size_t)ctx->n_slots, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_slot_dropped, flags, (size_t)n_flags, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1381,7 +1395,7 @@ static int ensure_tally(mia_hip_ctx* ctx) {
   const int Lp = ctx->L + 1;
   if (Lp > ctx->tally_cap) {
     int rc = 0;
-    rc |= dev_alloc(ctx, &ctx->tb.tally, (size_t)(TALLY_WORDS + 1) * Lp);      // tally[12][Lp], then gaps[Lp]: one memset clears both
+    rc |= dev_alloc(ctx, &ctx->tb.tally, (size_t)(TALLY_WORDS + 1) * Lp + 256);      // tally[12][Lp], then gaps[Lp] (+ one slot per rank of a sharded run): one memset clears all
     rc |= dev_alloc(ctx, &ctx->d_ins_off, (size_t)Lp);
     rc |= dev_alloc(ctx, &ctx->d_calls, (size_t)Lp);
     if (rc) return MIA_HIP_ERR_NOMEM;
@@ -1410,7 +1424,7 @@ static int tally_launch(mia_hip_ctx* ctx) {
   int rc = ensure_tally(ctx);
   if (rc) return rc;
   const int Lp = ctx->tb.Lp;
-  HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, (size_t)(TALLY_WORDS + 1) * Lp * 4, ctx->stream));      // tally and gaps
+  HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, ((size_t)(TALLY_WORDS + 1) * Lp + 256) * 4, ctx->stream));      // tally, gaps, the ranks' event counts
   if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->tb.n_events, 0, 8, ctx->stream));              // event count, flags (neighbours in the control block)
   const int64_t n = ctx->rs.n;
   if (n > 0) {
@@ -1615,6 +1629,114 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   return MIA_HIP_OK;
 }
 
+// ---- RCCL (reads shard, tallies all-reduce) -----------------------------------------------
+// librccl is opened on first use; its entry points are looked up by name so that libmia_hip.so has no link-time dependency
+// on it (a single-GPU run never touches it).
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi* rccl_api(std::string* err) {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) { api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
+    if (api.lib) {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+      api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    }
+  }
+  if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) {
+    if (err) *err = "librccl.so.1 (RCCL) could not be opened";
+    return nullptr;
+  }
+  return &api;
+}
+#define NCCLCHK(call)                                                                                  \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) {                                                                           \
+      ctx->err = std::string(#call) + ": " + (rccl_api(nullptr) && rccl_api(nullptr)->GetErrorString ? rccl_api(nullptr)->GetErrorString(r_) : "RCCL error"); \
+      return MIA_HIP_ERR_DEVICE;                                                                       \
+    }                                                                                                  \
+  } while (0)
+
+extern "C" int mia_hip_comm_unique_id(void* id128) {
+  if (!id128) return MIA_HIP_ERR_ARG;
+  RcclApi* api = rccl_api(nullptr);
+  if (!api) return MIA_HIP_ERR_DEVICE;
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return MIA_HIP_ERR_DEVICE;
+  memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_comm_init(mia_hip_ctx* ctx, const void* id128, int32_t n_ranks, int32_t rank) {
+  if (!ctx || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return MIA_HIP_ERR_ARG;
+  if (ctx->comm) { ctx->err = "this context already has a communicator"; return MIA_HIP_ERR_STATE; }
+  RcclApi* api = rccl_api(&ctx->err);
+  if (!api) return MIA_HIP_ERR_DEVICE;
+  HIPCHK(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+  NCCLCHK(api->CommInitRank(&ctx->comm, n_ranks, id, rank));
+  ctx->comm_ranks = n_ranks; ctx->comm_rank = rank;
+  if (dev_alloc(ctx, &ctx->d_gather, (size_t)7 * n_ranks)) return MIA_HIP_ERR_NOMEM;
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_comm_destroy(mia_hip_ctx* ctx) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  if (!ctx->comm) return MIA_HIP_OK;
+  RcclApi* api = rccl_api(&ctx->err);
+  if (!api) return MIA_HIP_ERR_DEVICE;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)api->CommDestroy(ctx->comm);
+  ctx->comm = nullptr; ctx->comm_ranks = 1; ctx->comm_rank = 0;
+  return MIA_HIP_OK;
+}
+
+// all-gather of ragged 8-byte records (links: 4 words each; insert events: 1): every rank contributes counts[rank] * words
+// words from `mine`; the concatenation in rank order lands in ctx->d_lall.  counts are known on every rank.
+static int comm_gather_ragged(mia_hip_ctx* ctx, const int64_t* mine, const std::vector<int64_t>& counts, int words, int64_t* total_out) {
+  RcclApi* api = rccl_api(&ctx->err);
+  if (!api) return MIA_HIP_ERR_DEVICE;
+  const int W = ctx->comm_ranks;
+  int64_t mx = 0, total = 0;
+  for (int r = 0; r < W; r++) { mx = std::max(mx, counts[(size_t)r]); total += counts[(size_t)r]; }
+  *total_out = total;
+  if (total == 0) return MIA_HIP_OK;
+  const int64_t pad = mx * words;
+  if (pad > ctx->lmine_cap) { if (dev_alloc(ctx, &ctx->d_lmine, (size_t)pad * 2)) return MIA_HIP_ERR_NOMEM; ctx->lmine_cap = pad * 2; }
+  if (pad * W > ctx->lstage_cap) { if (dev_alloc(ctx, &ctx->d_lstage, (size_t)pad * W * 2)) return MIA_HIP_ERR_NOMEM; ctx->lstage_cap = pad * W * 2; }
+  if (total * words > ctx->lall_cap) { if (dev_alloc(ctx, &ctx->d_lall, (size_t)total * words * 2)) return MIA_HIP_ERR_NOMEM; ctx->lall_cap = total * words * 2; }
+  HIPCHK(hipMemsetAsync(ctx->d_lmine, 0, (size_t)pad * 8, ctx->stream));
+  const int64_t nm = counts[(size_t)ctx->comm_rank] * words;
+  if (nm > 0) HIPCHK(hipMemcpyAsync(ctx->d_lmine, mine, (size_t)nm * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  NCCLCHK(api->AllGather(ctx->d_lmine, ctx->d_lstage, (size_t)pad, ncclInt64, ctx->comm, ctx->stream));
+  int64_t o = 0;
+  for (int r = 0; r < W; r++) {
+    const int64_t c = counts[(size_t)r] * words;
+    if (c > 0) HIPCHK(hipMemcpyAsync(ctx->d_lall + o, ctx->d_lstage + (int64_t)r * pad, (size_t)c * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    o += c;
+  }
+  return MIA_HIP_OK;
+}
+
+__global__ void k_put_i32(int32_t* dst, const int32_t* src, int32_t clamp) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = min(*src, clamp); }
+
 // ---- one whole iteration -------------------------------------------------------------------------
 // reiterate_assembly + pop_smp_from_FSDB + cull_maln_from_fsdb + consensus_assembly_string (src/mia_main.c:931-963) as
 // one call: the same kernels as mia_hip_realign / _cull / _tally / _consensus, but what those entry points hand back to
@@ -1661,25 +1783,106 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   if (rca) return rca;
   checkpoint("realign");
   const int64_t n = ctx->rs.n;
+  // -- sharded run: what the cull needs from the other ranks -- their score sums (find_fsdb_score_cut's first pass), how
+  //    many AlnSeq records precede this rank's, how many links each cull will emit -- in ONE small all-gather
+  RcclApi* api = ctx->comm ? rccl_api(&ctx->err) : nullptr;
+  if (ctx->comm && !api) return MIA_HIP_ERR_DEVICE;
+  const int W = ctx->comm_ranks;
+  int64_t slot_base = 0, g_sums[5] = {0, 0, 0, 0, 0};
+  std::vector<int64_t> link_counts((size_t)W, 0), n_of((size_t)W, n);
+  if (ctx->comm) {
+    if (n == 0) { ctx->err = "iterate: every rank of a sharded run needs reads"; return MIA_HIP_ERR_ARG; }
+    if (!ctx->d_sums && dev_alloc(ctx, &ctx->d_sums, 8)) return MIA_HIP_ERR_NOMEM;
+    hipLaunchKernelGGL(k_score_sums_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_sums);
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus);
+    hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums, ctx->L, ctx->d_back_slot, ctx->d_front_slot0);
+    HIPCHK(hipGetLastError());
+    NCCLCHK(api->AllGather(ctx->d_sums, ctx->d_gather, 7, ncclUint64, ctx->comm, ctx->stream));
+    std::vector<int64_t> g((size_t)7 * W);
+    HIPCHK(hipMemcpyAsync(g.data(), ctx->d_gather, (size_t)7 * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    g_sums[3] = INT32_MAX; g_sums[4] = INT32_MIN;
+    for (int r = 0; r < W; r++) {
+      const int64_t* q = g.data() + (size_t)7 * r;
+      g_sums[0] += q[0]; g_sums[1] += q[1]; g_sums[2] += q[2];
+      g_sums[3] = std::min(g_sums[3], q[3]); g_sums[4] = std::max(g_sums[4], q[4]);
+      if (r < ctx->comm_rank) slot_base += q[5];
+      link_counts[(size_t)r] = q[6];
+    }
+  }
   // -- the cut line of find_fsdb_score_cut (src/fsdb.c:269-383)
   double slope = 0, intercept = 0;
+  const bool one_length = ctx->comm ? (g_sums[2] == 0 || g_sums[3] == g_sums[4]) : (ctx->min_len == ctx->max_len || n == 0);
   if (hard_cut > 0) {
   } else if (slope_intercept) {
     slope = slope_intercept[0]; intercept = slope_intercept[1];
-  } else if (ctx->min_len == ctx->max_len || n == 0) {
+  } else if (one_length) {
     // reads of one length: both regression sums are exactly 0, slope_bf = 0/0, and every derived quantity is that NaN
     // whatever the scores (mia_hip_score_cut_from_sums spells the arithmetic out) -- nothing to compute
     const double zero = 0.0;
     slope = intercept = zero / zero;
-  } else {
+  } else if (!ctx->comm) {
     // sums of products in IEEE double are order dependent: the reference's sequential order over the scores, on the host
     std::vector<int32_t> score((size_t)n);
     HIPCHK(hipMemcpyAsync(score.data(), ctx->d_score, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     mia_hip_score_cut(score.data(), ctx->h_len.data(), nullptr, n, &slope, &intercept);
+  } else {
+    // the same over the reads of ALL ranks in fsdb order (= rank order): scores and lengths gathered, the regression on
+    // every rank's host (identical inputs, identical arithmetic)
+    int32_t* d_nl = nullptr;                               // {n, score..., len...} of this rank, padded to the longest
+    ScopeFree sf; sf.watch((void**)&d_nl);
+    std::vector<int64_t> cnt1((size_t)W, 1);
+    int64_t tot = 0;
+    int64_t n64 = n;
+    int64_t* d_n = nullptr; sf.watch((void**)&d_n);
+    if (hipMalloc((void**)&d_n, 8) != hipSuccess) return MIA_HIP_ERR_NOMEM;
+    HIPCHK(hipMemcpyAsync(d_n, &n64, 8, hipMemcpyHostToDevice, ctx->stream));
+    if (int rcg = comm_gather_ragged(ctx, d_n, cnt1, 1, &tot)) return rcg;
+    HIPCHK(hipMemcpyAsync(n_of.data(), ctx->d_lall, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int64_t nmax = 0, ntot = 0;
+    for (int r = 0; r < W; r++) { nmax = std::max(nmax, n_of[(size_t)r]); ntot += n_of[(size_t)r]; }
+    if (hipMalloc((void**)&d_nl, (size_t)nmax * 2 * 4) != hipSuccess) return MIA_HIP_ERR_NOMEM;
+    if ((int64_t)W * nmax * 2 > ctx->scores_all_cap) {
+      if (dev_alloc(ctx, &ctx->d_scores_all, (size_t)W * nmax * 2)) return MIA_HIP_ERR_NOMEM;
+      ctx->scores_all_cap = (int64_t)W * nmax * 2;
+    }
+    HIPCHK(hipMemsetAsync(d_nl, 0, (size_t)nmax * 2 * 4, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_nl, ctx->d_score, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_nl + nmax, ctx->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(api->AllGather(d_nl, ctx->d_scores_all, (size_t)nmax * 2, ncclInt32, ctx->comm, ctx->stream));
+    std::vector<int32_t> all((size_t)W * nmax * 2), score((size_t)ntot), lens((size_t)ntot);
+    HIPCHK(hipMemcpyAsync(all.data(), ctx->d_scores_all, all.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int64_t o = 0;
+    for (int r = 0; r < W; r++) {
+      memcpy(score.data() + o, all.data() + (size_t)r * nmax * 2, (size_t)n_of[(size_t)r] * 4);
+      memcpy(lens.data() + o, all.data() + (size_t)r * nmax * 2 + nmax, (size_t)n_of[(size_t)r] * 4);
+      o += n_of[(size_t)r];
+    }
+    mia_hip_score_cut(score.data(), lens.data(), nullptr, ntot, &slope, &intercept);
   }
   if (!(hard_cut > 0) && slope <= 0) slope = 100.0;         // src/mia.c:440-442
-  if (int rcc = mia_hip_cull(ctx, hard_cut, slope, intercept, 0)) return rcc;
+  if (int rcc = mia_hip_cull(ctx, hard_cut, slope, intercept, slot_base)) return rcc;
+  if (ctx->comm) {
+    // links of formerly split reads (stale fs->back_asp, include/mia_hip.h) may point at slots of another rank: every rank
+    // gets all links, applies those that hit its own slots, the record lengths the readers need come back by a max-reduce
+    int64_t any = 0;
+    for (int r = 0; r < W; r++) any += link_counts[(size_t)r];
+    if (any > 0) {
+      int64_t* dl = nullptr; int64_t nl = 0, total = 0;
+      if (int rcl = mia_hip_links(ctx, &dl, &nl)) return rcl;
+      if (nl != link_counts[(size_t)ctx->comm_rank]) { ctx->err = "iterate: the cull emitted another number of links than the score sweep announced"; return MIA_HIP_ERR_STATE; }
+      if (int rcg = comm_gather_ragged(ctx, dl, link_counts, 4, &total)) return rcg;
+      if (int rcs = mia_hip_set_links(ctx, ctx->d_lall, total)) return rcs;
+      int32_t *dlen = nullptr, *dact = nullptr; int64_t nn = 0;
+      if (int rcl = mia_hip_link_lengths(ctx, &dlen, &dact, &nn)) return rcl;
+      NCCLCHK(api->AllReduce(dlen, dlen, (size_t)nn, ncclInt32, ncclMax, ctx->comm, ctx->stream));
+      NCCLCHK(api->AllReduce(dact, dact, (size_t)nn, ncclInt32, ncclMax, ctx->comm, ctx->stream));
+      if (int rcf = mia_hip_finish_links(ctx)) return rcf;
+    }
+  }
   checkpoint("cull");
   if (n == 0) { out[0] = 0; if (out_len) *out_len = 0; return MIA_HIP_OK; }
   // -- tally and consensus, queued back to back
@@ -1687,6 +1890,29 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   checkpoint("tally");
   const int Lp = ctx->tb.Lp;
   ctx->n_events_host = 0;
+  if (ctx->comm) {
+    // integer column tallies add up, ref->gaps is a maximum (src/mia.c:486-504); every rank's insert-event count rides on
+    // the max-reduce in W extra slots behind gaps; then the events themselves are gathered
+    if (W > 256) { ctx->err = "iterate: more than 256 ranks"; return MIA_HIP_ERR_ARG; }
+    hipLaunchKernelGGL(k_put_i32, dim3(1), dim3(1), 0, ctx->stream, ctx->tb.gaps + Lp + ctx->comm_rank, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events);
+    NCCLCHK(api->AllReduce(ctx->tb.tally, ctx->tb.tally, (size_t)TALLY_WORDS * Lp, ncclInt32, ncclSum, ctx->comm, ctx->stream));
+    NCCLCHK(api->AllReduce(ctx->tb.gaps, ctx->tb.gaps, (size_t)Lp + W, ncclInt32, ncclMax, ctx->comm, ctx->stream));
+    std::vector<int32_t> evc((size_t)W);
+    HIPCHK(hipMemcpyAsync(evc.data(), ctx->tb.gaps + Lp, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> ev_counts((size_t)W);
+    for (int r = 0; r < W; r++) ev_counts[(size_t)r] = evc[(size_t)r];
+    int64_t total_ev = 0;
+    if (int rcg = comm_gather_ragged(ctx, reinterpret_cast<const int64_t*>(ctx->tb.events), ev_counts, 1, &total_ev)) return rcg;
+    if (total_ev > ctx->tb.cap_events) {
+      if (dev_alloc(ctx, &ctx->tb.events, (size_t)total_ev + 4096)) return MIA_HIP_ERR_NOMEM;
+      ctx->tb.cap_events = (int32_t)std::min<int64_t>(total_ev + 4096, INT32_MAX);
+    }
+    if (total_ev > 0) HIPCHK(hipMemcpyAsync(ctx->tb.events, ctx->d_lall, (size_t)total_ev * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    const int32_t te = (int32_t)total_ev;
+    HIPCHK(hipMemcpyAsync(ctx->tb.n_events, &te, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));           // (te is a stack local)
+  }
   if (int rcc = consensus_launch(ctx, cons_code, ctx->ins_tally_cap, true, true)) return rcc;
   checkpoint("consensus kernels");
   const int64_t cons_cap = (int64_t)L + ctx->ins_tally_cap + 64;          // string bytes

@@ -1,0 +1,195 @@
+"""Sharded iteration on the real kernels.
+
+* test_one_rank_communicator_changes_nothing: mia_hip_iterate with an RCCL communicator of one rank attached (every
+  exchange of the sharded path runs: the all-gather of the score sums, the link exchange, both all-reduces, the event
+  gather) gives what it gives without one, iteration by iteration, on the adapter-trimmed set whose stale back_asp
+  pointers produce real links.
+* test_two_contexts_exchange_real_links: the read store split in two contiguous fsdb blocks, one context each (what two
+  ranks hold), driven through mia_hip_links -> mia_hip_set_links -> mia_hip_link_lengths -> mia_hip_finish_links with
+  host-side reductions standing in for RCCL (one GPU here): scores, dropped bits, depth-code parameters, multiplicities,
+  summed tallies, maximum gaps and the consensus equal the single context's, every iteration.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ctypes as oc  # noqa: F401
+from mia_flow import fsdb_arrays, oracle_after_pass1, pssm_array
+
+pytestmark = pytest.mark.gpu
+
+ADAPTER = "GTCAGACACGCAACAGG"
+
+
+def setup(oracle):
+    st, opts, anc = oracle_after_pass1(oracle, "mt311.fa", "adapt.fa", True, 12, None, 0, 1, None, None, ADAPTER)
+    fs = fsdb_arrays(oracle, st)
+    n_slots1 = oracle.ora_num_culled(st)
+    dropped1 = np.array([oracle.ora_slot_at(st, i).contents.dropped for i in range(n_slots1)], np.uint8)
+    L0 = oracle.ora_ref_len(st)
+    ref = oracle.ora_ref_seq(st)[:L0].decode()
+    return fs, anc, dropped1, ref
+
+
+def context(mod, fs, anc, dropped1, lo=0, hi=None):
+    hi = fs["n"] if hi is None else hi
+    hip = mod.MiaHip(0)
+    hip.set_pssm(pssm_array(anc))
+    off = fs["offsets"][lo:hi + 1] - fs["offsets"][lo]
+    bases = fs["bases"][fs["offsets"][lo]:fs["offsets"][hi]]
+    hip.upload_reads(bases, off, fs["rc"][lo:hi], fs["sk"][lo:hi], fs["as_"][lo:hi], fs["ae"][lo:hi])
+    hip.set_slot_dropped(dropped1)                                  # marks of ALL slots (global slot numbers)
+    hip.set_pass1_state(fs["front"][lo:hi], fs["back"][lo:hi], fs["score"][lo:hi])
+    hip.set_read_base(lo)
+    return hip
+
+
+def test_one_rank_communicator_changes_nothing(oracle):
+    import mia_amd
+    fs, anc, dropped1, ref0 = setup(oracle)
+    a = context(mia_amd, fs, anc, dropped1)
+    b = context(mia_amd, fs, anc, dropped1)
+    b.comm_init(mia_amd.comm_unique_id(), 1, 0)
+    ref, links_seen = ref0, 0
+    for it in range(1, 8):
+        ca, cb = a.iterate(ref, True), b.iterate(ref, True)
+        assert ca == cb, it
+        for x, y in zip(a.alignments(), b.alignments()):
+            assert np.array_equal(x, y), it
+        for x, y in zip(a.dropped(), b.dropped()):
+            assert np.array_equal(x, y), it
+        pa, pb = a.record_params(), b.record_params()
+        assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]), it
+        links_seen = max(links_seen, int(pa[0][:, 3].max()), int(pa[0][:, 7].max()))
+        ta, tb = a.get_tally(), b.get_tally()
+        assert np.array_equal(ta[0], tb[0]) and np.array_equal(ta[1], tb[1]), it
+        if ca == ref:
+            break
+        ref = ca
+    assert links_seen == 2          # some record was listed twice through a stale back_asp: the link exchange had work
+    b.comm_destroy()
+    a.close(); b.close()
+
+
+class Hip:
+    """hipMalloc / hipMemcpy through ctypes: the test plays the collectives between two contexts of one process"""
+
+    def __init__(self):
+        self.l = C.CDLL("libamdhip64.so")
+        self.l.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.l.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.l.hipFree.argtypes = [C.c_void_p]
+
+    def to_host(self, dptr, n, dtype):
+        out = np.empty(n, dtype)
+        if n:
+            assert self.l.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), out.nbytes, 2) == 0
+        return out
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        assert self.l.hipMalloc(C.byref(p), max(arr.nbytes, 16)) == 0
+        if arr.nbytes:
+            assert self.l.hipMemcpy(p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1) == 0
+        return p.value
+
+    def write(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes:
+            assert self.l.hipMemcpy(C.c_void_p(dptr), arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1) == 0
+
+
+def test_two_contexts_exchange_real_links(oracle):
+    import mia_amd
+    hipapi = Hip()
+    fs, anc, dropped1, ref0 = setup(oracle)
+    n = fs["n"]
+    lens = (fs["offsets"][1:] - fs["offsets"][:-1]).astype(np.int32)
+    whole = context(mia_amd, fs, anc, dropped1)
+    cuts = [0, n // 2, n]
+    # put the boundary where it hurts: between a formerly split read and the slot its stale pointer addresses, if possible
+    back = fs["back"]
+    hot = [i for i in range(1, n - 1) if back[i] >= 0]
+    if hot:
+        cuts[1] = hot[len(hot) // 2]
+    parts = [context(mia_amd, fs, anc, dropped1, cuts[k], cuts[k + 1]) for k in range(2)]
+    ref, crossed, any_links = ref0, False, False
+    for it in range(1, 8):
+        cons_whole = whole.iterate(ref, True)
+        # --- the two "ranks", step by step
+        for h in parts:
+            h.realign(ref, True)
+        scores = np.concatenate([h.scores() for h in parts])
+        assert np.array_equal(scores, whole.alignments()[0]), it
+        slope, intercept = parts[0].score_cut(scores, lens)             # find_fsdb_score_cut over ALL reads, fsdb order
+        if slope <= 0:
+            slope = 100.0
+        counts = []
+        for h in parts:
+            h.score_sums()
+            counts.append(h.pre_cull_counts())                          # (records, links) before the cull
+        base = 0
+        for h, (nrec, _) in zip(parts, counts):
+            h.cull(0, slope, intercept, base)
+            base += nrec
+        links = []
+        for h, (_, nl) in zip(parts, counts):
+            ptr, cnt = h.links()
+            assert cnt == nl, it
+            links.append(hipapi.to_host(ptr, 4 * cnt, np.int64).reshape(-1, 4))
+        all_links = np.concatenate(links) if links else np.zeros((0, 4), np.int64)
+        if len(all_links):
+            any_links = True
+            # does some link address a slot of the other shard?
+            for k, lk in enumerate(links):
+                lo = sum(c[0] for c in counts[:k])
+                hi = lo + counts[k][0]
+                crossed = crossed or bool(((lk[:, 1] < lo) | (lk[:, 1] >= hi)).any())
+            d_all = hipapi.to_device(all_links.reshape(-1))
+            lens_bufs = []
+            for h in parts:
+                h.set_links(d_all, len(all_links))
+                lp, ap, ln = h.link_lengths()
+                assert ln == len(all_links)
+                lens_bufs.append((lp, ap, hipapi.to_host(lp, ln, np.int32), hipapi.to_host(ap, ln, np.int32)))
+            mx_len = np.maximum(lens_bufs[0][2], lens_bufs[1][2])          # all-reduce(max)
+            mx_act = np.maximum(lens_bufs[0][3], lens_bufs[1][3])
+            for h, (lp, ap, _, _) in zip(parts, lens_bufs):
+                hipapi.write(lp, mx_len)
+                hipapi.write(ap, mx_act)
+                h.finish_links()
+        # dropped bits and depth-code parameters of every read
+        dF = np.concatenate([h.dropped()[0] for h in parts])
+        dB = np.concatenate([h.dropped()[1] for h in parts])
+        wF, wB = whole.dropped()
+        assert np.array_equal(dF, wF) and np.array_equal(dB, wB), it
+        prm = np.concatenate([h.record_params()[0] for h in parts])
+        assert np.array_equal(prm, whole.record_params()[0]), it
+        # tallies add, gaps combine by maximum, insert events concatenate
+        tallies, events = [], []
+        for h in parts:
+            h.tally()
+            tallies.append(h.get_tally())
+            pe, ne = h.ins_events()
+            events.append(hipapi.to_host(pe, ne, np.uint64))
+        t = tallies[0][0] + tallies[1][0]
+        g = np.maximum(tallies[0][1], tallies[1][1])
+        wt, wg = whole.get_tally()
+        assert np.array_equal(t, wt) and np.array_equal(g, wg), it
+        ev = np.concatenate(events)
+        d_ev = hipapi.to_device(ev)
+        cons = []
+        for h in parts:
+            h.set_tally(t, g)
+            h.set_ins_events(d_ev, len(ev))
+            cons.append(h.consensus(1))
+        assert cons[0] == cons[1] == cons_whole, it
+        if cons_whole == ref:
+            break
+        ref = cons_whole
+    assert any_links
+    for h in parts + [whole]:
+        h.close()
