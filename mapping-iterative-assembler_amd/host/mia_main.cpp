@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <charconv>
 #include <chrono>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -210,20 +211,22 @@ void run_parallel(int T, F&& fn) {
 
 void die(mia_hip_ctx* g, const char* what) {
   fprintf(stderr, "%s: %s\n", what, g ? mia_hip_last_error(g) : "no context");
-  exit(1);
+  fflush(stderr);
+  _exit(1);      // (may be called from one of several per-GPU threads: no static destructors under the others' feet)
 }
 
 void help() {
   printf("\n\nMIA -- Mapping Iterativ Assembler V 1.0 (MI355X build, libmia_hip)\n"
          "usage: mia_hip -r <reference fasta> -f <fasta/fastq reads> [-m maln root] [-s matrix] [-c] [-i|-n]\n"
-         "               [-p cons code] [-H hard score cut] [-S slope -N intercept] [-k kmer] [-M] [-F] [-g gpu]\n");
+         "               [-p cons code] [-H hard score cut] [-S slope -N intercept] [-k kmer] [-M] [-F] [-g gpu[,gpu...]]\n");
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
   std::string maln_root = "assembly.maln.iter", ref_fn, frag_fn;
-  int hard_cut = 0, circular = 0, iterate = 1, final_only = 0, score_cut_set = 0, kmer = -1, soft_mask = 0, cc = 1, any = 0, gpu = 0;
+  int hard_cut = 0, circular = 0, iterate = 1, final_only = 0, score_cut_set = 0, kmer = -1, soft_mask = 0, cc = 1, any = 0;
+  std::vector<int> gpus{0};             // -g 0  or  -g 0,1,2,3: the read store is split over these GPUs (contiguous fsdb blocks)
   double slope = 200.0, intercept = 0.0;
   int do_adapter_trimming = 0;
   // src/mia_main.c:462-466: the two built-in adapters, Neandertal by default
@@ -252,7 +255,12 @@ int main(int argc, char** argv) {
       case 'S': slope = atof(optarg); score_cut_set = 1; break;
       case 'N': intercept = atof(optarg); score_cut_set = 1; break;
       case 'F': final_only = 1; break;
-      case 'g': gpu = atoi(optarg); break;
+      case 'g': {
+        gpus.clear();
+        for (const char* q = optarg; *q;) { gpus.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+        if (gpus.empty()) gpus.push_back(0);
+        break;
+      }
       case 'T': do_adapter_trimming = 1; break;
       case 'a':                                        // src/mia_main.c:558-578
         if (strlen(optarg) > 127) { fprintf(stderr, "That adapter is too big!\nMIA will use the standard adapter.\n"); adapter = stand_adapt; }
@@ -284,9 +292,21 @@ int main(int argc, char** argv) {
   Ref ref;
   if (!read_fasta_ref(ref_fn.c_str(), &ref)) { fprintf(stderr, "Problem reading reference sequence file %s\n", ref_fn.c_str()); exit(1); }
 
-  mia_hip_ctx* g = nullptr;
-  if (mia_hip_create(&g, gpu) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: no usable MI355X (gfx950) device %d; there is no CPU fallback\n", gpu); exit(1); }
-  if (mia_hip_set_pssm(g, &anc.sm[0][0][0], &rcanc.sm[0][0][0]) != MIA_HIP_OK) die(g, "set_pssm");
+  // one context per GPU; every per-read step below runs on all of them at once, each on its contiguous share of the reads
+  const int NG = (int)gpus.size();
+  std::vector<mia_hip_ctx*> G((size_t)NG, nullptr);
+  for (int k = 0; k < NG; k++) {
+    if (mia_hip_create(&G[(size_t)k], gpus[(size_t)k]) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: no usable MI355X (gfx950) device %d; there is no CPU fallback\n", gpus[(size_t)k]); exit(1); }
+    if (mia_hip_set_pssm(G[(size_t)k], &anc.sm[0][0][0], &rcanc.sm[0][0][0]) != MIA_HIP_OK) die(G[(size_t)k], "set_pssm");
+  }
+  mia_hip_ctx* g = G[0];
+  auto on_gpus = [&](const std::function<void(int)>& fn) {      // fn(k) for every GPU k, concurrently (the collectives need that)
+    if (NG == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < NG; k++) th.emplace_back(fn, k);
+    for (auto& t : th) t.join();
+  };
+  auto share = [&](int64_t total, int k) { return total * k / NG; };    // first item of GPU k's contiguous share
 
   // ---- read the fragments (read_next_seq loop, src/mia_main.c:759)
   FILE* ff = fopen(frag_fn.c_str(), "r");
@@ -317,7 +337,14 @@ int main(int argc, char** argv) {
       if (!reads[i].seq.empty()) { tb += reads[i].seq; toff.push_back((int64_t)tb.size()); tsrc.push_back(i); }
     std::vector<uint8_t> tr(tsrc.size());
     std::vector<int32_t> tp(tsrc.size());
-    if (!tsrc.empty() && mia_hip_trim(g, adapter.c_str(), (int64_t)tsrc.size(), tb.data(), toff.data(), tr.data(), tp.data()) != MIA_HIP_OK) die(g, "trim");
+    const int64_t nt = (int64_t)tsrc.size();
+    on_gpus([&](int k) {
+      const int64_t lo = share(nt, k), hi = share(nt, k + 1);
+      if (hi <= lo) return;
+      std::vector<int64_t> o2((size_t)(hi - lo) + 1);
+      for (int64_t q = lo; q <= hi; q++) o2[(size_t)(q - lo)] = toff[(size_t)q] - toff[(size_t)lo];
+      if (mia_hip_trim(G[(size_t)k], adapter.c_str(), hi - lo, tb.data() + toff[(size_t)lo], o2.data(), tr.data() + lo, tp.data() + lo) != MIA_HIP_OK) die(G[(size_t)k], "trim");
+    });
     int emptied = 0;
     for (size_t k = 0; k < tsrc.size(); k++) {
       if (!tr[k]) continue;
@@ -340,8 +367,14 @@ int main(int argc, char** argv) {
   const int64_t n1 = (int64_t)src.size();
   std::vector<int32_t> p_score((size_t)n1), p_as((size_t)n1), p_ae((size_t)n1);
   std::vector<uint8_t> p_rc((size_t)n1), p_fl((size_t)n1);
-  if (n1 > 0 && mia_hip_pass1(g, ref.seq.c_str(), (int32_t)ref.seq.size(), circular, kmer, soft_mask, n1, bases.data(), off.data(),
-                              p_score.data(), p_rc.data(), p_as.data(), p_ae.data(), p_fl.data()) != MIA_HIP_OK) die(g, "pass1");
+  on_gpus([&](int k) {
+    const int64_t lo = share(n1, k), hi = share(n1, k + 1);
+    if (hi <= lo) return;
+    std::vector<int64_t> o2((size_t)(hi - lo) + 1);
+    for (int64_t q = lo; q <= hi; q++) o2[(size_t)(q - lo)] = off[(size_t)q] - off[(size_t)lo];
+    if (mia_hip_pass1(G[(size_t)k], ref.seq.c_str(), (int32_t)ref.seq.size(), circular, kmer, soft_mask, hi - lo, bases.data() + off[(size_t)lo], o2.data(),
+                      p_score.data() + lo, p_rc.data() + lo, p_as.data() + lo, p_ae.data() + lo, p_fl.data() + lo) != MIA_HIP_OK) die(G[(size_t)k], "pass1");
+  });
   lap("pass 1");
   fprintf(stderr, "\n");
 
@@ -370,7 +403,8 @@ int main(int argc, char** argv) {
   }
   const int n = (int)fsdb.size();
   const int pass1_records = (int)slot_dropped.size();   // culled_maln->size, frozen here (src/mia.c:54)
-  if (n == 0) { fprintf(stderr, "No sequence aligned to the reference with a score of at least 2000.\n"); mia_hip_destroy(g); exit(0); }
+  if (n == 0) { fprintf(stderr, "No sequence aligned to the reference with a score of at least 2000.\n"); for (auto* c : G) mia_hip_destroy(c); exit(0); }
+  if (NG > n) { fprintf(stderr, "mia_hip: more GPUs (%d) than reads in the store (%d)\n", NG, n); exit(1); }
   (void)n_unknown;   // strand-unknown reads (score exactly 2000) stay in the fsdb: their stale pointers are followed as the reference does
   std::vector<int32_t> len((size_t)n), score((size_t)n), as((size_t)n), ae((size_t)n);
   std::vector<int64_t> f0((size_t)n, -1);     // pass-1 front slot of every read
@@ -382,8 +416,8 @@ int main(int argc, char** argv) {
     if (hard_cut <= 0 && !score_cut_set) {
       // the regression's first pass (integer sums) runs on the device; with equally long reads that is all of it
       int64_t sums5[5];
-      if (!on_device || mia_hip_score_sums(g, sums5) != MIA_HIP_OK || mia_hip_score_cut_from_sums(sums5, s, ic) != 0)
-        mia_hip_score_cut(score.data(), len.data(), NULL, n, s, ic);
+      (void)sums5;
+      mia_hip_score_cut(score.data(), len.data(), NULL, n, s, ic);
     }
     if (*s <= 0) *s = 100.0;
   };
@@ -401,22 +435,39 @@ int main(int argc, char** argv) {
   // clean_FSDB (src/mia.c:400-406) cannot remove anything: every kept read scores >= 2000
 
   lap("read store");
-  // ---- upload the read store
+  // ---- upload the read store: GPU k holds the contiguous fsdb block [lo_k, hi_k); AlnSeq slot numbers stay global
+  std::vector<int> lo_of((size_t)NG + 1);
+  for (int k = 0; k <= NG; k++) lo_of[(size_t)k] = (int)share(n, k);
   {
-    std::vector<int64_t> o2((size_t)n + 1, 0);
-    std::string b2;
-    std::vector<uint8_t> rc((size_t)n), sk((size_t)n);
-    for (int i = 0; i < n; i++) {
-      b2 += fsdb[i].seq; o2[i + 1] = (int64_t)b2.size();
-      rc[i] = (uint8_t)fsdb[i].rc; sk[i] = (uint8_t)fsdb[i].strand_known; as[i] = fsdb[i].as; ae[i] = fsdb[i].ae;
-    }
-    if (mia_hip_upload_reads(g, n, b2.data(), o2.data(), rc.data(), sk.data(), as.data(), ae.data()) != MIA_HIP_OK) die(g, "upload_reads");
-    if (mia_hip_set_slot_dropped(g, slot_dropped.data(), (int64_t)slot_dropped.size()) != MIA_HIP_OK) die(g, "set_slot_dropped");
-    // fs->front_asp / back_asp and fs->score after pass 1 (src/mia.c:1619-1653): the back slot of every split read, and
-    // for strand-unknown reads (never re-aligned, src/mia_main.c:178) also the front slot and the score
     std::vector<int64_t> b0((size_t)n, -1);
-    for (int i = 0; i < n; i++) { f0[(size_t)i] = first_slot[i]; if (n_slots[i] == 2) b0[(size_t)i] = (int64_t)first_slot[i] + 1; }
-    if (mia_hip_set_pass1_state(g, f0.data(), b0.data(), score.data()) != MIA_HIP_OK) die(g, "set_pass1_state");
+    for (int i = 0; i < n; i++) {
+      as[i] = fsdb[i].as; ae[i] = fsdb[i].ae;
+      f0[(size_t)i] = first_slot[i];
+      if (n_slots[i] == 2) b0[(size_t)i] = (int64_t)first_slot[i] + 1;
+    }
+    on_gpus([&](int k) {
+      const int lo = lo_of[(size_t)k], hi = lo_of[(size_t)k + 1], m = hi - lo;
+      std::vector<int64_t> o2((size_t)m + 1, 0);
+      std::string b2;
+      std::vector<uint8_t> rc((size_t)m), sk((size_t)m);
+      for (int i = lo; i < hi; i++) {
+        b2 += fsdb[i].seq; o2[(size_t)(i - lo) + 1] = (int64_t)b2.size();
+        rc[(size_t)(i - lo)] = (uint8_t)fsdb[i].rc; sk[(size_t)(i - lo)] = (uint8_t)fsdb[i].strand_known;
+      }
+      mia_hip_ctx* c = G[(size_t)k];
+      if (mia_hip_upload_reads(c, m, b2.data(), o2.data(), rc.data(), sk.data(), as.data() + lo, ae.data() + lo) != MIA_HIP_OK) die(c, "upload_reads");
+      if (mia_hip_set_slot_dropped(c, slot_dropped.data(), (int64_t)slot_dropped.size()) != MIA_HIP_OK) die(c, "set_slot_dropped");
+      // fs->front_asp / back_asp and fs->score after pass 1 (src/mia.c:1619-1653): the back slot of every split read, and
+      // for strand-unknown reads (never re-aligned, src/mia_main.c:178) also the front slot and the score
+      if (mia_hip_set_pass1_state(c, f0.data() + lo, b0.data() + lo, score.data() + lo) != MIA_HIP_OK) die(c, "set_pass1_state");
+      if (mia_hip_set_read_base(c, lo) != MIA_HIP_OK) die(c, "set_read_base");
+    });
+    if (NG > 1) {
+      // RCCL over xGMI: rank k = GPU k of the list; the id goes from here to every thread
+      char id[MIA_HIP_COMM_ID_BYTES];
+      if (mia_hip_comm_unique_id(id) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: RCCL (librccl.so.1) is needed for more than one GPU and could not be opened\n"); exit(1); }
+      on_gpus([&](int k) { if (mia_hip_comm_init(G[(size_t)k], id, NG, k) != MIA_HIP_OK) die(G[(size_t)k], "comm_init"); });
+    }
   }
   lap("upload");
 
@@ -432,21 +483,28 @@ int main(int argc, char** argv) {
   std::vector<int32_t> rparams((size_t)n * 8);
   std::vector<int64_t> back_slot((size_t)n);
 
+  std::string next_cons;     // consensus_assembly_string of the iteration just run
   auto iteration = [&](int iter_num) {
-    // reiterate_assembly (src/mia_main.c:24-280)
-    if (mia_hip_realign(g, cons.c_str(), (int32_t)cons.size(), circular) != MIA_HIP_OK) die(g, "realign");
-    lap("  realign");
-    if (mia_hip_get_alignments(g, score.data(), as.data(), ae.data()) != MIA_HIP_OK) die(g, "get_alignments");
-    lap("  get_alignments");
+    // reiterate_assembly + cull_maln_from_fsdb + consensus_assembly_string (src/mia_main.c:24-280, 931-963) as one call per
+    // GPU; with several GPUs the call also exchanges tallies, gaps, links and insert events (RCCL)
+    const double sn[2] = {slope, intercept};
+    std::vector<std::string> outs((size_t)NG);
+    on_gpus([&](int k) {
+      std::string& out = outs[(size_t)k];
+      out.assign(cons.size() * 2 + (1 << 20), '\0');
+      int64_t clen = 0;
+      if (mia_hip_iterate(G[(size_t)k], cons.c_str(), (int32_t)cons.size(), circular, hard_cut, score_cut_set ? sn : nullptr, cc, &out[0], (int64_t)out.size(),
+                          &clen) != MIA_HIP_OK) die(G[(size_t)k], "iterate");
+      out.resize((size_t)clen);
+      const int lo = lo_of[(size_t)k];
+      if (mia_hip_get_alignments(G[(size_t)k], score.data() + lo, as.data() + lo, ae.data() + lo) != MIA_HIP_OK) die(G[(size_t)k], "get_alignments");
+    });
+    for (int k = 1; k < NG; k++) if (outs[(size_t)k] != outs[0]) { fprintf(stderr, "mia_hip: the GPUs disagree on the consensus (internal error)\n"); exit(1); }
+    next_cons = std::move(outs[0]);
+    lap("  iteration (realign, cull, tally, consensus)");
     on_device = true;
     if (iter_num > 1) { ref_id = "ConsAssem." + std::to_string(iter_num); ref_desc = "iteration assembly"; }
     fprintf(stderr, "Repeat and score filtering\n");
-    double s, ic;
-    score_cut(&s, &ic);
-    lap("  score cut");
-    if (mia_hip_cull(g, hard_cut, s, ic, 0) != MIA_HIP_OK) die(g, "cull");
-    if (mia_hip_tally(g) != MIA_HIP_OK) die(g, "tally");
-    lap("  cull + tally");
   };
 
   // write_ma (src/map_alignment.c:283-382) from the device results
@@ -454,9 +512,13 @@ int main(int argc, char** argv) {
     const int L = (int)cons.size();
     const int wl = circular ? std::min(L, MAX_READ) : 0;
     std::string wrapped = cons + cons.substr(0, (size_t)wl);
-    if (mia_hip_get_scripts(g, cols.data(), stride, rstart.data()) != MIA_HIP_OK) die(g, "get_scripts");
-    if (mia_hip_get_dropped(g, dF.data(), dB.data()) != MIA_HIP_OK) die(g, "get_dropped");
-    if (mia_hip_get_record_params(g, rparams.data(), back_slot.data()) != MIA_HIP_OK) die(g, "get_record_params");
+    on_gpus([&](int k) {
+      mia_hip_ctx* c = G[(size_t)k];
+      const size_t lo = (size_t)lo_of[(size_t)k];
+      if (mia_hip_get_scripts(c, cols.data() + lo * (size_t)stride, stride, rstart.data() + lo) != MIA_HIP_OK) die(c, "get_scripts");
+      if (mia_hip_get_dropped(c, dF.data() + lo, dB.data() + lo) != MIA_HIP_OK) die(c, "get_dropped");
+      if (mia_hip_get_record_params(c, rparams.data() + lo * 8, back_slot.data() + lo) != MIA_HIP_OK) die(c, "get_record_params");
+    });
     gaps.assign((size_t)L + 1, 0);
     if (mia_hip_get_tally(g, NULL, gaps.data()) != MIA_HIP_OK) die(g, "get_tally");
     // records of reads [lo, hi), in cull order (front record, then back record)
@@ -612,13 +674,7 @@ int main(int argc, char** argv) {
     lap("write .maln");
   };
 
-  auto consensus = [&]() {
-    std::string out(cons.size() * 2 + (1 << 20), '\0');
-    int64_t clen = 0;
-    if (mia_hip_consensus(g, cc, &out[0], (int64_t)out.size(), &clen) != MIA_HIP_OK) die(g, "consensus");
-    out.resize((size_t)clen);
-    return out;
-  };
+  auto consensus = [&]() { return next_cons; };     // mia_hip_iterate has called it already
 
   // ---- main loop (src/mia_main.c:878-976)
   int iter_num = 1;
@@ -641,6 +697,6 @@ int main(int argc, char** argv) {
   }
   now = time(NULL);
   fprintf(stderr, "Assembly finished at %s\n", asctime(localtime(&now)));
-  mia_hip_destroy(g);
+  for (auto* c : G) mia_hip_destroy(c);
   return 0;
 }
