@@ -39,6 +39,8 @@ namespace mia {
 constexpr int BX_BLOCKS = 9;          // 10-mers cut out of a read: len / 10 of them, at most 9
 constexpr int BX_MIN_BLOCKS = 3;
 constexpr int BX_MAXW = 32;           // widest band
+constexpr int BX_CLUSTER_TRIGGER = 8;  // anchors further apart than this are clustered around their median ...
+constexpr int BX_CLUSTER_RADIUS = 12; // ... keeping those within this many diagonals of it
 constexpr int BX_NEG = -(1 << 22);    // "no such cell"
 constexpr int BX_SUB_ROW = 8;         // words per (strand, depth, read base) row of the substitution table: codes 0..4
 constexpr int BX_SUB_WORDS = 2 * 31 * 4 * BX_SUB_ROW;
@@ -52,11 +54,16 @@ struct BxTab {
   const int32_t* sub;      // [2][31][4][8]: sm[strand][depth][ref code 0..4][read base], read base major
   const int32_t* mrow;     // [2][31][4]:    M
   const int16_t* loss;     // [2][31][4][4]: M - sm, by (strand, depth, read base, reference base)
-  const int16_t* dl;       // [2][MAX_READ+1][BX_BLOCKS]: what breaking block b of a read of that length costs at least
+  const int16_t* dl;       // [2][MAX_READ+1][BX_BLOCKS]: what breaking block b of a read of that length costs at least;
+                           // behind it the stray tables (bx_stray_off): what straying n diagonals costs at least, net of the
+                           // blocks the gaps themselves break
   int32_t min_m, max_m;
 };
 constexpr int BX_LOSS_WORDS = 2 * 31 * 4 * 4;
-constexpr int BX_DL_WORDS = 2 * (MAX_READ + 1) * BX_BLOCKS;
+constexpr int BX_GMAX = 32;            // stray tables: phi / psi for 0..BX_GMAX diagonals
+constexpr int BX_DL_BLOCKS = 2 * (MAX_READ + 1) * BX_BLOCKS;                       // dl proper
+constexpr int BX_DL_WORDS = BX_DL_BLOCKS + 2 * (MAX_READ + 1) * 2 * (BX_GMAX + 1);  // + [strand][len][down | up][0..BX_GMAX]
+MIA_HD inline int bx_stray_off(int st, int len2, int up) { return BX_DL_BLOCKS + ((st * (MAX_READ + 1) + len2) * 2 + up) * (BX_GMAX + 1); }
 
 MIA_HD inline int64_t bx_nib_words(int64_t n_codes) { return (BX_NIB_LEAD + n_codes + BX_NIB_TAIL) / 8 + 2; }
 // first row of block b of a read of len2 bases cut into nb_cut blocks
@@ -107,6 +114,46 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
         }
         dl[(st * (MAX_READ + 1) + len2) * BX_BLOCKS + b] = (int16_t)v;
       }
+  // STRAY TABLES.  A path that reaches a diagonal n above (below) its anchors holds column gaps (skipped rows) that add up
+  // to n or more.  An event costs c_e and spoils at most the blocks it touches, which the pigeonhole sum would otherwise
+  // charge dl each: a column gap touches one block at most, a run of k skipped rows t(k) blocks (exact, from the block
+  // positions of this read length).  psi(n) / phi(n) = the least of sum(c_e - dl_max * touched) over all ways to make up n,
+  // never below 0 per event (dl <= e <= every event's cost per touched block, see above).
+  for (int st = 0; st < 2; st++)
+    for (int len2 = 0; len2 <= MAX_READ; len2++) {
+      int16_t* dn = dl + bx_stray_off(st, len2, 0);
+      int16_t* up = dl + bx_stray_off(st, len2, 1);
+      for (int n = 0; n <= BX_GMAX; n++) { dn[n] = 0; up[n] = 0; }
+      const int nb_cut = bx_blocks_of(len2);
+      if (nb_cut < BX_MIN_BLOCKS) continue;
+      int dmax = 0;
+      for (int b = 0; b < nb_cut; b++) { const int v = dl[(st * (MAX_READ + 1) + len2) * BX_BLOCKS + b]; if (v > dmax) dmax = v; }
+      constexpr int NMAX = 3 * BX_GMAX;
+      int fdn[NMAX + 1], fup[NMAX + 1];
+      for (int n = 1; n <= NMAX; n++) {
+        int t = 0;                                     // most blocks a run of n rows can meet
+        for (int q = -DF_K; q < len2; q++) {
+          int c = 0;
+          for (int b = 0; b < nb_cut; b++) { const int o = bx_block_row(b, len2, nb_cut); if (o < q + n && o + DF_K > q) c++; }
+          if (c > t) t = c;
+        }
+        const int vd = GOP + (GEP + mn) * n - dmax * t, vu = GOP + GEP * n - dmax;
+        fdn[n] = vd > 0 ? vd : 0;
+        fup[n] = vu > 0 ? vu : 0;
+      }
+      int phi[BX_GMAX + 1], psi[BX_GMAX + 1];
+      phi[0] = psi[0] = 0;
+      for (int d = 1; d <= BX_GMAX; d++) {
+        int bd = 1 << 30, bu = 1 << 30;
+        for (int n = 1; n <= NMAX; n++) {
+          const int rest = d - n > 0 ? d - n : 0;
+          if (fdn[n] + phi[rest] < bd) bd = fdn[n] + phi[rest];
+          if (fup[n] + psi[rest] < bu) bu = fup[n] + psi[rest];
+        }
+        phi[d] = bd; psi[d] = bu;
+      }
+      for (int d = 0; d <= BX_GMAX; d++) { dn[d] = (int16_t)(phi[d] > 32000 ? 32000 : phi[d]); up[d] = (int16_t)(psi[d] > 32000 ? 32000 : psi[d]); }
+    }
   *min_m = mn; *max_m = mx;
   return true;
 }
@@ -173,7 +220,7 @@ struct BxPlan { int mode, d0, w, dstar, b0, edge; };
 enum { BXF_READ = 1, BXF_WINDOW, BXF_BLOCKS, BXF_SPAN, BXF_PATH, BXF_BUDGET, BXF_WIDTH, BXF_KINDS };
 
 // the anchors of a read and what they imply, before any loss is summed
-struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi; };
+struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_out, s_un; };   // l_out < 0: every anchor counts; s_un: dl of the blocks that occur nowhere in the window
 
 // Where the read's blocks occur inside the window.  sc holds the read's planes.
 template <int NW>
@@ -199,33 +246,79 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
     for (int k = 0; k < DF_KCAP; k++) ps[b][k] = 0;
     if (b < nb_cut) cn[b] = kh_resolve(kh, kidx[b], kh0[b], ke[b][0], ke[b][1], ke[b][2], ke[b][3], ps[b]);
   }
-  int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0, budget = -1, b_first = 0;
+  int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0, budget = -1, b_first = 0, l_out = -1, s_un = 0;
   bool any = false;
   const int16_t* dl = T.dl + (st * (MAX_READ + 1) + len2) * BX_BLOCKS;
+  // the anchors whose diagonal lies in [m_lo, m_hi]: their extent, the first and the last in block order; l_out (if asked
+  // for) = what a path loses at least that crosses NONE of them cleanly: dl of every block without an anchor outside
+  auto scan = [&](int m_lo, int m_hi, bool want_out) {
+    nb = 0; a_lo = 1 << 20; a_hi = -(1 << 20); d_first = 0; d_last = 0; budget = -1; b_first = 0; any = false; s_un = 0;
+    int lo_sum = 0;
 #pragma unroll
-  for (int b = 0; b < BX_BLOCKS; b++) {
-    if (cn[b] > DF_KCAP) continue;                   // no such block, or an overloaded 10-mer: not part of the pigeonhole
-    nb++;
-    budget += dl[b];
-    const int o = bx_block_row(b, len2, nb_cut);
+    for (int b = 0; b < BX_BLOCKS; b++) {
+      if (cn[b] > DF_KCAP) continue;                   // no such block, or an overloaded 10-mer: not part of the pigeonhole
+      nb++;
+      budget += dl[b];
+      const int o = bx_block_row(b, len2, nb_cut);
+      bool outside = false, nowhere = true;
 #pragma unroll
-    for (int k = 0; k < DF_KCAP; k++) {
-      if (k >= cn[b]) continue;
-      const int d = ps[b][k] - o - s;                         // diagonal in window coordinates
-      if (d < -R || d > len1 - 1) continue;                   // not a place inside this window
-      if (!any) { d_first = d; any = true; }
-      if (d == d_first) b_first = b;                          // (the last block that has an anchor on d_first)
-      d_last = d;
-      if (d < a_lo) a_lo = d;
-      if (d > a_hi) a_hi = d;
+      for (int k = 0; k < DF_KCAP; k++) {
+        if (k >= cn[b]) continue;
+        const int d = ps[b][k] - o - s;                         // diagonal in window coordinates
+        if (d < -R || d > len1 - 1) continue;                   // not a place inside this window
+        nowhere = false;
+        if (d < m_lo || d > m_hi) { outside = true; continue; }
+        if (!any) { d_first = d; any = true; }
+        if (d == d_first) b_first = b;                          // (the last block that has an anchor on d_first)
+        d_last = d;
+        if (d < a_lo) a_lo = d;
+        if (d > a_hi) a_hi = d;
+      }
+      if (!outside) lo_sum += dl[b];
+      if (nowhere) s_un += dl[b];                       // no path crosses this block cleanly
     }
+    l_out = want_out ? lo_sum : -1;
+  };
+  scan(-(1 << 20), 1 << 20, false);
+  if (any && nb >= BX_MIN_BLOCKS && a_hi - a_lo > BX_CLUSTER_TRIGGER) {
+    // Anchors far apart: a 10-mer of the read that also occurs elsewhere in the window (one read in a few hundred), or a long
+    // indel.  Keep the cluster around the MEDIAN of the blocks' first anchors (the true diagonals hold the majority) and
+    // drop the rest -- soundly: a path through a kept anchor strays at most g diagonals from it, whatever else it visits,
+    // and a path that crosses no kept anchor cleanly breaks every block that has no anchor elsewhere, i.e. loses >= l_out,
+    // which bx_finish requires to exceed the loss B0 of the path it writes down.
+    int v[BX_BLOCKS];
+    int c = 0;
+#pragma unroll
+    for (int b = 0; b < BX_BLOCKS; b++) {
+      v[b] = 1 << 20;
+      if (cn[b] > DF_KCAP) continue;
+      const int o = bx_block_row(b, len2, nb_cut);
+      bool got = false;
+#pragma unroll
+      for (int k = 0; k < DF_KCAP; k++) {
+        if (k >= cn[b] || got) continue;
+        const int d = ps[b][k] - o - s;
+        if (d < -R || d > len1 - 1) continue;
+        v[b] = d; got = true;
+      }
+      c += got ? 1 : 0;
+    }
+#pragma unroll
+    for (int pass = 0; pass < BX_BLOCKS; pass++)
+#pragma unroll
+      for (int k = pass & 1; k + 1 < BX_BLOCKS; k += 2) { const int lo = v[k] < v[k + 1] ? v[k] : v[k + 1], hi = v[k] < v[k + 1] ? v[k + 1] : v[k]; v[k] = lo; v[k + 1] = hi; }
+    int med = v[0];
+    const int mi = (c - 1) >> 1;
+#pragma unroll
+    for (int k = 1; k < BX_BLOCKS; k++) if (k == mi) med = v[k];
+    scan(med - BX_CLUSTER_RADIUS, med + BX_CLUSTER_RADIUS, true);
   }
   an->fail = 0;
   if (nb < BX_MIN_BLOCKS || !any) { an->fail = BXF_BLOCKS; return; }
   if (a_hi - a_lo >= BX_MAXW) { an->fail = BXF_SPAN; return; }
   // keep the written-down path inside the window
   if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) { an->fail = BXF_PATH; return; }
-  an->a_lo = a_lo; an->a_hi = a_hi; an->d_first = d_first; an->d_last = d_last; an->budget = budget;
+  an->a_lo = a_lo; an->a_hi = a_hi; an->d_first = d_first; an->d_last = d_last; an->budget = budget; an->l_out = l_out; an->s_un = s_un;
   an->t_lo = 1; an->t_hi = R;
   if (d_first != d_last) {
     // the switch row is looked for between the last block anchored on d_first and the first one after it anchored on d_last
@@ -330,10 +423,29 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   }
   out->b0 = BXF_BUDGET;
   if (b0 > an.budget) return;
+  if (an.l_out >= 0 && an.l_out <= b0) { out->b0 = BXF_SPAN; return; }      // some anchors were set aside: see bx_anchors
+  // how far a path that loses no more than b0 can stray from the anchors: all of b0 spent on one gap (band_body.h) --
+  // or, tighter, what is left of b0 once every block that occurs nowhere in the window has been paid for (an.s_un: such
+  // a block costs dl wherever it is crossed, unless a gap of the path itself breaks it -- the stray tables are net of
+  // that).  In full: loss(P) >= s_un + sum over P's events of (cost - dl of the unanchored blocks the event touches), every
+  // term >= 0; to be n diagonals off an anchor, the events between that place and the anchor add up to n in one direction.
+  int g_dn = b0 < GOP + GEP ? 0 : (b0 - GOP) / GEP, g_up = g_dn;
+  if (g_dn > 0) {
+    const int x = b0 - an.s_un;
+    if (x < 0) { out->b0 = BXF_PATH; return; }         // (cannot happen: every path pays for the blocks that occur nowhere)
+    const int16_t* dn = T.dl + bx_stray_off(st, len2, 0);
+    const int16_t* up = T.dl + bx_stray_off(st, len2, 1);
+    if (g_dn > BX_GMAX) g_dn = g_up = BX_GMAX + 1;     // (beyond the tables: the band is too wide anyway)
+    else {
+      // either side can be reached either way: below the anchors by skipped rows behind them or by a column gap in front
+      // of them (the path starts low and comes up), above them the other way round
+      while (g_dn > 0 && dn[g_dn] > x && up[g_dn] > x) g_dn--;
+      g_up = g_dn;
+    }
+  }
   // (one diagonal more where the window's first column is within reach, as band_body.h)
-  int g = b0 < GOP + GEP ? 0 : (b0 - GOP) / GEP;
-  if (an.a_lo - g - 1 < 0) g++;
-  const int d0 = an.a_lo - g, w = an.a_hi - an.a_lo + 2 * g + 1;
+  if (an.a_lo - g_dn - 1 < 0) { g_dn++; g_up++; }
+  const int d0 = an.a_lo - g_dn, w = an.a_hi - an.a_lo + g_dn + g_up + 1;
   out->b0 = BXF_WIDTH;
   if (w > BX_MAXW) return;
   out->d0 = d0; out->w = w; out->b0 = b0; out->dstar = d_first;

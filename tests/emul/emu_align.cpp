@@ -350,10 +350,21 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
     const int64_t idx = kmer_at(ref_codes, n_codes, p);
     if (idx >= 0) kh_insert_host(kslot.data(), kovf.data(), kslots - 1, ko.shift, (uint32_t)idx, (int32_t)p);
   }
-  std::vector<int32_t> sub(BX_SUB_WORDS, 0), sub256(BX_SUB_WORDS, 0), mrow(2 * 31 * 4);
-  std::vector<int16_t> loss(BX_LOSS_WORDS), dl(BX_DL_WORDS);
-  BxTab T{sub.data(), mrow.data(), loss.data(), dl.data(), 0, 0};
-  if (!bx_make_tables(fwd, rc, sub.data(), mrow.data(), loss.data(), dl.data(), &T.min_m, &T.max_m)) return 0;
+  // the tables of a matrix pair are made once (the stray tables take a moment) and kept
+  static std::vector<int32_t> sub, mrow, key;
+  static std::vector<int16_t> loss, dl;
+  static int32_t s_min_m = 0, s_max_m = 0;
+  static bool s_ok = false;
+  std::vector<int32_t> k2(fwd, fwd + PSSM_WORDS);
+  k2.insert(k2.end(), rc, rc + PSSM_WORDS);
+  if (k2 != key) {
+    key = k2;
+    sub.assign(BX_SUB_WORDS, 0); mrow.assign(2 * 31 * 4, 0); loss.assign(BX_LOSS_WORDS, 0); dl.assign(BX_DL_WORDS, 0);
+    s_ok = bx_make_tables(fwd, rc, sub.data(), mrow.data(), loss.data(), dl.data(), &s_min_m, &s_max_m);
+  }
+  if (!s_ok) return 0;
+  std::vector<int32_t> sub256(BX_SUB_WORDS, 0);
+  BxTab T{sub.data(), mrow.data(), loss.data(), dl.data(), s_min_m, s_max_m};
   for (int k = 0; k < BX_SUB_WORDS; k++) sub256[(size_t)k] = sub[(size_t)k] * 256;
   std::vector<uint32_t> nib((size_t)bx_nib_words(n_codes), 0x44444444u);
   for (int64_t p = 0; p < n_codes; p++) {
@@ -363,7 +374,7 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
   BxPlan bp;
   bx_plan(rp, ko, n_codes, ref_start, len1, pb, len2, strand, T, &bp);
   out6[5] = 0;
-  if (bp.mode == BX_NONE) return 0;
+  if (bp.mode == BX_NONE) { plan5[3] = bp.b0; return 0; }      // (b0 = the reason, BXF_*)
   plan5[0] = bp.d0; plan5[1] = bp.w; plan5[2] = bp.dstar; plan5[3] = bp.b0; plan5[4] = bp.edge;
   const int u = bx_umax(mrow.data(), pb, len2, strand);
   const int expect = u - bp.b0;

@@ -207,3 +207,102 @@ def test_second_copies_compete(emul, oracle):
                 continue
             check(emul, oracle, spec, strand, ref, s, l1, read, stats)
     assert stats["n"] > 300, stats
+
+
+def test_stray_anchors_are_set_aside_soundly(emul, oracle):
+    """Ten-mers of the read that occur a second time inside the window (bx_anchors clusters the anchors around their median
+    and sets the others aside -- only when every path through none of the kept ones provably loses more): single planted
+    ten-mers, second copies of long stretches of the read 13-90 columns away (which may well hold the better alignment),
+    with the true locus damaged more or less."""
+    rnd = random.Random(77)
+    stats = {"n": 0}
+    finished = 0
+    for spec, strand in MATS[:3]:
+        for i in range(260):
+            n = rnd.choice([100, 100, 150, rnd.randint(60, 200)])
+            core = "".join(rnd.choice("ACGT") for _ in range(n))
+            left = "".join(rnd.choice("ACGT") for _ in range(60))
+            right = "".join(rnd.choice("ACGT") for _ in range(60))
+            locus = mutate(rnd, core, rnd.sample(range(n), rnd.choice([0, 0, 1, 2, 4, 6, 9])))
+            kind = i % 4
+            if kind == 0:                                   # one or two ten-mers of the read, planted in the flanks
+                for _ in range(rnd.choice([1, 2])):
+                    at = rnd.randint(0, n - 10)
+                    p = rnd.randint(0, 50)
+                    if rnd.random() < 0.5:
+                        left = left[:p] + core[at:at + 10] + left[p + 10:]
+                    else:
+                        right = right[:p] + core[at:at + 10] + right[p + 10:]
+                ref = left + locus + right
+            elif kind == 1:                                 # a second copy of a stretch of the read right behind the locus
+                a = rnd.randint(0, n - 30)
+                ln = rnd.randint(20, min(90, n - a))
+                seg = mutate(rnd, core[a:a + ln], rnd.sample(range(ln), rnd.choice([0, 0, 1, 3])))
+                ref = left + locus + seg + right
+            elif kind == 2:                                 # ... or in front of it
+                a = rnd.randint(0, n - 30)
+                ln = rnd.randint(20, min(90, n - a))
+                seg = mutate(rnd, core[a:a + ln], rnd.sample(range(ln), rnd.choice([0, 0, 1, 3])))
+                ref = left + seg + locus + right
+            else:                                           # the locus itself torn apart by an insertion of unrelated bases
+                cut = rnd.randint(15, n - 15)
+                ref = left + locus[:cut] + "".join(rnd.choice("ACGT") for _ in range(rnd.randint(9, 40))) + locus[cut:] + right
+            read = damage(rnd, core) if spec != "flat" else core
+            read = mutate(rnd, read, rnd.sample(range(n), rnd.choice([0, 1, 2])))
+            pos = ref.find(locus[:25]) if kind != 2 else len(left)
+            s, l1 = window(ref, max(pos, 0), n, margin=rnd.choice([50, 50, 80]))
+            if l1 > 760 or l1 < n:
+                continue
+            finished += 1 if check(emul, oracle, spec, strand, ref, s, l1, read, stats) else 0
+    assert stats["n"] > 600 and finished > 200, (stats, finished)
+
+
+def test_tight_stray_bound_on_low_complexity(emul, oracle):
+    """The band is as narrow as the loss budget allows once every block that occurs nowhere in the window is paid for
+    (bx_finish, stray tables): cases where alignments a few diagonals off compete -- microsatellites and homopolymer runs
+    inside the read, tandem duplications of 1-9 bases between read and reference at every distance from the ends,
+    substitutions spread one per block (the budget left for straying is then nil) or clustered."""
+    rnd = random.Random(99)
+    stats = {"n": 0}
+    finished = 0
+
+    def low_complexity(n):
+        out = []
+        while sum(map(len, out)) < n:
+            kind = rnd.random()
+            if kind < 0.35:
+                out.append(rnd.choice("ACGT") * rnd.randint(3, 14))
+            elif kind < 0.7:
+                unit = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([2, 2, 3, 4, 5])))
+                out.append(unit * rnd.randint(2, 8))
+            else:
+                out.append("".join(rnd.choice("ACGT") for _ in range(rnd.randint(5, 25))))
+        return "".join(out)[:n]
+
+    for spec, strand in MATS[:3]:
+        for i in range(420):
+            n = rnd.choice([100, 100, 150, rnd.randint(40, 220)])
+            core = low_complexity(n) if i % 3 else "".join(rnd.choice("ACGT") for _ in range(n))
+            locus = core
+            if i % 2:                                       # a tandem duplication / deletion between read and reference
+                at = rnd.choice([1, 2, 4, 9, 10, 11, n // 2, n - 11, n - 9, n - 3, rnd.randint(1, n - 2)])
+                k = rnd.randint(1, 9)
+                if rnd.random() < 0.5:
+                    locus = core[:at] + core[max(0, at - k):at] + core[at:]        # the reference repeats k bases
+                else:
+                    locus = core[:at] + core[at + k:]                              # the reference lacks k bases
+            left = low_complexity(70) if i % 5 == 0 else "".join(rnd.choice("ACGT") for _ in range(70))
+            right = low_complexity(70) if i % 7 == 0 else "".join(rnd.choice("ACGT") for _ in range(70))
+            ref = left + locus + right
+            read = damage(rnd, core) if spec != "flat" else core
+            nsub = rnd.choice([0, 1, 2, 3, 4, 5, 6, 8])
+            if i % 4 == 0:                                  # one substitution per ten-mer block
+                rows = [min(n - 1, 11 * b + rnd.randint(0, 9)) for b in rnd.sample(range(max(1, n // 11)), min(nsub, max(1, n // 11)))]
+            else:
+                rows = rnd.sample(range(n), nsub)
+            read = mutate(rnd, read, rows)
+            s, l1 = window(ref, 70, len(locus), margin=rnd.choice([50, 50, 20]))
+            if l1 < len(read) or l1 > 760:
+                continue
+            finished += 1 if check(emul, oracle, spec, strand, ref, s, l1, read, stats) else 0
+    assert stats["n"] > 1000 and finished > 500, (stats, finished)
