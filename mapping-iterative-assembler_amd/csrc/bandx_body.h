@@ -36,7 +36,8 @@
 
 namespace mia {
 
-constexpr int BX_BLOCKS = 9;          // 10-mers cut out of a read: len / 10 of them, at most 9
+constexpr int BX_BLOCKS = 12;         // 10-mers cut out of a read: len / 10 of them, at most 9 (reads up to 128 bases) or 12 (longer ones)
+template <int NW> constexpr int bx_nb_max() { return NW <= 2 ? 9 : 12; }   // NW: 64-row words of the longest read
 constexpr int BX_MIN_BLOCKS = 3;
 constexpr int BX_MAXW = 32;           // widest band
 constexpr int BX_CLUSTER_TRIGGER = 8;  // anchors further apart than this are clustered around their median ...
@@ -68,7 +69,7 @@ MIA_HD inline int bx_stray_off(int st, int len2, int up) { return BX_DL_BLOCKS +
 MIA_HD inline int64_t bx_nib_words(int64_t n_codes) { return (BX_NIB_LEAD + n_codes + BX_NIB_TAIL) / 8 + 2; }
 // first row of block b of a read of len2 bases cut into nb_cut blocks
 MIA_HD inline int bx_block_row(int b, int len2, int nb_cut) { return (int)((int64_t)b * (len2 - DF_K) / (nb_cut - 1)); }
-MIA_HD inline int bx_blocks_of(int len2) { return len2 / DF_K < BX_BLOCKS ? len2 / DF_K : BX_BLOCKS; }
+MIA_HD inline int bx_blocks_of(int len2) { const int cap = len2 > 128 ? BX_BLOCKS : 9; return len2 / DF_K < cap ? len2 / DF_K : cap; }
 
 // host side of BxTab; false: the band pipeline cannot be used with these matrices
 inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, int32_t* mrow, int16_t* loss, int16_t* dl, int32_t* min_m, int32_t* max_m) {
@@ -225,12 +226,13 @@ struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_
 // Where the read's blocks occur inside the window.  sc holds the read's planes.
 template <int NW>
 MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const uint32_t* pw, int s, int len1, int len2, int st, const BxTab& T, BxAnchors* an) {
+  constexpr int NB = bx_nb_max<NW>();      // (a read of NW words has at most this many blocks)
   const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
   // the home slots of all blocks first, then their use: nine independent loads in flight instead of nine round trips
-  int32_t cn[BX_BLOCKS], ps[BX_BLOCKS][DF_KCAP];
-  uint32_t kidx[BX_BLOCKS], kh0[BX_BLOCKS], ke[BX_BLOCKS][4];
+  int32_t cn[NB], ps[NB][DF_KCAP];
+  uint32_t kidx[NB], kh0[NB], ke[NB][4];
 #pragma unroll
-  for (int b = 0; b < BX_BLOCKS; b++) {
+  for (int b = 0; b < NB; b++) {
     if (b < nb_cut) {
       kidx[b] = (uint32_t)bx_kmer(pw, len2, bx_block_row(b, len2, nb_cut));
       kh0[b] = kh_home(kh, kidx[b]);
@@ -240,7 +242,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
     }
   }
 #pragma unroll
-  for (int b = 0; b < BX_BLOCKS; b++) {
+  for (int b = 0; b < NB; b++) {
     cn[b] = DF_KCAP + 1;
 #pragma unroll
     for (int k = 0; k < DF_KCAP; k++) ps[b][k] = 0;
@@ -255,7 +257,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
     nb = 0; a_lo = 1 << 20; a_hi = -(1 << 20); d_first = 0; d_last = 0; budget = -1; b_first = 0; any = false; s_un = 0;
     int lo_sum = 0;
 #pragma unroll
-    for (int b = 0; b < BX_BLOCKS; b++) {
+    for (int b = 0; b < NB; b++) {
       if (cn[b] > DF_KCAP) continue;                   // no such block, or an overloaded 10-mer: not part of the pigeonhole
       nb++;
       budget += dl[b];
@@ -286,10 +288,10 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
     // drop the rest -- soundly: a path through a kept anchor strays at most g diagonals from it, whatever else it visits,
     // and a path that crosses no kept anchor cleanly breaks every block that has no anchor elsewhere, i.e. loses >= l_out,
     // which bx_finish requires to exceed the loss B0 of the path it writes down.
-    int v[BX_BLOCKS];
+    int v[NB];
     int c = 0;
 #pragma unroll
-    for (int b = 0; b < BX_BLOCKS; b++) {
+    for (int b = 0; b < NB; b++) {
       v[b] = 1 << 20;
       if (cn[b] > DF_KCAP) continue;
       const int o = bx_block_row(b, len2, nb_cut);
@@ -304,13 +306,13 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
       c += got ? 1 : 0;
     }
 #pragma unroll
-    for (int pass = 0; pass < BX_BLOCKS; pass++)
+    for (int pass = 0; pass < NB; pass++)
 #pragma unroll
-      for (int k = pass & 1; k + 1 < BX_BLOCKS; k += 2) { const int lo = v[k] < v[k + 1] ? v[k] : v[k + 1], hi = v[k] < v[k + 1] ? v[k + 1] : v[k]; v[k] = lo; v[k + 1] = hi; }
+      for (int k = pass & 1; k + 1 < NB; k += 2) { const int lo = v[k] < v[k + 1] ? v[k] : v[k + 1], hi = v[k] < v[k + 1] ? v[k + 1] : v[k]; v[k] = lo; v[k + 1] = hi; }
     int med = v[0];
     const int mi = (c - 1) >> 1;
 #pragma unroll
-    for (int k = 1; k < BX_BLOCKS; k++) if (k == mi) med = v[k];
+    for (int k = 1; k < NB; k++) if (k == mi) med = v[k];
     scan(med - BX_CLUSTER_RADIUS, med + BX_CLUSTER_RADIUS, true);
   }
   an->fail = 0;
@@ -325,7 +327,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
     int b_last = nb_cut - 1;
     bool found = false;
 #pragma unroll
-    for (int b = 0; b < BX_BLOCKS; b++) {
+    for (int b = 0; b < NB; b++) {
       if (cn[b] > DF_KCAP || b <= b_first || found) continue;
       const int o = bx_block_row(b, len2, nb_cut);
 #pragma unroll
