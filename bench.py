@@ -46,6 +46,9 @@ def bytes_per_read(read_len):
 PMC_DIR = os.path.join(ROOT, "profiles", "r02", "pmc")
 CSRC = os.path.join(ROOT, "mapping-iterative-assembler_amd", "csrc")
 STAGES = ["k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_trace", "k_align_quad_plain", "k_align_quad", "k_tally_binned"]
+# the full-window stage is timed as a whole: k_align_quad (four reads per wavefront, windows up to 208 columns) and the
+# k_align_window<CPL> launches (one read per wavefront: wider windows, reads whose path left the quad kernel's trace band)
+STAGE_KERNELS = {"k_align_quad": ["k_align_quad", "k_align_window"]}
 
 
 def source_hash():
@@ -248,7 +251,11 @@ class Pipeline:
             ms, k = st[name]
             if k <= 0 or ms <= 0:
                 continue
+            if name == "k_align_quad":
+                k = steps                          # several launches per step (quad, window classes, retries): one figure per step
             reads, cells = per_launch[name]
+            if name == "k_align_quad":
+                reads = reads * st[name][1] / steps
             if cells is not None and name in ("k_band_align", "k_align_quad_plain", "k_align_quad"):
                 cells = cells * reads              # per read -> per launch
             k_ms = ms / k
@@ -257,16 +264,21 @@ class Pipeline:
                  "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                  "gcups": cells / (k_ms * 1e-3) / 1e9 if cells else None, "traffic": None, "valu_frac": None}
             if pmc_usable(pmc, pmc_stale, n):
-                if name not in pmc or not all(k in pmc[name] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")):
-                    raise RuntimeError(f"PMC summary has no entry for {name}: re-run tools/pmc_collect.sh for this build")
-                c = pmc[name]
+                kept = pmc["_meta"].get("steps_kept", 4)
+                tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0}
+                for kn in STAGE_KERNELS.get(name, [name]):
+                    if kn not in pmc or not all(c in pmc[kn] for c in tot):
+                        raise RuntimeError(f"PMC summary has no entry for {kn}: re-run tools/pmc_collect.sh for this build")
+                    for c in tot:                   # average per dispatch x dispatches per step
+                        per_step = pmc[kn][c] * pmc[kn]["dispatches_" + c] / kept
+                        tot[c] += per_step if name in STAGE_KERNELS else pmc[kn][c]
                 # MI355X_MICROARCH.md, HBM: FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE counts 128-byte read
                 # requests as 64 bytes for wide streaming reads -> doubled (calibrated on k_peak_copy in the same passes,
                 # see _meta.fetch_calibration); per launch, like `achieved`
-                s["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+                s["traffic"] = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024
                 if peaks and peaks.get("valu_ginst_s"):
-                    s["valu_insts"] = c["SQ_INSTS_VALU"]
-                    s["valu_frac"] = c["SQ_INSTS_VALU"] / (k_ms * 1e-3) / (peaks["valu_ginst_s"] * 1e9)
+                    s["valu_insts"] = tot["SQ_INSTS_VALU"]
+                    s["valu_frac"] = tot["SQ_INSTS_VALU"] / (k_ms * 1e-3) / (peaks["valu_ginst_s"] * 1e9)
             out.append(s)
         return out, {"reads_seen": seen or f_seen, "finished_by_plan_or_filter": f_done, "finished_by_values_dp": by_values,
                      "finished_by_trace_dp": by_trace + band_done, "to_full_window_kernels": max(left, 0)}

@@ -518,6 +518,32 @@ MIA_HD inline void bx_codes(const uint32_t* refnib, int64_t nib, uint32_t* cw) {
   }
 }
 
+// The same W nibbles for a position that advances by ONE per read row (the band slides along the reference): NWD + 2 raw
+// words stay in registers, a new one is fetched every eighth row and one group ahead of its use, so that the row loop
+// never waits for the load (one read per thread: a few wavefronts per SIMD do not hide a trip to the L2 per row).
+template <int NWD>
+struct BxSlide {
+  uint32_t raw[NWD + 2];
+  int64_t q;               // word index of raw[0]
+  MIA_HD inline void init(const uint32_t* refnib, int64_t nib) {
+    q = nib >> 3;
+#pragma unroll
+    for (int k = 0; k < NWD + 2; k++) raw[k] = refnib[q + k];
+  }
+  // codes for nibble index nib (>= the previous one, at most 8 further on)
+  MIA_HD inline void get(const uint32_t* refnib, int64_t nib, uint32_t* cw) {
+    if ((nib >> 3) != q) {
+#pragma unroll
+      for (int k = 0; k < NWD + 1; k++) raw[k] = raw[k + 1];
+      q++;
+      raw[NWD + 1] = refnib[q + NWD + 1];
+    }
+    const int sh = (int)(nib & 7) * 4;
+#pragma unroll
+    for (int k = 0; k < NWD; k++) cw[k] = sh ? (raw[k] >> sh) | (raw[k + 1] << (32 - sh)) : raw[k];
+  }
+};
+
 struct BxResult { int score, abc, aec, abr, gaps; uint32_t gap_desc; };
 
 // Values only.  sub: the substitution table of the read's strand (31 x 4 x BX_SUB_ROW words; LDS on the device).
@@ -532,8 +558,10 @@ MIA_HD inline void bx_values(const uint32_t* refnib, int s, int len1, const uint
     const int jlo = c0 < 0 ? -c0 : 0, jhi = (len1 - c0) < W ? (len1 - c0) : W;
     return jhi > jlo ? ((jhi >= 32 ? ~0u : ((1u << jhi) - 1u)) & ~((1u << jlo) - 1u)) : 0u;
   };
+  BxSlide<NWD> slide;
+  slide.init(refnib, (int64_t)s + d0 + BX_NIB_LEAD);
   {
-    bx_codes<NWD>(refnib, (int64_t)s + d0 + BX_NIB_LEAD, cw);
+    slide.get(refnib, (int64_t)s + d0 + BX_NIB_LEAD, cw);
     const int32_t* row = sub + ((0 * 4) + (int)(rw & 3u)) * BX_SUB_ROW;          // depth 0
     const uint32_t live = EDGE ? live_mask(d0) : ~0u;
 #pragma unroll
@@ -545,7 +573,7 @@ MIA_HD inline void bx_values(const uint32_t* refnib, int s, int len1, const uint
   }
   for (int r = 1; r < len2; r++) {
     const int c0 = r + d0;
-    bx_codes<NWD>(refnib, (int64_t)s + c0 + BX_NIB_LEAD, cw);
+    slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD, cw);
     if ((r & 7) == 0) rw = rwords[r >> 3];
     const int32_t* row = sub + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
     uint32_t live = ~0u, col0 = 0u;
@@ -607,8 +635,10 @@ MIA_HD inline bool bx_trace(const uint32_t* refnib, int s, int len1, const uint3
     const int jlo = c0 < 0 ? -c0 : 0, jhi = (len1 - c0) < W ? (len1 - c0) : W;
     return jhi > jlo ? ((jhi >= 32 ? ~0u : ((1u << jhi) - 1u)) & ~((1u << jlo) - 1u)) : 0u;
   };
+  BxSlide<NWD> slide;
+  slide.init(refnib, (int64_t)s + d0 + BX_NIB_LEAD);
   {
-    bx_codes<NWD>(refnib, (int64_t)s + d0 + BX_NIB_LEAD, cw);
+    slide.get(refnib, (int64_t)s + d0 + BX_NIB_LEAD, cw);
     const int32_t* row = sub256 + ((0 * 4) + (int)(rw & 3u)) * BX_SUB_ROW;
     const uint32_t live = EDGE ? live_mask(d0) : ~0u;
 #pragma unroll
@@ -622,7 +652,7 @@ MIA_HD inline bool bx_trace(const uint32_t* refnib, int s, int len1, const uint3
   }
   for (int r = 1; r < len2; r++) {
     const int c0 = r + d0;
-    bx_codes<NWD>(refnib, (int64_t)s + c0 + BX_NIB_LEAD, cw);
+    slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD, cw);
     if ((r & 7) == 0) rw = rwords[r >> 3];
     const int32_t* row = sub256 + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
     uint32_t live = ~0u, col0 = 0u;

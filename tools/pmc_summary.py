@@ -2,8 +2,9 @@
 """Per-kernel averages of rocprofv3 --pmc counter_collection.csv files (one file per counter pass; FETCH_SIZE and
 WRITE_SIZE need separate passes on gfx950).
 usage: pmc_summary.py out.json reads_per_gpu pass1_counter_collection.csv [...]
-Values are per dispatch, averaged over the dispatches of the kernel whose counter came to at least half of the largest
-one (the timed steps; warm-up and tiny launches are left out).  FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports
+Values are per dispatch, averaged over the LAST 40 % of the kernel's dispatches in time order: `bench.py --pmc-run` does
+2 warm-up iterations (the first against mt311 itself, whose ambiguity codes send every read through the full-window
+kernels), 4 timed and 4 instrumented ones -- the last four are the steady state the stage table describes.  FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports
 them, uncorrected; bench.py applies the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE x 2) and this file records
 what k_peak_copy -- a streaming copy of a known size in the same passes -- showed, as the calibration of that factor.
 _meta.source_hash names the build (sha256 over csrc/): bench.py does not replay counters of another build."""
@@ -29,16 +30,17 @@ def main():
     for path in sys.argv[3:]:
         per = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(path)):
-            per[short(r["Kernel_Name"])][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            per[short(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Start_Timestamp"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for name, ctrs in per.items():
-            for c, vals in ctrs.items():
-                big = max(v for v, _ in vals)
-                keep = [(v, t) for v, t in vals if v >= 0.5 * big] or vals
+            for c, vals3 in ctrs.items():
+                vals3.sort()
+                k = max(1, int(round(len(vals3) * 0.4)))
+                keep = [(v, t) for _, v, t in vals3[-k:]]
                 out[name][c] = sum(v for v, _ in keep) / len(keep)
                 out[name]["dispatches_" + c] = len(keep)
                 out[name]["kernel_ms_under_" + c] = sum(t for _, t in keep) / len(keep) / 1e6
     import bench
-    meta = {"source_hash": bench.source_hash(), "reads_per_gpu": int(sys.argv[2]),
+    meta = {"source_hash": bench.source_hash(), "reads_per_gpu": int(sys.argv[2]), "steps_kept": 4,
             "command": "rocprofv3 --kernel-trace --pmc <set> --output-format csv -- python3 bench.py --pmc-run <tag> --config <k> (tools/pmc_collect.sh)"}
     pc = out.get("k_peak_copy")
     if pc and "FETCH_SIZE" in pc:
