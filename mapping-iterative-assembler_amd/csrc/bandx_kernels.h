@@ -7,7 +7,8 @@
 //   k_bx_plan      one read per thread: band from the 10-mer anchors; one-diagonal bands are finished here; the rest is
 //                  appended to one of eight lists (values / trace x band class)
 //   k_bx_values    persistent wavefronts take chunks of 64 reads of one class: values-only DP in registers, substitution
-//                  table in LDS; a read whose best score is the plan's diagonal's is finished, the others go on to the trace lists
+//                  table in LDS; a read whose best score is the plan's diagonal's is finished, the others stay open for the
+//                  full-window kernels.  Runs BESIDE k_bx_trace (two streams): neither depends on the other.
 //   k_bx_trace     the same with a byte trace in a private slab and the reference's traceback
 // Nothing here waits for the host: list lengths and chunk cursors stay on the device.
 #pragma once
@@ -256,20 +257,21 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
   }
 }
 
-// the chunk a wavefront takes next: classes in descending width (the long chunks first), 64 reads each
+// the chunk a wavefront takes next: classes in descending width (the long chunks first), 64 reads each.  The entries of
+// list `list0 + c` from *lo (counter index lo_ctr + c, or 0 if lo_ctr < 0) up to *hi (counter index hi_ctr + c).
 struct BxChunk { int cls; uint32_t first, count; };
-__device__ __forceinline__ bool bx_next_chunk(const BxDev& bx, int list0, int cursor, BxChunk* out) {
+__device__ __forceinline__ bool bx_next_chunk(const BxDev& bx, int cursor, int lo_ctr, int hi_ctr, BxChunk* out) {
   uint32_t chunk = 0;
   if ((threadIdx.x & 63) == 0) chunk = atomicAdd(bxc(bx.ctr, cursor), 1u);
   chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
   for (int c = BX_NCLS - 1; c >= 0; c--) {
-    const uint32_t cnt = *bxc(bx.ctr, BXC_LIST0 + list0 + c), nch = (cnt + 63u) >> 6;
-    if (chunk < nch) { out->cls = c; out->first = chunk * 64u; out->count = cnt; return true; }
+    const uint32_t lo = lo_ctr < 0 ? 0u : *bxc(bx.ctr, lo_ctr + c), hi = *bxc(bx.ctr, hi_ctr + c);
+    const uint32_t cnt = hi > lo ? hi - lo : 0u, nch = (cnt + 63u) >> 6;
+    if (chunk < nch) { out->cls = c; out->first = lo + chunk * 64u; out->count = hi; return true; }
     chunk -= nch;
   }
   return false;
 }
-
 struct BxRead { int32_t i; int len2, s, l1, d0, jstar, st; bool edge; const uint32_t* rw; };
 __device__ __forceinline__ BxRead bx_load(const ReadSet& rs, const RefInfo& ref, const BxDev& bx, int32_t i) {
   BxRead r;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void k_bx_values(ReadSet rs, RefInfo ref, BxDe
   const int lane = threadIdx.x & 63;
   uint32_t done = 0;
   BxChunk ch;
-  while (bx_next_chunk(bx, 0, BXC_CUR_VALUES, &ch)) {
+  while (bx_next_chunk(bx, BXC_CUR_VALUES, -1, BXC_LIST0, &ch)) {
     const uint32_t t = ch.first + lane;
     const bool live = t < ch.count;
     int best = BX_NEG, bj = -1;
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(256) void k_bx_values(ReadSet rs, RefInfo ref, BxDe
       bin_of[r.i] = -4;
       done++;
     }
-    bx_append(bx, BX_NCLS + ch.cls, live && !ok, r.i);
+    // (a read whose best score is not the plan's diagonal's has a gap or a soft clip: it stays open -- bin_of = 0 -- and the
+    // planner hands it to the full-window kernels; a second trace launch for these few would cost a whole chunk's latency)
     bx_diag_scripts(rs, __ballot(ok), r.i, r.d0 + r.jstar, r.len2);
   }
   for (int o = 32; o; o >>= 1) done += __shfl_xor(done, o);
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void k_bx_trace(ReadSet rs, RefInfo ref, BxDev
   uint32_t* slab = slabs + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * slab_words;
   uint32_t done = 0;
   BxChunk ch;
-  while (bx_next_chunk(bx, BX_NCLS, BXC_CUR_TRACE, &ch)) {
+  while (bx_next_chunk(bx, BXC_CUR_TRACE, -1, BXC_LIST0 + BX_NCLS, &ch)) {
     const uint32_t t = ch.first + lane;
     const bool live = t < ch.count;
     BxRead r{};

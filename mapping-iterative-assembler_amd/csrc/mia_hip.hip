@@ -44,6 +44,7 @@ struct mia_hip_ctx {
   int32_t* d_ctrl = nullptr;
   uint32_t stage_mask = ~0u;               // timed stages (mia_hip_set_stage_mask): an event pair costs the stream a few microseconds
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the trace DP of the plan's own lists runs beside the values DP
   std::string err;
   // PSSMs (fwd, rc)
   int32_t* d_pssm = nullptr;
@@ -202,7 +203,9 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
   if (device_index < 0 || device_index >= ndev) return MIA_HIP_ERR_ARG;
   mia_hip_ctx* ctx = new mia_hip_ctx();
   ctx->device = device_index;
-  if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return MIA_HIP_ERR_DEVICE;
   }
@@ -282,6 +285,9 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   for (auto& e : ctx->ev_free) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& t : ctx->stg) for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
 }
 
@@ -458,7 +464,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
 }
 
 // an event pair for one launch of stage `st`; the start event is recorded here, the end event by stage_end
-static int stage_begin(mia_hip_ctx* ctx, Stage st) {
+static int stage_begin(mia_hip_ctx* ctx, Stage st, hipStream_t on = nullptr) {
   if (!((ctx->stage_mask >> st) & 1u)) return 0;
   if (ctx->ev_free.empty()) {
     hipEvent_t x, y;
@@ -468,11 +474,11 @@ static int stage_begin(mia_hip_ctx* ctx, Stage st) {
   auto p = ctx->ev_free.back();
   ctx->ev_free.pop_back();
   ctx->stg[st].pending.push_back(p);
-  (void)hipEventRecord(p.first, ctx->stream);
+  (void)hipEventRecord(p.first, on ? on : ctx->stream);
   return 0;
 }
-static void stage_end(mia_hip_ctx* ctx, Stage st) {
-  if (((ctx->stage_mask >> st) & 1u) && !ctx->stg[st].pending.empty()) (void)hipEventRecord(ctx->stg[st].pending.back().second, ctx->stream);
+static void stage_end(mia_hip_ctx* ctx, Stage st, hipStream_t on = nullptr) {
+  if (((ctx->stage_mask >> st) & 1u) && !ctx->stg[st].pending.empty()) (void)hipEventRecord(ctx->stg[st].pending.back().second, on ? on : ctx->stream);
 }
 
 static void drain_events(mia_hip_ctx* ctx) {
@@ -769,12 +775,19 @@ static int align_all(mia_hip_ctx* ctx) {
       stage_end(ctx, STG_BX_PLAN);
       HIPCHK(hipGetLastError());
       if (!(ctx->dbg & 256u)) {
+        // The two band DPs do not depend on each other (a read the values DP cannot finish stays open for the full-window
+        // kernels): they run side by side on two streams -- both are persistent grids whose wavefronts leave as soon as the
+        // chunks run out, so each fills what the other leaves idle, and the step pays the longer of the two tails, not both.
+        HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        if (stage_begin(ctx, STG_BX_TRACE, ctx->stream2)) return MIA_HIP_ERR_NOMEM;
+        hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
+        stage_end(ctx, STG_BX_TRACE, ctx->stream2);
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
         if (stage_begin(ctx, STG_BX_VALUES)) return MIA_HIP_ERR_NOMEM;
         hipLaunchKernelGGL(k_bx_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
         stage_end(ctx, STG_BX_VALUES);
-        if (stage_begin(ctx, STG_BX_TRACE)) return MIA_HIP_ERR_NOMEM;
-        hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
-        stage_end(ctx, STG_BX_TRACE);
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         HIPCHK(hipGetLastError());
       }
       ctx->bx_launches++;
