@@ -597,11 +597,19 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
   }
 }
 
+template <bool LINEAR>
 __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
-                                                       const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, int32_t linear) {
+                                                       const int32_t* rec_actf, int32_t* slabs, uint32_t dbg) {
+  constexpr bool linear = LINEAR;
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
+  // !LINEAR (a position-specific matrix): the scores of a base depend on its depth code and its strand -- but every base
+  // further than 15 from both ends of its read has depth code 15 (src/pssm.c:6-46), seven in ten of a 100 bp read.  Those
+  // are only COUNTED, per strand (forward strand in the low half of the word, reverse in the high half; a workgroup holds
+  // at most TALLY_CHUNK reads), and their base counts and score sums are filled in from sm[strand][15] at the flush: one
+  // LDS atomic per base instead of five.  The 15 bases at either end keep their explicit adds.
+  __shared__ int32_t mid_cnt[LINEAR ? 1 : 5 * TALLY_WIN];
   // linear: the matrix does not depend on depth or strand (the flat matrix), so scoreX(column) = sum_b count_b * sm[X][b].
   // The window then takes ONE LDS atomic per base (its count; N in n_cnt) instead of five, and the four score rows are
   // filled in from the counts when the window is flushed.  Same integer sums.
@@ -624,6 +632,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) lds[k] = 0;
   for (int k = threadIdx.x; k < 2 * PSSM_WORDS; k += blockDim.x) pssm_lds[k] = (int16_t)pssm2[k];
   for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { cov_diff[k] = 0; span_diff[k] = 0; n_cnt[k] = 0; }
+  if (!LINEAR) for (int k = threadIdx.x; k < 5 * TALLY_WIN; k += blockDim.x) mid_cnt[k] = 0;
   if (threadIdx.x == 0) ev_cnt = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -634,6 +643,18 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   // general one-read-per-wavefront path.  Same integer sums either way.
   typedef __attribute__((address_space(3))) int32_t lds_i32;
   auto aadd = [](lds_i32* q, int v) { (void)__hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // one aligned base of a record that is listed once and not dropped, at window slot wc: code 0..4, depth code d, strand
+  auto add_base = [&](int wc, int code, int d, bool is_rc) {
+    lds_i32* t = (lds_i32*)lds + wc;
+    if (LINEAR) { if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1); else aadd((lds_i32*)n_cnt + wc, 1); return; }
+    if (d == PSSM_DEPTH) { aadd((lds_i32*)mid_cnt + (code < 4 ? code : 4) * TALLY_WIN + wc, is_rc ? 65536 : 1); return; }
+    const int16_t* row = pssm_lds + (is_rc ? PSSM_WORDS : 0) + d * 25 + code;
+    if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1);
+    aadd(&t[T_SA * TALLY_WIN], (int)row[0]);
+    aadd(&t[T_SC * TALLY_WIN], (int)row[5]);
+    aadd(&t[T_SG * TALLY_WIN], (int)row[10]);
+    aadd(&t[T_ST * TALLY_WIN], (int)row[15]);
+  };
   const int L = ref.L, Lp = tb.Lp;
   int warm = 0;
   for (int k0 = first; k0 < last; k0 += 256) {
@@ -653,7 +674,6 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
              w0 + n_al <= TALLY_WIN && g.start_w + n_al <= Lp && n_al <= g.ncols_f && n_al > 0;
       if (fast && !(dbg & 8u)) {
         const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);    // reads start on 4-byte boundaries
-        const int16_t* pmat = pssm_lds + ((flags & TRF_RC) ? PSSM_WORDS : 0);
         const bool dF = (flags & TRF_DF) != 0;
         lds_i32* t = (lds_i32*)lds + w0;
         uint32_t word = 0;
@@ -680,14 +700,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
           const int d = depth_code(act, fB - act - 1);
           bad |= (d < 0) | (d > 2 * PSSM_DEPTH);
           const int dd = d < 0 ? 0 : (d > 2 * PSSM_DEPTH ? 2 * PSSM_DEPTH : d);
-          if (!dF && !(dbg & 16u)) {
-            const int16_t* row = pmat + dd * 25 + code;
-            if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1);
-            aadd(&t[T_SA * TALLY_WIN], (int)row[0]);
-            aadd(&t[T_SC * TALLY_WIN], (int)row[5]);
-            aadd(&t[T_SG * TALLY_WIN], (int)row[10]);
-            aadd(&t[T_ST * TALLY_WIN], (int)row[15]);
-          }
+          if (!dF && !(dbg & 16u)) add_base(w0 + act, code, dd, (flags & TRF_RC) != 0);
           t++;
         }
         // coverage (not dropped): columns w0 .. w0+n_al-1; span (start < pos <= end, dropped or not): w0+1 .. w0+n_al-1
@@ -707,7 +720,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
       const int len2 = a.z & 0xFFFF, abr = (int)(int16_t)((uint32_t)a.z >> 16);
       const RecGeom g = rec_geom(a.x, a.y, L);
       const int n_al = len2 - abr, w0 = g.start_w - win_base, actF = b4.z;
-      const bool wrap2 = linear && (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && (flags & TRF_DIAG) && g.split && g.start_w < L && w0 >= 0 &&
+      const bool wrap2 = (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && (flags & TRF_DIAG) && g.split && g.start_w < L && w0 >= 0 &&
                          w0 + g.ncols_f <= TALLY_WIN && n_al == g.ncols_f + g.ncols_b && n_al > 0 && actF == g.ncols_f;
       if (wrap2) {
         fast = true;
@@ -735,18 +748,19 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
             lds_i32* t = (lds_i32*)lds + wc;
             if (!dropped) {
               if (!ranges) aadd(&t[T_COV * TALLY_WIN], mult);
-              if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], mult); else aadd((lds_i32*)n_cnt + wc, mult);
+              for (int m = 0; m < mult; m++) add_base(wc, code, d, (flags & TRF_RC) != 0);
             }
             if (!ranges && p > 0) aadd(&t[T_SPAN * TALLY_WIN], mult);
           } else {
             int32_t* t = tb.tally + gc;
             if (!dropped) {
+              const int16_t* row = pssm_lds + (LINEAR ? 0 : ((flags & TRF_RC) ? PSSM_WORDS : 0) + d * 25) + code;
               atomicAdd(&t[T_COV * Lp], mult);
               if (code < 4) atomicAdd(&t[(T_A + code) * Lp], mult);
-              atomicAdd(&t[T_SA * Lp], mult * (int)pssm_lds[0 * 5 + code]);
-              atomicAdd(&t[T_SC * Lp], mult * (int)pssm_lds[1 * 5 + code]);
-              atomicAdd(&t[T_SG * Lp], mult * (int)pssm_lds[2 * 5 + code]);
-              atomicAdd(&t[T_ST * Lp], mult * (int)pssm_lds[3 * 5 + code]);
+              atomicAdd(&t[T_SA * Lp], mult * (int)row[0]);
+              atomicAdd(&t[T_SC * Lp], mult * (int)row[5]);
+              atomicAdd(&t[T_SG * Lp], mult * (int)row[10]);
+              atomicAdd(&t[T_ST * Lp], mult * (int)row[15]);
             }
             if (p > 0) atomicAdd(&t[T_SPAN * Lp], mult);
           }
@@ -768,7 +782,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
     // Second most common: one gap (k_band_align says where), otherwise as above, counts only (linear).  Also one read per
     // lane: the bases before the gap, the gap -- deleted reference columns count as '-', inserted read rows become insert
     // events (src/map_align.c:444-510 through the general path's event format) --, the bases after it.
-    if (have && !fast && linear && !(dbg & 8u)) {
+    if (have && !fast && !(dbg & 8u)) {
       const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16);
       const int4 a = tr4[0], b4 = tr4[1], c4 = tr4[2];
       const int flags = a.w;
@@ -787,14 +801,13 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
         const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);
         const bool dF = (flags & TRF_DF) != 0;
         lds_i32* t = (lds_i32*)lds + w0;
-        lds_i32* nc = (lds_i32*)n_cnt + w0;
-        const int bad = n_al > PSSM_DEPTH + 1 && fB < n_al;            // (depth codes only have to be valid, see above)
+        const int bad = n_al > PSSM_DEPTH + 1 && fB < n_al;            // (depth codes have to be valid: act <= 15 always is, beyond that fB - act - 1 >= 0)
         uint32_t word = 0;
         for (int r = abr; r < len2; r++) {
           if (r == abr || (r & 7) == 0) word = rp[r >> 3];
           const int code = (int)((word >> ((r & 7) * 4)) & 15u);
           if (r == grow && !ins) {                                     // deleted reference columns: '-' (covered, not a base)
-            for (int q = 0; q < gn; q++) { if (!dF) aadd(&t[T_GAP * TALLY_WIN], 1); t++; nc++; }
+            for (int q = 0; q < gn; q++) { if (!dF) aadd(&t[T_GAP * TALLY_WIN], 1); t++; }
           }
           if (ins && r >= grow && r < grow + gn) {                     // an inserted base: an event at the column that follows
             const int o = grow - abr, gc = g.start_w + o, act = grow + gn - abr, j = r - grow;
@@ -810,8 +823,11 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
             }
             continue;
           }
-          if (!dF) { if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1); else aadd(nc, 1); }
-          t++; nc++;
+          if (!dF) {
+            const int act = r - abr, d = depth_code(act, fB - act - 1);          // inserted rows count as read bases (src/fsdb.c:568-581)
+            add_base((int)(t - ((lds_i32*)lds)), code, d < 0 ? 0 : (d > 2 * PSSM_DEPTH ? 2 * PSSM_DEPTH : d), (flags & TRF_RC) != 0);
+          }
+          t++;
         }
         if (!dF) { aadd((lds_i32*)cov_diff + w0, 1); if (w0 + ncol < TALLY_WIN) aadd((lds_i32*)cov_diff + w0 + ncol, -1); }
         if (ncol > 1) { aadd((lds_i32*)span_diff + w0 + 1, 1); if (w0 + ncol < TALLY_WIN) aadd((lds_i32*)span_diff + w0 + ncol, -1); }
@@ -871,6 +887,20 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
     __syncthreads();
   }
   for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { lds[T_COV * TALLY_WIN + k] += cov_diff[k]; lds[T_SPAN * TALLY_WIN + k] += span_diff[k]; }
+  if (!LINEAR) {
+    // the bases of depth code 15: their counts into the base rows, their scores from sm[strand][15][X][b]
+    for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) {
+      int sc[4] = {0, 0, 0, 0};
+      for (int b5 = 0; b5 < 5; b5++) {
+        const uint32_t w = (uint32_t)mid_cnt[b5 * TALLY_WIN + k];
+        const int cf = (int)(w & 0xFFFFu), cr = (int)(w >> 16);
+        if (b5 < 4) lds[(T_A + b5) * TALLY_WIN + k] += cf + cr;
+        for (int x = 0; x < 4; x++)
+          sc[x] += cf * (int)pssm_lds[PSSM_DEPTH * 25 + x * 5 + b5] + cr * (int)pssm_lds[PSSM_WORDS + PSSM_DEPTH * 25 + x * 5 + b5];
+      }
+      lds[T_SA * TALLY_WIN + k] += sc[0]; lds[T_SC * TALLY_WIN + k] += sc[1]; lds[T_SG * TALLY_WIN + k] += sc[2]; lds[T_ST * TALLY_WIN + k] += sc[3];
+    }
+  }
   if (linear) {
     // the score rows from the counts: sm[X][b] of depth 0, forward table (src/map_align.c:258-261 adds sm[d][X][b] per base)
     for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) {

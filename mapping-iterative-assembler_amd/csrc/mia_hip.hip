@@ -1463,8 +1463,12 @@ static int tally_launch(mia_hip_ctx* ctx) {
         ctx->tally_slab_cap = slab_words;
       }
       if (stage_begin(ctx, STG_TALLY)) return MIA_HIP_ERR_NOMEM;
-      hipLaunchKernelGGL(k_tally_binned, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
-                         ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg, ctx->tally_linear ? 1 : 0);
+      if (ctx->tally_linear)
+        hipLaunchKernelGGL(k_tally_binned<true>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
+                           ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg);
+      else
+        hipLaunchKernelGGL(k_tally_binned<false>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
+                           ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg);
       stage_end(ctx, STG_TALLY);
       hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
     } else {

@@ -202,3 +202,27 @@ def test_fused_iteration_identical(full):
     t, g = hip.get_tally()
     assert np.array_equal(t, f.tally2) and np.array_equal(g, f.gaps2)
     hip.close()
+
+
+def test_window_tally_equals_plain_atomic_tally(full):
+    """the LDS-window tally (per-lane paths, bases of depth code 15 only counted and scored at the flush, one-gap and
+    over-the-origin reads one per lane) against the plain global-atomic tally that walks every script (MIA_HIP_NO_BINNED_TALLY=1):
+    all twelve words of every column, ref->gaps, the consensus and the insert-column tallies"""
+    f = full
+    os.environ["MIA_HIP_NO_BINNED_TALLY"] = "1"
+    try:
+        hip = f.mod.MiaHip(0)
+    finally:
+        os.environ.pop("MIA_HIP_NO_BINNED_TALLY", None)
+    hip.set_pssm(f.pssm)
+    hip.upload_reads(f.stored.reshape(-1), f.soff, f.rc, f.sk, f.al1[1], f.al1[2])
+    hip.realign(f.cons1, False)
+    s, ic = hip.score_cut(f.al2[0], f.lens)
+    hip.cull(0, s if s > 0 else 100.0, ic, 0)
+    hip.tally()
+    t, g = hip.get_tally()
+    assert np.array_equal(g, f.gaps2)
+    for w in range(11):
+        assert np.array_equal(t[w], f.tally2[w]), w
+    assert hip.consensus(1) == f.cons2
+    hip.close()
