@@ -364,10 +364,14 @@ MIA_HD inline int bx_count(const uint64_t* m, int from, int to) {
   return n;
 }
 
-// loss of the rows in [from, to) that mismatch on the diagonal sc is on (m = its mismatch words); *proof (if given):
-// D(q) >= -P(q+2) after every mismatch row q, with D(q) >= (q+1) min M - loss so far
+// loss of the rows in [from, to) that mismatch on the diagonal sc is on (m = its mismatch words).  *nfail counts the
+// mismatch rows q behind which dyn_prog's "new start" branch can fire on this path: D(q) < -P(q+2), with D(q) >= (q+1) min M
+// - loss so far.  That branch DROPS the substitution score of the row it starts in (src/mia.c:916-917), so the value the
+// recurrence reaches along the path is lower than the path's own by less than max M each time it fires (and it can only
+// fire behind a mismatch row; the test counts earlier firings against the later ones).  nfail == 0: the diagonal proof of
+// align_body_quad_plain.h.
 template <int NW>
-MIA_HD inline int bx_rows_loss(const DiagScan<NW>& sc, const uint64_t* m, int from, int to, int len2, int st, const BxTab& T, int b0, bool* proof) {
+MIA_HD inline int bx_rows_loss(const DiagScan<NW>& sc, const uint64_t* m, int from, int to, int len2, int st, const BxTab& T, int b0, int* nfail) {
 #pragma unroll
   for (int j = 0; j < NW; j++) {
     uint64_t w = m[j];
@@ -381,7 +385,7 @@ MIA_HD inline int bx_rows_loss(const DiagScan<NW>& sc, const uint64_t* m, int fr
       const int b = (int)(((sc.rlo[j] >> k) & 1ull) | (((sc.rhi[j] >> k) & 1ull) << 1));
       const int i = (int)(((sc.clo[j] >> k) & 1ull) | (((sc.chi[j] >> k) & 1ull) << 1));
       b0 += T.loss[((st * 31 + sm_depth(q, len2)) * 4 + b) * 4 + i];
-      if (proof && b0 > (q + 1) * T.min_m + GOP + GEP * (q + 2)) *proof = false;
+      if (b0 + *nfail * T.max_m > (q + 1) * T.min_m + GOP + GEP * (q + 2)) (*nfail)++;
     }
   }
   return b0;
@@ -397,10 +401,9 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   sc.seek(rp, (int64_t)s + d_first);
 #pragma unroll
   for (int j = 0; j < NW; j++) m1[j] = sc.mis(j);
-  int b0 = 0;
-  bool proof = true;
+  int b0 = 0, nfail = 0;
   if (PATHS == 1 || (PATHS == 0 && d_first == d_last)) {
-    b0 = bx_rows_loss<NW>(sc, m1, 0, len2, len2, st, T, 0, &proof);
+    b0 = bx_rows_loss<NW>(sc, m1, 0, len2, len2, st, T, 0, &nfail);
   } else {
     // rows [0, t) on d_first, one gap, the rest on d_last: a column gap (d_last > d_first) or `skip` inserted rows
     const int shift = d_last - d_first, skip = shift < 0 ? -shift : 0;            // |shift| < BX_MAXW
@@ -420,20 +423,25 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
       if (cur < best) { best = cur; tbest = t; }
     }
     b0 = shift > 0 ? GOP + GEP * shift : GOP + (GEP + T.max_m) * skip;
-    b0 = bx_rows_loss<NW>(sc, m1, 0, tbest, len2, st, T, b0, nullptr);
-    b0 = bx_rows_loss<NW>(s2, m2, tbest + skip, len2, len2, st, T, b0, nullptr);
+    b0 = bx_rows_loss<NW>(sc, m1, 0, tbest, len2, st, T, b0, &nfail);
+    b0 = bx_rows_loss<NW>(s2, m2, tbest + skip, len2, len2, st, T, b0, &nfail);
   }
+  const bool proof = nfail == 0;
+  // what bounds the optimum is the value the RECURRENCE reaches along the written-down path, which the new-start quirk
+  // can push below the path's own (found by tools/band_campaign.py with the ancient matrix: two heavy substitutions in
+  // rows 0 and 1, a start in row 2 that forfeits 214, and a six-column gap that then wins by 30)
+  const int b0x = b0 + nfail * T.max_m;
   out->b0 = BXF_BUDGET;
-  if (b0 > an.budget) return;
-  if (an.l_out >= 0 && an.l_out <= b0) { out->b0 = BXF_SPAN; return; }      // some anchors were set aside: see bx_anchors
+  if (b0x > an.budget) return;
+  if (an.l_out >= 0 && an.l_out <= b0x) { out->b0 = BXF_SPAN; return; }      // some anchors were set aside: see bx_anchors
   // how far a path that loses no more than b0 can stray from the anchors: all of b0 spent on one gap (band_body.h) --
   // or, tighter, what is left of b0 once every block that occurs nowhere in the window has been paid for (an.s_un: such
   // a block costs dl wherever it is crossed, unless a gap of the path itself breaks it -- the stray tables are net of
   // that).  In full: loss(P) >= s_un + sum over P's events of (cost - dl of the unanchored blocks the event touches), every
   // term >= 0; to be n diagonals off an anchor, the events between that place and the anchor add up to n in one direction.
-  int g_dn = b0 < GOP + GEP ? 0 : (b0 - GOP) / GEP, g_up = g_dn;
+  int g_dn = b0x < GOP + GEP ? 0 : (b0x - GOP) / GEP, g_up = g_dn;
   if (g_dn > 0) {
-    const int x = b0 - an.s_un;
+    const int x = b0x - an.s_un;
     if (x < 0) { out->b0 = BXF_PATH; return; }         // (cannot happen: every path pays for the blocks that occur nowhere)
     const int16_t* dn = T.dl + bx_stray_off(st, len2, 0);
     const int16_t* up = T.dl + bx_stray_off(st, len2, 1);

@@ -306,3 +306,36 @@ def test_tight_stray_bound_on_low_complexity(emul, oracle):
                 continue
             finished += 1 if check(emul, oracle, spec, strand, ref, s, l1, read, stats) else 0
     assert stats["n"] > 1000 and finished > 500, (stats, finished)
+
+
+def test_new_start_quirk_under_the_written_path(emul, oracle):
+    """dyn_prog's "new start" branch drops the substitution score of the row it starts in (src/mia.c:916-917): along a
+    diagonal whose first rows mismatch heavily the recurrence reaches LESS than the path's own value, so a deletion right
+    behind a head of 2-5 rows can win although its loss exceeds the diagonal's (found by tools/band_campaign.py, ancient
+    matrix: rows 0 and 1 mismatch, a start in row 2 forfeits 214, a six-column gap wins by 30).  The band must be sized
+    from the value the recurrence reaches (bx_rows_loss: nfail).  Heads whose bases face transversions on the body's
+    diagonal, every gap length from 3 to 12 -- the critical one, whose cost just exceeds the diagonal's loss, among them."""
+    rnd = random.Random(123)
+    stats = {"n": 0}
+    finished = 0
+    worst = {"A": "C", "C": "A", "G": "T", "T": "G"}
+    for spec, strand in MATS:
+        for i in range(60):
+            n = rnd.choice([100, 150, 250])
+            head = rnd.randint(2, 5)
+            left = "".join(rnd.choice("ACGT") for _ in range(80))
+            body = "".join(rnd.choice("ACGT") for _ in range(n + 60))
+            core_head = "".join(rnd.choice("ACGT") for _ in range(head))
+            for k in range(max(head, 3), 13):
+                filler = "".join(rnd.choice("ACGT") for _ in range(k - head)) + "".join(worst[c] for c in core_head)
+                # reference: head, k unrelated bases (the last `head` of them as unlike the head as can be), body;
+                # read: head + body -- a deletion of k right behind the head
+                ref = left + core_head + filler + body
+                read = (core_head + body)[:n]
+                if i % 3 == 0:
+                    read = read[:head] + damage(rnd, read)[head:]
+                s, l1 = window(ref, len(left) + k, n, margin=50)
+                if l1 < n or l1 > 760:
+                    continue
+                finished += 1 if check(emul, oracle, spec, strand, ref, s, l1, read, stats) else 0
+    assert stats["n"] > 2000 and finished > 1500, (stats, finished)

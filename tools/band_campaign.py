@@ -1,8 +1,9 @@
 """A longer differential campaign for the banded DP than the test suite has time for: many seeds of
 tests/test_gpu_band.py's generators (random and adversarial references, read lengths 30-250, indels up to 12, jittered
 pass-1 coordinates), banded DP on against off, every read's score, end points and script.
-usage: band_campaign.py [rounds [first seed [MIA_HIP_NO_DIAG_FILTER]]]   (third argument: the switch that defines "off";
-MIA_HIP_NO_DIAG_FILTER takes filter AND banded DP out, i.e. compares both shortcuts with the full-window DP kernels)"""
+usage: band_campaign.py [rounds [first seed [MIA_HIP_NO_DIAG_FILTER [matrix]]]]   (third argument: the switch that defines
+"off"; MIA_HIP_NO_DIAG_FILTER takes every shortcut out, i.e. compares the band pipeline with the full-window DP kernels;
+fourth: flat (default), ancient, solexa -- the position-specific matrices, both strands mixed, aDNA damage on the reads)"""
 import os
 import sys
 import time
@@ -19,10 +20,14 @@ from test_gpu_filter_stress import adversarial_reference  # noqa: E402
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 switch = sys.argv[3] if len(sys.argv) > 3 else "MIA_HIP_NO_BAND_DP"
+matrix = sys.argv[4] if len(sys.argv) > 4 else "flat"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PSSM = mia_amd.flat_pssm() if matrix == "flat" else mia_amd.read_pssm(os.path.join(GOLDEN, {"ancient": "ancient.submat.txt", "solexa": "ancient.submat.solexa.pe.txt"}[matrix]))
 
 
-def compare(refs, reads, read_len, as0, ae0):
+def compare(refs, reads, read_len, as0, ae0, rc=None):
     n = len(reads)
+    rc = np.zeros(n, np.uint8) if rc is None else rc
     off = np.arange(n + 1, dtype=np.int64) * read_len
     out = []
     for env in (None, switch):
@@ -31,8 +36,8 @@ def compare(refs, reads, read_len, as0, ae0):
         hip = mia_amd.MiaHip(0)
         if env:
             os.environ.pop(env)
-        hip.set_pssm(mia_amd.flat_pssm())
-        hip.upload_reads(reads.reshape(-1), off, np.zeros(n, np.uint8), np.ones(n, np.uint8), as0, ae0)
+        hip.set_pssm(PSSM)
+        hip.upload_reads(reads.reshape(-1), off, rc, np.ones(n, np.uint8), as0, ae0)
         hip.realign(refs, True)
         sc, a, e = hip.alignments()
         cols, rstart = hip.scripts()
@@ -55,10 +60,23 @@ for k in range(rounds):
     jitter = rng.integers(-10, 11, n) * (rng.random(n) < 0.3)
     as0 = ((start + jitter) % L).astype(np.int32)
     ae0 = (as0 + read_len - 1).astype(np.int32)
-    if switch == "MIA_HIP_NO_BAND_DP":
+    if matrix != "flat":
+        # aDNA damage on the stored read (C->T towards one end, G->A towards the other, by strand) and a random strand flag
+        rc = (rng.random(n) < 0.5).astype(np.uint8)
+        pos = np.arange(read_len)
+        p5 = 0.30 * np.exp(-0.35 * pos)[None, :]
+        p3 = p5[:, ::-1]
+        u, v = rng.random(reads.shape), rng.random(reads.shape)
+        fw = rc[:, None] == 0
+        reads = np.where((reads == ord("C")) & (u < np.where(fw, p5, 0)), ord("T"), reads)
+        reads = np.where((reads == ord("G")) & (v < np.where(fw, p3, 0)), ord("A"), reads)
+        reads = np.where((reads == ord("G")) & (u < np.where(~fw, p3, 0)), ord("A"), reads)
+        reads = np.where((reads == ord("C")) & (v < np.where(~fw, p5, 0)), ord("T"), reads).astype(np.uint8)
+        compare(ref.tobytes().decode(), reads, read_len, as0, ae0, rc)
+    elif switch == "MIA_HIP_NO_BAND_DP":
         run_both(mia_amd, ref.tobytes().decode(), reads, read_len, as0, ae0, 0.0)
     else:
         compare(ref.tobytes().decode(), reads, read_len, as0, ae0)
     reads_total += n
     print("round", k, "seed", seed, "len", read_len, "L", L, "ok", round(time.time() - t0, 1), "s", flush=True)
-print("campaign done:", reads_total, "reads, no difference")
+print("campaign done:", matrix, "matrix,", reads_total, "reads, no difference")
