@@ -284,6 +284,25 @@ class Pipeline:
                      "finished_by_trace_dp": by_trace + band_done, "to_full_window_kernels": max(left, 0)}
 
 
+def use_timed_region(stages, dominant, dom_ms, dom_launches, steps):
+    """Replace the dominant stage's duration by the one measured inside the timed region (only that stage carried event
+    pairs there) and rescale the figures derived from it.  A grouped stage (STAGE_KERNELS) stays one figure per step."""
+    if not dominant or not dom_launches:
+        return
+    for sg in stages:
+        if sg["kernel"] != dominant:
+            continue
+        per = steps if dominant in STAGE_KERNELS else dom_launches
+        scale = (dom_ms / per) / sg["kernel_ms"]
+        sg["kernel_ms_instrumented_steps"] = sg["kernel_ms"]
+        sg["kernel_ms"], sg["ms_per_step"], sg["launches"], sg["timed_region"] = dom_ms / per, dom_ms / steps, per, True
+        if dominant in STAGE_KERNELS:
+            sg["device_launches"] = dom_launches
+        for key in ("achieved", "frac", "gcups", "valu_frac"):
+            if sg.get(key) is not None:
+                sg[key] = sg[key] / scale
+
+
 def roofline(stages, peaks, pmc_tag, pmc_stale):
     timed = [s for s in stages if s.get("timed_region")]
     dom = timed[0] if timed else max(stages, key=lambda s: s["ms_per_step"])
@@ -347,14 +366,7 @@ def section_converge(hip_mod, device, cfg, n, seed, peaks, no_cpu, max_iters=12)
     tag = f"cfg{cfg}"
     pmc, stale = load_pmc(tag)
     stages, counts = pipe.stages(K, peaks, pmc, stale)
-    for sg in stages:
-        if sg["kernel"] == dominant and dom_launches:
-            scale = (dom_ms / dom_launches) / sg["kernel_ms"]
-            sg["kernel_ms_instrumented_steps"] = sg["kernel_ms"]
-            sg["kernel_ms"], sg["ms_per_step"], sg["launches"], sg["timed_region"] = dom_ms / dom_launches, dom_ms / K, dom_launches, True
-            for key in ("achieved", "frac", "gcups", "valu_frac"):
-                if sg.get(key) is not None:
-                    sg[key] = sg[key] / scale
+    use_timed_region(stages, dominant, dom_ms, dom_launches, K)
     out = {"workload": f"configs[{cfg}]: {n} synthetic {w['read_len']} bp aDNA-damaged reads vs {w['ref_name']}, matrix {w['matrix_file']}; "
                        "pass-1 coordinates = true positions",
            "iterations_to_convergence": rounds, "converged": converged, "ms_per_iteration": it_ms,
@@ -509,18 +521,7 @@ def main():
         tag = f"cfg{a.config}"
         pmc, stale = load_pmc(tag)
         stages, counts = pipe.stages(a.steps, peaks, pmc, stale)
-        if dominant and dom_launches:
-            for sg in stages:                       # the dominant kernel's duration as measured inside the timed region
-                if sg["kernel"] == dominant:
-                    scale = (dom_ms / dom_launches) / sg["kernel_ms"]
-                    sg["kernel_ms_instrumented_steps"] = sg["kernel_ms"]
-                    sg["kernel_ms"] = dom_ms / dom_launches
-                    sg["ms_per_step"] = dom_ms / a.steps
-                    sg["launches"] = dom_launches
-                    for key in ("achieved", "frac", "gcups", "valu_frac"):
-                        if sg.get(key) is not None:
-                            sg[key] = sg[key] / scale
-                    sg["timed_region"] = True
+        use_timed_region(stages, dominant, dom_ms, dom_launches, a.steps)
         out = {
             "metric": "reads aligned/sec per iteration (16.5kb mito ref, 100bp reads)",
             "value": total_reads * a.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

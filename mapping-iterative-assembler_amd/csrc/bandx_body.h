@@ -25,6 +25,14 @@
 // path that is cheap to write down, bounds the optimum's loss: every alignment that can win OR TIE lies on the diagonals
 // [lowest anchor - g, highest anchor + g].  The band argument itself (band_body.h) never looked at the matrix.
 //
+// N COLUMNS.  A reference column that holds an ambiguity code scores sm[d][N][b] whatever the read base (base2inx,
+// src/mia.c:1521-1541): a known loss lambda(r) = M(r) - sm[d][N][b_r] >= 0, small next to a substitution (210 against 800 with
+// the flat matrix).  Such a column cannot break a block: "cleanly" means ten rows on one diagonal over columns that are
+// identical OR N, and the table lists those places too -- a reference 10-mer with k <= BX_WILD ambiguity codes is entered
+// under all 4^k spellings (k_kmer_hash).  A clean crossing over more than BX_WILD of them is in no table, so it must
+// cost at least dl_b like any other way past the block: dl_b is capped at (BX_WILD + 1) min lambda over the block's
+// rows.  Everything else is unchanged: B0 counts the N columns of the written-down path, gaps cost what they cost.
+//
 // With one anchor diagonal and g = 0 the band is that diagonal: the pure diagonal path D is the only path that loses
 // <= B0 (a late start on it costs > GOP + GEP), hence the unique optimum, and with D(r-1) >= -P(r+1) for every row the
 // reference's traceback walks it (align_body_quad_plain.h's proof) -- no DP at all.
@@ -48,19 +56,23 @@ constexpr int BX_SUB_WORDS = 2 * 31 * 4 * BX_SUB_ROW;
 constexpr int BX_NIB_LEAD = 320;      // nibbles in front of reference position 0 (multiple of 8, >= MAX_READ)
 constexpr int BX_NIB_TAIL = 704;
 constexpr int BX_NCLS = 4;            // band classes: 8, 16, 24, 32 diagonals
+constexpr int BX_WILD = 3;            // most N columns in a reference 10-mer that is still entered in the table (4^k spellings)
 MIA_HD inline int bx_class_of(int w) { return w <= 8 ? 0 : (w <= 16 ? 1 : (w <= 24 ? 2 : 3)); }
 
 // what the host derives from the two matrices (mia_hip_set_pssm) -- see bx_make_tables
 struct BxTab {
   const int32_t* sub;      // [2][31][4][8]: sm[strand][depth][ref code 0..4][read base], read base major
   const int32_t* mrow;     // [2][31][4]:    M
-  const int16_t* loss;     // [2][31][4][4]: M - sm, by (strand, depth, read base, reference base)
+  const int16_t* loss;     // [2][31][4][4]: M - sm, by (strand, depth, read base, reference base); behind it [2][31][4]: the
+                           // same over an N column (BX_LOSS_N), and the N-column credit (BX_LOSS_KAP, see bx_finish)
   const int16_t* dl;       // [2][MAX_READ+1][BX_BLOCKS]: what breaking block b of a read of that length costs at least;
                            // behind it the stray tables (bx_stray_off): what straying n diagonals costs at least, net of the
                            // blocks the gaps themselves break
   int32_t min_m, max_m;
 };
-constexpr int BX_LOSS_WORDS = 2 * 31 * 4 * 4;
+constexpr int BX_LOSS_N = 2 * 31 * 4 * 4;
+constexpr int BX_LOSS_KAP = BX_LOSS_N + 2 * 31 * 4;       // [2][31][31]: what crossing an N column costs at least, by strand and depth range
+constexpr int BX_LOSS_WORDS = BX_LOSS_KAP + 2 * 31 * 31;
 constexpr int BX_GMAX = 32;            // stray tables: phi / psi for 0..BX_GMAX diagonals
 constexpr int BX_DL_BLOCKS = 2 * (MAX_READ + 1) * BX_BLOCKS;                       // dl proper
 constexpr int BX_DL_WORDS = BX_DL_BLOCKS + 2 * (MAX_READ + 1) * 2 * (BX_GMAX + 1);  // + [strand][len][down | up][0..BX_GMAX]
@@ -75,10 +87,10 @@ MIA_HD inline int bx_blocks_of(int len2) { const int cap = len2 > 128 ? BX_BLOCK
 inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, int32_t* mrow, int16_t* loss, int16_t* dl, int32_t* min_m, int32_t* max_m) {
   const int32_t* tabs[2] = {fwd, rc};
   int mn = 1 << 30, mx = -(1 << 30);
-  int delta[2][31];
+  int delta[2][31], lamn[2][31];
   for (int st = 0; st < 2; st++)
     for (int d = 0; d < 31; d++) {
-      int dmin = 1 << 30;
+      int dmin = 1 << 30, lmin = 1 << 30;
       for (int b = 0; b < 4; b++) {
         int32_t* row = sub + ((st * 31 + d) * 4 + b) * BX_SUB_ROW;
         for (int i = 0; i < BX_SUB_ROW; i++) row[i] = tabs[st][(d * 5 + (i < 5 ? i : 4)) * 5 + b];
@@ -87,6 +99,8 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
         if (row[b] != m || m <= 0 || row[4] > m) return false;      // identity is the best base; skipping a row never pays; N is no better
         for (int i = 0; i < 5; i++) if (row[i] > 4000 || row[i] < -4000) return false;   // (value * 256 + code must fit a word, with room)
         mrow[(st * 31 + d) * 4 + b] = m;
+        loss[BX_LOSS_N + (st * 31 + d) * 4 + b] = (int16_t)(m - row[4]);
+        if (m - row[4] < lmin) lmin = m - row[4];
         for (int i = 0; i < 4; i++) {
           loss[((st * 31 + d) * 4 + b) * 4 + i] = (int16_t)(m - row[i]);
           if (i != b && m - row[i] < dmin) dmin = m - row[i];
@@ -95,7 +109,16 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
         if (m > mx) mx = m;
       }
       delta[st][d] = dmin;
+      lamn[st][d] = lmin;
     }
+  // kap[st][dlo][dhi]: an N column crossed by a row of depth dlo..dhi, or inside a column gap, costs at least this
+  for (int st = 0; st < 2; st++)
+    for (int a = 0; a < 31; a++)
+      for (int b = 0; b < 31; b++) {
+        int v = GEP;
+        for (int d = a; d <= b; d++) if (lamn[st][d] < v) v = lamn[st][d];
+        loss[BX_LOSS_KAP + (st * 31 + a) * 31 + b] = (int16_t)(a <= b && v > 0 ? v : 0);
+      }
   // skipped rows (an insert, a soft clip): n of them touch at most ceil((n-1)/10)+1 blocks and cost at least GOP + (GEP + min M) n
   int e = GOP + GEP;                    // (a column gap inside a block)
   for (int n = 1; n <= 2 * MAX_READ; n++) {
@@ -111,7 +134,13 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
         if (nb_cut >= BX_MIN_BLOCKS && b < nb_cut) {
           const int o = bx_block_row(b, len2, nb_cut);
           v = e;
-          for (int r = o; r < o + DF_K; r++) { const int dd = delta[st][sm_depth(r, len2)]; if (dd < v) v = dd; }
+          int lam = 1 << 20;
+          for (int r = o; r < o + DF_K; r++) {
+            const int dd = delta[st][sm_depth(r, len2)], ll = lamn[st][sm_depth(r, len2)];
+            if (dd < v) v = dd;
+            if (ll < lam) lam = ll;
+          }
+          if ((BX_WILD + 1) * lam < v) v = (BX_WILD + 1) * lam;      // a clean crossing over more N columns than the table knows
         }
         dl[(st * (MAX_READ + 1) + len2) * BX_BLOCKS + b] = (int16_t)v;
       }
@@ -180,6 +209,7 @@ struct KmerHash {
   const int32_t* ovf;      // [2 * (mask + 1)]
   uint32_t mask;
   int32_t shift;           // 32 - log2(slots)
+  int32_t wild;            // reference 10-mers with up to this many N are in the table under every spelling (0: none with N)
 };
 constexpr uint32_t KH_EMPTY = 0xFFFFFFFFu;
 MIA_HD inline uint32_t kh_slots_for(int64_t n_codes) { uint32_t s = 1024; while ((int64_t)s < 4 * n_codes) s <<= 1; return s; }
@@ -201,6 +231,22 @@ MIA_HD inline int kh_resolve(const KmerHash& kh, uint32_t idx, uint32_t h, uint3
   }
   return DF_KCAP + 1;                                // a crowded neighbourhood: not part of the pigeonhole
 }
+// table entries a reference makes (host; the slots must outnumber them two to one)
+inline int64_t kh_wild_entries(const uint8_t* codes, int64_t n_codes, int wild) {
+  int64_t e = 0;
+  int k = 0;
+  for (int64_t p = 0; p < n_codes; p++) {
+    k += codes[p] > 3;
+    if (p >= DF_K) k -= codes[p - DF_K] > 3;
+    if (p >= DF_K - 1 && k <= wild) e += (int64_t)1 << (2 * k);
+  }
+  return e;
+}
+inline uint32_t kh_slots_for_entries(int64_t n_codes, int64_t entries) {
+  uint32_t s = kh_slots_for(n_codes);
+  while ((int64_t)s < 2 * entries && s < (1u << 30)) s <<= 1;
+  return s;
+}
 // host-side insert (the tests); the device inserts with atomics (k_kmer_hash)
 inline void kh_insert_host(uint32_t* slot, int32_t* ovf, uint32_t mask, int shift, uint32_t idx, int32_t p) {
   uint32_t h = (idx * 2654435761u) >> shift;
@@ -209,6 +255,14 @@ inline void kh_insert_host(uint32_t* slot, int32_t* ovf, uint32_t mask, int shif
   e[0] = idx;
   const uint32_t c = ++e[2];                        // (starts at all ones)
   if (c == 0) e[1] = (uint32_t)p; else if (c == 1) e[3] = (uint32_t)p; else if (c < 4) ovf[2 * (size_t)h + c - 2] = p;
+}
+// every spelling of the 10-mer at p (the tests; k_kmer_hash on the device)
+inline void kh_insert_wild_host(uint32_t* slot, int32_t* ovf, uint32_t mask, int shift, const uint8_t* codes, int64_t n_codes, int64_t p, int wild) {
+  uint32_t idx;
+  uint64_t npos;
+  const int k = kmer_wild_at(codes, n_codes, p, &idx, &npos);
+  if (k < 0 || k > wild) return;
+  for (uint32_t x = 0; x < (1u << (2 * k)); x++) kh_insert_host(slot, ovf, mask, shift, kmer_wild_key(idx, npos, k, x), (int32_t)p);
 }
 
 // mode of a planned read
@@ -364,8 +418,9 @@ MIA_HD inline int bx_count(const uint64_t* m, int from, int to) {
   return n;
 }
 
-// loss of the rows in [from, to) that mismatch on the diagonal sc is on (m = its mismatch words).  *nfail counts the
-// mismatch rows q behind which dyn_prog's "new start" branch can fire on this path: D(q) < -P(q+2), with D(q) >= (q+1) min M
+// loss of the rows in [from, to) that lose anything on the diagonal sc is on (m = those rows: mismatches and N columns,
+// bx_loss_rows).  *nfail counts the
+// rows q among them behind which dyn_prog's "new start" branch can fire on this path: D(q) < -P(q+2), with D(q) >= (q+1) min M
 // - loss so far.  That branch DROPS the substitution score of the row it starts in (src/mia.c:916-917), so the value the
 // recurrence reaches along the path is lower than the path's own by less than max M each time it fires (and it can only
 // fire behind a mismatch row; the test counts earlier firings against the later ones).  nfail == 0: the diagonal proof of
@@ -384,12 +439,17 @@ MIA_HD inline int bx_rows_loss(const DiagScan<NW>& sc, const uint64_t* m, int fr
       w &= w - 1;
       const int b = (int)(((sc.rlo[j] >> k) & 1ull) | (((sc.rhi[j] >> k) & 1ull) << 1));
       const int i = (int)(((sc.clo[j] >> k) & 1ull) | (((sc.chi[j] >> k) & 1ull) << 1));
-      b0 += T.loss[((st * 31 + sm_depth(q, len2)) * 4 + b) * 4 + i];
+      const int at = (st * 31 + sm_depth(q, len2)) * 4 + b;
+      b0 += ((sc.cok[j] >> k) & 1ull) ? T.loss[at * 4 + i] : T.loss[BX_LOSS_N + at];
       if (b0 + *nfail * T.max_m > (q + 1) * T.min_m + GOP + GEP * (q + 2)) (*nfail)++;
     }
   }
   return b0;
 }
+
+// the rows of word j that lose anything on the diagonal sc is on: definite mismatches and N columns
+template <int NW>
+MIA_HD inline uint64_t bx_loss_rows(const DiagScan<NW>& sc, int j) { return sc.mis(j) | (~sc.cok[j] & sc.rows[j]); }
 
 // B0 (the loss of one valid path) and what follows from it
 // PATHS: 0 = whatever the anchors say, 1 = the caller knows d_first == d_last, 2 = the caller knows they differ
@@ -400,7 +460,7 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   uint64_t m1[NW];
   sc.seek(rp, (int64_t)s + d_first);
 #pragma unroll
-  for (int j = 0; j < NW; j++) m1[j] = sc.mis(j);
+  for (int j = 0; j < NW; j++) m1[j] = bx_loss_rows<NW>(sc, j);
   int b0 = 0, nfail = 0;
   if (PATHS == 1 || (PATHS == 0 && d_first == d_last)) {
     b0 = bx_rows_loss<NW>(sc, m1, 0, len2, len2, st, T, 0, &nfail);
@@ -415,7 +475,7 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
     DiagScan<NW> s2 = sc;
     s2.seek(rp, (int64_t)s + d_last);
 #pragma unroll
-    for (int j = 0; j < NW; j++) m2[j] = s2.mis(j);
+    for (int j = 0; j < NW; j++) m2[j] = bx_loss_rows<NW>(s2, j);
     // the switch row with the fewest mismatches in [t_lo, t_hi]
     int cur = bx_count<NW>(m1, 0, t_lo) + bx_count<NW>(m2, t_lo + skip, len2), best = cur, tbest = t_lo;
     for (int t = t_lo + 1; t <= t_hi; t++) {
@@ -453,6 +513,50 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
       g_up = g_dn;
     }
   }
+  // N CREDIT.  Anchors on one diagonal d*, the written-down path P0 the pure diagonal, and a band of +-G around it that is
+  // already proven.  Every N column under P0's rows G .. R-G is crossed by EVERY path P of that band that starts in row 0:
+  // by a row within G of P0's (cost >= kap of that depth range) or inside a column gap (GEP >= kap).  Take that much
+  // (credit = the sum of kap over those columns) out of both sides: P's events must fit into y = B0 - credit, where an
+  // event costs, net of the credit it may consume, at least GOP -- a column gap GOP + GEP per column that is NOT one
+  // of those, skipped rows GOP + (GEP + min M) each (they cross nothing), a late start of r rows GOP + GEP (r + 1) +
+  // r min M (it misses at most r of the columns).
+  //   y < GOP      no event at all: pure diagonals from row 0, which by the pigeonhole run through an anchor -- P0 itself.
+  //   y < 2 GOP    one event, so P is on d* before or behind it (the pigeonhole again).  A column gap holds at most
+  //                m = (y - GOP) / GEP columns without credit, i.e. at most m + 1 runs of credited ones: it is no longer
+  //                than (m + 1) * (longest such run) + m; skipped rows number at most (y - GOP) / (GEP + min M).
+  // (Against mt311, every tenth column an ambiguity code, B0 is mostly such columns: without the credit the band would
+  // be 20-30 diagonals wide.)
+  if (g_dn + g_up > 0 && (PATHS == 1 || d_first == d_last) && an.a_lo == an.a_hi) {
+    int G = b0x < GOP + GEP ? 0 : (b0x - GOP) / GEP;
+    const int gt = g_dn > g_up ? g_dn : g_up;
+    if (gt <= BX_GMAX && gt < G) G = gt;
+    int credit = 0, run = 0, run_max = 0, prev = -2;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+      uint64_t w = ~sc.cok[j] & sc.rows[j];
+      while (w) {
+        const int k = df_ctz(w), q = j * 64 + k;
+        w &= w - 1;
+        if (q < G || q > R - G) continue;
+        const int kv = T.loss[BX_LOSS_KAP + (st * 31 + sm_depth(q - G, len2)) * 31 + sm_depth(q + G, len2)];
+        if (kv <= 0) continue;
+        credit += kv;
+        run = q == prev + 1 ? run + 1 : 1;
+        prev = q;
+        if (run > run_max) run_max = run;
+      }
+    }
+    const int y = b0x - credit;
+    if (credit > 0 && y < 2 * GOP) {
+      int gn = 0;
+      if (y >= GOP) {
+        const int m = (y - GOP) / GEP, by_gap = (m + 1) * run_max + m, by_rows = (y - GOP) / (GEP + T.min_m);
+        gn = by_gap > by_rows ? by_gap : by_rows;
+      }
+      if (gn < g_dn) g_dn = gn;
+      if (gn < g_up) g_up = gn;
+    }
+  }
   // (one diagonal more where the window's first column is within reach, as band_body.h)
   if (an.a_lo - g_dn - 1 < 0) { g_dn++; g_up++; }
   const int d0 = an.a_lo - g_dn, w = an.a_hi - an.a_lo + g_dn + g_up + 1;
@@ -468,7 +572,7 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
 
 MIA_HD inline bool bx_plannable(const RefPlanes& rp, const KmerHash& ko, int64_t n_ref, int s, int len1, int len2) {
   if (!ko.slot || len2 < BX_MIN_BLOCKS * DF_K || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1 || s < 0 || (int64_t)s + len1 > n_ref) return false;
-  return all_bases(rp, s, (int64_t)s + len1);
+  return ko.wild > 0 || all_bases(rp, s, (int64_t)s + len1);     // (N columns: only with a table that lists them)
 }
 
 // everything in one go (the kernel does the same in two phases: reads with anchors on two diagonals are collected and

@@ -94,22 +94,27 @@ __device__ __forceinline__ void bx_diag_scripts(const ReadSet& rs, unsigned long
   }
 }
 
-// the reference's 10-mers into the hash table (bandx_body.h: KmerHash); slots and ovf are all ones / anything before
-__global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t n_codes, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift) {
+// the reference's 10-mers into the hash table (bandx_body.h: KmerHash); slots and ovf are all ones / anything before.
+// A 10-mer with up to `wild` N columns goes in under each of its 4^k spellings (the host sized the table for them).
+__global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t n_codes, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift, int32_t wild) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t idx64 = kmer_at(codes, n_codes, p);
-  if (idx64 < 0) return;
-  const uint32_t idx = (uint32_t)idx64;
-  uint32_t h = (idx * 2654435761u) >> shift;
-  for (;;) {
-    uint32_t* e = slot + 4 * (size_t)h;
-    const uint32_t prev = atomicCAS(&e[0], KH_EMPTY, idx);
-    if (prev == KH_EMPTY || prev == idx) {
-      const uint32_t c = atomicAdd(&e[2], 1u) + 1u;           // (starts at all ones)
-      if (c == 0) e[1] = (uint32_t)p; else if (c == 1) e[3] = (uint32_t)p; else if (c < 4) ovf[2 * (size_t)h + c - 2] = (int32_t)p;
-      return;
+  uint32_t base;
+  uint64_t npos;
+  const int k = kmer_wild_at(codes, n_codes, p, &base, &npos);
+  if (k < 0 || k > wild) return;
+  for (uint32_t x = 0; x < (1u << (2 * k)); x++) {
+    const uint32_t idx = kmer_wild_key(base, npos, k, x);
+    uint32_t h = (idx * 2654435761u) >> shift;
+    for (;;) {
+      uint32_t* e = slot + 4 * (size_t)h;
+      const uint32_t prev = atomicCAS(&e[0], KH_EMPTY, idx);
+      if (prev == KH_EMPTY || prev == idx) {
+        const uint32_t c = atomicAdd(&e[2], 1u) + 1u;           // (starts at all ones)
+        if (c == 0) e[1] = (uint32_t)p; else if (c == 1) e[3] = (uint32_t)p; else if (c < 4) ovf[2 * (size_t)h + c - 2] = (int32_t)p;
+        break;
+      }
+      h = (h + 1) & mask;
     }
-    h = (h + 1) & mask;
   }
 }
 

@@ -76,6 +76,26 @@ MIA_HD inline int64_t kmer_at(const uint8_t* codes, int64_t n_codes, int64_t p) 
   return idx;
 }
 
+// The 10-mer at reference position p with its N columns: *idx = the bases (N as 0), *npos = the places of the N, four bits
+// each; returns how many there are, -1 off the end of the reference.
+MIA_HD inline int kmer_wild_at(const uint8_t* codes, int64_t n_codes, int64_t p, uint32_t* idx, uint64_t* npos) {
+  if (p < 0 || p + DF_K > n_codes) return -1;
+  uint32_t x = 0;
+  uint64_t np = 0;
+  int k = 0;
+  for (int t = 0; t < DF_K; t++) {
+    const uint32_t c = codes[p + t];
+    if (c > 3) { np |= (uint64_t)t << (4 * k); k++; }
+    else x |= c << (2 * t);
+  }
+  *idx = x; *npos = np;
+  return k;
+}
+// spelling number x (0 .. 4^k - 1) of such a 10-mer
+MIA_HD inline uint32_t kmer_wild_key(uint32_t idx, uint64_t npos, int k, uint32_t x) {
+  for (int j = 0; j < k; j++) idx |= ((x >> (2 * j)) & 3u) << (2 * (int)((npos >> (4 * j)) & 15u));
+  return idx;
+}
 // one word of the three planes from 64 consecutive reference codes (0..3 bases, anything else N)
 MIA_HD inline void plane_word(const uint8_t* codes, int64_t n_codes, int64_t word, uint64_t* lo, uint64_t* hi, uint64_t* ok) {
   uint64_t l = 0, h = 0, k = 0;

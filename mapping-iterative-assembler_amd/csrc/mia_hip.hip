@@ -46,6 +46,8 @@ struct mia_hip_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the trace DP of the plan's own lists runs beside the values DP
   std::string err;
+  struct PoolBlock { void* p; size_t cap; bool lent; };
+  std::vector<PoolBlock> pool;             // device temporaries of the one-off calls (pool_alloc)
   // PSSMs (fwd, rc)
   int32_t* d_pssm = nullptr;
   int max_abs = 0;
@@ -100,6 +102,8 @@ struct mia_hip_ctx {
   // the diagonal filter (diag_filter.h): flat matrix only
   bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
   bool ref_mostly_bases = true;            // fewer than 2 % of the reference columns are N
+  int64_t kh_entries = 0;                  // > 0: the reference has N columns and its 10-mer table lists them (bandx_body.h, N COLUMNS)
+  int use_wild = 1;                        // MIA_HIP_NO_WILD=1: reads whose window holds an N go to the full-window kernels
   bool flat = false; int use_filter = 1;   // MIA_HIP_NO_DIAG_FILTER=1 sends every read to the DP kernels
   int64_t pre_cull_records = 0, pre_cull_links = 0; bool pre_cull_valid = false;   // mia_hip_score_sums' by-products
   int32_t *d_kocc_cnt = nullptr, *d_kocc_pos = nullptr;   // 10-mer table of the reference (diag_filter.h: KmerOcc)
@@ -193,6 +197,50 @@ static int dev_alloc(mia_hip_ctx* ctx, T** p, size_t n) {
   return MIA_HIP_OK;
 }
 
+// Temporaries of the one-off calls (pass 1, adapter trimming) come from blocks the context keeps: hipMalloc/hipFree of
+// twenty-odd buffers per call cost more than the kernels between them.  A block is lent for the length of a scope.
+template <class T>
+static int pool_alloc(mia_hip_ctx* ctx, T** p, size_t n) {
+  size_t bytes = (n ? n : 1) * sizeof(T);
+  int best = -1;
+  for (size_t k = 0; k < ctx->pool.size(); k++) {
+    auto& b = ctx->pool[k];
+    if (!b.lent && b.cap >= bytes && (best < 0 || b.cap < ctx->pool[best].cap)) best = (int)k;
+  }
+  if (best < 0) {
+    // grow the largest idle block rather than keep one that nothing fits any more
+    int idle = -1;
+    for (size_t k = 0; k < ctx->pool.size(); k++)
+      if (!ctx->pool[k].lent && (idle < 0 || ctx->pool[k].cap > ctx->pool[idle].cap)) idle = (int)k;
+    if (idle >= 0) { (void)hipFree(ctx->pool[idle].p); ctx->pool.erase(ctx->pool.begin() + idle); }
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); *p = nullptr; return MIA_HIP_ERR_NOMEM; }
+    ctx->pool.push_back({q, bytes, false});
+    best = (int)ctx->pool.size() - 1;
+  }
+  ctx->pool[best].lent = true;
+  *p = (T*)ctx->pool[best].p;
+  return MIA_HIP_OK;
+}
+struct PoolScope {
+  mia_hip_ctx* c;
+  std::vector<void**> w;
+  explicit PoolScope(mia_hip_ctx* ctx) : c(ctx) {}
+  void watch(void** pp) { w.push_back(pp); }
+  ~PoolScope() {
+    for (void** pp : w) {
+      if (!*pp) continue;
+      for (auto& b : c->pool) if (b.p == *pp) b.lent = false;
+      *pp = nullptr;
+    }
+  }
+};
+static void pool_drop(mia_hip_ctx* ctx) {
+  for (auto& b : ctx->pool) (void)hipFree(b.p);
+  ctx->pool.clear();
+}
+
 extern "C" const char* mia_hip_last_error(const mia_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
@@ -230,6 +278,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nbd && atoi(nbd)) { ctx->use_banddp = 0; ctx->use_bx = 0; }
     const char* nbx = getenv("MIA_HIP_NO_BANDX");
     if (nbx && atoi(nbx)) ctx->use_bx = 0;
+    const char* nwl = getenv("MIA_HIP_NO_WILD");
+    if (nwl && atoi(nwl)) ctx->use_wild = 0;
     const char* bxf = getenv("MIA_HIP_BX_FILTER");
     if (bxf && atoi(bxf)) ctx->bx_filter_first = 1;
     const char* nq = getenv("MIA_HIP_NO_QUAD");
@@ -279,6 +329,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->lk.rec, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs,
                   ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_slabs, ctx->d_cut_buf, ctx->d_ascii, ctx->d_cons, ctx->d_cons_pos, ctx->d_gather, ctx->d_lstage, ctx->d_lmine, ctx->d_lall, ctx->d_scores_all};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  pool_drop(ctx);
   for (int64_t* p : ctx->owned_links) if (p) (void)hipFree(p);
   if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
   if (ctx->h_pin2) (void)hipHostFree(ctx->h_pin2);
@@ -618,6 +669,11 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   for (int i = 0; i < wl; i++) codes[L + i] = codes[i];
   // a reference full of ambiguity codes (mt311 itself: every other column) leaves the diagonal filter nothing to decide
   ctx->ref_mostly_bases = n_other * 50 <= L;
+  ctx->kh_entries = 0;
+  if (n_other && ctx->use_wild) {
+    ctx->kh_entries = kh_wild_entries(codes.data(), wrap, BX_WILD);
+    if (ctx->kh_entries > ((int64_t)1 << 24)) ctx->kh_entries = 0;
+  }
   if ((int)codes.size() > ctx->ref_cap) {
     if (dev_alloc(ctx, &ctx->d_ref, codes.size() * 2)) return MIA_HIP_ERR_NOMEM;
     ctx->ref_cap = (int)codes.size() * 2;
@@ -680,7 +736,7 @@ static int align_all(mia_hip_ctx* ctx) {
   const int tb = 256, gb = (int)((n + (int64_t)tb * PLAN_PER - 1) / ((int64_t)tb * PLAN_PER));
   const int filter_ok = ctx->flat && ctx->use_filter && ctx->ref_mostly_bases;
   // the band pipeline for any matrix (bandx_kernels.h); it needs the 10-mer table and windows free of N
-  const bool bx = ctx->bx_ok && ctx->use_bx && ctx->ref_mostly_bases && wrap <= (1 << 22) && !(ctx->dbg & 128u);
+  const bool bx = ctx->bx_ok && ctx->use_bx && (ctx->ref_mostly_bases || ctx->kh_entries > 0) && wrap <= (1 << 22) && !(ctx->dbg & 128u);
   const bool run_filter = filter_ok && (!bx || ctx->bx_filter_first);
   const int filtered = run_filter || bx;            // bin_of carries marks for the planner
   uint32_t h_filter_n = 0;
@@ -702,7 +758,7 @@ static int align_all(mia_hip_ctx* ctx) {
       if (!ctx->d_kocc_cnt && (dev_alloc(ctx, &ctx->d_kocc_cnt, (size_t)DF_KTAB) || dev_alloc(ctx, &ctx->d_kocc_pos, (size_t)DF_KTAB * DF_KCAP)))
         return MIA_HIP_ERR_NOMEM;
       HIPCHK(hipMemsetAsync(ctx->d_kocc_cnt, 0, (size_t)DF_KTAB * 4, ctx->stream));
-      hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_kocc_cnt, ctx->d_kocc_pos);
+      hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_kocc_cnt, ctx->d_kocc_pos, 0);
       ko.cnt = ctx->d_kocc_cnt; ko.pos = ctx->d_kocc_pos;
     }
     // what the filter leaves over goes through a banded DP first (bandx_kernels.h, or round 1's band_body.h); both need the table
@@ -726,15 +782,15 @@ static int align_all(mia_hip_ctx* ctx) {
         ctx->refnib_cap = nw * 2;
       }
       hipLaunchKernelGGL(k_ref_nibbles, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, nw, ctx->d_refnib);
-      const uint32_t kslots = kh_slots_for(wrap);
+      const uint32_t kslots = kh_slots_for_entries(wrap, ctx->kh_entries);
       if (kslots > ctx->khash_cap) {
         if (dev_alloc(ctx, &ctx->d_khash, (size_t)kslots * 4) || dev_alloc(ctx, &ctx->d_khash_ovf, (size_t)kslots * 2)) return MIA_HIP_ERR_NOMEM;
         ctx->khash_cap = kslots;
       }
       HIPCHK(hipMemsetAsync(ctx->d_khash, 0xFF, (size_t)kslots * 16, ctx->stream));
-      const KmerHash kh{ctx->d_khash, ctx->d_khash_ovf, kslots - 1, kh_shift_for(kslots)};
+      const KmerHash kh{ctx->d_khash, ctx->d_khash_ovf, kslots - 1, kh_shift_for(kslots), ctx->kh_entries > 0 ? BX_WILD : 0};
       hipLaunchKernelGGL(k_kmer_hash, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_khash, ctx->d_khash_ovf,
-                         kh.mask, kh.shift);
+                         kh.mask, kh.shift, kh.wild);
       if (n > ctx->bx_cap) {
         if (dev_alloc(ctx, &ctx->d_bx_plan, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_expect, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_lists, (size_t)n * 2 * BX_NCLS))
           return MIA_HIP_ERR_NOMEM;
@@ -1051,7 +1107,7 @@ extern "C" int mia_hip_align_windows(mia_hip_ctx* ctx, const char* ref, int64_t 
     HIPCHK(hipMemcpyAsync(ctx->d_ae, ae.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   }
   // not a reference the consensus path can use: cull / tally need a realign first
-  ctx->L = (int)ref_len; ctx->wrap = (int)ref_len; ctx->have_ref = false; ctx->explicit_win = 1; ctx->ref_mostly_bases = true;
+  ctx->L = (int)ref_len; ctx->wrap = (int)ref_len; ctx->have_ref = false; ctx->explicit_win = 1; ctx->ref_mostly_bases = true; ctx->kh_entries = 0;
   const int rcode = align_all(ctx);
   HIPCHK(hipStreamSynchronize(ctx->stream));   // as / ae / codes are host buffers of this call
   return rcode;
@@ -1770,6 +1826,18 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   int64_t n_other = 0;
   for (int i = 0; i < L; i++) n_other += base_code(new_ref[i]) > 3;
   ctx->ref_mostly_bases = n_other * 50 <= L;
+  ctx->kh_entries = 0;
+  if (n_other && ctx->use_wild) {            // (kh_wild_entries over the wrapped string, without making the codes here)
+    int64_t e = 0;
+    int k = 0;
+    auto other = [&](int j) { return base_code(new_ref[j < L ? j : j - L]) > 3 ? 1 : 0; };
+    for (int pq = 0; pq < wrap; pq++) {
+      k += other(pq);
+      if (pq >= DF_K) k -= other(pq - DF_K);
+      if (pq >= DF_K - 1 && k <= BX_WILD) e += (int64_t)1 << (2 * k);
+    }
+    ctx->kh_entries = e > ((int64_t)1 << 24) ? 0 : e;
+  }
   if (total > ctx->ref_cap) {
     if (dev_alloc(ctx, &ctx->d_ref, (size_t)total * 2)) return MIA_HIP_ERR_NOMEM;
     ctx->ref_cap = total * 2;
@@ -2208,13 +2276,14 @@ struct AlignBorrow {
   mia_hip_ctx* c;
   ReadSet rs; int32_t *bin_of, *list, *wide, *retry; int max_len; uint8_t* d_ref; int L, wrap, explicit_win, use_filter;
   bool aligned, culled, tallied, pre_cull_valid, ref_mostly_bases;
+  int64_t kh_entries;
   int64_t plain_total, plain_retried, filter_seen, filter_proven, bx_seen, bx_done0, bx_done1, bx_done2;
   double stg_ms[STG_COUNT]; int64_t stg_launches[STG_COUNT];
   explicit AlignBorrow(mia_hip_ctx* ctx)
       : c(ctx), rs(ctx->rs), bin_of(ctx->d_bin_of), list(ctx->d_list), wide(ctx->d_wide_list), retry(ctx->d_retry_list), max_len(ctx->max_len),
         d_ref(ctx->d_ref), L(ctx->L), wrap(ctx->wrap), explicit_win(ctx->explicit_win), use_filter(ctx->use_filter), aligned(ctx->aligned),
         culled(ctx->culled), tallied(ctx->tallied), pre_cull_valid(ctx->pre_cull_valid), ref_mostly_bases(ctx->ref_mostly_bases),
-        plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven),
+        kh_entries(ctx->kh_entries), plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven),
         bx_seen(ctx->bx_seen), bx_done0(ctx->bx_done[0]), bx_done1(ctx->bx_done[1]), bx_done2(ctx->bx_done[2]) {
     // the stage timers of the iteration path must not see what the borrowed runs add (bench.py's roofline reads them)
     for (int k = 0; k < STG_COUNT; k++) {
@@ -2237,7 +2306,7 @@ struct AlignBorrow {
     }
     c->rs = rs; c->d_bin_of = bin_of; c->d_list = list; c->d_wide_list = wide; c->d_retry_list = retry; c->max_len = max_len; c->d_ref = d_ref;
     c->L = L; c->wrap = wrap; c->explicit_win = explicit_win; c->use_filter = use_filter; c->aligned = aligned; c->culled = culled;
-    c->tallied = tallied; c->pre_cull_valid = pre_cull_valid; c->ref_mostly_bases = ref_mostly_bases; c->plain_total = plain_total;
+    c->tallied = tallied; c->pre_cull_valid = pre_cull_valid; c->ref_mostly_bases = ref_mostly_bases; c->kh_entries = kh_entries; c->plain_total = plain_total;
     c->plain_retried = plain_retried; c->filter_seen = filter_seen; c->filter_proven = filter_proven;
     c->bx_seen = bx_seen; c->bx_done[0] = bx_done0; c->bx_done[1] = bx_done1; c->bx_done[2] = bx_done2;
   }
@@ -2313,13 +2382,13 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   int32_t *d_p1kcnt = nullptr, *d_p1kpos = nullptr;
   int32_t* d_todo = nullptr;
   uint32_t* d_ntodo = nullptr;
-  ScopeFree guard;   // every temporary below is released on any return
+  PoolScope guard(ctx);   // every temporary below goes back to the context's pool on any return
   guard.watch((void**)&d_p1planes); guard.watch((void**)&d_todo); guard.watch((void**)&d_ntodo); guard.watch((void**)&d_p1kcnt); guard.watch((void**)&d_p1kpos);
   for (void** pp : {(void**)&d_cf, (void**)&d_cr, (void**)&d_tab[0], (void**)&d_tab[1], (void**)&d_kl[0], (void**)&d_kl[1], (void**)&d_el[0],
                     (void**)&d_el[1], (void**)&d_pos[0], (void**)&d_pos[1], (void**)&d_packed, (void**)&d_rc, (void**)&d_flags, (void**)&d_roff,
                     (void**)&d_status, (void**)&d_len, (void**)&d_score, (void**)&d_as, (void**)&d_ae, (void**)&d_trace, (void**)&d_ckpt})
     guard.watch(pp);
-  int rcx = dev_alloc(ctx, &d_cf, cf.size()) | dev_alloc(ctx, &d_cr, cr.size());
+  int rcx = pool_alloc(ctx, &d_cf, cf.size()) | pool_alloc(ctx, &d_cr, cr.size());
   KmerIndex kx{};
   kx.k = kmer_len > 0 ? kmer_len : -1;
   if (kx.k > 0 && !rcx) {
@@ -2329,8 +2398,8 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       std::vector<int32_t> pos;
       build_kmer_lists(s ? rcs : fw, kx.k, soft_mask, kmer, entry, pos);
       const size_t ne = kmer.size();
-      rcx |= dev_alloc(ctx, &d_tab[s], nk) | dev_alloc(ctx, &d_pos[s], pos.size()) | dev_alloc(ctx, &d_kl[s], ne + 1) |
-             dev_alloc(ctx, &d_el[s], ne + 1);
+      rcx |= pool_alloc(ctx, &d_tab[s], nk) | pool_alloc(ctx, &d_pos[s], pos.size()) | pool_alloc(ctx, &d_kl[s], ne + 1) |
+             pool_alloc(ctx, &d_el[s], ne + 1);
       if (rcx) break;
       hipError_t ke = hipMemsetAsync(d_tab[s], 0, nk * 4, ctx->stream);
       if (ke == hipSuccess) ke = hipMemcpy(d_pos[s], pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
@@ -2348,9 +2417,9 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   lap("ref+kmer");
   std::vector<uint8_t> packed((size_t)total + 8, 0);
   pack_reads(n, bases, offsets, roff.data(), len.data(), packed.data());
-  rcx |= dev_alloc(ctx, &d_packed, packed.size()) | dev_alloc(ctx, &d_roff, (size_t)n) | dev_alloc(ctx, &d_len, (size_t)n) |
-         dev_alloc(ctx, &d_rc, (size_t)n) | dev_alloc(ctx, &d_flags, (size_t)n) | dev_alloc(ctx, &d_status, (size_t)n) |
-         dev_alloc(ctx, &d_score, (size_t)n) | dev_alloc(ctx, &d_as, (size_t)n) | dev_alloc(ctx, &d_ae, (size_t)n);
+  rcx |= pool_alloc(ctx, &d_packed, packed.size()) | pool_alloc(ctx, &d_roff, (size_t)n) | pool_alloc(ctx, &d_len, (size_t)n) |
+         pool_alloc(ctx, &d_rc, (size_t)n) | pool_alloc(ctx, &d_flags, (size_t)n) | pool_alloc(ctx, &d_status, (size_t)n) |
+         pool_alloc(ctx, &d_score, (size_t)n) | pool_alloc(ctx, &d_as, (size_t)n) | pool_alloc(ctx, &d_ae, (size_t)n);
   // persistent grid; LDS: sub table + 5 carry arrays + 2 column masks
   // (the column masks are only read when the k-mer filter is on)
   const int nch = (len1 + P1_CH - 1) / P1_CH, mask_words = kmer_len > 0 ? nch * (P1_CH / 32) + 4 : 0;
@@ -2373,7 +2442,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
   int64_t grid = (int64_t)prop.multiProcessorCount * waves_cu;
   if (grid > n) grid = n;
-  rcx |= dev_alloc(ctx, &d_trace, (size_t)(trace_bytes * grid)) | dev_alloc(ctx, &d_ckpt, (size_t)(ckpt_words * grid));
+  rcx |= pool_alloc(ctx, &d_trace, (size_t)(trace_bytes * grid)) | pool_alloc(ctx, &d_ckpt, (size_t)(ckpt_words * grid));
   if (rcx) return rcx == 2 ? MIA_HIP_ERR_DEVICE : MIA_HIP_ERR_NOMEM;
   lap("pack+alloc");
   hipError_t e = hipSuccess;
@@ -2386,7 +2455,18 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   // the whole-reference DP then runs on what is left.
   int64_t p1_other = 0;
   for (int i = 0; i < L; i++) p1_other += cf[(size_t)i] > 3;
-  const bool filtered = ctx->flat && ctx->use_filter && kmer_len <= 0 && len1 >= max_len && p1_other * 50 <= L;
+  const bool fast_ok = ctx->flat && ctx->use_filter && kmer_len <= 0 && len1 >= max_len;
+  const bool filtered = fast_ok && p1_other * 50 <= L;
+  // the anchored stage behind it (or in its place: a reference full of ambiguity codes, mt311 itself, leaves the filter
+  // nothing to decide): the windows' 10-mer tables list the N columns under every spelling (bandx_body.h, N COLUMNS)
+  int64_t wild_entries = 0;
+  if (fast_ok && p1_other && ctx->use_wild && len1 <= (1 << 22)) {
+    std::vector<uint8_t> both(cf.begin(), cf.begin() + len1);
+    both.insert(both.end(), cr.begin(), cr.begin() + len1);
+    wild_entries = kh_wild_entries(both.data(), (int64_t)both.size(), BX_WILD);
+    if (wild_entries > ((int64_t)1 << 24)) wild_entries = 0;
+  }
+  const bool anchored_ok = fast_ok && (p1_other == 0 || wild_entries > 0) && len1 <= (1 << 22) && !getenv("MIA_HIP_NO_ANCHOR");
   int64_t n_dp = n;
   ctx->pass1_filtered = 0;
   ctx->pass1_anchored = 0;
@@ -2394,9 +2474,14 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
     Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
     drain_events(ctx);                       // (nothing of an earlier call may sit in the pass-1 timer)
     p1_timed = ((ctx->stage_mask >> STG_PASS1) & 1u) && stage_begin(ctx, STG_PASS1) == 0;
+    if (filtered || anchored_ok) {
+      if (pool_alloc(ctx, &d_todo, (size_t)n) || pool_alloc(ctx, &d_ntodo, 1)) return MIA_HIP_ERR_NOMEM;
+      if (len1 <= (1 << 22) && (pool_alloc(ctx, &d_p1kcnt, (size_t)DF_KTAB * 2) || pool_alloc(ctx, &d_p1kpos, (size_t)DF_KTAB * DF_KCAP * 2))) return MIA_HIP_ERR_NOMEM;
+    }
+    if (!filtered && anchored_ok) hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_todo);
     if (filtered) {
       const int64_t words = plane_words(len1);
-      if (dev_alloc(ctx, &d_p1planes, (size_t)words * 6) || dev_alloc(ctx, &d_todo, (size_t)n) || dev_alloc(ctx, &d_ntodo, 1)) return MIA_HIP_ERR_NOMEM;
+      if (pool_alloc(ctx, &d_p1planes, (size_t)words * 6)) return MIA_HIP_ERR_NOMEM;
       uint64_t* pl = d_p1planes;
       hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, words, pl, pl + words, pl + 2 * words);
       hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, words, pl + 3 * words, pl + 4 * words, pl + 5 * words);
@@ -2404,12 +2489,11 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       RefPlanes pf{pl, pl + words, pl + 2 * words}, prc{pl + 3 * words, pl + 4 * words, pl + 5 * words};
       // 10-mer tables of both strands for rule (c) (diag_filter.h: KmerOcc)
       KmerOcc kf{nullptr, nullptr}, kr{nullptr, nullptr};
-      if (len1 <= (1 << 22)) {
-        if (dev_alloc(ctx, &d_p1kcnt, (size_t)DF_KTAB * 2) || dev_alloc(ctx, &d_p1kpos, (size_t)DF_KTAB * DF_KCAP * 2)) return MIA_HIP_ERR_NOMEM;
+      if (d_p1kcnt) {
         if (e == hipSuccess) e = hipMemsetAsync(d_p1kcnt, 0, (size_t)DF_KTAB * 2 * 4, ctx->stream);
-        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, d_p1kcnt, d_p1kpos);
+        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, d_p1kcnt, d_p1kpos, 0);
         hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, d_p1kcnt + DF_KTAB,
-                           d_p1kpos + DF_KTAB * DF_KCAP);
+                           d_p1kpos + DF_KTAB * DF_KCAP, 0);
         kf.cnt = d_p1kcnt; kf.pos = d_p1kpos; kr.cnt = d_p1kcnt + DF_KTAB; kr.pos = d_p1kpos + DF_KTAB * DF_KCAP;
       }
       hipLaunchKernelGGL(k_pass1_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pr, pf, prc, kf, kr, len1, L, d_todo, d_ntodo);
@@ -2425,13 +2509,19 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
     // six 10-mers of the read occur -- provably the same result as the whole-strand DP when the budget check of
     // k_pass1_select holds; everything else goes on to k_pass1.  Needs both strands free of N (a 10-mer with an N is not
     // in the table and an N column costs less than a mismatch).
-    const int32_t* dp_list = filtered ? d_todo : nullptr;
-    if (e == hipSuccess && filtered && n_dp > 0 && p1_other == 0 && d_p1kcnt && !getenv("MIA_HIP_NO_ANCHOR")) {
+    if (e == hipSuccess && anchored_ok && n_dp > 0 && d_p1kcnt) {
+      if (p1_other || !filtered) {            // the anchors' tables: with the N columns' spellings (the filter's rule (c) wants them without)
+        HIPCHK(hipMemsetAsync(d_p1kcnt, 0, (size_t)DF_KTAB * 2 * 4, ctx->stream));
+        const int wild = p1_other ? BX_WILD : 0;
+        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, d_p1kcnt, d_p1kpos, wild);
+        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, d_p1kcnt + DF_KTAB,
+                           d_p1kpos + DF_KTAB * DF_KCAP, wild);
+      }
       const int64_t m = n_dp * P1A_SLOTS;
       const int stride = (max_len + 3) & ~3;
       // one allocation for all the temporaries of this stage (twenty separate ones cost more than the stage)
       unsigned char* arena = nullptr;
-      ScopeFree g2;
+      PoolScope g2(ctx);
       g2.watch((void**)&arena);
       size_t top = 0;
       auto carve = [&](size_t bytes) { const size_t at = top; top += (bytes + 255) & ~(size_t)255; return at; };
@@ -2441,7 +2531,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
                    o_list = carve(((size_t)m + 4 * N_BINS) * 4), o_wide = carve((size_t)m * 4), o_retry = carve((size_t)m * 4),
                    o_rest = carve((size_t)n_dp * 4), o_abr = carve((size_t)m * 2), o_cols = carve((size_t)m * stride * 2),
                    o_bound = carve((size_t)n_dp * 4), o_budget = carve((size_t)n_dp * 4);
-      if (dev_alloc(ctx, &arena, top)) return MIA_HIP_ERR_NOMEM;
+      if (pool_alloc(ctx, &arena, top)) return MIA_HIP_ERR_NOMEM;
       uint32_t *w_roff = (uint32_t*)(arena + o_roff), *w_status = (uint32_t*)(arena + o_status), *d_nrest = (uint32_t*)(arena + o_nrest);
       uint16_t* w_len = (uint16_t*)(arena + o_len);
       uint8_t *w_rc = arena + o_rc, *w_sk = arena + o_sk, *d_ref2 = arena + o_ref2;
@@ -2470,6 +2560,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
         r.refstart = w_refstart; r.abr = w_abr; r.status = w_status; r.cols = w_cols; r.stride = stride;
         ctx->d_bin_of = w_bin; ctx->d_list = w_list; ctx->d_wide_list = w_wide; ctx->d_retry_list = w_retry; ctx->max_len = max_len;
         ctx->d_ref = d_ref2; ctx->L = 2 * len1; ctx->wrap = 2 * len1; ctx->explicit_win = 1; ctx->use_filter = 0;
+        ctx->ref_mostly_bases = p1_other * 50 <= L; ctx->kh_entries = wild_entries;
         rc_inner = align_all(ctx);
       }
       if (rc_inner != MIA_HIP_OK) return rc_inner;
@@ -2485,11 +2576,10 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       if (timing) fprintf(stderr, "[mia_hip_pass1] anchored windows: %lld of %lld left-over reads decided\n", (long long)(n_dp - h_nrest), (long long)n_dp);
       n_dp = h_nrest;
     }
-    (void)dp_list;
     if (e == hipSuccess && n_dp > 0) {
       const int64_t g = grid < n_dp ? grid : n_dp;
       hipLaunchKernelGGL(kfn, dim3((unsigned)g), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
-                         trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words, plain, filtered ? d_todo : nullptr, n_dp);
+                         trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words, plain, (filtered || anchored_ok) ? d_todo : nullptr, n_dp);
       e = hipGetLastError();
     }
     if (p1_timed) stage_end(ctx, STG_PASS1);
@@ -2532,7 +2622,9 @@ extern "C" int mia_hip_myers(mia_hip_ctx* ctx, int64_t n, const char* const* seq
   char* d_blob = nullptr;
   MyersPair* d_pairs = nullptr;
   uint32_t* d_out = nullptr;
-  if (dev_alloc(ctx, &d_blob, blob.size() + 1) || dev_alloc(ctx, &d_pairs, (size_t)n) || dev_alloc(ctx, &d_out, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+  PoolScope guard(ctx);
+  guard.watch((void**)&d_blob); guard.watch((void**)&d_pairs); guard.watch((void**)&d_out);
+  if (pool_alloc(ctx, &d_blob, blob.size() + 1) || pool_alloc(ctx, &d_pairs, (size_t)n) || pool_alloc(ctx, &d_out, (size_t)n)) return MIA_HIP_ERR_NOMEM;
   for (int64_t i = 0; i < n; i++) { pairs[i].a = d_blob + oa[i]; pairs[i].b = d_blob + ob[i]; }
   hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, pairs.data(), (size_t)n * sizeof(MyersPair), hipMemcpyHostToDevice, ctx->stream);
@@ -2545,7 +2637,6 @@ extern "C" int mia_hip_myers(mia_hip_ctx* ctx, int64_t n, const char* const* seq
   }
   if (e == hipSuccess) e = hipMemcpyAsync(dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_blob); (void)hipFree(d_pairs); (void)hipFree(d_out);
   if (e != hipSuccess) { ctx->err = std::string("myers: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   return MIA_HIP_OK;
 }

@@ -108,13 +108,25 @@ __global__ __launch_bounds__(256) void k_ref_planes(const uint8_t* codes, int64_
   if (w < words) plane_word(codes, n_codes, w, &lo[w], &hi[w], &ok[w]);
 }
 
-// the 10-mer table of the reference for rule (c) (diag_filter.h: KmerOcc); cnt is zeroed before
-__global__ __launch_bounds__(256) void k_kmer_occ(const uint8_t* codes, int64_t n_codes, int32_t* cnt, int32_t* pos) {
+// the 10-mer table of the reference for rule (c) (diag_filter.h: KmerOcc); cnt is zeroed before.  wild > 0: a 10-mer with
+// up to that many N columns is entered under every spelling (bandx_body.h, N COLUMNS) -- for the anchors of pass 1, not
+// for rule (c).
+__global__ __launch_bounds__(256) void k_kmer_occ(const uint8_t* codes, int64_t n_codes, int32_t* cnt, int32_t* pos, int32_t wild) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t idx = kmer_at(codes, n_codes, p);
-  if (idx < 0) return;
-  const int c = atomicAdd(&cnt[idx], 1);
-  if (c < DF_KCAP) pos[idx * DF_KCAP + c] = (int32_t)p;
+  uint32_t base;
+  uint64_t npos;
+  const int k = kmer_wild_at(codes, n_codes, p, &base, &npos);
+  if (k < 0 || k > wild) return;
+  for (uint32_t x = 0; x < (1u << (2 * k)); x++) {
+    const int64_t idx = kmer_wild_key(base, npos, k, x);
+    const int c = atomicAdd(&cnt[idx], 1);
+    if (c < DF_KCAP) pos[idx * DF_KCAP + c] = (int32_t)p;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_iota(int64_t n, int32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (int32_t)i;
 }
 
 __global__ __launch_bounds__(256) void k_diag_filter(ReadSet rs, RefInfo ref, RefPlanes rp, KmerOcc ko, int64_t n_ref, int32_t* bin_of, uint32_t dbg,

@@ -342,14 +342,15 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
   uint8_t* pb = (uint8_t*)packed.data();
   for (int r = 0; r < len2; r++) pb[r >> 1] |= (uint8_t)((read_codes[r] & 15) << ((r & 1) * 4));
   RefPlanes rp{lo.data(), hi.data(), ok.data()};
-  const uint32_t kslots = kh_slots_for(n_codes);
+  // (opts & 8: the table without the N columns' spellings, as for a reference that has none)
+  bool has_n = false;
+  for (int64_t p = 0; p < n_codes; p++) has_n |= ref_codes[p] > 3;
+  const int wild = has_n && !(opts & 8) ? BX_WILD : 0;
+  const uint32_t kslots = kh_slots_for_entries(n_codes, wild ? kh_wild_entries(ref_codes, n_codes, wild) : 0);
   std::vector<uint32_t> kslot((size_t)kslots * 4, KH_EMPTY);
   std::vector<int32_t> kovf((size_t)kslots * 2, 0);
-  const KmerHash ko{kslot.data(), kovf.data(), kslots - 1, kh_shift_for(kslots)};
-  for (int64_t p = 0; p < n_codes; p++) {
-    const int64_t idx = kmer_at(ref_codes, n_codes, p);
-    if (idx >= 0) kh_insert_host(kslot.data(), kovf.data(), kslots - 1, ko.shift, (uint32_t)idx, (int32_t)p);
-  }
+  const KmerHash ko{kslot.data(), kovf.data(), kslots - 1, kh_shift_for(kslots), wild};
+  for (int64_t p = 0; p < n_codes; p++) kh_insert_wild_host(kslot.data(), kovf.data(), kslots - 1, ko.shift, ref_codes, n_codes, p, wild);
   // the tables of a matrix pair are made once (the stray tables take a moment) and kept
   static std::vector<int32_t> sub, mrow, key;
   static std::vector<int16_t> loss, dl;

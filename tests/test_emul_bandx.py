@@ -45,6 +45,8 @@ def check(emul, oracle, spec, strand, ref, s, len1, read, stats, opts=None):
     stats["n"] += 1
     mode, out6, cols, plan = run_bandx(emul, oracle, spec, strand, ref, s, len1, read, opts)
     stats["mode%d" % mode] = stats.get("mode%d" % mode, 0) + 1
+    if mode == 0:
+        stats["why%d" % plan[3]] = stats.get("why%d" % plan[3], 0) + 1
     if out6[5] == 0:
         return False
     stats["how%d" % out6[5]] = stats.get("how%d" % out6[5], 0) + 1
@@ -339,3 +341,82 @@ def test_new_start_quirk_under_the_written_path(emul, oracle):
                     continue
                 finished += 1 if check(emul, oracle, spec, strand, ref, s, l1, read, stats) else 0
     assert stats["n"] > 2000 and finished > 1500, (stats, finished)
+
+
+def sprinkle_n(rnd, seq, rate, runs=0):
+    """Ambiguity codes over a sequence as in mt311 (src/mt311.c: every tenth column a Y, R, M ...): single columns at
+    `rate`, plus `runs` stretches of 2-12 of them."""
+    s = list(seq)
+    for i in range(len(s)):
+        if rnd.random() < rate:
+            s[i] = rnd.choice("YRYRMWVHDSBKN")
+    for _ in range(runs):
+        at = rnd.randint(0, len(s) - 13)
+        for i in range(at, at + rnd.randint(2, 12)):
+            s[i] = rnd.choice("YRN")
+    return "".join(s)
+
+
+@pytest.mark.parametrize("spec,strand", MATS)
+def test_reference_with_ambiguity_codes(emul, oracle, spec, strand):
+    """A reference whose columns are one in ten ambiguity codes (mt311 itself, the start of every run): an N column is a
+    known small loss under any base, the table lists the 10-mers that hold up to three of them under every spelling, and
+    the band follows from the same pigeonhole (bandx_body.h, N COLUMNS).  Substitutions, indels next to and across the N
+    columns, damage; the plan must still finish or place most reads, and whatever it finishes must be dyn_prog's answer."""
+    rnd = random.Random(31 + strand)
+    stats = {"n": 0}
+    finished = 0
+    for rate, runs in ((0.10, 6), (0.03, 2), (0.20, 10)):
+        truth = "".join(rnd.choice("ACGT") for _ in range(3000))
+        ref = sprinkle_n(rnd, truth, rate, runs)
+        for i in range(200):
+            n = rnd.choice([100, 100, 60, 150, rnd.randint(30, 250)])
+            pos = rnd.randint(0, len(ref) - n - 40)
+            src = truth[pos:pos + n + 30]
+            kind = i % 4
+            if kind == 0:
+                read = src[:n]
+            elif kind == 1:
+                at, k = rnd.randint(1, n - 2), rnd.choice([1, 1, 2, 3, 5, 8])
+                read = src[:at] + src[at + k:][:n - at]
+            elif kind == 2:
+                at, k = rnd.randint(1, n - 2), rnd.choice([1, 1, 2, 3, 5])
+                read = (src[:at] + "".join(rnd.choice("ACGT") for _ in range(k)) + src[at:])[:n]
+            else:
+                read = damage(rnd, src[:n], p0=0.6)
+            read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([0, 0, 1, 1, 2, 3, 5])))
+            s, l1 = window(ref, pos + rnd.randint(-3, 3) if 3 <= pos else pos, len(read))
+            if l1 < len(read):
+                continue
+            finished += 1 if check(emul, oracle, spec, strand, ref, s, l1, read, stats) else 0
+    assert stats["n"] > 550 and finished > 150, (sorted(stats.items()), finished)
+
+
+def test_gaps_through_ambiguity_columns(emul, oracle):
+    """With the flat matrix a column gap crosses an N column for 200 (GEP) where a row aligned to it loses 210: next to a
+    stretch of N columns a deletion and the diagonal are nearly level, and which of them wins (or ties -- dyn_prog's
+    cascade decides) hangs on single substitutions.  Reads over such stretches, with the stretch deleted, shortened or kept
+    and 0-3 substitutions just beside it; every matrix."""
+    rnd = random.Random(77)
+    stats = {"n": 0}
+    finished = 0
+    for spec, strand in MATS:
+        for i in range(120):
+            n = rnd.choice([100, 100, 150, 64])
+            left = "".join(rnd.choice("ACGT") for _ in range(60 + rnd.randint(0, 9)))
+            a = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(12, n - 12)))
+            k = rnd.randint(1, 9)
+            gap_truth = "".join(rnd.choice("ACGT") for _ in range(k))
+            b = "".join(rnd.choice("ACGT") for _ in range(n + 40))
+            ref = sprinkle_n(rnd, left + a, 0.05) + "N" * k + sprinkle_n(rnd, b, 0.05)
+            keep = rnd.choice([0, 0, k, k, rnd.randint(0, k)])                # columns of the stretch the read holds
+            read = (a + gap_truth[:keep] + b)[:n]
+            near = [len(a) - 1 - rnd.randint(0, 4), len(a) + keep + rnd.randint(0, 4)]
+            read = mutate(rnd, read, [r for r in rnd.sample(near, rnd.choice([0, 1, 2])) if 0 <= r < len(read)])
+            if i % 3 == 0:
+                read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([1, 2, 3])))
+            s, l1 = window(ref, len(left), len(read), margin=rnd.choice([50, 50, 30]))
+            if l1 < len(read):
+                continue
+            finished += 1 if check(emul, oracle, spec, strand, ref, s, l1, read, stats) else 0
+    assert stats["n"] > 500 and finished > 200, (stats, finished)

@@ -3,7 +3,9 @@ tests/test_gpu_band.py's generators (random and adversarial references, read len
 pass-1 coordinates), banded DP on against off, every read's score, end points and script.
 usage: band_campaign.py [rounds [first seed [MIA_HIP_NO_DIAG_FILTER [matrix]]]]   (third argument: the switch that defines
 "off"; MIA_HIP_NO_DIAG_FILTER takes every shortcut out, i.e. compares the band pipeline with the full-window DP kernels;
-fourth: flat (default), ancient, solexa -- the position-specific matrices, both strands mixed, aDNA damage on the reads)"""
+fourth: flat (default), ancient, solexa -- the position-specific matrices, both strands mixed, aDNA damage on the reads;
+fifth: nrich -- after the reads are drawn, 3-20 % of the reference columns (and a few stretches of 2-12) become
+ambiguity codes, as in mt311)"""
 import os
 import sys
 import time
@@ -21,6 +23,8 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 switch = sys.argv[3] if len(sys.argv) > 3 else "MIA_HIP_NO_BAND_DP"
 matrix = sys.argv[4] if len(sys.argv) > 4 else "flat"
+nrich = len(sys.argv) > 5 and sys.argv[5] == "nrich"
+planned = [0, 0]
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 PSSM = mia_amd.flat_pssm() if matrix == "flat" else mia_amd.read_pssm(os.path.join(GOLDEN, {"ancient": "ancient.submat.txt", "solexa": "ancient.submat.solexa.pe.txt"}[matrix]))
 
@@ -39,6 +43,9 @@ def compare(refs, reads, read_len, as0, ae0, rc=None):
         hip.set_pssm(PSSM)
         hip.upload_reads(reads.reshape(-1), off, rc, np.ones(n, np.uint8), as0, ae0)
         hip.realign(refs, True)
+        if not env:
+            bx = hip.bx_stats()[0]
+            planned[0] += int(sum(bx[1:4])); planned[1] += n
         sc, a, e = hip.alignments()
         cols, rstart = hip.scripts()
         out.append((sc, a, e, np.where(cols >= 0, cols.astype(np.int32) + rstart[:, None], cols.astype(np.int32))))
@@ -60,6 +67,14 @@ for k in range(rounds):
     jitter = rng.integers(-10, 11, n) * (rng.random(n) < 0.3)
     as0 = ((start + jitter) % L).astype(np.int32)
     ae0 = (as0 + read_len - 1).astype(np.int32)
+    if nrich:
+        ref = ref.copy()
+        codes = np.frombuffer(b"YRYRMWVHDSBKN", np.uint8)
+        hit = rng.random(L) < float(rng.choice([0.03, 0.1, 0.1, 0.2]))
+        ref[hit] = rng.choice(codes, int(hit.sum()))
+        for _ in range(int(rng.integers(0, 12))):
+            at = int(rng.integers(0, L - 13))
+            ref[at:at + int(rng.integers(2, 13))] = ord("N")
     if matrix != "flat":
         # aDNA damage on the stored read (C->T towards one end, G->A towards the other, by strand) and a random strand flag
         rc = (rng.random(n) < 0.5).astype(np.uint8)
@@ -73,10 +88,11 @@ for k in range(rounds):
         reads = np.where((reads == ord("G")) & (u < np.where(~fw, p3, 0)), ord("A"), reads)
         reads = np.where((reads == ord("C")) & (v < np.where(~fw, p5, 0)), ord("T"), reads).astype(np.uint8)
         compare(ref.tobytes().decode(), reads, read_len, as0, ae0, rc)
-    elif switch == "MIA_HIP_NO_BAND_DP":
+    elif switch == "MIA_HIP_NO_BAND_DP" and not nrich:
         run_both(mia_amd, ref.tobytes().decode(), reads, read_len, as0, ae0, 0.0)
     else:
         compare(ref.tobytes().decode(), reads, read_len, as0, ae0)
     reads_total += n
     print("round", k, "seed", seed, "len", read_len, "L", L, "ok", round(time.time() - t0, 1), "s", flush=True)
-print("campaign done:", matrix, "matrix,", reads_total, "reads, no difference")
+print("campaign done:", matrix, "matrix,", "N-rich references," if nrich else "", reads_total, "reads, no difference;", planned[0], "of", planned[1],
+      "finished or placed by the band pipeline")

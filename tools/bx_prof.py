@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--ref", default="mt311")
     ap.add_argument("--linear", action="store_true")
     ap.add_argument("--no-damage", action="store_true")
+    ap.add_argument("--again", action="store_true", help="one more step from the starting reference at the end (the first step pays for the allocations)")
     a = ap.parse_args()
     if a.ref == "mt311":
         _, _, mt = gen_data.read_fasta_one(os.path.join(ROOT, "tests", "golden", "mt311.fa"))
@@ -70,7 +71,9 @@ def main():
 
     cur = ref0
     out = {"matrix": a.matrix, "reads": n, "len": a.len, "steps": []}
-    for k in range(a.steps):
+    for k in range(a.steps + (1 if a.again else 0)):
+        if k == a.steps:
+            cur = ref0
         for f in (hip.bx_stats, hip.filter_stats, hip.band_stats, hip.plain_stats, hip.kernel_time):
             f(reset=True)
         t0 = time.perf_counter()
