@@ -103,6 +103,7 @@ struct mia_hip_ctx {
   bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
   bool ref_mostly_bases = true;            // fewer than 2 % of the reference columns are N
   int64_t kh_entries = 0;                  // > 0: the reference has N columns and its 10-mer table lists them (bandx_body.h, N COLUMNS)
+  bool wide_to_caller = false;             // run_wide marks its reads ST_ESCAPE instead of aligning them (the anchored pass 1)
   int use_wild = 1;                        // MIA_HIP_NO_WILD=1: reads whose window holds an N go to the full-window kernels
   bool flat = false; int use_filter = 1;   // MIA_HIP_NO_DIAG_FILTER=1 sends every read to the DP kernels
   int64_t pre_cull_records = 0, pre_cull_links = 0; bool pre_cull_valid = false;   // mia_hip_score_sums' by-products
@@ -691,6 +692,14 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
 
 // exact kernel for whole-reference windows and escaped reads (rare): one read per thread, int32 scores and trace in scratch
 static int run_wide(mia_hip_ctx* ctx, const RefInfo& ref, int32_t n_wide) {
+    if (ctx->wide_to_caller) {
+      // pass 1's windows: a read the trace kernels could not finish (a gap of 63 or more on the path -- a window around a
+      // stray cluster, where the read does not belong) goes to the whole-strand DP with everything else that is left over;
+      // one read per thread here would take longer than that whole kernel
+      hipLaunchKernelGGL(k_mark_status, dim3((n_wide + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_wide_list, n_wide, ctx->rs.status, ST_ESCAPE);
+      HIPCHK(hipGetLastError());
+      return MIA_HIP_OK;
+    }
     std::vector<int32_t> wl((size_t)n_wide), as((size_t)n_wide), ae((size_t)n_wide);
     std::vector<uint16_t> ln((size_t)n_wide);
     HIPCHK(hipMemcpy(wl.data(), ctx->d_wide_list, (size_t)n_wide * 4, hipMemcpyDeviceToHost));
@@ -2525,7 +2534,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       g2.watch((void**)&arena);
       size_t top = 0;
       auto carve = [&](size_t bytes) { const size_t at = top; top += (bytes + 255) & ~(size_t)255; return at; };
-      const size_t o_roff = carve((size_t)m * 4), o_status = carve((size_t)m * 4), o_nrest = carve(4), o_len = carve((size_t)m * 2),
+      const size_t o_roff = carve((size_t)m * 4), o_status = carve((size_t)m * 4), o_nrest = carve(64), o_len = carve((size_t)m * 2),
                    o_rc = carve((size_t)m), o_sk = carve((size_t)m), o_ref2 = carve((size_t)2 * len1 + 64), o_as = carve((size_t)m * 4),
                    o_ae = carve((size_t)m * 4), o_score = carve((size_t)m * 4), o_refstart = carve((size_t)m * 4), o_bin = carve((size_t)m * 4),
                    o_list = carve(((size_t)m + 4 * N_BINS) * 4), o_wide = carve((size_t)m * 4), o_retry = carve((size_t)m * 4),
@@ -2544,7 +2553,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       HIPCHK(hipMemsetAsync(w_abr, 0, (size_t)m * 2, ctx->stream));
       HIPCHK(hipMemsetAsync(w_status, 0, (size_t)m * 4, ctx->stream));
       HIPCHK(hipMemsetAsync(w_score, 0, (size_t)m * 4, ctx->stream));
-      HIPCHK(hipMemsetAsync(d_nrest, 0, 4, ctx->stream));
+      HIPCHK(hipMemsetAsync(d_nrest, 0, 64, ctx->stream));
       HIPCHK(hipMemsetAsync(d_ref2, 4, (size_t)2 * len1 + 64, ctx->stream));
       HIPCHK(hipMemcpyAsync(d_ref2, d_cf, (size_t)len1, hipMemcpyDeviceToDevice, ctx->stream));
       HIPCHK(hipMemcpyAsync(d_ref2 + len1, d_cr, (size_t)len1, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2561,15 +2570,22 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
         ctx->d_bin_of = w_bin; ctx->d_list = w_list; ctx->d_wide_list = w_wide; ctx->d_retry_list = w_retry; ctx->max_len = max_len;
         ctx->d_ref = d_ref2; ctx->L = 2 * len1; ctx->wrap = 2 * len1; ctx->explicit_win = 1; ctx->use_filter = 0;
         ctx->ref_mostly_bases = p1_other * 50 <= L; ctx->kh_entries = wild_entries;
+        ctx->wide_to_caller = true;
         rc_inner = align_all(ctx);
+        ctx->wide_to_caller = false;
       }
       if (rc_inner != MIA_HIP_OK) return rc_inner;
       hipLaunchKernelGGL(k_pass1_select, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, len1, L, w_sk, w_score, w_as,
                          w_ae, w_abr, w_status, w_bound, w_budget, d_rest, d_nrest);
       HIPCHK(hipGetLastError());
-      uint32_t h_nrest = 0;
-      HIPCHK(hipMemcpyAsync(&h_nrest, d_nrest, 4, hipMemcpyDeviceToHost, ctx->stream));
+      uint32_t h_rest[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      HIPCHK(hipMemcpyAsync(h_rest, d_nrest, 64, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
+      const uint32_t h_nrest = h_rest[0];
+      if (timing) fprintf(stderr, "[mia_hip_pass1] left to the whole-strand DP: %u no cluster, %u unfinished windows, %u clipped, %u over budget, %u weak clusters\n",
+                          h_rest[1], h_rest[2], h_rest[3], h_rest[4], h_rest[5]);
+      if (timing) fprintf(stderr, "[mia_hip_pass1] no cluster: %u reads with N, %u too few blocks, %u too many clusters, %u too wide, %u too many strong, %u none strong, %u no room\n",
+                          h_rest[9], h_rest[10], h_rest[11], h_rest[12], h_rest[13], h_rest[14], h_rest[15]);
       // the survivors' list replaces the filter's (d_todo is at least as long)
       HIPCHK(hipMemcpyAsync(d_todo, d_rest, (size_t)h_nrest * 4, hipMemcpyDeviceToDevice, ctx->stream));
       ctx->pass1_anchored = n_dp - h_nrest;

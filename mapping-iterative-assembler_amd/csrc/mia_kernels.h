@@ -124,6 +124,12 @@ __global__ __launch_bounds__(256) void k_kmer_occ(const uint8_t* codes, int64_t 
   }
 }
 
+// reads of a list get a status instead of an alignment (pass 1's windows: the whole-strand DP takes them)
+__global__ __launch_bounds__(256) void k_mark_status(const int32_t* list, int32_t count, uint32_t* status, uint32_t flag) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < count) status[list[t]] = flag;
+}
+
 __global__ __launch_bounds__(256) void k_iota(int64_t n, int32_t* out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (int32_t)i;

@@ -126,10 +126,11 @@ __global__ __launch_bounds__(256) void k_pass1_filter(Pass1Reads rs, RefPlanes f
 // [forward strand | reverse strand]); k_pass1_select checks the budget on the result, applies max_sg_score's first
 // maximum and sg_align's strand rule (src/mia.c:1549) and hands everything it cannot vouch for to k_pass1.
 constexpr int P1A_SLOTS = 2;       // windows per read that are aligned
-constexpr int P1A_CLUSTERS = 8;    // clusters of anchors a read may have (most of them one stray 10-mer)
+constexpr int P1A_CLUSTERS = 24;   // clusters of anchors a read may have (most of them one stray 10-mer)
 constexpr int P1A_BLOCKS = 9;      // 10-mers cut out of the read (fewer for reads under 90 bases, at least 6)
 constexpr int P1A_JOIN = 20;       // anchors this close (in diagonals) share a window
 constexpr int P1A_MARGIN = 50;     // columns around a cluster, as reiterate_assembly's REALIGN_BUFFER
+constexpr int P1A_APART = 8;       // weak clusters at least this many diagonals apart cannot both be used by one path
 // With nb blocks the budget is 800 nb - 400: fewer than nb defects, and 200 in hand because the first column of a window
 // may give a late start its substitution score back (src/mia.c: column 0 against the "new start" branch elsewhere).  A path
 // that loses no more strays at most (800*9 - 400 - 1000) / 200 = 29 diagonals from its anchor: inside the margin.
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32
   const int nb_cut = len2 / DF_K < P1A_BLOCKS ? len2 / DF_K : P1A_BLOCKS;
   int n_cl = 0, c_strand[P1A_CLUSTERS], c_lo[P1A_CLUSTERS], c_hi[P1A_CLUSTERS], c_mask[P1A_CLUSTERS];
   bool usable = nb_cut >= 6;
-  for (int r = 0; usable && r < len2; r++) if (((rp[r >> 1] >> ((r & 1) * 4)) & 15) > 3) usable = false;     // a read with N
+  int why = usable ? 0 : 2;          // (statistics: 1 a read with N, 2 too few blocks, 3 too many clusters, 4 a cluster too wide, 5 too many strong ones, 6 none, 7 no room)
+  for (int r = 0; usable && r < len2; r++) if (((rp[r >> 1] >> ((r & 1) * 4)) & 15) > 3) { usable = false; why = 1; }     // a read with N
   // A block whose 10-mer has more occurrences (on either strand) than the table keeps cannot be used -- the pigeonhole
   // then runs over the nb blocks that can: still "fewer than nb defects leave one of them intact".
   int blocks = 0;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32
       if (kf.cnt[idx] <= DF_KCAP && kr.cnt[idx] <= DF_KCAP) blocks |= 1 << b;
     }
   const int nb = __popc((unsigned)blocks);
-  if (nb < 6) usable = false;
+  if (usable && nb < 6) { usable = false; why = 2; }
   for (int st = 0; usable && st < 2; st++) {
     const KmerOcc& ko = st ? kr : kf;
     for (int b = 0; usable && b < nb_cut; b++) {
@@ -176,9 +178,9 @@ __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32
           if (d < c_lo[hit]) c_lo[hit] = d;
           if (d > c_hi[hit]) c_hi[hit] = d;
           c_mask[hit] |= 1 << b;
-          if (c_hi[hit] - c_lo[hit] > 100) usable = false;
+          if (c_hi[hit] - c_lo[hit] > 100) { usable = false; why = 4; }
         } else if (n_cl < P1A_CLUSTERS) { c_strand[n_cl] = st; c_lo[n_cl] = d; c_hi[n_cl] = d; c_mask[n_cl] = 1 << b; n_cl++; }
-        else usable = false;
+        else { usable = false; why = 3; }
       }
     }
   }
@@ -188,13 +190,24 @@ __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32
   for (int c = 0; usable && c < n_cl; c++) {
     if (__popc((unsigned)c_mask[c]) >= 2) {
       if (n_slot < P1A_SLOTS) { s_strand[n_slot] = c_strand[c]; s_lo[n_slot] = c_lo[c]; s_hi[n_slot] = c_hi[c]; n_slot++; }
-      else usable = false;
+      else { usable = false; why = 5; }
     } else weak |= c_mask[c];
   }
-  // A path that runs through no aligned cluster keeps intact only blocks that occur in the weak clusters (it may visit
-  // several of them): at most popc(weak) of the nb, every other block costs it 800.
-  const int bound = weak ? FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * (nb - __popc((unsigned)weak)) + FLAT_MATCH : INT32_MIN;
-  if (n_slot == 0) usable = false;                             // nothing strong to align: nothing bounds the optimum from below
+  // A path that runs through no aligned cluster keeps intact only blocks that occur in the weak clusters: at most
+  // popc(weak) of the nb, every other block costs it 800.  To keep the blocks of TWO weak clusters it must change diagonal
+  // between them, and where they lie P1A_APART or more diagonals apart that costs more than the second block saves: an
+  // event pays for the blocks it touches itself (a column gap of g: 1000 + 200 g, one block at most; n skipped rows:
+  // 1000 + 400 n, at most ceil((n-1)/10) + 1 blocks) and has at least 100 per diagonal to spare -- 800 over eight
+  // diagonals, the price of a block.  So with all weak clusters that far apart one block is all such a path keeps.
+  // (A table with the N columns' spellings hands every read two or three stray 10-mers somewhere on the two strands.)
+  bool apart = true;
+  for (int c = 0; c < n_cl; c++)
+    for (int e = c + 1; e < n_cl; e++)
+      if (__popc((unsigned)c_mask[c]) < 2 && __popc((unsigned)c_mask[e]) < 2 && c_strand[c] == c_strand[e] &&
+          c_lo[e] - c_hi[c] < P1A_APART && c_lo[c] - c_hi[e] < P1A_APART) apart = false;
+  const int kept = apart ? 1 : __popc((unsigned)weak);
+  const int bound = weak ? FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * (nb - kept) + FLAT_MATCH : INT32_MIN;
+  if (usable && n_slot == 0) { usable = false; why = 6; }                           // nothing strong to align: nothing bounds the optimum from below
   for (int c = 0; c < P1A_SLOTS; c++) {
     const int64_t slot = t * P1A_SLOTS + c;
     w_roff[slot] = rs.roff[i];
@@ -203,14 +216,14 @@ __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32
     if (usable && c < n_slot) {
       ws = s_lo[c] - P1A_MARGIN; if (ws < 0) ws = 0;
       we = s_hi[c] + len2 + P1A_MARGIN; if (we > len1) we = len1;     // exclusive
-      if (we - ws < len2) usable = false;                            // the read does not fit: leave it to k_pass1
+      if (we - ws < len2) { usable = false; why = 7; }               // the read does not fit: leave it to k_pass1
     }
     w_as[slot] = (c < n_slot && s_strand[c] ? len1 : 0) + ws;        // the reverse strand follows the forward one
     w_ae[slot] = (c < n_slot && s_strand[c] ? len1 : 0) + we - 1;
   }
   for (int c = 0; c < P1A_SLOTS; c++) w_sk[t * P1A_SLOTS + c] = (uint8_t)(usable && c < n_slot);
   w_bound[t] = bound;
-  w_budget[t] = (FLAT_MATCH - FLAT_MISMATCH) * nb - 2 * FLAT_MATCH;
+  w_budget[t] = usable ? (FLAT_MATCH - FLAT_MISMATCH) * nb - 2 * FLAT_MATCH : -why;
 }
 
 // after the windowed alignment of the slots: the read's result, or its place in the list of k_pass1
@@ -223,23 +236,28 @@ __global__ __launch_bounds__(256) void k_pass1_select(Pass1Reads rs, const int32
   const int64_t i = todo[t];
   const int len2 = rs.len[i];
   int best[2] = {INT32_MIN, INT32_MIN}, abc[2] = {0, 0}, aec[2] = {0, 0};
-  bool good = false, bad = false;
+  bool good = false, bad = false, clipped = false;
   for (int c = 0; c < P1A_SLOTS; c++) {
     const int64_t slot = t * P1A_SLOTS + c;
     if (!w_sk[slot]) continue;
     good = true;
     const uint32_t stt = w_status[slot];
-    if ((stt & (ST_TOO_LONG | ST_ESCAPE | ST_BAND)) || w_abr[slot] != 0) bad = true;   // (a clipped start is left to the whole-strand DP)
+    if (stt & (ST_TOO_LONG | ST_ESCAPE | ST_BAND)) bad = true;
+    if (w_abr[slot] != 0) clipped = true;                                              // (a clipped start is left to the whole-strand DP)
     const int st = w_as[slot] >= len1 ? 1 : 0, base = st ? len1 : 0;
     const int sc = w_score[slot], a = w_as[slot] - base, e = w_ae[slot] - base;
     if (sc > best[st] || (sc == best[st] && e < aec[st])) { best[st] = sc; abc[st] = a; aec[st] = e; }     // first maximum of the last row
   }
   const int st = best[0] > best[1] ? 0 : 1;                        // src/mia.c:1549: the reverse strand on a tie
   // within the budget of its blocks, and better than anything the clusters that were not aligned could hold
-  if (good && !bad && FLAT_MATCH * len2 - best[st] <= w_budget[t] && best[st] > w_bound[t]) {
+  if (good && !bad && !clipped && FLAT_MATCH * len2 - best[st] <= w_budget[t] && best[st] > w_bound[t]) {
     pass1_store(rs, i, L, st, best[st], abc[st], aec[st], ST_OK);
   } else {
     rest[atomicAdd(n_rest, 1u)] = (int32_t)i;
+    // why (n_rest[1..5], statistics): no usable cluster; a window the kernels did not finish; a clipped start; over budget; a weak cluster could hold better
+    const int why = !good ? 1 : (bad ? 2 : (clipped ? 3 : (FLAT_MATCH * len2 - best[st] > w_budget[t] ? 4 : 5)));
+    atomicAdd(n_rest + why, 1u);
+    if (!good && w_budget[t] < 0 && w_budget[t] >= -7) atomicAdd(n_rest + 8 - w_budget[t], 1u);
   }
 }
 
