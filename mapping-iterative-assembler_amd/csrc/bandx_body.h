@@ -447,6 +447,33 @@ MIA_HD inline int bx_rows_loss(const DiagScan<NW>& sc, const uint64_t* m, int fr
   return b0;
 }
 
+// the most set bits of m[] that lie in one stretch holding at most `zeros` clear ones between its first and last set bit
+template <int NW>
+MIA_HD inline int bx_ones_span(const uint64_t* m, int zeros) {
+  uint64_t hi[NW], lo[NW];                 // bits still to come at the front / not yet dropped at the back
+#pragma unroll
+  for (int j = 0; j < NW; j++) { hi[j] = m[j]; lo[j] = m[j]; }
+  auto first = [&](const uint64_t* w) -> int {
+    int p = -1;
+#pragma unroll
+    for (int j = NW - 1; j >= 0; j--) if (w[j]) p = j * 64 + df_ctz(w[j]);
+    return p;
+  };
+  auto drop = [&](uint64_t* w) {
+    bool done = false;
+#pragma unroll
+    for (int j = 0; j < NW; j++) if (!done && w[j]) { w[j] &= w[j] - 1; done = true; }
+  };
+  int best = 0, cnt = 0;
+  for (int pb = first(hi); pb >= 0; pb = first(hi)) {
+    drop(hi);
+    cnt++;
+    while ((pb - first(lo)) - (cnt - 1) > zeros) { drop(lo); cnt--; }
+    if (cnt > best) best = cnt;
+  }
+  return best;
+}
+
 // the rows of word j that lose anything on the diagonal sc is on: definite mismatches and N columns
 template <int NW>
 MIA_HD inline uint64_t bx_loss_rows(const DiagScan<NW>& sc, int j) { return sc.mis(j) | (~sc.cok[j] & sc.rows[j]); }
@@ -519,40 +546,50 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   // (credit = the sum of kap over those columns) out of both sides: P's events must fit into y = B0 - credit, where an
   // event costs, net of the credit it may consume, at least GOP -- a column gap GOP + GEP per column that is NOT one
   // of those, skipped rows GOP + (GEP + min M) each (they cross nothing), a late start of r rows GOP + GEP (r + 1) +
-  // r min M (it misses at most r of the columns).
-  //   y < GOP      no event at all: pure diagonals from row 0, which by the pigeonhole run through an anchor -- P0 itself.
-  //   y < 2 GOP    one event, so P is on d* before or behind it (the pigeonhole again).  A column gap holds at most
-  //                m = (y - GOP) / GEP columns without credit, i.e. at most m + 1 runs of credited ones: it is no longer
-  //                than (m + 1) * (longest such run) + m; skipped rows number at most (y - GOP) / (GEP + min M).
+  // r min M (it misses at most r of the columns).  P runs through d* somewhere (the pigeonhole), so it never is further
+  // from d* than its column gaps add up to, or its skipped rows:
+  //   y < GOP      no event at all: P is P0.
+  //   j gaps       hold m_j = (y - j GOP) / GEP columns without credit between them, and each of them at most H(m_j) credited
+  //                ones, H(m) = the most credited columns in a stretch with at most m others (bx_ones_span): together no
+  //                more than m_j + min(all credited, j H(m_j)) columns;
+  //   skipped rows number at most (y - GOP) / (GEP + min M).
+  // The band this gives is proven in turn, so the argument can be repeated with it (more columns count, y shrinks).
   // (Against mt311, every tenth column an ambiguity code, B0 is mostly such columns: without the credit the band would
   // be 20-30 diagonals wide.)
   if (g_dn + g_up > 0 && (PATHS == 1 || d_first == d_last) && an.a_lo == an.a_hi) {
     int G = b0x < GOP + GEP ? 0 : (b0x - GOP) / GEP;
     const int gt = g_dn > g_up ? g_dn : g_up;
     if (gt <= BX_GMAX && gt < G) G = gt;
-    int credit = 0, run = 0, run_max = 0, prev = -2;
+    for (int pass = 0; pass < 2 && G > 0; pass++) {
+      int credit = 0, k = 0;
+      uint64_t cm[NW];
 #pragma unroll
-    for (int j = 0; j < NW; j++) {
-      uint64_t w = ~sc.cok[j] & sc.rows[j];
-      while (w) {
-        const int k = df_ctz(w), q = j * 64 + k;
-        w &= w - 1;
-        if (q < G || q > R - G) continue;
-        const int kv = T.loss[BX_LOSS_KAP + (st * 31 + sm_depth(q - G, len2)) * 31 + sm_depth(q + G, len2)];
-        if (kv <= 0) continue;
-        credit += kv;
-        run = q == prev + 1 ? run + 1 : 1;
-        prev = q;
-        if (run > run_max) run_max = run;
+      for (int j = 0; j < NW; j++) {
+        uint64_t w = ~sc.cok[j] & sc.rows[j];
+        cm[j] = 0;
+        while (w) {
+          const int t = df_ctz(w), q = j * 64 + t;
+          w &= w - 1;
+          if (q < G || q > R - G) continue;
+          const int kv = T.loss[BX_LOSS_KAP + (st * 31 + sm_depth(q - G, len2)) * 31 + sm_depth(q + G, len2)];
+          if (kv <= 0) continue;
+          credit += kv;
+          k++;
+          cm[j] |= 1ull << t;
+        }
       }
-    }
-    const int y = b0x - credit;
-    if (credit > 0 && y < 2 * GOP) {
+      const int y = b0x - credit;
+      if (credit <= 0 || y >= 4 * GOP) break;
       int gn = 0;
       if (y >= GOP) {
-        const int m = (y - GOP) / GEP, by_gap = (m + 1) * run_max + m, by_rows = (y - GOP) / (GEP + T.min_m);
-        gn = by_gap > by_rows ? by_gap : by_rows;
+        gn = (y - GOP) / (GEP + T.min_m);
+        for (int j = 1; j * GOP <= y; j++) {
+          const int m = (y - j * GOP) / GEP, h = j * bx_ones_span<NW>(cm, m), tot = m + (h < k ? h : k);
+          if (tot > gn) gn = tot;
+        }
       }
+      if (gn >= G) break;
+      G = gn;
       if (gn < g_dn) g_dn = gn;
       if (gn < g_up) g_up = gn;
     }

@@ -632,7 +632,7 @@ extern "C" int mia_hip_plain_stats(mia_hip_ctx* ctx, int reset, double* plain_ms
 }
 
 template <int CPL>
-static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count, const int32_t* dev_range = nullptr) {
+static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count, const int32_t* dev_range = nullptr, hipStream_t on = nullptr) {
   // slab = the largest trace of this class: 256 rows x 64*CPL columns, one byte per cell
   const int64_t slab = (int64_t)MAX_READ * 64 * CPL;
   // persistent grid: never more workgroups than are resident at once (a late starter would work through its whole
@@ -649,10 +649,10 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
     if (hipMalloc((void**)&ctx->d_slabs[ci], (size_t)slab * ctx->grid_wgs) != hipSuccess) return hipErrorOutOfMemory;
   }
   RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
-  if (stage_begin(ctx, STG_TRACE)) return hipErrorOutOfMemory;
-  hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
+  if (stage_begin(ctx, STG_TRACE, on)) return hipErrorOutOfMemory;
+  hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, on ? on : ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
                      count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg, dev_range);
-  stage_end(ctx, STG_TRACE);
+  stage_end(ctx, STG_TRACE, on);
   return hipGetLastError();
 }
 
@@ -892,7 +892,8 @@ static int align_all(mia_hip_ctx* ctx) {
     hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ctx->stream, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count);
     ck("scan fill seed");
     // every window class reads its own range from the header (the list is rewritten by the re-plan below, so they all go
-    // first; a class without reads costs an empty launch)
+    // first; a class without reads costs an empty launch -- a few microseconds; putting them on the second stream beside
+    // the quad kernels was tried and gained nothing)
     for (int ci = 0; ci < N_CPL; ci++) {
       hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci)
                    : ci == 1 ? launch_window<8>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci)
