@@ -39,6 +39,7 @@ struct BxDev {
   int32_t* lists;          // [2 * BX_NCLS][list_stride] read indices
   int64_t list_stride;
   uint32_t* ctr;           // BXC_*
+  int32_t lazy_scripts;    // the scripts of reads finished as pure diagonals are not written (k_diag_scripts makes them when asked for)
 };
 
 __device__ __forceinline__ uint32_t bx_pack(const BxPlan& p) {
@@ -92,6 +93,15 @@ __device__ __forceinline__ void bx_diag_scripts(const ReadSet& rs, unsigned long
       *reinterpret_cast<uint2*>(cols + base) = v;
     }
   }
+}
+
+// The scripts the band pipeline did not write (BxDev::lazy_scripts): a read finished as a pure diagonal (ST_DIAG, abr = 0)
+// sits on consecutive columns from as - refstart on.  Nothing on the device reads the script of such a read (k_rec_geom,
+// the tallies and the insert events all go by the flag); the host does, through mia_hip_get_scripts.
+__global__ __launch_bounds__(256) void k_diag_scripts(ReadSet rs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool mine = i < rs.n && rs.sk[i] && (rs.status[i] & ST_DIAG) && rs.abr[i] == 0;     // (the band pipeline's are all of this kind)
+  bx_diag_scripts(rs, __ballot(mine), (int32_t)(mine ? i : 0), mine ? rs.as[i] - rs.refstart[i] : 0, mine ? rs.len[i] : 0);
 }
 
 // the reference's 10-mers into the hash table (bandx_body.h: KmerHash); slots and ovf are all ones / anything before.
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
       atomicAdd(bxc(bx.ctr, BXC_FAIL0 + (int)threadIdx.x - 2 * BX_NCLS - 2), blk_cnt[threadIdx.x]);
     __syncthreads();
     if (which >= 0) bx.lists[(int64_t)which * bx.list_stride + blk_base[which] + rank] = r.i;
-    bx_diag_scripts(rs, __ballot(bp.mode == BX_DONE), r.i, bp.dstar, r.len2);
+    if (!bx.lazy_scripts) bx_diag_scripts(rs, __ballot(bp.mode == BX_DONE), r.i, bp.dstar, r.len2);
     __syncthreads();
     if (threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256) void k_bx_values(ReadSet rs, RefInfo ref, BxDe
     }
     // (a read whose best score is not the plan's diagonal's has a gap or a soft clip: it stays open -- bin_of = 0 -- and the
     // planner hands it to the full-window kernels; a second trace launch for these few would cost a whole chunk's latency)
-    bx_diag_scripts(rs, __ballot(ok), r.i, r.d0 + r.jstar, r.len2);
+    if (!bx.lazy_scripts) bx_diag_scripts(rs, __ballot(ok), r.i, r.d0 + r.jstar, r.len2);
   }
   for (int o = 32; o; o >>= 1) done += __shfl_xor(done, o);
   if (lane == 0 && done) atomicAdd(bxc(bx.ctr, BXC_DONE_VALUES), done);

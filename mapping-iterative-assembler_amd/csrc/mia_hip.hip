@@ -103,6 +103,8 @@ struct mia_hip_ctx {
   bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
   bool ref_mostly_bases = true;            // fewer than 2 % of the reference columns are N
   int64_t kh_entries = 0;                  // > 0: the reference has N columns and its 10-mer table lists them (bandx_body.h, N COLUMNS)
+  bool diag_scripts_missing = false;       // the last alignment left the scripts of its ST_DIAG reads unwritten (k_diag_scripts)
+  int lazy_scripts = 1;                    // MIA_HIP_EAGER_SCRIPTS=1: the band pipeline writes them as it goes
   bool wide_to_caller = false;             // run_wide marks its reads ST_ESCAPE instead of aligning them (the anchored pass 1)
   int use_wild = 1;                        // MIA_HIP_NO_WILD=1: reads whose window holds an N go to the full-window kernels
   bool flat = false; int use_filter = 1;   // MIA_HIP_NO_DIAG_FILTER=1 sends every read to the DP kernels
@@ -279,6 +281,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nbd && atoi(nbd)) { ctx->use_banddp = 0; ctx->use_bx = 0; }
     const char* nbx = getenv("MIA_HIP_NO_BANDX");
     if (nbx && atoi(nbx)) ctx->use_bx = 0;
+    const char* egs = getenv("MIA_HIP_EAGER_SCRIPTS");
+    if (egs && atoi(egs)) ctx->lazy_scripts = 0;
     const char* nwl = getenv("MIA_HIP_NO_WILD");
     if (nwl && atoi(nwl)) ctx->use_wild = 0;
     const char* bxf = getenv("MIA_HIP_BX_FILTER");
@@ -819,6 +823,8 @@ static int align_all(mia_hip_ctx* ctx) {
       }
       BxDev bd;
       bd.tab.sub = ctx->d_bx_sub; bd.tab.mrow = ctx->d_bx_mrow; bd.tab.loss = ctx->d_bx_loss; bd.tab.dl = ctx->d_bx_dl;
+      bd.lazy_scripts = ctx->lazy_scripts;
+      if (ctx->lazy_scripts) ctx->diag_scripts_missing = true;
       bd.tab.min_m = ctx->bx_min_m; bd.tab.max_m = ctx->bx_max_m;
       bd.sub256 = ctx->d_bx_sub + BX_SUB_WORDS;
       bd.refnib = ctx->d_refnib;
@@ -1141,6 +1147,11 @@ extern "C" int mia_hip_get_scripts(mia_hip_ctx* ctx, int16_t* cols, int32_t stri
   HIPCHK(hipSetDevice(ctx->device));
   const size_t n = (size_t)ctx->rs.n;
   if (cols) {
+    if (ctx->diag_scripts_missing && n > 0) {
+      hipLaunchKernelGGL(k_diag_scripts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs);
+      HIPCHK(hipGetLastError());
+      ctx->diag_scripts_missing = false;
+    }
     HIPCHK(hipMemcpy2DAsync(cols, (size_t)stride * 2, ctx->d_cols, (size_t)ctx->rs.stride * 2, (size_t)ctx->max_len * 2, n,
                             hipMemcpyDeviceToHost, ctx->stream));
   }
@@ -2285,7 +2296,7 @@ static void build_kmer_lists(const std::string& seq, int k, int soft_mask, std::
 struct AlignBorrow {
   mia_hip_ctx* c;
   ReadSet rs; int32_t *bin_of, *list, *wide, *retry; int max_len; uint8_t* d_ref; int L, wrap, explicit_win, use_filter;
-  bool aligned, culled, tallied, pre_cull_valid, ref_mostly_bases;
+  bool aligned, culled, tallied, pre_cull_valid, ref_mostly_bases, diag_scripts_missing;
   int64_t kh_entries;
   int64_t plain_total, plain_retried, filter_seen, filter_proven, bx_seen, bx_done0, bx_done1, bx_done2;
   double stg_ms[STG_COUNT]; int64_t stg_launches[STG_COUNT];
@@ -2293,7 +2304,7 @@ struct AlignBorrow {
       : c(ctx), rs(ctx->rs), bin_of(ctx->d_bin_of), list(ctx->d_list), wide(ctx->d_wide_list), retry(ctx->d_retry_list), max_len(ctx->max_len),
         d_ref(ctx->d_ref), L(ctx->L), wrap(ctx->wrap), explicit_win(ctx->explicit_win), use_filter(ctx->use_filter), aligned(ctx->aligned),
         culled(ctx->culled), tallied(ctx->tallied), pre_cull_valid(ctx->pre_cull_valid), ref_mostly_bases(ctx->ref_mostly_bases),
-        kh_entries(ctx->kh_entries), plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven),
+        diag_scripts_missing(ctx->diag_scripts_missing), kh_entries(ctx->kh_entries), plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven),
         bx_seen(ctx->bx_seen), bx_done0(ctx->bx_done[0]), bx_done1(ctx->bx_done[1]), bx_done2(ctx->bx_done[2]) {
     // the stage timers of the iteration path must not see what the borrowed runs add (bench.py's roofline reads them)
     for (int k = 0; k < STG_COUNT; k++) {
@@ -2316,7 +2327,7 @@ struct AlignBorrow {
     }
     c->rs = rs; c->d_bin_of = bin_of; c->d_list = list; c->d_wide_list = wide; c->d_retry_list = retry; c->max_len = max_len; c->d_ref = d_ref;
     c->L = L; c->wrap = wrap; c->explicit_win = explicit_win; c->use_filter = use_filter; c->aligned = aligned; c->culled = culled;
-    c->tallied = tallied; c->pre_cull_valid = pre_cull_valid; c->ref_mostly_bases = ref_mostly_bases; c->kh_entries = kh_entries; c->plain_total = plain_total;
+    c->tallied = tallied; c->pre_cull_valid = pre_cull_valid; c->ref_mostly_bases = ref_mostly_bases; c->kh_entries = kh_entries; c->diag_scripts_missing = diag_scripts_missing; c->plain_total = plain_total;
     c->plain_retried = plain_retried; c->filter_seen = filter_seen; c->filter_proven = filter_proven;
     c->bx_seen = bx_seen; c->bx_done[0] = bx_done0; c->bx_done[1] = bx_done1; c->bx_done[2] = bx_done2;
   }
