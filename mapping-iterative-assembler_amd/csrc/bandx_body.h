@@ -201,6 +201,25 @@ MIA_HD inline int64_t bx_kmer(const uint32_t* pw, int len2, int o) {
   return (int64_t)((y & 0xFFFFull) | ((y >> 16) & 0xF0000ull));
 }
 
+// The same index from the read's bit planes (which the planner holds in registers anyway: no trip to the packed read)
+template <int NW>
+MIA_HD inline uint32_t bx_kmer_planes(const DiagScan<NW>& sc, int o) {
+  const int j = o >> 6, sh = o & 63;
+  uint64_t l0 = sc.rlo[0], h0 = sc.rhi[0], l1 = 0, h1 = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) {
+    if (k == j) { l0 = sc.rlo[k]; h0 = sc.rhi[k]; }
+    if (k == j + 1) { l1 = sc.rlo[k]; h1 = sc.rhi[k]; }
+  }
+  uint32_t lo = (uint32_t)((l0 >> sh) | ((l1 << 1) << (63 - sh))) & 0x3FFu;
+  uint32_t hi = (uint32_t)((h0 >> sh) | ((h1 << 1) << (63 - sh))) & 0x3FFu;
+  lo = (lo | (lo << 8)) & 0x00FF00FFu; hi = (hi | (hi << 8)) & 0x00FF00FFu;
+  lo = (lo | (lo << 4)) & 0x0F0F0F0Fu; hi = (hi | (hi << 4)) & 0x0F0F0F0Fu;
+  lo = (lo | (lo << 2)) & 0x33333333u; hi = (hi | (hi << 2)) & 0x33333333u;
+  lo = (lo | (lo << 1)) & 0x55555555u; hi = (hi | (hi << 1)) & 0x55555555u;
+  return lo | (hi << 1);
+}
+
 // The reference's 10-mers as a compact hash table (open addressing, 16-byte slots {key, pos0, count - 1, pos1}, load <= 1/4):
 // a megabyte for a mitochondrion, so that the nine look-ups of a read stay in the L2 (the direct-addressed table of
 // diag_filter.h is 20 MB and every look-up a trip to memory).  Positions 3 and 4 of a repeated 10-mer sit in `ovf`.
@@ -281,6 +300,7 @@ struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_
 template <int NW>
 MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const uint32_t* pw, int s, int len1, int len2, int st, const BxTab& T, BxAnchors* an) {
   constexpr int NB = bx_nb_max<NW>();      // (a read of NW words has at most this many blocks)
+  (void)pw;                                // (the 10-mers come from the planes in sc)
   const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
   // the home slots of all blocks first, then their use: nine independent loads in flight instead of nine round trips
   int32_t cn[NB], ps[NB][DF_KCAP];
@@ -288,7 +308,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     if (b < nb_cut) {
-      kidx[b] = (uint32_t)bx_kmer(pw, len2, bx_block_row(b, len2, nb_cut));
+      kidx[b] = bx_kmer_planes<NW>(sc, bx_block_row(b, len2, nb_cut));
       kh0[b] = kh_home(kh, kidx[b]);
       const uint32_t* e = kh.slot + 4 * (size_t)kh0[b];
 #pragma unroll

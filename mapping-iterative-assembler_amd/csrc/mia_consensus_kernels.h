@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, in
   for (int b = threadIdx.x; b < nb; b += blockDim.x) if (hist[b]) atomicAdd(&count[b], hist[b]);
 }
 // off[b] = first read of bucket b in `order`, wgoff[b] = first workgroup of bucket b (TALLY_CHUNK reads each)
-__global__ __launch_bounds__(256) void k_bucket_scan(const int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor) {
+__global__ __launch_bounds__(256) void k_bucket_scan(const int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor, int32_t* wg_bucket) {
   // one workgroup of 256 threads: every thread a stretch of buckets, a scan over the 256 partial sums in LDS
   __shared__ int32_t s_run[256], s_wg[256];
   const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
@@ -573,7 +573,12 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const int32_t* count, int32
     __syncthreads();
   }
   int r = s_run[t] - run, w = s_wg[t] - wg;
-  for (int b = b0; b < b1; b++) { off[b] = r; wgoff[b] = w; cursor[b] = 0; r += count[b]; w += (count[b] + TALLY_CHUNK - 1) / TALLY_CHUNK; }
+  for (int b = b0; b < b1; b++) {
+    off[b] = r; wgoff[b] = w; cursor[b] = 0;
+    const int nw = (count[b] + TALLY_CHUNK - 1) / TALLY_CHUNK;
+    for (int q = 0; q < nw; q++) wg_bucket[w + q] = b;          // (the tally's workgroups look their bucket up instead of searching wgoff)
+    r += count[b]; w += nw;
+  }
   if (t == 255) { off[nb] = s_run[255]; wgoff[nb] = s_wg[255]; }
 }
 __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order) {
@@ -601,7 +606,8 @@ template <bool LINEAR>
 __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
-                                                       const int32_t* rec_actf, int32_t* slabs, uint32_t dbg) {
+                                                       const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, const uint64_t* rplanes,
+                                                       int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket) {
   constexpr bool linear = LINEAR;
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
   // !LINEAR (a position-specific matrix): the scores of a base depend on its depth code and its strand -- but every base
@@ -623,10 +629,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   __shared__ unsigned long long ev_buf[TALLY_EV_CAP];
   __shared__ int ev_cnt, ev_base;
   if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
-  // which bucket does this workgroup belong to?  (wgoff is ascending, nb <= a few hundred)
-  int lo = 0, hi = nb;
-  while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (wgoff[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
-  const int b = lo, chunk = (int)blockIdx.x - wgoff[b];
+  const int b = wg_bucket[blockIdx.x], chunk = (int)blockIdx.x - wgoff[b];     // (k_bucket_scan's table)
   const int first = off[b] + chunk * TALLY_CHUNK, last = min(first + TALLY_CHUNK, off[b + 1]);
   const int win_base = b * TALLY_BUCKET;
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) lds[k] = 0;
@@ -657,6 +660,57 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   };
   const int L = ref.L, Lp = tb.Lp;
   int warm = 0;
+  // BIT-SLICED COUNTS (linear matrix, reads of up to 128 bases without N, the bit planes of k_read_planes at hand).  The
+  // window takes its base counts through LDS atomics, and those run at ~1.4 lane-atomics per cycle and CU whatever the
+  // addresses: a hundred per read was two thirds of this kernel.  Instead every lane keeps, for each base X and each 64-column
+  // word w of the window's first 256 columns, a 2-bit vertical counter (two 64-bit planes): a read's planes, shifted to its
+  // place, give four one-hot masks per word, and adding a mask to a vertical counter is three logic operations for 64
+  // columns at once.  A lane sees at most TALLY_CHUNK / 256 = 2 reads.  At the end the 64 lanes' counters are added up in
+  // a halving exchange (the lane keeps the half of the items its lane-id bit names, sends the other half, adds what it
+  // receives bit plane by bit plane: 16 items on 64 lanes become one 8-bit item on each group of four lanes) and each lane
+  // adds 16 columns of its item to the window -- 1 024 atomics per wavefront instead of 12 800.
+  constexpr int BS_W = 4;                                   // window words covered: columns 0 .. 255
+  unsigned long long bs0[4 * BS_W], bs1[4 * BS_W];
+  const bool bs_on = LINEAR && rplanes && umax && !(dbg & 4096u);
+  // a stretch of a read's planes (rows from r_lo on, n_rows of them) counted at window columns c .. c + n_rows - 1 < 256
+  auto bs_count = [&](unsigned long long l0, unsigned long long l1, unsigned long long h0, unsigned long long h1, int r_lo, int n_rows, int c) {
+    // rows r_lo.. down to bit 0 (a 128-bit shift right), then n_rows of them kept
+    const int rs_ = r_lo & 63;
+    const bool rw = r_lo >= 64;
+    auto down = [&](unsigned long long a0, unsigned long long a1, unsigned long long* o0, unsigned long long* o1) {
+      const unsigned long long b0 = rw ? a1 : a0, b1 = rw ? 0ull : a1;
+      *o0 = (b0 >> rs_) | ((b1 << 1) << (63 - rs_));
+      *o1 = b1 >> rs_;
+    };
+    unsigned long long dl0, dl1, dh0, dh1;
+    down(l0, l1, &dl0, &dl1); down(h0, h1, &dh0, &dh1);
+    const unsigned long long v0 = n_rows >= 64 ? ~0ull : ((1ull << n_rows) - 1ull);
+    const unsigned long long v1 = n_rows <= 64 ? 0ull : (n_rows >= 128 ? ~0ull : ((1ull << (n_rows - 64)) - 1ull));
+    const int bsh = c & 63, ws = c >> 6;
+    auto place = [&](unsigned long long a0, unsigned long long a1, unsigned long long* o) {
+      const unsigned long long t0 = a0 << bsh, t1 = (a1 << bsh) | ((a0 >> 1) >> (63 - bsh)), t2 = (a1 >> 1) >> (63 - bsh);
+#pragma unroll
+      for (int w = 0; w < BS_W; w++) o[w] = w == ws ? t0 : (w == ws + 1 ? t1 : (w == ws + 2 ? t2 : 0ull));
+    };
+    unsigned long long pl_lo[BS_W], pl_hi[BS_W], pl_v[BS_W];
+    place(dl0 & v0, dl1 & v1, pl_lo); place(dh0 & v0, dh1 & v1, pl_hi); place(v0, v1, pl_v);
+#pragma unroll
+    for (int w = 0; w < BS_W; w++) {
+      const unsigned long long lo_w = pl_lo[w], hi_w = pl_hi[w];
+      const unsigned long long m[4] = {pl_v[w] & ~(lo_w | hi_w), lo_w & ~hi_w, hi_w & ~lo_w, lo_w & hi_w};
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const unsigned long long cy = bs0[x * BS_W + w] & m[x];
+        bs0[x * BS_W + w] ^= m[x];
+        bs1[x * BS_W + w] |= cy;
+      }
+    }
+  };
+  if (LINEAR) {
+#pragma unroll
+    for (int t = 0; t < 4 * BS_W; t++) { bs0[t] = 0; bs1[t] = 0; }
+  }
+  static_assert(TALLY_CHUNK <= 3 * 256, "a lane's vertical counters hold two bits");
   for (int k0 = first; k0 < last; k0 += 256) {
     const int k = k0 + (int)threadIdx.x;
     const bool have = k < last;
@@ -682,7 +736,10 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
           // depth codes are not needed for the sums; they only have to be valid: act <= 15 always is, beyond that
           // dfb = fB - act - 1 must not be negative (depth_code above)
           bad = n_al > PSSM_DEPTH + 1 && fB < n_al;
-          if (!dF) {
+          if (!dF && bs_on && abr == 0 && len2 <= 128 && w0 + n_al <= 64 * BS_W && umax[i] >= 0) {
+            const uint64_t* pl = rplanes + (int64_t)i * 2 * rplane_words;
+            bs_count(pl[0], rplane_words > 1 ? pl[1] : 0ull, pl[rplane_words], rplane_words > 1 ? pl[rplane_words + 1] : 0ull, 0, n_al, w0);
+          } else if (!dF) {
             lds_i32* nc = (lds_i32*)n_cnt + w0;
             for (int act = 0; act < n_al; act++) {
               const int r = abr + act;
@@ -803,6 +860,34 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
         lds_i32* t = (lds_i32*)lds + w0;
         const int bad = n_al > PSSM_DEPTH + 1 && fB < n_al;            // (depth codes have to be valid: act <= 15 always is, beyond that fB - act - 1 >= 0)
         uint32_t word = 0;
+        const bool sliced = LINEAR && bs_on && abr == 0 && len2 <= 128 && w0 + ncol <= 64 * BS_W && umax[i] >= 0;
+        if (sliced) {
+          // the two stretches of the read either side of its gap through the vertical counters; the gap itself as before
+          if (!dF) {
+            const uint64_t* pl = rplanes + (int64_t)i * 2 * rplane_words;
+            const unsigned long long l0 = pl[0], l1 = rplane_words > 1 ? pl[1] : 0ull, h0 = pl[rplane_words], h1 = rplane_words > 1 ? pl[rplane_words + 1] : 0ull;
+            const int r2 = ins ? grow + gn : grow;                       // first row behind the gap, at column w0 + grow (+ gn behind a deletion)
+            bs_count(l0, l1, h0, h1, 0, grow, w0);
+            bs_count(l0, l1, h0, h1, r2, len2 - r2, w0 + grow + (ins ? 0 : gn));
+            if (!ins) for (int q = 0; q < gn; q++) aadd(&t[T_GAP * TALLY_WIN + grow + q], 1);
+          }
+          if (ins)
+            for (int j = 0; j < gn; j++) {
+              const int r = grow + j;
+              const int code = (int)((rp[r >> 3] >> ((r & 7) * 4)) & 15u);
+              const int gc = g.start_w + grow, act = grow + gn;
+              if (j == 0) atomicMax(&tb.gaps[gc], gn);
+              const int d = depth_code(act, fB - act - 1);
+              const uint64_t ev = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
+                                  ((uint64_t)((flags & TRF_RC) ? 1 : 0) << 50);
+              const int slot = atomicAdd(&ev_cnt, 1);
+              if (slot < TALLY_EV_CAP) ev_buf[slot] = ev;
+              else {
+                const int e = atomicAdd(tb.n_events, 1);
+                if (e < tb.cap_events) tb.events[e] = ev; else atomicOr(tb.flags, 1u);
+              }
+            }
+        } else
         for (int r = abr; r < len2; r++) {
           if (r == abr || (r & 7) == 0) word = rp[r >> 3];
           const int code = (int)((word >> ((r & 7) * 4)) & 15u);
@@ -863,6 +948,87 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
       tally_one_read<true>(__builtin_amdgcn_readfirstlane(ii), lane, rs, ref, pssm2, drop_front, drop_back, tb, lds, win_base, rec_params, rec_actf, pssm_lds, ev_buf, &ev_cnt,
                            linear ? n_cnt : nullptr, rec_stage[wv]);
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (LINEAR && bs_on) {
+    // the wavefront's 64 x 16 vertical counters -> one 8-bit item per group of four lanes -> the window
+    auto xch = [&](unsigned long long v, int m) -> unsigned long long { return (unsigned long long)__shfl_xor((long long)v, m); };
+    // stage A (lane bit 5): items t and t + 8, 2-bit + 2-bit -> 3 bits; lane bit set keeps the upper half
+    unsigned long long a3[8][3];
+    {
+      const bool hi = (lane & 32) != 0;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const unsigned long long k0 = hi ? bs0[t + 8] : bs0[t], k1 = hi ? bs1[t + 8] : bs1[t];
+        const unsigned long long s0 = hi ? bs0[t] : bs0[t + 8], s1 = hi ? bs1[t] : bs1[t + 8];
+        const unsigned long long r0 = xch(s0, 32), r1 = xch(s1, 32);
+        const unsigned long long c0 = k0 & r0, x1 = k1 ^ r1;
+        a3[t][0] = k0 ^ r0; a3[t][1] = x1 ^ c0; a3[t][2] = (k1 & r1) | (c0 & x1);
+      }
+    }
+    // stage B (lane bit 4): 3 + 3 -> 4 bits
+    unsigned long long a4[4][4];
+    {
+      const bool hi = (lane & 16) != 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        unsigned long long carry = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const unsigned long long k = hi ? a3[t + 4][q] : a3[t][q], sd = hi ? a3[t][q] : a3[t + 4][q], r = xch(sd, 16), x = k ^ r;
+          a4[t][q] = x ^ carry; carry = (k & r) | (carry & x);
+        }
+        a4[t][3] = carry;
+      }
+    }
+    // stage C (lane bit 3): 4 + 4 -> 5 bits
+    unsigned long long a5[2][5];
+    {
+      const bool hi = (lane & 8) != 0;
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        unsigned long long carry = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const unsigned long long k = hi ? a4[t + 2][q] : a4[t][q], sd = hi ? a4[t][q] : a4[t + 2][q], r = xch(sd, 8), x = k ^ r;
+          a5[t][q] = x ^ carry; carry = (k & r) | (carry & x);
+        }
+        a5[t][4] = carry;
+      }
+    }
+    // stage D (lane bit 2): 5 + 5 -> 6 bits; then two plain exchanges inside the group of four: 7, 8 bits
+    unsigned long long a8[8];
+    {
+      const bool hi = (lane & 4) != 0;
+      unsigned long long carry = 0;
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        const unsigned long long k = hi ? a5[1][q] : a5[0][q], sd = hi ? a5[0][q] : a5[1][q], r = xch(sd, 4), x = k ^ r;
+        a8[q] = x ^ carry; carry = (k & r) | (carry & x);
+      }
+      a8[5] = carry; a8[6] = 0; a8[7] = 0;
+#pragma unroll
+      for (int st = 0; st < 2; st++) {
+        const int bits = 6 + st;
+        carry = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          if (q < bits) {
+            const unsigned long long k = a8[q], r = xch(k, st == 0 ? 2 : 1), x = k ^ r;
+            a8[q] = x ^ carry; carry = (k & r) | (carry & x);
+          }
+        }
+        a8[bits] = carry;
+      }
+    }
+    // this lane's item: t = (lane >> 2) & 15 = base * BS_W + word; its 16 columns: (lane & 3) * 16 ...
+    const int item = (lane >> 2) & 15, bx_ = item / BS_W, wd = item % BS_W, c0 = (lane & 3) * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      int v = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) v |= (int)((a8[q] >> (c0 + j)) & 1ull) << q;
+      if (v) aadd((lds_i32*)lds + (T_A + bx_) * TALLY_WIN + wd * 64 + c0 + j, v);
     }
   }
   if (warm == 0x7FFFFFF1) atomicOr(tb.flags, 4u);   // keeps the warming loads alive; never true for real data

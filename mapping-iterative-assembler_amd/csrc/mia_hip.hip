@@ -1522,30 +1522,34 @@ static int tally_launch(mia_hip_ctx* ctx) {
     const int nb = ctx->wrap / TALLY_BUCKET + 1;
     if (ctx->use_binned_tally && nb <= 4096 && ctx->max_abs <= 32767) {   // (the LDS copy of the matrices is int16)
       // counting sort of the reads by alignment start, then one LDS tally window per workgroup
-      if (nb + 1 > ctx->bucket_cap) {
-        if (dev_alloc(ctx, &ctx->d_bucket, (size_t)4 * (nb + 1))) return MIA_HIP_ERR_NOMEM;
-        ctx->bucket_cap = nb + 1;
+      const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
+      if (4 * (nb + 1) + grid > ctx->bucket_cap) {
+        if (dev_alloc(ctx, &ctx->d_bucket, (size_t)(4 * (nb + 1) + grid) * 2)) return MIA_HIP_ERR_NOMEM;
+        ctx->bucket_cap = (4 * (nb + 1) + grid) * 2;
       }
       if (!ctx->d_order && dev_alloc(ctx, &ctx->d_order, (size_t)n)) return MIA_HIP_ERR_NOMEM;
-      int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1);
+      int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1), *d_wgb = d_cur + (nb + 1);
       HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, ctx->stream));
       const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
       hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, ctx->stream, ctx->rs, nb, d_cnt);
-      hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur);
+      hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb);
       hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, ctx->stream, ctx->rs, nb, d_off, d_cur, ctx->d_order);
-      const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
       const int64_t slab_words = (int64_t)grid * (TALLY_WORDS - 1) * TALLY_WIN;
       if (slab_words > ctx->tally_slab_cap) {
         if (dev_alloc(ctx, &ctx->d_tally_slabs, (size_t)slab_words)) return MIA_HIP_ERR_NOMEM;
         ctx->tally_slab_cap = slab_words;
       }
+      // (the bit planes and the N marks of the context's own reads: k_read_planes / k_bx_umax at upload)
+      const bool planes_ok = ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax;
       if (stage_begin(ctx, STG_TALLY)) return MIA_HIP_ERR_NOMEM;
       if (ctx->tally_linear)
         hipLaunchKernelGGL(k_tally_binned<true>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
-                           ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg);
+                           ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
+                           planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb);
       else
         hipLaunchKernelGGL(k_tally_binned<false>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
-                           ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg);
+                           ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
+                           (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb);
       stage_end(ctx, STG_TALLY);
       hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
     } else {
