@@ -164,7 +164,6 @@ struct RecInfo {              // per read, rebuilt every iteration by k_rec_geom
   int32_t* flen;              // asp_len of the front record (columns + inserted bases, src/fsdb.c:518-530)
   int32_t* blen;              // same for the read's own back record (0 if not split)
   int32_t* actf;              // read bases in the front record
-  int32_t* params;            // [n][8]: front {dffBase, actOff, B, mult}, back {dffBase, actOff, B, mult}
   int32_t* trec;              // [n][16]: everything the tally needs about a read in ONE 64-byte line (see TREC_*)
 };
 // The tally visits the reads in bucket order, i.e. at random with respect to the per-read arrays: gathering a dozen
@@ -342,8 +341,7 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
   if (i >= rs.n) return;
   const int n_links = min(*n_links_p, cap);
   uint8_t df = 0, db = 0;
-  int32_t* p = ri.params + i * 8;
-  for (int k = 0; k < 8; k++) p[k] = 0;
+  int32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // front {dffBase, actOff, B, mult}, back {...}: words 8..15 of the read's record below
   if (rs.sk[i]) {
     const bool split = rec_geom(rs.as[i], rs.ae[i], L).split;
     const int64_t s = slot[i], ls = s - si.base;
@@ -1090,30 +1088,25 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
 // and the last buckets' windows where they wrap around to the start of the reference.
 // Runs after k_tally_binned; nothing else writes the tally then, so plain read-modify-write.
 __global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs) {
-  const int gc = blockIdx.x * blockDim.x + threadIdx.x;
+  // one thread per (column, tally word): blockIdx.y is the word (a thread per column alone is 66 workgroups for a
+  // mitochondrion, each thread a chain of five hundred loads)
+  const int gc = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
   const int Lp = tb.Lp;
   if (gc >= Lp) return;
-  int acc[TALLY_WORDS - 1];
-  for (int w = 0; w < TALLY_WORDS - 1; w++) acc[w] = 0;
+  int acc = 0;
   const int bhi = min(gc / TALLY_BUCKET, nb - 1);
   for (int b = max(0, gc / TALLY_BUCKET - (TALLY_WIN / TALLY_BUCKET - 1)); b <= bhi; b++) {
     const int wc = gc - b * TALLY_BUCKET;
     if (wc < 0 || wc >= TALLY_WIN) continue;
-    for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) {
-      const int32_t* slab = slabs + (int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + wc;
-      for (int w = 0; w < TALLY_WORDS - 1; w++) acc[w] += slab[w * TALLY_WIN];
-    }
+    for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
   }
   // ... and the circular part of the last buckets' windows (tally_slot): slot gc + Lp - b * TALLY_BUCKET
   for (int b = max(0, (Lp + gc - TALLY_WIN) / TALLY_BUCKET); b < nb; b++) {
     const int wc = gc + Lp - b * TALLY_BUCKET;
     if (wc < 0 || wc >= TALLY_WIN || gc >= b * TALLY_BUCKET) continue;     // (columns from win_base on sit in their direct slot)
-    for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) {
-      const int32_t* slab = slabs + (int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + wc;
-      for (int w = 0; w < TALLY_WORDS - 1; w++) acc[w] += slab[w * TALLY_WIN];
-    }
+    for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
   }
-  for (int w = 0; w < TALLY_WORDS - 1; w++) if (acc[w]) tb.tally[w * Lp + gc] += acc[w];
+  if (acc) tb.tally[w * Lp + gc] += acc;
 }
 
 // ---- ma: tally of stored AlnSeq records (show_consensus, src/map_alignment.c:139-170) -------------

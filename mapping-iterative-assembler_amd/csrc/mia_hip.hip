@@ -330,7 +330,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_drop_b, ctx->tb.tally, ctx->tb.events, ctx->d_ins_off,
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
                   ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order,
-                  ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.params, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
+                  ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
                   ctx->lk.rec, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs,
                   ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_slabs, ctx->d_cut_buf, ctx->d_ascii, ctx->d_cons, ctx->d_cons_pos, ctx->d_gather, ctx->d_lstage, ctx->d_lmine, ctx->d_lall, ctx->d_scores_all};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -477,7 +477,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_slot_dropped, (size_t)ctx->n_slots);
   rcx |= dev_alloc(ctx, &ctx->d_back_slot, (size_t)n) | dev_alloc(ctx, &ctx->d_front_slot0, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->ri.flen, (size_t)n) | dev_alloc(ctx, &ctx->ri.blen, (size_t)n) | dev_alloc(ctx, &ctx->ri.actf, (size_t)n) |
-         dev_alloc(ctx, &ctx->ri.params, (size_t)n * 8) | dev_alloc(ctx, &ctx->ri.trec, (size_t)n * 16);
+         dev_alloc(ctx, &ctx->ri.trec, (size_t)n * 16);
   ctx->slot_cap = 2 * n + 16;
   rcx |= dev_alloc(ctx, &ctx->si.reclen, (size_t)ctx->slot_cap) | dev_alloc(ctx, &ctx->si.recact, (size_t)ctx->slot_cap) | dev_alloc(ctx, &ctx->si.writer, (size_t)ctx->slot_cap) |
          dev_alloc(ctx, &ctx->si.mult, (size_t)ctx->slot_cap);
@@ -762,7 +762,7 @@ static int align_all(mia_hip_ctx* ctx) {
       ctx->plane_cap = words;
     }
     RefPlanes rp{ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap};
-    hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
+    hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 3) / 4 < 4096 ? (words + 3) / 4 : 4096)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
                        ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
     // the 10-mer table of this reference (rule (c) looks long clean stretches up instead of sliding over every diagonal;
     // the band plans are made of its anchors); not for the very long concatenated strings mia_hip_align_windows may be given
@@ -1334,7 +1334,7 @@ extern "C" int mia_hip_get_record_params(mia_hip_ctx* ctx, int32_t* params, int6
   if (!ctx->culled) { ctx->err = "cull first"; return MIA_HIP_ERR_STATE; }
   HIPCHK(hipSetDevice(ctx->device));
   const size_t n = (size_t)ctx->rs.n;
-  if (params) HIPCHK(hipMemcpyAsync(params, ctx->ri.params, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  if (params) HIPCHK(hipMemcpy2DAsync(params, 32, ctx->ri.trec + TREC_PARAMS, 64, 32, n, hipMemcpyDeviceToHost, ctx->stream));   // words 8..15 of each record
   if (back_slot) HIPCHK(hipMemcpyAsync(back_slot, ctx->d_back_slot, n * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return MIA_HIP_OK;
@@ -1551,7 +1551,7 @@ static int tally_launch(mia_hip_ctx* ctx) {
                            ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
                            (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb);
       stage_end(ctx, STG_TALLY);
-      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
+      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256, TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
                          ctx->d_drop_b, ctx->tb, ctx->ri.trec, ctx->ri.actf);
@@ -2508,8 +2508,8 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       const int64_t words = plane_words(len1);
       if (pool_alloc(ctx, &d_p1planes, (size_t)words * 6)) return MIA_HIP_ERR_NOMEM;
       uint64_t* pl = d_p1planes;
-      hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, words, pl, pl + words, pl + 2 * words);
-      hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, words, pl + 3 * words, pl + 4 * words, pl + 5 * words);
+      hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 3) / 4 < 4096 ? (words + 3) / 4 : 4096)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, words, pl, pl + words, pl + 2 * words);
+      hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 3) / 4 < 4096 ? (words + 3) / 4 : 4096)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, words, pl + 3 * words, pl + 4 * words, pl + 5 * words);
       e = hipMemsetAsync(d_ntodo, 0, 4, ctx->stream);
       RefPlanes pf{pl, pl + words, pl + 2 * words}, prc{pl + 3 * words, pl + 4 * words, pl + 5 * words};
       // 10-mer tables of both strands for rule (c) (diag_filter.h: KmerOcc)

@@ -103,9 +103,17 @@ constexpr int PLAN_PER = 8;   // reads per thread of the planner kernels: a bloc
 // ---- the diagonal filter (diag_filter.h), ahead of everything else: one read per thread.  A read whose alignment
 // is provably one gap-free diagonal is finished here (score, end points, script, ST_DIAG) and marked bin_of = -2 so
 // that the planner leaves it out; all others are marked 0.  Flat matrix only (the host checks).
+// one plane word per wavefront and step, one code per lane, three ballots (a thread that builds a word alone walks 64
+// bytes); any grid: the wavefronts stride over the words
 __global__ __launch_bounds__(256) void k_ref_planes(const uint8_t* codes, int64_t n_codes, int64_t words, uint64_t* lo, uint64_t* hi, uint64_t* ok) {
-  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (w < words) plane_word(codes, n_codes, w, &lo[w], &hi[w], &ok[w]);
+  const int lane = threadIdx.x & 63;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < words; w += (int64_t)gridDim.x * 4) {
+    const int64_t p = w * 64 + lane - PLANE_LEAD;
+    const uint32_t c = (p >= 0 && p < n_codes) ? codes[p] : 4u;
+    const bool base = c <= 3u;
+    const uint64_t l = __ballot(base && (c & 1u)), h = __ballot(base && (c >> 1)), v = __ballot(base);
+    if (lane == 0) { lo[w] = l; hi[w] = h; ok[w] = v; }
+  }
 }
 
 // the 10-mer table of the reference for rule (c) (diag_filter.h: KmerOcc); cnt is zeroed before.  wild > 0: a 10-mer with
