@@ -24,26 +24,35 @@ __global__ __launch_bounds__(256) void k_ref_encode(const char* ascii, int32_t L
 
 enum { CH_LEN = 0, CH_INS_TOTAL, CH_OVERFLOW, CH_N_EVENTS, CH_TALLY_FLAGS, CH_CULL_FLAGS, CH_WORDS = 8 };
 
-// Exclusive prefix sum of in[0..n) by ONE 1024-thread workgroup (in place is fine).  Elements outside [lo_valid, hi_valid)
-// count as 0.  *total = the sum of everything.
+// Exclusive prefix sum of in[0..n) by ONE 1024-thread workgroup (in place is fine): each of the 16 wavefronts owns a
+// contiguous stretch and walks it 256 elements at a time (four per lane, a wave prefix sum per step); the stretches are
+// joined through LDS.  Elements outside [lo_valid, hi_valid) count as 0.  *total = the sum of everything.
 __global__ __launch_bounds__(1024) void k_excl_scan(const int32_t* in, int32_t n, int32_t lo_valid, int32_t hi_valid, int32_t* out, int32_t* total) {
-  // one pass: every thread a stretch of n / 1024 entries (their sum, a scan of the 1 024 sums, the stretch again)
   __shared__ int32_t wsum[16];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int per = (n + 1023) / 1024, lo = t * per, hi = min(lo + per, n);
-  auto at = [&](int q) -> int32_t { return (q >= lo_valid && q < hi_valid) ? in[q] : 0; };
-  int32_t sum = 0;
-  for (int q = lo; q < hi; q++) sum += at(q);
-  int32_t inc = sum;
+  const int per = ((n + 15) / 16 + 255) & ~255;
+  const int lo = w * per, hi = min(lo + per, n);
+  int32_t carry = 0;
+  for (int base = lo; base < hi; base += 256) {
+    const int p = base + lane * 4;
+    int32_t v[4];
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-  if (lane == 63) wsum[w] = inc;
+    for (int k = 0; k < 4; k++) { const int q = p + k; v[k] = (q < hi && q >= lo_valid && q < hi_valid) ? in[q] : 0; }
+    const int32_t s4 = v[0] + v[1] + v[2] + v[3];
+    int32_t inc = s4;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    int32_t run = carry + inc - s4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (p + k < hi) out[p + k] = run; run += v[k]; }
+    carry += __shfl(inc, 63);
+  }
+  if (lane == 0) wsum[w] = carry;
   __syncthreads();
   int32_t off = 0;
   for (int k = 0; k < w; k++) off += wsum[k];
-  int32_t run = off + inc - sum;
-  for (int q = lo; q < hi; q++) { const int32_t v = at(q); out[q] = run; run += v; }      // (in place is fine: every thread keeps to its stretch)
-  if (t == 1023) *total = run;
+  if (off) for (int p = lo + lane; p < hi; p += 64) out[p] += off;
+  if (t == 1023) *total = off + wsum[15];
 }
 
 __device__ __forceinline__ bool cons_emits(char c) { return c != '-' && c != ' '; }
