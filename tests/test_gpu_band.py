@@ -148,9 +148,11 @@ def test_tally_of_one_gap_reads(seed, read_len):
     out = []
     # the one-read-per-lane paths for one-gap and over-the-origin reads exist for the count-only ("linear") tally; with
     # MIA_HIP_NO_LINEAR_TALLY=1 those reads walk their scripts one per wavefront and every base adds its four score words
-    for env in (None, "MIA_HIP_NO_BAND_DP", "MIA_HIP_NO_LINEAR_TALLY"):
+    # (round 2: the count-only tally takes pure-diagonal and one-gap reads through bit-sliced vertical counters;
+    # MIA_HIP_DEBUG_SKIP=4096 is the same tally with one LDS atomic per base)
+    for env, val in ((None, ""), ("MIA_HIP_NO_BAND_DP", "1"), ("MIA_HIP_NO_LINEAR_TALLY", "1"), ("MIA_HIP_DEBUG_SKIP", "4096")):
         if env:
-            os.environ[env] = "1"
+            os.environ[env] = val
         try:
             hip = mia_amd.MiaHip(0)
         finally:
@@ -168,7 +170,7 @@ def test_tally_of_one_gap_reads(seed, read_len):
         it = hip.ins_tally()
         out.append((t, g, cons, it, hip.band_stats()[0] + sum(hip.bx_stats()[0][1:])))
         hip.close()
-    assert out[0][4] > 0.2 * n and out[1][4] == 0
+    assert out[0][4] > 0.2 * n and out[1][4] == 0 and out[3][4] == out[0][4]
     for other in out[1:]:
         assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1])
         assert out[0][2] == other[2] and out[0][1].max() > 0          # (the same consensus; insert events did reach ref->gaps)
