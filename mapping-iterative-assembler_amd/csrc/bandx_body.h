@@ -294,7 +294,8 @@ struct BxPlan { int mode, d0, w, dstar, b0, edge; };
 enum { BXF_READ = 1, BXF_WINDOW, BXF_BLOCKS, BXF_SPAN, BXF_PATH, BXF_BUDGET, BXF_WIDTH, BXF_KINDS };
 
 // the anchors of a read and what they imply, before any loss is summed
-struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_out, s_un; };   // l_out < 0: every anchor counts; s_un: dl of the blocks that occur nowhere in the window
+struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_out, s_un, r_head, r_tail, rescue; };
+// r_head: first row of the first block with a kept anchor; r_tail: first row behind the last such block; rescue: bx_rescue is to be tried   // l_out < 0: every anchor counts; s_un: dl of the blocks that occur nowhere in the window
 
 // Where the read's blocks occur inside the window.  sc holds the read's planes.
 template <int NW>
@@ -322,7 +323,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
     for (int k = 0; k < DF_KCAP; k++) ps[b][k] = 0;
     if (b < nb_cut) cn[b] = kh_resolve(kh, kidx[b], kh0[b], ke[b][0], ke[b][1], ke[b][2], ke[b][3], ps[b]);
   }
-  int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0, budget = -1, b_first = 0, l_out = -1, s_un = 0;
+  int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0, budget = -1, b_first = 0, l_out = -1, s_un = 0, b_lo_any = 0, b_hi_any = 0;
   bool any = false;
   const int16_t* dl = T.dl + (st * (MAX_READ + 1) + len2) * BX_BLOCKS;
   // the anchors whose diagonal lies in [m_lo, m_hi]: their extent, the first and the last in block order; l_out (if asked
@@ -344,7 +345,8 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
         if (d < -R || d > len1 - 1) continue;                   // not a place inside this window
         nowhere = false;
         if (d < m_lo || d > m_hi) { outside = true; continue; }
-        if (!any) { d_first = d; any = true; }
+        if (!any) { d_first = d; any = true; b_lo_any = b; }
+        b_hi_any = b;
         if (d == d_first) b_first = b;                          // (the last block that has an anchor on d_first)
         d_last = d;
         if (d < a_lo) a_lo = d;
@@ -395,6 +397,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
   // keep the written-down path inside the window
   if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) { an->fail = BXF_PATH; return; }
   an->a_lo = a_lo; an->a_hi = a_hi; an->d_first = d_first; an->d_last = d_last; an->budget = budget; an->l_out = l_out; an->s_un = s_un;
+  an->r_head = bx_block_row(b_lo_any, len2, nb_cut); an->r_tail = bx_block_row(b_hi_any, len2, nb_cut) + DF_K; an->rescue = 0;
   an->t_lo = 1; an->t_hi = R;
   if (d_first != d_last) {
     // the switch row is looked for between the last block anchored on d_first and the first one after it anchored on d_last
@@ -492,6 +495,80 @@ MIA_HD inline int bx_ones_span(const uint64_t* m, int zeros) {
     if (cnt > best) best = cnt;
   }
   return best;
+}
+
+// END INDELS.  An indel within a dozen rows of a read end leaves that end without a block of its own: all anchors lie on
+// one diagonal, the written-down path is that diagonal, and it pays a substitution for most of the shifted rows -- B0
+// exceeds the budget and the read (three in a hundred with the synthetic indel rate: nearly all the plan gives up on) went
+// to the full-window kernels.  B0 only has to be the loss of SOME valid path: look at the unanchored head and tail on
+// the diagonals one to three off, and if one of them explains that end much better, write the path down with a gap there
+// (bx_finish's two-diagonal form finds the switch row).  The anchors, and with them the band's centre, stay what they
+// are: the proof is the same, only its bound got better.  false: nothing to gain.
+template <int NW>
+MIA_HD inline bool bx_rescue(DiagScan<NW>& sc, const RefPlanes& rp, BxAnchors& an, int s, int len1, int len2) {
+  const int R = len2 - 1, dstar = an.d_first;
+  sc.seek(rp, (int64_t)s + dstar);
+  uint64_t m0[NW];
+#pragma unroll
+  for (int j = 0; j < NW; j++) m0[j] = sc.mis(j);
+  const int head = an.r_head > 0 ? bx_count<NW>(m0, 0, an.r_head) : 0, tail = an.r_tail < len2 ? bx_count<NW>(m0, an.r_tail, len2) : 0;
+  const bool at_tail = tail >= head;
+  const int here = at_tail ? tail : head;
+  if (here < 3) return false;
+  // which diagonal?  The six rows at the very end of the read (its start) sit on it: one seek three columns below d*, then
+  // the planes slide along (DiagScan::advance) -- the mismatches of those rows on d* - 3 .. d* + 3
+  const int e_lo = at_tail ? (len2 - 6 > an.r_tail ? len2 - 6 : an.r_tail) : 0, e_hi = at_tail ? len2 : (an.r_head < 6 ? an.r_head : 6);
+  if (e_hi - e_lo < 4) return false;
+  const int crude0 = bx_count<NW>(m0, e_lo, e_hi);
+  int pick = 0, pick_c = crude0;
+  {
+    DiagScan<NW> s2 = sc;
+    s2.seek(rp, (int64_t)s + dstar - 3);
+    for (int k = 0; k < 7; k++) {
+      const int sh = k - 3, d = dstar + sh;
+      if (sh != 0 && d >= 0 && d <= len1 - len2) {                // (the written-down path stays inside the window)
+        uint64_t m[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) m[j] = s2.mis(j);
+        const int c = bx_count<NW>(m, e_lo, e_hi);
+        if (c < pick_c) { pick_c = c; pick = sh; }
+      }
+      if (k < 6) s2.advance(rp, (int64_t)s + dstar - 3 + k + 1);
+    }
+  }
+  if (pick == 0 || pick_c + 2 > crude0) return false;
+  // that end's mismatches with the best switch row: rows below it on the first diagonal, `skip` rows left out where the
+  // second diagonal is the lower one (an insert), the rest on the second
+  int best = here, best_sh = 0;
+  {
+    const int sh = pick;
+    DiagScan<NW> s2 = sc;
+    s2.seek(rp, (int64_t)s + dstar + sh);
+    uint64_t m[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) m[j] = s2.mis(j);
+    int c = here;
+    if (at_tail) {
+      const int skip = sh < 0 ? -sh : 0, t0 = an.r_tail, t1 = len2 - skip;
+      if (t1 >= t0) {
+        int cur = bx_count<NW>(m, t0 + skip, len2);
+        c = cur;
+        for (int t = t0 + 1; t <= t1; t++) { cur += bx_bit<NW>(m0, t - 1) - bx_bit<NW>(m, t - 1 + skip); if (cur < c) c = cur; }
+      }
+    } else {
+      const int skip = sh > 0 ? sh : 0, t1 = an.r_head - skip;
+      if (t1 >= 1) {
+        int cur = bx_bit<NW>(m, 0) + bx_count<NW>(m0, 1 + skip, an.r_head);
+        c = cur;
+        for (int t = 2; t <= t1; t++) { cur += bx_bit<NW>(m, t - 1) - bx_bit<NW>(m0, t - 1 + skip); if (cur < c) c = cur; }
+      }
+    }
+    if (c < best) { best = c; best_sh = sh; }
+  }
+  if (best_sh == 0 || best + 2 > here) return false;
+  if (at_tail) { an.d_last = dstar + best_sh; an.t_lo = an.r_tail > 1 ? an.r_tail : 1; an.t_hi = R; }
+  else { an.d_first = dstar + best_sh; an.t_lo = 1; an.t_hi = an.r_head > 1 ? an.r_head : 1; }
+  return true;
 }
 
 // the rows of word j that lose anything on the diagonal sc is on: definite mismatches and N columns
@@ -646,6 +723,11 @@ MIA_HD inline void bx_plan_nw(const RefPlanes& rp, const KmerHash& ko, int64_t n
   out->b0 = an.fail;
   if (an.fail) return;
   bx_finish<NW>(sc, rp, an, s, len1, len2, st, T, out);
+  if (out->mode == BX_NONE && (out->b0 == BXF_BUDGET || out->b0 == BXF_WIDTH) && an.d_first == an.d_last && an.a_lo == an.a_hi) {
+    const int why = out->b0;
+    if (bx_rescue<NW>(sc, rp, an, s, len1, len2)) bx_finish<NW, 2>(sc, rp, an, s, len1, len2, st, T, out);
+    else out->b0 = why;
+  }
 }
 
 MIA_HD inline void bx_plan(const RefPlanes& rp, const KmerHash& ko, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2, int st,

@@ -236,13 +236,18 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
           bx_anchors<NW>(sc, ko, reinterpret_cast<const uint32_t*>(rs.packed + rs.roff[r.i]), r.s, r.l1, r.len2, r.st, T, &an);
           bp.b0 = an.fail;
           if (!an.fail) {
-            if (an.d_first == an.d_last) bx_finish<NW, 1>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
-            else {
+            bool later = an.d_first != an.d_last;
+            if (!later) {
+              bx_finish<NW, 1>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
+              // an end indel, perhaps (bx_rescue): with the reads of two diagonals, for the block's first threads
+              if (bp.mode == BX_NONE && (bp.b0 == BXF_BUDGET || bp.b0 == BXF_WIDTH) && an.a_lo == an.a_hi) { later = true; an.rescue = bp.b0; }
+            }
+            if (later) {
               const int slot = atomicAdd(&n_cand, 1);
               cand_an[slot] = an;
               cand_tid[slot] = (uint8_t)threadIdx.x;
               waits = true;
-              bp.b0 = 0;
+              bp.mode = BX_NONE; bp.b0 = 0;
             }
           }
         }
@@ -265,8 +270,9 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     if ((int)threadIdx.x < n_cand) {
       r = fetch(cand_tid[threadIdx.x], sc);
       load_planes(r, sc);
-      const BxAnchors an = cand_an[threadIdx.x];
-      bx_finish<NW, 2>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
+      BxAnchors an = cand_an[threadIdx.x];
+      if (an.rescue && !bx_rescue<NW>(sc, rp, an, r.s, r.l1, r.len2)) bp.b0 = an.rescue;      // (the reason it was not planned stands)
+      else bx_finish<NW, 2>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
     }
     emit(r, bp, !in_list && r.ok);
   }
