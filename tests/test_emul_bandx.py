@@ -420,3 +420,37 @@ def test_gaps_through_ambiguity_columns(emul, oracle):
                 continue
             finished += 1 if check(emul, oracle, spec, strand, ref, s, l1, read, stats) else 0
     assert stats["n"] > 500 and finished > 200, (stats, finished)
+
+
+@pytest.mark.parametrize("spec,strand", MATS)
+def test_end_indels_are_rescued(emul, oracle, spec, strand):
+    """An indel within a dozen rows of a read end: the end has no block of its own, all anchors lie on one diagonal and the
+    pure diagonal pays a substitution for most of the shifted rows -- over the budget.  bx_rescue tries the unanchored end
+    on the diagonals one to three off and, where that explains it, writes the path down with a gap there (the band then
+    follows from a B0 of one gap instead of ten substitutions).  Indels of 1-5 at 2-16 rows from either end, with and
+    without a substitution beside them; sizes above three are not rescued and must simply stay correct."""
+    rnd = random.Random(91 + strand)
+    ref = "".join(rnd.choice("ACGT") for _ in range(4000))
+    stats = {"n": 0}
+    finished = small = 0
+    for i in range(360):
+        n = rnd.choice([100, 100, 150, 64, 128])
+        pos = rnd.randint(10, len(ref) - n - 60)
+        src = ref[pos:pos + n + 30]
+        dist = rnd.randint(2, 16)
+        k = rnd.choice([1, 1, 2, 2, 3, 3, 4, 5])
+        at = dist if i % 2 else n - dist - (k if i % 4 < 2 else 0)
+        if i % 4 < 2:
+            read = (src[:at] + "".join(rnd.choice("ACGT") for _ in range(k)) + src[at:])[:n]      # inserted bases
+        else:
+            read = src[:at] + src[at + k:][:n - at]                                                # deleted columns
+        if i % 3 == 0:
+            read = mutate(rnd, read, [rnd.randint(0, 9) if i % 2 else rnd.randint(n - 10, n - 1)])
+        if i % 5 == 0:
+            read = damage(rnd, read)
+        s, l1 = window(ref, pos, len(read))
+        ok = check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+        if k <= 3:
+            small += 1
+            finished += 1 if ok else 0
+    assert stats["n"] == 360 and finished > 0.8 * small, (sorted(stats.items()), finished, small)
