@@ -637,27 +637,28 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
       g_up = g_dn;
     }
   }
-  // N CREDIT.  Anchors on one diagonal d*, the written-down path P0 the pure diagonal, and a band of +-G around it that is
-  // already proven.  Every N column under P0's rows G .. R-G is crossed by EVERY path P of that band that starts in row 0:
-  // by a row within G of P0's (cost >= kap of that depth range) or inside a column gap (GEP >= kap).  Take that much
-  // (credit = the sum of kap over those columns) out of both sides: P's events must fit into y = B0 - credit, where an
+  // N CREDIT.  A band of [a_lo - G, a_hi + G] is already proven, the written-down path P0 lies in it.  Every N column c
+  // with a_hi + G <= c <= R + a_lo - G (window columns) is crossed by EVERY path P of that band that starts in row 0: by a row
+  // r = c - d for a diagonal d of the band (cost >= kap of that depth range) or inside a column gap (GEP >= kap).  Take that
+  // much (credit = the sum of kap over those columns) out of both sides: P's events must fit into y = B0 - credit, where an
   // event costs, net of the credit it may consume, at least GOP -- a column gap GOP + GEP per column that is NOT one
   // of those, skipped rows GOP + (GEP + min M) each (they cross nothing), a late start of r rows GOP + GEP (r + 1) +
-  // r min M (it misses at most r of the columns).  P runs through d* somewhere (the pigeonhole), so it never is further
-  // from d* than its column gaps add up to, or its skipped rows:
-  //   y < GOP      no event at all: P is P0.
+  // r min M (it misses at most r of the columns).  P runs through an anchor somewhere (the pigeonhole), so it never is
+  // further from the anchors than its column gaps add up to, or its skipped rows:
+  //   y < GOP      no event at all: a pure diagonal through an anchor.
   //   j gaps       hold m_j = (y - j GOP) / GEP columns without credit between them, and each of them at most H(m_j) credited
   //                ones, H(m) = the most credited columns in a stretch with at most m others (bx_ones_span): together no
   //                more than m_j + min(all credited, j H(m_j)) columns;
   //   skipped rows number at most (y - GOP) / (GEP + min M).
   // The band this gives is proven in turn, so the argument can be repeated with it (more columns count, y shrinks).
   // (Against mt311, every tenth column an ambiguity code, B0 is mostly such columns: without the credit the band would
-  // be 20-30 diagonals wide.)
-  if (g_dn + g_up > 0 && (PATHS == 1 || d_first == d_last) && an.a_lo == an.a_hi) {
+  // be 20-30 diagonals wide.)  sc sits on d_first: bit q of its planes is window column d_first + q.
+  if (g_dn + g_up > 0) {
     int G = b0x < GOP + GEP ? 0 : (b0x - GOP) / GEP;
     const int gt = g_dn > g_up ? g_dn : g_up;
     if (gt <= BX_GMAX && gt < G) G = gt;
     for (int pass = 0; pass < 2 && G > 0; pass++) {
+      const int q_lo = an.a_hi + G - d_first, q_hi = R + an.a_lo - G - d_first;      // (0 <= q_lo, q_hi <= R)
       int credit = 0, k = 0;
       uint64_t cm[NW];
 #pragma unroll
@@ -667,8 +668,11 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
         while (w) {
           const int t = df_ctz(w), q = j * 64 + t;
           w &= w - 1;
-          if (q < G || q > R - G) continue;
-          const int kv = T.loss[BX_LOSS_KAP + (st * 31 + sm_depth(q - G, len2)) * 31 + sm_depth(q + G, len2)];
+          if (q < q_lo || q > q_hi) continue;
+          int r_lo = q + d_first - an.a_hi - G, r_hi = q + d_first - an.a_lo + G;
+          if (r_lo < 0) r_lo = 0;
+          if (r_hi > R) r_hi = R;
+          const int kv = T.loss[BX_LOSS_KAP + (st * 31 + sm_depth(r_lo, len2)) * 31 + sm_depth(r_hi, len2)];
           if (kv <= 0) continue;
           credit += kv;
           k++;
