@@ -210,20 +210,61 @@ int mia_hip_consensus(mia_hip_ctx *ctx, int cons_code, char *out, int64_t out_ca
  * after the four separate calls.
  * SHARDED (a communicator attached by mia_hip_comm_init, the read store split in contiguous fsdb blocks, this context's
  * first read announced by mia_hip_set_read_base): the call also does the exchanges between the GPUs, on its own stream --
- * one all-gather of seven integers per rank before the cull (score sums, AlnSeq records, links), the link exchange if any
- * rank has links, all-reduce(sum) of the tallies, all-reduce(max) of ref->gaps with the ranks' insert-event counts riding
- * on it, all-gather of the insert events -- and every rank returns the same consensus.  Every rank must call it. */
+ * one all-gather of eight integers per rank before the cull (score sums, AlnSeq records, links, reads still waiting for
+ * the exact kernel), the link exchange if any rank has links, all-reduce(sum) of the tallies, all-reduce(max) of ref->gaps
+ * with the ranks' insert-event counts riding on it, all-gather of the insert events -- and every rank returns the same
+ * consensus.  Every rank must call it.  The host waits as often as without a communicator (twice); a rank that fails
+ * calls the transport's abort so that the others return an error too. */
 int mia_hip_iterate(mia_hip_ctx *ctx, const char *new_ref, int32_t ref_len, int circular, int32_t hard_cut,
                     const double *slope_intercept, int cons_code, char *out, int64_t out_cap, int64_t *out_len);
 
 /* ---- several GPUs: RCCL over xGMI -------------------------------------------
  * One context per GPU (one process or one host thread each).  Rank 0 makes an id, hands the 128 bytes to the others by
  * whatever channel the host program has (a pipe, MPI, a file, an in-process variable), and every rank calls
- * mia_hip_comm_init -- together, as ncclCommInitRank wants.  librccl is opened at that moment (dlopen), not before. */
+ * mia_hip_comm_init -- together, as ncclCommInitRank wants.  librccl is opened at that moment (dlopen), not before.
+ * The reference has no counterpart (src/ is single-threaded); the contract is SURVEY.md section 8(e). */
 #define MIA_HIP_COMM_ID_BYTES 128
 int mia_hip_comm_unique_id(void *id128);
 int mia_hip_comm_init(mia_hip_ctx *ctx, const void *id128, int32_t n_ranks, int32_t rank);
 int mia_hip_comm_destroy(mia_hip_ctx *ctx);
+
+/* The exchanges of a sharded mia_hip_iterate go through a table of two collectives and nothing else; mia_hip_comm_init
+ * attaches the RCCL one.  A host program with a transport of its own (MPI, a test harness) attaches its table with
+ * mia_hip_comm_attach.  All buffers are DEVICE pointers of the context's GPU, `hip_stream` is the context's hipStream_t:
+ * the collective is ordered behind the work queued there and the work queued afterwards is ordered behind it (it may
+ * wait for the stream on the host).  Every function returns 0 or a negative MIA_HIP_ERR_* code.
+ *   all_gather      every rank contributes `bytes` bytes; d_recv gets n_ranks * bytes in rank order
+ *   all_reduce_i32  in place over `count` int32, op = MIA_HIP_OP_SUM / MIA_HIP_OP_MAX
+ *   query           what the transport itself says about the group (may be NULL)
+ *   abort           called when this rank fails inside a sharded call, so that the peers' collectives return with an
+ *                   error instead of waiting for a rank that will not come (may be NULL: then they wait)
+ *   destroy         releases `user` (mia_hip_comm_destroy / mia_hip_destroy; may be NULL)
+ *   error           text of the last failure (may be NULL) */
+#define MIA_HIP_OP_SUM 0
+#define MIA_HIP_OP_MAX 1
+typedef struct mia_hip_collectives {
+  void *user;
+  int32_t n_ranks, rank;
+  int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes, void *hip_stream);
+  int (*all_reduce_i32)(void *user, void *d_buf, size_t count, int op, void *hip_stream);
+  int (*query)(void *user, int32_t *n_ranks, int32_t *rank);
+  void (*abort)(void *user);
+  void (*destroy)(void *user);
+  const char *(*error)(void *user);
+  const char *name;
+} mia_hip_collectives;
+int mia_hip_comm_attach(mia_hip_ctx *ctx, const mia_hip_collectives *table);
+/* ranks and rank as the attached transport reports them (RCCL: ncclCommCount / ncclCommUserRank), its name
+ * ("rccl", "loopback", the caller's); n_ranks = 1, transport = "none" without a communicator */
+int mia_hip_comm_info(mia_hip_ctx *ctx, int32_t *n_ranks, int32_t *rank, const char **transport);
+
+/* In-process loopback: n_ranks contexts of ONE process, one host thread each, on one GPU (or GPUs with peer access).
+ * The ranks meet at a host barrier and copy each other's device buffers.  RCCL refuses two ranks on one device; this is
+ * how the sharded path runs (and is tested) on a single GPU, and what `mia_hip -g 0,0` uses.  A rank that does not
+ * arrive within MIA_HIP_LOOPBACK_TIMEOUT seconds (default 120) fails the collective on every rank. */
+int mia_hip_loopback_create(int32_t n_ranks, void **group);
+int mia_hip_loopback_table(void *group, int32_t rank, mia_hip_collectives *table);
+void mia_hip_loopback_destroy(void *group); /* after every context of the group dropped its table */
 
 /* ---- adapter trimming ---------------------------------------------------- */
 

@@ -86,6 +86,12 @@ def _load():
     lib.mia_hip_comm_unique_id.argtypes = [vp]
     lib.mia_hip_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32]
     lib.mia_hip_comm_destroy.argtypes = [vp]
+    lib.mia_hip_comm_attach.argtypes = [vp, vp]
+    lib.mia_hip_comm_info.argtypes = [vp, P(C.c_int32), P(C.c_int32), P(C.c_char_p)]
+    lib.mia_hip_loopback_create.argtypes = [C.c_int32, P(vp)]
+    lib.mia_hip_loopback_table.argtypes = [vp, C.c_int32, vp]
+    lib.mia_hip_loopback_destroy.argtypes = [vp]
+    lib.mia_hip_loopback_destroy.restype = None
     lib.mia_hip_measure_peaks.argtypes = [vp, C.c_int64, P(C.c_double), P(C.c_double)]
     return lib
 
@@ -109,7 +115,8 @@ def exported_symbols():
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
-            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask", "mia_hip_comm_unique_id", "mia_hip_comm_init", "mia_hip_comm_destroy"]
+            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask", "mia_hip_comm_unique_id", "mia_hip_comm_init", "mia_hip_comm_destroy",
+            "mia_hip_comm_attach", "mia_hip_comm_info", "mia_hip_loopback_create", "mia_hip_loopback_table", "mia_hip_loopback_destroy"]
 
 
 def _ptr(a):
@@ -148,6 +155,35 @@ def read_pssm(path):
         p[d, 4, :] = -10
         k += 6
     return p
+
+
+class Collectives(C.Structure):
+    """mia_hip_collectives (include/mia_hip.h): the table of collectives a sharded iterate() speaks through"""
+    _fields_ = [("user", C.c_void_p), ("n_ranks", C.c_int32), ("rank", C.c_int32),
+                ("all_gather", C.c_void_p), ("all_reduce_i32", C.c_void_p), ("query", C.c_void_p), ("abort", C.c_void_p),
+                ("destroy", C.c_void_p), ("error", C.c_void_p), ("name", C.c_char_p)]
+
+
+class LoopbackGroup:
+    """mia_hip_loopback_*: n_ranks contexts of this process, one host thread each, exchange through host barriers and
+    device copies -- the sharded path on a single GPU (RCCL refuses two ranks on one device)"""
+
+    def __init__(self, n_ranks):
+        self._g = C.c_void_p()
+        if lib().mia_hip_loopback_create(n_ranks, C.byref(self._g)) != 0:
+            raise MiaHipError("mia_hip_loopback_create failed")
+        self.n_ranks = n_ranks
+
+    def attach(self, hip, rank):
+        t = Collectives()
+        if lib().mia_hip_loopback_table(self._g, rank, C.byref(t)) != 0:
+            raise MiaHipError("mia_hip_loopback_table failed")
+        hip.comm_attach(t)
+
+    def close(self):
+        if self._g:
+            lib().mia_hip_loopback_destroy(self._g)
+            self._g = C.c_void_p()
 
 
 def comm_unique_id():
@@ -436,6 +472,16 @@ class MiaHip:
         of rank 0.  iterate() then does the exchanges of a sharded run itself."""
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._chk(self._l.mia_hip_comm_init(self._h, buf, n_ranks, rank))
+
+    def comm_attach(self, table):
+        """attach a caller-made table of collectives (Collectives); the library copies it"""
+        self._chk(self._l.mia_hip_comm_attach(self._h, C.byref(table)))
+
+    def comm_info(self):
+        """(ranks, rank, transport) as the attached transport itself reports them"""
+        n, r, t = C.c_int32(), C.c_int32(), C.c_char_p()
+        self._chk(self._l.mia_hip_comm_info(self._h, C.byref(n), C.byref(r), C.byref(t)))
+        return n.value, r.value, (t.value or b"").decode()
 
     def comm_destroy(self):
         self._chk(self._l.mia_hip_comm_destroy(self._h))

@@ -99,8 +99,13 @@ __global__ void k_scan_apply(ReadSet rs, int32_t L, const int64_t* partial, int6
   }
 }
 
-__global__ void k_score_sums_init(unsigned long long* sums) {   // the neutral element of k_score_sums' five accumulators
-  if (threadIdx.x == 0) { sums[0] = 0; sums[1] = 0; sums[2] = 0; sums[3] = (unsigned long long)(long long)INT32_MAX; sums[4] = (unsigned long long)(long long)INT32_MIN; sums[5] = 0; sums[6] = 0; }
+// the neutral element of k_score_sums' accumulators; word 7 = reads still waiting for the exact kernel (a sharded
+// iteration gathers these words before the host has looked at that counter), 0 without one
+__global__ void k_score_sums_init(unsigned long long* sums, const int32_t* wide_count) {
+  if (threadIdx.x == 0) {
+    sums[0] = 0; sums[1] = 0; sums[2] = 0; sums[3] = (unsigned long long)(long long)INT32_MAX; sums[4] = (unsigned long long)(long long)INT32_MIN; sums[5] = 0; sums[6] = 0;
+    sums[7] = wide_count ? (unsigned long long)*wide_count : 0;
+  }
 }
 
 // ---- first pass of find_fsdb_score_cut (src/fsdb.c:269-383) on the device: the sums of length and score over the reads

@@ -1,8 +1,6 @@
 // mia_hip.hip -- libmia_hip.so: C ABI (include/mia_hip.h) over the gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>      // types only: librccl is opened at run time by mia_hip_comm_init (single-GPU runs never load it)
-#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -13,6 +11,7 @@
 #include <vector>
 
 #include "../../include/mia_hip.h"
+#include "mia_comm.h"
 #include "mia_consensus_kernels.h"
 #include "mia_kernels.h"
 #include "bandx_kernels.h"
@@ -164,9 +163,12 @@ struct mia_hip_ctx {
   int32_t* d_cons_pos = nullptr; int64_t cons_pos_cap = 0;
   unsigned char* h_pin2 = nullptr; size_t pin2_bytes = 0;   // results of an iteration (header + consensus string)
   int64_t iter_fallbacks = 0;
-  // sharded runs: one context per GPU, RCCL over xGMI on the context's own stream (mia_hip_comm_init)
-  ncclComm_t comm = nullptr; int comm_ranks = 1, comm_rank = 0;
-  unsigned long long* d_gather = nullptr;   // [7 * ranks] score sums, record and link counts of every rank
+  // sharded runs: one context per GPU; the exchanges go through a table of collectives (RCCL over xGMI from
+  // mia_hip_comm_init, or whatever mia_hip_comm_attach was given), on the context's own stream
+  mia_hip_collectives coll{}; bool comm = false; int comm_ranks = 1, comm_rank = 0;
+  unsigned long long* d_gather = nullptr;   // [PRE_WORDS * ranks] score sums, record, link and exact-kernel counts of every rank
+  std::vector<int64_t> h_gather;            // ... on the host, once the alignment's one wait is over
+  int64_t ev_pad = 0;                       // insert events per rank the event all-gather is sized for (0: not known yet)
   int64_t* d_lstage = nullptr; int64_t lstage_cap = 0;       // links / insert events of all ranks, padded to the longest
   int64_t* d_lmine = nullptr; int64_t lmine_cap = 0;
   int64_t* d_lall = nullptr; int64_t lall_cap = 0;
@@ -661,6 +663,8 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
 }
 
 static int align_all(mia_hip_ctx* ctx);
+static int comm_pre_cull_enqueue(mia_hip_ctx* ctx, const int32_t* d_wide_count);
+static bool comm_pre_cull_collect(mia_hip_ctx* ctx);
 
 extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular) {
   if (!ctx || !new_ref || ref_len <= 0) return MIA_HIP_ERR_ARG;
@@ -954,6 +958,8 @@ static int align_all(mia_hip_ctx* ctx) {
     int32_t* hb;
     if (ctx->h_pin) hb = reinterpret_cast<int32_t*>(ctx->h_pin);
     else { pageable.resize(CN); hb = pageable.data(); }
+    const bool pre_cull = ctx->in_iterate && ctx->comm;
+    if (pre_cull) { if (int rcp = comm_pre_cull_enqueue(ctx, d_wide_count)) return rcp; }
     HIPCHK(hipMemcpyAsync(hb, ctx->d_ctrl + C0, (size_t)CN * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int32_t* h_hdr = hb + (CTRL_HDR - C0);
@@ -973,6 +979,13 @@ static int align_all(mia_hip_ctx* ctx) {
     if (use_plain && ctx->use_quad) ctx->plain_retried += h_hdr[PH_RETRIED_PLAIN];
     const int32_t n_wide = hb[0];
     if (n_wide > 0) { if (int rcw = run_wide(ctx, ref, n_wide)) return rcw; }
+    if (pre_cull && comm_pre_cull_collect(ctx)) {
+      // some rank had reads for the exact kernel: its sums were taken before their scores were final.  Every rank saw the
+      // same eight words per rank, so every rank comes here and the all-gather is repeated with the final numbers.
+      if (int rcp = comm_pre_cull_enqueue(ctx, nullptr)) return rcp;
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      (void)comm_pre_cull_collect(ctx);
+    }
     ctx->aligned = true; ctx->culled = false; ctx->tallied = false; ctx->pre_cull_valid = false;
     return MIA_HIP_OK;
   }
@@ -1420,7 +1433,7 @@ extern "C" int mia_hip_score_sums(mia_hip_ctx* ctx, int64_t* sums5) {
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->d_sums && dev_alloc(ctx, &ctx->d_sums, 8)) return MIA_HIP_ERR_NOMEM;
   ctx->pre_cull_valid = false;
-  hipLaunchKernelGGL(k_score_sums_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_sums);
+  hipLaunchKernelGGL(k_score_sums_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_sums, (const int32_t*)nullptr);
   const int64_t n = ctx->rs.n;
   if (n > 0) {
     int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus);   // few blocks: five same-address atomics per block
@@ -1628,13 +1641,18 @@ extern "C" int mia_hip_get_tally(mia_hip_ctx* ctx, int32_t* tally, int32_t* gaps
 extern "C" int mia_hip_set_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_t* tally, const int32_t* gaps) {
   if (!ctx || ref_len <= 0 || !tally) return MIA_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
+  if (ref_len != ctx->L) {
+    // tallies of another reference than the one the reads were aligned to: the alignment state (windows, wrap, cull marks)
+    // no longer belongs to them -- whatever needs it must realign first
+    ctx->aligned = false; ctx->culled = false; ctx->have_ref = false; ctx->links_applied = false;
+  }
   ctx->L = ref_len;
   int rc = ensure_tally(ctx);
   if (rc) return rc;
   const int Lp = ctx->tb.Lp;
   HIPCHK(hipMemcpyAsync(ctx->tb.tally, tally, (size_t)TALLY_WORDS * Lp * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->tb.gaps, 0, ((size_t)Lp + 256) * 4, ctx->stream));      // gaps and the ranks' event-count slots behind them
   if (gaps) HIPCHK(hipMemcpyAsync(ctx->tb.gaps, gaps, (size_t)Lp * 4, hipMemcpyHostToDevice, ctx->stream));
-  else HIPCHK(hipMemsetAsync(ctx->tb.gaps, 0, (size_t)Lp * 4, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->tb.n_events, 0, 4, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->n_events_host = 0;
@@ -1727,90 +1745,75 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   return MIA_HIP_OK;
 }
 
-// ---- RCCL (reads shard, tallies all-reduce) -----------------------------------------------
-// librccl is opened on first use; its entry points are looked up by name so that libmia_hip.so has no link-time dependency
-// on it (a single-GPU run never touches it).
-struct RcclApi {
-  void* lib = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
-};
-static RcclApi* rccl_api(std::string* err) {
-  static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* nm : names) { api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (api.lib) break; }
-    if (api.lib) {
-      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
-      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
-      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
-      api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
-      api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
-      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-    }
-  }
-  if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.AllGather) {
-    if (err) *err = "librccl.so.1 (RCCL) could not be opened";
-    return nullptr;
-  }
-  return &api;
-}
-#define NCCLCHK(call)                                                                                  \
+// ---- several GPUs (reads shard, tallies all-reduce) ------------------------------------------
+// The exchanges of a sharded iteration go through ctx->coll, a table of two collectives (include/mia_hip.h); the
+// transports themselves -- RCCL over xGMI, the in-process loopback -- live in mia_comm.hip.
+constexpr int PRE_WORDS = 8;         // per rank before the cull: five score sums, AlnSeq records, links, reads waiting for the exact kernel
+#define COLLCHK(call)                                                                                  \
   do {                                                                                                 \
-    ncclResult_t r_ = (call);                                                                          \
-    if (r_ != ncclSuccess) {                                                                           \
-      ctx->err = std::string(#call) + ": " + (rccl_api(nullptr) && rccl_api(nullptr)->GetErrorString ? rccl_api(nullptr)->GetErrorString(r_) : "RCCL error"); \
-      return MIA_HIP_ERR_DEVICE;                                                                       \
+    const int r_ = (call);                                                                             \
+    if (r_ != MIA_HIP_OK) {                                                                            \
+      const char* t_ = ctx->coll.error ? ctx->coll.error(ctx->coll.user) : nullptr;                    \
+      ctx->err = std::string(#call) + ": " + (t_ && *t_ ? t_ : "collective failed");                   \
+      return r_;                                                                                       \
     }                                                                                                  \
   } while (0)
 
-extern "C" int mia_hip_comm_unique_id(void* id128) {
-  if (!id128) return MIA_HIP_ERR_ARG;
-  RcclApi* api = rccl_api(nullptr);
-  if (!api) return MIA_HIP_ERR_DEVICE;
-  ncclUniqueId id;
-  if (api->GetUniqueId(&id) != ncclSuccess) return MIA_HIP_ERR_DEVICE;
-  memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+static int comm_attach_table(mia_hip_ctx* ctx, const mia_hip_collectives& t) {
+  if (dev_alloc(ctx, &ctx->d_gather, (size_t)PRE_WORDS * t.n_ranks)) return MIA_HIP_ERR_NOMEM;
+  ctx->coll = t;
+  ctx->comm = true; ctx->comm_ranks = t.n_ranks; ctx->comm_rank = t.rank;
+  ctx->h_gather.assign((size_t)PRE_WORDS * t.n_ranks, 0);
+  ctx->ev_pad = 0;
   return MIA_HIP_OK;
 }
 
 extern "C" int mia_hip_comm_init(mia_hip_ctx* ctx, const void* id128, int32_t n_ranks, int32_t rank) {
-  if (!ctx || !id128 || n_ranks < 1 || rank < 0 || rank >= n_ranks) return MIA_HIP_ERR_ARG;
+  if (!ctx || !id128 || n_ranks < 1 || n_ranks > 256 || rank < 0 || rank >= n_ranks) return MIA_HIP_ERR_ARG;
   if (ctx->comm) { ctx->err = "this context already has a communicator"; return MIA_HIP_ERR_STATE; }
-  RcclApi* api = rccl_api(&ctx->err);
-  if (!api) return MIA_HIP_ERR_DEVICE;
   HIPCHK(hipSetDevice(ctx->device));
-  ncclUniqueId id;
-  memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
-  NCCLCHK(api->CommInitRank(&ctx->comm, n_ranks, id, rank));
-  ctx->comm_ranks = n_ranks; ctx->comm_rank = rank;
-  if (dev_alloc(ctx, &ctx->d_gather, (size_t)7 * n_ranks)) return MIA_HIP_ERR_NOMEM;
+  mia_hip_collectives t;
+  if (int rc = mia_comm_rccl_table(id128, n_ranks, rank, &t, &ctx->err)) return rc;
+  if (int rc = comm_attach_table(ctx, t)) { if (t.destroy) t.destroy(t.user); return rc; }     // (no half-made communicator stays behind)
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_comm_attach(mia_hip_ctx* ctx, const mia_hip_collectives* table) {
+  if (!ctx || !table || !table->all_gather || !table->all_reduce_i32 || table->n_ranks < 1 || table->n_ranks > 256 || table->rank < 0 ||
+      table->rank >= table->n_ranks)
+    return MIA_HIP_ERR_ARG;
+  if (ctx->comm) { ctx->err = "this context already has a communicator"; return MIA_HIP_ERR_STATE; }
+  HIPCHK(hipSetDevice(ctx->device));
+  return comm_attach_table(ctx, *table);
+}
+
+extern "C" int mia_hip_comm_info(mia_hip_ctx* ctx, int32_t* n_ranks, int32_t* rank, const char** transport) {
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  int32_t nr = 1, rk = 0;
+  if (ctx->comm) {
+    nr = ctx->comm_ranks; rk = ctx->comm_rank;
+    if (ctx->coll.query) { if (int rc = ctx->coll.query(ctx->coll.user, &nr, &rk)) { ctx->err = "the transport could not say how many ranks it has"; return rc; } }
+  }
+  if (n_ranks) *n_ranks = nr;
+  if (rank) *rank = rk;
+  if (transport) *transport = ctx->comm ? (ctx->coll.name ? ctx->coll.name : "caller") : "none";
   return MIA_HIP_OK;
 }
 
 extern "C" int mia_hip_comm_destroy(mia_hip_ctx* ctx) {
   if (!ctx) return MIA_HIP_ERR_ARG;
   if (!ctx->comm) return MIA_HIP_OK;
-  RcclApi* api = rccl_api(&ctx->err);
-  if (!api) return MIA_HIP_ERR_DEVICE;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)api->CommDestroy(ctx->comm);
-  ctx->comm = nullptr; ctx->comm_ranks = 1; ctx->comm_rank = 0;
+  if (ctx->coll.destroy) ctx->coll.destroy(ctx->coll.user);
+  ctx->coll = mia_hip_collectives{};
+  ctx->comm = false; ctx->comm_ranks = 1; ctx->comm_rank = 0;
   return MIA_HIP_OK;
 }
 
 // all-gather of ragged 8-byte records (links: 4 words each; insert events: 1): every rank contributes counts[rank] * words
 // words from `mine`; the concatenation in rank order lands in ctx->d_lall.  counts are known on every rank.
 static int comm_gather_ragged(mia_hip_ctx* ctx, const int64_t* mine, const std::vector<int64_t>& counts, int words, int64_t* total_out) {
-  RcclApi* api = rccl_api(&ctx->err);
-  if (!api) return MIA_HIP_ERR_DEVICE;
   const int W = ctx->comm_ranks;
   int64_t mx = 0, total = 0;
   for (int r = 0; r < W; r++) { mx = std::max(mx, counts[(size_t)r]); total += counts[(size_t)r]; }
@@ -1823,7 +1826,7 @@ static int comm_gather_ragged(mia_hip_ctx* ctx, const int64_t* mine, const std::
   HIPCHK(hipMemsetAsync(ctx->d_lmine, 0, (size_t)pad * 8, ctx->stream));
   const int64_t nm = counts[(size_t)ctx->comm_rank] * words;
   if (nm > 0) HIPCHK(hipMemcpyAsync(ctx->d_lmine, mine, (size_t)nm * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  NCCLCHK(api->AllGather(ctx->d_lmine, ctx->d_lstage, (size_t)pad, ncclInt64, ctx->comm, ctx->stream));
+  COLLCHK(ctx->coll.all_gather(ctx->coll.user, ctx->d_lmine, ctx->d_lstage, (size_t)pad * 8, ctx->stream));
   int64_t o = 0;
   for (int r = 0; r < W; r++) {
     const int64_t c = counts[(size_t)r] * words;
@@ -1833,18 +1836,81 @@ static int comm_gather_ragged(mia_hip_ctx* ctx, const int64_t* mine, const std::
   return MIA_HIP_OK;
 }
 
+// What the cull needs from the other ranks -- their score sums (find_fsdb_score_cut's first pass), how many AlnSeq records
+// precede this rank's, how many links each cull will emit, and whether some rank still has reads for the exact kernel --
+// in ONE small all-gather, queued BEHIND the alignment kernels and in front of the alignment's one host wait: a sharded
+// iteration waits for the host as often as a single context does.
+static int comm_pre_cull_enqueue(mia_hip_ctx* ctx, const int32_t* d_wide_count) {
+  const int64_t n = ctx->rs.n;
+  const int W = ctx->comm_ranks;
+  if (!ctx->d_sums && dev_alloc(ctx, &ctx->d_sums, 8)) return MIA_HIP_ERR_NOMEM;
+  hipLaunchKernelGGL(k_score_sums_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_sums, d_wide_count);
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus);
+  hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums, ctx->L, ctx->d_back_slot, ctx->d_front_slot0);
+  HIPCHK(hipGetLastError());
+  COLLCHK(ctx->coll.all_gather(ctx->coll.user, ctx->d_sums, ctx->d_gather, (size_t)PRE_WORDS * 8, ctx->stream));
+  int64_t* stage = ctx->h_pin ? reinterpret_cast<int64_t*>(ctx->h_pin + (40 << 10)) : ctx->h_gather.data();
+  HIPCHK(hipMemcpyAsync(stage, ctx->d_gather, (size_t)PRE_WORDS * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+  return MIA_HIP_OK;
+}
+// ... and once the stream has been waited for
+static bool comm_pre_cull_collect(mia_hip_ctx* ctx) {
+  const int W = ctx->comm_ranks;
+  if (ctx->h_pin) memcpy(ctx->h_gather.data(), ctx->h_pin + (40 << 10), (size_t)PRE_WORDS * W * 8);
+  bool any_wide = false;
+  for (int r = 0; r < W; r++) any_wide = any_wide || ctx->h_gather[(size_t)PRE_WORDS * r + 7] != 0;
+  return any_wide;
+}
+
 __global__ void k_put_i32(int32_t* dst, const int32_t* src, int32_t clamp) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = min(*src, clamp); }
+
+// The insert events of all ranks, gathered in blocks of `pad` (stage[r * pad + i], i < counts[r]), packed into one list in
+// rank order; *n_out = their number.  counts[] are the W slots behind ref->gaps that rode on its max-reduce.  If some rank
+// had more than `pad` events nothing is touched and bit 8 of the tally flags says so (the host repeats the exchange with
+// the counts in hand).  One workgroup per rank in y.
+__global__ __launch_bounds__(256) void k_events_compact(const uint64_t* __restrict__ stage, int64_t pad, const int32_t* __restrict__ counts, int W,
+                                                          uint64_t* __restrict__ out, int32_t cap, int32_t* n_out, uint32_t* flags) {
+  const int r = blockIdx.y;
+  int64_t before = 0, total = 0;
+  bool over = false;
+  for (int k = 0; k < W; k++) {
+    const int64_t c = counts[k];
+    over = over || c > pad;
+    if (k < r) before += c;
+    total += c;
+  }
+  over = over || total > cap;
+  if (over) { if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flags, 8u); return; }
+  const int64_t mine = counts[r];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mine; i += (int64_t)gridDim.x * 256) out[before + i] = stage[(int64_t)r * pad + i];
+  if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0) *n_out = (int32_t)total;
+}
 
 // ---- one whole iteration -------------------------------------------------------------------------
 // reiterate_assembly + pop_smp_from_FSDB + cull_maln_from_fsdb + consensus_assembly_string (src/mia_main.c:931-963) as
 // one call: the same kernels as mia_hip_realign / _cull / _tally / _consensus, but what those entry points hand back to
 // the host between the kernels -- the planner's bin sizes, the cut line, the insert-event count, five result arrays --
 // stays on the device.  The host waits twice: once behind the alignment (reads that need the exact scalar kernel must be
-// known before anything is culled) and once for the consensus string.
+// known before anything is culled) and once for the consensus string -- with or without a communicator.
+static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular, int32_t hard_cut, const double* slope_intercept,
+                        int cons_code, char* out, int64_t out_cap, int64_t* out_len);
+
 extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular, int32_t hard_cut, const double* slope_intercept,
                                int cons_code, char* out, int64_t out_cap, int64_t* out_len) {
-  if (!ctx || !new_ref || ref_len <= 0 || !out || out_cap < 1) return MIA_HIP_ERR_ARG;
-  if (!ctx->have_pssm || !ctx->d_packed) { ctx->err = "set_pssm and upload_reads must precede iterate"; return MIA_HIP_ERR_STATE; }
+  if (!ctx) return MIA_HIP_ERR_ARG;
+  int rc;
+  if (!new_ref || ref_len <= 0 || !out || out_cap < 1) { ctx->err = "iterate: bad argument"; rc = MIA_HIP_ERR_ARG; }
+  else if (!ctx->have_pssm || !ctx->d_packed) { ctx->err = "set_pssm and upload_reads must precede iterate"; rc = MIA_HIP_ERR_STATE; }
+  else rc = iterate_body(ctx, new_ref, ref_len, circular, hard_cut, slope_intercept, cons_code, out, out_cap, out_len);
+  ctx->in_iterate = false; ctx->deferred = false;
+  // a rank that fails here will not come to the collectives the others are about to enter: tell the transport, so that
+  // they return an error as well instead of waiting for ever
+  if (rc != MIA_HIP_OK && ctx->comm && ctx->coll.abort) ctx->coll.abort(ctx->coll.user);
+  return rc;
+}
+
+static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular, int32_t hard_cut, const double* slope_intercept,
+                        int cons_code, char* out, int64_t out_cap, int64_t* out_len) {
   HIPCHK(hipSetDevice(ctx->device));
   // -- the new reference: ASCII up, codes and wrap made on the device (make_ref_upper / add_ref_wrap, src/mia.c:642-689)
   const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl, total = wrap + 64;
@@ -1884,36 +1950,23 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   auto checkpoint = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[mia_hip_iterate] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
   checkpoint("reference");
   ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true; ctx->explicit_win = 0;
-  // -- re-alignment (one wait, at its end)
-  struct IterScope { mia_hip_ctx* c; ~IterScope() { c->in_iterate = false; c->deferred = false; } } iter_scope{ctx};
+  const int64_t n = ctx->rs.n;
+  const int W = ctx->comm_ranks;
+  if (ctx->comm && n == 0) { ctx->err = "iterate: every rank of a sharded run needs reads"; return MIA_HIP_ERR_ARG; }
+  if (ctx->comm && W > 256) { ctx->err = "iterate: more than 256 ranks"; return MIA_HIP_ERR_ARG; }
+  // -- re-alignment (one wait, at its end; a sharded run's pre-cull all-gather rides in front of that wait)
   ctx->in_iterate = true;
   ctx->deferred = true;
   const int rca = align_all(ctx);
   ctx->deferred = false;
   if (rca) return rca;
   checkpoint("realign");
-  const int64_t n = ctx->rs.n;
-  // -- sharded run: what the cull needs from the other ranks -- their score sums (find_fsdb_score_cut's first pass), how
-  //    many AlnSeq records precede this rank's, how many links each cull will emit -- in ONE small all-gather
-  RcclApi* api = ctx->comm ? rccl_api(&ctx->err) : nullptr;
-  if (ctx->comm && !api) return MIA_HIP_ERR_DEVICE;
-  const int W = ctx->comm_ranks;
   int64_t slot_base = 0, g_sums[5] = {0, 0, 0, 0, 0};
   std::vector<int64_t> link_counts((size_t)W, 0), n_of((size_t)W, n);
   if (ctx->comm) {
-    if (n == 0) { ctx->err = "iterate: every rank of a sharded run needs reads"; return MIA_HIP_ERR_ARG; }
-    if (!ctx->d_sums && dev_alloc(ctx, &ctx->d_sums, 8)) return MIA_HIP_ERR_NOMEM;
-    hipLaunchKernelGGL(k_score_sums_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_sums);
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus);
-    hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums, ctx->L, ctx->d_back_slot, ctx->d_front_slot0);
-    HIPCHK(hipGetLastError());
-    NCCLCHK(api->AllGather(ctx->d_sums, ctx->d_gather, 7, ncclUint64, ctx->comm, ctx->stream));
-    std::vector<int64_t> g((size_t)7 * W);
-    HIPCHK(hipMemcpyAsync(g.data(), ctx->d_gather, (size_t)7 * W * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     g_sums[3] = INT32_MAX; g_sums[4] = INT32_MIN;
     for (int r = 0; r < W; r++) {
-      const int64_t* q = g.data() + (size_t)7 * r;
+      const int64_t* q = ctx->h_gather.data() + (size_t)PRE_WORDS * r;
       g_sums[0] += q[0]; g_sums[1] += q[1]; g_sums[2] += q[2];
       g_sums[3] = std::min(g_sums[3], q[3]); g_sums[4] = std::max(g_sums[4], q[4]);
       if (r < ctx->comm_rank) slot_base += q[5];
@@ -1940,7 +1993,7 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   } else {
     // the same over the reads of ALL ranks in fsdb order (= rank order): scores and lengths gathered, the regression on
     // every rank's host (identical inputs, identical arithmetic)
-    int32_t* d_nl = nullptr;                               // {n, score..., len...} of this rank, padded to the longest
+    int32_t* d_nl = nullptr;                               // {score..., len...} of this rank, padded to the longest
     ScopeFree sf; sf.watch((void**)&d_nl);
     std::vector<int64_t> cnt1((size_t)W, 1);
     int64_t tot = 0;
@@ -1961,7 +2014,7 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     HIPCHK(hipMemsetAsync(d_nl, 0, (size_t)nmax * 2 * 4, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_nl, ctx->d_score, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(d_nl + nmax, ctx->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    NCCLCHK(api->AllGather(d_nl, ctx->d_scores_all, (size_t)nmax * 2, ncclInt32, ctx->comm, ctx->stream));
+    COLLCHK(ctx->coll.all_gather(ctx->coll.user, d_nl, ctx->d_scores_all, (size_t)nmax * 2 * 4, ctx->stream));
     std::vector<int32_t> all((size_t)W * nmax * 2), score((size_t)ntot), lens((size_t)ntot);
     HIPCHK(hipMemcpyAsync(all.data(), ctx->d_scores_all, all.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1981,37 +2034,45 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     int64_t any = 0;
     for (int r = 0; r < W; r++) any += link_counts[(size_t)r];
     if (any > 0) {
-      int64_t* dl = nullptr; int64_t nl = 0, total = 0;
+      int64_t* dl = nullptr; int64_t nl = 0, total_l = 0;
       if (int rcl = mia_hip_links(ctx, &dl, &nl)) return rcl;
       if (nl != link_counts[(size_t)ctx->comm_rank]) { ctx->err = "iterate: the cull emitted another number of links than the score sweep announced"; return MIA_HIP_ERR_STATE; }
-      if (int rcg = comm_gather_ragged(ctx, dl, link_counts, 4, &total)) return rcg;
-      if (int rcs = mia_hip_set_links(ctx, ctx->d_lall, total)) return rcs;
+      if (int rcg = comm_gather_ragged(ctx, dl, link_counts, 4, &total_l)) return rcg;
+      if (int rcs = mia_hip_set_links(ctx, ctx->d_lall, total_l)) return rcs;
       int32_t *dlen = nullptr, *dact = nullptr; int64_t nn = 0;
       if (int rcl = mia_hip_link_lengths(ctx, &dlen, &dact, &nn)) return rcl;
-      NCCLCHK(api->AllReduce(dlen, dlen, (size_t)nn, ncclInt32, ncclMax, ctx->comm, ctx->stream));
-      NCCLCHK(api->AllReduce(dact, dact, (size_t)nn, ncclInt32, ncclMax, ctx->comm, ctx->stream));
+      COLLCHK(ctx->coll.all_reduce_i32(ctx->coll.user, dlen, (size_t)nn, MIA_HIP_OP_MAX, ctx->stream));
+      COLLCHK(ctx->coll.all_reduce_i32(ctx->coll.user, dact, (size_t)nn, MIA_HIP_OP_MAX, ctx->stream));
       if (int rcf = mia_hip_finish_links(ctx)) return rcf;
     }
   }
   checkpoint("cull");
   if (n == 0) { out[0] = 0; if (out_len) *out_len = 0; return MIA_HIP_OK; }
   // -- tally and consensus, queued back to back
+  if (ctx->comm && ctx->ev_pad > 0) {
+    if (const char* e = getenv("MIA_HIP_EV_PAD")) { const long long v = atoll(e); if (v > 0) ctx->ev_pad = v; }   // (tests: force the overflow path; every rank reads the same value)
+    // the gathered events land in this context's list: room for every rank's block before anything is tallied into it
+    if (int rct = ensure_tally(ctx)) return rct;
+    if (ctx->ev_pad * W > ctx->tb.cap_events) {
+      const int64_t cap = std::min<int64_t>(ctx->ev_pad * W + 4096, (int64_t)1 << 30);
+      if (dev_alloc(ctx, &ctx->tb.events, (size_t)cap)) return MIA_HIP_ERR_NOMEM;
+      ctx->tb.cap_events = (int32_t)cap;
+    }
+  }
   if (int rct = tally_launch(ctx)) return rct;
   checkpoint("tally");
   const int Lp = ctx->tb.Lp;
   ctx->n_events_host = 0;
-  if (ctx->comm) {
-    // integer column tallies add up, ref->gaps is a maximum (src/mia.c:486-504); every rank's insert-event count rides on
-    // the max-reduce in W extra slots behind gaps; then the events themselves are gathered
-    if (W > 256) { ctx->err = "iterate: more than 256 ranks"; return MIA_HIP_ERR_ARG; }
-    hipLaunchKernelGGL(k_put_i32, dim3(1), dim3(1), 0, ctx->stream, ctx->tb.gaps + Lp + ctx->comm_rank, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events);
-    NCCLCHK(api->AllReduce(ctx->tb.tally, ctx->tb.tally, (size_t)TALLY_WORDS * Lp, ncclInt32, ncclSum, ctx->comm, ctx->stream));
-    NCCLCHK(api->AllReduce(ctx->tb.gaps, ctx->tb.gaps, (size_t)Lp + W, ncclInt32, ncclMax, ctx->comm, ctx->stream));
-    std::vector<int32_t> evc((size_t)W);
-    HIPCHK(hipMemcpyAsync(evc.data(), ctx->tb.gaps + Lp, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  int32_t* h_evc = ctx->h_pin ? reinterpret_cast<int32_t*>(ctx->h_pin + (56 << 10)) : nullptr;      // the ranks' event counts, read with the results
+  std::vector<int32_t> evc_pageable;
+  if (ctx->comm && !h_evc) { evc_pageable.resize((size_t)W); h_evc = evc_pageable.data(); }
+  // the events of all ranks with the counts in hand (one more wait for the host): the first sharded iteration, and whenever
+  // a rank had more events than the blocks of the other way were sized for
+  auto exchange_events_counted = [&]() -> int {
+    HIPCHK(hipMemcpyAsync(h_evc, ctx->tb.gaps + Lp, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     std::vector<int64_t> ev_counts((size_t)W);
-    for (int r = 0; r < W; r++) ev_counts[(size_t)r] = evc[(size_t)r];
+    for (int r = 0; r < W; r++) ev_counts[(size_t)r] = h_evc[r];
     int64_t total_ev = 0;
     if (int rcg = comm_gather_ragged(ctx, reinterpret_cast<const int64_t*>(ctx->tb.events), ev_counts, 1, &total_ev)) return rcg;
     if (total_ev > ctx->tb.cap_events) {
@@ -2019,12 +2080,34 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
       ctx->tb.cap_events = (int32_t)std::min<int64_t>(total_ev + 4096, INT32_MAX);
     }
     if (total_ev > 0) HIPCHK(hipMemcpyAsync(ctx->tb.events, ctx->d_lall, (size_t)total_ev * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    const int32_t te = (int32_t)total_ev;
-    HIPCHK(hipMemcpyAsync(ctx->tb.n_events, &te, 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));           // (te is a stack local)
+    int32_t* te = ctx->h_pin ? reinterpret_cast<int32_t*>(ctx->h_pin + (60 << 10)) : nullptr;
+    int32_t te_local = (int32_t)total_ev;
+    if (te) { *te = te_local; HIPCHK(hipMemcpyAsync(ctx->tb.n_events, te, 4, hipMemcpyHostToDevice, ctx->stream)); }
+    else { HIPCHK(hipMemcpyAsync(ctx->tb.n_events, &te_local, 4, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); }
+    return MIA_HIP_OK;
+  };
+  // ... and without: every rank contributes a block of ev_pad events (sized from the counts of the iteration before, the
+  // same on every rank), the counts that rode on the gaps reduce tell k_events_compact how much of each block is real
+  auto exchange_events_padded = [&]() -> int {
+    const int64_t pad = ctx->ev_pad;
+    if (pad * W > ctx->lstage_cap) { if (dev_alloc(ctx, &ctx->d_lstage, (size_t)pad * W * 2)) return MIA_HIP_ERR_NOMEM; ctx->lstage_cap = pad * W * 2; }
+    COLLCHK(ctx->coll.all_gather(ctx->coll.user, ctx->tb.events, ctx->d_lstage, (size_t)pad * 8, ctx->stream));
+    const unsigned gx = (unsigned)std::min<int64_t>((pad + 255) / 256, 64);
+    hipLaunchKernelGGL(k_events_compact, dim3(gx, (unsigned)W), dim3(256), 0, ctx->stream, (const uint64_t*)ctx->d_lstage, pad, (const int32_t*)(ctx->tb.gaps + Lp), W,
+                       ctx->tb.events, ctx->tb.cap_events, ctx->tb.n_events, ctx->tb.flags);
+    HIPCHK(hipGetLastError());
+    return MIA_HIP_OK;
+  };
+  bool counted = false;
+  if (ctx->comm) {
+    // integer column tallies add up, ref->gaps is a maximum (src/mia.c:486-504); every rank's insert-event count rides on
+    // the max-reduce in W extra slots behind gaps; then the events themselves are gathered
+    hipLaunchKernelGGL(k_put_i32, dim3(1), dim3(1), 0, ctx->stream, ctx->tb.gaps + Lp + ctx->comm_rank, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events);
+    COLLCHK(ctx->coll.all_reduce_i32(ctx->coll.user, ctx->tb.tally, (size_t)TALLY_WORDS * Lp, MIA_HIP_OP_SUM, ctx->stream));
+    COLLCHK(ctx->coll.all_reduce_i32(ctx->coll.user, ctx->tb.gaps, (size_t)Lp + W, MIA_HIP_OP_MAX, ctx->stream));
+    counted = ctx->ev_pad <= 0;
+    if (int rce = counted ? exchange_events_counted() : exchange_events_padded()) return rce;
   }
-  if (int rcc = consensus_launch(ctx, cons_code, ctx->ins_tally_cap, true, true)) return rcc;
-  checkpoint("consensus kernels");
   const int64_t cons_cap = (int64_t)L + ctx->ins_tally_cap + 64;          // string bytes
   const int64_t res_bytes = (int64_t)CH_WORDS * 4 + cons_cap;
   if (res_bytes > ctx->cons_cap) {
@@ -2035,18 +2118,6 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
     if (dev_alloc(ctx, &ctx->d_cons_pos, (size_t)Lp * 2)) return MIA_HIP_ERR_NOMEM;
     ctx->cons_pos_cap = (int64_t)Lp * 2;
   }
-  // the string consensus_assembly_string returns, put together on the device: characters per column, their prefix sums,
-  // a scatter; header and string come back in one copy
-  int32_t* d_res = reinterpret_cast<int32_t*>(ctx->d_cons);
-  hipLaunchKernelGGL(k_cons_count, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
-                     (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos);
-  hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->d_cons_pos, L, 0, L, ctx->d_cons_pos, d_res + CH_LEN);
-  hipLaunchKernelGGL(k_cons_scatter, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
-                     (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total,
-                     (const int32_t*)ctx->d_cons_pos, d_res, (int32_t)cons_cap, (const int32_t*)ctx->tb.n_events, (const uint32_t*)ctx->tb.flags,
-                     (const uint32_t*)ctx->d_cull_flags);
-  HIPCHK(hipGetLastError());
-  checkpoint("assemble");
   const size_t need = (size_t)res_bytes;
   if (need > ctx->pin2_bytes) {
     if (ctx->h_pin2) (void)hipHostFree(ctx->h_pin2);
@@ -2056,10 +2127,46 @@ extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   }
   int32_t* h_hdr = reinterpret_cast<int32_t*>(ctx->h_pin2);
   char* h_str = reinterpret_cast<char*>(ctx->h_pin2) + CH_WORDS * 4;
-  HIPCHK(hipMemcpyAsync(ctx->h_pin2, ctx->d_cons, need, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // consensus calls, the string consensus_assembly_string returns put together on the device (characters per column, their
+  // prefix sums, a scatter), header and string back in one copy, the second and last wait
+  auto consensus_tail = [&]() -> int {
+    if (int rcc = consensus_launch(ctx, cons_code, ctx->ins_tally_cap, true, true)) return rcc;
+    checkpoint("consensus kernels");
+    int32_t* d_res = reinterpret_cast<int32_t*>(ctx->d_cons);
+    hipLaunchKernelGGL(k_cons_count, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
+                       (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos);
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->d_cons_pos, L, 0, L, ctx->d_cons_pos, d_res + CH_LEN);
+    hipLaunchKernelGGL(k_cons_scatter, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
+                       (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total,
+                       (const int32_t*)ctx->d_cons_pos, d_res, (int32_t)cons_cap, (const int32_t*)ctx->tb.n_events, (const uint32_t*)ctx->tb.flags,
+                       (const uint32_t*)ctx->d_cull_flags);
+    HIPCHK(hipGetLastError());
+    checkpoint("assemble");
+    HIPCHK(hipMemcpyAsync(ctx->h_pin2, ctx->d_cons, need, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->comm && !counted) HIPCHK(hipMemcpyAsync(h_evc, ctx->tb.gaps + Lp, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return MIA_HIP_OK;
+  };
+  if (int rct = consensus_tail()) return rct;
+  uint32_t tflags = (uint32_t)h_hdr[CH_TALLY_FLAGS];
+  if (ctx->comm && !counted && (tflags & 8u)) {
+    // some rank had more insert events than the blocks held (every rank sees the same counts, so every rank is here):
+    // the lists and counts are untouched -- exchange them with the counts in hand and call the consensus again
+    counted = true;
+    if (int rce = exchange_events_counted()) return rce;
+    if (int rct = consensus_tail()) return rct;
+    tflags = (uint32_t)h_hdr[CH_TALLY_FLAGS];
+  }
+  tflags &= ~8u;
+  if (ctx->comm) {
+    // the block size of the next iteration's event exchange, from counts every rank has seen: half as much again as the
+    // largest, re-sized only when that leaves the band [pad/4, 0.8 pad] (identical arithmetic on identical numbers)
+    int64_t mx = 0;
+    for (int r = 0; r < W; r++) mx = std::max<int64_t>(mx, h_evc[r]);
+    if (ctx->ev_pad <= 0 || mx * 5 > ctx->ev_pad * 4 || mx * 4 < ctx->ev_pad) ctx->ev_pad = mx + mx / 2 + 1024;
+  }
   ctx->in_iterate = false;
-  if (int rcf = tally_finish(ctx, (uint32_t)h_hdr[CH_N_EVENTS], (uint32_t)h_hdr[CH_TALLY_FLAGS], (uint32_t)h_hdr[CH_CULL_FLAGS])) return rcf;
+  if (int rcf = tally_finish(ctx, (uint32_t)h_hdr[CH_N_EVENTS], tflags, (uint32_t)h_hdr[CH_CULL_FLAGS])) return rcf;
   if (h_hdr[CH_OVERFLOW]) {
     // more insert columns than the buffers of the last call hold: the step-wise entry point enlarges them and calls again
     ctx->iter_fallbacks++;
@@ -2756,16 +2863,24 @@ extern "C" int mia_hip_measure_peaks(mia_hip_ctx* ctx, int64_t copy_bytes, doubl
     if (hipMalloc(&a, (size_t)n16 * 16) != hipSuccess || hipMalloc(&b, (size_t)n16 * 16) != hipSuccess) { ctx->err = "measure_peaks: hipMalloc"; rc = MIA_HIP_ERR_NOMEM; }
     else {
       HIPCHK(hipMemsetAsync(a, 1, (size_t)n16 * 16, ctx->stream));
-      const int grid = ctx->cus * 16;
       float best = 1e30f;
-      for (int rep = 0; rep < 6; rep++) {                     // the first repetition warms the TLBs
-        (void)hipEventRecord(e0, ctx->stream);
-        hipLaunchKernelGGL(k_peak_copy, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16);
-        (void)hipEventRecord(e1, ctx->stream);
-        HIPCHK(hipEventSynchronize(e1));
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-        if (rep > 0 && ms < best) best = ms;
+      for (int variant = 0; variant < 8; variant++) {
+        const int grid = ctx->cus * (variant & 1 ? 32 : 8);
+        for (int rep = 0; rep < 4; rep++) {                   // the first repetition warms the TLBs
+          (void)hipEventRecord(e0, ctx->stream);
+          switch (variant >> 1) {
+            case 0: hipLaunchKernelGGL((k_peak_copy<1, false>), dim3(grid * 2), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16); break;
+            case 1: hipLaunchKernelGGL((k_peak_copy<4, false>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16); break;
+            case 2: hipLaunchKernelGGL((k_peak_copy<4, true>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16); break;
+            default: hipLaunchKernelGGL((k_peak_copy<8, true>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16); break;
+          }
+          (void)hipEventRecord(e1, ctx->stream);
+          HIPCHK(hipEventSynchronize(e1));
+          float ms = 0;
+          HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+          if (getenv("MIA_HIP_PEAK_DEBUG")) fprintf(stderr, "[peak copy] variant %d rep %d: %.1f GB/s\n", variant, rep, 2.0 * (double)n16 * 16 / (ms * 1e-3) / 1e9);
+          if (rep > 0 && ms < best) best = ms;
+        }
       }
       *hbm_copy_gbs = 2.0 * (double)n16 * 16 / (best * 1e-3) / 1e9;      // bytes read + bytes written
     }

@@ -256,9 +256,18 @@ int main(int argc, char** argv) {
       case 'N': intercept = atof(optarg); score_cut_set = 1; break;
       case 'F': final_only = 1; break;
       case 'g': {
+        // a comma-separated list of device numbers, nothing else: no empty fields, no signs, no blanks
         gpus.clear();
-        for (const char* q = optarg; *q;) { gpus.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
-        if (gpus.empty()) gpus.push_back(0);
+        bool ok = *optarg != 0;
+        for (const char* q = optarg; ok && *q;) {
+          if (!isdigit((unsigned char)*q)) { ok = false; break; }
+          char* e = nullptr;
+          const long v = strtol(q, &e, 10);
+          if (v > 1023 || (*e && *e != ',') || (*e == ',' && !e[1])) { ok = false; break; }
+          gpus.push_back((int)v);
+          q = *e ? e + 1 : e;
+        }
+        if (!ok || gpus.empty()) { fprintf(stderr, "mia_hip: -g wants a list of GPU numbers such as 0 or 0,1,2,3 (got \"%s\")\n", optarg); exit(1); }
         break;
       }
       case 'T': do_adapter_trimming = 1; break;
@@ -294,6 +303,15 @@ int main(int argc, char** argv) {
 
   // one context per GPU; every per-read step below runs on all of them at once, each on its contiguous share of the reads
   const int NG = (int)gpus.size();
+  // The same GPU several times (-g 0,0): as many contexts on that one device, one host thread each, joined by the library's
+  // in-process transport instead of RCCL (which refuses two ranks on one device) -- the sharded driver on a single GPU.
+  // Mixing that with other devices is refused: the in-process transport copies between the contexts' buffers directly.
+  bool same_gpu = NG > 1;
+  for (int k = 1; k < NG; k++) same_gpu = same_gpu && gpus[(size_t)k] == gpus[0];
+  if (!same_gpu)
+    for (int k = 0; k < NG; k++)
+      for (int j = 0; j < k; j++)
+        if (gpus[(size_t)j] == gpus[(size_t)k]) { fprintf(stderr, "mia_hip: -g lists GPU %d twice beside other GPUs (list every GPU once, or one GPU several times)\n", gpus[(size_t)k]); exit(1); }
   std::vector<mia_hip_ctx*> G((size_t)NG, nullptr);
   for (int k = 0; k < NG; k++) {
     if (mia_hip_create(&G[(size_t)k], gpus[(size_t)k]) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: no usable MI355X (gfx950) device %d; there is no CPU fallback\n", gpus[(size_t)k]); exit(1); }
@@ -415,8 +433,6 @@ int main(int argc, char** argv) {
     *s = slope; *ic = intercept;
     if (hard_cut <= 0 && !score_cut_set) {
       // the regression's first pass (integer sums) runs on the device; with equally long reads that is all of it
-      int64_t sums5[5];
-      (void)sums5;
       mia_hip_score_cut(score.data(), len.data(), NULL, n, s, ic);
     }
     if (*s <= 0) *s = 100.0;
@@ -462,7 +478,14 @@ int main(int argc, char** argv) {
       if (mia_hip_set_pass1_state(c, f0.data() + lo, b0.data() + lo, score.data() + lo) != MIA_HIP_OK) die(c, "set_pass1_state");
       if (mia_hip_set_read_base(c, lo) != MIA_HIP_OK) die(c, "set_read_base");
     });
-    if (NG > 1) {
+    if (same_gpu) {
+      void* group = nullptr;
+      if (mia_hip_loopback_create(NG, &group) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: the in-process transport could not be made\n"); exit(1); }
+      for (int k = 0; k < NG; k++) {
+        mia_hip_collectives t;
+        if (mia_hip_loopback_table(group, k, &t) != MIA_HIP_OK || mia_hip_comm_attach(G[(size_t)k], &t) != MIA_HIP_OK) die(G[(size_t)k], "comm_attach");
+      }
+    } else if (NG > 1) {
       // RCCL over xGMI: rank k = GPU k of the list; the id goes from here to every thread
       char id[MIA_HIP_COMM_ID_BYTES];
       if (mia_hip_comm_unique_id(id) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: RCCL (librccl.so.1) is needed for more than one GPU and could not be opened\n"); exit(1); }

@@ -8,9 +8,20 @@
   ranks hold), driven through mia_hip_links -> mia_hip_set_links -> mia_hip_link_lengths -> mia_hip_finish_links with
   host-side reductions standing in for RCCL (one GPU here): scores, dropped bits, depth-code parameters, multiplicities,
   summed tallies, maximum gaps and the consensus equal the single context's, every iteration.
+* test_two_ranks_through_the_library_*: the sharded path of mia_hip_iterate ITSELF with W = 2 and 3 -- contexts on host
+  threads of one process, joined by the library's in-process loopback transport (mia_hip_loopback_*: host barrier + device
+  copies; RCCL refuses two ranks on one device) -- against the single context, every output, every iteration: the
+  eight-word pre-cull gather in front of the alignment's wait, the ragged score / length gather (reads of different
+  lengths), the link exchange across the shard boundary, both all-reduces with the event counts in the slack slots, and
+  both ways of gathering the insert events (counted the first time, padded blocks + k_events_compact afterwards).
+* test_a_failing_rank_does_not_hang_the_others: a rank that fails (or never comes) makes its peers return an error.
+* test_mia_hip_two_threads_one_gpu: `mia_hip -g 0,0` -- the host program's threaded driver (sharded trimming, pass 1,
+  iterations, .maln records collected from both contexts) writes the same bytes as the one-context run.
 """
 import ctypes as C
 import os
+import subprocess
+import threading
 
 import numpy as np
 import pytest
@@ -193,3 +204,178 @@ def test_two_contexts_exchange_real_links(oracle):
     assert any_links
     for h in parts + [whole]:
         h.close()
+
+
+# ---- the library's own sharded path with W > 1 (loopback transport) ------------------------------------------------
+def run_ranks(fns):
+    """one host thread per rank (ctypes drops the GIL inside the library); returns the results in rank order"""
+    out, err = [None] * len(fns), [None] * len(fns)
+
+    def work(k):
+        try:
+            out[k] = fns[k]()
+        except BaseException as e:        # noqa: BLE001 -- reported by the caller
+            err[k] = e
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(fns))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return out, err
+
+
+def compare_ranks(whole, parts, it):
+    """every per-read output of the shards, concatenated in rank order, and the (all-reduced) tallies of every rank"""
+    wa = whole.alignments()
+    for k in range(3):
+        assert np.array_equal(np.concatenate([h.alignments()[k] for h in parts]), wa[k]), (it, k)
+    wF, wB = whole.dropped()
+    assert np.array_equal(np.concatenate([h.dropped()[0] for h in parts]), wF), it
+    assert np.array_equal(np.concatenate([h.dropped()[1] for h in parts]), wB), it
+    assert np.array_equal(np.concatenate([h.record_params()[0] for h in parts]), whole.record_params()[0]), it
+    wt, wg = whole.get_tally()
+    for h in parts:
+        t, g = h.get_tally()
+        assert np.array_equal(t, wt) and np.array_equal(g, wg), it
+
+
+def test_two_ranks_through_the_library_real_links(oracle):
+    """adapter-trimmed reads of different lengths (the regression needs everybody's scores in fsdb order), stale back_asp
+    pointers (links), the boundary between a formerly split read and the slot it points at"""
+    import mia_amd
+    fs, anc, dropped1, ref0 = setup(oracle)
+    n = fs["n"]
+    whole = context(mia_amd, fs, anc, dropped1)
+    back = fs["back"]
+    hot = [i for i in range(1, n - 1) if back[i] >= 0]
+    cuts = [0, hot[len(hot) // 2] if hot else n // 2, n]
+    parts = [context(mia_amd, fs, anc, dropped1, cuts[k], cuts[k + 1]) for k in range(2)]
+    grp = mia_amd.LoopbackGroup(2)
+    for k, h in enumerate(parts):
+        grp.attach(h, k)
+        assert h.comm_info() == (2, k, "loopback")
+    ref, links_seen = ref0, 0
+    for it in range(1, 8):
+        cw = whole.iterate(ref, True)
+        cons, err = run_ranks([lambda h=h: h.iterate(ref, True) for h in parts])
+        assert err == [None, None], (it, err)
+        assert cons[0] == cons[1] == cw, it
+        compare_ranks(whole, parts, it)
+        pa = whole.record_params()[0]
+        links_seen = max(links_seen, int(pa[:, 3].max()), int(pa[:, 7].max()))
+        if cw == ref:
+            break
+        ref = cw
+    assert links_seen == 2
+    for h in parts:
+        h.comm_destroy()
+    grp.close()
+    for h in parts + [whole]:
+        h.close()
+
+
+@pytest.mark.parametrize("W", [2, 3])
+def test_ranks_through_the_library_equal_lengths(W):
+    """60 000 synthetic 100 bp reads with indels (a few thousand insert events per rank) against mt311, uneven shards: the
+    iterations run from mt311 itself to a fixed point, the event exchange goes the counted way once and the padded way
+    afterwards; one more round with the block size forced down to 16 events takes the overflow path."""
+    import gen_data
+    import mia_amd
+    from conftest import GOLDEN
+    _, _, mt = gen_data.read_fasta_one(os.path.join(GOLDEN, "mt311.fa"))
+    indiv = gen_data.resolve_individual(mt)
+    n, L = 60_000, 100
+    d = gen_data.make_reads(indiv, n, L, seed=23, circular=True, indel_rate=0.004)
+    stored = gen_data.stored_orientation(d)
+    rc, as_ = d["strand"].astype(np.uint8), d["start"].astype(np.int32)
+    ae = (as_ + L - 1).astype(np.int32)
+
+    def ctx(lo, hi):
+        h = mia_amd.MiaHip(0)
+        h.set_pssm(mia_amd.flat_pssm())
+        h.upload_reads(stored[lo:hi].reshape(-1), np.arange(hi - lo + 1, dtype=np.int64) * L, rc[lo:hi], np.ones(hi - lo, np.uint8), as_[lo:hi], ae[lo:hi])
+        h.set_read_base(lo)
+        return h
+    whole = ctx(0, n)
+    cuts = [0] + sorted(int(x) for x in np.random.default_rng(W).choice(np.arange(5000, n - 5000), W - 1, replace=False)) + [n]
+    parts = [ctx(cuts[k], cuts[k + 1]) for k in range(W)]
+    grp = mia_amd.LoopbackGroup(W)
+    for k, h in enumerate(parts):
+        grp.attach(h, k)
+    ref = mt.upper()
+    for it in range(1, 9):
+        if it == 4:
+            os.environ["MIA_HIP_EV_PAD"] = "16"          # far fewer than any rank has: k_events_compact refuses, the counted way runs
+        cw = whole.iterate(ref, True)
+        cons, err = run_ranks([lambda h=h: h.iterate(ref, True) for h in parts])
+        os.environ.pop("MIA_HIP_EV_PAD", None)
+        assert err == [None] * W, (it, err)
+        assert all(c == cw for c in cons), it
+        compare_ranks(whole, parts, it)
+        if cw == ref and it > 4:
+            break
+        ref = cw
+    ev = whole.ins_events()[1]
+    assert ev > 1000                                     # the event exchange had work
+    for h in parts:
+        h.comm_destroy()
+    grp.close()
+    for h in parts + [whole]:
+        h.close()
+
+
+def test_a_failing_rank_does_not_hang_the_others(oracle):
+    import mia_amd
+    fs, anc, dropped1, ref0 = setup(oracle)
+    n = fs["n"]
+    os.environ["MIA_HIP_LOOPBACK_TIMEOUT"] = "3"
+    try:
+        parts = [context(mia_amd, fs, anc, dropped1, lo, hi) for lo, hi in ((0, n // 2), (n // 2, n))]
+        grp = mia_amd.LoopbackGroup(2)
+    finally:
+        os.environ.pop("MIA_HIP_LOOPBACK_TIMEOUT")
+    for k, h in enumerate(parts):
+        grp.attach(h, k)
+
+    def bad():
+        # an argument error inside the sharded call: rank 1 gives up before its first collective and says so to the group
+        buf = C.create_string_buffer(16)
+        return parts[1]._l.mia_hip_iterate(parts[1]._h, ref0.encode(), len(ref0), 1, 0, None, 1, buf, 0, None)
+    out, err = run_ranks([lambda: parts[0].iterate(ref0, True), bad])
+    assert out[1] == -2 and isinstance(err[0], mia_amd.MiaHipError), (out, err)
+    # the group is gone for good: the next call fails at once on every rank instead of waiting
+    out, err = run_ranks([lambda h=h: h.iterate(ref0, True) for h in parts])
+    assert all(isinstance(e, mia_amd.MiaHipError) for e in err), err
+    for h in parts:
+        h.comm_destroy()
+    grp.close()
+    # a rank that never comes: the other one gives up after the time limit
+    os.environ["MIA_HIP_LOOPBACK_TIMEOUT"] = "2"
+    try:
+        grp = mia_amd.LoopbackGroup(2)
+    finally:
+        os.environ.pop("MIA_HIP_LOOPBACK_TIMEOUT")
+    grp.attach(parts[0], 0)
+    with pytest.raises(mia_amd.MiaHipError):
+        parts[0].iterate(ref0, True)
+    parts[0].comm_destroy()
+    grp.close()
+    for h in parts:
+        h.close()
+
+
+def test_mia_hip_two_threads_one_gpu(tmp_path):
+    """the host program's threaded driver on one GPU: `-g 0,0` (loopback transport) against `-g 0`, byte for byte"""
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "mapping-iterative-assembler_amd", "mia_hip")
+    outs = []
+    for tag, g in (("one", "0"), ("two", "0,0"), ("three", "0,0,0")):
+        root = str(tmp_path / tag)
+        cmd = [exe, "-r", os.path.join(GOLDEN, "mt311.fa"), "-f", os.path.join(GOLDEN, "adapt.fa"), "-c", "-i", "-k", "12", "-T", "-a", ADAPTER,
+               "-s", os.path.join(GOLDEN, "ancient.submat.txt"), "-m", root, "-g", g]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        files = sorted(f for f in os.listdir(tmp_path) if f.startswith(tag + "."))
+        assert files
+        outs.append([open(tmp_path / f).read().split("\n", 1)[1] for f in files])
+    assert outs[0] == outs[1] == outs[2]
