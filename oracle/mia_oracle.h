@@ -138,6 +138,12 @@ void ora_pass1_read(ora_state *st, const char *id, const char *desc, const char 
 /* whole FASTA/FASTQ file through read_next_seq (src/io.c:35-281); returns #records seen */
 int ora_pass1_file(ora_state *st, const char *path);
 
+/* a read whose strand and coordinates are already known (add_fs2fsdb, src/fsdb.c:628-663, without the sg_align in front
+ * of it): seq in alignment orientation; the first ora_iterate merges its records */
+void ora_push_frag(ora_state *st, const char *id, const char *seq, int rc, int as, int ae, int score, int strand_known);
+/* host threads for the alignments of ora_iterate (the records are still merged in fsdb order); default 1 */
+void ora_set_threads(ora_state *st, int n);
+
 /* src/mia_main.c:812-875: pop_smp, cull, sort, mask reset, clean_FSDB */
 void ora_finish_pass1(ora_state *st);
 /* one iteration: reiterate_assembly + pop_smp + cull + sort (src/mia_main.c:931-955) */

@@ -8,6 +8,7 @@
 
 #include <ctype.h>
 #include <limits.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,6 +43,7 @@ struct ora_state {
   unsigned char *fw_mask, *rc_mask;
   int fw_len1;
   int ref_prepared;
+  int threads; /* ora_set_threads: host threads for the alignments of an iteration (results are merged in fsdb order) */
 };
 
 void ora_opts_default(ora_opts *o) {
@@ -688,6 +690,54 @@ void ora_finish_pass1(ora_state *st) {
 /* the per-iteration driver                                             */
 /* ------------------------------------------------------------------ */
 
+/* one read of reiterate_assembly's loop up to the alignment itself, src/mia_main.c:179-252 */
+typedef struct { pwaln front; ora_aln res; int ref_start; } realigned;
+typedef struct { ora_state *st; realigned *out; int lo, hi; } realign_job;
+
+static void *realign_range(void *arg) {
+  realign_job *job = (realign_job *)arg;
+  ora_state *st = job->st;
+  int i;
+  for (i = job->lo; i < job->hi; i++) {
+    const ora_frag *fs = &st->fss[i];
+    realigned *r = &job->out[i];
+    const ora_pssm *pm;
+    int len2, ref_start, ref_end;
+    if (!fs->strand_known) continue; /* :178 */
+    pm = fs->rc ? &st->rcanc : &st->anc;
+    len2 = (int)strlen(fs->seq);
+    ref_start = (fs->as - ORA_REALIGN_BUFFER) < 0 ? 0 : fs->as - ORA_REALIGN_BUFFER;       /* :191-196 */
+    ref_end = (fs->ae + ORA_REALIGN_BUFFER + 1) > st->wrap_seq_len ? st->wrap_seq_len
+                                                                    : fs->ae + ORA_REALIGN_BUFFER; /* :197-203 */
+    if (ref_start + len2 > ref_end) { ref_start = 0; ref_end = st->wrap_seq_len; }          /* :209-212 */
+    r->ref_start = ref_start;
+    ora_align(st->seq + ref_start, ref_end - ref_start, fs->seq, len2, NULL, pm, 1, &r->res,
+              r->front.ref_seq, r->front.frag_seq, NULL, NULL);
+  }
+  return NULL;
+}
+
+static void realign_run(realign_job *all) {
+  ora_state *st = all->st;
+  int T = st->threads > 1 ? st->threads : 1, t;
+  if (T > 64) T = 64;
+  if (T == 1 || st->num_fss < 2 * T) { all->lo = 0; all->hi = st->num_fss; realign_range(all); return; }
+  {
+    pthread_t th[64];
+    realign_job jobs[64];
+    int started = 0;
+    for (t = 0; t < T; t++) {
+      jobs[t] = *all;
+      jobs[t].lo = (int)((long long)st->num_fss * t / T);
+      jobs[t].hi = (int)((long long)st->num_fss * (t + 1) / T);
+      if (pthread_create(&th[t], NULL, realign_range, &jobs[t]) != 0) break;
+      started++;
+    }
+    for (t = started; t < T; t++) realign_range(&jobs[t]); /* (a thread that could not be started: do its share here) */
+    for (t = 0; t < started; t++) pthread_join(th[t], NULL);
+  }
+}
+
 /* reiterate_assembly, src/mia_main.c:24-280 (distant_ref and hp are out of scope) */
 static void realign_all(ora_state *st, const char *new_ref, int iter_num) {
   int i, j, L = (int)strlen(new_ref);
@@ -706,39 +756,39 @@ static void realign_all(ora_state *st, const char *new_ref, int iter_num) {
     for (j = 0; j < n; j++) if (a->ins[j]) { free(a->ins[j]); a->ins[j] = NULL; }
   }
   st->num_aln_seqs = 0;
-  for (i = 0; i < st->num_fss; i++) {
-    ora_frag *fs = &st->fss[i];
-    const ora_pssm *pm;
-    ora_aln res;
-    pwaln front, back;
-    int len2, ref_start, ref_end;
-    if (!fs->strand_known) continue; /* :178 */
-    pm = fs->rc ? &st->rcanc : &st->anc;
-    len2 = (int)strlen(fs->seq);
-    ref_start = (fs->as - ORA_REALIGN_BUFFER) < 0 ? 0 : fs->as - ORA_REALIGN_BUFFER;       /* :191-196 */
-    ref_end = (fs->ae + ORA_REALIGN_BUFFER + 1) > st->wrap_seq_len ? st->wrap_seq_len
-                                                                    : fs->ae + ORA_REALIGN_BUFFER; /* :197-203 */
-    if (ref_start + len2 > ref_end) { ref_start = 0; ref_end = st->wrap_seq_len; }          /* :209-212 */
-    memset(&front, 0, sizeof front);
-    memset(&back, 0, sizeof back);
-    ora_align(st->seq + ref_start, ref_end - ref_start, fs->seq, len2, NULL, pm, 1, &res,
-              front.ref_seq, front.frag_seq, NULL, NULL);
-    strcpy(front.frag_id, fs->id);
-    strcpy(front.frag_desc, fs->desc);
-    front.trimmed = fs->trimmed; front.revcom = fs->rc; front.num_inputs = fs->num_inputs;
-    front.segment = 'a'; front.score = res.best;
-    front.start = res.abc + ref_start;
-    front.end = res.aec + ref_start;
-    fs->as = front.start; fs->ae = front.end; fs->unique_best = 1; fs->score = res.best;
-    if (front.end > st->seq_len) front.end -= st->seq_len; /* :259-263 */
-    if (front.start > front.end) {
-      split_record(&front, &back, st->seq_len);
-      merge_record(st, &front); fs->front = st->num_aln_seqs - 1;
-      merge_record(st, &back); fs->back = st->num_aln_seqs - 1;
-    } else {
-      merge_record(st, &front); fs->front = st->num_aln_seqs - 1;
-      /* fs->back is left untouched (stale index if the read was split before), :273-276 */
+  /* The alignment of a read depends on the new reference and on the read's own previous coordinates only, so the
+   * alignments may be computed ahead of the merge loop -- on several host threads when ora_set_threads asked for them --
+   * as long as the records are merged in fsdb order, one read after the other, exactly as the reference's single loop
+   * does (:176-278). */
+  {
+    realign_job job;
+    job.st = st;
+    job.out = (realigned *)calloc((size_t)(st->num_fss ? st->num_fss : 1), sizeof(realigned));
+    realign_run(&job);
+    for (i = 0; i < st->num_fss; i++) {
+      ora_frag *fs = &st->fss[i];
+      realigned *r = &job.out[i];
+      pwaln *front = &r->front, back;
+      if (!fs->strand_known) continue; /* :178 */
+      memset(&back, 0, sizeof back);
+      strcpy(front->frag_id, fs->id);
+      strcpy(front->frag_desc, fs->desc);
+      front->trimmed = fs->trimmed; front->revcom = fs->rc; front->num_inputs = fs->num_inputs;
+      front->segment = 'a'; front->score = r->res.best;
+      front->start = r->res.abc + r->ref_start;
+      front->end = r->res.aec + r->ref_start;
+      fs->as = front->start; fs->ae = front->end; fs->unique_best = 1; fs->score = r->res.best;
+      if (front->end > st->seq_len) front->end -= st->seq_len; /* :259-263 */
+      if (front->start > front->end) {
+        split_record(front, &back, st->seq_len);
+        merge_record(st, front); fs->front = st->num_aln_seqs - 1;
+        merge_record(st, &back); fs->back = st->num_aln_seqs - 1;
+      } else {
+        merge_record(st, front); fs->front = st->num_aln_seqs - 1;
+        /* fs->back is left untouched (stale index if the read was split before), :273-276 */
+      }
     }
+    free(job.out);
   }
 }
 
@@ -884,6 +934,22 @@ int ora_run(ora_state *st, const char *frag_path, const char *maln_root) {
 }
 
 /* accessors */
+/* A read with its post-pass-1 fields set directly -- add_fs2fsdb (src/fsdb.c:628-663) without sg_align before it: what a
+ * caller holds who already knows strand and coordinates (bench.py's inputs; oracle/ref_iter_driver.c fills the
+ * reference's FSDB the same way).  front/back slots are empty until the first ora_iterate merges records. */
+void ora_push_frag(ora_state *st, const char *id, const char *seq, int rc, int as, int ae, int score, int strand_known) {
+  ora_frag *fs = fsdb_push(st);
+  int n = 0;
+  strncpy(fs->id, id, ORA_MAX_ID);
+  while (seq[n] && n < ORA_MAX_READ) { fs->seq[n] = seq[n]; n++; }
+  fs->seq[n] = 0;
+  fs->seq_len = n;
+  fs->rc = rc; fs->as = as; fs->ae = ae; fs->score = score; fs->strand_known = strand_known;
+  fs->unique_best = 1; fs->num_inputs = 1; fs->front = -1; fs->back = -1;
+}
+
+void ora_set_threads(ora_state *st, int n) { st->threads = n; }
+
 int ora_num_frags(const ora_state *st) { return st->num_fss; }
 const ora_frag *ora_frag_at(const ora_state *st, int i) { return &st->fss[i]; }
 int ora_num_culled(const ora_state *st) { return st->culled_n; }

@@ -9,7 +9,9 @@
  * against the reference's own objects by oracle/Makefile.ref; the binary lands
  * in oracle/_ref/ and is used by bench.py's cpu_baseline leg (kind "reference").
  *
- * usage: ref_iter_driver <ref.fa> <reads.txt> <circular 0|1> <matrix|flat> <iterations>
+ * usage: ref_iter_driver <ref.fa> <reads.txt> <circular 0|1> <matrix|flat> <iterations> [dump.txt]
+ *   dump.txt (golden fixtures, tools/make_goldens.py iter_push): after every iteration one line "I <k> <consensus>" and
+ *   one line "R <score> <as> <ae>" per read in fsdb order
  *   reads.txt: one read per line "rc as ae SEQUENCE" (sequence already in
  *   alignment orientation, as add_virgin_fs2fsdb leaves it)
  * stdout: "reads N iterations K seconds S cons_len L" (S = time inside the path only)
@@ -64,6 +66,7 @@ int main(int argc, char **argv) {
   last[maln->ref->seq_len] = 0;
   char *cons = last;
   double t = 0;
+  FILE *dump = argc > 6 ? fopen(argv[6], "w") : NULL;
   for (i = 1; i <= iters; i++) {
     double t0 = now();
     reiterate_assembly(cons, i, maln, fsdb, a, front, back, anc, rcanc);
@@ -73,7 +76,13 @@ int main(int argc, char **argv) {
     sort_aln_frags(culled);
     cons = consensus_assembly_string(culled);
     t += now() - t0;
+    if (dump) {
+      int k;
+      fprintf(dump, "I %d %s\n", i, cons);
+      for (k = 0; k < (int)fsdb->num_fss; k++) fprintf(dump, "R %d %d %d\n", fsdb->fss[k]->score, fsdb->fss[k]->as, fsdb->fss[k]->ae);
+    }
   }
+  if (dump) fclose(dump);
   printf("reads %d iterations %d seconds %.6f cons_len %d\n", n, iters, t, (int)strlen(cons));
   return 0;
 }

@@ -63,6 +63,10 @@ def load(path):
     lib.ora_pass1_read.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.ora_pass1_file.argtypes = [C.c_void_p, C.c_char_p]
     lib.ora_finish_pass1.argtypes = [C.c_void_p]
+    lib.ora_push_frag.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.ora_push_frag.restype = None
+    lib.ora_set_threads.argtypes = [C.c_void_p, C.c_int]
+    lib.ora_set_threads.restype = None
     lib.ora_iterate.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.ora_consensus.argtypes = [C.c_void_p]
     lib.ora_consensus.restype = C.c_void_p

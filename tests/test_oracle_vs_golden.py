@@ -149,3 +149,50 @@ def test_trim_vectors(oracle):
         oracle.ora_trim(read.encode(), len(read), ad.encode(), C.byref(tr), C.byref(tp), C.byref(a))
         got = [tr.value, tp.value if tr.value else -999, a.aec, a.aer, a.abc, a.abr]
         assert got == exp, (ad, read, got, exp)
+
+
+# ---- the per-iteration loop on a read store filled with post-pass-1 fields (ora_push_frag), alignments on host threads ----
+def _iter_push_sets():
+    import json
+    with open(os.path.join(GOLDEN, "iter_push.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", sorted(_iter_push_sets().keys()))
+def test_pushed_reads_iterate_like_the_reference(oracle, name):
+    """tests/golden/iter_push.json: what the reference's own loop (oracle/ref_iter_driver.c around reiterate_assembly,
+    pop_smp_from_FSDB, cull_maln_from_fsdb, sort_aln_frags, consensus_assembly_string -- src/mia_main.c:931-963) gives for
+    3 000 seeded reads whose strand and coordinates are set directly.  The oracle must give the same per-read
+    (score, as, ae) and the same consensus in every iteration -- through ora_push_frag and with the alignments spread over
+    four host threads, the way the full-size GPU tests drive it."""
+    import hashlib
+    import ctypes as C
+    import numpy as np
+    import make_goldens
+    import oracle_ctypes as oc
+    want = _iter_push_sets()[name]
+    ref, stored, rc, as_, ae = make_goldens.iter_push_inputs(name)
+    assert hashlib.sha256(stored.tobytes() + rc.tobytes() + as_.tobytes()).hexdigest() == want["inputs_sha256"]
+    o = oc.Opts()
+    oracle.ora_opts_default(C.byref(o))
+    o.circular = 1
+    anc = oc.Pssm()
+    if want["matrix"]:
+        assert oracle.ora_pssm_read(os.path.join(GOLDEN, want["matrix"]).encode(), C.byref(anc)) == 1
+    else:
+        oracle.ora_pssm_flat(C.byref(anc))
+    st = oracle.ora_new(C.byref(o), C.byref(anc))
+    oracle.ora_set_ref(st, b"ref", b"", ref.encode())
+    oracle.ora_prepare_ref(st)
+    for i in range(len(rc)):
+        oracle.ora_push_frag(st, b"r%d" % i, stored[i].tobytes(), int(rc[i]), int(as_[i]), int(ae[i]), 2001, 1)
+    oracle.ora_set_threads(st, 4)
+    cons = ref
+    for k, it in enumerate(want["iterations"], 1):
+        oracle.ora_iterate(st, cons.encode(), k)
+        cons = oc.consensus_string(oracle, st)
+        got = np.array([[f.score, f.as_, f.ae] for f in (oracle.ora_frag_at(st, i).contents for i in range(len(rc)))], dtype=np.int32)
+        assert got[:8].tolist() == it["first_reads"], (name, k)
+        assert hashlib.sha256(got.tobytes()).hexdigest() == it["reads_sha256"], (name, k)
+        assert len(cons) == it["cons_len"] and hashlib.sha256(cons.encode()).hexdigest() == it["cons_sha256"], (name, k)
+    oracle.ora_free(st)

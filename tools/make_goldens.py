@@ -324,6 +324,67 @@ def g2_cases(only=None):
     shutil.rmtree(tmp)
 
 
+def iter_push_sets():
+    """The reference's own per-iteration loop (oracle/ref_iter_driver.c around reiterate_assembly + pop_smp + cull + sort +
+    consensus_assembly_string) on a read store filled with post-pass-1 fields -- what bench.py and the full-size parity
+    tests hand to the GPU path and, through ora_push_frag, to the oracle.  3 000 seeded reads each, true positions jittered
+    by up to +-12 columns so that windows are not centred, three iterations."""
+    return {
+        "ip_flat": dict(seed=31, damage=False, matrix=None, paired=False),
+        "ip_anc": dict(seed=32, damage=True, matrix="ancient.submat.txt", paired=False),
+        "ip_pe": dict(seed=33, damage=True, matrix="ancient.submat.solexa.pe.txt", paired=True),
+    }
+
+
+def iter_push_inputs(name):
+    """(reference string, stored reads [n, 100], rc, as, ae) of an iter_push set, regenerated from its seed"""
+    import numpy as np
+    kw = iter_push_sets()[name]
+    _, _, mt = gen_data.read_fasta_one(os.path.join(G, "mt311.fa"))
+    indiv = gen_data.resolve_individual(mt)
+    n, L = 3000, 100
+    d = (gen_data.make_paired_reads(indiv, n, L, kw["seed"], damage=True) if kw["paired"]
+         else gen_data.make_reads(indiv, n, L, kw["seed"], circular=True, damage=kw["damage"], indel_rate=0.003))
+    stored = gen_data.stored_orientation(d)
+    jit = np.random.default_rng(kw["seed"] + 1000).integers(-12, 13, size=n)
+    as_ = ((d["start"] + jit) % len(indiv)).astype(np.int32)
+    return mt.upper(), stored, d["strand"].astype(np.uint8), as_, (as_ + L - 1).astype(np.int32)
+
+
+def iter_push_cases():
+    import hashlib
+    import numpy as np
+    tmp = tempfile.mkdtemp()
+    out = {}
+    for name, kw in iter_push_sets().items():
+        ref, stored, rc, as_, ae = iter_push_inputs(name)
+        gen_data.write_fasta(os.path.join(tmp, "ref.fa"), "ref", ref)
+        with open(os.path.join(tmp, "reads.txt"), "w") as f:
+            for i in range(len(rc)):
+                f.write(f"{int(rc[i])} {int(as_[i])} {int(ae[i])} {stored[i].tobytes().decode()}\n")
+        matrix = os.path.join(REF, "matrices", kw["matrix"]) if kw["matrix"] else "flat"
+        dump = os.path.join(tmp, "dump.txt")
+        sh([os.path.join(RB, "ref_iter_driver"), os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.txt"), "1", matrix, "3", dump])
+        its, cur = [], None
+        for line in open(dump):
+            t = line.split()
+            if t[0] == "I":
+                cur = {"cons_len": len(t[2]), "cons_sha256": hashlib.sha256(t[2].encode()).hexdigest(), "reads": []}
+                its.append(cur)
+            else:
+                cur["reads"].append([int(x) for x in t[1:4]])
+        for it in its:
+            a = np.array(it.pop("reads"), dtype=np.int32)
+            it["n_reads"] = len(a)
+            it["reads_sha256"] = hashlib.sha256(a.tobytes()).hexdigest()          # [n, 3] int32: score, as, ae
+            it["first_reads"] = a[:8].tolist()
+        out[name] = {"matrix": kw["matrix"], "inputs_sha256": hashlib.sha256(stored.tobytes() + rc.tobytes() + as_.tobytes()).hexdigest(), "iterations": its}
+        print(name, [it["cons_len"] for it in its])
+    with open(os.path.join(G, "iter_push.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp)
+
+
 NEAND_ADAPT = "GTCAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG"     # src/mia_main.c:462-463 (data, quoted for the inputs)
 STAND_ADAPT = "CTGAGACACGCAACAGGGGATAGGCAAGGCACACAGGGGATAGG"
 
@@ -541,6 +602,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ccheck":      # only the ccheck inputs and reports
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
         ccheck_cases(os.path.join(G, "mt311.fa"))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "iter_push":   # only the per-iteration loop on pushed reads
+        iter_push_cases()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "g2":          # only the 2 000-read whole runs
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
