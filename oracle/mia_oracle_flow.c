@@ -799,11 +799,37 @@ void ora_iterate(ora_state *st, const char *new_ref, int iter_num) {
   sort_culled(st);
 }
 
+/* The reference scans ALL records for every column (src/mia.c:576-595, src/map_align.c:463-495: O(L*N)).  The records
+ * that can cover column `pos` are those with start <= pos <= end; when the list is sorted by start (sort_aln_frags ran:
+ * every caller here) they lie in the index range [lo, hi) with hi = first record starting beyond pos and lo = first
+ * record starting at or after pos - (longest record span).  Scanning that range in list order adds the same bases in
+ * the same order as the full scan -- the records left out fail the reference's own test.  An unsorted list is scanned
+ * in full. */
+typedef struct { int sorted, maxspan, lo, hi; } col_window;
+
+static void window_init(const ora_state *st, col_window *w) {
+  int j;
+  w->sorted = 1; w->maxspan = 0; w->lo = 0; w->hi = 0;
+  for (j = 0; j < st->culled_n; j++) {
+    const ora_alnseq *a = st->slots[st->culled[j]];
+    if (j > 0 && st->slots[st->culled[j - 1]]->start > a->start) w->sorted = 0;
+    if (a->end - a->start > w->maxspan) w->maxspan = a->end - a->start;
+  }
+}
+
+/* columns are visited in ascending order: both ends of the range only move forward */
+static void window_at(const ora_state *st, col_window *w, int pos, int *lo, int *hi) {
+  if (!w->sorted) { *lo = 0; *hi = st->culled_n; return; }
+  while (w->hi < st->culled_n && st->slots[st->culled[w->hi]]->start <= pos) w->hi++;
+  while (w->lo < w->hi && st->slots[st->culled[w->lo]]->start < pos - w->maxspan) w->lo++;
+  *lo = w->lo; *hi = w->hi;
+}
+
 /* find_ins_cons, src/map_align.c:444-510 (no `dropped` test) */
-static void insert_consensus(const ora_state *st, int pos, char *out) {
+static void insert_consensus(const ora_state *st, int pos, char *out, int lo, int hi) {
   int n = st->gaps[pos], i, j;
   ora_counts *bc = (ora_counts *)calloc((size_t)n, sizeof(ora_counts));
-  for (i = 0; i < st->culled_n; i++) {
+  for (i = lo; i < hi; i++) {
     const ora_alnseq *a = st->slots[st->culled[i]];
     const ora_pssm *pm;
     const char *ins;
@@ -823,17 +849,21 @@ char *ora_consensus(ora_state *st) {
   int num_gaps = 0, j, pos, o = 0;
   char *cons, ins_cons[ORA_MAX_ALN + 2];
   for (j = 0; j < st->seq_len; j++) num_gaps += st->gaps[j];
+  col_window w;
   cons = (char *)malloc((size_t)st->seq_len + num_gaps + 1);
+  window_init(st, &w);
   for (pos = 0; pos < st->seq_len; pos++) {
     ora_counts bc;
     char b;
+    int lo, hi;
+    window_at(st, &w, pos, &lo, &hi);
     if (st->gaps[pos] > 0 && pos > 0) {
-      insert_consensus(st, pos, ins_cons);
+      insert_consensus(st, pos, ins_cons, lo, hi);
       for (j = 0; j < st->gaps[pos]; j++)
         if (ins_cons[j] != '-' && ins_cons[j] != ' ') cons[o++] = ins_cons[j];
     }
     memset(&bc, 0, sizeof bc);
-    for (j = 0; j < st->culled_n; j++) {
+    for (j = lo; j < hi; j++) {
       const ora_alnseq *a = st->slots[st->culled[j]];
       if (a->start <= pos && a->end >= pos && !a->dropped)
         ora_add_base(a->seq[pos - a->start], &bc, a->revcom ? &st->rcanc : &st->anc, a->smp[pos - a->start]);
@@ -847,10 +877,14 @@ char *ora_consensus(ora_state *st) {
 
 void ora_column_tallies(ora_state *st, int *out) {
   int pos, j;
+  col_window w;
+  window_init(st, &w);
   for (pos = 0; pos < st->seq_len; pos++) {
     ora_counts bc;
+    int lo, hi;
+    window_at(st, &w, pos, &lo, &hi);
     memset(&bc, 0, sizeof bc);
-    for (j = 0; j < st->culled_n; j++) {
+    for (j = lo; j < hi; j++) {
       const ora_alnseq *a = st->slots[st->culled[j]];
       if (a->start <= pos && a->end >= pos && !a->dropped)
         ora_add_base(a->seq[pos - a->start], &bc, a->revcom ? &st->rcanc : &st->anc, a->smp[pos - a->start]);

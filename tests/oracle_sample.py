@@ -72,3 +72,53 @@ class PushedOracle:
 
     def close(self):
         self.lib.ora_free(self.st)
+
+
+def check_subset_iterations(mod, oracle, ref, circular, matrix_file, pssm, stored, rc, sk, as0, ae0, iters=3, expect_first=None, lens=None):
+    """A read set in a HIP context of its own and in a PushedOracle, iterated side by side from `ref`: after every
+    iteration EVERY read's (score, as, ae), the dropped marks, all ten tally words of every column
+    (consensus_assembly_string's BaseCounts, reference src/mia.c:576-595), ref->gaps and the consensus string must be
+    equal.  expect_first: (score, as, ae) these reads got in iteration 1 inside a larger batch -- per-read results do not
+    depend on the company, so this pins the larger batch's reads to the oracle as well.  Returns the number of
+    iterations run and the final consensus."""
+    n = len(rc)
+    width = stored.shape[1]
+    hip = mod.MiaHip(0)
+    hip.set_pssm(pssm)
+    if lens is None:
+        offsets = np.arange(n + 1, dtype=np.int64) * width
+        hip.upload_reads(stored.reshape(-1), offsets, rc, sk, as0, ae0)
+    else:
+        offsets = np.zeros(n + 1, np.int64)
+        offsets[1:] = np.cumsum(lens)
+        flat = np.concatenate([stored[i, : lens[i]] for i in range(n)])
+        hip.upload_reads(flat, offsets, rc, sk, as0, ae0)
+    po = PushedOracle(oracle, ref, circular, matrix_file, stored, rc, as0, ae0, sk=sk, lens=lens)
+    known = sk.astype(bool)
+    cur, done = ref, 0
+    for it in range(1, iters + 1):
+        cons = hip.iterate(cur, circular)
+        po.iterate(cur)
+        h = hip.alignments()
+        o = po.alignments()
+        for k, name in enumerate(("score", "as", "ae")):
+            bad = np.nonzero((h[k] != o[k]) & known)[0]
+            assert len(bad) == 0, (it, name, len(bad), bad[:5].tolist(), h[k][bad[:5]].tolist(), o[k][bad[:5]].tolist())
+        if it == 1 and expect_first is not None:
+            for k in range(3):
+                assert np.array_equal(h[k][known], expect_first[k][known]), (it, k)
+        assert np.array_equal(hip.dropped()[0][known].astype(bool), po.dropped()[known].astype(bool)), it
+        L = len(cur)
+        t, g = hip.get_tally()
+        et, eg = po.tallies()
+        assert np.array_equal(g[:L], eg), it
+        bad = np.nonzero((t[:10, :L].T != et).any(axis=1))[0]
+        assert len(bad) == 0, (it, "tally columns", len(bad), bad[:5].tolist())
+        assert cons == po.consensus(), it
+        done = it
+        if cons == cur:
+            break
+        cur = cons
+    po.close()
+    hip.close()
+    return done, cur

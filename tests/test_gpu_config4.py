@@ -5,7 +5,9 @@ region (seed 5), linear (no -c: src/mia_main.c:645 appends no wrap), matrices/an
 * pass 1 with the k-mer filter, the first realignment (against the region itself) and the second (against the batch's
   consensus) of a random sample are compared with the oracle read by read;
 * a context with every shortcut switched off must return the same score, end points and script for every read;
-* re-aligning is idempotent, the tally is linear over a split of the read set, the iteration reaches a fixed point.
+* re-aligning is idempotent, the tally is linear over a split of the read set, the iteration reaches a fixed point;
+* 4 000 reads of the batch through both of its realignments against the oracle, and a 20 000-read subset iterated side by
+  side with the oracle (every read, dropped marks, tallies, gaps, consensus).
 The whole-run identity against the reference's own mia on 2 000 such reads is tests/test_gpu_g2.py::g2_c4.
 
 MIA_CONFIG4_READS overrides the read count."""
@@ -18,6 +20,7 @@ import pytest
 import gen_data
 import oracle_ctypes as oc
 from conftest import GOLDEN
+from oracle_sample import PushedOracle, check_subset_iterations
 
 pytestmark = pytest.mark.gpu
 
@@ -226,3 +229,28 @@ def test_window_tally_equals_plain_atomic_tally(full):
         assert np.array_equal(t[w], f.tally2[w]), w
     assert hip.consensus(1) == f.cons2
     hip.close()
+
+
+def test_big_sample_of_the_batch_against_oracle(full, oracle):
+    """4 000 reads of the batch (pass-1 coordinates from the GPU, themselves pinned by the 120-read sample above) through
+    both realignments -- against the region and against the batch's consensus -- read by read against the oracle"""
+    f = full
+    pick = np.sort(np.random.default_rng(31).choice(f.n, min(4000, f.n), replace=False))
+    po = PushedOracle(oracle, f.ref, False, "ancient.submat.txt", f.stored[pick], f.rc[pick], f.as0[pick], f.ae0[pick], sk=f.sk[pick])
+    known = f.sk[pick].astype(bool)
+    for it, (ref, al) in enumerate(((f.ref, f.al1), (f.cons1, f.al2)), 1):
+        po.iterate(ref)
+        o = po.alignments()
+        for k in range(3):
+            bad = np.nonzero((al[k][pick] != o[k]) & known)[0]
+            assert len(bad) == 0, (it, k, len(bad), pick[bad[:5]].tolist())
+    po.close()
+
+
+def test_subset_iterations_against_oracle(full, oracle):
+    f = full
+    pick = np.sort(np.random.default_rng(32).choice(f.n, min(20_000, f.n), replace=False))
+    first = tuple(a[pick] for a in f.al1)
+    done, _ = check_subset_iterations(f.mod, oracle, f.ref, False, "ancient.submat.txt", f.pssm, f.stored[pick], f.rc[pick], f.sk[pick], f.as0[pick],
+                                      f.ae0[pick], iters=3, expect_first=first)
+    assert done >= 2

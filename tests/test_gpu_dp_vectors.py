@@ -1,8 +1,9 @@
 """The reference's own DP answers (tests/golden/dp_vectors.txt, dumped from the real
 dyn_prog/max_sg_score/find_align_begin/populate_pwaln_to_begin) replayed through the C ABI:
 each vector becomes a one-read realign call whose window is the whole (linear) reference.
-Covers all three window classes (<=256, <=512, <=768 columns), gaps >= 63 (byte-trace escape
--> exact wide kernel) and windows > 768 columns (wide kernel directly)."""
+tests/golden/dp_vectors_wide.txt adds what the first file is thin on: windows of 257-512, 513-768 and more than 768
+columns (the three one-read-per-wavefront classes, the exact scalar kernel) and gaps of 63 and more on the best path
+(byte-trace escape -> exact kernel); the counts at the end make sure each of them was really exercised."""
 import numpy as np
 import pytest
 
@@ -16,7 +17,8 @@ def test_dp_vectors_through_abi():
     import mia_amd
     flat = mia_amd.flat_pssm()
     anc = mia_amd.read_pssm(__import__("os").path.join(__import__("conftest").GOLDEN, "ancient.submat.txt"))
-    n_run = n_long = n_wide = 0
+    n_run = n_long = 0
+    n_class = [0, 0, 0, 0]
     hips = {}
     for inp, exp in dp_cases():
         _, spec, rc, sg5, _sg3, s1, s2, mask = inp.split(" ")
@@ -44,9 +46,9 @@ def test_dp_vectors_through_abi():
             c = np.where(c >= 0, c + int(rstart[0]), c)
             r, f = script_to_strings(s1, s2, c, abr, aer)
             assert (r, f) == (e[8], e[9]), inp[:90]
-            n_long += max(len(x) for x in e[8].split("-") + e[9].split("-")) >= 0 and ("-" * 63 in e[8] or "-" * 63 in e[9])
-        n_wide += len(s1) > 768
+            n_long += ("-" * 63 in e[8]) or ("-" * 63 in e[9])
+        n_class[0 if len(s1) <= 256 else 1 if len(s1) <= 512 else 2 if len(s1) <= 768 else 3] += 1
         n_run += 1
-    assert n_run > 100 and n_long >= 1 and n_wide >= 0
+    assert n_run > 150 and n_long >= 6 and min(n_class) >= 8, (n_run, n_long, n_class)
     for h in hips.values():
         h.close()

@@ -17,6 +17,7 @@ import pytest
 import gen_data
 import oracle_ctypes as oc
 from conftest import GOLDEN
+from oracle_sample import PushedOracle, check_subset_iterations
 
 pytestmark = pytest.mark.gpu
 
@@ -257,3 +258,41 @@ def test_diag_filter_changes_nothing(full):
     as0 = start.astype(np.int32)
     ae0 = (start + 99).astype(np.int32)
     both(ref2, stored, soff, strand.astype(np.uint8), np.ones(m, np.uint8), as0, ae0, 0.3)
+
+
+def test_subset_iterations_against_oracle(full, oracle):
+    """100 000 reads of the batch in a context of their own, three iterations from mt311 side by side with the oracle:
+    every read's (score, as, ae), the dropped marks, all ten tally words of every column, ref->gaps and the consensus;
+    the first iteration also against what the same reads got inside the 1 M batch"""
+    f = full
+    pick = np.sort(np.random.default_rng(21).choice(f.n, min(100_000, f.n), replace=False))
+    first = tuple(a[pick] for a in f.al)
+    done, _ = check_subset_iterations(f.mod, oracle, f.ref, True, None, f.mod.flat_pssm(), f.stored[pick], f.rc[pick], f.sk[pick], f.as0[pick], f.ae0[pick],
+                                      iters=3, expect_first=first)
+    assert done >= 2
+
+
+def test_big_sample_of_the_batch_against_oracle(full, oracle):
+    """the whole 1 M batch iterated twice in a fresh context (mt311, then its own consensus: plain bases, where the plan
+    finishes four reads in five without a DP); 50 000 of its reads through both realignments against the oracle"""
+    f = full
+    hip = f.mod.MiaHip(0)
+    hip.set_pssm(f.mod.flat_pssm())
+    hip.upload_reads(f.stored.reshape(-1), f.soff, f.rc, f.sk, f.as0, f.ae0)
+    cons1 = hip.iterate(f.ref, True)
+    al1 = hip.alignments()
+    hip.iterate(cons1, True)
+    al2 = hip.alignments()
+    hip.close()
+    for a, b in zip(al1, f.al):
+        assert np.array_equal(a, b)
+    pick = np.sort(np.random.default_rng(22).choice(f.n, min(50_000, f.n), replace=False))
+    po = PushedOracle(oracle, f.ref, True, None, f.stored[pick], f.rc[pick], f.as0[pick], f.ae0[pick], sk=f.sk[pick])
+    known = f.sk[pick].astype(bool)
+    for it, (ref, al) in enumerate(((f.ref, al1), (cons1, al2)), 1):
+        po.iterate(ref)
+        o = po.alignments()
+        for k in range(3):
+            bad = np.nonzero((al[k][pick] != o[k]) & known)[0]
+            assert len(bad) == 0, (it, k, len(bad), pick[bad[:5]].tolist())
+    po.close()

@@ -6,7 +6,10 @@ find_sm_depth, src/pssm.c:6-46; the strand picks the matrix, src/mia_main.c:179-
   SECOND realignment (against the consensus of the whole batch -- plain bases, where the band pipeline of
   csrc/bandx_body.h takes nearly every read) of a random sample are compared with the oracle read by read;
 * a context with every shortcut switched off must return the same score, end points and script for every read;
-* re-aligning is idempotent, the tally is linear over a split of the read set, the iteration reaches a fixed point.
+* re-aligning is idempotent, the tally is linear over a split of the read set, the iteration reaches a fixed point;
+* a 100 000-read subset in a context of its own, iterated from mt311 side by side with the oracle: every read's result,
+  the dropped marks, all ten tally words of every column, ref->gaps and the consensus, every iteration -- and, for 50 000
+  reads of the full batch, the second realignment (against the full batch's consensus) read by read.
 
 MIA_FULLSIZE_READS overrides the read count."""
 import ctypes as C
@@ -18,6 +21,7 @@ import pytest
 import gen_data
 import oracle_ctypes as oc
 from conftest import GOLDEN
+from oracle_sample import PushedOracle, check_subset_iterations
 
 pytestmark = pytest.mark.gpu
 
@@ -231,3 +235,30 @@ def test_window_tally_equals_plain_atomic_tally(full):
         assert np.array_equal(t[w], f.tally2[w]), w
     assert hip.consensus(1) == f.cons2
     hip.close()
+
+
+def test_subset_iterations_against_oracle(full, oracle):
+    """100 000 reads of the batch, three iterations from mt311: alignments of every read, dropped marks, tallies, gaps
+    and consensus against the oracle; the first iteration also against what the same reads got inside the 1 M batch"""
+    f = full
+    pick = np.sort(np.random.default_rng(21).choice(f.n, min(100_000, f.n), replace=False))
+    first = tuple(a[pick] for a in f.al1)
+    done, _ = check_subset_iterations(f.mod, oracle, f.ref, True, f.spec, f.pssm, f.stored[pick], f.rc[pick], f.sk[pick], f.as0[pick], f.ae0[pick],
+                                      iters=3, expect_first=first)
+    assert done >= 2
+
+
+def test_big_sample_of_the_batch_against_oracle(full, oracle):
+    """50 000 reads of the 1 M batch through both of ITS realignments -- against mt311 and against the batch's own
+    consensus (plain bases: the band pipeline's home ground) -- read by read against the oracle"""
+    f = full
+    pick = np.sort(np.random.default_rng(22).choice(f.n, min(50_000, f.n), replace=False))
+    po = PushedOracle(oracle, f.ref, True, f.spec, f.stored[pick], f.rc[pick], f.as0[pick], f.ae0[pick], sk=f.sk[pick])
+    known = f.sk[pick].astype(bool)
+    for it, (ref, al) in enumerate(((f.ref, f.al1), (f.cons1, f.al2)), 1):
+        po.iterate(ref)
+        o = po.alignments()
+        for k in range(3):
+            bad = np.nonzero((al[k][pick] != o[k]) & known)[0]
+            assert len(bad) == 0, (it, k, len(bad), pick[bad[:5]].tolist())
+    po.close()

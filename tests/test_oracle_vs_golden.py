@@ -41,10 +41,13 @@ def _pssm(lib, spec, rc, cache={}):
     return cache[key]
 
 
-def dp_cases():
-    with open(os.path.join(GOLDEN, "dp_vectors.txt")) as f:
-        lines = [l.rstrip("\n") for l in f if not l.startswith("#")]
-    return list(zip(lines[0::2], lines[1::2]))
+def dp_cases(files=("dp_vectors.txt", "dp_vectors_wide.txt")):
+    out = []
+    for name in files:
+        with open(os.path.join(GOLDEN, name)) as f:
+            lines = [l.rstrip("\n") for l in f if not l.startswith("#")]
+        out += list(zip(lines[0::2], lines[1::2]))
+    return out
 
 
 def test_dp_vectors(oracle):

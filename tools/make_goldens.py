@@ -102,6 +102,58 @@ def dp_vectors():
             f.write(a.replace(anc, "ancient.submat.txt") + "\n" + b + "\n")
 
 
+def dp_vectors_wide():
+    """More of the reference's own dyn_prog answers where dp_vectors.txt is thin: windows of 257-512, 513-768 and more than
+    768 columns (the three one-read-per-wavefront classes and the exact scalar kernel of the GPU path), gaps of 63 and
+    more on the optimal path in either direction (the byte trace's escape), both matrices and both strands; all-ones
+    mask and sg5 = 1 as reiterate_assembly aligns (src/mia_main.c:190-252).  Alignments stay below the 512 characters
+    populate_pwaln_to_begin's buffers hold."""
+    rnd = random.Random(20261004)
+    anc = os.path.join(G, "ancient.submat.txt")
+    lines = []
+
+    def rseq(n, alphabet="ACGT"):
+        return "".join(rnd.choice(alphabet) for _ in range(n))
+
+    def noisy(s, p):
+        out = []
+        for ch in s:
+            u = rnd.random()
+            if u < p / 4:
+                continue
+            if u < p / 2:
+                out.append(rnd.choice("ACGT"))
+            out.append(rnd.choice("ACGT") if u < p else ch)
+        return "".join(out) or "A"
+
+    k = 0
+    for lo, hi in ((257, 512), (513, 768), (769, 1500)):
+        for _ in range(12):
+            len1 = rnd.randint(lo, hi)
+            len2 = rnd.choice([36, 60, 100, 100, 150, 200, 250])
+            s1 = rseq(len1, "ACGT" if k % 4 else "ACGTNRY")
+            st = rnd.randint(0, len1 - len2)
+            s2 = noisy(s1[st:st + len2].replace("R", "A").replace("Y", "C").replace("N", "G"), rnd.choice([0.02, 0.08, 0.2]))[:256]
+            lines.append(f"D {['flat', anc][k % 2]} {1 if k % 3 == 0 else 0} 1 1 {s1} {s2} *")
+            k += 1
+    for g in (63, 64, 80, 130, 220, 300):       # a deletion of g columns / an insertion of g read bases on the best path
+        left, right = rseq(70), rseq(70)
+        pad_l, pad_r = rseq(rnd.randint(10, 300)), rseq(rnd.randint(10, 300))
+        lines.append(f"D {['flat', anc][g % 2]} 0 1 1 {pad_l + left + rseq(g) + right + pad_r} {left + right} *")
+        if g <= 110:
+            s2 = left + rseq(g) + right
+            lines.append(f"D flat {g % 2} 1 1 {pad_l + left + right + pad_r} {s2[:256]} *")
+    inp = "\n".join(lines) + "\n"
+    out = subprocess.run([os.path.join(RB, "ref_dp_driver")], input=inp.encode(), stdout=subprocess.PIPE, check=True).stdout.decode()
+    outs = out.strip().split("\n")
+    assert len(outs) == len(lines)
+    with open(os.path.join(G, "dp_vectors_wide.txt"), "w") as f:
+        f.write("# as dp_vectors.txt: input line (oracle/ref_dp_driver.c), then the reference's answer\n")
+        for a, b in zip(lines, outs):
+            f.write(a.replace(anc, "ancient.submat.txt") + "\n" + b + "\n")
+    print(len(lines), "wide DP vectors")
+
+
 def cons_vectors():
     rnd = random.Random(7)
     lines = []
@@ -602,6 +654,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ccheck":      # only the ccheck inputs and reports
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
         ccheck_cases(os.path.join(G, "mt311.fa"))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "dp_wide":     # only the wide-window / long-gap DP vectors
+        dp_vectors_wide()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "iter_push":   # only the per-iteration loop on pushed reads
         iter_push_cases()
