@@ -11,6 +11,7 @@
 // "OUT OF SCOPE": -T -a -u -U -A -C -h -D -I -q) are rejected with a message
 // instead of being silently ignored.
 #include <ctype.h>
+#include <fcntl.h>
 #include <getopt.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -28,6 +29,7 @@
 #include <vector>
 
 #include "../../include/mia_hip.h"
+#include "ingest.h"
 
 namespace {
 
@@ -123,57 +125,7 @@ bool read_fasta_ref(const char* fn, Ref* r) {   // src/io.c:287-386
   return true;
 }
 
-struct Read { std::string id, desc, seq; int trimmed = 0; };
-
-// read_fasta / read_fastq, src/io.c:35-281 (including the doubled first description character
-// of read_fasta, src/io.c:228-234, and the 256-base truncation)
-bool next_record(FILE* f, bool fastq, Read* r) {
-  r->id.clear(); r->desc.clear(); r->seq.clear();
-  int c = getc_unlocked(f);
-  if (c == EOF) return false;
-  if (c != (fastq ? '@' : '>')) {
-    if (fastq) fprintf(stderr, "While reading fastq file, saw record not beginning with @\nMaybe badly formed input? Continuing, anyway...\n");
-    return false;
-  }
-  while (!isspace(c = getc_unlocked(f)) && (int)r->id.size() < MAX_ID_LEN) {
-    if (c == EOF) return false;
-    r->id.push_back((char)c);
-  }
-  if (c != '\n') {
-    while (c != '\n' && isspace(c)) c = getc_unlocked(f);
-    if (!fastq && c != '\n') r->desc.push_back((char)c);
-    while (c != '\n' && c != EOF && (int)r->desc.size() < MAX_DESC_LEN) { r->desc.push_back((char)c); c = getc_unlocked(f); }
-  }
-  c = getc_unlocked(f);
-  if (!fastq) {
-    while (c != '>' && c != EOF && (int)r->seq.size() < MAX_READ) {
-      if (!isspace(c)) r->seq.push_back((char)toupper(c));
-      c = getc_unlocked(f);
-    }
-    if (c == '>') { ungetc('>', f); return true; }
-    if ((int)r->seq.size() == MAX_READ) {
-      while (c != '>' && c != EOF) c = getc_unlocked(f);
-      if (c == '>') ungetc('>', f);
-      fprintf(stderr, "%s is longer than allowed length: %d\n", r->id.c_str(), MAX_READ);
-    }
-    return true;
-  }
-  while (c != '\n' && c != EOF && (int)r->seq.size() < MAX_READ) {
-    if (!isspace(c)) r->seq.push_back((char)toupper(c));
-    c = getc_unlocked(f);
-  }
-  if ((int)r->seq.size() == MAX_READ) while (c != '\n' && c != EOF) c = getc_unlocked(f);
-  c = getc_unlocked(f);
-  if (c != '+') { fprintf(stderr, "Problem reading quality line for %s\n", r->id.c_str()); return true; }
-  c = getc_unlocked(f);
-  while (c != '\n' && c != EOF) c = getc_unlocked(f);
-  int q = 0;
-  c = getc_unlocked(f);
-  while (c != '\n' && c != EOF && q < MAX_READ) { if (!isspace(c)) q++; c = getc_unlocked(f); }
-  if (q == MAX_READ) while (c != '\n' && c != EOF) c = getc_unlocked(f);
-  if (q != (int)r->seq.size()) { fprintf(stderr, "%s has unequal sequence and qual line lengths\n", r->id.c_str()); return false; }
-  return true;
-}
+using ingest::Read;      // one input record (host/ingest.h: the reference's reader, on all host threads)
 
 // One fsdb entry (FragSeq, src/types.h:110-143) -- only what the path needs.
 struct Frag {
@@ -181,24 +133,6 @@ struct Frag {
   int rc, strand_known, as, ae, score;
   int trimmed = 0;             // adapter found by trim_frag: seq is already cut at the trim point (src/fsdb.c:199-203)
 };
-
-// AlnSeq as it is printed (src/types.h:61-76)
-struct Record {
-  std::string id, desc, seq, smp;
-  std::vector<std::pair<int, std::string>> ins;
-  int start, end, score, rc, dropped;
-  int trimmed = 0;
-  char segment;
-};
-
-// host-side fan-out for the per-read text work (.maln records); MIA_HIP_THREADS overrides
-int worker_threads(int items) {
-  int t = (int)std::thread::hardware_concurrency();
-  if (const char* e = getenv("MIA_HIP_THREADS")) t = atoi(e);
-  if (t > 64) t = 64;
-  if (t > items / 2048) t = items / 2048;
-  return t < 1 ? 1 : t;
-}
 
 template <class F>
 void run_parallel(int T, F&& fn) {
@@ -313,11 +247,13 @@ int main(int argc, char** argv) {
       for (int j = 0; j < k; j++)
         if (gpus[(size_t)j] == gpus[(size_t)k]) { fprintf(stderr, "mia_hip: -g lists GPU %d twice beside other GPUs (list every GPU once, or one GPU several times)\n", gpus[(size_t)k]); exit(1); }
   std::vector<mia_hip_ctx*> G((size_t)NG, nullptr);
-  for (int k = 0; k < NG; k++) {
-    if (mia_hip_create(&G[(size_t)k], gpus[(size_t)k]) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: no usable MI355X (gfx950) device %d; there is no CPU fallback\n", gpus[(size_t)k]); exit(1); }
-    if (mia_hip_set_pssm(G[(size_t)k], &anc.sm[0][0][0], &rcanc.sm[0][0][0]) != MIA_HIP_OK) die(G[(size_t)k], "set_pssm");
-  }
-  mia_hip_ctx* g = G[0];
+  // (the HIP runtime takes a third of a second to come up: that happens beside the parsing of the input)
+  std::thread gpu_init([&] {
+    for (int k = 0; k < NG; k++) {
+      if (mia_hip_create(&G[(size_t)k], gpus[(size_t)k]) != MIA_HIP_OK) { fprintf(stderr, "mia_hip: no usable MI355X (gfx950) device %d; there is no CPU fallback\n", gpus[(size_t)k]); fflush(stderr); _exit(1); }
+      if (mia_hip_set_pssm(G[(size_t)k], &anc.sm[0][0][0], &rcanc.sm[0][0][0]) != MIA_HIP_OK) die(G[(size_t)k], "set_pssm");
+    }
+  });
   auto on_gpus = [&](const std::function<void(int)>& fn) {      // fn(k) for every GPU k, concurrently (the collectives need that)
     if (NG == 1) { fn(0); return; }
     std::vector<std::thread> th;
@@ -326,23 +262,27 @@ int main(int argc, char** argv) {
   };
   auto share = [&](int64_t total, int k) { return total * k / NG; };    // first item of GPU k's contiguous share
 
-  // ---- read the fragments (read_next_seq loop, src/mia_main.c:759)
-  FILE* ff = fopen(frag_fn.c_str(), "r");
-  if (!ff) { fprintf(stderr, "Cannot open %s\n", frag_fn.c_str()); exit(1); }
-  int c0 = fgetc(ff);
-  if (c0 != EOF) ungetc(c0, ff);
-  const bool fastq = (c0 == '@');   // find_input_type, src/io.c:11-26
-  lap("init");
+  // ---- read the fragments (read_next_seq loop, src/mia_main.c:759): the reference's character-level reader, run over the
+  //      mapped file on all host threads at once (host/ingest.h); MIA_HIP_THREADS=1 is the plain sequential walk
   std::vector<Read> reads;
+  bool fastq = false;
   {
-    // same character-level state machine as the reference's reader, on an 8 MB unlocked stdio buffer
-    std::vector<char> iobuf((size_t)8 << 20);
-    setvbuf(ff, iobuf.data(), _IOFBF, iobuf.size());
-    Read r;
-    while (next_record(ff, fastq, &r)) { reads.emplace_back(); std::swap(reads.back(), r); }
-    fclose(ff);
+    int T = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("MIA_HIP_THREADS")) T = atoi(e);
+    if (T > 64) T = 64;
+    std::string msgs;
+    const auto ti = std::chrono::steady_clock::now();
+    if (!ingest::read_all(frag_fn.c_str(), T, &reads, &fastq, &msgs)) { fprintf(stderr, "Cannot open %s\n", frag_fn.c_str()); exit(1); }
+    fputs(msgs.c_str(), stderr);
+    if (timing) {
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count();
+      fprintf(stderr, "[mia_hip timing] read input alone       %9.1f ms  (%zu records, %.1f M records/s, beside the GPU start-up)\n", ms, reads.size(), reads.size() / ms / 1e3);
+    }
   }
-  lap("read input");
+  (void)fastq;
+  gpu_init.join();
+  mia_hip_ctx* g = G[0];
+  lap("init + read input");
   fprintf(stderr, "Starting to align sequences to the reference...\n");
 
   // ---- adapter trimming (trim_frag, src/mia_main.c:771-775): the read ends at the trim point from here on
@@ -408,10 +348,6 @@ int main(int argc, char** argv) {
     f.id = std::move(r.id); f.desc = std::move(r.desc); f.seq = std::move(r.seq); f.trimmed = r.trimmed;
     f.rc = p_rc[k]; f.strand_known = (p_fl[k] & MIA_HIP_P1_STRAND_KNOWN) ? 1 : 0;
     f.as = p_as[k]; f.ae = p_ae[k]; f.score = p_score[k];
-    if (f.rc && f.strand_known) {
-      std::reverse(f.seq.begin(), f.seq.end());
-      for (auto& ch : f.seq) ch = revcom_char(ch);
-    }
     if (!f.strand_known) n_unknown++;
     first_slot.push_back((int)slot_dropped.size());
     slot_dropped.push_back(0);
@@ -420,6 +356,21 @@ int main(int argc, char** argv) {
     fsdb.push_back(std::move(f));
   }
   const int n = (int)fsdb.size();
+  {
+    // reverse-strand reads are kept reverse-complemented from here on (add_virgin_fs2fsdb, src/fsdb.c:209-227)
+    int T = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("MIA_HIP_THREADS")) T = atoi(e);
+    T = std::max(1, std::min(std::min(T, 64), n / 8192 + 1));
+    run_parallel(T, [&](int t) {
+      for (int i = (int)((int64_t)n * t / T), hi = (int)((int64_t)n * (t + 1) / T); i < hi; i++) {
+        Frag& f = fsdb[(size_t)i];
+        if (f.rc && f.strand_known) {
+          std::reverse(f.seq.begin(), f.seq.end());
+          for (auto& ch : f.seq) ch = revcom_char(ch);
+        }
+      }
+    });
+  }
   const int pass1_records = (int)slot_dropped.size();   // culled_maln->size, frozen here (src/mia.c:54)
   if (n == 0) { fprintf(stderr, "No sequence aligned to the reference with a score of at least 2000.\n"); for (auto* c : G) mia_hip_destroy(c); exit(0); }
   if (NG > n) { fprintf(stderr, "mia_hip: more GPUs (%d) than reads in the store (%d)\n", NG, n); exit(1); }
@@ -544,156 +495,190 @@ int main(int argc, char** argv) {
     });
     gaps.assign((size_t)L + 1, 0);
     if (mia_hip_get_tally(g, NULL, gaps.data()) != MIA_HIP_OK) die(g, "get_tally");
-    // records of reads [lo, hi), in cull order (front record, then back record)
-    auto build_range = [&](int lo, int hi, std::vector<Record>& recs) {
-    for (int i = lo; i < hi; i++) {
-      const Frag& f = fsdb[i];
-      if (!f.strand_known) continue;
-      const int16_t* cs = &cols[(size_t)i * stride];
-      const int len2 = (int)f.seq.size();
-      // the two gapped strings of populate_pwaln_to_begin (src/mia.c:1440-1497)
-      std::string rg, fg;
-      int prev = -1;
-      for (int r = 0; r < len2; r++) {
-        if (cs[r] == MIA_HIP_COL_CLIP) continue;
-        if (cs[r] == MIA_HIP_COL_INSERT) { rg.push_back('-'); fg.push_back(f.seq[r]); continue; }
-        const int gc = rstart[i] + cs[r];
-        if (prev >= 0) for (int k = prev + 1; k < gc; k++) { rg.push_back(wrapped[(size_t)k]); fg.push_back('-'); }
-        rg.push_back(wrapped[(size_t)gc]); fg.push_back(f.seq[r]);
-        prev = gc;
-      }
+    // ---- the AlnSeq records of this iteration, by slot (merge order: front record, then back record of every strand-known
+    //      read, src/map_align.c:866-954).  Start and end follow from the alignment's end points alone, so the records can be
+    //      listed, culled and sorted before a single character of them is formatted.
+    std::vector<int32_t> rec_read, rec_start, rec_end;
+    std::vector<uint8_t> rec_half;                 // 0: whole read ('a') or front ('f'), 1: back ('b')
+    std::vector<int32_t> first_rec((size_t)n + 1, 0);
+    rec_read.reserve((size_t)n + 1024); rec_start.reserve((size_t)n + 1024); rec_end.reserve((size_t)n + 1024); rec_half.reserve((size_t)n + 1024);
+    for (int i = 0; i < n; i++) {
+      first_rec[(size_t)i] = (int32_t)rec_read.size();
+      if (!fsdb[i].strand_known) continue;
       int start = as[i], end = ae[i];
       if (end > L) end -= L;                      // src/mia_main.c:259-263
-      auto build = [&](const std::string& r, const std::string& q, int st, int en, char seg, int dropped, const std::string& id) {
-        Record a;   // merge_pwaln_into_maln, src/map_align.c:866-954
-        a.id = id; a.desc = f.desc; a.start = st; a.end = en; a.score = score[i]; a.rc = f.rc; a.dropped = dropped; a.segment = seg; a.trimmed = f.trimmed;
-        std::string cur; bool in = false;
-        for (size_t k = 0; k < r.size(); k++) {
-          if (r[k] == '-') { cur.push_back(q[k]); in = true; }
-          else { if (in) { a.ins.push_back({(int)a.seq.size(), cur}); cur.clear(); in = false; } a.seq.push_back(q[k]); }
-        }
-        return a;
-      };
-      size_t first = recs.size();
       if (start > end) {                          // split_pwaln, src/mia.c:1376-1438
-        int rp = start; size_t ap = 0;
-        while (rp < L && ap < rg.size()) { if (rg[ap] != '-') rp++; ap++; }
-        std::string idf = f.id.substr(0, (size_t)MAX_ID_LEN - 1) + "_f", idb = f.id.substr(0, (size_t)MAX_ID_LEN - 1) + "_b";
-        recs.push_back(build(rg.substr(0, ap), fg.substr(0, ap), start, L - 1, 'f', dF[i], idf));
-        recs.push_back(build(rg.substr(ap), fg.substr(ap), 0, end, 'b', dB[i], idb));
-      } else recs.push_back(build(rg, fg, start, end, 'a', dF[i], f.id));
-      // pop_smp_from_FSDB (src/fsdb.c:542-619) for this read's record(s).  The depth code of a column reached after
-      // `a` bases of its record is depth(q[0] + q[1] + a, q[2] - (q[1] + a) - 1); q = {0, 0, flen+blen} for a front
-      // record and {flen, bases in the front, flen+blen} for a back record, unless a formerly split read further
-      // down the fsdb overwrote the codes through its stale back_asp (mia_hip_get_record_params).
-      Record& fa = recs[first];
-      Record* ba = recs.size() - first == 2 ? &recs[first + 1] : nullptr;
-      auto fill = [&](Record& a, const int32_t* q) {
-        const int span = a.end - a.start + 1;
-        size_t ii = 0;
-        int act = 0;
-        for (int p = 0; p < span; p++) {
-          while (ii < a.ins.size() && a.ins[ii].first < p) ii++;
-          if (ii < a.ins.size() && a.ins[ii].first == p) act += (int)a.ins[ii].second.size();
-          const int dff = q[0] + q[1] + act, dfb = q[2] - (q[1] + act) - 1;
-          char code = dff <= PSSM_DEPTH ? (char)('A' + dff) : (dfb < PSSM_DEPTH ? (char)('A' + 2 * PSSM_DEPTH - dfb) : (char)('A' + PSSM_DEPTH));
-          a.smp.push_back(code);
-          if (p < (int)a.seq.size() && a.seq[(size_t)p] != '-') act++;
-        }
-      };
-      fill(fa, &rparams[(size_t)i * 8]);
-      if (ba) fill(*ba, &rparams[(size_t)i * 8 + 4]);
+        rec_read.push_back(i); rec_half.push_back(0); rec_start.push_back(start); rec_end.push_back(L - 1);
+        rec_read.push_back(i); rec_half.push_back(1); rec_start.push_back(0); rec_end.push_back(end);
+      } else {
+        rec_read.push_back(i); rec_half.push_back(0); rec_start.push_back(start); rec_end.push_back(end);
+      }
     }
-    };
-    // reads are independent: build on all host threads, keep the order
-    const int T = worker_threads(n);
-    std::vector<std::vector<Record>> part((size_t)T);
-    run_parallel(T, [&](int t) { build_range((int)((int64_t)n * t / T), (int)((int64_t)n * (t + 1) / T), part[(size_t)t]); });
-    std::vector<Record> recs;
-    {
-      size_t tot = 0;
-      for (auto& v : part) tot += v.size();
-      recs.reserve(tot);
-      for (auto& v : part) { for (auto& a : v) recs.push_back(std::move(a)); std::vector<Record>().swap(v); }
-    }
+    first_rec[(size_t)n] = (int32_t)rec_read.size();
+    const size_t n_recs = rec_read.size();
     // cull_maln_from_fsdb (src/mia.c:451-481): front_asp of every read, then back_asp if it is not NULL.  back_asp is
     // never cleared (src/mia_main.c:259-276): for a read that is not split any more it addresses the record that
     // sits in that slot NOW, which is thereby listed twice.
-    std::vector<int> order;
-    {
-      std::vector<int> slot_rec;                 // AlnSeq slot -> record
-      slot_rec.reserve(recs.size());
-      for (size_t k = 0; k < recs.size(); k++) slot_rec.push_back((int)k);   // records are in merge (= slot) order
-      size_t k = 0;
-      order.reserve(recs.size() + 16);
-      for (int i = 0; i < n; i++) {
-        if (!fsdb[i].strand_known) {             // both pointers still address the pass-1 slots (src/mia_main.c:178)
-          if (f0[(size_t)i] >= 0 && f0[(size_t)i] < (int64_t)slot_rec.size()) order.push_back(slot_rec[(size_t)f0[(size_t)i]]);
-          if (back_slot[(size_t)i] >= 0 && back_slot[(size_t)i] < (int64_t)slot_rec.size()) order.push_back(slot_rec[(size_t)back_slot[(size_t)i]]);
-          continue;
-        }
-        const bool split = recs[k].segment == 'f';
-        order.push_back((int)k);
-        if (split) order.push_back((int)k + 1);
-        else if (back_slot[(size_t)i] >= 0) {
-          const int64_t sl = back_slot[(size_t)i];
-          if (sl < (int64_t)slot_rec.size()) order.push_back(slot_rec[(size_t)sl]);
-        }
-        k += split ? 2 : 1;
+    std::vector<int32_t> order;
+    order.reserve(n_recs + 16);
+    for (int i = 0; i < n; i++) {
+      if (!fsdb[i].strand_known) {               // both pointers still address the pass-1 slots (src/mia_main.c:178)
+        if (f0[(size_t)i] >= 0 && f0[(size_t)i] < (int64_t)n_recs) order.push_back((int32_t)f0[(size_t)i]);
+        if (back_slot[(size_t)i] >= 0 && back_slot[(size_t)i] < (int64_t)n_recs) order.push_back((int32_t)back_slot[(size_t)i]);
+        continue;
       }
+      const int32_t k = first_rec[(size_t)i];
+      const bool split = first_rec[(size_t)i + 1] - k == 2;
+      order.push_back(k);
+      if (split) order.push_back(k + 1);
+      else if (back_slot[(size_t)i] >= 0 && back_slot[(size_t)i] < (int64_t)n_recs) order.push_back((int32_t)back_slot[(size_t)i]);
     }
-    // sort_aln_frags: stable by (start, end) over cull order (src/map_align.c:393-414)
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-      if (recs[x].start != recs[y].start) return recs[x].start < recs[y].start;
-      return recs[x].end < recs[y].end;
-    });
-    FILE* mf = fopen(fn.c_str(), "w");
-    if (!mf) { fprintf(stderr, "Cannot write %s\n", fn.c_str()); exit(1); }
-    time_t t = time(NULL);
-    fprintf(mf, "/* map_alignment [V%s] */ %s", "1.0", asctime(localtime(&t)));
-    int size = L + 1;                             // src/mia_main.c:66, src/mia.c:669-675
-    if (circular) while (L + wl >= size) size *= 2;
-    fprintf(mf, "MALN_NAS %d\nMALN_SIZ %d\nMALN_COC %d\n__REFERENCE__\nID %s\nDESC %s\nLEN %d\nSIZE %d\nSEQ %s\nGAPS", (int)order.size(),
-            pass1_records, cc, ref_id.c_str(), ref_desc.c_str(), L, size, cons.c_str());
-    for (int p = 0; p < L; p++) fprintf(mf, " %d", gaps[(size_t)p]);
-    fprintf(mf, "\n__PSSM__\nDEPTH %d\nFPSM:\n", PSSM_DEPTH);
-    for (int d = 0; d < 31; d++) { for (int r = 0; r < 5; r++) fprintf(mf, "%d %d %d %d %d\n", anc.sm[d][r][0], anc.sm[d][r][1], anc.sm[d][r][2], anc.sm[d][r][3], anc.sm[d][r][4]); fprintf(mf, "\n"); }
-    fprintf(mf, "RPSM:\n");
-    for (int d = 0; d < 31; d++) { for (int r = 0; r < 5; r++) fprintf(mf, "%d %d %d %d %d\n", rcanc.sm[d][r][0], rcanc.sm[d][r][1], rcanc.sm[d][r][2], rcanc.sm[d][r][3], rcanc.sm[d][r][4]); fprintf(mf, "\n"); }
-    fprintf(mf, "__ALNSEQS__\n");
+    // sort_aln_frags: stable by (start, end) over cull order (src/map_align.c:393-414; glibc's qsort is a merge sort here).
+    // Two stable counting sorts -- by end, then by start -- give the same order in O(n + L).
     {
-      // the record texts are formatted in parallel (contiguous runs of the sorted order), written in order
-      const size_t nr = order.size();
-      const int TF = worker_threads((int)std::min<size_t>(nr, (size_t)INT32_MAX));
-      std::vector<std::string> text((size_t)TF);
-      run_parallel(TF, [&](int t) {
-        std::string& o = text[(size_t)t];
-        const size_t lo = nr * (size_t)t / (size_t)TF, hi = nr * (size_t)(t + 1) / (size_t)TF;
-        o.reserve((hi - lo) * 420);
-        auto num = [&](int v) { char b[16]; auto r = std::to_chars(b, b + sizeof b, v); o.append(b, r.ptr); };
-        for (size_t q = lo; q < hi; q++) {
-          const Record& a = recs[(size_t)order[q]];
-          o += "ID "; o += a.id; o += "\nDESC "; o += a.desc; o += "\nSCORE "; num(a.score);
-          o += "\nNUM_INPUTS 1\nSTART "; num(a.start); o += "\nEND "; num(a.end);
-          o += a.rc ? "\nRC 1\nTR " : "\nRC 0\nTR "; o += a.trimmed ? '1' : '0'; o += "\nDR "; o += a.dropped ? '1' : '0';
-          o += "\nSEG "; o += a.segment; o += "\nSEQ "; o += a.seq; o += "\nSMP "; o += a.smp; o += "\nINS_POS";
-          for (auto& in : a.ins) { o += ' '; num(in.first); o += ' '; o += in.second; }
-          o += '\n';
+      std::vector<int32_t> tmp(order.size());
+      auto pass = [&](const std::vector<int32_t>& key, const std::vector<int32_t>& in, std::vector<int32_t>& out) {
+        std::vector<int64_t> cnt((size_t)L + 3, 0);
+        for (int32_t k : in) cnt[(size_t)std::min(std::max(key[(size_t)k], 0), L + 1) + 1]++;
+        for (size_t v = 1; v < cnt.size(); v++) cnt[v] += cnt[v - 1];
+        for (int32_t k : in) out[(size_t)cnt[(size_t)std::min(std::max(key[(size_t)k], 0), L + 1)]++] = k;
+      };
+      pass(rec_end, order, tmp);
+      pass(rec_start, tmp, order);
+    }
+    // ---- the header
+    std::string head;
+    {
+      time_t t = time(NULL);
+      head += "/* map_alignment [V1.0] */ ";
+      head += asctime(localtime(&t));
+      int size = L + 1;                             // src/mia_main.c:66, src/mia.c:669-675
+      if (circular) while (L + wl >= size) size *= 2;
+      char b[256];
+      snprintf(b, sizeof b, "MALN_NAS %d\nMALN_SIZ %d\nMALN_COC %d\n__REFERENCE__\nID ", (int)order.size(), pass1_records, cc);
+      head += b; head += ref_id; head += "\nDESC "; head += ref_desc;
+      snprintf(b, sizeof b, "\nLEN %d\nSIZE %d\nSEQ ", L, size);
+      head += b; head += cons; head += "\nGAPS";
+      for (int p = 0; p < L; p++) { char nb[16]; auto r = std::to_chars(nb, nb + sizeof nb, gaps[(size_t)p]); head += ' '; head.append(nb, r.ptr); }
+      snprintf(b, sizeof b, "\n__PSSM__\nDEPTH %d\nFPSM:\n", PSSM_DEPTH);
+      head += b;
+      for (int pass2 = 0; pass2 < 2; pass2++) {
+        const Pssm& m = pass2 ? rcanc : anc;
+        if (pass2) head += "RPSM:\n";
+        for (int d = 0; d < 31; d++) {
+          for (int r = 0; r < 5; r++) { snprintf(b, sizeof b, "%d %d %d %d %d\n", m.sm[d][r][0], m.sm[d][r][1], m.sm[d][r][2], m.sm[d][r][3], m.sm[d][r][4]); head += b; }
+          head += "\n";
         }
-      });
-      for (auto& o : text) fwrite(o.data(), 1, o.size(), mf);
+      }
+      head += "__ALNSEQS__\n";
     }
-    fclose(mf);
-    {
-      // a million records own several strings each: giving them back on one thread when the vector dies costs as much as
-      // formatting them did
-      const size_t nrec = recs.size();
-      const int TD = worker_threads((int)std::min<size_t>(nrec, (size_t)INT32_MAX));
-      run_parallel(TD, [&](int t) {
-        for (size_t q = nrec * (size_t)t / (size_t)TD, hi = nrec * (size_t)(t + 1) / (size_t)TD; q < hi; q++) recs[q] = Record();
-      });
-      std::vector<Record>().swap(recs);
-    }
+    // ---- one record as text (write_ma, src/map_alignment.c:283-382), straight from the device's script of its read:
+    //      the two gapped strings of populate_pwaln_to_begin (src/mia.c:1440-1497), split_pwaln at the origin
+    //      (src/mia.c:1376-1438), merge_pwaln_into_maln (src/map_align.c:866-954: one character per reference column, inserts
+    //      before the column that follows them, a trailing insert run is lost as in the reference) and the depth codes of
+    //      pop_smp_from_FSDB (src/fsdb.c:542-619).  The depth code of a column reached after `a` bases of its record is
+    //      depth(q[0] + q[1] + a, q[2] - (q[1] + a) - 1); q = {0, 0, flen+blen} for a front record and {flen, bases in the
+    //      front, flen+blen} for a back record, unless a formerly split read further down the fsdb overwrote the codes
+    //      through its stale back_asp (mia_hip_get_record_params).
+    struct Scratch { std::string rg, fg, seq, smp; std::vector<std::pair<int, int>> ins; std::string ins_text; };
+    auto emit = [&](int32_t k, Scratch& w, std::string& o) {
+      const int i = rec_read[(size_t)k];
+      const int half = rec_half[(size_t)k];
+      const Frag& f = fsdb[i];
+      const int16_t* cs = &cols[(size_t)i * stride];
+      const int len2 = (int)f.seq.size();
+      w.rg.clear(); w.fg.clear();
+      int prev = -1;
+      for (int r = 0; r < len2; r++) {
+        if (cs[r] == MIA_HIP_COL_CLIP) continue;
+        if (cs[r] == MIA_HIP_COL_INSERT) { w.rg.push_back('-'); w.fg.push_back(f.seq[(size_t)r]); continue; }
+        const int gc = rstart[i] + cs[r];
+        if (prev >= 0) for (int c = prev + 1; c < gc; c++) { w.rg.push_back(wrapped[(size_t)c]); w.fg.push_back('-'); }
+        w.rg.push_back(wrapped[(size_t)gc]); w.fg.push_back(f.seq[(size_t)r]);
+        prev = gc;
+      }
+      const bool split = first_rec[(size_t)i + 1] - first_rec[(size_t)i] == 2;
+      size_t lo = 0, hi = w.rg.size();
+      if (split) {
+        int rp = rec_start[(size_t)first_rec[(size_t)i]];
+        size_t ap = 0;
+        while (rp < L && ap < w.rg.size()) { if (w.rg[ap] != '-') rp++; ap++; }
+        if (half) lo = ap; else hi = ap;
+      }
+      w.seq.clear(); w.ins.clear(); w.ins_text.clear();
+      {
+        bool in = false;
+        size_t run0 = 0;
+        for (size_t c = lo; c < hi; c++) {
+          if (w.rg[c] == '-') { if (!in) { run0 = w.ins_text.size(); in = true; } w.ins_text.push_back(w.fg[c]); }
+          else {
+            if (in) { w.ins.push_back({(int)w.seq.size(), (int)run0}); in = false; }
+            w.seq.push_back(w.fg[c]);
+          }
+        }
+        if (in) w.ins_text.resize(run0);          // (a run of inserted bases at the very end of a record is not stored)
+      }
+      const int st = rec_start[(size_t)k], en = rec_end[(size_t)k];
+      const int32_t* q = &rparams[(size_t)i * 8 + (half ? 4 : 0)];
+      w.smp.clear();
+      {
+        const int span = en - st + 1;
+        size_t ii = 0;
+        int act = 0;
+        for (int p2 = 0; p2 < span; p2++) {
+          while (ii < w.ins.size() && w.ins[ii].first < p2) ii++;
+          if (ii < w.ins.size() && w.ins[ii].first == p2) {
+            const size_t e = ii + 1 < w.ins.size() ? (size_t)w.ins[ii + 1].second : w.ins_text.size();
+            act += (int)(e - (size_t)w.ins[ii].second);
+          }
+          const int dff = q[0] + q[1] + act, dfb = q[2] - (q[1] + act) - 1;
+          w.smp.push_back(dff <= PSSM_DEPTH ? (char)('A' + dff) : (dfb < PSSM_DEPTH ? (char)('A' + 2 * PSSM_DEPTH - dfb) : (char)('A' + PSSM_DEPTH)));
+          if (p2 < (int)w.seq.size() && w.seq[(size_t)p2] != '-') act++;
+        }
+      }
+      auto num = [&](int v) { char b[16]; auto r = std::to_chars(b, b + sizeof b, v); o.append(b, r.ptr); };
+      o += "ID ";
+      if (split) { o.append(f.id, 0, (size_t)MAX_ID_LEN - 1); o += half ? "_b" : "_f"; } else o += f.id;
+      o += "\nDESC "; o += f.desc; o += "\nSCORE "; num(score[i]);
+      o += "\nNUM_INPUTS 1\nSTART "; num(st); o += "\nEND "; num(en);
+      o += f.rc ? "\nRC 1\nTR " : "\nRC 0\nTR "; o += f.trimmed ? '1' : '0'; o += "\nDR "; o += (half ? dB[i] : dF[i]) ? '1' : '0';
+      o += "\nSEG "; o += split ? (half ? 'b' : 'f') : 'a'; o += "\nSEQ "; o += w.seq; o += "\nSMP "; o += w.smp; o += "\nINS_POS";
+      for (size_t x = 0; x < w.ins.size(); x++) {
+        const size_t e = x + 1 < w.ins.size() ? (size_t)w.ins[x + 1].second : w.ins_text.size();
+        o += ' '; num(w.ins[x].first); o += ' '; o.append(w.ins_text, (size_t)w.ins[x].second, e - (size_t)w.ins[x].second);
+      }
+      o += '\n';
+    };
+    // ---- format on all host threads (contiguous runs of the sorted order), then every thread writes its own stretch of
+    //      the file (pwrite at the offset the sizes before it add up to)
+    const size_t nr = order.size();
+    int TF = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("MIA_HIP_THREADS")) TF = atoi(e);
+    TF = std::max(1, std::min(std::min(TF, 64), (int)(nr / 4096) + 1));
+    std::vector<std::string> text((size_t)TF);
+    const int fd = open(fn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) { fprintf(stderr, "Cannot write %s\n", fn.c_str()); exit(1); }
+    std::vector<size_t> sizes((size_t)TF, 0), at((size_t)TF + 1, 0);
+    run_parallel(TF, [&](int t) {
+      std::string& o = text[(size_t)t];
+      Scratch w;
+      const size_t lo = nr * (size_t)t / (size_t)TF, hi = nr * (size_t)(t + 1) / (size_t)TF;
+      o.reserve((hi - lo) * 330 + 4096);
+      for (size_t q = lo; q < hi; q++) emit(order[q], w, o);
+      sizes[(size_t)t] = o.size();
+    });
+    at[0] = head.size();
+    for (int t = 0; t < TF; t++) at[(size_t)t + 1] = at[(size_t)t] + sizes[(size_t)t];
+    auto put = [&](const char* p2, size_t len, size_t off) {
+      while (len) {
+        const ssize_t w = pwrite(fd, p2, len, (off_t)off);
+        if (w <= 0) { fprintf(stderr, "Cannot write %s\n", fn.c_str()); _exit(1); }
+        p2 += w; len -= (size_t)w; off += (size_t)w;
+      }
+    };
+    put(head.data(), head.size(), 0);
+    run_parallel(TF, [&](int t) { put(text[(size_t)t].data(), text[(size_t)t].size(), at[(size_t)t]); std::string().swap(text[(size_t)t]); });
+    close(fd);
     lap("write .maln");
   };
 
@@ -721,5 +706,7 @@ int main(int argc, char** argv) {
   now = time(NULL);
   fprintf(stderr, "Assembly finished at %s\n", asctime(localtime(&now)));
   for (auto* c : G) mia_hip_destroy(c);
-  return 0;
+  // every file is closed; the read store's millions of small strings need not be handed back one by one
+  fflush(stdout); fflush(stderr);
+  _exit(0);
 }

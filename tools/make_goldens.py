@@ -376,6 +376,27 @@ def g2_cases(only=None):
     shutil.rmtree(tmp)
 
 
+def ingest_cases_golden():
+    """what the reference's own reader (oracle/_ref/ref_read_driver) makes of tools/ingest_cases.py's inputs"""
+    import hashlib
+    import ingest_cases
+    tmp = tempfile.mkdtemp()
+    out = {}
+    for name, text in ingest_cases.cases().items():
+        path = os.path.join(tmp, name)
+        with open(path, "wb") as f:
+            f.write(text.encode())
+        r = subprocess.run([os.path.join(RB, "ref_read_driver"), path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+        recs = r.stdout.split(b"\n")[:-1]
+        out[name] = {"input_sha256": hashlib.sha256(text.encode()).hexdigest(), "records": len(recs),
+                     "records_sha256": hashlib.sha256(r.stdout).hexdigest(), "stderr_sha256": hashlib.sha256(r.stderr).hexdigest(),
+                     "stderr_lines": len(r.stderr.split(b"\n")) - 1, "first": recs[0].decode("latin1") if recs else "", "last": recs[-1].decode("latin1") if recs else ""}
+        print(name, out[name]["records"], "records,", out[name]["stderr_lines"], "message lines")
+    with open(os.path.join(G, "ingest.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp)
+
+
 def iter_push_sets():
     """The reference's own per-iteration loop (oracle/ref_iter_driver.c around reiterate_assembly + pop_smp + cull + sort +
     consensus_assembly_string) on a read store filled with post-pass-1 fields -- what bench.py and the full-size parity
@@ -654,6 +675,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "ccheck":      # only the ccheck inputs and reports
         sh(["make", "-s", "-f", "oracle/Makefile.ref"], cwd=ROOT)
         ccheck_cases(os.path.join(G, "mt311.fa"))
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "ingest":      # only the fragment reader's cases
+        ingest_cases_golden()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "dp_wide":     # only the wide-window / long-gap DP vectors
         dp_vectors_wide()
