@@ -16,13 +16,15 @@
 #include <stdint.h>
 
 #include "bandx_body.h"
+#include "bandx_lanes.h"
 #include "mia_kernels.h"
 
 namespace mia {
 
 // counters of the pipeline; each on a cache line of its own (BXC_STRIDE words apart): thousands of wavefronts add to them,
 // and atomics on one line are served one after the other
-enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_COUNTERS = 32 };
+enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_COUNTERS = 32 };
+static_assert(BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_COUNTERS, "counter layout");
 constexpr int BXC_STRIDE = 64;
 constexpr int BXC_WORDS = BXC_COUNTERS * BXC_STRIDE;
 __device__ __forceinline__ uint32_t* bxc(const uint32_t* ctr, int k) { return const_cast<uint32_t*>(ctr) + (size_t)k * BXC_STRIDE; }
@@ -36,10 +38,14 @@ struct BxDev {
   int32_t rplane_words;
   uint32_t* plan;          // [n] packed BxPlan of a read on a list
   int32_t* expect;         // [n] U - b0: the score of the plan's diagonal
-  int32_t* lists;          // [2 * BX_NCLS][list_stride] read indices
+  int32_t* lists;          // [3 * BX_NCLS][list_stride] read indices: values lists, trace lists, late trace lists (what the values DP could not finish)
+  int32_t* retry;          // reads no band kernel could finish (the reference's index-0 quirk ...): the one-read-per-wavefront window kernel takes them
+  int32_t* retry_n;        // ... their number
+  int32_t listed_mark;     // bin_of of a read on a list: -5 (the planner leaves it alone: it runs BESIDE the band kernels), or 0 (open: round 2's order)
   int64_t list_stride;
   uint32_t* ctr;           // BXC_*
   int32_t lazy_scripts;    // the scripts of reads finished as pure diagonals are not written (k_diag_scripts makes them when asked for)
+  uint32_t dbg;            // MIA_HIP_BX_DEBUG (profiling only, results are wrong): 1 no traceback, 2 one DP row only
 };
 
 __device__ __forceinline__ uint32_t bx_pack(const BxPlan& p) {
@@ -72,6 +78,17 @@ __device__ __forceinline__ void bx_append(const BxDev& bx, int which, bool want,
   if (lane == __builtin_ctzll(m)) base = atomicAdd(bxc(bx.ctr, BXC_LIST0 + which), (uint32_t)__popcll(m));
   base = __shfl(base, __builtin_ctzll(m));
   if (want) bx.lists[(int64_t)which * bx.list_stride + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+// append `i` to a plain list for the lanes with want == true: one atomic per wavefront
+__device__ __forceinline__ void bxl_append(int32_t* list, uint32_t* counter, bool want, int32_t i) {
+  const unsigned long long m = __ballot(want);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == __builtin_ctzll(m)) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = __shfl(base, __builtin_ctzll(m));
+  if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
 }
 
 // the script of a pure diagonal (consecutive columns from c0 on) for the lanes in `mask`: the wavefront writes one read
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
         } else bx.expect[r.i] = expect;
       }
       if (bp.mode == BX_VALUES || bp.mode == BX_TRACE) bx.plan[r.i] = bx_pack(bp);
-      if (mark_open && bp.mode != BX_DONE) bin_of[r.i] = 0;
+      if (mark_open && bp.mode != BX_DONE) bin_of[r.i] = (bp.mode == BX_VALUES || bp.mode == BX_TRACE) ? bx.listed_mark : 0;
     }
     // list appends and counters go through the block: one global atomic per block and list instead of one per wavefront
     const int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? BX_NCLS + bx_class_of(bp.w) : -1);
@@ -401,6 +418,149 @@ __global__ __launch_bounds__(256) void k_bx_trace(ReadSet rs, RefInfo ref, BxDev
   }
   for (int o = 32; o; o >>= 1) done += __shfl_xor(done, o);
   if (lane == 0 && done) atomicAdd(bxc(bx.ctr, BXC_DONE_TRACE), done);
+}
+
+// ---- the same two kernels with a read spread over W / 8 lanes (bandx_lanes.h) ---------------------------------------------
+// A chunk is bxl_chunk_reads(class) reads -- 64, 32, 20, 16 -- so that every wavefront walks eight cells per row and lane.
+// Chunks are dealt out statically: wavefront w of the grid takes chunks w, w + waves, w + 2 waves ... (classes in descending
+// width, so every wavefront gets its share of the long ones).  A shared cursor looks more flexible, but thousands of
+// wavefronts adding to ONE word are served one after the other by the L2 (~12 ns each): with a grid as large as the chunk
+// list that was 60-75 us of every launch, more than the DP itself took (tools/bxl_probe.py).
+__device__ __forceinline__ bool bxl_chunk_at(const BxDev& bx, uint32_t chunk, int hi_ctr, BxChunk* out) {
+  for (int c = BX_NCLS - 1; c >= 0; c--) {
+    const uint32_t hi = *bxc(bx.ctr, hi_ctr + c), per = (uint32_t)bxl_chunk_reads(c), nch = (hi + per - 1u) / per;
+    if (chunk < nch) { out->cls = c; out->first = chunk * per; out->count = hi; return true; }
+    chunk -= nch;
+  }
+  return false;
+}
+// what the wavefronts of a workgroup finished, added up in LDS: one atomic per workgroup on the statistics word
+__device__ __forceinline__ void bxl_count_done(uint32_t done, uint32_t* lds_word, uint32_t* global_word) {
+  for (int o = 32; o; o >>= 1) done += __shfl_xor(done, o);
+  if ((threadIdx.x & 63) == 0 && done) atomicAdd(lds_word, done);
+  __syncthreads();
+  if (threadIdx.x == 0 && *lds_word) atomicAdd(global_word, *lds_word);
+}
+// which read of the chunk this lane works on, and its place among that read's lanes; false: an idle lane
+template <int LPR>
+__device__ __forceinline__ bool bxl_place(const BxChunk& ch, uint32_t* t, int* u) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, slot = l16 / LPR;
+  *u = l16 - slot * LPR;
+  *t = ch.first + (uint32_t)((lane >> 4) * bxl_reads_per_row<LPR>() + slot);
+  return slot < bxl_reads_per_row<LPR>() && *t < ch.count;
+}
+
+template <int LPR>
+__device__ __forceinline__ uint32_t bxl_values_chunk(const ReadSet& rs, const RefInfo& ref, const BxDev& bx, int32_t* bin_of, const BxChunk& ch, const int32_t* sub_lds) {
+  uint32_t t;
+  int u;
+  const bool live = bxl_place<LPR>(ch, &t, &u);
+  int best = BX_NEG, bj = -1;
+  BxRead r{};
+  if (live) r = bx_load(rs, ref, bx, bx.lists[(int64_t)ch.cls * bx.list_stride + t]);
+  const bool edge = __ballot(live && r.edge) != 0ull;       // one form of the recurrence per wavefront
+  if (live) {
+    const int32_t* sub = sub_lds + r.st * (31 * 4 * BX_SUB_ROW);
+    const int rows = (bx.dbg & 2u) ? 1 : r.len2;
+    if (edge) bxl_values<LPR, true>(bx.refnib, r.s, r.l1, r.rw, rows, r.d0, sub, u, &best, &bj);
+    else bxl_values<LPR, false>(bx.refnib, r.s, r.l1, r.rw, rows, r.d0, sub, u, &best, &bj);
+  }
+  const bool ok = live && u == 0 && bj >= 0 && bj == r.jstar && best == bx.expect[r.i];
+  if (ok) {
+    const int dstar = r.d0 + r.jstar;
+    rs.score[r.i] = best;
+    rs.refstart[r.i] = r.s;
+    rs.abr[r.i] = 0;
+    rs.as[r.i] = r.s + dstar;                   // src/mia_main.c:254-255
+    rs.ae[r.i] = r.s + dstar + r.len2 - 1;
+    rs.status[r.i] = ST_DIAG;
+    bin_of[r.i] = -4;
+  }
+  if (!bx.lazy_scripts) bx_diag_scripts(rs, __ballot(ok), r.i, r.d0 + r.jstar, r.len2);
+  // a read whose best score is not the plan's diagonal's has a gap or a soft clip: on to the late trace list of its class
+  // (k_bxl_trace runs once more, behind this kernel); with listed_mark == 0 it simply stays open for the planner
+  if (bx.listed_mark != 0)
+    bxl_append(bx.lists + (int64_t)(2 * BX_NCLS + ch.cls) * bx.list_stride, bxc(bx.ctr, BXC_LATE0 + ch.cls), live && u == 0 && !ok, r.i);
+  return ok ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_bxl_values(ReadSet rs, RefInfo ref, BxDev bx, int32_t* bin_of) {
+  __shared__ int32_t sub_lds[BX_SUB_WORDS];
+  for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.tab.sub[k];
+  __syncthreads();
+  __shared__ uint32_t done_wg;
+  if (threadIdx.x == 0) done_wg = 0;
+  __syncthreads();
+  uint32_t done = 0;
+  BxChunk ch;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), waves = gridDim.x * 4u;
+  for (uint32_t chunk = wave; bxl_chunk_at(bx, chunk, BXC_LIST0, &ch); chunk += waves) {
+    switch (ch.cls) {
+      case 0: done += bxl_values_chunk<1>(rs, ref, bx, bin_of, ch, sub_lds); break;
+      case 1: done += bxl_values_chunk<2>(rs, ref, bx, bin_of, ch, sub_lds); break;
+      case 2: done += bxl_values_chunk<3>(rs, ref, bx, bin_of, ch, sub_lds); break;
+      default: done += bxl_values_chunk<4>(rs, ref, bx, bin_of, ch, sub_lds); break;
+    }
+  }
+  bxl_count_done(done, &done_wg, bxc(bx.ctr, BXC_DONE_VALUES));
+}
+
+template <int LPR>
+__device__ __forceinline__ uint32_t bxl_trace_chunk(const ReadSet& rs, const RefInfo& ref, const BxDev& bx, int32_t* bin_of, const BxChunk& ch, const int32_t* sub_lds,
+                                                    uint32_t* slab, int list0) {
+  uint32_t t;
+  int u;
+  const bool live = bxl_place<LPR>(ch, &t, &u);
+  BxRead r{};
+  if (live) r = bx_load(rs, ref, bx, bx.lists[(int64_t)(list0 + ch.cls) * bx.list_stride + t]);
+  const bool edge = __ballot(live && r.edge) != 0ull;
+  bool got = false;
+  BxResult res{};
+  if (live) {
+    const int32_t* sub = sub_lds + r.st * (31 * 4 * BX_SUB_ROW);
+    int16_t* cols = rs.cols + (int64_t)r.i * rs.stride;
+    const int rows = (bx.dbg & 2u) ? 1 : r.len2;
+    got = edge ? bxl_trace<LPR, true>(bx.refnib, r.s, r.l1, r.rw, rows, r.d0, sub, u, (int)(threadIdx.x & 63), slab, cols, &res, bx.lazy_scripts != 0, (bx.dbg & 1u) != 0)
+               : bxl_trace<LPR, false>(bx.refnib, r.s, r.l1, r.rw, rows, r.d0, sub, u, (int)(threadIdx.x & 63), slab, cols, &res, bx.lazy_scripts != 0, (bx.dbg & 1u) != 0);
+  }
+  if (got) {                                   // (not got on a read's first lane: the reference's index-0 quirk -- the full-window kernels take the read)
+    rs.score[r.i] = res.score;
+    rs.refstart[r.i] = r.s;
+    rs.abr[r.i] = (int16_t)res.abr;
+    rs.as[r.i] = res.abc + r.s;                // src/mia_main.c:254-255
+    rs.ae[r.i] = res.aec + r.s;
+    rs.status[r.i] = res.gaps == 0 ? ST_DIAG : (res.gaps == 1 ? (ST_ONEGAP | (res.gap_desc << 8)) : ST_OK);
+    bin_of[r.i] = -4;
+  }
+  // not finished on a read's first lane: the reference's index-0 quirk (bandx_lanes.h).  With the planner running beside
+  // this kernel the read goes on the retry list (a window kernel behind everything takes it); otherwise it is open again.
+  if (bx.listed_mark != 0) bxl_append(bx.retry, reinterpret_cast<uint32_t*>(bx.retry_n), live && u == 0 && !got && !(bx.dbg & 3u), r.i);
+  return got ? 1u : 0u;
+}
+
+// trace slab of a wavefront: [row][lane][2 words]
+constexpr int BXL_SLAB_ROW_WORDS = 128;
+// list0 / ctr0: BX_NCLS / BXC_LIST0 + BX_NCLS for the plan's trace lists, 2 BX_NCLS / BXC_LATE0 for the values DP's left-overs
+__global__ __launch_bounds__(256) void k_bxl_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of, int list0, int ctr0) {
+  __shared__ int32_t sub_lds[BX_SUB_WORDS];
+  for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.sub256[k];
+  __syncthreads();
+  uint32_t* slab = slabs + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * slab_words;
+  __shared__ uint32_t done_wg;
+  if (threadIdx.x == 0) done_wg = 0;
+  __syncthreads();
+  uint32_t done = 0;
+  BxChunk ch;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), waves = gridDim.x * 4u;
+  for (uint32_t chunk = wave; bxl_chunk_at(bx, chunk, ctr0, &ch); chunk += waves) {
+    switch (ch.cls) {
+      case 0: done += bxl_trace_chunk<1>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
+      case 1: done += bxl_trace_chunk<2>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
+      case 2: done += bxl_trace_chunk<3>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
+      default: done += bxl_trace_chunk<4>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
+    }
+  }
+  bxl_count_done(done, &done_wg, bxc(bx.ctr, BXC_DONE_TRACE));
 }
 
 }  // namespace mia

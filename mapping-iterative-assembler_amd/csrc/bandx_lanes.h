@@ -1,0 +1,379 @@
+// bandx_lanes.h -- the band DP of bandx_body.h with a read spread over W/8 lanes (gfx950 only: DPP).
+//
+// bx_values / bx_trace keep a whole band row -- W = 8 ... 32 cells -- in the registers of ONE lane and walk it cell by
+// cell: a wavefront issues one instruction per four cycles whatever it does, so a chunk of 64 such reads lasts
+// rows x W x 13-15 instructions x 4+ cycles, 0.1-0.3 ms for the wide classes, and with fewer chunks than the chip has wave
+// slots each band kernel lasted exactly as long as its widest chunk (round 2: k_bx_trace 0.29 ms at 18 % of the issue
+// rate).  Here a read of class W owns LPR = W / 8 neighbouring lanes of one 16-lane DPP row, eight cells each: every
+// chunk -- 64, 32, 20 or 16 reads -- walks eight cells per row, and the wide classes simply make more wavefronts.
+//
+// What crosses a lane boundary (recurrence: /root/reference/src/mia.c:740-981, restated in bandx_body.h):
+//   * the column-gap maximum G(j) = max over j' < j of prev[j'] - GOP - GEP (j - j'): a prefix maximum over the PREVIOUS
+//     row.  Each lane folds its own eight cells first (g_loc), the lanes to its left hand theirs over by row_shr, aged by
+//     eight positions per lane in between; the cell loop then starts from that G instead of "none".
+//   * the row-gap candidates H slide down one band index per row (the band moves one column to the right): what a lane
+//     computes for its cell 0 becomes its left neighbour's H[7] (row_shl:1); the rightmost lane's H[7] is "none".
+//   * the best cell of the last row (first maximum: the lower band index wins ties, src/mia.c:1278-1302) is reduced
+//     across the read's lanes; the traceback is walked by the read's first lane, which reads the other lanes' trace bytes
+//     from the slab.
+// Tie rules, packed words (value * 256 + code), the reference's index-0 quirk: exactly as bx_values / bx_trace, which stay
+// in bandx_body.h as the one-lane statement of the same recurrence (tests/test_emul_bandx.py runs them on the CPU;
+// MIA_HIP_NO_LANES=1 runs them on the GPU; tests/test_gpu_bandx.py and the campaigns hold these kernels against the
+// full-window kernels and the oracle).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bandx_body.h"
+
+namespace mia {
+
+constexpr int BXL_CELLS = 8;                       // band cells per lane
+template <int LPR> constexpr int bxl_reads_per_row() { return 16 / LPR; }
+template <int LPR> constexpr int bxl_reads_per_wave() { return 4 * (16 / LPR); }
+__host__ __device__ constexpr int bxl_chunk_reads(int cls) { return cls == 0 ? 64 : (cls == 1 ? 32 : (cls == 2 ? 20 : 16)); }
+
+// value of the lane K places to the left (right) in the 16-lane row; lanes without such a neighbour get `fill`
+template <int K>
+__device__ __forceinline__ int bxl_from_left(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x110 + K, 0xF, 0xF, false); }
+__device__ __forceinline__ int bxl_from_right1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x101, 0xF, 0xF, false); }
+template <int K>
+__device__ __forceinline__ int bxl_from_right(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x100 + K, 0xF, 0xF, false); }
+
+// eight nibbles of reference codes at a position that advances by one per row (BxSlide<1> of bandx_body.h)
+struct BxlSlide {
+  uint32_t raw[3];
+  int64_t q;
+  __device__ __forceinline__ void init(const uint32_t* refnib, int64_t nib) {
+    q = nib >> 3;
+    raw[0] = refnib[q]; raw[1] = refnib[q + 1]; raw[2] = refnib[q + 2];
+  }
+  __device__ __forceinline__ uint32_t get(const uint32_t* refnib, int64_t nib) {
+    if ((nib >> 3) != q) { raw[0] = raw[1]; raw[1] = raw[2]; q++; raw[2] = refnib[q + 2]; }
+    const int sh = (int)(nib & 7) * 4;
+    return sh ? (raw[0] >> sh) | (raw[1] << (32 - sh)) : raw[0];
+  }
+};
+
+// cells of this lane (band indices 8u .. 8u + 7) whose column lies inside the window [0, len1)
+__device__ __forceinline__ uint32_t bxl_live(int c0_lane, int len1) {
+  const int jlo = c0_lane < 0 ? -c0_lane : 0, jhi = (len1 - c0_lane) < BXL_CELLS ? (len1 - c0_lane) : BXL_CELLS;
+  return jhi > jlo ? (((1u << jhi) - 1u) & ~((1u << jlo) - 1u)) : 0u;
+}
+
+// ---- values only ---------------------------------------------------------------------------------------------------------
+// u: this lane's place among the read's LPR lanes.  Every lane of a read is given the same read.  *best_out / *bj_out
+// (band index, -1: none) are valid on the read's first lane.
+template <int LPR, bool EDGE>
+__device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int len1, const uint32_t* rwords, int len2, int d0, const int32_t* sub, int u,
+                                           int* best_out, int* bj_out) {
+  const int dl = d0 + BXL_CELLS * u;                       // this lane's first diagonal
+  int32_t P[BXL_CELLS], H[BXL_CELLS];
+  uint32_t rw = rwords[0], rw_next = rwords[1];
+  BxlSlide slide;
+  slide.init(refnib, (int64_t)s + dl + BX_NIB_LEAD);
+  {
+    const uint32_t cw = slide.get(refnib, (int64_t)s + dl + BX_NIB_LEAD);
+    const int32_t* row = sub + (int)(rw & 3u) * BX_SUB_ROW;              // depth 0
+    const uint32_t live = EDGE ? bxl_live(dl, len1) : 0xFFu;
+#pragma unroll
+    for (int j = 0; j < BXL_CELLS; j++) {
+      H[j] = BX_NEG;
+      const int v = row[(cw >> (4 * j)) & 7u];
+      P[j] = ((live >> j) & 1u) ? v : BX_NEG;
+    }
+  }
+  for (int r = 1; r < len2; r++) {
+    const int c0 = r + dl;
+    const uint32_t cw = slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD);
+    if ((r & 7) == 0) { rw = rw_next; rw_next = rwords[(r >> 3) + 1]; }      // (packed reads are padded: one word beyond the last is readable)
+    const int32_t* row = sub + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
+    uint32_t live = 0xFFu, col0 = 0u;
+    if (EDGE) {
+      live = bxl_live(c0, len1);
+      col0 = (c0 <= 0 && c0 > -BXL_CELLS) ? (1u << (-c0)) : 0u;
+    }
+    const int fresh = -(GOP + GEP * (r + 1));
+    // the column-gap maximum this lane's cells start from: the lanes to the left, each aged by the positions in between
+    int cand[BXL_CELLS];
+    int G = BX_NEG;
+    if (LPR > 1) {
+      int gloc = BX_NEG;
+#pragma unroll
+      for (int j = 0; j < BXL_CELLS; j++) {
+        cand[j] = P[j] - (GOP + GEP);
+        gloc = gloc - GEP > cand[j] ? gloc - GEP : cand[j];
+      }
+      const int g1 = bxl_from_left<1>(gloc, BX_NEG);
+      if (u >= 1) G = g1;
+      if (LPR > 2) {
+        const int g2 = bxl_from_left<2>(gloc, BX_NEG) - BXL_CELLS * GEP;
+        if (u >= 2 && g2 > G) G = g2;
+      }
+      if (LPR > 3) {
+        const int g3 = bxl_from_left<3>(gloc, BX_NEG) - 2 * BXL_CELLS * GEP;
+        if (u >= 3 && g3 > G) G = g3;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < BXL_CELLS; j++) cand[j] = P[j] - (GOP + GEP);
+    }
+    int nh0 = BX_NEG;
+#pragma unroll
+    for (int j = 0; j < BXL_CELLS; j++) {
+      const int pd = P[j], h = H[j];
+      const int sb = row[(cw >> (4 * j)) & 7u];
+      const int x = pd > G ? (pd > h ? pd : h) : (G > h ? G : h);
+      int cur = fresh > x ? fresh : x + sb;
+      if (EDGE) {
+        if ((col0 >> j) & 1u) cur = sb + fresh;                                       // src/mia.c:805-822
+        if (!((live >> j) & 1u)) cur = BX_NEG;
+      }
+      G = G - GEP > cand[j] ? G - GEP : cand[j];
+      const int nh = h - GEP > cand[j] ? h - GEP : cand[j];
+      if (j >= 1) H[j - 1] = nh; else nh0 = nh;
+      P[j] = cur;
+    }
+    if (LPR > 1) {
+      const int hr = bxl_from_right1(nh0, BX_NEG);
+      H[BXL_CELLS - 1] = u < LPR - 1 ? hr : BX_NEG;
+    } else H[BXL_CELLS - 1] = BX_NEG;
+  }
+  int best = BX_NEG, bj = -1;
+#pragma unroll
+  for (int j = 0; j < BXL_CELLS; j++) if (P[j] > best) { best = P[j]; bj = j; }
+  bj = bj < 0 ? -1 : bj + BXL_CELLS * u;
+  if (LPR > 1) {                                           // first maximum over the read's lanes: a lane further right must be strictly better
+    const int b1 = bxl_from_right<1>(best, BX_NEG), j1 = bxl_from_right<1>(bj, -1);
+    int bb = best, jj = bj;
+    if (LPR > 3) {
+      const int b3 = bxl_from_right<3>(best, BX_NEG), j3 = bxl_from_right<3>(bj, -1);
+      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
+      if (b1 > bb) { bb = b1; jj = j1; }
+      if (b2 > bb) { bb = b2; jj = j2; }
+      if (b3 > bb) { bb = b3; jj = j3; }
+    } else if (LPR > 2) {
+      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
+      if (b1 > bb) { bb = b1; jj = j1; }
+      if (b2 > bb) { bb = b2; jj = j2; }
+    } else {
+      if (b1 > bb) { bb = b1; jj = j1; }
+    }
+    best = bb; bj = jj;                                    // (meaningful on the read's first lane, u == 0)
+  }
+  if (best <= BX_NEG / 2) bj = -1;
+  *best_out = best; *bj_out = bj;
+}
+
+// ---- with a trace ----------------------------------------------------------------------------------------------------------
+// trace: this WAVEFRONT's slab, row r at trace + r * 128 words, lane l's two words at + 2 l.  lane_in_wave: this lane;
+// the read's first lane walks the traceback and writes cols_out / res.  Returns (on the first lane) whether the read is
+// finished here; false: the reference's index-0 quirk, or nothing alive in the last row.
+template <int LPR, bool EDGE>
+__device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len1, const uint32_t* rwords, int len2, int d0, const int32_t* sub256, int u,
+                                          int lane_in_wave, uint32_t* trace, int16_t* cols_out, BxResult* res, bool lazy_diag, bool no_traceback = false) {
+  constexpr int DEAD = BX_NEG * 256;
+  constexpr int STEP = 1 - GEP * 256;                 // a running maximum ages by one position: value - GEP, length + 1
+  constexpr int CAND = -GOP * 256 + STEP - 0xFF;      // a cell (packed as a diagonal source) becomes a gap source
+  constexpr int ROW_WORDS = 128;
+  const int R = len2 - 1;
+  const int dl = d0 + BXL_CELLS * u;
+  int32_t P[BXL_CELLS], H[BXL_CELLS];
+  uint32_t rw = rwords[0], rw_next = rwords[1];
+  uint32_t* mine = trace + 2 * lane_in_wave;
+  BxlSlide slide;
+  slide.init(refnib, (int64_t)s + dl + BX_NIB_LEAD);
+  {
+    const uint32_t cw = slide.get(refnib, (int64_t)s + dl + BX_NIB_LEAD);
+    const int32_t* row = sub256 + (int)(rw & 3u) * BX_SUB_ROW;
+    const uint32_t live = EDGE ? bxl_live(dl, len1) : 0xFFu;
+#pragma unroll
+    for (int j = 0; j < BXL_CELLS; j++) {
+      H[j] = DEAD;
+      const int v = row[(cw >> (4 * j)) & 7u];
+      P[j] = ((live >> j) & 1u) ? (v | 0xFF) : DEAD;
+    }
+    mine[0] = 0xFFFFFFFFu; mine[1] = 0xFFFFFFFFu;
+  }
+  for (int r = 1; r < len2; r++) {
+    const int c0 = r + dl;
+    const uint32_t cw = slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD);
+    if ((r & 7) == 0) { rw = rw_next; rw_next = rwords[(r >> 3) + 1]; }      // (packed reads are padded: one word beyond the last is readable)
+    const int32_t* row = sub256 + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
+    uint32_t live = 0xFFu, col0 = 0u;
+    if (EDGE) {
+      live = bxl_live(c0, len1);
+      col0 = (c0 <= 0 && c0 > -BXL_CELLS) ? (1u << (-c0)) : 0u;
+    }
+    const int f0 = -(GOP + GEP * (r + 1)) * 256, f0s = f0 | 0x80;
+    int cand[BXL_CELLS];
+    int G = DEAD;
+    if (LPR > 1) {
+      int gloc = DEAD;
+#pragma unroll
+      for (int j = 0; j < BXL_CELLS; j++) {
+        cand[j] = (P[j] | 0xFF) + CAND;
+        gloc = gloc + STEP > cand[j] ? gloc + STEP : cand[j];
+      }
+      const int g1 = bxl_from_left<1>(gloc, DEAD);
+      if (u >= 1) G = g1;
+      if (LPR > 2) {
+        const int g2 = bxl_from_left<2>(gloc, DEAD) + BXL_CELLS * STEP;
+        if (u >= 2 && g2 > G) G = g2;
+      }
+      if (LPR > 3) {
+        const int g3 = bxl_from_left<3>(gloc, DEAD) + 2 * BXL_CELLS * STEP;
+        if (u >= 3 && g3 > G) G = g3;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < BXL_CELLS; j++) cand[j] = (P[j] | 0xFF) + CAND;
+    }
+    uint32_t tw0 = 0, tw1 = 0;
+    int nh0 = DEAD;
+#pragma unroll
+    for (int j = 0; j < BXL_CELLS; j++) {
+      const int pd = P[j] | 0xFF, h = H[j], gc = G | 0x40;
+      const int sb = row[(cw >> (4 * j)) & 7u];
+      const int x = pd > gc ? (pd > h ? pd : h) : (gc > h ? gc : h);
+      int cur = f0 > x ? f0s : x + sb;                  // fresh must beat all three strictly (its code byte is 0 in f0)
+      if (EDGE) {
+        if ((col0 >> j) & 1u) cur = (sb + f0) | 0xFF;
+        if (!((live >> j) & 1u)) cur = DEAD;
+      }
+      if (j < 4) tw0 = bx_put(tw0, (uint32_t)cur, j & 3); else tw1 = bx_put(tw1, (uint32_t)cur, j & 3);
+      G = G + STEP > cand[j] ? G + STEP : cand[j];
+      const int nh = h + STEP > cand[j] ? h + STEP : cand[j];
+      if (j >= 1) H[j - 1] = nh; else nh0 = nh;
+      P[j] = cur;
+    }
+    if (LPR > 1) {
+      const int hr = bxl_from_right1(nh0, DEAD);
+      H[BXL_CELLS - 1] = u < LPR - 1 ? hr : DEAD;
+    } else H[BXL_CELLS - 1] = DEAD;
+    uint32_t* tr = mine + (int64_t)r * ROW_WORDS;
+    tr[0] = tw0; tr[1] = tw1;
+  }
+  // max_sg_score: first maximum of the last row (src/mia.c:1278-1302)
+  int best = BX_NEG, bj = -1;
+#pragma unroll
+  for (int j = 0; j < BXL_CELLS; j++) if ((P[j] >> 8) > best) { best = P[j] >> 8; bj = j; }
+  bj = bj < 0 ? -1 : bj + BXL_CELLS * u;
+  if (LPR > 1) {
+    const int b1 = bxl_from_right<1>(best, BX_NEG), j1 = bxl_from_right<1>(bj, -1);
+    int bb = best, jj = bj;
+    if (LPR > 3) {
+      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
+      const int b3 = bxl_from_right<3>(best, BX_NEG), j3 = bxl_from_right<3>(bj, -1);
+      if (b1 > bb) { bb = b1; jj = j1; }
+      if (b2 > bb) { bb = b2; jj = j2; }
+      if (b3 > bb) { bb = b3; jj = j3; }
+    } else if (LPR > 2) {
+      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
+      if (b1 > bb) { bb = b1; jj = j1; }
+      if (b2 > bb) { bb = b2; jj = j2; }
+    } else {
+      if (b1 > bb) { bb = b1; jj = j1; }
+    }
+    best = bb; bj = jj;
+  }
+  // the traceback is the first lane's business.  It reads trace bytes its neighbours stored: same wavefront, same memory
+  // pipe, the loads are issued after the stores -- the fence only keeps the compiler from moving them.
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (u != 0 || no_traceback) return false;
+  if (bj < 0 || best <= BX_NEG / 2) return false;
+  // find_align_begin + populate_pwaln_to_begin (src/mia.c:612-637, 1440-1497).  The path is a handful of diagonal
+  // stretches: the walk only notes where they break (sixteen rows of one band index per fetch -- nearly every step is
+  // diagonal and stays on it), the script is written afterwards, four rows per 8-byte store.  (One 2-byte store per row and
+  // lane -- 64 different cache lines per instruction -- was a third of this kernel's time.)
+  constexpr int W = BXL_CELLS * LPR;
+  constexpr int EV = 4;                                  // breaks kept in registers; a path with more is walked again, storing as it goes
+  const uint32_t* base = trace + 2 * lane_in_wave;       // band index j: word (j >> 2) counted from the first lane's pair
+  int ev_row[EV], ev_delta[EV];                          // rows above ev_row sit ev_delta columns further right than the diagonal below says
+#pragma unroll
+  for (int k = 0; k < EV; k++) { ev_row[k] = -1; ev_delta[k] = 0; }
+  int r = R, c = R + d0 + bj, gaps = 0;
+  uint32_t gap_desc = 0;
+  const int aec = c;
+  bool stop = false;
+  while (!stop) {
+    const int j = c - r - d0;
+    if (j < 0 || j >= W) return false;
+    constexpr int TB = 16;
+    uint32_t wv[TB];
+#pragma unroll
+    for (int k = 0; k < TB; k++) wv[k] = base[(int64_t)(r - k > 0 ? r - k : 0) * ROW_WORDS + (j >> 2)];
+    bool moved = false;                      // left index j: fetch again
+#pragma unroll
+    for (int k = 0; k < TB; k++) {
+      if (stop || moved) continue;
+      if (r == 0 || c == 0) { stop = true; continue; }
+      const int code = (int)((wv[k] >> (8 * (j & 3))) & 255u);
+      if (code == 0x80) { stop = true; continue; }
+      if (code == 0xFF) { r--; c--; continue; }
+      moved = true;
+      int delta;
+      if (code & 0x40) {
+        const int sc = c - 1 - (code & 63);
+        if (sc <= 0) return false;           // a gap from column 0 reads back as a diagonal step in the reference: not followed here
+        gap_desc = 0u | ((uint32_t)r << 1) | ((uint32_t)(code & 63) << 10);
+        delta = -(code & 63);
+      } else {
+        const int sr = r - 1 - code;
+        if (sr <= 0) return false;           // a gap from row 0: the same quirk
+        gap_desc = 1u | ((uint32_t)(sr + 1) << 1) | ((uint32_t)code << 10);
+        delta = code;
+      }
+#pragma unroll
+      for (int e = 0; e < EV; e++) if (e == gaps) { ev_row[e] = r; ev_delta[e] = delta; }
+      gaps++;
+      if (delta < 0) { r--; c = c - 1 + delta; } else { r = r - 1 - delta; c--; }
+    }
+  }
+  const int abr = r, abc = c;
+  res->score = best; res->abc = abc; res->aec = aec; res->abr = abr; res->gaps = gaps; res->gap_desc = gap_desc;
+  if (gaps == 0 && abr == 0 && lazy_diag) return true;   // a pure diagonal from row 0: k_diag_scripts writes it when somebody asks
+  if (gaps <= EV) {
+    // row q (>= abr) sits on column q + off, off = aec - R plus the shifts of every break above it; the rows a row gap
+    // skipped are inserts
+    const int off0 = aec - R;
+    for (int q0 = 0; q0 < len2; q0 += 4) {
+      uint32_t v[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int q = q0 + t;
+        int col = q + off0;
+        bool ins = false;
+#pragma unroll
+        for (int e = 0; e < EV; e++) {
+          const bool above = ev_row[e] > q;              // (unused entries: row -1)
+          const int d = ev_delta[e];
+          if (above) col += d < 0 ? d : d;               // a column gap of n: the rows above it lie n columns further LEFT; a row gap of n rows: n further RIGHT
+          ins = ins || (above && d > 0 && q >= ev_row[e] - d);
+        }
+        v[t] = (uint32_t)(uint16_t)(int16_t)(q < abr ? COL_CLIP : (ins ? COL_INSERT : col));
+      }
+      uint2 w2;
+      w2.x = v[0] | (v[1] << 16);
+      w2.y = v[2] | (v[3] << 16);
+      *reinterpret_cast<uint2*>(cols_out + q0) = w2;     // (the script row is a multiple of four entries long and 8-byte aligned)
+    }
+    return true;
+  }
+  // more breaks than the registers hold (rare): the same walk again, storing every row as it goes
+  r = R; c = aec; stop = false;
+  while (!stop) {
+    const int j = c - r - d0;
+    cols_out[r] = (int16_t)c;
+    if (r == 0 || c == 0) break;
+    const int code = (int)((base[(int64_t)r * ROW_WORDS + (j >> 2)] >> (8 * (j & 3))) & 255u);
+    if (code == 0x80) break;
+    if (code == 0xFF) { r--; c--; continue; }
+    if (code & 0x40) { r--; c = c - 1 - (code & 63); }
+    else { const int sr = r - 1 - code; for (int q = r - 1; q > sr; q--) cols_out[q] = COL_INSERT; r = sr; c--; }
+  }
+  for (int q = 0; q < abr; q++) cols_out[q] = COL_CLIP;
+  return true;
+}
+
+}  // namespace mia

@@ -44,6 +44,10 @@ struct mia_hip_ctx {
   uint32_t stage_mask = ~0u;               // timed stages (mia_hip_set_stage_mask): an event pair costs the stream a few microseconds
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // the trace DP of the plan's own lists runs beside the values DP
+  hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr;                      // ... and both beside the planner and the full-window kernels of the reads the plan gave up on
+  int32_t* d_retry2 = nullptr; int64_t retry2_cap = 0;                              // reads no band kernel could finish
+  uint32_t* d_bx_slabs_late = nullptr; int64_t bx_slab_late_cap = 0; int bx_late_wgs = 0;
+  bool bx_pending_join = false;                                                     // band kernels are still running on stream2 / stream3
   std::string err;
   struct PoolBlock { void* p; size_t cap; bool lent; };
   std::vector<PoolBlock> pool;             // device temporaries of the one-off calls (pool_alloc)
@@ -117,6 +121,9 @@ struct mia_hip_ctx {
   int64_t band_done = 0;
   // the matrix-agnostic band pipeline (bandx_kernels.h): plan -> values-only DP -> trace DP, for any PSSM
   bool bx_ok = false;                       // the matrices allow it (bx_make_tables)
+  bool bx_serial = false;                   // MIA_HIP_BX_SERIAL=1
+  uint32_t bx_dbg = 0;                      // MIA_HIP_BX_DEBUG (profiling): 1 no traceback, 2 one DP row, 4 no values launch, 8 no trace launch
+  int use_lanes = 1;                        // MIA_HIP_NO_LANES=1: the band DPs one read per lane (bx_values / bx_trace) instead of W/8 lanes per read (bandx_lanes.h)
   int use_bx = 1;                           // MIA_HIP_NO_BANDX=1: the round-1 path (flat: filter + k_band_align; PSSM: full-window kernels)
   int bx_filter_first = 0;                  // MIA_HIP_BX_FILTER=1 (flat matrix): k_diag_filter runs ahead of the plan
   int32_t *d_bx_sub = nullptr, *d_bx_mrow = nullptr; int16_t *d_bx_loss = nullptr, *d_bx_dl = nullptr;   // sub | sub * 256; M; losses; block costs
@@ -257,7 +264,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
   mia_hip_ctx* ctx = new mia_hip_ctx();
   ctx->device = device_index;
   if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete ctx;
     return MIA_HIP_ERR_DEVICE;
@@ -283,6 +291,9 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nbd && atoi(nbd)) { ctx->use_banddp = 0; ctx->use_bx = 0; }
     const char* nbx = getenv("MIA_HIP_NO_BANDX");
     if (nbx && atoi(nbx)) ctx->use_bx = 0;
+    if (const char* nl2 = getenv("MIA_HIP_NO_LANES")) if (atoi(nl2)) ctx->use_lanes = 0;
+    if (const char* bd2 = getenv("MIA_HIP_BX_DEBUG")) ctx->bx_dbg = (uint32_t)atoi(bd2);
+    if (const char* bs2 = getenv("MIA_HIP_BX_SERIAL")) ctx->bx_serial = atoi(bs2) != 0;
     const char* egs = getenv("MIA_HIP_EAGER_SCRIPTS");
     if (egs && atoi(egs)) ctx->lazy_scripts = 0;
     const char* nwl = getenv("MIA_HIP_NO_WILD");
@@ -344,6 +355,10 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   for (auto& t : ctx->stg) for (auto& e : t.pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
+  if (ctx->d_retry2) (void)hipFree(ctx->d_retry2);
+  if (ctx->d_bx_slabs_late) (void)hipFree(ctx->d_bx_slabs_late);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
@@ -662,6 +677,22 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
   return hipGetLastError();
 }
 
+// The band kernels of the three-stream order (align_all) are still running beside the context's stream: wait for them
+// there, then let a window kernel take what they put on the retry list (its length stays on the device).
+static int bx_join_and_retry(mia_hip_ctx* ctx) {
+  if (!ctx->bx_pending_join) return MIA_HIP_OK;
+  ctx->bx_pending_join = false;
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
+  const int32_t* range = ctx->d_plan_hdr + PH_RETRY2;
+  const int cols = ctx->max_len + 2 * REALIGN_BUFFER + 2;
+  hipError_t e = cols <= 64 * 4 ? launch_window<4>(ctx, 0, ctx->d_retry2, 0, range)
+               : cols <= 64 * 8 ? launch_window<8>(ctx, 1, ctx->d_retry2, 0, range)
+                                : launch_window<12>(ctx, 2, ctx->d_retry2, 0, range);
+  if (e != hipSuccess) { ctx->err = std::string("k_align_window (band retry list) launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  return MIA_HIP_OK;
+}
+
 static int align_all(mia_hip_ctx* ctx);
 static int comm_pre_cull_enqueue(mia_hip_ctx* ctx, const int32_t* d_wide_count);
 static bool comm_pre_cull_collect(mia_hip_ctx* ctx);
@@ -742,6 +773,7 @@ static int run_wide(mia_hip_ctx* ctx, const RefInfo& ref, int32_t n_wide) {
 static int align_all(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   const int wrap = ctx->wrap;
+  ctx->bx_pending_join = false;
   if (n == 0) { ctx->aligned = true; return MIA_HIP_OK; }
   RefInfo ref{ctx->d_ref, ctx->L, wrap, ctx->explicit_win};
   int32_t* d_count = ctx->d_bins;
@@ -809,18 +841,18 @@ static int align_all(mia_hip_ctx* ctx) {
       hipLaunchKernelGGL(k_kmer_hash, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_khash, ctx->d_khash_ovf,
                          kh.mask, kh.shift, kh.wild);
       if (n > ctx->bx_cap) {
-        if (dev_alloc(ctx, &ctx->d_bx_plan, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_expect, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_lists, (size_t)n * 2 * BX_NCLS))
+        if (dev_alloc(ctx, &ctx->d_bx_plan, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_expect, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_lists, (size_t)n * 3 * BX_NCLS))
           return MIA_HIP_ERR_NOMEM;
         ctx->bx_cap = n;
       }
       if (!ctx->bx_values_wgs) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_bx_values, 256, 0) != hipSuccess || occ < 1) occ = 1;
-        ctx->bx_values_wgs = ctx->cus * occ;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_bx_trace, 256, 0) != hipSuccess || occ < 1) occ = 1;
-        ctx->bx_trace_wgs = ctx->cus * occ;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ctx->use_lanes ? (const void*)k_bxl_values : (const void*)k_bx_values, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        ctx->bx_values_wgs = ctx->cus * std::min(occ, 4);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ctx->use_lanes ? (const void*)k_bxl_trace : (const void*)k_bx_trace, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        ctx->bx_trace_wgs = ctx->cus * std::min(occ, 4);      // (every wavefront of the trace grid owns a slab)
       }
-      const int64_t slab_words = (int64_t)ctx->max_len * BX_SLAB_ROW_WORDS;
+      const int64_t slab_words = (int64_t)ctx->max_len * (ctx->use_lanes ? BXL_SLAB_ROW_WORDS : BX_SLAB_ROW_WORDS);
       if (slab_words * ctx->bx_trace_wgs * 4 > ctx->bx_slab_cap) {
         if (dev_alloc(ctx, &ctx->d_bx_slabs, (size_t)(slab_words * ctx->bx_trace_wgs * 4))) return MIA_HIP_ERR_NOMEM;
         ctx->bx_slab_cap = slab_words * ctx->bx_trace_wgs * 4;
@@ -828,6 +860,18 @@ static int align_all(mia_hip_ctx* ctx) {
       BxDev bd;
       bd.tab.sub = ctx->d_bx_sub; bd.tab.mrow = ctx->d_bx_mrow; bd.tab.loss = ctx->d_bx_loss; bd.tab.dl = ctx->d_bx_dl;
       bd.lazy_scripts = ctx->lazy_scripts;
+      bd.dbg = ctx->bx_dbg & 3u;
+      // MIA_HIP_BX_SERIAL=1: round 2's order (band kernels, then the planner over everything they left open)
+      // (caller-supplied windows -- mia_hip_align_windows -- can be of any length: the retry list's window kernel is picked by read length)
+      const bool new_flow = ctx->use_lanes && !ctx->bx_serial && !(ctx->dbg & 256u) && !ctx->explicit_win;
+      if (new_flow) {
+        if (n > ctx->retry2_cap) { if (dev_alloc(ctx, &ctx->d_retry2, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->retry2_cap = n; }
+        if (!ctx->bx_late_wgs) ctx->bx_late_wgs = ctx->cus;        // the values DP's left-overs are few: one workgroup per CU
+        const int64_t late_words = (int64_t)ctx->max_len * BXL_SLAB_ROW_WORDS * ctx->bx_late_wgs * 4;
+        if (late_words > ctx->bx_slab_late_cap) { if (dev_alloc(ctx, &ctx->d_bx_slabs_late, (size_t)late_words)) return MIA_HIP_ERR_NOMEM; ctx->bx_slab_late_cap = late_words; }
+      }
+      bd.retry = ctx->d_retry2; bd.retry_n = ctx->d_plan_hdr + PH_RETRY2 + 1;
+      bd.listed_mark = new_flow ? -5 : 0;
       if (ctx->lazy_scripts) ctx->diag_scripts_missing = true;
       bd.tab.min_m = ctx->bx_min_m; bd.tab.max_m = ctx->bx_max_m;
       bd.sub256 = ctx->d_bx_sub + BX_SUB_WORDS;
@@ -850,20 +894,52 @@ static int align_all(mia_hip_ctx* ctx) {
       stage_end(ctx, STG_BX_PLAN);
       HIPCHK(hipGetLastError());
       if (!(ctx->dbg & 256u)) {
+        if (new_flow) {
+          // Three things that do not depend on each other run side by side: the trace DP of the plan's own lists (stream3),
+          // the values DP with one more trace launch behind it for what it could not finish (stream2), and -- on the
+          // context's stream, below -- the planner and the full-window kernels for the reads the plan gave up on.  The
+          // step pays the longest of the three instead of their sum; what no band kernel can finish (the reference's
+          // index-0 quirk: next to nothing) goes on a retry list that a window kernel reads behind the join.
+          HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+          HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+          HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
+          if (stage_begin(ctx, STG_BX_TRACE, ctx->stream3)) return MIA_HIP_ERR_NOMEM;
+          if (!(ctx->bx_dbg & 8u))
+            hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of,
+                               (int)BX_NCLS, (int)(BXC_LIST0 + BX_NCLS));
+          stage_end(ctx, STG_BX_TRACE, ctx->stream3);
+          HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
+          if (stage_begin(ctx, STG_BX_VALUES, ctx->stream2)) return MIA_HIP_ERR_NOMEM;
+          if (!(ctx->bx_dbg & 4u)) {
+            hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bin_of);
+            hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of,
+                               (int)(2 * BX_NCLS), (int)BXC_LATE0);
+          }
+          stage_end(ctx, STG_BX_VALUES, ctx->stream2);
+          HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+          HIPCHK(hipGetLastError());
+          ctx->bx_pending_join = true;
+        } else {
         // The two band DPs do not depend on each other (a read the values DP cannot finish stays open for the full-window
         // kernels): they run side by side on two streams -- both are persistent grids whose wavefronts leave as soon as the
         // chunks run out, so each fills what the other leaves idle, and the step pays the longer of the two tails, not both.
         HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
         HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         if (stage_begin(ctx, STG_BX_TRACE, ctx->stream2)) return MIA_HIP_ERR_NOMEM;
-        hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
+        if (ctx->bx_dbg & 8u) {}
+        else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of,
+                                                     (int)BX_NCLS, (int)(BXC_LIST0 + BX_NCLS));
+        else hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
         stage_end(ctx, STG_BX_TRACE, ctx->stream2);
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
         if (stage_begin(ctx, STG_BX_VALUES)) return MIA_HIP_ERR_NOMEM;
-        hipLaunchKernelGGL(k_bx_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
+        if (ctx->bx_dbg & 4u) {}
+        else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
+        else hipLaunchKernelGGL(k_bx_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
         stage_end(ctx, STG_BX_VALUES);
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         HIPCHK(hipGetLastError());
+        }
       }
       ctx->bx_launches++;
     } else if (banded) {
@@ -951,6 +1027,8 @@ static int align_all(mia_hip_ctx* ctx) {
       }
     }
     ck("retry");
+    if (int rcj = bx_join_and_retry(ctx)) return rcj;
+    ck("band join");
     // the one look at the counters: wide / retry counts, the planner's header, filter and band-pipeline counters lie side by
     // side in the control block
     constexpr int C0 = CTRL_BINS + 3 * N_BINS, CN = CTRL_WORDS - C0;
@@ -1012,10 +1090,15 @@ static int align_all(mia_hip_ctx* ctx) {
   ctx->filter_proven += h_filter_n;
   ctx->band_done += (uint32_t)h_misc[6];
   ctx->filter_seen += n;
-  ctx->filter_proven += h_bxc[BXC_DONE_PLAN * BXC_STRIDE];          // finished without any DP: by the diagonal filter or by the band plan
-  for (int k = 0; k < 3; k++) ctx->bx_done[k] += h_bxc[(BXC_DONE_PLAN + k) * BXC_STRIDE];
-  ctx->bx_seen += h_bxc[BXC_SEEN * BXC_STRIDE];
-  for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = h_bxc[k * BXC_STRIDE];
+  // (with the band kernels still running beside this stream their counters are read behind the join, below)
+  const bool bx_counters_later = ctx->bx_pending_join;
+  auto take_bx_counters = [&]() {
+    ctx->filter_proven += h_bxc[BXC_DONE_PLAN * BXC_STRIDE];          // finished without any DP: by the diagonal filter or by the band plan
+    for (int k = 0; k < 3; k++) ctx->bx_done[k] += h_bxc[(BXC_DONE_PLAN + k) * BXC_STRIDE];
+    ctx->bx_seen += h_bxc[BXC_SEEN * BXC_STRIDE];
+    for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = h_bxc[k * BXC_STRIDE];
+  };
+  if (!bx_counters_later) take_bx_counters();
   int run = 0;
   for (int b = 0; b < N_BINS; b++) {
     h_off[b] = run;
@@ -1095,10 +1178,13 @@ static int align_all(mia_hip_ctx* ctx) {
       }
     }
   }
+  if (ctx->bx_pending_join) { if (int rcj = bx_join_and_retry(ctx)) return rcj; wide_known = false; }
   // exact kernel for whole-reference windows and escaped reads
   if (!wide_known) {
     HIPCHK(hipMemcpyAsync(&h_misc[2], d_wide_count, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (bx_counters_later) HIPCHK(hipMemcpyAsync(h_bxc, ctx->d_bx_ctr, BXC_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (bx_counters_later) take_bx_counters();
   }
   const int32_t n_wide = h_misc[2];
   if (n_wide > 0) { if (int rcw = run_wide(ctx, ref, n_wide)) return rcw; }

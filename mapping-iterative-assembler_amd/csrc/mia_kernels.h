@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
       const int mark = filtered ? bin_of[i] : 0;
       if (mark == -2) {
         was_done = true;
-      } else if (mark == -4) {                 // finished by k_band_align (counted there)
+      } else if (mark == -4 || mark == -5) {   // finished by a band kernel (counted there), or on one of its lists (it may be finishing
+                                               // the read this very moment: the planner runs beside the band kernels and must not touch the mark)
       } else if (rs.sk[i]) {
         int s, l1;
         read_window(ref, rs.as[i], rs.ae[i], rs.len[i], &s, &l1);
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void k_plan_count(ReadSet rs, RefInfo ref, Pac
       } else {
         rs.status[i] = ST_SKIPPED;
       }
-      bin_of[i] = b;
+      if (mark != -4 && mark != -5) bin_of[i] = b;
     }
     hist_add_aggregated(hist, b);
     const unsigned long long dm = __ballot(was_done);
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(256) void k_plan_fill(int64_t n, const int32_t* bin
 //   hdr[PH_WIN + 2 ci] = {offset, count} of window class ci,  hdr[PH_QUAD] = {offset, quads},  hdr[PH_WIDE0] = {offset, count}
 //   hdr[PH_RETRY] = {0, reads whose path left the quad kernel's trace band} (k_align_quad counts into the second word)
 //   hdr[PH_TOTAL] = list entries in use (padding included)
-enum { PH_WIN = 0, PH_QUAD = 2 * N_CPL, PH_WIDE0 = PH_QUAD + 2, PH_RETRY = PH_WIDE0 + 2, PH_TOTAL = PH_RETRY + 2, PH_RETRIED_PLAIN, PH_WORDS = 16 };
+enum { PH_WIN = 0, PH_QUAD = 2 * N_CPL, PH_WIDE0 = PH_QUAD + 2, PH_RETRY = PH_WIDE0 + 2, PH_TOTAL = PH_RETRY + 2, PH_RETRIED_PLAIN, PH_RETRY2, PH_WORDS = 16 };
+static_assert(PH_RETRY2 + 2 <= PH_WORDS && (PH_RETRY2 & 1) == 0, "hdr[PH_RETRY2] = {0, reads the band kernels put on the retry list}: an aligned pair");
 __global__ __launch_bounds__(512) void k_plan_scan(const int32_t* count, int32_t* off, int32_t* hdr, int32_t quads_only) {
   __shared__ int32_t sh[512];
   const int b = threadIdx.x;
