@@ -405,13 +405,15 @@ def section_converge(hip_mod, device, cfg, n, seed, peaks, no_cpu, max_iters=12)
     return out
 
 
-def section_myers(hip):
-    """myers_diff (reference src/myers_align.c:10-99) as a batch: 10 000 pairs of 100-300 characters with ~3 % edits, and
-    the ccheck-sized pair (16.6 kb, maxd = len/10 as src/ccheck.cc:477)."""
+def section_myers(hip, no_cpu=False):
+    """myers_diff (reference src/myers_align.c:10-99) as a batch: 100 000 pairs of 100-300 characters with ~3 % edits (what a
+    read-against-read use holds; one pair per lane), and the ccheck-sized pair (16.6 kb, maxd = len/10 as src/ccheck.cc:477;
+    one pair per wavefront).  Kernel figures from HIP events (mia_hip_myers_time), wall figures including the packing of the
+    strings on the host and the copies; the reference's own myers_diff on one host core beside them."""
     rng = np.random.default_rng(7)
     bases = np.frombuffer(b"ACGT", dtype=np.uint8)
     A, B = [], []
-    for _ in range(10_000):
+    for _ in range(100_000):
         n = int(rng.integers(100, 301))
         a = bases[rng.integers(0, 4, n)].copy()
         b = a.copy()
@@ -425,7 +427,10 @@ def section_myers(hip):
     t0 = time.perf_counter()
     d = hip.myers(A, B, mode, maxd)
     dt = time.perf_counter() - t0
+    k_ms = hip.myers_time()
     cells = sum(len(a) * len(b) for a, b in zip(A, B))
+    # algorithmic bytes: both sequences as 4-bit codes in, one distance out
+    algo_bytes = sum((len(a) + len(b) + 1) // 2 + 4 for a, b in zip(A, B))
     big = bases[rng.integers(0, 4, 16_600)].copy()
     big2 = big.copy()
     for p in rng.integers(0, len(big), 160):
@@ -433,9 +438,26 @@ def section_myers(hip):
     t1 = time.perf_counter()
     dbig = hip.myers([big.tobytes()], [big2.tobytes()], np.zeros(1, np.int32), np.full(1, 1660, np.int32))
     dt_big = time.perf_counter() - t1
-    return {"pairs": len(A), "pairs_per_s": len(A) / dt, "gcups": cells / dt / 1e9, "mean_distance": float(d[d != 0xFFFFFFFF].mean()),
-            "pair_16k6_ms": dt_big * 1e3, "pair_16k6_distance": int(dbig[0]),
-            "note": "wall time of mia_hip_myers including packing and PCIe; one pair per wavefront, 64-bit lanes"}
+    out = {"pairs": len(A), "pairs_per_s": len(A) / dt, "gcups": cells / dt / 1e9, "mean_distance": float(d[d != 0xFFFFFFFF].mean()),
+           "kernel_ms": k_ms, "kernel_pairs_per_s": len(A) / (k_ms * 1e-3), "kernel_gcups": cells / (k_ms * 1e-3) / 1e9,
+           "roofline": {"bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "bit-vector DP: 64 cells per 64-bit operation, bound by integer issue; bytes = packed sequences in + distances out"},
+           "pair_16k6_ms": dt_big * 1e3, "pair_16k6_kernel_ms": hip.myers_time(), "pair_16k6_distance": int(dbig[0]),
+           "note": "wall figures include strlen, packing and PCIe (mia_hip_myers takes C strings); k_myers_lanes: one pair per lane, "
+                   "k_myers: one pair per wavefront, 64-bit lanes"}
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_myers_driver")
+    if not no_cpu and os.path.exists(drv):
+        m = 4000
+        inp = "".join("0 64 %s %s\n" % (a.decode(), b.decode()) for a, b in zip(A[:m], B[:m]))
+        t2 = time.perf_counter()
+        r = subprocess.run([drv], input=inp.encode(), stdout=subprocess.PIPE)
+        cpu_dt = time.perf_counter() - t2
+        ok = [int(x.split()[0]) for x in r.stdout.decode().strip().split("\n")]
+        out["cpu_baseline"] = {"value": m / cpu_dt, "unit": "pairs/s", "cores": 1, "kind": "reference",
+                               "sample": f"{m} of the same pairs through oracle/_ref/ref_myers_driver (the reference's myers_diff with backtrace), "
+                                         f"{cpu_dt:.2f} s; distances equal: {ok == [int(x) for x in d[:m]]}"}
+    return out
 
 
 def self_launch(a):
@@ -658,7 +680,7 @@ def main():
                              "reads": m, "kept": int((fl & 2).astype(bool).sum()), "decided_by_diag_filter": hip.pass1_filtered(),
                              "decided_by_anchored_windows": hip.pass1_anchored()}
             out["pass1"] = p1
-            out["myers"] = section_myers(hip)
+            out["myers"] = section_myers(hip, a.no_cpu_baseline)
         if a.pmc_run:
             hip.measure_peaks(1 << 28)           # k_peak_copy in the counter passes: the FETCH_SIZE calibration
         if not a.no_cpu_baseline and world == 1:      # the CPU comparator is timed beside the single-GPU line only

@@ -311,6 +311,10 @@ int mia_hip_get_ins_tally(mia_hip_ctx *ctx, int32_t *ins_off, int32_t *ins_tally
 int mia_hip_myers(mia_hip_ctx *ctx, int64_t n_pairs, const char *const *seq_a, const char *const *seq_b, const int32_t *mode,
                   const int32_t *maxd, uint32_t *dist);
 
+/* duration of the kernels of the most recent mia_hip_myers call, from HIP events on the context's stream (diagnostic:
+ * bench.py prices the kernel apart from the packing of the strings and the copies) */
+int mia_hip_myers_time(mia_hip_ctx *ctx, double *kernel_ms);
+
 /* One myers_diff call with its backtrace (what ccheck asks for, src/ccheck.cc:478-480): the distance comes from the
  * bit-vector kernel above; the two rows of the alignment (bt_a over seq_a, bt_b over seq_b, '-' for a gap) are
  * rebuilt on the host from the furthest-reaching D-paths with the reference's preferences (src/myers_align.c:47-83).

@@ -64,6 +64,7 @@ def _load():
     lib.mia_hip_bx_counters.argtypes = [vp, vp]
     lib.mia_hip_myers_align.argtypes = [vp, C.c_char_p, C.c_int32, C.c_char_p, C.c_int32, vp, vp, vp]
     lib.mia_hip_pass1_time.argtypes = [vp, P(C.c_double)]
+    lib.mia_hip_myers_time.argtypes = [vp, P(C.c_double)]
     lib.mia_hip_ma_tally.argtypes = [vp, C.c_int32, vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
     lib.mia_hip_trim.argtypes = [vp, C.c_char_p, C.c_int64, vp, vp, vp, vp]
     lib.mia_hip_set_back_slots.argtypes = [vp, vp]
@@ -112,7 +113,7 @@ def exported_symbols():
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_align_windows", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_myers_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
             "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask", "mia_hip_comm_unique_id", "mia_hip_comm_init", "mia_hip_comm_destroy",
@@ -381,6 +382,12 @@ class MiaHip:
         self._chk(self._l.mia_hip_iterate(self._h, ref, len(ref), 1 if circular else 0, hard_cut, _ptr(sc), cons_code, self._cons_buf,
                                           self._cons_buf_cap, C.byref(n)))
         return self._cons_buf.raw[: n.value].decode()
+
+    def myers_time(self):
+        """kernel time (ms, HIP events) of the last myers() call"""
+        v = C.c_double(0)
+        self._chk(self._l.mia_hip_myers_time(self._h, C.byref(v)))
+        return v.value
 
     def pass1_anchored(self):
         """reads of the last pass1() call decided by windowed alignment around their 10-mer anchors"""

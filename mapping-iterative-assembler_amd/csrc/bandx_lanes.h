@@ -338,24 +338,41 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
     // skipped are inserts
     const int off0 = aec - R;
     for (int q0 = 0; q0 < len2; q0 += 4) {
-      uint32_t v[4];
+      // a group of four rows that no break touches -- nearly all of them -- is four consecutive columns
+      int off = off0;
+      bool clean = q0 >= abr;
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int q = q0 + t;
-        int col = q + off0;
-        bool ins = false;
-#pragma unroll
-        for (int e = 0; e < EV; e++) {
-          const bool above = ev_row[e] > q;              // (unused entries: row -1)
-          const int d = ev_delta[e];
-          if (above) col += d < 0 ? d : d;               // a column gap of n: the rows above it lie n columns further LEFT; a row gap of n rows: n further RIGHT
-          ins = ins || (above && d > 0 && q >= ev_row[e] - d);
+      for (int e = 0; e < EV; e++) {
+        const int er = ev_row[e], d = ev_delta[e];       // (unused entries: row -1, never above anything)
+        if (er > q0) {
+          off += d;
+          if (er - (d > 0 ? d : 0) <= q0 + 3) clean = false;       // the break itself, or the rows a row gap skipped, fall into the group
         }
-        v[t] = (uint32_t)(uint16_t)(int16_t)(q < abr ? COL_CLIP : (ins ? COL_INSERT : col));
       }
       uint2 w2;
-      w2.x = v[0] | (v[1] << 16);
-      w2.y = v[2] | (v[3] << 16);
+      if (clean) {
+        const uint32_t c0 = (uint32_t)(q0 + off);
+        w2.x = (c0 & 0xFFFFu) | ((c0 + 1u) << 16);
+        w2.y = ((c0 + 2u) & 0xFFFFu) | ((c0 + 3u) << 16);
+      } else {
+        uint32_t v[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const int q = q0 + t;
+          int col = q + off0;
+          bool ins = false;
+#pragma unroll
+          for (int e = 0; e < EV; e++) {
+            const bool above = ev_row[e] > q;
+            const int d = ev_delta[e];
+            if (above) col += d;                         // a column gap of n: the rows above it lie n columns further LEFT (d = -n); a row gap of n rows: n further RIGHT
+            ins = ins || (above && d > 0 && q >= ev_row[e] - d);
+          }
+          v[t] = (uint32_t)(uint16_t)(int16_t)(q < abr ? COL_CLIP : (ins ? COL_INSERT : col));
+        }
+        w2.x = v[0] | (v[1] << 16);
+        w2.y = v[2] | (v[3] << 16);
+      }
       *reinterpret_cast<uint2*>(cols_out + q0) = w2;     // (the script row is a multiple of four entries long and 8-byte aligned)
     }
     return true;

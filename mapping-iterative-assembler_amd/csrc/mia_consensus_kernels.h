@@ -196,16 +196,20 @@ struct Links {                // [cap][4] int64: reader (global read index), slo
 // inserted bases per record and bases in the front: one read per wavefront (the script walk of the tally's pass A)
 // A block takes 256 reads.  Proven-diagonal reads (ST_DIAG, the large majority) need no script: one thread each.  The
 // others are walked by the block's four wavefronts, 64 script rows at a time (ballot counts).
-__device__ __forceinline__ void rec_store(int64_t i, const RecGeom& g, int nf, int nb, int af, int bases, const int64_t* slot, RecInfo& ri,
-                                          SlotInfo& si, int64_t read_base, uint32_t* flags) {
+__device__ __forceinline__ void rec_store_at(int64_t i, const RecGeom& g, int nf, int nb, int af, int bases, int64_t slot_i, RecInfo& ri,
+                                             SlotInfo& si, int64_t read_base, uint32_t* flags) {
   const int flen = g.ncols_f + nf, blen = g.split ? g.ncols_b + nb : 0;
   ri.flen[i] = flen; ri.blen[i] = blen; ri.actf[i] = af + nf;
-  const int64_t ls = slot[i] - si.base;
+  const int64_t ls = slot_i - si.base;
   if (ls >= 0 && ls + (g.split ? 1 : 0) < (*si.n_local_p)) {
     const unsigned long long me = ((unsigned long long)(read_base + i) << 20) | LINK_NONE;
     si.reclen[ls] = flen; si.recact[ls] = af + nf; si.mult[ls] = 1; si.writer[ls] = me;
     if (g.split) { si.reclen[ls + 1] = blen; si.recact[ls + 1] = bases - (af + nf); si.mult[ls + 1] = 1; si.writer[ls + 1] = me; }
   } else atomicOr(flags, 4u);
+}
+__device__ __forceinline__ void rec_store(int64_t i, const RecGeom& g, int nf, int nb, int af, int bases, const int64_t* slot, RecInfo& ri,
+                                          SlotInfo& si, int64_t read_base, uint32_t* flags) {
+  rec_store_at(i, g, nf, nb, af, bases, slot[i], ri, si, read_base, flags);
 }
 
 __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const int64_t* slot, RecInfo ri, SlotInfo si, int64_t read_base,
@@ -285,6 +289,171 @@ __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const i
     }
     if (lane == 0) rec_store(i, g, nf, nb, af, len2 - abr, slot, ri, si, read_base, flags);
   }
+}
+
+// ---- the cull's first half as two launches (mia_hip_cull; k_scan_blocks / _partials / _apply, k_rec_geom and k_cull_mark
+// above remain for the entry points that need one of them alone) -----------------------------------------------------------
+// k_slot_count: AlnSeq records per stretch of 256 reads (a workgroup takes sixteen stretches one after the other: one
+// arrival per 4 096 reads -- a counter every block of 256 adds to is served one add at a time, 80 us for a million reads);
+// the workgroup that arrives last turns the counts into exclusive offsets (+ base) and leaves the total in *total.
+// nb: stretches.  *blocks_done must be 0 on entry and is 0 again on exit.
+__global__ __launch_bounds__(256) void k_slot_count(ReadSet rs, int32_t L, int64_t* partial, int nb, int64_t base, int64_t* total, uint32_t* blocks_done) {
+  __shared__ bool last;
+  __shared__ int64_t s_run[256];
+  __shared__ int32_t wsum[16][4];
+  // stretch k of this workgroup = reads base + 256 k .. + 255, one per thread (neighbouring threads, neighbouring reads)
+  const int64_t base_read = (int64_t)blockIdx.x * 4096;
+  for (int k = 0; k < 16; k++) {
+    const int64_t i = base_read + k * 256 + threadIdx.x;
+    const int cnt = (i < rs.n && rs.sk[i]) ? (rec_geom(rs.as[i], rs.ae[i], L).split ? 2 : 1) : 0;
+    const int w = __popcll(__ballot(cnt >= 1)) + __popcll(__ballot(cnt == 2));
+    if ((threadIdx.x & 63) == 0) wsum[k][threadIdx.x >> 6] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && blockIdx.x * 16 + (int)threadIdx.x < nb)
+    partial[blockIdx.x * 16 + threadIdx.x] = (int64_t)wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(blocks_done, 1u) == (uint32_t)gridDim.x - 1u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // (k_scan_partials: every thread a run of the partial sums, a scan over the 256 run sums in LDS)
+  const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
+  int64_t mine = 0;
+  for (int b2 = b0; b2 < b1; b2++) mine += __builtin_nontemporal_load(partial + b2);
+  s_run[t] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int64_t a2 = t >= o ? s_run[t - o] : 0;
+    __syncthreads();
+    s_run[t] += a2;
+    __syncthreads();
+  }
+  int64_t run = base + s_run[t] - mine;
+  for (int b2 = b0; b2 < b1; b2++) { const int64_t v = __builtin_nontemporal_load(partial + b2); partial[b2] = run; run += v; }
+  if (t == 255) *total = s_run[255];
+  if (t == 0) *blocks_done = 0;
+}
+
+// k_cull_records: slot numbers (k_scan_apply), record geometry (k_rec_geom) and the reads' own dropped marks / back slots /
+// links (k_cull_mark) of a block of 256 reads in one go: what the three kernels hand each other per read stays in registers.
+__global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, const int64_t* partial, int64_t* slot, RecInfo ri, SlotInfo si, int64_t read_base,
+                                                        uint32_t* flags, uint8_t* slot_dropped, int64_t n_slots, int32_t hard_cut, double slope, double intercept,
+                                                        int64_t* back_slot, const int64_t* front_slot0, Links lk, const double* dev_cut) {
+  __shared__ int32_t wsum[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);     // first read of this wavefront
+  const int64_t me = i0 + lane;
+  const bool in = me < rs.n;
+  const bool sk = in && rs.sk[me];
+  int as_me = 0, ae_me = 0;
+  if (sk) { as_me = rs.as[me]; ae_me = rs.ae[me]; }
+  const RecGeom g_me = rec_geom(as_me, ae_me, L);
+  // ---- slot of every read: exclusive scan of the record counts (1, or 2 when split at the origin) over the block
+  const int cnt = sk ? (g_me.split ? 2 : 1) : 0;
+  const unsigned long long m1 = __ballot(cnt >= 1), m2 = __ballot(cnt == 2), below = (1ull << lane) - 1ull;
+  if (lane == 0) wsum[wv] = __popcll(m1) + __popcll(m2);
+  __syncthreads();
+  int64_t my_slot = partial[blockIdx.x] + __popcll(m1 & below) + __popcll(m2 & below);
+  for (int k = 0; k < wv; k++) my_slot += wsum[k];
+  if (in) slot[me] = my_slot;
+  // ---- record geometry (k_rec_geom)
+  int my_flen = 0, my_actf = 0;
+  bool walk = false;
+  if (in) {
+    if (!sk) { ri.flen[me] = 0; ri.blen[me] = 0; ri.actf[me] = 0; }
+    else if (rs.status[me] & ST_DIAG) {
+      const int len2 = rs.len[me], abr = rs.abr[me];
+      const int af = (len2 - abr) < g_me.ncols_f ? (len2 - abr) : g_me.ncols_f;
+      rec_store_at(me, g_me, 0, 0, af, len2 - abr, my_slot, ri, si, read_base, flags);
+      my_flen = g_me.ncols_f; my_actf = af;
+    } else if ((rs.status[me] & ST_ONEGAP) && !g_me.split) {
+      const uint32_t desc = rs.status[me] >> 8;
+      const int len2 = rs.len[me], abr = rs.abr[me], gn = (int)((desc >> 10) & 63u), ins = (int)(desc & 1u);
+      rec_store_at(me, g_me, ins ? gn : 0, 0, len2 - abr - (ins ? gn : 0), len2 - abr, my_slot, ri, si, read_base, flags);
+      my_flen = g_me.ncols_f + (ins ? gn : 0); my_actf = len2 - abr;
+    } else walk = true;
+  }
+  unsigned long long todo = __ballot(walk);
+  while (todo) {
+    const int li = __builtin_ctzll(todo);
+    const int64_t i = i0 + li;
+    todo &= todo - 1;
+    const int len2 = rs.len[i], abr = rs.abr[i];
+    const RecGeom g = rec_geom(rs.as[i], rs.ae[i], L);
+    const int16_t* cols = rs.cols + (int64_t)i * rs.stride;
+    const int cbase = rs.refstart[i] - g.start_w;
+    int nf = 0, nb = 0, af = 0;
+    int n_ev = 0, ins_rows = 0, ev_row = 0, ev_len = 0, ev_kind = 0;
+    for (int r0 = abr; r0 < len2; r0 += 64) {
+      const int r = r0 + lane;
+      bool isF = false, isB = false, alF = false, ins_row = false, ins_start = false, jump = false;
+      int jump_len = 0;
+      if (r < len2) {
+        const int cp = r > abr ? (int)cols[r - 1] : -3;
+        if (cols[r] == COL_INSERT) {
+          int rn = r + 1;
+          while (rn < len2 && cols[rn] < 0) rn++;
+          const int o = cbase + cols[rn];
+          if (o < g.ncols_f) isF = true; else if (g.split && o - g.ncols_f < g.ncols_b) isB = true;
+          ins_row = true;
+          ins_start = cp != COL_INSERT;
+        } else if (cols[r] >= 0) {
+          alF = (cbase + cols[r]) < g.ncols_f;
+          if (cp >= 0 && cols[r] - cp > 1) { jump = true; jump_len = cols[r] - cp - 1; }
+        }
+      }
+      nf += __popcll(__ballot(isF));
+      nb += __popcll(__ballot(isB));
+      af += __popcll(__ballot(alF));
+      const unsigned long long m_ins = __ballot(ins_start), m_del = __ballot(jump);
+      ins_rows += __popcll(__ballot(ins_row));
+      if (n_ev == 0 && (m_ins | m_del)) {
+        const int l = __builtin_ctzll(m_ins | m_del);
+        ev_row = r0 + l;
+        ev_kind = (int)((m_ins >> l) & 1ull);
+        ev_len = __shfl(jump_len, l);
+      }
+      n_ev += __popcll(m_ins) + __popcll(m_del);
+    }
+    const int64_t slot_i = __shfl(my_slot, li);
+    if (lane == 0) {
+      const uint32_t st = rs.status[i];
+      if (!(st & (ST_ESCAPE | ST_TOO_LONG | ST_SKIPPED | ST_BAND | ST_DIAG))) {
+        const int gn = ev_kind ? ins_rows : ev_len, n_al = len2 - abr;
+        const bool one = n_ev == 1 && !g.split && gn > 0 && gn < 64 && ev_row < 512 && g.ncols_f == (ev_kind ? n_al - gn : n_al + gn);
+        const uint32_t want = one ? (ST_ONEGAP | (((uint32_t)ev_kind | ((uint32_t)ev_row << 1) | ((uint32_t)gn << 10)) << 8)) : ST_OK;
+        if (st != want) rs.status[i] = want;
+      }
+      rec_store_at(i, g, nf, nb, af, len2 - abr, slot_i, ri, si, read_base, flags);
+    }
+    if (lane == li) { my_flen = g.ncols_f + nf; my_actf = af + nf; }        // (the counts are wave-uniform: the read's own lane keeps them for its link)
+  }
+  // ---- own dropped marks, the persistent back slot, the links of formerly split reads (k_cull_mark)
+  if (!in) return;
+  if (dev_cut) { slope = dev_cut[0]; intercept = dev_cut[1]; }
+  const double min_score = hard_cut > 0 ? (double)hard_cut : (double)(intercept + (slope * (double)rs.len[me]));
+  const bool low = (double)rs.score[me] < min_score;
+  auto add_link = [&](int64_t target, int kind, int fl, int ac) {
+    const int e = atomicAdd(lk.n, 1);
+    if (e < lk.cap) {
+      int64_t* r = lk.rec + (int64_t)e * 4;
+      r[0] = read_base + me; r[1] = target;
+      r[2] = ((int64_t)fl << 32) | (uint32_t)ac;
+      r[3] = (low ? 1 : 0) | (kind << 8);
+    } else atomicOr(flags, 8u);
+  };
+  if (!sk) {
+    if (front_slot0[me] >= 0) add_link(front_slot0[me], 1, 0, 0);
+    if (back_slot[me] >= 0) add_link(back_slot[me], 2, 0, 0);
+    return;
+  }
+  if (low && my_slot < n_slots) slot_dropped[my_slot] = 1;
+  if (g_me.split) {
+    if (low && my_slot + 1 < n_slots) slot_dropped[my_slot + 1] = 1;
+    back_slot[me] = my_slot + 1;
+  } else if (back_slot[me] >= 0) add_link(back_slot[me], 0, my_flen, my_actf);
 }
 
 // own dropped marks, the persistent back slot, and the links of formerly split reads
@@ -549,9 +718,12 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
 
 // ---- bucketing of the reads by alignment start (counting sort, one pass per iteration) ----
 constexpr int BUCKET_PER = 8;   // reads per thread of the bucketing kernels
-__global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count) {
+// zero / zero_words: a buffer this launch clears on the side (the tally, the gaps and the ranks' event-count slots behind them:
+// nothing adds to them before the tally kernel, which runs behind this one), or nullptr
+__global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count, int32_t* zero, int64_t zero_words) {
   extern __shared__ int32_t hist[];
   for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
+  if (zero) for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < zero_words; k += (int64_t)gridDim.x * 256) zero[k] = 0;
   __syncthreads();
   for (int k = 0; k < BUCKET_PER; k++) {
     const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
@@ -561,7 +733,7 @@ __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, in
   for (int b = threadIdx.x; b < nb; b += blockDim.x) if (hist[b]) atomicAdd(&count[b], hist[b]);
 }
 // off[b] = first read of bucket b in `order`, wgoff[b] = first workgroup of bucket b (TALLY_CHUNK reads each)
-__global__ __launch_bounds__(256) void k_bucket_scan(const int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor, int32_t* wg_bucket) {
+__global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor, int32_t* wg_bucket) {
   // one workgroup of 256 threads: every thread a stretch of buckets, a scan over the 256 partial sums in LDS
   __shared__ int32_t s_run[256], s_wg[256];
   const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
@@ -578,9 +750,11 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const int32_t* count, int32
   int r = s_run[t] - run, w = s_wg[t] - wg;
   for (int b = b0; b < b1; b++) {
     off[b] = r; wgoff[b] = w; cursor[b] = 0;
-    const int nw = (count[b] + TALLY_CHUNK - 1) / TALLY_CHUNK;
+    const int cb = count[b];
+    const int nw = (cb + TALLY_CHUNK - 1) / TALLY_CHUNK;
     for (int q = 0; q < nw; q++) wg_bucket[w + q] = b;          // (the tally's workgroups look their bucket up instead of searching wgoff)
-    r += count[b]; w += nw;
+    r += cb; w += nw;
+    count[b] = 0;                                               // read for the last time: clean for the next call's k_bucket_count
   }
   if (t == 255) { off[nb] = s_run[255]; wgoff[nb] = s_wg[255]; }
 }
@@ -1221,15 +1395,19 @@ __global__ void k_call_columns(const int32_t* tally, int32_t Lp, int32_t L, int 
                        tally[T_GAP * Lp + p], tally[T_COV * Lp + p], tally[T_SA * Lp + p], tally[T_SC * Lp + p],
                        tally[T_SG * Lp + p], tally[T_ST * Lp + p], cons_code);
 }
-__global__ void k_call_inserts(const int32_t* tally, int32_t Lp, int32_t L, const int32_t* gaps, const int32_t* ins_off,
-                               const int32_t* ins_tally, int cons_code, char* ins_calls, int32_t cap) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p <= 0 || p >= L) return;
+__device__ __forceinline__ void call_inserts_at(int p, const int32_t* tally, int32_t Lp, const int32_t* gaps, const int32_t* ins_off,
+                                                const int32_t* ins_tally, int cons_code, char* ins_calls, int32_t cap) {
   const int span = tally[T_SPAN * Lp + p];
   for (int j = 0; j < gaps[p] && ins_off[p] + j < cap; j++) {
     const int32_t* t = ins_tally + (int64_t)(ins_off[p] + j) * 9;
     ins_calls[ins_off[p] + j] = call_base(t[0], t[1], t[2], t[3], span - t[4], span, t[5], t[6], t[7], t[8], cons_code);
   }
+}
+__global__ void k_call_inserts(const int32_t* tally, int32_t Lp, int32_t L, const int32_t* gaps, const int32_t* ins_off,
+                               const int32_t* ins_tally, int cons_code, char* ins_calls, int32_t cap) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p <= 0 || p >= L) return;
+  call_inserts_at(p, tally, Lp, gaps, ins_off, ins_tally, cons_code, ins_calls, cap);
 }
 
 }  // namespace mia

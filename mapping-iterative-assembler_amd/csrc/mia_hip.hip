@@ -121,6 +121,9 @@ struct mia_hip_ctx {
   int64_t band_done = 0;
   // the matrix-agnostic band pipeline (bandx_kernels.h): plan -> values-only DP -> trace DP, for any PSSM
   bool bx_ok = false;                       // the matrices allow it (bx_make_tables)
+  uint32_t* d_cull_sync = nullptr;          // k_slot_count's arrival counter (zero between launches)
+  double myers_kernel_ms = 0; bool myers_no_lanes = false;   // the kernels of the last mia_hip_myers call (HIP events); MIA_HIP_MYERS_NO_LANES=1: every pair through k_myers
+  int bucket_clean_nb = -1;                 // the tally's bucket counts are zero for this bucket count (k_bucket_scan leaves them so)
   bool bx_serial = false;                   // MIA_HIP_BX_SERIAL=1
   uint32_t bx_dbg = 0;                      // MIA_HIP_BX_DEBUG (profiling): 1 no traceback, 2 one DP row, 4 no values launch, 8 no trace launch
   int use_lanes = 1;                        // MIA_HIP_NO_LANES=1: the band DPs one read per lane (bx_values / bx_trace) instead of W/8 lanes per read (bandx_lanes.h)
@@ -294,6 +297,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* nl2 = getenv("MIA_HIP_NO_LANES")) if (atoi(nl2)) ctx->use_lanes = 0;
     if (const char* bd2 = getenv("MIA_HIP_BX_DEBUG")) ctx->bx_dbg = (uint32_t)atoi(bd2);
     if (const char* bs2 = getenv("MIA_HIP_BX_SERIAL")) ctx->bx_serial = atoi(bs2) != 0;
+    if (const char* ml = getenv("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
     const char* egs = getenv("MIA_HIP_EAGER_SCRIPTS");
     if (egs && atoi(egs)) ctx->lazy_scripts = 0;
     const char* nwl = getenv("MIA_HIP_NO_WILD");
@@ -358,6 +362,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
   if (ctx->d_retry2) (void)hipFree(ctx->d_retry2);
+  if (ctx->d_cull_sync) (void)hipFree(ctx->d_cull_sync);
   if (ctx->d_bx_slabs_late) (void)hipFree(ctx->d_bx_slabs_late);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -487,7 +492,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_wide_list, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_retry_list, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_slot, (size_t)n);
-  rcx |= dev_alloc(ctx, &ctx->d_partial, (size_t)(n / 4096 + 2));
+  rcx |= dev_alloc(ctx, &ctx->d_partial, (size_t)(n / 256 + 2));
   rcx |= dev_alloc(ctx, &ctx->d_drop_f, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_drop_b, (size_t)n);
   ctx->n_slots = 2 * n + 16;
@@ -1302,10 +1307,14 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   HIPCHK(hipSetDevice(ctx->device));
   const int64_t n = ctx->rs.n;
   if (n == 0) return MIA_HIP_OK;
-  const int nb = (int)((n + 4095) / 4096);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial);
-  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partial, nb, slot_base, ctx->d_total);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, ctx->d_slot);
+  // (two launches: record counts per block of 256 reads, scanned by the block that finishes last; then slots, record
+  // geometry, dropped marks and links of every read in one kernel -- k_slot_count / k_cull_records)
+  const int nb = (int)((n + 255) / 256);
+  if (!ctx->d_cull_sync) {
+    if (dev_alloc(ctx, &ctx->d_cull_sync, 4)) return MIA_HIP_ERR_NOMEM;
+    HIPCHK(hipMemsetAsync(ctx->d_cull_sync, 0, 16, ctx->stream));
+  }
+  hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, nb, slot_base, ctx->d_total, ctx->d_cull_sync);
   if (slot_base + 2 * n + 16 > ctx->n_slots) {   // sharded runs: slots are global indices
     uint8_t* nd = nullptr;
     const int64_t ns = slot_base + 2 * n + 16;
@@ -1323,11 +1332,9 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   ctx->si.base = slot_base;
   ctx->si.n_local_p = ctx->d_total;
   if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 8, ctx->stream));                     // link count, cull flags (neighbours in the control block)
-  hipLaunchKernelGGL(k_rec_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->ri, ctx->si,
-                     ctx->read_base, ctx->d_cull_flags);
-  hipLaunchKernelGGL(k_cull_mark, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
-                     ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot, ctx->d_front_slot0, ctx->ri, ctx->lk, ctx->read_base,
-                     ctx->d_cull_flags, ctx->dev_cut);
+  hipLaunchKernelGGL(k_cull_records, dim3((unsigned)nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, (const int64_t*)ctx->d_partial, ctx->d_slot, ctx->ri, ctx->si,
+                     ctx->read_base, ctx->d_cull_flags, ctx->d_slot_dropped, ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot,
+                     (const int64_t*)ctx->d_front_slot0, ctx->lk, ctx->dev_cut);
   HIPCHK(hipGetLastError());
   // by default the links to apply are this context's own; a sharded run replaces them with the gathered list (mia_hip_set_links)
   ctx->d_links_all = ctx->lk.rec;
@@ -1613,9 +1620,12 @@ static int tally_launch(mia_hip_ctx* ctx) {
   int rc = ensure_tally(ctx);
   if (rc) return rc;
   const int Lp = ctx->tb.Lp;
-  HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, ((size_t)(TALLY_WORDS + 1) * Lp + 256) * 4, ctx->stream));      // tally, gaps, the ranks' event counts
+  const int64_t tally_words = (int64_t)(TALLY_WORDS + 1) * Lp + 256;                               // tally, gaps, the ranks' event counts
   if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->tb.n_events, 0, 8, ctx->stream));              // event count, flags (neighbours in the control block)
   const int64_t n = ctx->rs.n;
+  const int nb_plan = ctx->wrap / TALLY_BUCKET + 1;
+  const bool binned = n > 0 && ctx->use_binned_tally && nb_plan <= 4096 && ctx->max_abs <= 32767;
+  if (!binned) HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, (size_t)tally_words * 4, ctx->stream));     // (the binned path clears it inside k_bucket_count)
   if (n > 0) {
     RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
     const int nb = ctx->wrap / TALLY_BUCKET + 1;
@@ -1625,12 +1635,14 @@ static int tally_launch(mia_hip_ctx* ctx) {
       if (4 * (nb + 1) + grid > ctx->bucket_cap) {
         if (dev_alloc(ctx, &ctx->d_bucket, (size_t)(4 * (nb + 1) + grid) * 2)) return MIA_HIP_ERR_NOMEM;
         ctx->bucket_cap = (4 * (nb + 1) + grid) * 2;
+        ctx->bucket_clean_nb = -1;
       }
       if (!ctx->d_order && dev_alloc(ctx, &ctx->d_order, (size_t)n)) return MIA_HIP_ERR_NOMEM;
       int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1), *d_wgb = d_cur + (nb + 1);
-      HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, ctx->stream));
+      // the bucket counts are left at zero by k_bucket_scan; only a fresh (or differently laid out) buffer is cleared here
+      if (ctx->bucket_clean_nb != nb) { HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, ctx->stream)); ctx->bucket_clean_nb = nb; }
       const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
-      hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, ctx->stream, ctx->rs, nb, d_cnt);
+      hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, ctx->stream, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words);
       hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb);
       hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, ctx->stream, ctx->rs, nb, d_off, d_cur, ctx->d_order);
       const int64_t slab_words = (int64_t)grid * (TALLY_WORDS - 1) * TALLY_WIN;
@@ -2216,14 +2228,23 @@ static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, 
   // consensus calls, the string consensus_assembly_string returns put together on the device (characters per column, their
   // prefix sums, a scatter), header and string back in one copy, the second and last wait
   auto consensus_tail = [&]() -> int {
-    if (int rcc = consensus_launch(ctx, cons_code, ctx->ins_tally_cap, true, true)) return rcc;
-    checkpoint("consensus kernels");
+    // (a workgroup alone on sixteen thousand columns is slower than a launch costs -- 44 + 111 us for two single-workgroup
+    // kernels against 5 us each for these: the launches that remain are the ones with a chip-wide dependence between them)
+    const int64_t cap = ctx->ins_tally_cap;
     int32_t* d_res = reinterpret_cast<int32_t*>(ctx->d_cons);
-    hipLaunchKernelGGL(k_cons_count, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
-                       (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos);
+    const unsigned gl = (unsigned)((L + 255) / 256);
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->tb.gaps, Lp, 1, L, ctx->d_ins_off, ctx->d_ins_total);   // ins_off[p] = gaps[1] + .. + gaps[p-1]
+    hipLaunchKernelGGL(k_call_columns_z, dim3(gl), dim3(256), 0, ctx->stream, (const int32_t*)ctx->tb.tally, Lp, L, cons_code, ctx->d_calls, ctx->d_ins_tally, cap * 9);
+    if (cap > 0)
+      hipLaunchKernelGGL(k_ins_tally, dim3(256), dim3(256), 0, ctx->stream, ctx->tb.events, 0, ctx->d_pssm, ctx->d_ins_off, ctx->tb.gaps, L, ctx->d_ins_tally,
+                         (int32_t)cap, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events);
+    checkpoint("consensus kernels");
+    hipLaunchKernelGGL(k_call_inserts_count, dim3(gl), dim3(256), 0, ctx->stream, (const int32_t*)ctx->tb.tally, Lp, L, (const int32_t*)ctx->tb.gaps,
+                       (const int32_t*)ctx->d_ins_off, (const int32_t*)ctx->d_ins_tally, cons_code, (const char*)ctx->d_calls, ctx->d_ins_calls, (int32_t)cap,
+                       (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos);
     hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->d_cons_pos, L, 0, L, ctx->d_cons_pos, d_res + CH_LEN);
-    hipLaunchKernelGGL(k_cons_scatter, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
-                       (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)ctx->ins_tally_cap, (const int32_t*)ctx->d_ins_total,
+    hipLaunchKernelGGL(k_cons_scatter, dim3(gl), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
+                       (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)cap, (const int32_t*)ctx->d_ins_total,
                        (const int32_t*)ctx->d_cons_pos, d_res, (int32_t)cons_cap, (const int32_t*)ctx->tb.n_events, (const uint32_t*)ctx->tb.flags,
                        (const uint32_t*)ctx->d_cull_flags);
     HIPCHK(hipGetLastError());
@@ -2831,38 +2852,104 @@ extern "C" int mia_hip_myers(mia_hip_ctx* ctx, int64_t n, const char* const* seq
   if (!ctx || n < 0 || (n > 0 && (!seq_a || !seq_b || !mode || !maxd || !dist))) return MIA_HIP_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   if (n == 0) return MIA_HIP_OK;
-  std::vector<MyersPair> pairs((size_t)n);
+  // two kinds of pair: seq_a of up to 320 characters -- one pair per lane (k_myers_lanes), sequences packed as 4-bit IUPAC
+  // bitmaps -- and longer ones, one pair per wavefront (k_myers), as ASCII
+  static const struct Bits { uint8_t t[256]; Bits() { for (int c = 0; c < 256; c++) t[c] = (uint8_t)iupac_bits((char)c); } } bits;
+  std::vector<MyersPair> pairs;
+  std::vector<MyersLanePair> lp;
+  std::vector<int32_t> long_index, lane_index;
+  std::vector<uint32_t> codes;
   std::string blob;
-  std::vector<size_t> oa((size_t)n), ob((size_t)n);
+  std::vector<size_t> oa, ob;
   int max_blk = 1;
+  codes.reserve((size_t)n * 64);
+  auto pack = [&](const char* s2, size_t len) -> uint32_t {
+    const uint32_t off = (uint32_t)codes.size();
+    for (size_t w = 0; w < (len + 7) / 8; w++) {
+      uint32_t v = 0;
+      for (size_t q = 0; q < 8 && w * 8 + q < len; q++) v |= (uint32_t)bits.t[(unsigned char)s2[w * 8 + q]] << (4 * q);
+      codes.push_back(v);
+    }
+    codes.push_back(0);                      // (the kernel may fetch one word beyond a sequence whose length is a multiple of eight)
+    return off;
+  };
   for (int64_t i = 0; i < n; i++) {
     const size_t la = strlen(seq_a[i]), lb = strlen(seq_b[i]);
     if (la > 64u * 64u * MYERS_MAX_K) { ctx->err = "seq_a longer than 32768 characters"; return MIA_HIP_ERR_ARG; }
-    oa[i] = blob.size(); blob.append(seq_a[i], la);
-    ob[i] = blob.size(); blob.append(seq_b[i], lb);
-    pairs[i].la = (int32_t)la; pairs[i].lb = (int32_t)lb; pairs[i].mode = mode[i]; pairs[i].maxd = maxd[i];
-    const int nb = (int)((la + 63) / 64);
-    if (nb > max_blk) max_blk = nb;
+    if (la <= 64u * MYERS_LANE_K && codes.size() + (la + lb) / 8 + 4 < ((size_t)1 << 31) && !ctx->myers_no_lanes) {
+      MyersLanePair q;
+      q.a_off = pack(seq_a[i], la); q.b_off = pack(seq_b[i], lb);
+      q.la = (int32_t)la; q.lb = (int32_t)lb; q.mode = mode[i]; q.maxd = maxd[i];
+      lp.push_back(q);
+      lane_index.push_back((int32_t)i);
+    } else {
+      MyersPair q;
+      oa.push_back(blob.size()); blob.append(seq_a[i], la);
+      ob.push_back(blob.size()); blob.append(seq_b[i], lb);
+      q.a = nullptr; q.b = nullptr;
+      q.la = (int32_t)la; q.lb = (int32_t)lb; q.mode = mode[i]; q.maxd = maxd[i];
+      pairs.push_back(q);
+      long_index.push_back((int32_t)i);
+      const int nb = (int)((la + 63) / 64);
+      if (nb > max_blk) max_blk = nb;
+    }
   }
   char* d_blob = nullptr;
   MyersPair* d_pairs = nullptr;
-  uint32_t* d_out = nullptr;
+  MyersLanePair* d_lp = nullptr;
+  uint32_t *d_out = nullptr, *d_out_long = nullptr, *d_codes = nullptr;
+  int32_t* d_index = nullptr;
   PoolScope guard(ctx);
-  guard.watch((void**)&d_blob); guard.watch((void**)&d_pairs); guard.watch((void**)&d_out);
-  if (pool_alloc(ctx, &d_blob, blob.size() + 1) || pool_alloc(ctx, &d_pairs, (size_t)n) || pool_alloc(ctx, &d_out, (size_t)n)) return MIA_HIP_ERR_NOMEM;
-  for (int64_t i = 0; i < n; i++) { pairs[i].a = d_blob + oa[i]; pairs[i].b = d_blob + ob[i]; }
-  hipError_t e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, pairs.data(), (size_t)n * sizeof(MyersPair), hipMemcpyHostToDevice, ctx->stream);
-  const int lds = 16 * max_blk * 8;
-  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_myers, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) {
-    const int grid = (int)(n < 8192 ? n : 8192);
-    hipLaunchKernelGGL(k_myers, dim3(grid), dim3(64), lds, ctx->stream, d_pairs, (int32_t)n, d_out);
+  guard.watch((void**)&d_blob); guard.watch((void**)&d_pairs); guard.watch((void**)&d_out); guard.watch((void**)&d_lp); guard.watch((void**)&d_codes);
+  guard.watch((void**)&d_index); guard.watch((void**)&d_out_long);
+  const size_t nl = lp.size(), ng = pairs.size();
+  if (pool_alloc(ctx, &d_out, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+  hipError_t e = hipSuccess;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  if (nl) {
+    if (pool_alloc(ctx, &d_lp, nl) || pool_alloc(ctx, &d_codes, codes.size() + 8) || pool_alloc(ctx, &d_index, nl)) return MIA_HIP_ERR_NOMEM;
+    e = hipMemcpyAsync(d_lp, lp.data(), nl * sizeof(MyersLanePair), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_codes, codes.data(), codes.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_index, lane_index.data(), nl * 4, hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (ng && e == hipSuccess) {
+    if (pool_alloc(ctx, &d_blob, blob.size() + 1) || pool_alloc(ctx, &d_pairs, ng) || pool_alloc(ctx, &d_out_long, ng)) return MIA_HIP_ERR_NOMEM;
+    for (size_t i = 0; i < ng; i++) { pairs[i].a = d_blob + oa[i]; pairs[i].b = d_blob + ob[i]; }
+    e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, pairs.data(), ng * sizeof(MyersPair), hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (e0) (void)hipEventRecord(e0, ctx->stream);
+  if (nl && e == hipSuccess) {
+    hipLaunchKernelGGL(k_myers_lanes, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, ctx->stream, (const MyersLanePair*)d_lp, (const uint32_t*)d_codes, (int32_t)nl,
+                       (const int32_t*)d_index, d_out);
     e = hipGetLastError();
   }
-  if (e == hipSuccess) e = hipMemcpyAsync(dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (ng && e == hipSuccess) {
+    const int lds = 16 * max_blk * 8;
+    e = hipFuncSetAttribute((const void*)k_myers, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) {
+      const int grid = (int)(ng < 8192 ? ng : 8192);
+      hipLaunchKernelGGL(k_myers, dim3(grid), dim3(64), lds, ctx->stream, d_pairs, (int32_t)ng, d_out_long);
+      e = hipGetLastError();
+    }
+  }
+  if (e1) (void)hipEventRecord(e1, ctx->stream);
+  std::vector<uint32_t> out_long(ng);
+  if (e == hipSuccess && nl) e = hipMemcpyAsync(dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);      // (the long pairs' entries are filled in below)
+  if (e == hipSuccess && ng) e = hipMemcpyAsync(out_long.data(), d_out_long, ng * 4, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess && e0 && e1) { float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->myers_kernel_ms = ms; }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
   if (e != hipSuccess) { ctx->err = std::string("myers: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  for (size_t i = 0; i < ng; i++) dist[long_index[i]] = out_long[i];
+  return MIA_HIP_OK;
+}
+
+extern "C" int mia_hip_myers_time(mia_hip_ctx* ctx, double* kernel_ms) {
+  if (!ctx || !kernel_ms) return MIA_HIP_ERR_ARG;
+  *kernel_ms = ctx->myers_kernel_ms;
   return MIA_HIP_OK;
 }
 

@@ -27,8 +27,8 @@ enum { CH_LEN = 0, CH_INS_TOTAL, CH_OVERFLOW, CH_N_EVENTS, CH_TALLY_FLAGS, CH_CU
 // Exclusive prefix sum of in[0..n) by ONE 1024-thread workgroup (in place is fine): each of the 16 wavefronts owns a
 // contiguous stretch and walks it 256 elements at a time (four per lane, a wave prefix sum per step); the stretches are
 // joined through LDS.  Elements outside [lo_valid, hi_valid) count as 0.  *total = the sum of everything.
-__global__ __launch_bounds__(1024) void k_excl_scan(const int32_t* in, int32_t n, int32_t lo_valid, int32_t hi_valid, int32_t* out, int32_t* total) {
-  __shared__ int32_t wsum[16];
+// (the body, for kernels that scan on the way: wsum = 16 words of LDS; every thread of the 1024 must call it)
+__device__ __forceinline__ void excl_scan_wg(const int32_t* in, int32_t n, int32_t lo_valid, int32_t hi_valid, int32_t* out, int32_t* total, int32_t* wsum) {
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int per = ((n + 15) / 16 + 255) & ~255;
   const int lo = w * per, hi = min(lo + per, n);
@@ -53,6 +53,10 @@ __global__ __launch_bounds__(1024) void k_excl_scan(const int32_t* in, int32_t n
   for (int k = 0; k < w; k++) off += wsum[k];
   if (off) for (int p = lo + lane; p < hi; p += 64) out[p] += off;
   if (t == 1023) *total = off + wsum[15];
+}
+__global__ __launch_bounds__(1024) void k_excl_scan(const int32_t* in, int32_t n, int32_t lo_valid, int32_t hi_valid, int32_t* out, int32_t* total) {
+  __shared__ int32_t wsum[16];
+  excl_scan_wg(in, n, lo_valid, hi_valid, out, total, wsum);
 }
 
 __device__ __forceinline__ bool cons_emits(char c) { return c != '-' && c != ' '; }
@@ -90,6 +94,32 @@ __global__ __launch_bounds__(256) void k_cons_scatter(const char* calls, const c
     res[CH_TALLY_FLAGS] = tally_flags ? (int32_t)*tally_flags : 0;
     res[CH_CULL_FLAGS] = cull_flags ? (int32_t)*cull_flags : 0;
   }
+}
+
+// ---- mia_hip_iterate's consensus kernels with the fills and one launch folded in ------------------------------------------
+// k_call_columns_z: find_consensus of every column (k_call_columns) and, on the side, the cleared insert tallies;
+// k_call_inserts_count: the insert columns' calls (k_call_inserts) and the characters each column contributes (k_cons_count)
+// -- a column's count needs only its own insert calls.  (Putting the whole tail into two single-workgroup kernels was
+// tried: a workgroup alone on 16.6 k columns takes 44 + 111 us, the five launches it saves cost 25.)
+__global__ __launch_bounds__(256) void k_call_columns_z(const int32_t* tally, int32_t Lp, int32_t L, int cons_code, char* calls, int32_t* zero, int64_t zero_words) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  for (int64_t k = p; k < zero_words; k += (int64_t)gridDim.x * 256) zero[k] = 0;
+  if (p >= L) return;
+  calls[p] = call_base(tally[T_A * Lp + p], tally[T_C * Lp + p], tally[T_G * Lp + p], tally[T_T * Lp + p], tally[T_GAP * Lp + p], tally[T_COV * Lp + p],
+                       tally[T_SA * Lp + p], tally[T_SC * Lp + p], tally[T_SG * Lp + p], tally[T_ST * Lp + p], cons_code);
+}
+
+__global__ __launch_bounds__(256) void k_call_inserts_count(const int32_t* tally, int32_t Lp, int32_t L, const int32_t* gaps, const int32_t* ins_off,
+                                                              const int32_t* ins_tally, int cons_code, const char* calls, char* ins_calls, int32_t ins_cap,
+                                                              const int32_t* ins_total, int32_t* cnt) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= L) return;
+  int32_t v = cons_emits(calls[p]) ? 1 : 0;
+  if (p > 0) {
+    call_inserts_at(p, tally, Lp, gaps, ins_off, ins_tally, cons_code, ins_calls, ins_cap);
+    if (*ins_total <= ins_cap) for (int j = 0; j < gaps[p]; j++) v += cons_emits(ins_calls[ins_off[p] + j]) ? 1 : 0;     // (its own stores, just above)
+  }
+  cnt[p] = v;
 }
 
 }  // namespace mia

@@ -137,4 +137,105 @@ __global__ __launch_bounds__(64) void k_myers(const MyersPair* pairs, int32_t n_
   }
 }
 
+// ---- short patterns: one pair per LANE --------------------------------------------------------------------------------------
+// A pair of reads (100-300 characters: what ccheck's batches and any read-against-read use hold) fills five of the
+// systolic kernel's 64 lanes.  Here every lane runs its own pair: seq_a as up to MYERS_LANE_K 64-row blocks in registers,
+// one column of the same Myers / Hyyro recurrence per character of seq_b.  The match vector of a column is not looked up
+// in a 16-entry table per pair (640 bytes of LDS each) but OR-ed together from four bit planes of seq_a -- "which rows
+// hold a code compatible with A / C / G / T" (IUPAC bitmaps, src/myers_align.h:40-67): Eq = the planes of the bases the
+// column's character may be.  Both sequences arrive as 4-bit IUPAC bitmaps, eight per word (the host packs them).
+constexpr int MYERS_LANE_K = 5;              // 320 rows
+
+struct MyersLanePair {
+  uint32_t a_off, b_off;                     // word offsets of the packed sequences
+  int32_t la, lb, mode, maxd;
+};
+
+__global__ __launch_bounds__(64) void k_myers_lanes(const MyersLanePair* pairs, const uint32_t* codes, int32_t n_pairs, const int32_t* index, uint32_t* out) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  const bool live = p < n_pairs;
+  MyersLanePair pr{0, 0, 0, 0, 0, 0};
+  if (live) pr = pairs[p];
+  const int m = pr.la, n = pr.lb;
+  int maxd = pr.maxd;
+  if (maxd > m + n) maxd = m + n;                                   // src/myers_align.c:13
+  const int nblk = (m + 63) / 64;
+  uint64_t P0[MYERS_LANE_K], P1[MYERS_LANE_K], P2[MYERS_LANE_K], P3[MYERS_LANE_K], Pv[MYERS_LANE_K], Mv[MYERS_LANE_K];
+#pragma unroll
+  for (int k = 0; k < MYERS_LANE_K; k++) { P0[k] = P1[k] = P2[k] = P3[k] = 0; Pv[k] = ~0ull; Mv[k] = 0; }
+  // bit planes of seq_a, eight rows per packed word
+  const uint32_t* ca = codes + pr.a_off;
+  for (int w = 0; w < (m + 7) / 8; w++) {
+    const uint32_t v = ca[w];
+    uint64_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t c = (v >> (4 * q)) & 15u;                       // rows beyond m are packed as 0: compatible with nothing
+      b0 |= (uint64_t)(c & 1u) << q; b1 |= (uint64_t)((c >> 1) & 1u) << q; b2 |= (uint64_t)((c >> 2) & 1u) << q; b3 |= (uint64_t)((c >> 3) & 1u) << q;
+    }
+    const int blk = w >> 3, sh = (w & 7) * 8;
+#pragma unroll
+    for (int k = 0; k < MYERS_LANE_K; k++)
+      if (k == blk) { P0[k] |= b0 << sh; P1[k] |= b1 << sh; P2[k] |= b2 << sh; P3[k] |= b3 << sh; }
+  }
+  const int last_blk = nblk - 1, last_bit = (m - 1) & 63;
+  int score = m, best_row = m;            // D[m][j]; its minimum over j for mode 2 (j = 0 counts: D[m][0] = m)
+  const uint32_t* cb = codes + pr.b_off;
+  uint32_t bw = 0;
+  int n_max = n;
+  for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(n_max, o); n_max = v > n_max ? v : n_max; }
+  for (int j = 0; j < n_max; j++) {
+    if (j < n && m > 0) {
+      if ((j & 7) == 0) bw = cb[j >> 3];
+      const uint32_t tb = (bw >> (4 * (j & 7))) & 15u;
+      const uint64_t s0 = (tb & 1u) ? ~0ull : 0ull, s1 = (tb & 2u) ? ~0ull : 0ull, s2 = (tb & 4u) ? ~0ull : 0ull, s3 = (tb & 8u) ? ~0ull : 0ull;
+      int hin = 1;                                                   // D[0][j] - D[0][j-1]
+#pragma unroll
+      for (int k = 0; k < MYERS_LANE_K; k++) {
+        if (k < nblk) {
+          uint64_t Eq = (P0[k] & s0) | (P1[k] & s1) | (P2[k] & s2) | (P3[k] & s3);
+          const uint64_t pv = Pv[k], mv = Mv[k];
+          const uint64_t neg = hin < 0 ? 1ull : 0ull, pos = hin > 0 ? 1ull : 0ull;
+          const uint64_t Xv = Eq | mv;
+          Eq |= neg;
+          const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+          uint64_t Ph = mv | ~(Xh | pv), Mh = pv & Xh;
+          if (k == last_blk) score += (int)((Ph >> last_bit) & 1) - (int)((Mh >> last_bit) & 1);
+          hin = (int)(Ph >> 63) - (int)(Mh >> 63);
+          Ph = (Ph << 1) | pos;
+          Mh = (Mh << 1) | neg;
+          Pv[k] = Mh | ~(Xv | Ph);
+          Mv[k] = Ph & Xv;
+        }
+      }
+      if (score < best_row) best_row = score;
+    }
+  }
+  if (!live) return;
+  uint32_t result = 0xFFFFFFFFu;
+  if (maxd > 0) {
+    int d;
+    if (m == 0 || n == 0) {                                          // degenerate: the walk only takes gaps (k_myers)
+      d = (pr.mode == 0) ? m + n : (pr.mode == 1 ? n : m);
+      if (m == 0 && pr.mode == 2) d = 0;
+      if (n == 0 && pr.mode == 1) d = 0;
+    } else if (pr.mode == 0) d = score;
+    else if (pr.mode == 2) d = best_row;
+    else {
+      // mode 1: min_i D[i][n], D[0][n] = n, D[i][n] = n + the vertical deltas of rows 1 .. i
+      int tot = 0, mn = 0;
+#pragma unroll
+      for (int k = 0; k < MYERS_LANE_K; k++)
+        if (k < nblk)
+          for (int i = 0; i < 64 && k * 64 + i < m; i++) {
+            tot += (int)((Pv[k] >> i) & 1) - (int)((Mv[k] >> i) & 1);
+            if (tot < mn) mn = tot;
+          }
+      d = n + mn;
+    }
+    if (d < maxd) result = (uint32_t)d;
+  }
+  out[index[p]] = result;
+}
+
 }  // namespace mia

@@ -58,3 +58,53 @@ def test_myers_align_backtrace():
         n += 1
     assert n > 100
     hip.close()
+
+
+def test_lane_kernel_equals_systolic_kernel():
+    """k_myers_lanes (one pair per lane, seq_a up to 320 characters, four bit planes instead of a Peq table) against k_myers
+    (one pair per wavefront; MIA_HIP_MYERS_NO_LANES=1), which the reference's vectors pin: 30 000 random pairs -- lengths 0..340
+    on either side (around the 64-row block edges and the 320-row limit), IUPAC codes and characters no bitmap knows, edits
+    from none to everything, all three modes, maxd from 1 to beyond the sum of the lengths."""
+    import mia_amd
+    rng = np.random.default_rng(99)
+    alpha = np.frombuffer(b"ACGTACGTACGTNRYKMSWBDHVacgtnX-", np.uint8)
+    A, B, mode, maxd = [], [], [], []
+    edge = [0, 1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 255, 256, 257, 319, 320, 321, 340]
+    for i in range(30_000):
+        la = int(rng.choice(edge)) if i % 3 == 0 else int(rng.integers(0, 341))
+        a = alpha[rng.integers(0, len(alpha), la)].copy()
+        kind = i % 5
+        if kind == 0:
+            b = alpha[rng.integers(0, len(alpha), int(rng.integers(0, 341)))].copy()          # unrelated
+        else:
+            b = list(a)
+            for _ in range(int(rng.integers(0, 1 + la // (3 if kind == 1 else 12)))):
+                if not b:
+                    break
+                p = int(rng.integers(0, len(b)))
+                u = rng.random()
+                if u < 0.4:
+                    b[p] = alpha[rng.integers(0, len(alpha))]
+                elif u < 0.7:
+                    del b[p]
+                else:
+                    b.insert(p, alpha[rng.integers(0, len(alpha))])
+            if kind == 2 and len(b) > 20:
+                b = b[int(rng.integers(0, 10)):len(b) - int(rng.integers(0, 10))]                 # overhangs (modes 1 and 2)
+            b = np.array(b[:400], np.uint8)
+        A.append(a.tobytes().decode("latin1")); B.append(b.tobytes().decode("latin1"))
+        mode.append(int(rng.integers(0, 3)))
+        maxd.append(int(rng.choice([1, 2, 5, 30, 100, 700, 100000])))
+    hip = mia_amd.MiaHip(0)
+    got = hip.myers(A, B, mode, maxd)
+    hip.close()
+    os.environ["MIA_HIP_MYERS_NO_LANES"] = "1"
+    try:
+        ref = mia_amd.MiaHip(0)
+    finally:
+        os.environ.pop("MIA_HIP_MYERS_NO_LANES")
+    want = ref.myers(A, B, mode, maxd)
+    ref.close()
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, [(int(i), int(got[i]), int(want[i]), mode[i], maxd[i], len(A[i]), len(B[i])) for i in bad[:8]]
+    assert (want != 0xFFFFFFFF).sum() > 5000 and (want == 0xFFFFFFFF).sum() > 1000
