@@ -124,6 +124,7 @@ struct mia_hip_ctx {
   uint32_t* d_cull_sync = nullptr;          // k_slot_count's arrival counter (zero between launches)
   double myers_kernel_ms = 0; bool myers_no_lanes = false;   // the kernels of the last mia_hip_myers call (HIP events); MIA_HIP_MYERS_NO_LANES=1: every pair through k_myers
   int bucket_clean_nb = -1;                 // the tally's bucket counts are zero for this bucket count (k_bucket_scan leaves them so)
+  bool no_auto_plain = false;               // MIA_HIP_NO_AUTO_PLAIN=1: the values-only pass behind the band only when MIA_HIP_PLAIN_BEHIND_BAND asks for it
   bool bx_serial = false;                   // MIA_HIP_BX_SERIAL=1
   uint32_t bx_dbg = 0;                      // MIA_HIP_BX_DEBUG (profiling): 1 no traceback, 2 one DP row, 4 no values launch, 8 no trace launch
   int use_lanes = 1;                        // MIA_HIP_NO_LANES=1: the band DPs one read per lane (bx_values / bx_trace) instead of W/8 lanes per read (bandx_lanes.h)
@@ -298,6 +299,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* bd2 = getenv("MIA_HIP_BX_DEBUG")) ctx->bx_dbg = (uint32_t)atoi(bd2);
     if (const char* bs2 = getenv("MIA_HIP_BX_SERIAL")) ctx->bx_serial = atoi(bs2) != 0;
     if (const char* ml = getenv("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
+    if (const char* na = getenv("MIA_HIP_NO_AUTO_PLAIN")) ctx->no_auto_plain = atoi(na) != 0;
     const char* egs = getenv("MIA_HIP_EAGER_SCRIPTS");
     if (egs && atoi(egs)) ctx->lazy_scripts = 0;
     const char* nwl = getenv("MIA_HIP_NO_WILD");
@@ -966,7 +968,15 @@ static int align_all(mia_hip_ctx* ctx) {
   // behind the banded DP the values-only pass has nothing left to prove: what the band could not take nearly always needs a trace
   // (MIA_HIP_PLAIN_BEHIND_BAND=1: values-only pass over the band pipeline's left-overs all the same -- with a position-specific
   // matrix most of them are gap-free reads with many substitutions, which it finishes at half the trace kernel's price)
-  const bool use_plain = ctx->use_plain && (!banded || ctx->plain_behind_band);
+  // ... unless the plan gives up on many reads: against a reference full of ambiguity codes (every run's first iteration
+  // against mt311: the N columns alone exhaust the loss budget of one read in twenty, one in five with the ancient matrix),
+  // or when it did so in the iteration before.  Most of those reads are gap-free; the values-only pass finishes them at
+  // half the trace kernel's price (first iteration 2.84 -> 2.59 ms flat, 5.35 -> 4.08 ms ancient, per 1 M reads).
+  // Either way every read gets the reference's alignment: the choice only moves work between exact kernels.
+  int64_t last_rejects = 0;
+  for (int k = 1; k < BXF_KINDS; k++) last_rejects += ctx->bx_last[BXC_FAIL0 + k];
+  const bool many_rejects = bx && !ctx->no_auto_plain && (!ctx->ref_mostly_bases || last_rejects * 50 > n);
+  const bool use_plain = ctx->use_plain && (!banded || ctx->plain_behind_band || many_rejects);
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   if (ctx->deferred) {
     // ---- mia_hip_iterate: the same plan, but its numbers stay on the device (k_plan_scan) and every DP kernel reads its own
