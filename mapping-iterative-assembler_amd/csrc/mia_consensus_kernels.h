@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
                                                        const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, const uint64_t* rplanes,
-                                                       int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket) {
+                                                       int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket, int32_t pk_bias) {
   constexpr bool linear = LINEAR;
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
   // !LINEAR (a position-specific matrix): the scores of a base depend on its depth code and its strand -- but every base
@@ -793,6 +793,14 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   // at most TALLY_CHUNK reads), and their base counts and score sums are filled in from sm[strand][15] at the flush: one
   // LDS atomic per base instead of five.  The 15 bases at either end keep their explicit adds.
   __shared__ int32_t mid_cnt[LINEAR ? 1 : 5 * TALLY_WIN];
+  // !LINEAR, the 15 bases at either end of a read (depth codes other than 15): their base count and four scores used to be
+  // five LDS atomics each -- 150 of a 100 bp read's 220, and LDS atomic instructions are what this kernel waits for.  With
+  // every score biased to be positive (pk_bias >= the most negative entry, bias + largest entry <= 2047: the host checks)
+  // three 20-bit score sums share one 64-bit word and the fourth shares another with four 10-bit base counts: TWO 64-bit
+  // atomics per base.  A workgroup adds at most TALLY_CHUNK = 512 bases to a column, so no field overflows into the next
+  // (512 x 2047 < 2^20); the flush takes bias x count off again.  Bases that are not A/C/G/T keep the explicit adds.
+  __shared__ unsigned long long pk1[LINEAR ? 1 : TALLY_WIN], pk2[LINEAR ? 1 : TALLY_WIN];
+  static_assert(TALLY_CHUNK <= 512, "packed end-base sums: 512 adds of at most 2047 stay below 2^20");
   // linear: the matrix does not depend on depth or strand (the flat matrix), so scoreX(column) = sum_b count_b * sm[X][b].
   // The window then takes ONE LDS atomic per base (its count; N in n_cnt) instead of five, and the four score rows are
   // filled in from the counts when the window is flushed.  Same integer sums.
@@ -813,6 +821,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   for (int k = threadIdx.x; k < 2 * PSSM_WORDS; k += blockDim.x) pssm_lds[k] = (int16_t)pssm2[k];
   for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { cov_diff[k] = 0; span_diff[k] = 0; n_cnt[k] = 0; }
   if (!LINEAR) for (int k = threadIdx.x; k < 5 * TALLY_WIN; k += blockDim.x) mid_cnt[k] = 0;
+  if (!LINEAR) for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { pk1[k] = 0; pk2[k] = 0; }
   if (threadIdx.x == 0) ev_cnt = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -824,11 +833,20 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   typedef __attribute__((address_space(3))) int32_t lds_i32;
   auto aadd = [](lds_i32* q, int v) { (void)__hip_atomic_fetch_add(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   // one aligned base of a record that is listed once and not dropped, at window slot wc: code 0..4, depth code d, strand
-  auto add_base = [&](int wc, int code, int d, bool is_rc) {
+  auto add_base = [&](int wc, int code, int d, bool is_rc, bool pack_ok = true) {      // pack_ok: this record is listed once (see pk1)
     lds_i32* t = (lds_i32*)lds + wc;
     if (LINEAR) { if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1); else aadd((lds_i32*)n_cnt + wc, 1); return; }
     if (d == PSSM_DEPTH) { aadd((lds_i32*)mid_cnt + (code < 4 ? code : 4) * TALLY_WIN + wc, is_rc ? 65536 : 1); return; }
     const int16_t* row = pssm_lds + (is_rc ? PSSM_WORDS : 0) + d * 25 + code;
+    if (pk_bias >= 0 && code < 4 && pack_ok) {
+      typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+      const unsigned long long v1 = (unsigned long long)(uint32_t)((int)row[0] + pk_bias) | ((unsigned long long)(uint32_t)((int)row[5] + pk_bias) << 20) |
+                                    ((unsigned long long)(uint32_t)((int)row[10] + pk_bias) << 40);
+      const unsigned long long v2 = (unsigned long long)(uint32_t)((int)row[15] + pk_bias) | (1ull << (20 + 10 * code));
+      (void)__hip_atomic_fetch_add((lds_u64*)pk1 + wc, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      (void)__hip_atomic_fetch_add((lds_u64*)pk2 + wc, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
     if (code < 4) aadd(&t[(T_A + code) * TALLY_WIN], 1);
     aadd(&t[T_SA * TALLY_WIN], (int)row[0]);
     aadd(&t[T_SC * TALLY_WIN], (int)row[5]);
@@ -982,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
             lds_i32* t = (lds_i32*)lds + wc;
             if (!dropped) {
               if (!ranges) aadd(&t[T_COV * TALLY_WIN], mult);
-              for (int m = 0; m < mult; m++) add_base(wc, code, d, (flags & TRF_RC) != 0);
+              for (int m = 0; m < mult; m++) add_base(wc, code, d, (flags & TRF_RC) != 0, mult == 1);
             }
             if (!ranges && p > 0) aadd(&t[T_SPAN * TALLY_WIN], mult);
           } else {
@@ -1241,6 +1259,13 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
         for (int x = 0; x < 4; x++)
           sc[x] += cf * (int)pssm_lds[PSSM_DEPTH * 25 + x * 5 + b5] + cr * (int)pssm_lds[PSSM_WORDS + PSSM_DEPTH * 25 + x * 5 + b5];
       }
+      // ... and the end bases' packed sums: counts, and the scores less the bias every add carried
+      const unsigned long long p1 = pk1[k], p2 = pk2[k];
+      int cnt = 0;
+      for (int b5 = 0; b5 < 4; b5++) { const int c = (int)((p2 >> (20 + 10 * b5)) & 1023ull); lds[(T_A + b5) * TALLY_WIN + k] += c; cnt += c; }
+      const int off = pk_bias > 0 ? pk_bias * cnt : 0;
+      sc[0] += (int)(p1 & 0xFFFFFull) - off; sc[1] += (int)((p1 >> 20) & 0xFFFFFull) - off; sc[2] += (int)((p1 >> 40) & 0xFFFFFull) - off;
+      sc[3] += (int)(p2 & 0xFFFFFull) - off;
       lds[T_SA * TALLY_WIN + k] += sc[0]; lds[T_SC * TALLY_WIN + k] += sc[1]; lds[T_SG * TALLY_WIN + k] += sc[2]; lds[T_ST * TALLY_WIN + k] += sc[3];
     }
   }

@@ -54,6 +54,7 @@ struct mia_hip_ctx {
   // PSSMs (fwd, rc)
   int32_t* d_pssm = nullptr;
   int max_abs = 0;
+  int tally_pk_bias = -1;                   // the tally's packed end-base sums (k_tally_binned): the bias that makes every score positive, or -1: entries too large
   int max_pos = 0;   // largest positive PSSM entry: bounds any score by rows * max_pos
   bool have_pssm = false;
   PackSet packs;
@@ -389,6 +390,11 @@ extern "C" int mia_hip_set_pssm(mia_hip_ctx* ctx, const int32_t* fwd, const int3
   }
   if (m > 32000) { ctx->err = "PSSM entries beyond +-32000 do not fit the int16 substitution table"; return MIA_HIP_ERR_RANGE; }
   ctx->max_abs = m;
+  {
+    int lo = 0, hi = 0;
+    for (int k = 0; k < PSSM_WORDS; k++) { lo = std::min(lo, std::min((int)fwd[k], (int)rc[k])); hi = std::max(hi, std::max((int)fwd[k], (int)rc[k])); }
+    ctx->tally_pk_bias = (-lo + hi <= 2047 && !getenv("MIA_HIP_NO_PACKED_TALLY")) ? -lo : -1;
+  }
   ctx->max_pos = 0;
   for (int i = 0; i < PSSM_WORDS; i++) { if (fwd[i] > ctx->max_pos) ctx->max_pos = fwd[i]; if (rc[i] > ctx->max_pos) ctx->max_pos = rc[i]; }
   const int cpls[N_CPL] = {4, 8, 12};
@@ -975,7 +981,7 @@ static int align_all(mia_hip_ctx* ctx) {
   // Either way every read gets the reference's alignment: the choice only moves work between exact kernels.
   int64_t last_rejects = 0;
   for (int k = 1; k < BXF_KINDS; k++) last_rejects += ctx->bx_last[BXC_FAIL0 + k];
-  const bool many_rejects = bx && !ctx->no_auto_plain && (!ctx->ref_mostly_bases || last_rejects * 50 > n);
+  const bool many_rejects = bx && !ctx->no_auto_plain && (!ctx->ref_mostly_bases || last_rejects * 20 > n);
   const bool use_plain = ctx->use_plain && (!banded || ctx->plain_behind_band || many_rejects);
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   if (ctx->deferred) {
@@ -1666,11 +1672,11 @@ static int tally_launch(mia_hip_ctx* ctx) {
       if (ctx->tally_linear)
         hipLaunchKernelGGL(k_tally_binned<true>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                            ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
-                           planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb);
+                           planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb, -1);
       else
         hipLaunchKernelGGL(k_tally_binned<false>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                            ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
-                           (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb);
+                           (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb, ctx->tally_pk_bias);
       stage_end(ctx, STG_TALLY);
       hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256, TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
     } else {
