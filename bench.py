@@ -51,12 +51,13 @@ def bytes_per_read(read_len):
     return (read_len + 1) // 2 + 16 + 16 + read_len
 
 
-PMC_DIR = os.path.join(ROOT, "profiles", "r02", "pmc")
+PMC_DIR = os.path.join(ROOT, "profiles", "r03", "pmc")
 CSRC = os.path.join(ROOT, "mapping-iterative-assembler_amd", "csrc")
 STAGES = ["k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_trace", "k_align_quad_plain", "k_align_quad", "k_tally_binned"]
 # the full-window stage is timed as a whole: k_align_quad (four reads per wavefront, windows up to 208 columns) and the
 # k_align_window<CPL> launches (one read per wavefront: wider windows, reads whose path left the quad kernel's trace band)
-STAGE_KERNELS = {"k_align_quad": ["k_align_quad", "k_align_window"]}
+# the band DPs are timed by stream: stream2 carries the values DP and, behind it, the trace DP of its left-overs
+STAGE_KERNELS = {"k_align_quad": ["k_align_quad", "k_align_window"], "k_bx_values": ["k_bxl_values", "k_bxl_trace_late"], "k_bx_trace": ["k_bxl_trace"]}
 
 
 def source_hash():
@@ -327,7 +328,7 @@ def roofline(stages, peaks, pmc_tag, pmc_stale):
                   "peak": peaks.get("valu_ginst_s") if peaks else None, "unit": "1e9 wave64 instructions/s", "frac": dom["valu_frac"]},
          "peak_measured_copy": peaks.get("hbm_copy_gbs") if peaks else None,
          "frac_of_measured_copy": dom["achieved"] / peaks["hbm_copy_gbs"] if peaks and peaks.get("hbm_copy_gbs") else None,
-         "pmc": {"summary": f"profiles/r02/pmc/{pmc_tag}.json", "from_this_build": not pmc_stale},
+         "pmc": {"summary": f"profiles/r03/pmc/{pmc_tag}.json", "from_this_build": not pmc_stale},
          "stages": stages,
          "note": "integer DP: the kernels are bound by VALU issue, not HBM -- `frac` prices the SURVEY 8(d) algorithmic bytes of the "
                  "kernel with the most time per step against the nominal 8 TB/s as the contract asks; `valu.frac` = its VALU "
@@ -428,6 +429,7 @@ def section_myers(hip, no_cpu=False):
     d = hip.myers(A, B, mode, maxd)
     dt = time.perf_counter() - t0
     k_ms = hip.myers_time()
+    call_s = hip.myers_call_s
     cells = sum(len(a) * len(b) for a, b in zip(A, B))
     # algorithmic bytes: both sequences as 4-bit codes in, one distance out
     algo_bytes = sum((len(a) + len(b) + 1) // 2 + 4 for a, b in zip(A, B))
@@ -439,12 +441,14 @@ def section_myers(hip, no_cpu=False):
     dbig = hip.myers([big.tobytes()], [big2.tobytes()], np.zeros(1, np.int32), np.full(1, 1660, np.int32))
     dt_big = time.perf_counter() - t1
     out = {"pairs": len(A), "pairs_per_s": len(A) / dt, "gcups": cells / dt / 1e9, "mean_distance": float(d[d != 0xFFFFFFFF].mean()),
+           "c_abi_call_pairs_per_s": len(A) / call_s, "c_abi_call_gcups": cells / call_s / 1e9,
            "kernel_ms": k_ms, "kernel_pairs_per_s": len(A) / (k_ms * 1e-3), "kernel_gcups": cells / (k_ms * 1e-3) / 1e9,
            "roofline": {"bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "note": "bit-vector DP: 64 cells per 64-bit operation, bound by integer issue; bytes = packed sequences in + distances out"},
            "pair_16k6_ms": dt_big * 1e3, "pair_16k6_kernel_ms": hip.myers_time(), "pair_16k6_distance": int(dbig[0]),
-           "note": "wall figures include strlen, packing and PCIe (mia_hip_myers takes C strings); k_myers_lanes: one pair per lane, "
+           "note": "pairs_per_s: the Python call (list -> char** included); c_abi_call: mia_hip_myers alone (strlen, packing on the host threads, "
+                   "PCIe, kernel); kernel: HIP events.  k_myers_lanes: one pair per lane, "
                    "k_myers: one pair per wavefront, 64-bit lanes"}
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_myers_driver")
     if not no_cpu and os.path.exists(drv):
@@ -457,6 +461,48 @@ def section_myers(hip, no_cpu=False):
         out["cpu_baseline"] = {"value": m / cpu_dt, "unit": "pairs/s", "cores": 1, "kind": "reference",
                                "sample": f"{m} of the same pairs through oracle/_ref/ref_myers_driver (the reference's myers_diff with backtrace), "
                                          f"{cpu_dt:.2f} s; distances equal: {ok == [int(x) for x in d[:m]]}"}
+    return out
+
+
+def section_cli(w, n=1_000_000):
+    """The host program end to end (mia_hip: FASTA in, .maln out) on the headline workload: ingest (host/ingest.h: the
+    reference's reader on all host threads, beside the GPU start-up), pass 1 without a k-mer mask, read store, iterations
+    to convergence, .maln files -- wall time of the process and the phases it reports itself (MIA_HIP_TIMING=1)."""
+    import re
+    exe = os.path.join(ROOT, "mapping-iterative-assembler_amd", "mia_hip")
+    if not os.path.exists(exe):
+        return {"error": "mia_hip not built"}
+    import gen_data
+    m = min(n, w["n"])
+    tmp = tempfile.mkdtemp()
+    stored, rc = w["stored"][:m], w["rc"][:m]
+    seq = np.where(rc[:, None] == 1, gen_data._COMP[stored[:, ::-1]], stored).astype(np.uint8)       # as sequenced
+    L = seq.shape[1]
+    rec = np.empty((m, 10 + L + 1), np.uint8)                                                         # ">r0000000\n" + bases + "\n"
+    rec[:, 0], rec[:, 1], rec[:, 9], rec[:, -1] = ord(">"), ord("r"), ord("\n"), ord("\n")
+    idx = np.arange(m)
+    for k in range(7):
+        rec[:, 8 - k] = ord("0") + (idx // 10 ** k) % 10
+    rec[:, 10:10 + L] = seq
+    fa = os.path.join(tmp, "reads.fa")
+    rec.tofile(fa)
+    gen_data.write_fasta(os.path.join(tmp, "ref.fa"), "ref", w["ref"])
+    out = {"reads": m, "input_bytes": int(rec.size)}
+    for label, extra in (("every_iteration_written", []), ("final_maln_only", ["-F"])):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "-r", os.path.join(tmp, "ref.fa"), "-f", fa, "-c", "-i", "-m", os.path.join(tmp, "out_" + label)] + extra,
+                           env=dict(os.environ, MIA_HIP_TIMING="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        wall = time.perf_counter() - t0
+        phases = {}
+        for mm in re.finditer(r"\[mia_hip timing\]\s+(.*?)\s+([0-9.]+) ms", r.stderr.decode(errors="replace")):
+            phases.setdefault(mm.group(1).strip(), []).append(float(mm.group(2)))
+        files = [f for f in os.listdir(tmp) if f.startswith("out_" + label)]
+        out[label] = {"wall_s": wall, "exit": r.returncode, "maln_files": len(files), "maln_bytes": sum(os.path.getsize(os.path.join(tmp, f)) for f in files),
+                      "phases_ms": {k: (v if len(v) > 1 else v[0]) for k, v in phases.items()}}
+        if "read input alone" in phases:
+            out["ingest_reads_per_s"] = m / (phases["read input alone"][0] * 1e-3)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -681,6 +727,7 @@ def main():
                              "decided_by_anchored_windows": hip.pass1_anchored()}
             out["pass1"] = p1
             out["myers"] = section_myers(hip, a.no_cpu_baseline)
+            out["cli"] = section_cli(w)
         if a.pmc_run:
             hip.measure_peaks(1 << 28)           # k_peak_copy in the counter passes: the FETCH_SIZE calibration
         if not a.no_cpu_baseline and world == 1:      # the CPU comparator is timed beside the single-GPU line only

@@ -541,7 +541,7 @@ __device__ __forceinline__ uint32_t bxl_trace_chunk(const ReadSet& rs, const Ref
 // trace slab of a wavefront: [row][lane][2 words]
 constexpr int BXL_SLAB_ROW_WORDS = 128;
 // list0 / ctr0: BX_NCLS / BXC_LIST0 + BX_NCLS for the plan's trace lists, 2 BX_NCLS / BXC_LATE0 for the values DP's left-overs
-__global__ __launch_bounds__(256) void k_bxl_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of, int list0, int ctr0) {
+__device__ __forceinline__ void bxl_trace_grid(const ReadSet& rs, const RefInfo& ref, const BxDev& bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of, int list0, int ctr0) {
   __shared__ int32_t sub_lds[BX_SUB_WORDS];
   for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.sub256[k];
   __syncthreads();
@@ -561,6 +561,13 @@ __global__ __launch_bounds__(256) void k_bxl_trace(ReadSet rs, RefInfo ref, BxDe
     }
   }
   bxl_count_done(done, &done_wg, bxc(bx.ctr, BXC_DONE_TRACE));
+}
+// (two names for one body: a profile tells the plan's lists and the values DP's left-overs apart)
+__global__ __launch_bounds__(256) void k_bxl_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
+  bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, BX_NCLS, BXC_LIST0 + BX_NCLS);
+}
+__global__ __launch_bounds__(256) void k_bxl_trace_late(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
+  bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, 2 * BX_NCLS, BXC_LATE0);
 }
 
 }  // namespace mia

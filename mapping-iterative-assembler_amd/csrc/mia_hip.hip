@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mia_hip.h"
@@ -441,17 +442,28 @@ static inline uint8_t base_code(char b) {   // src/map_align.c:16-29: only upper
 }
 
 // 4-bit base codes, two per byte, each read starting on a 4-byte boundary of `packed` (zero-filled by the caller)
+// (on the host's threads: a million reads are 100 MB of characters, 0.1 s on one core -- as long as thirty iterations)
 static void pack_reads(int64_t n, const char* bases, const int64_t* offsets, const uint32_t* roff, const uint16_t* len, uint8_t* packed) {
   uint8_t lut[256];
   for (int c = 0; c < 256; c++) lut[c] = base_code((char)c);
-  for (int64_t i = 0; i < n; i++) {
-    const unsigned char* s = reinterpret_cast<const unsigned char*>(bases) + offsets[i];
-    uint8_t* d = packed + roff[i];
-    const int l = len[i];
-    int k = 0;
-    for (; k + 1 < l; k += 2) d[k >> 1] = (uint8_t)(lut[s[k]] | (lut[s[k + 1]] << 4));
-    if (k < l) d[k >> 1] = lut[s[k]];
-  }
+  auto range = [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++) {
+      const unsigned char* s = reinterpret_cast<const unsigned char*>(bases) + offsets[i];
+      uint8_t* d = packed + roff[i];
+      const int l = len[i];
+      int k = 0;
+      for (; k + 1 < l; k += 2) d[k >> 1] = (uint8_t)(lut[s[k]] | (lut[s[k + 1]] << 4));
+      if (k < l) d[k >> 1] = lut[s[k]];
+    }
+  };
+  int T = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("MIA_HIP_THREADS")) T = atoi(e);
+  T = std::max(1, std::min(std::min(T, 32), (int)(n / 16384) + 1));
+  if (T == 1) { range(0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; t++) th.emplace_back(range, n * t / T, n * (t + 1) / T);
+  range(0, n / T);
+  for (auto& x : th) x.join();
 }
 
 extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bases, const int64_t* offsets, const uint8_t* rc,
@@ -918,15 +930,13 @@ static int align_all(mia_hip_ctx* ctx) {
           HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
           if (stage_begin(ctx, STG_BX_TRACE, ctx->stream3)) return MIA_HIP_ERR_NOMEM;
           if (!(ctx->bx_dbg & 8u))
-            hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of,
-                               (int)BX_NCLS, (int)(BXC_LIST0 + BX_NCLS));
+            hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
           stage_end(ctx, STG_BX_TRACE, ctx->stream3);
           HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
           if (stage_begin(ctx, STG_BX_VALUES, ctx->stream2)) return MIA_HIP_ERR_NOMEM;
           if (!(ctx->bx_dbg & 4u)) {
             hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bin_of);
-            hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of,
-                               (int)(2 * BX_NCLS), (int)BXC_LATE0);
+            hipLaunchKernelGGL(k_bxl_trace_late, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of);
           }
           stage_end(ctx, STG_BX_VALUES, ctx->stream2);
           HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -940,8 +950,7 @@ static int align_all(mia_hip_ctx* ctx) {
         HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         if (stage_begin(ctx, STG_BX_TRACE, ctx->stream2)) return MIA_HIP_ERR_NOMEM;
         if (ctx->bx_dbg & 8u) {}
-        else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of,
-                                                     (int)BX_NCLS, (int)(BXC_LIST0 + BX_NCLS));
+        else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
         else hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
         stage_end(ctx, STG_BX_TRACE, ctx->stream2);
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -2878,37 +2887,74 @@ extern "C" int mia_hip_myers(mia_hip_ctx* ctx, int64_t n, const char* const* seq
   std::string blob;
   std::vector<size_t> oa, ob;
   int max_blk = 1;
-  codes.reserve((size_t)n * 64);
-  auto pack = [&](const char* s2, size_t len) -> uint32_t {
-    const uint32_t off = (uint32_t)codes.size();
-    for (size_t w = 0; w < (len + 7) / 8; w++) {
-      uint32_t v = 0;
-      for (size_t q = 0; q < 8 && w * 8 + q < len; q++) v |= (uint32_t)bits.t[(unsigned char)s2[w * 8 + q]] << (4 * q);
-      codes.push_back(v);
-    }
-    codes.push_back(0);                      // (the kernel may fetch one word beyond a sequence whose length is a multiple of eight)
-    return off;
+  // lengths first (on all host threads: a hundred thousand strlen calls and forty million characters to pack are most of
+  // this call's time next to a 0.3 ms kernel), then the offsets, then the packing into the places they name
+  std::vector<uint32_t> la_of((size_t)n), lb_of((size_t)n);
+  int T = (int)std::thread::hardware_concurrency();
+  T = std::max(1, std::min(std::min(T, 32), (int)(n / 2048) + 1));
+  auto parallel = [&](auto&& fn) {
+    if (T == 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back([&fn, t] { fn(t); });
+    fn(0);
+    for (auto& x : th) x.join();
   };
-  for (int64_t i = 0; i < n; i++) {
-    const size_t la = strlen(seq_a[i]), lb = strlen(seq_b[i]);
-    if (la > 64u * 64u * MYERS_MAX_K) { ctx->err = "seq_a longer than 32768 characters"; return MIA_HIP_ERR_ARG; }
-    if (la <= 64u * MYERS_LANE_K && codes.size() + (la + lb) / 8 + 4 < ((size_t)1 << 31) && !ctx->myers_no_lanes) {
-      MyersLanePair q;
-      q.a_off = pack(seq_a[i], la); q.b_off = pack(seq_b[i], lb);
-      q.la = (int32_t)la; q.lb = (int32_t)lb; q.mode = mode[i]; q.maxd = maxd[i];
-      lp.push_back(q);
-      lane_index.push_back((int32_t)i);
-    } else {
-      MyersPair q;
-      oa.push_back(blob.size()); blob.append(seq_a[i], la);
-      ob.push_back(blob.size()); blob.append(seq_b[i], lb);
-      q.a = nullptr; q.b = nullptr;
-      q.la = (int32_t)la; q.lb = (int32_t)lb; q.mode = mode[i]; q.maxd = maxd[i];
-      pairs.push_back(q);
-      long_index.push_back((int32_t)i);
-      const int nb = (int)((la + 63) / 64);
-      if (nb > max_blk) max_blk = nb;
+  bool too_long = false;
+  parallel([&](int t) {
+    for (int64_t i = n * t / T, hi = n * (t + 1) / T; i < hi; i++) {
+      const size_t la = strlen(seq_a[i]), lb = strlen(seq_b[i]);
+      if (la > 64u * 64u * MYERS_MAX_K || lb >= ((size_t)1 << 31)) { too_long = true; la_of[(size_t)i] = 0; lb_of[(size_t)i] = 0; continue; }
+      la_of[(size_t)i] = (uint32_t)la; lb_of[(size_t)i] = (uint32_t)lb;
     }
+  });
+  if (too_long) { ctx->err = "seq_a longer than 32768 characters"; return MIA_HIP_ERR_ARG; }
+  std::vector<uint32_t> word_off((size_t)n, 0);
+  {
+    uint64_t words = 0;
+    for (int64_t i = 0; i < n; i++) {
+      const size_t la = la_of[(size_t)i], lb = lb_of[(size_t)i];
+      const uint64_t need = (la + 7) / 8 + 1 + (lb + 7) / 8 + 1;       // (one spare word behind each sequence: the kernel may fetch it)
+      if (la <= 64u * MYERS_LANE_K && words + need < ((uint64_t)1 << 31) && !ctx->myers_no_lanes) {
+        MyersLanePair q;
+        q.a_off = (uint32_t)words; q.b_off = (uint32_t)(words + (la + 7) / 8 + 1);
+        q.la = (int32_t)la; q.lb = (int32_t)lb; q.mode = mode[i]; q.maxd = maxd[i];
+        word_off[(size_t)i] = (uint32_t)words;
+        words += need;
+        lp.push_back(q);
+        lane_index.push_back((int32_t)i);
+      } else {
+        MyersPair q;
+        oa.push_back(blob.size()); blob.append(seq_a[i], la);
+        ob.push_back(blob.size()); blob.append(seq_b[i], lb);
+        q.a = nullptr; q.b = nullptr;
+        q.la = (int32_t)la; q.lb = (int32_t)lb; q.mode = mode[i]; q.maxd = maxd[i];
+        pairs.push_back(q);
+        long_index.push_back((int32_t)i);
+        const int nb = (int)((la + 63) / 64);
+        if (nb > max_blk) max_blk = nb;
+      }
+    }
+    codes.assign((size_t)words, 0u);
+  }
+  {
+    const size_t nlp = lp.size();
+    parallel([&](int t) {
+      for (size_t k = nlp * (size_t)t / (size_t)T, hi = nlp * (size_t)(t + 1) / (size_t)T; k < hi; k++) {
+        const MyersLanePair& q = lp[k];
+        const int64_t i = lane_index[k];
+        for (int side = 0; side < 2; side++) {
+          const unsigned char* s2 = reinterpret_cast<const unsigned char*>(side ? seq_b[i] : seq_a[i]);
+          const size_t len = side ? (size_t)q.lb : (size_t)q.la;
+          uint32_t* dst = codes.data() + (side ? q.b_off : q.a_off);
+          for (size_t w = 0; w < (len + 7) / 8; w++) {
+            uint32_t v = 0;
+            const size_t lim = std::min<size_t>(8, len - w * 8);
+            for (size_t c = 0; c < lim; c++) v |= (uint32_t)bits.t[s2[w * 8 + c]] << (4 * c);
+            dst[w] = v;
+          }
+        }
+      }
+    });
   }
   char* d_blob = nullptr;
   MyersPair* d_pairs = nullptr;
