@@ -545,7 +545,7 @@ __device__ __forceinline__ void bxl_trace_grid(const ReadSet& rs, const RefInfo&
   __shared__ int32_t sub_lds[BX_SUB_WORDS];
   for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.sub256[k];
   __syncthreads();
-  uint32_t* slab = slabs + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * slab_words;
+  uint32_t* slab = slabs + ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * slab_words;       // (uniform: scalar base + 32-bit lane offsets)
   __shared__ uint32_t done_wg;
   if (threadIdx.x == 0) done_wg = 0;
   __syncthreads();
@@ -563,10 +563,10 @@ __device__ __forceinline__ void bxl_trace_grid(const ReadSet& rs, const RefInfo&
   bxl_count_done(done, &done_wg, bxc(bx.ctr, BXC_DONE_TRACE));
 }
 // (two names for one body: a profile tells the plan's lists and the values DP's left-overs apart)
-__global__ __launch_bounds__(256) void k_bxl_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
+__global__ __launch_bounds__(256, 4) void k_bxl_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
   bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, BX_NCLS, BXC_LIST0 + BX_NCLS);
 }
-__global__ __launch_bounds__(256) void k_bxl_trace_late(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
+__global__ __launch_bounds__(256, 4) void k_bxl_trace_late(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
   bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, 2 * BX_NCLS, BXC_LATE0);
 }
 

@@ -48,6 +48,9 @@ struct mia_hip_ctx {
   hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr;                      // ... and both beside the planner and the full-window kernels of the reads the plan gave up on
   int32_t* d_retry2 = nullptr; int64_t retry2_cap = 0;                              // reads no band kernel could finish
   uint32_t* d_bx_slabs_late = nullptr; int64_t bx_slab_late_cap = 0; int bx_late_wgs = 0;
+  bool no_side_buckets = false;             // MIA_HIP_NO_SIDE_BUCKETS=1
+  int buckets_queued = 0;                   // the tally's counting sort is already queued: 1 on the context's stream, 2 on stream2 (ev_join behind it)
+  bool bx_planner_aside = false;            // this call: the planner and the full-window kernels run on stream2, the band DPs on the context's stream
   bool bx_pending_join = false;                                                     // band kernels are still running on stream2 / stream3
   std::string err;
   struct PoolBlock { void* p; size_t cap; bool lent; };
@@ -300,6 +303,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* nl2 = getenv("MIA_HIP_NO_LANES")) if (atoi(nl2)) ctx->use_lanes = 0;
     if (const char* bd2 = getenv("MIA_HIP_BX_DEBUG")) ctx->bx_dbg = (uint32_t)atoi(bd2);
     if (const char* bs2 = getenv("MIA_HIP_BX_SERIAL")) ctx->bx_serial = atoi(bs2) != 0;
+    if (const char* sb2 = getenv("MIA_HIP_NO_SIDE_BUCKETS")) ctx->no_side_buckets = atoi(sb2) != 0;
     if (const char* ml = getenv("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
     if (const char* na = getenv("MIA_HIP_NO_AUTO_PLAIN")) ctx->no_auto_plain = atoi(na) != 0;
     const char* egs = getenv("MIA_HIP_EAGER_SCRIPTS");
@@ -707,6 +711,7 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
 static int bx_join_and_retry(mia_hip_ctx* ctx) {
   if (!ctx->bx_pending_join) return MIA_HIP_OK;
   ctx->bx_pending_join = false;
+  if (ctx->bx_planner_aside) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));      // (the planner's chain ends here; it finished long ago)
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
   const int32_t* range = ctx->d_plan_hdr + PH_RETRY2;
@@ -799,6 +804,8 @@ static int align_all(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   const int wrap = ctx->wrap;
   ctx->bx_pending_join = false;
+  ctx->bx_planner_aside = false;
+  ctx->buckets_queued = 0;                  // (a counting sort queued for an earlier alignment is void)
   if (n == 0) { ctx->aligned = true; return MIA_HIP_OK; }
   RefInfo ref{ctx->d_ref, ctx->L, wrap, ctx->explicit_win};
   int32_t* d_count = ctx->d_bins;
@@ -925,6 +932,10 @@ static int align_all(mia_hip_ctx* ctx) {
           // context's stream, below -- the planner and the full-window kernels for the reads the plan gave up on.  The
           // step pays the longest of the three instead of their sum; what no band kernel can finish (the reference's
           // index-0 quirk: next to nothing) goes on a retry list that a window kernel reads behind the join.
+          // mia_hip_iterate (deferred): the values DP and the trace launch behind it ARE the step's critical path, so they
+          // stay on the context's stream, right behind the plan -- a cross-stream wait costs 20-30 us each way, and it is the
+          // planner with the full-window kernels (short, done long before) that moves to stream2.
+          hipStream_t vs = ctx->deferred ? ctx->stream : ctx->stream2;
           HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
           HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
           HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
@@ -933,14 +944,15 @@ static int align_all(mia_hip_ctx* ctx) {
             hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
           stage_end(ctx, STG_BX_TRACE, ctx->stream3);
           HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
-          if (stage_begin(ctx, STG_BX_VALUES, ctx->stream2)) return MIA_HIP_ERR_NOMEM;
+          if (stage_begin(ctx, STG_BX_VALUES, vs)) return MIA_HIP_ERR_NOMEM;
           if (!(ctx->bx_dbg & 4u)) {
-            hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bin_of);
-            hipLaunchKernelGGL(k_bxl_trace_late, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of);
+            hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bin_of);
+            hipLaunchKernelGGL(k_bxl_trace_late, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of);
           }
-          stage_end(ctx, STG_BX_VALUES, ctx->stream2);
-          HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+          stage_end(ctx, STG_BX_VALUES, vs);
+          if (!ctx->deferred) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
           HIPCHK(hipGetLastError());
+          ctx->bx_planner_aside = ctx->deferred;
           ctx->bx_pending_join = true;
         } else {
         // The two band DPs do not depend on each other (a read the values DP cannot finish stays open for the full-window
@@ -992,46 +1004,47 @@ static int align_all(mia_hip_ctx* ctx) {
   for (int k = 1; k < BXF_KINDS; k++) last_rejects += ctx->bx_last[BXC_FAIL0 + k];
   const bool many_rejects = bx && !ctx->no_auto_plain && (!ctx->ref_mostly_bases || last_rejects * 20 > n);
   const bool use_plain = ctx->use_plain && (!banded || ctx->plain_behind_band || many_rejects);
-  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
+  hipStream_t ps = ctx->bx_planner_aside ? ctx->stream2 : ctx->stream;      // the planner's stream (see the band launches above)
+  hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ps, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   if (ctx->deferred) {
     // ---- mia_hip_iterate: the same plan, but its numbers stay on the device (k_plan_scan) and every DP kernel reads its own
     // range; the host looks at the counters once, when everything has been queued --------------------------------------
     int32_t* hdr = ctx->d_plan_hdr;
     const bool dbg_steps = getenv("MIA_HIP_ITER_DEBUG") != nullptr;
-    auto ck = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[align_all deferred] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
+    auto ck = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ps); fprintf(stderr, "[align_all deferred] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
     ck("plan_count");
     int32_t* d_retry_cnt = hdr + PH_RETRY + 1;
-    HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ctx->stream));           // -1 = empty slot (quad padding)
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ctx->stream, d_count, d_off, hdr, 0);
-    hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
+    HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ps));           // -1 = empty slot (quad padding)
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 0);
+    hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
     ck("memsets");
-    hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ctx->stream, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count);
+    hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ps, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count);
     ck("scan fill seed");
     // every window class reads its own range from the header (the list is rewritten by the re-plan below, so they all go
     // first; a class without reads costs an empty launch -- a few microseconds; putting them on the second stream beside
     // the quad kernels was tried and gained nothing)
     for (int ci = 0; ci < N_CPL; ci++) {
-      hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci)
-                   : ci == 1 ? launch_window<8>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci)
-                             : launch_window<12>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci);
+      hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps)
+                   : ci == 1 ? launch_window<8>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps)
+                             : launch_window<12>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps);
       if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
     }
     ck("window classes");
     const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
     if (ctx->use_quad) {
       if (use_plain) {
-        if (stage_begin(ctx, STG_PLAIN)) return MIA_HIP_ERR_NOMEM;
-        hipLaunchKernelGGL(k_align_quad_plain, dim3(ctx->quad_wgs), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_list, 0, ctx->d_bin_of,
+        if (stage_begin(ctx, STG_PLAIN, ps)) return MIA_HIP_ERR_NOMEM;
+        hipLaunchKernelGGL(k_align_quad_plain, dim3(ctx->quad_wgs), dim3(64), quad_lds, ps, ctx->rs, ref, ctx->d_pssm, ctx->d_list, 0, ctx->d_bin_of,
                            (const int32_t*)(hdr + PH_QUAD));
-        stage_end(ctx, STG_PLAIN);
+        stage_end(ctx, STG_PLAIN, ps);
         ck("quad plain");
         // what it could not finish (and what the filter's gap hint kept out of it), re-planned into quads
-        HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ctx->stream));
-        HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ctx->stream));
-        hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_count);
-        HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ctx->stream));
-        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ctx->stream, d_count, d_off, hdr, 1);
-        hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
+        HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ps));
+        HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ps));
+        hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_count);
+        HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ps));
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 1);
+        hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
         ck("replan");
       }
       const int64_t slab = (int64_t)Q_G * MAX_READ * Q_TRACE_STRIDE;
@@ -1044,15 +1057,15 @@ static int align_all(mia_hip_ctx* ctx) {
         for (int k = 0; k < PH_WORDS; k++) fprintf(stderr, " %d", hh[k]);
         fprintf(stderr, "  n=%lld max_len=%d quad_lds=%zu\n", (long long)n, ctx->max_len, quad_lds);
       }
-      if (stage_begin(ctx, STG_TRACE)) return MIA_HIP_ERR_NOMEM;
-      hipLaunchKernelGGL(k_align_quad, dim3(qgrid), dim3(64), quad_lds, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list, 0,
+      if (stage_begin(ctx, STG_TRACE, ps)) return MIA_HIP_ERR_NOMEM;
+      hipLaunchKernelGGL(k_align_quad, dim3(qgrid), dim3(64), quad_lds, ps, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[0], ctx->d_list, 0,
                          ctx->d_quad_slabs, slab, ctx->d_wide_list, d_wide_count, ctx->d_retry_list, d_retry_cnt, ctx->use_band, ctx->dbg,
                          (const int32_t*)(hdr + PH_QUAD));
-      stage_end(ctx, STG_TRACE);
+      stage_end(ctx, STG_TRACE, ps);
       HIPCHK(hipGetLastError());
       ck("quad trace");
       if (ctx->use_band) {
-        hipError_t e = launch_window<4>(ctx, 0, ctx->d_retry_list, 0, hdr + PH_RETRY);
+        hipError_t e = launch_window<4>(ctx, 0, ctx->d_retry_list, 0, hdr + PH_RETRY, ps);
         if (e != hipSuccess) { ctx->err = std::string("k_align_window retry launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
       }
     }
@@ -1638,6 +1651,41 @@ static int ensure_tally(mia_hip_ctx* ctx) {
 }
 
 // everything of mia_hip_tally that is queued on the stream; the event count and the error flags are read afterwards
+// the binned tally's layout for this reference: buckets of TALLY_BUCKET columns, one workgroup per TALLY_CHUNK reads of a bucket
+static bool tally_is_binned(const mia_hip_ctx* ctx) {
+  const int nb = ctx->wrap / TALLY_BUCKET + 1;
+  return ctx->rs.n > 0 && ctx->use_binned_tally && nb <= 4096 && ctx->max_abs <= 32767;   // (the LDS copy of the matrices is int16)
+}
+// Counting sort of the reads by alignment start (k_bucket_count / _scan / _fill) on stream `on`.  It reads nothing but the
+// alignment starts, so mia_hip_iterate queues it on stream2 BESIDE the cull kernels (it also clears the tally buffers:
+// nothing adds to them before the tally kernel).  tally_launch waits for ev_join if `on` is not the context's stream.
+static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
+  int rc = ensure_tally(ctx);
+  if (rc) return rc;
+  const int Lp = ctx->tb.Lp;
+  const int64_t tally_words = (int64_t)(TALLY_WORDS + 1) * Lp + 256;                               // tally, gaps, the ranks' event counts
+  const int64_t n = ctx->rs.n;
+  const int nb = ctx->wrap / TALLY_BUCKET + 1;
+  const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
+  if (4 * (nb + 1) + grid > ctx->bucket_cap) {
+    if (dev_alloc(ctx, &ctx->d_bucket, (size_t)(4 * (nb + 1) + grid) * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->bucket_cap = (4 * (nb + 1) + grid) * 2;
+    ctx->bucket_clean_nb = -1;
+  }
+  if (!ctx->d_order && dev_alloc(ctx, &ctx->d_order, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+  int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1), *d_wgb = d_cur + (nb + 1);
+  // the bucket counts are left at zero by k_bucket_scan; only a fresh (or differently laid out) buffer is cleared here
+  if (ctx->bucket_clean_nb != nb) { HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, on)); ctx->bucket_clean_nb = nb; }
+  const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
+  hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb);
+  hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, ctx->rs, nb, d_off, d_cur, ctx->d_order);
+  HIPCHK(hipGetLastError());
+  if (on != ctx->stream) HIPCHK(hipEventRecord(ctx->ev_join, on));
+  ctx->buckets_queued = on != ctx->stream ? 2 : 1;
+  return MIA_HIP_OK;
+}
+
 static int tally_launch(mia_hip_ctx* ctx) {
   if (!ctx->aligned) { ctx->err = "realign first"; return MIA_HIP_ERR_STATE; }
   if (!ctx->culled) { ctx->err = "cull first (the dropped bits and record parameters are its output)"; return MIA_HIP_ERR_STATE; }
@@ -1648,28 +1696,18 @@ static int tally_launch(mia_hip_ctx* ctx) {
   const int64_t tally_words = (int64_t)(TALLY_WORDS + 1) * Lp + 256;                               // tally, gaps, the ranks' event counts
   if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->tb.n_events, 0, 8, ctx->stream));              // event count, flags (neighbours in the control block)
   const int64_t n = ctx->rs.n;
-  const int nb_plan = ctx->wrap / TALLY_BUCKET + 1;
-  const bool binned = n > 0 && ctx->use_binned_tally && nb_plan <= 4096 && ctx->max_abs <= 32767;
+  const bool binned = tally_is_binned(ctx);
   if (!binned) HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, (size_t)tally_words * 4, ctx->stream));     // (the binned path clears it inside k_bucket_count)
   if (n > 0) {
     RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
     const int nb = ctx->wrap / TALLY_BUCKET + 1;
-    if (ctx->use_binned_tally && nb <= 4096 && ctx->max_abs <= 32767) {   // (the LDS copy of the matrices is int16)
+    if (binned) {
       // counting sort of the reads by alignment start, then one LDS tally window per workgroup
+      if (!ctx->buckets_queued) { if (int rcb = bucket_launch(ctx, ctx->stream)) return rcb; }
+      if (ctx->buckets_queued == 2) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+      ctx->buckets_queued = 0;
       const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
-      if (4 * (nb + 1) + grid > ctx->bucket_cap) {
-        if (dev_alloc(ctx, &ctx->d_bucket, (size_t)(4 * (nb + 1) + grid) * 2)) return MIA_HIP_ERR_NOMEM;
-        ctx->bucket_cap = (4 * (nb + 1) + grid) * 2;
-        ctx->bucket_clean_nb = -1;
-      }
-      if (!ctx->d_order && dev_alloc(ctx, &ctx->d_order, (size_t)n)) return MIA_HIP_ERR_NOMEM;
       int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1), *d_wgb = d_cur + (nb + 1);
-      // the bucket counts are left at zero by k_bucket_scan; only a fresh (or differently laid out) buffer is cleared here
-      if (ctx->bucket_clean_nb != nb) { HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, ctx->stream)); ctx->bucket_clean_nb = nb; }
-      const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
-      hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, ctx->stream, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words);
-      hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, ctx->stream, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb);
-      hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, ctx->stream, ctx->rs, nb, d_off, d_cur, ctx->d_order);
       const int64_t slab_words = (int64_t)grid * (TALLY_WORDS - 1) * TALLY_WIN;
       if (slab_words > ctx->tally_slab_cap) {
         if (dev_alloc(ctx, &ctx->d_tally_slabs, (size_t)slab_words)) return MIA_HIP_ERR_NOMEM;
@@ -2150,7 +2188,14 @@ static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, 
     mia_hip_score_cut(score.data(), lens.data(), nullptr, ntot, &slope, &intercept);
   }
   if (!(hard_cut > 0) && slope <= 0) slope = 100.0;         // src/mia.c:440-442
+  ctx->buckets_queued = 0;
   if (int rcc = mia_hip_cull(ctx, hard_cut, slope, intercept, slot_base)) return rcc;
+  // the tally's counting sort reads nothing the cull writes: on stream2, beside the cull kernels (queued behind them on the
+  // host side -- the GPU is waiting for the first cull kernel at this point, not for these)
+  if (tally_is_binned(ctx) && !ctx->no_side_buckets) {
+    // (no event in front: the host has waited for every alignment kernel, and stream2's own work ended before that)
+    if (int rcb = bucket_launch(ctx, ctx->stream2)) return rcb;
+  }
   if (ctx->comm) {
     // links of formerly split reads (stale fs->back_asp, include/mia_hip.h) may point at slots of another rank: every rank
     // gets all links, applies those that hit its own slots, the record lengths the readers need come back by a max-reduce
