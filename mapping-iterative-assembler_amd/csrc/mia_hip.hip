@@ -2765,17 +2765,20 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
   int64_t p1_other = 0;
   for (int i = 0; i < L; i++) p1_other += cf[(size_t)i] > 3;
   const bool fast_ok = ctx->flat && ctx->use_filter && kmer_len <= 0 && len1 >= max_len;
+  // any other matrix the band pipeline has tables for: the anchored windows in losses (mia_pass1_kernels.h, GEN); the
+  // diagonal filter stays the flat matrix's
+  const bool gen_ok = !ctx->flat && ctx->bx_ok && ctx->use_bx && ctx->use_filter && kmer_len <= 0 && len1 >= max_len && !getenv("MIA_HIP_NO_ANCHOR_GEN");
   const bool filtered = fast_ok && p1_other * 50 <= L;
   // the anchored stage behind it (or in its place: a reference full of ambiguity codes, mt311 itself, leaves the filter
   // nothing to decide): the windows' 10-mer tables list the N columns under every spelling (bandx_body.h, N COLUMNS)
   int64_t wild_entries = 0;
-  if (fast_ok && p1_other && ctx->use_wild && len1 <= (1 << 22)) {
+  if ((fast_ok || gen_ok) && p1_other && ctx->use_wild && len1 <= (1 << 22)) {
     std::vector<uint8_t> both(cf.begin(), cf.begin() + len1);
     both.insert(both.end(), cr.begin(), cr.begin() + len1);
     wild_entries = kh_wild_entries(both.data(), (int64_t)both.size(), BX_WILD);
     if (wild_entries > ((int64_t)1 << 24)) wild_entries = 0;
   }
-  const bool anchored_ok = fast_ok && (p1_other == 0 || wild_entries > 0) && len1 <= (1 << 22) && !getenv("MIA_HIP_NO_ANCHOR");
+  const bool anchored_ok = (fast_ok || gen_ok) && (p1_other == 0 || wild_entries > 0) && len1 <= (1 << 22) && !getenv("MIA_HIP_NO_ANCHOR");
   int64_t n_dp = n;
   ctx->pass1_filtered = 0;
   ctx->pass1_anchored = 0;
@@ -2839,7 +2842,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
                    o_ae = carve((size_t)m * 4), o_score = carve((size_t)m * 4), o_refstart = carve((size_t)m * 4), o_bin = carve((size_t)m * 4),
                    o_list = carve(((size_t)m + 4 * N_BINS) * 4), o_wide = carve((size_t)m * 4), o_retry = carve((size_t)m * 4),
                    o_rest = carve((size_t)n_dp * 4), o_abr = carve((size_t)m * 2), o_cols = carve((size_t)m * stride * 2),
-                   o_bound = carve((size_t)n_dp * 4), o_budget = carve((size_t)n_dp * 4);
+                   o_bound = carve((size_t)n_dp * 4), o_budget = carve((size_t)n_dp * 4), o_u = carve((size_t)n_dp * 4);
       if (pool_alloc(ctx, &arena, top)) return MIA_HIP_ERR_NOMEM;
       uint32_t *w_roff = (uint32_t*)(arena + o_roff), *w_status = (uint32_t*)(arena + o_status), *d_nrest = (uint32_t*)(arena + o_nrest);
       uint16_t* w_len = (uint16_t*)(arena + o_len);
@@ -2847,7 +2850,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       int32_t *w_as = (int32_t*)(arena + o_as), *w_ae = (int32_t*)(arena + o_ae), *w_score = (int32_t*)(arena + o_score),
               *w_refstart = (int32_t*)(arena + o_refstart), *w_bin = (int32_t*)(arena + o_bin), *w_list = (int32_t*)(arena + o_list),
               *w_wide = (int32_t*)(arena + o_wide), *w_retry = (int32_t*)(arena + o_retry), *d_rest = (int32_t*)(arena + o_rest),
-              *w_bound = (int32_t*)(arena + o_bound), *w_budget = (int32_t*)(arena + o_budget);
+              *w_bound = (int32_t*)(arena + o_bound), *w_budget = (int32_t*)(arena + o_budget), *w_u = (int32_t*)(arena + o_u);
       int16_t *w_abr = (int16_t*)(arena + o_abr), *w_cols = (int16_t*)(arena + o_cols);
       HIPCHK(hipMemsetAsync(w_rc, 0, (size_t)m, ctx->stream));
       HIPCHK(hipMemsetAsync(w_abr, 0, (size_t)m * 2, ctx->stream));
@@ -2858,8 +2861,14 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       HIPCHK(hipMemcpyAsync(d_ref2, d_cf, (size_t)len1, hipMemcpyDeviceToDevice, ctx->stream));
       HIPCHK(hipMemcpyAsync(d_ref2 + len1, d_cr, (size_t)len1, hipMemcpyDeviceToDevice, ctx->stream));
       KmerOcc kf{d_p1kcnt, d_p1kpos}, kr{d_p1kcnt + DF_KTAB, d_p1kpos + DF_KTAB * DF_KCAP};
-      hipLaunchKernelGGL(k_pass1_anchor, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, kf, kr, len1, w_roff, w_len,
-                         w_sk, w_as, w_ae, w_bound, w_budget);
+      BxTab p1tab;
+      p1tab.sub = ctx->d_bx_sub; p1tab.mrow = ctx->d_bx_mrow; p1tab.loss = ctx->d_bx_loss; p1tab.dl = ctx->d_bx_dl; p1tab.min_m = ctx->bx_min_m; p1tab.max_m = ctx->bx_max_m;
+      if (ctx->flat)
+        hipLaunchKernelGGL(k_pass1_anchor<false>, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, kf, kr, len1, w_roff, w_len,
+                           w_sk, w_as, w_ae, w_bound, w_budget, w_u, p1tab);
+      else
+        hipLaunchKernelGGL(k_pass1_anchor<true>, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, kf, kr, len1, w_roff, w_len,
+                           w_sk, w_as, w_ae, w_bound, w_budget, w_u, p1tab);
       HIPCHK(hipGetLastError());
       int rc_inner;
       {
@@ -2876,7 +2885,7 @@ extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len,
       }
       if (rc_inner != MIA_HIP_OK) return rc_inner;
       hipLaunchKernelGGL(k_pass1_select, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, len1, L, w_sk, w_score, w_as,
-                         w_ae, w_abr, w_status, w_bound, w_budget, d_rest, d_nrest);
+                         w_ae, w_abr, w_status, w_bound, w_budget, w_u, d_rest, d_nrest);
       HIPCHK(hipGetLastError());
       uint32_t h_rest[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       HIPCHK(hipMemcpyAsync(h_rest, d_nrest, 64, hipMemcpyDeviceToHost, ctx->stream));

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bandx_body.h"
 #include "diag_filter.h"
 #include "mia_layout.h"
 #include "pass1_body.h"
@@ -137,15 +138,28 @@ constexpr int P1A_APART = 8;       // weak clusters at least this many diagonals
 // Clusters in which a single block occurs are not aligned: a path through them alone keeps at most as many blocks intact
 // as occur in such clusters, which bounds it by 200 len - 800 (nb - that many) + 200; k_pass1_select wants more (w_bound).
 
+//
+// GEN (any matrix the band pipeline has tables for -- bandx_body.h: identity is the best base at every depth): the same
+// argument in LOSSES against U = sum of the rows' best scores (sg_align scores both strands with the forward matrix,
+// src/mia.c:1500-1560, so strand 0's tables).  Breaking block b costs at least dl_b (BxTab::dl: the cheapest other base
+// over its rows, never more than a gap's GOP + GEP or a run of skipped rows' cost per touched block; capped where a clean
+// crossing could hold more N columns than the table spells out), so a path that loses less than the sum of dl over the
+// usable blocks crosses one of them cleanly.  The window quirk's slack (one substitution score) is max M instead of 200:
+//   budget = sum dl - 2 max M        bound = U - (sum dl - the `kept` largest dl) + max M
+// and a path within the budget strays at most (9 x 1200 - 1000) / 200 = 49 columns from its anchor: inside the margin.
+// Blocks are cut as the band pipeline cuts them (bx_blocks_of / bx_block_row: twelve for reads beyond 128 bases), so that
+// dl and the stray tables apply as they stand.  Two weak clusters P1A_APART diagonals apart count as one kept block only if
+// straying that far costs at least the dearest block (BxTab's stray tables: net of the blocks the gaps break themselves).
+template <bool GEN>
 __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32_t* todo, int64_t n_todo, KmerOcc kf, KmerOcc kr, int32_t len1,
                                                       uint32_t* w_roff, uint16_t* w_len, uint8_t* w_sk, int32_t* w_as, int32_t* w_ae,
-                                                      int32_t* w_bound, int32_t* w_budget) {
+                                                      int32_t* w_bound, int32_t* w_budget, int32_t* w_u, BxTab tab) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_todo) return;
   const int64_t i = todo[t];
   const int len2 = rs.len[i];
   const uint8_t* rp = rs.packed + rs.roff[i];
-  const int nb_cut = len2 / DF_K < P1A_BLOCKS ? len2 / DF_K : P1A_BLOCKS;
+  const int nb_cut = GEN ? bx_blocks_of(len2) : (len2 / DF_K < P1A_BLOCKS ? len2 / DF_K : P1A_BLOCKS);
   int n_cl = 0, c_strand[P1A_CLUSTERS], c_lo[P1A_CLUSTERS], c_hi[P1A_CLUSTERS], c_mask[P1A_CLUSTERS];
   bool usable = nb_cut >= 6;
   int why = usable ? 0 : 2;          // (statistics: 1 a read with N, 2 too few blocks, 3 too many clusters, 4 a cluster too wide, 5 too many strong ones, 6 none, 7 no room)
@@ -205,8 +219,34 @@ __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32
     for (int e = c + 1; e < n_cl; e++)
       if (__popc((unsigned)c_mask[c]) < 2 && __popc((unsigned)c_mask[e]) < 2 && c_strand[c] == c_strand[e] &&
           c_lo[e] - c_hi[c] < P1A_APART && c_lo[c] - c_hi[e] < P1A_APART) apart = false;
-  const int kept = apart ? 1 : __popc((unsigned)weak);
-  const int bound = weak ? FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * (nb - kept) + FLAT_MATCH : INT32_MIN;
+  int kept = apart ? 1 : __popc((unsigned)weak);
+  int bound = weak ? FLAT_MATCH * len2 - (FLAT_MATCH - FLAT_MISMATCH) * (nb - kept) + FLAT_MATCH : INT32_MIN;
+  int budget = (FLAT_MATCH - FLAT_MISMATCH) * nb - 2 * FLAT_MATCH, u_all = FLAT_MATCH * len2;
+  if (GEN) {
+    u_all = 0;
+    for (int r = 0; r < len2; r++) u_all += tab.mrow[sm_depth(r, len2) * 4 + (int)((rp[r >> 1] >> ((r & 1) * 4)) & 3)];     // (a read with N is not usable anyway)
+    const int16_t* dlb = tab.dl + (int64_t)len2 * BX_BLOCKS;                  // strand 0
+    int sum = 0, dmax = 0, top[BX_BLOCKS];
+    for (int b = 0; b < BX_BLOCKS; b++) top[b] = 0;
+    for (int b = 0; b < nb_cut; b++) {
+      if (!((blocks >> b) & 1)) continue;
+      const int v = dlb[b];
+      sum += v;
+      if (v > dmax) dmax = v;
+      // (insertion into the descending list of the blocks' prices)
+      int x = v;
+      for (int q = 0; q < BX_BLOCKS; q++) if (x > top[q]) { const int y = top[q]; top[q] = x; x = y; }
+    }
+    const int16_t* dn = tab.dl + bx_stray_off(0, len2, 0);
+    const int16_t* up = tab.dl + bx_stray_off(0, len2, 1);
+    const int stray = dn[P1A_APART] < up[P1A_APART] ? dn[P1A_APART] : up[P1A_APART];
+    kept = (apart && stray >= dmax) ? 1 : __popc((unsigned)weak);
+    int keep_sum = 0;
+    for (int q = 0; q < kept && q < BX_BLOCKS; q++) keep_sum += top[q];
+    budget = sum - 2 * tab.max_m;
+    bound = weak ? u_all - (sum - keep_sum) + tab.max_m : INT32_MIN;
+    if (usable && (budget <= 0 || dmax <= 0)) { usable = false; why = 2; }
+  }
   if (usable && n_slot == 0) { usable = false; why = 6; }                           // nothing strong to align: nothing bounds the optimum from below
   for (int c = 0; c < P1A_SLOTS; c++) {
     const int64_t slot = t * P1A_SLOTS + c;
@@ -223,18 +263,18 @@ __global__ __launch_bounds__(256) void k_pass1_anchor(Pass1Reads rs, const int32
   }
   for (int c = 0; c < P1A_SLOTS; c++) w_sk[t * P1A_SLOTS + c] = (uint8_t)(usable && c < n_slot);
   w_bound[t] = bound;
-  w_budget[t] = usable ? (FLAT_MATCH - FLAT_MISMATCH) * nb - 2 * FLAT_MATCH : -why;
+  w_budget[t] = usable ? budget : -why;
+  w_u[t] = u_all;
 }
 
 // after the windowed alignment of the slots: the read's result, or its place in the list of k_pass1
 __global__ __launch_bounds__(256) void k_pass1_select(Pass1Reads rs, const int32_t* todo, int64_t n_todo, int32_t len1, int32_t L, const uint8_t* w_sk,
                                                       const int32_t* w_score, const int32_t* w_as, const int32_t* w_ae, const int16_t* w_abr,
-                                                      const uint32_t* w_status, const int32_t* w_bound, const int32_t* w_budget, int32_t* rest,
-                                                      uint32_t* n_rest) {
+                                                      const uint32_t* w_status, const int32_t* w_bound, const int32_t* w_budget, const int32_t* w_u,
+                                                      int32_t* rest, uint32_t* n_rest) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_todo) return;
   const int64_t i = todo[t];
-  const int len2 = rs.len[i];
   int best[2] = {INT32_MIN, INT32_MIN}, abc[2] = {0, 0}, aec[2] = {0, 0};
   bool good = false, bad = false, clipped = false;
   for (int c = 0; c < P1A_SLOTS; c++) {
@@ -250,12 +290,12 @@ __global__ __launch_bounds__(256) void k_pass1_select(Pass1Reads rs, const int32
   }
   const int st = best[0] > best[1] ? 0 : 1;                        // src/mia.c:1549: the reverse strand on a tie
   // within the budget of its blocks, and better than anything the clusters that were not aligned could hold
-  if (good && !bad && !clipped && FLAT_MATCH * len2 - best[st] <= w_budget[t] && best[st] > w_bound[t]) {
+  if (good && !bad && !clipped && w_u[t] - best[st] <= w_budget[t] && best[st] > w_bound[t]) {      // (w_u: 200 x len with the flat matrix)
     pass1_store(rs, i, L, st, best[st], abc[st], aec[st], ST_OK);
   } else {
     rest[atomicAdd(n_rest, 1u)] = (int32_t)i;
     // why (n_rest[1..5], statistics): no usable cluster; a window the kernels did not finish; a clipped start; over budget; a weak cluster could hold better
-    const int why = !good ? 1 : (bad ? 2 : (clipped ? 3 : (FLAT_MATCH * len2 - best[st] > w_budget[t] ? 4 : 5)));
+    const int why = !good ? 1 : (bad ? 2 : (clipped ? 3 : (w_u[t] - best[st] > w_budget[t] ? 4 : 5)));
     atomicAdd(n_rest + why, 1u);
     if (!good && w_budget[t] < 0 && w_budget[t] >= -7) atomicAdd(n_rest + 8 - w_budget[t], 1u);
   }

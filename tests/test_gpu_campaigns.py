@@ -10,7 +10,7 @@ window / the whole strand / every base, on random and adversarial configurations
   plain global-atomic tally (ancient matrix): all tally words, ref->gaps, consensus, insert tallies
   (/root/reference/src/map_align.c:229-276, src/mia.c:515-603);
 * pass 1 without a k-mer mask: diagonal filter + anchored windows against the whole-strand DP, plain and N-rich
-  references (/root/reference/src/mia.c:1500-1665).
+  references, flat and position-specific matrices (/root/reference/src/mia.c:1500-1665).
 The long campaigns of profiles/r0*/README.md are the same functions with more rounds."""
 import pytest
 
@@ -43,3 +43,10 @@ def test_pass1_shortcuts_against_whole_strand_dp():
         total += r
         decided += f + a
     assert total >= 5_000_000 and decided > 0.3 * total, (total, decided)
+    # position-specific matrices: the anchored windows in losses (no diagonal filter), damaged reads
+    total = decided = 0
+    for seed, nrich, matrix in ((432000, False, "ancient"), (433000, True, "ancient"), (434000, False, "solexa")):
+        r, f, a = pass1_campaign.run(5, seed, nrich, n=100_000, quiet=True, matrix=matrix)
+        total += r
+        decided += a
+    assert total >= 1_500_000 and decided > 0.15 * total, (total, decided)

@@ -119,3 +119,50 @@ def test_pass1_diag_filter_changes_nothing():
             hip.close()
         for x, y in zip(out[0], out[1]):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("pfile", ["ancient.submat.txt", "ancient.submat.solexa.pe.txt"])
+def test_pass1_anchored_windows_with_a_position_specific_matrix(pfile, oracle, tmp_path):
+    """pass 1 without a k-mer mask and with a position-specific matrix against a reference of plain bases: nearly every
+    read is decided by the anchored windows in losses (mia_pass1_kernels.h, GEN) instead of the whole-strand DP.  The
+    oracle's sg_align (reference src/mia.c:1500-1665: both strands of the whole wrapped reference) on a sample of damaged
+    reads -- substitutions, indels, both strands, reads across the origin -- must give the same score, strand and end points."""
+    import gen_data
+    import mia_amd
+    _, _, mt = gen_data.read_fasta_one(os.path.join(GOLDEN, "mt311.fa"))
+    indiv = gen_data.resolve_individual(mt)[:6000]           # (the oracle's whole-strand DP is 0.1 s per read and kilobase)
+    n = 48
+    d = gen_data.make_reads(indiv, n, 100, seed=77, circular=True, sub_rate=0.02, indel_rate=0.004, damage=True)
+    seq = d["reads"].copy()
+    seq[:6] = gen_data.make_reads(indiv[-150:] + indiv[:150], 6, 100, seed=78, circular=False)["reads"]     # across the origin
+    ref_fa, reads_fa = tmp_path / "ref.fa", tmp_path / "reads.fa"
+    ref_fa.write_text(">r\n" + indiv + "\n")
+    reads_fa.write_text("".join(">q%d\n%s\n" % (i, bytes(seq[i]).decode()) for i in range(n)))
+    o = oc.Opts()
+    oracle.ora_opts_default(C.byref(o))
+    o.circular, o.kmer_len, o.soft_mask = 1, -1, 0
+    anc = oc.Pssm()
+    assert oracle.ora_pssm_read(os.path.join(GOLDEN, pfile).encode(), C.byref(anc)) == 1
+    st = oracle.ora_new(C.byref(o), C.byref(anc))
+    assert oracle.ora_load_ref_fasta(st, str(ref_fa).encode()) == 1
+    oracle.ora_prepare_ref(st)
+    oracle.ora_pass1_file(st, str(reads_fa).encode())
+    exp = {}
+    for i in range(oracle.ora_num_frags(st)):
+        f = oracle.ora_frag_at(st, i).contents
+        exp[f.id.decode()] = (f.score, f.rc, f.as_, f.ae)
+    hip = mia_amd.MiaHip(0)
+    hip.set_pssm(pssm_array(anc))
+    offsets = np.arange(n + 1, dtype=np.int64) * 100
+    score, rc, as_, ae, flags = hip.pass1(indiv, True, seq.reshape(-1), offsets, -1, False)
+    assert hip.pass1_anchored() >= n // 2, hip.pass1_anchored()
+    kept = 0
+    for k in range(n):
+        if flags[k] & mia_amd.P1_KEPT:
+            kept += 1
+            assert (int(score[k]), int(rc[k]), int(as_[k]), int(ae[k])) == exp["q%d" % k], (k, exp["q%d" % k])
+        else:
+            assert "q%d" % k not in exp
+    assert kept == len(exp) and kept >= n - 2
+    hip.close()
+    oracle.ora_free(st)

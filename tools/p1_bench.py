@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Pass-1 micro-benchmark: N synthetic 100 bp reads against mt311, kernel time from HIP events.
-usage: python tools/p1_bench.py [n_reads] [kmer_len] [resolved]      (env: MIA_HIP_P1_CPL, MIA_HIP_P1_PLAIN, MIA_HIP_NO_DIAG_FILTER)
+usage: python tools/p1_bench.py [n_reads] [kmer_len] [resolved|mt311] [flat|ancient|solexa]      (env: MIA_HIP_P1_CPL, MIA_HIP_P1_PLAIN, MIA_HIP_NO_DIAG_FILTER)
 "resolved": reference and reads come from mt311 with its ambiguity codes resolved to plain bases (the usual kind of
 reference; against mt311 itself half of the columns are N for the aligner and the diagonal filter cannot decide anything)."""
 import os
@@ -34,7 +34,9 @@ def main():
     seq[rc] = gen_data._COMP[seq[rc][:, ::-1]]
     offsets = (np.arange(n + 1, dtype=np.int64) * 100)
     hip = mia_amd.MiaHip(0)
-    hip.set_pssm(mia_amd.flat_pssm())
+    matrix = sys.argv[4] if len(sys.argv) > 4 else "flat"
+    golden = os.path.join(ROOT, "tests", "golden")
+    hip.set_pssm(mia_amd.flat_pssm() if matrix == "flat" else mia_amd.read_pssm(os.path.join(golden, {"ancient": "ancient.submat.txt", "solexa": "ancient.submat.solexa.pe.txt"}[matrix])))
     hip.pass1(ref, True, seq[:256].reshape(-1), offsets[:257], k)
     t0 = time.perf_counter()
     sc, rcs, as_, ae, fl = hip.pass1(ref, True, seq.reshape(-1), offsets, k)
