@@ -52,16 +52,19 @@ __device__ __forceinline__ uint32_t bx_pack(const BxPlan& p) {
   return (uint32_t)(p.d0 + 512) | ((uint32_t)(p.dstar - p.d0) << 11) | ((uint32_t)p.edge << 16) | ((uint32_t)p.w << 17);
 }
 
-__global__ __launch_bounds__(256) void k_ref_nibbles(const uint8_t* codes, int64_t n_codes, int64_t words, uint32_t* out) {
-  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (w >= words) return;
+__device__ __forceinline__ uint32_t ref_nibble_word(const uint8_t* codes, int64_t n_codes, int64_t w) {
   uint32_t v = 0;
   for (int k = 0; k < 8; k++) {
     const int64_t p = w * 8 + k - BX_NIB_LEAD;
     const uint32_t c = (p >= 0 && p < n_codes) ? codes[p] : 4u;
     v |= (c > 4u ? 4u : c) << (4 * k);
   }
-  out[w] = v;
+  return v;
+}
+__global__ __launch_bounds__(256) void k_ref_nibbles(const uint8_t* codes, int64_t n_codes, int64_t words, uint32_t* out) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w >= words) return;
+  out[w] = ref_nibble_word(codes, n_codes, w);
 }
 
 __global__ __launch_bounds__(256) void k_bx_umax(ReadSet rs, const int32_t* mrow, int32_t* umax) {
@@ -123,8 +126,7 @@ __global__ __launch_bounds__(256) void k_diag_scripts(ReadSet rs) {
 
 // the reference's 10-mers into the hash table (bandx_body.h: KmerHash); slots and ovf are all ones / anything before.
 // A 10-mer with up to `wild` N columns goes in under each of its 4^k spellings (the host sized the table for them).
-__global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t n_codes, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift, int32_t wild) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void kmer_hash_insert(const uint8_t* codes, int64_t n_codes, int64_t p, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift, int32_t wild) {
   uint32_t base;
   uint64_t npos;
   const int k = kmer_wild_at(codes, n_codes, p, &base, &npos);
@@ -143,6 +145,9 @@ __global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t
       h = (h + 1) & mask;
     }
   }
+}
+__global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t n_codes, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift, int32_t wild) {
+  kmer_hash_insert(codes, n_codes, (int64_t)blockIdx.x * 256 + threadIdx.x, slot, ovf, mask, shift, wild);
 }
 
 // bit planes of every read (diag_filter.h: DiagScan::load_read), once per read set: words lo words, then words hi words

@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void k_rec_geom(ReadSet rs, int32_t L, const i
 // arrival per 4 096 reads -- a counter every block of 256 adds to is served one add at a time, 80 us for a million reads);
 // the workgroup that arrives last turns the counts into exclusive offsets (+ base) and leaves the total in *total.
 // nb: stretches.  *blocks_done must be 0 on entry and is 0 again on exit.
-__global__ __launch_bounds__(256) void k_slot_count(ReadSet rs, int32_t L, int64_t* partial, int nb, int64_t base, int64_t* total, uint32_t* blocks_done) {
+__global__ __launch_bounds__(256) void k_slot_count(ReadSet rs, int32_t L, int64_t* partial, int nb, int64_t base, int64_t* total, uint32_t* blocks_done, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   __shared__ bool last;
   __shared__ int64_t s_run[256];
   __shared__ int32_t wsum[16][4];
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(256) void k_slot_count(ReadSet rs, int32_t L, int64
 // links (k_cull_mark) of a block of 256 reads in one go: what the three kernels hand each other per read stays in registers.
 __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, const int64_t* partial, int64_t* slot, RecInfo ri, SlotInfo si, int64_t read_base,
                                                         uint32_t* flags, uint8_t* slot_dropped, int64_t n_slots, int32_t hard_cut, double slope, double intercept,
-                                                        int64_t* back_slot, const int64_t* front_slot0, Links lk, const double* dev_cut) {
+                                                        int64_t* back_slot, const int64_t* front_slot0, Links lk, const double* dev_cut, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   __shared__ int32_t wsum[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);     // first read of this wavefront
@@ -490,7 +492,8 @@ __global__ void k_cull_mark(ReadSet rs, int32_t L, const int64_t* slot, uint8_t*
 
 // every link (of this context or gathered from the others): effects on the slot it points at, if that slot is ours
 __global__ void k_links_apply(const int64_t* links, const int32_t* n_links_p, int32_t cap, SlotInfo si, uint8_t* slot_dropped, int64_t n_slots,
-                              int32_t* link_len, int32_t* link_act, uint32_t* flags) {
+                              int32_t* link_len, int32_t* link_act, uint32_t* flags, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int n_links = min(*n_links_p, cap);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_links; e += gridDim.x * blockDim.x) {
     const int64_t* r = links + (int64_t)e * 4;
@@ -510,7 +513,8 @@ __global__ void k_links_apply(const int64_t* links, const int32_t* n_links_p, in
 __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const uint8_t* slot_dropped, int64_t n_slots, const int64_t* back_slot,
                              RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, const int32_t* link_act, const int32_t* n_links_p,
                              int32_t cap, int64_t read_base,
-                             uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags) {
+                             uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rs.n) return;
   const int n_links = min(*n_links_p, cap);
@@ -720,7 +724,8 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
 constexpr int BUCKET_PER = 8;   // reads per thread of the bucketing kernels
 // zero / zero_words: a buffer this launch clears on the side (the tally, the gaps and the ranks' event-count slots behind them:
 // nothing adds to them before the tally kernel, which runs behind this one), or nullptr
-__global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count, int32_t* zero, int64_t zero_words) {
+__global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count, int32_t* zero, int64_t zero_words, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   extern __shared__ int32_t hist[];
   for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
   if (zero) for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < zero_words; k += (int64_t)gridDim.x * 256) zero[k] = 0;
@@ -733,7 +738,8 @@ __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, in
   for (int b = threadIdx.x; b < nb; b += blockDim.x) if (hist[b]) atomicAdd(&count[b], hist[b]);
 }
 // off[b] = first read of bucket b in `order`, wgoff[b] = first workgroup of bucket b (TALLY_CHUNK reads each)
-__global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor, int32_t* wg_bucket) {
+__global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor, int32_t* wg_bucket, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   // one workgroup of 256 threads: every thread a stretch of buckets, a scan over the 256 partial sums in LDS
   __shared__ int32_t s_run[256], s_wg[256];
   const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
@@ -758,7 +764,8 @@ __global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb,
   }
   if (t == 255) { off[nb] = s_run[255]; wgoff[nb] = s_wg[255]; }
 }
-__global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order) {
+__global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   extern __shared__ int32_t sh[];
   int32_t* hist = sh;
   int32_t* base = sh + nb;
@@ -784,7 +791,8 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
                                                        const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, const uint64_t* rplanes,
-                                                       int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket, int32_t pk_bias) {
+                                                       int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket, int32_t pk_bias, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   constexpr bool linear = LINEAR;
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
   // !LINEAR (a position-specific matrix): the scores of a base depend on its depth code and its strand -- but every base
@@ -1291,7 +1299,8 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
 // tally[word][gc] += sum of the windows that cover column gc: buckets floor(gc/128)-2 .. floor(gc/128), all their chunks,
 // and the last buckets' windows where they wrap around to the start of the reference.
 // Runs after k_tally_binned; nothing else writes the tally then, so plain read-modify-write.
-__global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs) {
+__global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   // one thread per (column, tally word): blockIdx.y is the word (a thread per column alone is 66 workgroups for a
   // mitochondrion, each thread a chain of five hundred loads)
   const int gc = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
@@ -1380,7 +1389,8 @@ __global__ void k_ma_ins_events(MaRecords mr, int64_t n_ins, const int32_t* ins_
 // cap: slots the insert buffers hold.  The host launches with the capacity left from the last call and reads the real total
 // back with the results; only if the total outgrew the capacity does it enlarge the buffers and run the insert part again.
 __global__ void k_ins_tally(const uint64_t* events, int32_t n_events, const int32_t* pssm2, const int32_t* ins_off,
-                            const int32_t* gaps, int32_t L, int32_t* ins_tally, int32_t cap, const int32_t* n_events_dev, int32_t cap_events) {
+                            const int32_t* gaps, int32_t L, int32_t* ins_tally, int32_t cap, const int32_t* n_events_dev, int32_t cap_events, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   if (n_events_dev) n_events = min(*n_events_dev, cap_events);      // the count stayed on the device: a grid-stride sweep
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_events; e += gridDim.x * blockDim.x) {
   const uint64_t ev = events[e];

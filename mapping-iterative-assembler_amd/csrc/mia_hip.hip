@@ -48,6 +48,16 @@ struct mia_hip_ctx {
   hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr;                      // ... and both beside the planner and the full-window kernels of the reads the plan gave up on
   int32_t* d_retry2 = nullptr; int64_t retry2_cap = 0;                              // reads no band kernel could finish
   uint32_t* d_bx_slabs_late = nullptr; int64_t bx_slab_late_cap = 0; int bx_late_wgs = 0;
+  // mia_hip_iterate without a host wait behind the alignment: cull, tally and consensus are queued at once and every one of
+  // their kernels returns at its first instruction if *abort_if != 0 (reads are waiting for the exact one-read-per-thread
+  // kernel: the host sees that with the consensus, runs it, and queues the chain again)
+  const int32_t* abort_if = nullptr;
+  bool spec_ok = false, spec_pending = false, spec_filtered = false, spec_bx = false, spec_plain = false;
+  int64_t spec_redone = 0;                  // iterations whose cull / tally / consensus were queued twice (reads for the exact kernel)
+  bool pend_encode = false; int32_t pend_L = 0, pend_wl = 0, pend_total = 0;      // mia_hip_iterate: d_ascii holds the new reference, d_ref not yet
+  uint32_t* d_prep_bar = nullptr; uint32_t prep_bar_count = 0; bool no_prep_fuse = false;   // k_ref_prep's grid barrier (MIA_HIP_NO_PREP_FUSE=1: six launches)
+  bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
+  bool no_spec = false;                     // MIA_HIP_NO_SPEC=1: wait for the alignment's counters before the cull is queued
   bool no_side_buckets = false;             // MIA_HIP_NO_SIDE_BUCKETS=1
   int buckets_queued = 0;                   // the tally's counting sort is already queued: 1 on the context's stream, 2 on stream2 (ev_join behind it)
   bool bx_planner_aside = false;            // this call: the planner and the full-window kernels run on stream2, the band DPs on the context's stream
@@ -304,6 +314,9 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* bd2 = getenv("MIA_HIP_BX_DEBUG")) ctx->bx_dbg = (uint32_t)atoi(bd2);
     if (const char* bs2 = getenv("MIA_HIP_BX_SERIAL")) ctx->bx_serial = atoi(bs2) != 0;
     if (const char* sb2 = getenv("MIA_HIP_NO_SIDE_BUCKETS")) ctx->no_side_buckets = atoi(sb2) != 0;
+    if (const char* ns2 = getenv("MIA_HIP_NO_SPEC")) ctx->no_spec = atoi(ns2) != 0;
+    if (const char* pf2 = getenv("MIA_HIP_NO_PREP_FUSE")) ctx->no_prep_fuse = atoi(pf2) != 0;
+    if (const char* st2 = getenv("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
     if (const char* ml = getenv("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
     if (const char* na = getenv("MIA_HIP_NO_AUTO_PLAIN")) ctx->no_auto_plain = atoi(na) != 0;
     const char* egs = getenv("MIA_HIP_EAGER_SCRIPTS");
@@ -338,6 +351,11 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
   ctx->tb.flags = reinterpret_cast<uint32_t*>(ctx->d_ctrl + CTRL_TFLAGS);
   ctx->d_bx_ctr = reinterpret_cast<uint32_t*>(ctx->d_ctrl + CTRL_BXC);
   if (hipMemset(ctx->d_ctrl, 0, CTRL_WORDS * 4) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
+  {
+    const int32_t one = 1;
+    if (hipMalloc((void**)&ctx->d_one, 4) != hipSuccess || hipMemcpy(ctx->d_one, &one, 4, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
+    if (hipMalloc((void**)&ctx->d_prep_bar, 4) != hipSuccess || hipMemset(ctx->d_prep_bar, 0, 4) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
+  }
   if (hipHostMalloc((void**)&ctx->h_pin, mia_hip_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
   *out = ctx;
   return MIA_HIP_OK;
@@ -372,6 +390,8 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (ctx->d_retry2) (void)hipFree(ctx->d_retry2);
   if (ctx->d_cull_sync) (void)hipFree(ctx->d_cull_sync);
   if (ctx->d_bx_slabs_late) (void)hipFree(ctx->d_bx_slabs_late);
+  if (ctx->d_one) (void)hipFree(ctx->d_one);
+  if (ctx->d_prep_bar) (void)hipFree(ctx->d_prep_bar);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
@@ -799,11 +819,40 @@ static int run_wide(mia_hip_ctx* ctx, const RefInfo& ref, int32_t n_wide) {
   return MIA_HIP_OK;
 }
 
+// mia_hip_iterate left the new reference as ASCII in d_ascii: its codes, if no k_ref_prep makes them
+static void encode_now(mia_hip_ctx* ctx) {
+  if (!ctx->pend_encode) return;
+  ctx->pend_encode = false;
+  hipLaunchKernelGGL(k_ref_encode, dim3((unsigned)((ctx->pend_total + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_ascii, ctx->pend_L, ctx->pend_wl,
+                     ctx->d_ref, ctx->pend_total);
+}
+
+// the counters of a deferred alignment, once its control block has reached the host (hb: the words from CTRL_BINS + 3 N_BINS on)
+static void align_counters_collect(mia_hip_ctx* ctx, const int32_t* hb, bool filtered, bool bx, bool plain) {
+  constexpr int C0 = CTRL_BINS + 3 * N_BINS;
+  const int32_t* h_hdr = hb + (CTRL_HDR - C0);
+  const uint32_t* h_filter = reinterpret_cast<const uint32_t*>(hb + (CTRL_FILTER - C0));
+  const uint32_t* h_bxc = reinterpret_cast<const uint32_t*>(hb + (CTRL_BXC - C0));
+  ctx->filter_seen += ctx->rs.n;
+  if (filtered) {
+    ctx->filter_proven += h_filter[0];
+    ctx->band_done += h_filter[2];
+    if (bx) {
+      ctx->filter_proven += h_bxc[BXC_DONE_PLAN * BXC_STRIDE];
+      for (int k = 0; k < 3; k++) ctx->bx_done[k] += h_bxc[(BXC_DONE_PLAN + k) * BXC_STRIDE];
+      ctx->bx_seen += h_bxc[BXC_SEEN * BXC_STRIDE];
+    }
+  }
+  for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = bx ? h_bxc[k * BXC_STRIDE] : 0;
+  if (plain) ctx->plain_retried += h_hdr[PH_RETRIED_PLAIN];
+}
+
 // every strand_known read against its window of ctx->d_ref: plan, values-only pass, trace kernels, exact kernel
 static int align_all(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   const int wrap = ctx->wrap;
   ctx->bx_pending_join = false;
+  if (!ctx->spec_ok) { ctx->spec_pending = false; ctx->abort_if = nullptr; }
   ctx->bx_planner_aside = false;
   ctx->buckets_queued = 0;                  // (a counting sort queued for an earlier alignment is void)
   if (n == 0) { ctx->aligned = true; return MIA_HIP_OK; }
@@ -812,13 +861,18 @@ static int align_all(mia_hip_ctx* ctx) {
   int32_t* d_off = ctx->d_bins + N_BINS;
   int32_t* d_cursor = ctx->d_bins + 2 * N_BINS;
   int32_t* d_wide_count = ctx->d_bins + 3 * N_BINS;
-  HIPCHK(hipMemsetAsync(ctx->d_ctrl, 0, (size_t)CTRL_WORDS * 4, ctx->stream));       // every counter of the iteration at once
   int32_t* d_retry_count = ctx->d_bins + 3 * N_BINS + 1;
   const int tb = 256, gb = (int)((n + (int64_t)tb * PLAN_PER - 1) / ((int64_t)tb * PLAN_PER));
   const int filter_ok = ctx->flat && ctx->use_filter && ctx->ref_mostly_bases;
   // the band pipeline for any matrix (bandx_kernels.h); it needs the 10-mer table and windows free of N
   const bool bx = ctx->bx_ok && ctx->use_bx && (ctx->ref_mostly_bases || ctx->kh_entries > 0) && wrap <= (1 << 22) && !(ctx->dbg & 128u);
   const bool run_filter = filter_ok && (!bx || ctx->bx_filter_first);
+  // mia_hip_iterate with the band pipeline alone: codes, control block, planes, nibbles and 10-mer table in one launch (k_ref_prep)
+  const bool fused_prep = ctx->pend_encode && bx && !run_filter && !ctx->no_prep_fuse;
+  if (!fused_prep) {
+    encode_now(ctx);
+    HIPCHK(hipMemsetAsync(ctx->d_ctrl, 0, (size_t)CTRL_WORDS * 4, ctx->stream));     // every counter of the iteration at once
+  }
   const int filtered = run_filter || bx;            // bin_of carries marks for the planner
   uint32_t h_filter_n = 0;
   bool banded = false;
@@ -830,6 +884,7 @@ static int align_all(mia_hip_ctx* ctx) {
       ctx->plane_cap = words;
     }
     RefPlanes rp{ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap};
+    if (!fused_prep)
     hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 3) / 4 < 4096 ? (words + 3) / 4 : 4096)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap + 64, words,
                        ctx->d_planes, ctx->d_planes + ctx->plane_cap, ctx->d_planes + 2 * ctx->plane_cap);
     // the 10-mer table of this reference (rule (c) looks long clean stretches up instead of sliding over every diagonal;
@@ -862,16 +917,32 @@ static int align_all(mia_hip_ctx* ctx) {
         if (dev_alloc(ctx, &ctx->d_refnib, (size_t)nw * 2)) return MIA_HIP_ERR_NOMEM;
         ctx->refnib_cap = nw * 2;
       }
+      if (!fused_prep)
       hipLaunchKernelGGL(k_ref_nibbles, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, nw, ctx->d_refnib);
       const uint32_t kslots = kh_slots_for_entries(wrap, ctx->kh_entries);
       if (kslots > ctx->khash_cap) {
         if (dev_alloc(ctx, &ctx->d_khash, (size_t)kslots * 4) || dev_alloc(ctx, &ctx->d_khash_ovf, (size_t)kslots * 2)) return MIA_HIP_ERR_NOMEM;
         ctx->khash_cap = kslots;
       }
-      HIPCHK(hipMemsetAsync(ctx->d_khash, 0xFF, (size_t)kslots * 16, ctx->stream));
       const KmerHash kh{ctx->d_khash, ctx->d_khash_ovf, kslots - 1, kh_shift_for(kslots), ctx->kh_entries > 0 ? BX_WILD : 0};
+      if (fused_prep) {
+        RefPrep rp2;
+        rp2.ascii = (const char*)ctx->d_ascii; rp2.L = ctx->pend_L; rp2.wl = ctx->pend_wl; rp2.total = ctx->pend_total; rp2.codes = ctx->d_ref;
+        rp2.ctrl = ctx->d_ctrl; rp2.ctrl_words = CTRL_WORDS;
+        rp2.kslot = ctx->d_khash; rp2.kovf = ctx->d_khash_ovf; rp2.kslots = kslots; rp2.kmask = kh.mask; rp2.kshift = kh.shift; rp2.kwild = kh.wild;
+        rp2.plane_words = words; rp2.plo = ctx->d_planes; rp2.phi = ctx->d_planes + ctx->plane_cap; rp2.pok = ctx->d_planes + 2 * ctx->plane_cap;
+        rp2.nib_words = nw; rp2.nib = ctx->d_refnib;
+        const int64_t want = ((int64_t)wrap + 255) / 256;
+        const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, ctx->cus));      // one workgroup per compute unit at most: all resident
+        ctx->prep_bar_count += grid;
+        rp2.bar = ctx->d_prep_bar; rp2.bar_target = ctx->prep_bar_count;
+        ctx->pend_encode = false;
+        hipLaunchKernelGGL(k_ref_prep, dim3(grid), dim3(256), 0, ctx->stream, rp2);
+      } else {
+      HIPCHK(hipMemsetAsync(ctx->d_khash, 0xFF, (size_t)kslots * 16, ctx->stream));
       hipLaunchKernelGGL(k_kmer_hash, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_khash, ctx->d_khash_ovf,
                          kh.mask, kh.shift, kh.wild);
+      }
       if (n > ctx->bx_cap) {
         if (dev_alloc(ctx, &ctx->d_bx_plan, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_expect, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_lists, (size_t)n * 3 * BX_NCLS))
           return MIA_HIP_ERR_NOMEM;
@@ -1082,22 +1153,17 @@ static int align_all(mia_hip_ctx* ctx) {
     const bool pre_cull = ctx->in_iterate && ctx->comm;
     if (pre_cull) { if (int rcp = comm_pre_cull_enqueue(ctx, d_wide_count)) return rcp; }
     HIPCHK(hipMemcpyAsync(hb, ctx->d_ctrl + C0, (size_t)CN * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    const int32_t* h_hdr = hb + (CTRL_HDR - C0);
-    const uint32_t* h_filter = reinterpret_cast<const uint32_t*>(hb + (CTRL_FILTER - C0));
-    const uint32_t* h_bxc = reinterpret_cast<const uint32_t*>(hb + (CTRL_BXC - C0));
-    ctx->filter_seen += n;
-    if (filtered) {
-      ctx->filter_proven += h_filter[0];
-      ctx->band_done += h_filter[2];
-      if (bx) {
-        ctx->filter_proven += h_bxc[BXC_DONE_PLAN * BXC_STRIDE];
-        for (int k = 0; k < 3; k++) ctx->bx_done[k] += h_bxc[(BXC_DONE_PLAN + k) * BXC_STRIDE];
-        ctx->bx_seen += h_bxc[BXC_SEEN * BXC_STRIDE];
-      }
+    if (ctx->spec_ok && ctx->h_pin && !pre_cull && !dbg_steps) {
+      // mia_hip_iterate, one context, a cut line that needs no scores on the host: no wait here.  The caller queues cull,
+      // tally and consensus behind this copy; their kernels look at the exact-kernel count themselves (abort_if) and
+      // iterate_body reads these counters when it waits for the consensus (align_counters_collect).
+      ctx->spec_pending = true; ctx->spec_filtered = filtered != 0; ctx->spec_bx = bx; ctx->spec_plain = use_plain && ctx->use_quad;
+      ctx->abort_if = ctx->spec_force ? ctx->d_one : d_wide_count;      // (MIA_HIP_SPEC_TEST=1: every iteration takes the second round)
+      ctx->aligned = true; ctx->culled = false; ctx->tallied = false; ctx->pre_cull_valid = false;
+      return MIA_HIP_OK;
     }
-    for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = bx ? h_bxc[k * BXC_STRIDE] : 0;
-    if (use_plain && ctx->use_quad) ctx->plain_retried += h_hdr[PH_RETRIED_PLAIN];
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    align_counters_collect(ctx, hb, filtered != 0, bx, use_plain && ctx->use_quad);
     const int32_t n_wide = hb[0];
     if (n_wide > 0) { if (int rcw = run_wide(ctx, ref, n_wide)) return rcw; }
     if (pre_cull && comm_pre_cull_collect(ctx)) {
@@ -1313,7 +1379,7 @@ static int finish_cull(mia_hip_ctx* ctx) {
     ctx->link_len_cap = ctx->links_cap_all + 64;
   }
   hipLaunchKernelGGL(k_links_apply, dim3(32), dim3(256), 0, ctx->stream, ctx->d_links_all, ctx->d_n_links_all, (int32_t)ctx->links_cap_all, ctx->si,
-                     ctx->d_slot_dropped, ctx->n_slots, ctx->d_link_len, ctx->d_link_act, ctx->d_cull_flags);
+                     ctx->d_slot_dropped, ctx->n_slots, ctx->d_link_len, ctx->d_link_act, ctx->d_cull_flags, ctx->abort_if);
   ctx->links_applied = true;
   return finish_params(ctx);
 }
@@ -1322,7 +1388,7 @@ static int finish_params(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   hipLaunchKernelGGL(k_rec_params, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
                      ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->d_link_act, ctx->d_n_links_all,
-                     (int32_t)ctx->links_cap_all, ctx->read_base, ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags);
+                     (int32_t)ctx->links_cap_all, ctx->read_base, ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags, ctx->abort_if);
   HIPCHK(hipGetLastError());
   return MIA_HIP_OK;
 }
@@ -1352,7 +1418,7 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
     if (dev_alloc(ctx, &ctx->d_cull_sync, 4)) return MIA_HIP_ERR_NOMEM;
     HIPCHK(hipMemsetAsync(ctx->d_cull_sync, 0, 16, ctx->stream));
   }
-  hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, nb, slot_base, ctx->d_total, ctx->d_cull_sync);
+  hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, nb, slot_base, ctx->d_total, ctx->d_cull_sync, ctx->abort_if);
   if (slot_base + 2 * n + 16 > ctx->n_slots) {   // sharded runs: slots are global indices
     uint8_t* nd = nullptr;
     const int64_t ns = slot_base + 2 * n + 16;
@@ -1372,7 +1438,7 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 8, ctx->stream));                     // link count, cull flags (neighbours in the control block)
   hipLaunchKernelGGL(k_cull_records, dim3((unsigned)nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, (const int64_t*)ctx->d_partial, ctx->d_slot, ctx->ri, ctx->si,
                      ctx->read_base, ctx->d_cull_flags, ctx->d_slot_dropped, ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot,
-                     (const int64_t*)ctx->d_front_slot0, ctx->lk, ctx->dev_cut);
+                     (const int64_t*)ctx->d_front_slot0, ctx->lk, ctx->dev_cut, ctx->abort_if);
   HIPCHK(hipGetLastError());
   // by default the links to apply are this context's own; a sharded run replaces them with the gathered list (mia_hip_set_links)
   ctx->d_links_all = ctx->lk.rec;
@@ -1677,9 +1743,9 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
   // the bucket counts are left at zero by k_bucket_scan; only a fresh (or differently laid out) buffer is cleared here
   if (ctx->bucket_clean_nb != nb) { HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, on)); ctx->bucket_clean_nb = nb; }
   const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
-  hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words);
-  hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb);
-  hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, ctx->rs, nb, d_off, d_cur, ctx->d_order);
+  hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words, ctx->abort_if);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb, ctx->abort_if);
+  hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if);
   HIPCHK(hipGetLastError());
   if (on != ctx->stream) HIPCHK(hipEventRecord(ctx->ev_join, on));
   ctx->buckets_queued = on != ctx->stream ? 2 : 1;
@@ -1719,13 +1785,13 @@ static int tally_launch(mia_hip_ctx* ctx) {
       if (ctx->tally_linear)
         hipLaunchKernelGGL(k_tally_binned<true>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                            ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
-                           planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb, -1);
+                           planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb, -1, ctx->abort_if);
       else
         hipLaunchKernelGGL(k_tally_binned<false>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                            ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
-                           (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb, ctx->tally_pk_bias);
+                           (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb, ctx->tally_pk_bias, ctx->abort_if);
       stage_end(ctx, STG_TALLY);
-      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256, TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs);
+      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256, TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs, ctx->abort_if);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
                          ctx->d_drop_b, ctx->tb, ctx->ri.trec, ctx->ri.actf);
@@ -2105,8 +2171,9 @@ static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, 
   } else {
     HIPCHK(hipMemcpyAsync(ctx->d_ascii, new_ref, (size_t)L, hipMemcpyHostToDevice, ctx->stream));
   }
-  hipLaunchKernelGGL(k_ref_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_ascii, L, wl, ctx->d_ref, total);
-  HIPCHK(hipGetLastError());
+  // (the codes are made by align_all's first launch: k_ref_prep with everything else that is derived from the reference, or k_ref_encode)
+  ctx->pend_encode = true; ctx->pend_L = L; ctx->pend_wl = wl; ctx->pend_total = total;
+  if (ctx->rs.n == 0) { encode_now(ctx); HIPCHK(hipGetLastError()); }
   const bool dbg_steps = getenv("MIA_HIP_ITER_DEBUG") != nullptr;      // diagnostic: wait and report after every stage
   auto checkpoint = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[mia_hip_iterate] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
   checkpoint("reference");
@@ -2118,9 +2185,15 @@ static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, 
   // -- re-alignment (one wait, at its end; a sharded run's pre-cull all-gather rides in front of that wait)
   ctx->in_iterate = true;
   ctx->deferred = true;
+  // no host wait behind the alignment when nothing on the host depends on it: one context, and a cut line that is given,
+  // hard, or NaN by construction (reads of one length) -- see align_all / abort_if
+  ctx->spec_pending = false; ctx->abort_if = nullptr;
+  ctx->spec_ok = !ctx->comm && n > 0 && !ctx->no_spec && (hard_cut > 0 || slope_intercept || ctx->min_len == ctx->max_len);
   const int rca = align_all(ctx);
   ctx->deferred = false;
-  if (rca) return rca;
+  ctx->spec_ok = false;
+  ctx->pend_encode = false;                 // (never outlives the call)
+  if (rca) { ctx->spec_pending = false; ctx->abort_if = nullptr; return rca; }
   checkpoint("realign");
   int64_t slot_base = 0, g_sums[5] = {0, 0, 0, 0, 0};
   std::vector<int64_t> link_counts((size_t)W, 0), n_of((size_t)W, n);
@@ -2188,14 +2261,21 @@ static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, 
     mia_hip_score_cut(score.data(), lens.data(), nullptr, ntot, &slope, &intercept);
   }
   if (!(hard_cut > 0) && slope <= 0) slope = 100.0;         // src/mia.c:440-442
-  ctx->buckets_queued = 0;
-  if (int rcc = mia_hip_cull(ctx, hard_cut, slope, intercept, slot_base)) return rcc;
-  // the tally's counting sort reads nothing the cull writes: on stream2, beside the cull kernels (queued behind them on the
-  // host side -- the GPU is waiting for the first cull kernel at this point, not for these)
-  if (tally_is_binned(ctx) && !ctx->no_side_buckets) {
-    // (no event in front: the host has waited for every alignment kernel, and stream2's own work ended before that)
-    if (int rcb = bucket_launch(ctx, ctx->stream2)) return rcb;
-  }
+  auto queue_cull = [&]() -> int {
+    ctx->buckets_queued = 0;
+    const bool side = tally_is_binned(ctx) && !ctx->no_side_buckets;
+    // (nothing has been waited for: stream2 must stay behind the alignment -- but not behind the cull)
+    if (side && ctx->spec_pending) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    if (int rcc = mia_hip_cull(ctx, hard_cut, slope, intercept, slot_base)) return rcc;
+    // the tally's counting sort reads nothing the cull writes: on stream2, beside the cull kernels (queued behind them on the
+    // host side -- the GPU is waiting for the first cull kernel at this point, not for these)
+    if (side) {
+      if (ctx->spec_pending) HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+      if (int rcb = bucket_launch(ctx, ctx->stream2)) return rcb;
+    }
+    return MIA_HIP_OK;
+  };
+  if (int rcq = queue_cull()) return rcq;
   if (ctx->comm) {
     // links of formerly split reads (stale fs->back_asp, include/mia_hip.h) may point at slots of another rank: every rank
     // gets all links, applies those that hit its own slots, the record lengths the readers need come back by a max-reduce
@@ -2303,20 +2383,20 @@ static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, 
     const int64_t cap = ctx->ins_tally_cap;
     int32_t* d_res = reinterpret_cast<int32_t*>(ctx->d_cons);
     const unsigned gl = (unsigned)((L + 255) / 256);
-    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->tb.gaps, Lp, 1, L, ctx->d_ins_off, ctx->d_ins_total);   // ins_off[p] = gaps[1] + .. + gaps[p-1]
-    hipLaunchKernelGGL(k_call_columns_z, dim3(gl), dim3(256), 0, ctx->stream, (const int32_t*)ctx->tb.tally, Lp, L, cons_code, ctx->d_calls, ctx->d_ins_tally, cap * 9);
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->tb.gaps, Lp, 1, L, ctx->d_ins_off, ctx->d_ins_total, ctx->abort_if);   // ins_off[p] = gaps[1] + .. + gaps[p-1]
+    hipLaunchKernelGGL(k_call_columns_z, dim3(gl), dim3(256), 0, ctx->stream, (const int32_t*)ctx->tb.tally, Lp, L, cons_code, ctx->d_calls, ctx->d_ins_tally, cap * 9, ctx->abort_if);
     if (cap > 0)
       hipLaunchKernelGGL(k_ins_tally, dim3(256), dim3(256), 0, ctx->stream, ctx->tb.events, 0, ctx->d_pssm, ctx->d_ins_off, ctx->tb.gaps, L, ctx->d_ins_tally,
-                         (int32_t)cap, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events);
+                         (int32_t)cap, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events, ctx->abort_if);
     checkpoint("consensus kernels");
     hipLaunchKernelGGL(k_call_inserts_count, dim3(gl), dim3(256), 0, ctx->stream, (const int32_t*)ctx->tb.tally, Lp, L, (const int32_t*)ctx->tb.gaps,
                        (const int32_t*)ctx->d_ins_off, (const int32_t*)ctx->d_ins_tally, cons_code, (const char*)ctx->d_calls, ctx->d_ins_calls, (int32_t)cap,
-                       (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos);
-    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->d_cons_pos, L, 0, L, ctx->d_cons_pos, d_res + CH_LEN);
+                       (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos, ctx->abort_if);
+    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->d_cons_pos, L, 0, L, ctx->d_cons_pos, d_res + CH_LEN, ctx->abort_if);
     hipLaunchKernelGGL(k_cons_scatter, dim3(gl), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
                        (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)cap, (const int32_t*)ctx->d_ins_total,
                        (const int32_t*)ctx->d_cons_pos, d_res, (int32_t)cons_cap, (const int32_t*)ctx->tb.n_events, (const uint32_t*)ctx->tb.flags,
-                       (const uint32_t*)ctx->d_cull_flags);
+                       (const uint32_t*)ctx->d_cull_flags, ctx->abort_if);
     HIPCHK(hipGetLastError());
     checkpoint("assemble");
     HIPCHK(hipMemcpyAsync(ctx->h_pin2, ctx->d_cons, need, hipMemcpyDeviceToHost, ctx->stream));
@@ -2325,6 +2405,24 @@ static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, 
     return MIA_HIP_OK;
   };
   if (int rct = consensus_tail()) return rct;
+  if (ctx->spec_pending) {
+    // the alignment's counters arrived with the consensus.  Reads waiting for the exact kernel (next to never): every kernel
+    // queued behind the alignment has returned without touching anything; the exact kernel runs, and cull, tally and consensus
+    // are queued again -- this time unconditionally
+    ctx->spec_pending = false;
+    ctx->abort_if = nullptr;
+    const int32_t* hb = reinterpret_cast<const int32_t*>(ctx->h_pin);
+    align_counters_collect(ctx, hb, ctx->spec_filtered, ctx->spec_bx, ctx->spec_plain);
+    const int32_t n_wide = hb[0];
+    if (n_wide > 0 || ctx->spec_force) {
+      ctx->spec_redone++;
+      RefInfo rinfo{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
+      if (n_wide > 0) { if (int rcw = run_wide(ctx, rinfo, n_wide)) return rcw; }
+      if (int rcq = queue_cull()) return rcq;
+      if (int rct = tally_launch(ctx)) return rct;
+      if (int rct = consensus_tail()) return rct;
+    }
+  }
   uint32_t tflags = (uint32_t)h_hdr[CH_TALLY_FLAGS];
   if (ctx->comm && !counted && (tflags & 8u)) {
     // some rank had more insert events than the blocks held (every rank sees the same counts, so every rank is here):

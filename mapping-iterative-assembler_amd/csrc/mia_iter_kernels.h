@@ -22,6 +22,42 @@ __global__ __launch_bounds__(256) void k_ref_encode(const char* ascii, int32_t L
   codes[p] = p < L ? dev_base_code(ascii[p]) : (p < L + wl ? dev_base_code(ascii[p - L]) : (uint8_t)4);
 }
 
+// ---- everything mia_hip_iterate derives from a new reference, in ONE launch ---------------------------------------------
+// k_ref_encode, the control block's memset, k_ref_planes, k_ref_nibbles, the 10-mer table's memset and k_kmer_hash were six
+// launches of 3-7 us each with the host's launch latency between them (the queue is empty at that point: 45-55 us before
+// the plan could start).  Here: phase 0 writes the codes, fills the table's slots with "empty" and clears the control block;
+// a barrier over the grid (at most one workgroup per compute unit, so all of it is resident; the counter only ever grows:
+// every launch is told the value it reaches); phase 1 makes planes, nibbles and table from the codes.
+struct RefPrep {
+  const char* ascii; int32_t L, wl, total;          // total = wrap + 64 codes
+  uint8_t* codes;
+  int32_t* ctrl; int32_t ctrl_words;
+  uint32_t* kslot; int32_t* kovf; uint32_t kslots, kmask; int32_t kshift, kwild;
+  int64_t plane_words; uint64_t *plo, *phi, *pok;
+  int64_t nib_words; uint32_t* nib;
+  uint32_t* bar; uint32_t bar_target;
+};
+__global__ __launch_bounds__(256) void k_ref_prep(RefPrep a) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  for (int64_t p = tid; p < a.total; p += nth)
+    a.codes[p] = p < a.L ? dev_base_code(a.ascii[p]) : (p < a.L + a.wl ? dev_base_code(a.ascii[p - a.L]) : (uint8_t)4);
+  uint4* ks = reinterpret_cast<uint4*>(a.kslot);
+  for (int64_t k = tid; k < (int64_t)a.kslots; k += nth) ks[k] = make_uint4(KH_EMPTY, KH_EMPTY, KH_EMPTY, KH_EMPTY);
+  for (int64_t k = tid; k < a.ctrl_words; k += nth) a.ctrl[k] = 0;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(a.bar, 1u);
+    while ((int32_t)(__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.bar_target) < 0) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  __threadfence();
+  const int64_t wrap = (int64_t)a.total - 64;
+  ref_planes_body(a.codes, (int64_t)a.total, a.plane_words, a.plo, a.phi, a.pok);
+  for (int64_t w = tid; w < a.nib_words; w += nth) a.nib[w] = ref_nibble_word(a.codes, wrap, w);
+  for (int64_t p = tid; p < wrap; p += nth) kmer_hash_insert(a.codes, wrap, p, a.kslot, a.kovf, a.kmask, a.kshift, a.kwild);
+}
+
 enum { CH_LEN = 0, CH_INS_TOTAL, CH_OVERFLOW, CH_N_EVENTS, CH_TALLY_FLAGS, CH_CULL_FLAGS, CH_WORDS = 8 };
 
 // Exclusive prefix sum of in[0..n) by ONE 1024-thread workgroup (in place is fine): each of the 16 wavefronts owns a
@@ -54,7 +90,8 @@ __device__ __forceinline__ void excl_scan_wg(const int32_t* in, int32_t n, int32
   if (off) for (int p = lo + lane; p < hi; p += 64) out[p] += off;
   if (t == 1023) *total = off + wsum[15];
 }
-__global__ __launch_bounds__(1024) void k_excl_scan(const int32_t* in, int32_t n, int32_t lo_valid, int32_t hi_valid, int32_t* out, int32_t* total) {
+__global__ __launch_bounds__(1024) void k_excl_scan(const int32_t* in, int32_t n, int32_t lo_valid, int32_t hi_valid, int32_t* out, int32_t* total, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   __shared__ int32_t wsum[16];
   excl_scan_wg(in, n, lo_valid, hi_valid, out, total, wsum);
 }
@@ -76,7 +113,8 @@ __global__ __launch_bounds__(256) void k_cons_count(const char* calls, const cha
 // res = [CH_WORDS header words][string]; pos = exclusive scan of k_cons_count's output, res[CH_LEN] = its total
 __global__ __launch_bounds__(256) void k_cons_scatter(const char* calls, const char* ins_calls, const int32_t* gaps, const int32_t* ins_off, int32_t L,
                                                         int32_t ins_cap, const int32_t* ins_total, const int32_t* pos, int32_t* res, int32_t out_cap,
-                                                        const int32_t* n_events, const uint32_t* tally_flags, const uint32_t* cull_flags) {
+                                                        const int32_t* n_events, const uint32_t* tally_flags, const uint32_t* cull_flags, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int p = blockIdx.x * 256 + threadIdx.x;
   const int total = *ins_total, len = res[CH_LEN];
   const bool ins_ok = total <= ins_cap, fits = len + 1 <= out_cap;
@@ -101,7 +139,8 @@ __global__ __launch_bounds__(256) void k_cons_scatter(const char* calls, const c
 // k_call_inserts_count: the insert columns' calls (k_call_inserts) and the characters each column contributes (k_cons_count)
 // -- a column's count needs only its own insert calls.  (Putting the whole tail into two single-workgroup kernels was
 // tried: a workgroup alone on 16.6 k columns takes 44 + 111 us, the five launches it saves cost 25.)
-__global__ __launch_bounds__(256) void k_call_columns_z(const int32_t* tally, int32_t Lp, int32_t L, int cons_code, char* calls, int32_t* zero, int64_t zero_words) {
+__global__ __launch_bounds__(256) void k_call_columns_z(const int32_t* tally, int32_t Lp, int32_t L, int cons_code, char* calls, int32_t* zero, int64_t zero_words, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int p = blockIdx.x * 256 + threadIdx.x;
   for (int64_t k = p; k < zero_words; k += (int64_t)gridDim.x * 256) zero[k] = 0;
   if (p >= L) return;
@@ -111,7 +150,8 @@ __global__ __launch_bounds__(256) void k_call_columns_z(const int32_t* tally, in
 
 __global__ __launch_bounds__(256) void k_call_inserts_count(const int32_t* tally, int32_t Lp, int32_t L, const int32_t* gaps, const int32_t* ins_off,
                                                               const int32_t* ins_tally, int cons_code, const char* calls, char* ins_calls, int32_t ins_cap,
-                                                              const int32_t* ins_total, int32_t* cnt) {
+                                                              const int32_t* ins_total, int32_t* cnt, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= L) return;
   int32_t v = cons_emits(calls[p]) ? 1 : 0;

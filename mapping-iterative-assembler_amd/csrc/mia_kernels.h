@@ -105,7 +105,7 @@ constexpr int PLAN_PER = 8;   // reads per thread of the planner kernels: a bloc
 // that the planner leaves it out; all others are marked 0.  Flat matrix only (the host checks).
 // one plane word per wavefront and step, one code per lane, three ballots (a thread that builds a word alone walks 64
 // bytes); any grid: the wavefronts stride over the words
-__global__ __launch_bounds__(256) void k_ref_planes(const uint8_t* codes, int64_t n_codes, int64_t words, uint64_t* lo, uint64_t* hi, uint64_t* ok) {
+__device__ __forceinline__ void ref_planes_body(const uint8_t* codes, int64_t n_codes, int64_t words, uint64_t* lo, uint64_t* hi, uint64_t* ok) {
   const int lane = threadIdx.x & 63;
   for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < words; w += (int64_t)gridDim.x * 4) {
     const int64_t p = w * 64 + lane - PLANE_LEAD;
@@ -114,6 +114,9 @@ __global__ __launch_bounds__(256) void k_ref_planes(const uint8_t* codes, int64_
     const uint64_t l = __ballot(base && (c & 1u)), h = __ballot(base && (c >> 1)), v = __ballot(base);
     if (lane == 0) { lo[w] = l; hi[w] = h; ok[w] = v; }
   }
+}
+__global__ __launch_bounds__(256) void k_ref_planes(const uint8_t* codes, int64_t n_codes, int64_t words, uint64_t* lo, uint64_t* hi, uint64_t* ok) {
+  ref_planes_body(codes, n_codes, words, lo, hi, ok);
 }
 
 // the 10-mer table of the reference for rule (c) (diag_filter.h: KmerOcc); cnt is zeroed before.  wild > 0: a 10-mer with

@@ -37,11 +37,14 @@ def hipmod():
     return mia_amd
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["stepwise", "iterate"])
+@pytest.mark.parametrize("fused", [False, True, "redo"], ids=["stepwise", "iterate", "iterate-second-round"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_iterations_match_oracle(name, fused, oracle, hipmod, tmp_path):
     """fused: the whole iteration through mia_hip_iterate (planner, cut line and event count stay on the device) instead of
-    mia_hip_realign + _cull + _tally + _consensus; everything below is checked the same way after either."""
+    mia_hip_realign + _cull + _tally + _consensus; everything below is checked the same way after either.
+    "redo": mia_hip_iterate queues cull, tally and consensus without waiting for the alignment's counters; their kernels
+    return at once if reads are waiting for the exact one-read-per-thread kernel, and the chain is queued a second time.
+    MIA_HIP_SPEC_TEST=1 makes every iteration take that second round (where the cut line leaves the host nothing to wait for)."""
     ref_fa, reads_fa, circ, pfile, hard, cc, sn = CASES[name][:7]
     adapter = CASES[name][7] if len(CASES[name]) > 7 else None
     if ":-" in reads_fa:            # drop one record from a committed FASTA
@@ -57,7 +60,13 @@ def test_iterations_match_oracle(name, fused, oracle, hipmod, tmp_path):
     assert fs["n"] > 0
     if name == "fixture_lin":
         assert not fs["sk"].all()
-    hip = hipmod.MiaHip(0)
+    if fused == "redo":
+        os.environ["MIA_HIP_SPEC_TEST"] = "1"
+    try:
+        hip = hipmod.MiaHip(0)
+    finally:
+        os.environ.pop("MIA_HIP_SPEC_TEST", None)
+    fused = bool(fused)
     hip.set_pssm(pssm_array(anc))
     hip.upload_reads(fs["bases"], fs["offsets"], fs["rc"], fs["sk"], fs["as_"], fs["ae"])
     n_slots1 = oracle.ora_num_culled(st)
