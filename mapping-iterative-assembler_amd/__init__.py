@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmia_hip.so")
+LIB_PATH = os.environ.get("MIA_HIP_LIB") or os.path.join(_HERE, "libmia_hip.so")    # (MIA_HIP_LIB: another build of the same library, for A/B timing)
 
 PSSM_WORDS = 31 * 5 * 5
 TALLY_WORDS = 12

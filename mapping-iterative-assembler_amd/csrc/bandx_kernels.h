@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     emit(rr, bp, !in_list && t0 + threadIdx.x < total && !waits);
   }
   __syncthreads();
-  if (n_cand == 0) return;
+  if (n_cand == 0 || (bx.dbg & 32u)) return;      // (MIA_HIP_BX_DEBUG=32, profiling only: no second phase)
   {                                                 // (every thread: emit has barriers)
     DiagScan<NW> sc;
     Rd r{0, 0, 0, 0, 0, false};
