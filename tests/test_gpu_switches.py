@@ -1,0 +1,58 @@
+"""Every alternative route through the product path that an environment switch still reaches must give the same iteration:
+round 1's flat-matrix pipeline (diagonal filter + k_band_align, MIA_HIP_NO_BANDX=1), the one-lane band kernels
+(MIA_HIP_NO_LANES=1), round 2's stream order (MIA_HIP_BX_SERIAL=1), and this round's host-side orders switched off one by one
+(MIA_HIP_NO_SPEC: wait for the alignment's counters before the cull is queued; MIA_HIP_SPEC_TEST: always take the second
+round; MIA_HIP_NO_PREP_FUSE: six launches instead of k_ref_prep; MIA_HIP_NO_SIDE_BUCKETS: counting sort behind the cull).
+Two calls of mia_hip_iterate on 200 000 reads (first against mt311, then against the consensus): scores, end points,
+scripts, all tally words, ref->gaps and the consensus string of both iterations must be identical to the default build's
+(reference loop body: /root/reference/src/mia_main.c:915-964)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HIP_NO_SPEC", "MIA_HIP_SPEC_TEST", "MIA_HIP_NO_PREP_FUSE",
+            "MIA_HIP_NO_SIDE_BUCKETS"]
+
+
+def two_iterations(mod, w, env):
+    if env:
+        os.environ[env] = "1"
+    try:
+        hip = mod.MiaHip(0)
+    finally:
+        if env:
+            os.environ.pop(env, None)
+    hip.set_pssm(w["pssm"])
+    n = w["n"]
+    hip.upload_reads(w["stored"].reshape(-1), w["offsets"], w["rc"], np.ones(n, np.uint8), w["as_"], w["ae"])
+    out = []
+    ref = w["ref"]
+    for _ in range(2):
+        cons = hip.iterate(ref, w["circular"])
+        sc, a, e = hip.alignments()
+        cols, rstart = hip.scripts()
+        t, g = hip.get_tally()
+        out.append((cons, sc.copy(), a.copy(), e.copy(), np.where(cols >= 0, cols.astype(np.int32) + rstart[:, None], cols.astype(np.int32)), t.copy(), g.copy()))
+        ref = cons
+    hip.close()
+    return out
+
+
+@pytest.mark.parametrize("config", [1, 2], ids=["flat", "ancient"])
+def test_every_switch_gives_the_same_iterations(config):
+    import bench
+    import mia_amd
+    w = bench.make_workload(config, 200_000, 3)
+    base = two_iterations(mia_amd, w, None)
+    assert len(base[0][0]) > 16000 and base[0][0] != w["ref"]
+    for env in SWITCHES:
+        got = two_iterations(mia_amd, w, env)
+        for it in range(2):
+            for k, name in enumerate(("consensus", "score", "as", "ae", "script", "tally", "gaps")):
+                x, y = base[it][k], got[it][k]
+                assert (x == y) if isinstance(x, str) else np.array_equal(x, y), (env, it, name)
