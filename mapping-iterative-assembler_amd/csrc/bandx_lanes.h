@@ -166,8 +166,11 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
 }
 
 // ---- with a trace ----------------------------------------------------------------------------------------------------------
-// trace: this WAVEFRONT's slab, row r at trace + r * 128 words, lane l's two words at + 2 l.  lane_in_wave: this lane;
-// the read's first lane walks the traceback and writes cols_out / res.  Returns (on the first lane) whether the read is
+// trace: this WAVEFRONT's slab.  A trace word holds the codes of ONE cell (band index) in FOUR consecutive rows: rows 4q ..
+// 4q + 3 of lane l's cell jj sit in word (q * 64 + l) * 8 + jj, so a lane's stores are 32 contiguous bytes every four rows
+// (the wavefront's: 2 KB) and the traceback -- which follows one band index down the rows -- finds sixteen rows in four
+// words instead of sixteen (round 2's layout had a row's eight cells side by side: sixteen cache lines per fetch and lane,
+// a third of the kernel's time).  lane_in_wave: this lane; the read's first lane walks the traceback and writes cols_out / res.  Returns (on the first lane) whether the read is
 // finished here; false: the reference's index-0 quirk, or nothing alive in the last row.
 template <int LPR, bool EDGE>
 __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len1, const uint32_t* rwords, int len2, int d0, const int32_t* sub256, int u,
@@ -175,12 +178,13 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
   constexpr int DEAD = BX_NEG * 256;
   constexpr int STEP = 1 - GEP * 256;                 // a running maximum ages by one position: value - GEP, length + 1
   constexpr int CAND = -GOP * 256 + STEP - 0xFF;      // a cell (packed as a diagonal source) becomes a gap source
-  constexpr int ROW_WORDS = 128;
+  constexpr int BLK_WORDS = 64 * BXL_CELLS;           // words of four rows of the wavefront
   const int R = len2 - 1;
   const int dl = d0 + BXL_CELLS * u;
   int32_t P[BXL_CELLS], H[BXL_CELLS];
+  uint32_t tb[BXL_CELLS];                             // the four rows' codes of each of this lane's cells
   uint32_t rw = rwords[0], rw_next = rwords[1];
-  uint32_t* mine = trace + 2 * lane_in_wave;
+  uint32_t* mine = trace + BXL_CELLS * lane_in_wave;
   BxlSlide slide;
   slide.init(refnib, (int64_t)s + dl + BX_NIB_LEAD);
   {
@@ -192,8 +196,12 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
       H[j] = DEAD;
       const int v = row[(cw >> (4 * j)) & 7u];
       P[j] = ((live >> j) & 1u) ? (v | 0xFF) : DEAD;
+      tb[j] = 0xFFFFFFFFu;                            // row 0 reads as a diagonal step (the walk stops there anyway)
     }
-    mine[0] = 0xFFFFFFFFu; mine[1] = 0xFFFFFFFFu;
+    if (R == 0) {
+#pragma unroll
+      for (int j = 0; j < BXL_CELLS; j += 4) *reinterpret_cast<uint4*>(mine + j) = make_uint4(tb[j], tb[j + 1], tb[j + 2], tb[j + 3]);
+    }
   }
   for (int r = 1; r < len2; r++) {
     const int c0 = r + dl;
@@ -229,7 +237,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
 #pragma unroll
       for (int j = 0; j < BXL_CELLS; j++) cand[j] = (P[j] | 0xFF) + CAND;
     }
-    uint32_t tw0 = 0, tw1 = 0;
+    const int rk = r & 3;
     int nh0 = DEAD;
 #pragma unroll
     for (int j = 0; j < BXL_CELLS; j++) {
@@ -241,7 +249,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
         if ((col0 >> j) & 1u) cur = (sb + f0) | 0xFF;
         if (!((live >> j) & 1u)) cur = DEAD;
       }
-      if (j < 4) tw0 = bx_put(tw0, (uint32_t)cur, j & 3); else tw1 = bx_put(tw1, (uint32_t)cur, j & 3);
+      tb[j] = bx_put(tb[j], (uint32_t)cur, rk);
       G = G + STEP > cand[j] ? G + STEP : cand[j];
       const int nh = h + STEP > cand[j] ? h + STEP : cand[j];
       if (j >= 1) H[j - 1] = nh; else nh0 = nh;
@@ -251,8 +259,11 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
       const int hr = bxl_from_right1(nh0, DEAD);
       H[BXL_CELLS - 1] = u < LPR - 1 ? hr : DEAD;
     } else H[BXL_CELLS - 1] = DEAD;
-    uint32_t* tr = mine + (int64_t)r * ROW_WORDS;
-    tr[0] = tw0; tr[1] = tw1;
+    if (rk == 3 || r == R) {                            // (the bytes of rows beyond the read's last are never looked at)
+      uint32_t* tr = mine + (uint32_t)(r >> 2) * BLK_WORDS;
+#pragma unroll
+      for (int j = 0; j < BXL_CELLS; j += 4) *reinterpret_cast<uint4*>(tr + j) = make_uint4(tb[j], tb[j + 1], tb[j + 2], tb[j + 3]);
+    }
   }
   // max_sg_score: first maximum of the last row (src/mia.c:1278-1302)
   int best = BX_NEG, bj = -1;
@@ -288,37 +299,39 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
   // lane -- 64 different cache lines per instruction -- was a third of this kernel's time.)
   constexpr int W = BXL_CELLS * LPR;
   constexpr int EV = 4;                                  // breaks kept in registers; a path with more is walked again, storing as it goes
-  const uint32_t* base = trace + 2 * lane_in_wave;       // band index j: word (j >> 2) counted from the first lane's pair
   int ev_row[EV], ev_delta[EV];                          // rows above ev_row sit ev_delta columns further right than the diagonal below says
 #pragma unroll
   for (int k = 0; k < EV; k++) { ev_row[k] = -1; ev_delta[k] = 0; }
   int r = R, c = R + d0 + bj, gaps = 0;
   uint32_t gap_desc = 0;
   const int aec = c;
-  // Nearly every step is diagonal and stays on its band index j: sixteen rows of that index are fetched at once, turned
-  // into a bit mask of "not a diagonal step" and the whole run is taken in one go (round 2 walked the sixteen bytes one
-  // by one under sixteen levels of predication: 1 100 vector instructions per fetch, a third of the kernel).  Only where a
+  // Nearly every step is diagonal and stays on its band index j: the four words that hold sixteen rows of that index are
+  // fetched at once, turned into a bit mask of "not a diagonal step" and the whole run is taken in one go.  Only where a
   // run breaks is the byte itself looked at.
   for (;;) {
     if (r == 0 || c == 0) break;
     const int j = c - r - d0;
     if (j < 0 || j >= W) return false;
-    constexpr int TB = 16;
-    const uint32_t col = 2u * (uint32_t)lane_in_wave + (uint32_t)(j >> 2);      // (word offset in the slab: the slab pointer is uniform)
-    const int sh = 8 * (j & 3);
-    uint32_t nd = 0;                         // bit k: row r - k holds something else than a diagonal step
+    const uint32_t col = (uint32_t)(BXL_CELLS * lane_in_wave + j);      // (band index j: cell j & 7 of the lane j >> 3 places to the right)
+    const int q0 = r >> 2;
+    uint32_t nd = 0;                         // bit i: row 4 (q0 - 3) + i holds something else than a diagonal step
 #pragma unroll
-    for (int k = 0; k < TB; k++) {
-      const uint32_t wv = trace[(uint32_t)(r - k > 0 ? r - k : 0) * ROW_WORDS + col];       // (row 0 reads as diagonal; the walk never gets there: kmax)
-      nd |= (((wv >> sh) & 255u) != 255u ? 1u : 0u) << k;
+    for (int t = 0; t < 4; t++) {
+      const int q = q0 - t;
+      const uint32_t wv = trace[(uint32_t)(q > 0 ? q : 0) * BLK_WORDS + col];
+      const uint32_t x = ~wv, y = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;      // bit 8 k + 7: byte k is not 0xFF
+      const uint32_t z = y >> 7, nib = (z | (z >> 7) | (z >> 14) | (z >> 21)) & 15u;
+      if (q >= 0) nd |= nib << (4 * (3 - t));  // (blocks above the matrix: all diagonal; the walk never gets there: kmax)
     }
-    const int run = nd ? __builtin_ctz(nd) : TB;
+    const int rel = r - 4 * (q0 - 3);        // 12 .. 15: this row's bit
+    const uint32_t low = nd & ((2u << rel) - 1u);
+    const int run = low ? rel - (31 - __builtin_clz(low)) : rel + 1;
     const int kmax = r < c ? r : c;
     const int k = run < kmax ? run : kmax;
     r -= k; c -= k;
     if (k == kmax) break;                    // row 0 or column 0
-    if (run == TB) continue;
-    const int code = (int)((trace[(uint32_t)r * ROW_WORDS + col] >> sh) & 255u);
+    if (!low) continue;
+    const int code = (int)((trace[(uint32_t)(r >> 2) * BLK_WORDS + col] >> (8 * (r & 3))) & 255u);
     if (code == 0x80) break;
     int delta;
     if (code & 0x40) {
@@ -390,7 +403,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
     const int j = c - r - d0;
     cols_out[r] = (int16_t)c;
     if (r == 0 || c == 0) break;
-    const int code = (int)((base[(int64_t)r * ROW_WORDS + (j >> 2)] >> (8 * (j & 3))) & 255u);
+    const int code = (int)((trace[(uint32_t)(r >> 2) * BLK_WORDS + (uint32_t)(BXL_CELLS * lane_in_wave + j)] >> (8 * (r & 3))) & 255u);
     if (code == 0x80) break;
     if (code == 0xFF) { r--; c--; continue; }
     if (code & 0x40) { r--; c = c - 1 - (code & 63); }

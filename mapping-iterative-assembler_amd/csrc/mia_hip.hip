@@ -955,7 +955,8 @@ static int align_all(mia_hip_ctx* ctx) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ctx->use_lanes ? (const void*)k_bxl_trace : (const void*)k_bx_trace, 256, 0) != hipSuccess || occ < 1) occ = 1;
         ctx->bx_trace_wgs = ctx->cus * std::min(occ, 4);      // (every wavefront of the trace grid owns a slab)
       }
-      const int64_t slab_words = (int64_t)ctx->max_len * (ctx->use_lanes ? BXL_SLAB_ROW_WORDS : BX_SLAB_ROW_WORDS);
+      // (the lanes kernels store four rows per word: whole blocks of four rows)
+      const int64_t slab_words = ctx->use_lanes ? (int64_t)((ctx->max_len + 3) & ~3) * BXL_SLAB_ROW_WORDS : (int64_t)ctx->max_len * BX_SLAB_ROW_WORDS;
       if (slab_words * ctx->bx_trace_wgs * 4 > ctx->bx_slab_cap) {
         if (dev_alloc(ctx, &ctx->d_bx_slabs, (size_t)(slab_words * ctx->bx_trace_wgs * 4))) return MIA_HIP_ERR_NOMEM;
         ctx->bx_slab_cap = slab_words * ctx->bx_trace_wgs * 4;
@@ -970,7 +971,7 @@ static int align_all(mia_hip_ctx* ctx) {
       if (new_flow) {
         if (n > ctx->retry2_cap) { if (dev_alloc(ctx, &ctx->d_retry2, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->retry2_cap = n; }
         if (!ctx->bx_late_wgs) ctx->bx_late_wgs = ctx->cus;        // the values DP's left-overs are few: one workgroup per CU
-        const int64_t late_words = (int64_t)ctx->max_len * BXL_SLAB_ROW_WORDS * ctx->bx_late_wgs * 4;
+        const int64_t late_words = (int64_t)((ctx->max_len + 3) & ~3) * BXL_SLAB_ROW_WORDS * ctx->bx_late_wgs * 4;
         if (late_words > ctx->bx_slab_late_cap) { if (dev_alloc(ctx, &ctx->d_bx_slabs_late, (size_t)late_words)) return MIA_HIP_ERR_NOMEM; ctx->bx_slab_late_cap = late_words; }
       }
       bd.retry = ctx->d_retry2; bd.retry_n = ctx->d_plan_hdr + PH_RETRY2 + 1;
