@@ -929,7 +929,20 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
       const int fBase = c4.x, fOff = c4.y, fB = c4.z, fMult = c4.w;
       fast = (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && (flags & TRF_DIAG) && !g.split && fMult == 1 && fBase == 0 && fOff == 0 && w0 >= 0 &&
              w0 + n_al <= TALLY_WIN && g.start_w + n_al <= Lp && n_al <= g.ncols_f && n_al > 0;
-      if (fast && !(dbg & 8u)) {
+      // !LINEAR: the BASES of a one-gap read go through this loop as well, beside the gap-free reads' (the same per-base
+      // adds at columns shifted by the gap) -- a loop of their own further down was a second pass of a hundred LDS-atomic
+      // round trips for a tenth of the lanes, 0.1 of configs[2]'s 0.40 ms.  The gap itself stays with the one-gap block.
+      bool one_here = false;
+      int og_row = 1 << 20, og_n = 0, og_ins = 0;
+      if (!LINEAR && !fast && (flags & TRF_ONEGAP)) {
+        const uint32_t desc = (uint32_t)b4.w;
+        const int ins = (int)(desc & 1u), grow = (int)((desc >> 1) & 511u), gn = (int)((desc >> 10) & 63u);
+        const int ncol = ins ? n_al - gn : n_al + gn;
+        one_here = (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && !(flags & TRF_DIAG) && !g.split && fMult == 1 && fBase == 0 && fOff == 0 && w0 >= 0 &&
+                   ncol > 0 && w0 + ncol <= TALLY_WIN && g.start_w + ncol <= Lp && ncol == g.ncols_f && gn > 0 && grow > abr && grow + (ins ? gn : 0) < len2;
+        if (one_here) { og_row = grow; og_n = gn; og_ins = ins; }
+      }
+      if ((fast || one_here) && !(dbg & 8u)) {
         const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);    // reads start on 4-byte boundaries
         const bool dF = (flags & TRF_DF) != 0;
         lds_i32* t = (lds_i32*)lds + w0;
@@ -952,21 +965,38 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
               t++; nc++;
             }
           }
-        } else
+        } else {
+        // (the read's words three ahead of their use: a load per eight rows that is waited for on the spot was a
+        // microsecond of every eight iterations; packed reads are padded, so the words beyond the last may be fetched)
+        const int wlast = (len2 - 1) >> 3;
+        int wi = abr >> 3;
+        uint32_t wq1 = rp[wi + 1 <= wlast ? wi + 1 : wlast], wq2 = rp[wi + 2 <= wlast ? wi + 2 : wlast], wq3 = rp[wi + 3 <= wlast ? wi + 3 : wlast];
+        word = rp[wi];
         for (int act = 0; act < n_al; act++) {
           const int r = abr + act;
-          if (act == 0 || (r & 7) == 0) word = rp[r >> 3];
+          if (act != 0 && (r & 7) == 0) { wi++; word = wq1; wq1 = wq2; wq2 = wq3; wq3 = rp[wi + 3 <= wlast ? wi + 3 : wlast]; }
           const int code = (int)((word >> ((r & 7) * 4)) & 15u);
           const int d = depth_code(act, fB - act - 1);
+          if (one_here) {
+            // (a one-gap read: its depth codes are checked by its own block below; an inserted row is an event there, the rows
+            // behind the gap sit og_n columns further left (insert) or right (deleted reference columns))
+            if (og_ins && r >= og_row && r < og_row + og_n) continue;
+            const int dd = d < 0 ? 0 : (d > 2 * PSSM_DEPTH ? 2 * PSSM_DEPTH : d);
+            if (!dF) add_base(w0 + act + (r >= og_row ? (og_ins ? -og_n : og_n) : 0), code, dd, (flags & TRF_RC) != 0);
+            continue;
+          }
           bad |= (d < 0) | (d > 2 * PSSM_DEPTH);
           const int dd = d < 0 ? 0 : (d > 2 * PSSM_DEPTH ? 2 * PSSM_DEPTH : d);
           if (!dF && !(dbg & 16u)) add_base(w0 + act, code, dd, (flags & TRF_RC) != 0);
           t++;
         }
+        }
+        if (fast) {
         // coverage (not dropped): columns w0 .. w0+n_al-1; span (start < pos <= end, dropped or not): w0+1 .. w0+n_al-1
         if (!dF) { aadd((lds_i32*)cov_diff + w0, 1); if (w0 + n_al < TALLY_WIN) aadd((lds_i32*)cov_diff + w0 + n_al, -1); }
         if (n_al > 1) { aadd((lds_i32*)span_diff + w0 + 1, 1); if (w0 + n_al < TALLY_WIN) aadd((lds_i32*)span_diff + w0 + n_al, -1); }
         if (bad | (int)(word & (dbg & 16u ? 0x40000000u : 0u))) atomicOr(tb.flags, 2u);
+        }
       }
     }
     // Proven-diagonal reads that run over the origin (two records: front in this window, back at the start of the
@@ -1090,6 +1120,27 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
                 if (e < tb.cap_events) tb.events[e] = ev; else atomicOr(tb.flags, 1u);
               }
             }
+        } else if (!LINEAR) {
+          // the bases went through the gap-free reads' loop above; here only the gap: deleted reference columns count as '-',
+          // inserted read rows become insert events at the column that follows
+          const int o = grow - abr;
+          if (!ins) { if (!dF) for (int q = 0; q < gn; q++) aadd(&t[T_GAP * TALLY_WIN + o + q], 1); }
+          else
+            for (int j = 0; j < gn; j++) {
+              const int r = grow + j;
+              const int code = (int)((rp[r >> 3] >> ((r & 7) * 4)) & 15u);
+              const int gc = g.start_w + o, act = grow + gn - abr;
+              if (j == 0) atomicMax(&tb.gaps[gc], gn);
+              const int d = depth_code(act, fB - act - 1);
+              const uint64_t ev = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
+                                  ((uint64_t)((flags & TRF_RC) ? 1 : 0) << 50);
+              const int slot = atomicAdd(&ev_cnt, 1);
+              if (slot < TALLY_EV_CAP) ev_buf[slot] = ev;
+              else {
+                const int e = atomicAdd(tb.n_events, 1);
+                if (e < tb.cap_events) tb.events[e] = ev; else atomicOr(tb.flags, 1u);
+              }
+            }
         } else
         for (int r = abr; r < len2; r++) {
           if (r == abr || (r & 7) == 0) word = rp[r >> 3];
@@ -1111,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
             }
             continue;
           }
-          if (!dF) {
+          if (!dF && LINEAR) {                                                   // (!LINEAR: the bases went through the gap-free reads' loop above)
             const int act = r - abr, d = depth_code(act, fB - act - 1);          // inserted rows count as read bases (src/fsdb.c:568-581)
             add_base((int)(t - ((lds_i32*)lds)), code, d < 0 ? 0 : (d > 2 * PSSM_DEPTH ? 2 * PSSM_DEPTH : d), (flags & TRF_RC) != 0);
           }

@@ -1,40 +1,40 @@
-"""Wall time of mia_hip_tally on the bench workload under debug switches (MIA_HIP_DEBUG_SKIP bit 32 = no one-read-per-
-wavefront path in k_tally_binned: wrong sums, only the timing means something) and without the banded DP."""
+"""Where k_tally_binned's time goes (profiling only): the steady step of configs[1] / [2] with parts of the kernel switched off
+through MIA_HIP_DEBUG_SKIP (8: no one-read-per-lane paths, 32: no one-read-per-wavefront path, 2048: one-gap reads dropped,
+4096: no bit-sliced counts, 16: position-specific matrix: no per-base adds).  The sums of such runs are wrong by construction;
+only the stage time is read.  usage: tally_prof.py [config]"""
 import os
 import sys
-import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bench  # noqa: E402
-import gen_data  # noqa: E402
 import mia_amd  # noqa: E402
 
-n = 1_000_000
-ref0, stored, soff, strand, as0, ae0 = bench.make_workload(n, 1)
-ref = gen_data.resolve_individual(ref0)
-for label, env in (("default", {}), ("no general path", {"MIA_HIP_DEBUG_SKIP": "32"}), ("no banded DP", {"MIA_HIP_NO_BAND_DP": "1"}), ("one-gap reads dropped", {"MIA_HIP_DEBUG_SKIP": "2048"}), ("neither", {"MIA_HIP_DEBUG_SKIP": "2080"})):
-    for k, v in env.items():
-        os.environ[k] = v
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+w = bench.make_workload(cfg, 1_000_000, 1 if cfg == 1 else 3)
+hip = mia_amd.MiaHip(0)
+pipe = bench.Pipeline(hip, w)
+cur = w["ref"]
+for _ in range(5):
+    cur = pipe.step(cur)
+hip.close()
+for label, skip in (("default", 0), ("no lane paths", 8), ("no wavefront path", 32), ("one-gap reads dropped", 2048), ("no bit slices", 4096),
+                    ("no per-base adds (PSSM)", 16), ("lanes and wavefront paths off", 40)):
+    if skip:
+        os.environ["MIA_HIP_DEBUG_SKIP"] = str(skip)
     hip = mia_amd.MiaHip(0)
-    for k in env:
-        os.environ.pop(k)
-    hip.set_pssm(mia_amd.flat_pssm())
-    hip.upload_reads(stored.reshape(-1), soff, strand, np.ones(n, np.uint8), as0, ae0)
-    hip.realign(ref, True)
-    sc, a, e = hip.alignments()
-    hip.cull(0, 100.0, 0.0, 0)
-    ts = []
-    for it in range(6):
+    os.environ.pop("MIA_HIP_DEBUG_SKIP", None)
+    pipe = bench.Pipeline(hip, w)
+    try:
+        pipe.step(cur)
+        pipe.reset_stats()
+        for _ in range(6):
+            pipe.step(cur)
         hip.sync()
-        t0 = time.perf_counter()
-        hip.tally()
-        hip.sync()
-        ts.append(time.perf_counter() - t0)
-    cols, rstart = hip.scripts()
-    ngap = ((cols[:, 1:] >= 0) & (cols[:, :-1] >= 0) & (cols[:, 1:] - cols[:, :-1] > 1)).sum(axis=1) + ((cols[:, 1:] == -1) & (cols[:, :-1] != -1)).sum(axis=1)
-    print(label, "tally ms", round(min(ts) * 1e3, 3), "reads with 0/1/2+ gaps", int((ngap == 0).sum()), int((ngap == 1).sum()), int((ngap > 1).sum()), flush=True)
+        st = hip.stage_stats()
+        print(label, {k: round(v[0] / max(v[1], 1), 4) for k, v in st.items() if v[1] and k == "k_tally_binned"}, flush=True)
+    except Exception as ex:
+        print(label, "failed:", repr(ex)[:120], flush=True)
     hip.close()
