@@ -381,7 +381,7 @@ class MiaHip:
         sc = None if score_cut is None else np.ascontiguousarray(score_cut, dtype=np.float64)
         self._chk(self._l.mia_hip_iterate(self._h, ref, len(ref), 1 if circular else 0, hard_cut, _ptr(sc), cons_code, self._cons_buf,
                                           self._cons_buf_cap, C.byref(n)))
-        return self._cons_buf.raw[: n.value].decode()
+        return C.string_at(self._cons_buf, n.value).decode()
 
     def myers_time(self):
         """kernel time (ms, HIP events) of the last myers() call"""

@@ -55,7 +55,8 @@ __global__ void k_scan_blocks(ReadSet rs, int32_t L, int64_t* partial) {
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
-__global__ __launch_bounds__(256) void k_scan_partials(int64_t* partial, int nb, int64_t base, int64_t* total) {
+__global__ __launch_bounds__(256) void k_scan_partials(int64_t* partial, int nb, int64_t base, int64_t* total, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;     // (see k_slot_count)
   // one workgroup of 256 threads: every thread a stretch of the partial sums, a scan over the 256 stretch sums in LDS
   __shared__ int64_t s_run[256];
   const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
@@ -304,15 +305,28 @@ __global__ __launch_bounds__(256) void k_slot_count(ReadSet rs, int32_t L, int64
   __shared__ int32_t wsum[16][4];
   // stretch k of this workgroup = reads base + 256 k .. + 255, one per thread (neighbouring threads, neighbouring reads)
   const int64_t base_read = (int64_t)blockIdx.x * 4096;
+  // (all sixteen stretches' loads first: one after the other, each waited for, they were 25 of this kernel's 40 us)
+  uint8_t sk16[16];
+  int32_t as16[16], ae16[16];
+#pragma unroll
   for (int k = 0; k < 16; k++) {
     const int64_t i = base_read + k * 256 + threadIdx.x;
-    const int cnt = (i < rs.n && rs.sk[i]) ? (rec_geom(rs.as[i], rs.ae[i], L).split ? 2 : 1) : 0;
+    const bool in = i < rs.n;
+    sk16[k] = in ? rs.sk[i] : (uint8_t)0;
+    as16[k] = in ? rs.as[i] : 0;
+    ae16[k] = in ? rs.ae[i] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int cnt = sk16[k] ? (rec_geom(as16[k], ae16[k], L).split ? 2 : 1) : 0;
     const int w = __popcll(__ballot(cnt >= 1)) + __popcll(__ballot(cnt == 2));
     if ((threadIdx.x & 63) == 0) wsum[k][threadIdx.x >> 6] = w;
   }
   __syncthreads();
   if (threadIdx.x < 16 && blockIdx.x * 16 + (int)threadIdx.x < nb)
     partial[blockIdx.x * 16 + threadIdx.x] = (int64_t)wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+  if (!blocks_done) return;                    // (the counts alone: k_scan_partials follows -- mia_hip_cull; the arrival below, with its
+                                               //  device-scope fence per workgroup, was 25 of this kernel's 40 us)
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(blocks_done, 1u) == (uint32_t)gridDim.x - 1u;

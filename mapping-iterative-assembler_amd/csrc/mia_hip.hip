@@ -60,6 +60,7 @@ struct mia_hip_ctx {
   bool no_spec = false;                     // MIA_HIP_NO_SPEC=1: wait for the alignment's counters before the cull is queued
   bool no_side_buckets = false;             // MIA_HIP_NO_SIDE_BUCKETS=1
   int buckets_queued = 0;                   // the tally's counting sort is already queued: 1 on the context's stream, 2 on stream2 (ev_join behind it)
+  unsigned char* d_slabs_retry[3] = {nullptr, nullptr, nullptr};      // trace slabs of the band kernels' retry launch (see launch_window)
   bool bx_planner_aside = false;            // this call: the planner and the full-window kernels run on stream2, the band DPs on the context's stream
   bool bx_pending_join = false;                                                     // band kernels are still running on stream2 / stream3
   std::string err;
@@ -391,6 +392,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (ctx->d_cull_sync) (void)hipFree(ctx->d_cull_sync);
   if (ctx->d_bx_slabs_late) (void)hipFree(ctx->d_bx_slabs_late);
   if (ctx->d_one) (void)hipFree(ctx->d_one);
+  for (int k = 0; k < 3; k++) if (ctx->d_slabs_retry[k]) (void)hipFree(ctx->d_slabs_retry[k]);
   if (ctx->d_prep_bar) (void)hipFree(ctx->d_prep_bar);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -702,7 +704,10 @@ extern "C" int mia_hip_plain_stats(mia_hip_ctx* ctx, int reset, double* plain_ms
 }
 
 template <int CPL>
-static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count, const int32_t* dev_range = nullptr, hipStream_t on = nullptr) {
+// own_slabs: the launch gets trace slabs of its own (ctx->d_slabs_retry) and a grid of at most 1 024 workgroups -- it may run
+// beside another launch of the same class on another stream (the band kernels' retry list beside the planner's kernels)
+static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count, const int32_t* dev_range = nullptr, hipStream_t on = nullptr,
+                                bool own_slabs = false) {
   // slab = the largest trace of this class: 256 rows x 64*CPL columns, one byte per cell
   const int64_t slab = (int64_t)MAX_READ * 64 * CPL;
   // persistent grid: never more workgroups than are resident at once (a late starter would work through its whole
@@ -714,14 +719,22 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
     const int per_cu = ctx->grid_wgs / cus;      // the configured ceiling (MIA_HIP_GRID_WAVES_PER_CU)
     ctx->window_wgs[ci] = cus * (occ < per_cu ? occ : per_cu);
   }
-  const int grid = (dev_range || count >= ctx->window_wgs[ci]) ? ctx->window_wgs[ci] : count;   // (a count on the device: the whole persistent grid)
-  if (!ctx->d_slabs[ci]) {
-    if (hipMalloc((void**)&ctx->d_slabs[ci], (size_t)slab * ctx->grid_wgs) != hipSuccess) return hipErrorOutOfMemory;
+  int grid = (dev_range || count >= ctx->window_wgs[ci]) ? ctx->window_wgs[ci] : count;   // (a count on the device: the whole persistent grid)
+  unsigned char* slabs = nullptr;
+  if (own_slabs) {
+    grid = std::min(grid, 1024);
+    if (!ctx->d_slabs_retry[ci] && hipMalloc((void**)&ctx->d_slabs_retry[ci], (size_t)slab * 1024) != hipSuccess) return hipErrorOutOfMemory;
+    slabs = ctx->d_slabs_retry[ci];
+  } else {
+    if (!ctx->d_slabs[ci]) {
+      if (hipMalloc((void**)&ctx->d_slabs[ci], (size_t)slab * ctx->grid_wgs) != hipSuccess) return hipErrorOutOfMemory;
+    }
+    slabs = ctx->d_slabs[ci];
   }
   RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
   if (stage_begin(ctx, STG_TRACE, on)) return hipErrorOutOfMemory;
   hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, on ? on : ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
-                     count, ctx->d_slabs[ci], slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg, dev_range);
+                     count, slabs, slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg, dev_range);
   stage_end(ctx, STG_TRACE, on);
   return hipGetLastError();
 }
@@ -731,15 +744,22 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
 static int bx_join_and_retry(mia_hip_ctx* ctx) {
   if (!ctx->bx_pending_join) return MIA_HIP_OK;
   ctx->bx_pending_join = false;
-  if (ctx->bx_planner_aside) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));      // (the planner's chain ends here; it finished long ago)
-  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
   const int32_t* range = ctx->d_plan_hdr + PH_RETRY2;
   const int cols = ctx->max_len + 2 * REALIGN_BUFFER + 2;
-  hipError_t e = cols <= 64 * 4 ? launch_window<4>(ctx, 0, ctx->d_retry2, 0, range)
-               : cols <= 64 * 8 ? launch_window<8>(ctx, 1, ctx->d_retry2, 0, range)
-                                : launch_window<12>(ctx, 2, ctx->d_retry2, 0, range);
+  const bool aside = ctx->bx_planner_aside;
+  // mia_hip_iterate: the retry list is the band kernels' alone, so its window kernel only waits for THEM (the trace DP on
+  // stream3; values and late trace are ahead of it on this stream) and runs beside the tail of the planner's chain on
+  // stream2, with trace slabs of its own; the planner is waited for behind it
+  if (!aside) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
+  hipError_t e = cols <= 64 * 4 ? launch_window<4>(ctx, 0, ctx->d_retry2, 0, range, nullptr, aside)
+               : cols <= 64 * 8 ? launch_window<8>(ctx, 1, ctx->d_retry2, 0, range, nullptr, aside)
+                                : launch_window<12>(ctx, 2, ctx->d_retry2, 0, range, nullptr, aside);
   if (e != hipSuccess) { ctx->err = std::string("k_align_window (band retry list) launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+  if (aside) {
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));      // (the planner's chain ends here)
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  }
   return MIA_HIP_OK;
 }
 
@@ -1419,7 +1439,8 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
     if (dev_alloc(ctx, &ctx->d_cull_sync, 4)) return MIA_HIP_ERR_NOMEM;
     HIPCHK(hipMemsetAsync(ctx->d_cull_sync, 0, 16, ctx->stream));
   }
-  hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, nb, slot_base, ctx->d_total, ctx->d_cull_sync, ctx->abort_if);
+  hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, nb, slot_base, ctx->d_total, (uint32_t*)nullptr, ctx->abort_if);
+  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partial, nb, slot_base, ctx->d_total, ctx->abort_if);
   if (slot_base + 2 * n + 16 > ctx->n_slots) {   // sharded runs: slots are global indices
     uint8_t* nd = nullptr;
     const int64_t ns = slot_base + 2 * n + 16;

@@ -2,7 +2,7 @@ import csv,sys,glob
 f=glob.glob(sys.argv[1]+'/**/*kernel_trace.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'k_ref_encode' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'k_ref_encode' in r['Kernel_Name'] or 'k_ref_prep' in r['Kernel_Name']]
 a,b=idx[-3],idx[-2]
 t0=int(rows[a]['Start_Timestamp'])
 prev_end=t0
