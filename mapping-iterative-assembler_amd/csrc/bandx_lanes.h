@@ -167,8 +167,9 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
 
 // ---- with a trace ----------------------------------------------------------------------------------------------------------
 // trace: this WAVEFRONT's slab.  A trace word holds the codes of ONE cell (band index) in FOUR consecutive rows: rows 4q ..
-// 4q + 3 of lane l's cell jj sit in word (q * 64 + l) * 8 + jj, so a lane's stores are 32 contiguous bytes every four rows
-// (the wavefront's: 2 KB) and the traceback -- which follows one band index down the rows -- finds sixteen rows in four
+// 4q + 3 of lane l's cell jj sit in word q * 512 + (jj >> 2) * 256 + l * 4 + (jj & 3): each of a lane's two 16-byte stores per four
+// rows lies in a stretch of 1 KB that the wavefront's 64 lanes fill completely (whole cache lines: a line written in two halves by
+// two instructions was fetched first -- 210 MB per launch, the size of the slabs), and the traceback -- which follows one band index down the rows -- finds sixteen rows in four
 // words instead of sixteen (round 2's layout had a row's eight cells side by side: sixteen cache lines per fetch and lane,
 // a third of the kernel's time).  lane_in_wave: this lane; the read's first lane walks the traceback and writes cols_out / res.  Returns (on the first lane) whether the read is
 // finished here; false: the reference's index-0 quirk, or nothing alive in the last row.
@@ -184,7 +185,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
   int32_t P[BXL_CELLS], H[BXL_CELLS];
   uint32_t tb[BXL_CELLS];                             // the four rows' codes of each of this lane's cells
   uint32_t rw = rwords[0], rw_next = rwords[1];
-  uint32_t* mine = trace + BXL_CELLS * lane_in_wave;
+  uint32_t* mine = trace + 4 * lane_in_wave;          // this lane's four words of cells 0..3; cells 4..7 sit 256 words further
   BxlSlide slide;
   slide.init(refnib, (int64_t)s + dl + BX_NIB_LEAD);
   {
@@ -200,7 +201,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
     }
     if (R == 0) {
 #pragma unroll
-      for (int j = 0; j < BXL_CELLS; j += 4) *reinterpret_cast<uint4*>(mine + j) = make_uint4(tb[j], tb[j + 1], tb[j + 2], tb[j + 3]);
+      for (int j = 0; j < BXL_CELLS; j += 4) *reinterpret_cast<uint4*>(mine + (j >> 2) * 256) = make_uint4(tb[j], tb[j + 1], tb[j + 2], tb[j + 3]);
     }
   }
   for (int r = 1; r < len2; r++) {
@@ -262,7 +263,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
     if (rk == 3 || r == R) {                            // (the bytes of rows beyond the read's last are never looked at)
       uint32_t* tr = mine + (uint32_t)(r >> 2) * BLK_WORDS;
 #pragma unroll
-      for (int j = 0; j < BXL_CELLS; j += 4) *reinterpret_cast<uint4*>(tr + j) = make_uint4(tb[j], tb[j + 1], tb[j + 2], tb[j + 3]);
+      for (int j = 0; j < BXL_CELLS; j += 4) *reinterpret_cast<uint4*>(tr + (j >> 2) * 256) = make_uint4(tb[j], tb[j + 1], tb[j + 2], tb[j + 3]);
     }
   }
   // max_sg_score: first maximum of the last row (src/mia.c:1278-1302)
@@ -312,7 +313,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
     if (r == 0 || c == 0) break;
     const int j = c - r - d0;
     if (j < 0 || j >= W) return false;
-    const uint32_t col = (uint32_t)(BXL_CELLS * lane_in_wave + j);      // (band index j: cell j & 7 of the lane j >> 3 places to the right)
+    const uint32_t col = (uint32_t)(((j >> 2) & 1) * 256 + (lane_in_wave + (j >> 3)) * 4 + (j & 3));      // (band index j: cell j & 7 of the lane j >> 3 places to the right)
     const int q0 = r >> 2;
     uint32_t nd = 0;                         // bit i: row 4 (q0 - 3) + i holds something else than a diagonal step
 #pragma unroll
@@ -403,7 +404,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
     const int j = c - r - d0;
     cols_out[r] = (int16_t)c;
     if (r == 0 || c == 0) break;
-    const int code = (int)((trace[(uint32_t)(r >> 2) * BLK_WORDS + (uint32_t)(BXL_CELLS * lane_in_wave + j)] >> (8 * (r & 3))) & 255u);
+    const int code = (int)((trace[(uint32_t)(r >> 2) * BLK_WORDS + (uint32_t)(((j >> 2) & 1) * 256 + (lane_in_wave + (j >> 3)) * 4 + (j & 3))] >> (8 * (r & 3))) & 255u);
     if (code == 0x80) break;
     if (code == 0xFF) { r--; c--; continue; }
     if (code & 0x40) { r--; c = c - 1 - (code & 63); }
