@@ -2164,7 +2164,10 @@ static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, 
   // -- the new reference: ASCII up, codes and wrap made on the device (make_ref_upper / add_ref_wrap, src/mia.c:642-689)
   const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl, total = wrap + 64;
   int64_t n_other = 0;
-  for (int i = 0; i < L; i++) n_other += base_code(new_ref[i]) > 3;
+  {
+    static const struct Other { uint8_t t[256]; Other() { for (int c = 0; c < 256; c++) t[c] = base_code((char)c) > 3; } } other_of;   // (a load and an add per character)
+    for (int i = 0; i < L; i++) n_other += other_of.t[(uint8_t)new_ref[i]];
+  }
   ctx->ref_mostly_bases = n_other * 50 <= L;
   ctx->kh_entries = 0;
   if (n_other && ctx->use_wild) {            // (kh_wild_entries over the wrapped string, without making the codes here)
