@@ -1994,1346 +1994,6 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   return MIA_HIP_OK;
 }
 
-// ---- several GPUs (reads shard, tallies all-reduce) ------------------------------------------
-// The exchanges of a sharded iteration go through ctx->coll, a table of two collectives (include/mia_hip.h); the
-// transports themselves -- RCCL over xGMI, the in-process loopback -- live in mia_comm.hip.
-constexpr int PRE_WORDS = 8;         // per rank before the cull: five score sums, AlnSeq records, links, reads waiting for the exact kernel
-#define COLLCHK(call)                                                                                  \
-  do {                                                                                                 \
-    const int r_ = (call);                                                                             \
-    if (r_ != MIA_HIP_OK) {                                                                            \
-      const char* t_ = ctx->coll.error ? ctx->coll.error(ctx->coll.user) : nullptr;                    \
-      ctx->err = std::string(#call) + ": " + (t_ && *t_ ? t_ : "collective failed");                   \
-      return r_;                                                                                       \
-    }                                                                                                  \
-  } while (0)
-
-static int comm_attach_table(mia_hip_ctx* ctx, const mia_hip_collectives& t) {
-  if (dev_alloc(ctx, &ctx->d_gather, (size_t)PRE_WORDS * t.n_ranks)) return MIA_HIP_ERR_NOMEM;
-  ctx->coll = t;
-  ctx->comm = true; ctx->comm_ranks = t.n_ranks; ctx->comm_rank = t.rank;
-  ctx->h_gather.assign((size_t)PRE_WORDS * t.n_ranks, 0);
-  ctx->ev_pad = 0;
-  return MIA_HIP_OK;
-}
-
-extern "C" int mia_hip_comm_init(mia_hip_ctx* ctx, const void* id128, int32_t n_ranks, int32_t rank) {
-  if (!ctx || !id128 || n_ranks < 1 || n_ranks > 256 || rank < 0 || rank >= n_ranks) return MIA_HIP_ERR_ARG;
-  if (ctx->comm) { ctx->err = "this context already has a communicator"; return MIA_HIP_ERR_STATE; }
-  HIPCHK(hipSetDevice(ctx->device));
-  mia_hip_collectives t;
-  if (int rc = mia_comm_rccl_table(id128, n_ranks, rank, &t, &ctx->err)) return rc;
-  if (int rc = comm_attach_table(ctx, t)) { if (t.destroy) t.destroy(t.user); return rc; }     // (no half-made communicator stays behind)
-  return MIA_HIP_OK;
-}
-
-extern "C" int mia_hip_comm_attach(mia_hip_ctx* ctx, const mia_hip_collectives* table) {
-  if (!ctx || !table || !table->all_gather || !table->all_reduce_i32 || table->n_ranks < 1 || table->n_ranks > 256 || table->rank < 0 ||
-      table->rank >= table->n_ranks)
-    return MIA_HIP_ERR_ARG;
-  if (ctx->comm) { ctx->err = "this context already has a communicator"; return MIA_HIP_ERR_STATE; }
-  HIPCHK(hipSetDevice(ctx->device));
-  return comm_attach_table(ctx, *table);
-}
-
-extern "C" int mia_hip_comm_info(mia_hip_ctx* ctx, int32_t* n_ranks, int32_t* rank, const char** transport) {
-  if (!ctx) return MIA_HIP_ERR_ARG;
-  int32_t nr = 1, rk = 0;
-  if (ctx->comm) {
-    nr = ctx->comm_ranks; rk = ctx->comm_rank;
-    if (ctx->coll.query) { if (int rc = ctx->coll.query(ctx->coll.user, &nr, &rk)) { ctx->err = "the transport could not say how many ranks it has"; return rc; } }
-  }
-  if (n_ranks) *n_ranks = nr;
-  if (rank) *rank = rk;
-  if (transport) *transport = ctx->comm ? (ctx->coll.name ? ctx->coll.name : "caller") : "none";
-  return MIA_HIP_OK;
-}
-
-extern "C" int mia_hip_comm_destroy(mia_hip_ctx* ctx) {
-  if (!ctx) return MIA_HIP_ERR_ARG;
-  if (!ctx->comm) return MIA_HIP_OK;
-  (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->coll.destroy) ctx->coll.destroy(ctx->coll.user);
-  ctx->coll = mia_hip_collectives{};
-  ctx->comm = false; ctx->comm_ranks = 1; ctx->comm_rank = 0;
-  return MIA_HIP_OK;
-}
-
-// all-gather of ragged 8-byte records (links: 4 words each; insert events: 1): every rank contributes counts[rank] * words
-// words from `mine`; the concatenation in rank order lands in ctx->d_lall.  counts are known on every rank.
-static int comm_gather_ragged(mia_hip_ctx* ctx, const int64_t* mine, const std::vector<int64_t>& counts, int words, int64_t* total_out) {
-  const int W = ctx->comm_ranks;
-  int64_t mx = 0, total = 0;
-  for (int r = 0; r < W; r++) { mx = std::max(mx, counts[(size_t)r]); total += counts[(size_t)r]; }
-  *total_out = total;
-  if (total == 0) return MIA_HIP_OK;
-  const int64_t pad = mx * words;
-  if (pad > ctx->lmine_cap) { if (dev_alloc(ctx, &ctx->d_lmine, (size_t)pad * 2)) return MIA_HIP_ERR_NOMEM; ctx->lmine_cap = pad * 2; }
-  if (pad * W > ctx->lstage_cap) { if (dev_alloc(ctx, &ctx->d_lstage, (size_t)pad * W * 2)) return MIA_HIP_ERR_NOMEM; ctx->lstage_cap = pad * W * 2; }
-  if (total * words > ctx->lall_cap) { if (dev_alloc(ctx, &ctx->d_lall, (size_t)total * words * 2)) return MIA_HIP_ERR_NOMEM; ctx->lall_cap = total * words * 2; }
-  HIPCHK(hipMemsetAsync(ctx->d_lmine, 0, (size_t)pad * 8, ctx->stream));
-  const int64_t nm = counts[(size_t)ctx->comm_rank] * words;
-  if (nm > 0) HIPCHK(hipMemcpyAsync(ctx->d_lmine, mine, (size_t)nm * 8, hipMemcpyDeviceToDevice, ctx->stream));
-  COLLCHK(ctx->coll.all_gather(ctx->coll.user, ctx->d_lmine, ctx->d_lstage, (size_t)pad * 8, ctx->stream));
-  int64_t o = 0;
-  for (int r = 0; r < W; r++) {
-    const int64_t c = counts[(size_t)r] * words;
-    if (c > 0) HIPCHK(hipMemcpyAsync(ctx->d_lall + o, ctx->d_lstage + (int64_t)r * pad, (size_t)c * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    o += c;
-  }
-  return MIA_HIP_OK;
-}
-
-// What the cull needs from the other ranks -- their score sums (find_fsdb_score_cut's first pass), how many AlnSeq records
-// precede this rank's, how many links each cull will emit, and whether some rank still has reads for the exact kernel --
-// in ONE small all-gather, queued BEHIND the alignment kernels and in front of the alignment's one host wait: a sharded
-// iteration waits for the host as often as a single context does.
-static int comm_pre_cull_enqueue(mia_hip_ctx* ctx, const int32_t* d_wide_count) {
-  const int64_t n = ctx->rs.n;
-  const int W = ctx->comm_ranks;
-  if (!ctx->d_sums && dev_alloc(ctx, &ctx->d_sums, 8)) return MIA_HIP_ERR_NOMEM;
-  hipLaunchKernelGGL(k_score_sums_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_sums, d_wide_count);
-  const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cus);
-  hipLaunchKernelGGL(k_score_sums, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ctx->d_sums, ctx->L, ctx->d_back_slot, ctx->d_front_slot0);
-  HIPCHK(hipGetLastError());
-  COLLCHK(ctx->coll.all_gather(ctx->coll.user, ctx->d_sums, ctx->d_gather, (size_t)PRE_WORDS * 8, ctx->stream));
-  int64_t* stage = ctx->h_pin ? reinterpret_cast<int64_t*>(ctx->h_pin + (40 << 10)) : ctx->h_gather.data();
-  HIPCHK(hipMemcpyAsync(stage, ctx->d_gather, (size_t)PRE_WORDS * W * 8, hipMemcpyDeviceToHost, ctx->stream));
-  return MIA_HIP_OK;
-}
-// ... and once the stream has been waited for
-static bool comm_pre_cull_collect(mia_hip_ctx* ctx) {
-  const int W = ctx->comm_ranks;
-  if (ctx->h_pin) memcpy(ctx->h_gather.data(), ctx->h_pin + (40 << 10), (size_t)PRE_WORDS * W * 8);
-  bool any_wide = false;
-  for (int r = 0; r < W; r++) any_wide = any_wide || ctx->h_gather[(size_t)PRE_WORDS * r + 7] != 0;
-  return any_wide;
-}
-
-__global__ void k_put_i32(int32_t* dst, const int32_t* src, int32_t clamp) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = min(*src, clamp); }
-
-// The insert events of all ranks, gathered in blocks of `pad` (stage[r * pad + i], i < counts[r]), packed into one list in
-// rank order; *n_out = their number.  counts[] are the W slots behind ref->gaps that rode on its max-reduce.  If some rank
-// had more than `pad` events nothing is touched and bit 8 of the tally flags says so (the host repeats the exchange with
-// the counts in hand).  One workgroup per rank in y.
-__global__ __launch_bounds__(256) void k_events_compact(const uint64_t* __restrict__ stage, int64_t pad, const int32_t* __restrict__ counts, int W,
-                                                          uint64_t* __restrict__ out, int32_t cap, int32_t* n_out, uint32_t* flags) {
-  const int r = blockIdx.y;
-  int64_t before = 0, total = 0;
-  bool over = false;
-  for (int k = 0; k < W; k++) {
-    const int64_t c = counts[k];
-    over = over || c > pad;
-    if (k < r) before += c;
-    total += c;
-  }
-  over = over || total > cap;
-  if (over) { if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flags, 8u); return; }
-  const int64_t mine = counts[r];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mine; i += (int64_t)gridDim.x * 256) out[before + i] = stage[(int64_t)r * pad + i];
-  if (r == 0 && blockIdx.x == 0 && threadIdx.x == 0) *n_out = (int32_t)total;
-}
-
-// ---- one whole iteration -------------------------------------------------------------------------
-// reiterate_assembly + pop_smp_from_FSDB + cull_maln_from_fsdb + consensus_assembly_string (src/mia_main.c:931-963) as
-// one call: the same kernels as mia_hip_realign / _cull / _tally / _consensus, but what those entry points hand back to
-// the host between the kernels -- the planner's bin sizes, the cut line, the insert-event count, five result arrays --
-// stays on the device.  The host waits twice: once behind the alignment (reads that need the exact scalar kernel must be
-// known before anything is culled) and once for the consensus string -- with or without a communicator.
-static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular, int32_t hard_cut, const double* slope_intercept,
-                        int cons_code, char* out, int64_t out_cap, int64_t* out_len);
-
-extern "C" int mia_hip_iterate(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular, int32_t hard_cut, const double* slope_intercept,
-                               int cons_code, char* out, int64_t out_cap, int64_t* out_len) {
-  if (!ctx) return MIA_HIP_ERR_ARG;
-  int rc;
-  if (!new_ref || ref_len <= 0 || !out || out_cap < 1) { ctx->err = "iterate: bad argument"; rc = MIA_HIP_ERR_ARG; }
-  else if (!ctx->have_pssm || !ctx->d_packed) { ctx->err = "set_pssm and upload_reads must precede iterate"; rc = MIA_HIP_ERR_STATE; }
-  else rc = iterate_body(ctx, new_ref, ref_len, circular, hard_cut, slope_intercept, cons_code, out, out_cap, out_len);
-  ctx->in_iterate = false; ctx->deferred = false;
-  // a rank that fails here will not come to the collectives the others are about to enter: tell the transport, so that
-  // they return an error as well instead of waiting for ever
-  if (rc != MIA_HIP_OK && ctx->comm && ctx->coll.abort) ctx->coll.abort(ctx->coll.user);
-  return rc;
-}
-
-static int iterate_body(mia_hip_ctx* ctx, const char* new_ref, int32_t ref_len, int circular, int32_t hard_cut, const double* slope_intercept,
-                        int cons_code, char* out, int64_t out_cap, int64_t* out_len) {
-  HIPCHK(hipSetDevice(ctx->device));
-  // -- the new reference: ASCII up, codes and wrap made on the device (make_ref_upper / add_ref_wrap, src/mia.c:642-689)
-  const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl, total = wrap + 64;
-  int64_t n_other = 0;
-  {
-    static const struct Other { uint8_t t[256]; Other() { for (int c = 0; c < 256; c++) t[c] = base_code((char)c) > 3; } } other_of;   // (a load and an add per character)
-    for (int i = 0; i < L; i++) n_other += other_of.t[(uint8_t)new_ref[i]];
-  }
-  ctx->ref_mostly_bases = n_other * 50 <= L;
-  ctx->kh_entries = 0;
-  if (n_other && ctx->use_wild) {            // (kh_wild_entries over the wrapped string, without making the codes here)
-    int64_t e = 0;
-    int k = 0;
-    auto other = [&](int j) { return base_code(new_ref[j < L ? j : j - L]) > 3 ? 1 : 0; };
-    for (int pq = 0; pq < wrap; pq++) {
-      k += other(pq);
-      if (pq >= DF_K) k -= other(pq - DF_K);
-      if (pq >= DF_K - 1 && k <= BX_WILD) e += (int64_t)1 << (2 * k);
-    }
-    ctx->kh_entries = e > ((int64_t)1 << 24) ? 0 : e;
-  }
-  if (total > ctx->ref_cap) {
-    if (dev_alloc(ctx, &ctx->d_ref, (size_t)total * 2)) return MIA_HIP_ERR_NOMEM;
-    ctx->ref_cap = total * 2;
-  }
-  if (L > ctx->ascii_cap) {
-    if (dev_alloc(ctx, &ctx->d_ascii, (size_t)L * 2)) return MIA_HIP_ERR_NOMEM;
-    ctx->ascii_cap = (int64_t)L * 2;
-  }
-  if (ctx->h_pin && (size_t)L <= mia_hip_ctx::PIN_BYTES - mia_hip_ctx::PIN_MISC) {
-    HIPCHK(hipStreamSynchronize(ctx->stream));             // the staging area may still feed an earlier copy
-    memcpy(ctx->h_pin + mia_hip_ctx::PIN_MISC, new_ref, (size_t)L);
-    HIPCHK(hipMemcpyAsync(ctx->d_ascii, ctx->h_pin + mia_hip_ctx::PIN_MISC, (size_t)L, hipMemcpyHostToDevice, ctx->stream));
-  } else {
-    HIPCHK(hipMemcpyAsync(ctx->d_ascii, new_ref, (size_t)L, hipMemcpyHostToDevice, ctx->stream));
-  }
-  // (the codes are made by align_all's first launch: k_ref_prep with everything else that is derived from the reference, or k_ref_encode)
-  ctx->pend_encode = true; ctx->pend_L = L; ctx->pend_wl = wl; ctx->pend_total = total;
-  if (ctx->rs.n == 0) { encode_now(ctx); HIPCHK(hipGetLastError()); }
-  const bool dbg_steps = getenv("MIA_HIP_ITER_DEBUG") != nullptr;      // diagnostic: wait and report after every stage
-  auto checkpoint = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ctx->stream); fprintf(stderr, "[mia_hip_iterate] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
-  checkpoint("reference");
-  ctx->L = L; ctx->wrap = wrap; ctx->have_ref = true; ctx->explicit_win = 0;
-  const int64_t n = ctx->rs.n;
-  const int W = ctx->comm_ranks;
-  if (ctx->comm && n == 0) { ctx->err = "iterate: every rank of a sharded run needs reads"; return MIA_HIP_ERR_ARG; }
-  if (ctx->comm && W > 256) { ctx->err = "iterate: more than 256 ranks"; return MIA_HIP_ERR_ARG; }
-  // -- re-alignment (one wait, at its end; a sharded run's pre-cull all-gather rides in front of that wait)
-  ctx->in_iterate = true;
-  ctx->deferred = true;
-  // no host wait behind the alignment when nothing on the host depends on it: one context, and a cut line that is given,
-  // hard, or NaN by construction (reads of one length) -- see align_all / abort_if
-  ctx->spec_pending = false; ctx->abort_if = nullptr;
-  ctx->spec_ok = !ctx->comm && n > 0 && !ctx->no_spec && (hard_cut > 0 || slope_intercept || ctx->min_len == ctx->max_len);
-  const int rca = align_all(ctx);
-  ctx->deferred = false;
-  ctx->spec_ok = false;
-  ctx->pend_encode = false;                 // (never outlives the call)
-  if (rca) { ctx->spec_pending = false; ctx->abort_if = nullptr; return rca; }
-  checkpoint("realign");
-  int64_t slot_base = 0, g_sums[5] = {0, 0, 0, 0, 0};
-  std::vector<int64_t> link_counts((size_t)W, 0), n_of((size_t)W, n);
-  if (ctx->comm) {
-    g_sums[3] = INT32_MAX; g_sums[4] = INT32_MIN;
-    for (int r = 0; r < W; r++) {
-      const int64_t* q = ctx->h_gather.data() + (size_t)PRE_WORDS * r;
-      g_sums[0] += q[0]; g_sums[1] += q[1]; g_sums[2] += q[2];
-      g_sums[3] = std::min(g_sums[3], q[3]); g_sums[4] = std::max(g_sums[4], q[4]);
-      if (r < ctx->comm_rank) slot_base += q[5];
-      link_counts[(size_t)r] = q[6];
-    }
-  }
-  // -- the cut line of find_fsdb_score_cut (src/fsdb.c:269-383)
-  double slope = 0, intercept = 0;
-  const bool one_length = ctx->comm ? (g_sums[2] == 0 || g_sums[3] == g_sums[4]) : (ctx->min_len == ctx->max_len || n == 0);
-  if (hard_cut > 0) {
-  } else if (slope_intercept) {
-    slope = slope_intercept[0]; intercept = slope_intercept[1];
-  } else if (one_length) {
-    // reads of one length: both regression sums are exactly 0, slope_bf = 0/0, and every derived quantity is that NaN
-    // whatever the scores (mia_hip_score_cut_from_sums spells the arithmetic out) -- nothing to compute
-    const double zero = 0.0;
-    slope = intercept = zero / zero;
-  } else if (!ctx->comm) {
-    // sums of products in IEEE double are order dependent: the reference's sequential order over the scores, on the host
-    std::vector<int32_t> score((size_t)n);
-    HIPCHK(hipMemcpyAsync(score.data(), ctx->d_score, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    mia_hip_score_cut(score.data(), ctx->h_len.data(), nullptr, n, &slope, &intercept);
-  } else {
-    // the same over the reads of ALL ranks in fsdb order (= rank order): scores and lengths gathered, the regression on
-    // every rank's host (identical inputs, identical arithmetic)
-    int32_t* d_nl = nullptr;                               // {score..., len...} of this rank, padded to the longest
-    ScopeFree sf; sf.watch((void**)&d_nl);
-    std::vector<int64_t> cnt1((size_t)W, 1);
-    int64_t tot = 0;
-    int64_t n64 = n;
-    int64_t* d_n = nullptr; sf.watch((void**)&d_n);
-    if (hipMalloc((void**)&d_n, 8) != hipSuccess) return MIA_HIP_ERR_NOMEM;
-    HIPCHK(hipMemcpyAsync(d_n, &n64, 8, hipMemcpyHostToDevice, ctx->stream));
-    if (int rcg = comm_gather_ragged(ctx, d_n, cnt1, 1, &tot)) return rcg;
-    HIPCHK(hipMemcpyAsync(n_of.data(), ctx->d_lall, (size_t)W * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    int64_t nmax = 0, ntot = 0;
-    for (int r = 0; r < W; r++) { nmax = std::max(nmax, n_of[(size_t)r]); ntot += n_of[(size_t)r]; }
-    if (hipMalloc((void**)&d_nl, (size_t)nmax * 2 * 4) != hipSuccess) return MIA_HIP_ERR_NOMEM;
-    if ((int64_t)W * nmax * 2 > ctx->scores_all_cap) {
-      if (dev_alloc(ctx, &ctx->d_scores_all, (size_t)W * nmax * 2)) return MIA_HIP_ERR_NOMEM;
-      ctx->scores_all_cap = (int64_t)W * nmax * 2;
-    }
-    HIPCHK(hipMemsetAsync(d_nl, 0, (size_t)nmax * 2 * 4, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_nl, ctx->d_score, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d_nl + nmax, ctx->h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    COLLCHK(ctx->coll.all_gather(ctx->coll.user, d_nl, ctx->d_scores_all, (size_t)nmax * 2 * 4, ctx->stream));
-    std::vector<int32_t> all((size_t)W * nmax * 2), score((size_t)ntot), lens((size_t)ntot);
-    HIPCHK(hipMemcpyAsync(all.data(), ctx->d_scores_all, all.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    int64_t o = 0;
-    for (int r = 0; r < W; r++) {
-      memcpy(score.data() + o, all.data() + (size_t)r * nmax * 2, (size_t)n_of[(size_t)r] * 4);
-      memcpy(lens.data() + o, all.data() + (size_t)r * nmax * 2 + nmax, (size_t)n_of[(size_t)r] * 4);
-      o += n_of[(size_t)r];
-    }
-    mia_hip_score_cut(score.data(), lens.data(), nullptr, ntot, &slope, &intercept);
-  }
-  if (!(hard_cut > 0) && slope <= 0) slope = 100.0;         // src/mia.c:440-442
-  auto queue_cull = [&]() -> int {
-    ctx->buckets_queued = 0;
-    const bool side = tally_is_binned(ctx) && !ctx->no_side_buckets;
-    // (nothing has been waited for: stream2 must stay behind the alignment -- but not behind the cull)
-    if (side && ctx->spec_pending) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
-    if (int rcc = mia_hip_cull(ctx, hard_cut, slope, intercept, slot_base)) return rcc;
-    // the tally's counting sort reads nothing the cull writes: on stream2, beside the cull kernels (queued behind them on the
-    // host side -- the GPU is waiting for the first cull kernel at this point, not for these)
-    if (side) {
-      if (ctx->spec_pending) HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-      if (int rcb = bucket_launch(ctx, ctx->stream2)) return rcb;
-    }
-    return MIA_HIP_OK;
-  };
-  if (int rcq = queue_cull()) return rcq;
-  if (ctx->comm) {
-    // links of formerly split reads (stale fs->back_asp, include/mia_hip.h) may point at slots of another rank: every rank
-    // gets all links, applies those that hit its own slots, the record lengths the readers need come back by a max-reduce
-    int64_t any = 0;
-    for (int r = 0; r < W; r++) any += link_counts[(size_t)r];
-    if (any > 0) {
-      int64_t* dl = nullptr; int64_t nl = 0, total_l = 0;
-      if (int rcl = mia_hip_links(ctx, &dl, &nl)) return rcl;
-      if (nl != link_counts[(size_t)ctx->comm_rank]) { ctx->err = "iterate: the cull emitted another number of links than the score sweep announced"; return MIA_HIP_ERR_STATE; }
-      if (int rcg = comm_gather_ragged(ctx, dl, link_counts, 4, &total_l)) return rcg;
-      if (int rcs = mia_hip_set_links(ctx, ctx->d_lall, total_l)) return rcs;
-      int32_t *dlen = nullptr, *dact = nullptr; int64_t nn = 0;
-      if (int rcl = mia_hip_link_lengths(ctx, &dlen, &dact, &nn)) return rcl;
-      COLLCHK(ctx->coll.all_reduce_i32(ctx->coll.user, dlen, (size_t)nn, MIA_HIP_OP_MAX, ctx->stream));
-      COLLCHK(ctx->coll.all_reduce_i32(ctx->coll.user, dact, (size_t)nn, MIA_HIP_OP_MAX, ctx->stream));
-      if (int rcf = mia_hip_finish_links(ctx)) return rcf;
-    }
-  }
-  checkpoint("cull");
-  if (n == 0) { out[0] = 0; if (out_len) *out_len = 0; return MIA_HIP_OK; }
-  // -- tally and consensus, queued back to back
-  if (ctx->comm && ctx->ev_pad > 0) {
-    if (const char* e = getenv("MIA_HIP_EV_PAD")) { const long long v = atoll(e); if (v > 0) ctx->ev_pad = v; }   // (tests: force the overflow path; every rank reads the same value)
-    // the gathered events land in this context's list: room for every rank's block before anything is tallied into it
-    if (int rct = ensure_tally(ctx)) return rct;
-    if (ctx->ev_pad * W > ctx->tb.cap_events) {
-      const int64_t cap = std::min<int64_t>(ctx->ev_pad * W + 4096, (int64_t)1 << 30);
-      if (dev_alloc(ctx, &ctx->tb.events, (size_t)cap)) return MIA_HIP_ERR_NOMEM;
-      ctx->tb.cap_events = (int32_t)cap;
-    }
-  }
-  if (int rct = tally_launch(ctx)) return rct;
-  checkpoint("tally");
-  const int Lp = ctx->tb.Lp;
-  ctx->n_events_host = 0;
-  int32_t* h_evc = ctx->h_pin ? reinterpret_cast<int32_t*>(ctx->h_pin + (56 << 10)) : nullptr;      // the ranks' event counts, read with the results
-  std::vector<int32_t> evc_pageable;
-  if (ctx->comm && !h_evc) { evc_pageable.resize((size_t)W); h_evc = evc_pageable.data(); }
-  // the events of all ranks with the counts in hand (one more wait for the host): the first sharded iteration, and whenever
-  // a rank had more events than the blocks of the other way were sized for
-  auto exchange_events_counted = [&]() -> int {
-    HIPCHK(hipMemcpyAsync(h_evc, ctx->tb.gaps + Lp, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    std::vector<int64_t> ev_counts((size_t)W);
-    for (int r = 0; r < W; r++) ev_counts[(size_t)r] = h_evc[r];
-    int64_t total_ev = 0;
-    if (int rcg = comm_gather_ragged(ctx, reinterpret_cast<const int64_t*>(ctx->tb.events), ev_counts, 1, &total_ev)) return rcg;
-    if (total_ev > ctx->tb.cap_events) {
-      if (dev_alloc(ctx, &ctx->tb.events, (size_t)total_ev + 4096)) return MIA_HIP_ERR_NOMEM;
-      ctx->tb.cap_events = (int32_t)std::min<int64_t>(total_ev + 4096, INT32_MAX);
-    }
-    if (total_ev > 0) HIPCHK(hipMemcpyAsync(ctx->tb.events, ctx->d_lall, (size_t)total_ev * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    int32_t* te = ctx->h_pin ? reinterpret_cast<int32_t*>(ctx->h_pin + (60 << 10)) : nullptr;
-    int32_t te_local = (int32_t)total_ev;
-    if (te) { *te = te_local; HIPCHK(hipMemcpyAsync(ctx->tb.n_events, te, 4, hipMemcpyHostToDevice, ctx->stream)); }
-    else { HIPCHK(hipMemcpyAsync(ctx->tb.n_events, &te_local, 4, hipMemcpyHostToDevice, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); }
-    return MIA_HIP_OK;
-  };
-  // ... and without: every rank contributes a block of ev_pad events (sized from the counts of the iteration before, the
-  // same on every rank), the counts that rode on the gaps reduce tell k_events_compact how much of each block is real
-  auto exchange_events_padded = [&]() -> int {
-    const int64_t pad = ctx->ev_pad;
-    if (pad * W > ctx->lstage_cap) { if (dev_alloc(ctx, &ctx->d_lstage, (size_t)pad * W * 2)) return MIA_HIP_ERR_NOMEM; ctx->lstage_cap = pad * W * 2; }
-    COLLCHK(ctx->coll.all_gather(ctx->coll.user, ctx->tb.events, ctx->d_lstage, (size_t)pad * 8, ctx->stream));
-    const unsigned gx = (unsigned)std::min<int64_t>((pad + 255) / 256, 64);
-    hipLaunchKernelGGL(k_events_compact, dim3(gx, (unsigned)W), dim3(256), 0, ctx->stream, (const uint64_t*)ctx->d_lstage, pad, (const int32_t*)(ctx->tb.gaps + Lp), W,
-                       ctx->tb.events, ctx->tb.cap_events, ctx->tb.n_events, ctx->tb.flags);
-    HIPCHK(hipGetLastError());
-    return MIA_HIP_OK;
-  };
-  bool counted = false;
-  if (ctx->comm) {
-    // integer column tallies add up, ref->gaps is a maximum (src/mia.c:486-504); every rank's insert-event count rides on
-    // the max-reduce in W extra slots behind gaps; then the events themselves are gathered
-    hipLaunchKernelGGL(k_put_i32, dim3(1), dim3(1), 0, ctx->stream, ctx->tb.gaps + Lp + ctx->comm_rank, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events);
-    COLLCHK(ctx->coll.all_reduce_i32(ctx->coll.user, ctx->tb.tally, (size_t)TALLY_WORDS * Lp, MIA_HIP_OP_SUM, ctx->stream));
-    COLLCHK(ctx->coll.all_reduce_i32(ctx->coll.user, ctx->tb.gaps, (size_t)Lp + W, MIA_HIP_OP_MAX, ctx->stream));
-    counted = ctx->ev_pad <= 0;
-    if (int rce = counted ? exchange_events_counted() : exchange_events_padded()) return rce;
-  }
-  const int64_t cons_cap = (int64_t)L + ctx->ins_tally_cap + 64;          // string bytes
-  const int64_t res_bytes = (int64_t)CH_WORDS * 4 + cons_cap;
-  if (res_bytes > ctx->cons_cap) {
-    if (dev_alloc(ctx, &ctx->d_cons, (size_t)res_bytes * 2)) return MIA_HIP_ERR_NOMEM;
-    ctx->cons_cap = res_bytes * 2;
-  }
-  if (Lp > ctx->cons_pos_cap) {
-    if (dev_alloc(ctx, &ctx->d_cons_pos, (size_t)Lp * 2)) return MIA_HIP_ERR_NOMEM;
-    ctx->cons_pos_cap = (int64_t)Lp * 2;
-  }
-  const size_t need = (size_t)res_bytes;
-  if (need > ctx->pin2_bytes) {
-    if (ctx->h_pin2) (void)hipHostFree(ctx->h_pin2);
-    ctx->h_pin2 = nullptr; ctx->pin2_bytes = 0;
-    if (hipHostMalloc((void**)&ctx->h_pin2, need * 2, hipHostMallocDefault) != hipSuccess) { ctx->err = "hipHostMalloc"; return MIA_HIP_ERR_NOMEM; }
-    ctx->pin2_bytes = need * 2;
-  }
-  int32_t* h_hdr = reinterpret_cast<int32_t*>(ctx->h_pin2);
-  char* h_str = reinterpret_cast<char*>(ctx->h_pin2) + CH_WORDS * 4;
-  // consensus calls, the string consensus_assembly_string returns put together on the device (characters per column, their
-  // prefix sums, a scatter), header and string back in one copy, the second and last wait
-  auto consensus_tail = [&]() -> int {
-    // (a workgroup alone on sixteen thousand columns is slower than a launch costs -- 44 + 111 us for two single-workgroup
-    // kernels against 5 us each for these: the launches that remain are the ones with a chip-wide dependence between them)
-    const int64_t cap = ctx->ins_tally_cap;
-    int32_t* d_res = reinterpret_cast<int32_t*>(ctx->d_cons);
-    const unsigned gl = (unsigned)((L + 255) / 256);
-    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->tb.gaps, Lp, 1, L, ctx->d_ins_off, ctx->d_ins_total, ctx->abort_if);   // ins_off[p] = gaps[1] + .. + gaps[p-1]
-    hipLaunchKernelGGL(k_call_columns_z, dim3(gl), dim3(256), 0, ctx->stream, (const int32_t*)ctx->tb.tally, Lp, L, cons_code, ctx->d_calls, ctx->d_ins_tally, cap * 9, ctx->abort_if);
-    if (cap > 0)
-      hipLaunchKernelGGL(k_ins_tally, dim3(256), dim3(256), 0, ctx->stream, ctx->tb.events, 0, ctx->d_pssm, ctx->d_ins_off, ctx->tb.gaps, L, ctx->d_ins_tally,
-                         (int32_t)cap, (const int32_t*)ctx->tb.n_events, ctx->tb.cap_events, ctx->abort_if);
-    checkpoint("consensus kernels");
-    hipLaunchKernelGGL(k_call_inserts_count, dim3(gl), dim3(256), 0, ctx->stream, (const int32_t*)ctx->tb.tally, Lp, L, (const int32_t*)ctx->tb.gaps,
-                       (const int32_t*)ctx->d_ins_off, (const int32_t*)ctx->d_ins_tally, cons_code, (const char*)ctx->d_calls, ctx->d_ins_calls, (int32_t)cap,
-                       (const int32_t*)ctx->d_ins_total, ctx->d_cons_pos, ctx->abort_if);
-    hipLaunchKernelGGL(k_excl_scan, dim3(1), dim3(1024), 0, ctx->stream, (const int32_t*)ctx->d_cons_pos, L, 0, L, ctx->d_cons_pos, d_res + CH_LEN, ctx->abort_if);
-    hipLaunchKernelGGL(k_cons_scatter, dim3(gl), dim3(256), 0, ctx->stream, (const char*)ctx->d_calls, (const char*)ctx->d_ins_calls,
-                       (const int32_t*)ctx->tb.gaps, (const int32_t*)ctx->d_ins_off, L, (int32_t)cap, (const int32_t*)ctx->d_ins_total,
-                       (const int32_t*)ctx->d_cons_pos, d_res, (int32_t)cons_cap, (const int32_t*)ctx->tb.n_events, (const uint32_t*)ctx->tb.flags,
-                       (const uint32_t*)ctx->d_cull_flags, ctx->abort_if);
-    HIPCHK(hipGetLastError());
-    checkpoint("assemble");
-    HIPCHK(hipMemcpyAsync(ctx->h_pin2, ctx->d_cons, need, hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->comm && !counted) HIPCHK(hipMemcpyAsync(h_evc, ctx->tb.gaps + Lp, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return MIA_HIP_OK;
-  };
-  if (int rct = consensus_tail()) return rct;
-  if (ctx->spec_pending) {
-    // the alignment's counters arrived with the consensus.  Reads waiting for the exact kernel (next to never): every kernel
-    // queued behind the alignment has returned without touching anything; the exact kernel runs, and cull, tally and consensus
-    // are queued again -- this time unconditionally
-    ctx->spec_pending = false;
-    ctx->abort_if = nullptr;
-    const int32_t* hb = reinterpret_cast<const int32_t*>(ctx->h_pin);
-    align_counters_collect(ctx, hb, ctx->spec_filtered, ctx->spec_bx, ctx->spec_plain);
-    const int32_t n_wide = hb[0];
-    if (n_wide > 0 || ctx->spec_force) {
-      ctx->spec_redone++;
-      RefInfo rinfo{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
-      if (n_wide > 0) { if (int rcw = run_wide(ctx, rinfo, n_wide)) return rcw; }
-      if (int rcq = queue_cull()) return rcq;
-      if (int rct = tally_launch(ctx)) return rct;
-      if (int rct = consensus_tail()) return rct;
-    }
-  }
-  uint32_t tflags = (uint32_t)h_hdr[CH_TALLY_FLAGS];
-  if (ctx->comm && !counted && (tflags & 8u)) {
-    // some rank had more insert events than the blocks held (every rank sees the same counts, so every rank is here):
-    // the lists and counts are untouched -- exchange them with the counts in hand and call the consensus again
-    counted = true;
-    if (int rce = exchange_events_counted()) return rce;
-    if (int rct = consensus_tail()) return rct;
-    tflags = (uint32_t)h_hdr[CH_TALLY_FLAGS];
-  }
-  tflags &= ~8u;
-  if (ctx->comm) {
-    // the block size of the next iteration's event exchange, from counts every rank has seen: half as much again as the
-    // largest, re-sized only when that leaves the band [pad/4, 0.8 pad] (identical arithmetic on identical numbers)
-    int64_t mx = 0;
-    for (int r = 0; r < W; r++) mx = std::max<int64_t>(mx, h_evc[r]);
-    if (ctx->ev_pad <= 0 || mx * 5 > ctx->ev_pad * 4 || mx * 4 < ctx->ev_pad) ctx->ev_pad = mx + mx / 2 + 1024;
-  }
-  ctx->in_iterate = false;
-  if (int rcf = tally_finish(ctx, (uint32_t)h_hdr[CH_N_EVENTS], tflags, (uint32_t)h_hdr[CH_CULL_FLAGS])) return rcf;
-  if (h_hdr[CH_OVERFLOW]) {
-    // more insert columns than the buffers of the last call hold: the step-wise entry point enlarges them and calls again
-    ctx->iter_fallbacks++;
-    return mia_hip_consensus(ctx, cons_code, out, out_cap, out_len);
-  }
-  const int64_t len = h_hdr[CH_LEN];
-  if (len + 1 > out_cap) { ctx->err = "consensus buffer too small"; return MIA_HIP_ERR_ARG; }
-  memcpy(out, h_str, (size_t)len);
-  out[len] = 0;
-  if (out_len) *out_len = len;
-  ctx->consensus_done = true;
-  ctx->ins_total_host = h_hdr[CH_INS_TOTAL];
-  return MIA_HIP_OK;
-}
-
-// ---- adapter trimming ---------------------------------------------------------------------------
-extern "C" int mia_hip_trim(mia_hip_ctx* ctx, const char* adapter, int64_t n, const char* bases, const int64_t* offsets,
-                            uint8_t* trimmed, int32_t* trim_point) {
-  if (!ctx || !adapter || n < 0 || (n > 0 && (!bases || !offsets || !trimmed || !trim_point))) return MIA_HIP_ERR_ARG;
-  const int len2 = (int)strlen(adapter);
-  if (len2 < 1 || len2 > MAX_ADAPTER) { ctx->err = "adapter length outside 1..127"; return MIA_HIP_ERR_ARG; }
-  HIPCHK(hipSetDevice(ctx->device));
-  if (n == 0) return MIA_HIP_OK;
-  for (int64_t i = 0; i < n; i++) {
-    const int64_t l = offsets[i + 1] - offsets[i];
-    if (l < 1 || l > MIA_HIP_MAX_READ) { ctx->err = "read length outside 1..256"; return MIA_HIP_ERR_ARG; }
-  }
-  // init_flatsubmat (src/pssm.c:96-126)
-  std::vector<int32_t> flat((size_t)PSSM_WORDS);
-  for (int d = 0; d < 31; d++)
-    for (int i = 0; i < 5; i++)
-      for (int j = 0; j < 5; j++)
-        flat[(size_t)(d * 5 + i) * 5 + j] = i == 4 ? -10 : (j == 4 ? -100 : (i == j ? 200 : -600));
-  PackParams pk;
-  if (!make_pack_params(256, 600, &pk)) return MIA_HIP_ERR_RANGE;
-  const int64_t chars = offsets[n] - offsets[0];
-  std::vector<uint8_t> codes((size_t)chars), acodes((size_t)len2), apacked((size_t)(len2 + 1) / 2 + 4, 0);
-  for (int64_t k = 0; k < chars; k++) codes[(size_t)k] = base_code(bases[offsets[0] + k]);
-  for (int k = 0; k < len2; k++) { acodes[(size_t)k] = base_code(adapter[k]); apacked[(size_t)k >> 1] |= (uint8_t)(acodes[(size_t)k] << ((k & 1) * 4)); }
-  std::vector<int64_t> off0((size_t)n + 1);
-  for (int64_t i = 0; i <= n; i++) off0[(size_t)i] = offsets[i] - offsets[0];
-  int occ = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_trim, 64, 0));
-  if (occ < 1) occ = 1;
-  if (occ > 32) occ = 32;
-  if (occ > 4) occ &= ~3;
-  int64_t grid = (int64_t)ctx->cus * occ;
-  if (grid > n) grid = n;
-  const int64_t slab = (int64_t)(MAX_ADAPTER + 1) * MAX_READ;
-  uint8_t *d_codes = nullptr, *d_ap = nullptr, *d_ac = nullptr, *d_trimmed = nullptr;
-  int64_t* d_off = nullptr;
-  int32_t *d_flat = nullptr, *d_tp = nullptr, *d_list = nullptr, *d_scratch = nullptr;
-  uint32_t* d_status = nullptr;
-  unsigned char* d_slabs = nullptr;
-  int16_t* d_cols = nullptr;
-  ScopeFree guard;   // every temporary is released on any return
-  for (void** pp : {(void**)&d_codes, (void**)&d_ap, (void**)&d_ac, (void**)&d_trimmed, (void**)&d_off, (void**)&d_flat, (void**)&d_tp,
-                    (void**)&d_list, (void**)&d_scratch, (void**)&d_status, (void**)&d_slabs, (void**)&d_cols})
-    guard.watch(pp);
-  int rcx = dev_alloc(ctx, &d_codes, (size_t)chars + 8) | dev_alloc(ctx, &d_ap, apacked.size()) | dev_alloc(ctx, &d_ac, (size_t)len2) |
-            dev_alloc(ctx, &d_trimmed, (size_t)n) | dev_alloc(ctx, &d_off, (size_t)n + 1) | dev_alloc(ctx, &d_flat, (size_t)PSSM_WORDS) |
-            dev_alloc(ctx, &d_tp, (size_t)n) | dev_alloc(ctx, &d_status, (size_t)n) | dev_alloc(ctx, &d_slabs, (size_t)(slab * grid)) |
-            dev_alloc(ctx, &d_cols, (size_t)(grid * MAX_READ));
-  if (rcx) return MIA_HIP_ERR_NOMEM;
-  hipError_t e = hipSuccess;
-  auto up = [&](void* d, const void* h, size_t b) { if (e == hipSuccess && b) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
-  up(d_codes, codes.data(), (size_t)chars); up(d_ap, apacked.data(), apacked.size()); up(d_ac, acodes.data(), (size_t)len2);
-  up(d_off, off0.data(), (size_t)(n + 1) * 8); up(d_flat, flat.data(), (size_t)PSSM_WORDS * 4);
-  TrimReads tr{n, d_codes, d_off, d_trimmed, d_tp, d_status};
-  std::vector<uint32_t> status((size_t)n);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_trim, dim3((unsigned)grid), dim3(64), 0, ctx->stream, tr, d_ap, len2, d_flat, pk, d_slabs, slab, d_cols);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(status.data(), d_status, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  // gaps of 63 or more on the optimal path: exact scalar re-run of those reads
-  std::vector<int32_t> esc;
-  if (e == hipSuccess)
-    for (int64_t i = 0; i < n; i++) if (status[(size_t)i] != ST_OK) esc.push_back((int32_t)i);
-  if (e == hipSuccess && !esc.empty()) {
-    const int64_t words = (int64_t)len2 * MAX_READ + 5 * (int64_t)MAX_READ;
-    if (dev_alloc(ctx, &d_list, esc.size()) || dev_alloc(ctx, &d_scratch, (size_t)(words * (int64_t)esc.size()))) return MIA_HIP_ERR_NOMEM;
-    up(d_list, esc.data(), esc.size() * 4);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_trim_wide, dim3((unsigned)((esc.size() + 63) / 64)), dim3(64), 0, ctx->stream, tr, d_ac, len2, d_flat, d_list,
-                         (int32_t)esc.size(), d_scratch, words);
-      e = hipGetLastError();
-    }
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(trimmed, d_trimmed, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(trim_point, d_tp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { ctx->err = std::string("trim: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
-  ctx->trim_escapes = (int64_t)esc.size();
-  return MIA_HIP_OK;
-}
-
-extern "C" int mia_hip_trim_stats(mia_hip_ctx* ctx, int64_t* exact_reruns) {
-  if (!ctx || !exact_reruns) return MIA_HIP_ERR_ARG;
-  *exact_reruns = ctx->trim_escapes;
-  return MIA_HIP_OK;
-}
-
-// ---- ma -------------------------------------------------------------------------------------
-extern "C" int mia_hip_ma_tally(mia_hip_ctx* ctx, int32_t ref_len, const int32_t* gaps, int64_t n, const int32_t* start,
-                                const uint8_t* revcom, const int64_t* col_off, const char* seq, const char* smp, int64_t n_ins,
-                                const int32_t* ins_record, const int32_t* ins_pos, const int64_t* ins_off, const char* ins_bases) {
-  if (!ctx || ref_len <= 0 || !gaps || n < 0 || n_ins < 0 || (n > 0 && (!start || !revcom || !col_off || !seq || !smp)) ||
-      (n_ins > 0 && (!ins_record || !ins_pos || !ins_off || !ins_bases)))
-    return MIA_HIP_ERR_ARG;
-  if (!ctx->have_pssm) { ctx->err = "set_pssm must precede ma_tally"; return MIA_HIP_ERR_STATE; }
-  HIPCHK(hipSetDevice(ctx->device));
-  for (int64_t r = 0; r < n; r++)
-    if (col_off[r + 1] < col_off[r] || start[r] < 0) { ctx->err = "malformed record geometry"; return MIA_HIP_ERR_ARG; }
-  for (int64_t e = 0; e < n_ins; e++)
-    if (ins_record[e] < 0 || ins_record[e] >= n || ins_off[e + 1] < ins_off[e]) { ctx->err = "malformed insert list"; return MIA_HIP_ERR_ARG; }
-  ctx->L = ref_len;
-  ctx->wrap = ref_len;
-  const int64_t ins_chars = n_ins ? ins_off[n_ins] : 0;
-  if (ctx->tb.events && ctx->tb.cap_events < ins_chars + 16) {   // the list was sized for another job
-    (void)hipFree(ctx->tb.events); ctx->tb.events = nullptr;
-    if (dev_alloc(ctx, &ctx->tb.events, (size_t)ins_chars + 4096)) return MIA_HIP_ERR_NOMEM;
-    ctx->tb.cap_events = (int32_t)std::min<int64_t>(ins_chars + 4096, INT32_MAX);
-  }
-  if (!ctx->tb.events) {
-    int rc0 = dev_alloc(ctx, &ctx->tb.events, (size_t)ins_chars + 4096);
-    if (rc0) return MIA_HIP_ERR_NOMEM;
-    ctx->tb.cap_events = (int32_t)std::min<int64_t>(ins_chars + 4096, INT32_MAX);
-  }
-  int rc = ensure_tally(ctx);
-  if (rc) return rc;
-  const int Lp = ctx->tb.Lp;
-  const int64_t chars = n ? col_off[n] : 0;
-  int32_t *d_start = nullptr, *d_irec = nullptr, *d_ipos = nullptr;
-  uint8_t* d_rev = nullptr;
-  int64_t *d_coff = nullptr, *d_ioff = nullptr;
-  char *d_seq = nullptr, *d_smp = nullptr, *d_ib = nullptr;
-  ScopeFree guard;   // every temporary is released on any return
-  for (void** pp : {(void**)&d_start, (void**)&d_rev, (void**)&d_coff, (void**)&d_seq, (void**)&d_smp, (void**)&d_irec, (void**)&d_ipos,
-                    (void**)&d_ioff, (void**)&d_ib})
-    guard.watch(pp);
-  int rcx = dev_alloc(ctx, &d_start, (size_t)n + 1) | dev_alloc(ctx, &d_rev, (size_t)n + 1) | dev_alloc(ctx, &d_coff, (size_t)n + 1) |
-            dev_alloc(ctx, &d_seq, (size_t)chars + 1) | dev_alloc(ctx, &d_smp, (size_t)chars + 1) | dev_alloc(ctx, &d_irec, (size_t)n_ins + 1) |
-            dev_alloc(ctx, &d_ipos, (size_t)n_ins + 1) | dev_alloc(ctx, &d_ioff, (size_t)n_ins + 1) | dev_alloc(ctx, &d_ib, (size_t)ins_chars + 1);
-  if (rcx) return MIA_HIP_ERR_NOMEM;
-  hipError_t e = hipSuccess;
-  auto up = [&](void* d, const void* h, size_t b) { if (e == hipSuccess && b) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
-  auto zero = [&](void* d, size_t b) { if (e == hipSuccess) e = hipMemsetAsync(d, 0, b, ctx->stream); };
-  zero(ctx->tb.tally, (size_t)TALLY_WORDS * Lp * 4);
-  zero(ctx->tb.gaps, (size_t)Lp * 4);
-  zero(ctx->tb.n_events, 4);
-  zero(ctx->tb.flags, 4);
-  up(ctx->tb.gaps, gaps, (size_t)ref_len * 4);
-  up(d_start, start, (size_t)n * 4); up(d_rev, revcom, (size_t)n); up(d_coff, col_off, (size_t)(n + 1) * 8);
-  up(d_seq, seq, (size_t)chars); up(d_smp, smp, (size_t)chars);
-  if (n_ins) { up(d_irec, ins_record, (size_t)n_ins * 4); up(d_ipos, ins_pos, (size_t)n_ins * 4); up(d_ioff, ins_off, (size_t)(n_ins + 1) * 8); up(d_ib, ins_bases, (size_t)ins_chars); }
-  if (e == hipSuccess && n > 0) {
-    MaRecords mr{n, d_start, d_rev, d_coff, d_seq, d_smp};
-    hipLaunchKernelGGL(k_ma_tally, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, mr, ctx->d_pssm, ctx->tb);
-    if (n_ins > 0)
-      hipLaunchKernelGGL(k_ma_ins_events, dim3((unsigned)((n_ins + 255) / 256)), dim3(256), 0, ctx->stream, mr, n_ins, d_irec, d_ipos, d_ioff,
-                         d_ib, ctx->tb);
-    e = hipGetLastError();
-  }
-  uint32_t flags = 0;
-  if (e == hipSuccess) e = hipMemcpyAsync(&ctx->n_events_host, ctx->tb.n_events, 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&flags, ctx->tb.flags, 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) { ctx->err = std::string("ma_tally: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
-  if (flags & 1u) { ctx->err = "insert event list overflow"; return MIA_HIP_ERR_NOMEM; }
-  if (flags & 2u) { ctx->err = "a record reaches past the reference or carries a depth code outside A.._"; return MIA_HIP_ERR_ARG; }
-  if (ctx->n_events_host > ctx->tb.cap_events) ctx->n_events_host = ctx->tb.cap_events;
-  ctx->tallied = true;
-  ctx->consensus_done = false;
-  return MIA_HIP_OK;
-}
-
-extern "C" int mia_hip_get_ins_tally(mia_hip_ctx* ctx, int32_t* ins_off, int32_t* ins_tally, int64_t cap_slots, int64_t* n_slots) {
-  if (!ctx) return MIA_HIP_ERR_ARG;
-  if (!ctx->tallied || !ctx->consensus_done) { ctx->err = "consensus first"; return MIA_HIP_ERR_STATE; }
-  HIPCHK(hipSetDevice(ctx->device));
-  const int64_t total = ctx->ins_total_host;
-  if (n_slots) *n_slots = total;
-  if (ins_off) HIPCHK(hipMemcpyAsync(ins_off, ctx->d_ins_off, (size_t)ctx->tb.Lp * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (ins_tally && total > 0) {
-    if (cap_slots < total) { ctx->err = "ins_tally buffer too small"; return MIA_HIP_ERR_ARG; }
-    HIPCHK(hipMemcpyAsync(ins_tally, ctx->d_ins_tally, (size_t)total * 9 * 4, hipMemcpyDeviceToHost, ctx->stream));
-  }
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return MIA_HIP_OK;
-}
-
-// ---- pass 1 ----------------------------------------------------------------------------
-static char revcom_char_host(char b) {   // src/map_align.c:418-432
-  static const char tbl[] = "TVGH\0\0CD\0\0M\0KN\0\0\0YSAABWXR\0";
-  char r = 0;
-  if (b == '-') return '-';
-  if (b >= 'A' && b <= 'Z') r = tbl[b - 'A'];
-  else if (b >= 'a' && b <= 'z') r = (char)(tbl[b - 'a'] + 32);
-  return r ? r : 'N';
-}
-
-// populate_kpa + add_kmer (src/kmer.c:65-107,153-168): the k-mers that occur in `seq`, each with its ascending
-// positions (at most 128; further ones are silently dropped, :75-77).  Only the occurring k-mers are listed -- the
-// dense 4^k table is zeroed and filled on the device.
-static void build_kmer_lists(const std::string& seq, int k, int soft_mask, std::vector<uint32_t>& kmer, std::vector<uint32_t>& entry,
-                             std::vector<int32_t>& pos) {
-  const int n = (int)seq.size();
-  std::vector<uint64_t> kp;   // (k-mer << 32) | position: sorting keeps positions ascending inside a k-mer
-  kp.reserve((size_t)(n > 0 ? n : 1));
-  for (int i = 0; i + k <= n; i++) {
-    bool ok = true;
-    uint64_t v = 0;
-    for (int t = 0; t < k && ok; t++) {
-      char c = seq[i + t];
-      if (soft_mask && (c >= 'a' && c <= 'z')) ok = false;
-      switch (c & ~32) { case 'A': v = v << 2; break; case 'C': v = (v << 2) | 1; break; case 'G': v = (v << 2) | 2; break;
-                         case 'T': v = (v << 2) | 3; break; default: ok = false; }
-    }
-    if (ok) kp.push_back((v << 32) | (uint32_t)i);
-  }
-  std::sort(kp.begin(), kp.end());
-  kmer.clear(); entry.clear(); pos.clear();
-  for (size_t i = 0; i < kp.size();) {
-    size_t j = i;
-    while (j < kp.size() && (kp[j] >> 32) == (kp[i] >> 32)) j++;
-    const size_t cnt = (j - i) < (size_t)MAX_KMER_POS ? (j - i) : (size_t)MAX_KMER_POS;
-    kmer.push_back((uint32_t)(kp[i] >> 32));
-    entry.push_back((uint32_t)(pos.size() << 8) | (uint32_t)cnt);
-    for (size_t t = 0; t < cnt; t++) pos.push_back((int32_t)(uint32_t)kp[i + t]);
-    i = j;
-  }
-  pos.push_back(0);
-}
-
-// Lets align_all run on a borrowed read set and reference (the anchored part of pass 1) and puts the context back as it was.
-struct AlignBorrow {
-  mia_hip_ctx* c;
-  ReadSet rs; int32_t *bin_of, *list, *wide, *retry; int max_len; uint8_t* d_ref; int L, wrap, explicit_win, use_filter;
-  bool aligned, culled, tallied, pre_cull_valid, ref_mostly_bases, diag_scripts_missing;
-  int64_t kh_entries;
-  int64_t plain_total, plain_retried, filter_seen, filter_proven, bx_seen, bx_done0, bx_done1, bx_done2;
-  double stg_ms[STG_COUNT]; int64_t stg_launches[STG_COUNT];
-  explicit AlignBorrow(mia_hip_ctx* ctx)
-      : c(ctx), rs(ctx->rs), bin_of(ctx->d_bin_of), list(ctx->d_list), wide(ctx->d_wide_list), retry(ctx->d_retry_list), max_len(ctx->max_len),
-        d_ref(ctx->d_ref), L(ctx->L), wrap(ctx->wrap), explicit_win(ctx->explicit_win), use_filter(ctx->use_filter), aligned(ctx->aligned),
-        culled(ctx->culled), tallied(ctx->tallied), pre_cull_valid(ctx->pre_cull_valid), ref_mostly_bases(ctx->ref_mostly_bases),
-        diag_scripts_missing(ctx->diag_scripts_missing), kh_entries(ctx->kh_entries), plain_total(ctx->plain_total), plain_retried(ctx->plain_retried), filter_seen(ctx->filter_seen), filter_proven(ctx->filter_proven),
-        bx_seen(ctx->bx_seen), bx_done0(ctx->bx_done[0]), bx_done1(ctx->bx_done[1]), bx_done2(ctx->bx_done[2]) {
-    // the stage timers of the iteration path must not see what the borrowed runs add (bench.py's roofline reads them)
-    for (int k = 0; k < STG_COUNT; k++) {
-      if (k == STG_PASS1) continue;
-      float ms = 0;
-      for (auto& e : ctx->stg[k].pending) {
-        if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { ctx->stg[k].ms += ms; ctx->stg[k].launches++; }
-        ctx->ev_free.push_back(e);
-      }
-      ctx->stg[k].pending.clear();
-      stg_ms[k] = ctx->stg[k].ms; stg_launches[k] = ctx->stg[k].launches;
-    }
-  }
-  ~AlignBorrow() {
-    for (int k = 0; k < STG_COUNT; k++) {
-      if (k == STG_PASS1) continue;
-      for (auto& e : c->stg[k].pending) { (void)hipEventSynchronize(e.second); c->ev_free.push_back(e); }
-      c->stg[k].pending.clear();
-      c->stg[k].ms = stg_ms[k]; c->stg[k].launches = stg_launches[k];
-    }
-    c->rs = rs; c->d_bin_of = bin_of; c->d_list = list; c->d_wide_list = wide; c->d_retry_list = retry; c->max_len = max_len; c->d_ref = d_ref;
-    c->L = L; c->wrap = wrap; c->explicit_win = explicit_win; c->use_filter = use_filter; c->aligned = aligned; c->culled = culled;
-    c->tallied = tallied; c->pre_cull_valid = pre_cull_valid; c->ref_mostly_bases = ref_mostly_bases; c->kh_entries = kh_entries; c->diag_scripts_missing = diag_scripts_missing; c->plain_total = plain_total;
-    c->plain_retried = plain_retried; c->filter_seen = filter_seen; c->filter_proven = filter_proven;
-    c->bx_seen = bx_seen; c->bx_done[0] = bx_done0; c->bx_done[1] = bx_done1; c->bx_done[2] = bx_done2;
-  }
-};
-
-extern "C" int mia_hip_pass1(mia_hip_ctx* ctx, const char* ref, int32_t ref_len, int circular, int kmer_len, int soft_mask,
-                             int64_t n, const char* bases, const int64_t* offsets, int32_t* score, uint8_t* rc, int32_t* as,
-                             int32_t* ae, uint8_t* flags) {
-  if (!ctx || !ref || ref_len <= 0 || n < 0 || (n > 0 && (!bases || !offsets || !score || !rc || !as || !ae || !flags))) return MIA_HIP_ERR_ARG;
-  if (!ctx->have_pssm) { ctx->err = "set_pssm must precede pass1"; return MIA_HIP_ERR_STATE; }
-  const bool timing = getenv("MIA_HIP_P1_TIMING") != nullptr;
-  auto t_start = std::chrono::steady_clock::now();
-  auto lap = [&](const char* what) {
-    if (!timing) return;
-    auto t = std::chrono::steady_clock::now();
-    fprintf(stderr, "[mia_hip_pass1] %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_start).count());
-    t_start = t;
-  };
-  if (kmer_len > 14) { ctx->err = "Cannot use kmer length greater than 14"; return MIA_HIP_ERR_ARG; }   // MAX_KMER_LEN
-  HIPCHK(hipSetDevice(ctx->device));
-  if (n == 0) return MIA_HIP_OK;
-  PackParams pk;
-  if (!make_pack_params(1024, ctx->max_abs, &pk)) { ctx->err = "PSSM too large for the packed pass-1 kernel"; return MIA_HIP_ERR_RANGE; }
-  // reference strands: make_reverse_complement, add_ref_wrap, (k-mer tables), make_ref_upper -- src/mia_main.c:637-676
-  const int L = ref_len, wl = circular ? (L < MAX_READ ? L : MAX_READ) : 0, wrap = L + wl, len1 = circular ? wrap : L;
-  std::string fw(ref, ref + L), rcs((size_t)L, 'N');
-  for (int i = 0; i < L; i++) rcs[i] = revcom_char_host(ref[L - 1 - i]);
-  fw += fw.substr(0, wl);
-  rcs += rcs.substr(0, wl);
-  std::vector<uint8_t> cf((size_t)wrap + 64, 4), cr((size_t)wrap + 64, 4);
-  for (int i = 0; i < wrap; i++) { cf[i] = base_code((char)toupper((unsigned char)fw[i])); cr[i] = base_code((char)toupper((unsigned char)rcs[i])); }
-  // reads (as sequenced); validated before anything is allocated on the device
-  std::vector<uint32_t> roff((size_t)n);
-  std::vector<uint16_t> len((size_t)n);
-  uint64_t total = 0;
-  int max_len = 1;
-  for (int64_t i = 0; i < n; i++) {
-    int64_t l = offsets[i + 1] - offsets[i];
-    if (l < 1 || l > MIA_HIP_MAX_READ) { ctx->err = "read length outside 1..256"; return MIA_HIP_ERR_ARG; }
-    roff[i] = (uint32_t)total; len[i] = (uint16_t)l;
-    if (l > max_len) max_len = (int)l;
-    total += (uint64_t)(((l + 1) / 2 + 3) & ~3);
-    if (total >= ((uint64_t)1 << 32)) { ctx->err = "packed read store exceeds 4 GiB per call"; return MIA_HIP_ERR_ARG; }
-  }
-  // Chunk width.  Dropping candidates further left than the horizon `rel` is exact only if they can never beat a
-  // new start: a score is at most rows * max positive entry, a new start costs P(rows+1), a gap of >= rel-1 columns
-  // costs P(rel-1).  Wide chunks (768 columns, horizon 256) for the unmasked sweep when that holds, else narrow
-  // ones (256 columns, horizon 768), which also skip masked stretches at a finer grain.
-  auto horizon_ok = [&](int rel) {
-    return (int64_t)max_len * ctx->max_pos + (GOP + GEP * (max_len + 1)) < (int64_t)(GOP + GEP * (rel - 1));
-  };
-  int cpl = (kmer_len <= 0 && horizon_ok(p1_rel(P1_CPL_WIDE))) ? P1_CPL_WIDE : P1_CPL_NARROW;
-  if (const char* ev = getenv("MIA_HIP_P1_CPL")) {
-    const int want = atoi(ev);
-    if ((want == P1_CPL_WIDE && horizon_ok(p1_rel(P1_CPL_WIDE))) || want == P1_CPL_NARROW) cpl = want;
-  }
-  if (!horizon_ok(p1_rel(cpl))) { ctx->err = "PSSM too large for the pass-1 candidate horizon"; return MIA_HIP_ERR_RANGE; }
-  const int P1_CH = p1_ch(cpl);
-  // the wide unmasked sweep runs on plain keys (pass1_body.h, run_plain); MIA_HIP_P1_PLAIN=0 keeps the packed sweep
-  int plain = 1;
-  if (const char* ev = getenv("MIA_HIP_P1_PLAIN")) plain = atoi(ev) != 0;
-  if (kmer_len > 0 && (size_t)wrap >= ((size_t)1 << 24)) { ctx->err = "reference too long for the k-mer table"; return MIA_HIP_ERR_RANGE; }
-  uint8_t *d_cf = nullptr, *d_cr = nullptr;
-  uint32_t *d_tab[2] = {nullptr, nullptr}, *d_kl[2] = {nullptr, nullptr}, *d_el[2] = {nullptr, nullptr};
-  int32_t* d_pos[2] = {nullptr, nullptr};
-  uint8_t *d_packed = nullptr, *d_rc = nullptr, *d_flags = nullptr;
-  uint32_t *d_roff = nullptr, *d_status = nullptr;
-  uint16_t* d_len = nullptr;
-  int32_t *d_score = nullptr, *d_as = nullptr, *d_ae = nullptr;
-  unsigned char* d_trace = nullptr;
-  uint32_t* d_ckpt = nullptr;
-  uint64_t* d_p1planes = nullptr;
-  int32_t *d_p1kcnt = nullptr, *d_p1kpos = nullptr;
-  int32_t* d_todo = nullptr;
-  uint32_t* d_ntodo = nullptr;
-  PoolScope guard(ctx);   // every temporary below goes back to the context's pool on any return
-  guard.watch((void**)&d_p1planes); guard.watch((void**)&d_todo); guard.watch((void**)&d_ntodo); guard.watch((void**)&d_p1kcnt); guard.watch((void**)&d_p1kpos);
-  for (void** pp : {(void**)&d_cf, (void**)&d_cr, (void**)&d_tab[0], (void**)&d_tab[1], (void**)&d_kl[0], (void**)&d_kl[1], (void**)&d_el[0],
-                    (void**)&d_el[1], (void**)&d_pos[0], (void**)&d_pos[1], (void**)&d_packed, (void**)&d_rc, (void**)&d_flags, (void**)&d_roff,
-                    (void**)&d_status, (void**)&d_len, (void**)&d_score, (void**)&d_as, (void**)&d_ae, (void**)&d_trace, (void**)&d_ckpt})
-    guard.watch(pp);
-  int rcx = pool_alloc(ctx, &d_cf, cf.size()) | pool_alloc(ctx, &d_cr, cr.size());
-  KmerIndex kx{};
-  kx.k = kmer_len > 0 ? kmer_len : -1;
-  if (kx.k > 0 && !rcx) {
-    const size_t nk = (size_t)1 << (2 * kx.k);
-    for (int s = 0; s < 2 && !rcx; s++) {
-      std::vector<uint32_t> kmer, entry;
-      std::vector<int32_t> pos;
-      build_kmer_lists(s ? rcs : fw, kx.k, soft_mask, kmer, entry, pos);
-      const size_t ne = kmer.size();
-      rcx |= pool_alloc(ctx, &d_tab[s], nk) | pool_alloc(ctx, &d_pos[s], pos.size()) | pool_alloc(ctx, &d_kl[s], ne + 1) |
-             pool_alloc(ctx, &d_el[s], ne + 1);
-      if (rcx) break;
-      hipError_t ke = hipMemsetAsync(d_tab[s], 0, nk * 4, ctx->stream);
-      if (ke == hipSuccess) ke = hipMemcpy(d_pos[s], pos.data(), pos.size() * 4, hipMemcpyHostToDevice);
-      if (ke == hipSuccess && ne) ke = hipMemcpy(d_kl[s], kmer.data(), ne * 4, hipMemcpyHostToDevice);
-      if (ke == hipSuccess && ne) ke = hipMemcpy(d_el[s], entry.data(), ne * 4, hipMemcpyHostToDevice);
-      if (ke == hipSuccess && ne) {
-        hipLaunchKernelGGL(k_kmer_fill, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, (int32_t)ne, d_kl[s], d_el[s], d_tab[s]);
-        ke = hipGetLastError();
-      }
-      if (ke != hipSuccess) { ctx->err = std::string("pass1 k-mer table: ") + hipGetErrorString(ke); rcx = 2; }
-      kx.tab[s] = d_tab[s];
-      kx.pos[s] = d_pos[s];
-    }
-  }
-  lap("ref+kmer");
-  std::vector<uint8_t> packed((size_t)total + 8, 0);
-  pack_reads(n, bases, offsets, roff.data(), len.data(), packed.data());
-  rcx |= pool_alloc(ctx, &d_packed, packed.size()) | pool_alloc(ctx, &d_roff, (size_t)n) | pool_alloc(ctx, &d_len, (size_t)n) |
-         pool_alloc(ctx, &d_rc, (size_t)n) | pool_alloc(ctx, &d_flags, (size_t)n) | pool_alloc(ctx, &d_status, (size_t)n) |
-         pool_alloc(ctx, &d_score, (size_t)n) | pool_alloc(ctx, &d_as, (size_t)n) | pool_alloc(ctx, &d_ae, (size_t)n);
-  // persistent grid; LDS: sub table + 5 carry arrays + 2 column masks
-  // (the column masks are only read when the k-mer filter is on)
-  const int nch = (len1 + P1_CH - 1) / P1_CH, mask_words = kmer_len > 0 ? nch * (P1_CH / 32) + 4 : 0;
-  const int lds = MAX_READ * 10 + 5 * MAX_READ * 4 + 2 * mask_words * 4;
-  const int rows_p = (max_len + 3) & ~3;
-  const int64_t trace_bytes = (int64_t)rows_p * P1_CH * 2, ckpt_words = (int64_t)2 * nch * 5 * rows_p;
-  if (lds > 160 * 1024) { ctx->err = "reference too long for the pass-1 LDS masks"; return MIA_HIP_ERR_RANGE; }
-  // persistent grid = exactly the waves that are resident at once (registers AND LDS): a wave that only starts
-  // when another has drained would run its whole share of the reads on a nearly idle GPU
-  auto kfn = (cpl == P1_CPL_WIDE) ? k_pass1<P1_CPL_WIDE> : k_pass1<P1_CPL_NARROW>;
-  HIPCHK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  int waves_cu = 0;
-  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&waves_cu, (const void*)kfn, 64, (size_t)lds));
-  if (waves_cu < 1) { ctx->err = "pass-1 kernel does not fit a compute unit"; return MIA_HIP_ERR_RANGE; }
-  // whole waves per SIMD only: an uneven remainder (13 = 4+3+3+3) measured slower than 12, the extra workgroups start late
-  if (waves_cu > 4) waves_cu &= ~3;
-  if (const char* ev = getenv("MIA_HIP_P1_WAVES_PER_CU")) { const int wv = atoi(ev); if (wv > 0 && wv < waves_cu) waves_cu = wv; }
-  if (timing) fprintf(stderr, "[mia_hip_pass1] cpl %d plain %d waves/CU %d lds %d\n", cpl, plain, waves_cu, lds);
-  hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
-  int64_t grid = (int64_t)prop.multiProcessorCount * waves_cu;
-  if (grid > n) grid = n;
-  rcx |= pool_alloc(ctx, &d_trace, (size_t)(trace_bytes * grid)) | pool_alloc(ctx, &d_ckpt, (size_t)(ckpt_words * grid));
-  if (rcx) return rcx == 2 ? MIA_HIP_ERR_DEVICE : MIA_HIP_ERR_NOMEM;
-  lap("pack+alloc");
-  hipError_t e = hipSuccess;
-  bool p1_timed = false;
-  auto cp = [&](void* d, const void* h, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(d, h, b, hipMemcpyHostToDevice, ctx->stream); };
-  cp(d_cf, cf.data(), cf.size()); cp(d_cr, cr.data(), cr.size());
-  cp(d_packed, packed.data(), packed.size()); cp(d_roff, roff.data(), (size_t)n * 4); cp(d_len, len.data(), (size_t)n * 2);
-  // The diagonal filter (diag_filter.h) first, when its premises hold: flat matrix and no k-mer mask (a masked DP is a
-  // different recurrence).  It decides most reads by bit-parallel comparison against every diagonal of both strands;
-  // the whole-reference DP then runs on what is left.
-  int64_t p1_other = 0;
-  for (int i = 0; i < L; i++) p1_other += cf[(size_t)i] > 3;
-  const bool fast_ok = ctx->flat && ctx->use_filter && kmer_len <= 0 && len1 >= max_len;
-  // any other matrix the band pipeline has tables for: the anchored windows in losses (mia_pass1_kernels.h, GEN); the
-  // diagonal filter stays the flat matrix's
-  const bool gen_ok = !ctx->flat && ctx->bx_ok && ctx->use_bx && ctx->use_filter && kmer_len <= 0 && len1 >= max_len && !getenv("MIA_HIP_NO_ANCHOR_GEN");
-  const bool filtered = fast_ok && p1_other * 50 <= L;
-  // the anchored stage behind it (or in its place: a reference full of ambiguity codes, mt311 itself, leaves the filter
-  // nothing to decide): the windows' 10-mer tables list the N columns under every spelling (bandx_body.h, N COLUMNS)
-  int64_t wild_entries = 0;
-  if ((fast_ok || gen_ok) && p1_other && ctx->use_wild && len1 <= (1 << 22)) {
-    std::vector<uint8_t> both(cf.begin(), cf.begin() + len1);
-    both.insert(both.end(), cr.begin(), cr.begin() + len1);
-    wild_entries = kh_wild_entries(both.data(), (int64_t)both.size(), BX_WILD);
-    if (wild_entries > ((int64_t)1 << 24)) wild_entries = 0;
-  }
-  const bool anchored_ok = (fast_ok || gen_ok) && (p1_other == 0 || wild_entries > 0) && len1 <= (1 << 22) && !getenv("MIA_HIP_NO_ANCHOR");
-  int64_t n_dp = n;
-  ctx->pass1_filtered = 0;
-  ctx->pass1_anchored = 0;
-  if (e == hipSuccess) {
-    Pass1Reads pr{n, d_packed, d_roff, d_len, d_score, d_as, d_ae, d_rc, d_flags, d_status};
-    drain_events(ctx);                       // (nothing of an earlier call may sit in the pass-1 timer)
-    p1_timed = ((ctx->stage_mask >> STG_PASS1) & 1u) && stage_begin(ctx, STG_PASS1) == 0;
-    if (filtered || anchored_ok) {
-      if (pool_alloc(ctx, &d_todo, (size_t)n) || pool_alloc(ctx, &d_ntodo, 1)) return MIA_HIP_ERR_NOMEM;
-      if (len1 <= (1 << 22) && (pool_alloc(ctx, &d_p1kcnt, (size_t)DF_KTAB * 2) || pool_alloc(ctx, &d_p1kpos, (size_t)DF_KTAB * DF_KCAP * 2))) return MIA_HIP_ERR_NOMEM;
-    }
-    if (!filtered && anchored_ok) hipLaunchKernelGGL(k_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, d_todo);
-    if (filtered) {
-      const int64_t words = plane_words(len1);
-      if (pool_alloc(ctx, &d_p1planes, (size_t)words * 6)) return MIA_HIP_ERR_NOMEM;
-      uint64_t* pl = d_p1planes;
-      hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 3) / 4 < 4096 ? (words + 3) / 4 : 4096)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, words, pl, pl + words, pl + 2 * words);
-      hipLaunchKernelGGL(k_ref_planes, dim3((unsigned)((words + 3) / 4 < 4096 ? (words + 3) / 4 : 4096)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, words, pl + 3 * words, pl + 4 * words, pl + 5 * words);
-      e = hipMemsetAsync(d_ntodo, 0, 4, ctx->stream);
-      RefPlanes pf{pl, pl + words, pl + 2 * words}, prc{pl + 3 * words, pl + 4 * words, pl + 5 * words};
-      // 10-mer tables of both strands for rule (c) (diag_filter.h: KmerOcc)
-      KmerOcc kf{nullptr, nullptr}, kr{nullptr, nullptr};
-      if (d_p1kcnt) {
-        if (e == hipSuccess) e = hipMemsetAsync(d_p1kcnt, 0, (size_t)DF_KTAB * 2 * 4, ctx->stream);
-        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, d_p1kcnt, d_p1kpos, 0);
-        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, d_p1kcnt + DF_KTAB,
-                           d_p1kpos + DF_KTAB * DF_KCAP, 0);
-        kf.cnt = d_p1kcnt; kf.pos = d_p1kpos; kr.cnt = d_p1kcnt + DF_KTAB; kr.pos = d_p1kpos + DF_KTAB * DF_KCAP;
-      }
-      hipLaunchKernelGGL(k_pass1_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, pr, pf, prc, kf, kr, len1, L, d_todo, d_ntodo);
-      if (e == hipSuccess) e = hipGetLastError();
-      uint32_t h_ntodo = 0;
-      if (e == hipSuccess) e = hipMemcpyAsync(&h_ntodo, d_ntodo, 4, hipMemcpyDeviceToHost, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      n_dp = h_ntodo;
-      ctx->pass1_filtered = n - n_dp;
-      if (timing) fprintf(stderr, "[mia_hip_pass1] diagonal filter: %lld of %lld reads decided\n", (long long)(n - n_dp), (long long)n);
-    }
-    // Anchored stage (mia_pass1_kernels.h): what the filter left over is aligned in +-50 windows around the places where
-    // six 10-mers of the read occur -- provably the same result as the whole-strand DP when the budget check of
-    // k_pass1_select holds; everything else goes on to k_pass1.  Needs both strands free of N (a 10-mer with an N is not
-    // in the table and an N column costs less than a mismatch).
-    if (e == hipSuccess && anchored_ok && n_dp > 0 && d_p1kcnt) {
-      if (p1_other || !filtered) {            // the anchors' tables: with the N columns' spellings (the filter's rule (c) wants them without)
-        HIPCHK(hipMemsetAsync(d_p1kcnt, 0, (size_t)DF_KTAB * 2 * 4, ctx->stream));
-        const int wild = p1_other ? BX_WILD : 0;
-        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cf, (int64_t)len1, d_p1kcnt, d_p1kpos, wild);
-        hipLaunchKernelGGL(k_kmer_occ, dim3((unsigned)((len1 + 255) / 256)), dim3(256), 0, ctx->stream, d_cr, (int64_t)len1, d_p1kcnt + DF_KTAB,
-                           d_p1kpos + DF_KTAB * DF_KCAP, wild);
-      }
-      const int64_t m = n_dp * P1A_SLOTS;
-      const int stride = (max_len + 3) & ~3;
-      // one allocation for all the temporaries of this stage (twenty separate ones cost more than the stage)
-      unsigned char* arena = nullptr;
-      PoolScope g2(ctx);
-      g2.watch((void**)&arena);
-      size_t top = 0;
-      auto carve = [&](size_t bytes) { const size_t at = top; top += (bytes + 255) & ~(size_t)255; return at; };
-      const size_t o_roff = carve((size_t)m * 4), o_status = carve((size_t)m * 4), o_nrest = carve(64), o_len = carve((size_t)m * 2),
-                   o_rc = carve((size_t)m), o_sk = carve((size_t)m), o_ref2 = carve((size_t)2 * len1 + 64), o_as = carve((size_t)m * 4),
-                   o_ae = carve((size_t)m * 4), o_score = carve((size_t)m * 4), o_refstart = carve((size_t)m * 4), o_bin = carve((size_t)m * 4),
-                   o_list = carve(((size_t)m + 4 * N_BINS) * 4), o_wide = carve((size_t)m * 4), o_retry = carve((size_t)m * 4),
-                   o_rest = carve((size_t)n_dp * 4), o_abr = carve((size_t)m * 2), o_cols = carve((size_t)m * stride * 2),
-                   o_bound = carve((size_t)n_dp * 4), o_budget = carve((size_t)n_dp * 4), o_u = carve((size_t)n_dp * 4);
-      if (pool_alloc(ctx, &arena, top)) return MIA_HIP_ERR_NOMEM;
-      uint32_t *w_roff = (uint32_t*)(arena + o_roff), *w_status = (uint32_t*)(arena + o_status), *d_nrest = (uint32_t*)(arena + o_nrest);
-      uint16_t* w_len = (uint16_t*)(arena + o_len);
-      uint8_t *w_rc = arena + o_rc, *w_sk = arena + o_sk, *d_ref2 = arena + o_ref2;
-      int32_t *w_as = (int32_t*)(arena + o_as), *w_ae = (int32_t*)(arena + o_ae), *w_score = (int32_t*)(arena + o_score),
-              *w_refstart = (int32_t*)(arena + o_refstart), *w_bin = (int32_t*)(arena + o_bin), *w_list = (int32_t*)(arena + o_list),
-              *w_wide = (int32_t*)(arena + o_wide), *w_retry = (int32_t*)(arena + o_retry), *d_rest = (int32_t*)(arena + o_rest),
-              *w_bound = (int32_t*)(arena + o_bound), *w_budget = (int32_t*)(arena + o_budget), *w_u = (int32_t*)(arena + o_u);
-      int16_t *w_abr = (int16_t*)(arena + o_abr), *w_cols = (int16_t*)(arena + o_cols);
-      HIPCHK(hipMemsetAsync(w_rc, 0, (size_t)m, ctx->stream));
-      HIPCHK(hipMemsetAsync(w_abr, 0, (size_t)m * 2, ctx->stream));
-      HIPCHK(hipMemsetAsync(w_status, 0, (size_t)m * 4, ctx->stream));
-      HIPCHK(hipMemsetAsync(w_score, 0, (size_t)m * 4, ctx->stream));
-      HIPCHK(hipMemsetAsync(d_nrest, 0, 64, ctx->stream));
-      HIPCHK(hipMemsetAsync(d_ref2, 4, (size_t)2 * len1 + 64, ctx->stream));
-      HIPCHK(hipMemcpyAsync(d_ref2, d_cf, (size_t)len1, hipMemcpyDeviceToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(d_ref2 + len1, d_cr, (size_t)len1, hipMemcpyDeviceToDevice, ctx->stream));
-      KmerOcc kf{d_p1kcnt, d_p1kpos}, kr{d_p1kcnt + DF_KTAB, d_p1kpos + DF_KTAB * DF_KCAP};
-      BxTab p1tab;
-      p1tab.sub = ctx->d_bx_sub; p1tab.mrow = ctx->d_bx_mrow; p1tab.loss = ctx->d_bx_loss; p1tab.dl = ctx->d_bx_dl; p1tab.min_m = ctx->bx_min_m; p1tab.max_m = ctx->bx_max_m;
-      if (ctx->flat)
-        hipLaunchKernelGGL(k_pass1_anchor<false>, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, kf, kr, len1, w_roff, w_len,
-                           w_sk, w_as, w_ae, w_bound, w_budget, w_u, p1tab);
-      else
-        hipLaunchKernelGGL(k_pass1_anchor<true>, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, kf, kr, len1, w_roff, w_len,
-                           w_sk, w_as, w_ae, w_bound, w_budget, w_u, p1tab);
-      HIPCHK(hipGetLastError());
-      int rc_inner;
-      {
-        AlignBorrow borrow(ctx);
-        ReadSet& r = ctx->rs;
-        r.n = m; r.packed = d_packed; r.roff = w_roff; r.len = w_len; r.rc = w_rc; r.sk = w_sk; r.as = w_as; r.ae = w_ae; r.score = w_score;
-        r.refstart = w_refstart; r.abr = w_abr; r.status = w_status; r.cols = w_cols; r.stride = stride;
-        ctx->d_bin_of = w_bin; ctx->d_list = w_list; ctx->d_wide_list = w_wide; ctx->d_retry_list = w_retry; ctx->max_len = max_len;
-        ctx->d_ref = d_ref2; ctx->L = 2 * len1; ctx->wrap = 2 * len1; ctx->explicit_win = 1; ctx->use_filter = 0;
-        ctx->ref_mostly_bases = p1_other * 50 <= L; ctx->kh_entries = wild_entries;
-        ctx->wide_to_caller = true;
-        rc_inner = align_all(ctx);
-        ctx->wide_to_caller = false;
-      }
-      if (rc_inner != MIA_HIP_OK) return rc_inner;
-      hipLaunchKernelGGL(k_pass1_select, dim3((unsigned)((n_dp + 255) / 256)), dim3(256), 0, ctx->stream, pr, d_todo, n_dp, len1, L, w_sk, w_score, w_as,
-                         w_ae, w_abr, w_status, w_bound, w_budget, w_u, d_rest, d_nrest);
-      HIPCHK(hipGetLastError());
-      uint32_t h_rest[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      HIPCHK(hipMemcpyAsync(h_rest, d_nrest, 64, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      const uint32_t h_nrest = h_rest[0];
-      if (timing) fprintf(stderr, "[mia_hip_pass1] left to the whole-strand DP: %u no cluster, %u unfinished windows, %u clipped, %u over budget, %u weak clusters\n",
-                          h_rest[1], h_rest[2], h_rest[3], h_rest[4], h_rest[5]);
-      if (timing) fprintf(stderr, "[mia_hip_pass1] no cluster: %u reads with N, %u too few blocks, %u too many clusters, %u too wide, %u too many strong, %u none strong, %u no room\n",
-                          h_rest[9], h_rest[10], h_rest[11], h_rest[12], h_rest[13], h_rest[14], h_rest[15]);
-      // the survivors' list replaces the filter's (d_todo is at least as long)
-      HIPCHK(hipMemcpyAsync(d_todo, d_rest, (size_t)h_nrest * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      ctx->pass1_anchored = n_dp - h_nrest;
-      if (timing) fprintf(stderr, "[mia_hip_pass1] anchored windows: %lld of %lld left-over reads decided\n", (long long)(n_dp - h_nrest), (long long)n_dp);
-      n_dp = h_nrest;
-    }
-    if (e == hipSuccess && n_dp > 0) {
-      const int64_t g = grid < n_dp ? grid : n_dp;
-      hipLaunchKernelGGL(kfn, dim3((unsigned)g), dim3(64), lds, ctx->stream, pr, d_cf, d_cr, len1, L, ctx->d_pssm, pk, kx, d_trace,
-                         trace_bytes, d_ckpt, ckpt_words, rows_p, mask_words, plain, (filtered || anchored_ok) ? d_todo : nullptr, n_dp);
-      e = hipGetLastError();
-    }
-    if (p1_timed) stage_end(ctx, STG_PASS1);
-  }
-  auto back = [&](void* h, const void* d, size_t b) { if (e == hipSuccess) e = hipMemcpyAsync(h, d, b, hipMemcpyDeviceToHost, ctx->stream); };
-  back(score, d_score, (size_t)n * 4); back(as, d_as, (size_t)n * 4); back(ae, d_ae, (size_t)n * 4);
-  back(rc, d_rc, (size_t)n); back(flags, d_flags, (size_t)n);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  lap("h2d+kernel+d2h");
-  if (p1_timed && !ctx->stg[STG_PASS1].pending.empty()) {
-    // the whole call's device time (filter, anchored windows and DP), measured on the pair taken above
-    const auto pr = ctx->stg[STG_PASS1].pending.back();
-    float ms = 0;
-    if (e == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ctx->pass1_ms = ms;
-  }
-  lap("done");
-  if (e != hipSuccess) { ctx->err = std::string("pass1: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
-  return MIA_HIP_OK;
-}
-
-// ---- Myers ------------------------------------------------------------------------------
-extern "C" int mia_hip_myers(mia_hip_ctx* ctx, int64_t n, const char* const* seq_a, const char* const* seq_b, const int32_t* mode,
-                             const int32_t* maxd, uint32_t* dist) {
-  if (!ctx || n < 0 || (n > 0 && (!seq_a || !seq_b || !mode || !maxd || !dist))) return MIA_HIP_ERR_ARG;
-  HIPCHK(hipSetDevice(ctx->device));
-  if (n == 0) return MIA_HIP_OK;
-  // two kinds of pair: seq_a of up to 320 characters -- one pair per lane (k_myers_lanes), sequences packed as 4-bit IUPAC
-  // bitmaps -- and longer ones, one pair per wavefront (k_myers), as ASCII
-  static const struct Bits { uint8_t t[256]; Bits() { for (int c = 0; c < 256; c++) t[c] = (uint8_t)iupac_bits((char)c); } } bits;
-  std::vector<MyersPair> pairs;
-  std::vector<MyersLanePair> lp;
-  std::vector<int32_t> long_index, lane_index;
-  std::vector<uint32_t> codes;
-  std::string blob;
-  std::vector<size_t> oa, ob;
-  int max_blk = 1;
-  // lengths first (on all host threads: a hundred thousand strlen calls and forty million characters to pack are most of
-  // this call's time next to a 0.3 ms kernel), then the offsets, then the packing into the places they name
-  std::vector<uint32_t> la_of((size_t)n), lb_of((size_t)n);
-  int T = (int)std::thread::hardware_concurrency();
-  T = std::max(1, std::min(std::min(T, 32), (int)(n / 2048) + 1));
-  auto parallel = [&](auto&& fn) {
-    if (T == 1) { fn(0); return; }
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; t++) th.emplace_back([&fn, t] { fn(t); });
-    fn(0);
-    for (auto& x : th) x.join();
-  };
-  bool too_long = false;
-  parallel([&](int t) {
-    for (int64_t i = n * t / T, hi = n * (t + 1) / T; i < hi; i++) {
-      const size_t la = strlen(seq_a[i]), lb = strlen(seq_b[i]);
-      if (la > 64u * 64u * MYERS_MAX_K || lb >= ((size_t)1 << 31)) { too_long = true; la_of[(size_t)i] = 0; lb_of[(size_t)i] = 0; continue; }
-      la_of[(size_t)i] = (uint32_t)la; lb_of[(size_t)i] = (uint32_t)lb;
-    }
-  });
-  if (too_long) { ctx->err = "seq_a longer than 32768 characters"; return MIA_HIP_ERR_ARG; }
-  std::vector<uint32_t> word_off((size_t)n, 0);
-  {
-    uint64_t words = 0;
-    for (int64_t i = 0; i < n; i++) {
-      const size_t la = la_of[(size_t)i], lb = lb_of[(size_t)i];
-      const uint64_t need = (la + 7) / 8 + 1 + (lb + 7) / 8 + 1;       // (one spare word behind each sequence: the kernel may fetch it)
-      if (la <= 64u * MYERS_LANE_K && words + need < ((uint64_t)1 << 31) && !ctx->myers_no_lanes) {
-        MyersLanePair q;
-        q.a_off = (uint32_t)words; q.b_off = (uint32_t)(words + (la + 7) / 8 + 1);
-        q.la = (int32_t)la; q.lb = (int32_t)lb; q.mode = mode[i]; q.maxd = maxd[i];
-        word_off[(size_t)i] = (uint32_t)words;
-        words += need;
-        lp.push_back(q);
-        lane_index.push_back((int32_t)i);
-      } else {
-        MyersPair q;
-        oa.push_back(blob.size()); blob.append(seq_a[i], la);
-        ob.push_back(blob.size()); blob.append(seq_b[i], lb);
-        q.a = nullptr; q.b = nullptr;
-        q.la = (int32_t)la; q.lb = (int32_t)lb; q.mode = mode[i]; q.maxd = maxd[i];
-        pairs.push_back(q);
-        long_index.push_back((int32_t)i);
-        const int nb = (int)((la + 63) / 64);
-        if (nb > max_blk) max_blk = nb;
-      }
-    }
-    codes.assign((size_t)words, 0u);
-  }
-  {
-    const size_t nlp = lp.size();
-    parallel([&](int t) {
-      for (size_t k = nlp * (size_t)t / (size_t)T, hi = nlp * (size_t)(t + 1) / (size_t)T; k < hi; k++) {
-        const MyersLanePair& q = lp[k];
-        const int64_t i = lane_index[k];
-        for (int side = 0; side < 2; side++) {
-          const unsigned char* s2 = reinterpret_cast<const unsigned char*>(side ? seq_b[i] : seq_a[i]);
-          const size_t len = side ? (size_t)q.lb : (size_t)q.la;
-          uint32_t* dst = codes.data() + (side ? q.b_off : q.a_off);
-          for (size_t w = 0; w < (len + 7) / 8; w++) {
-            uint32_t v = 0;
-            const size_t lim = std::min<size_t>(8, len - w * 8);
-            for (size_t c = 0; c < lim; c++) v |= (uint32_t)bits.t[s2[w * 8 + c]] << (4 * c);
-            dst[w] = v;
-          }
-        }
-      }
-    });
-  }
-  char* d_blob = nullptr;
-  MyersPair* d_pairs = nullptr;
-  MyersLanePair* d_lp = nullptr;
-  uint32_t *d_out = nullptr, *d_out_long = nullptr, *d_codes = nullptr;
-  int32_t* d_index = nullptr;
-  PoolScope guard(ctx);
-  guard.watch((void**)&d_blob); guard.watch((void**)&d_pairs); guard.watch((void**)&d_out); guard.watch((void**)&d_lp); guard.watch((void**)&d_codes);
-  guard.watch((void**)&d_index); guard.watch((void**)&d_out_long);
-  const size_t nl = lp.size(), ng = pairs.size();
-  if (pool_alloc(ctx, &d_out, (size_t)n)) return MIA_HIP_ERR_NOMEM;
-  hipError_t e = hipSuccess;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  if (nl) {
-    if (pool_alloc(ctx, &d_lp, nl) || pool_alloc(ctx, &d_codes, codes.size() + 8) || pool_alloc(ctx, &d_index, nl)) return MIA_HIP_ERR_NOMEM;
-    e = hipMemcpyAsync(d_lp, lp.data(), nl * sizeof(MyersLanePair), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_codes, codes.data(), codes.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_index, lane_index.data(), nl * 4, hipMemcpyHostToDevice, ctx->stream);
-  }
-  if (ng && e == hipSuccess) {
-    if (pool_alloc(ctx, &d_blob, blob.size() + 1) || pool_alloc(ctx, &d_pairs, ng) || pool_alloc(ctx, &d_out_long, ng)) return MIA_HIP_ERR_NOMEM;
-    for (size_t i = 0; i < ng; i++) { pairs[i].a = d_blob + oa[i]; pairs[i].b = d_blob + ob[i]; }
-    e = hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_pairs, pairs.data(), ng * sizeof(MyersPair), hipMemcpyHostToDevice, ctx->stream);
-  }
-  if (e0) (void)hipEventRecord(e0, ctx->stream);
-  if (nl && e == hipSuccess) {
-    hipLaunchKernelGGL(k_myers_lanes, dim3((unsigned)((nl + 63) / 64)), dim3(64), 0, ctx->stream, (const MyersLanePair*)d_lp, (const uint32_t*)d_codes, (int32_t)nl,
-                       (const int32_t*)d_index, d_out);
-    e = hipGetLastError();
-  }
-  if (ng && e == hipSuccess) {
-    const int lds = 16 * max_blk * 8;
-    e = hipFuncSetAttribute((const void*)k_myers, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) {
-      const int grid = (int)(ng < 8192 ? ng : 8192);
-      hipLaunchKernelGGL(k_myers, dim3(grid), dim3(64), lds, ctx->stream, d_pairs, (int32_t)ng, d_out_long);
-      e = hipGetLastError();
-    }
-  }
-  if (e1) (void)hipEventRecord(e1, ctx->stream);
-  std::vector<uint32_t> out_long(ng);
-  if (e == hipSuccess && nl) e = hipMemcpyAsync(dist, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);      // (the long pairs' entries are filled in below)
-  if (e == hipSuccess && ng) e = hipMemcpyAsync(out_long.data(), d_out_long, ng * 4, hipMemcpyDeviceToHost, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e == hipSuccess && e0 && e1) { float ms = 0; if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->myers_kernel_ms = ms; }
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  if (e != hipSuccess) { ctx->err = std::string("myers: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
-  for (size_t i = 0; i < ng; i++) dist[long_index[i]] = out_long[i];
-  return MIA_HIP_OK;
-}
-
-extern "C" int mia_hip_myers_time(mia_hip_ctx* ctx, double* kernel_ms) {
-  if (!ctx || !kernel_ms) return MIA_HIP_ERR_ARG;
-  *kernel_ms = ctx->myers_kernel_ms;
-  return MIA_HIP_OK;
-}
-
-// The alignment behind a distance the device has already established: Myers' furthest-reaching D-paths (1986) for
-// D = 0 .. dist, then the walk back with the reference's preferences (mismatch, then a seq_b-only column, then a
-// seq_a-only column, else one step down the snake; src/myers_align.c:47-83).  Host code: the table has (dist+1)^2
-// cells and is walked once; the O(len * dist / 64) search for `dist` itself ran on the GPU.
-static bool ond_backtrace(const char* a, int la, const char* b, int lb, int mode, int dist, std::string* row_a, std::string* row_b) {
-  const int NONE = INT32_MIN / 2;
-  auto bits = [](char c) { return (int)iupac_bits(c); };
-  std::vector<int> v((size_t)(dist + 1) * (size_t)(dist + 1), NONE);   // row d starts at d*d, diagonal k at index k+d
-  auto at = [&](int d, int k) -> int { return (k < -d || k > d) ? NONE : v[(size_t)d * d + (size_t)(k + d)]; };
-  int end_k = 0;
-  bool found = false;
-  for (int d = 0; d <= dist && !found; d++) {
-    const int klo = -d > -la ? -d : -la, khi = d < lb ? d : lb;
-    for (int k = klo; k <= khi; k++) {
-      int x = 0;
-      if (d > 0) {
-        const int keep = at(d - 1, k), from_left = at(d - 1, k - 1), from_right = at(d - 1, k + 1);
-        x = keep == NONE ? NONE : keep + 1;
-        if (from_left != NONE && from_left + 1 > x) x = from_left + 1;
-        if (from_right != NONE && from_right > x) x = from_right;
-        if (x == NONE) continue;
-      }
-      int y = x - k;
-      while (x < lb && y < la && x >= 0 && y >= 0 && (bits(b[x]) & bits(a[y]))) { x++; y++; }
-      v[(size_t)d * d + (size_t)(k + d)] = x;
-      if ((mode == 1 || y == la) && (mode == 2 || x == lb)) {
-        if (d != dist) return false;
-        end_k = k; found = true;
-        break;
-      }
-    }
-  }
-  if (!found) return false;
-  std::string ra, rb;   // built back to front
-  // In the prefix modes a D-path may run past the end of the sequence that need not be consumed (the recurrence has no
-  // bound there, src/myers_align.c:26-32): the reference then copies that sequence's terminator into the row, which
-  // ends the C string early.  Same here, without reading past the terminator.
-  auto ca = [&](int y) { return y < la ? a[y] : '\0'; };
-  auto cb = [&](int x) { return x < lb ? b[x] : '\0'; };
-  int k = end_k, x = at(dist, k), y = x - k;
-  for (int d = dist; d != 0;) {
-    if (k != -d && k != d && x == at(d - 1, k) + 1) { d--; x--; y--; rb.push_back(cb(x)); ra.push_back(ca(y)); }
-    else if (k > -d + 1 && x == at(d - 1, k - 1) + 1) { x--; k--; d--; rb.push_back(cb(x)); ra.push_back('-'); }
-    else if (k < d - 1 && x == at(d - 1, k + 1)) { k++; y--; d--; rb.push_back('-'); ra.push_back(ca(y)); }
-    else { x--; y--; rb.push_back(cb(x)); ra.push_back(ca(y)); }
-    if (x < 0 || y < 0) return false;
-  }
-  while (x > 0) { x--; rb.push_back(cb(x)); ra.push_back(ca(x)); }
-  row_a->assign(ra.rbegin(), ra.rend());
-  row_b->assign(rb.rbegin(), rb.rend());
-  return true;
-}
-
-extern "C" int mia_hip_myers_align(mia_hip_ctx* ctx, const char* seq_a, int32_t mode, const char* seq_b, int32_t maxd, uint32_t* dist,
-                                   char* bt_a, char* bt_b) {
-  if (!ctx || !seq_a || !seq_b || !dist || mode < 0 || mode > 2) return MIA_HIP_ERR_ARG;
-  const int rc = mia_hip_myers(ctx, 1, &seq_a, &seq_b, &mode, &maxd, dist);
-  if (rc != MIA_HIP_OK || *dist == 0xFFFFFFFFu || (!bt_a && !bt_b)) return rc;
-  std::string ra, rb;
-  if (!ond_backtrace(seq_a, (int)strlen(seq_a), seq_b, (int)strlen(seq_b), mode, (int)*dist, &ra, &rb)) {
-    ctx->err = "myers_align: the D-path table does not end at the distance the device computed";
-    return MIA_HIP_ERR_DEVICE;
-  }
-  if (bt_a) memcpy(bt_a, ra.c_str(), ra.size() + 1);
-  if (bt_b) memcpy(bt_b, rb.c_str(), rb.size() + 1);
-  return MIA_HIP_OK;
-}
-
-// ---- measured ceilings (bench.py's roofline) -----------------------------------------------
-extern "C" int mia_hip_measure_peaks(mia_hip_ctx* ctx, int64_t copy_bytes, double* hbm_copy_gbs, double* valu_ginst_s) {
-  if (!ctx || copy_bytes < (1 << 20)) return MIA_HIP_ERR_ARG;
-  HIPCHK(hipSetDevice(ctx->device));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
-  void *a = nullptr, *b = nullptr;
-  ScopeFree sf; sf.watch(&a); sf.watch(&b);
-  int rc = MIA_HIP_OK;
-  if (hbm_copy_gbs) {
-    const int64_t n16 = copy_bytes / 16;
-    if (hipMalloc(&a, (size_t)n16 * 16) != hipSuccess || hipMalloc(&b, (size_t)n16 * 16) != hipSuccess) { ctx->err = "measure_peaks: hipMalloc"; rc = MIA_HIP_ERR_NOMEM; }
-    else {
-      HIPCHK(hipMemsetAsync(a, 1, (size_t)n16 * 16, ctx->stream));
-      float best = 1e30f;
-      for (int variant = 0; variant < 8; variant++) {
-        const int grid = ctx->cus * (variant & 1 ? 32 : 8);
-        for (int rep = 0; rep < 4; rep++) {                   // the first repetition warms the TLBs
-          (void)hipEventRecord(e0, ctx->stream);
-          switch (variant >> 1) {
-            case 0: hipLaunchKernelGGL((k_peak_copy<1, false>), dim3(grid * 2), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16); break;
-            case 1: hipLaunchKernelGGL((k_peak_copy<4, false>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16); break;
-            case 2: hipLaunchKernelGGL((k_peak_copy<4, true>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16); break;
-            default: hipLaunchKernelGGL((k_peak_copy<8, true>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)a, (uint4*)b, n16); break;
-          }
-          (void)hipEventRecord(e1, ctx->stream);
-          HIPCHK(hipEventSynchronize(e1));
-          float ms = 0;
-          HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-          if (getenv("MIA_HIP_PEAK_DEBUG")) fprintf(stderr, "[peak copy] variant %d rep %d: %.1f GB/s\n", variant, rep, 2.0 * (double)n16 * 16 / (ms * 1e-3) / 1e9);
-          if (rep > 0 && ms < best) best = ms;
-        }
-      }
-      *hbm_copy_gbs = 2.0 * (double)n16 * 16 / (best * 1e-3) / 1e9;      // bytes read + bytes written
-    }
-  }
-  if (valu_ginst_s && rc == MIA_HIP_OK) {
-    int32_t* out = nullptr;
-    const int wgs = ctx->cus * 8, iters = 4096;               // 8 waves per SIMD: enough to cover the issue latency
-    if (hipMalloc((void**)&out, (size_t)wgs * 256 * 4) != hipSuccess) { ctx->err = "measure_peaks: hipMalloc"; rc = MIA_HIP_ERR_NOMEM; }
-    else {
-      float best = 1e30f;
-      for (int rep = 0; rep < 4; rep++) {
-        (void)hipEventRecord(e0, ctx->stream);
-        hipLaunchKernelGGL(k_peak_valu, dim3(wgs), dim3(256), 0, ctx->stream, out, iters, 12345 + rep);
-        (void)hipEventRecord(e1, ctx->stream);
-        if (hipEventSynchronize(e1) != hipSuccess) break;
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && rep > 0 && ms < best) best = ms;
-      }
-      (void)hipFree(out);
-      *valu_ginst_s = (double)wgs * 4 * iters * PEAK_VALU_OPS_PER_ITER / (best * 1e-3) / 1e9;   // wave instructions per second
-    }
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  return rc;
-}
-
-extern "C" int mia_hip_pass1_time(mia_hip_ctx* ctx, double* kernel_ms) {
-  if (!ctx || !kernel_ms) return MIA_HIP_ERR_ARG;
-  *kernel_ms = ctx->pass1_ms;
-  return MIA_HIP_OK;
-}
-
-extern "C" int mia_hip_pass1_filtered(mia_hip_ctx* ctx, int64_t* reads) {
-  if (!ctx || !reads) return MIA_HIP_ERR_ARG;
-  *reads = ctx->pass1_filtered;
-  return MIA_HIP_OK;
-}
-
-extern "C" int mia_hip_pass1_anchored(mia_hip_ctx* ctx, int64_t* reads) {
-  if (!ctx || !reads) return MIA_HIP_ERR_ARG;
-  *reads = ctx->pass1_anchored;
-  return MIA_HIP_OK;
-}
+// (the communicator entry points and mia_hip_iterate: mia_hip_iterate.inc; trimming, ma, pass 1, Myers, ceilings: mia_hip_tools.inc)
+#include "mia_hip_iterate.inc"
+#include "mia_hip_tools.inc"
