@@ -468,7 +468,8 @@ __device__ __forceinline__ uint32_t bxl_values_chunk(const ReadSet& rs, const Re
     const int32_t* sub = sub_lds + r.st * (31 * 4 * BX_SUB_ROW);
     const int rows = (bx.dbg & 2u) ? 1 : r.len2;
     if (edge) bxl_values<LPR, true>(bx.refnib, r.s, r.l1, r.rw, rows, r.d0, sub, u, &best, &bj);
-    else bxl_values<LPR, false>(bx.refnib, r.s, r.l1, r.rw, rows, r.d0, sub, u, &best, &bj);
+    else if (bx.dbg & 64u) bxl_values<LPR, false>(bx.refnib, r.s, r.l1, r.rw, rows, r.d0, sub, u, &best, &bj);      // (MIA_HIP_BX_DEBUG=64: the aged form)
+    else bxl_values_star<LPR>(bx.refnib, r.s, r.rw, rows, r.d0, sub, u, bx.umax ? bx.umax[r.i] - bx.expect[r.i] : -1, &best, &bj);
   }
   const bool ok = live && u == 0 && bj >= 0 && bj == r.jstar && best == bx.expect[r.i];
   if (ok) {

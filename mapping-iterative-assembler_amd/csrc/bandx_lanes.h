@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "bandx_body.h"
 
 namespace mia {
@@ -160,6 +162,128 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
       if (b1 > bb) { bb = b1; jj = j1; }
     }
     best = bb; bj = jj;                                    // (meaningful on the read's first lane, u == 0)
+  }
+  if (best <= BX_NEG / 2) bj = -1;
+  *best_out = best; *bj_out = bj;
+}
+
+// ---- values only, windows that hold the whole band (no EDGE), in coordinates that need no ageing ---------------------------
+// bxl_values ages two running maxima per cell (G - GEP per band index, H - GEP per row and index) and decides "new start"
+// with a compare and a select: 11 vector instructions per cell, and with the position-specific matrices' long values lists
+// (configs[2]: 333 k reads) this kernel runs at 69 % of the chip's issue rate -- instructions are what it costs.  Here
+// every value is carried as  S*(r, j) = S(r, j) + 2 GEP r + GEP j  (row r, band index j, src/mia.c:905-948 restated):
+//   * the column-gap maximum of cell (r, j) over the previous row, max over j' < j of S(r-1, j') - GOP - GEP (j - j'),
+//     becomes max over j' < j of Q(j') - GOP with Q(j') = S*(r-1, j') + 2 GEP: a plain prefix maximum, across lanes too;
+//   * the row-gap candidate that slides from (r, j) to (r+1, j-1) and loses GEP on the way keeps its value
+//     (2 GEP (r+1) + GEP (j-1) = 2 GEP r + GEP j + GEP): H(r+1, j-1) = max(H(r, j), Q(j) - GOP), the SAME Q(j) - GOP;
+//   * the diagonal predecessor of (r, j) is Q(j) itself, and Q of the new row is max3(Q, G, H) + sub + 2 GEP.
+// Seven instructions per cell.  The "new start" branch (score -(GOP + GEP (r+1)), which forfeits the row's substitution
+// score) is only kept for rows r < r_cut, as max(x + sub, fresh): (1) any cell may come out HIGHER than dyn_prog's without
+// harm -- the caller accepts a read only if the best of the last row equals the plan's diagonal's score `expect` at the
+// plan's band index and first: values never below the true ones, a true optimum >= expect (the diagonal is a path), so
+// equality with expect at the first maximum carries over; (2) a path that starts in row r scores at most
+// U - sum of M(0..r) - GOP - GEP (r+1), below expect = U - b0 from r_cut on (the first r where sum M(0..r) + GOP + GEP (r+1)
+// > b0): cells that would take the branch there never reach a last-row value >= expect, with or without it.
+// sub: the unshifted table (the EDGE form of the same chunk class reads it too).  b0 < 0: not known, the branch stays in every row.
+template <int LPR>
+__device__ __forceinline__ void bxl_values_star(const uint32_t* refnib, int s, const uint32_t* rwords, int len2, int d0, const int32_t* sub, int u, int b0,
+                                                int* best_out, int* bj_out) {
+  const int dl = d0 + BXL_CELLS * u;
+  int32_t Q[BXL_CELLS], H[BXL_CELLS];
+  uint32_t rw = rwords[0], rw_next = rwords[1];
+  BxlSlide slide;
+  slide.init(refnib, (int64_t)s + dl + BX_NIB_LEAD);
+  // rows below r_cut keep the new-start branch (this lane's read; the wavefront runs the largest)
+  int r_cut = len2;
+  if (b0 >= 0) {
+    int acc = GOP, q = 0;
+    uint32_t w = rw;
+    for (; q < len2; q++) {
+      if (q && (q & 7) == 0) w = rwords[q >> 3];
+      const int b = (int)((w >> (4 * (q & 7))) & 3u);
+      acc += sub[(sm_depth(q, len2) * 4 + b) * BX_SUB_ROW + b] + GEP;
+      if (acc > b0) break;
+    }
+    r_cut = q < len2 ? q : len2;
+  }
+  for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(r_cut, o); r_cut = t > r_cut ? t : r_cut; }
+  r_cut = __builtin_amdgcn_readfirstlane(r_cut);            // (the same in every lane: a scalar, so that `early` below is a branch)
+  {
+    const uint32_t cw = slide.get(refnib, (int64_t)s + dl + BX_NIB_LEAD);
+    const int32_t* row = sub + (int)(rw & 3u) * BX_SUB_ROW;              // depth 0
+#pragma unroll
+    for (int j = 0; j < BXL_CELLS; j++) {
+      H[j] = BX_NEG;
+      Q[j] = row[__builtin_amdgcn_ubfe(cw, 4 * j, 3)] + 2 * GEP + GEP * (BXL_CELLS * u + j);
+    }
+  }
+  int fl = -GOP - GEP + 2 * GEP + GEP * BXL_CELLS * u + GEP;           // fresh*(r, 8 u) + 2 GEP at r = 1
+  // one row; EARLY: with the new-start branch (two loops below: a flag tested per cell would be a select per cell)
+  auto row_step = [&](int r, auto early_tag) {
+    constexpr bool EARLY = decltype(early_tag)::value;
+    const int c0 = r + dl;
+    const uint32_t cw = slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD);
+    if ((r & 7) == 0) { rw = rw_next; rw_next = rwords[(r >> 3) + 1]; }
+    const int32_t* row = sub + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
+    int cand[BXL_CELLS];
+#pragma unroll
+    for (int j = 0; j < BXL_CELLS; j++) cand[j] = Q[j] - GOP;
+    int G = BX_NEG;
+    if (LPR > 1) {
+      int gloc = cand[0];
+#pragma unroll
+      for (int j = 1; j < BXL_CELLS; j++) gloc = gloc > cand[j] ? gloc : cand[j];
+      const int g1 = bxl_from_left<1>(gloc, BX_NEG);
+      if (u >= 1) G = g1;
+      if (LPR > 2) { const int g2 = bxl_from_left<2>(gloc, BX_NEG); if (u >= 2 && g2 > G) G = g2; }
+      if (LPR > 3) { const int g3 = bxl_from_left<3>(gloc, BX_NEG); if (u >= 3 && g3 > G) G = g3; }
+    }
+    int nh0 = BX_NEG;
+#pragma unroll
+    for (int j = 0; j < BXL_CELLS; j++) {
+      const int pd = Q[j], h = H[j];
+      const int sb = row[__builtin_amdgcn_ubfe(cw, 4 * j, 3)];
+      const int x = pd > G ? (pd > h ? pd : h) : (G > h ? G : h);
+      int q = x + sb + 2 * GEP;
+      if (EARLY) { const int f = fl + GEP * j; q = q > f ? q : f; }
+      G = G > cand[j] ? G : cand[j];
+      const int nh = h > cand[j] ? h : cand[j];
+      if (j >= 1) H[j - 1] = nh; else nh0 = nh;
+      Q[j] = q;
+    }
+    if (LPR > 1) {
+      const int hr = bxl_from_right1(nh0, BX_NEG);
+      H[BXL_CELLS - 1] = u < LPR - 1 ? hr : BX_NEG;
+    } else H[BXL_CELLS - 1] = BX_NEG;
+    fl += GEP;
+  };
+  int r = 1;
+  const int r_mid = r_cut < len2 ? r_cut : len2;
+  for (; r < r_mid; r++) row_step(r, std::true_type{});
+  for (; r < len2; r++) row_step(r, std::false_type{});
+  // back to scores: S(R, j) = Q(j) - 2 GEP - 2 GEP R - GEP j
+  const int back = 2 * GEP + 2 * GEP * (len2 - 1) + GEP * BXL_CELLS * u;
+  int best = BX_NEG, bj = -1;
+#pragma unroll
+  for (int j = 0; j < BXL_CELLS; j++) { const int v = Q[j] - back - GEP * j; if (v > best) { best = v; bj = j; } }
+  bj = bj < 0 ? -1 : bj + BXL_CELLS * u;
+  if (LPR > 1) {                                           // first maximum over the read's lanes: a lane further right must be strictly better
+    const int b1 = bxl_from_right<1>(best, BX_NEG), j1 = bxl_from_right<1>(bj, -1);
+    int bb = best, jj = bj;
+    if (LPR > 3) {
+      const int b3 = bxl_from_right<3>(best, BX_NEG), j3 = bxl_from_right<3>(bj, -1);
+      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
+      if (b1 > bb) { bb = b1; jj = j1; }
+      if (b2 > bb) { bb = b2; jj = j2; }
+      if (b3 > bb) { bb = b3; jj = j3; }
+    } else if (LPR > 2) {
+      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
+      if (b1 > bb) { bb = b1; jj = j1; }
+      if (b2 > bb) { bb = b2; jj = j2; }
+    } else {
+      if (b1 > bb) { bb = b1; jj = j1; }
+    }
+    best = bb; bj = jj;
   }
   if (best <= BX_NEG / 2) bj = -1;
   *best_out = best; *bj_out = bj;

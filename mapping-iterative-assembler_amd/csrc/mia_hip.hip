@@ -984,7 +984,7 @@ static int align_all(mia_hip_ctx* ctx) {
       BxDev bd;
       bd.tab.sub = ctx->d_bx_sub; bd.tab.mrow = ctx->d_bx_mrow; bd.tab.loss = ctx->d_bx_loss; bd.tab.dl = ctx->d_bx_dl;
       bd.lazy_scripts = ctx->lazy_scripts;
-      bd.dbg = ctx->bx_dbg & (3u | 32u);
+      bd.dbg = ctx->bx_dbg & (3u | 32u | 64u);
       // MIA_HIP_BX_SERIAL=1: round 2's order (band kernels, then the planner over everything they left open)
       // (caller-supplied windows -- mia_hip_align_windows -- can be of any length: the retry list's window kernel is picked by read length)
       const bool new_flow = ctx->use_lanes && !ctx->bx_serial && !(ctx->dbg & 256u) && !ctx->explicit_win;
