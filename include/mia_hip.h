@@ -201,7 +201,10 @@ int mia_hip_consensus(mia_hip_ctx *ctx, int cons_code, char *out, int64_t out_ca
  * cull_maln_from_fsdb (with find_fsdb_score_cut unless hard_cut > 0 or a line is given) and consensus_assembly_string --
  * as one call.  Same kernels and same results as mia_hip_realign + mia_hip_cull + mia_hip_tally + mia_hip_consensus, but
  * the numbers those calls pass through the host in between (planner bins, cut line, insert-event count, result arrays)
- * stay on the device; the host waits once behind the alignment and once for the consensus string.
+ * stay on the device; the host waits once behind the alignment and once for the consensus string -- or, with one context
+ * and a cut line that is given, hard, or needs no scores (reads of one length), only for the consensus string: cull, tally
+ * and consensus are then queued without a look at the alignment's counters and queued again in the rare case that reads
+ * were still waiting for the exact one-read-per-thread kernel (their kernels return untouched in that case).
  *   new_ref/ref_len/circular   as mia_hip_realign
  *   hard_cut                   -H (> 0), else
  *   slope_intercept            -S / -N as {slope, intercept}, or NULL: the regression of find_fsdb_score_cut
