@@ -23,12 +23,13 @@ namespace mia {
 
 // counters of the pipeline; each on a cache line of its own (BXC_STRIDE words apart): thousands of wavefronts add to them,
 // and atomics on one line are served one after the other
-enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_COUNTERS = 32 };
-static_assert(BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_COUNTERS, "counter layout");
+enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_CAND = 28, BXC_COUNTERS = 32 };     // CAND: reads handed from the plan's first launch to its second
+static_assert(BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_CAND && BXC_CAND < BXC_COUNTERS, "counter layout");
 constexpr int BXC_STRIDE = 64;
 constexpr int BXC_WORDS = BXC_COUNTERS * BXC_STRIDE;
 __device__ __forceinline__ uint32_t* bxc(const uint32_t* ctr, int k) { return const_cast<uint32_t*>(ctr) + (size_t)k * BXC_STRIDE; }
 
+struct BxCandRec;
 struct BxDev {
   BxTab tab;               // tables in global memory
   const int32_t* sub256;   // tab.sub times 256 (the trace DP's packed words)
@@ -46,7 +47,12 @@ struct BxDev {
   uint32_t* ctr;           // BXC_*
   int32_t lazy_scripts;    // the scripts of reads finished as pure diagonals are not written (k_diag_scripts makes them when asked for)
   uint32_t dbg;            // MIA_HIP_BX_DEBUG (profiling only, results are wrong): 1 no traceback, 2 one DP row only
+  // k_bx_plan in two launches (phase 1 / phase 2): the reads whose anchors lie on two diagonals (or that want the end-indel
+  // rescue) are handed from the first to the second through this list; nullptr: one launch, the block's first threads finish them
+  struct BxCandRec* cand;
+  uint32_t* cand_n;
 };
+struct BxCandRec { int32_t i; BxAnchors an; };
 
 __device__ __forceinline__ uint32_t bx_pack(const BxPlan& p) {
   return (uint32_t)(p.d0 + 512) | ((uint32_t)(p.dstar - p.d0) << 11) | ((uint32_t)p.edge << 16) | ((uint32_t)p.w << 17);
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void k_read_planes(ReadSet rs, int32_t words, 
 // for the sake of a few lanes.
 template <int NW>
 __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPlanes rp, KmerHash ko, int64_t n_ref, BxDev bx, const int32_t* in_list,
-                                                  const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of) {
+                                                  const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of, int32_t phase = 0) {
   __shared__ int16_t loss_lds[BX_LOSS_WORDS];
   __shared__ BxAnchors cand_an[256];
   __shared__ uint8_t cand_tid[256];
@@ -243,7 +249,10 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     if (threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
   };
-  {
+  // phase 0: everything here (the reads with anchors on two diagonals by the block's first threads, below); phase 1: those
+  // reads go on bx.cand instead -- the launch with phase 2 finishes them with every lane at work (in one launch a block's
+  // three other wavefronts sat at the barrier meanwhile: 58 of the kernel's 224 us)
+  if (phase != 2) {
     DiagScan<NW> sc;
     Rd r = fetch((int)threadIdx.x, sc);
     BxPlan bp;
@@ -281,18 +290,45 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     Rd rr = r;
     if (waits) rr.ok = false;
     emit(rr, bp, !in_list && t0 + threadIdx.x < total && !waits);
+    if (phase == 1) {                               // hand the waiting reads over: one reservation per block
+      __shared__ uint32_t cand_base;
+      __syncthreads();
+      if (threadIdx.x == 0 && n_cand) cand_base = atomicAdd(bx.cand_n, (uint32_t)n_cand);
+      __syncthreads();
+      if ((int)threadIdx.x < n_cand) {
+        BxCandRec rec;
+        rec.i = (int32_t)(in_list ? in_list[t0 + cand_tid[threadIdx.x]] : t0 + cand_tid[threadIdx.x]);
+        rec.an = cand_an[threadIdx.x];
+        bx.cand[cand_base + threadIdx.x] = rec;
+      }
+      return;
+    }
   }
   __syncthreads();
-  if (n_cand == 0 || (bx.dbg & 32u)) return;      // (MIA_HIP_BX_DEBUG=32, profiling only: no second phase)
-  {                                                 // (every thread: emit has barriers)
+  if ((phase == 0 && n_cand == 0) || (bx.dbg & 32u)) return;      // (MIA_HIP_BX_DEBUG=32, profiling only: no second phase)
+  // the candidates: this block's own (phase 0), or 256 of the list per step (phase 2; every thread loops alike: emit has barriers)
+  const int64_t n_list = phase == 2 ? (int64_t)*bx.cand_n : 0;
+  for (int64_t c0 = phase == 2 ? (int64_t)blockIdx.x * 256 : 0; phase == 2 ? c0 < n_list : c0 == 0; c0 += phase == 2 ? (int64_t)gridDim.x * 256 : 1) {
     DiagScan<NW> sc;
     Rd r{0, 0, 0, 0, 0, false};
     BxPlan bp;
     bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
-    if ((int)threadIdx.x < n_cand) {
-      r = fetch(cand_tid[threadIdx.x], sc);
+    const bool mine = phase == 2 ? c0 + threadIdx.x < n_list : (int)threadIdx.x < n_cand;
+    if (mine) {
+      BxAnchors an;
+      if (phase == 2) {
+        const BxCandRec rec = bx.cand[c0 + threadIdx.x];
+        an = rec.an;
+        r.i = rec.i;
+        r.len2 = rs.len[r.i];
+        r.st = rs.rc[r.i] ? 1 : 0;
+        read_window(ref, rs.as[r.i], rs.ae[r.i], r.len2, &r.s, &r.l1);
+        r.ok = true;                                // (only reads that passed the first launch's tests are on the list)
+      } else {
+        r = fetch(cand_tid[threadIdx.x], sc);
+        an = cand_an[threadIdx.x];
+      }
       load_planes(r, sc);
-      BxAnchors an = cand_an[threadIdx.x];
       if (an.rescue && !bx_rescue<NW>(sc, rp, an, r.s, r.l1, r.len2)) bp.b0 = an.rescue;      // (the reason it was not planned stands)
       else bx_finish<NW, 2>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
     }

@@ -57,6 +57,7 @@ struct mia_hip_ctx {
   bool pend_encode = false; int32_t pend_L = 0, pend_wl = 0, pend_total = 0;      // mia_hip_iterate: d_ascii holds the new reference, d_ref not yet
   uint32_t* d_prep_bar = nullptr; uint32_t prep_bar_count = 0; bool no_prep_fuse = false;   // k_ref_prep's grid barrier (MIA_HIP_NO_PREP_FUSE=1: six launches)
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
+  BxCandRec* d_bx_cand = nullptr; int64_t cand_cap = 0; bool plan_split = true;      // k_bx_plan's hand-over list between its two launches (MIA_HIP_NO_PLAN_SPLIT=1: one launch)
   bool no_spec = false;                     // MIA_HIP_NO_SPEC=1: wait for the alignment's counters before the cull is queued
   bool no_side_buckets = false;             // MIA_HIP_NO_SIDE_BUCKETS=1
   int buckets_queued = 0;                   // the tally's counting sort is already queued: 1 on the context's stream, 2 on stream2 (ev_join behind it)
@@ -317,6 +318,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* sb2 = getenv("MIA_HIP_NO_SIDE_BUCKETS")) ctx->no_side_buckets = atoi(sb2) != 0;
     if (const char* ns2 = getenv("MIA_HIP_NO_SPEC")) ctx->no_spec = atoi(ns2) != 0;
     if (const char* pf2 = getenv("MIA_HIP_NO_PREP_FUSE")) ctx->no_prep_fuse = atoi(pf2) != 0;
+    if (const char* ps2 = getenv("MIA_HIP_NO_PLAN_SPLIT")) ctx->plan_split = atoi(ps2) == 0;
     if (const char* st2 = getenv("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
     if (const char* ml = getenv("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
     if (const char* na = getenv("MIA_HIP_NO_AUTO_PLAIN")) ctx->no_auto_plain = atoi(na) != 0;
@@ -392,6 +394,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (ctx->d_cull_sync) (void)hipFree(ctx->d_cull_sync);
   if (ctx->d_bx_slabs_late) (void)hipFree(ctx->d_bx_slabs_late);
   if (ctx->d_one) (void)hipFree(ctx->d_one);
+  if (ctx->d_bx_cand) (void)hipFree(ctx->d_bx_cand);
   for (int k = 0; k < 3; k++) if (ctx->d_slabs_retry[k]) (void)hipFree(ctx->d_slabs_retry[k]);
   if (ctx->d_prep_bar) (void)hipFree(ctx->d_prep_bar);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -1004,15 +1007,26 @@ static int align_all(mia_hip_ctx* ctx) {
       bd.rplanes = bd.umax ? ctx->d_rplanes : nullptr;
       bd.rplane_words = ctx->rplane_words;
       bd.plan = ctx->d_bx_plan; bd.expect = ctx->d_bx_expect; bd.lists = ctx->d_bx_lists; bd.list_stride = ctx->bx_cap; bd.ctr = ctx->d_bx_ctr;
+      // the plan in two launches (bandx_kernels.h, phase): the reads with anchors on two diagonals are finished by a second launch
+      // with every lane at work (MIA_HIP_NO_PLAN_SPLIT=1: by the first threads of their blocks, one launch)
+      const bool split = ctx->plan_split;
+      bd.cand = nullptr; bd.cand_n = ctx->d_bx_ctr + (size_t)BXC_CAND * BXC_STRIDE;
+      if (split) {
+        if (n > ctx->cand_cap) { if (dev_alloc(ctx, &ctx->d_bx_cand, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->cand_cap = n; }
+        bd.cand = ctx->d_bx_cand;
+      }
       if (stage_begin(ctx, STG_BX_PLAN)) return MIA_HIP_ERR_NOMEM;
       {
         const int32_t* in_list = run_filter ? ctx->d_left_list : nullptr;
-        const dim3 pg((unsigned)((n + 255) / 256)), pb(256);
-        switch ((ctx->max_len + 63) >> 6) {       // 64-row words of the longest read
-          case 1: hipLaunchKernelGGL(k_bx_plan<1>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
-          case 2: hipLaunchKernelGGL(k_bx_plan<2>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
-          case 3: hipLaunchKernelGGL(k_bx_plan<3>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
-          default: hipLaunchKernelGGL(k_bx_plan<4>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of); break;
+        const dim3 pb(256);
+        for (int phase = split ? 1 : 0; phase <= (split ? 2 : 0); phase++) {
+          const dim3 pg(phase == 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
+          switch ((ctx->max_len + 63) >> 6) {       // 64-row words of the longest read
+            case 1: hipLaunchKernelGGL(k_bx_plan<1>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
+            case 2: hipLaunchKernelGGL(k_bx_plan<2>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
+            case 3: hipLaunchKernelGGL(k_bx_plan<3>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
+            default: hipLaunchKernelGGL(k_bx_plan<4>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
+          }
         }
       }
       stage_end(ctx, STG_BX_PLAN);

@@ -3,7 +3,7 @@ round 1's flat-matrix pipeline (diagonal filter + k_band_align, MIA_HIP_NO_BANDX
 (MIA_HIP_NO_LANES=1), round 2's stream order (MIA_HIP_BX_SERIAL=1), and this round's host-side orders switched off one by one
 (MIA_HIP_NO_SPEC: wait for the alignment's counters before the cull is queued; MIA_HIP_SPEC_TEST: always take the second
 round; MIA_HIP_NO_PREP_FUSE: six launches instead of k_ref_prep; MIA_HIP_NO_SIDE_BUCKETS: counting sort behind the cull; MIA_HIP_BX_DEBUG=64: the values DP in its aged form instead of
-the ageing-free coordinates of bxl_values_star).
+the ageing-free coordinates of bxl_values_star; MIA_HIP_NO_PLAN_SPLIT: k_bx_plan in one launch).
 Two calls of mia_hip_iterate on 200 000 reads (first against mt311, then against the consensus): scores, end points,
 scripts, all tally words, ref->gaps and the consensus string of both iterations must be identical to the default build's
 (reference loop body: /root/reference/src/mia_main.c:915-964)."""
@@ -17,7 +17,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HIP_NO_SPEC", "MIA_HIP_SPEC_TEST", "MIA_HIP_NO_PREP_FUSE",
-            "MIA_HIP_NO_SIDE_BUCKETS", "MIA_HIP_BX_DEBUG=64"]
+            "MIA_HIP_NO_SIDE_BUCKETS", "MIA_HIP_BX_DEBUG=64", "MIA_HIP_NO_PLAN_SPLIT"]
 
 
 def two_iterations(mod, w, env):
