@@ -57,7 +57,8 @@ STAGES = ["k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_tra
 # the full-window stage is timed as a whole: k_align_quad (four reads per wavefront, windows up to 208 columns) and the
 # k_align_window<CPL> launches (one read per wavefront: wider windows, reads whose path left the quad kernel's trace band)
 # the band DPs are timed by stream: stream2 carries the values DP and, behind it, the trace DP of its left-overs
-STAGE_KERNELS = {"k_align_quad": ["k_align_quad", "k_align_window"], "k_bx_values": ["k_bxl_values", "k_bxl_trace_late"], "k_bx_trace": ["k_bxl_trace"]}
+STAGE_KERNELS = {"k_align_quad": ["k_align_quad", "k_align_window"], "k_bx_values": ["k_bxl_values", "k_bxl_trace_late"], "k_bx_trace": ["k_bxl_trace"],
+                 "k_bx_plan": ["k_bx_plan"]}           # (the plan is two launches of one kernel per step)
 
 
 def source_hash():
