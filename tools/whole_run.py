@@ -3,7 +3,7 @@
 /root/reference by oracle/Makefile.ref) against the mia_hip command line on the same synthetic FASTA.
 Checks that every .maln iteration is byte-identical from line 2 and reports both wall times as JSON.
 
-usage: python tools/whole_run.py [-n READS] [--kmer K] [--keep DIR]
+usage: python tools/whole_run.py [-n READS] [--kmer K] [--matrix FILE] [--plain-ref] [--damage] [--keep DIR]
 Needs a GPU (mia_hip) and the prebuilt reference binary; reads nothing under /root/reference at run time."""
 import argparse
 import json
@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--skip-reference", action="store_true")
     ap.add_argument("--plain-ref", action="store_true", help="reference = mt311 with its ambiguity codes resolved (the usual kind of "
                     "reference; lets the diagonal filter of pass 1 work)")
+    ap.add_argument("--matrix", default=None, help="substitution matrix file under tests/golden (-s), e.g. ancient.submat.txt; default: the flat matrix")
+    ap.add_argument("--damage", action="store_true", help="aDNA damage on the synthetic reads")
     ap.add_argument("--ccheck", action="store_true", help="also run ccheck (reference and ccheck_hip) on the final .maln")
     ap.add_argument("--ccheck-reference", action="store_true", help="with --skip-reference: still time the reference's ccheck on mia_hip's .maln")
     a = ap.parse_args()
@@ -34,7 +36,7 @@ def main():
     os.makedirs(work, exist_ok=True)
     reads = os.path.join(work, "reads.fa")
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_data.py"), "--ref", os.path.join(GOLDEN, "mt311.fa"),
-                    "--out", reads, "-n", str(a.n), "--len", "100", "--seed", "7"], check=True)
+                    "--out", reads, "-n", str(a.n), "--len", "100", "--seed", "7"] + (["--damage"] if a.damage else []), check=True)
     ref_fa = os.path.join(GOLDEN, "mt311.fa")
     if a.plain_ref:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -45,8 +47,10 @@ def main():
     args = ["-r", ref_fa, "-f", reads, "-c"]
     if a.kmer > 0:
         args += ["-k", str(a.kmer)]
+    if a.matrix:
+        args += ["-s", os.path.join(GOLDEN, a.matrix)]
     env = dict(os.environ, MIA_DATA_PATH=GOLDEN)
-    out = {"reads": a.n, "kmer": a.kmer, "plain_ref": bool(a.plain_ref)}
+    out = {"reads": a.n, "kmer": a.kmer, "plain_ref": bool(a.plain_ref), "matrix": a.matrix or "flat", "damage": bool(a.damage)}
     runs = [("mia_hip", hip_bin)] + ([] if a.skip_reference else [("reference", ref_bin)])
     for label, exe in runs:
         root = os.path.join(work, label)
