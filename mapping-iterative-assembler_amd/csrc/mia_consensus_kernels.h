@@ -1312,14 +1312,22 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
       if (ev_base + k < tb.cap_events) tb.events[ev_base + k] = ev_buf[k]; else atomicOr(tb.flags, 1u);
     }
   }
-  // prefix sums of the two difference arrays (Hillis-Steele over TALLY_WIN entries), folded into the cov / span rows
-  for (int o = 1; o < TALLY_WIN; o <<= 1) {
-    int c[(TALLY_WIN + 255) / 256], sp[(TALLY_WIN + 255) / 256];
-    for (int q = 0, k = threadIdx.x; k < TALLY_WIN; k += blockDim.x, q++) { c[q] = k >= o ? cov_diff[k - o] : 0; sp[q] = k >= o ? span_diff[k - o] : 0; }
-    __syncthreads();
-    for (int q = 0, k = threadIdx.x; k < TALLY_WIN; k += blockDim.x, q++) { cov_diff[k] += c[q]; span_diff[k] += sp[q]; }
-    __syncthreads();
+  // prefix sums of the two difference arrays, folded into the cov / span rows: one wavefront each, six consecutive entries
+  // per lane and a shuffle scan over the lanes' sums (a Hillis-Steele scan by the whole workgroup was eighteen barriers)
+  static_assert(TALLY_WIN == 64 * 6, "the difference arrays are scanned six entries per lane");
+  if (wv < 2) {
+    int32_t* d = wv == 0 ? cov_diff : span_diff;
+    int32_t e[6], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) { e[q] = d[lane * 6 + q]; sum += e[q]; }
+    int32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    int32_t run = inc - sum;
+#pragma unroll
+    for (int q = 0; q < 6; q++) { run += e[q]; d[lane * 6 + q] = run; }
   }
+  __syncthreads();
   for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { lds[T_COV * TALLY_WIN + k] += cov_diff[k]; lds[T_SPAN * TALLY_WIN + k] += span_diff[k]; }
   if (!LINEAR) {
     // the bases of depth code 15: their counts into the base rows, their scores from sm[strand][15][X][b]
