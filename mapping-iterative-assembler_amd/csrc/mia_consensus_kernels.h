@@ -62,17 +62,20 @@ __global__ __launch_bounds__(256) void k_scan_partials(int64_t* partial, int nb,
   const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
   int64_t mine = 0;
   for (int b = b0; b < b1; b++) mine += partial[b];
-  s_run[t] = mine;
+  // inclusive scan of the 256 run sums: a shuffle scan per wavefront, the four wavefronts joined through LDS (two barriers
+  // instead of sixteen)
+  const int lane = t & 63, w = t >> 6;
+  int64_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int64_t u = (int64_t)__shfl_up((long long)inc, o); if (lane >= o) inc += u; }
+  if (lane == 63) s_run[w] = inc;
   __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    const int64_t a = t >= o ? s_run[t - o] : 0;
-    __syncthreads();
-    s_run[t] += a;
-    __syncthreads();
-  }
-  int64_t run = base + s_run[t] - mine;
+  int64_t off = 0;
+  for (int k = 0; k < w; k++) off += s_run[k];
+  const int64_t all = s_run[0] + s_run[1] + s_run[2] + s_run[3];
+  int64_t run = base + off + inc - mine;
   for (int b = b0; b < b1; b++) { const int64_t v = partial[b]; partial[b] = run; run += v; }
-  if (t == 255) *total = s_run[255];
+  if (t == 255) *total = all;
 }
 __global__ void k_scan_apply(ReadSet rs, int32_t L, const int64_t* partial, int64_t* slot) {
   __shared__ int32_t sh[256];
