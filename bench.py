@@ -319,6 +319,24 @@ def use_timed_region(stages, dominant, dom_ms, dom_launches, steps):
                 sg[key] = sg[key] / scale
 
 
+def dp_phase(stages, peaks):
+    """The DP kernels of one step run SIDE BY SIDE on three streams (values DP and the trace launch behind it; the trace DP of
+    the plan's own lists; planner + full-window kernels), so one kernel's instructions over its own elapsed time says little
+    about the chip: here all their VALU instructions (PMC summary of this build) over the wall time of the phase -- the HIP
+    events around values DP + late trace on the context's stream, which is the critical path the others hide behind."""
+    by = {s["kernel"]: s for s in stages}
+    v = by.get("k_bx_values")
+    names = [k for k in ("k_bx_values", "k_bx_trace", "k_align_quad", "k_align_quad_plain") if k in by]
+    if not v or any(by[k].get("valu_insts") is None for k in names) or not (peaks and peaks.get("valu_ginst_s")):
+        return None
+    insts = sum(by[k]["valu_insts"] * (1 if k in STAGE_KERNELS else by[k]["launches"] / max(v["launches"], 1)) for k in names)
+    ms = v["kernel_ms"]
+    cells = sum((by[k]["gcups"] or 0) * by[k]["kernel_ms"] * 1e6 * (1 if k in STAGE_KERNELS else by[k]["launches"] / max(v["launches"], 1)) for k in names)
+    return {"kernels": names, "wall_ms": ms, "valu_insts": insts, "achieved": insts / (ms * 1e-3) / 1e9, "peak": peaks["valu_ginst_s"],
+            "unit": "1e9 wave64 instructions/s", "frac": insts / (ms * 1e-3) / (peaks["valu_ginst_s"] * 1e9),
+            "gcups": cells / (ms * 1e-3) / 1e9 if cells else None}
+
+
 def roofline(stages, peaks, pmc_tag, pmc_stale):
     timed = [s for s in stages if s.get("timed_region")]
     dom = timed[0] if timed else max(stages, key=lambda s: s["ms_per_step"])
@@ -330,11 +348,14 @@ def roofline(stages, peaks, pmc_tag, pmc_stale):
          "peak_measured_copy": peaks.get("hbm_copy_gbs") if peaks else None,
          "frac_of_measured_copy": dom["achieved"] / peaks["hbm_copy_gbs"] if peaks and peaks.get("hbm_copy_gbs") else None,
          "pmc": {"summary": f"profiles/r03/pmc/{pmc_tag}.json", "from_this_build": not pmc_stale},
+         "dp_phase": dp_phase(stages, peaks),
          "stages": stages,
          "note": "integer DP: the kernels are bound by VALU issue, not HBM -- `frac` prices the SURVEY 8(d) algorithmic bytes of the "
                  "kernel with the most time per step against the nominal 8 TB/s as the contract asks; `valu.frac` = its VALU "
                  "instructions (rocprofv3 SQ_INSTS_VALU of this build) over its live HIP-event time, against the issue rate "
-                 "measured by k_peak_valu in this run; traffic/valu are null when the committed PMC summary is from another build"}
+                 "measured by k_peak_valu in this run; dp_phase = the same for all DP kernels of the step together, which share the chip "
+                 "on three streams (their instructions over the phase's wall time); traffic/valu are null when the committed PMC "
+                 "summary is from another build"}
     return r
 
 

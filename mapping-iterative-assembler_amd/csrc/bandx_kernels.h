@@ -132,25 +132,59 @@ __global__ __launch_bounds__(256) void k_diag_scripts(ReadSet rs) {
 
 // the reference's 10-mers into the hash table (bandx_body.h: KmerHash); slots and ovf are all ones / anything before.
 // A 10-mer with up to `wild` N columns goes in under each of its 4^k spellings (the host sized the table for them).
+// one spelling (10-mer index idx) of the 10-mer at reference position p
+__device__ __forceinline__ void kmer_hash_insert_key(uint32_t idx, int64_t p, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift) {
+  uint32_t h = (idx * 2654435761u) >> shift;
+  for (;;) {
+    uint32_t* e = slot + 4 * (size_t)h;
+    const uint32_t prev = atomicCAS(&e[0], KH_EMPTY, idx);
+    if (prev == KH_EMPTY || prev == idx) {
+      const uint32_t c = atomicAdd(&e[2], 1u) + 1u;           // (starts at all ones)
+      if (c == 0) e[1] = (uint32_t)p; else if (c == 1) e[3] = (uint32_t)p; else if (c < 4) ovf[2 * (size_t)h + c - 2] = (int32_t)p;
+      break;
+    }
+    h = (h + 1) & mask;
+  }
+}
 __device__ __forceinline__ void kmer_hash_insert(const uint8_t* codes, int64_t n_codes, int64_t p, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift, int32_t wild) {
   uint32_t base;
   uint64_t npos;
   const int k = kmer_wild_at(codes, n_codes, p, &base, &npos);
   if (k < 0 || k > wild) return;
-  for (uint32_t x = 0; x < (1u << (2 * k)); x++) {
-    const uint32_t idx = kmer_wild_key(base, npos, k, x);
-    uint32_t h = (idx * 2654435761u) >> shift;
-    for (;;) {
-      uint32_t* e = slot + 4 * (size_t)h;
-      const uint32_t prev = atomicCAS(&e[0], KH_EMPTY, idx);
-      if (prev == KH_EMPTY || prev == idx) {
-        const uint32_t c = atomicAdd(&e[2], 1u) + 1u;           // (starts at all ones)
-        if (c == 0) e[1] = (uint32_t)p; else if (c == 1) e[3] = (uint32_t)p; else if (c < 4) ovf[2 * (size_t)h + c - 2] = (int32_t)p;
-        break;
-      }
-      h = (h + 1) & mask;
+  for (uint32_t x = 0; x < (1u << (2 * k)); x++) kmer_hash_insert_key(kmer_wild_key(base, npos, k, x), p, slot, ovf, mask, shift);
+}
+// the same for 256 consecutive positions by a whole workgroup: a 10-mer with two or three N columns has 16 or 64 spellings, and
+// a thread that enters them one after the other is what a reference full of ambiguity codes (mt311: one 10-mer in six) made
+// k_ref_prep wait for -- 0.16 ms.  Those positions go on a list in LDS and the block's threads share their spellings out.
+__device__ __forceinline__ void kmer_hash_insert_block(const uint8_t* codes, int64_t n_codes, int64_t p0, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift,
+                                                       int32_t wild) {
+  __shared__ int32_t q_n;
+  __shared__ uint16_t q_t[256];
+  if (threadIdx.x == 0) q_n = 0;
+  __syncthreads();
+  {
+    const int64_t p = p0 + threadIdx.x;
+    uint32_t base;
+    uint64_t npos;
+    const int k = kmer_wild_at(codes, n_codes, p, &base, &npos);
+    if (k >= 0 && k <= wild) {
+      if (k >= 2) q_t[atomicAdd(&q_n, 1)] = (uint16_t)threadIdx.x;
+      else for (uint32_t x = 0; x < (1u << (2 * k)); x++) kmer_hash_insert_key(kmer_wild_key(base, npos, k, x), p, slot, ovf, mask, shift);
     }
   }
+  __syncthreads();
+  const int nq = q_n;
+  for (int q0 = 0; q0 < nq; q0 += 4) {                 // four listed positions per step, 64 threads each
+    const int q = q0 + (int)(threadIdx.x >> 6);
+    if (q >= nq) continue;
+    const int64_t p = p0 + q_t[q];
+    uint32_t base;
+    uint64_t npos;
+    const int k = kmer_wild_at(codes, n_codes, p, &base, &npos);
+    const uint32_t x = threadIdx.x & 63u;
+    if (x < (1u << (2 * k))) kmer_hash_insert_key(kmer_wild_key(base, npos, k, x), p, slot, ovf, mask, shift);
+  }
+  __syncthreads();
 }
 __global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t n_codes, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift, int32_t wild) {
   kmer_hash_insert(codes, n_codes, (int64_t)blockIdx.x * 256 + threadIdx.x, slot, ovf, mask, shift, wild);

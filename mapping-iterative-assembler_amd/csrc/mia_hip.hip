@@ -1,6 +1,7 @@
 // mia_hip.hip -- libmia_hip.so: C ABI (include/mia_hip.h) over the gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -38,6 +39,7 @@ constexpr int CTRL_FILTER = CTRL_HDR + PH_WORDS;               // 4 words (k_dia
 constexpr int CTRL_LKN = CTRL_FILTER + 4, CTRL_CULLF = CTRL_LKN + 1, CTRL_NEV = CTRL_CULLF + 1, CTRL_TFLAGS = CTRL_NEV + 1;
 constexpr int CTRL_BXC = (CTRL_TFLAGS + 1 + 63) & ~63;         // BXC_* counters, a cache line each
 constexpr int CTRL_WORDS = CTRL_BXC + BXC_WORDS;
+constexpr int CTRL_C0 = CTRL_BINS + 3 * N_BINS, CTRL_CN = CTRL_WORDS - CTRL_C0;    // what the host looks at behind an alignment: wide / retry counts, planner header, filter and band counters
 
 struct mia_hip_ctx {
   int device = 0;
@@ -57,6 +59,10 @@ struct mia_hip_ctx {
   bool pend_encode = false; int32_t pend_L = 0, pend_wl = 0, pend_total = 0;      // mia_hip_iterate: d_ascii holds the new reference, d_ref not yet
   uint32_t* d_prep_bar = nullptr; uint32_t prep_bar_count = 0; bool no_prep_fuse = false;   // k_ref_prep's grid barrier (MIA_HIP_NO_PREP_FUSE=1: six launches)
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
+  bool zero_copy = true;        // mia_hip_iterate: the last kernel writes consensus and counters into pinned host memory itself (MIA_HIP_NO_ZERO_COPY=1: two copies)
+  // the launches other streams wait for signal their events themselves (launch_k) instead of a marker behind them; MIA_HIP_NO_EXT_EVENTS=1: markers
+  bool spin_wait = true;        // mia_hip_iterate's one wait asks (hipStreamQuery) instead of sleeping on an interrupt; MIA_HIP_SPIN_WAIT=0: hipStreamSynchronize
+  uint32_t ext_events = 31u; bool planner_end_signalled = false, align_end_signalled = false;
   BxCandRec* d_bx_cand = nullptr; int64_t cand_cap = 0; bool plan_split = true;      // k_bx_plan's hand-over list between its two launches (MIA_HIP_NO_PLAN_SPLIT=1: one launch)
   bool no_spec = false;                     // MIA_HIP_NO_SPEC=1: wait for the alignment's counters before the cull is queued
   bool no_side_buckets = false;             // MIA_HIP_NO_SIDE_BUCKETS=1
@@ -284,10 +290,13 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
   if (device_index < 0 || device_index >= ndev) return MIA_HIP_ERR_ARG;
   mia_hip_ctx* ctx = new mia_hip_ctx();
   ctx->device = device_index;
+  // the events order kernels of this context's streams on this device and nothing else (MIA_HIP_EVENT_DEVICE_SCOPE=1: say so)
+  unsigned evf = hipEventDisableTiming;
+  if (const char* es = getenv("MIA_HIP_EVENT_DEVICE_SCOPE")) if (atoi(es)) evf |= hipEventReleaseToDevice;
   if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_join3, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&ctx->ev_join3, evf) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, evf) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, evf) != hipSuccess) {
     delete ctx;
     return MIA_HIP_ERR_DEVICE;
   }
@@ -319,6 +328,10 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* ns2 = getenv("MIA_HIP_NO_SPEC")) ctx->no_spec = atoi(ns2) != 0;
     if (const char* pf2 = getenv("MIA_HIP_NO_PREP_FUSE")) ctx->no_prep_fuse = atoi(pf2) != 0;
     if (const char* ps2 = getenv("MIA_HIP_NO_PLAN_SPLIT")) ctx->plan_split = atoi(ps2) == 0;
+    if (const char* zc = getenv("MIA_HIP_NO_ZERO_COPY")) ctx->zero_copy = atoi(zc) == 0;
+    if (const char* ef = getenv("MIA_HIP_NO_EXT_EVENTS")) ctx->ext_events = atoi(ef) ? 0u : 31u;
+    if (const char* sw = getenv("MIA_HIP_SPIN_WAIT")) ctx->spin_wait = atoi(sw) != 0;
+    if (const char* em = getenv("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
     if (const char* st2 = getenv("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
     if (const char* ml = getenv("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
     if (const char* na = getenv("MIA_HIP_NO_AUTO_PLAIN")) ctx->no_auto_plain = atoi(na) != 0;
@@ -590,6 +603,16 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   return MIA_HIP_OK;
 }
 
+// A launch that signals `stop` with its own completion (hipExtLaunchKernelGGL), or a plain launch if stop is null.  An event
+// recorded BEHIND a launch is a marker packet of its own: the next kernel of that stream starts 15-20 us later (measured
+// between the plan and the values DP), and a stream waiting for the event sees it as late.
+template <typename... KArgs, typename... Args>
+static void launch_k(void (*kernel)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, hipEvent_t stop, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "every kernel argument, defaults included");
+  if (stop) hipExtLaunchKernelGGL(kernel, g, b, (uint32_t)shm, s, nullptr, stop, 0, static_cast<KArgs>(args)...);
+  else hipLaunchKernelGGL(kernel, g, b, shm, s, static_cast<KArgs>(args)...);
+}
+
 // an event pair for one launch of stage `st`; the start event is recorded here, the end event by stage_end
 static int stage_begin(mia_hip_ctx* ctx, Stage st, hipStream_t on = nullptr) {
   if (!((ctx->stage_mask >> st) & 1u)) return 0;
@@ -710,7 +733,7 @@ template <int CPL>
 // own_slabs: the launch gets trace slabs of its own (ctx->d_slabs_retry) and a grid of at most 1 024 workgroups -- it may run
 // beside another launch of the same class on another stream (the band kernels' retry list beside the planner's kernels)
 static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, int count, const int32_t* dev_range = nullptr, hipStream_t on = nullptr,
-                                bool own_slabs = false) {
+                                bool own_slabs = false, hipEvent_t stop = nullptr) {
   // slab = the largest trace of this class: 256 rows x 64*CPL columns, one byte per cell
   const int64_t slab = (int64_t)MAX_READ * 64 * CPL;
   // persistent grid: never more workgroups than are resident at once (a late starter would work through its whole
@@ -736,8 +759,8 @@ static hipError_t launch_window(mia_hip_ctx* ctx, int ci, const int32_t* list, i
   }
   RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
   if (stage_begin(ctx, STG_TRACE, on)) return hipErrorOutOfMemory;
-  hipLaunchKernelGGL((k_align_window<CPL>), dim3(grid), dim3(64), 0, on ? on : ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
-                     count, slabs, slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg, dev_range);
+  launch_k(k_align_window<CPL>, dim3(grid), dim3(64), 0, on ? on : ctx->stream, stop, ctx->rs, ref, ctx->d_pssm, ctx->packs.p[ci], list,
+           count, slabs, slab, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg, dev_range);
   stage_end(ctx, STG_TRACE, on);
   return hipGetLastError();
 }
@@ -755,12 +778,17 @@ static int bx_join_and_retry(mia_hip_ctx* ctx) {
   // stream2, with trace slabs of its own; the planner is waited for behind it
   if (!aside) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
-  hipError_t e = cols <= 64 * 4 ? launch_window<4>(ctx, 0, ctx->d_retry2, 0, range, nullptr, aside)
-               : cols <= 64 * 8 ? launch_window<8>(ctx, 1, ctx->d_retry2, 0, range, nullptr, aside)
-                                : launch_window<12>(ctx, 2, ctx->d_retry2, 0, range, nullptr, aside);
+  // (this launch is the last of the alignment on the context's stream: with ext_events it signals ev_fork, which
+  // mia_hip_iterate's counting sort on stream2 waits for -- see queue_cull)
+  hipEvent_t stop = (aside && (ctx->ext_events & 8u)) ? ctx->ev_fork : nullptr;
+  ctx->align_end_signalled = stop != nullptr;
+  hipError_t e = cols <= 64 * 4 ? launch_window<4>(ctx, 0, ctx->d_retry2, 0, range, nullptr, aside, stop)
+               : cols <= 64 * 8 ? launch_window<8>(ctx, 1, ctx->d_retry2, 0, range, nullptr, aside, stop)
+                                : launch_window<12>(ctx, 2, ctx->d_retry2, 0, range, nullptr, aside, stop);
   if (e != hipSuccess) { ctx->err = std::string("k_align_window (band retry list) launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   if (aside) {
-    HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));      // (the planner's chain ends here)
+    if (!ctx->planner_end_signalled) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));      // (the planner's chain ends here)
+    ctx->planner_end_signalled = false;
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   }
   return MIA_HIP_OK;
@@ -852,7 +880,7 @@ static void encode_now(mia_hip_ctx* ctx) {
 
 // the counters of a deferred alignment, once its control block has reached the host (hb: the words from CTRL_BINS + 3 N_BINS on)
 static void align_counters_collect(mia_hip_ctx* ctx, const int32_t* hb, bool filtered, bool bx, bool plain) {
-  constexpr int C0 = CTRL_BINS + 3 * N_BINS;
+  constexpr int C0 = CTRL_C0;
   const int32_t* h_hdr = hb + (CTRL_HDR - C0);
   const uint32_t* h_filter = reinterpret_cast<const uint32_t*>(hb + (CTRL_FILTER - C0));
   const uint32_t* h_bxc = reinterpret_cast<const uint32_t*>(hb + (CTRL_BXC - C0));
@@ -877,6 +905,7 @@ static int align_all(mia_hip_ctx* ctx) {
   ctx->bx_pending_join = false;
   if (!ctx->spec_ok) { ctx->spec_pending = false; ctx->abort_if = nullptr; }
   ctx->bx_planner_aside = false;
+  ctx->planner_end_signalled = false; ctx->align_end_signalled = false;
   ctx->buckets_queued = 0;                  // (a counting sort queued for an earlier alignment is void)
   if (n == 0) { ctx->aligned = true; return MIA_HIP_OK; }
   RefInfo ref{ctx->d_ref, ctx->L, wrap, ctx->explicit_win};
@@ -1010,6 +1039,7 @@ static int align_all(mia_hip_ctx* ctx) {
       // the plan in two launches (bandx_kernels.h, phase): the reads with anchors on two diagonals are finished by a second launch
       // with every lane at work (MIA_HIP_NO_PLAN_SPLIT=1: by the first threads of their blocks, one launch)
       const bool split = ctx->plan_split;
+      const bool fork_by_launch = (ctx->ext_events & 1u) && new_flow && !(ctx->dbg & 256u);
       bd.cand = nullptr; bd.cand_n = ctx->d_bx_ctr + (size_t)BXC_CAND * BXC_STRIDE;
       if (split) {
         if (n > ctx->cand_cap) { if (dev_alloc(ctx, &ctx->d_bx_cand, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->cand_cap = n; }
@@ -1021,6 +1051,16 @@ static int align_all(mia_hip_ctx* ctx) {
         const dim3 pb(256);
         for (int phase = split ? 1 : 0; phase <= (split ? 2 : 0); phase++) {
           const dim3 pg(phase == 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
+          if (fork_by_launch && phase == (split ? 2 : 0)) {
+            // the fork event rides on this launch's own completion signal: no marker between the plan and the values DP
+            switch ((ctx->max_len + 63) >> 6) {
+              case 1: hipExtLaunchKernelGGL(k_bx_plan<1>, pg, pb, 0, ctx->stream, nullptr, ctx->ev_fork, 0, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
+              case 2: hipExtLaunchKernelGGL(k_bx_plan<2>, pg, pb, 0, ctx->stream, nullptr, ctx->ev_fork, 0, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
+              case 3: hipExtLaunchKernelGGL(k_bx_plan<3>, pg, pb, 0, ctx->stream, nullptr, ctx->ev_fork, 0, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
+              default: hipExtLaunchKernelGGL(k_bx_plan<4>, pg, pb, 0, ctx->stream, nullptr, ctx->ev_fork, 0, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
+            }
+            continue;
+          }
           switch ((ctx->max_len + 63) >> 6) {       // 64-row words of the longest read
             case 1: hipLaunchKernelGGL(k_bx_plan<1>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
             case 2: hipLaunchKernelGGL(k_bx_plan<2>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
@@ -1042,14 +1082,15 @@ static int align_all(mia_hip_ctx* ctx) {
           // stay on the context's stream, right behind the plan -- a cross-stream wait costs 20-30 us each way, and it is the
           // planner with the full-window kernels (short, done long before) that moves to stream2.
           hipStream_t vs = ctx->deferred ? ctx->stream : ctx->stream2;
-          HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+          if (!fork_by_launch) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
           HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
           HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
           if (stage_begin(ctx, STG_BX_TRACE, ctx->stream3)) return MIA_HIP_ERR_NOMEM;
+          const bool sig3 = (ctx->ext_events & 2u) && new_flow && !(ctx->bx_dbg & 8u);
           if (!(ctx->bx_dbg & 8u))
-            hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
+            launch_k(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, sig3 ? ctx->ev_join3 : nullptr, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
           stage_end(ctx, STG_BX_TRACE, ctx->stream3);
-          HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
+          if (!sig3) HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
           if (stage_begin(ctx, STG_BX_VALUES, vs)) return MIA_HIP_ERR_NOMEM;
           if (!(ctx->bx_dbg & 4u)) {
             hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bin_of);
@@ -1171,7 +1212,10 @@ static int align_all(mia_hip_ctx* ctx) {
       HIPCHK(hipGetLastError());
       ck("quad trace");
       if (ctx->use_band) {
-        hipError_t e = launch_window<4>(ctx, 0, ctx->d_retry_list, 0, hdr + PH_RETRY, ps);
+        // (the last launch of the planner's chain: on stream2 it signals ev_join itself, see bx_join_and_retry)
+        const bool sig = ctx->bx_planner_aside && ctx->bx_pending_join && (ctx->ext_events & 4u);
+        hipError_t e = launch_window<4>(ctx, 0, ctx->d_retry_list, 0, hdr + PH_RETRY, ps, false, sig ? ctx->ev_join : nullptr);
+        ctx->planner_end_signalled = sig && e == hipSuccess;
         if (e != hipSuccess) { ctx->err = std::string("k_align_window retry launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
       }
     }
@@ -1180,15 +1224,18 @@ static int align_all(mia_hip_ctx* ctx) {
     ck("band join");
     // the one look at the counters: wide / retry counts, the planner's header, filter and band-pipeline counters lie side by
     // side in the control block
-    constexpr int C0 = CTRL_BINS + 3 * N_BINS, CN = CTRL_WORDS - C0;
+    constexpr int C0 = CTRL_C0, CN = CTRL_CN;
     std::vector<int32_t> pageable;
     int32_t* hb;
     if (ctx->h_pin) hb = reinterpret_cast<int32_t*>(ctx->h_pin);
     else { pageable.resize(CN); hb = pageable.data(); }
     const bool pre_cull = ctx->in_iterate && ctx->comm;
     if (pre_cull) { if (int rcp = comm_pre_cull_enqueue(ctx, d_wide_count)) return rcp; }
-    HIPCHK(hipMemcpyAsync(hb, ctx->d_ctrl + C0, (size_t)CN * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->spec_ok && ctx->h_pin && !pre_cull && !dbg_steps) {
+    const bool spec = ctx->spec_ok && ctx->h_pin && !pre_cull && !dbg_steps;
+    // (a copy in the middle of the step holds the stream up for 20 us: with zero_copy the step's last kernel, k_cons_scatter,
+    // writes these words into h_pin itself, whether or not the speculation held)
+    if (!(spec && ctx->zero_copy)) HIPCHK(hipMemcpyAsync(hb, ctx->d_ctrl + C0, (size_t)CN * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (spec) {
       // mia_hip_iterate, one context, a cut line that needs no scores on the host: no wait here.  The caller queues cull,
       // tally and consensus behind this copy; their kernels look at the exact-kernel count themselves (abort_if) and
       // iterate_body reads these counters when it waits for the consensus (align_counters_collect).
@@ -1781,9 +1828,10 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
   const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
   hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words, ctx->abort_if);
   hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb, ctx->abort_if);
-  hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if);
+  const bool sigb = on != ctx->stream && (ctx->ext_events & 16u);
+  launch_k(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, sigb ? ctx->ev_join : nullptr, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if);
   HIPCHK(hipGetLastError());
-  if (on != ctx->stream) HIPCHK(hipEventRecord(ctx->ev_join, on));
+  if (on != ctx->stream && !sigb) HIPCHK(hipEventRecord(ctx->ev_join, on));
   ctx->buckets_queued = on != ctx->stream ? 2 : 1;
   return MIA_HIP_OK;
 }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_ref_prep(RefPrep a) {
   const int64_t wrap = (int64_t)a.total - 64;
   ref_planes_body(a.codes, (int64_t)a.total, a.plane_words, a.plo, a.phi, a.pok);
   for (int64_t w = tid; w < a.nib_words; w += nth) a.nib[w] = ref_nibble_word(a.codes, wrap, w);
-  for (int64_t p = tid; p < wrap; p += nth) kmer_hash_insert(a.codes, wrap, p, a.kslot, a.kovf, a.kmask, a.kshift, a.kwild);
+  for (int64_t p0 = (int64_t)blockIdx.x * 256; p0 < wrap; p0 += nth) kmer_hash_insert_block(a.codes, wrap, p0, a.kslot, a.kovf, a.kmask, a.kshift, a.kwild);      // (every thread of the block: barriers inside)
 }
 
 enum { CH_LEN = 0, CH_INS_TOTAL, CH_OVERFLOW, CH_N_EVENTS, CH_TALLY_FLAGS, CH_CULL_FLAGS, CH_WORDS = 8 };
@@ -130,14 +130,20 @@ __global__ __launch_bounds__(256) void k_cons_count(const char* calls, const cha
 }
 
 // res = [CH_WORDS header words][string]; pos = exclusive scan of k_cons_count's output, res[CH_LEN] = its total
+// host_res: the same block in pinned host memory, or nullptr -- header and string are then written there and nowhere else (no
+// copy behind the step's last kernel); host_ctr: ctr_words words from ctr_src go there first, whatever abort_if says (the
+// alignment's counters, which tell the host whether the speculation held: see align_all)
 __global__ __launch_bounds__(256) void k_cons_scatter(const char* calls, const char* ins_calls, const int32_t* gaps, const int32_t* ins_off, int32_t L,
                                                         int32_t ins_cap, const int32_t* ins_total, const int32_t* pos, int32_t* res, int32_t out_cap,
-                                                        const int32_t* n_events, const uint32_t* tally_flags, const uint32_t* cull_flags, const int32_t* abort_if = nullptr) {
-  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
+                                                        const int32_t* n_events, const uint32_t* tally_flags, const uint32_t* cull_flags, const int32_t* abort_if = nullptr,
+                                                        int32_t* host_res = nullptr, const int32_t* ctr_src = nullptr, int32_t ctr_words = 0, int32_t* host_ctr = nullptr) {
   const int p = blockIdx.x * 256 + threadIdx.x;
+  if (host_ctr) for (int k = p; k < ctr_words; k += (int)gridDim.x * 256) host_ctr[k] = ctr_src[k];
+  if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int total = *ins_total, len = res[CH_LEN];
   const bool ins_ok = total <= ins_cap, fits = len + 1 <= out_cap;
-  char* out = reinterpret_cast<char*>(res + CH_WORDS);
+  int32_t* dst = host_res ? host_res : res;
+  char* out = reinterpret_cast<char*>(dst + CH_WORDS);
   if (p < L && fits) {
     int32_t o = pos[p];
     if (p > 0 && ins_ok) for (int j = 0; j < gaps[p]; j++) { const char c = ins_calls[ins_off[p] + j]; if (cons_emits(c)) out[o++] = c; }
@@ -146,10 +152,11 @@ __global__ __launch_bounds__(256) void k_cons_scatter(const char* calls, const c
   }
   if (p == 0) {
     if (fits) out[len] = 0;
-    res[CH_INS_TOTAL] = total; res[CH_OVERFLOW] = (ins_ok && fits) ? 0 : 1;
-    res[CH_N_EVENTS] = n_events ? *n_events : 0;
-    res[CH_TALLY_FLAGS] = tally_flags ? (int32_t)*tally_flags : 0;
-    res[CH_CULL_FLAGS] = cull_flags ? (int32_t)*cull_flags : 0;
+    dst[CH_LEN] = len;
+    dst[CH_INS_TOTAL] = total; dst[CH_OVERFLOW] = (ins_ok && fits) ? 0 : 1;
+    dst[CH_N_EVENTS] = n_events ? *n_events : 0;
+    dst[CH_TALLY_FLAGS] = tally_flags ? (int32_t)*tally_flags : 0;
+    dst[CH_CULL_FLAGS] = cull_flags ? (int32_t)*cull_flags : 0;
   }
 }
 
