@@ -328,8 +328,17 @@ __global__ __launch_bounds__(256) void k_slot_count(ReadSet rs, int32_t L, int64
   __syncthreads();
   if (threadIdx.x < 16 && blockIdx.x * 16 + (int)threadIdx.x < nb)
     partial[blockIdx.x * 16 + threadIdx.x] = (int64_t)wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
-  if (!blocks_done) return;                    // (the counts alone: k_scan_partials follows -- mia_hip_cull; the arrival below, with its
-                                               //  device-scope fence per workgroup, was 25 of this kernel's 40 us)
+  if (!blocks_done) {
+    // the counts alone, and behind them (partial[nb + workgroup]) this workgroup's sum: k_cull_records adds up what lies before
+    // each of its blocks itself (raw_nb) -- the arrival below, with its device-scope fence per workgroup, was 25 of this
+    // kernel's 40 us, and a single-workgroup scan between the two kernels (k_scan_partials) another 15
+    if (threadIdx.x == 0) {
+      int64_t g = 0;
+      for (int k = 0; k < 16; k++) g += (int64_t)wsum[k][0] + wsum[k][1] + wsum[k][2] + wsum[k][3];
+      partial[nb + blockIdx.x] = g;
+    }
+    return;
+  }
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(blocks_done, 1u) == (uint32_t)gridDim.x - 1u;
@@ -358,10 +367,30 @@ __global__ __launch_bounds__(256) void k_slot_count(ReadSet rs, int32_t L, int64
 // links (k_cull_mark) of a block of 256 reads in one go: what the three kernels hand each other per read stays in registers.
 __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, const int64_t* partial, int64_t* slot, RecInfo ri, SlotInfo si, int64_t read_base,
                                                         uint32_t* flags, uint8_t* slot_dropped, int64_t n_slots, int32_t hard_cut, double slope, double intercept,
-                                                        int64_t* back_slot, const int64_t* front_slot0, Links lk, const double* dev_cut, const int32_t* abort_if = nullptr) {
+                                                        int64_t* back_slot, const int64_t* front_slot0, Links lk, const double* dev_cut, const int32_t* abort_if = nullptr,
+                                                        int32_t raw_nb = 0, int64_t slot_base = 0, int64_t* total_out = nullptr) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   __shared__ int32_t wsum[4];
+  __shared__ int64_t s_red[2][4], s_first, s_total;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (raw_nb) {
+    // partial[] holds k_slot_count's counts as they are -- per block of 256 reads, and from [raw_nb] on per sixteen blocks:
+    // the first slot of this block = slot_base + the sixteens before its own + the blocks before it in its sixteen
+    const int ng = (raw_nb + 15) >> 4, myg = (int)(blockIdx.x >> 4);
+    int64_t pre = 0, tot = 0;
+    for (int g = threadIdx.x; g < ng; g += 256) { const int64_t v = partial[raw_nb + g]; tot += v; if (g < myg) pre += v; }
+    if (threadIdx.x < 16) { const int b = myg * 16 + (int)threadIdx.x; if (b < (int)blockIdx.x) pre += partial[b]; }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { pre += __shfl_xor(pre, o); tot += __shfl_xor(tot, o); }
+    if (lane == 0) { s_red[0][wv] = pre; s_red[1][wv] = tot; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_first = slot_base + s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+      s_total = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+      if (blockIdx.x == 0 && total_out) *total_out = s_total;
+    }
+    si.n_local_p = &s_total;                  // (rec_store_at reads the total through the pointer: this block's own sum, not a word another block is writing)
+  }
   const int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);     // first read of this wavefront
   const int64_t me = i0 + lane;
   const bool in = me < rs.n;
@@ -374,7 +403,7 @@ __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, con
   const unsigned long long m1 = __ballot(cnt >= 1), m2 = __ballot(cnt == 2), below = (1ull << lane) - 1ull;
   if (lane == 0) wsum[wv] = __popcll(m1) + __popcll(m2);
   __syncthreads();
-  int64_t my_slot = partial[blockIdx.x] + __popcll(m1 & below) + __popcll(m2 & below);
+  int64_t my_slot = (raw_nb ? s_first : partial[blockIdx.x]) + __popcll(m1 & below) + __popcll(m2 & below);
   for (int k = 0; k < wv; k++) my_slot += wsum[k];
   if (in) slot[me] = my_slot;
   // ---- record geometry (k_rec_geom)

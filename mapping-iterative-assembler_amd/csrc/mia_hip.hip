@@ -61,6 +61,7 @@ struct mia_hip_ctx {
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
   bool zero_copy = true;        // mia_hip_iterate: the last kernel writes consensus and counters into pinned host memory itself (MIA_HIP_NO_ZERO_COPY=1: two copies)
   // the launches other streams wait for signal their events themselves (launch_k) instead of a marker behind them; MIA_HIP_NO_EXT_EVENTS=1: markers
+  bool cull_scan = false;
   bool spin_wait = true;        // mia_hip_iterate's one wait asks (hipStreamQuery) instead of sleeping on an interrupt; MIA_HIP_SPIN_WAIT=0: hipStreamSynchronize
   uint32_t ext_events = 31u; bool planner_end_signalled = false, align_end_signalled = false;
   BxCandRec* d_bx_cand = nullptr; int64_t cand_cap = 0; bool plan_split = true;      // k_bx_plan's hand-over list between its two launches (MIA_HIP_NO_PLAN_SPLIT=1: one launch)
@@ -330,6 +331,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* ps2 = getenv("MIA_HIP_NO_PLAN_SPLIT")) ctx->plan_split = atoi(ps2) == 0;
     if (const char* zc = getenv("MIA_HIP_NO_ZERO_COPY")) ctx->zero_copy = atoi(zc) == 0;
     if (const char* ef = getenv("MIA_HIP_NO_EXT_EVENTS")) ctx->ext_events = atoi(ef) ? 0u : 31u;
+    if (const char* cs = getenv("MIA_HIP_CULL_SCAN")) ctx->cull_scan = atoi(cs) != 0;
     if (const char* sw = getenv("MIA_HIP_SPIN_WAIT")) ctx->spin_wait = atoi(sw) != 0;
     if (const char* em = getenv("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
     if (const char* st2 = getenv("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
@@ -554,7 +556,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_wide_list, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_retry_list, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_slot, (size_t)n);
-  rcx |= dev_alloc(ctx, &ctx->d_partial, (size_t)(n / 256 + 2));
+  rcx |= dev_alloc(ctx, &ctx->d_partial, (size_t)(n / 256 + n / 4096 + 8));      // per 256 reads, and behind them per 4 096 (k_slot_count)
   rcx |= dev_alloc(ctx, &ctx->d_drop_f, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_drop_b, (size_t)n);
   ctx->n_slots = 2 * n + 16;
@@ -1501,7 +1503,8 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
     HIPCHK(hipMemsetAsync(ctx->d_cull_sync, 0, 16, ctx->stream));
   }
   hipLaunchKernelGGL(k_slot_count, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_partial, nb, slot_base, ctx->d_total, (uint32_t*)nullptr, ctx->abort_if);
-  hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partial, nb, slot_base, ctx->d_total, ctx->abort_if);
+  // (MIA_HIP_CULL_SCAN=1: the counts scanned by a single-workgroup launch in between, as before)
+  if (ctx->cull_scan) hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, ctx->stream, ctx->d_partial, nb, slot_base, ctx->d_total, ctx->abort_if);
   if (slot_base + 2 * n + 16 > ctx->n_slots) {   // sharded runs: slots are global indices
     uint8_t* nd = nullptr;
     const int64_t ns = slot_base + 2 * n + 16;
@@ -1521,7 +1524,7 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 8, ctx->stream));                     // link count, cull flags (neighbours in the control block)
   hipLaunchKernelGGL(k_cull_records, dim3((unsigned)nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, (const int64_t*)ctx->d_partial, ctx->d_slot, ctx->ri, ctx->si,
                      ctx->read_base, ctx->d_cull_flags, ctx->d_slot_dropped, ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot,
-                     (const int64_t*)ctx->d_front_slot0, ctx->lk, ctx->dev_cut, ctx->abort_if);
+                     (const int64_t*)ctx->d_front_slot0, ctx->lk, ctx->dev_cut, ctx->abort_if, ctx->cull_scan ? 0 : nb, slot_base, ctx->d_total);
   HIPCHK(hipGetLastError());
   // by default the links to apply are this context's own; a sharded run replaces them with the gathered list (mia_hip_set_links)
   ctx->d_links_all = ctx->lk.rec;
