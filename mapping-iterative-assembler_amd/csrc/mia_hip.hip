@@ -61,7 +61,7 @@ struct mia_hip_ctx {
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
   bool zero_copy = true;        // mia_hip_iterate: the last kernel writes consensus and counters into pinned host memory itself (MIA_HIP_NO_ZERO_COPY=1: two copies)
   // the launches other streams wait for signal their events themselves (launch_k) instead of a marker behind them; MIA_HIP_NO_EXT_EVENTS=1: markers
-  bool cull_scan = false;
+  bool cull_scan = false, tail_scans = false;
   bool spin_wait = true;        // mia_hip_iterate's one wait asks (hipStreamQuery) instead of sleeping on an interrupt; MIA_HIP_SPIN_WAIT=0: hipStreamSynchronize
   uint32_t ext_events = 31u; bool planner_end_signalled = false, align_end_signalled = false;
   BxCandRec* d_bx_cand = nullptr; int64_t cand_cap = 0; bool plan_split = true;      // k_bx_plan's hand-over list between its two launches (MIA_HIP_NO_PLAN_SPLIT=1: one launch)
@@ -332,6 +332,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* zc = getenv("MIA_HIP_NO_ZERO_COPY")) ctx->zero_copy = atoi(zc) == 0;
     if (const char* ef = getenv("MIA_HIP_NO_EXT_EVENTS")) ctx->ext_events = atoi(ef) ? 0u : 31u;
     if (const char* cs = getenv("MIA_HIP_CULL_SCAN")) ctx->cull_scan = atoi(cs) != 0;
+    if (const char* ts = getenv("MIA_HIP_TAIL_SCANS")) ctx->tail_scans = atoi(ts) != 0;
     if (const char* sw = getenv("MIA_HIP_SPIN_WAIT")) ctx->spin_wait = atoi(sw) != 0;
     if (const char* em = getenv("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
     if (const char* st2 = getenv("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;

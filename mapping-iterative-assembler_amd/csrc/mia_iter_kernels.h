@@ -130,22 +130,56 @@ __global__ __launch_bounds__(256) void k_cons_count(const char* calls, const cha
 }
 
 // res = [CH_WORDS header words][string]; pos = exclusive scan of k_cons_count's output, res[CH_LEN] = its total
+// The same prefix sums without a launch of their own, for sequences of a few ten thousand elements (a mitochondrion's columns):
+// a block of 256 threads adds up everything before its own 256 elements itself -- at most n/256 loads per thread, all in
+// flight together, against 12 us for one workgroup walking the whole sequence between two kernels.  Returns the exclusive
+// prefix sum at element blockIdx.x * 256 + threadIdx.x (elements outside [lo_valid, hi_valid) count as 0); *all = the sum of
+// everything if want_all, else undefined.  Every thread of the block must call it.
+__device__ __forceinline__ int32_t block_prefix_256(const int32_t* in, int32_t n, int32_t lo_valid, int32_t hi_valid, bool want_all, int32_t* all) {
+  __shared__ int32_t s_w[2][4], s_scan[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int first = (int)blockIdx.x * 256;
+  auto val = [&](int q) -> int32_t { return (q < n && q >= lo_valid && q < hi_valid) ? in[q] : 0; };
+  int32_t before = 0, rest = 0;
+  const int stop = want_all ? n : min(first, n);
+#pragma unroll 8
+  for (int q = t; q < stop; q += 256) { const int32_t v = val(q); if (q < first) before += v; else rest += v; }
+  const int32_t mine = val(first + t);
+  int32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { before += __shfl_xor(before, o); rest += __shfl_xor(rest, o); }
+  if (lane == 63) s_scan[wv] = inc;
+  if (lane == 0) { s_w[0][wv] = before; s_w[1][wv] = rest; }
+  __syncthreads();
+  int32_t pre = s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3];
+  *all = pre + s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3];
+  for (int k = 0; k < wv; k++) pre += s_scan[k];
+  return pre + inc - mine;
+}
+
 // host_res: the same block in pinned host memory, or nullptr -- header and string are then written there and nowhere else (no
 // copy behind the step's last kernel); host_ctr: ctr_words words from ctr_src go there first, whatever abort_if says (the
 // alignment's counters, which tell the host whether the speculation held: see align_all)
 __global__ __launch_bounds__(256) void k_cons_scatter(const char* calls, const char* ins_calls, const int32_t* gaps, const int32_t* ins_off, int32_t L,
                                                         int32_t ins_cap, const int32_t* ins_total, const int32_t* pos, int32_t* res, int32_t out_cap,
                                                         const int32_t* n_events, const uint32_t* tally_flags, const uint32_t* cull_flags, const int32_t* abort_if = nullptr,
-                                                        int32_t* host_res = nullptr, const int32_t* ctr_src = nullptr, int32_t ctr_words = 0, int32_t* host_ctr = nullptr) {
+                                                        int32_t* host_res = nullptr, const int32_t* ctr_src = nullptr, int32_t ctr_words = 0, int32_t* host_ctr = nullptr,
+                                                        int32_t counts_in_pos = 0) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (host_ctr) for (int k = p; k < ctr_words; k += (int)gridDim.x * 256) host_ctr[k] = ctr_src[k];
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
-  const int total = *ins_total, len = res[CH_LEN];
+  // counts_in_pos: pos[] holds k_call_inserts_count's counts as they are, and res[CH_LEN] nothing yet -- the block works out
+  // where its columns start and how long the string is (block_prefix_256) instead of a single-workgroup scan in between
+  int32_t my_pos = 0, len_all = 0;
+  if (counts_in_pos) my_pos = block_prefix_256(pos, L, 0, L, true, &len_all);
+  const int total = *ins_total, len = counts_in_pos ? len_all : res[CH_LEN];
   const bool ins_ok = total <= ins_cap, fits = len + 1 <= out_cap;
   int32_t* dst = host_res ? host_res : res;
   char* out = reinterpret_cast<char*>(dst + CH_WORDS);
   if (p < L && fits) {
-    int32_t o = pos[p];
+    int32_t o = counts_in_pos ? my_pos : pos[p];
     if (p > 0 && ins_ok) for (int j = 0; j < gaps[p]; j++) { const char c = ins_calls[ins_off[p] + j]; if (cons_emits(c)) out[o++] = c; }
     const char c = calls[p];
     if (cons_emits(c)) out[o++] = c;
@@ -165,9 +199,19 @@ __global__ __launch_bounds__(256) void k_cons_scatter(const char* calls, const c
 // k_call_inserts_count: the insert columns' calls (k_call_inserts) and the characters each column contributes (k_cons_count)
 // -- a column's count needs only its own insert calls.  (Putting the whole tail into two single-workgroup kernels was
 // tried: a workgroup alone on 16.6 k columns takes 44 + 111 us, the five launches it saves cost 25.)
-__global__ __launch_bounds__(256) void k_call_columns_z(const int32_t* tally, int32_t Lp, int32_t L, int cons_code, char* calls, int32_t* zero, int64_t zero_words, const int32_t* abort_if = nullptr) {
+// gaps / ins_off / ins_total (or nullptr): on the side as well, ins_off[p] = gaps[1] + .. + gaps[p-1] for p < Lp and their sum --
+// what k_excl_scan(gaps, Lp, 1, L, ins_off, ins_total) leaves; the grid must cover Lp columns then (block_prefix_256)
+__global__ __launch_bounds__(256) void k_call_columns_z(const int32_t* tally, int32_t Lp, int32_t L, int cons_code, char* calls, int32_t* zero, int64_t zero_words, const int32_t* abort_if = nullptr,
+                                                          const int32_t* gaps = nullptr, int32_t* ins_off = nullptr, int32_t* ins_total = nullptr) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int p = blockIdx.x * 256 + threadIdx.x;
+  if (gaps) {
+    const bool last = (int)blockIdx.x == (Lp - 1) / 256;
+    int32_t all = 0;
+    const int32_t off = block_prefix_256(gaps, Lp, 1, L, last, &all);
+    if (p < Lp) ins_off[p] = off;
+    if (last && threadIdx.x == 0) *ins_total = all;
+  }
   for (int64_t k = p; k < zero_words; k += (int64_t)gridDim.x * 256) zero[k] = 0;
   if (p >= L) return;
   calls[p] = call_base(tally[T_A * Lp + p], tally[T_C * Lp + p], tally[T_G * Lp + p], tally[T_T * Lp + p], tally[T_GAP * Lp + p], tally[T_COV * Lp + p],
