@@ -153,36 +153,34 @@ __device__ __forceinline__ void kmer_hash_insert(const uint8_t* codes, int64_t n
   if (k < 0 || k > wild) return;
   for (uint32_t x = 0; x < (1u << (2 * k)); x++) kmer_hash_insert_key(kmer_wild_key(base, npos, k, x), p, slot, ovf, mask, shift);
 }
-// the same for 256 consecutive positions by a whole workgroup: a 10-mer with two or three N columns has 16 or 64 spellings, and
+// the same for 64 consecutive positions by a whole workgroup: a 10-mer with two or three N columns has 16 or 64 spellings, and
 // a thread that enters them one after the other is what a reference full of ambiguity codes (mt311: one 10-mer in six) made
-// k_ref_prep wait for -- 0.16 ms.  Those positions go on a list in LDS and the block's threads share their spellings out.
+// k_ref_prep wait for -- 0.16 ms.  Here the positions' spellings are numbered through (a prefix sum over the 64 counts) and
+// dealt to the 256 threads one by one, whatever position they belong to.
 __device__ __forceinline__ void kmer_hash_insert_block(const uint8_t* codes, int64_t n_codes, int64_t p0, uint32_t* slot, int32_t* ovf, uint32_t mask, int32_t shift,
                                                        int32_t wild) {
-  __shared__ int32_t q_n;
-  __shared__ uint16_t q_t[256];
-  if (threadIdx.x == 0) q_n = 0;
-  __syncthreads();
-  {
-    const int64_t p = p0 + threadIdx.x;
+  __shared__ uint32_t s_base[64];
+  __shared__ uint64_t s_npos[64];
+  __shared__ int32_t s_k[64], s_off[65];
+  if (threadIdx.x < 64) {
     uint32_t base;
     uint64_t npos;
-    const int k = kmer_wild_at(codes, n_codes, p, &base, &npos);
-    if (k >= 0 && k <= wild) {
-      if (k >= 2) q_t[atomicAdd(&q_n, 1)] = (uint16_t)threadIdx.x;
-      else for (uint32_t x = 0; x < (1u << (2 * k)); x++) kmer_hash_insert_key(kmer_wild_key(base, npos, k, x), p, slot, ovf, mask, shift);
-    }
+    const int k = kmer_wild_at(codes, n_codes, p0 + threadIdx.x, &base, &npos);
+    const int32_t cnt = (k >= 0 && k <= wild) ? (1 << (2 * k)) : 0;
+    s_base[threadIdx.x] = base; s_npos[threadIdx.x] = npos; s_k[threadIdx.x] = k;
+    int32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int32_t u = __shfl_up(inc, o); if ((int)threadIdx.x >= o) inc += u; }
+    s_off[threadIdx.x + 1] = inc;
+    if (threadIdx.x == 0) s_off[0] = 0;
   }
   __syncthreads();
-  const int nq = q_n;
-  for (int q0 = 0; q0 < nq; q0 += 4) {                 // four listed positions per step, 64 threads each
-    const int q = q0 + (int)(threadIdx.x >> 6);
-    if (q >= nq) continue;
-    const int64_t p = p0 + q_t[q];
-    uint32_t base;
-    uint64_t npos;
-    const int k = kmer_wild_at(codes, n_codes, p, &base, &npos);
-    const uint32_t x = threadIdx.x & 63u;
-    if (x < (1u << (2 * k))) kmer_hash_insert_key(kmer_wild_key(base, npos, k, x), p, slot, ovf, mask, shift);
+  const int32_t total = s_off[64];
+  for (int32_t item = threadIdx.x; item < total; item += 256) {
+    int j = 0;                                     // the position whose spellings hold `item`: largest j with s_off[j] <= item
+#pragma unroll
+    for (int step = 32; step; step >>= 1) if (s_off[j + step] <= item) j += step;
+    kmer_hash_insert_key(kmer_wild_key(s_base[j], s_npos[j], s_k[j], (uint32_t)(item - s_off[j])), p0 + j, slot, ovf, mask, shift);
   }
   __syncthreads();
 }

@@ -987,7 +987,7 @@ static int align_all(mia_hip_ctx* ctx) {
         rp2.kslot = ctx->d_khash; rp2.kovf = ctx->d_khash_ovf; rp2.kslots = kslots; rp2.kmask = kh.mask; rp2.kshift = kh.shift; rp2.kwild = kh.wild;
         rp2.plane_words = words; rp2.plo = ctx->d_planes; rp2.phi = ctx->d_planes + ctx->plane_cap; rp2.pok = ctx->d_planes + 2 * ctx->plane_cap;
         rp2.nib_words = nw; rp2.nib = ctx->d_refnib;
-        const int64_t want = ((int64_t)wrap + 255) / 256;
+        const int64_t want = ((int64_t)wrap + (kh.wild > 0 ? 63 : 255)) / (kh.wild > 0 ? 64 : 256);       // (N columns spelled out: 64 positions per workgroup, see kmer_hash_insert_block)
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, ctx->cus));      // one workgroup per compute unit at most: all resident
         ctx->prep_bar_count += grid;
         rp2.bar = ctx->d_prep_bar; rp2.bar_target = ctx->prep_bar_count;

@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void k_ref_prep(RefPrep a) {
   const int64_t wrap = (int64_t)a.total - 64;
   ref_planes_body(a.codes, (int64_t)a.total, a.plane_words, a.plo, a.phi, a.pok);
   for (int64_t w = tid; w < a.nib_words; w += nth) a.nib[w] = ref_nibble_word(a.codes, wrap, w);
-  for (int64_t p0 = (int64_t)blockIdx.x * 256; p0 < wrap; p0 += nth) kmer_hash_insert_block(a.codes, wrap, p0, a.kslot, a.kovf, a.kmask, a.kshift, a.kwild);      // (every thread of the block: barriers inside)
+  if (a.kwild > 0)        // N columns spelled out: 64 positions per workgroup and round (every thread of the block: barriers inside)
+    for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < wrap; p0 += (int64_t)gridDim.x * 64) kmer_hash_insert_block(a.codes, wrap, p0, a.kslot, a.kovf, a.kmask, a.kshift, a.kwild);
+  else
+    for (int64_t p = tid; p < wrap; p += nth) kmer_hash_insert(a.codes, wrap, p, a.kslot, a.kovf, a.kmask, a.kshift, 0);
 }
 
 enum { CH_LEN = 0, CH_INS_TOTAL, CH_OVERFLOW, CH_N_EVENTS, CH_TALLY_FLAGS, CH_CULL_FLAGS, CH_WORDS = 8 };
