@@ -193,7 +193,7 @@ struct mia_hip_ctx {
   const double* dev_cut = nullptr; double* d_cut_buf = nullptr;
   int min_len = 0;                          // shortest stored read
   std::vector<int32_t> h_len;               // read lengths on the host (the score-cut regression of reads of different lengths)
-  char* d_ascii = nullptr; int64_t ascii_cap = 0;
+  char* d_ascii = nullptr; int64_t ascii_cap = 0; const char* ascii_src = nullptr;     // ascii_src: where the pending reference is read from (d_ascii, or the pinned staging area)
   char* d_cons = nullptr; int64_t cons_cap = 0;              // result of an iteration: [CH_WORDS header][consensus string]
   int32_t* d_cons_pos = nullptr; int64_t cons_pos_cap = 0;
   unsigned char* h_pin2 = nullptr; size_t pin2_bytes = 0;   // results of an iteration (header + consensus string)
@@ -877,7 +877,7 @@ static int run_wide(mia_hip_ctx* ctx, const RefInfo& ref, int32_t n_wide) {
 static void encode_now(mia_hip_ctx* ctx) {
   if (!ctx->pend_encode) return;
   ctx->pend_encode = false;
-  hipLaunchKernelGGL(k_ref_encode, dim3((unsigned)((ctx->pend_total + 255) / 256)), dim3(256), 0, ctx->stream, (const char*)ctx->d_ascii, ctx->pend_L, ctx->pend_wl,
+  hipLaunchKernelGGL(k_ref_encode, dim3((unsigned)((ctx->pend_total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->ascii_src, ctx->pend_L, ctx->pend_wl,
                      ctx->d_ref, ctx->pend_total);
 }
 
@@ -982,7 +982,7 @@ static int align_all(mia_hip_ctx* ctx) {
       const KmerHash kh{ctx->d_khash, ctx->d_khash_ovf, kslots - 1, kh_shift_for(kslots), ctx->kh_entries > 0 ? BX_WILD : 0};
       if (fused_prep) {
         RefPrep rp2;
-        rp2.ascii = (const char*)ctx->d_ascii; rp2.L = ctx->pend_L; rp2.wl = ctx->pend_wl; rp2.total = ctx->pend_total; rp2.codes = ctx->d_ref;
+        rp2.ascii = ctx->ascii_src; rp2.L = ctx->pend_L; rp2.wl = ctx->pend_wl; rp2.total = ctx->pend_total; rp2.codes = ctx->d_ref;
         rp2.ctrl = ctx->d_ctrl; rp2.ctrl_words = CTRL_WORDS;
         rp2.kslot = ctx->d_khash; rp2.kovf = ctx->d_khash_ovf; rp2.kslots = kslots; rp2.kmask = kh.mask; rp2.kshift = kh.shift; rp2.kwild = kh.wild;
         rp2.plane_words = words; rp2.plo = ctx->d_planes; rp2.phi = ctx->d_planes + ctx->plane_cap; rp2.pok = ctx->d_planes + 2 * ctx->plane_cap;
