@@ -267,8 +267,8 @@ class Pipeline:
             ms, k = st[name]
             if k <= 0 or ms <= 0:
                 continue
-            if name == "k_align_quad":
-                k = steps                          # several launches per step (quad, window classes, retries): one figure per step
+            if name in STAGE_KERNELS:
+                k = steps                          # several launches per step (quad, window classes, retries; values DP + late trace): one figure per step
             reads, cells = per_launch[name]
             if name == "k_align_quad":
                 reads = reads * st[name][1] / steps

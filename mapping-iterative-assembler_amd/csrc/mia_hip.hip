@@ -61,7 +61,7 @@ struct mia_hip_ctx {
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
   bool zero_copy = true;        // mia_hip_iterate: the last kernel writes consensus and counters into pinned host memory itself (MIA_HIP_NO_ZERO_COPY=1: two copies)
   // the launches other streams wait for signal their events themselves (launch_k) instead of a marker behind them; MIA_HIP_NO_EXT_EVENTS=1: markers
-  bool cull_scan = false, tail_scans = false;
+  bool cull_scan = false, tail_scans = false, stage_markers = false;
   bool spin_wait = true;        // mia_hip_iterate's one wait asks (hipStreamQuery) instead of sleeping on an interrupt; MIA_HIP_SPIN_WAIT=0: hipStreamSynchronize
   uint32_t ext_events = 31u; bool planner_end_signalled = false, align_end_signalled = false;
   BxCandRec* d_bx_cand = nullptr; int64_t cand_cap = 0; bool plan_split = true;      // k_bx_plan's hand-over list between its two launches (MIA_HIP_NO_PLAN_SPLIT=1: one launch)
@@ -332,6 +332,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* zc = getenv("MIA_HIP_NO_ZERO_COPY")) ctx->zero_copy = atoi(zc) == 0;
     if (const char* ef = getenv("MIA_HIP_NO_EXT_EVENTS")) ctx->ext_events = atoi(ef) ? 0u : 31u;
     if (const char* cs = getenv("MIA_HIP_CULL_SCAN")) ctx->cull_scan = atoi(cs) != 0;
+    if (const char* sm = getenv("MIA_HIP_STAGE_MARKERS")) ctx->stage_markers = atoi(sm) != 0;
     if (const char* ts = getenv("MIA_HIP_TAIL_SCANS")) ctx->tail_scans = atoi(ts) != 0;
     if (const char* sw = getenv("MIA_HIP_SPIN_WAIT")) ctx->spin_wait = atoi(sw) != 0;
     if (const char* em = getenv("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
@@ -632,6 +633,31 @@ static int stage_begin(mia_hip_ctx* ctx, Stage st, hipStream_t on = nullptr) {
 }
 static void stage_end(mia_hip_ctx* ctx, Stage st, hipStream_t on = nullptr) {
   if (((ctx->stage_mask >> st) & 1u) && !ctx->stg[st].pending.empty()) (void)hipEventRecord(ctx->stg[st].pending.back().second, on ? on : ctx->stream);
+}
+
+// One launch of a timed stage whose kernel carries no event for another stream: the event pair rides on the launch itself
+// (start and end of that dispatch, no marker packets in front of and behind the kernel -- on the critical path those cost
+// the step 10-20 us each, and the timed region of bench.py times the dominant stage in every step); MIA_HIP_STAGE_MARKERS=1
+// or an untimed stage: the launch as it is, between stage_begin / stage_end.
+template <typename... KArgs, typename... Args>
+static int stage_launch(mia_hip_ctx* ctx, Stage st, void (*kernel)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "every kernel argument, defaults included");
+  if (!((ctx->stage_mask >> st) & 1u) || ctx->stage_markers) {
+    if (stage_begin(ctx, st, s)) return -1;
+    hipLaunchKernelGGL(kernel, g, b, shm, s, static_cast<KArgs>(args)...);
+    stage_end(ctx, st, s);
+    return 0;
+  }
+  if (ctx->ev_free.empty()) {
+    hipEvent_t x, y;
+    if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) return -1;
+    ctx->ev_free.push_back({x, y});
+  }
+  auto p = ctx->ev_free.back();
+  ctx->ev_free.pop_back();
+  ctx->stg[st].pending.push_back(p);
+  hipExtLaunchKernelGGL(kernel, g, b, (uint32_t)shm, s, p.first, p.second, 0, static_cast<KArgs>(args)...);
+  return 0;
 }
 
 static void drain_events(mia_hip_ctx* ctx) {
@@ -1094,12 +1120,11 @@ static int align_all(mia_hip_ctx* ctx) {
             launch_k(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, sig3 ? ctx->ev_join3 : nullptr, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
           stage_end(ctx, STG_BX_TRACE, ctx->stream3);
           if (!sig3) HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
-          if (stage_begin(ctx, STG_BX_VALUES, vs)) return MIA_HIP_ERR_NOMEM;
           if (!(ctx->bx_dbg & 4u)) {
-            hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bin_of);
-            hipLaunchKernelGGL(k_bxl_trace_late, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of);
+            if (stage_launch(ctx, STG_BX_VALUES, k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bin_of) ||
+                stage_launch(ctx, STG_BX_VALUES, k_bxl_trace_late, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of))
+              return MIA_HIP_ERR_NOMEM;
           }
-          stage_end(ctx, STG_BX_VALUES, vs);
           if (!ctx->deferred) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
           HIPCHK(hipGetLastError());
           ctx->bx_planner_aside = ctx->deferred;
@@ -1869,16 +1894,14 @@ static int tally_launch(mia_hip_ctx* ctx) {
       }
       // (the bit planes and the N marks of the context's own reads: k_read_planes / k_bx_umax at upload)
       const bool planes_ok = ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax;
-      if (stage_begin(ctx, STG_TALLY)) return MIA_HIP_ERR_NOMEM;
-      if (ctx->tally_linear)
-        hipLaunchKernelGGL(k_tally_binned<true>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
+      if (ctx->tally_linear
+            ? stage_launch(ctx, STG_TALLY, k_tally_binned<true>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                            ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
-                           planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb, -1, ctx->abort_if);
-      else
-        hipLaunchKernelGGL(k_tally_binned<false>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
+                           planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb, -1, ctx->abort_if)
+            : stage_launch(ctx, STG_TALLY, k_tally_binned<false>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                            ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
-                           (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb, ctx->tally_pk_bias, ctx->abort_if);
-      stage_end(ctx, STG_TALLY);
+                           (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb, ctx->tally_pk_bias, ctx->abort_if))
+        return MIA_HIP_ERR_NOMEM;
       hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256, TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs, ctx->abort_if);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
