@@ -51,7 +51,8 @@ def bytes_per_read(read_len):
     return (read_len + 1) // 2 + 16 + 16 + read_len
 
 
-PMC_DIR = os.path.join(ROOT, "profiles", "r03", "pmc")
+PROFILE_ROUND = "r04"
+PMC_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc")
 CSRC = os.path.join(ROOT, "mapping-iterative-assembler_amd", "csrc")
 STAGES = ["k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_trace", "k_align_quad_plain", "k_align_quad", "k_tally_binned"]
 # the full-window stage is timed as a whole: k_align_quad (four reads per wavefront, windows up to 208 columns) and the
@@ -59,6 +60,13 @@ STAGES = ["k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_tra
 # the band DPs are timed by stream: stream2 carries the values DP and, behind it, the trace DP of its left-overs
 STAGE_KERNELS = {"k_align_quad": ["k_align_quad", "k_align_window"], "k_bx_values": ["k_bxl_values", "k_bxl_trace_late"], "k_bx_trace": ["k_bxl_trace"],
                  "k_bx_plan": ["k_bx_plan"]}           # (the plan is two launches of one kernel per step)
+# what `roofline.kernel` may name: stages that are ONE kernel of the rocprofv3 kernel trace (profiles/r0N/cfgK_kernel_stats.csv),
+# under the name it carries there; stage groups (k_bx_values = values DP + late trace, k_align_quad = quad + window classes)
+# are reported under roofline.groups in bench_extras.json, never as the dominant kernel
+ROCPROF_NAME = {"k_bx_trace": "k_bxl_trace", "k_tally_binned": "k_tally_binned", "k_diag_filter": "k_diag_filter",
+                "k_band_align": "k_band_align", "k_align_quad_plain": "k_align_quad_plain"}
+EXTRAS_FILE = "bench_extras.json"
+HEADLINE_MAX = 4096
 
 
 def source_hash():
@@ -339,16 +347,20 @@ def dp_phase(stages, peaks):
 
 def roofline(stages, peaks, pmc_tag, pmc_stale):
     timed = [s for s in stages if s.get("timed_region")]
-    dom = timed[0] if timed else max(stages, key=lambda s: s["ms_per_step"])
+    single = [s for s in stages if s["kernel"] in ROCPROF_NAME]
+    dom = timed[0] if timed else max(single or stages, key=lambda s: s["ms_per_step"])
     r = {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
-         "kernel": dom["kernel"], "kernel_ms": dom["kernel_ms"], "launches": dom["launches"], "reads_per_launch": dom["reads_per_launch"],
+         "kernel": ROCPROF_NAME.get(dom["kernel"], dom["kernel"]), "stage": dom["kernel"],
+         "kernel_ms": dom["kernel_ms"], "launches": dom["launches"], "reads_per_launch": dom["reads_per_launch"],
+
          "primary_bound": "valu",
          "valu": {"bound": "valu", "achieved": (dom["valu_insts"] / (dom["kernel_ms"] * 1e-3) / 1e9) if dom.get("valu_insts") else None,
                   "peak": peaks.get("valu_ginst_s") if peaks else None, "unit": "1e9 wave64 instructions/s", "frac": dom["valu_frac"]},
          "peak_measured_copy": peaks.get("hbm_copy_gbs") if peaks else None,
          "frac_of_measured_copy": dom["achieved"] / peaks["hbm_copy_gbs"] if peaks and peaks.get("hbm_copy_gbs") else None,
-         "pmc": {"summary": f"profiles/r03/pmc/{pmc_tag}.json", "from_this_build": not pmc_stale},
+         "pmc": {"summary": f"profiles/{PROFILE_ROUND}/pmc/{pmc_tag}.json", "from_this_build": not pmc_stale},
          "dp_phase": dp_phase(stages, peaks),
+         "groups": [s for s in stages if s["kernel"] in STAGE_KERNELS and s["kernel"] not in ROCPROF_NAME],
          "stages": stages,
          "note": "integer DP: the kernels are bound by VALU issue, not HBM -- `frac` prices the SURVEY 8(d) algorithmic bytes of the "
                  "kernel with the most time per step against the nominal 8 TB/s as the contract asks; `valu.frac` = its VALU "
@@ -389,7 +401,7 @@ def section_converge(hip_mod, device, cfg, n, seed, peaks, no_cpu, max_iters=12)
     pipe.reset_stats()
     cur = run_steps(pipe, cur, 2)                   # which kernel takes the most time in the converged state
     st = hip.stage_stats()
-    dominant = max((k for k in STAGES), key=lambda k: st[k][0])
+    dominant = max((k for k in STAGES if k in ROCPROF_NAME), key=lambda k: st[k][0])
     hip.set_timed_stages([dominant])
     pipe.reset_stats()
     hip.sync()
@@ -413,7 +425,7 @@ def section_converge(hip_mod, device, cfg, n, seed, peaks, no_cpu, max_iters=12)
     hip.sync()
     first_warm_ms = (time.perf_counter() - t0) * 1e3
     _, first_counts = pipe.stages(1, None, None, True)
-    out = {"workload": f"configs[{cfg}]: {n} synthetic {w['read_len']} bp aDNA-damaged reads vs {w['ref_name']}, matrix {w['matrix_file']}; "
+    out = {"reads": n, "workload": f"configs[{cfg}]: {n} synthetic {w['read_len']} bp aDNA-damaged reads vs {w['ref_name']}, matrix {w['matrix_file']}; "
                        "pass-1 coordinates = true positions",
            "iterations_to_convergence": rounds, "converged": converged, "ms_per_iteration": it_ms,
            "reads_per_s_per_iteration": n * rounds / (sum(it_ms) * 1e-3),
@@ -528,6 +540,75 @@ def section_cli(w, n=1_000_000):
     return out
 
 
+def write_extras(out):
+    """Everything the run measured (stage tables, configs2/3/4 sections, pass 1, Myers, CLI, peaks, notes) goes to
+    bench_extras.json beside bench.py -- and to gpurun_out/ when that exists, so it comes back from a GPU box; the one
+    stdout line is the compact headline (a 21 KB line was more than the driver parses)."""
+    path = os.path.join(ROOT, EXTRAS_FILE)
+    for p in (path, os.path.join(ROOT, "gpurun_out", EXTRAS_FILE)):
+        if os.path.isdir(os.path.dirname(p)):
+            try:
+                with open(p, "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError as e:                       # (a read-only tree must not cost the run its line)
+                sys.stderr.write("bench.py: %s not written: %s\n" % (p, e))
+    return EXTRAS_FILE
+
+
+def _r(x, nd=4):
+    """shorten floats for the headline: 4 significant decimals are more than the measurement holds"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def headline(out, extras_path):
+    """The driver's line: the contract's keys, the roofline of the dominant KERNEL (a name of the rocprofv3 kernel trace),
+    the CPU baseline, and the product-speed figures (first iteration, to convergence); the rest is in `extras`."""
+    ro = out["roofline"]
+    h = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                             "dtype", "data", "config") if k in out}
+    rl = {k: ro.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "launches", "reads_per_launch",
+                                 "primary_bound", "peak_measured_copy", "frac_of_measured_copy")}
+    rl["bytes_per_read"] = out["config"].get("bytes_per_read")
+    if ro.get("valu"):
+        rl["valu"] = {k: ro["valu"].get(k) for k in ("achieved", "peak", "unit", "frac")}
+    if ro.get("dp_phase"):
+        rl["dp_phase"] = {k: ro["dp_phase"].get(k) for k in ("wall_ms", "frac", "gcups")}
+    rl["pmc"] = ro.get("pmc")
+    h["roofline"] = rl
+    if "cpu_baseline" in out:
+        cb = dict(out["cpu_baseline"])
+        cb["sample"] = str(cb.get("sample", ""))[:200]
+        h["cpu_baseline"] = cb
+    for k in ("value_first_iteration", "collectives", "communicator", "collectives_note"):
+        if k in out:
+            h[k] = out[k]
+    if "first_iteration" in out:
+        h["first_iteration_ms"] = out["first_iteration"]["ms"]
+        h["first_iteration_over_steady"] = out["first_iteration"]["over_steady"]
+    conv = {}
+    for k in ("configs2", "configs3", "configs4"):
+        c = out.get(k)
+        if c:
+            conv[k] = {"reads": c.get("reads"), "iterations": c["iterations_to_convergence"], "value_to_convergence": c["reads_per_s_per_iteration"],
+                       "steady_ms": c["steady_state_ms_per_iteration"], "first_ms": c["first_iteration_again_ms"],
+                       "first_over_steady": c["first_iteration_over_steady"], "steady_reads_per_s": c["steady_state_reads_per_s"],
+                       "roofline_kernel": c["roofline"]["kernel"], "roofline_frac": c["roofline"]["frac"],
+                       "cpu_reads_per_s": (c.get("cpu_baseline") or {}).get("value")}
+    if conv:
+        h["to_convergence"] = conv
+        h["value_to_convergence"] = conv.get("configs2", {}).get("value_to_convergence")
+    if "weak" in out:
+        h["weak"] = {k: out["weak"].get(k) for k in ("value", "ms_per_step", "reads_per_gpu", "total_reads")}
+    h["extras"] = extras_path
+    return _r(h)
+
+
 def self_launch(a):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks here -- BEFORE anything touches a GPU (a
     child process per rank through torch.distributed.run) -- pass their output through and leave with their exit code.
@@ -559,14 +640,22 @@ def timed_job(a, env, cfg, reads, scaling, peaks=None):
     # hands out through torch.distributed); --coll torch keeps them in Python over torch.distributed (dist.py) instead
     c_comm, coll_note, comm_info = False, None, None
     if (world > 1 or force_dist) and a.coll == "rccl":
+        # no silent fallback: if the library's communicator cannot be made the run ends non-zero -- the
+        # Python path over torch.distributed runs only when asked for by name (--coll torch)
         try:
             box = [mia_amd.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             hip.comm_init(box[0], world, rank)
             c_comm = True
             comm_info = hip.comm_info()                 # what RCCL itself says: (ncclCommCount, ncclCommUserRank, "rccl")
-        except Exception as e:              # noqa: BLE001 -- a second way to run beats no number at all; the line says which one ran
-            coll_note = "library communicator failed (%s): collectives through torch.distributed" % e
+        except Exception as e:              # noqa: BLE001
+            sys.stderr.write("bench.py: rank %d: the library's RCCL communicator failed (%s); not falling back -- run with "
+                             "--coll torch to time the torch.distributed path instead\n" % (rank, e))
+            sys.stderr.flush()
+            os._exit(4)                     # (the other ranks sit in a collective: the launcher takes them down with this one)
+        if comm_info and comm_info[0] != world:
+            sys.stderr.write("bench.py: communicator reports %d ranks, launched %d\n" % (comm_info[0], world))
+            os._exit(4)
     pipe = Pipeline(hip, w, world, rank, force_dist, breakdown=bool(os.environ.get("MIA_BENCH_BREAKDOWN")), c_comm=c_comm)
     cur = w["ref"]
     dominant = None
@@ -576,7 +665,7 @@ def timed_job(a, env, cfg, reads, scaling, peaks=None):
         cur = pipe.step(cur)
     if a.warmup >= 2:
         st = hip.stage_stats()
-        dominant = max((k for k in STAGES), key=lambda k: st[k][0])
+        dominant = max((k for k in STAGES if k in ROCPROF_NAME), key=lambda k: st[k][0])
         # HIP events cost the stream a few microseconds each: over the timed region only the dominant kernel carries them;
         # the other stages are timed in as many instrumented steps after it
         hip.set_timed_stages([dominant])
@@ -778,9 +867,12 @@ def main():
             out["configs2"] = section_converge(mia_amd, local, 2, 1_000_000, 3, peaks, a.no_cpu_baseline)
             out["configs3"] = section_converge(mia_amd, local, 3, 10_000_000, 4, peaks, a.no_cpu_baseline)
             out["configs4"] = section_converge(mia_amd, local, 4, 500_000, 5, peaks, a.no_cpu_baseline)
+        extras_path = write_extras(out)
+        line = json.dumps(headline(out, extras_path), separators=(",", ":"))
+        assert len(line) < HEADLINE_MAX, "headline of %d bytes: the driver reads at most a few KB" % len(line)
         sys.stdout.flush()
         os.dup2(stdout_fd, 1)
-        print(json.dumps(out), flush=True)
+        print(line, flush=True)                       # the LAST (and only) stdout line
         os.dup2(2, 1)
     if rank != 0 and not weak:
         hip.close()                         # (the communicator goes with the context)
