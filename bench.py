@@ -256,15 +256,15 @@ class Pipeline:
         band_done, _, _ = h.band_stats()
         _, _, plain_in, plain_retried = h.plain_stats()
         ctr = h.bx_counters()                      # of the last realign: list lengths by band class
-        widths = (8, 16, 24, 32)
+        widths = (8, 16, 24, 32, 64)                # band classes (csrc/bandx_body.h: BX_NCLS); counters: values lists, trace lists
         n, L2 = w["n"], w["read_len"]
         win = L2 + 100                             # +-50 window (src/mia_main.c:190-212)
         per_launch = {
             "k_diag_filter": (n if f_launches else 0, None),
             "k_band_align": ((f_seen - f_done) / max(st["k_band_align"][1], 1), 32 * L2),
             "k_bx_plan": (seen / max(bx_launches, 1), None),
-            "k_bx_values": (sum(ctr[0:4]), sum(c * wd for c, wd in zip(ctr[0:4], widths)) * L2),
-            "k_bx_trace": (sum(ctr[4:8]), sum(c * wd for c, wd in zip(ctr[4:8], widths)) * L2),
+            "k_bx_values": (sum(ctr[0:5]), sum(c * wd for c, wd in zip(ctr[0:5], widths)) * L2),
+            "k_bx_trace": (sum(ctr[5:10]), sum(c * wd for c, wd in zip(ctr[5:10], widths)) * L2),
             "k_align_quad_plain": (plain_in / max(st["k_align_quad_plain"][1], 1), win * L2),
             "k_tally_binned": (n, None),
         }

@@ -47,7 +47,7 @@ namespace mia {
 constexpr int BX_BLOCKS = 12;         // 10-mers cut out of a read: len / 10 of them, at most 9 (reads up to 128 bases) or 12 (longer ones)
 template <int NW> constexpr int bx_nb_max() { return NW <= 2 ? 9 : 12; }   // NW: 64-row words of the longest read
 constexpr int BX_MIN_BLOCKS = 3;
-constexpr int BX_MAXW = 32;           // widest band
+constexpr int BX_MAXW = 64;           // widest band (BxTab::maxw: what the kernels in use hold -- 64 spread over eight lanes, 32 in one lane)
 constexpr int BX_CLUSTER_TRIGGER = 8;  // anchors further apart than this are clustered around their median ...
 constexpr int BX_CLUSTER_RADIUS = 12; // ... keeping those within this many diagonals of it
 constexpr int BX_NEG = -(1 << 22);    // "no such cell"
@@ -55,9 +55,10 @@ constexpr int BX_SUB_ROW = 8;         // words per (strand, depth, read base) ro
 constexpr int BX_SUB_WORDS = 2 * 31 * 4 * BX_SUB_ROW;
 constexpr int BX_NIB_LEAD = 320;      // nibbles in front of reference position 0 (multiple of 8, >= MAX_READ)
 constexpr int BX_NIB_TAIL = 704;
-constexpr int BX_NCLS = 4;            // band classes: 8, 16, 24, 32 diagonals
+constexpr int BX_NCLS = 5;            // band classes: 8, 16, 24, 32, 64 diagonals (the last one only with a read spread over lanes, bandx_lanes.h)
 constexpr int BX_WILD = 3;            // most N columns in a reference 10-mer that is still entered in the table (4^k spellings)
-MIA_HD inline int bx_class_of(int w) { return w <= 8 ? 0 : (w <= 16 ? 1 : (w <= 24 ? 2 : 3)); }
+MIA_HD inline int bx_class_of(int w) { return w <= 8 ? 0 : (w <= 16 ? 1 : (w <= 24 ? 2 : (w <= 32 ? 3 : 4))); }
+MIA_HD inline int bx_class_width(int c) { return c < 4 ? 8 * (c + 1) : 64; }
 
 // what the host derives from the two matrices (mia_hip_set_pssm) -- see bx_make_tables
 struct BxTab {
@@ -69,10 +70,13 @@ struct BxTab {
                            // behind it the stray tables (bx_stray_off): what straying n diagonals costs at least, net of the
                            // blocks the gaps themselves break
   int32_t min_m, max_m;
+  int32_t maxw;            // widest band the DP kernels in use hold (32: one read per lane; BX_MAXW: a read over eight lanes)
 };
 constexpr int BX_LOSS_N = 2 * 31 * 4 * 4;
 constexpr int BX_LOSS_KAP = BX_LOSS_N + 2 * 31 * 4;       // [2][31][31]: what crossing an N column costs at least, by strand and depth range
-constexpr int BX_LOSS_WORDS = BX_LOSS_KAP + 2 * 31 * 31;
+constexpr int BX_LOSS_NCRED = BX_LOSS_KAP + 2 * 31 * 31;    // [2][32]: what ANY path pays at least for k N columns it spans (bx_window_nmin), all 0 = not usable
+constexpr int BX_NCRED_K = 32;
+constexpr int BX_LOSS_WORDS = BX_LOSS_NCRED + 2 * BX_NCRED_K;
 constexpr int BX_GMAX = 32;            // stray tables: phi / psi for 0..BX_GMAX diagonals
 constexpr int BX_DL_BLOCKS = 2 * (MAX_READ + 1) * BX_BLOCKS;                       // dl proper
 constexpr int BX_DL_WORDS = BX_DL_BLOCKS + 2 * (MAX_READ + 1) * 2 * (BX_GMAX + 1);  // + [strand][len][down | up][0..BX_GMAX]
@@ -184,6 +188,46 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
       }
       for (int d = 0; d <= BX_GMAX; d++) { dn[d] = (int16_t)(phi[d] > 32000 ? 32000 : phi[d]); up[d] = (int16_t)(psi[d] > 32000 ? 32000 : psi[d]); }
     }
+  // WINDOW-WIDE N CREDIT (bx_window_ncredit).  Every path spans at least len2 - (skipped rows) consecutive window columns, each
+  // of them under a row or inside a column gap; an N column under a row costs lambda(r), inside a gap GEP: at least
+  // kap = min(GEP, min lambda) either way.  The pigeonhole sum may be raised by kap x (fewest N columns in any stretch of len2
+  // columns of the window) if nothing is counted twice:
+  //   * a mismatch row sits on a column that is not N: disjoint;
+  //   * a column gap of n columns inside block b pays GOP + GEP n >= dl_b + kap n             needs dl_b <= GOP;
+  //   * a run of n skipped rows pays GOP + (GEP + min M) n, breaks at most t(n) blocks and shortens the span by n: no column
+  //     carries more credit than (GOP + (GEP + min M) n - dl_max t(n)) / n for any n (and never more than GEP);
+  //   * a clean crossing over more than BX_WILD N columns is in no table and counts as a break costing (BX_WILD + 1) min lambda --
+  //     the same N columns again: the columns of such places carry no credit (bx_window_nmin).
+  // Which row crosses an N column is not known, but every row crosses one column at most: k spanned N columns cost at least the
+  // k smallest of { min(GEP, lambda_min(depth of r)) : rows r } -- the end depths (0..14, 16..30) occur once each, depth 15 as
+  // often as the read is long (a read under 31 bases has a subset of the depths: the sum of ITS k smallest is no less).
+  for (int st = 0; st < 2; st++) {
+    int kap = GEP;
+    for (int d = 0; d < 31; d++) if (lamn[st][d] < kap) kap = lamn[st][d];
+    int dmax = 0;
+    for (int len2 = 0; len2 <= MAX_READ; len2++)
+      for (int b = 0; b < BX_BLOCKS; b++) { const int v = dl[(st * (MAX_READ + 1) + len2) * BX_BLOCKS + b]; if (v > dmax) dmax = v; }
+    // skipped rows: a run of n pays GOP + (GEP + min M) n, breaks at most t(n) blocks (dl_max each) and costs the span n columns:
+    // no column may carry more credit than what is left of that per row, for any n
+    bool ok = kap > 0 && dmax <= GOP && mn > 0;
+    int ccap = GEP;
+    for (int n = 1; n <= 2 * MAX_READ; n++) {
+      const int left = (GOP + (GEP + mn) * n - dmax * ((n - 1 + 9) / 10 + 1)) / n;
+      if (left < ccap) ccap = left;
+    }
+    if (ccap <= 0) ok = false;
+    int v[31];
+    for (int d = 0; d < 31; d++) v[d] = lamn[st][d] < ccap ? lamn[st][d] : ccap;
+    const int mid = v[15];
+    for (int a = 0; a < 31; a++)
+      for (int b = a + 1; b < 31; b++) if (v[b] < v[a]) { const int t = v[a]; v[a] = v[b]; v[b] = t; }
+    int cum = 0;
+    for (int k = 0; k < BX_NCRED_K; k++) {
+      loss[BX_LOSS_NCRED + st * BX_NCRED_K + k] = (int16_t)(ok ? cum : 0);
+      const int next = k < 31 ? (v[k] < mid ? v[k] : mid) : mid;
+      cum += next;
+    }
+  }
   *min_m = mn; *max_m = mx;
   return true;
 }
@@ -393,7 +437,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
   }
   an->fail = 0;
   if (nb < BX_MIN_BLOCKS || !any) { an->fail = BXF_BLOCKS; return; }
-  if (a_hi - a_lo >= BX_MAXW) { an->fail = BXF_SPAN; return; }
+  if (a_hi - a_lo >= T.maxw) { an->fail = BXF_SPAN; return; }
   // keep the written-down path inside the window
   if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) { an->fail = BXF_PATH; return; }
   an->a_lo = a_lo; an->a_hi = a_hi; an->d_first = d_first; an->d_last = d_last; an->budget = budget; an->l_out = l_out; an->s_un = s_un;
@@ -571,6 +615,86 @@ MIA_HD inline bool bx_rescue(DiagScan<NW>& sc, const RefPlanes& rp, BxAnchors& a
   return true;
 }
 
+// WINDOW-WIDE N CREDIT: the fewest credited N columns in any stretch of len2 consecutive columns of the window [s, s + len1) --
+// what every path crosses at least, by a row or inside a column gap (bx_make_tables: when that may be added to the pigeonhole
+// sum).  Credited = not part of any ten consecutive columns that hold more than BX_WILD N columns: a clean crossing of a
+// block over such a place is in no 10-mer table, counts as a break (dl_b <= (BX_WILD + 1) min lambda) and must not be paid
+// for twice (mt311: 481 such places, one window in two holds one).  Windows beyond 64 BX_NWW columns: 0 (no credit).
+constexpr int BX_NWW = 5;
+MIA_HD inline int bx_window_nmin(const RefPlanes& rp, int s, int len1, int len2) {
+  if (len1 > 64 * BX_NWW || len2 > len1) return 0;
+  uint64_t n[BX_NWW + 1];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < BX_NWW; k++) {
+    const int lo = 64 * k;
+    uint64_t w = 0;
+    if (lo < len1) {
+      const int64_t bit = (int64_t)s + lo + PLANE_LEAD;
+      const int64_t q = bit >> 6;
+      const int b = (int)(bit & 63);
+      w = ~((rp.ok[q] >> b) | ((rp.ok[q + 1] << 1) << (63 - b)));
+      if (len1 - lo < 64) w &= (1ull << (len1 - lo)) - 1ull;
+    }
+    n[k] = w;
+    any = any || w != 0;
+  }
+  n[BX_NWW] = 0;
+  if (!any) return 0;
+  // N columns in [p, p + 10) for every p at once: a bit-sliced counter over the ten shifted masks; over = "four or more"
+  uint64_t c0[BX_NWW], c1[BX_NWW], over[BX_NWW];
+#pragma unroll
+  for (int k = 0; k < BX_NWW; k++) { c0[k] = 0; c1[k] = 0; over[k] = 0; }
+#pragma unroll
+  for (int t = 0; t < DF_K; t++) {
+#pragma unroll
+    for (int k = 0; k < BX_NWW; k++) {
+      const uint64_t x = t ? (n[k] >> t) | (n[k + 1] << (64 - t)) : n[k];
+      const uint64_t k0 = c0[k] & x;
+      c0[k] ^= x;
+      const uint64_t k1 = c1[k] & k0;
+      c1[k] ^= k0;
+      over[k] |= k1;                                    // a carry out of the two-bit counter: the count reached four (and stays flagged)
+    }
+  }
+  // a column belongs to an overloaded place if one starts at most nine columns before it
+  uint64_t cr[BX_NWW];
+#pragma unroll
+  for (int k = 0; k < BX_NWW; k++) {
+    uint64_t e = over[k];
+#pragma unroll
+    for (int t = 1; t < DF_K; t++) e |= (over[k] << t) | (k ? over[k - 1] >> (64 - t) : 0ull);
+    cr[k] = n[k] & ~e;
+  }
+  auto below = [&](int end) -> int {                     // credited columns at positions < end
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < BX_NWW; k++) {
+      const int hi = end - 64 * k;
+      if (hi <= 0) continue;
+      c += df_popc(hi >= 64 ? cr[k] : cr[k] & ((1ull << hi) - 1ull));
+    }
+    return c;
+  };
+  // the count over [c, c + len2) changes only where c passes a credited column: the minimum is at c = 0 or just behind one
+  int best = below(len2), seen = 0;
+#pragma unroll
+  for (int k = 0; k < BX_NWW; k++) {
+    uint64_t w = cr[k];
+    while (w) {
+      const int c = 64 * k + df_ctz(w) + 1;
+      w &= w - 1;
+      seen++;
+      if (c + len2 <= len1) {
+        const int v = below(c + len2) - seen;
+        if (v < best) best = v;
+      }
+    }
+  }
+  return best;
+}
+static_assert(BX_WILD == 3, "bx_window_nmin flags four N columns within ten");
+
 // the rows of word j that lose anything on the diagonal sc is on: definite mismatches and N columns
 template <int NW>
 MIA_HD inline uint64_t bx_loss_rows(const DiagScan<NW>& sc, int j) { return sc.mis(j) | (~sc.cok[j] & sc.rows[j]); }
@@ -616,8 +740,18 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   // rows 0 and 1, a start in row 2 that forfeits 214, and a six-column gap that then wins by 30)
   const int b0x = b0 + nfail * T.max_m;
   out->b0 = BXF_BUDGET;
-  if (b0x > an.budget) return;
-  if (an.l_out >= 0 && an.l_out <= b0x) { out->b0 = BXF_SPAN; return; }      // some anchors were set aside: see bx_anchors
+  // the pigeonhole: a path that crosses no block cleanly loses more than B0.  Against a reference full of ambiguity codes B0
+  // is mostly N columns (ten of them under a 100-base read, 210 each) -- but so is every other path's loss: the window-wide
+  // credit (bx_make_tables, bx_window_nmin) is worked out only for the reads the plain sum turns away
+  int ncredit = 0;
+  if (b0x > an.budget || (an.l_out >= 0 && an.l_out <= b0x)) {
+    if (T.loss[BX_LOSS_NCRED + st * BX_NCRED_K + 1] > 0) {
+      const int nm = bx_window_nmin(rp, s, len1, len2);
+      if (nm > 0) ncredit = T.loss[BX_LOSS_NCRED + st * BX_NCRED_K + (nm < BX_NCRED_K ? nm : BX_NCRED_K - 1)];
+    }
+  }
+  if (b0x > an.budget + ncredit) return;
+  if (an.l_out >= 0 && an.l_out + ncredit <= b0x) { out->b0 = BXF_SPAN; return; }      // some anchors were set aside: see bx_anchors
   // how far a path that loses no more than b0 can stray from the anchors: all of b0 spent on one gap (band_body.h) --
   // or, tighter, what is left of b0 once every block that occurs nowhere in the window has been paid for (an.s_un: such
   // a block costs dl wherever it is crossed, unless a gap of the path itself breaks it -- the stray tables are net of
@@ -699,12 +833,12 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   if (an.a_lo - g_dn - 1 < 0) { g_dn++; g_up++; }
   const int d0 = an.a_lo - g_dn, w = an.a_hi - an.a_lo + g_dn + g_up + 1;
   out->b0 = BXF_WIDTH;
-  if (w > BX_MAXW) return;
+  if (w > T.maxw) return;
   out->d0 = d0; out->w = w; out->b0 = b0; out->dstar = d_first;
   if (d_first != d_last || !proof) out->mode = BX_TRACE;
   else out->mode = w == 1 ? BX_DONE : BX_VALUES;
   // the widest band of the read's class must not leave the window anywhere for the plain form of the recurrence
-  const int wc = 8 * (bx_class_of(w) + 1);
+  const int wc = bx_class_width(bx_class_of(w));
   out->edge = !(d0 >= 0 && len2 - 1 + d0 + wc <= len1);
 }
 
@@ -809,21 +943,21 @@ MIA_HD inline void bx_values(const uint32_t* refnib, int s, int len1, const uint
   int32_t P[W], H[W];
   uint32_t cw[NWD];
   uint32_t rw = rwords[0];
-  auto live_mask = [&](int c0) -> uint32_t {             // cells whose column c0 + j lies inside the window
+  auto live_mask = [&](int c0) -> uint64_t {             // cells whose column c0 + j lies inside the window
     const int jlo = c0 < 0 ? -c0 : 0, jhi = (len1 - c0) < W ? (len1 - c0) : W;
-    return jhi > jlo ? ((jhi >= 32 ? ~0u : ((1u << jhi) - 1u)) & ~((1u << jlo) - 1u)) : 0u;
+    return jhi > jlo ? ((jhi >= 64 ? ~0ull : ((1ull << jhi) - 1ull)) & ~((1ull << jlo) - 1ull)) : 0ull;
   };
   BxSlide<NWD> slide;
   slide.init(refnib, (int64_t)s + d0 + BX_NIB_LEAD);
   {
     slide.get(refnib, (int64_t)s + d0 + BX_NIB_LEAD, cw);
     const int32_t* row = sub + ((0 * 4) + (int)(rw & 3u)) * BX_SUB_ROW;          // depth 0
-    const uint32_t live = EDGE ? live_mask(d0) : ~0u;
+    const uint64_t live = EDGE ? live_mask(d0) : ~0ull;
 #pragma unroll
     for (int j = 0; j < W; j++) {
       H[j] = BX_NEG;
       const int v = row[(cw[j >> 3] >> (4 * (j & 7))) & 7u];
-      P[j] = ((live >> j) & 1u) ? v : BX_NEG;
+      P[j] = ((live >> j) & 1ull) ? v : BX_NEG;
     }
   }
   for (int r = 1; r < len2; r++) {
@@ -831,10 +965,10 @@ MIA_HD inline void bx_values(const uint32_t* refnib, int s, int len1, const uint
     slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD, cw);
     if ((r & 7) == 0) rw = rwords[r >> 3];
     const int32_t* row = sub + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
-    uint32_t live = ~0u, col0 = 0u;
+    uint64_t live = ~0ull, col0 = 0ull;
     if (EDGE) {
       live = live_mask(c0);
-      col0 = (c0 <= 0 && c0 > -W) ? (1u << (-c0)) : 0u;
+      col0 = (c0 <= 0 && c0 > -W) ? (1ull << (-c0)) : 0ull;
     }
     const int fresh = -(GOP + GEP * (r + 1));
     int G = BX_NEG;
@@ -845,8 +979,8 @@ MIA_HD inline void bx_values(const uint32_t* refnib, int s, int len1, const uint
       const int x = pd > G ? (pd > h ? pd : h) : (G > h ? G : h);
       int cur = fresh > x ? fresh : x + sb;
       if (EDGE) {
-        if ((col0 >> j) & 1u) cur = sb + fresh;                                       // src/mia.c:805-822
-        if (!((live >> j) & 1u)) cur = BX_NEG;
+        if ((col0 >> j) & 1ull) cur = sb + fresh;                                       // src/mia.c:805-822
+        if (!((live >> j) & 1ull)) cur = BX_NEG;
       }
       const int cand = pd - (GOP + GEP);
       G = G - GEP > cand ? G - GEP : cand;
@@ -886,21 +1020,21 @@ MIA_HD inline bool bx_trace(const uint32_t* refnib, int s, int len1, const uint3
   int32_t P[W], H[W];
   uint32_t cw[NWD];
   uint32_t rw = rwords[0];
-  auto live_mask = [&](int c0) -> uint32_t {
+  auto live_mask = [&](int c0) -> uint64_t {
     const int jlo = c0 < 0 ? -c0 : 0, jhi = (len1 - c0) < W ? (len1 - c0) : W;
-    return jhi > jlo ? ((jhi >= 32 ? ~0u : ((1u << jhi) - 1u)) & ~((1u << jlo) - 1u)) : 0u;
+    return jhi > jlo ? ((jhi >= 64 ? ~0ull : ((1ull << jhi) - 1ull)) & ~((1ull << jlo) - 1ull)) : 0ull;
   };
   BxSlide<NWD> slide;
   slide.init(refnib, (int64_t)s + d0 + BX_NIB_LEAD);
   {
     slide.get(refnib, (int64_t)s + d0 + BX_NIB_LEAD, cw);
     const int32_t* row = sub256 + ((0 * 4) + (int)(rw & 3u)) * BX_SUB_ROW;
-    const uint32_t live = EDGE ? live_mask(d0) : ~0u;
+    const uint64_t live = EDGE ? live_mask(d0) : ~0ull;
 #pragma unroll
     for (int j = 0; j < W; j++) {
       H[j] = DEAD;
       const int v = row[(cw[j >> 3] >> (4 * (j & 7))) & 7u];
-      P[j] = ((live >> j) & 1u) ? (v | 0xFF) : DEAD;
+      P[j] = ((live >> j) & 1ull) ? (v | 0xFF) : DEAD;
     }
 #pragma unroll
     for (int k = 0; k < W / 4; k++) trace[k] = 0xFFFFFFFFu;
@@ -910,10 +1044,10 @@ MIA_HD inline bool bx_trace(const uint32_t* refnib, int s, int len1, const uint3
     slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD, cw);
     if ((r & 7) == 0) rw = rwords[r >> 3];
     const int32_t* row = sub256 + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
-    uint32_t live = ~0u, col0 = 0u;
+    uint64_t live = ~0ull, col0 = 0ull;
     if (EDGE) {
       live = live_mask(c0);
-      col0 = (c0 <= 0 && c0 > -W) ? (1u << (-c0)) : 0u;
+      col0 = (c0 <= 0 && c0 > -W) ? (1ull << (-c0)) : 0ull;
     }
     const int f0 = -(GOP + GEP * (r + 1)) * 256, f0s = f0 | 0x80;
     int G = DEAD;
@@ -927,8 +1061,8 @@ MIA_HD inline bool bx_trace(const uint32_t* refnib, int s, int len1, const uint3
       const int x = pd > gc ? (pd > h ? pd : h) : (gc > h ? gc : h);
       int cur = f0 > x ? f0s : x + sb;                  // fresh must beat all three strictly (its code byte is 0 in f0)
       if (EDGE) {
-        if ((col0 >> j) & 1u) cur = (sb + f0) | 0xFF;
-        if (!((live >> j) & 1u)) cur = DEAD;
+        if ((col0 >> j) & 1ull) cur = (sb + f0) | 0xFF;
+        if (!((live >> j) & 1ull)) cur = DEAD;
       }
       tw[j >> 2] = bx_put(tw[j >> 2], (uint32_t)cur, j & 3);
       const int cand = pd + CAND;

@@ -23,8 +23,8 @@ namespace mia {
 
 // counters of the pipeline; each on a cache line of its own (BXC_STRIDE words apart): thousands of wavefronts add to them,
 // and atomics on one line are served one after the other
-enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_CAND = 28, BXC_COUNTERS = 32 };     // CAND: reads handed from the plan's first launch to its second
-static_assert(BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_CAND && BXC_CAND < BXC_COUNTERS, "counter layout");
+enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_CAND = 30, BXC_COUNTERS = 32 };     // CAND: reads handed from the plan's first launch to its second
+static_assert(BXC_SEEN < BXC_FAIL0 && BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_CAND && BXC_CAND < BXC_COUNTERS, "counter layout");
 constexpr int BXC_STRIDE = 64;
 constexpr int BXC_WORDS = BXC_COUNTERS * BXC_STRIDE;
 __device__ __forceinline__ uint32_t* bxc(const uint32_t* ctr, int k) { return const_cast<uint32_t*>(ctr) + (size_t)k * BXC_STRIDE; }
@@ -55,7 +55,7 @@ struct BxDev {
 struct BxCandRec { int32_t i; BxAnchors an; };
 
 __device__ __forceinline__ uint32_t bx_pack(const BxPlan& p) {
-  return (uint32_t)(p.d0 + 512) | ((uint32_t)(p.dstar - p.d0) << 11) | ((uint32_t)p.edge << 16) | ((uint32_t)p.w << 17);
+  return (uint32_t)(p.d0 + 512) | ((uint32_t)(p.dstar - p.d0) << 11) | ((uint32_t)p.edge << 17) | ((uint32_t)p.w << 18);
 }
 
 __device__ __forceinline__ uint32_t ref_nibble_word(const uint8_t* codes, int64_t n_codes, int64_t w) {
@@ -391,8 +391,8 @@ __device__ __forceinline__ BxRead bx_load(const ReadSet& rs, const RefInfo& ref,
   read_window(ref, rs.as[i], rs.ae[i], r.len2, &r.s, &r.l1);
   const uint32_t w = bx.plan[i];
   r.d0 = (int)(w & 0x7FFu) - 512;
-  r.jstar = (int)((w >> 11) & 31u);
-  r.edge = ((w >> 16) & 1u) != 0;
+  r.jstar = (int)((w >> 11) & 63u);
+  r.edge = ((w >> 17) & 1u) != 0;
   r.st = rs.rc[i] ? 1 : 0;
   r.rw = reinterpret_cast<const uint32_t*>(rs.packed + rs.roff[i]);
   return r;
@@ -573,7 +573,8 @@ __global__ __launch_bounds__(256) void k_bxl_values(ReadSet rs, RefInfo ref, BxD
       case 0: done += bxl_values_chunk<1>(rs, ref, bx, bin_of, ch, sub_lds); break;
       case 1: done += bxl_values_chunk<2>(rs, ref, bx, bin_of, ch, sub_lds); break;
       case 2: done += bxl_values_chunk<3>(rs, ref, bx, bin_of, ch, sub_lds); break;
-      default: done += bxl_values_chunk<4>(rs, ref, bx, bin_of, ch, sub_lds); break;
+      case 3: done += bxl_values_chunk<4>(rs, ref, bx, bin_of, ch, sub_lds); break;
+      default: done += bxl_values_chunk<8>(rs, ref, bx, bin_of, ch, sub_lds); break;
     }
   }
   bxl_count_done(done, &done_wg, bxc(bx.ctr, BXC_DONE_VALUES));
@@ -631,7 +632,8 @@ __device__ __forceinline__ void bxl_trace_grid(const ReadSet& rs, const RefInfo&
       case 0: done += bxl_trace_chunk<1>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
       case 1: done += bxl_trace_chunk<2>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
       case 2: done += bxl_trace_chunk<3>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
-      default: done += bxl_trace_chunk<4>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
+      case 3: done += bxl_trace_chunk<4>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
+      default: done += bxl_trace_chunk<8>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
     }
   }
   bxl_count_done(done, &done_wg, bxc(bx.ctr, BXC_DONE_TRACE));

@@ -33,7 +33,7 @@ namespace mia {
 constexpr int BXL_CELLS = 8;                       // band cells per lane
 template <int LPR> constexpr int bxl_reads_per_row() { return 16 / LPR; }
 template <int LPR> constexpr int bxl_reads_per_wave() { return 4 * (16 / LPR); }
-__host__ __device__ constexpr int bxl_chunk_reads(int cls) { return cls == 0 ? 64 : (cls == 1 ? 32 : (cls == 2 ? 20 : 16)); }
+__host__ __device__ constexpr int bxl_chunk_reads(int cls) { return cls == 0 ? 64 : (cls == 1 ? 32 : (cls == 2 ? 20 : (cls == 3 ? 16 : 8))); }
 
 // value of the lane K places to the left (right) in the 16-lane row; lanes without such a neighbour get `fill`
 template <int K>
@@ -41,6 +41,59 @@ __device__ __forceinline__ int bxl_from_left(int x, int fill) { return __builtin
 __device__ __forceinline__ int bxl_from_right1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x101, 0xF, 0xF, false); }
 template <int K>
 __device__ __forceinline__ int bxl_from_right(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x100 + K, 0xF, 0xF, false); }
+
+// The column-gap maximum a lane's cells start from: the best of the lanes to its left within the read, the lane k places
+// away aged by (k - 1) * age (age = what a running maximum loses over one lane's eight cells; 0 in the coordinates of
+// bxl_values_star).  Up to four lanes: one DPP move per neighbour; eight lanes: an inclusive scan in three doubling steps
+// (S(u) = max over k >= 0 of v(u - k) + k age), handed on by one lane.  u: this lane's place in its read; none: "no cell".
+template <int LPR>
+__device__ __forceinline__ int bxl_prefix_left(int v, int u, int age, int none) {
+  int G = none;
+  if (LPR <= 1) return G;
+  if (LPR <= 4) {
+    const int g1 = bxl_from_left<1>(v, none);
+    if (u >= 1) G = g1;
+    if (LPR > 2) { const int g2 = bxl_from_left<2>(v, none) + age; if (u >= 2 && g2 > G) G = g2; }
+    if (LPR > 3) { const int g3 = bxl_from_left<3>(v, none) + 2 * age; if (u >= 3 && g3 > G) G = g3; }
+    return G;
+  }
+  static_assert(LPR <= 4 || LPR == 8, "a read owns 1, 2, 3, 4 or 8 lanes of a 16-lane row");
+  int s = v;
+  { const int t = bxl_from_left<1>(s, none) + age; if (u >= 1 && t > s) s = t; }
+  { const int t = bxl_from_left<2>(s, none) + 2 * age; if (u >= 2 && t > s) s = t; }
+  { const int t = bxl_from_left<4>(s, none) + 4 * age; if (u >= 4 && t > s) s = t; }
+  const int g = bxl_from_left<1>(s, none);
+  return u >= 1 ? g : none;
+}
+// First maximum of the last row over the read's lanes (the lower band index wins ties: a lane further right must be strictly
+// better, src/mia.c:1278-1302); valid on the read's first lane.
+template <int LPR>
+__device__ __forceinline__ void bxl_first_max(int& best, int& bj) {
+  if (LPR <= 1) return;
+  if (LPR <= 4) {
+    const int b1 = bxl_from_right<1>(best, BX_NEG), j1 = bxl_from_right<1>(bj, -1);
+    int bb = best, jj = bj;
+    if (LPR > 3) {
+      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
+      const int b3 = bxl_from_right<3>(best, BX_NEG), j3 = bxl_from_right<3>(bj, -1);
+      if (b1 > bb) { bb = b1; jj = j1; }
+      if (b2 > bb) { bb = b2; jj = j2; }
+      if (b3 > bb) { bb = b3; jj = j3; }
+    } else if (LPR > 2) {
+      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
+      if (b1 > bb) { bb = b1; jj = j1; }
+      if (b2 > bb) { bb = b2; jj = j2; }
+    } else {
+      if (b1 > bb) { bb = b1; jj = j1; }
+    }
+    best = bb; bj = jj;
+    return;
+  }
+  // eight lanes: three halving steps towards the first lane (it only ever takes in lanes of its own read)
+  { const int b = bxl_from_right<1>(best, BX_NEG), j = bxl_from_right<1>(bj, -1); if (b > best) { best = b; bj = j; } }
+  { const int b = bxl_from_right<2>(best, BX_NEG), j = bxl_from_right<2>(bj, -1); if (b > best) { best = b; bj = j; } }
+  { const int b = bxl_from_right<4>(best, BX_NEG), j = bxl_from_right<4>(bj, -1); if (b > best) { best = b; bj = j; } }
+}
 
 // eight nibbles of reference codes at a position that advances by one per row (BxSlide<1> of bandx_body.h)
 struct BxlSlide {
@@ -106,16 +159,7 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
         cand[j] = P[j] - (GOP + GEP);
         gloc = gloc - GEP > cand[j] ? gloc - GEP : cand[j];
       }
-      const int g1 = bxl_from_left<1>(gloc, BX_NEG);
-      if (u >= 1) G = g1;
-      if (LPR > 2) {
-        const int g2 = bxl_from_left<2>(gloc, BX_NEG) - BXL_CELLS * GEP;
-        if (u >= 2 && g2 > G) G = g2;
-      }
-      if (LPR > 3) {
-        const int g3 = bxl_from_left<3>(gloc, BX_NEG) - 2 * BXL_CELLS * GEP;
-        if (u >= 3 && g3 > G) G = g3;
-      }
+      G = bxl_prefix_left<LPR>(gloc, u, -BXL_CELLS * GEP, BX_NEG);
     } else {
 #pragma unroll
       for (int j = 0; j < BXL_CELLS; j++) cand[j] = P[j] - (GOP + GEP);
@@ -145,24 +189,7 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
 #pragma unroll
   for (int j = 0; j < BXL_CELLS; j++) if (P[j] > best) { best = P[j]; bj = j; }
   bj = bj < 0 ? -1 : bj + BXL_CELLS * u;
-  if (LPR > 1) {                                           // first maximum over the read's lanes: a lane further right must be strictly better
-    const int b1 = bxl_from_right<1>(best, BX_NEG), j1 = bxl_from_right<1>(bj, -1);
-    int bb = best, jj = bj;
-    if (LPR > 3) {
-      const int b3 = bxl_from_right<3>(best, BX_NEG), j3 = bxl_from_right<3>(bj, -1);
-      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
-      if (b1 > bb) { bb = b1; jj = j1; }
-      if (b2 > bb) { bb = b2; jj = j2; }
-      if (b3 > bb) { bb = b3; jj = j3; }
-    } else if (LPR > 2) {
-      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
-      if (b1 > bb) { bb = b1; jj = j1; }
-      if (b2 > bb) { bb = b2; jj = j2; }
-    } else {
-      if (b1 > bb) { bb = b1; jj = j1; }
-    }
-    best = bb; bj = jj;                                    // (meaningful on the read's first lane, u == 0)
-  }
+  bxl_first_max<LPR>(best, bj);                            // (meaningful on the read's first lane, u == 0)
   if (best <= BX_NEG / 2) bj = -1;
   *best_out = best; *bj_out = bj;
 }
@@ -233,10 +260,7 @@ __device__ __forceinline__ void bxl_values_star(const uint32_t* refnib, int s, c
       int gloc = cand[0];
 #pragma unroll
       for (int j = 1; j < BXL_CELLS; j++) gloc = gloc > cand[j] ? gloc : cand[j];
-      const int g1 = bxl_from_left<1>(gloc, BX_NEG);
-      if (u >= 1) G = g1;
-      if (LPR > 2) { const int g2 = bxl_from_left<2>(gloc, BX_NEG); if (u >= 2 && g2 > G) G = g2; }
-      if (LPR > 3) { const int g3 = bxl_from_left<3>(gloc, BX_NEG); if (u >= 3 && g3 > G) G = g3; }
+      G = bxl_prefix_left<LPR>(gloc, u, 0, BX_NEG);
     }
     int nh0 = BX_NEG;
 #pragma unroll
@@ -267,24 +291,7 @@ __device__ __forceinline__ void bxl_values_star(const uint32_t* refnib, int s, c
 #pragma unroll
   for (int j = 0; j < BXL_CELLS; j++) { const int v = Q[j] - back - GEP * j; if (v > best) { best = v; bj = j; } }
   bj = bj < 0 ? -1 : bj + BXL_CELLS * u;
-  if (LPR > 1) {                                           // first maximum over the read's lanes: a lane further right must be strictly better
-    const int b1 = bxl_from_right<1>(best, BX_NEG), j1 = bxl_from_right<1>(bj, -1);
-    int bb = best, jj = bj;
-    if (LPR > 3) {
-      const int b3 = bxl_from_right<3>(best, BX_NEG), j3 = bxl_from_right<3>(bj, -1);
-      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
-      if (b1 > bb) { bb = b1; jj = j1; }
-      if (b2 > bb) { bb = b2; jj = j2; }
-      if (b3 > bb) { bb = b3; jj = j3; }
-    } else if (LPR > 2) {
-      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
-      if (b1 > bb) { bb = b1; jj = j1; }
-      if (b2 > bb) { bb = b2; jj = j2; }
-    } else {
-      if (b1 > bb) { bb = b1; jj = j1; }
-    }
-    best = bb; bj = jj;
-  }
+  bxl_first_max<LPR>(best, bj);
   if (best <= BX_NEG / 2) bj = -1;
   *best_out = best; *bj_out = bj;
 }
@@ -348,16 +355,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
         cand[j] = (P[j] | 0xFF) + CAND;
         gloc = gloc + STEP > cand[j] ? gloc + STEP : cand[j];
       }
-      const int g1 = bxl_from_left<1>(gloc, DEAD);
-      if (u >= 1) G = g1;
-      if (LPR > 2) {
-        const int g2 = bxl_from_left<2>(gloc, DEAD) + BXL_CELLS * STEP;
-        if (u >= 2 && g2 > G) G = g2;
-      }
-      if (LPR > 3) {
-        const int g3 = bxl_from_left<3>(gloc, DEAD) + 2 * BXL_CELLS * STEP;
-        if (u >= 3 && g3 > G) G = g3;
-      }
+      G = bxl_prefix_left<LPR>(gloc, u, BXL_CELLS * STEP, DEAD);
     } else {
 #pragma unroll
       for (int j = 0; j < BXL_CELLS; j++) cand[j] = (P[j] | 0xFF) + CAND;
@@ -395,24 +393,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
 #pragma unroll
   for (int j = 0; j < BXL_CELLS; j++) if ((P[j] >> 8) > best) { best = P[j] >> 8; bj = j; }
   bj = bj < 0 ? -1 : bj + BXL_CELLS * u;
-  if (LPR > 1) {
-    const int b1 = bxl_from_right<1>(best, BX_NEG), j1 = bxl_from_right<1>(bj, -1);
-    int bb = best, jj = bj;
-    if (LPR > 3) {
-      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
-      const int b3 = bxl_from_right<3>(best, BX_NEG), j3 = bxl_from_right<3>(bj, -1);
-      if (b1 > bb) { bb = b1; jj = j1; }
-      if (b2 > bb) { bb = b2; jj = j2; }
-      if (b3 > bb) { bb = b3; jj = j3; }
-    } else if (LPR > 2) {
-      const int b2 = bxl_from_right<2>(best, BX_NEG), j2 = bxl_from_right<2>(bj, -1);
-      if (b1 > bb) { bb = b1; jj = j1; }
-      if (b2 > bb) { bb = b2; jj = j2; }
-    } else {
-      if (b1 > bb) { bb = b1; jj = j1; }
-    }
-    best = bb; bj = jj;
-  }
+  bxl_first_max<LPR>(best, bj);
   // the traceback is the first lane's business.  It reads trace bytes its neighbours stored: same wavefront, same memory
   // pipe, the loads are issued after the stores -- the fence only keeps the compiler from moving them.
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

@@ -1059,6 +1059,7 @@ static int align_all(mia_hip_ctx* ctx) {
       bd.listed_mark = new_flow ? -5 : 0;
       if (ctx->lazy_scripts) ctx->diag_scripts_missing = true;
       bd.tab.min_m = ctx->bx_min_m; bd.tab.max_m = ctx->bx_max_m;
+      bd.tab.maxw = ctx->use_lanes ? BX_MAXW : 32;           // (the widest class needs a read spread over eight lanes)
       bd.sub256 = ctx->d_bx_sub + BX_SUB_WORDS;
       bd.refnib = ctx->d_refnib;
       bd.umax = (ctx->umax_valid && ctx->rs.roff == ctx->d_roff) ? ctx->d_umax : nullptr;    // (a borrowed read set has none)

@@ -365,7 +365,7 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
   }
   if (!s_ok) return 0;
   std::vector<int32_t> sub256(BX_SUB_WORDS, 0);
-  BxTab T{sub.data(), mrow.data(), loss.data(), dl.data(), s_min_m, s_max_m};
+  BxTab T{sub.data(), mrow.data(), loss.data(), dl.data(), s_min_m, s_max_m, BX_MAXW};
   for (int k = 0; k < BX_SUB_WORDS; k++) sub256[(size_t)k] = sub[(size_t)k] * 256;
   std::vector<uint32_t> nib((size_t)bx_nib_words(n_codes), 0x44444444u);
   for (int64_t p = 0; p < n_codes; p++) {
@@ -386,8 +386,8 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
     for (int r = 0; r < len2; r++) cols[r] = (int16_t)(bp.dstar + r);
   }
   int cls = bx_class_of(bp.w) + (opts >> 4);
-  if (cls > 3) cls = 3;
-  const int wc = 8 * (cls + 1);
+  if (cls > 4) cls = 4;
+  const int wc = bx_class_width(cls);
   const bool interior = bp.d0 >= 0 && len2 - 1 + bp.d0 + wc <= len1;
   const bool edge = !interior || (opts & 2);
   const bool force_trace = (opts & 1) != 0;
@@ -404,7 +404,8 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
     case 0: h2 = emu_bandx_w<8>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
     case 1: h2 = emu_bandx_w<16>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
     case 2: h2 = emu_bandx_w<24>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
-    default: h2 = emu_bandx_w<32>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
+    case 3: h2 = emu_bandx_w<32>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
+    default: h2 = emu_bandx_w<64>(nib.data(), ref_start, len1, rw, len2, bp, edge, st_sub, st_sub256, want_values, want_trace, expect, o2, c2.data()); break;
   }
   if (h2 < 0) return h2;
   if (how == 1) {

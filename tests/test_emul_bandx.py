@@ -454,3 +454,49 @@ def test_end_indels_are_rescued(emul, oracle, spec, strand):
             small += 1
             finished += 1 if ok else 0
     assert stats["n"] == 360 and finished > 0.8 * small, (sorted(stats.items()), finished, small)
+
+
+@pytest.mark.parametrize("spec,strand", MATS)
+def test_window_wide_n_credit(emul, oracle, spec, strand):
+    """Round 4: against a reference with an ambiguity code in every tenth column B0 is mostly N columns, and three
+    substitutions used to exhaust the pigeonhole's budget (a fifth of the damaged reads of configs[2] in their first
+    iteration).  Every other path crosses N columns as well: the fewest any stretch of len2 window columns holds, at min(GEP,
+    lambda) each, is added to the budget (bx_window_nmin / BX_LOSS_NCRED).  Reads with 2-8 substitutions; and the case the
+    credit must NOT be given for -- a second copy of the locus a few columns away that is free of N columns, so that a path
+    over it pays nothing of the kind: whatever the plan finishes must still be dyn_prog's answer."""
+    rnd = random.Random(404 + strand)
+    stats = {"n": 0}
+    finished = planned = 0
+    for rep in range(3):
+        truth = "".join(rnd.choice("ACGT") for _ in range(3000))
+        ref = sprinkle_n(rnd, truth, 0.10, 0)
+        for i in range(150):
+            n = rnd.choice([100, 100, 100, 150, 70])
+            pos = rnd.randint(60, len(ref) - n - 60)
+            read = truth[pos:pos + n]
+            if i % 3 == 0:
+                read = damage(rnd, read, p0=0.5)
+            read = mutate(rnd, read, rnd.sample(range(n), rnd.choice([2, 2, 3, 3, 3, 4, 5, 7])))
+            s, l1 = window(ref, pos + rnd.randint(-3, 3), n)
+            ok = check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+            finished += 1 if ok else 0
+    # a clean second copy beside an N-rich locus: locus at `at`, copy `shift` columns further on, both inside the window
+    for i in range(150):
+        n = rnd.choice([100, 100, 64])
+        shift = rnd.randint(11, 40)
+        core = "".join(rnd.choice("ACGT") for _ in range(n))
+        left = "".join(rnd.choice("ACGT") for _ in range(80))
+        right = "".join(rnd.choice("ACGT") for _ in range(120))
+        locus = sprinkle_n(rnd, core, rnd.choice([0.10, 0.15]), 0)
+        # the copy: every block of the read broken by one substitution, no N column at all
+        copy = mutate(rnd, core, [min(n - 1, b * 11 + rnd.randint(0, 9)) for b in range(n // 11 + 1)])
+        ref = left + locus[:shift] + copy if i % 2 else left + locus + right
+        if i % 2:
+            # (overlapping placement: the copy starts `shift` columns into the locus -- a path can leave the locus for it)
+            ref = left + locus[:shift] + copy + right
+        read = mutate(rnd, core, rnd.sample(range(n), rnd.choice([1, 2, 3, 4, 5])))
+        s, l1 = window(ref, len(left), n, margin=50)
+        if l1 < n:
+            continue
+        check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+    assert stats["n"] > 550 and finished > 150, (str(sorted(stats.items())), finished)

@@ -25,5 +25,5 @@ for _ in range(4):
 hip.sync()
 print("config", cfg, "first-iteration step: %.3f ms" % ((time.perf_counter() - t0) / 4 * 1e3), {k: os.environ[k] for k in os.environ if k.startswith("MIA_HIP")})
 c = hip.bx_counters()
-print("lists", list(c[:8]), "late", list(c[24:28]), "plan gave up by reason (READ WINDOW BLOCKS SPAN PATH BUDGET WIDTH)", list(c[17:24]), pipe.stages(1, None, None, True)[1])
+print("values lists", list(c[:5]), "trace lists", list(c[5:10]), "late", list(c[24:29]), "plan gave up by reason (READ WINDOW BLOCKS SPAN PATH BUDGET WIDTH)", list(c[17:24]), pipe.stages(1, None, None, True)[1])
 hip.close()
