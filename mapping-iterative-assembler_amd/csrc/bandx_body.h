@@ -76,11 +76,19 @@ constexpr int BX_LOSS_N = 2 * 31 * 4 * 4;
 constexpr int BX_LOSS_KAP = BX_LOSS_N + 2 * 31 * 4;       // [2][31][31]: what crossing an N column costs at least, by strand and depth range
 constexpr int BX_LOSS_NCRED = BX_LOSS_KAP + 2 * 31 * 31;    // [2][32]: what ANY path pays at least for k N columns it spans (bx_window_nmin), all 0 = not usable
 constexpr int BX_NCRED_K = 32;
-constexpr int BX_LOSS_WORDS = BX_LOSS_NCRED + 2 * BX_NCRED_K;
+constexpr int BX_LOSS_FDL = BX_LOSS_NCRED + 2 * BX_NCRED_K;  // [2][31]: what breaking a FINE block costs at least, by strand and depth of its cheapest row (bx_fine_anchors); 0 = not usable
+constexpr int BX_LOSS_WORDS = BX_LOSS_FDL + 2 * 31;
+constexpr int BX_FQ = 6;               // rows of a fine block
+constexpr int BX_FINE_RADIUS = 3;      // fine anchors this close to the 10-mer anchors' diagonals are kept, the others set aside
 constexpr int BX_GMAX = 32;            // stray tables: phi / psi for 0..BX_GMAX diagonals
 constexpr int BX_DL_BLOCKS = 2 * (MAX_READ + 1) * BX_BLOCKS;                       // dl proper
-constexpr int BX_DL_WORDS = BX_DL_BLOCKS + 2 * (MAX_READ + 1) * 2 * (BX_GMAX + 1);  // + [strand][len][down | up][0..BX_GMAX]
+constexpr int BX_DL_FINE = BX_DL_BLOCKS + 2 * (MAX_READ + 1) * 2 * (BX_GMAX + 1);   // + [strand][len][down | up][0..BX_GMAX]
+constexpr int BX_DL_WORDS = BX_DL_FINE + 2 * 2 * (BX_GMAX + 1);                    // + the stray tables of the fine blocks: [strand][down | up][0..BX_GMAX]
 MIA_HD inline int bx_stray_off(int st, int len2, int up) { return BX_DL_BLOCKS + ((st * (MAX_READ + 1) + len2) * 2 + up) * (BX_GMAX + 1); }
+MIA_HD inline int bx_stray_off_fine(int st, int up) { return BX_DL_FINE + (st * 2 + up) * (BX_GMAX + 1); }
+// fine blocks: len2 / BX_FQ of them, spread like the 10-mers
+MIA_HD inline int bx_fine_blocks_of(int len2) { return len2 / BX_FQ; }
+MIA_HD inline int bx_fine_block_row(int b, int len2, int nb_cut) { return (int)((int64_t)b * (len2 - BX_FQ) / (nb_cut - 1)); }
 
 MIA_HD inline int64_t bx_nib_words(int64_t n_codes) { return (BX_NIB_LEAD + n_codes + BX_NIB_TAIL) / 8 + 2; }
 // first row of block b of a read of len2 bases cut into nb_cut blocks
@@ -198,6 +206,48 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
   //     carries more credit than (GOP + (GEP + min M) n - dl_max t(n)) / n for any n (and never more than GEP);
   //   * a clean crossing over more than BX_WILD N columns is in no table and counts as a break costing (BX_WILD + 1) min lambda --
   //     the same N columns again: the columns of such places carry no credit (bx_window_nmin).
+  // FINE BLOCKS (bx_fine_anchors): the read cut into blocks of BX_FQ rows, their clean places found by comparing every
+  // diagonal of the window directly (no table, so any number of N columns under a block is a clean place).  Breaking one costs
+  // at least fdl(depth) = min(delta, GOP, E_q) with E_q the skipped-row quotient for t_q(n) = ceil((n-1)/q) + 1 touched blocks;
+  // the stray tables are made with the largest fdl and that t_q for every read length (never above the exact ones).
+  int fdmax[2] = {0, 0};
+  {
+    int eq = GOP + GEP;
+    for (int n = 1; n <= 2 * MAX_READ; n++) {
+      const int q = (GOP + (GEP + mn) * n) / ((n - 1 + BX_FQ - 1) / BX_FQ + 1);
+      if (q < eq) eq = q;
+    }
+    if (eq > GOP) eq = GOP;
+    for (int st = 0; st < 2; st++) {
+      for (int d = 0; d < 31; d++) {
+        const int v = delta[st][d] < eq ? delta[st][d] : eq;
+        loss[BX_LOSS_FDL + st * 31 + d] = (int16_t)(eq > 0 && v > 0 ? v : 0);
+        if (v > fdmax[st]) fdmax[st] = v;
+      }
+      int16_t* dn = dl + bx_stray_off_fine(st, 0);
+      int16_t* up = dl + bx_stray_off_fine(st, 1);
+      constexpr int NMAX = 3 * BX_GMAX;
+      int fdn[NMAX + 1], fup[NMAX + 1];
+      for (int n = 1; n <= NMAX; n++) {
+        const int t = (n - 1 + BX_FQ - 1) / BX_FQ + 1;
+        const int vd = GOP + (GEP + mn) * n - fdmax[st] * t, vu = GOP + GEP * n - fdmax[st];
+        fdn[n] = vd > 0 ? vd : 0;
+        fup[n] = vu > 0 ? vu : 0;
+      }
+      int phi[BX_GMAX + 1], psi[BX_GMAX + 1];
+      phi[0] = psi[0] = 0;
+      for (int d = 1; d <= BX_GMAX; d++) {
+        int bd = 1 << 30, bu = 1 << 30;
+        for (int n = 1; n <= NMAX; n++) {
+          const int rest = d - n > 0 ? d - n : 0;
+          if (fdn[n] + phi[rest] < bd) bd = fdn[n] + phi[rest];
+          if (fup[n] + psi[rest] < bu) bu = fup[n] + psi[rest];
+        }
+        phi[d] = bd; psi[d] = bu;
+      }
+      for (int d = 0; d <= BX_GMAX; d++) { dn[d] = (int16_t)(phi[d] > 32000 ? 32000 : phi[d]); up[d] = (int16_t)(psi[d] > 32000 ? 32000 : psi[d]); }
+    }
+  }
   // Which row crosses an N column is not known, but every row crosses one column at most: k spanned N columns cost at least the
   // k smallest of { min(GEP, lambda_min(depth of r)) : rows r } -- the end depths (0..14, 16..30) occur once each, depth 15 as
   // often as the read is long (a read under 31 bases has a subset of the depths: the sum of ITS k smallest is no less).
@@ -213,7 +263,9 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
     int ccap = GEP;
     for (int n = 1; n <= 2 * MAX_READ; n++) {
       const int left = (GOP + (GEP + mn) * n - dmax * ((n - 1 + 9) / 10 + 1)) / n;
+      const int leftq = (GOP + (GEP + mn) * n - fdmax[st] * ((n - 1 + BX_FQ - 1) / BX_FQ + 1)) / n;      // (the fine blocks' geometry)
       if (left < ccap) ccap = left;
+      if (leftq < ccap) ccap = leftq;
     }
     if (ccap <= 0) ok = false;
     int v[31];
@@ -338,7 +390,7 @@ struct BxPlan { int mode, d0, w, dstar, b0, edge; };
 enum { BXF_READ = 1, BXF_WINDOW, BXF_BLOCKS, BXF_SPAN, BXF_PATH, BXF_BUDGET, BXF_WIDTH, BXF_KINDS };
 
 // the anchors of a read and what they imply, before any loss is summed
-struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_out, s_un, r_head, r_tail, rescue; };
+struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_out, s_un, r_head, r_tail, rescue, fine; };
 // r_head: first row of the first block with a kept anchor; r_tail: first row behind the last such block; rescue: bx_rescue is to be tried   // l_out < 0: every anchor counts; s_un: dl of the blocks that occur nowhere in the window
 
 // Where the read's blocks occur inside the window.  sc holds the read's planes.
@@ -441,7 +493,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
   // keep the written-down path inside the window
   if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) { an->fail = BXF_PATH; return; }
   an->a_lo = a_lo; an->a_hi = a_hi; an->d_first = d_first; an->d_last = d_last; an->budget = budget; an->l_out = l_out; an->s_un = s_un;
-  an->r_head = bx_block_row(b_lo_any, len2, nb_cut); an->r_tail = bx_block_row(b_hi_any, len2, nb_cut) + DF_K; an->rescue = 0;
+  an->r_head = bx_block_row(b_lo_any, len2, nb_cut); an->r_tail = bx_block_row(b_hi_any, len2, nb_cut) + DF_K; an->rescue = 0; an->fine = 0;
   an->t_lo = 1; an->t_hi = R;
   if (d_first != d_last) {
     // the switch row is looked for between the last block anchored on d_first and the first one after it anchored on d_last
@@ -621,7 +673,8 @@ MIA_HD inline bool bx_rescue(DiagScan<NW>& sc, const RefPlanes& rp, BxAnchors& a
 // block over such a place is in no 10-mer table, counts as a break (dl_b <= (BX_WILD + 1) min lambda) and must not be paid
 // for twice (mt311: 481 such places, one window in two holds one).  Windows beyond 64 BX_NWW columns: 0 (no credit).
 constexpr int BX_NWW = 5;
-MIA_HD inline int bx_window_nmin(const RefPlanes& rp, int s, int len1, int len2) {
+// all_count: every N column is credited (the caller's clean places are found by comparison, not looked up: bx_fine_anchors).
+MIA_HD inline int bx_window_nmin(const RefPlanes& rp, int s, int len1, int len2, bool all_count = false) {
   if (len1 > 64 * BX_NWW || len2 > len1) return 0;
   uint64_t n[BX_NWW + 1];
   bool any = false;
@@ -664,7 +717,7 @@ MIA_HD inline int bx_window_nmin(const RefPlanes& rp, int s, int len1, int len2)
     uint64_t e = over[k];
 #pragma unroll
     for (int t = 1; t < DF_K; t++) e |= (over[k] << t) | (k ? over[k - 1] >> (64 - t) : 0ull);
-    cr[k] = n[k] & ~e;
+    cr[k] = all_count ? n[k] : n[k] & ~e;
   }
   auto below = [&](int end) -> int {                     // credited columns at positions < end
     int c = 0;
@@ -694,6 +747,130 @@ MIA_HD inline int bx_window_nmin(const RefPlanes& rp, int s, int len1, int len2)
   return best;
 }
 static_assert(BX_WILD == 3, "bx_window_nmin flags four N columns within ten");
+
+// FINE BLOCKS -- a second chance for the reads whose loss B0 exceeds what the nine 10-mers can vouch for (sum of dl: 4 500 with
+// the ancient matrix -- three ordinary substitutions at 1 000 each beside the N columns of mt311; a fifth of configs[2]'s reads in
+// their first iteration, one in fifty later on).  The pigeonhole holds for ANY disjoint blocks: with blocks of BX_FQ rows
+// there are len2 / BX_FQ of them (16 for 100 bases, sum of fdl about 8 300).  Their clean places are not looked up but
+// found: the read's planes against every diagonal of the window (one shift per diagonal, DiagScan::advance), a block being
+// clean where none of its rows is a definite mismatch (N columns are clean by definition) and all of them lie inside the
+// window.  Six-mers occur by chance (one block in twenty somewhere in a 200-column window): clean places within
+// BX_FINE_RADIUS of the 10-mer anchors' diagonals are kept (the band must hold them), all others are set aside the way
+// bx_anchors sets stray anchors aside -- a path that crosses no kept place cleanly breaks every block that has none
+// elsewhere and loses at least l_out, which bx_finish requires to exceed B0.  The written-down path (d_first, d_last, switch
+// rows) stays what the 10-mers gave.  an: in/out.  false: no gain possible (tables not usable, too few blocks).
+// How the clean places are found: the window as four bit planes over its COLUMNS (bit p of plane x: column p holds base x or an
+// N; nothing beyond the window), and for block b the columns p at which it is clean, M_b(p) = AND over its six rows k of
+// plane[read base of row o_b + k](p + k) -- six shift-and-AND steps over the window's words per block, whatever the number of
+// diagonals (walking the ~290 diagonals of a window one by one with the read's row planes cost ten times as much).
+// In parts, so that a kernel can deal the blocks of one read to several lanes: bx_fine_scan for blocks b0, b0 + step, ...,
+// the lanes' results combined (OR, min, max), bx_fine_sums on one of them.
+constexpr int BX_FWW = 5;               // words of a window's column planes: windows up to 320 columns
+template <int NW>
+MIA_HD inline bool bx_fine_usable(int len1, int len2, int st, const BxTab& T) {
+  const int nbq = bx_fine_blocks_of(len2);
+  return nbq >= 2 * BX_MIN_BLOCKS && nbq <= 64 && len1 <= 64 * BX_FWW && T.loss[BX_LOSS_FDL + st * 31 + 15] > 0;
+}
+struct BxWinPlanes { uint64_t p[4][BX_FWW]; };
+MIA_HD inline void bx_win_planes(const RefPlanes& rp, int s, int len1, BxWinPlanes* wp) {
+#pragma unroll
+  for (int k = 0; k < BX_FWW; k++) {
+    const int lo = 64 * k;
+    uint64_t l = 0, h = 0, ok = ~0ull, in = 0;
+    if (lo < len1) {
+      const int64_t bit = (int64_t)s + lo + PLANE_LEAD;
+      const int64_t q = bit >> 6;
+      const int b = (int)(bit & 63);
+      l = (rp.lo[q] >> b) | ((rp.lo[q + 1] << 1) << (63 - b));
+      h = (rp.hi[q] >> b) | ((rp.hi[q + 1] << 1) << (63 - b));
+      ok = (rp.ok[q] >> b) | ((rp.ok[q + 1] << 1) << (63 - b));
+      in = len1 - lo < 64 ? (1ull << (len1 - lo)) - 1ull : ~0ull;
+    }
+    wp->p[0][k] = ((~l & ~h) | ~ok) & in;
+    wp->p[1][k] = ((l & ~h) | ~ok) & in;
+    wp->p[2][k] = ((~l & h) | ~ok) & in;
+    wp->p[3][k] = ((l & h) | ~ok) & in;
+  }
+}
+// blocks b0, b0 + step, ... of the read in sc: bit b of *in / *out = block b is clean somewhere on the kept diagonals k_lo .. k_hi /
+// somewhere else in the window; *a_lo / *a_hi take in the kept diagonals that hold a clean block
+template <int NW>
+MIA_HD inline void bx_fine_scan(const DiagScan<NW>& sc, const BxWinPlanes& wp, int len1, int len2, int k_lo, int k_hi, int b0, int step,
+                                uint64_t* in, uint64_t* out, int* a_lo, int* a_hi) {
+  const int nbq = bx_fine_blocks_of(len2);
+  for (int b = b0; b < nbq; b += step) {
+    const int o = bx_fine_block_row(b, len2, nbq);
+    uint64_t A[BX_FWW];
+#pragma unroll
+    for (int k = BX_FQ - 1; k >= 0; k--) {
+      const int row = o + k;
+      uint64_t wl = sc.rlo[0], wh = sc.rhi[0];
+#pragma unroll
+      for (int j = 1; j < NW; j++) if ((row >> 6) == j) { wl = sc.rlo[j]; wh = sc.rhi[j]; }
+      const int x = (int)(((wl >> (row & 63)) & 1ull) | (((wh >> (row & 63)) & 1ull) << 1));
+#pragma unroll
+      for (int w = 0; w < BX_FWW; w++) {
+        const uint64_t pl = x == 0 ? wp.p[0][w] : (x == 1 ? wp.p[1][w] : (x == 2 ? wp.p[2][w] : wp.p[3][w]));
+        if (k == BX_FQ - 1) A[w] = pl;
+        else A[w] = pl & ((A[w] >> 1) | (w + 1 < BX_FWW ? A[w + 1] << 63 : 0ull));      // (words ascend: A[w + 1] still holds the previous step)
+      }
+    }
+    // kept: columns k_lo + o .. k_hi + o
+    const int p_lo = k_lo + o < 0 ? 0 : k_lo + o, p_hi = k_hi + o;
+    bool is_in = false, is_out = false;
+    int first = 1 << 20, last = -(1 << 20);
+#pragma unroll
+    for (int w = 0; w < BX_FWW; w++) {
+      const int lo = p_lo - 64 * w, hi = p_hi + 1 - 64 * w;               // bits lo .. hi - 1 of this word are kept columns
+      uint64_t R = 0;
+      if (hi > 0 && lo < 64) {
+        R = ~0ull;
+        if (lo > 0) R &= ~0ull << lo;
+        if (hi < 64) R &= (1ull << hi) - 1ull;
+      }
+      const uint64_t ai = A[w] & R, ao = A[w] & ~R;
+      if (ai) {
+        is_in = true;
+        const int f = 64 * w + df_ctz(ai), l = 64 * w + 63 - df_clz(ai);
+        if (f < first) first = f;
+        if (l > last) last = l;
+      }
+      if (ao) is_out = true;
+    }
+    if (is_in) {
+      *in |= 1ull << b;
+      if (first - o < *a_lo) *a_lo = first - o;
+      if (last - o > *a_hi) *a_hi = last - o;
+    }
+    if (is_out) *out |= 1ull << b;
+  }
+}
+template <int NW>
+MIA_HD inline void bx_fine_sums(uint64_t in, uint64_t out, int a_lo, int a_hi, int len2, int st, const BxTab& T, BxAnchors* an) {
+  const int nbq = bx_fine_blocks_of(len2);
+  int budget = -1, l_out = 0, s_un = 0;
+  for (int b = 0; b < nbq; b++) {
+    const int o = bx_fine_block_row(b, len2, nbq);
+    int v = 1 << 20;
+    for (int r = o; r < o + BX_FQ; r++) { const int f = T.loss[BX_LOSS_FDL + st * 31 + sm_depth(r, len2)]; if (f < v) v = f; }
+    const int is_in = (int)((in >> b) & 1ull), is_out = (int)((out >> b) & 1ull);
+    budget += v;
+    if (!is_out) l_out += v;
+    if (!is_in && !is_out) s_un += v;
+  }
+  an->budget = budget; an->l_out = l_out; an->s_un = s_un; an->a_lo = a_lo; an->a_hi = a_hi; an->fine = 1;
+}
+template <int NW>
+MIA_HD inline bool bx_fine_anchors(DiagScan<NW>& sc, const RefPlanes& rp, int s, int len1, int len2, int st, const BxTab& T, BxAnchors* an) {
+  if (!bx_fine_usable<NW>(len1, len2, st, T)) return false;
+  BxWinPlanes wp;
+  bx_win_planes(rp, s, len1, &wp);
+  uint64_t in = 0, out = 0;
+  int a_lo = an->a_lo, a_hi = an->a_hi;
+  bx_fine_scan<NW>(sc, wp, len1, len2, an->a_lo - BX_FINE_RADIUS, an->a_hi + BX_FINE_RADIUS, 0, 1, &in, &out, &a_lo, &a_hi);
+  bx_fine_sums<NW>(in, out, a_lo, a_hi, len2, st, T, an);
+  return true;
+}
 
 // the rows of word j that lose anything on the diagonal sc is on: definite mismatches and N columns
 template <int NW>
@@ -746,8 +923,10 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   int ncredit = 0;
   if (b0x > an.budget || (an.l_out >= 0 && an.l_out <= b0x)) {
     if (T.loss[BX_LOSS_NCRED + st * BX_NCRED_K + 1] > 0) {
-      const int nm = bx_window_nmin(rp, s, len1, len2);
-      if (nm > 0) ncredit = T.loss[BX_LOSS_NCRED + st * BX_NCRED_K + (nm < BX_NCRED_K ? nm : BX_NCRED_K - 1)];
+      const int nm = bx_window_nmin(rp, s, len1, len2, an.fine != 0);
+      const int16_t* cum = T.loss + BX_LOSS_NCRED + st * BX_NCRED_K;
+      // (beyond the table every further column carries what the last one did: the interior rows' credit)
+      if (nm > 0) ncredit = nm < BX_NCRED_K ? cum[nm] : cum[BX_NCRED_K - 1] + (nm - (BX_NCRED_K - 1)) * (cum[BX_NCRED_K - 1] - cum[BX_NCRED_K - 2]);
     }
   }
   if (b0x > an.budget + ncredit) return;
@@ -761,8 +940,8 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   if (g_dn > 0) {
     const int x = b0x - an.s_un;
     if (x < 0) { out->b0 = BXF_PATH; return; }         // (cannot happen: every path pays for the blocks that occur nowhere)
-    const int16_t* dn = T.dl + bx_stray_off(st, len2, 0);
-    const int16_t* up = T.dl + bx_stray_off(st, len2, 1);
+    const int16_t* dn = T.dl + (an.fine ? bx_stray_off_fine(st, 0) : bx_stray_off(st, len2, 0));
+    const int16_t* up = T.dl + (an.fine ? bx_stray_off_fine(st, 1) : bx_stray_off(st, len2, 1));
     if (g_dn > BX_GMAX) g_dn = g_up = BX_GMAX + 1;     // (beyond the tables: the band is too wide anyway)
     else {
       // either side can be reached either way: below the anchors by skipped rows behind them or by a column gap in front
@@ -842,6 +1021,10 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   out->edge = !(d0 >= 0 && len2 - 1 + d0 + wc <= len1);
 }
 
+// a read the 10-mers could not vouch for (budget, or anchors set aside that l_out could not cover): the fine blocks may
+MIA_HD inline bool bx_wants_fine(const BxPlan& p) { return p.mode == BX_NONE && (p.b0 == BXF_BUDGET || p.b0 == BXF_SPAN); }
+MIA_HD inline bool a_hi_ok(const BxAnchors& an, const BxTab& T) { return an.fail == 0 && an.a_hi - an.a_lo + 2 * BX_FINE_RADIUS < T.maxw; }
+
 MIA_HD inline bool bx_plannable(const RefPlanes& rp, const KmerHash& ko, int64_t n_ref, int s, int len1, int len2) {
   if (!ko.slot || len2 < BX_MIN_BLOCKS * DF_K || len2 > MAX_READ || len1 < len2 || len1 > DF_MAX_LEN1 || s < 0 || (int64_t)s + len1 > n_ref) return false;
   return ko.wild > 0 || all_bases(rp, s, (int64_t)s + len1);     // (N columns: only with a table that lists them)
@@ -865,6 +1048,11 @@ MIA_HD inline void bx_plan_nw(const RefPlanes& rp, const KmerHash& ko, int64_t n
     const int why = out->b0;
     if (bx_rescue<NW>(sc, rp, an, s, len1, len2)) bx_finish<NW, 2>(sc, rp, an, s, len1, len2, st, T, out);
     else out->b0 = why;
+  }
+  if (bx_wants_fine(*out) && a_hi_ok(an, T)) {
+    const int why = out->b0;
+    if (bx_fine_anchors<NW>(sc, rp, s, len1, len2, st, T, &an)) bx_finish<NW>(sc, rp, an, s, len1, len2, st, T, out);
+    if (out->mode == BX_NONE && out->b0 != BXF_WIDTH) out->b0 = why;
   }
 }
 

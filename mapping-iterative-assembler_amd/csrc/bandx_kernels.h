@@ -23,7 +23,7 @@ namespace mia {
 
 // counters of the pipeline; each on a cache line of its own (BXC_STRIDE words apart): thousands of wavefronts add to them,
 // and atomics on one line are served one after the other
-enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_CAND = 30, BXC_COUNTERS = 32 };     // CAND: reads handed from the plan's first launch to its second
+enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_CAND = 30, BXC_CAND2 = 31, BXC_COUNTERS = 32 };     // CAND: reads handed from the plan's first launch to its second; CAND2: on to the third (fine blocks)
 static_assert(BXC_SEEN < BXC_FAIL0 && BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_CAND && BXC_CAND < BXC_COUNTERS, "counter layout");
 constexpr int BXC_STRIDE = 64;
 constexpr int BXC_WORDS = BXC_COUNTERS * BXC_STRIDE;
@@ -51,8 +51,13 @@ struct BxDev {
   // rescue) are handed from the first to the second through this list; nullptr: one launch, the block's first threads finish them
   struct BxCandRec* cand;
   uint32_t* cand_n;
+  // ... and the reads whose loss exceeds what the 10-mers vouch for go on to a third launch (phase 3: bx_fine_anchors); nullptr: no third launch
+  struct BxCandRec* cand2;
+  uint32_t* cand2_n;
 };
 struct BxCandRec { int32_t i; BxAnchors an; };
+constexpr int BX_FINE_LANES = 1;         // lanes that share the fine blocks of one read in the plan's third launch (measured: what a read costs there is
+                                         // bx_finish, which one lane walks alone -- eight lanes per read made the launch no shorter and the bulk case four times longer)
 
 __device__ __forceinline__ uint32_t bx_pack(const BxPlan& p) {
   return (uint32_t)(p.d0 + 512) | ((uint32_t)(p.dstar - p.d0) << 11) | ((uint32_t)p.edge << 17) | ((uint32_t)p.w << 18);
@@ -204,22 +209,29 @@ __global__ __launch_bounds__(256) void k_read_planes(ReadSet rs, int32_t words, 
 // they lie on one diagonal (nine reads in ten), through the rest; the others are collected and finished by the block's
 // first threads, so that their longer way (two diagonals, the switch row between them) is not walked by whole wavefronts
 // for the sake of a few lanes.
-template <int NW>
+// PH (a template parameter: each launch carries only the registers and LDS of its own part): 0 = everything in one launch (the
+// reads with anchors on two diagonals by the block's first threads); 1 = the first of three launches (those reads go on
+// bx.cand, the reads the 10-mers cannot vouch for on bx.cand2); 2 = bx.cand with every lane at work; 3 = bx.cand2, the
+// fine blocks (bx_fine_anchors), the diagonals of one read dealt to BX_FINE_LANES neighbouring lanes.
+template <int NW, int PH>
 __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPlanes rp, KmerHash ko, int64_t n_ref, BxDev bx, const int32_t* in_list,
-                                                  const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of, int32_t phase = 0) {
+                                                  const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of) {
+  constexpr int SLOT_FINE = 2 * BX_NCLS + 2 + BXF_KINDS;     // blk_cnt: reads handed on to the third launch
   __shared__ int16_t loss_lds[BX_LOSS_WORDS];
-  __shared__ BxAnchors cand_an[256];
-  __shared__ uint8_t cand_tid[256];
+  __shared__ BxAnchors cand_an[PH < 2 ? 256 : 1];
+  __shared__ uint8_t cand_tid[PH < 2 ? 256 : 1];
   __shared__ int32_t n_cand;
-  __shared__ uint32_t blk_cnt[2 * BX_NCLS + 2 + BXF_KINDS], blk_base[2 * BX_NCLS];   // per block: list appends, finished, seen, reasons
+  __shared__ uint32_t blk_cnt[SLOT_FINE + 1], blk_base[2 * BX_NCLS + 1];   // per block: list appends, finished, seen, reasons, hand-overs
   for (int k = threadIdx.x; k < BX_LOSS_WORDS; k += 256) loss_lds[k] = bx.tab.loss[k];
   if (threadIdx.x == 0) n_cand = 0;
-  if (threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS) blk_cnt[threadIdx.x] = 0;
+  if (threadIdx.x <= SLOT_FINE) blk_cnt[threadIdx.x] = 0;
   __syncthreads();
   BxTab T = bx.tab;
   T.loss = loss_lds;
   const int64_t total = in_list ? (int64_t)*n_in_p : n_all;
   const int64_t t0 = (int64_t)blockIdx.x * 256;
+  // a read the 10-mers cannot vouch for goes on to the third launch instead of being given up
+  const bool fine_on = (PH == 1 || PH == 2) && bx.cand2 != nullptr;
 
   struct Rd { int32_t i; int len2, s, l1, st; bool ok; };
   auto fetch = [&](int tid, DiagScan<NW>& sc) -> Rd {
@@ -243,8 +255,8 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     }
     return sc.load_read(rs.packed + rs.roff[r.i], r.len2);
   };
-  // results of a planned read: finished (scripts follow), or on to a list
-  auto emit = [&](const Rd& r, const BxPlan& bp, bool mark_open) {
+  // results of a planned read: finished (scripts follow), on to a list -- or, with to_fine, on to the third launch with its anchors
+  auto emit = [&](const Rd& r, const BxPlan& bp, bool mark_open, bool to_fine, const BxAnchors& an) {
     if (r.ok || mark_open) {
       if (bp.mode == BX_DONE || bp.mode == BX_VALUES) {
         const int u = bx.umax ? bx.umax[r.i] : bx_umax(bx.tab.mrow, rs.packed + rs.roff[r.i], r.len2, r.st);
@@ -266,6 +278,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     const int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? BX_NCLS + bx_class_of(bp.w) : -1);
     uint32_t rank = 0;
     if (which >= 0) rank = atomicAdd(&blk_cnt[which], 1u);
+    if (to_fine) rank = atomicAdd(&blk_cnt[SLOT_FINE], 1u);
     if (bp.mode == BX_DONE) atomicAdd(&blk_cnt[2 * BX_NCLS], 1u);
     if (r.ok && bp.mode == BX_NONE && bp.b0 > 0 && bp.b0 < BXF_KINDS) atomicAdd(&blk_cnt[2 * BX_NCLS + 2 + bp.b0], 1u);
     __syncthreads();
@@ -274,28 +287,27 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     if (threadIdx.x == 2 * BX_NCLS + 1 && blk_cnt[2 * BX_NCLS + 1]) atomicAdd(bxc(bx.ctr, BXC_SEEN), blk_cnt[2 * BX_NCLS + 1]);
     if (threadIdx.x > 2 * BX_NCLS + 2 && threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS && blk_cnt[threadIdx.x])
       atomicAdd(bxc(bx.ctr, BXC_FAIL0 + (int)threadIdx.x - 2 * BX_NCLS - 2), blk_cnt[threadIdx.x]);
+    if (threadIdx.x == SLOT_FINE && blk_cnt[SLOT_FINE]) blk_base[2 * BX_NCLS] = atomicAdd(bx.cand2_n, blk_cnt[SLOT_FINE]);
     __syncthreads();
     if (which >= 0) bx.lists[(int64_t)which * bx.list_stride + blk_base[which] + rank] = r.i;
+    if (to_fine) { BxCandRec rec; rec.i = r.i; rec.an = an; bx.cand2[blk_base[2 * BX_NCLS] + rank] = rec; }
     if (!bx.lazy_scripts) bx_diag_scripts(rs, __ballot(bp.mode == BX_DONE), r.i, bp.dstar, r.len2);
     __syncthreads();
-    if (threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS) blk_cnt[threadIdx.x] = 0;
+    if (threadIdx.x <= SLOT_FINE) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
   };
-  // phase 0: everything here (the reads with anchors on two diagonals by the block's first threads, below); phase 1: those
-  // reads go on bx.cand instead -- the launch with phase 2 finishes them with every lane at work (in one launch a block's
-  // three other wavefronts sat at the barrier meanwhile: 58 of the kernel's 224 us)
-  if (phase != 2) {
+  if (PH < 2) {
     DiagScan<NW> sc;
     Rd r = fetch((int)threadIdx.x, sc);
     BxPlan bp;
     bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
-    bool waits = false;
+    BxAnchors an{};
+    bool waits = false, to_fine = false;
     if (r.ok) {
       bp.b0 = BXF_WINDOW;
       if (bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2)) {
         bp.b0 = BXF_READ;
         if (load_planes(r, sc)) {
-          BxAnchors an;
           bx_anchors<NW>(sc, ko, reinterpret_cast<const uint32_t*>(rs.packed + rs.roff[r.i]), r.s, r.l1, r.len2, r.st, T, &an);
           bp.b0 = an.fail;
           if (!an.fail) {
@@ -304,6 +316,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
               bx_finish<NW, 1>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
               // an end indel, perhaps (bx_rescue): with the reads of two diagonals, for the block's first threads
               if (bp.mode == BX_NONE && (bp.b0 == BXF_BUDGET || bp.b0 == BXF_WIDTH) && an.a_lo == an.a_hi) { later = true; an.rescue = bp.b0; }
+              else if (fine_on && bx_wants_fine(bp) && a_hi_ok(an, T)) { an.rescue = bp.b0; to_fine = true; waits = true; bp.mode = BX_NONE; bp.b0 = 0; }
             }
             if (later) {
               const int slot = atomicAdd(&n_cand, 1);
@@ -318,11 +331,11 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     }
     const unsigned long long sm = __ballot(r.ok);
     if ((threadIdx.x & 63) == 0 && sm) atomicAdd(&blk_cnt[2 * BX_NCLS + 1], (uint32_t)__popcll(sm));
-    // (a waiting read's mark is written in the second phase)
+    // (a waiting read's mark is written by the launch that finishes it)
     Rd rr = r;
     if (waits) rr.ok = false;
-    emit(rr, bp, !in_list && t0 + threadIdx.x < total && !waits);
-    if (phase == 1) {                               // hand the waiting reads over: one reservation per block
+    emit(rr, bp, !in_list && t0 + threadIdx.x < total && !waits, to_fine, an);
+    if (PH == 1) {                                  // hand the waiting reads over: one reservation per block
       __shared__ uint32_t cand_base;
       __syncthreads();
       if (threadIdx.x == 0 && n_cand) cand_base = atomicAdd(bx.cand_n, (uint32_t)n_cand);
@@ -337,19 +350,25 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     }
   }
   __syncthreads();
-  if ((phase == 0 && n_cand == 0) || (bx.dbg & 32u)) return;      // (MIA_HIP_BX_DEBUG=32, profiling only: no second phase)
-  // the candidates: this block's own (phase 0), or 256 of the list per step (phase 2; every thread loops alike: emit has barriers)
-  const int64_t n_list = phase == 2 ? (int64_t)*bx.cand_n : 0;
-  for (int64_t c0 = phase == 2 ? (int64_t)blockIdx.x * 256 : 0; phase == 2 ? c0 < n_list : c0 == 0; c0 += phase == 2 ? (int64_t)gridDim.x * 256 : 1) {
+  if ((PH == 0 && n_cand == 0) || (bx.dbg & 32u)) return;      // (MIA_HIP_BX_DEBUG=32, profiling only: no second phase)
+  if (PH == 3 && !bx.cand2) return;
+  // the candidates: this block's own (PH 0), or a stretch of the list per step (PH 2, 3; every thread loops alike: emit has barriers)
+  constexpr bool listed = PH >= 2;
+  const BxCandRec* const list = PH == 3 ? bx.cand2 : bx.cand;
+  const int64_t n_list = PH == 3 ? (int64_t)*bx.cand2_n : (PH == 2 ? (int64_t)*bx.cand_n : 0);
+  constexpr int per = PH == 3 ? 256 / BX_FINE_LANES : 256;            // reads per block and step
+  for (int64_t c0 = listed ? (int64_t)blockIdx.x * per : 0; listed ? c0 < n_list : c0 == 0; c0 += listed ? (int64_t)gridDim.x * per : 1) {
     DiagScan<NW> sc;
     Rd r{0, 0, 0, 0, 0, false};
     BxPlan bp;
     bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
-    const bool mine = phase == 2 ? c0 + threadIdx.x < n_list : (int)threadIdx.x < n_cand;
+    const int slot = PH == 3 ? (int)threadIdx.x / BX_FINE_LANES : (int)threadIdx.x, u = PH == 3 ? (int)threadIdx.x % BX_FINE_LANES : 0;
+    const bool mine = listed ? c0 + slot < n_list : (int)threadIdx.x < n_cand;
+    bool to_fine = false;
+    BxAnchors an{};
     if (mine) {
-      BxAnchors an;
-      if (phase == 2) {
-        const BxCandRec rec = bx.cand[c0 + threadIdx.x];
+      if (listed) {
+        const BxCandRec rec = list[c0 + slot];
         an = rec.an;
         r.i = rec.i;
         r.len2 = rs.len[r.i];
@@ -361,10 +380,43 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
         an = cand_an[threadIdx.x];
       }
       load_planes(r, sc);
-      if (an.rescue && !bx_rescue<NW>(sc, rp, an, r.s, r.l1, r.len2)) bp.b0 = an.rescue;      // (the reason it was not planned stands)
-      else bx_finish<NW, 2>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
+      if (PH == 3) {
+        // the fine blocks (bx_fine_anchors): more blocks, more budget; the reason the 10-mers gave stands if they do not help either
+        const int why = an.rescue;
+        an.rescue = 0;
+        const bool usable = bx_fine_usable<NW>(r.l1, r.len2, r.st, T);
+        uint64_t in = 0, out = 0;
+        int a_lo = an.a_lo, a_hi = an.a_hi;
+        if (usable) {
+          // this lane's share of the blocks (u, u + BX_FINE_LANES, ...) against the window's column planes
+          BxWinPlanes wp;
+          bx_win_planes(rp, r.s, r.l1, &wp);
+          bx_fine_scan<NW>(sc, wp, r.l1, r.len2, an.a_lo - BX_FINE_RADIUS, an.a_hi + BX_FINE_RADIUS, u, BX_FINE_LANES, &in, &out, &a_lo, &a_hi);
+        }
+        // (all lanes of a read are here together: `mine`, the record and `usable` are the same for them)
+#pragma unroll
+        for (int o = 1; o < BX_FINE_LANES; o <<= 1) {
+          in |= __shfl_xor(in, o); out |= __shfl_xor(out, o);
+          const int lo2 = __shfl_xor(a_lo, o), hi2 = __shfl_xor(a_hi, o);
+          a_lo = lo2 < a_lo ? lo2 : a_lo;
+          a_hi = hi2 > a_hi ? hi2 : a_hi;
+        }
+        if (u == 0) {
+          if (usable) {
+            bx_fine_sums<NW>(in, out, a_lo, a_hi, r.len2, r.st, T, &an);
+            bx_finish<NW>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
+          }
+          if (bp.mode == BX_NONE && bp.b0 != BXF_WIDTH) bp.b0 = why;
+        } else r.ok = false;                        // (the read's other lanes have nothing to report)
+      } else {
+        if (an.rescue && !bx_rescue<NW>(sc, rp, an, r.s, r.l1, r.len2)) bp.b0 = an.rescue;      // (the reason it was not planned stands)
+        else bx_finish<NW, 2>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
+        if (fine_on && bx_wants_fine(bp) && a_hi_ok(an, T)) { an.rescue = bp.b0; to_fine = true; bp.mode = BX_NONE; bp.b0 = 0; }
+      }
     }
-    emit(r, bp, !in_list && r.ok);
+    Rd rr = r;
+    if (to_fine) rr.ok = false;
+    emit(rr, bp, !in_list && rr.ok, to_fine, an);
   }
 }
 
@@ -558,7 +610,7 @@ __device__ __forceinline__ uint32_t bxl_values_chunk(const ReadSet& rs, const Re
   return ok ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(256) void k_bxl_values(ReadSet rs, RefInfo ref, BxDev bx, int32_t* bin_of) {
+__global__ __launch_bounds__(256, 4) void k_bxl_values(ReadSet rs, RefInfo ref, BxDev bx, int32_t* bin_of) {
   __shared__ int32_t sub_lds[BX_SUB_WORDS];
   for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.tab.sub[k];
   __syncthreads();

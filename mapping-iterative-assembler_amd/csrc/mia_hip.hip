@@ -64,6 +64,7 @@ struct mia_hip_ctx {
   bool cull_scan = false, tail_scans = false, stage_markers = false;
   bool spin_wait = true;        // mia_hip_iterate's one wait asks (hipStreamQuery) instead of sleeping on an interrupt; MIA_HIP_SPIN_WAIT=0: hipStreamSynchronize
   uint32_t ext_events = 31u; bool planner_end_signalled = false, align_end_signalled = false;
+  BxCandRec* d_bx_cand2 = nullptr; int use_fine = 1;      // the third launch's list (reads for the fine blocks); MIA_HIP_NO_FINE=1: none; MIA_HIP_FINE=2: in every iteration
   BxCandRec* d_bx_cand = nullptr; int64_t cand_cap = 0; bool plan_split = true;      // k_bx_plan's hand-over list between its two launches (MIA_HIP_NO_PLAN_SPLIT=1: one launch)
   bool no_spec = false;                     // MIA_HIP_NO_SPEC=1: wait for the alignment's counters before the cull is queued
   bool no_side_buckets = false;             // MIA_HIP_NO_SIDE_BUCKETS=1
@@ -343,6 +344,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (egs && atoi(egs)) ctx->lazy_scripts = 0;
     const char* nwl = getenv("MIA_HIP_NO_WILD");
     if (nwl && atoi(nwl)) ctx->use_wild = 0;
+    if (const char* nf = getenv("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
+    if (const char* nf = getenv("MIA_HIP_FINE")) ctx->use_fine = atoi(nf);
     const char* bxf = getenv("MIA_HIP_BX_FILTER");
     if (bxf && atoi(bxf)) ctx->bx_filter_first = 1;
     const char* nq = getenv("MIA_HIP_NO_QUAD");
@@ -412,6 +415,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (ctx->d_bx_slabs_late) (void)hipFree(ctx->d_bx_slabs_late);
   if (ctx->d_one) (void)hipFree(ctx->d_one);
   if (ctx->d_bx_cand) (void)hipFree(ctx->d_bx_cand);
+  if (ctx->d_bx_cand2) (void)hipFree(ctx->d_bx_cand2);
   for (int k = 0; k < 3; k++) if (ctx->d_slabs_retry[k]) (void)hipFree(ctx->d_slabs_retry[k]);
   if (ctx->d_prep_bar) (void)hipFree(ctx->d_prep_bar);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -1071,32 +1075,42 @@ static int align_all(mia_hip_ctx* ctx) {
       const bool split = ctx->plan_split;
       const bool fork_by_launch = (ctx->ext_events & 1u) && new_flow && !(ctx->dbg & 256u);
       bd.cand = nullptr; bd.cand_n = ctx->d_bx_ctr + (size_t)BXC_CAND * BXC_STRIDE;
+      bd.cand2 = nullptr; bd.cand2_n = ctx->d_bx_ctr + (size_t)BXC_CAND2 * BXC_STRIDE;
+      // a third launch for the reads whose loss exceeds what the 10-mers vouch for (bx_fine_anchors; MIA_HIP_NO_FINE=1: given up as before)
+      // ... when the plan gives up on many reads: against a reference full of ambiguity codes (every run's first iteration), or when
+      // it did so in the iteration before.  Otherwise the launch would sit on the step's critical path (~50 us) for the sake of reads
+      // whose full-window kernels run beside the band DPs anyway.
+      int64_t rejects_before = 0;
+      for (int k = 1; k < BXF_KINDS; k++) rejects_before += ctx->bx_last[BXC_FAIL0 + k];
+      const bool fine = split && ctx->use_fine && (ctx->use_fine > 1 || !ctx->ref_mostly_bases || rejects_before * 20 > n);
       if (split) {
-        if (n > ctx->cand_cap) { if (dev_alloc(ctx, &ctx->d_bx_cand, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->cand_cap = n; }
+        if (n > ctx->cand_cap) {
+          if (dev_alloc(ctx, &ctx->d_bx_cand, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_cand2, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+          ctx->cand_cap = n;
+        }
         bd.cand = ctx->d_bx_cand;
+        if (fine) bd.cand2 = ctx->d_bx_cand2;
       }
+      const int last_phase = split ? (fine ? 3 : 2) : 0;
       if (stage_begin(ctx, STG_BX_PLAN)) return MIA_HIP_ERR_NOMEM;
       {
         const int32_t* in_list = run_filter ? ctx->d_left_list : nullptr;
         const dim3 pb(256);
-        for (int phase = split ? 1 : 0; phase <= (split ? 2 : 0); phase++) {
-          const dim3 pg(phase == 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
-          if (fork_by_launch && phase == (split ? 2 : 0)) {
-            // the fork event rides on this launch's own completion signal: no marker between the plan and the values DP
-            switch ((ctx->max_len + 63) >> 6) {
-              case 1: hipExtLaunchKernelGGL(k_bx_plan<1>, pg, pb, 0, ctx->stream, nullptr, ctx->ev_fork, 0, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
-              case 2: hipExtLaunchKernelGGL(k_bx_plan<2>, pg, pb, 0, ctx->stream, nullptr, ctx->ev_fork, 0, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
-              case 3: hipExtLaunchKernelGGL(k_bx_plan<3>, pg, pb, 0, ctx->stream, nullptr, ctx->ev_fork, 0, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
-              default: hipExtLaunchKernelGGL(k_bx_plan<4>, pg, pb, 0, ctx->stream, nullptr, ctx->ev_fork, 0, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
-            }
-            continue;
+        const int nwords = (ctx->max_len + 63) >> 6;       // 64-row words of the longest read
+        for (int phase = split ? 1 : 0; phase <= last_phase; phase++) {
+          const dim3 pg(phase >= 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
+          // (the fork event rides on the last launch's own completion signal: no marker between the plan and the values DP)
+          hipEvent_t done = (fork_by_launch && phase == last_phase) ? ctx->ev_fork : nullptr;
+#define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, 0, ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
+#define MIA_PLAN_NW(PHV) switch (nwords) { case 1: MIA_PLAN(1, PHV); break; case 2: MIA_PLAN(2, PHV); break; case 3: MIA_PLAN(3, PHV); break; default: MIA_PLAN(4, PHV); break; }
+          switch (phase) {
+            case 0: MIA_PLAN_NW(0) break;
+            case 1: MIA_PLAN_NW(1) break;
+            case 2: MIA_PLAN_NW(2) break;
+            default: MIA_PLAN_NW(3) break;
           }
-          switch ((ctx->max_len + 63) >> 6) {       // 64-row words of the longest read
-            case 1: hipLaunchKernelGGL(k_bx_plan<1>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
-            case 2: hipLaunchKernelGGL(k_bx_plan<2>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
-            case 3: hipLaunchKernelGGL(k_bx_plan<3>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
-            default: hipLaunchKernelGGL(k_bx_plan<4>, pg, pb, 0, ctx->stream, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, ctx->d_filter_n + 1, n, ctx->d_bin_of, phase); break;
-          }
+#undef MIA_PLAN_NW
+#undef MIA_PLAN
         }
       }
       stage_end(ctx, STG_BX_PLAN);

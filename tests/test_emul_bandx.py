@@ -499,4 +499,5 @@ def test_window_wide_n_credit(emul, oracle, spec, strand):
         if l1 < n:
             continue
         check(emul, oracle, spec, strand, ref, s, l1, read, stats)
+    print("n_credit", spec, strand, sorted(stats.items()), finished)
     assert stats["n"] > 550 and finished > 150, (str(sorted(stats.items())), finished)

@@ -18,7 +18,9 @@ pytestmark = pytest.mark.gpu
 
 SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HIP_NO_SPEC", "MIA_HIP_SPEC_TEST", "MIA_HIP_NO_PREP_FUSE",
             "MIA_HIP_NO_SIDE_BUCKETS", "MIA_HIP_BX_DEBUG=64", "MIA_HIP_NO_PLAN_SPLIT", "MIA_HIP_NO_ZERO_COPY", "MIA_HIP_NO_EXT_EVENTS",
-            "MIA_HIP_EVENT_DEVICE_SCOPE", "MIA_HIP_SPIN_WAIT=0", "MIA_HIP_CULL_SCAN", "MIA_HIP_TAIL_SCANS"]
+            "MIA_HIP_EVENT_DEVICE_SCOPE", "MIA_HIP_SPIN_WAIT=0", "MIA_HIP_CULL_SCAN", "MIA_HIP_TAIL_SCANS",
+            # round 4: the plan's third launch (fine blocks, bandx_body.h: bx_fine_anchors) never / in every iteration
+            "MIA_HIP_NO_FINE", "MIA_HIP_FINE=2"]
 
 
 def two_iterations(mod, w, env):
