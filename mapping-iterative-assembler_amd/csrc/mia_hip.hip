@@ -1,6 +1,7 @@
 // mia_hip.hip -- libmia_hip.so: C ABI (include/mia_hip.h) over the gfx950 kernels.
 // Build: hipcc --offload-arch=gfx950 -O3 -fPIC -shared (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -201,7 +202,7 @@ struct mia_hip_ctx {
   int64_t iter_fallbacks = 0;
   // sharded runs: one context per GPU; the exchanges go through a table of collectives (RCCL over xGMI from
   // mia_hip_comm_init, or whatever mia_hip_comm_attach was given), on the context's own stream
-  mia_hip_collectives coll{}; bool comm = false; int comm_ranks = 1, comm_rank = 0;
+  mia_hip_collectives coll{}; bool comm = false; int comm_ranks = 1, comm_rank = 0; std::string coll_name;
   unsigned long long* d_gather = nullptr;   // [PRE_WORDS * ranks] score sums, record, link and exact-kernel counts of every rank
   std::vector<int64_t> h_gather;            // ... on the host, once the alignment's one wait is over
   int64_t ev_pad = 0;                       // insert events per rank the event all-gather is sized for (0: not known yet)
@@ -380,6 +381,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (hipMalloc((void**)&ctx->d_prep_bar, 4) != hipSuccess || hipMemset(ctx->d_prep_bar, 0, 4) != hipSuccess) { delete ctx; return MIA_HIP_ERR_DEVICE; }
   }
   if (hipHostMalloc((void**)&ctx->h_pin, mia_hip_ctx::PIN_BYTES, hipHostMallocDefault) != hipSuccess) ctx->h_pin = nullptr;   // optional
+  if (ctx->h_pin) memset(ctx->h_pin, 0, mia_hip_ctx::PIN_MISC);
+  else ctx->no_prep_fuse = true;            // (k_ref_prep reports a barrier it gave up on through a pinned word: without one, six plain launches)
   *out = ctx;
   return MIA_HIP_OK;
 }
@@ -1019,10 +1022,15 @@ static int align_all(mia_hip_ctx* ctx) {
         rp2.nib_words = nw; rp2.nib = ctx->d_refnib;
         const int64_t want = ((int64_t)wrap + (kh.wild > 0 ? 63 : 255)) / (kh.wild > 0 ? 64 : 256);       // (N columns spelled out: 64 positions per workgroup, see kmer_hash_insert_block)
         const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, ctx->cus));      // one workgroup per compute unit at most: all resident
-        ctx->prep_bar_count += grid;
-        rp2.bar = ctx->d_prep_bar; rp2.bar_target = ctx->prep_bar_count;
-        ctx->pend_encode = false;
+        // the grid barrier's target: what the counter reaches when this launch's workgroups have all arrived.  The host's count only
+        // moves once the launch is known to be queued (a refused launch adds nothing on the device either), the wait inside the
+        // kernel is bounded, and a barrier given up on is reported through a pinned word the step's one wait looks at.
+        rp2.bar = ctx->d_prep_bar; rp2.bar_target = ctx->prep_bar_count + grid;
+        rp2.stuck = ctx->h_pin ? reinterpret_cast<uint32_t*>(ctx->h_pin + (62 << 10)) : nullptr;
         hipLaunchKernelGGL(k_ref_prep, dim3(grid), dim3(256), 0, ctx->stream, rp2);
+        HIPCHK(hipGetLastError());
+        ctx->prep_bar_count += grid;
+        ctx->pend_encode = false;
       } else {
       HIPCHK(hipMemsetAsync(ctx->d_khash, 0xFF, (size_t)kslots * 16, ctx->stream));
       hipLaunchKernelGGL(k_kmer_hash, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_khash, ctx->d_khash_ovf,

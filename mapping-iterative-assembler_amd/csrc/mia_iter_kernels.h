@@ -36,7 +36,11 @@ struct RefPrep {
   int64_t plane_words; uint64_t *plo, *phi, *pok;
   int64_t nib_words; uint32_t* nib;
   uint32_t* bar; uint32_t bar_target;
+  uint32_t* stuck;        // pinned host word: set if the barrier was given up on (a part of the grid never arrived)
 };
+// the barrier's wait is bounded: a grid that is not wholly resident (device partitioned, compute units masked) must end in an error,
+// not in a wait for ever -- about a second of 64-cycle naps, a thousand times what a launch of this grid needs to arrive
+constexpr uint32_t REF_PREP_SPIN_CAP = 1u << 25;
 __global__ __launch_bounds__(256) void k_ref_prep(RefPrep a) {
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
   for (int64_t p = tid; p < a.total; p += nth)
@@ -48,7 +52,11 @@ __global__ __launch_bounds__(256) void k_ref_prep(RefPrep a) {
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(a.bar, 1u);
-    while ((int32_t)(__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.bar_target) < 0) __builtin_amdgcn_s_sleep(2);
+    uint32_t spins = 0;
+    while ((int32_t)(__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.bar_target) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins == REF_PREP_SPIN_CAP) { if (a.stuck) __hip_atomic_store(a.stuck, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
   }
   __syncthreads();
   __threadfence();

@@ -233,7 +233,8 @@ inline bool load(const char* path, Mapped* m) {
     if (m->size == 0) { close(fd); return true; }
     void* p = mmap(nullptr, m->size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (p != MAP_FAILED) {
-      (void)madvise(p, m->size, MADV_SEQUENTIAL | MADV_WILLNEED);
+      (void)madvise(p, m->size, MADV_SEQUENTIAL);      // (advice values are enumerators, not flags: one call each)
+      (void)madvise(p, m->size, MADV_WILLNEED);
       m->data = (const unsigned char*)p; m->mapped = true;
       close(fd);
       return true;

@@ -15,6 +15,8 @@
 #include <getopt.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <errno.h>
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -272,7 +274,7 @@ int main(int argc, char** argv) {
     if (T > 64) T = 64;
     std::string msgs;
     const auto ti = std::chrono::steady_clock::now();
-    if (!ingest::read_all(frag_fn.c_str(), T, &reads, &fastq, &msgs)) { fprintf(stderr, "Cannot open %s\n", frag_fn.c_str()); exit(1); }
+    if (!ingest::read_all(frag_fn.c_str(), T, &reads, &fastq, &msgs)) { fprintf(stderr, "Cannot open %s\n", frag_fn.c_str()); fflush(stderr); _exit(1); }   // (the GPU start-up thread is still running: no atexit handlers under its feet)
     fputs(msgs.c_str(), stderr);
     if (timing) {
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti).count();
@@ -669,15 +671,34 @@ int main(int argc, char** argv) {
     });
     at[0] = head.size();
     for (int t = 0; t < TF; t++) at[(size_t)t + 1] = at[(size_t)t] + sizes[(size_t)t];
-    auto put = [&](const char* p2, size_t len, size_t off) {
+    // positioned writes from all threads -- or, where the target cannot seek (a pipe, a FIFO: ESPIPE), the pieces one after the
+    // other with write(); an interrupted call (EINTR) is repeated
+    std::atomic<bool> seekable{true};
+    auto put = [&](const char* p2, size_t len, size_t off) -> bool {
       while (len) {
         const ssize_t w = pwrite(fd, p2, len, (off_t)off);
+        if (w < 0 && errno == EINTR) continue;
+        if (w < 0 && errno == ESPIPE) { seekable.store(false); return false; }
         if (w <= 0) { fprintf(stderr, "Cannot write %s\n", fn.c_str()); _exit(1); }
         p2 += w; len -= (size_t)w; off += (size_t)w;
       }
+      return true;
     };
-    put(head.data(), head.size(), 0);
-    run_parallel(TF, [&](int t) { put(text[(size_t)t].data(), text[(size_t)t].size(), at[(size_t)t]); std::string().swap(text[(size_t)t]); });
+    auto put_seq = [&](const char* p2, size_t len) {
+      while (len) {
+        const ssize_t w = write(fd, p2, len);
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) { fprintf(stderr, "Cannot write %s\n", fn.c_str()); _exit(1); }
+        p2 += w; len -= (size_t)w;
+      }
+    };
+    if (put(head.data(), head.size(), 0))
+      run_parallel(TF, [&](int t) { if (seekable.load()) put(text[(size_t)t].data(), text[(size_t)t].size(), at[(size_t)t]); });
+    if (!seekable.load()) {
+      put_seq(head.data(), head.size());
+      for (int t = 0; t < TF; t++) put_seq(text[(size_t)t].data(), text[(size_t)t].size());
+    }
+    for (int t = 0; t < TF; t++) std::string().swap(text[(size_t)t]);
     close(fd);
     lap("write .maln");
   };
