@@ -10,7 +10,8 @@ against the 16 619 bp mt311 reference, circular, flat matrix.  Pass-1 coordinate
 (pass 1 is reported separately under "pass1"); every iteration re-aligns every read in its +-50 window exactly as the
 reference does.  At N = 1 the same JSON line also carries
   "configs2"  configs[2]: 1 M aDNA-damaged reads, matrices/ancient.submat.txt, iterated from mt311 itself to convergence
-  "configs4"  configs[4]'s shape on one GPU: 150 bp reads against a 100 kb linear reference, ancient matrix
+  "configs4"  configs[4] at its size on one GPU: 5 M reads of 150 bp against a 100 kb linear reference, ancient matrix
+              ("configs4_share": 625 k of them, one GPU's share of the 8-GPU job)
   "peaks"     the two ceilings measured on this device: streaming-copy GB/s and int32 VALU wave-instructions/s
   "myers"     the bit-vector edit distance (reference src/myers_align.c) on a batch of pairs
   "cpu_baseline"  the reference's own loop (oracle/_ref/ref_iter_driver) on the host cores, flat and ancient matrix
@@ -592,7 +593,7 @@ def headline(out, extras_path):
         h["first_iteration_ms"] = out["first_iteration"]["ms"]
         h["first_iteration_over_steady"] = out["first_iteration"]["over_steady"]
     conv = {}
-    for k in ("configs2", "configs3", "configs4"):
+    for k in ("configs2", "configs3", "configs4", "configs4_share"):
         c = out.get(k)
         if c:
             conv[k] = {"reads": c.get("reads"), "iterations": c["iterations_to_convergence"], "value_to_convergence": c["reads_per_s_per_iteration"],
@@ -866,7 +867,10 @@ def main():
         if world == 1 and not a.no_extras and cfg == 1:
             out["configs2"] = section_converge(mia_amd, local, 2, 1_000_000, 3, peaks, a.no_cpu_baseline)
             out["configs3"] = section_converge(mia_amd, local, 3, 10_000_000, 4, peaks, a.no_cpu_baseline)
-            out["configs4"] = section_converge(mia_amd, local, 4, 500_000, 5, peaks, a.no_cpu_baseline)
+            # configs[4] at its size (5 M reads of 150 bp against the 100 kb region: what BASELINE.json spreads over 8 GPUs, on one), and one
+            # GPU's share of it (625 k reads: the N = 8 point of that job as far as one GPU can show it)
+            out["configs4"] = section_converge(mia_amd, local, 4, 5_000_000, 5, peaks, a.no_cpu_baseline)
+            out["configs4_share"] = section_converge(mia_amd, local, 4, 625_000, 5, peaks, True)
         extras_path = write_extras(out)
         line = json.dumps(headline(out, extras_path), separators=(",", ":"))
         assert len(line) < HEADLINE_MAX, "headline of %d bytes: the driver reads at most a few KB" % len(line)

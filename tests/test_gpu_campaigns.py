@@ -1,6 +1,7 @@
 """Fixed-seed slices of the differential campaigns (tools/band_campaign.py, tally_campaign.py, pass1_campaign.py), run by
 the driver with the rest of `-m gpu`: every shortcut of the product path against the kernels that evaluate the whole
-window / the whole strand / every base, on random and adversarial configurations, five million reads each.
+window / the whole strand / every base, on random and adversarial configurations: five million reads for the band pipeline, two million each
+for the tally and pass 1 (round 4: the time went to configs[4] at its full size, tests/test_gpu_config4_full.py).
 
 * band pipeline (plan, values DP, trace DP: csrc/bandx_body.h) against the full-window DP kernels
   (MIA_HIP_NO_DIAG_FILTER=1): flat, ancient.submat.txt and ancient.submat.solexa.pe.txt, references of plain bases and
@@ -30,19 +31,19 @@ def test_band_pipeline_against_full_window_kernels():
 
 def test_tally_paths_against_plain_tallies():
     import tally_campaign
-    total = tally_campaign.run(14, 420000, n=200_000, matrix="flat", switch="MIA_HIP_NO_LINEAR_TALLY", quiet=True)
-    total += tally_campaign.run(12, 421000, n=200_000, matrix="ancient", switch="MIA_HIP_NO_BINNED_TALLY", quiet=True)
-    assert total >= 5_000_000
+    total = tally_campaign.run(6, 420000, n=200_000, matrix="flat", switch="MIA_HIP_NO_LINEAR_TALLY", quiet=True)
+    total += tally_campaign.run(5, 421000, n=200_000, matrix="ancient", switch="MIA_HIP_NO_BINNED_TALLY", quiet=True)
+    assert total >= 2_000_000
 
 
 def test_pass1_shortcuts_against_whole_strand_dp():
     import pass1_campaign
     total = decided = 0
     for seed, nrich in ((430000, False), (431000, True)):
-        r, f, a = pass1_campaign.run(25, seed, nrich, n=100_000, quiet=True)
+        r, f, a = pass1_campaign.run(10, seed, nrich, n=100_000, quiet=True)
         total += r
         decided += f + a
-    assert total >= 5_000_000 and decided > 0.3 * total, (total, decided)
+    assert total >= 2_000_000 and decided > 0.3 * total, (total, decided)
     # position-specific matrices: the anchored windows in losses (no diagonal filter), damaged reads
     total = decided = 0
     for seed, nrich, matrix in ((432000, False, "ancient"), (433000, True, "ancient"), (434000, False, "solexa")):

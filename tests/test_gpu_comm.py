@@ -379,3 +379,76 @@ def test_mia_hip_two_threads_one_gpu(tmp_path):
         assert files
         outs.append([open(tmp_path / f).read().split("\n", 1)[1] for f in files])
     assert outs[0] == outs[1] == outs[2]
+
+
+# ---- RCCL with more than one rank: these arm themselves the day the box shows a second GPU ------------------------------------
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    except Exception:                             # noqa: BLE001
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the loopback tests above run W > 1 on one)")
+def test_rccl_two_ranks():
+    """The library's sharded iteration over its RCCL table with two ranks, one context per GPU, one host thread per rank
+    (ncclCommInitRank from a shared id): every iteration's consensus, per-read results and reduced tallies against one
+    context that holds all reads -- the same comparison as the loopback tests, over xGMI.  VERDICT r03 item 6(b)."""
+    import gen_data
+    import mia_amd
+    from conftest import GOLDEN
+    _, _, mt = gen_data.read_fasta_one(os.path.join(GOLDEN, "mt311.fa"))
+    indiv = gen_data.resolve_individual(mt)
+    n, L, W = 60_000, 100, 2
+    d = gen_data.make_reads(indiv, n, L, seed=29, circular=True, indel_rate=0.004)
+    stored = gen_data.stored_orientation(d)
+    rc, as_ = d["strand"].astype(np.uint8), d["start"].astype(np.int32)
+    ae = (as_ + L - 1).astype(np.int32)
+
+    def ctx(dev, lo, hi):
+        h = mia_amd.MiaHip(dev)
+        h.set_pssm(mia_amd.flat_pssm())
+        h.upload_reads(stored[lo:hi].reshape(-1), np.arange(hi - lo + 1, dtype=np.int64) * L, rc[lo:hi], np.ones(hi - lo, np.uint8), as_[lo:hi], ae[lo:hi])
+        h.set_read_base(lo)
+        return h
+    whole = ctx(0, 0, n)
+    cuts = [0, 27_001, n]
+    parts = [ctx(k, cuts[k], cuts[k + 1]) for k in range(W)]
+    uid = mia_amd.comm_unique_id()
+    _, err = run_ranks([lambda h=h, k=k: h.comm_init(uid, W, k) for k, h in enumerate(parts)])
+    assert err == [None] * W, err
+    for k, h in enumerate(parts):
+        assert h.comm_info() == (W, k, "rccl")
+    ref = mt.upper()
+    for it in range(1, 7):
+        cw = whole.iterate(ref, True)
+        cons, err = run_ranks([lambda h=h: h.iterate(ref, True) for h in parts])
+        assert err == [None] * W, (it, err)
+        assert all(c == cw for c in cons), it
+        compare_ranks(whole, parts, it)
+        if cw == ref:
+            break
+        ref = cw
+    for h in parts:
+        h.comm_destroy()
+    for h in parts + [whole]:
+        h.close()
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs")
+def test_mia_hip_two_gpus(tmp_path):
+    """`mia_hip -g 0,1` (RCCL between two GPUs) against `-g 0`, byte for byte"""
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "mapping-iterative-assembler_amd", "mia_hip")
+    outs = []
+    for tag, g in (("one", "0"), ("two", "0,1")):
+        root = str(tmp_path / tag)
+        cmd = [exe, "-r", os.path.join(GOLDEN, "mt311.fa"), "-f", os.path.join(GOLDEN, "adapt.fa"), "-c", "-i", "-k", "12", "-T", "-a", ADAPTER,
+               "-s", os.path.join(GOLDEN, "ancient.submat.txt"), "-m", root, "-g", g]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        files = sorted(f for f in os.listdir(tmp_path) if f.startswith(tag + "."))
+        assert files
+        outs.append([open(tmp_path / f).read().split("\n", 1)[1] for f in files])
+    assert outs[0] == outs[1]

@@ -1,0 +1,149 @@
+"""BASELINE.json configs[4] AT ITS SIZE on one GPU: 5 M aDNA-damaged 150 bp reads against the 100 kb synthetic region (seed 5,
+linear: no -c), matrices/ancient.submat.txt -- 3 GB of read store in HBM (tests/test_gpu_config4.py
+holds the 400 k-read share with pass 1 and the plain-atomic tally; the windows are 250 columns wide,
+/root/reference/src/mia_main.c:190-217).  Pass-1 coordinates are the generator's true positions, as in bench.py.  The
+reference's own loop cannot hold this many reads (5.4 KB of host memory per AlnSeq), hence samples and size-independent
+properties:
+
+* two iterations from the region (one call each, mia_hip_iterate); 4 000 sampled reads through both realignments against the
+  oracle read by read;
+* a 500 k-read slice with every shortcut off (full-window DP kernels only): same score, end points and script;
+* the 8-GPU decomposition of north_star -- eight contiguous shards of 625 k reads, eight contexts on eight host threads
+  joined by the library's loopback transport, mia_hip_iterate's own sharded path: every rank returns the single context's
+  consensus in both iterations, the concatenated per-read results and the reduced tallies are identical;
+* the consensus is a fixed point after a few more rounds.
+MIA_CONFIG4_FULL_READS overrides the read count."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import gen_data
+from conftest import GOLDEN
+from oracle_sample import PushedOracle
+
+pytestmark = pytest.mark.gpu
+
+N = int(os.environ.get("MIA_CONFIG4_FULL_READS", "5000000"))
+SPEC = "ancient.submat.txt"
+L = 150
+
+
+class Full:
+    pass
+
+
+def upload(mod, f, lo, hi, as_, ae, env=None):
+    if env:
+        os.environ[env] = "1"
+    try:
+        hip = mod.MiaHip(0)
+    finally:
+        if env:
+            os.environ.pop(env, None)
+    hip.set_pssm(f.pssm)
+    hip.upload_reads(f.stored[lo:hi].reshape(-1), np.arange(hi - lo + 1, dtype=np.int64) * L, f.rc[lo:hi], np.ones(hi - lo, np.uint8), as_[lo:hi], ae[lo:hi])
+    hip.set_read_base(lo)
+    return hip
+
+
+@pytest.fixture(scope="module")
+def full():
+    import mia_amd
+    f = Full()
+    f.mod = mia_amd
+    f.pssm = mia_amd.read_pssm(os.path.join(GOLDEN, SPEC))
+    f.ref = gen_data.random_reference(100_000, seed=5)
+    d = gen_data.make_reads_chunked(f.ref, N, L, 5, circular=False, damage=True) if N > 2_000_000 else gen_data.make_reads(f.ref, N, L, 5, circular=False, damage=True)
+    f.stored = gen_data.stored_orientation(d)
+    f.rc = d["strand"].astype(np.uint8)
+    f.as0 = d["start"].astype(np.int32)
+    f.ae0 = (f.as0 + L - 1).astype(np.int32)
+    hip = upload(mia_amd, f, 0, N, f.as0, f.ae0)
+    f.cons1 = hip.iterate(f.ref, False)
+    f.al1 = hip.alignments()
+    f.cons2 = hip.iterate(f.cons1, False)
+    f.al2 = hip.alignments()
+    f.tally2, f.gaps2 = hip.get_tally()
+    f.hip = hip
+    yield f
+    hip.close()
+
+
+def test_sample_against_oracle(full, oracle):
+    f = full
+    pick = np.sort(np.random.default_rng(43).choice(N, min(4_000, N), replace=False))
+    po = PushedOracle(oracle, f.ref, False, SPEC, f.stored[pick], f.rc[pick], f.as0[pick], f.ae0[pick])
+    for it, (ref, al) in enumerate(((f.ref, f.al1), (f.cons1, f.al2)), 1):
+        po.iterate(ref)
+        o = po.alignments()
+        for k in range(3):
+            bad = np.nonzero(al[k][pick] != o[k])[0]
+            assert len(bad) == 0, (it, k, len(bad), pick[bad[:5]].tolist())
+    po.close()
+
+
+def test_shortcuts_change_nothing_on_a_slice(full):
+    f = full
+    m = min(500_000, N)
+    hip = upload(f.mod, f, 0, m, f.al1[1], f.al1[2], env="MIA_HIP_NO_DIAG_FILTER")
+    hip.realign(f.cons1, False)
+    assert sum(hip.bx_stats()[0]) == 0
+    for x, y in zip(hip.alignments(), f.al2):
+        assert np.array_equal(x, y[:m])
+    cols, rstart = hip.scripts()
+    hip.close()
+    own = upload(f.mod, f, 0, m, f.al1[1], f.al1[2])
+    own.realign(f.cons1, False)
+    c2, r2 = own.scripts()
+    own.close()
+    absolute = lambda c, r: np.where(c >= 0, c.astype(np.int32) + r[:, None], c.astype(np.int32))   # noqa: E731
+    assert np.array_equal(absolute(cols, rstart), absolute(c2, r2))
+
+
+def test_eight_shards_through_the_library(full):
+    """north_star's partition of configs[4]: contiguous fsdb blocks of 625 k reads on 8 ranks, tallies all-reduced before each consensus call"""
+    f = full
+    W = 8
+    cuts = [N * k // W for k in range(W + 1)]
+    parts = [upload(f.mod, f, cuts[k], cuts[k + 1], f.as0, f.ae0) for k in range(W)]
+    grp = f.mod.LoopbackGroup(W)
+    for k, h in enumerate(parts):
+        grp.attach(h, k)
+    for it, (ref, want_cons, want_al) in enumerate(((f.ref, f.cons1, f.al1), (f.cons1, f.cons2, f.al2)), 1):
+        out, err = [None] * W, [None] * W
+
+        def work(r):
+            try:
+                out[r] = parts[r].iterate(ref, False)
+            except BaseException as e:    # noqa: BLE001
+                err[r] = e
+        th = [threading.Thread(target=work, args=(r,)) for r in range(W)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert err == [None] * W, (it, err)
+        assert all(c == want_cons for c in out), it
+        for k in range(3):
+            assert np.array_equal(np.concatenate([h.alignments()[k] for h in parts]), want_al[k]), (it, k)
+    for h in parts:                                  # every rank holds the reduced tallies of the whole job
+        t, g = h.get_tally()
+        assert np.array_equal(t, f.tally2) and np.array_equal(g, f.gaps2)
+    for h in parts:
+        h.comm_destroy()
+    grp.close()
+    for h in parts:
+        h.close()
+
+
+def test_fixed_point(full):
+    f = full
+    ref, cons, rounds = f.cons1, f.cons2, 0
+    while cons != ref and rounds < 8:
+        ref = cons
+        cons = f.hip.iterate(ref, False)
+        rounds += 1
+    assert cons == ref, rounds
+    assert abs(len(cons) - len(f.ref)) < 100
