@@ -1085,12 +1085,15 @@ static int align_all(mia_hip_ctx* ctx) {
       bd.cand = nullptr; bd.cand_n = ctx->d_bx_ctr + (size_t)BXC_CAND * BXC_STRIDE;
       bd.cand2 = nullptr; bd.cand2_n = ctx->d_bx_ctr + (size_t)BXC_CAND2 * BXC_STRIDE;
       // a third launch for the reads whose loss exceeds what the 10-mers vouch for (bx_fine_anchors; MIA_HIP_NO_FINE=1: given up as before)
-      // ... when the plan gives up on many reads: against a reference full of ambiguity codes (every run's first iteration), or when
-      // it did so in the iteration before.  Otherwise the launch would sit on the step's critical path (~50 us) for the sake of reads
-      // whose full-window kernels run beside the band DPs anyway.
+      // ... with a position-specific matrix (two reads in a hundred exceed the 10-mers' budget in every iteration, and the full-window
+      // kernels they went to were the largest consumer of vector instructions at 10 M reads: configs[3] 8.47 -> 7.44 ms, configs[2]
+      // 1.41 -> 1.35 ms), with many reads (the launch costs next to nothing where the step is bound by throughput), and whenever
+      // the plan gives up on many reads: against a reference full of ambiguity codes (every run's first iteration), or when it did so
+      // in the iteration before.  With the flat matrix and a million reads the launch would sit on the step's critical path (~55 us)
+      // for the sake of a few thousand reads whose full-window kernels run beside the band DPs anyway.
       int64_t rejects_before = 0;
       for (int k = 1; k < BXF_KINDS; k++) rejects_before += ctx->bx_last[BXC_FAIL0 + k];
-      const bool fine = split && ctx->use_fine && (ctx->use_fine > 1 || !ctx->ref_mostly_bases || rejects_before * 20 > n);
+      const bool fine = split && ctx->use_fine && (ctx->use_fine > 1 || !ctx->flat || n >= 4000000 || !ctx->ref_mostly_bases || rejects_before * 20 > n);
       if (split) {
         if (n > ctx->cand_cap) {
           if (dev_alloc(ctx, &ctx->d_bx_cand, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_cand2, (size_t)n)) return MIA_HIP_ERR_NOMEM;
