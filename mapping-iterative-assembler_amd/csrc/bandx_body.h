@@ -390,7 +390,9 @@ struct BxPlan { int mode, d0, w, dstar, b0, edge; };
 enum { BXF_READ = 1, BXF_WINDOW, BXF_BLOCKS, BXF_SPAN, BXF_PATH, BXF_BUDGET, BXF_WIDTH, BXF_KINDS };
 
 // the anchors of a read and what they imply, before any loss is summed
-struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_out, s_un, r_head, r_tail, rescue, fine; };
+struct BxAnchors { int fail, a_lo, a_hi, d_first, d_last, budget, t_lo, t_hi, l_out, s_un, r_head, r_tail, rescue, fine, fc1, fc2, fmax; };
+// fine blocks only: fc1 / fc2 = diagonals outside the kept range on which at least one / two blocks are clean (fc2 < 0: some diagonal
+// holds three or more, or the window is too wide to tell); fmax = the dearest block
 // r_head: first row of the first block with a kept anchor; r_tail: first row behind the last such block; rescue: bx_rescue is to be tried   // l_out < 0: every anchor counts; s_un: dl of the blocks that occur nowhere in the window
 
 // Where the read's blocks occur inside the window.  sc holds the read's planes.
@@ -494,6 +496,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
   if (d_first < 0 || d_first > len1 - len2 || d_last < 0 || d_last > len1 - len2) { an->fail = BXF_PATH; return; }
   an->a_lo = a_lo; an->a_hi = a_hi; an->d_first = d_first; an->d_last = d_last; an->budget = budget; an->l_out = l_out; an->s_un = s_un;
   an->r_head = bx_block_row(b_lo_any, len2, nb_cut); an->r_tail = bx_block_row(b_hi_any, len2, nb_cut) + DF_K; an->rescue = 0; an->fine = 0;
+  an->fc1 = 0; an->fc2 = 0; an->fmax = 0;
   an->t_lo = 1; an->t_hi = R;
   if (d_first != d_last) {
     // the switch row is looked for between the last block anchored on d_first and the first one after it anchored on d_last
@@ -794,9 +797,12 @@ MIA_HD inline void bx_win_planes(const RefPlanes& rp, int s, int len1, BxWinPlan
 }
 // blocks b0, b0 + step, ... of the read in sc: bit b of *in / *out = block b is clean somewhere on the kept diagonals k_lo .. k_hi /
 // somewhere else in the window; *a_lo / *a_hi take in the kept diagonals that hold a clean block
+constexpr int BX_FDW = 8;               // words of the per-diagonal counters: diagonals -(len2 - 6) .. len1 - 6, at most 512 of them
+// ge[0..BX_FDW) / ge[BX_FDW..2 BX_FDW) / ge[2 BX_FDW..3 BX_FDW): diagonals outside the kept range on which at least one / two / three of
+// the blocks seen so far are clean (bit d + len2 - BX_FQ); nullptr: not kept
 template <int NW>
 MIA_HD inline void bx_fine_scan(const DiagScan<NW>& sc, const BxWinPlanes& wp, int len1, int len2, int k_lo, int k_hi, int b0, int step,
-                                uint64_t* in, uint64_t* out, int* a_lo, int* a_hi) {
+                                uint64_t* in, uint64_t* out, int* a_lo, int* a_hi, uint64_t* ge = nullptr) {
   const int nbq = bx_fine_blocks_of(len2);
   for (int b = b0; b < nbq; b += step) {
     const int o = bx_fine_block_row(b, len2, nbq);
@@ -829,6 +835,7 @@ MIA_HD inline void bx_fine_scan(const DiagScan<NW>& sc, const BxWinPlanes& wp, i
         if (hi < 64) R &= (1ull << hi) - 1ull;
       }
       const uint64_t ai = A[w] & R, ao = A[w] & ~R;
+      A[w] = ao;                                          // (from here on: the clean places outside the kept range)
       if (ai) {
         is_in = true;
         const int f = 64 * w + df_ctz(ai), l = 64 * w + 63 - df_clz(ai);
@@ -843,22 +850,50 @@ MIA_HD inline void bx_fine_scan(const DiagScan<NW>& sc, const BxWinPlanes& wp, i
       if (last - o > *a_hi) *a_hi = last - o;
     }
     if (is_out) *out |= 1ull << b;
+    if (ge && is_out) {
+      // the block's outside places by DIAGONAL (column p is diagonal p - o: bit p + len2 - BX_FQ - o), added to the saturating
+      // per-diagonal counters: first the bit shift, then the shift by whole words
+      const int sh = len2 - BX_FQ - o, bs = sh & 63, ws = sh >> 6;
+      uint64_t S[BX_FWW + 1];
+#pragma unroll
+      for (int w = 0; w <= BX_FWW; w++) {
+        const uint64_t lo = w < BX_FWW ? A[w] : 0ull, below = w > 0 ? A[w - 1] : 0ull;
+        S[w] = (lo << bs) | (bs ? below >> (64 - bs) : 0ull);
+      }
+#pragma unroll
+      for (int dw = 0; dw < BX_FDW; dw++) {
+        uint64_t D = 0;
+#pragma unroll
+        for (int w = 0; w <= BX_FWW; w++) if (dw - ws == w) D = S[w];
+        const uint64_t c1 = ge[dw] & D, c2 = ge[BX_FDW + dw] & c1;
+        ge[dw] |= D; ge[BX_FDW + dw] |= c1; ge[2 * BX_FDW + dw] |= c2;
+      }
+    }
   }
 }
 template <int NW>
-MIA_HD inline void bx_fine_sums(uint64_t in, uint64_t out, int a_lo, int a_hi, int len2, int st, const BxTab& T, BxAnchors* an) {
+MIA_HD inline void bx_fine_sums(uint64_t in, uint64_t out, int a_lo, int a_hi, int len2, int st, const BxTab& T, BxAnchors* an, const uint64_t* ge = nullptr) {
   const int nbq = bx_fine_blocks_of(len2);
-  int budget = -1, l_out = 0, s_un = 0;
+  int budget = -1, l_out = 0, s_un = 0, fmax = 0;
+  an->fc1 = 0; an->fc2 = -1;
+  if (ge) {
+    int c1 = 0, c2 = 0;
+    bool three = false;
+#pragma unroll
+    for (int dw = 0; dw < BX_FDW; dw++) { c1 += df_popc(ge[dw]); c2 += df_popc(ge[BX_FDW + dw]); three = three || ge[2 * BX_FDW + dw] != 0; }
+    an->fc1 = c1; an->fc2 = three ? -1 : c2;
+  }
   for (int b = 0; b < nbq; b++) {
     const int o = bx_fine_block_row(b, len2, nbq);
     int v = 1 << 20;
     for (int r = o; r < o + BX_FQ; r++) { const int f = T.loss[BX_LOSS_FDL + st * 31 + sm_depth(r, len2)]; if (f < v) v = f; }
     const int is_in = (int)((in >> b) & 1ull), is_out = (int)((out >> b) & 1ull);
     budget += v;
+    if (v > fmax) fmax = v;
     if (!is_out) l_out += v;
     if (!is_in && !is_out) s_un += v;
   }
-  an->budget = budget; an->l_out = l_out; an->s_un = s_un; an->a_lo = a_lo; an->a_hi = a_hi; an->fine = 1;
+  an->budget = budget; an->l_out = l_out; an->s_un = s_un; an->a_lo = a_lo; an->a_hi = a_hi; an->fine = 1; an->fmax = fmax;
 }
 template <int NW>
 MIA_HD inline bool bx_fine_anchors(DiagScan<NW>& sc, const RefPlanes& rp, int s, int len1, int len2, int st, const BxTab& T, BxAnchors* an) {
@@ -867,8 +902,12 @@ MIA_HD inline bool bx_fine_anchors(DiagScan<NW>& sc, const RefPlanes& rp, int s,
   bx_win_planes(rp, s, len1, &wp);
   uint64_t in = 0, out = 0;
   int a_lo = an->a_lo, a_hi = an->a_hi;
-  bx_fine_scan<NW>(sc, wp, len1, len2, an->a_lo - BX_FINE_RADIUS, an->a_hi + BX_FINE_RADIUS, 0, 1, &in, &out, &a_lo, &a_hi);
-  bx_fine_sums<NW>(in, out, a_lo, a_hi, len2, st, T, an);
+  uint64_t ge[3 * BX_FDW];
+#pragma unroll
+  for (int k = 0; k < 3 * BX_FDW; k++) ge[k] = 0;
+  const bool counted = len1 + len2 <= 64 * BX_FDW;
+  bx_fine_scan<NW>(sc, wp, len1, len2, an->a_lo - BX_FINE_RADIUS, an->a_hi + BX_FINE_RADIUS, 0, 1, &in, &out, &a_lo, &a_hi, counted ? ge : nullptr);
+  bx_fine_sums<NW>(in, out, a_lo, a_hi, len2, st, T, an, counted ? ge : nullptr);
   return true;
 }
 
@@ -876,6 +915,9 @@ MIA_HD inline bool bx_fine_anchors(DiagScan<NW>& sc, const RefPlanes& rp, int s,
 template <int NW>
 MIA_HD inline uint64_t bx_loss_rows(const DiagScan<NW>& sc, int j) { return sc.mis(j) | (~sc.cok[j] & sc.rows[j]); }
 
+#ifdef BX_DIAG
+static int bx_diag[8];       // (tests / tools only: what the last bx_finish saw)
+#endif
 // B0 (the loss of one valid path) and what follows from it
 // PATHS: 0 = whatever the anchors say, 1 = the caller knows d_first == d_last, 2 = the caller knows they differ
 template <int NW, int PATHS = 0>
@@ -929,8 +971,26 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
       if (nm > 0) ncredit = nm < BX_NCRED_K ? cum[nm] : cum[BX_NCRED_K - 1] + (nm - (BX_NCRED_K - 1)) * (cum[BX_NCRED_K - 1] - cum[BX_NCRED_K - 2]);
     }
   }
+#ifdef BX_DIAG
+  bx_diag[0] = b0x; bx_diag[1] = an.budget; bx_diag[2] = an.l_out; bx_diag[3] = ncredit; bx_diag[4] = an.fine; bx_diag[5] = an.s_un; bx_diag[6] = an.a_hi - an.a_lo;
+#endif
   if (b0x > an.budget + ncredit) return;
-  if (an.l_out >= 0 && an.l_out + ncredit <= b0x) { out->b0 = BXF_SPAN; return; }      // some anchors were set aside: see bx_anchors
+  // Anchors were set aside (bx_anchors, bx_fine_anchors): a path that crosses none of the kept ones cleanly must lose more than B0.
+  // l_out charges it every block that is clean nowhere outside the kept range.  Six-mers are clean somewhere by chance -- against a
+  // reference with an N in every tenth column half the blocks are, and l_out collapsed -- but a path does not get to USE them all:
+  // it has at most J = B0 / (GOP + GEP) events (each costs that much), so its rows lie on at most J + 1 diagonals, and the blocks it
+  // crosses cleanly are clean on one of those: at most the J + 1 largest per-diagonal counts together (fc2 diagonals hold two, fc1
+  // hold one or more, none holds three).  Every other block is broken -- by a row that is no match (fdl_b) or by an event, which
+  // pays for the blocks it touches (the netting of the stray tables).
+  int l_out = an.l_out;
+  if (an.fine && l_out >= 0 && an.fc2 >= 0) {
+    const int m = b0x / (GOP + GEP) + 1;
+    const int two = m < an.fc2 ? m : an.fc2, rest = m - two, ones = an.fc1 - an.fc2;
+    const int t = 2 * two + (rest < ones ? rest : ones);
+    const int alt = an.budget + 1 - an.fmax * t;
+    if (alt > l_out) l_out = alt;
+  }
+  if (l_out >= 0 && l_out + ncredit <= b0x) { out->b0 = BXF_SPAN; return; }
   // how far a path that loses no more than b0 can stray from the anchors: all of b0 spent on one gap (band_body.h) --
   // or, tighter, what is left of b0 once every block that occurs nowhere in the window has been paid for (an.s_un: such
   // a block costs dl wherever it is crossed, unless a gap of the path itself breaks it -- the stray tables are net of

@@ -387,11 +387,15 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
         const bool usable = bx_fine_usable<NW>(r.l1, r.len2, r.st, T);
         uint64_t in = 0, out = 0;
         int a_lo = an.a_lo, a_hi = an.a_hi;
+        uint64_t ge[3 * BX_FDW];
+#pragma unroll
+        for (int q = 0; q < 3 * BX_FDW; q++) ge[q] = 0;
+        const bool counted = BX_FINE_LANES == 1 && r.l1 + r.len2 <= 64 * BX_FDW;      // (per-diagonal counts: one lane sees all blocks)
         if (usable) {
           // this lane's share of the blocks (u, u + BX_FINE_LANES, ...) against the window's column planes
           BxWinPlanes wp;
           bx_win_planes(rp, r.s, r.l1, &wp);
-          bx_fine_scan<NW>(sc, wp, r.l1, r.len2, an.a_lo - BX_FINE_RADIUS, an.a_hi + BX_FINE_RADIUS, u, BX_FINE_LANES, &in, &out, &a_lo, &a_hi);
+          bx_fine_scan<NW>(sc, wp, r.l1, r.len2, an.a_lo - BX_FINE_RADIUS, an.a_hi + BX_FINE_RADIUS, u, BX_FINE_LANES, &in, &out, &a_lo, &a_hi, counted ? ge : nullptr);
         }
         // (all lanes of a read are here together: `mine`, the record and `usable` are the same for them)
 #pragma unroll
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
         }
         if (u == 0) {
           if (usable) {
-            bx_fine_sums<NW>(in, out, a_lo, a_hi, r.len2, r.st, T, &an);
+            bx_fine_sums<NW>(in, out, a_lo, a_hi, r.len2, r.st, T, &an, counted ? ge : nullptr);
             bx_finish<NW>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
           }
           if (bp.mode == BX_NONE && bp.b0 != BXF_WIDTH) bp.b0 = why;

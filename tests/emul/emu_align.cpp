@@ -296,6 +296,7 @@ extern "C" int emu_band(const uint8_t* ref_codes, int64_t n_codes, int ref_start
 //   opts >> 4 : widen the band class (0..3 classes up)
 // Returns the plan's mode (0 = not planned), negated if the stages disagree among themselves; out6 = score, abc, aec,
 // abr, gaps, how the read was finished (1 plan, 2 values, 3 trace, 0 not finished); plan5 = d0, w, dstar, b0, edge.
+#define BX_DIAG 1
 #include "bandx_body.h"
 template <int W>
 static int emu_bandx_w(const uint32_t* nib, int s, int len1, const uint32_t* rw, int len2, const mia::BxPlan& bp, bool edge, const int32_t* sub,
@@ -421,3 +422,5 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
   out6[5] = how;
   return bp.mode;
 }
+
+extern "C" void emu_bandx_diag(int32_t* out8) { for (int k = 0; k < 8; k++) out8[k] = mia::bx_diag[k]; }

@@ -12,7 +12,8 @@ import bench  # noqa: E402
 import mia_amd  # noqa: E402
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-w = bench.make_workload(cfg, 1_000_000, 1 if cfg == 1 else 3)
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+w = bench.make_workload(cfg, n_reads, 1 if cfg == 1 else 3)
 hip = mia_amd.MiaHip(0)
 pipe = bench.Pipeline(hip, w)
 import time

@@ -3,7 +3,7 @@ set -e
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/tl; mkdir -p $O
 c=$1; reads=$2; tag=$3
 if [ "$4" = first ]; then
-  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/$tag -o p -- python3 $R/tools/first_iter_probe.py $c > $O/$tag.txt 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/$tag -o p -- python3 $R/tools/first_iter_probe.py $c $reads > $O/$tag.txt 2>&1
 else
   timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/$tag -o p -- python3 $R/bench.py --config $c --reads $reads --no-extras --no-cpu-baseline --steps 10 --warmup 3 > $O/$tag.json 2> $O/$tag.err
 fi
