@@ -136,6 +136,18 @@ struct Frag {
   int trimmed = 0;             // adapter found by trim_frag: seq is already cut at the trim point (src/fsdb.c:199-203)
 };
 
+// a buffer that is written before it is read: no zero fill (std::vector value-initialises, a page fault per 4 KB at first touch)
+template <class T>
+struct HostBuf {
+  T* p = nullptr; size_t n = 0;
+  explicit HostBuf(size_t count) : p((T*)malloc(count * sizeof(T) + 64)), n(count) { if (!p) { fprintf(stderr, "mia_hip: out of memory\n"); _exit(1); } }
+  HostBuf(const HostBuf&) = delete; HostBuf& operator=(const HostBuf&) = delete;
+  ~HostBuf() { free(p); }
+  T* data() { return p; } const T* data() const { return p; }
+  size_t bytes() const { return n * sizeof(T); }
+  T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
+};
+
 template <class F>
 void run_parallel(int T, F&& fn) {
   if (T <= 1) { fn(0); return; }
@@ -343,21 +355,24 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> slot_dropped;   // pass-1 slots, merge order
   std::vector<int> first_slot, n_slots;
   int n_unknown = 0;
-  for (int64_t k = 0; k < n1; k++) {
-    if (!(p_fl[k] & MIA_HIP_P1_KEPT)) continue;
-    Read& r = reads[src[(size_t)k]];      // each input read is looked at once: move its strings into the store
-    Frag f;
-    f.id = std::move(r.id); f.desc = std::move(r.desc); f.seq = std::move(r.seq); f.trimmed = r.trimmed;
-    f.rc = p_rc[k]; f.strand_known = (p_fl[k] & MIA_HIP_P1_STRAND_KNOWN) ? 1 : 0;
-    f.as = p_as[k]; f.ae = p_ae[k]; f.score = p_score[k];
-    if (!f.strand_known) n_unknown++;
-    first_slot.push_back((int)slot_dropped.size());
-    slot_dropped.push_back(0);
-    if (p_fl[k] & MIA_HIP_P1_SPLIT) slot_dropped.push_back(0);
-    n_slots.push_back((p_fl[k] & MIA_HIP_P1_SPLIT) ? 2 : 1);
-    fsdb.push_back(std::move(f));
+  // (which reads were kept and where their slots start: one cheap pass; the strings are moved into the store by all threads)
+  std::vector<int64_t> kept_k;
+  kept_k.reserve((size_t)n1);
+  {
+    int slots = 0;
+    for (int64_t k = 0; k < n1; k++) {
+      if (!(p_fl[k] & MIA_HIP_P1_KEPT)) continue;
+      kept_k.push_back(k);
+      first_slot.push_back(slots);
+      const int ns = (p_fl[k] & MIA_HIP_P1_SPLIT) ? 2 : 1;
+      n_slots.push_back(ns);
+      slots += ns;
+      if (!(p_fl[k] & MIA_HIP_P1_STRAND_KNOWN)) n_unknown++;
+    }
+    slot_dropped.assign((size_t)slots, 0);
   }
-  const int n = (int)fsdb.size();
+  const int n = (int)kept_k.size();
+  fsdb.resize((size_t)n);
   {
     // reverse-strand reads are kept reverse-complemented from here on (add_virgin_fs2fsdb, src/fsdb.c:209-227)
     int T = (int)std::thread::hardware_concurrency();
@@ -365,7 +380,12 @@ int main(int argc, char** argv) {
     T = std::max(1, std::min(std::min(T, 64), n / 8192 + 1));
     run_parallel(T, [&](int t) {
       for (int i = (int)((int64_t)n * t / T), hi = (int)((int64_t)n * (t + 1) / T); i < hi; i++) {
+        const int64_t k = kept_k[(size_t)i];
+        Read& r = reads[src[(size_t)k]];      // each input read is looked at once: move its strings into the store
         Frag& f = fsdb[(size_t)i];
+        f.id = std::move(r.id); f.desc = std::move(r.desc); f.seq = std::move(r.seq); f.trimmed = r.trimmed;
+        f.rc = p_rc[k]; f.strand_known = (p_fl[k] & MIA_HIP_P1_STRAND_KNOWN) ? 1 : 0;
+        f.as = p_as[k]; f.ae = p_ae[k]; f.score = p_score[k];
         if (f.rc && f.strand_known) {
           std::reverse(f.seq.begin(), f.seq.end());
           for (auto& ch : f.seq) ch = revcom_char(ch);
@@ -417,11 +437,19 @@ int main(int argc, char** argv) {
     on_gpus([&](int k) {
       const int lo = lo_of[(size_t)k], hi = lo_of[(size_t)k + 1], m = hi - lo;
       std::vector<int64_t> o2((size_t)m + 1, 0);
-      std::string b2;
       std::vector<uint8_t> rc((size_t)m), sk((size_t)m);
-      for (int i = lo; i < hi; i++) {
-        b2 += fsdb[i].seq; o2[(size_t)(i - lo) + 1] = (int64_t)b2.size();
-        rc[(size_t)(i - lo)] = (uint8_t)fsdb[i].rc; sk[(size_t)(i - lo)] = (uint8_t)fsdb[i].strand_known;
+      for (int i = lo; i < hi; i++) o2[(size_t)(i - lo) + 1] = o2[(size_t)(i - lo)] + (int64_t)fsdb[i].seq.size();
+      HostBuf<char> b2((size_t)o2[(size_t)m] + 1);
+      {
+        int T = (int)std::thread::hardware_concurrency();
+        if (const char* e = getenv("MIA_HIP_THREADS")) T = atoi(e);
+        T = std::max(1, std::min(std::min(T, 64) / NG, m / 8192 + 1));
+        run_parallel(T, [&](int t) {
+          for (int i = lo + (int)((int64_t)m * t / T), e2 = lo + (int)((int64_t)m * (t + 1) / T); i < e2; i++) {
+            memcpy(b2.data() + o2[(size_t)(i - lo)], fsdb[i].seq.data(), fsdb[i].seq.size());
+            rc[(size_t)(i - lo)] = (uint8_t)fsdb[i].rc; sk[(size_t)(i - lo)] = (uint8_t)fsdb[i].strand_known;
+          }
+        });
       }
       mia_hip_ctx* c = G[(size_t)k];
       if (mia_hip_upload_reads(c, m, b2.data(), o2.data(), rc.data(), sk.data(), as.data() + lo, ae.data() + lo) != MIA_HIP_OK) die(c, "upload_reads");
@@ -453,12 +481,28 @@ int main(int argc, char** argv) {
   std::string ref_id = ref.id, ref_desc = ref.desc;
   int stride = 4;                        // columns of the script table: longest stored read, rounded up
   for (int i = 0; i < n; i++) stride = std::max(stride, (len[i] + 3) & ~3);
-  std::vector<int16_t> cols((size_t)n * stride);
-  std::vector<int32_t> rstart((size_t)n), gaps;
-  std::vector<uint8_t> dF((size_t)n), dB((size_t)n);
-  std::vector<int32_t> rparams((size_t)n * 8);
-  std::vector<int64_t> back_slot((size_t)n);
+  // what comes back from the device for the .maln writer: 230 bytes per read.  Plain allocations (every byte is written by a copy
+  // before it is read) whose pages are touched here by all host threads at once -- a zero-filled std::vector of 200 MB, faulted
+  // in page by page by the first copy from the device, was 80 ms in front of the first iteration
+  HostBuf<int16_t> cols((size_t)n * stride);
+  HostBuf<int32_t> rstart((size_t)n), rparams((size_t)n * 8);
+  HostBuf<uint8_t> dF((size_t)n), dB((size_t)n);
+  HostBuf<int64_t> back_slot((size_t)n);
+  std::vector<int32_t> gaps;
+  {
+    int T = (int)std::thread::hardware_concurrency();
+    if (const char* e = getenv("MIA_HIP_THREADS")) T = atoi(e);
+    T = std::max(1, std::min(T, 64));
+    struct Span { char* p; size_t bytes; };
+    const Span spans[] = {{(char*)cols.data(), cols.bytes()}, {(char*)rstart.data(), rstart.bytes()}, {(char*)rparams.data(), rparams.bytes()},
+                          {(char*)dF.data(), dF.bytes()}, {(char*)dB.data(), dB.bytes()}, {(char*)back_slot.data(), back_slot.bytes()}};
+    run_parallel(T, [&](int t) {
+      for (const Span& sp : spans)
+        for (size_t o = sp.bytes * (size_t)t / (size_t)T & ~(size_t)4095, hi = sp.bytes * (size_t)(t + 1) / (size_t)T; o < hi; o += 4096) sp.p[o] = 0;
+    });
+  }
 
+  lap("host buffers");
   std::string next_cons;     // consensus_assembly_string of the iteration just run
   auto iteration = [&](int iter_num) {
     // reiterate_assembly + cull_maln_from_fsdb + consensus_assembly_string (src/mia_main.c:24-280, 931-963) as one call per
@@ -472,6 +516,7 @@ int main(int argc, char** argv) {
       if (mia_hip_iterate(G[(size_t)k], cons.c_str(), (int32_t)cons.size(), circular, hard_cut, score_cut_set ? sn : nullptr, cc, &out[0], (int64_t)out.size(),
                           &clen) != MIA_HIP_OK) die(G[(size_t)k], "iterate");
       out.resize((size_t)clen);
+      if (k == 0) lap("    mia_hip_iterate");
       const int lo = lo_of[(size_t)k];
       if (mia_hip_get_alignments(G[(size_t)k], score.data() + lo, as.data() + lo, ae.data() + lo) != MIA_HIP_OK) die(G[(size_t)k], "get_alignments");
     });
@@ -726,7 +771,9 @@ int main(int argc, char** argv) {
   }
   now = time(NULL);
   fprintf(stderr, "Assembly finished at %s\n", asctime(localtime(&now)));
-  for (auto* c : G) mia_hip_destroy(c);
+  // (one context: the process ends here and the driver takes the device memory back with it -- handing every buffer back one by one
+  // first was 30-40 ms; several contexts leave their communicator in an orderly way)
+  if (NG > 1) for (auto* c : G) mia_hip_destroy(c);
   // every file is closed; the read store's millions of small strings need not be handed back one by one
   fflush(stdout); fflush(stderr);
   _exit(0);
