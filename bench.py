@@ -468,6 +468,13 @@ def section_myers(hip, no_cpu=False):
     cells = sum(len(a) * len(b) for a, b in zip(A, B))
     # algorithmic bytes: both sequences as 4-bit codes in, one distance out
     algo_bytes = sum((len(a) + len(b) + 1) // 2 + 4 for a, b in zip(A, B))
+    # the pre-packed batch form (mia_hip_myers_packed: no strlen, no packing inside the call)
+    import mia_amd as _m
+    packed = _m.pack_myers_pairs(A, B)
+    hip.myers_packed(packed, mode, maxd)                                   # warm-up
+    d_packed = hip.myers_packed(packed, mode, maxd)
+    packed_call_s = hip.myers_call_s
+    packed_kernel_ms = hip.myers_time()
     big = bases[rng.integers(0, 4, 16_600)].copy()
     big2 = big.copy()
     for p in rng.integers(0, len(big), 160):
@@ -478,6 +485,7 @@ def section_myers(hip, no_cpu=False):
     out = {"pairs": len(A), "pairs_per_s": len(A) / dt, "gcups": cells / dt / 1e9, "mean_distance": float(d[d != 0xFFFFFFFF].mean()),
            "c_abi_call_pairs_per_s": len(A) / call_s, "c_abi_call_gcups": cells / call_s / 1e9,
            "kernel_ms": k_ms, "kernel_pairs_per_s": len(A) / (k_ms * 1e-3), "kernel_gcups": cells / (k_ms * 1e-3) / 1e9,
+           "packed_c_abi_call_pairs_per_s": len(A) / packed_call_s, "packed_kernel_ms": packed_kernel_ms, "packed_equal": bool(np.array_equal(d, d_packed)),
            "roofline": {"bound": "hbm", "achieved": algo_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": algo_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "note": "bit-vector DP: 64 cells per 64-bit operation, bound by integer issue; bytes = packed sequences in + distances out"},

@@ -314,6 +314,16 @@ int mia_hip_get_ins_tally(mia_hip_ctx *ctx, int32_t *ins_off, int32_t *ins_tally
 int mia_hip_myers(mia_hip_ctx *ctx, int64_t n_pairs, const char *const *seq_a, const char *const *seq_b, const int32_t *mode,
                   const int32_t *maxd, uint32_t *dist);
 
+/* The same for pairs the caller has packed already -- the batch form a read-against-read use would keep its sequences in (no
+ * strlen, no packing on the way in: the host side of mia_hip_myers was seventeen times its kernel).  codes[n_words]: every
+ * sequence as 4-bit IUPAC bitmaps (A = 1, C = 2, G = 4, T = 8, the codes of src/myers_align.h:40-67 OR-ed; 0 = matches
+ * nothing), character c of a sequence in bits 4 (c % 8) .. 4 (c % 8) + 3 of word off + c / 8, and ONE spare word behind the
+ * last word of every sequence.  a_off / b_off: first word of seq_a / seq_b of pair i; la / lb: their lengths in characters.
+ * seq_a of up to 320 characters (one pair per lane); longer ones are refused with MIA_HIP_ERR_ARG: mia_hip_myers takes
+ * those.  mode, maxd, dist: as mia_hip_myers. */
+int mia_hip_myers_packed(mia_hip_ctx *ctx, int64_t n_pairs, const uint32_t *codes, int64_t n_words, const uint32_t *a_off, const uint32_t *b_off,
+                         const int32_t *la, const int32_t *lb, const int32_t *mode, const int32_t *maxd, uint32_t *dist);
+
 /* duration of the kernels of the most recent mia_hip_myers call, from HIP events on the context's stream (diagnostic:
  * bench.py prices the kernel apart from the packing of the strings and the copies) */
 int mia_hip_myers_time(mia_hip_ctx *ctx, double *kernel_ms);

@@ -13,6 +13,15 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MIA_HIP_LIB") or os.path.join(_HERE, "libmia_hip.so")    # (MIA_HIP_LIB: another build of the same library, for A/B timing)
+# libmia_hip_alt.so: the same sources with -DMIA_HIP_ALT_PATHS -- every alternative route and debug switch the differential tests and
+# the profiling tools reach through MIA_HIP_* variables.  The release library does not read them (csrc/mia_hip.hip: alt_env): a context
+# made while one of them is set comes from the alt build.
+ALT_LIB_PATH = os.path.join(_HERE, "libmia_hip_alt.so")
+RELEASE_ENV = {"MIA_HIP_THREADS", "MIA_HIP_TIMING", "MIA_HIP_LOOPBACK_TIMEOUT", "MIA_HIP_SPIN_WAIT", "MIA_HIP_LIB"}
+
+
+def alt_switches_set():
+    return sorted(k for k in os.environ if k.startswith("MIA_HIP_") and k not in RELEASE_ENV)
 
 PSSM_WORDS = 31 * 5 * 5
 TALLY_WORDS = 12
@@ -24,10 +33,11 @@ class MiaHipError(RuntimeError):
     pass
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
-        raise MiaHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
-    lib = C.CDLL(LIB_PATH)
+def _load(path=None):
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise MiaHipError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(path)
     P, vp = C.POINTER, C.c_void_p
     lib.mia_hip_create.argtypes = [P(vp), C.c_int]
     lib.mia_hip_destroy.argtypes = [vp]
@@ -57,6 +67,7 @@ def _load():
     lib.mia_hip_iterate.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int, C.c_int32, vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
+    lib.mia_hip_myers_packed.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     lib.mia_hip_pre_cull_counts.argtypes = [vp, vp, vp]
     lib.mia_hip_filter_stats.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.mia_hip_band_stats.argtypes = [vp, C.c_int, vp, vp, vp]
@@ -107,13 +118,24 @@ def lib():
     return _lib
 
 
+_alt_lib = None
+
+
+def alt_lib():
+    """the build with the alternative routes and debug switches (see ALT_LIB_PATH)"""
+    global _alt_lib
+    if _alt_lib is None:
+        _alt_lib = _load(ALT_LIB_PATH)
+    return _alt_lib
+
+
 def exported_symbols():
     """Every entry point include/mia_hip.h declares (used by the CPU-side ABI test)."""
     return ["mia_hip_create", "mia_hip_destroy", "mia_hip_last_error", "mia_hip_sync", "mia_hip_set_pssm",
             "mia_hip_upload_reads", "mia_hip_pass1", "mia_hip_realign", "mia_hip_align_windows", "mia_hip_get_alignments", "mia_hip_get_scripts", "mia_hip_cull",
             "mia_hip_get_dropped", "mia_hip_set_slot_dropped", "mia_hip_score_cut", "mia_hip_num_records",
             "mia_hip_tally", "mia_hip_tally_buffers", "mia_hip_ins_events", "mia_hip_set_ins_events",
-            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_myers_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
+            "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_packed", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_myers_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
             "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask", "mia_hip_comm_unique_id", "mia_hip_comm_init", "mia_hip_comm_destroy",
@@ -195,12 +217,39 @@ def comm_unique_id():
     return buf.raw
 
 
+_IUPAC_BITS = np.zeros(256, np.uint8)
+for _c, _v in zip("ACGTUSWRYKMBDHVN", (1, 2, 4, 8, 8, 6, 9, 5, 10, 12, 3, 14, 13, 11, 7, 15)):
+    _IUPAC_BITS[ord(_c)] = _v
+    _IUPAC_BITS[ord(_c.lower())] = _v
+
+
+def pack_myers_pairs(seq_a, seq_b):
+    """The layout mia_hip_myers_packed takes (include/mia_hip.h): 4-bit IUPAC bitmaps, eight to a word, one spare word behind
+    every sequence.  Returns (codes uint32, a_off, b_off, la, lb)."""
+    n = len(seq_a)
+    la = np.array([len(s) for s in seq_a], np.int32)
+    lb = np.array([len(s) for s in seq_b], np.int32)
+    wa, wb = (la + 7) // 8 + 1, (lb + 7) // 8 + 1
+    tot = np.cumsum(np.stack([wa, wb], 1).reshape(-1).astype(np.int64))
+    a_off = np.concatenate([[0], tot[1:-1:2]]).astype(np.uint32) if n else np.zeros(0, np.uint32)
+    b_off = tot[0::2].astype(np.uint32)
+    nib = np.zeros(int(tot[-1]) * 8 if n else 0, np.uint8)
+    for i in range(n):
+        a = np.frombuffer(seq_a[i] if isinstance(seq_a[i], bytes) else seq_a[i].encode(), np.uint8)
+        b = np.frombuffer(seq_b[i] if isinstance(seq_b[i], bytes) else seq_b[i].encode(), np.uint8)
+        nib[int(a_off[i]) * 8: int(a_off[i]) * 8 + len(a)] = _IUPAC_BITS[a]
+        nib[int(b_off[i]) * 8: int(b_off[i]) * 8 + len(b)] = _IUPAC_BITS[b]
+    codes = (nib.reshape(-1, 8).astype(np.uint32) << (4 * np.arange(8, dtype=np.uint32))).sum(axis=1).astype(np.uint32)
+    return codes, a_off, b_off, la, lb
+
+
 class MiaHip:
     """One context = one GPU.  Mirrors the call order of the reference's main loop
     (src/mia_main.c:931-963): realign -> cull -> tally -> consensus."""
 
     def __init__(self, device=0):
-        self._l = lib()
+        # (switches are read once, when the context is made: a context made while a non-release switch is set needs the alt build)
+        self._l = alt_lib() if (alt_switches_set() and not os.environ.get("MIA_HIP_LIB")) else lib()
         self._h = C.c_void_p()
         rc = self._l.mia_hip_create(C.byref(self._h), device)
         if rc != 0:
@@ -445,6 +494,19 @@ class MiaHip:
         if d.value == 0xFFFFFFFF:
             return None, None, None
         return d.value, ra.value.decode(), rb.value.decode()
+
+    def myers_packed(self, packed, mode, maxd):
+        """mia_hip_myers_packed: distances for pairs packed by pack_myers_pairs() (no strlen, no packing inside the call)"""
+        codes, a_off, b_off, la, lb = packed
+        n = len(la)
+        mode = np.ascontiguousarray(mode, dtype=np.int32)
+        maxd = np.ascontiguousarray(maxd, dtype=np.int32)
+        out = np.zeros(n, dtype=np.uint32)
+        import time
+        t0 = time.perf_counter()
+        self._chk(self._l.mia_hip_myers_packed(self._h, n, _ptr(codes), len(codes), _ptr(a_off), _ptr(b_off), _ptr(la), _ptr(lb), _ptr(mode), _ptr(maxd), _ptr(out)))
+        self.myers_call_s = time.perf_counter() - t0
+        return out
 
     def myers(self, seq_a, seq_b, mode, maxd):
         """Batch of myers_diff calls (reference src/myers_align.h:35): distances, 0xFFFFFFFF if >= maxd."""

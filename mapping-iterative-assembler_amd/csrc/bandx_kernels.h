@@ -454,6 +454,8 @@ __device__ __forceinline__ BxRead bx_load(const ReadSet& rs, const RefInfo& ref,
   return r;
 }
 
+constexpr int BX_SLAB_ROW_WORDS = 64 * (32 / 4);      // trace slab row of the one-lane kernel: 64 lanes x 32 bytes
+#ifdef MIA_HIP_ALT_PATHS      // the one-lane statement of the band DPs: MIA_HIP_NO_LANES=1 of the alt build (and, as plain functions, the CPU emulation tests)
 __global__ __launch_bounds__(256) void k_bx_values(ReadSet rs, RefInfo ref, BxDev bx, int32_t* bin_of) {
   __shared__ int32_t sub_lds[BX_SUB_WORDS];
   for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.tab.sub[k];
@@ -503,7 +505,6 @@ __global__ __launch_bounds__(256) void k_bx_values(ReadSet rs, RefInfo ref, BxDe
 
 // trace slab of a wavefront: [row][lane][BX_MAXW bytes], so that the 64 stores of a row are one stretch
 // trace slab of a wavefront: [row][lane][W bytes], so that the 64 stores of a row are one stretch
-constexpr int BX_SLAB_ROW_WORDS = 64 * (BX_MAXW / 4);
 __global__ __launch_bounds__(256) void k_bx_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
   __shared__ int32_t sub_lds[BX_SUB_WORDS];
   for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.sub256[k];
@@ -548,6 +549,7 @@ __global__ __launch_bounds__(256) void k_bx_trace(ReadSet rs, RefInfo ref, BxDev
   for (int o = 32; o; o >>= 1) done += __shfl_xor(done, o);
   if (lane == 0 && done) atomicAdd(bxc(bx.ctr, BXC_DONE_TRACE), done);
 }
+#endif
 
 // ---- the same two kernels with a read spread over W / 8 lanes (bandx_lanes.h) ---------------------------------------------
 // A chunk is bxl_chunk_reads(class) reads -- 64, 32, 20, 16 -- so that every wavefront walks eight cells per row and lane.

@@ -42,6 +42,19 @@ constexpr int CTRL_BXC = (CTRL_TFLAGS + 1 + 63) & ~63;         // BXC_* counters
 constexpr int CTRL_WORDS = CTRL_BXC + BXC_WORDS;
 constexpr int CTRL_C0 = CTRL_BINS + 3 * N_BINS, CTRL_CN = CTRL_WORDS - CTRL_C0;    // what the host looks at behind an alignment: wide / retry counts, planner header, filter and band counters
 
+// Environment switches.  The release library reads FIVE (documented in DESIGN.md 6.1): MIA_HIP_SPIN_WAIT and MIA_HIP_LOOPBACK_TIMEOUT
+// here, MIA_HIP_THREADS, MIA_HIP_TIMING and MIA_DATA_PATH in the host programs.  Everything else -- the "off" sides of the
+// differential tests, the round-1 and one-lane routes, the profiling switches that make results wrong on purpose
+// (MIA_HIP_DEBUG_SKIP, MIA_HIP_BX_DEBUG) -- exists only in libmia_hip_alt.so, built with -DMIA_HIP_ALT_PATHS; the Python binding
+// loads that build for a context made while such a variable is set (tests, tools), and nothing else does.
+#ifdef MIA_HIP_ALT_PATHS
+static inline const char* alt_env(const char* name) { return getenv(name); }
+#define ALT_KERNEL(k) ((const void*)(k))
+#else
+static inline const char* alt_env(const char*) { return nullptr; }
+#define ALT_KERNEL(k) ((const void*)nullptr)        // (the one-lane band kernels are not part of the release build's code object)
+#endif
+
 struct mia_hip_ctx {
   int device = 0;
   int32_t* d_ctrl = nullptr;
@@ -295,7 +308,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
   ctx->device = device_index;
   // the events order kernels of this context's streams on this device and nothing else (MIA_HIP_EVENT_DEVICE_SCOPE=1: say so)
   unsigned evf = hipEventDisableTiming;
-  if (const char* es = getenv("MIA_HIP_EVENT_DEVICE_SCOPE")) if (atoi(es)) evf |= hipEventReleaseToDevice;
+  if (const char* es = alt_env("MIA_HIP_EVENT_DEVICE_SCOPE")) if (atoi(es)) evf |= hipEventReleaseToDevice;
   if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join3, evf) != hipSuccess ||
@@ -310,52 +323,52 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
     ctx->grid_wgs = prop.multiProcessorCount * 32;
     ctx->quad_wgs = prop.multiProcessorCount * 16;   // 128 VGPRs -> 4 waves per SIMD
-    const char* nbt = getenv("MIA_HIP_NO_BINNED_TALLY");
+    const char* nbt = alt_env("MIA_HIP_NO_BINNED_TALLY");
     if (nbt && atoi(nbt)) ctx->use_binned_tally = 0;
-    const char* nband = getenv("MIA_HIP_NO_BAND");
+    const char* nband = alt_env("MIA_HIP_NO_BAND");
     if (nband && atoi(nband)) ctx->use_band = 0;
-    const char* npl = getenv("MIA_HIP_NO_PLAIN");
+    const char* npl = alt_env("MIA_HIP_NO_PLAIN");
     if (npl && atoi(npl)) ctx->use_plain = 0;
-    const char* pbb = getenv("MIA_HIP_PLAIN_BEHIND_BAND");
+    const char* pbb = alt_env("MIA_HIP_PLAIN_BEHIND_BAND");
     if (pbb && atoi(pbb)) ctx->plain_behind_band = 1;
-    const char* nf = getenv("MIA_HIP_NO_DIAG_FILTER");
+    const char* nf = alt_env("MIA_HIP_NO_DIAG_FILTER");
     if (nf && atoi(nf)) { ctx->use_filter = 0; ctx->use_bx = 0; }      // every shortcut off: the full-window DP kernels only
-    const char* nbd = getenv("MIA_HIP_NO_BAND_DP");
+    const char* nbd = alt_env("MIA_HIP_NO_BAND_DP");
     if (nbd && atoi(nbd)) { ctx->use_banddp = 0; ctx->use_bx = 0; }
-    const char* nbx = getenv("MIA_HIP_NO_BANDX");
+    const char* nbx = alt_env("MIA_HIP_NO_BANDX");
     if (nbx && atoi(nbx)) ctx->use_bx = 0;
-    if (const char* nl2 = getenv("MIA_HIP_NO_LANES")) if (atoi(nl2)) ctx->use_lanes = 0;
-    if (const char* bd2 = getenv("MIA_HIP_BX_DEBUG")) ctx->bx_dbg = (uint32_t)atoi(bd2);
-    if (const char* bs2 = getenv("MIA_HIP_BX_SERIAL")) ctx->bx_serial = atoi(bs2) != 0;
-    if (const char* sb2 = getenv("MIA_HIP_NO_SIDE_BUCKETS")) ctx->no_side_buckets = atoi(sb2) != 0;
-    if (const char* ns2 = getenv("MIA_HIP_NO_SPEC")) ctx->no_spec = atoi(ns2) != 0;
-    if (const char* pf2 = getenv("MIA_HIP_NO_PREP_FUSE")) ctx->no_prep_fuse = atoi(pf2) != 0;
-    if (const char* ps2 = getenv("MIA_HIP_NO_PLAN_SPLIT")) ctx->plan_split = atoi(ps2) == 0;
-    if (const char* zc = getenv("MIA_HIP_NO_ZERO_COPY")) ctx->zero_copy = atoi(zc) == 0;
-    if (const char* ef = getenv("MIA_HIP_NO_EXT_EVENTS")) ctx->ext_events = atoi(ef) ? 0u : 31u;
-    if (const char* cs = getenv("MIA_HIP_CULL_SCAN")) ctx->cull_scan = atoi(cs) != 0;
-    if (const char* sm = getenv("MIA_HIP_STAGE_MARKERS")) ctx->stage_markers = atoi(sm) != 0;
-    if (const char* ts = getenv("MIA_HIP_TAIL_SCANS")) ctx->tail_scans = atoi(ts) != 0;
+    if (const char* nl2 = alt_env("MIA_HIP_NO_LANES")) if (atoi(nl2)) ctx->use_lanes = 0;
+    if (const char* bd2 = alt_env("MIA_HIP_BX_DEBUG")) ctx->bx_dbg = (uint32_t)atoi(bd2);
+    if (const char* bs2 = alt_env("MIA_HIP_BX_SERIAL")) ctx->bx_serial = atoi(bs2) != 0;
+    if (const char* sb2 = alt_env("MIA_HIP_NO_SIDE_BUCKETS")) ctx->no_side_buckets = atoi(sb2) != 0;
+    if (const char* ns2 = alt_env("MIA_HIP_NO_SPEC")) ctx->no_spec = atoi(ns2) != 0;
+    if (const char* pf2 = alt_env("MIA_HIP_NO_PREP_FUSE")) ctx->no_prep_fuse = atoi(pf2) != 0;
+    if (const char* ps2 = alt_env("MIA_HIP_NO_PLAN_SPLIT")) ctx->plan_split = atoi(ps2) == 0;
+    if (const char* zc = alt_env("MIA_HIP_NO_ZERO_COPY")) ctx->zero_copy = atoi(zc) == 0;
+    if (const char* ef = alt_env("MIA_HIP_NO_EXT_EVENTS")) ctx->ext_events = atoi(ef) ? 0u : 31u;
+    if (const char* cs = alt_env("MIA_HIP_CULL_SCAN")) ctx->cull_scan = atoi(cs) != 0;
+    if (const char* sm = alt_env("MIA_HIP_STAGE_MARKERS")) ctx->stage_markers = atoi(sm) != 0;
+    if (const char* ts = alt_env("MIA_HIP_TAIL_SCANS")) ctx->tail_scans = atoi(ts) != 0;
     if (const char* sw = getenv("MIA_HIP_SPIN_WAIT")) ctx->spin_wait = atoi(sw) != 0;
-    if (const char* em = getenv("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
-    if (const char* st2 = getenv("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
-    if (const char* ml = getenv("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
-    if (const char* na = getenv("MIA_HIP_NO_AUTO_PLAIN")) ctx->no_auto_plain = atoi(na) != 0;
-    const char* egs = getenv("MIA_HIP_EAGER_SCRIPTS");
+    if (const char* em = alt_env("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
+    if (const char* st2 = alt_env("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
+    if (const char* ml = alt_env("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
+    if (const char* na = alt_env("MIA_HIP_NO_AUTO_PLAIN")) ctx->no_auto_plain = atoi(na) != 0;
+    const char* egs = alt_env("MIA_HIP_EAGER_SCRIPTS");
     if (egs && atoi(egs)) ctx->lazy_scripts = 0;
-    const char* nwl = getenv("MIA_HIP_NO_WILD");
+    const char* nwl = alt_env("MIA_HIP_NO_WILD");
     if (nwl && atoi(nwl)) ctx->use_wild = 0;
-    if (const char* nf = getenv("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
-    if (const char* nf = getenv("MIA_HIP_FINE")) ctx->use_fine = atoi(nf);
-    const char* bxf = getenv("MIA_HIP_BX_FILTER");
+    if (const char* nf = alt_env("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
+    if (const char* nf = alt_env("MIA_HIP_FINE")) ctx->use_fine = atoi(nf);
+    const char* bxf = alt_env("MIA_HIP_BX_FILTER");
     if (bxf && atoi(bxf)) ctx->bx_filter_first = 1;
-    const char* nq = getenv("MIA_HIP_NO_QUAD");
+    const char* nq = alt_env("MIA_HIP_NO_QUAD");
     if (nq && atoi(nq)) ctx->use_quad = 0;
-    const char* qw = getenv("MIA_HIP_QUAD_WAVES_PER_CU");
+    const char* qw = alt_env("MIA_HIP_QUAD_WAVES_PER_CU");
     if (qw && atoi(qw) > 0) ctx->quad_wgs = prop.multiProcessorCount * atoi(qw);
-    const char* dbg = getenv("MIA_HIP_DEBUG_SKIP");
+    const char* dbg = alt_env("MIA_HIP_DEBUG_SKIP");
     if (dbg) ctx->dbg = (uint32_t)atoi(dbg);
-    const char* g = getenv("MIA_HIP_GRID_WAVES_PER_CU");
+    const char* g = alt_env("MIA_HIP_GRID_WAVES_PER_CU");
     if (g && atoi(g) > 0) ctx->grid_wgs = prop.multiProcessorCount * atoi(g);
   }
   if (dev_alloc(ctx, &ctx->d_pssm, 2 * PSSM_WORDS) || dev_alloc(ctx, &ctx->d_ctrl, CTRL_WORDS) ||
@@ -447,7 +460,7 @@ extern "C" int mia_hip_set_pssm(mia_hip_ctx* ctx, const int32_t* fwd, const int3
   {
     int lo = 0, hi = 0;
     for (int k = 0; k < PSSM_WORDS; k++) { lo = std::min(lo, std::min((int)fwd[k], (int)rc[k])); hi = std::max(hi, std::max((int)fwd[k], (int)rc[k])); }
-    ctx->tally_pk_bias = (-lo + hi <= 2047 && !getenv("MIA_HIP_NO_PACKED_TALLY")) ? -lo : -1;
+    ctx->tally_pk_bias = (-lo + hi <= 2047 && !alt_env("MIA_HIP_NO_PACKED_TALLY")) ? -lo : -1;
   }
   ctx->max_pos = 0;
   for (int i = 0; i < PSSM_WORDS; i++) { if (fwd[i] > ctx->max_pos) ctx->max_pos = fwd[i]; if (rc[i] > ctx->max_pos) ctx->max_pos = rc[i]; }
@@ -465,7 +478,7 @@ extern "C" int mia_hip_set_pssm(mia_hip_ctx* ctx, const int32_t* fwd, const int3
     for (int x = 0; x < 4; x++)
       for (int b = 0; b < 5; b++)
         if (fwd[(d * 5 + x) * 5 + b] != fwd[x * 5 + b] || rc[(d * 5 + x) * 5 + b] != fwd[x * 5 + b]) ctx->tally_linear = false;
-  if (const char* nl = getenv("MIA_HIP_NO_LINEAR_TALLY")) if (atoi(nl)) ctx->tally_linear = false;
+  if (const char* nl = alt_env("MIA_HIP_NO_LINEAR_TALLY")) if (atoi(nl)) ctx->tally_linear = false;
   // tables of the band pipeline (bandx_body.h): substitution scores by (strand, depth, read base, reference code), the best
   // score of every row kind, and what a non-identical base costs at least
   {
@@ -1043,9 +1056,9 @@ static int align_all(mia_hip_ctx* ctx) {
       }
       if (!ctx->bx_values_wgs) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ctx->use_lanes ? (const void*)k_bxl_values : (const void*)k_bx_values, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ctx->use_lanes ? (const void*)k_bxl_values : ALT_KERNEL(k_bx_values), 256, 0) != hipSuccess || occ < 1) occ = 1;
         ctx->bx_values_wgs = ctx->cus * std::min(occ, 4);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ctx->use_lanes ? (const void*)k_bxl_trace : (const void*)k_bx_trace, 256, 0) != hipSuccess || occ < 1) occ = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ctx->use_lanes ? (const void*)k_bxl_trace : ALT_KERNEL(k_bx_trace), 256, 0) != hipSuccess || occ < 1) occ = 1;
         ctx->bx_trace_wgs = ctx->cus * std::min(occ, 4);      // (every wavefront of the trace grid owns a slab)
       }
       // (the lanes kernels store four rows per word: whole blocks of four rows)
@@ -1164,13 +1177,17 @@ static int align_all(mia_hip_ctx* ctx) {
         if (stage_begin(ctx, STG_BX_TRACE, ctx->stream2)) return MIA_HIP_ERR_NOMEM;
         if (ctx->bx_dbg & 8u) {}
         else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
+#ifdef MIA_HIP_ALT_PATHS
         else hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
+#endif
         stage_end(ctx, STG_BX_TRACE, ctx->stream2);
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
         if (stage_begin(ctx, STG_BX_VALUES)) return MIA_HIP_ERR_NOMEM;
         if (ctx->bx_dbg & 4u) {}
         else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
+#ifdef MIA_HIP_ALT_PATHS
         else hipLaunchKernelGGL(k_bx_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
+#endif
         stage_end(ctx, STG_BX_VALUES);
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         HIPCHK(hipGetLastError());
@@ -1211,7 +1228,7 @@ static int align_all(mia_hip_ctx* ctx) {
     // ---- mia_hip_iterate: the same plan, but its numbers stay on the device (k_plan_scan) and every DP kernel reads its own
     // range; the host looks at the counters once, when everything has been queued --------------------------------------
     int32_t* hdr = ctx->d_plan_hdr;
-    const bool dbg_steps = getenv("MIA_HIP_ITER_DEBUG") != nullptr;
+    const bool dbg_steps = alt_env("MIA_HIP_ITER_DEBUG") != nullptr;
     auto ck = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ps); fprintf(stderr, "[align_all deferred] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
     ck("plan_count");
     int32_t* d_retry_cnt = hdr + PH_RETRY + 1;

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(64) void k_myers_lanes(const MyersLanePair* pairs, 
     }
     if (d < maxd) result = (uint32_t)d;
   }
-  out[index[p]] = result;
+  out[index ? index[p] : p] = result;        // (index == nullptr: the pairs in the caller's order, mia_hip_myers_packed)
 }
 
 }  // namespace mia

@@ -108,3 +108,24 @@ def test_lane_kernel_equals_systolic_kernel():
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, [(int(i), int(got[i]), int(want[i]), mode[i], maxd[i], len(A[i]), len(B[i])) for i in bad[:8]]
     assert (want != 0xFFFFFFFF).sum() > 5000 and (want == 0xFFFFFFFF).sum() > 1000
+
+
+def test_packed_entry_point_on_the_reference_vectors():
+    """mia_hip_myers_packed (round 4: the pre-packed batch form, no strlen / packing inside the call) on every golden pair whose
+    seq_a fits one lane (up to 320 characters): the reference's myers_diff answers again; a longer seq_a is refused."""
+    import mia_amd
+    lines = [l.rstrip("\n") for l in open(os.path.join(GOLDEN, "myers_vectors.txt"))]
+    A, B, mode, maxd, exp = [], [], [], [], []
+    for inp, out in zip(lines[0::2], lines[1::2]):
+        m, d, a, b = inp.split(" ")
+        if len(a) > 320:
+            continue
+        A.append(a); B.append(b); mode.append(int(m)); maxd.append(int(d)); exp.append(int(out.split(" ")[0]))
+    assert len(exp) >= 150
+    hip = mia_amd.MiaHip(0)
+    got = hip.myers_packed(mia_amd.pack_myers_pairs(A, B), mode, maxd)
+    bad = [(i, int(got[i]), exp[i], mode[i], maxd[i], len(A[i]), len(B[i])) for i in range(len(exp)) if int(got[i]) != exp[i]]
+    assert not bad, bad[:10]
+    with pytest.raises(mia_amd.MiaHipError):
+        hip.myers_packed(mia_amd.pack_myers_pairs(["A" * 400], ["A" * 400]), [0], [10])
+    hip.close()
