@@ -42,7 +42,7 @@ constexpr int CTRL_BXC = (CTRL_TFLAGS + 1 + 63) & ~63;         // BXC_* counters
 constexpr int CTRL_WORDS = CTRL_BXC + BXC_WORDS;
 constexpr int CTRL_C0 = CTRL_BINS + 3 * N_BINS, CTRL_CN = CTRL_WORDS - CTRL_C0;    // what the host looks at behind an alignment: wide / retry counts, planner header, filter and band counters
 
-// Environment switches.  The release library reads FIVE (documented in DESIGN.md 6.1): MIA_HIP_SPIN_WAIT and MIA_HIP_LOOPBACK_TIMEOUT
+// Environment switches.  The release library reads FIVE (documented in DESIGN.md 1): MIA_HIP_SPIN_WAIT and MIA_HIP_LOOPBACK_TIMEOUT
 // here, MIA_HIP_THREADS, MIA_HIP_TIMING and MIA_DATA_PATH in the host programs.  Everything else -- the "off" sides of the
 // differential tests, the round-1 and one-lane routes, the profiling switches that make results wrong on purpose
 // (MIA_HIP_DEBUG_SKIP, MIA_HIP_BX_DEBUG) -- exists only in libmia_hip_alt.so, built with -DMIA_HIP_ALT_PATHS; the Python binding

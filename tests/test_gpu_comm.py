@@ -3,7 +3,7 @@
 * test_one_rank_communicator_changes_nothing: mia_hip_iterate with an RCCL communicator of one rank attached (every
   exchange of the sharded path runs: the all-gather of the score sums, the link exchange, both all-reduces, the event
   gather) gives what it gives without one, iteration by iteration, on the adapter-trimmed set whose stale back_asp
-  pointers produce real links.
+  pointers produce real links (HISTORY.md 3.4).
 * test_two_contexts_exchange_real_links: the read store split in two contiguous fsdb blocks, one context each (what two
   ranks hold), driven through mia_hip_links -> mia_hip_set_links -> mia_hip_link_lengths -> mia_hip_finish_links with
   host-side reductions standing in for RCCL (one GPU here): scores, dropped bits, depth-code parameters, multiplicities,

@@ -21,12 +21,12 @@ CASES = {
     "indel_anc_H": ("mt311.fa", "indel.fa", True, "ancient.submat.txt", 17000, 2, None),
     "fixture_c": ("tr1.fna", "tf.fna", True, None, 0, 1, None),
     # linear reference; tf11-adapt scores exactly 2000 there => strand_known == 0: it is never re-aligned and both its
-    # AlnSeq pointers stay on the pass-1 slots, whose later occupants are listed twice
+    # AlnSeq pointers stay on the pass-1 slots, whose later occupants are listed twice (HISTORY.md 3.4)
     "fixture_lin": ("tr1.fna", "tf.fna", False, None, 0, 1, None),
     "fixture_lin_minus": ("tr1.fna", "tf.fna:-tf11-adapt", False, None, 0, 1, None),
     "fixture_c_anc_H": ("tr1.fna", "tf.fna", True, "ancient.submat.txt", 4000, 1, None),
     # adapter-trimmed reads (-T -a GTCAGACACGCAACAGG); two reads that are split at the origin after pass 1 are not
-    # in iteration 2: their stale back_asp makes the reference list two unrelated records twice
+    # in iteration 2: their stale back_asp makes the reference list two unrelated records twice (HISTORY.md 3.4)
     "adapt_T_user": ("mt311.fa", "adapt.fa", True, None, 0, 1, None, "GTCAGACACGCAACAGG"),
 }
 
