@@ -76,7 +76,8 @@ constexpr int BX_LOSS_N = 2 * 31 * 4 * 4;
 constexpr int BX_LOSS_KAP = BX_LOSS_N + 2 * 31 * 4;       // [2][31][31]: what crossing an N column costs at least, by strand and depth range
 constexpr int BX_LOSS_NCRED = BX_LOSS_KAP + 2 * 31 * 31;    // [2][32]: what ANY path pays at least for k N columns it spans (bx_window_nmin), all 0 = not usable
 constexpr int BX_NCRED_K = 32;
-constexpr int BX_LOSS_FDL = BX_LOSS_NCRED + 2 * BX_NCRED_K;  // [2][31]: what breaking a FINE block costs at least, by strand and depth of its cheapest row (bx_fine_anchors); 0 = not usable
+constexpr int BX_LOSS_KAP2 = BX_LOSS_NCRED + 2 * BX_NCRED_K;  // [2][31][31]: the least a ROW over an N column costs, by strand and depth range (not capped at GEP)
+constexpr int BX_LOSS_FDL = BX_LOSS_KAP2 + 2 * 31 * 31;  // [2][31]: what breaking a FINE block costs at least, by strand and depth of its cheapest row (bx_fine_anchors); 0 = not usable
 constexpr int BX_LOSS_WORDS = BX_LOSS_FDL + 2 * 31;
 constexpr int BX_FQ = 6;               // rows of a fine block
 constexpr int BX_FINE_RADIUS = 3;      // fine anchors this close to the 10-mer anchors' diagonals are kept, the others set aside
@@ -130,6 +131,9 @@ inline bool bx_make_tables(const int32_t* fwd, const int32_t* rc, int32_t* sub, 
         int v = GEP;
         for (int d = a; d <= b; d++) if (lamn[st][d] < v) v = lamn[st][d];
         loss[BX_LOSS_KAP + (st * 31 + a) * 31 + b] = (int16_t)(a <= b && v > 0 ? v : 0);
+        int v2 = 1 << 14;
+        for (int d = a; d <= b; d++) if (lamn[st][d] < v2) v2 = lamn[st][d];
+        loss[BX_LOSS_KAP2 + (st * 31 + a) * 31 + b] = (int16_t)(a <= b && v2 > 0 && v2 < (1 << 14) ? v2 : 0);
       }
   // skipped rows (an insert, a soft clip): n of them touch at most ceil((n-1)/10)+1 blocks and cost at least GOP + (GEP + min M) n
   int e = GOP + GEP;                    // (a column gap inside a block)
@@ -1037,7 +1041,7 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
     if (gt <= BX_GMAX && gt < G) G = gt;
     for (int pass = 0; pass < 2 && G > 0; pass++) {
       const int q_lo = an.a_hi + G - d_first, q_hi = R + an.a_lo - G - d_first;      // (0 <= q_lo, q_hi <= R)
-      int credit = 0, k = 0;
+      int credit = 0, k = 0, dmin = 1 << 14;              // dmin: the least a credited column costs MORE when a row crosses it than the credit it carries
       uint64_t cm[NW];
 #pragma unroll
       for (int j = 0; j < NW; j++) {
@@ -1052,6 +1056,8 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
           if (r_hi > R) r_hi = R;
           const int kv = T.loss[BX_LOSS_KAP + (st * 31 + sm_depth(r_lo, len2)) * 31 + sm_depth(r_hi, len2)];
           if (kv <= 0) continue;
+          const int kv2 = T.loss[BX_LOSS_KAP2 + (st * 31 + sm_depth(r_lo, len2)) * 31 + sm_depth(r_hi, len2)];
+          if (kv2 - kv < dmin) dmin = kv2 - kv;
           credit += kv;
           k++;
           cm[j] |= 1ull << t;
@@ -1059,14 +1065,22 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
       }
       const int y = b0x - credit;
       if (credit <= 0 || y >= 4 * GOP) break;
+      // A credited column under a ROW costs lambda, which may exceed the credit it carries (min(GEP, lambda): 210 against 200 with the
+      // flat matrix) by dmin or more; only the columns inside the path's gaps get away with GEP.  A path with j gaps that hold
+      // h of the k credited columns therefore needs  j GOP + GEP m + (k - h) dmin <= y  -- with ten N columns under a read that is
+      // what tells "one substitution, no room for any gap" (the plan finishes the read) from "one substitution and a gap of one".
+      if (dmin < 0 || dmin >= (1 << 14)) dmin = 0;
       int gn = 0;
       if (y >= GOP) {
-        gn = (y - GOP) / (GEP + T.min_m);
+        const int rows_room = y - GOP - k * dmin;                   // skipped rows cross nothing: every credited column is under a row
+        gn = rows_room >= 0 ? rows_room / (GEP + T.min_m) : 0;
         // (H is worked out once, for the one-gap case's m -- the largest: H grows with m, so the same value bounds the cases of two
         // and more gaps from above; walking the bit masks once per case was a third of the planner's time against mt311)
         const int h1 = bx_ones_span<NW>(cm, (y - GOP) / GEP);
         for (int j = 1; j * GOP <= y; j++) {
-          const int m = (y - j * GOP) / GEP, h = j * h1, tot = m + (h < k ? h : k);
+          const int h = j * h1 < k ? j * h1 : k, room = y - j * GOP - (k - h) * dmin;
+          if (room < 0) continue;
+          const int tot = room / GEP + h;
           if (tot > gn) gn = tot;
         }
       }

@@ -31,6 +31,24 @@ def test_every_declared_symbol_is_exported(mia):
     assert sorted(mia.exported_symbols()) == declared
 
 
+def test_release_library_reads_five_environment_variables(mia):
+    """the wrong-results switches (MIA_HIP_DEBUG_SKIP ...) and the alternative routes are not in the release
+    library at all -- its text holds only the documented names; the alt build (-DMIA_HIP_ALT_PATHS) holds them and exports
+    the same ABI."""
+    def names(path):
+        with open(path, "rb") as f:
+            return set(m.decode() for m in re.findall(rb"MIA_HIP_[A-Z0-9_]+", f.read()))
+    rel = names(mia.LIB_PATH) - {"MIA_HIP_OP_MAX", "MIA_HIP_OP_SUM"}
+    assert rel <= {"MIA_HIP_SPIN_WAIT", "MIA_HIP_LOOPBACK_TIMEOUT", "MIA_HIP_THREADS", "MIA_HIP_TIMING"}, rel
+    assert os.path.exists(mia.ALT_LIB_PATH)
+    alt = names(mia.ALT_LIB_PATH)
+    assert {"MIA_HIP_DEBUG_SKIP", "MIA_HIP_NO_LANES", "MIA_HIP_NO_DIAG_FILTER", "MIA_HIP_NO_FINE"} <= alt
+    hdr = open(os.path.join(ROOT, "include", "mia_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(mia_hip_[a-z_0-9]+)\s*\(", hdr)))
+    lib = mia.alt_lib()
+    assert not [s for s in declared if not hasattr(lib, s)]
+
+
 def test_no_cpu_fallback(mia):
     import torch
     if torch.cuda.is_available():
