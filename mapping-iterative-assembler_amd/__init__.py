@@ -67,7 +67,8 @@ def _load(path=None):
     lib.mia_hip_iterate.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int, C.c_int32, vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_consensus.argtypes = [vp, C.c_int, vp, C.c_int64, P(C.c_int64)]
     lib.mia_hip_myers.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp]
-    lib.mia_hip_myers_packed.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
+    if hasattr(lib, "mia_hip_myers_packed"):      # (MIA_HIP_LIB may name an older build, for A/B timing)
+        lib.mia_hip_myers_packed.argtypes = [vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp]
     lib.mia_hip_pre_cull_counts.argtypes = [vp, vp, vp]
     lib.mia_hip_filter_stats.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.mia_hip_band_stats.argtypes = [vp, C.c_int, vp, vp, vp]

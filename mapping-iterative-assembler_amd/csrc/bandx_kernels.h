@@ -46,6 +46,7 @@ struct BxDev {
   int64_t list_stride;
   uint32_t* ctr;           // BXC_*
   int32_t lazy_scripts;    // the scripts of reads finished as pure diagonals are not written (k_diag_scripts makes them when asked for)
+  int32_t wide_to_trace;   // reads of the widest class skip the values DP: straight onto the trace lists (see align_all)
   uint32_t dbg;            // MIA_HIP_BX_DEBUG (profiling only, results are wrong): 1 no traceback, 2 one DP row only
   // k_bx_plan in two launches (phase 1 / phase 2): the reads whose anchors lie on two diagonals (or that want the end-indel
   // rescue) are handed from the first to the second through this list; nullptr: one launch, the block's first threads finish them
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
       if (mark_open && bp.mode != BX_DONE) bin_of[r.i] = (bp.mode == BX_VALUES || bp.mode == BX_TRACE) ? bx.listed_mark : 0;
     }
     // list appends and counters go through the block: one global atomic per block and list instead of one per wavefront
-    const int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? BX_NCLS + bx_class_of(bp.w) : -1);
+    int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? BX_NCLS + bx_class_of(bp.w) : -1);
+    if (bx.wide_to_trace && which == BX_NCLS - 1) which = 2 * BX_NCLS - 1;
     uint32_t rank = 0;
     if (which >= 0) rank = atomicAdd(&blk_cnt[which], 1u);
     if (to_fine) rank = atomicAdd(&blk_cnt[SLOT_FINE], 1u);

@@ -1116,6 +1116,10 @@ static int align_all(mia_hip_ctx* ctx) {
         if (fine) bd.cand2 = ctx->d_bx_cand2;
       }
       const int last_phase = split ? (fine ? 3 : 2) : 0;
+      // The widest class (33-64 diagonals) holds the few reads a step that used to go to the full-window kernels beside the band DPs.
+      // Through the values DP their left-overs land on the late lists, i.e. on the step's critical path (late trace 0.125 -> 0.17 ms per
+      // 1 M flat reads); where the lists are short anyway they go straight to the trace DP on its own stream instead.
+      bd.wide_to_trace = (new_flow && !fine) ? 1 : 0;
       if (stage_begin(ctx, STG_BX_PLAN)) return MIA_HIP_ERR_NOMEM;
       {
         const int32_t* in_list = run_filter ? ctx->d_left_list : nullptr;
