@@ -1120,6 +1120,10 @@ static int align_all(mia_hip_ctx* ctx) {
       // Through the values DP their left-overs land on the late lists, i.e. on the step's critical path (late trace 0.125 -> 0.17 ms per
       // 1 M flat reads); where the lists are short anyway they go straight to the trace DP on its own stream instead.
       bd.wide_to_trace = (new_flow && !fine) ? 1 : 0;
+      // ... and where the plan's third launch is off (flat matrix, a million reads, hardly any rejects: the step is a chain of
+      // latencies) the widest class is not used at all: those few reads keep going to the full-window kernels on the planner's stream,
+      // whose chain is as long with them as without (measured: 0.960 against 0.944 ms per step with the class in use)
+      if (!fine && ctx->use_fine < 2) bd.tab.maxw = 32;
       if (stage_begin(ctx, STG_BX_PLAN)) return MIA_HIP_ERR_NOMEM;
       {
         const int32_t* in_list = run_filter ? ctx->d_left_list : nullptr;
@@ -1236,8 +1240,7 @@ static int align_all(mia_hip_ctx* ctx) {
     auto ck = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ps); fprintf(stderr, "[align_all deferred] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
     ck("plan_count");
     int32_t* d_retry_cnt = hdr + PH_RETRY + 1;
-    HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ps));           // -1 = empty slot (quad padding)
-    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 0);
+    hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 0, ctx->d_list);      // (writes the quad bins' padding itself: -1 = empty slot)
     hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
     ck("memsets");
     hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ps, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count);
@@ -1264,8 +1267,7 @@ static int align_all(mia_hip_ctx* ctx) {
         HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ps));
         HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ps));
         hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_count);
-        HIPCHK(hipMemsetAsync(ctx->d_list, 0xFF, ((size_t)n + 4 * N_BINS) * 4, ps));
-        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 1);
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 1, ctx->d_list);
         hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
         ck("replan");
       }

@@ -1,15 +1,17 @@
 #!/bin/bash
-# gpurun_out/r03 (tools/collect_profiles.sh on the GPU box) -> profiles/r03
+# gpurun_out/<round> (tools/collect_profiles.sh on the GPU box) -> profiles/<round>; ROUND=r04 by default
 cd "$(dirname "$0")/.."
+RND=${ROUND:-r04}; mkdir -p profiles/$RND/pmc
 for c in 1 2 3 4; do
-  cp gpurun_out/r03/ks_cfg$c/p_kernel_stats.csv profiles/r03/cfg${c}_kernel_stats.csv
-  tail -1 gpurun_out/r03/ks_cfg$c.json > profiles/r03/cfg${c}_bench_under_rocprofv3.json
-  cp gpurun_out/r03/cfg${c}_timeline.txt profiles/r03/cfg${c}_timeline.txt
-  cp gpurun_out/r03/pmc/cfg$c.json profiles/r03/pmc/cfg$c.json
+  cp gpurun_out/$RND/ks_cfg$c/p_kernel_stats.csv profiles/$RND/cfg${c}_kernel_stats.csv
+  tail -1 gpurun_out/$RND/ks_cfg$c.json > profiles/$RND/cfg${c}_bench_under_rocprofv3.json
+  cp gpurun_out/$RND/cfg${c}_timeline.txt profiles/$RND/cfg${c}_timeline.txt
+  cp gpurun_out/$RND/pmc/cfg$c.json profiles/$RND/pmc/cfg$c.json
 done
-[ -f gpurun_out/r03/bench_default.json ] && tail -1 gpurun_out/r03/bench_default.json > profiles/r03/bench_default.json
+cp gpurun_out/$RND/first_iteration_*_timeline.txt profiles/$RND/ 2>/dev/null
+[ -f gpurun_out/$RND/bench_default.json ] && tail -1 gpurun_out/$RND/bench_default.json > profiles/$RND/bench_default.json
 python3 -c "
 import json,sys
 sys.path.insert(0,'.')
 import bench
-print('source hash', bench.source_hash(), [json.load(open('profiles/r03/pmc/cfg%d.json'%c))['_meta']['source_hash'] for c in (1,2,3,4)])"
+print('source hash', bench.source_hash(), [json.load(open('profiles/'+__import__('os').environ.get('ROUND','r04')+'/pmc/cfg%d.json'%c))['_meta']['source_hash'] for c in (1,2,3,4)])"

@@ -2,7 +2,7 @@
 # Three rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; the SQ set is the third) of the
 # timed steps of one BASELINE config, summarised per kernel by tools/pmc_summary.py.  Run on the GPU box:
 #   tools/pmc_collect.sh <config 1|2|4> <reads> <outdir under gpurun_out/>
-# then copy <outdir>/cfg<k>.json to profiles/r03/pmc/.  Counter runs carry --kernel-trace only (no other trace domain).
+# then copy <outdir>/cfg<k>.json to profiles/<round>/pmc/.  Counter runs carry --kernel-trace only (no other trace domain).
 set -e
 cfg=$1; reads=$2; out=$(realpath -m "$3"); mkdir -p "$out"
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
