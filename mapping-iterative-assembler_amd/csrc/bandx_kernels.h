@@ -47,6 +47,7 @@ struct BxDev {
   uint32_t* ctr;           // BXC_*
   int32_t lazy_scripts;    // the scripts of reads finished as pure diagonals are not written (k_diag_scripts makes them when asked for)
   int32_t wide_to_trace;   // reads of the widest class skip the values DP: straight onto the trace lists (see align_all)
+  uint8_t* early;          // [n] or nullptr: 1 for the reads the plan finishes (the early tally, mia_consensus_kernels.h: k_rec_early), 0 for all others
   uint32_t dbg;            // MIA_HIP_BX_DEBUG (profiling only, results are wrong): 1 no traceback, 2 one DP row only
   // k_bx_plan in two launches (phase 1 / phase 2): the reads whose anchors lie on two diagonals (or that want the end-indel
   // rescue) are handed from the first to the second through this list; nullptr: one launch, the block's first threads finish them
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     Rd rr = r;
     if (waits) rr.ok = false;
     emit(rr, bp, !in_list && t0 + threadIdx.x < total && !waits, to_fine, an);
+    if (bx.early && !in_list && t0 + threadIdx.x < total) bx.early[t0 + threadIdx.x] = bp.mode == BX_DONE ? 1 : 0;      // (every read passes here once)
     if (PH == 1) {                                  // hand the waiting reads over: one reservation per block
       __shared__ uint32_t cand_base;
       __syncthreads();
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     Rd rr = r;
     if (to_fine) rr.ok = false;
     emit(rr, bp, !in_list && rr.ok, to_fine, an);
+    if (bx.early && rr.ok && bp.mode == BX_DONE) bx.early[r.i] = 1;
   }
 }
 

@@ -556,10 +556,40 @@ __global__ void k_links_apply(const int64_t* links, const int32_t* n_links_p, in
 }
 
 // depth-code parameters and multiplicities of every read's records + its dropped bits, after all links are in
+// ---- the early tally (round 4) ------------------------------------------------------------------------------------------
+// Four reads in five are finished by the PLAN (k_bx_plan: a proven gap-free diagonal) and do not change while the band DPs work
+// on the rest -- a quarter of a millisecond per million reads during which the tally's LDS pipes have nothing to do.  Their tally
+// runs then, beside the DPs, on what is known of them at that point: end points, strand, bases.  What is NOT known yet is what the
+// cull decides (it needs every read's records: AlnSeq slots are numbered across all reads, `dropped` lives in the slot) -- the
+// read's dropped marks, and the parameters of formerly split or doubly listed records.  The early tally ASSUMES the ordinary
+// case (not dropped, listed once, its own depth codes: the record k_rec_early writes); k_rec_params, which knows, puts every
+// early read whose true record differs on a list, and k_tally_fix takes the assumed contribution off again and adds the true
+// one (integer sums: exact).  k_bx_plan marks the reads it finishes in early[].
+__device__ __forceinline__ void rec_default_params(const RecGeom& g, int n_al, int32_t* p, int* actf) {
+  const int flen = g.ncols_f, blen = g.split ? g.ncols_b : 0;          // a gap-free read: a record's asp_len is its columns
+  *actf = g.split ? g.ncols_f : n_al;
+  p[0] = 0; p[1] = 0; p[2] = flen + blen; p[3] = 1;
+  p[4] = g.split ? flen : 0; p[5] = g.split ? *actf : 0; p[6] = g.split ? flen + blen : 0; p[7] = g.split ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_rec_early(ReadSet rs, int32_t L, const uint8_t* early, int32_t* trec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rs.n || !early[i]) return;
+  const RecGeom g = rec_geom(rs.as[i], rs.ae[i], L);
+  int32_t p[8];
+  int actf;
+  rec_default_params(g, (int)rs.len[i], p, &actf);
+  int4* t4 = reinterpret_cast<int4*>(trec + i * 16);
+  t4[0] = make_int4(rs.as[i], rs.ae[i], (int32_t)(uint32_t)rs.len[i], (rs.rc[i] ? TRF_RC : 0) | TRF_DIAG | TRF_SK);      // (abr = 0: the plan's reads start in row 0)
+  t4[1] = make_int4(rs.refstart[i], (int32_t)rs.roff[i], actf, 0);
+  t4[2] = make_int4(p[0], p[1], p[2], p[3]);
+  t4[3] = make_int4(p[4], p[5], p[6], p[7]);
+}
+
 __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const uint8_t* slot_dropped, int64_t n_slots, const int64_t* back_slot,
                              RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, const int32_t* link_act, const int32_t* n_links_p,
                              int32_t cap, int64_t read_base,
-                             uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags, const int32_t* abort_if = nullptr) {
+                             uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags, const int32_t* abort_if = nullptr,
+                             const uint8_t* early = nullptr, int32_t* fix_list = nullptr, int32_t* n_fix = nullptr) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rs.n) return;
@@ -617,6 +647,15 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
   t4[1] = make_int4(rs.refstart[i], (int32_t)rs.roff[i], ri.actf[i], (int32_t)(st >> 8));                                // TREC_REFSTART, _ROFF, _ACTF, _SPARE
   t4[2] = make_int4(p[0], p[1], p[2], p[3]);                                                                              // TREC_PARAMS ..
   t4[3] = make_int4(p[4], p[5], p[6], p[7]);
+  if (early && early[i]) {
+    // tallied already, on the ordinary record (k_rec_early): does the true one say the same?
+    int32_t q[8];
+    int actf0;
+    rec_default_params(rec_geom(rs.as[i], rs.ae[i], L), (int)rs.len[i], q, &actf0);
+    bool same = df == 0 && db == 0 && rs.sk[i] && ri.actf[i] == actf0 && (st & ST_DIAG) && !(st & ST_TOO_LONG) && rs.abr[i] == 0;
+    for (int k = 0; k < 8; k++) same = same && p[k] == q[k];
+    if (!same) fix_list[atomicAdd(n_fix, 1)] = (int32_t)i;
+  }
 }
 
 // ---- tally: one read per wavefront, one read row per lane (4 passes for 256-base reads) ----
@@ -629,6 +668,7 @@ __device__ __forceinline__ int depth_code(int dff, int dfb) {   // src/fsdb.c:57
 // LDS and flushed once; anything outside the window (the back part of a read that wraps
 // around the origin) takes the global atomic.  Same integer sums either way.
 constexpr int TALLY_EV_CAP = 256;    // insert events a workgroup buffers in LDS
+constexpr int TALLY_CHUNK_LATE = 256;  // reads per workgroup of the tally's second half when the plan's reads went through the early tally
 constexpr int TALLY_BUCKET = 128, TALLY_WIN = 384, TALLY_CHUNK = 512;   // 20 KB of LDS per workgroup: 8 workgroups (32 waves) per CU
 
 // The LDS window of a workgroup is circular: slot k holds column win_base + k, and past the end of the reference the
@@ -767,10 +807,39 @@ __global__ __launch_bounds__(256) void k_tally(ReadSet rs, RefInfo ref, const in
 }
 
 // ---- bucketing of the reads by alignment start (counting sort, one pass per iteration) ----
+// the early tally's corrections: one read per wavefront, its assumed contribution (the record k_rec_early wrote) off again --
+// the same adds with multiplicity -1 -- and its true one (k_rec_params' record) on; global atomics (a handful of reads)
+__global__ __launch_bounds__(256) void k_tally_fix(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front, const uint8_t* drop_back, TallyBuf tb,
+                                                    const int32_t* rec_true, const int32_t* rec_early, const int32_t* rec_actf, const int32_t* fix_list,
+                                                    const int32_t* n_fix, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;
+  __shared__ int32_t stage[4][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = *n_fix;
+  for (int k = (int)blockIdx.x * 4 + wv; k < n; k += (int)gridDim.x * 4) {
+    const int i = fix_list[k];
+    if (lane < 16) {
+      int v = rec_early[(int64_t)i * 16 + lane];
+      if (lane == TREC_PARAMS + 3 || lane == TREC_PARAMS + 7) v = -v;          // the two records' multiplicities
+      stage[wv][lane] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    tally_one_read<false>(i, lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0, rec_early, rec_actf, nullptr, nullptr, nullptr, nullptr, stage[wv]);
+    __builtin_amdgcn_wave_barrier();
+    tally_one_read<false>(i, lane, rs, ref, pssm2, drop_front, drop_back, tb, nullptr, 0, rec_true, rec_actf, nullptr, nullptr, nullptr);
+  }
+}
+
 constexpr int BUCKET_PER = 8;   // reads per thread of the bucketing kernels
 // zero / zero_words: a buffer this launch clears on the side (the tally, the gaps and the ranks' event-count slots behind them:
 // nothing adds to them before the tally kernel, which runs behind this one), or nullptr
-__global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count, int32_t* zero, int64_t zero_words, const int32_t* abort_if = nullptr) {
+// part / want (the early tally, k_rec_early): only the reads with (part[i] != 0) == (want != 0) are sorted; part == nullptr: all
+__device__ __forceinline__ bool bucket_takes(const ReadSet& rs, int64_t i, const uint8_t* part, int want) {
+  return i < rs.n && rs.sk[i] && (!part || (part[i] != 0) == (want != 0));
+}
+__global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count, int32_t* zero, int64_t zero_words, const int32_t* abort_if = nullptr,
+                                                       const uint8_t* part = nullptr, int32_t want = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   extern __shared__ int32_t hist[];
   for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
@@ -778,19 +847,21 @@ __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, in
   __syncthreads();
   for (int k = 0; k < BUCKET_PER; k++) {
     const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
-    if (i < rs.n && rs.sk[i]) atomicAdd(&hist[min(rs.as[i] / TALLY_BUCKET, nb - 1)], 1);
+    if (bucket_takes(rs, i, part, want)) atomicAdd(&hist[min(rs.as[i] / TALLY_BUCKET, nb - 1)], 1);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nb; b += blockDim.x) if (hist[b]) atomicAdd(&count[b], hist[b]);
 }
 // off[b] = first read of bucket b in `order`, wgoff[b] = first workgroup of bucket b (TALLY_CHUNK reads each)
-__global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor, int32_t* wg_bucket, const int32_t* abort_if = nullptr) {
+// chunk: reads per tally workgroup (TALLY_CHUNK at most; the late half of a split tally takes fewer -- its reads are the slow ones)
+__global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb, int32_t* off, int32_t* wgoff, int32_t* cursor, int32_t* wg_bucket, const int32_t* abort_if = nullptr,
+                                                      int32_t chunk = TALLY_CHUNK) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   // one workgroup of 256 threads: every thread a stretch of buckets, a scan over the 256 partial sums in LDS
   __shared__ int32_t s_run[256], s_wg[256];
   const int t = threadIdx.x, per = (nb + 255) / 256, b0 = t * per, b1 = b0 + per < nb ? b0 + per : nb;
   int run = 0, wg = 0;
-  for (int b = b0; b < b1; b++) { run += count[b]; wg += (count[b] + TALLY_CHUNK - 1) / TALLY_CHUNK; }
+  for (int b = b0; b < b1; b++) { run += count[b]; wg += (count[b] + chunk - 1) / chunk; }
   s_run[t] = run; s_wg[t] = wg;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
@@ -803,14 +874,15 @@ __global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb,
   for (int b = b0; b < b1; b++) {
     off[b] = r; wgoff[b] = w; cursor[b] = 0;
     const int cb = count[b];
-    const int nw = (cb + TALLY_CHUNK - 1) / TALLY_CHUNK;
+    const int nw = (cb + chunk - 1) / chunk;
     for (int q = 0; q < nw; q++) wg_bucket[w + q] = b;          // (the tally's workgroups look their bucket up instead of searching wgoff)
     r += cb; w += nw;
     count[b] = 0;                                               // read for the last time: clean for the next call's k_bucket_count
   }
   if (t == 255) { off[nb] = s_run[255]; wgoff[nb] = s_wg[255]; }
 }
-__global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order, const int32_t* abort_if = nullptr) {
+__global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order, const int32_t* abort_if = nullptr,
+                                                      const uint8_t* part = nullptr, int32_t want = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   extern __shared__ int32_t sh[];
   int32_t* hist = sh;
@@ -821,7 +893,7 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
   for (int k = 0; k < BUCKET_PER; k++) {
     const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
     bb[k] = -1; rank[k] = 0;
-    if (i < rs.n && rs.sk[i]) { bb[k] = min(rs.as[i] / TALLY_BUCKET, nb - 1); rank[k] = atomicAdd(&hist[bb[k]], 1); }
+    if (bucket_takes(rs, i, part, want)) { bb[k] = min(rs.as[i] / TALLY_BUCKET, nb - 1); rank[k] = atomicAdd(&hist[bb[k]], 1); }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < nb; k += blockDim.x) if (hist[k]) base[k] = atomicAdd(&cursor[k], hist[k]);
@@ -832,12 +904,23 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
   }
 }
 
-template <bool LINEAR>
+#ifdef MIA_HIP_ALT_PATHS
+// (MIA_HIP_DEBUG_SKIP & 65536, alt build: how many reads take which route of k_tally_binned -- tools/tally_kinds_probe.py)
+__device__ unsigned long long g_tally_kinds[8];
+#define TALLY_KIND(k) do { if (dbg & 65536u) atomicAdd(&g_tally_kinds[k], 1ull); } while (0)
+#else
+#define TALLY_KIND(k) do { } while (0)
+#endif
+// DEFER: the reads that fit none of the one-read-per-lane routes (two gaps, soft ends, odd records: a thousand in a million) are
+// not tallied here, one per wavefront while the other lanes wait, but put on gen_list for k_tally_reduce's extra workgroups.  Seven hundred such reads cost 54 of this kernel's 215 us per million reads: every one of them is a stretch of code
+// nobody else runs (instruction fetches from memory) and a chain of loads in front of a workgroup's barrier.
+template <bool LINEAR, bool DEFER>
 __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
                                                        const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, const uint64_t* rplanes,
-                                                       int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket, int32_t pk_bias, const int32_t* abort_if = nullptr) {
+                                                       int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket, int32_t pk_bias, const int32_t* abort_if = nullptr,
+                                                       int32_t chunk_reads = TALLY_CHUNK, int32_t* gen_list = nullptr, int32_t* n_gen = nullptr) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   constexpr bool linear = LINEAR;
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
@@ -869,7 +952,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   __shared__ int ev_cnt, ev_base;
   if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
   const int b = wg_bucket[blockIdx.x], chunk = (int)blockIdx.x - wgoff[b];     // (k_bucket_scan's table)
-  const int first = off[b] + chunk * TALLY_CHUNK, last = min(first + TALLY_CHUNK, off[b + 1]);
+  const int first = off[b] + chunk * chunk_reads, last = min(first + chunk_reads, off[b + 1]);
   const int win_base = b * TALLY_BUCKET;
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) lds[k] = 0;
   for (int k = threadIdx.x; k < 2 * PSSM_WORDS; k += blockDim.x) pssm_lds[k] = (int16_t)pssm2[k];
@@ -988,7 +1071,22 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
                    ncol > 0 && w0 + ncol <= TALLY_WIN && g.start_w + ncol <= Lp && ncol == g.ncols_f && gn > 0 && grow > abr && grow + (ins ? gn : 0) < len2;
         if (one_here) { og_row = grow; og_n = gn; og_ins = ins; }
       }
-      if ((fast || one_here) && !(dbg & 8u)) {
+      // LINEAR: a one-gap read whose two stretches fit the vertical counters is taken HERE as well, its loads (record, planes, the
+      // inserted bases' word) side by side with the gap-free reads' -- in a block of its own further down the tenth of the lanes
+      // that have one waited for the same chain of loads a second time, 39 of the tally's 215 us per million reads.
+      bool one_sl = false;
+      int sl_ins = 0, sl_row = 0, sl_n = 0, sl_ncol = 0;
+      if (LINEAR && !fast && (flags & TRF_ONEGAP) && bs_on && abr == 0 && len2 <= 128 && !(dbg & (8u | 2048u))) {
+        const uint32_t desc = (uint32_t)b4.w;
+        const int ins = (int)(desc & 1u), grow = (int)((desc >> 1) & 511u), gn = (int)((desc >> 10) & 63u);
+        const int ncol = ins ? n_al - gn : n_al + gn;
+        one_sl = (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && !(flags & TRF_DIAG) && !g.split && fMult == 1 && fBase == 0 && fOff == 0 && w0 >= 0 &&
+                 ncol > 0 && w0 + ncol <= 64 * BS_W && g.start_w + ncol <= Lp && ncol == g.ncols_f && gn > 0 && grow > abr && grow + (ins ? gn : 0) < len2 &&
+                 umax[i] >= 0;
+        if (one_sl) { sl_ins = ins; sl_row = grow; sl_n = gn; sl_ncol = ncol; }
+      }
+      if (fast) TALLY_KIND(0);
+      if ((fast || one_here || one_sl) && !(dbg & 8u)) {
         const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);    // reads start on 4-byte boundaries
         const bool dF = (flags & TRF_DF) != 0;
         lds_i32* t = (lds_i32*)lds + w0;
@@ -998,9 +1096,45 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
           // depth codes are not needed for the sums; they only have to be valid: act <= 15 always is, beyond that
           // dfb = fB - act - 1 must not be negative (depth_code above)
           bad = n_al > PSSM_DEPTH + 1 && fB < n_al;
-          if (!dF && bs_on && abr == 0 && len2 <= 128 && w0 + n_al <= 64 * BS_W && umax[i] >= 0) {
+          const bool fast_sl = !one_sl && !dF && bs_on && abr == 0 && len2 <= 128 && w0 + n_al <= 64 * BS_W && umax[i] >= 0;
+          unsigned long long l0 = 0, l1 = 0, h0 = 0, h1 = 0;
+          uint32_t iw0 = 0, iw1 = 0;
+          if ((fast_sl || (one_sl && !dF)) ) {
             const uint64_t* pl = rplanes + (int64_t)i * 2 * rplane_words;
-            bs_count(pl[0], rplane_words > 1 ? pl[1] : 0ull, pl[rplane_words], rplane_words > 1 ? pl[rplane_words + 1] : 0ull, 0, n_al, w0);
+            l0 = pl[0]; l1 = rplane_words > 1 ? pl[1] : 0ull; h0 = pl[rplane_words]; h1 = rplane_words > 1 ? pl[rplane_words + 1] : 0ull;
+          }
+          if (one_sl && sl_ins) { iw0 = rp[sl_row >> 3]; iw1 = rp[(sl_row + sl_n - 1) >> 3]; }
+          if (one_sl) {
+            TALLY_KIND(3); TALLY_KIND(4);
+            // the two stretches of the read either side of its gap through the vertical counters; deleted reference columns count
+            // as '-', inserted read rows become insert events at the column that follows (src/map_align.c:444-510)
+            const int grow = sl_row, gn = sl_n, ins = sl_ins;
+            if (!dF) {
+              const int r2 = ins ? grow + gn : grow;                       // first row behind the gap, at column w0 + grow (+ gn behind a deletion)
+              bs_count(l0, l1, h0, h1, 0, grow, w0);
+              bs_count(l0, l1, h0, h1, r2, len2 - r2, w0 + grow + (ins ? 0 : gn));
+              if (!ins) for (int q = 0; q < gn; q++) aadd(&t[T_GAP * TALLY_WIN + grow + q], 1);
+            }
+            if (ins)
+              for (int j = 0; j < gn; j++) {
+                const int r = grow + j;
+                const uint32_t wj = (r >> 3) == (grow >> 3) ? iw0 : ((r >> 3) == ((grow + gn - 1) >> 3) ? iw1 : rp[r >> 3]);
+                const int code = (int)((wj >> ((r & 7) * 4)) & 15u);
+                const int gc = g.start_w + grow, act = grow + gn;
+                if (j == 0) atomicMax(&tb.gaps[gc], gn);
+                const int d = depth_code(act, fB - act - 1);
+                const uint64_t ev = (uint64_t)(uint32_t)gc | ((uint64_t)j << 32) | ((uint64_t)code << 42) | ((uint64_t)(d & 31) << 45) |
+                                    ((uint64_t)((flags & TRF_RC) ? 1 : 0) << 50);
+                const int slot = atomicAdd(&ev_cnt, 1);
+                if (slot < TALLY_EV_CAP) ev_buf[slot] = ev;
+                else {
+                  const int e = atomicAdd(tb.n_events, 1);
+                  if (e < tb.cap_events) tb.events[e] = ev; else atomicOr(tb.flags, 1u);
+                }
+              }
+          } else if (fast_sl) {
+            TALLY_KIND(1);
+            bs_count(l0, l1, h0, h1, 0, n_al, w0);
           } else if (!dF) {
             lds_i32* nc = (lds_i32*)n_cnt + w0;
             for (int act = 0; act < n_al; act++) {
@@ -1037,13 +1171,15 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
           t++;
         }
         }
-        if (fast) {
-        // coverage (not dropped): columns w0 .. w0+n_al-1; span (start < pos <= end, dropped or not): w0+1 .. w0+n_al-1
-        if (!dF) { aadd((lds_i32*)cov_diff + w0, 1); if (w0 + n_al < TALLY_WIN) aadd((lds_i32*)cov_diff + w0 + n_al, -1); }
-        if (n_al > 1) { aadd((lds_i32*)span_diff + w0 + 1, 1); if (w0 + n_al < TALLY_WIN) aadd((lds_i32*)span_diff + w0 + n_al, -1); }
+        if (fast || one_sl) {
+        // coverage (not dropped): columns w0 .. w0+n-1; span (start < pos <= end, dropped or not): w0+1 .. w0+n-1 (n: the read's columns)
+        const int nc = one_sl ? sl_ncol : n_al;
+        if (!dF) { aadd((lds_i32*)cov_diff + w0, 1); if (w0 + nc < TALLY_WIN) aadd((lds_i32*)cov_diff + w0 + nc, -1); }
+        if (nc > 1) { aadd((lds_i32*)span_diff + w0 + 1, 1); if (w0 + nc < TALLY_WIN) aadd((lds_i32*)span_diff + w0 + nc, -1); }
         if (bad | (int)(word & (dbg & 16u ? 0x40000000u : 0u))) atomicOr(tb.flags, 2u);
         }
       }
+      if (one_sl) fast = true;
     }
     // Proven-diagonal reads that run over the origin (two records: front in this window, back at the start of the
     // reference) all start in the last bucket, where nine reads in ten are of this kind: one per lane as well, every base
@@ -1060,6 +1196,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
                          w0 + g.ncols_f <= TALLY_WIN && n_al == g.ncols_f + g.ncols_b && n_al > 0 && actF == g.ncols_f;
       if (wrap2) {
         fast = true;
+        TALLY_KIND(2);
         const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);
         const bool dF = (flags & TRF_DF) != 0, dB = (flags & TRF_DB) != 0;
         const int fBase = c4.x, fOff = c4.y, fB = c4.z, fMult = c4.w, bBase = d4.x, bOff = d4.y, bB = d4.z, bMult = d4.w;
@@ -1133,6 +1270,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
                        gn > 0 && grow > abr && grow + (ins ? gn : 0) < len2;
       if (one) {
         fast = true;
+        TALLY_KIND(3);
         if (!(dbg & 2048u)) {
         const uint32_t* rp = reinterpret_cast<const uint32_t*>(rs.packed + (uint32_t)b4.y);
         const bool dF = (flags & TRF_DF) != 0;
@@ -1141,6 +1279,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
         uint32_t word = 0;
         const bool sliced = LINEAR && bs_on && abr == 0 && len2 <= 128 && w0 + ncol <= 64 * BS_W && umax[i] >= 0;
         if (sliced) {
+          TALLY_KIND(4);
           // the two stretches of the read either side of its gap through the vertical counters; the gap itself as before
           if (!dF) {
             const uint64_t* pl = rplanes + (int64_t)i * 2 * rplane_words;
@@ -1224,8 +1363,22 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
     // script and bases.  The record is already in the registers of the lane that owns the read and is handed over
     // through LDS; script and bases are touched by all owning lanes first, side by side, so that the serial part finds
     // them in L2.
+    if (DEFER) {
+      const bool mine = have && !fast && !(dbg & 32u);
+      const unsigned long long m = __ballot(mine);
+      if (m) {                                              // one reservation per wavefront
+        int base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(n_gen, __builtin_popcountll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (mine) { TALLY_KIND(5); gen_list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i; }
+      }
+      continue;
+    }
     int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
     if (have && !fast) {
+      TALLY_KIND(5);
+      if (reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16)[0].w & TRF_ONEGAP) TALLY_KIND(6);
+      if (reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16)[0].w & TRF_DIAG) TALLY_KIND(7);
       const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16);
       r0 = tr4[0]; r1 = tr4[1]; r2 = tr4[2]; r3 = tr4[3];
       const int16_t* cl = rs.cols + (int64_t)i * rs.stride;
@@ -1404,12 +1557,29 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
 // tally[word][gc] += sum of the windows that cover column gc: buckets floor(gc/128)-2 .. floor(gc/128), all their chunks,
 // and the last buckets' windows where they wrap around to the start of the reference.
 // Runs after k_tally_binned; nothing else writes the tally then, so plain read-modify-write.
-__global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs, const int32_t* abort_if = nullptr) {
+// gen (gen.list != nullptr): the reads k_tally_binned<.., true> put aside are tallied by TALLY_GEN_BLOCKS further workgroups of this
+// launch, one read per wavefront, straight into the tally -- every add of this kernel is an atomic, so the two kinds of workgroup
+// do not have to wait for each other (a launch of their own behind this one was 22 us for seven hundred reads).
+struct GenReads {
+  ReadSet rs; RefInfo ref; const int32_t* pssm2; const uint8_t* drop_front; const uint8_t* drop_back; const int32_t* rec_params; const int32_t* rec_actf;
+  const int32_t* list; const int32_t* n;
+};
+constexpr int TALLY_GEN_BLOCKS = 192;
+__global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs, const int32_t* abort_if, GenReads gen) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
+  const int Lp = tb.Lp;
+  const int col_blocks = (Lp + 255) / 256;
+  if ((int)blockIdx.x >= col_blocks) {
+    if (blockIdx.y != 0 || !gen.list) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = *gen.n;
+    for (int k = ((int)blockIdx.x - col_blocks) * 4 + wv; k < n; k += TALLY_GEN_BLOCKS * 4)
+      tally_one_read<false>(__builtin_amdgcn_readfirstlane(gen.list[k]), lane, gen.rs, gen.ref, gen.pssm2, gen.drop_front, gen.drop_back, tb, nullptr, 0, gen.rec_params,
+                            gen.rec_actf, nullptr, nullptr, nullptr);
+    return;
+  }
   // one thread per (column, tally word): blockIdx.y is the word (a thread per column alone is 66 workgroups for a
   // mitochondrion, each thread a chain of five hundred loads)
   const int gc = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
-  const int Lp = tb.Lp;
   if (gc >= Lp) return;
   int acc = 0;
   const int bhi = min(gc / TALLY_BUCKET, nb - 1);
@@ -1424,7 +1594,7 @@ __global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, c
     if (wc < 0 || wc >= TALLY_WIN || gc >= b * TALLY_BUCKET) continue;     // (columns from win_base on sit in their direct slot)
     for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
   }
-  if (acc) tb.tally[w * Lp + gc] += acc;
+  if (acc) (void)__hip_atomic_fetch_add(&tb.tally[w * Lp + gc], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- ma: tally of stored AlnSeq records (show_consensus, src/map_alignment.c:139-170) -------------

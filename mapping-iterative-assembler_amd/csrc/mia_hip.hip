@@ -37,8 +37,9 @@ static const char* const STAGE_NAMES[STG_COUNT] = {"k_align_quad", "k_align_quad
 constexpr int CTRL_BINS = 0;                                   // [count N_BINS][off N_BINS][cursor N_BINS][wide_count][retry_count]
 constexpr int CTRL_HDR = (3 * N_BINS + 2 + 1) & ~1;            // PH_* (8-byte aligned: the DP kernels fetch their range as a pair)
 constexpr int CTRL_FILTER = CTRL_HDR + PH_WORDS;               // 4 words (k_diag_filter / k_band_align)
-constexpr int CTRL_LKN = CTRL_FILTER + 4, CTRL_CULLF = CTRL_LKN + 1, CTRL_NEV = CTRL_CULLF + 1, CTRL_TFLAGS = CTRL_NEV + 1;
-constexpr int CTRL_BXC = (CTRL_TFLAGS + 1 + 63) & ~63;         // BXC_* counters, a cache line each
+constexpr int CTRL_LKN = CTRL_FILTER + 4, CTRL_CULLF = CTRL_LKN + 1, CTRL_NEV = CTRL_CULLF + 1, CTRL_TFLAGS = CTRL_NEV + 1, CTRL_FIXN = CTRL_TFLAGS + 1;   // FIXN: reads on the early tally's fix list
+constexpr int CTRL_GENN = CTRL_FIXN + 1;                           // reads k_tally_binned left to k_tally_general
+constexpr int CTRL_BXC = (CTRL_GENN + 1 + 63) & ~63;           // BXC_* counters, a cache line each
 constexpr int CTRL_WORDS = CTRL_BXC + BXC_WORDS;
 constexpr int CTRL_C0 = CTRL_BINS + 3 * N_BINS, CTRL_CN = CTRL_WORDS - CTRL_C0;    // what the host looks at behind an alignment: wide / retry counts, planner header, filter and band counters
 
@@ -83,6 +84,14 @@ struct mia_hip_ctx {
   bool no_spec = false;                     // MIA_HIP_NO_SPEC=1: wait for the alignment's counters before the cull is queued
   bool no_side_buckets = false;             // MIA_HIP_NO_SIDE_BUCKETS=1
   int buckets_queued = 0;                   // the tally's counting sort is already queued: 1 on the context's stream, 2 on stream2 (ev_join behind it)
+  // the early tally (mia_consensus_kernels.h, k_rec_early): the reads the plan finishes are tallied on stream4 beside the band DPs
+  hipStream_t stream4 = nullptr; hipEvent_t ev_early = nullptr;
+  // MIA_HIP_EARLY_TALLY=1 (alt build only; an experiment that measured SLOWER): the plan's reads tallied beside the band DPs
+  bool use_early = false, early_queued = false;
+  int early_wgs_per_cu = 2;
+  uint8_t* d_early = nullptr; int32_t* d_trec_early = nullptr; int32_t* d_order_e = nullptr; int32_t* d_fix_list = nullptr; int64_t early_cap = 0;
+  int32_t* d_bucket_e = nullptr; int bucket_e_cap = 0, bucket_e_clean_nb = -1;
+  int32_t* d_tally_slabs_e = nullptr; int64_t tally_slab_e_cap = 0;
   unsigned char* d_slabs_retry[3] = {nullptr, nullptr, nullptr};      // trace slabs of the band kernels' retry launch (see launch_window)
   bool bx_planner_aside = false;            // this call: the planner and the full-window kernels run on stream2, the band DPs on the context's stream
   bool bx_pending_join = false;                                                     // band kernels are still running on stream2 / stream3
@@ -190,6 +199,8 @@ struct mia_hip_ctx {
   int32_t* d_bucket = nullptr; int bucket_cap = 0; int32_t* d_order = nullptr;
   int use_binned_tally = 1;   // MIA_HIP_NO_BINNED_TALLY=1: plain global-atomic tally
   int32_t* d_tally_slabs = nullptr; int64_t tally_slab_cap = 0;   // one LDS window per tally workgroup, summed by k_tally_reduce
+  int32_t* d_gen_list = nullptr; int64_t gen_cap = 0;             // the reads k_tally_binned leaves to k_tally_general (a thousand in a million; room for all)
+  bool tally_defer = true;                                        // MIA_HIP_TALLY_INLINE=1 (alt build): they are taken inside k_tally_binned, one per wavefront
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
   // timing
@@ -312,6 +323,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
   if (hipSetDevice(device_index) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join3, evf) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_early, evf) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, evf) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, evf) != hipSuccess) {
     delete ctx;
     return MIA_HIP_ERR_DEVICE;
@@ -358,6 +370,9 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (egs && atoi(egs)) ctx->lazy_scripts = 0;
     const char* nwl = alt_env("MIA_HIP_NO_WILD");
     if (nwl && atoi(nwl)) ctx->use_wild = 0;
+    if (const char* ne = alt_env("MIA_HIP_EARLY_TALLY")) ctx->use_early = atoi(ne) != 0;
+    if (const char* ti = alt_env("MIA_HIP_TALLY_INLINE")) ctx->tally_defer = atoi(ti) == 0;
+    if (const char* ew = alt_env("MIA_HIP_EARLY_WGS")) ctx->early_wgs_per_cu = atoi(ew);
     if (const char* nf = alt_env("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
     if (const char* nf = alt_env("MIA_HIP_FINE")) ctx->use_fine = atoi(nf);
     const char* bxf = alt_env("MIA_HIP_BX_FILTER");
@@ -425,6 +440,10 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
+  if (ctx->ev_early) (void)hipEventDestroy(ctx->ev_early);
+  if (ctx->d_gen_list) (void)hipFree(ctx->d_gen_list);
+  for (void* p : {(void*)ctx->d_early, (void*)ctx->d_trec_early, (void*)ctx->d_order_e, (void*)ctx->d_fix_list, (void*)ctx->d_bucket_e, (void*)ctx->d_tally_slabs_e}) if (p) (void)hipFree(p);
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
   if (ctx->d_retry2) (void)hipFree(ctx->d_retry2);
   if (ctx->d_cull_sync) (void)hipFree(ctx->d_cull_sync);
@@ -760,6 +779,17 @@ extern "C" int mia_hip_bx_stats(mia_hip_ctx* ctx, int reset, int64_t* reads4, do
   return MIA_HIP_OK;
 }
 
+#ifdef MIA_HIP_ALT_PATHS
+// (alt build only, not in include/mia_hip.h: the counts MIA_HIP_DEBUG_SKIP & 65536 collects in k_tally_binned, and their reset)
+extern "C" int mia_hip_debug_tally_kinds(mia_hip_ctx* ctx, uint64_t* out8) {
+  if (!ctx || !out8) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tally_kinds), 8 * sizeof(uint64_t)));
+  uint64_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tally_kinds), z, sizeof z));
+  return MIA_HIP_OK;
+}
+#endif
 extern "C" int mia_hip_bx_counters(mia_hip_ctx* ctx, uint32_t* out32) {
   if (!ctx || !out32) return MIA_HIP_ERR_ARG;
   for (int k = 0; k < BXC_COUNTERS; k++) out32[k] = ctx->bx_last[k];
@@ -844,6 +874,8 @@ static int bx_join_and_retry(mia_hip_ctx* ctx) {
 }
 
 static int align_all(mia_hip_ctx* ctx);
+static int early_tally_launch(mia_hip_ctx* ctx);
+static bool tally_is_binned(const mia_hip_ctx* ctx);
 static int comm_pre_cull_enqueue(mia_hip_ctx* ctx, const int32_t* d_wide_count);
 static bool comm_pre_cull_collect(mia_hip_ctx* ctx);
 
@@ -956,6 +988,7 @@ static int align_all(mia_hip_ctx* ctx) {
   ctx->bx_planner_aside = false;
   ctx->planner_end_signalled = false; ctx->align_end_signalled = false;
   ctx->buckets_queued = 0;                  // (a counting sort queued for an earlier alignment is void)
+  ctx->early_queued = false;
   if (n == 0) { ctx->aligned = true; return MIA_HIP_OK; }
   RefInfo ref{ctx->d_ref, ctx->L, wrap, ctx->explicit_win};
   int32_t* d_count = ctx->d_bins;
@@ -1120,6 +1153,18 @@ static int align_all(mia_hip_ctx* ctx) {
       // Through the values DP their left-overs land on the late lists, i.e. on the step's critical path (late trace 0.125 -> 0.17 ms per
       // 1 M flat reads); where the lists are short anyway they go straight to the trace DP on its own stream instead.
       bd.wide_to_trace = (new_flow && !fine) ? 1 : 0;
+      // the early tally (k_rec_early): the plan marks the reads it finishes, their tally runs on stream4 beside the band DPs.  Only in
+      // mia_hip_iterate (the whole step is queued at once), for read sets small enough that the step is a chain of latencies.
+      const bool early = ctx->deferred && new_flow && ctx->use_early && !run_filter && tally_is_binned(ctx) && n <= 4000000;
+      bd.early = nullptr;
+      if (early) {
+        if (n > ctx->early_cap) {
+          if (dev_alloc(ctx, &ctx->d_early, (size_t)n) || dev_alloc(ctx, &ctx->d_trec_early, (size_t)n * 16) || dev_alloc(ctx, &ctx->d_order_e, (size_t)n) ||
+              dev_alloc(ctx, &ctx->d_fix_list, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+          ctx->early_cap = n;
+        }
+        bd.early = ctx->d_early;
+      }
       // ... and where the plan's third launch is off (flat matrix, a million reads, hardly any rejects: the step is a chain of
       // latencies) the widest class is not used at all: those few reads keep going to the full-window kernels on the planner's stream,
       // whose chain is as long with them as without (measured: 0.960 against 0.944 ms per step with the class in use)
@@ -1161,6 +1206,7 @@ static int align_all(mia_hip_ctx* ctx) {
           if (!fork_by_launch) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
           HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
           HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
+          if (early) HIPCHK(hipStreamWaitEvent(ctx->stream4, ctx->ev_fork, 0));
           if (stage_begin(ctx, STG_BX_TRACE, ctx->stream3)) return MIA_HIP_ERR_NOMEM;
           const bool sig3 = (ctx->ext_events & 2u) && new_flow && !(ctx->bx_dbg & 8u);
           if (!(ctx->bx_dbg & 8u))
@@ -1176,6 +1222,8 @@ static int align_all(mia_hip_ctx* ctx) {
           HIPCHK(hipGetLastError());
           ctx->bx_planner_aside = ctx->deferred;
           ctx->bx_pending_join = true;
+          // (queued behind the band DPs on the host side: the GPU starts it as soon as the plan's last launch is done)
+          if (early) { if (int rce = early_tally_launch(ctx)) return rce; }
         } else {
         // The two band DPs do not depend on each other (a read the values DP cannot finish stays open for the full-window
         // kernels): they run side by side on two streams -- both are persistent grids whose wavefronts leave as soon as the
@@ -1547,7 +1595,8 @@ static int finish_params(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   hipLaunchKernelGGL(k_rec_params, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
                      ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->d_link_act, ctx->d_n_links_all,
-                     (int32_t)ctx->links_cap_all, ctx->read_base, ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags, ctx->abort_if);
+                     (int32_t)ctx->links_cap_all, ctx->read_base, ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags, ctx->abort_if,
+                     ctx->early_queued ? ctx->d_early : (const uint8_t*)nullptr, ctx->d_fix_list, ctx->d_ctrl + CTRL_FIXN);
   HIPCHK(hipGetLastError());
   return MIA_HIP_OK;
 }
@@ -1893,7 +1942,10 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
   const int64_t tally_words = (int64_t)(TALLY_WORDS + 1) * Lp + 256;                               // tally, gaps, the ranks' event counts
   const int64_t n = ctx->rs.n;
   const int nb = ctx->wrap / TALLY_BUCKET + 1;
-  const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
+  // (behind an early tally what is left are the reads with substitutions and gaps -- a fifth of them, and the slow ones: smaller shares
+  // per workgroup, or a few hundred workgroups with 512 slow reads each take longer than the whole tally did)
+  const int chunk = ctx->early_queued ? TALLY_CHUNK_LATE : TALLY_CHUNK;
+  const int grid = (int)(n / chunk) + nb + 1;
   if (4 * (nb + 1) + grid > ctx->bucket_cap) {
     if (dev_alloc(ctx, &ctx->d_bucket, (size_t)(4 * (nb + 1) + grid) * 2)) return MIA_HIP_ERR_NOMEM;
     ctx->bucket_cap = (4 * (nb + 1) + grid) * 2;
@@ -1904,13 +1956,72 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
   // the bucket counts are left at zero by k_bucket_scan; only a fresh (or differently laid out) buffer is cleared here
   if (ctx->bucket_clean_nb != nb) { HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, on)); ctx->bucket_clean_nb = nb; }
   const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
-  hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words, ctx->abort_if);
-  hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb, ctx->abort_if);
+  // (with an early tally queued: only the reads it did not take, and the tally buffers are left alone -- its own sort cleared them)
+  const uint8_t* part = ctx->early_queued ? ctx->d_early : nullptr;
+  hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, part ? (int32_t*)nullptr : ctx->tb.tally, part ? (int64_t)0 : tally_words,
+                     ctx->abort_if, part, 0);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb, ctx->abort_if, chunk);
   const bool sigb = on != ctx->stream && (ctx->ext_events & 16u);
-  launch_k(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, sigb ? ctx->ev_join : nullptr, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if);
+  launch_k(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, sigb ? ctx->ev_join : nullptr, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if, part, 0);
   HIPCHK(hipGetLastError());
   if (on != ctx->stream && !sigb) HIPCHK(hipEventRecord(ctx->ev_join, on));
   ctx->buckets_queued = on != ctx->stream ? 2 : 1;
+  return MIA_HIP_OK;
+}
+
+// The early tally: record, counting sort and LDS-window tally of the reads the plan has finished, on stream4 (behind ev_fork);
+// ev_early tells tally_launch when its windows may be summed.  None of its kernels looks at abort_if: the reads it takes do not
+// change if the step's second half is queued again (reads for the exact kernel), and its sort clears the tally buffers once.
+static int early_tally_launch(mia_hip_ctx* ctx) {
+  if (int rc = ensure_tally(ctx)) return rc;
+  hipStream_t on = ctx->stream4;
+  const int Lp = ctx->tb.Lp;
+  const int64_t tally_words = (int64_t)(TALLY_WORDS + 1) * Lp + 256;
+  const int64_t n = ctx->rs.n;
+  const int nb = ctx->wrap / TALLY_BUCKET + 1;
+  const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
+  if (4 * (nb + 1) + grid > ctx->bucket_e_cap) {
+    if (dev_alloc(ctx, &ctx->d_bucket_e, (size_t)(4 * (nb + 1) + grid) * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->bucket_e_cap = (4 * (nb + 1) + grid) * 2;
+    ctx->bucket_e_clean_nb = -1;
+  }
+  int32_t *d_cnt = ctx->d_bucket_e, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1), *d_wgb = d_cur + (nb + 1);
+  if (ctx->bucket_e_clean_nb != nb) { HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)(nb + 1) * 4, on)); ctx->bucket_e_clean_nb = nb; }
+  const int64_t slab_words = (int64_t)grid * (TALLY_WORDS - 1) * TALLY_WIN;
+  if (slab_words > ctx->tally_slab_e_cap) {
+    if (dev_alloc(ctx, &ctx->d_tally_slabs_e, (size_t)slab_words)) return MIA_HIP_ERR_NOMEM;
+    ctx->tally_slab_e_cap = slab_words;
+  }
+  RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
+  hipLaunchKernelGGL(k_rec_early, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, on, ctx->rs, ctx->L, (const uint8_t*)ctx->d_early, ctx->d_trec_early);
+  const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
+  hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words, (const int32_t*)nullptr,
+                     (const uint8_t*)ctx->d_early, 1);
+  hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb, (const int32_t*)nullptr, TALLY_CHUNK);
+  hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, ctx->rs, nb, (const int32_t*)d_off, d_cur, ctx->d_order_e, (const int32_t*)nullptr,
+                     (const uint8_t*)ctx->d_early, 1);
+  const bool planes_ok = ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax;
+  // This launch has the whole band-DP phase to finish in and must not take the DPs' issue slots: extra LDS per workgroup (unused)
+  // keeps it to `early_wgs_per_cu` workgroups per compute unit (MIA_HIP_EARLY_WGS, alt build; 0: no limit)
+  size_t throttle = 0;
+  if (ctx->early_wgs_per_cu > 0) {
+    const size_t lds_static = ctx->tally_linear ? 27 * 1024 : 41 * 1024, want = (size_t)(160 * 1024) / (size_t)ctx->early_wgs_per_cu;
+    if (want > lds_static + 1024) throttle = std::min<size_t>(want - lds_static - 512, (size_t)(64 * 1024) - lds_static - 512);
+  }
+  // (the plan's reads all take the one-read-per-lane route: nothing of this launch goes to k_tally_general)
+  if (ctx->tally_linear
+        ? stage_launch(ctx, STG_TALLY, k_tally_binned<true, false>, dim3(grid), dim3(256), throttle, on, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
+                       ctx->tb, nb, d_off, d_wgoff, ctx->d_order_e, ctx->d_trec_early, ctx->ri.actf, ctx->d_tally_slabs_e, ctx->dbg,
+                       planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb, -1, (const int32_t*)nullptr, (int32_t)TALLY_CHUNK,
+                       (int32_t*)nullptr, (int32_t*)nullptr)
+        : stage_launch(ctx, STG_TALLY, k_tally_binned<false, false>, dim3(grid), dim3(256), throttle, on, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
+                       ctx->tb, nb, d_off, d_wgoff, ctx->d_order_e, ctx->d_trec_early, ctx->ri.actf, ctx->d_tally_slabs_e, ctx->dbg,
+                       (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb, ctx->tally_pk_bias, (const int32_t*)nullptr, (int32_t)TALLY_CHUNK,
+                       (int32_t*)nullptr, (int32_t*)nullptr))
+    return MIA_HIP_ERR_NOMEM;
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(ctx->ev_early, on));
+  ctx->early_queued = true;
   return MIA_HIP_OK;
 }
 
@@ -1934,7 +2045,8 @@ static int tally_launch(mia_hip_ctx* ctx) {
       if (!ctx->buckets_queued) { if (int rcb = bucket_launch(ctx, ctx->stream)) return rcb; }
       if (ctx->buckets_queued == 2) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
       ctx->buckets_queued = 0;
-      const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
+      const int chunk = ctx->early_queued ? TALLY_CHUNK_LATE : TALLY_CHUNK;
+      const int grid = (int)(n / chunk) + nb + 1;
       int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1), *d_wgb = d_cur + (nb + 1);
       const int64_t slab_words = (int64_t)grid * (TALLY_WORDS - 1) * TALLY_WIN;
       if (slab_words > ctx->tally_slab_cap) {
@@ -1943,15 +2055,39 @@ static int tally_launch(mia_hip_ctx* ctx) {
       }
       // (the bit planes and the N marks of the context's own reads: k_read_planes / k_bx_umax at upload)
       const bool planes_ok = ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax;
-      if (ctx->tally_linear
-            ? stage_launch(ctx, STG_TALLY, k_tally_binned<true>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
-                           ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
-                           planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb, -1, ctx->abort_if)
-            : stage_launch(ctx, STG_TALLY, k_tally_binned<false>, dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
-                           ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg,
-                           (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb, ctx->tally_pk_bias, ctx->abort_if))
-        return MIA_HIP_ERR_NOMEM;
-      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256, TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff, ctx->d_tally_slabs, ctx->abort_if);
+      const bool defer = ctx->tally_defer;
+      if (defer && n > ctx->gen_cap) {
+        if (dev_alloc(ctx, &ctx->d_gen_list, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+        ctx->gen_cap = n;
+      }
+      int32_t* n_gen = ctx->d_ctrl + CTRL_GENN;
+      if (defer && !ctx->in_iterate) HIPCHK(hipMemsetAsync(n_gen, 0, 4, ctx->stream));     // (mia_hip_iterate clears the whole control block)
+#define MIA_TALLY_ARGS(PL, RW, UM, BIAS)                                                                                                              \
+  dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b, ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, \
+      ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg, PL, RW, UM, d_wgb, BIAS, ctx->abort_if, chunk, defer ? ctx->d_gen_list : (int32_t*)nullptr, n_gen
+      const uint64_t* pl_arg = planes_ok ? ctx->d_rplanes : nullptr;
+      const int32_t* um_arg = planes_ok ? ctx->d_umax : nullptr;
+      int rct;
+      if (ctx->tally_linear)
+        rct = defer ? stage_launch(ctx, STG_TALLY, k_tally_binned<true, true>, MIA_TALLY_ARGS(pl_arg, ctx->rplane_words, um_arg, -1))
+                    : stage_launch(ctx, STG_TALLY, k_tally_binned<true, false>, MIA_TALLY_ARGS(pl_arg, ctx->rplane_words, um_arg, -1));
+      else
+        rct = defer ? stage_launch(ctx, STG_TALLY, k_tally_binned<false, true>, MIA_TALLY_ARGS((const uint64_t*)nullptr, 0, (const int32_t*)nullptr, ctx->tally_pk_bias))
+                    : stage_launch(ctx, STG_TALLY, k_tally_binned<false, false>, MIA_TALLY_ARGS((const uint64_t*)nullptr, 0, (const int32_t*)nullptr, ctx->tally_pk_bias));
+#undef MIA_TALLY_ARGS
+      if (rct) return MIA_HIP_ERR_NOMEM;
+      if (ctx->early_queued) {
+        // the early tally's corrections (reads whose true record is not the ordinary one it assumed), then its windows join the sum
+        hipLaunchKernelGGL(k_tally_fix, dim3(64), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b, ctx->tb, ctx->ri.trec,
+                           ctx->d_trec_early, ctx->ri.actf, ctx->d_fix_list, ctx->d_ctrl + CTRL_FIXN, ctx->abort_if);
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_early, 0));
+        int32_t* e_wgoff = ctx->d_bucket_e + 2 * (nb + 1);
+        GenReads none{ctx->rs, ref, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256, TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, e_wgoff, ctx->d_tally_slabs_e, ctx->abort_if, none);
+      }
+      GenReads gen{ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b, ctx->ri.trec, ctx->ri.actf, defer ? ctx->d_gen_list : nullptr, n_gen};
+      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256 + (defer ? TALLY_GEN_BLOCKS : 0), TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff,
+                         ctx->d_tally_slabs, ctx->abort_if, gen);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
                          ctx->d_drop_b, ctx->tb, ctx->ri.trec, ctx->ri.actf);

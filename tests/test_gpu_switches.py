@@ -20,7 +20,11 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             "MIA_HIP_NO_SIDE_BUCKETS", "MIA_HIP_BX_DEBUG=64", "MIA_HIP_NO_PLAN_SPLIT", "MIA_HIP_NO_ZERO_COPY", "MIA_HIP_NO_EXT_EVENTS",
             "MIA_HIP_EVENT_DEVICE_SCOPE", "MIA_HIP_SPIN_WAIT=0", "MIA_HIP_CULL_SCAN", "MIA_HIP_TAIL_SCANS",
             # round 4: the plan's third launch (fine blocks, bandx_body.h: bx_fine_anchors) never / in every iteration
-            "MIA_HIP_NO_FINE", "MIA_HIP_FINE=2"]
+            "MIA_HIP_NO_FINE", "MIA_HIP_FINE=2",
+            # ... and the early tally experiment (the plan's reads tallied beside the band DPs, k_rec_early / k_tally_fix) on
+            "MIA_HIP_EARLY_TALLY",
+            # the reads no one-read-per-lane route of k_tally_binned takes: inside it, one per wavefront (default: k_tally_general behind the sums)
+            "MIA_HIP_TALLY_INLINE"]
 
 
 def two_iterations(mod, w, env):
