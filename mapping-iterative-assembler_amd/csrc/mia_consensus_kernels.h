@@ -669,6 +669,7 @@ __device__ __forceinline__ int depth_code(int dff, int dfb) {   // src/fsdb.c:57
 // around the origin) takes the global atomic.  Same integer sums either way.
 constexpr int TALLY_EV_CAP = 256;    // insert events a workgroup buffers in LDS
 constexpr int TALLY_CHUNK_LATE = 256;  // reads per workgroup of the tally's second half when the plan's reads went through the early tally
+constexpr int TALLY_CHUNK_LINEAR = 256;  // ... with the linear matrix: measured best of 256 / 512 / 768 (0.899 / 0.906 / 0.934 ms per million-read step)
 constexpr int TALLY_BUCKET = 128, TALLY_WIN = 384, TALLY_CHUNK = 512;   // 20 KB of LDS per workgroup: 8 workgroups (32 waves) per CU
 
 // The LDS window of a workgroup is circular: slot k holds column win_base + k, and past the end of the reference the
@@ -875,7 +876,8 @@ __global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb,
     off[b] = r; wgoff[b] = w; cursor[b] = 0;
     const int cb = count[b];
     const int nw = (cb + chunk - 1) / chunk;
-    for (int q = 0; q < nw; q++) wg_bucket[w + q] = b;          // (the tally's workgroups look their bucket up instead of searching wgoff)
+    // (the tally's workgroups look bucket and reads up -- one load -- instead of searching wgoff and reading off[] behind it)
+    for (int q = 0; q < nw; q++) reinterpret_cast<int4*>(wg_bucket)[w + q] = make_int4(b, r + q * chunk, min(r + (q + 1) * chunk, r + cb), 0);
     r += cb; w += nw;
     count[b] = 0;                                               // read for the last time: clean for the next call's k_bucket_count
   }
@@ -908,14 +910,20 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
 // (MIA_HIP_DEBUG_SKIP & 65536, alt build: how many reads take which route of k_tally_binned -- tools/tally_kinds_probe.py)
 __device__ unsigned long long g_tally_kinds[8];
 #define TALLY_KIND(k) do { if (dbg & 65536u) atomicAdd(&g_tally_kinds[k], 1ull); } while (0)
+// (MIA_HIP_DEBUG_SKIP & 131072: shader-clock cycles of a workgroup's phases, summed over the workgroups; slot 7 counts them)
+__device__ unsigned long long g_tally_clk[8];
+#define TALLY_CLK(k) do { if ((dbg & 131072u) && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_tally_clk[k], now_ - clk_); clk_ = now_; } } while (0)
+#define TALLY_CLK_DECL unsigned long long clk_ = (dbg & 131072u) ? __builtin_amdgcn_s_memtime() : 0ull
 #else
 #define TALLY_KIND(k) do { } while (0)
+#define TALLY_CLK(k) do { } while (0)
+#define TALLY_CLK_DECL do { } while (0)
 #endif
 // DEFER: the reads that fit none of the one-read-per-lane routes (two gaps, soft ends, odd records: a thousand in a million) are
 // not tallied here, one per wavefront while the other lanes wait, but put on gen_list for k_tally_reduce's extra workgroups.  Seven hundred such reads cost 54 of this kernel's 215 us per million reads: every one of them is a stretch of code
 // nobody else runs (instruction fetches from memory) and a chain of loads in front of a workgroup's barrier.
 template <bool LINEAR, bool DEFER>
-__global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
+__global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
                                                        const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, const uint64_t* rplanes,
@@ -951,16 +959,25 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
   __shared__ unsigned long long ev_buf[TALLY_EV_CAP];
   __shared__ int ev_cnt, ev_base;
   if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
-  const int b = wg_bucket[blockIdx.x], chunk = (int)blockIdx.x - wgoff[b];     // (k_bucket_scan's table)
-  const int first = off[b] + chunk * chunk_reads, last = min(first + chunk_reads, off[b + 1]);
+  TALLY_CLK_DECL;
+  const int4 wgi = reinterpret_cast<const int4*>(wg_bucket)[blockIdx.x];       // (k_bucket_scan's table: bucket, first read, last read)
+  const int b = wgi.x, first = wgi.y, last = wgi.z;
   const int win_base = b * TALLY_BUCKET;
+  (void)off; (void)chunk_reads;
+  // the first two passes' reads, asked for before the window is set up (every pass is a chain order -> record; the loop below keeps
+  // the next pass's records in flight while it works on this one's)
+  int i_nx = first + (int)threadIdx.x < last ? order[first + (int)threadIdx.x] : -1;
+  int i_nx2 = first + 256 + (int)threadIdx.x < last ? order[first + 256 + (int)threadIdx.x] : -1;
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) lds[k] = 0;
-  for (int k = threadIdx.x; k < 2 * PSSM_WORDS; k += blockDim.x) pssm_lds[k] = (int16_t)pssm2[k];
+  // (LINEAR with the one-per-wavefront reads deferred: only sm[0][X][b] of the forward table is looked up, by the flush -- the whole
+  // copy was six dependent rounds of global loads per thread, a sixth of a workgroup's time)
+  for (int k = threadIdx.x; k < ((LINEAR && DEFER) ? 25 : 2 * PSSM_WORDS); k += blockDim.x) pssm_lds[k] = (int16_t)pssm2[k];
   for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { cov_diff[k] = 0; span_diff[k] = 0; n_cnt[k] = 0; }
   if (!LINEAR) for (int k = threadIdx.x; k < 5 * TALLY_WIN; k += blockDim.x) mid_cnt[k] = 0;
   if (!LINEAR) for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { pk1[k] = 0; pk2[k] = 0; }
   if (threadIdx.x == 0) ev_cnt = 0;
   __syncthreads();
+  TALLY_CLK(0);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   (void)wv;
   // The common case by far -- proven diagonal, one record, listed once, its own depth codes, every column inside the LDS
@@ -1038,19 +1055,75 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
       }
     }
   };
+  // the same for a whole read whose planes are already laid out by COLUMN (bit q of lo / hi / valid: the base at window column c + q;
+  // a read with one gap is laid out by bs_gap below), c < 128: the three 128-bit planes land in words c / 64 .. c / 64 + 2
+  auto bs_add = [&](unsigned long long lo0, unsigned long long lo1, unsigned long long hi0, unsigned long long hi1, unsigned long long v0, unsigned long long v1, int c) {
+    const int bsh = c & 63;
+    const bool up = c >= 64;
+    auto place = [&](unsigned long long a0, unsigned long long a1, unsigned long long* o) {
+      const unsigned long long t0 = a0 << bsh, t1 = (a1 << bsh) | ((a0 >> 1) >> (63 - bsh)), t2 = (a1 >> 1) >> (63 - bsh);
+      o[0] = up ? 0ull : t0; o[1] = up ? t0 : t1; o[2] = up ? t1 : t2; o[3] = up ? t2 : 0ull;
+    };
+    static_assert(BS_W == 4, "bs_add places three words at word 0 or 1");
+    unsigned long long pl_lo[BS_W], pl_hi[BS_W], pl_v[BS_W];
+    place(lo0, lo1, pl_lo); place(hi0, hi1, pl_hi); place(v0, v1, pl_v);
+#pragma unroll
+    for (int w = 0; w < BS_W; w++) {
+      const unsigned long long lo_w = pl_lo[w], hi_w = pl_hi[w];
+      const unsigned long long m[4] = {pl_v[w] & ~(lo_w | hi_w), lo_w & ~hi_w, hi_w & ~lo_w, lo_w & hi_w};
+#pragma unroll
+      for (int x = 0; x < 4; x++) {
+        const unsigned long long cy = bs0[x * BS_W + w] & m[x];
+        bs0[x * BS_W + w] ^= m[x];
+        bs1[x * BS_W + w] |= cy;
+      }
+    }
+  };
+  // rows -> columns for a read with one gap in front of row `grow`: gn inserted rows drop out and the rows behind them move down
+  // (ins), or gn deleted reference columns open up and the rows from grow on move up; gn = 0: as it is.  The same for every plane.
+  auto bs_gap = [&](unsigned long long* x0, unsigned long long* x1, bool ins, int grow, int gn) {
+    const unsigned long long m0 = grow >= 64 ? ~0ull : ((1ull << grow) - 1ull), m1 = grow <= 64 ? 0ull : ((1ull << (grow - 64)) - 1ull);
+    const unsigned long long a0 = *x0, a1 = *x1;
+    const unsigned long long r0 = (a0 >> gn) | ((a1 << 1) << (63 - gn)), r1 = a1 >> gn;                                  // down by gn (< 64)
+    const unsigned long long k0 = a0 & ~m0, k1 = a1 & ~m1;
+    const unsigned long long u0 = k0 << gn, u1 = (k1 << gn) | ((k0 >> 1) >> (63 - gn));                                  // the rows from grow on, up by gn
+    *x0 = (a0 & m0) | (ins ? r0 & ~m0 : u0);
+    *x1 = (a1 & m1) | (ins ? r1 & ~m1 : u1);
+  };
   if (LINEAR) {
 #pragma unroll
     for (int t = 0; t < 4 * BS_W; t++) { bs0[t] = 0; bs1[t] = 0; }
   }
-  static_assert(TALLY_CHUNK <= 3 * 256, "a lane's vertical counters hold two bits");
+  static_assert(TALLY_CHUNK <= 3 * 256 && TALLY_CHUNK_LINEAR <= 3 * 256, "a lane's vertical counters hold two bits");
+  // a read's record, and -- fetched before the record says whether they are needed, one round trip less -- its planes and N mark
+  struct ReadIn { int4 a, b4, c4; unsigned long long l0, l1, h0, h1; int um; };
+  auto fetch = [&](int ii) -> ReadIn {
+    ReadIn q;
+    q.a = make_int4(0, 0, 0, 0); q.b4 = q.a; q.c4 = q.a; q.l0 = q.l1 = q.h0 = q.h1 = 0ull; q.um = -1;
+    if (ii >= 0) {
+      const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)ii * 16);
+      q.a = tr4[0]; q.b4 = tr4[1]; q.c4 = tr4[2];
+      if (bs_on) {
+        q.um = umax[ii];
+        const uint64_t* pl = rplanes + (int64_t)ii * 2 * rplane_words;
+        q.l0 = pl[0]; q.l1 = rplane_words > 1 ? pl[1] : 0ull; q.h0 = pl[rplane_words]; q.h1 = rplane_words > 1 ? pl[rplane_words + 1] : 0ull;
+      }
+    }
+    return q;
+  };
+  ReadIn in_nx = fetch(i_nx);
   for (int k0 = first; k0 < last; k0 += 256) {
-    const int k = k0 + (int)threadIdx.x;
-    const bool have = k < last;
-    const int i = have ? order[k] : -1;
+    const int i = i_nx;
+    const bool have = i >= 0;
+    const ReadIn in = in_nx;
+    i_nx = i_nx2;
+    i_nx2 = k0 + 512 + (int)threadIdx.x < last ? order[k0 + 512 + (int)threadIdx.x] : -1;
+    in_nx = fetch(i_nx);
+    const int4 a = in.a, b4 = in.b4, c4 = in.c4;
+    const unsigned long long pv_l0 = in.l0, pv_l1 = in.l1, pv_h0 = in.h0, pv_h1 = in.h1;
+    const bool um_ok = bs_on && in.um >= 0;
     bool fast = false;
     if (have) {
-      const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)i * 16);
-      const int4 a = tr4[0], b4 = tr4[1], c4 = tr4[2];
       const int flags = a.w;
       const int len2 = a.z & 0xFFFF, abr = (int)(int16_t)((uint32_t)a.z >> 16);
       const RecGeom g = rec_geom(a.x, a.y, L);
@@ -1081,8 +1154,8 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
         const int ins = (int)(desc & 1u), grow = (int)((desc >> 1) & 511u), gn = (int)((desc >> 10) & 63u);
         const int ncol = ins ? n_al - gn : n_al + gn;
         one_sl = (flags & TRF_SK) && !(flags & TRF_TOO_LONG) && !(flags & TRF_DIAG) && !g.split && fMult == 1 && fBase == 0 && fOff == 0 && w0 >= 0 &&
-                 ncol > 0 && w0 + ncol <= 64 * BS_W && g.start_w + ncol <= Lp && ncol == g.ncols_f && gn > 0 && grow > abr && grow + (ins ? gn : 0) < len2 &&
-                 umax[i] >= 0;
+                 ncol > 0 && ncol <= 128 && w0 < 128 && g.start_w + ncol <= Lp && ncol == g.ncols_f && gn > 0 && grow > abr && grow + (ins ? gn : 0) < len2 &&
+                 um_ok;
         if (one_sl) { sl_ins = ins; sl_row = grow; sl_n = gn; sl_ncol = ncol; }
       }
       if (fast) TALLY_KIND(0);
@@ -1096,25 +1169,27 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
           // depth codes are not needed for the sums; they only have to be valid: act <= 15 always is, beyond that
           // dfb = fB - act - 1 must not be negative (depth_code above)
           bad = n_al > PSSM_DEPTH + 1 && fB < n_al;
-          const bool fast_sl = !one_sl && !dF && bs_on && abr == 0 && len2 <= 128 && w0 + n_al <= 64 * BS_W && umax[i] >= 0;
-          unsigned long long l0 = 0, l1 = 0, h0 = 0, h1 = 0;
+          const bool fast_sl = !one_sl && !dF && bs_on && abr == 0 && len2 <= 128 && w0 < 128 && um_ok;
           uint32_t iw0 = 0, iw1 = 0;
-          if ((fast_sl || (one_sl && !dF)) ) {
-            const uint64_t* pl = rplanes + (int64_t)i * 2 * rplane_words;
-            l0 = pl[0]; l1 = rplane_words > 1 ? pl[1] : 0ull; h0 = pl[rplane_words]; h1 = rplane_words > 1 ? pl[rplane_words + 1] : 0ull;
-          }
           if (one_sl && sl_ins) { iw0 = rp[sl_row >> 3]; iw1 = rp[(sl_row + sl_n - 1) >> 3]; }
+          if (fast_sl || (one_sl && !dF)) {
+            // gap-free reads and reads with one gap in ONE instruction stream: the planes go from rows to columns (bs_gap; nothing to do
+            // without a gap) and into the vertical counters once.  (Two calls of bs_count either side of the gap, in a branch only the
+            // one-gap lanes take, was as much work again as all the gap-free lanes' -- and this loop is bound by its 64-bit logic.)
+            unsigned long long l0 = pv_l0, l1 = pv_l1, h0 = pv_h0, h1 = pv_h1;
+            unsigned long long v0 = len2 >= 64 ? ~0ull : ((1ull << len2) - 1ull), v1 = len2 <= 64 ? 0ull : (len2 >= 128 ? ~0ull : ((1ull << (len2 - 64)) - 1ull));
+            l0 &= v0; l1 &= v1; h0 &= v0; h1 &= v1;
+            const int gn = one_sl ? sl_n : 0, grow = one_sl ? sl_row : 0;
+            const bool gi = one_sl && sl_ins;
+            bs_gap(&l0, &l1, gi, grow, gn); bs_gap(&h0, &h1, gi, grow, gn); bs_gap(&v0, &v1, gi, grow, gn);
+            bs_add(l0, l1, h0, h1, v0, v1, w0);
+          }
           if (one_sl) {
             TALLY_KIND(3); TALLY_KIND(4);
-            // the two stretches of the read either side of its gap through the vertical counters; deleted reference columns count
-            // as '-', inserted read rows become insert events at the column that follows (src/map_align.c:444-510)
+            // the gap itself: deleted reference columns count as '-', inserted read rows become insert events at the column that
+            // follows (src/map_align.c:444-510)
             const int grow = sl_row, gn = sl_n, ins = sl_ins;
-            if (!dF) {
-              const int r2 = ins ? grow + gn : grow;                       // first row behind the gap, at column w0 + grow (+ gn behind a deletion)
-              bs_count(l0, l1, h0, h1, 0, grow, w0);
-              bs_count(l0, l1, h0, h1, r2, len2 - r2, w0 + grow + (ins ? 0 : gn));
-              if (!ins) for (int q = 0; q < gn; q++) aadd(&t[T_GAP * TALLY_WIN + grow + q], 1);
-            }
+            if (!dF && !ins) for (int q = 0; q < gn; q++) aadd(&t[T_GAP * TALLY_WIN + grow + q], 1);
             if (ins)
               for (int j = 0; j < gn; j++) {
                 const int r = grow + j;
@@ -1134,7 +1209,6 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
               }
           } else if (fast_sl) {
             TALLY_KIND(1);
-            bs_count(l0, l1, h0, h1, 0, n_al, w0);
           } else if (!dF) {
             lds_i32* nc = (lds_i32*)n_cnt + w0;
             for (int act = 0; act < n_al; act++) {
@@ -1403,6 +1477,7 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
       __builtin_amdgcn_wave_barrier();
     }
   }
+  TALLY_CLK(1);
   if (LINEAR && bs_on) {
     // the wavefront's 64 x 16 vertical counters -> one 8-bit item per group of four lanes -> the window
     auto xch = [&](unsigned long long v, int m) -> unsigned long long { return (unsigned long long)__shfl_xor((long long)v, m); };
@@ -1485,18 +1560,17 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
     }
   }
   if (warm == 0x7FFFFFF1) atomicOr(tb.flags, 4u);   // keeps the warming loads alive; never true for real data
+  TALLY_CLK(2);
   __syncthreads();
+  TALLY_CLK(3);
   // The window goes to this workgroup's slab with plain stores; k_tally_reduce adds the slabs up.  (Flushing with
   // global atomics cost more than the tally itself: ~9 M device-scope atomics per 1 M reads, and the eight XCDs
   // share no L2, so every one of them is resolved at the memory side.)
-  {   // the buffered insert events: one reservation for all of them
-    const int ne = ev_cnt < TALLY_EV_CAP ? ev_cnt : TALLY_EV_CAP;
-    if (threadIdx.x == 0 && ne > 0) ev_base = atomicAdd(tb.n_events, ne);
-    __syncthreads();
-    for (int k = threadIdx.x; k < ne; k += blockDim.x) {
-      if (ev_base + k < tb.cap_events) tb.events[ev_base + k] = ev_buf[k]; else atomicOr(tb.flags, 1u);
-    }
-  }
+  // the buffered insert events: one reservation for all of them -- asked for here, used at the very end (a returning atomic on ONE
+  // address from two thousand workgroups: a few microseconds each that the rest of the flush does not have to wait for)
+  const int ne = ev_cnt < TALLY_EV_CAP ? ev_cnt : TALLY_EV_CAP;
+  int ev_base_reg = 0;
+  if (threadIdx.x == 255 && ne > 0) ev_base_reg = atomicAdd(tb.n_events, ne);
   // prefix sums of the two difference arrays, folded into the cov / span rows: one wavefront each, six consecutive entries
   // per lane and a shuffle scan over the lanes' sums (a Hillis-Steele scan by the whole workgroup was eighteen barriers)
   static_assert(TALLY_WIN == 64 * 6, "the difference arrays are scanned six entries per lane");
@@ -1549,9 +1623,18 @@ __global__ __launch_bounds__(256) void k_tally_binned(ReadSet rs, RefInfo ref, c
       }
     }
   }
+  if (threadIdx.x == 255) ev_base = ev_base_reg;             // (the first use of the atomic's result: only here is it waited for)
   __syncthreads();
+  TALLY_CLK(4);
   int32_t* slab = slabs + (int64_t)blockIdx.x * ((TALLY_WORDS - 1) * TALLY_WIN);
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) slab[k] = lds[k];
+  for (int k = threadIdx.x; k < ne; k += blockDim.x) {
+    if (ev_base + k < tb.cap_events) tb.events[ev_base + k] = ev_buf[k]; else atomicOr(tb.flags, 1u);
+  }
+  TALLY_CLK(5);
+#ifdef MIA_HIP_ALT_PATHS
+  if ((dbg & 131072u) && threadIdx.x == 0) atomicAdd(&g_tally_clk[7], 1ull);
+#endif
 }
 
 // tally[word][gc] += sum of the windows that cover column gc: buckets floor(gc/128)-2 .. floor(gc/128), all their chunks,

@@ -199,7 +199,8 @@ struct mia_hip_ctx {
   int32_t* d_bucket = nullptr; int bucket_cap = 0; int32_t* d_order = nullptr;
   int use_binned_tally = 1;   // MIA_HIP_NO_BINNED_TALLY=1: plain global-atomic tally
   int32_t* d_tally_slabs = nullptr; int64_t tally_slab_cap = 0;   // one LDS window per tally workgroup, summed by k_tally_reduce
-  int32_t* d_gen_list = nullptr; int64_t gen_cap = 0;             // the reads k_tally_binned leaves to k_tally_general (a thousand in a million; room for all)
+  int32_t* d_gen_list = nullptr; int64_t gen_cap = 0;             // the reads k_tally_binned leaves to k_tally_reduce's extra workgroups (a thousand in a million; room for all)
+  int tally_chunk_linear = TALLY_CHUNK_LINEAR;                    // MIA_HIP_TALLY_CHUNK=256|512|768 (alt build)
   bool tally_defer = true;                                        // MIA_HIP_TALLY_INLINE=1 (alt build): they are taken inside k_tally_binned, one per wavefront
   // wide scratch
   int32_t* d_scratch = nullptr; int64_t scratch_cap = 0; int64_t* d_scratch_off = nullptr; int64_t scratch_off_cap = 0;
@@ -372,6 +373,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nwl && atoi(nwl)) ctx->use_wild = 0;
     if (const char* ne = alt_env("MIA_HIP_EARLY_TALLY")) ctx->use_early = atoi(ne) != 0;
     if (const char* ti = alt_env("MIA_HIP_TALLY_INLINE")) ctx->tally_defer = atoi(ti) == 0;
+    if (const char* tc = alt_env("MIA_HIP_TALLY_CHUNK")) { const int c = atoi(tc); if (c == 256 || c == 512 || c == 768) ctx->tally_chunk_linear = c; }
     if (const char* ew = alt_env("MIA_HIP_EARLY_WGS")) ctx->early_wgs_per_cu = atoi(ew);
     if (const char* nf = alt_env("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
     if (const char* nf = alt_env("MIA_HIP_FINE")) ctx->use_fine = atoi(nf);
@@ -787,6 +789,8 @@ extern "C" int mia_hip_debug_tally_kinds(mia_hip_ctx* ctx, uint64_t* out8) {
   HIPCHK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tally_kinds), 8 * sizeof(uint64_t)));
   uint64_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tally_kinds), z, sizeof z));
+  HIPCHK(hipMemcpyFromSymbol(out8 + 8, HIP_SYMBOL(g_tally_clk), 8 * sizeof(uint64_t)));      // (out8: 16 words)
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tally_clk), z, sizeof z));
   return MIA_HIP_OK;
 }
 #endif
@@ -1935,6 +1939,8 @@ static bool tally_is_binned(const mia_hip_ctx* ctx) {
 // Counting sort of the reads by alignment start (k_bucket_count / _scan / _fill) on stream `on`.  It reads nothing but the
 // alignment starts, so mia_hip_iterate queues it on stream2 BESIDE the cull kernels (it also clears the tally buffers:
 // nothing adds to them before the tally kernel).  tally_launch waits for ev_join if `on` is not the context's stream.
+// reads per workgroup of the binned tally (the linear matrix: one read per lane -- measured, mia_consensus_kernels.h)
+static int tally_chunk(const mia_hip_ctx* ctx) { return ctx->early_queued ? TALLY_CHUNK_LATE : (ctx->tally_linear ? ctx->tally_chunk_linear : TALLY_CHUNK); }
 static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
   int rc = ensure_tally(ctx);
   if (rc) return rc;
@@ -1944,11 +1950,11 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
   const int nb = ctx->wrap / TALLY_BUCKET + 1;
   // (behind an early tally what is left are the reads with substitutions and gaps -- a fifth of them, and the slow ones: smaller shares
   // per workgroup, or a few hundred workgroups with 512 slow reads each take longer than the whole tally did)
-  const int chunk = ctx->early_queued ? TALLY_CHUNK_LATE : TALLY_CHUNK;
+  const int chunk = tally_chunk(ctx);
   const int grid = (int)(n / chunk) + nb + 1;
-  if (4 * (nb + 1) + grid > ctx->bucket_cap) {
-    if (dev_alloc(ctx, &ctx->d_bucket, (size_t)(4 * (nb + 1) + grid) * 2)) return MIA_HIP_ERR_NOMEM;
-    ctx->bucket_cap = (4 * (nb + 1) + grid) * 2;
+  if (4 * (nb + 1) + 4 * grid > ctx->bucket_cap) {
+    if (dev_alloc(ctx, &ctx->d_bucket, (size_t)(4 * (nb + 1) + 4 * grid) * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->bucket_cap = (4 * (nb + 1) + 4 * grid) * 2;
     ctx->bucket_clean_nb = -1;
   }
   if (!ctx->d_order && dev_alloc(ctx, &ctx->d_order, (size_t)n)) return MIA_HIP_ERR_NOMEM;
@@ -1980,9 +1986,9 @@ static int early_tally_launch(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   const int nb = ctx->wrap / TALLY_BUCKET + 1;
   const int grid = (int)(n / TALLY_CHUNK) + nb + 1;
-  if (4 * (nb + 1) + grid > ctx->bucket_e_cap) {
-    if (dev_alloc(ctx, &ctx->d_bucket_e, (size_t)(4 * (nb + 1) + grid) * 2)) return MIA_HIP_ERR_NOMEM;
-    ctx->bucket_e_cap = (4 * (nb + 1) + grid) * 2;
+  if (4 * (nb + 1) + 4 * grid > ctx->bucket_e_cap) {
+    if (dev_alloc(ctx, &ctx->d_bucket_e, (size_t)(4 * (nb + 1) + 4 * grid) * 2)) return MIA_HIP_ERR_NOMEM;
+    ctx->bucket_e_cap = (4 * (nb + 1) + 4 * grid) * 2;
     ctx->bucket_e_clean_nb = -1;
   }
   int32_t *d_cnt = ctx->d_bucket_e, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1), *d_wgb = d_cur + (nb + 1);
@@ -2045,7 +2051,7 @@ static int tally_launch(mia_hip_ctx* ctx) {
       if (!ctx->buckets_queued) { if (int rcb = bucket_launch(ctx, ctx->stream)) return rcb; }
       if (ctx->buckets_queued == 2) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
       ctx->buckets_queued = 0;
-      const int chunk = ctx->early_queued ? TALLY_CHUNK_LATE : TALLY_CHUNK;
+      const int chunk = tally_chunk(ctx);
       const int grid = (int)(n / chunk) + nb + 1;
       int32_t *d_cnt = ctx->d_bucket, *d_off = d_cnt + (nb + 1), *d_wgoff = d_off + (nb + 1), *d_cur = d_wgoff + (nb + 1), *d_wgb = d_cur + (nb + 1);
       const int64_t slab_words = (int64_t)grid * (TALLY_WORDS - 1) * TALLY_WIN;

@@ -23,7 +23,7 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             "MIA_HIP_NO_FINE", "MIA_HIP_FINE=2",
             # ... and the early tally experiment (the plan's reads tallied beside the band DPs, k_rec_early / k_tally_fix) on
             "MIA_HIP_EARLY_TALLY",
-            # the reads no one-read-per-lane route of k_tally_binned takes: inside it, one per wavefront (default: k_tally_general behind the sums)
+            # the reads no one-read-per-lane route of k_tally_binned takes: inside it, one per wavefront (default: by extra workgroups of k_tally_reduce)
             "MIA_HIP_TALLY_INLINE"]
 
 

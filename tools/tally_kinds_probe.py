@@ -47,11 +47,14 @@ print("reads", n, "gap-free", int((gaps == 0).sum()), "one gap", int((gaps == 1)
 print("bx counters", list(hip.bx_counters()[:10]))
 if os.environ.get("MIA_HIP_DEBUG_SKIP"):
     import ctypes as C
-    k = np.zeros(8, np.uint64)
+    k = np.zeros(16, np.uint64)
     hip._l.mia_hip_debug_tally_kinds.argtypes = [C.c_void_p, C.c_void_p]
     hip._l.mia_hip_debug_tally_kinds(hip._h, k.ctypes.data_as(C.c_void_p))      # (resets the counts)
     pipe.step(ref); hip.sync()
     hip._l.mia_hip_debug_tally_kinds(hip._h, k.ctypes.data_as(C.c_void_p))
     print("k_tally_binned routes of one step: gap-free lane", int(k[0]), "(bit-sliced", int(k[1]), ") over the origin", int(k[2]), "one gap", int(k[3]),
           "(bit-sliced", int(k[4]), ") one per wavefront", int(k[5]), "(of them marked one-gap", int(k[6]), ", marked diagonal", int(k[7]), ")")
+    if k[15]:
+        print("k_tally_binned, shader-clock cycles per workgroup (thread 0): init %.0f, reads %.0f, counters to window %.0f, barrier %.0f, flush %.0f, slab %.0f; workgroups %d"
+              % tuple([float(k[8 + q]) / float(k[15]) for q in range(6)] + [int(k[15])]))
 hip.close()
