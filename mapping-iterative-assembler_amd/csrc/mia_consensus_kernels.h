@@ -1648,34 +1648,39 @@ struct GenReads {
   const int32_t* list; const int32_t* n;
 };
 constexpr int TALLY_GEN_BLOCKS = 192;
+constexpr int TALLY_REDUCE_SHARES = 4;     // gridDim.z of k_tally_reduce: the workgroups of a bucket are summed in this many interleaved shares
 __global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs, const int32_t* abort_if, GenReads gen) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int Lp = tb.Lp;
-  const int col_blocks = (Lp + 255) / 256;
-  if ((int)blockIdx.x >= col_blocks) {
-    if (blockIdx.y != 0 || !gen.list) return;
+  // (the workgroups of the put-aside reads come FIRST in the grid: theirs is the longest chain of this launch -- list, record,
+  // script, bases, atomics -- and workgroups are started in order)
+  const int gen_blocks = gen.list ? TALLY_GEN_BLOCKS : 0;
+  if ((int)blockIdx.x < gen_blocks) {
+    if (blockIdx.y != 0 || blockIdx.z != 0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = *gen.n;
-    for (int k = ((int)blockIdx.x - col_blocks) * 4 + wv; k < n; k += TALLY_GEN_BLOCKS * 4)
+    for (int k = (int)blockIdx.x * 4 + wv; k < n; k += TALLY_GEN_BLOCKS * 4)
       tally_one_read<false>(__builtin_amdgcn_readfirstlane(gen.list[k]), lane, gen.rs, gen.ref, gen.pssm2, gen.drop_front, gen.drop_back, tb, nullptr, 0, gen.rec_params,
                             gen.rec_actf, nullptr, nullptr, nullptr);
     return;
   }
-  // one thread per (column, tally word): blockIdx.y is the word (a thread per column alone is 66 workgroups for a
-  // mitochondrion, each thread a chain of five hundred loads)
-  const int gc = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+  // one thread per (column, tally word, share of the bucket's workgroups): blockIdx.y is the word, blockIdx.z the share (a
+  // thread per column alone is 66 workgroups for a mitochondrion, each thread a chain of five hundred loads; with 256 reads per
+  // tally workgroup a thread per column and word still had a hundred)
+  const int gc = ((int)blockIdx.x - gen_blocks) * blockDim.x + threadIdx.x, w = blockIdx.y;
+  const int zs = blockIdx.z, zn = gridDim.z;
   if (gc >= Lp) return;
   int acc = 0;
   const int bhi = min(gc / TALLY_BUCKET, nb - 1);
   for (int b = max(0, gc / TALLY_BUCKET - (TALLY_WIN / TALLY_BUCKET - 1)); b <= bhi; b++) {
     const int wc = gc - b * TALLY_BUCKET;
     if (wc < 0 || wc >= TALLY_WIN) continue;
-    for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
+    for (int wg = wgoff[b] + zs; wg < wgoff[b + 1]; wg += zn) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
   }
   // ... and the circular part of the last buckets' windows (tally_slot): slot gc + Lp - b * TALLY_BUCKET
   for (int b = max(0, (Lp + gc - TALLY_WIN) / TALLY_BUCKET); b < nb; b++) {
     const int wc = gc + Lp - b * TALLY_BUCKET;
     if (wc < 0 || wc >= TALLY_WIN || gc >= b * TALLY_BUCKET) continue;     // (columns from win_base on sit in their direct slot)
-    for (int wg = wgoff[b]; wg < wgoff[b + 1]; wg++) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
+    for (int wg = wgoff[b] + zs; wg < wgoff[b + 1]; wg += zn) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
   }
   if (acc) (void)__hip_atomic_fetch_add(&tb.tally[w * Lp + gc], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

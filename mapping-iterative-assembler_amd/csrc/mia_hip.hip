@@ -2092,7 +2092,7 @@ static int tally_launch(mia_hip_ctx* ctx) {
         hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256, TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, e_wgoff, ctx->d_tally_slabs_e, ctx->abort_if, none);
       }
       GenReads gen{ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b, ctx->ri.trec, ctx->ri.actf, defer ? ctx->d_gen_list : nullptr, n_gen};
-      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256 + (defer ? TALLY_GEN_BLOCKS : 0), TALLY_WORDS - 1), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff,
+      hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256 + (defer ? TALLY_GEN_BLOCKS : 0), TALLY_WORDS - 1, TALLY_REDUCE_SHARES), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff,
                          ctx->d_tally_slabs, ctx->abort_if, gen);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
