@@ -836,11 +836,17 @@ constexpr int BUCKET_PER = 8;   // reads per thread of the bucketing kernels
 // zero / zero_words: a buffer this launch clears on the side (the tally, the gaps and the ranks' event-count slots behind them:
 // nothing adds to them before the tally kernel, which runs behind this one), or nullptr
 // part / want (the early tally, k_rec_early): only the reads with (part[i] != 0) == (want != 0) are sorted; part == nullptr: all
+// a read's bucket: its alignment start's stretch of TALLY_BUCKET columns -- and, split != 0 (the position-specific matrices' tally:
+// a workgroup's reads all of one strand, so that its vertical counters need no strand), the strand in the lowest bit.  nb counts
+// all buckets (twice the column stretches when split).
+__device__ __forceinline__ int bucket_of(const ReadSet& rs, int64_t i, int nb, int split) {
+  return (min(rs.as[i] / TALLY_BUCKET, (nb >> split) - 1) << split) | (split ? (rs.rc[i] ? 1 : 0) : 0);
+}
 __device__ __forceinline__ bool bucket_takes(const ReadSet& rs, int64_t i, const uint8_t* part, int want) {
   return i < rs.n && rs.sk[i] && (!part || (part[i] != 0) == (want != 0));
 }
 __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count, int32_t* zero, int64_t zero_words, const int32_t* abort_if = nullptr,
-                                                       const uint8_t* part = nullptr, int32_t want = 0) {
+                                                       const uint8_t* part = nullptr, int32_t want = 0, int32_t split = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   extern __shared__ int32_t hist[];
   for (int b = threadIdx.x; b < nb; b += blockDim.x) hist[b] = 0;
@@ -848,7 +854,7 @@ __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, in
   __syncthreads();
   for (int k = 0; k < BUCKET_PER; k++) {
     const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
-    if (bucket_takes(rs, i, part, want)) atomicAdd(&hist[min(rs.as[i] / TALLY_BUCKET, nb - 1)], 1);
+    if (bucket_takes(rs, i, part, want)) atomicAdd(&hist[bucket_of(rs, i, nb, split)], 1);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nb; b += blockDim.x) if (hist[b]) atomicAdd(&count[b], hist[b]);
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb,
   if (t == 255) { off[nb] = s_run[255]; wgoff[nb] = s_wg[255]; }
 }
 __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order, const int32_t* abort_if = nullptr,
-                                                      const uint8_t* part = nullptr, int32_t want = 0) {
+                                                      const uint8_t* part = nullptr, int32_t want = 0, int32_t split = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   extern __shared__ int32_t sh[];
   int32_t* hist = sh;
@@ -895,7 +901,7 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
   for (int k = 0; k < BUCKET_PER; k++) {
     const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
     bb[k] = -1; rank[k] = 0;
-    if (bucket_takes(rs, i, part, want)) { bb[k] = min(rs.as[i] / TALLY_BUCKET, nb - 1); rank[k] = atomicAdd(&hist[bb[k]], 1); }
+    if (bucket_takes(rs, i, part, want)) { bb[k] = bucket_of(rs, i, nb, split); rank[k] = atomicAdd(&hist[bb[k]], 1); }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < nb; k += blockDim.x) if (hist[k]) base[k] = atomicAdd(&cursor[k], hist[k]);
@@ -928,7 +934,7 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
                                                        const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, const uint64_t* rplanes,
                                                        int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket, int32_t pk_bias, const int32_t* abort_if = nullptr,
-                                                       int32_t chunk_reads = TALLY_CHUNK, int32_t* gen_list = nullptr, int32_t* n_gen = nullptr) {
+                                                       int32_t chunk_reads = TALLY_CHUNK, int32_t* gen_list = nullptr, int32_t* n_gen = nullptr, int32_t split = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   constexpr bool linear = LINEAR;
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
@@ -961,7 +967,9 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
   TALLY_CLK_DECL;
   const int4 wgi = reinterpret_cast<const int4*>(wg_bucket)[blockIdx.x];       // (k_bucket_scan's table: bucket, first read, last read)
-  const int b = wgi.x, first = wgi.y, last = wgi.z;
+  const int b = wgi.x >> split, first = wgi.y, last = wgi.z;                    // (split: the bucket's lowest bit is its reads' strand, bucket_of)
+  const int wg_rc = split ? (wgi.x & 1) : 0;
+  (void)wg_rc;
   const int win_base = b * TALLY_BUCKET;
   (void)off; (void)chunk_reads;
   // the first two passes' reads, asked for before the window is set up (every pass is a chain order -> record; the loop below keeps
@@ -1020,7 +1028,9 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   // adds 16 columns of its item to the window -- 1 024 atomics per wavefront instead of 12 800.
   constexpr int BS_W = 4;                                   // window words covered: columns 0 .. 255
   unsigned long long bs0[4 * BS_W], bs1[4 * BS_W];
-  const bool bs_on = LINEAR && rplanes && umax && !(dbg & 4096u);
+  // (position-specific matrices: the counters take the bases of depth code 15 -- seven in ten -- of a workgroup whose reads are all of
+  // one strand, split != 0; the fifteen rows at either end of a read keep their packed adds)
+  const bool bs_on = (LINEAR || split != 0) && rplanes && umax && !(dbg & 4096u);
   // a stretch of a read's planes (rows from r_lo on, n_rows of them) counted at window columns c .. c + n_rows - 1 < 256
   auto bs_count = [&](unsigned long long l0, unsigned long long l1, unsigned long long h0, unsigned long long h1, int r_lo, int n_rows, int c) {
     // rows r_lo.. down to bit 0 (a 128-bit shift right), then n_rows of them kept
@@ -1090,10 +1100,8 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
     *x0 = (a0 & m0) | (ins ? r0 & ~m0 : u0);
     *x1 = (a1 & m1) | (ins ? r1 & ~m1 : u1);
   };
-  if (LINEAR) {
 #pragma unroll
-    for (int t = 0; t < 4 * BS_W; t++) { bs0[t] = 0; bs1[t] = 0; }
-  }
+  for (int t = 0; t < 4 * BS_W; t++) { bs0[t] = 0; bs1[t] = 0; }
   static_assert(TALLY_CHUNK <= 3 * 256 && TALLY_CHUNK_LINEAR <= 3 * 256, "a lane's vertical counters hold two bits");
   // a read's record, and -- fetched before the record says whether they are needed, one round trip less -- its planes and N mark
   struct ReadIn { int4 a, b4, c4; unsigned long long l0, l1, h0, h1; int um; };
@@ -1222,13 +1230,36 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
         } else {
         // (the read's words three ahead of their use: a load per eight rows that is waited for on the spot was a
         // microsecond of every eight iterations; packed reads are padded, so the words beyond the last may be fetched)
+        // The rows of depth code 15 (row 15 .. B - 16: src/fsdb.c:572-582 through depth_code) of a read that fits the vertical
+        // counters -- up to 128 bases, no N, its strand the workgroup's -- are counted there, gap-free and one-gap reads alike
+        // (bs_gap), and scored at the flush like mid_cnt's; the loop below then only walks the rows at either end.
+        const int og_cols = n_al + (one_here ? (og_ins ? -og_n : og_n) : 0);
+        const bool mid_sl = bs_on && split != 0 && abr == 0 && len2 <= 128 && w0 < 128 && og_cols <= 128 && um_ok && ((flags & TRF_RC) != 0) == (wg_rc != 0);
+        const int mid_lo = PSSM_DEPTH, mid_hi = min(fB - PSSM_DEPTH - 1, n_al - 1);
+        const bool have_mid = mid_sl && mid_hi >= mid_lo;
+        if (have_mid && !dF) {
+          auto below = [](int q, unsigned long long* o0, unsigned long long* o1) {      // bits 0 .. q - 1 of 128
+            *o0 = q >= 64 ? ~0ull : ((1ull << q) - 1ull);
+            *o1 = q <= 64 ? 0ull : (q >= 128 ? ~0ull : ((1ull << (q - 64)) - 1ull));
+          };
+          unsigned long long a0, a1, b0, b1;
+          below(mid_hi + 1, &a0, &a1); below(mid_lo, &b0, &b1);
+          unsigned long long v0 = a0 & ~b0, v1 = a1 & ~b1;
+          unsigned long long l0 = pv_l0 & v0, l1 = pv_l1 & v1, h0 = pv_h0 & v0, h1 = pv_h1 & v1;
+          const int gn = one_here ? og_n : 0, grow = one_here ? og_row : 0;
+          const bool gi = one_here && og_ins;
+          bs_gap(&l0, &l1, gi, grow, gn); bs_gap(&h0, &h1, gi, grow, gn); bs_gap(&v0, &v1, gi, grow, gn);
+          bs_add(l0, l1, h0, h1, v0, v1, w0);
+        }
         const int wlast = (len2 - 1) >> 3;
-        int wi = abr >> 3;
+        auto rows = [&](int a_from, int a_to) {
+        if (a_from >= a_to) return;
+        int wi = (abr + a_from) >> 3;
         uint32_t wq1 = rp[wi + 1 <= wlast ? wi + 1 : wlast], wq2 = rp[wi + 2 <= wlast ? wi + 2 : wlast], wq3 = rp[wi + 3 <= wlast ? wi + 3 : wlast];
         word = rp[wi];
-        for (int act = 0; act < n_al; act++) {
+        for (int act = a_from; act < a_to; act++) {
           const int r = abr + act;
-          if (act != 0 && (r & 7) == 0) { wi++; word = wq1; wq1 = wq2; wq2 = wq3; wq3 = rp[wi + 3 <= wlast ? wi + 3 : wlast]; }
+          if (act != a_from && (r & 7) == 0) { wi++; word = wq1; wq1 = wq2; wq2 = wq3; wq3 = rp[wi + 3 <= wlast ? wi + 3 : wlast]; }
           const int code = (int)((word >> ((r & 7) * 4)) & 15u);
           const int d = depth_code(act, fB - act - 1);
           if (one_here) {
@@ -1242,8 +1273,10 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
           bad |= (d < 0) | (d > 2 * PSSM_DEPTH);
           const int dd = d < 0 ? 0 : (d > 2 * PSSM_DEPTH ? 2 * PSSM_DEPTH : d);
           if (!dF && !(dbg & 16u)) add_base(w0 + act, code, dd, (flags & TRF_RC) != 0);
-          t++;
         }
+        };
+        rows(0, have_mid ? mid_lo : n_al);
+        if (have_mid) rows(mid_hi + 1, n_al);
         }
         if (fast || one_sl) {
         // coverage (not dropped): columns w0 .. w0+n-1; span (start < pos <= end, dropped or not): w0+1 .. w0+n-1 (n: the read's columns)
@@ -1478,7 +1511,7 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
     }
   }
   TALLY_CLK(1);
-  if (LINEAR && bs_on) {
+  if (bs_on) {
     // the wavefront's 64 x 16 vertical counters -> one 8-bit item per group of four lanes -> the window
     auto xch = [&](unsigned long long v, int m) -> unsigned long long { return (unsigned long long)__shfl_xor((long long)v, m); };
     // stage A (lane bit 5): items t and t + 8, 2-bit + 2-bit -> 3 bits; lane bit set keeps the upper half
@@ -1556,7 +1589,10 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
       int v = 0;
 #pragma unroll
       for (int q = 0; q < 8; q++) v |= (int)((a8[q] >> (c0 + j)) & 1ull) << q;
-      if (v) aadd((lds_i32*)lds + (T_A + bx_) * TALLY_WIN + wd * 64 + c0 + j, v);
+      if (v) {
+        if (LINEAR) aadd((lds_i32*)lds + (T_A + bx_) * TALLY_WIN + wd * 64 + c0 + j, v);
+        else aadd((lds_i32*)mid_cnt + bx_ * TALLY_WIN + wd * 64 + c0 + j, wg_rc ? v << 16 : v);      // (depth code 15, this workgroup's strand: see mid_cnt)
+      }
     }
   }
   if (warm == 0x7FFFFFF1) atomicOr(tb.flags, 4u);   // keeps the warming loads alive; never true for real data
@@ -1649,7 +1685,7 @@ struct GenReads {
 };
 constexpr int TALLY_GEN_BLOCKS = 192;
 constexpr int TALLY_REDUCE_SHARES = 4;     // gridDim.z of k_tally_reduce: the workgroups of a bucket are summed in this many interleaved shares
-__global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs, const int32_t* abort_if, GenReads gen) {
+__global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, const int32_t* wgoff, const int32_t* slabs, const int32_t* abort_if, GenReads gen, int32_t split = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int Lp = tb.Lp;
   // (the workgroups of the put-aside reads come FIRST in the grid: theirs is the longest chain of this launch -- list, record,
@@ -1670,17 +1706,18 @@ __global__ __launch_bounds__(256) void k_tally_reduce(TallyBuf tb, int32_t nb, c
   const int zs = blockIdx.z, zn = gridDim.z;
   if (gc >= Lp) return;
   int acc = 0;
+  nb >>= split;                                                // stretches of columns; the workgroups of stretch b: wgoff[b << split] .. wgoff[(b + 1) << split]
   const int bhi = min(gc / TALLY_BUCKET, nb - 1);
   for (int b = max(0, gc / TALLY_BUCKET - (TALLY_WIN / TALLY_BUCKET - 1)); b <= bhi; b++) {
     const int wc = gc - b * TALLY_BUCKET;
     if (wc < 0 || wc >= TALLY_WIN) continue;
-    for (int wg = wgoff[b] + zs; wg < wgoff[b + 1]; wg += zn) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
+    for (int wg = wgoff[b << split] + zs; wg < wgoff[(b + 1) << split]; wg += zn) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
   }
   // ... and the circular part of the last buckets' windows (tally_slot): slot gc + Lp - b * TALLY_BUCKET
   for (int b = max(0, (Lp + gc - TALLY_WIN) / TALLY_BUCKET); b < nb; b++) {
     const int wc = gc + Lp - b * TALLY_BUCKET;
     if (wc < 0 || wc >= TALLY_WIN || gc >= b * TALLY_BUCKET) continue;     // (columns from win_base on sit in their direct slot)
-    for (int wg = wgoff[b] + zs; wg < wgoff[b + 1]; wg += zn) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
+    for (int wg = wgoff[b << split] + zs; wg < wgoff[(b + 1) << split]; wg += zn) acc += slabs[(int64_t)wg * ((TALLY_WORDS - 1) * TALLY_WIN) + w * TALLY_WIN + wc];
   }
   if (acc) (void)__hip_atomic_fetch_add(&tb.tally[w * Lp + gc], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

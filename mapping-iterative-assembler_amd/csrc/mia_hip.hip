@@ -200,6 +200,7 @@ struct mia_hip_ctx {
   int use_binned_tally = 1;   // MIA_HIP_NO_BINNED_TALLY=1: plain global-atomic tally
   int32_t* d_tally_slabs = nullptr; int64_t tally_slab_cap = 0;   // one LDS window per tally workgroup, summed by k_tally_reduce
   int32_t* d_gen_list = nullptr; int64_t gen_cap = 0;             // the reads k_tally_binned leaves to k_tally_reduce's extra workgroups (a thousand in a million; room for all)
+  bool tally_strand_split = true;                                 // MIA_HIP_NO_STRAND_SPLIT=1 (alt build): position-specific matrices, buckets by column only
   int tally_chunk_linear = TALLY_CHUNK_LINEAR;                    // MIA_HIP_TALLY_CHUNK=256|512|768 (alt build)
   bool tally_defer = true;                                        // MIA_HIP_TALLY_INLINE=1 (alt build): they are taken inside k_tally_binned, one per wavefront
   // wide scratch
@@ -373,6 +374,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nwl && atoi(nwl)) ctx->use_wild = 0;
     if (const char* ne = alt_env("MIA_HIP_EARLY_TALLY")) ctx->use_early = atoi(ne) != 0;
     if (const char* ti = alt_env("MIA_HIP_TALLY_INLINE")) ctx->tally_defer = atoi(ti) == 0;
+    if (const char* ss = alt_env("MIA_HIP_NO_STRAND_SPLIT")) ctx->tally_strand_split = atoi(ss) == 0;
     if (const char* tc = alt_env("MIA_HIP_TALLY_CHUNK")) { const int c = atoi(tc); if (c == 256 || c == 512 || c == 768) ctx->tally_chunk_linear = c; }
     if (const char* ew = alt_env("MIA_HIP_EARLY_WGS")) ctx->early_wgs_per_cu = atoi(ew);
     if (const char* nf = alt_env("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
@@ -1932,6 +1934,9 @@ static int ensure_tally(mia_hip_ctx* ctx) {
 
 // everything of mia_hip_tally that is queued on the stream; the event count and the error flags are read afterwards
 // the binned tally's layout for this reference: buckets of TALLY_BUCKET columns, one workgroup per TALLY_CHUNK reads of a bucket
+// the position-specific matrices' tally sorts by strand as well (bucket_of, mia_consensus_kernels.h): twice the buckets
+static int tally_split(const mia_hip_ctx* ctx) { return (!ctx->tally_linear && ctx->tally_strand_split && !ctx->early_queued && !ctx->use_early) ? 1 : 0; }
+static int tally_nb(const mia_hip_ctx* ctx) { return (ctx->wrap / TALLY_BUCKET + 1) << tally_split(ctx); }
 static bool tally_is_binned(const mia_hip_ctx* ctx) {
   const int nb = ctx->wrap / TALLY_BUCKET + 1;
   return ctx->rs.n > 0 && ctx->use_binned_tally && nb <= 4096 && ctx->max_abs <= 32767;   // (the LDS copy of the matrices is int16)
@@ -1947,7 +1952,7 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
   const int Lp = ctx->tb.Lp;
   const int64_t tally_words = (int64_t)(TALLY_WORDS + 1) * Lp + 256;                               // tally, gaps, the ranks' event counts
   const int64_t n = ctx->rs.n;
-  const int nb = ctx->wrap / TALLY_BUCKET + 1;
+  const int nb = tally_nb(ctx), split = tally_split(ctx);
   // (behind an early tally what is left are the reads with substitutions and gaps -- a fifth of them, and the slow ones: smaller shares
   // per workgroup, or a few hundred workgroups with 512 slow reads each take longer than the whole tally did)
   const int chunk = tally_chunk(ctx);
@@ -1965,10 +1970,10 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
   // (with an early tally queued: only the reads it did not take, and the tally buffers are left alone -- its own sort cleared them)
   const uint8_t* part = ctx->early_queued ? ctx->d_early : nullptr;
   hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, part ? (int32_t*)nullptr : ctx->tb.tally, part ? (int64_t)0 : tally_words,
-                     ctx->abort_if, part, 0);
+                     ctx->abort_if, part, 0, split);
   hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb, ctx->abort_if, chunk);
   const bool sigb = on != ctx->stream && (ctx->ext_events & 16u);
-  launch_k(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, sigb ? ctx->ev_join : nullptr, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if, part, 0);
+  launch_k(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, sigb ? ctx->ev_join : nullptr, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if, part, 0, split);
   HIPCHK(hipGetLastError());
   if (on != ctx->stream && !sigb) HIPCHK(hipEventRecord(ctx->ev_join, on));
   ctx->buckets_queued = on != ctx->stream ? 2 : 1;
@@ -2019,11 +2024,11 @@ static int early_tally_launch(mia_hip_ctx* ctx) {
         ? stage_launch(ctx, STG_TALLY, k_tally_binned<true, false>, dim3(grid), dim3(256), throttle, on, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                        ctx->tb, nb, d_off, d_wgoff, ctx->d_order_e, ctx->d_trec_early, ctx->ri.actf, ctx->d_tally_slabs_e, ctx->dbg,
                        planes_ok ? ctx->d_rplanes : nullptr, ctx->rplane_words, planes_ok ? ctx->d_umax : nullptr, d_wgb, -1, (const int32_t*)nullptr, (int32_t)TALLY_CHUNK,
-                       (int32_t*)nullptr, (int32_t*)nullptr)
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0)
         : stage_launch(ctx, STG_TALLY, k_tally_binned<false, false>, dim3(grid), dim3(256), throttle, on, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b,
                        ctx->tb, nb, d_off, d_wgoff, ctx->d_order_e, ctx->d_trec_early, ctx->ri.actf, ctx->d_tally_slabs_e, ctx->dbg,
                        (const uint64_t*)nullptr, 0, (const int32_t*)nullptr, d_wgb, ctx->tally_pk_bias, (const int32_t*)nullptr, (int32_t)TALLY_CHUNK,
-                       (int32_t*)nullptr, (int32_t*)nullptr))
+                       (int32_t*)nullptr, (int32_t*)nullptr, 0))
     return MIA_HIP_ERR_NOMEM;
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(ctx->ev_early, on));
@@ -2045,7 +2050,7 @@ static int tally_launch(mia_hip_ctx* ctx) {
   if (!binned) HIPCHK(hipMemsetAsync(ctx->tb.tally, 0, (size_t)tally_words * 4, ctx->stream));     // (the binned path clears it inside k_bucket_count)
   if (n > 0) {
     RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
-    const int nb = ctx->wrap / TALLY_BUCKET + 1;
+    const int nb = tally_nb(ctx), split = tally_split(ctx);
     if (binned) {
       // counting sort of the reads by alignment start, then one LDS tally window per workgroup
       if (!ctx->buckets_queued) { if (int rcb = bucket_launch(ctx, ctx->stream)) return rcb; }
@@ -2070,7 +2075,7 @@ static int tally_launch(mia_hip_ctx* ctx) {
       if (defer && !ctx->in_iterate) HIPCHK(hipMemsetAsync(n_gen, 0, 4, ctx->stream));     // (mia_hip_iterate clears the whole control block)
 #define MIA_TALLY_ARGS(PL, RW, UM, BIAS)                                                                                                              \
   dim3(grid), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b, ctx->tb, nb, d_off, d_wgoff, ctx->d_order, ctx->ri.trec, \
-      ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg, PL, RW, UM, d_wgb, BIAS, ctx->abort_if, chunk, defer ? ctx->d_gen_list : (int32_t*)nullptr, n_gen
+      ctx->ri.actf, ctx->d_tally_slabs, ctx->dbg, PL, RW, UM, d_wgb, BIAS, ctx->abort_if, chunk, defer ? ctx->d_gen_list : (int32_t*)nullptr, n_gen, split
       const uint64_t* pl_arg = planes_ok ? ctx->d_rplanes : nullptr;
       const int32_t* um_arg = planes_ok ? ctx->d_umax : nullptr;
       int rct;
@@ -2078,8 +2083,8 @@ static int tally_launch(mia_hip_ctx* ctx) {
         rct = defer ? stage_launch(ctx, STG_TALLY, k_tally_binned<true, true>, MIA_TALLY_ARGS(pl_arg, ctx->rplane_words, um_arg, -1))
                     : stage_launch(ctx, STG_TALLY, k_tally_binned<true, false>, MIA_TALLY_ARGS(pl_arg, ctx->rplane_words, um_arg, -1));
       else
-        rct = defer ? stage_launch(ctx, STG_TALLY, k_tally_binned<false, true>, MIA_TALLY_ARGS((const uint64_t*)nullptr, 0, (const int32_t*)nullptr, ctx->tally_pk_bias))
-                    : stage_launch(ctx, STG_TALLY, k_tally_binned<false, false>, MIA_TALLY_ARGS((const uint64_t*)nullptr, 0, (const int32_t*)nullptr, ctx->tally_pk_bias));
+        rct = defer ? stage_launch(ctx, STG_TALLY, k_tally_binned<false, true>, MIA_TALLY_ARGS(split ? pl_arg : nullptr, ctx->rplane_words, split ? um_arg : nullptr, ctx->tally_pk_bias))
+                    : stage_launch(ctx, STG_TALLY, k_tally_binned<false, false>, MIA_TALLY_ARGS(split ? pl_arg : nullptr, ctx->rplane_words, split ? um_arg : nullptr, ctx->tally_pk_bias));
 #undef MIA_TALLY_ARGS
       if (rct) return MIA_HIP_ERR_NOMEM;
       if (ctx->early_queued) {
@@ -2093,7 +2098,7 @@ static int tally_launch(mia_hip_ctx* ctx) {
       }
       GenReads gen{ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f, ctx->d_drop_b, ctx->ri.trec, ctx->ri.actf, defer ? ctx->d_gen_list : nullptr, n_gen};
       hipLaunchKernelGGL(k_tally_reduce, dim3((Lp + 255) / 256 + (defer ? TALLY_GEN_BLOCKS : 0), TALLY_WORDS - 1, TALLY_REDUCE_SHARES), dim3(256), 0, ctx->stream, ctx->tb, nb, d_wgoff,
-                         ctx->d_tally_slabs, ctx->abort_if, gen);
+                         ctx->d_tally_slabs, ctx->abort_if, gen, split);
     } else {
       hipLaunchKernelGGL(k_tally, dim3((int)((n + 3) / 4)), dim3(256), 0, ctx->stream, ctx->rs, ref, ctx->d_pssm, ctx->d_drop_f,
                          ctx->d_drop_b, ctx->tb, ctx->ri.trec, ctx->ri.actf);
