@@ -44,7 +44,12 @@ other = ((c < 0) & (c != INS) & valid).sum(1)
 gaps = runs_ins + runs_del
 print("reads", n, "gap-free", int((gaps == 0).sum()), "one gap", int((gaps == 1).sum()), "two", int((gaps == 2).sum()), "more", int((gaps > 2).sum()),
       "rows that are neither aligned nor inserted (soft ends)", int((other > 0).sum()))
-print("bx counters", list(hip.bx_counters()[:10]))
+c = hip.bx_counters()
+print("bx counters: values lists", list(c[:5]), "trace lists", list(c[5:10]), "cur/done/seen", list(c[10:16]), "plan gave up by reason", list(c[16:24]), "late", list(c[24:30]), "cand", list(c[30:32]))
+try:
+    print("stages", pipe.stages(1, None, None, True)[1])
+except Exception as e:
+    print("stages: n/a", e)
 if os.environ.get("MIA_HIP_DEBUG_SKIP"):
     import ctypes as C
     k = np.zeros(16, np.uint64)
