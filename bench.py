@@ -74,6 +74,8 @@ def source_hash():
     """what the kernels were built from: the PMC summaries name the build they were collected on"""
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
+        if f.startswith(".") or not os.path.isfile(os.path.join(CSRC, f)):
+            continue
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
