@@ -724,8 +724,8 @@ def timed_job(a, env, cfg, reads, scaling, peaks=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--reads", type=int, default=None, help="reads per GPU (weak) or in the whole job (strong); default 1 M on one GPU, 10 M (strong) on several")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None, help="default: weak on one GPU, strong (north_star's target) on several")
     ap.add_argument("--config", type=int, default=None, choices=(1, 2, 3, 4), help="BASELINE.json configs[k] for the timed steps; default 1 on one GPU, 3 on several")

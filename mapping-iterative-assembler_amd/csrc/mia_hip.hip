@@ -200,7 +200,10 @@ struct mia_hip_ctx {
   int use_binned_tally = 1;   // MIA_HIP_NO_BINNED_TALLY=1: plain global-atomic tally
   int32_t* d_tally_slabs = nullptr; int64_t tally_slab_cap = 0;   // one LDS window per tally workgroup, summed by k_tally_reduce
   int32_t* d_gen_list = nullptr; int64_t gen_cap = 0;             // the reads k_tally_binned leaves to k_tally_reduce's extra workgroups (a thousand in a million; room for all)
-  bool tally_strand_split = true;                                 // MIA_HIP_NO_STRAND_SPLIT=1 (alt build): position-specific matrices, buckets by column only
+  // MIA_HIP_STRAND_SPLIT=1 (alt build only): position-specific matrices, the tally's buckets by column AND strand, the rows of depth code 15
+  // through the vertical counters.  Measured: configs[2] 1.313 -> 1.306 ms, configs[4] at 5 M reads 9.91 -> 10.2 ms (twice the part-filled
+  // workgroups and slabs; the end rows' packed atomics are what the kernel waits for either way) -- off
+  bool tally_strand_split = false;
   int tally_chunk_linear = TALLY_CHUNK_LINEAR;                    // MIA_HIP_TALLY_CHUNK=256|512|768 (alt build)
   bool tally_defer = true;                                        // MIA_HIP_TALLY_INLINE=1 (alt build): they are taken inside k_tally_binned, one per wavefront
   // wide scratch
@@ -374,7 +377,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (nwl && atoi(nwl)) ctx->use_wild = 0;
     if (const char* ne = alt_env("MIA_HIP_EARLY_TALLY")) ctx->use_early = atoi(ne) != 0;
     if (const char* ti = alt_env("MIA_HIP_TALLY_INLINE")) ctx->tally_defer = atoi(ti) == 0;
-    if (const char* ss = alt_env("MIA_HIP_NO_STRAND_SPLIT")) ctx->tally_strand_split = atoi(ss) == 0;
+    if (const char* ss = alt_env("MIA_HIP_STRAND_SPLIT")) ctx->tally_strand_split = atoi(ss) != 0;
     if (const char* tc = alt_env("MIA_HIP_TALLY_CHUNK")) { const int c = atoi(tc); if (c == 256 || c == 512 || c == 768) ctx->tally_chunk_linear = c; }
     if (const char* ew = alt_env("MIA_HIP_EARLY_WGS")) ctx->early_wgs_per_cu = atoi(ew);
     if (const char* nf = alt_env("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;

@@ -25,9 +25,9 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             "MIA_HIP_EARLY_TALLY",
             # the reads no one-read-per-lane route of k_tally_binned takes: inside it, one per wavefront (default: by extra workgroups of k_tally_reduce)
             "MIA_HIP_TALLY_INLINE",
-            # position-specific matrices: the tally's buckets by column only (default: by column and strand, the rows of depth code 15 through
-            # the vertical counters); no vertical counters at all, either matrix
-            "MIA_HIP_NO_STRAND_SPLIT", "MIA_HIP_DEBUG_SKIP=4096"]
+            # position-specific matrices: the tally's buckets by column and strand, the rows of depth code 15 through the vertical counters
+            # (an experiment; default: by column only); no vertical counters at all, either matrix
+            "MIA_HIP_STRAND_SPLIT", "MIA_HIP_DEBUG_SKIP=4096"]
 
 
 def two_iterations(mod, w, env):
