@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03_campaigns.log; : > $O
+O=gpurun_out/${ROUND:-r04}_campaigns.log; : > $O
 run() { echo "== $*" >> $O; timeout -k 10 900 python3 "$@" 2>&1 | tail -1 >> $O; echo "rc $?" >> $O; tail -2 $O; }
 run tools/band_campaign.py 60 301000 MIA_HIP_NO_DIAG_FILTER flat
 run tools/band_campaign.py 60 302000 MIA_HIP_NO_DIAG_FILTER flat nrich
@@ -7,7 +7,7 @@ run tools/band_campaign.py 60 303000 MIA_HIP_NO_DIAG_FILTER ancient
 run tools/band_campaign.py 60 304000 MIA_HIP_NO_DIAG_FILTER ancient nrich
 run tools/band_campaign.py 40 305000 MIA_HIP_NO_DIAG_FILTER solexa
 run tools/band_campaign.py 40 306000 MIA_HIP_NO_DIAG_FILTER solexa nrich
-run tools/tally_campaign.py 40 307000
+run tools/tally_campaign.py 120 407000
 run tools/pass1_campaign.py 40 308000 plain flat
 run tools/pass1_campaign.py 40 309000 nrich flat
 run tools/pass1_campaign.py 60 310000 plain ancient
