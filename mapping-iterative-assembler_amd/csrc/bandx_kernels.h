@@ -622,6 +622,9 @@ __device__ __forceinline__ uint32_t bxl_values_chunk(const ReadSet& rs, const Re
 }
 
 __global__ __launch_bounds__(256, 4) void k_bxl_values(ReadSet rs, RefInfo ref, BxDev bx, int32_t* bin_of) {
+  // the step's chain runs through this kernel and the late trace behind it, while k_bxl_trace beside them has slack: their
+  // wavefronts go first wherever a SIMD has both to choose from (MIA_HIP_BX_DEBUG=128: all at priority 0)
+  if (!(bx.dbg & 128u)) __builtin_amdgcn_s_setprio(2);
   __shared__ int32_t sub_lds[BX_SUB_WORDS];
   for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.tab.sub[k];
   __syncthreads();
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(256, 4) void k_bxl_trace(ReadSet rs, RefInfo ref, B
   bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, BX_NCLS, BXC_LIST0 + BX_NCLS);
 }
 __global__ __launch_bounds__(256, 4) void k_bxl_trace_late(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
+  if (!(bx.dbg & 128u)) __builtin_amdgcn_s_setprio(3);
   bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, 2 * BX_NCLS, BXC_LATE0);
 }
 

@@ -96,19 +96,57 @@ __device__ __forceinline__ void bxl_first_max(int& best, int& bj) {
 }
 
 // eight nibbles of reference codes at a position that advances by one per row (BxSlide<1> of bandx_body.h)
-struct BxlSlide {
-  uint32_t raw[3];
-  int64_t q;
-  __device__ __forceinline__ void init(const uint32_t* refnib, int64_t nib) {
-    q = nib >> 3;
+// The operands of a lane's rows -- eight nibbles of reference codes at a position that advances by one per row, and the read's own
+// code of the row -- eight rows at a time.  A block of eight rows needs 8 + 7 + 7 nibbles of reference: three words, held in
+// registers; the word the NEXT block needs on top is asked for at the head of the block and taken over behind its last row, in a
+// different basic block, so that the wait for it falls eight rows after the load.  (With one `if (position crossed a word) load`
+// per row the compiler put the wait right behind the load: ~1 us of L2 latency every eight rows of every chunk, twice -- the
+// read's words came the same way.)
+struct BxlFeed {
+  uint32_t raw[3], rw;       // reference words q, q + 1, q + 2 of this block; the read's word of this block
+  uint32_t raw_n, rw_n;      // in flight: reference word q + 3, the read's next word
+  const uint32_t* rp;        // refnib + q + 3 of this block
+  const uint32_t* wp;        // the read's words, from this block's next one on
+  int a;                     // nibble offset of row 8 b in raw[0]
+  int more;                  // words of the read left behind rw_n's (packed reads are padded: one word beyond the last is readable)
+  __device__ __forceinline__ void init(const uint32_t* refnib, int64_t nib, const uint32_t* rwords, int len2) {
+    const int64_t q = nib >> 3;
+    a = (int)(nib & 7);
     raw[0] = refnib[q]; raw[1] = refnib[q + 1]; raw[2] = refnib[q + 2];
+    rp = refnib + q + 3;
+    rw = rwords[0];
+    wp = rwords + 1;
+    more = ((len2 - 1) >> 3);
   }
-  __device__ __forceinline__ uint32_t get(const uint32_t* refnib, int64_t nib) {
-    if ((nib >> 3) != q) { raw[0] = raw[1]; raw[1] = raw[2]; q++; raw[2] = refnib[q + 2]; }
-    const int sh = (int)(nib & 7) * 4;
-    return sh ? (raw[0] >> sh) | (raw[1] << (32 - sh)) : raw[0];
+  __device__ __forceinline__ void block_begin() { raw_n = *rp; rw_n = *wp; }
+  __device__ __forceinline__ void block_end() {
+    raw[0] = raw[1]; raw[1] = raw[2]; raw[2] = raw_n; rp++;
+    rw = rw_n; if (more > 0) { wp++; more--; }
   }
+  // row 8 b + k of the block: the eight reference nibbles from the lane's position on / the read's code
+  __device__ __forceinline__ uint32_t cw(int k) const {
+    const int t = a + k;       // 0 .. 14
+    const bool hi = t >= 8;
+    return __builtin_amdgcn_alignbit(hi ? raw[2] : raw[1], hi ? raw[1] : raw[0], (uint32_t)(4 * t) & 31u);
+  }
+  __device__ __forceinline__ int code(int k) const { return (int)((rw >> (4 * k)) & 3u); }
 };
+// for (r = 1; r < len2; r++) body(r, cw, code), fed block by block (row 0 is the caller's: feed.cw(0), feed.code(0) before this)
+template <class F>
+__device__ __forceinline__ void bxl_rows(BxlFeed& feed, int len2, F&& body) {
+  for (int r0 = 0; r0 < len2; r0 += 8) {
+    feed.block_begin();
+    const int k_hi = len2 - r0 < 8 ? len2 - r0 : 8;
+    for (int k = r0 ? 0 : 1; k < k_hi; k++) body(r0 + k, feed.cw(k), feed.code(k));
+    feed.block_end();
+  }
+}
+// the row's eight substitution scores: all eight LDS reads issued before anything waits for one (left to itself the compiler
+// interleaved them with the recurrence, one read and one wait per cell: eight LDS round trips per row)
+#define BXL_SUB_ROW(sb, row, cw)                                                              \
+  int sb[BXL_CELLS];                                                                          \
+  _Pragma("unroll") for (int j_ = 0; j_ < BXL_CELLS; j_++) sb[j_] = (row)[__builtin_amdgcn_ubfe((cw), 4 * j_, 3)]; \
+  __builtin_amdgcn_sched_barrier(0)
 
 // cells of this lane (band indices 8u .. 8u + 7) whose column lies inside the window [0, len1)
 __device__ __forceinline__ uint32_t bxl_live(int c0_lane, int len1) {
@@ -124,12 +162,11 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
                                            int* best_out, int* bj_out) {
   const int dl = d0 + BXL_CELLS * u;                       // this lane's first diagonal
   int32_t P[BXL_CELLS], H[BXL_CELLS];
-  uint32_t rw = rwords[0], rw_next = rwords[1];
-  BxlSlide slide;
-  slide.init(refnib, (int64_t)s + dl + BX_NIB_LEAD);
+  BxlFeed feed;
+  feed.init(refnib, (int64_t)s + dl + BX_NIB_LEAD, rwords, len2);
   {
-    const uint32_t cw = slide.get(refnib, (int64_t)s + dl + BX_NIB_LEAD);
-    const int32_t* row = sub + (int)(rw & 3u) * BX_SUB_ROW;              // depth 0
+    const uint32_t cw = feed.cw(0);
+    const int32_t* row = sub + feed.code(0) * BX_SUB_ROW;              // depth 0
     const uint32_t live = EDGE ? bxl_live(dl, len1) : 0xFFu;
 #pragma unroll
     for (int j = 0; j < BXL_CELLS; j++) {
@@ -138,11 +175,10 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
       P[j] = ((live >> j) & 1u) ? v : BX_NEG;
     }
   }
-  for (int r = 1; r < len2; r++) {
+  bxl_rows(feed, len2, [&](int r, uint32_t cw, int code) {
     const int c0 = r + dl;
-    const uint32_t cw = slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD);
-    if ((r & 7) == 0) { rw = rw_next; rw_next = rwords[(r >> 3) + 1]; }      // (packed reads are padded: one word beyond the last is readable)
-    const int32_t* row = sub + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
+    const int32_t* row = sub + (sm_depth(r, len2) * 4 + code) * BX_SUB_ROW;
+    BXL_SUB_ROW(sbv, row, cw);
     uint32_t live = 0xFFu, col0 = 0u;
     if (EDGE) {
       live = bxl_live(c0, len1);
@@ -168,7 +204,7 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
 #pragma unroll
     for (int j = 0; j < BXL_CELLS; j++) {
       const int pd = P[j], h = H[j];
-      const int sb = row[(cw >> (4 * j)) & 7u];
+      const int sb = sbv[j];
       const int x = pd > G ? (pd > h ? pd : h) : (G > h ? G : h);
       int cur = fresh > x ? fresh : x + sb;
       if (EDGE) {
@@ -184,7 +220,7 @@ __device__ __forceinline__ void bxl_values(const uint32_t* refnib, int s, int le
       const int hr = bxl_from_right1(nh0, BX_NEG);
       H[BXL_CELLS - 1] = u < LPR - 1 ? hr : BX_NEG;
     } else H[BXL_CELLS - 1] = BX_NEG;
-  }
+  });
   int best = BX_NEG, bj = -1;
 #pragma unroll
   for (int j = 0; j < BXL_CELLS; j++) if (P[j] > best) { best = P[j]; bj = j; }
@@ -217,14 +253,13 @@ __device__ __forceinline__ void bxl_values_star(const uint32_t* refnib, int s, c
                                                 int* best_out, int* bj_out) {
   const int dl = d0 + BXL_CELLS * u;
   int32_t Q[BXL_CELLS], H[BXL_CELLS];
-  uint32_t rw = rwords[0], rw_next = rwords[1];
-  BxlSlide slide;
-  slide.init(refnib, (int64_t)s + dl + BX_NIB_LEAD);
+  BxlFeed feed;
+  feed.init(refnib, (int64_t)s + dl + BX_NIB_LEAD, rwords, len2);
   // rows below r_cut keep the new-start branch (this lane's read; the wavefront runs the largest)
   int r_cut = len2;
   if (b0 >= 0) {
     int acc = GOP, q = 0;
-    uint32_t w = rw;
+    uint32_t w = feed.rw;
     for (; q < len2; q++) {
       if (q && (q & 7) == 0) w = rwords[q >> 3];
       const int b = (int)((w >> (4 * (q & 7))) & 3u);
@@ -236,8 +271,8 @@ __device__ __forceinline__ void bxl_values_star(const uint32_t* refnib, int s, c
   for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(r_cut, o); r_cut = t > r_cut ? t : r_cut; }
   r_cut = __builtin_amdgcn_readfirstlane(r_cut);            // (the same in every lane: a scalar, so that `early` below is a branch)
   {
-    const uint32_t cw = slide.get(refnib, (int64_t)s + dl + BX_NIB_LEAD);
-    const int32_t* row = sub + (int)(rw & 3u) * BX_SUB_ROW;              // depth 0
+    const uint32_t cw = feed.cw(0);
+    const int32_t* row = sub + feed.code(0) * BX_SUB_ROW;              // depth 0
 #pragma unroll
     for (int j = 0; j < BXL_CELLS; j++) {
       H[j] = BX_NEG;
@@ -246,12 +281,10 @@ __device__ __forceinline__ void bxl_values_star(const uint32_t* refnib, int s, c
   }
   int fl = -GOP - GEP + 2 * GEP + GEP * BXL_CELLS * u + GEP;           // fresh*(r, 8 u) + 2 GEP at r = 1
   // one row; EARLY: with the new-start branch (two loops below: a flag tested per cell would be a select per cell)
-  auto row_step = [&](int r, auto early_tag) {
+  auto row_step = [&](int r, uint32_t cw, int code, auto early_tag) {
     constexpr bool EARLY = decltype(early_tag)::value;
-    const int c0 = r + dl;
-    const uint32_t cw = slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD);
-    if ((r & 7) == 0) { rw = rw_next; rw_next = rwords[(r >> 3) + 1]; }
-    const int32_t* row = sub + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
+    const int32_t* row = sub + (sm_depth(r, len2) * 4 + code) * BX_SUB_ROW;
+    BXL_SUB_ROW(sbv, row, cw);
     int cand[BXL_CELLS];
 #pragma unroll
     for (int j = 0; j < BXL_CELLS; j++) cand[j] = Q[j] - GOP;
@@ -266,7 +299,7 @@ __device__ __forceinline__ void bxl_values_star(const uint32_t* refnib, int s, c
 #pragma unroll
     for (int j = 0; j < BXL_CELLS; j++) {
       const int pd = Q[j], h = H[j];
-      const int sb = row[__builtin_amdgcn_ubfe(cw, 4 * j, 3)];
+      const int sb = sbv[j];
       const int x = pd > G ? (pd > h ? pd : h) : (G > h ? G : h);
       int q = x + sb + 2 * GEP;
       if (EARLY) { const int f = fl + GEP * j; q = q > f ? q : f; }
@@ -281,10 +314,14 @@ __device__ __forceinline__ void bxl_values_star(const uint32_t* refnib, int s, c
     } else H[BXL_CELLS - 1] = BX_NEG;
     fl += GEP;
   };
-  int r = 1;
-  const int r_mid = r_cut < len2 ? r_cut : len2;
-  for (; r < r_mid; r++) row_step(r, std::true_type{});
-  for (; r < len2; r++) row_step(r, std::false_type{});
+  // (blocks of eight rows, see BxlFeed: a block is of one kind or the other, the one r_cut falls into keeps the branch)
+  for (int r0 = 0; r0 < len2; r0 += 8) {
+    feed.block_begin();
+    const int k_hi = len2 - r0 < 8 ? len2 - r0 : 8;
+    if (r0 < r_cut) { for (int k = r0 ? 0 : 1; k < k_hi; k++) row_step(r0 + k, feed.cw(k), feed.code(k), std::true_type{}); }
+    else { for (int k = 0; k < k_hi; k++) row_step(r0 + k, feed.cw(k), feed.code(k), std::false_type{}); }
+    feed.block_end();
+  }
   // back to scores: S(R, j) = Q(j) - 2 GEP - 2 GEP R - GEP j
   const int back = 2 * GEP + 2 * GEP * (len2 - 1) + GEP * BXL_CELLS * u;
   int best = BX_NEG, bj = -1;
@@ -315,13 +352,12 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
   const int dl = d0 + BXL_CELLS * u;
   int32_t P[BXL_CELLS], H[BXL_CELLS];
   uint32_t tb[BXL_CELLS];                             // the four rows' codes of each of this lane's cells
-  uint32_t rw = rwords[0], rw_next = rwords[1];
+  BxlFeed feed;
+  feed.init(refnib, (int64_t)s + dl + BX_NIB_LEAD, rwords, len2);
   uint32_t* mine = trace + 4 * lane_in_wave;          // this lane's four words of cells 0..3; cells 4..7 sit 256 words further
-  BxlSlide slide;
-  slide.init(refnib, (int64_t)s + dl + BX_NIB_LEAD);
   {
-    const uint32_t cw = slide.get(refnib, (int64_t)s + dl + BX_NIB_LEAD);
-    const int32_t* row = sub256 + (int)(rw & 3u) * BX_SUB_ROW;
+    const uint32_t cw = feed.cw(0);
+    const int32_t* row = sub256 + feed.code(0) * BX_SUB_ROW;
     const uint32_t live = EDGE ? bxl_live(dl, len1) : 0xFFu;
 #pragma unroll
     for (int j = 0; j < BXL_CELLS; j++) {
@@ -335,11 +371,10 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
       for (int j = 0; j < BXL_CELLS; j += 4) *reinterpret_cast<uint4*>(mine + (j >> 2) * 256) = make_uint4(tb[j], tb[j + 1], tb[j + 2], tb[j + 3]);
     }
   }
-  for (int r = 1; r < len2; r++) {
+  bxl_rows(feed, len2, [&](int r, uint32_t cw, int code) {
     const int c0 = r + dl;
-    const uint32_t cw = slide.get(refnib, (int64_t)s + c0 + BX_NIB_LEAD);
-    if ((r & 7) == 0) { rw = rw_next; rw_next = rwords[(r >> 3) + 1]; }      // (packed reads are padded: one word beyond the last is readable)
-    const int32_t* row = sub256 + (sm_depth(r, len2) * 4 + (int)((rw >> (4 * (r & 7))) & 3u)) * BX_SUB_ROW;
+    const int32_t* row = sub256 + (sm_depth(r, len2) * 4 + code) * BX_SUB_ROW;
+    BXL_SUB_ROW(sbv, row, cw);
     uint32_t live = 0xFFu, col0 = 0u;
     if (EDGE) {
       live = bxl_live(c0, len1);
@@ -365,7 +400,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
 #pragma unroll
     for (int j = 0; j < BXL_CELLS; j++) {
       const int pd = P[j] | 0xFF, h = H[j], gc = G | 0x40;
-      const int sb = row[(cw >> (4 * j)) & 7u];
+      const int sb = sbv[j];
       const int x = pd > gc ? (pd > h ? pd : h) : (gc > h ? gc : h);
       int cur = f0 > x ? f0s : x + sb;                  // fresh must beat all three strictly (its code byte is 0 in f0)
       if (EDGE) {
@@ -387,7 +422,7 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
 #pragma unroll
       for (int j = 0; j < BXL_CELLS; j += 4) *reinterpret_cast<uint4*>(tr + (j >> 2) * 256) = make_uint4(tb[j], tb[j + 1], tb[j + 2], tb[j + 3]);
     }
-  }
+  });
   // max_sg_score: first maximum of the last row (src/mia.c:1278-1302)
   int best = BX_NEG, bj = -1;
 #pragma unroll
@@ -421,10 +456,14 @@ __device__ __forceinline__ bool bxl_trace(const uint32_t* refnib, int s, int len
     const uint32_t col = (uint32_t)(((j >> 2) & 1) * 256 + (lane_in_wave + (j >> 3)) * 4 + (j & 3));      // (band index j: cell j & 7 of the lane j >> 3 places to the right)
     const int q0 = r >> 2;
     uint32_t nd = 0;                         // bit i: row 4 (q0 - 3) + i holds something else than a diagonal step
+    uint32_t wq[4];                          // (all four loads before the first wait: one after the other they were four trips to the L2 per step of the walk)
+#pragma unroll
+    for (int t = 0; t < 4; t++) { const int q = q0 - t; wq[t] = trace[(uint32_t)(q > 0 ? q : 0) * BLK_WORDS + col]; }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       const int q = q0 - t;
-      const uint32_t wv = trace[(uint32_t)(q > 0 ? q : 0) * BLK_WORDS + col];
+      const uint32_t wv = wq[t];
       const uint32_t x = ~wv, y = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;      // bit 8 k + 7: byte k is not 0xFF
       const uint32_t z = y >> 7, nib = (z | (z >> 7) | (z >> 14) | (z >> 21)) & 15u;
       if (q >= 0) nd |= nib << (4 * (3 - t));  // (blocks above the matrix: all diagonal; the walk never gets there: kmax)

@@ -179,6 +179,9 @@ struct RecInfo {              // per read, rebuilt every iteration by k_rec_geom
 // fields costs a dozen cache lines per read (1.8 GB per 1 M reads).  k_rec_params writes them side by side instead.
 enum { TREC_AS = 0, TREC_AE, TREC_LEN_ABR, TREC_FLAGS, TREC_REFSTART, TREC_ROFF, TREC_ACTF, TREC_SPARE, TREC_PARAMS = 8 };
 constexpr int TRF_RC = 1, TRF_DF = 2, TRF_DB = 4, TRF_DIAG = 8, TRF_TOO_LONG = 16, TRF_SK = 32, TRF_ONEGAP = 64;   // ONEGAP: TREC_SPARE describes the gap
+// NO_N: the read holds no N (k_bx_umax's mark, umax[i] >= 0: its bit planes say everything) -- in the record so that the tally does
+// not fetch a 128-byte line per read for that one bit (the gather of record, planes and mark is 60 % of k_tally_binned's time)
+constexpr int TRF_NO_N = 128;
 struct SlotInfo {             // per local AlnSeq slot (global slot - slot_base)
   int64_t base;               // first global slot of this context
   const int64_t* n_local_p;   // slots owned by this context in this iteration (device: the scan's total)
@@ -571,7 +574,7 @@ __device__ __forceinline__ void rec_default_params(const RecGeom& g, int n_al, i
   p[0] = 0; p[1] = 0; p[2] = flen + blen; p[3] = 1;
   p[4] = g.split ? flen : 0; p[5] = g.split ? *actf : 0; p[6] = g.split ? flen + blen : 0; p[7] = g.split ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_rec_early(ReadSet rs, int32_t L, const uint8_t* early, int32_t* trec) {
+__global__ __launch_bounds__(256) void k_rec_early(ReadSet rs, int32_t L, const uint8_t* early, int32_t* trec, const int32_t* umax = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= rs.n || !early[i]) return;
   const RecGeom g = rec_geom(rs.as[i], rs.ae[i], L);
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256) void k_rec_early(ReadSet rs, int32_t L, const 
   int actf;
   rec_default_params(g, (int)rs.len[i], p, &actf);
   int4* t4 = reinterpret_cast<int4*>(trec + i * 16);
-  t4[0] = make_int4(rs.as[i], rs.ae[i], (int32_t)(uint32_t)rs.len[i], (rs.rc[i] ? TRF_RC : 0) | TRF_DIAG | TRF_SK);      // (abr = 0: the plan's reads start in row 0)
+  t4[0] = make_int4(rs.as[i], rs.ae[i], (int32_t)(uint32_t)rs.len[i], (rs.rc[i] ? TRF_RC : 0) | TRF_DIAG | TRF_SK | ((umax && umax[i] >= 0) ? TRF_NO_N : 0));      // (abr = 0: the plan's reads start in row 0)
   t4[1] = make_int4(rs.refstart[i], (int32_t)rs.roff[i], actf, 0);
   t4[2] = make_int4(p[0], p[1], p[2], p[3]);
   t4[3] = make_int4(p[4], p[5], p[6], p[7]);
@@ -589,7 +592,7 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
                              RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, const int32_t* link_act, const int32_t* n_links_p,
                              int32_t cap, int64_t read_base,
                              uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags, const int32_t* abort_if = nullptr,
-                             const uint8_t* early = nullptr, int32_t* fix_list = nullptr, int32_t* n_fix = nullptr) {
+                             const uint8_t* early = nullptr, int32_t* fix_list = nullptr, int32_t* n_fix = nullptr, const int32_t* umax = nullptr) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rs.n) return;
@@ -642,7 +645,8 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
   // the 64-byte record in four 16-byte stores (sixteen 4-byte ones, 64 bytes apart across the lanes, took twice as long)
   int4* t4 = reinterpret_cast<int4*>(ri.trec + i * 16);
   const int fl = (rs.rc[i] ? TRF_RC : 0) | (df ? TRF_DF : 0) | (db ? TRF_DB : 0) | ((st & ST_DIAG) ? TRF_DIAG : 0) |
-                 ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0) | ((st & ST_ONEGAP) ? TRF_ONEGAP : 0);
+                 ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0) | ((st & ST_ONEGAP) ? TRF_ONEGAP : 0) |
+                 ((umax && umax[i] >= 0) ? TRF_NO_N : 0);
   t4[0] = make_int4(rs.as[i], rs.ae[i], (int32_t)((uint32_t)rs.len[i] | ((uint32_t)(uint16_t)rs.abr[i] << 16)), fl);   // TREC_AS, _AE, _LEN_ABR, _FLAGS
   t4[1] = make_int4(rs.refstart[i], (int32_t)rs.roff[i], ri.actf[i], (int32_t)(st >> 8));                                // TREC_REFSTART, _ROFF, _ACTF, _SPARE
   t4[2] = make_int4(p[0], p[1], p[2], p[3]);                                                                              // TREC_PARAMS ..
@@ -920,7 +924,11 @@ __device__ unsigned long long g_tally_kinds[8];
 __device__ unsigned long long g_tally_clk[8];
 #define TALLY_CLK(k) do { if ((dbg & 131072u) && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_tally_clk[k], now_ - clk_); clk_ = now_; } } while (0)
 #define TALLY_CLK_DECL unsigned long long clk_ = (dbg & 131072u) ? __builtin_amdgcn_s_memtime() : 0ull
+// (MIA_HIP_DEBUG_SKIP bits 1 << 18 .. 1 << 21, timing only: no adds to the vertical counters / counters not folded into the window / no slab
+// store / records fetched but no read taken -- tools/tally_prof.py)
+#define TALLY_ABL(bit) ((dbg & (bit)) != 0u)
 #else
+#define TALLY_ABL(bit) false
 #define TALLY_KIND(k) do { } while (0)
 #define TALLY_CLK(k) do { } while (0)
 #define TALLY_CLK_DECL do { } while (0)
@@ -1112,7 +1120,7 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
       const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)ii * 16);
       q.a = tr4[0]; q.b4 = tr4[1]; q.c4 = tr4[2];
       if (bs_on) {
-        q.um = umax[ii];
+        q.um = (q.a.w & TRF_NO_N) ? 0 : -1;
         const uint64_t* pl = rplanes + (int64_t)ii * 2 * rplane_words;
         q.l0 = pl[0]; q.l1 = rplane_words > 1 ? pl[1] : 0ull; q.h0 = pl[rplane_words]; q.h1 = rplane_words > 1 ? pl[rplane_words + 1] : 0ull;
       }
@@ -1122,8 +1130,8 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   ReadIn in_nx = fetch(i_nx);
   for (int k0 = first; k0 < last; k0 += 256) {
     const int i = i_nx;
-    const bool have = i >= 0;
     const ReadIn in = in_nx;
+    const bool have = i >= 0 && !(TALLY_ABL(1u << 21) && in.a.x != 0x7FFFFFFF);
     i_nx = i_nx2;
     i_nx2 = k0 + 512 + (int)threadIdx.x < last ? order[k0 + 512 + (int)threadIdx.x] : -1;
     in_nx = fetch(i_nx);
@@ -1189,8 +1197,10 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
             l0 &= v0; l1 &= v1; h0 &= v0; h1 &= v1;
             const int gn = one_sl ? sl_n : 0, grow = one_sl ? sl_row : 0;
             const bool gi = one_sl && sl_ins;
+            if (!TALLY_ABL(1u << 18)) {
             bs_gap(&l0, &l1, gi, grow, gn); bs_gap(&h0, &h1, gi, grow, gn); bs_gap(&v0, &v1, gi, grow, gn);
             bs_add(l0, l1, h0, h1, v0, v1, w0);
+            }
           }
           if (one_sl) {
             TALLY_KIND(3); TALLY_KIND(4);
@@ -1384,7 +1394,7 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
         lds_i32* t = (lds_i32*)lds + w0;
         const int bad = n_al > PSSM_DEPTH + 1 && fB < n_al;            // (depth codes have to be valid: act <= 15 always is, beyond that fB - act - 1 >= 0)
         uint32_t word = 0;
-        const bool sliced = LINEAR && bs_on && abr == 0 && len2 <= 128 && w0 + ncol <= 64 * BS_W && umax[i] >= 0;
+        const bool sliced = LINEAR && bs_on && abr == 0 && len2 <= 128 && w0 + ncol <= 64 * BS_W && (flags & TRF_NO_N);
         if (sliced) {
           TALLY_KIND(4);
           // the two stretches of the read either side of its gap through the vertical counters; the gap itself as before
@@ -1511,7 +1521,7 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
     }
   }
   TALLY_CLK(1);
-  if (bs_on) {
+  if (bs_on && !TALLY_ABL(1u << 19)) {
     // the wavefront's 64 x 16 vertical counters -> one 8-bit item per group of four lanes -> the window
     auto xch = [&](unsigned long long v, int m) -> unsigned long long { return (unsigned long long)__shfl_xor((long long)v, m); };
     // stage A (lane bit 5): items t and t + 8, 2-bit + 2-bit -> 3 bits; lane bit set keeps the upper half
@@ -1663,6 +1673,7 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   __syncthreads();
   TALLY_CLK(4);
   int32_t* slab = slabs + (int64_t)blockIdx.x * ((TALLY_WORDS - 1) * TALLY_WIN);
+  if (!TALLY_ABL(1u << 20))
   for (int k = threadIdx.x; k < (TALLY_WORDS - 1) * TALLY_WIN; k += blockDim.x) slab[k] = lds[k];
   for (int k = threadIdx.x; k < ne; k += blockDim.x) {
     if (ev_base + k < tb.cap_events) tb.events[ev_base + k] = ev_buf[k]; else atomicOr(tb.flags, 1u);

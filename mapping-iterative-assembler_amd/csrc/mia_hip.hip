@@ -1102,6 +1102,9 @@ static int align_all(mia_hip_ctx* ctx) {
         ctx->bx_values_wgs = ctx->cus * std::min(occ, 4);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, ctx->use_lanes ? (const void*)k_bxl_trace : ALT_KERNEL(k_bx_trace), 256, 0) != hipSuccess || occ < 1) occ = 1;
         ctx->bx_trace_wgs = ctx->cus * std::min(occ, 4);      // (every wavefront of the trace grid owns a slab)
+        // (alt build, percent of the above: how much room the persistent grids leave the planner's chain)
+        if (const char* pv = alt_env("MIA_HIP_BX_VALUES_PCT")) if (atoi(pv) > 0) ctx->bx_values_wgs = std::max(1, ctx->bx_values_wgs * atoi(pv) / 100);
+        if (const char* pt = alt_env("MIA_HIP_BX_TRACE_PCT")) if (atoi(pt) > 0) ctx->bx_trace_wgs = std::max(1, ctx->bx_trace_wgs * atoi(pt) / 100);
       }
       // (the lanes kernels store four rows per word: whole blocks of four rows)
       const int64_t slab_words = ctx->use_lanes ? (int64_t)((ctx->max_len + 3) & ~3) * BXL_SLAB_ROW_WORDS : (int64_t)ctx->max_len * BX_SLAB_ROW_WORDS;
@@ -1112,7 +1115,7 @@ static int align_all(mia_hip_ctx* ctx) {
       BxDev bd;
       bd.tab.sub = ctx->d_bx_sub; bd.tab.mrow = ctx->d_bx_mrow; bd.tab.loss = ctx->d_bx_loss; bd.tab.dl = ctx->d_bx_dl;
       bd.lazy_scripts = ctx->lazy_scripts;
-      bd.dbg = ctx->bx_dbg & (3u | 32u | 64u);
+      bd.dbg = ctx->bx_dbg & (3u | 32u | 64u | 128u);
       // MIA_HIP_BX_SERIAL=1: round 2's order (band kernels, then the planner over everything they left open)
       // (caller-supplied windows -- mia_hip_align_windows -- can be of any length: the retry list's window kernel is picked by read length)
       const bool new_flow = ctx->use_lanes && !ctx->bx_serial && !(ctx->dbg & 256u) && !ctx->explicit_win;
@@ -1605,7 +1608,8 @@ static int finish_params(mia_hip_ctx* ctx) {
   hipLaunchKernelGGL(k_rec_params, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, ctx->d_slot, ctx->d_slot_dropped,
                      ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->d_link_act, ctx->d_n_links_all,
                      (int32_t)ctx->links_cap_all, ctx->read_base, ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags, ctx->abort_if,
-                     ctx->early_queued ? ctx->d_early : (const uint8_t*)nullptr, ctx->d_fix_list, ctx->d_ctrl + CTRL_FIXN);
+                     ctx->early_queued ? ctx->d_early : (const uint8_t*)nullptr, ctx->d_fix_list, ctx->d_ctrl + CTRL_FIXN,
+                     (ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax) ? ctx->d_umax : (const int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   return MIA_HIP_OK;
 }
@@ -2007,7 +2011,8 @@ static int early_tally_launch(mia_hip_ctx* ctx) {
     ctx->tally_slab_e_cap = slab_words;
   }
   RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap};
-  hipLaunchKernelGGL(k_rec_early, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, on, ctx->rs, ctx->L, (const uint8_t*)ctx->d_early, ctx->d_trec_early);
+  hipLaunchKernelGGL(k_rec_early, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, on, ctx->rs, ctx->L, (const uint8_t*)ctx->d_early, ctx->d_trec_early,
+                     (ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax) ? ctx->d_umax : (const int32_t*)nullptr);
   const int gb = (int)((n + 256 * BUCKET_PER - 1) / (256 * BUCKET_PER));
   hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), (size_t)nb * 4, on, ctx->rs, nb, d_cnt, ctx->tb.tally, tally_words, (const int32_t*)nullptr,
                      (const uint8_t*)ctx->d_early, 1);

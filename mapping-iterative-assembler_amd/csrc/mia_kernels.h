@@ -401,6 +401,7 @@ __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, co
                                                       const int32_t* dev_range) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SUB_LDS_BYTES];
   if (dev_range) { list += dev_range[0]; count = dev_range[1]; }     // the planner's answer stayed on the device (k_plan_scan)
+  __builtin_amdgcn_s_setprio(3);    // (a handful of reads, each a chain of its window's rows: ahead of the persistent band grids on its SIMD)
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
   for (int w = blockIdx.x; w < count; w += gridDim.x) {
     const int i = list[w];
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, c
                                                     int32_t band, uint32_t dbg, const int32_t* dev_range) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];   // Q_G * q_sub_bytes(longest read)
   if (dev_range) { list += dev_range[0]; n_quads = dev_range[1]; }
+  __builtin_amdgcn_s_setprio(1);    // (between the step's chain -- values DP, late trace -- and k_bxl_trace, which has slack)
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
   for (int qd = blockIdx.x; qd < n_quads; qd += gridDim.x) {
     QuadArgs a;

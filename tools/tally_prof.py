@@ -21,7 +21,9 @@ for _ in range(5):
     cur = pipe.step(cur)
 hip.close()
 for label, skip in (("default", 0), ("no lane paths", 8), ("no wavefront path", 32), ("one-gap reads dropped", 2048), ("no bit slices", 4096),
-                    ("no per-base adds (PSSM)", 16), ("lanes and wavefront paths off", 40)):
+                    ("no per-base adds (PSSM)", 16), ("lanes and wavefront paths off", 40), ("no adds to the vertical counters", 1 << 18),
+                    ("counters not folded into the window", 1 << 19), ("no slab store", 1 << 20), ("records fetched, no read taken", 1 << 21),
+                    ("no counters, no fold, no slab", (1 << 18) | (1 << 19) | (1 << 20))):
     if skip:
         os.environ["MIA_HIP_DEBUG_SKIP"] = str(skip)
     hip = mia_amd.MiaHip(0)
