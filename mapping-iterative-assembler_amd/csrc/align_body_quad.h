@@ -149,6 +149,11 @@ struct QuadAligner {
       const uint32_t KR = (0u - ((uint32_t)(GOP + GEP * (r - 1)) << SH)) + (TR_ROWGAP << IB) + ((uint32_t)(r - 1) - IDXM);
       const uint32_t RKP = ((uint32_t)(GEP * (r - 1)) << SH) + (IDXM - (uint32_t)(r - 1)) - WDC;   // key constant of row r-1
 
+      // the row's substitution scores: all LDS reads issued before anything waits for one (interleaved with the cells by the
+      // compiler they were thirteen LDS round trips per row)
+      U subv[CPL];
+      for (int j = 0; j < CPL; j++) subv[j] = w.lds_ri16o(sub_addr[j], off);
+      w.sched_fence();
       U dleft = w.rshr1(Sd[CPL - 1], U(WS | WDC));
       U rleft = w.rshr1_max(rrun[CPL - 1], unav);
       U u0 = w.rshr1_max(q[CPL - 2], unav);
@@ -176,7 +181,7 @@ struct QuadAligner {
         U Wr = rl + KR;
         U m3 = w.umax3(Wd, Wc, Wr);
         U best = w.umax(m3, U(WS));
-        U sub = w.lds_ri16o(sub_addr[j], off);
+        U sub = subv[j];
         // start (only if strictly better than the other three) drops the substitution score (src/mia.c:910-917)
         U snew = w.shl_add(w.sel(m3 < WS, U(0u), sub), SH, w.bfi(HI, best, wdcv));
         rrun[j] = w.umax(rrun[j], Sd[j] + RKP);   // row r-1 becomes a best_gap_row candidate for row r+1

@@ -336,6 +336,12 @@ struct KmerHash {
   int32_t wild;            // reference 10-mers with up to this many N are in the table under every spelling (0: none with N)
 };
 constexpr uint32_t KH_EMPTY = 0xFFFFFFFFu;
+// behind a batch of independent loads: nothing is scheduled across, so that the loads are all issued before the first is waited for
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BX_LOADS_ISSUED() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BX_LOADS_ISSUED() do { } while (0)
+#endif
 MIA_HD inline uint32_t kh_slots_for(int64_t n_codes) { uint32_t s = 1024; while ((int64_t)s < 4 * n_codes) s <<= 1; return s; }
 MIA_HD inline int kh_shift_for(uint32_t slots) { int b = 0; while ((1u << b) < slots) b++; return 32 - b; }
 MIA_HD inline uint32_t kh_home(const KmerHash& kh, uint32_t idx) { return (idx * 2654435761u) >> kh.shift; }
@@ -410,29 +416,63 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
   constexpr int NB = bx_nb_max<NW>();      // (a read of NW words has at most this many blocks)
   (void)pw;                                // (the 10-mers come from the planes in sc)
   const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
-  // the home slots of all blocks first, then their use: nine independent loads in flight instead of nine round trips
-  int32_t cn[NB], ps[NB][DF_KCAP];
-  uint32_t kidx[NB], kh0[NB], ke[NB][4];
+  // Every trip to the table is made for all blocks at once: the home slots of the nine blocks are nine loads in flight, and so is
+  // every further round of the open-addressing walk (the blocks whose home slot holds another 10-mer move on together), and the
+  // overflow positions of the repeated 10-mers.  One block after the other -- each with its own probe loop -- a WAVEFRONT walked
+  // nine loops of dependent loads whenever any of its lanes had a collision in that block, i.e. always: a few dozen trips to
+  // the L2 per read, most of k_bx_plan's time.  The blocks' dl come in with the first round (they are wanted by every scan below).
+  // Rounds in straight-line code (selects, no branches; a block that is through loads its own slot again, which leaves its entry
+  // where it is): with a branch per block the loads of a round were issued one by one, each behind a wait for the one before.
+  const int16_t* dl = T.dl + (st * (MAX_READ + 1) + len2) * BX_BLOCKS;
+  int32_t cn[NB], ps[NB][DF_KCAP], dlv[NB];
+  uint32_t kidx[NB], hcur[NB], ke[NB][4];
+  uint32_t open = 0, found = 0;                      // bit b: block b still walks the table / its 10-mer is in the table (entry in ke[b])
 #pragma unroll
   for (int b = 0; b < NB; b++) {
+    kidx[b] = 0; hcur[b] = 0;
     if (b < nb_cut) {
       kidx[b] = bx_kmer_planes<NW>(sc, bx_block_row(b, len2, nb_cut));
-      kh0[b] = kh_home(kh, kidx[b]);
-      const uint32_t* e = kh.slot + 4 * (size_t)kh0[b];
+      hcur[b] = kh_home(kh, kidx[b]);
+      open |= 1u << b;
+    }
+  }
+  for (int probe = 0; ; probe++) {                  // (kh_resolve's walk: 32 slots looked at, then "a crowded neighbourhood")
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const uint32_t* e = kh.slot + 4 * (size_t)hcur[b];
 #pragma unroll
       for (int k = 0; k < 4; k++) ke[b][k] = e[k];
     }
+    BX_LOADS_ISSUED();
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const bool o = ((open >> b) & 1u) != 0u, emp = ke[b][0] == KH_EMPTY, hit = ke[b][0] == kidx[b];
+      const bool fin = o && (emp || hit);
+      found |= (o && hit && !emp) ? 1u << b : 0u;
+      open &= fin ? ~(1u << b) : ~0u;
+      hcur[b] = (o && !fin) ? ((hcur[b] + 1) & kh.mask) : hcur[b];
+    }
+    if (!open || probe == 31) break;
   }
+  uint32_t more = 0;                                 // bit b: overflow positions to fetch
 #pragma unroll
   for (int b = 0; b < NB; b++) {
-    cn[b] = DF_KCAP + 1;
-#pragma unroll
-    for (int k = 0; k < DF_KCAP; k++) ps[b][k] = 0;
-    if (b < nb_cut) cn[b] = kh_resolve(kh, kidx[b], kh0[b], ke[b][0], ke[b][1], ke[b][2], ke[b][3], ps[b]);
+    const bool got = ((found >> b) & 1u) != 0u;
+    const int cnt = (int)(ke[b][2] + 1u);
+    cn[b] = got ? (cnt > DF_KCAP ? DF_KCAP + 1 : cnt) : ((b < nb_cut && !((open >> b) & 1u)) ? 0 : DF_KCAP + 1);
+    ps[b][0] = got ? (int32_t)ke[b][1] : 0; ps[b][1] = got ? (int32_t)ke[b][3] : 0; ps[b][2] = 0; ps[b][3] = 0;
+    more |= (got && cnt > 2) ? 1u << b : 0u;
   }
+#pragma unroll
+  for (int b = 0; b < NB; b++) dlv[b] = dl[b];
+  if (more) {
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+      if ((more >> b) & 1u) { ps[b][2] = kh.ovf[2 * (size_t)hcur[b]]; ps[b][3] = kh.ovf[2 * (size_t)hcur[b] + 1]; }
+  }
+  BX_LOADS_ISSUED();
   int nb = 0, a_lo = 1 << 20, a_hi = -(1 << 20), d_first = 0, d_last = 0, budget = -1, b_first = 0, l_out = -1, s_un = 0, b_lo_any = 0, b_hi_any = 0;
   bool any = false;
-  const int16_t* dl = T.dl + (st * (MAX_READ + 1) + len2) * BX_BLOCKS;
   // the anchors whose diagonal lies in [m_lo, m_hi]: their extent, the first and the last in block order; l_out (if asked
   // for) = what a path loses at least that crosses NONE of them cleanly: dl of every block without an anchor outside
   auto scan = [&](int m_lo, int m_hi, bool want_out) {
@@ -442,7 +482,7 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
     for (int b = 0; b < NB; b++) {
       if (cn[b] > DF_KCAP) continue;                   // no such block, or an overloaded 10-mer: not part of the pigeonhole
       nb++;
-      budget += dl[b];
+      budget += dlv[b];
       const int o = bx_block_row(b, len2, nb_cut);
       bool outside = false, nowhere = true;
 #pragma unroll
@@ -459,8 +499,8 @@ MIA_HD inline void bx_anchors(const DiagScan<NW>& sc, const KmerHash& kh, const 
         if (d < a_lo) a_lo = d;
         if (d > a_hi) a_hi = d;
       }
-      if (!outside) lo_sum += dl[b];
-      if (nowhere) s_un += dl[b];                       // no path crosses this block cleanly
+      if (!outside) lo_sum += dlv[b];
+      if (nowhere) s_un += dlv[b];                       // no path crosses this block cleanly
     }
     l_out = want_out ? lo_sum : -1;
   };

@@ -1112,32 +1112,46 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   for (int t = 0; t < 4 * BS_W; t++) { bs0[t] = 0; bs1[t] = 0; }
   static_assert(TALLY_CHUNK <= 3 * 256 && TALLY_CHUNK_LINEAR <= 3 * 256, "a lane's vertical counters hold two bits");
   // a read's record, and -- fetched before the record says whether they are needed, one round trip less -- its planes and N mark
-  struct ReadIn { int4 a, b4, c4; unsigned long long l0, l1, h0, h1; int um; };
+  // Straight-line loads (a lane without a read asks for read 0's, the second words of one-word planes are the first again; what
+  // was loaded is only looked at a pass later): with the loads inside `if (ii >= 0)` the number of loads in flight at the first
+  // use of the PREVIOUS pass's record depended on the path, and the wait the compiler put there was for all of them -- the
+  // records "a pass ahead" were waited for on the spot, the gather's latency (60 % of this kernel) hidden by nothing.
+  struct ReadIn { int4 a, b4, c4; unsigned long long l0, l1, h0, h1; };
+  const int pw1 = rplane_words > 1 ? 1 : 0;
   auto fetch = [&](int ii) -> ReadIn {
     ReadIn q;
-    q.a = make_int4(0, 0, 0, 0); q.b4 = q.a; q.c4 = q.a; q.l0 = q.l1 = q.h0 = q.h1 = 0ull; q.um = -1;
-    if (ii >= 0) {
-      const int4* tr4 = reinterpret_cast<const int4*>(rec_params + (int64_t)ii * 16);
-      q.a = tr4[0]; q.b4 = tr4[1]; q.c4 = tr4[2];
-      if (bs_on) {
-        q.um = (q.a.w & TRF_NO_N) ? 0 : -1;
-        const uint64_t* pl = rplanes + (int64_t)ii * 2 * rplane_words;
-        q.l0 = pl[0]; q.l1 = rplane_words > 1 ? pl[1] : 0ull; q.h0 = pl[rplane_words]; q.h1 = rplane_words > 1 ? pl[rplane_words + 1] : 0ull;
-      }
+    const int64_t jj = ii >= 0 ? ii : 0;
+    const int4* tr4 = reinterpret_cast<const int4*>(rec_params + jj * 16);
+    q.a = tr4[0]; q.b4 = tr4[1]; q.c4 = tr4[2];
+    q.l0 = q.l1 = q.h0 = q.h1 = 0ull;
+    // (four different addresses whatever the number of words -- the planes are padded by two words --: given `pl[words > 1 ? 1 : 0]` the
+    // compiler loads one word, copies it and branches around the second load, and the copy waits for the load on the spot)
+    if (LINEAR) {
+      const uint64_t* pl = bs_on ? rplanes + jj * 2 * rplane_words : reinterpret_cast<const uint64_t*>(rec_params);
+      q.l0 = pl[0]; q.l1 = pl[1]; q.h0 = pl[rplane_words]; q.h1 = pl[rplane_words + 1];
+    } else if (bs_on) {
+      const uint64_t* pl = rplanes + jj * 2 * rplane_words;
+      q.l0 = pl[0]; q.l1 = pl[1]; q.h0 = pl[rplane_words]; q.h1 = pl[rplane_words + 1];
     }
     return q;
   };
   ReadIn in_nx = fetch(i_nx);
+  bool nx2_ok = true;                 // (i_nx2 holds -1 already where there is no read)
+  const int last_k = last > 0 ? last - 1 : 0;
   for (int k0 = first; k0 < last; k0 += 256) {
     const int i = i_nx;
     const ReadIn in = in_nx;
     const bool have = i >= 0 && !(TALLY_ABL(1u << 21) && in.a.x != 0x7FFFFFFF);
-    i_nx = i_nx2;
-    i_nx2 = k0 + 512 + (int)threadIdx.x < last ? order[k0 + 512 + (int)threadIdx.x] : -1;
+    i_nx = nx2_ok ? i_nx2 : -1;
+    {
+      const int kk = k0 + 512 + (int)threadIdx.x;
+      nx2_ok = kk < last;
+      i_nx2 = order[kk < last_k ? kk : last_k];
+    }
     in_nx = fetch(i_nx);
     const int4 a = in.a, b4 = in.b4, c4 = in.c4;
-    const unsigned long long pv_l0 = in.l0, pv_l1 = in.l1, pv_h0 = in.h0, pv_h1 = in.h1;
-    const bool um_ok = bs_on && in.um >= 0;
+    const unsigned long long pv_l0 = in.l0, pv_l1 = pw1 ? in.l1 : 0ull, pv_h0 = in.h0, pv_h1 = pw1 ? in.h1 : 0ull;
+    const bool um_ok = bs_on && (a.w & TRF_NO_N);
     bool fast = false;
     if (have) {
       const int flags = a.w;

@@ -599,7 +599,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   rcx |= dev_alloc(ctx, &ctx->d_bin_of, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_umax, (size_t)n);
   ctx->rplane_words = (max_len + 63) >> 6;
-  rcx |= dev_alloc(ctx, &ctx->d_rplanes, (size_t)n * 2 * ctx->rplane_words);
+  rcx |= dev_alloc(ctx, &ctx->d_rplanes, (size_t)n * 2 * ctx->rplane_words + 2);      // (+ 2: k_tally_binned asks for a second word of every plane)
   rcx |= dev_alloc(ctx, &ctx->d_list, (size_t)n + 4 * N_BINS);   // quad bins are padded to multiples of four
   rcx |= dev_alloc(ctx, &ctx->d_wide_list, (size_t)n);
   rcx |= dev_alloc(ctx, &ctx->d_retry_list, (size_t)n);

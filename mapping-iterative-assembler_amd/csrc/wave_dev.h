@@ -185,6 +185,8 @@ struct DevWave {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
+  // nothing is scheduled across (a batch of independent loads stays in front of the first wait for one of them)
+  __device__ __forceinline__ void sched_fence() const { __builtin_amdgcn_sched_barrier(0); }
   // order this wave's LDS writes before its later LDS reads (other lanes' data)
   __device__ __forceinline__ void lds_fence() const {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -115,6 +115,7 @@ struct EmuWave {
   static void gstore_u32(uint32_t* p, const U& idx, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) p[idx.a[i]] = v.a[i]; }
   U tr_r16(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) if (ok.a[i]) { uint16_t x; trace.at(off.a[i] + 1); memcpy(&x, &trace[off.a[i]], 2); r.a[i] = x; } return r; }
   void lds_fence() const {}
+  void sched_fence() const {}
   void tr_w32(const U& off, const U& v, const M& ok) { for (int i = 0; i < 64; i++) if (ok.a[i]) { trace.at(off.a[i] + 3); memcpy(&trace[off.a[i]], &v.a[i], 4); } }
   U tr_r8(const U& off, const M& ok) const { EV r; for (int i = 0; i < 64; i++) r.a[i] = ok.a[i] ? trace.at(off.a[i]) : 0u; return r; }
   void tr_fence() const {}
