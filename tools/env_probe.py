@@ -45,5 +45,7 @@ for spec in sys.argv[3:]:
     for k in env:
         os.environ.pop(k)
     pipe = bench.Pipeline(hip, w)
-    print("[%s] cfg %d %d reads: steady %.4f ms, first %.4f ms" % (spec, cfg, n, timed(pipe, hip, cur), timed(pipe, hip, w["ref"])), flush=True)
+    t_steady = timed(pipe, hip, cur)
+    st = {k: round(v[0] / max(v[1], 1), 4) for k, v in hip.stage_stats().items() if v[1]} if os.environ.get("PROBE_STAGES") else {}
+    print("[%s] cfg %d %d reads: steady %.4f ms, first %.4f ms" % (spec, cfg, n, t_steady, timed(pipe, hip, w["ref"])), st, flush=True)
     hip.close()
