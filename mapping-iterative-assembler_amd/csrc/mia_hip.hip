@@ -1306,15 +1306,19 @@ static int align_all(mia_hip_ctx* ctx) {
     hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ps, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count);
     ck("scan fill seed");
     // every window class reads its own range from the header (the list is rewritten by the re-plan below, so they all go
-    // first; a class without reads costs an empty launch -- a few microseconds; putting them on the second stream beside
-    // the quad kernels was tried and gained nothing)
-    for (int ci = 0; ci < N_CPL; ci++) {
-      hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps)
-                   : ci == 1 ? launch_window<8>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps)
-                             : launch_window<12>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps);
-      if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
-    }
-    ck("window classes");
+    // before it; a class without reads costs an empty launch -- a few microseconds -- and three of them in front of the quad
+    // kernel delayed it by ~50 us of launch gaps on a chain that ends about when the band DPs' does: they go behind its first launch)
+    auto window_classes = [&]() -> int {
+      for (int ci = 0; ci < N_CPL; ci++) {
+        hipError_t e = ci == 0 ? launch_window<4>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps)
+                     : ci == 1 ? launch_window<8>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps)
+                               : launch_window<12>(ctx, ci, ctx->d_list, 0, hdr + PH_WIN + 2 * ci, ps);
+        if (e != hipSuccess) { ctx->err = std::string("k_align_window launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+      }
+      ck("window classes");
+      return MIA_HIP_OK;
+    };
+    bool windows_done = false;
     const size_t quad_lds = (size_t)Q_G * q_sub_bytes(ctx->max_len) + 16;
     if (ctx->use_quad) {
       if (use_plain) {
@@ -1323,6 +1327,8 @@ static int align_all(mia_hip_ctx* ctx) {
                            (const int32_t*)(hdr + PH_QUAD));
         stage_end(ctx, STG_PLAIN, ps);
         ck("quad plain");
+        if (int rcw = window_classes()) return rcw;
+        windows_done = true;
         // what it could not finish (and what the filter's gap hint kept out of it), re-planned into quads
         HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ps));
         HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ps));
@@ -1348,6 +1354,7 @@ static int align_all(mia_hip_ctx* ctx) {
       stage_end(ctx, STG_TRACE, ps);
       HIPCHK(hipGetLastError());
       ck("quad trace");
+      if (!windows_done) { if (int rcw = window_classes()) return rcw; windows_done = true; }
       if (ctx->use_band) {
         // (the last launch of the planner's chain: on stream2 it signals ev_join itself, see bx_join_and_retry)
         const bool sig = ctx->bx_planner_aside && ctx->bx_pending_join && (ctx->ext_events & 4u);
@@ -1356,6 +1363,7 @@ static int align_all(mia_hip_ctx* ctx) {
         if (e != hipSuccess) { ctx->err = std::string("k_align_window retry launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
       }
     }
+    if (!windows_done) { if (int rcw = window_classes()) return rcw; }
     ck("retry");
     if (int rcj = bx_join_and_retry(ctx)) return rcj;
     ck("band join");
