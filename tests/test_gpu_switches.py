@@ -27,7 +27,9 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             "MIA_HIP_TALLY_INLINE",
             # position-specific matrices: the tally's buckets by column and strand, the rows of depth code 15 through the vertical counters
             # (an experiment; default: by column only); no vertical counters at all, either matrix
-            "MIA_HIP_STRAND_SPLIT", "MIA_HIP_DEBUG_SKIP=4096"]
+            "MIA_HIP_STRAND_SPLIT", "MIA_HIP_DEBUG_SKIP=4096",
+            # round 4, second half: every wavefront at priority 0 (default: the step's chain ahead of k_bxl_trace); smaller persistent grids
+            "MIA_HIP_BX_DEBUG=128", "MIA_HIP_BX_VALUES_PCT=50", "MIA_HIP_BX_TRACE_PCT=44"]
 
 
 def two_iterations(mod, w, env):
