@@ -188,6 +188,7 @@ struct mia_hip_ctx {
   uint32_t* d_bx_ctr = nullptr;
   uint32_t* d_bx_slabs = nullptr; int64_t bx_slab_cap = 0;
   int bx_values_wgs = 0, bx_trace_wgs = 0;
+  bool planner_beside = false;            // MIA_HIP_PLANNER_BESIDE=1 (alt build): the planner's head kernels beside the band DPs in every iteration
   int64_t bx_seen = 0, bx_done[3] = {0, 0, 0};   // reads planned on; finished by the plan / the values DP / the trace DP
   int64_t bx_launches = 0;
   uint32_t bx_last[BXC_COUNTERS] = {0};     // counters of the last call (list lengths, reasons a read was not planned)
@@ -382,6 +383,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* ew = alt_env("MIA_HIP_EARLY_WGS")) ctx->early_wgs_per_cu = atoi(ew);
     if (const char* nf = alt_env("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
     if (const char* nf = alt_env("MIA_HIP_FINE")) ctx->use_fine = atoi(nf);
+    if (const char* pb = alt_env("MIA_HIP_PLANNER_BESIDE")) ctx->planner_beside = atoi(pb) != 0;
     const char* bxf = alt_env("MIA_HIP_BX_FILTER");
     if (bxf && atoi(bxf)) ctx->bx_filter_first = 1;
     const char* nq = alt_env("MIA_HIP_NO_QUAD");
@@ -1019,6 +1021,7 @@ static int align_all(mia_hip_ctx* ctx) {
   const int filtered = run_filter || bx;            // bin_of carries marks for the planner
   uint32_t h_filter_n = 0;
   bool banded = false;
+  bool planner_head_first = false;      // count / scan / fill of the planner queued in front of the band DPs (see the band launches)
   if (filtered) {
     // reads whose alignment is provably one gap-free diagonal never reach the DP kernels (diag_filter.h)
     const int64_t words = plane_words((int64_t)wrap + 64);
@@ -1161,6 +1164,19 @@ static int align_all(mia_hip_ctx* ctx) {
         if (fine) bd.cand2 = ctx->d_bx_cand2;
       }
       const int last_phase = split ? (fine ? 3 : 2) : 0;
+      // PLANNER FIRST.  Where the plan gives up on many reads (against a reference full of ambiguity codes -- every run's first
+      // iteration --, or when it did so in the iteration before) the planner's chain on stream2 -- count, scan, fill, the values-only
+      // quad kernel, the re-plan, the trace quad kernel -- is the longest of the three, and its three small head kernels, launched
+      // beside the persistent band grids, wait for wave slots: k_plan_scan's single workgroup 70 us, the other two 65-80 us each
+      // instead of 10 (first iteration of 1 M flat reads; at 10 M reads 1 ms and 0.8 ms).  They go in front of the fork then: ~35 us
+      // later for the band DPs, ~190 us earlier for the chain that the step waits for.  (Not at steady state, where the
+      // planner's chain has slack and the band DPs' start is the step's critical path.)
+      {
+        int64_t lr = 0;
+        for (int k = 1; k < BXF_KINDS; k++) lr += ctx->bx_last[BXC_FAIL0 + k];
+        const bool many_early = !ctx->no_auto_plain && (!ctx->ref_mostly_bases || lr * 20 > n);
+        planner_head_first = new_flow && ctx->deferred && many_early && !ctx->planner_beside && !(ctx->dbg & 256u);
+      }
       // The widest class (33-64 diagonals) holds the few reads a step that used to go to the full-window kernels beside the band DPs.
       // Through the values DP their left-overs land on the late lists, i.e. on the step's critical path (late trace 0.125 -> 0.17 ms per
       // 1 M flat reads); where the lists are short anyway they go straight to the trace DP on its own stream instead.
@@ -1189,7 +1205,7 @@ static int align_all(mia_hip_ctx* ctx) {
         for (int phase = split ? 1 : 0; phase <= last_phase; phase++) {
           const dim3 pg(phase >= 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
           // (the fork event rides on the last launch's own completion signal: no marker between the plan and the values DP)
-          hipEvent_t done = (fork_by_launch && phase == last_phase) ? ctx->ev_fork : nullptr;
+          hipEvent_t done = (fork_by_launch && phase == last_phase && !planner_head_first) ? ctx->ev_fork : nullptr;
 #define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, 0, ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
 #define MIA_PLAN_NW(PHV) switch (nwords) { case 1: MIA_PLAN(1, PHV); break; case 2: MIA_PLAN(2, PHV); break; case 3: MIA_PLAN(3, PHV); break; default: MIA_PLAN(4, PHV); break; }
           switch (phase) {
@@ -1204,6 +1220,13 @@ static int align_all(mia_hip_ctx* ctx) {
       }
       stage_end(ctx, STG_BX_PLAN);
       HIPCHK(hipGetLastError());
+      if (planner_head_first) {
+        const bool use_plain_h = ctx->use_plain;      // (banded, many rejects: the values-only quad pass is on)
+        hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ctx->stream, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain_h, ctx->d_bin_of, d_count, ctx->d_filter_n);
+        hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ctx->stream, d_count, d_off, ctx->d_plan_hdr, 0, ctx->d_list);
+        launch_k(k_plan_fill, dim3(gb), dim3(tb), 0, ctx->stream, fork_by_launch ? ctx->ev_fork : nullptr, n, (const int32_t*)ctx->d_bin_of, (const int32_t*)d_off, d_cursor, ctx->d_list);
+        HIPCHK(hipGetLastError());
+      }
       if (!(ctx->dbg & 256u)) {
         if (new_flow) {
           // Three things that do not depend on each other run side by side: the trace DP of the plan's own lists (stream3),
@@ -1291,6 +1314,7 @@ static int align_all(mia_hip_ctx* ctx) {
   const bool many_rejects = bx && !ctx->no_auto_plain && (!ctx->ref_mostly_bases || last_rejects * 20 > n);
   const bool use_plain = ctx->use_plain && (!banded || ctx->plain_behind_band || many_rejects);
   hipStream_t ps = ctx->bx_planner_aside ? ctx->stream2 : ctx->stream;      // the planner's stream (see the band launches above)
+  if (!planner_head_first)
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ps, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   if (ctx->deferred) {
     // ---- mia_hip_iterate: the same plan, but its numbers stay on the device (k_plan_scan) and every DP kernel reads its own
@@ -1300,10 +1324,13 @@ static int align_all(mia_hip_ctx* ctx) {
     auto ck = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ps); fprintf(stderr, "[align_all deferred] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
     ck("plan_count");
     int32_t* d_retry_cnt = hdr + PH_RETRY + 1;
+    if (!planner_head_first) {
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 0, ctx->d_list);      // (writes the quad bins' padding itself: -1 = empty slot)
     hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
+    }
     ck("memsets");
-    hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ps, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count);
+    hipLaunchKernelGGL(k_wide_seed, dim3(1), dim3(256), 0, ps, ctx->d_list, hdr, ctx->d_wide_list, d_wide_count,
+                       (ctx->use_quad && use_plain) ? d_count : (int32_t*)nullptr, d_cursor);      // (cleared for the re-plan below)
     ck("scan fill seed");
     // every window class reads its own range from the header (the list is rewritten by the re-plan below, so they all go
     // before it; a class without reads costs an empty launch -- a few microseconds -- and three of them in front of the quad
@@ -1330,8 +1357,7 @@ static int align_all(mia_hip_ctx* ctx) {
         if (int rcw = window_classes()) return rcw;
         windows_done = true;
         // what it could not finish (and what the filter's gap hint kept out of it), re-planned into quads
-        HIPCHK(hipMemsetAsync(d_count, 0, (size_t)N_BINS * 4, ps));
-        HIPCHK(hipMemsetAsync(d_cursor, 0, (size_t)N_BINS * 4, ps));
+        // (d_count / d_cursor: cleared by k_wide_seed)
         hipLaunchKernelGGL(k_plan_recount, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_count);
         hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 1, ctx->d_list);
         hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);

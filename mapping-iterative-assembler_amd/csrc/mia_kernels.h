@@ -384,10 +384,14 @@ __global__ __launch_bounds__(512) void k_plan_scan(const int32_t* count, int32_t
   }
 }
 // reads that need the exact kernel from the start: the head of wide_list (the DP kernels append their escapes behind)
-__global__ __launch_bounds__(256) void k_wide_seed(const int32_t* list, const int32_t* hdr, int32_t* wide_list, int32_t* wide_count) {
+// zero_a / zero_b (or nullptr): the planner's bin counts and cursors, used up by the k_plan_fill in front of this launch, cleared for the
+// re-plan behind the values-only quad pass (two memsets there were five fill kernels, ~30 us on the chain a first iteration waits for)
+__global__ __launch_bounds__(256) void k_wide_seed(const int32_t* list, const int32_t* hdr, int32_t* wide_list, int32_t* wide_count,
+                                                    int32_t* zero_a = nullptr, int32_t* zero_b = nullptr) {
   const int off = hdr[PH_WIDE0], n = hdr[PH_WIDE0 + 1];
   for (int t = threadIdx.x; t < n; t += 256) wide_list[t] = list[off + t];
   if (threadIdx.x == 0) *wide_count = n;
+  if (zero_a) for (int t = threadIdx.x; t < N_BINS; t += 256) { zero_a[t] = 0; zero_b[t] = 0; }
 }
 
 // ---- the windowed DP: one read at a time per 64-lane workgroup, persistent grid -------------
