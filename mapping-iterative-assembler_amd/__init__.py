@@ -250,7 +250,9 @@ class MiaHip:
 
     def __init__(self, device=0):
         # (switches are read once, when the context is made: a context made while a non-release switch is set needs the alt build)
-        self._l = alt_lib() if (alt_switches_set() and not os.environ.get("MIA_HIP_LIB")) else lib()
+        self.is_alt_build = bool(alt_switches_set() and not os.environ.get("MIA_HIP_LIB"))
+        self._l = alt_lib() if self.is_alt_build else lib()
+        self.lib_path = ALT_LIB_PATH if self.is_alt_build else LIB_PATH
         self._h = C.c_void_p()
         rc = self._l.mia_hip_create(C.byref(self._h), device)
         if rc != 0:

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <string>
 #include <thread>
@@ -170,7 +171,7 @@ struct mia_hip_ctx {
   // the matrix-agnostic band pipeline (bandx_kernels.h): plan -> values-only DP -> trace DP, for any PSSM
   bool bx_ok = false;                       // the matrices allow it (bx_make_tables)
   uint32_t* d_cull_sync = nullptr;          // k_slot_count's arrival counter (zero between launches)
-  double myers_kernel_ms = 0; bool myers_no_lanes = false;   // the kernels of the last mia_hip_myers call (HIP events); MIA_HIP_MYERS_NO_LANES=1: every pair through k_myers
+  double myers_kernel_ms = 0; bool myers_no_lanes = false, myers_no_ond = false, fake_event_overflow = false;   // the kernels of the last mia_hip_myers call (HIP events); MIA_HIP_MYERS_NO_LANES=1: every pair through k_myers
   int bucket_clean_nb = -1;                 // the tally's bucket counts are zero for this bucket count (k_bucket_scan leaves them so)
   bool no_auto_plain = false;               // MIA_HIP_NO_AUTO_PLAIN=1: the values-only pass behind the band only when MIA_HIP_PLAIN_BEHIND_BAND asks for it
   bool bx_serial = false;                   // MIA_HIP_BX_SERIAL=1
@@ -371,6 +372,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* em = alt_env("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
     if (const char* st2 = alt_env("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
     if (const char* ml = alt_env("MIA_HIP_MYERS_NO_LANES")) ctx->myers_no_lanes = atoi(ml) != 0;
+    if (const char* mo = alt_env("MIA_HIP_MYERS_NO_OND")) ctx->myers_no_ond = atoi(mo) != 0;
+    if (const char* fo = alt_env("MIA_HIP_FAKE_EVENT_OVERFLOW")) ctx->fake_event_overflow = atoi(fo) != 0;
     if (const char* na = alt_env("MIA_HIP_NO_AUTO_PLAIN")) ctx->no_auto_plain = atoi(na) != 0;
     const char* egs = alt_env("MIA_HIP_EAGER_SCRIPTS");
     if (egs && atoi(egs)) ctx->lazy_scripts = 0;

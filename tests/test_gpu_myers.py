@@ -129,3 +129,89 @@ def test_packed_entry_point_on_the_reference_vectors():
     with pytest.raises(mia_amd.MiaHipError):
         hip.myers_packed(mia_amd.pack_myers_pairs(["A" * 400], ["A" * 400]), [0], [10])
     hip.close()
+
+
+def _edited_copy(rng, a, subs, dels, ins):
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    b = list(a)
+    for _ in range(subs):
+        b[int(rng.integers(0, len(b)))] = alpha[rng.integers(0, 4)]
+    for _ in range(dels):
+        p = int(rng.integers(0, len(b) - 4))
+        del b[p:p + int(rng.integers(1, 4))]
+    for _ in range(ins):
+        p = int(rng.integers(0, len(b)))
+        b[p:p] = list(alpha[rng.integers(0, 4, int(rng.integers(1, 4)))])
+    return np.array(b, np.uint8)
+
+
+def test_dpath_kernel_equals_bitvector_kernel_on_long_pairs():
+    """k_myers_ond (round 5: furthest-reaching D-paths, one row of diagonals per step, for the pairs too long for a lane)
+    against k_myers (MIA_HIP_MYERS_NO_OND=1: every long pair through the bit-vector sweep the reference's vectors pin):
+    400 pairs of 330 .. 6 000 characters -- near-identical (the D-path kernel finishes them), a tenth apart (its cap decides),
+    unrelated (it hands them on: 0xFFFFFFFE never reaches the caller), overhangs for the prefix modes, IUPAC codes and
+    characters no bitmap knows, maxd from 1 to beyond the sum of the lengths."""
+    import mia_amd
+    rng = np.random.default_rng(2024)
+    alpha = np.frombuffer(b"ACGTACGTACGTACGTNRYKMSWBDHVacgtX", np.uint8)
+    A, B, mode, maxd = [], [], [], []
+    for i in range(400):
+        la = int(rng.integers(330, 6000 if i % 8 == 0 else 1500))
+        a = alpha[rng.integers(0, len(alpha) if i % 2 else 16, la)].copy()
+        kind = i % 5
+        if kind == 0:
+            b = alpha[rng.integers(0, 16, int(rng.integers(330, 1500)))].copy()
+        elif kind == 1:
+            b = _edited_copy(rng, a, la // 10, la // 40, la // 40)
+        else:
+            b = _edited_copy(rng, a, int(rng.integers(0, 12)), int(rng.integers(0, 4)), int(rng.integers(0, 4)))
+        m = int(rng.integers(0, 3))
+        if kind == 2 and m == 1:
+            a = np.concatenate([a, alpha[rng.integers(0, 16, 40)]])
+        if kind == 2 and m == 2:
+            b = np.concatenate([b, alpha[rng.integers(0, 16, 40)]])
+        A.append(a.tobytes().decode("latin1")); B.append(b.tobytes().decode("latin1"))
+        mode.append(m)
+        maxd.append(int(rng.choice([1, 3, 20, 150, 700, 100000])))
+    hip = mia_amd.MiaHip(0)
+    got = hip.myers(A, B, mode, maxd)
+    hip.close()
+    os.environ["MIA_HIP_MYERS_NO_OND"] = "1"
+    try:
+        ref = mia_amd.MiaHip(0)
+    finally:
+        os.environ.pop("MIA_HIP_MYERS_NO_OND")
+    want = ref.myers(A, B, mode, maxd)
+    ref.close()
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, [(int(i), int(got[i]), int(want[i]), mode[i], maxd[i], len(A[i]), len(B[i])) for i in bad[:8]]
+    assert (want < 0xFFFFFFFE).sum() > 150 and (want == 0xFFFFFFFF).sum() > 50 and not (got == 0xFFFFFFFE).any()
+
+
+def test_ccheck_sized_pair_rows_from_the_device_table():
+    """The one call ccheck makes (src/ccheck.cc:477-480): 16.6 kb against 16.6 kb, maxd = len/10.  mia_hip_myers_align now
+    walks back through the table k_myers_ond wrote; the rows must spell both sequences and cost exactly the distance, and the
+    distance must be what the bit-vector kernel says."""
+    import mia_amd
+    rng = np.random.default_rng(16)
+    a = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 16_600)].copy()
+    a[rng.integers(0, len(a), 1600)] = ord("N")                  # mt311 carries an ambiguity code in every tenth column
+    b = _edited_copy(rng, np.where(a == ord("N"), ord("A"), a).astype(np.uint8), 90, 5, 5)
+    sa, sb = a.tobytes().decode(), b.tobytes().decode()
+    hip = mia_amd.MiaHip(0)
+    for mode in (0, 1, 2):
+        d, ra, rb = hip.myers_align(sa, mode, sb, len(sa) // 10)
+        assert d is not None and 20 < d < 140
+        os.environ["MIA_HIP_MYERS_NO_OND"] = "1"
+        try:
+            ref = mia_amd.MiaHip(0)
+        finally:
+            os.environ.pop("MIA_HIP_MYERS_NO_OND")
+        d2, ra2, rb2 = ref.myers_align(sa, mode, sb, len(sa) // 10)      # bit-vector distance, D-paths on the host
+        ref.close()
+        assert (d, ra, rb) == (d2, ra2, rb2)
+        if len(ra) == len(rb):
+            assert sb.startswith(rb.replace("-", "")) and sa.startswith(ra.replace("-", ""))
+            cost = sum(1 for x, y in zip(ra, rb) if x == "-" or y == "-" or not (_bits(x) & _bits(y)))
+            assert cost == d
+    hip.close()
