@@ -916,6 +916,74 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
   }
 }
 
+// ---- the reads of a bucket in the order of their alignment starts (round 5) -------------------------------------------------
+// The position-specific tally reduces the fifteen rows at either end of a read over RUNS of reads that start at the same
+// column (k_tally_binned: tally_runs): for that, reads of equal start have to sit in neighbouring lanes.  k_bucket_fill
+// leaves a bucket's reads in no particular order; these two launches sort every bucket by start -- a counting sort with
+// SORT2_KEYS keys per bucket whose unit of work is the tally's own workgroup share (k_bucket_scan's table: bucket, first,
+// last), so a bucket that holds all the reads is no slower than any other.  Order is a matter of speed only: the tally checks
+// the keys of a run itself.
+constexpr int SORT2_KEYS = 256;           // starts 0 .. 255 of a bucket's first column (the last bucket's reads may start beyond its 128)
+// (a read with a gap or a soft end goes behind all the gap-free ones of its bucket: the tally adds such a read's rows one by
+// one, and a few of them in every wavefront made every wavefront walk that loop -- 1.0 of the tally's 1.5 ms at 10 M reads;
+// collected at the end of the bucket they fill a few wavefronts of their own)
+__device__ __forceinline__ int sort2_key(const ReadSet& rs, int32_t i, int b, int split) {
+  if (!(rs.status[i] & ST_DIAG) || rs.abr[i] != 0) return SORT2_KEYS - 1;
+  const int k = rs.as[i] - (b >> split) * TALLY_BUCKET;
+  return k < 0 ? 0 : (k >= SORT2_KEYS - 1 ? SORT2_KEYS - 2 : k);
+}
+__global__ __launch_bounds__(256) void k_sort2_count(ReadSet rs, int32_t nb, const int32_t* wgoff, const int32_t* wg_bucket, const int32_t* order, int32_t* hist2,
+                                                      int32_t split, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;
+  if ((int)blockIdx.x >= wgoff[nb]) return;
+  __shared__ int32_t h[SORT2_KEYS];
+  const int4 wgi = reinterpret_cast<const int4*>(wg_bucket)[blockIdx.x];
+  const int b = wgi.x, first = wgi.y, last = wgi.z;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int t = first + (int)threadIdx.x; t < last; t += 256) atomicAdd(&h[sort2_key(rs, order[t], b, split)], 1);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist2[(int64_t)b * SORT2_KEYS + threadIdx.x], h[threadIdx.x]);
+}
+// cursor2: as hist2, zero before the launch; order2[off[b] + (reads of smaller keys in b) + (place among the key's reads)] = read
+__global__ __launch_bounds__(256) void k_sort2_fill(ReadSet rs, int32_t nb, const int32_t* off, const int32_t* wgoff, const int32_t* wg_bucket, const int32_t* order,
+                                                     const int32_t* hist2, int32_t* cursor2, int32_t* order2, int32_t split, const int32_t* abort_if = nullptr) {
+  if (abort_if && *abort_if != 0) return;
+  if ((int)blockIdx.x >= wgoff[nb]) return;
+  static_assert(SORT2_KEYS == 256, "one key per thread");
+  __shared__ int32_t h[SORT2_KEYS], pre[SORT2_KEYS], base[SORT2_KEYS];
+  const int4 wgi = reinterpret_cast<const int4*>(wg_bucket)[blockIdx.x];
+  const int b = wgi.x, first = wgi.y, last = wgi.z;
+  const int t = threadIdx.x;
+  h[t] = 0;
+  pre[t] = hist2[(int64_t)b * SORT2_KEYS + t];
+  __syncthreads();
+  constexpr int PER = (TALLY_CHUNK + 255) / 256;
+  int32_t rd[PER], key[PER], rank[PER];
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const int e = first + q * 256 + t;
+    rd[q] = -1; key[q] = 0; rank[q] = 0;
+    if (e < last) { rd[q] = order[e]; key[q] = sort2_key(rs, rd[q], b, split); rank[q] = atomicAdd(&h[key[q]], 1); }
+  }
+  // exclusive prefix of the bucket's histogram over the 256 keys (Hillis-Steele in LDS)
+  const int mine = pre[t];
+  for (int o = 1; o < SORT2_KEYS; o <<= 1) {
+    __syncthreads();
+    const int v = t >= o ? pre[t - o] : 0;
+    __syncthreads();
+    pre[t] += v;
+  }
+  __syncthreads();
+  pre[t] -= mine;
+  base[t] = h[t] ? atomicAdd(&cursor2[(int64_t)b * SORT2_KEYS + t], h[t]) : 0;
+  __syncthreads();
+  const int ob = off[b];
+#pragma unroll
+  for (int q = 0; q < PER; q++)
+    if (rd[q] >= 0) order2[ob + pre[key[q]] + base[key[q]] + rank[q]] = rd[q];
+}
+
 #ifdef MIA_HIP_ALT_PATHS
 // (MIA_HIP_DEBUG_SKIP & 65536, alt build: how many reads take which route of k_tally_binned -- tools/tally_kinds_probe.py)
 __device__ unsigned long long g_tally_kinds[8];
@@ -933,6 +1001,18 @@ __device__ unsigned long long g_tally_clk[8];
 #define TALLY_CLK(k) do { } while (0)
 #define TALLY_CLK_DECL do { } while (0)
 #endif
+// Bit-matrix transposition inside each half of a wavefront (five butterfly steps): lane l holds 32 bits going in; coming out,
+// lane r of half h holds in bit c what bit r of lane 32 h + c was.
+__device__ __forceinline__ uint32_t wave_transpose32(uint32_t x, int lane) {
+#pragma unroll
+  for (int j = 16; j >= 1; j >>= 1) {
+    const uint32_t m = j == 16 ? 0x0000FFFFu : (j == 8 ? 0x00FF00FFu : (j == 4 ? 0x0F0F0F0Fu : (j == 2 ? 0x33333333u : 0x55555555u)));
+    const uint32_t y = (uint32_t)__shfl_xor((int)x, j);
+    x = (lane & j) ? ((x & ~m) | ((y >> j) & m)) : ((x & m) | ((y << j) & ~m));
+  }
+  return x;
+}
+
 // DEFER: the reads that fit none of the one-read-per-lane routes (two gaps, soft ends, odd records: a thousand in a million) are
 // not tallied here, one per wavefront while the other lanes wait, but put on gen_list for k_tally_reduce's extra workgroups.  Seven hundred such reads cost 54 of this kernel's 215 us per million reads: every one of them is a stretch of code
 // nobody else runs (instruction fetches from memory) and a chain of loads in front of a workgroup's barrier.
@@ -942,9 +1022,12 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
                                                        const int32_t* rec_actf, int32_t* slabs, uint32_t dbg, const uint64_t* rplanes,
                                                        int32_t rplane_words, const int32_t* umax, const int32_t* wg_bucket, int32_t pk_bias, const int32_t* abort_if = nullptr,
-                                                       int32_t chunk_reads = TALLY_CHUNK, int32_t* gen_list = nullptr, int32_t* n_gen = nullptr, int32_t split = 0) {
+                                                       int32_t chunk_reads = TALLY_CHUNK, int32_t* gen_list = nullptr, int32_t* n_gen = nullptr, int32_t split_flags = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   constexpr bool linear = LINEAR;
+  // split_flags: bit 0 -- the buckets are split by strand (bucket_of) and sorted by start (k_sort2_*); bit 1 -- tally_runs below
+  const int split = split_flags & 1;
+  const bool runs_on = !LINEAR && (split_flags & 2) != 0;
   __shared__ int32_t lds[(TALLY_WORDS - 1) * TALLY_WIN];     // the pad word is never written
   // !LINEAR (a position-specific matrix): the scores of a base depend on its depth code and its strand -- but every base
   // further than 15 from both ends of its read has depth code 15 (src/pssm.c:6-46), seven in ten of a 100 bp read.  Those
@@ -972,6 +1055,15 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   __shared__ int32_t cov_diff[TALLY_WIN], span_diff[TALLY_WIN];
   __shared__ unsigned long long ev_buf[TALLY_EV_CAP];
   __shared__ int ev_cnt, ev_base;
+  // TALLY RUNS (round 5; !LINEAR, the buckets split by strand and sorted by start).  The fifteen rows at either end of a read
+  // cost two packed LDS atomics each, sixty per read, and those atomics were what this kernel waited for (r04: 130 M
+  // bank-conflict cycles on 168 M active LDS cycles at 10 M reads).  But reads that start at the same column put the same
+  // depth code on the same column: for a RUN of such reads in neighbouring lanes the adds of a row differ only in the base,
+  // so the run's leader-row adds  sum_b count_b * (packed scores of (depth, b))  ONCE.  The counts come from the reads' bit
+  // planes: rows 0..14 and the last fifteen of every lane, transposed over the wavefront (wave_transpose32: lane = row,
+  // bits = lanes), popcounted under the run's lane mask.  run_tab[d][b] = the two packed words add_base adds for a base b at
+  // depth code d on this workgroup's strand.
+  __shared__ unsigned long long run_tab[LINEAR ? 1 : (2 * PSSM_DEPTH + 1) * 4 * 2];
   if ((int)blockIdx.x >= wgoff[nb]) return;   // the grid is an upper bound (no host round trip for the exact count)
   TALLY_CLK_DECL;
   const int4 wgi = reinterpret_cast<const int4*>(wg_bucket)[blockIdx.x];       // (k_bucket_scan's table: bucket, first read, last read)
@@ -993,6 +1085,15 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   if (!LINEAR) for (int k = threadIdx.x; k < TALLY_WIN; k += blockDim.x) { pk1[k] = 0; pk2[k] = 0; }
   if (threadIdx.x == 0) ev_cnt = 0;
   __syncthreads();
+  if (!LINEAR && runs_on && pk_bias >= 0) {
+    for (int k = threadIdx.x; k < (2 * PSSM_DEPTH + 1) * 4; k += blockDim.x) {
+      const int16_t* row = pssm_lds + (wg_rc ? PSSM_WORDS : 0) + (k >> 2) * 25 + (k & 3);
+      run_tab[2 * k] = (unsigned long long)(uint32_t)((int)row[0] + pk_bias) | ((unsigned long long)(uint32_t)((int)row[5] + pk_bias) << 20) |
+                       ((unsigned long long)(uint32_t)((int)row[10] + pk_bias) << 40);
+      run_tab[2 * k + 1] = (unsigned long long)(uint32_t)((int)row[15] + pk_bias) | (1ull << (20 + 10 * (k & 3)));
+    }
+    __syncthreads();
+  }
   TALLY_CLK(0);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   (void)wv;
@@ -1153,6 +1254,8 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
     const unsigned long long pv_l0 = in.l0, pv_l1 = pw1 ? in.l1 : 0ull, pv_h0 = in.h0, pv_h1 = pw1 ? in.h1 : 0ull;
     const bool um_ok = bs_on && (a.w & TRF_NO_N);
     bool fast = false;
+    bool coop = false;                 // this lane's read takes part in the wavefront's runs (its end rows are not added one by one)
+    int c_w0 = 0, c_nal = 0;
     if (have) {
       const int flags = a.w;
       const int len2 = a.z & 0xFFFF, abr = (int)(int16_t)((uint32_t)a.z >> 16);
@@ -1299,8 +1402,13 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
           if (!dF && !(dbg & 16u)) add_base(w0 + act, code, dd, (flags & TRF_RC) != 0);
         }
         };
-        rows(0, have_mid ? mid_lo : n_al);
-        if (have_mid) rows(mid_hi + 1, n_al);
+        // (a gap-free read of at least 31 bases whose depth codes are its own: rows 0..14 carry codes 0..14, the last fifteen 16..30)
+        coop = runs_on && have_mid && fast && !one_here && !dF && pk_bias >= 0 && n_al >= 2 * PSSM_DEPTH + 1 && fB == n_al && !(dbg & 16u);
+        if (coop) { c_w0 = w0; c_nal = n_al; }
+        else {
+          rows(0, have_mid ? mid_lo : n_al);
+          if (have_mid) rows(mid_hi + 1, n_al);
+        }
         }
         if (fast || one_sl) {
         // coverage (not dropped): columns w0 .. w0+n-1; span (start < pos <= end, dropped or not): w0+1 .. w0+n-1 (n: the read's columns)
@@ -1311,6 +1419,54 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
         }
       }
       if (one_sl) fast = true;
+    }
+    if constexpr (!LINEAR) {
+      const unsigned long long cm = runs_on ? __ballot(coop) : 0ull;
+      if (cm) {
+        // rows 0 .. 14 and the last fifteen of this lane's read: low plane in bits 0 .. 14, high plane in bits 16 .. 30
+        uint32_t fw = 0, bw = 0;
+        if (coop) {
+          const int sh = c_nal - PSSM_DEPTH;                                  // (>= 16)
+          const unsigned long long bl = sh >= 64 ? (pv_l1 >> (sh - 64)) : ((pv_l0 >> sh) | ((pv_l1 << 1) << (63 - sh)));
+          const unsigned long long bh = sh >= 64 ? (pv_h1 >> (sh - 64)) : ((pv_h0 >> sh) | ((pv_h1 << 1) << (63 - sh)));
+          fw = ((uint32_t)pv_l0 & 0x7FFFu) | (((uint32_t)pv_h0 & 0x7FFFu) << 16);
+          bw = ((uint32_t)bl & 0x7FFFu) | (((uint32_t)bh & 0x7FFFu) << 16);
+        }
+        // lane = row: the lower half of the wavefront takes the front rows, the upper half the back rows; each half's transposition
+        // knows its own 32 lanes, the partner lane (xor 32) has the other 32
+        const uint32_t tf = wave_transpose32(fw, lane), tk = wave_transpose32(bw, lane);
+        const uint32_t got = (uint32_t)__shfl_xor((int)(lane < 32 ? tk : tf), 32);
+        const unsigned long long M = lane < 32 ? ((unsigned long long)tf | ((unsigned long long)got << 32)) : ((unsigned long long)got | ((unsigned long long)tk << 32));
+        const unsigned long long Mh = (unsigned long long)__shfl_xor((long long)M, 16);       // row q's high plane sits sixteen lanes up
+        const bool row_lane = (lane & 31) < PSSM_DEPTH;
+        const int dcode = lane < 32 ? lane : lane - 32 + PSSM_DEPTH + 1;
+        // runs: neighbouring lanes with the same start and length
+        const int key = (c_w0 << 8) | c_nal;
+        const int pkey = __shfl_up(key, 1);
+        const bool pcoop = __shfl_up((int)coop, 1) != 0;
+        unsigned long long lm = __ballot(coop && (lane == 0 || !pcoop || pkey != key));
+        const unsigned long long brk = lm | ~cm;
+        typedef __attribute__((address_space(3))) unsigned long long lds_u64r;
+        while (lm) {
+          const int a0 = __builtin_ctzll(lm);
+          lm &= lm - 1;
+          const unsigned long long above = a0 == 63 ? 0ull : (~0ull << (a0 + 1));
+          const unsigned long long nxt = brk & above;
+          const int e0 = nxt ? __builtin_ctzll(nxt) : 64;
+          const unsigned long long seg = (e0 == 64 ? ~0ull : ((1ull << e0) - 1ull)) & (~0ull << a0);
+          const int s_w0 = __builtin_amdgcn_readlane(c_w0, a0), s_nal = __builtin_amdgcn_readlane(c_nal, a0);
+          if (row_lane) {
+            const unsigned long long lo = M & seg, hi = Mh & seg;
+            const int cT = __popcll(lo & hi), cC = __popcll(lo & ~hi), cG = __popcll(hi & ~lo), cA = __popcll(seg) - cT - cC - cG;
+            const unsigned long long* tab = run_tab + dcode * 8;
+            const unsigned long long v1 = (unsigned long long)cA * tab[0] + (unsigned long long)cC * tab[2] + (unsigned long long)cG * tab[4] + (unsigned long long)cT * tab[6];
+            const unsigned long long v2 = (unsigned long long)cA * tab[1] + (unsigned long long)cC * tab[3] + (unsigned long long)cG * tab[5] + (unsigned long long)cT * tab[7];
+            const int wc = s_w0 + (lane < 32 ? lane : s_nal - PSSM_DEPTH + (lane - 32));
+            (void)__hip_atomic_fetch_add((lds_u64r*)pk1 + wc, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add((lds_u64r*)pk2 + wc, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
     }
     // Proven-diagonal reads that run over the origin (two records: front in this window, back at the start of the
     // reference) all start in the last bucket, where nine reads in ten are of this kind: one per lane as well, every base

@@ -27,7 +27,9 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             "MIA_HIP_TALLY_INLINE",
             # position-specific matrices: the tally's buckets by column and strand, the rows of depth code 15 through the vertical counters
             # (an experiment; default: by column only); no vertical counters at all, either matrix
-            "MIA_HIP_STRAND_SPLIT", "MIA_HIP_DEBUG_SKIP=4096",
+            # (round 5: split by strand, sorted by start, is the default -- MIA_HIP_STRAND_SPLIT=0 is round 4's tally; MIA_HIP_NO_TALLY_RUNS=1
+            # keeps the split and the sort but adds the rows at either end of a read one read at a time instead of one run at a time)
+            "MIA_HIP_STRAND_SPLIT=0", "MIA_HIP_NO_TALLY_RUNS", "MIA_HIP_DEBUG_SKIP=4096",
             # round 4, second half: every wavefront at priority 0 (default: the step's chain ahead of k_bxl_trace); smaller persistent grids
             "MIA_HIP_BX_DEBUG=128", "MIA_HIP_BX_VALUES_PCT=50", "MIA_HIP_BX_TRACE_PCT=44"]
 

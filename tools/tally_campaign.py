@@ -65,4 +65,7 @@ def run(rounds=40, seed0=3000, n=60_000, matrix="flat", switch="MIA_HIP_NO_LINEA
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 3000)
+    # usage: tally_campaign.py [rounds [first seed [matrix [switch [reads]]]]]
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 3000,
+        n=int(sys.argv[5]) if len(sys.argv) > 5 else 60_000,
+        matrix=sys.argv[3] if len(sys.argv) > 3 else "flat", switch=sys.argv[4] if len(sys.argv) > 4 else "MIA_HIP_NO_LINEAR_TALLY")

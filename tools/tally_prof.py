@@ -13,7 +13,8 @@ import bench  # noqa: E402
 import mia_amd  # noqa: E402
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-w = bench.make_workload(cfg, 1_000_000, 1 if cfg == 1 else 3)
+n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+w = bench.make_workload(cfg, n_reads, 1 if cfg == 1 else 3)
 hip = mia_amd.MiaHip(0)
 pipe = bench.Pipeline(hip, w)
 cur = w["ref"]
@@ -23,11 +24,16 @@ hip.close()
 for label, skip in (("default", 0), ("no lane paths", 8), ("no wavefront path", 32), ("one-gap reads dropped", 2048), ("no bit slices", 4096),
                     ("no per-base adds (PSSM)", 16), ("lanes and wavefront paths off", 40), ("no adds to the vertical counters", 1 << 18),
                     ("counters not folded into the window", 1 << 19), ("no slab store", 1 << 20), ("records fetched, no read taken", 1 << 21),
-                    ("no counters, no fold, no slab", (1 << 18) | (1 << 19) | (1 << 20))):
+                    ("no counters, no fold, no slab", (1 << 18) | (1 << 19) | (1 << 20)),
+                    ("rows at either end read by read (MIA_HIP_NO_TALLY_RUNS)", "MIA_HIP_NO_TALLY_RUNS"), ("round 4's tally (MIA_HIP_STRAND_SPLIT=0)", "MIA_HIP_STRAND_SPLIT=0")):
+    name, val = "MIA_HIP_DEBUG_SKIP", str(skip)
+    if isinstance(skip, str):
+        name, _, val = skip.partition("=")
+        val = val or "1"
     if skip:
-        os.environ["MIA_HIP_DEBUG_SKIP"] = str(skip)
+        os.environ[name] = val
     hip = mia_amd.MiaHip(0)
-    os.environ.pop("MIA_HIP_DEBUG_SKIP", None)
+    os.environ.pop(name, None)
     pipe = bench.Pipeline(hip, w)
     try:
         pipe.step(cur)
