@@ -46,7 +46,6 @@ struct BxDev {
   int64_t list_stride;
   uint32_t* ctr;           // BXC_*
   int32_t lazy_scripts;    // the scripts of reads finished as pure diagonals are not written (k_diag_scripts makes them when asked for)
-  int32_t wide_to_trace;   // reads of the widest class skip the values DP: straight onto the trace lists (see align_all)
   uint8_t* early;          // [n] or nullptr: 1 for the reads the plan finishes (the early tally, mia_consensus_kernels.h: k_rec_early), 0 for all others
   uint32_t dbg;            // MIA_HIP_BX_DEBUG (profiling only, results are wrong): 1 no traceback, 2 one DP row only
   // k_bx_plan in two launches (phase 1 / phase 2): the reads whose anchors lie on two diagonals (or that want the end-indel
@@ -56,7 +55,13 @@ struct BxDev {
   // ... and the reads whose loss exceeds what the 10-mers vouch for go on to a third launch (phase 3: bx_fine_anchors); nullptr: no third launch
   struct BxCandRec* cand2;
   uint32_t* cand2_n;
+  // the band DPs in two rounds (align_all: split_dp): `snap` holds the lengths of the values / trace lists as the plan's first launch left
+  // them (k_bx_snap); round 1 takes the entries below, round 2 -- behind the plan's last launch -- the ones from there on
+  const uint32_t* snap;
 };
+// which entries of the plan's lists a launch of the band DPs takes
+enum { BX_PART_ALL = 0, BX_PART_HEAD = 1, BX_PART_TAIL = 2 };
+__global__ void k_bx_snap(const uint32_t* ctr, uint32_t* snap);
 struct BxCandRec { int32_t i; BxAnchors an; };
 constexpr int BX_FINE_LANES = 1;         // lanes that share the fine blocks of one read in the plan's third launch (measured: what a read costs there is
                                          // bx_finish, which one lane walks alone -- eight lanes per read made the launch no shorter and the bulk case four times longer)
@@ -278,7 +283,6 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     }
     // list appends and counters go through the block: one global atomic per block and list instead of one per wavefront
     int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? BX_NCLS + bx_class_of(bp.w) : -1);
-    if (bx.wide_to_trace && which == BX_NCLS - 1) which = 2 * BX_NCLS - 1;
     uint32_t rank = 0;
     if (which >= 0) rank = atomicAdd(&blk_cnt[which], 1u);
     if (to_fine) rank = atomicAdd(&blk_cnt[SLOT_FINE], 1u);
@@ -562,13 +566,20 @@ __global__ __launch_bounds__(256) void k_bx_trace(ReadSet rs, RefInfo ref, BxDev
 // width, so every wavefront gets its share of the long ones).  A shared cursor looks more flexible, but thousands of
 // wavefronts adding to ONE word are served one after the other by the L2 (~12 ns each): with a grid as large as the chunk
 // list that was 60-75 us of every launch, more than the DP itself took (tools/bxl_probe.py).
-__device__ __forceinline__ bool bxl_chunk_at(const BxDev& bx, uint32_t chunk, int hi_ctr, BxChunk* out) {
+// part (BX_PART_*; HEAD / TAIL only for the plan's own lists, whose counters are the first 2 BX_NCLS: hi_ctr = BXC_LIST0 or BXC_LIST0 + BX_NCLS)
+__device__ __forceinline__ bool bxl_chunk_at(const BxDev& bx, uint32_t chunk, int hi_ctr, BxChunk* out, int part = BX_PART_ALL) {
   for (int c = BX_NCLS - 1; c >= 0; c--) {
-    const uint32_t hi = *bxc(bx.ctr, hi_ctr + c), per = (uint32_t)bxl_chunk_reads(c), nch = (hi + per - 1u) / per;
-    if (chunk < nch) { out->cls = c; out->first = chunk * per; out->count = hi; return true; }
+    const uint32_t live = *bxc(bx.ctr, hi_ctr + c);
+    const uint32_t mark = part == BX_PART_ALL ? 0u : bx.snap[hi_ctr - BXC_LIST0 + c];
+    const uint32_t lo = part == BX_PART_TAIL ? mark : 0u, hi = part == BX_PART_HEAD ? mark : live;
+    const uint32_t cnt = hi > lo ? hi - lo : 0u, per = (uint32_t)bxl_chunk_reads(c), nch = (cnt + per - 1u) / per;
+    if (chunk < nch) { out->cls = c; out->first = lo + chunk * per; out->count = hi; return true; }
     chunk -= nch;
   }
   return false;
+}
+__global__ void k_bx_snap(const uint32_t* ctr, uint32_t* snap) {
+  if (blockIdx.x == 0 && threadIdx.x < 2 * BX_NCLS) snap[threadIdx.x] = *bxc(ctr, BXC_LIST0 + (int)threadIdx.x);
 }
 // what the wavefronts of a workgroup finished, added up in LDS: one atomic per workgroup on the statistics word
 __device__ __forceinline__ void bxl_count_done(uint32_t done, uint32_t* lds_word, uint32_t* global_word) {
@@ -621,7 +632,7 @@ __device__ __forceinline__ uint32_t bxl_values_chunk(const ReadSet& rs, const Re
   return ok ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(256, 4) void k_bxl_values(ReadSet rs, RefInfo ref, BxDev bx, int32_t* bin_of) {
+__global__ __launch_bounds__(256, 4) void k_bxl_values(ReadSet rs, RefInfo ref, BxDev bx, int32_t* bin_of, int32_t part) {
   // the step's chain runs through this kernel and the late trace behind it, while k_bxl_trace beside them has slack: their
   // wavefronts go first wherever a SIMD has both to choose from (MIA_HIP_BX_DEBUG=128: all at priority 0)
   if (!(bx.dbg & 128u)) __builtin_amdgcn_s_setprio(2);
@@ -634,7 +645,7 @@ __global__ __launch_bounds__(256, 4) void k_bxl_values(ReadSet rs, RefInfo ref, 
   uint32_t done = 0;
   BxChunk ch;
   const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), waves = gridDim.x * 4u;
-  for (uint32_t chunk = wave; bxl_chunk_at(bx, chunk, BXC_LIST0, &ch); chunk += waves) {
+  for (uint32_t chunk = wave; bxl_chunk_at(bx, chunk, BXC_LIST0, &ch, part); chunk += waves) {
     switch (ch.cls) {
       case 0: done += bxl_values_chunk<1>(rs, ref, bx, bin_of, ch, sub_lds); break;
       case 1: done += bxl_values_chunk<2>(rs, ref, bx, bin_of, ch, sub_lds); break;
@@ -682,7 +693,8 @@ __device__ __forceinline__ uint32_t bxl_trace_chunk(const ReadSet& rs, const Ref
 // trace slab of a wavefront: [row][lane][2 words]
 constexpr int BXL_SLAB_ROW_WORDS = 128;
 // list0 / ctr0: BX_NCLS / BXC_LIST0 + BX_NCLS for the plan's trace lists, 2 BX_NCLS / BXC_LATE0 for the values DP's left-overs
-__device__ __forceinline__ void bxl_trace_grid(const ReadSet& rs, const RefInfo& ref, const BxDev& bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of, int list0, int ctr0) {
+__device__ __forceinline__ void bxl_trace_grid(const ReadSet& rs, const RefInfo& ref, const BxDev& bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of, int list0, int ctr0,
+                                               int part = BX_PART_ALL) {
   __shared__ int32_t sub_lds[BX_SUB_WORDS];
   for (int k = threadIdx.x; k < BX_SUB_WORDS; k += 256) sub_lds[k] = bx.sub256[k];
   __syncthreads();
@@ -693,7 +705,7 @@ __device__ __forceinline__ void bxl_trace_grid(const ReadSet& rs, const RefInfo&
   uint32_t done = 0;
   BxChunk ch;
   const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), waves = gridDim.x * 4u;
-  for (uint32_t chunk = wave; bxl_chunk_at(bx, chunk, ctr0, &ch); chunk += waves) {
+  for (uint32_t chunk = wave; bxl_chunk_at(bx, chunk, ctr0, &ch, part); chunk += waves) {
     switch (ch.cls) {
       case 0: done += bxl_trace_chunk<1>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
       case 1: done += bxl_trace_chunk<2>(rs, ref, bx, bin_of, ch, sub_lds, slab, list0); break;
@@ -705,8 +717,8 @@ __device__ __forceinline__ void bxl_trace_grid(const ReadSet& rs, const RefInfo&
   bxl_count_done(done, &done_wg, bxc(bx.ctr, BXC_DONE_TRACE));
 }
 // (two names for one body: a profile tells the plan's lists and the values DP's left-overs apart)
-__global__ __launch_bounds__(256, 4) void k_bxl_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
-  bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, BX_NCLS, BXC_LIST0 + BX_NCLS);
+__global__ __launch_bounds__(256, 4) void k_bxl_trace(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of, int32_t part) {
+  bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, BX_NCLS, BXC_LIST0 + BX_NCLS, part);
 }
 __global__ __launch_bounds__(256, 4) void k_bxl_trace_late(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
   if (!(bx.dbg & 128u)) __builtin_amdgcn_s_setprio(3);

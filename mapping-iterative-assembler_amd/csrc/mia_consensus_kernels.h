@@ -1016,7 +1016,10 @@ __device__ __forceinline__ uint32_t wave_transpose32(uint32_t x, int lane) {
 // DEFER: the reads that fit none of the one-read-per-lane routes (two gaps, soft ends, odd records: a thousand in a million) are
 // not tallied here, one per wavefront while the other lanes wait, but put on gen_list for k_tally_reduce's extra workgroups.  Seven hundred such reads cost 54 of this kernel's 215 us per million reads: every one of them is a stretch of code
 // nobody else runs (instruction fetches from memory) and a chain of loads in front of a workgroup's barrier.
-template <bool LINEAR, bool DEFER>
+// RALL (round 5, position-specific matrices, reads of 129 .. 256 bases -- configs[4]'s 150): EVERY row of a gap-free read goes through the
+// runs (tally_runs below), 64 rows of the reads' planes per round; no vertical counters in this instance (they hold 128 rows and 256
+// columns), four plane words per read instead of two.
+template <bool LINEAR, bool DEFER, bool RALL = false>
 __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref, const int32_t* pssm2, const uint8_t* drop_front,
                                                        const uint8_t* drop_back, TallyBuf tb, int32_t nb, const int32_t* off,
                                                        const int32_t* wgoff, const int32_t* order, const int32_t* rec_params,
@@ -1139,7 +1142,9 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   unsigned long long bs0[4 * BS_W], bs1[4 * BS_W];
   // (position-specific matrices: the counters take the bases of depth code 15 -- seven in ten -- of a workgroup whose reads are all of
   // one strand, split != 0; the fifteen rows at either end of a read keep their packed adds)
-  const bool bs_on = (LINEAR || split != 0) && rplanes && umax && !(dbg & 4096u);
+  static_assert(!(LINEAR && RALL), "RALL is a mode of the position-specific tally");
+  const bool bs_on = !RALL && (LINEAR || split != 0) && rplanes && umax && !(dbg & 4096u);
+  const bool planes_all = RALL && split != 0 && rplanes && umax;
   // a stretch of a read's planes (rows from r_lo on, n_rows of them) counted at window columns c .. c + n_rows - 1 < 256
   auto bs_count = [&](unsigned long long l0, unsigned long long l1, unsigned long long h0, unsigned long long h1, int r_lo, int n_rows, int c) {
     // rows r_lo.. down to bit 0 (a 128-bit shift right), then n_rows of them kept
@@ -1217,7 +1222,7 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
   // was loaded is only looked at a pass later): with the loads inside `if (ii >= 0)` the number of loads in flight at the first
   // use of the PREVIOUS pass's record depended on the path, and the wait the compiler put there was for all of them -- the
   // records "a pass ahead" were waited for on the spot, the gather's latency (60 % of this kernel) hidden by nothing.
-  struct ReadIn { int4 a, b4, c4; unsigned long long l0, l1, h0, h1; };
+  struct ReadIn { int4 a, b4, c4; unsigned long long l0, l1, h0, h1, l2, l3, h2, h3; };
   const int pw1 = rplane_words > 1 ? 1 : 0;
   auto fetch = [&](int ii) -> ReadIn {
     ReadIn q;
@@ -1233,6 +1238,14 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
     } else if (bs_on) {
       const uint64_t* pl = rplanes + jj * 2 * rplane_words;
       q.l0 = pl[0]; q.l1 = pl[1]; q.h0 = pl[rplane_words]; q.h1 = pl[rplane_words + 1];
+    }
+    q.l2 = q.l3 = q.h2 = q.h3 = 0ull;
+    if (RALL && planes_all) {
+      // (words beyond a read's own are the next plane's or the next read's -- the buffer is padded --: rows beyond the read are never looked at)
+      const uint64_t* pl = rplanes + jj * 2 * rplane_words;
+      const int w1 = rplane_words > 1 ? 1 : 0, w2 = rplane_words > 2 ? 2 : w1, w3 = rplane_words > 3 ? 3 : w2;
+      q.l0 = pl[0]; q.l1 = pl[w1]; q.l2 = pl[w2]; q.l3 = pl[w3];
+      q.h0 = pl[rplane_words]; q.h1 = pl[rplane_words + w1]; q.h2 = pl[rplane_words + w2]; q.h3 = pl[rplane_words + w3];
     }
     return q;
   };
@@ -1403,6 +1416,10 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
         }
         };
         // (a gap-free read of at least 31 bases whose depth codes are its own: rows 0..14 carry codes 0..14, the last fifteen 16..30)
+        if (RALL)      // every row through the runs: a gap-free read of this workgroup's strand without N, its planes at hand
+          coop = runs_on && planes_all && fast && !one_here && !dF && pk_bias >= 0 && fB == n_al && abr == 0 && len2 <= 64 * rplane_words && len2 <= 256 &&
+                 (a.w & TRF_NO_N) && ((flags & TRF_RC) != 0) == (wg_rc != 0) && !(dbg & 16u);
+        else
         coop = runs_on && have_mid && fast && !one_here && !dF && pk_bias >= 0 && n_al >= 2 * PSSM_DEPTH + 1 && fB == n_al && !(dbg & 16u);
         if (coop) { c_w0 = w0; c_nal = n_al; }
         else {
@@ -1422,7 +1439,47 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
     }
     if constexpr (!LINEAR) {
       const unsigned long long cm = runs_on ? __ballot(coop) : 0ull;
-      if (cm) {
+      if (RALL && cm) {
+        // runs: neighbouring lanes with the same start and length (as below)
+        const int key = (c_w0 << 9) | c_nal;
+        const int pkey = __shfl_up(key, 1);
+        const bool pcoop = __shfl_up((int)coop, 1) != 0;
+        const unsigned long long lm0 = __ballot(coop && (lane == 0 || !pcoop || pkey != key));
+        const unsigned long long brk = lm0 | ~cm;
+        typedef __attribute__((address_space(3))) unsigned long long lds_u64a;
+        const unsigned long long pl_lo[4] = {in.l0, in.l1, in.l2, in.l3}, pl_hi[4] = {in.h0, in.h1, in.h2, in.h3};
+        // a round: 64 rows -- the lower half of the wavefront takes rows 64 t .. 64 t + 31, the upper half the 32 behind them
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          if (__ballot(coop && c_nal > 64 * t) == 0ull) continue;        // (wave-uniform; `continue`, not `break`: the loop is unrolled for the constant plane index)
+          const uint32_t lo_a = coop ? (uint32_t)pl_lo[t] : 0u, lo_b = coop ? (uint32_t)(pl_lo[t] >> 32) : 0u;
+          const uint32_t hi_a = coop ? (uint32_t)pl_hi[t] : 0u, hi_b = coop ? (uint32_t)(pl_hi[t] >> 32) : 0u;
+          const uint32_t tla = wave_transpose32(lo_a, lane), tlb = wave_transpose32(lo_b, lane), tha = wave_transpose32(hi_a, lane), thb = wave_transpose32(hi_b, lane);
+          const uint32_t gl = (uint32_t)__shfl_xor((int)(lane < 32 ? tlb : tla), 32), gh = (uint32_t)__shfl_xor((int)(lane < 32 ? thb : tha), 32);
+          const unsigned long long Ml = lane < 32 ? ((unsigned long long)tla | ((unsigned long long)gl << 32)) : ((unsigned long long)gl | ((unsigned long long)tlb << 32));
+          const unsigned long long Mh2 = lane < 32 ? ((unsigned long long)tha | ((unsigned long long)gh << 32)) : ((unsigned long long)gh | ((unsigned long long)thb << 32));
+          const int row = 64 * t + lane;                       // (lane < 32: rows 64 t + lane of word a; lane >= 32: rows 64 t + 32 + (lane - 32) of word b)
+          unsigned long long lm = lm0;
+          while (lm) {
+            const int a0 = __builtin_ctzll(lm);
+            lm &= lm - 1;
+            const unsigned long long above = a0 == 63 ? 0ull : (~0ull << (a0 + 1));
+            const unsigned long long nxt = brk & above;
+            const int e0 = nxt ? __builtin_ctzll(nxt) : 64;
+            const unsigned long long seg = (e0 == 64 ? ~0ull : ((1ull << e0) - 1ull)) & (~0ull << a0);
+            const int s_w0 = __builtin_amdgcn_readlane(c_w0, a0), s_nal = __builtin_amdgcn_readlane(c_nal, a0);
+            if (row < s_nal) {
+              const unsigned long long lo = Ml & seg, hi = Mh2 & seg;
+              const int cT = __popcll(lo & hi), cC = __popcll(lo & ~hi), cG = __popcll(hi & ~lo), cA = __popcll(seg) - cT - cC - cG;
+              const unsigned long long* tab = run_tab + depth_code(row, s_nal - row - 1) * 8;
+              const unsigned long long v1 = (unsigned long long)cA * tab[0] + (unsigned long long)cC * tab[2] + (unsigned long long)cG * tab[4] + (unsigned long long)cT * tab[6];
+              const unsigned long long v2 = (unsigned long long)cA * tab[1] + (unsigned long long)cC * tab[3] + (unsigned long long)cG * tab[5] + (unsigned long long)cT * tab[7];
+              (void)__hip_atomic_fetch_add((lds_u64a*)pk1 + s_w0 + row, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              (void)__hip_atomic_fetch_add((lds_u64a*)pk2 + s_w0 + row, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+      } else if (cm) {
         // rows 0 .. 14 and the last fifteen of this lane's read: low plane in bits 0 .. 14, high plane in bits 16 .. 30
         uint32_t fw = 0, bw = 0;
         if (coop) {

@@ -81,12 +81,15 @@ struct mia_hip_ctx {
   bool spin_wait = true;        // mia_hip_iterate's one wait asks (hipStreamQuery) instead of sleeping on an interrupt; MIA_HIP_SPIN_WAIT=0: hipStreamSynchronize
   uint32_t ext_events = 31u; bool planner_end_signalled = false, align_end_signalled = false;
   BxCandRec* d_bx_cand2 = nullptr; int use_fine = 1;      // the third launch's list (reads for the fine blocks); MIA_HIP_NO_FINE=1: none; MIA_HIP_FINE=2: in every iteration
-  BxCandRec* d_bx_cand = nullptr; int64_t cand_cap = 0; bool plan_split = true;      // k_bx_plan's hand-over list between its two launches (MIA_HIP_NO_PLAN_SPLIT=1: one launch)
+  BxCandRec* d_bx_cand = nullptr; int64_t cand_cap = 0, cand2_cap = 0; bool plan_split = true;      // k_bx_plan's hand-over list between its two launches (MIA_HIP_NO_PLAN_SPLIT=1: one launch)
   bool no_spec = false;                     // MIA_HIP_NO_SPEC=1: wait for the alignment's counters before the cull is queued
   bool no_side_buckets = false;             // MIA_HIP_NO_SIDE_BUCKETS=1
   int buckets_queued = 0;                   // the tally's counting sort is already queued: 1 on the context's stream, 2 on stream2 (ev_join behind it)
   // the early tally (mia_consensus_kernels.h, k_rec_early): the reads the plan finishes are tallied on stream4 beside the band DPs
   hipStream_t stream4 = nullptr; hipEvent_t ev_early = nullptr;
+  // the band DPs in two rounds (align_all: split_dp): the first beside the plan's second and third launch, on the lists its first launch made
+  hipEvent_t ev_snap = nullptr, ev_v1 = nullptr; uint32_t* d_bx_snap = nullptr; int split_dp_mode = 0;      // mode: 0 auto, 1 always (MIA_HIP_SPLIT_DP=1), -1 never (MIA_HIP_SPLIT_DP=0)
+  int64_t split_dp_steps = 0;
   // MIA_HIP_EARLY_TALLY=1 (alt build only; an experiment that measured SLOWER): the plan's reads tallied beside the band DPs
   bool use_early = false, early_queued = false;
   int early_wgs_per_cu = 2;
@@ -206,6 +209,7 @@ struct mia_hip_ctx {
   // through the vertical counters.  Measured: configs[2] 1.313 -> 1.306 ms, configs[4] at 5 M reads 9.91 -> 10.2 ms (twice the part-filled
   // workgroups and slabs; the end rows' packed atomics are what the kernel waits for either way) -- off
   bool tally_strand_split = true;          // position-specific matrices: a workgroup's reads all of one strand, sorted by start (round 5; MIA_HIP_STRAND_SPLIT=0: round 4's tally)
+  bool tally_rall = true;                  // reads of 129 .. 256 bases: every row through the runs (MIA_HIP_NO_TALLY_RALL=1: round 4's tally for them)
   bool tally_runs = true;                  // ... and the rows at either end of a read reduced over runs of equal starts (MIA_HIP_NO_TALLY_RUNS=1: per read)
   int32_t* d_order2 = nullptr; int32_t* d_sort2 = nullptr; int64_t sort2_cap = 0;      // the reads of every bucket by start; histogram + cursors of that sort
   int tally_chunk_linear = TALLY_CHUNK_LINEAR;                    // MIA_HIP_TALLY_CHUNK=256|512|768 (alt build)
@@ -333,6 +337,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
       hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join3, evf) != hipSuccess ||
       hipStreamCreateWithFlags(&ctx->stream4, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_early, evf) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_snap, evf) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_v1, evf) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, evf) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_join, evf) != hipSuccess) {
     delete ctx;
     return MIA_HIP_ERR_DEVICE;
@@ -385,6 +390,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* ti = alt_env("MIA_HIP_TALLY_INLINE")) ctx->tally_defer = atoi(ti) == 0;
     if (const char* ss = alt_env("MIA_HIP_STRAND_SPLIT")) ctx->tally_strand_split = atoi(ss) != 0;
     if (const char* nr = alt_env("MIA_HIP_NO_TALLY_RUNS")) ctx->tally_runs = atoi(nr) == 0;
+    if (const char* sd = alt_env("MIA_HIP_SPLIT_DP")) ctx->split_dp_mode = atoi(sd) != 0 ? 1 : -1;
+    if (const char* ra = alt_env("MIA_HIP_NO_TALLY_RALL")) ctx->tally_rall = atoi(ra) == 0;
     if (const char* tc = alt_env("MIA_HIP_TALLY_CHUNK")) { const int c = atoi(tc); if (c == 256 || c == 512 || c == 768) ctx->tally_chunk_linear = c; }
     if (const char* ew = alt_env("MIA_HIP_EARLY_WGS")) ctx->early_wgs_per_cu = atoi(ew);
     if (const char* nf = alt_env("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
@@ -457,6 +464,9 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   if (ctx->stream4) (void)hipStreamDestroy(ctx->stream4);
   if (ctx->ev_early) (void)hipEventDestroy(ctx->ev_early);
+  if (ctx->ev_snap) (void)hipEventDestroy(ctx->ev_snap);
+  if (ctx->ev_v1) (void)hipEventDestroy(ctx->ev_v1);
+  if (ctx->d_bx_snap) (void)hipFree(ctx->d_bx_snap);
   if (ctx->d_gen_list) (void)hipFree(ctx->d_gen_list);
   for (void* p : {(void*)ctx->d_early, (void*)ctx->d_trec_early, (void*)ctx->d_order_e, (void*)ctx->d_fix_list, (void*)ctx->d_bucket_e, (void*)ctx->d_tally_slabs_e}) if (p) (void)hipFree(p);
   if (ctx->ev_join3) (void)hipEventDestroy(ctx->ev_join3);
@@ -1164,8 +1174,13 @@ static int align_all(mia_hip_ctx* ctx) {
       const bool fine = split && ctx->use_fine && (ctx->use_fine > 1 || !ctx->flat || n >= 4000000 || !ctx->ref_mostly_bases || rejects_before * 20 > n);
       if (split) {
         if (n > ctx->cand_cap) {
-          if (dev_alloc(ctx, &ctx->d_bx_cand, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_cand2, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+          if (dev_alloc(ctx, &ctx->d_bx_cand, (size_t)n)) return MIA_HIP_ERR_NOMEM;
           ctx->cand_cap = n;
+        }
+        // (the third launch's list only where that launch runs: a record is 72 bytes -- 0.7 GB at 10 M reads)
+        if (fine && n > ctx->cand2_cap) {
+          if (dev_alloc(ctx, &ctx->d_bx_cand2, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+          ctx->cand2_cap = n;
         }
         bd.cand = ctx->d_bx_cand;
         if (fine) bd.cand2 = ctx->d_bx_cand2;
@@ -1184,10 +1199,6 @@ static int align_all(mia_hip_ctx* ctx) {
         const bool many_early = !ctx->no_auto_plain && (!ctx->ref_mostly_bases || lr * 20 > n);
         planner_head_first = new_flow && ctx->deferred && many_early && !ctx->planner_beside && !(ctx->dbg & 256u);
       }
-      // The widest class (33-64 diagonals) holds the few reads a step that used to go to the full-window kernels beside the band DPs.
-      // Through the values DP their left-overs land on the late lists, i.e. on the step's critical path (late trace 0.125 -> 0.17 ms per
-      // 1 M flat reads); where the lists are short anyway they go straight to the trace DP on its own stream instead.
-      bd.wide_to_trace = (new_flow && !fine) ? 1 : 0;
       // the early tally (k_rec_early): the plan marks the reads it finishes, their tally runs on stream4 beside the band DPs.  Only in
       // mia_hip_iterate (the whole step is queued at once), for read sets small enough that the step is a chain of latencies.
       const bool early = ctx->deferred && new_flow && ctx->use_early && !run_filter && tally_is_binned(ctx) && n <= 4000000;
@@ -1204,6 +1215,21 @@ static int align_all(mia_hip_ctx* ctx) {
       // latencies) the widest class is not used at all: those few reads keep going to the full-window kernels on the planner's stream,
       // whose chain is as long with them as without (measured: 0.960 against 0.944 ms per step with the class in use)
       if (!fine && ctx->use_fine < 2) bd.tab.maxw = 32;
+      // THE BAND DPs IN TWO ROUNDS (MIA_HIP_SPLIT_DP=1, alt build).  Where the plan gives up on many reads (every run's
+      // first iteration: a reference full of ambiguity codes) its second and third launch are long -- 0.5 + 1.7 ms of 10 M solexa reads,
+      // behind 3.1 ms of the first -- and the band DPs wait for all three.  Nine lists in ten are complete after the first launch:
+      // k_bx_snap notes their lengths, the DPs of those entries start at once (values DP on stream4, trace DP on stream3) beside the other
+      // two launches, and a second round behind the last launch takes what they appended.  MEASURED, NO GAIN: first iteration of 10 M
+      // solexa reads 17.13 ms with it, 16.90 without; 1 M flat reads 1.90 / 1.83 -- the plan's launches and the DPs are all bound by
+      // vector issue, and what runs side by side only shares the chip.  Kept behind the switch (tests/test_gpu_switches.py runs it).
+      const bool split_dp = new_flow && ctx->deferred && split && last_phase >= 2 && !early && !(ctx->bx_dbg & (4u | 8u)) && ctx->split_dp_mode >= 0 &&
+                            ctx->split_dp_mode > 0;
+      bd.snap = nullptr;
+      if (split_dp) {
+        if (!ctx->d_bx_snap && dev_alloc(ctx, &ctx->d_bx_snap, (size_t)(2 * BX_NCLS))) return MIA_HIP_ERR_NOMEM;
+        bd.snap = ctx->d_bx_snap;
+        ctx->split_dp_steps++;
+      }
       if (stage_begin(ctx, STG_BX_PLAN)) return MIA_HIP_ERR_NOMEM;
       {
         const int32_t* in_list = run_filter ? ctx->d_left_list : nullptr;
@@ -1223,6 +1249,17 @@ static int align_all(mia_hip_ctx* ctx) {
           }
 #undef MIA_PLAN_NW
 #undef MIA_PLAN
+          if (split_dp && phase == 1) {
+            launch_k(k_bx_snap, dim3(1), dim3(64), 0, ctx->stream, ctx->ev_snap, (const uint32_t*)ctx->d_bx_ctr, ctx->d_bx_snap);
+            HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_snap, 0));
+            HIPCHK(hipStreamWaitEvent(ctx->stream4, ctx->ev_snap, 0));
+            if (stage_begin(ctx, STG_BX_TRACE, ctx->stream3)) return MIA_HIP_ERR_NOMEM;
+            hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of, (int32_t)BX_PART_HEAD);
+            stage_end(ctx, STG_BX_TRACE, ctx->stream3);
+            if (stage_launch(ctx, STG_BX_VALUES, k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream4, ctx->rs, ref, bd, ctx->d_bin_of, (int32_t)BX_PART_HEAD))
+              return MIA_HIP_ERR_NOMEM;
+            HIPCHK(hipEventRecord(ctx->ev_v1, ctx->stream4));
+          }
         }
       }
       stage_end(ctx, STG_BX_PLAN);
@@ -1251,13 +1288,15 @@ static int align_all(mia_hip_ctx* ctx) {
           if (early) HIPCHK(hipStreamWaitEvent(ctx->stream4, ctx->ev_fork, 0));
           if (stage_begin(ctx, STG_BX_TRACE, ctx->stream3)) return MIA_HIP_ERR_NOMEM;
           const bool sig3 = (ctx->ext_events & 2u) && new_flow && !(ctx->bx_dbg & 8u);
+          const int32_t part2 = split_dp ? BX_PART_TAIL : BX_PART_ALL;
           if (!(ctx->bx_dbg & 8u))
-            launch_k(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, sig3 ? ctx->ev_join3 : nullptr, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
+            launch_k(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream3, sig3 ? ctx->ev_join3 : nullptr, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of, part2);
           stage_end(ctx, STG_BX_TRACE, ctx->stream3);
           if (!sig3) HIPCHK(hipEventRecord(ctx->ev_join3, ctx->stream3));
           if (!(ctx->bx_dbg & 4u)) {
-            if (stage_launch(ctx, STG_BX_VALUES, k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bin_of) ||
-                stage_launch(ctx, STG_BX_VALUES, k_bxl_trace_late, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of))
+            if (stage_launch(ctx, STG_BX_VALUES, k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bin_of, part2)) return MIA_HIP_ERR_NOMEM;
+            if (split_dp) HIPCHK(hipStreamWaitEvent(vs, ctx->ev_v1, 0));          // (the late lists hold both rounds' left-overs)
+            if (stage_launch(ctx, STG_BX_VALUES, k_bxl_trace_late, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of))
               return MIA_HIP_ERR_NOMEM;
           }
           if (!ctx->deferred) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
@@ -1274,7 +1313,7 @@ static int align_all(mia_hip_ctx* ctx) {
         HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         if (stage_begin(ctx, STG_BX_TRACE, ctx->stream2)) return MIA_HIP_ERR_NOMEM;
         if (ctx->bx_dbg & 8u) {}
-        else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
+        else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of, (int32_t)BX_PART_ALL);
 #ifdef MIA_HIP_ALT_PATHS
         else hipLaunchKernelGGL(k_bx_trace, dim3((unsigned)ctx->bx_trace_wgs), dim3(256), 0, ctx->stream2, ctx->rs, ref, bd, ctx->d_bx_slabs, slab_words, ctx->d_bin_of);
 #endif
@@ -1282,7 +1321,7 @@ static int align_all(mia_hip_ctx* ctx) {
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
         if (stage_begin(ctx, STG_BX_VALUES)) return MIA_HIP_ERR_NOMEM;
         if (ctx->bx_dbg & 4u) {}
-        else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
+        else if (ctx->use_lanes) hipLaunchKernelGGL(k_bxl_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of, (int32_t)BX_PART_ALL);
 #ifdef MIA_HIP_ALT_PATHS
         else hipLaunchKernelGGL(k_bx_values, dim3((unsigned)ctx->bx_values_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bin_of);
 #endif
@@ -1983,7 +2022,13 @@ static int ensure_tally(mia_hip_ctx* ctx) {
 // everything of mia_hip_tally that is queued on the stream; the event count and the error flags are read afterwards
 // the binned tally's layout for this reference: buckets of TALLY_BUCKET columns, one workgroup per TALLY_CHUNK reads of a bucket
 // the position-specific matrices' tally sorts by strand as well (bucket_of, mia_consensus_kernels.h): twice the buckets
-static int tally_split(const mia_hip_ctx* ctx) { return (!ctx->tally_linear && ctx->tally_strand_split && !ctx->early_queued && !ctx->use_early) ? 1 : 0; }
+// (reads of more than 128 bases -- configs[4]'s 150 -- take the RALL instance of k_tally_binned: every row through the runs; the vertical
+// counters and the end-row runs work on two 64-row plane words.  With the split but neither -- a first attempt -- such reads paid for the
+// part-filled workgroups and got nothing for it: 2.18 against round 4's 1.51 ms per 5 M reads of 150 bases.)
+static bool tally_rall(const mia_hip_ctx* ctx) { return ctx->max_len > 128 && ctx->max_len <= 256 && ctx->tally_runs && ctx->tally_rall; }
+static int tally_split(const mia_hip_ctx* ctx) {
+  return (!ctx->tally_linear && ctx->tally_strand_split && !ctx->early_queued && !ctx->use_early && (ctx->max_len <= 128 || tally_rall(ctx))) ? 1 : 0;
+}
 static int tally_nb(const mia_hip_ctx* ctx) { return (ctx->wrap / TALLY_BUCKET + 1) << tally_split(ctx); }
 static bool tally_is_binned(const mia_hip_ctx* ctx) {
   const int nb = ctx->wrap / TALLY_BUCKET + 1;
@@ -2142,6 +2187,9 @@ static int tally_launch(mia_hip_ctx* ctx) {
       if (ctx->tally_linear)
         rct = defer ? stage_launch(ctx, STG_TALLY, k_tally_binned<true, true>, MIA_TALLY_ARGS(pl_arg, ctx->rplane_words, um_arg, -1))
                     : stage_launch(ctx, STG_TALLY, k_tally_binned<true, false>, MIA_TALLY_ARGS(pl_arg, ctx->rplane_words, um_arg, -1));
+      else if (split && tally_rall(ctx))
+        rct = defer ? stage_launch(ctx, STG_TALLY, k_tally_binned<false, true, true>, MIA_TALLY_ARGS(pl_arg, ctx->rplane_words, um_arg, ctx->tally_pk_bias))
+                    : stage_launch(ctx, STG_TALLY, k_tally_binned<false, false, true>, MIA_TALLY_ARGS(pl_arg, ctx->rplane_words, um_arg, ctx->tally_pk_bias));
       else
         rct = defer ? stage_launch(ctx, STG_TALLY, k_tally_binned<false, true>, MIA_TALLY_ARGS(split ? pl_arg : nullptr, ctx->rplane_words, split ? um_arg : nullptr, ctx->tally_pk_bias))
                     : stage_launch(ctx, STG_TALLY, k_tally_binned<false, false>, MIA_TALLY_ARGS(split ? pl_arg : nullptr, ctx->rplane_words, split ? um_arg : nullptr, ctx->tally_pk_bias));
