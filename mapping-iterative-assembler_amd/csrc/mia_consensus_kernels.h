@@ -1449,9 +1449,8 @@ __global__ __launch_bounds__(256, 3) void k_tally_binned(ReadSet rs, RefInfo ref
         typedef __attribute__((address_space(3))) unsigned long long lds_u64a;
         const unsigned long long pl_lo[4] = {in.l0, in.l1, in.l2, in.l3}, pl_hi[4] = {in.h0, in.h1, in.h2, in.h3};
         // a round: 64 rows -- the lower half of the wavefront takes rows 64 t .. 64 t + 31, the upper half the 32 behind them
-#pragma unroll
         for (int t = 0; t < 4; t++) {
-          if (__ballot(coop && c_nal > 64 * t) == 0ull) continue;        // (wave-uniform; `continue`, not `break`: the loop is unrolled for the constant plane index)
+          if (__ballot(coop && c_nal > 64 * t) == 0ull) break;           // (wave-uniform)
           const uint32_t lo_a = coop ? (uint32_t)pl_lo[t] : 0u, lo_b = coop ? (uint32_t)(pl_lo[t] >> 32) : 0u;
           const uint32_t hi_a = coop ? (uint32_t)pl_hi[t] : 0u, hi_b = coop ? (uint32_t)(pl_hi[t] >> 32) : 0u;
           const uint32_t tla = wave_transpose32(lo_a, lane), tlb = wave_transpose32(lo_b, lane), tha = wave_transpose32(hi_a, lane), thb = wave_transpose32(hi_b, lane);
