@@ -849,6 +849,18 @@ __device__ __forceinline__ int bucket_of(const ReadSet& rs, int64_t i, int nb, i
 __device__ __forceinline__ bool bucket_takes(const ReadSet& rs, int64_t i, const uint8_t* part, int want) {
   return i < rs.n && rs.sk[i] && (!part || (part[i] != 0) == (want != 0));
 }
+// the key of the second sort (k_sort2_*: every bucket by alignment start), worked out where the reads are walked in their own order
+// (k_bucket_fill) and carried beside `order` as a byte: looked up through `order` it was three gathers per read and launch, and the two
+// launches -- 0.47 + 0.51 ms at 10 M reads, beside the cull on the other stream -- took the cull's memory bandwidth (k_cull_records 0.48 -> 1.29 ms)
+constexpr int SORT2_KEYS = 256;           // starts 0 .. 254 of a bucket's first column (the last bucket's reads may start beyond its 128); 255: see below
+// (a read with a gap or a soft end goes behind all the gap-free ones of its bucket: the tally adds such a read's rows one by
+// one, and a few of them in every wavefront made every wavefront walk that loop -- 1.0 of the tally's 1.5 ms at 10 M reads;
+// collected at the end of the bucket they fill a few wavefronts of their own)
+__device__ __forceinline__ int sort2_key(const ReadSet& rs, int64_t i, int b, int split) {
+  if (!(rs.status[i] & ST_DIAG) || rs.abr[i] != 0) return SORT2_KEYS - 1;
+  const int k = rs.as[i] - (b >> split) * TALLY_BUCKET;
+  return k < 0 ? 0 : (k >= SORT2_KEYS - 1 ? SORT2_KEYS - 2 : k);
+}
 __global__ __launch_bounds__(256) void k_bucket_count(ReadSet rs, int32_t nb, int32_t* count, int32_t* zero, int64_t zero_words, const int32_t* abort_if = nullptr,
                                                        const uint8_t* part = nullptr, int32_t want = 0, int32_t split = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
@@ -894,7 +906,7 @@ __global__ __launch_bounds__(256) void k_bucket_scan(int32_t* count, int32_t nb,
   if (t == 255) { off[nb] = s_run[255]; wgoff[nb] = s_wg[255]; }
 }
 __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, const int32_t* off, int32_t* cursor, int32_t* order, const int32_t* abort_if = nullptr,
-                                                      const uint8_t* part = nullptr, int32_t want = 0, int32_t split = 0) {
+                                                      const uint8_t* part = nullptr, int32_t want = 0, int32_t split = 0, uint8_t* okey = nullptr, int32_t packed = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   extern __shared__ int32_t sh[];
   int32_t* hist = sh;
@@ -912,7 +924,15 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
   __syncthreads();
   for (int k = 0; k < BUCKET_PER; k++) {
     const int64_t i = ((int64_t)blockIdx.x * BUCKET_PER + k) * 256 + threadIdx.x;
-    if (bb[k] >= 0) order[off[bb[k]] + base[bb[k]] + rank[k]] = (int32_t)i;
+    if (bb[k] >= 0) {
+      const int32_t at = off[bb[k]] + base[bb[k]] + rank[k];
+      // (fewer than 2^24 reads: the key rides in the entry's top byte -- a scattered byte store beside the scattered word was 0.16 ms at 10 M reads)
+      if (okey && packed) order[at] = (int32_t)i | (sort2_key(rs, i, bb[k], split) << 24);
+      else {
+        order[at] = (int32_t)i;
+        if (okey) okey[at] = (uint8_t)sort2_key(rs, i, bb[k], split);
+      }
+    }
   }
 }
 
@@ -923,17 +943,9 @@ __global__ __launch_bounds__(256) void k_bucket_fill(ReadSet rs, int32_t nb, con
 // SORT2_KEYS keys per bucket whose unit of work is the tally's own workgroup share (k_bucket_scan's table: bucket, first,
 // last), so a bucket that holds all the reads is no slower than any other.  Order is a matter of speed only: the tally checks
 // the keys of a run itself.
-constexpr int SORT2_KEYS = 256;           // starts 0 .. 255 of a bucket's first column (the last bucket's reads may start beyond its 128)
-// (a read with a gap or a soft end goes behind all the gap-free ones of its bucket: the tally adds such a read's rows one by
-// one, and a few of them in every wavefront made every wavefront walk that loop -- 1.0 of the tally's 1.5 ms at 10 M reads;
-// collected at the end of the bucket they fill a few wavefronts of their own)
-__device__ __forceinline__ int sort2_key(const ReadSet& rs, int32_t i, int b, int split) {
-  if (!(rs.status[i] & ST_DIAG) || rs.abr[i] != 0) return SORT2_KEYS - 1;
-  const int k = rs.as[i] - (b >> split) * TALLY_BUCKET;
-  return k < 0 ? 0 : (k >= SORT2_KEYS - 1 ? SORT2_KEYS - 2 : k);
-}
-__global__ __launch_bounds__(256) void k_sort2_count(ReadSet rs, int32_t nb, const int32_t* wgoff, const int32_t* wg_bucket, const int32_t* order, int32_t* hist2,
-                                                      int32_t split, const int32_t* abort_if = nullptr) {
+// packed: the keys are the top bytes of `order` (see k_bucket_fill), okey is not used
+__global__ __launch_bounds__(256) void k_sort2_count(int32_t nb, const int32_t* wgoff, const int32_t* wg_bucket, const int32_t* order, const uint8_t* okey, int32_t packed,
+                                                      int32_t* hist2, const int32_t* abort_if = nullptr) {
   if (abort_if && *abort_if != 0) return;
   if ((int)blockIdx.x >= wgoff[nb]) return;
   __shared__ int32_t h[SORT2_KEYS];
@@ -941,13 +953,13 @@ __global__ __launch_bounds__(256) void k_sort2_count(ReadSet rs, int32_t nb, con
   const int b = wgi.x, first = wgi.y, last = wgi.z;
   h[threadIdx.x] = 0;
   __syncthreads();
-  for (int t = first + (int)threadIdx.x; t < last; t += 256) atomicAdd(&h[sort2_key(rs, order[t], b, split)], 1);
+  for (int t = first + (int)threadIdx.x; t < last; t += 256) atomicAdd(&h[packed ? (int)((uint32_t)order[t] >> 24) : (int)okey[t]], 1);
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&hist2[(int64_t)b * SORT2_KEYS + threadIdx.x], h[threadIdx.x]);
 }
 // cursor2: as hist2, zero before the launch; order2[off[b] + (reads of smaller keys in b) + (place among the key's reads)] = read
-__global__ __launch_bounds__(256) void k_sort2_fill(ReadSet rs, int32_t nb, const int32_t* off, const int32_t* wgoff, const int32_t* wg_bucket, const int32_t* order,
-                                                     const int32_t* hist2, int32_t* cursor2, int32_t* order2, int32_t split, const int32_t* abort_if = nullptr) {
+__global__ __launch_bounds__(256) void k_sort2_fill(int32_t nb, const int32_t* off, const int32_t* wgoff, const int32_t* wg_bucket, const int32_t* order, const uint8_t* okey,
+                                                     int32_t packed, const int32_t* hist2, int32_t* cursor2, int32_t* order2, const int32_t* abort_if = nullptr) {
   if (abort_if && *abort_if != 0) return;
   if ((int)blockIdx.x >= wgoff[nb]) return;
   static_assert(SORT2_KEYS == 256, "one key per thread");
@@ -964,7 +976,12 @@ __global__ __launch_bounds__(256) void k_sort2_fill(ReadSet rs, int32_t nb, cons
   for (int q = 0; q < PER; q++) {
     const int e = first + q * 256 + t;
     rd[q] = -1; key[q] = 0; rank[q] = 0;
-    if (e < last) { rd[q] = order[e]; key[q] = sort2_key(rs, rd[q], b, split); rank[q] = atomicAdd(&h[key[q]], 1); }
+    if (e < last) {
+      const int32_t v = order[e];
+      rd[q] = packed ? (v & 0xFFFFFF) : v;
+      key[q] = packed ? (int)((uint32_t)v >> 24) : (int)okey[e];
+      rank[q] = atomicAdd(&h[key[q]], 1);
+    }
   }
   // exclusive prefix of the bucket's histogram over the 256 keys (Hillis-Steele in LDS)
   const int mine = pre[t];

@@ -211,7 +211,7 @@ struct mia_hip_ctx {
   bool tally_strand_split = true;          // position-specific matrices: a workgroup's reads all of one strand, sorted by start (round 5; MIA_HIP_STRAND_SPLIT=0: round 4's tally)
   bool tally_rall = true;                  // reads of 129 .. 256 bases: every row through the runs (MIA_HIP_NO_TALLY_RALL=1: round 4's tally for them)
   bool tally_runs = true;                  // ... and the rows at either end of a read reduced over runs of equal starts (MIA_HIP_NO_TALLY_RUNS=1: per read)
-  int32_t* d_order2 = nullptr; int32_t* d_sort2 = nullptr; int64_t sort2_cap = 0;      // the reads of every bucket by start; histogram + cursors of that sort
+  int32_t* d_order2 = nullptr; uint8_t* d_okey = nullptr; int32_t* d_sort2 = nullptr; int64_t sort2_cap = 0;      // the reads of every bucket by start; histogram + cursors of that sort
   int tally_chunk_linear = TALLY_CHUNK_LINEAR;                    // MIA_HIP_TALLY_CHUNK=256|512|768 (alt build)
   bool tally_defer = true;                                        // MIA_HIP_TALLY_INLINE=1 (alt build): they are taken inside k_tally_binned, one per wavefront
   // wide scratch
@@ -448,7 +448,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
                   ctx->d_ref, ctx->d_slot, ctx->d_partial, ctx->d_total, ctx->d_slot_dropped, ctx->d_drop_f,
                   ctx->d_drop_b, ctx->tb.tally, ctx->tb.events, ctx->d_ins_off,
                   ctx->d_ins_total, ctx->d_ins_tally, ctx->d_calls, ctx->d_ins_calls, ctx->d_scratch, ctx->d_scratch_off,
-                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order, ctx->d_order2, ctx->d_sort2,
+                  ctx->d_slabs[0], ctx->d_slabs[1], ctx->d_slabs[2], ctx->d_quad_slabs, ctx->d_bucket, ctx->d_order, ctx->d_order2, ctx->d_okey, ctx->d_sort2,
                   ctx->d_back_slot, ctx->ri.flen, ctx->ri.blen, ctx->ri.actf, ctx->ri.trec, ctx->si.reclen, ctx->si.writer, ctx->si.mult,
                   ctx->lk.rec, ctx->d_link_len, ctx->d_link_act, ctx->d_front_slot0, ctx->si.recact, ctx->d_sums, ctx->d_n_links_gathered, ctx->d_tally_slabs, ctx->d_planes, ctx->d_kocc_cnt, ctx->d_kocc_pos, ctx->d_left_list, ctx->d_band_slabs,
                   ctx->d_bx_sub, ctx->d_bx_mrow, ctx->d_bx_loss, ctx->d_bx_dl, ctx->d_rplanes, ctx->d_khash, ctx->d_khash_ovf, ctx->d_refnib, ctx->d_umax, ctx->d_bx_plan, ctx->d_bx_expect, ctx->d_bx_lists, ctx->d_bx_slabs, ctx->d_cut_buf, ctx->d_ascii, ctx->d_cons, ctx->d_cons_pos, ctx->d_gather, ctx->d_lstage, ctx->d_lmine, ctx->d_lall, ctx->d_scores_all};
@@ -659,6 +659,7 @@ extern "C" int mia_hip_upload_reads(mia_hip_ctx* ctx, int64_t n, const char* bas
   r.status = ctx->d_status; r.cols = ctx->d_cols; r.stride = stride;
   if (ctx->d_order) { (void)hipFree(ctx->d_order); ctx->d_order = nullptr; }
   if (ctx->d_order2) { (void)hipFree(ctx->d_order2); ctx->d_order2 = nullptr; }
+  if (ctx->d_okey) { (void)hipFree(ctx->d_okey); ctx->d_okey = nullptr; }
   ctx->umax_valid = false;
   if (n > 0) hipLaunchKernelGGL(k_read_planes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs, ctx->rplane_words, ctx->d_rplanes);
   if (ctx->have_pssm && ctx->bx_ok && n > 0) {
@@ -2066,17 +2067,19 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
                      ctx->abort_if, part, 0, split);
   hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(256), 0, on, d_cnt, nb, d_off, d_wgoff, d_cur, d_wgb, ctx->abort_if, chunk);
   const bool sigb = on != ctx->stream && (ctx->ext_events & 16u);
-  if (!split) launch_k(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, sigb ? ctx->ev_join : nullptr, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if, part, 0, split);
+  if (!split) launch_k(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, sigb ? ctx->ev_join : nullptr, ctx->rs, nb, d_off, d_cur, ctx->d_order, ctx->abort_if, part, 0, split, (uint8_t*)nullptr, 0);
   else {
     // ... and every bucket by alignment start (k_sort2_count / k_sort2_fill: the tally's runs of equal starts)
     const int64_t words2 = (int64_t)nb * SORT2_KEYS * 2;
     if (words2 > ctx->sort2_cap) { if (dev_alloc(ctx, &ctx->d_sort2, (size_t)words2)) return MIA_HIP_ERR_NOMEM; ctx->sort2_cap = words2; }
-    if (!ctx->d_order2 && dev_alloc(ctx, &ctx->d_order2, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+    if (!ctx->d_order2 && (dev_alloc(ctx, &ctx->d_order2, (size_t)n) || dev_alloc(ctx, &ctx->d_okey, (size_t)n + 64))) return MIA_HIP_ERR_NOMEM;
     HIPCHK(hipMemsetAsync(ctx->d_sort2, 0, (size_t)words2 * 4, on));
-    hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, ctx->rs, nb, (const int32_t*)d_off, d_cur, ctx->d_order, ctx->abort_if, part, 0, split);
-    hipLaunchKernelGGL(k_sort2_count, dim3(grid), dim3(256), 0, on, ctx->rs, nb, (const int32_t*)d_wgoff, (const int32_t*)d_wgb, (const int32_t*)ctx->d_order, ctx->d_sort2, split, ctx->abort_if);
-    launch_k(k_sort2_fill, dim3(grid), dim3(256), 0, on, sigb ? ctx->ev_join : nullptr, ctx->rs, nb, (const int32_t*)d_off, (const int32_t*)d_wgoff, (const int32_t*)d_wgb,
-             (const int32_t*)ctx->d_order, (const int32_t*)ctx->d_sort2, ctx->d_sort2 + (int64_t)nb * SORT2_KEYS, ctx->d_order2, split, ctx->abort_if);
+    const int32_t packed = (n < (1 << 24) && !alt_env("MIA_HIP_SORT2_UNPACKED")) ? 1 : 0;      // (the key in the entry's top byte, or -- 2^24 reads and more -- in a byte array beside it)
+    hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, ctx->rs, nb, (const int32_t*)d_off, d_cur, ctx->d_order, ctx->abort_if, part, 0, split, ctx->d_okey, packed);
+    hipLaunchKernelGGL(k_sort2_count, dim3(grid), dim3(256), 0, on, nb, (const int32_t*)d_wgoff, (const int32_t*)d_wgb, (const int32_t*)ctx->d_order, (const uint8_t*)ctx->d_okey, packed,
+                       ctx->d_sort2, ctx->abort_if);
+    launch_k(k_sort2_fill, dim3(grid), dim3(256), 0, on, sigb ? ctx->ev_join : nullptr, nb, (const int32_t*)d_off, (const int32_t*)d_wgoff, (const int32_t*)d_wgb,
+             (const int32_t*)ctx->d_order, (const uint8_t*)ctx->d_okey, packed, (const int32_t*)ctx->d_sort2, ctx->d_sort2 + (int64_t)nb * SORT2_KEYS, ctx->d_order2, ctx->abort_if);
   }
   HIPCHK(hipGetLastError());
   if (on != ctx->stream && !sigb) HIPCHK(hipEventRecord(ctx->ev_join, on));

@@ -29,7 +29,7 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             # (an experiment; default: by column only); no vertical counters at all, either matrix
             # (round 5: split by strand, sorted by start, is the default -- MIA_HIP_STRAND_SPLIT=0 is round 4's tally; MIA_HIP_NO_TALLY_RUNS=1
             # keeps the split and the sort but adds the rows at either end of a read one read at a time instead of one run at a time)
-            "MIA_HIP_STRAND_SPLIT=0", "MIA_HIP_NO_TALLY_RUNS", "MIA_HIP_DEBUG_SKIP=4096",
+            "MIA_HIP_STRAND_SPLIT=0", "MIA_HIP_NO_TALLY_RUNS", "MIA_HIP_SORT2_UNPACKED", "MIA_HIP_DEBUG_SKIP=4096",
             # round 5: the band DPs in two rounds, the first beside the plan's second and third launch (measured, no gain: off by default)
             "MIA_HIP_SPLIT_DP=1",
             # round 4, second half: every wavefront at priority 0 (default: the step's chain ahead of k_bxl_trace); smaller persistent grids

@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun_out/<round> (tools/collect_profiles.sh on the GPU box) -> profiles/<round>; ROUND=r04 by default
 cd "$(dirname "$0")/.."
-RND=${ROUND:-r04}; mkdir -p profiles/$RND/pmc
+RND=${ROUND:-r05}; mkdir -p profiles/$RND/pmc
 for c in 1 2 3 4; do
   cp gpurun_out/$RND/ks_cfg$c/p_kernel_stats.csv profiles/$RND/cfg${c}_kernel_stats.csv
   tail -1 gpurun_out/$RND/ks_cfg$c.json > profiles/$RND/cfg${c}_bench_under_rocprofv3.json

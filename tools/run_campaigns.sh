@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/${ROUND:-r04}_campaigns.log; : > $O
+O=gpurun_out/${ROUND:-r05}_campaigns.log; : > $O
 run() { echo "== $*" >> $O; timeout -k 10 900 python3 "$@" 2>&1 | tail -1 >> $O; echo "rc $?" >> $O; tail -2 $O; }
 run tools/band_campaign.py 60 301000 MIA_HIP_NO_DIAG_FILTER flat
 run tools/band_campaign.py 60 302000 MIA_HIP_NO_DIAG_FILTER flat nrich
