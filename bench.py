@@ -358,6 +358,8 @@ def step_traffic(pmc, pmc_stale, reads_per_gpu, bytes_per_read_):
     for kn, c in pmc.items():
         if kn.startswith("_") or "k_peak" in kn or not all(k in c for k in ("FETCH_SIZE", "WRITE_SIZE", "dispatches_FETCH_SIZE", "dispatches_WRITE_SIZE")):
             continue
+        if c["dispatches_FETCH_SIZE"] < kept:       # not a kernel of the step: set-up (k_bx_umax, k_read_planes) or the warm-up's first iteration
+            continue
         tot += (2.0 * c["FETCH_SIZE"] * c["dispatches_FETCH_SIZE"] + c["WRITE_SIZE"] * c["dispatches_WRITE_SIZE"]) / kept * 1024
     algo = float(reads_per_gpu) * bytes_per_read_
     return {"bytes_per_step": tot, "algorithmic_bytes_per_step": algo, "ratio": tot / algo if algo else None}
@@ -518,7 +520,7 @@ def section_converge(hip_mod, device, cfg, n, seed, peaks, no_cpu, max_iters=12,
            "first_iteration_again_ms": first_warm_ms, "first_iteration_over_steady": first_warm_ms / steady_ms,
            "first_iteration_read_fate": first_counts,
            "bytes_per_read": w["bytes_per_read"], "consensus_len": len(cur), "read_fate": counts,
-           "roofline": roofline(stages, peaks, tag, stale)}
+           "roofline": roofline(stages, peaks, tag, stale), "step_traffic": step_traffic(pmc, stale, n, w["bytes_per_read"])}
     if not no_cpu:
         out["cpu_baseline"] = cpu_baseline(w, sample_per_proc=3000 if cfg != 4 else 1500)
     hip.close()
@@ -717,6 +719,7 @@ def headline(out, extras_path):
                        "steady_ms": c["steady_state_ms_per_iteration"], "first_ms": c["first_iteration_again_ms"],
                        "first_over_steady": c["first_iteration_over_steady"], "steady_reads_per_s": c["steady_state_reads_per_s"],
                        "roofline_kernel": c["roofline"]["kernel"], "roofline_frac": c["roofline"]["frac"],
+                       "traffic_over_algorithmic": (c.get("step_traffic") or {}).get("ratio"),
                        "cpu_reads_per_s": (c.get("cpu_baseline") or {}).get("value")}
     lb = out.get("configs3_loopback_w8")
     if lb and "error" not in lb:
