@@ -310,7 +310,9 @@ int mia_hip_get_ins_tally(mia_hip_ctx *ctx, int32_t *ins_off, int32_t *ins_tally
  * for a batch of pairs: unit-cost edit distance with IUPAC-compatible matching, modes 0/1/2 as
  * the enum (global / only seq_b must be consumed / only seq_a must be consumed, src/myers_align.c:39-40).
  * dist[i] = distance, or 0xFFFFFFFF when it is >= maxd[i] (maxd clamped to len_a+len_b, :13).
- * The backtrace strings of the reference are not produced.  seq_a up to 32768 characters. */
+ * The backtrace strings of the reference are not produced (mia_hip_myers_align does that for one pair).  seq_a up to 32768
+ * characters.  Pairs of up to 320 characters go one to a lane, longer ones one to a workgroup (D-paths while the distance
+ * stays under the kernel's cap, the bit-vector sweep beyond it). */
 int mia_hip_myers(mia_hip_ctx *ctx, int64_t n_pairs, const char *const *seq_a, const char *const *seq_b, const int32_t *mode,
                   const int32_t *maxd, uint32_t *dist);
 
@@ -328,9 +330,11 @@ int mia_hip_myers_packed(mia_hip_ctx *ctx, int64_t n_pairs, const uint32_t *code
  * bench.py prices the kernel apart from the packing of the strings and the copies) */
 int mia_hip_myers_time(mia_hip_ctx *ctx, double *kernel_ms);
 
-/* One myers_diff call with its backtrace (what ccheck asks for, src/ccheck.cc:478-480): the distance comes from the
- * bit-vector kernel above; the two rows of the alignment (bt_a over seq_a, bt_b over seq_b, '-' for a gap) are
- * rebuilt on the host from the furthest-reaching D-paths with the reference's preferences (src/myers_align.c:47-83).
+/* One myers_diff call with its backtrace (what ccheck asks for, src/ccheck.cc:478-480).  A long pair at a small distance
+ * (ccheck's: 16.6 kb each, maxd = len / 10) runs the reference's own recurrence on the device -- furthest-reaching D-paths,
+ * one row of diagonals per step (k_myers_ond) -- and the table of those rows comes back for the walk; any other pair gets
+ * its distance from the bit-vector kernels above and its D-paths on the host.  Either way the two rows of the alignment
+ * (bt_a over seq_a, bt_b over seq_b, '-' for a gap) follow the reference's preferences (src/myers_align.c:47-83).
  * Buffers of len + dist + 2 bytes each, as the reference wants them (len_a + maxd + 2 is enough).  BOTH rows are
  * NUL-terminated (the reference leaves bt_b without its terminator, src/myers_align.c:44-45).  dist = 0xFFFFFFFF and
  * untouched buffers when the distance is >= maxd.  bt_a / bt_b may be NULL. */
