@@ -220,6 +220,21 @@ __global__ __launch_bounds__(256) void k_read_planes(ReadSet rs, int32_t words, 
 // reads with anchors on two diagonals by the block's first threads); 1 = the first of three launches (those reads go on
 // bx.cand, the reads the 10-mers cannot vouch for on bx.cand2); 2 = bx.cand with every lane at work; 3 = bx.cand2, the
 // fine blocks (bx_fine_anchors), the diagonals of one read dealt to BX_FINE_LANES neighbouring lanes.
+#ifdef MIA_HIP_ALT_PATHS
+// (MIA_HIP_BX_DEBUG & 512, alt build: shader-clock cycles of a wavefront's stretches of k_bx_plan's first launch, summed over the wavefronts
+// -- 0 set-up, 1 fetch + window, 2 planes, 3 anchors, 4 finish, 5 emit, 6 hand-over; slot 11 counts the wavefronts; tools/plan_clk_probe.py)
+// (the stamps stay in registers; a block adds its four wavefronts' sums to one of 64 stripes at its end: an atomic per stamp and
+// wavefront on seven words made the launch six times as long)
+__device__ unsigned long long g_plan_clk[64 * 16];
+#define PLAN_CLK(k) do { if (bx.dbg & 512u) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pacc_[k] += now_ - pclk_; pclk_ = now_; } } while (0)
+#define PLAN_CLK_DECL unsigned long long pclk_ = (bx.dbg & 512u) ? __builtin_amdgcn_s_memtime() : 0ull, pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; __shared__ unsigned long long pclk_lds_[8]; if (threadIdx.x < 8) pclk_lds_[threadIdx.x] = 0
+#define PLAN_CLK_FLUSH do { if (bx.dbg & 512u) { if ((threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 7; q_++) atomicAdd(&pclk_lds_[q_], pacc_[q_]); __syncthreads(); \
+    if (threadIdx.x < 7) atomicAdd(&g_plan_clk[(blockIdx.x & 63) * 16 + threadIdx.x], pclk_lds_[threadIdx.x]); if (threadIdx.x == 7) atomicAdd(&g_plan_clk[(blockIdx.x & 63) * 16 + 11], 4ull); } } while (0)
+#else
+#define PLAN_CLK(k) do { } while (0)
+#define PLAN_CLK_DECL do { } while (0)
+#define PLAN_CLK_FLUSH do { } while (0)
+#endif
 template <int NW, int PH>
 __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPlanes rp, KmerHash ko, int64_t n_ref, BxDev bx, const int32_t* in_list,
                                                   const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of) {
@@ -229,6 +244,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
   __shared__ uint8_t cand_tid[PH < 2 ? 256 : 1];
   __shared__ int32_t n_cand;
   __shared__ uint32_t blk_cnt[SLOT_FINE + 1], blk_base[2 * BX_NCLS + 1];   // per block: list appends, finished, seen, reasons, hand-overs
+  PLAN_CLK_DECL;
   for (int k = threadIdx.x; k < BX_LOSS_WORDS; k += 256) loss_lds[k] = bx.tab.loss[k];
   if (threadIdx.x == 0) n_cand = 0;
   if (threadIdx.x <= SLOT_FINE) blk_cnt[threadIdx.x] = 0;
@@ -304,12 +320,43 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     __syncthreads();
   };
   if (PH < 2) {
+    PLAN_CLK(0);
     DiagScan<NW> sc;
     Rd r = fetch((int)threadIdx.x, sc);
     BxPlan bp;
     bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
     BxAnchors an{};
     bool waits = false, to_fine = false;
+#ifdef MIA_HIP_ALT_PATHS
+    if (PH == 1 && (bx.dbg & 512u)) {
+      // the same stretches one after the other over the whole wavefront (a clock between them): what the kernel does, in four steps
+      const bool pl = r.ok && bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2);
+      PLAN_CLK(1);
+      const bool lp = pl && load_planes(r, sc);
+      PLAN_CLK(2);
+      if (lp) bx_anchors<NW>(sc, ko, reinterpret_cast<const uint32_t*>(rs.packed + rs.roff[r.i]), r.s, r.l1, r.len2, r.st, T, &an);
+      PLAN_CLK(3);
+      if (r.ok) {
+        bp.b0 = !pl ? BXF_WINDOW : (!lp ? BXF_READ : an.fail);
+        if (lp && !an.fail) {
+          bool later = an.d_first != an.d_last;
+          if (!later) {
+            bx_finish<NW, 1>(sc, rp, an, r.s, r.l1, r.len2, r.st, T, &bp);
+            if (bp.mode == BX_NONE && (bp.b0 == BXF_BUDGET || bp.b0 == BXF_WIDTH) && an.a_lo == an.a_hi) { later = true; an.rescue = bp.b0; }
+            else if (fine_on && bx_wants_fine(bp) && a_hi_ok(an, T)) { an.rescue = bp.b0; to_fine = true; waits = true; bp.mode = BX_NONE; bp.b0 = 0; }
+          }
+          if (later) {
+            const int slot = atomicAdd(&n_cand, 1);
+            cand_an[slot] = an;
+            cand_tid[slot] = (uint8_t)threadIdx.x;
+            waits = true;
+            bp.mode = BX_NONE; bp.b0 = 0;
+          }
+        }
+      }
+      PLAN_CLK(4);
+    } else
+#endif
     if (r.ok) {
       bp.b0 = BXF_WINDOW;
       if (bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2)) {
@@ -342,6 +389,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     Rd rr = r;
     if (waits) rr.ok = false;
     emit(rr, bp, !in_list && t0 + threadIdx.x < total && !waits, to_fine, an);
+    PLAN_CLK(5);
     if (bx.early && !in_list && t0 + threadIdx.x < total) bx.early[t0 + threadIdx.x] = bp.mode == BX_DONE ? 1 : 0;      // (every read passes here once)
     if (PH == 1) {                                  // hand the waiting reads over: one reservation per block
       __shared__ uint32_t cand_base;
@@ -354,6 +402,8 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
         rec.an = cand_an[threadIdx.x];
         bx.cand[cand_base + threadIdx.x] = rec;
       }
+      PLAN_CLK(6);
+      PLAN_CLK_FLUSH;
       return;
     }
   }

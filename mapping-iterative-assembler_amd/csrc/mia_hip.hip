@@ -818,6 +818,16 @@ extern "C" int mia_hip_debug_tally_kinds(mia_hip_ctx* ctx, uint64_t* out8) {
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_tally_clk), z, sizeof z));
   return MIA_HIP_OK;
 }
+// (alt build only: the clocks MIA_HIP_BX_DEBUG & 512 collects in k_bx_plan's first launch, and their reset)
+extern "C" int mia_hip_debug_plan_clk(mia_hip_ctx* ctx, uint64_t* out12) {
+  if (!ctx || !out12) return MIA_HIP_ERR_ARG;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  static uint64_t all[64 * 16], z[64 * 16];
+  HIPCHK(hipMemcpyFromSymbol(all, HIP_SYMBOL(g_plan_clk), sizeof all));
+  for (int k = 0; k < 12; k++) { out12[k] = 0; for (int st = 0; st < 64; st++) out12[k] += all[st * 16 + k]; }
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_plan_clk), z, sizeof z));
+  return MIA_HIP_OK;
+}
 #endif
 extern "C" int mia_hip_bx_counters(mia_hip_ctx* ctx, uint32_t* out32) {
   if (!ctx || !out32) return MIA_HIP_ERR_ARG;
@@ -1136,7 +1146,7 @@ static int align_all(mia_hip_ctx* ctx) {
       BxDev bd;
       bd.tab.sub = ctx->d_bx_sub; bd.tab.mrow = ctx->d_bx_mrow; bd.tab.loss = ctx->d_bx_loss; bd.tab.dl = ctx->d_bx_dl;
       bd.lazy_scripts = ctx->lazy_scripts;
-      bd.dbg = ctx->bx_dbg & (3u | 32u | 64u | 128u);
+      bd.dbg = ctx->bx_dbg & (3u | 32u | 64u | 128u | 512u);
       // MIA_HIP_BX_SERIAL=1: round 2's order (band kernels, then the planner over everything they left open)
       // (caller-supplied windows -- mia_hip_align_windows -- can be of any length: the retry list's window kernel is picked by read length)
       const bool new_flow = ctx->use_lanes && !ctx->bx_serial && !(ctx->dbg & 256u) && !ctx->explicit_win;
