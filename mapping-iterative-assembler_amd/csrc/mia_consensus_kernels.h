@@ -182,6 +182,23 @@ constexpr int TRF_RC = 1, TRF_DF = 2, TRF_DB = 4, TRF_DIAG = 8, TRF_TOO_LONG = 1
 // NO_N: the read holds no N (k_bx_umax's mark, umax[i] >= 0: its bit planes say everything) -- in the record so that the tally does
 // not fetch a 128-byte line per read for that one bit (the gather of record, planes and mark is 60 % of k_tally_binned's time)
 constexpr int TRF_NO_N = 128;
+// the 64-byte record of read i and its dropped bits, as the tally reads them: written by k_rec_params -- and, for an iteration without
+// links, by k_cull_records already (rec_write is the one place that says what the words are)
+__device__ __forceinline__ void rec_write(const ReadSet& rs, int64_t i, int32_t* trec, uint8_t* drop_front, uint8_t* drop_back, uint8_t df, uint8_t db, const int32_t* p,
+                                          uint32_t st, int32_t actf, const int32_t* umax) {
+  drop_front[i] = df;
+  drop_back[i] = db;
+  // the 64-byte record in four 16-byte stores (sixteen 4-byte ones, 64 bytes apart across the lanes, took twice as long)
+  int4* t4 = reinterpret_cast<int4*>(trec + i * 16);
+  const int fl = (rs.rc[i] ? TRF_RC : 0) | (df ? TRF_DF : 0) | (db ? TRF_DB : 0) | ((st & ST_DIAG) ? TRF_DIAG : 0) |
+                 ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0) | ((st & ST_ONEGAP) ? TRF_ONEGAP : 0) |
+                 ((umax && umax[i] >= 0) ? TRF_NO_N : 0);
+  t4[0] = make_int4(rs.as[i], rs.ae[i], (int32_t)((uint32_t)rs.len[i] | ((uint32_t)(uint16_t)rs.abr[i] << 16)), fl);   // TREC_AS, _AE, _LEN_ABR, _FLAGS
+  t4[1] = make_int4(rs.refstart[i], (int32_t)rs.roff[i], actf, (int32_t)(st >> 8));                                      // TREC_REFSTART, _ROFF, _ACTF, _SPARE
+  t4[2] = make_int4(p[0], p[1], p[2], p[3]);                                                                              // TREC_PARAMS ..
+  t4[3] = make_int4(p[4], p[5], p[6], p[7]);
+}
+
 struct SlotInfo {             // per local AlnSeq slot (global slot - slot_base)
   int64_t base;               // first global slot of this context
   const int64_t* n_local_p;   // slots owned by this context in this iteration (device: the scan's total)
@@ -371,7 +388,8 @@ __global__ __launch_bounds__(256) void k_slot_count(ReadSet rs, int32_t L, int64
 __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, const int64_t* partial, int64_t* slot, RecInfo ri, SlotInfo si, int64_t read_base,
                                                         uint32_t* flags, uint8_t* slot_dropped, int64_t n_slots, int32_t hard_cut, double slope, double intercept,
                                                         int64_t* back_slot, const int64_t* front_slot0, Links lk, const double* dev_cut, const int32_t* abort_if = nullptr,
-                                                        int32_t raw_nb = 0, int64_t slot_base = 0, int64_t* total_out = nullptr) {
+                                                        int32_t raw_nb = 0, int64_t slot_base = 0, int64_t* total_out = nullptr,
+                                                        int32_t with_records = 0, uint8_t* drop_front = nullptr, uint8_t* drop_back = nullptr, const int32_t* umax = nullptr) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   __shared__ int32_t wsum[4];
   __shared__ int64_t s_red[2][4], s_first, s_total;
@@ -410,7 +428,8 @@ __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, con
   for (int k = 0; k < wv; k++) my_slot += wsum[k];
   if (in) slot[me] = my_slot;
   // ---- record geometry (k_rec_geom)
-  int my_flen = 0, my_actf = 0;
+  int my_flen = 0, my_actf = 0, my_blen = 0;
+  uint32_t my_st = in ? rs.status[me] : 0u;          // (the walk below may rewrite a read's status: its own lane keeps the new one)
   bool walk = false;
   if (in) {
     if (!sk) { ri.flen[me] = 0; ri.blen[me] = 0; ri.actf[me] = 0; }
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, con
       const int len2 = rs.len[me], abr = rs.abr[me];
       const int af = (len2 - abr) < g_me.ncols_f ? (len2 - abr) : g_me.ncols_f;
       rec_store_at(me, g_me, 0, 0, af, len2 - abr, my_slot, ri, si, read_base, flags);
-      my_flen = g_me.ncols_f; my_actf = af;
+      my_flen = g_me.ncols_f; my_actf = af; my_blen = g_me.split ? g_me.ncols_b : 0;
     } else if ((rs.status[me] & ST_ONEGAP) && !g_me.split) {
       const uint32_t desc = rs.status[me] >> 8;
       const int len2 = rs.len[me], abr = rs.abr[me], gn = (int)((desc >> 10) & 63u), ins = (int)(desc & 1u);
@@ -469,17 +488,15 @@ __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, con
       n_ev += __popcll(m_ins) + __popcll(m_del);
     }
     const int64_t slot_i = __shfl(my_slot, li);
-    if (lane == 0) {
-      const uint32_t st = rs.status[i];
-      if (!(st & (ST_ESCAPE | ST_TOO_LONG | ST_SKIPPED | ST_BAND | ST_DIAG))) {
-        const int gn = ev_kind ? ins_rows : ev_len, n_al = len2 - abr;
-        const bool one = n_ev == 1 && !g.split && gn > 0 && gn < 64 && ev_row < 512 && g.ncols_f == (ev_kind ? n_al - gn : n_al + gn);
-        const uint32_t want = one ? (ST_ONEGAP | (((uint32_t)ev_kind | ((uint32_t)ev_row << 1) | ((uint32_t)gn << 10)) << 8)) : ST_OK;
-        if (st != want) rs.status[i] = want;
-      }
-      rec_store_at(i, g, nf, nb, af, len2 - abr, slot_i, ri, si, read_base, flags);
+    uint32_t st_new = rs.status[i];                        // (wave-uniform, like everything the walk counted)
+    if (!(st_new & (ST_ESCAPE | ST_TOO_LONG | ST_SKIPPED | ST_BAND | ST_DIAG))) {
+      const int gn = ev_kind ? ins_rows : ev_len, n_al = len2 - abr;
+      const bool one = n_ev == 1 && !g.split && gn > 0 && gn < 64 && ev_row < 512 && g.ncols_f == (ev_kind ? n_al - gn : n_al + gn);
+      const uint32_t want = one ? (ST_ONEGAP | (((uint32_t)ev_kind | ((uint32_t)ev_row << 1) | ((uint32_t)gn << 10)) << 8)) : ST_OK;
+      if (st_new != want) { if (lane == 0) rs.status[i] = want; st_new = want; }
     }
-    if (lane == li) { my_flen = g.ncols_f + nf; my_actf = af + nf; }        // (the counts are wave-uniform: the read's own lane keeps them for its link)
+    if (lane == 0) rec_store_at(i, g, nf, nb, af, len2 - abr, slot_i, ri, si, read_base, flags);
+    if (lane == li) { my_flen = g.ncols_f + nf; my_actf = af + nf; my_blen = g.split ? g.ncols_b + nb : 0; my_st = st_new; }        // (the counts are wave-uniform: the read's own lane keeps them for its link and its record)
   }
   // ---- own dropped marks, the persistent back slot, the links of formerly split reads (k_cull_mark)
   if (!in) return;
@@ -495,16 +512,30 @@ __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, con
       r[3] = (low ? 1 : 0) | (kind << 8);
     } else atomicOr(flags, 8u);
   };
+  int32_t p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (!sk) {
     if (front_slot0[me] >= 0) add_link(front_slot0[me], 1, 0, 0);
     if (back_slot[me] >= 0) add_link(back_slot[me], 2, 0, 0);
+    if (with_records) rec_write(rs, me, ri.trec, drop_front, drop_back, 0, 0, p, my_st, 0, umax);
     return;
   }
+  // WITH_RECORDS (round 5): the read's tally record and dropped bits as k_rec_params would write them if no link existed -- its own slot(s),
+  // its own depth-code parameters, listed once.  k_rec_params then returns at once unless the iteration has a link (a formerly split read, a
+  // strand-unknown read with pass-1 slots): it read every per-read array again to write 64 bytes per read that are known here.
+  uint8_t df = 0, db = 0;
+  if (with_records && my_slot < n_slots) df = low ? (uint8_t)1 : slot_dropped[my_slot];
+  if (with_records && g_me.split && my_slot + 1 < n_slots) db = low ? (uint8_t)1 : slot_dropped[my_slot + 1];
   if (low && my_slot < n_slots) slot_dropped[my_slot] = 1;
   if (g_me.split) {
     if (low && my_slot + 1 < n_slots) slot_dropped[my_slot + 1] = 1;
     back_slot[me] = my_slot + 1;
   } else if (back_slot[me] >= 0) add_link(back_slot[me], 0, my_flen, my_actf);
+  if (with_records) {
+    const int64_t ls = my_slot - si.base, n_local = *si.n_local_p;
+    if (ls >= 0 && ls < n_local) { p[2] = my_flen + my_blen; p[3] = 1; }
+    if (g_me.split && ls + 1 < n_local) { p[4] = my_flen; p[5] = my_actf; p[6] = my_flen + my_blen; p[7] = 1; }
+    rec_write(rs, me, ri.trec, drop_front, drop_back, df, db, p, my_st, my_actf, umax);
+  }
 }
 
 // own dropped marks, the persistent back slot, and the links of formerly split reads
@@ -588,12 +619,17 @@ __global__ __launch_bounds__(256) void k_rec_early(ReadSet rs, int32_t L, const 
   t4[3] = make_int4(p[4], p[5], p[6], p[7]);
 }
 
+// skip_if_no_links: k_cull_records has written every record already (its with_records argument) -- they stand unless a link exists:
+// a link changes the dropped bit, the multiplicity or the depth-code parameters of the slot it points at, and the record of the
+// read it comes from (its back length)
 __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const uint8_t* slot_dropped, int64_t n_slots, const int64_t* back_slot,
                              RecInfo ri, SlotInfo si, const int64_t* links, const int32_t* link_len, const int32_t* link_act, const int32_t* n_links_p,
                              int32_t cap, int64_t read_base,
                              uint8_t* drop_front, uint8_t* drop_back, uint32_t* flags, const int32_t* abort_if = nullptr,
-                             const uint8_t* early = nullptr, int32_t* fix_list = nullptr, int32_t* n_fix = nullptr, const int32_t* umax = nullptr) {
+                             const uint8_t* early = nullptr, int32_t* fix_list = nullptr, int32_t* n_fix = nullptr, const int32_t* umax = nullptr,
+                             int32_t skip_if_no_links = 0) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
+  if (skip_if_no_links && *n_links_p == 0) return;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rs.n) return;
   const int n_links = min(*n_links_p, cap);
@@ -639,18 +675,8 @@ __global__ void k_rec_params(ReadSet rs, int32_t L, const int64_t* slot, const u
     if (ls >= 0 && ls < (*si.n_local_p)) fill(p, ls, 0, 0, flen + back_len, flen);
     if (split && ls + 1 < (*si.n_local_p)) fill(p + 4, ls + 1, flen, actf, flen + blen, blen);
   }
-  drop_front[i] = df;
-  drop_back[i] = db;
   const uint32_t st = rs.status[i];
-  // the 64-byte record in four 16-byte stores (sixteen 4-byte ones, 64 bytes apart across the lanes, took twice as long)
-  int4* t4 = reinterpret_cast<int4*>(ri.trec + i * 16);
-  const int fl = (rs.rc[i] ? TRF_RC : 0) | (df ? TRF_DF : 0) | (db ? TRF_DB : 0) | ((st & ST_DIAG) ? TRF_DIAG : 0) |
-                 ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0) | ((st & ST_ONEGAP) ? TRF_ONEGAP : 0) |
-                 ((umax && umax[i] >= 0) ? TRF_NO_N : 0);
-  t4[0] = make_int4(rs.as[i], rs.ae[i], (int32_t)((uint32_t)rs.len[i] | ((uint32_t)(uint16_t)rs.abr[i] << 16)), fl);   // TREC_AS, _AE, _LEN_ABR, _FLAGS
-  t4[1] = make_int4(rs.refstart[i], (int32_t)rs.roff[i], ri.actf[i], (int32_t)(st >> 8));                                // TREC_REFSTART, _ROFF, _ACTF, _SPARE
-  t4[2] = make_int4(p[0], p[1], p[2], p[3]);                                                                              // TREC_PARAMS ..
-  t4[3] = make_int4(p[4], p[5], p[6], p[7]);
+  rec_write(rs, i, ri.trec, drop_front, drop_back, df, db, p, st, ri.actf[i], umax);
   if (early && early[i]) {
     // tallied already, on the ordinary record (k_rec_early): does the true one say the same?
     int32_t q[8];

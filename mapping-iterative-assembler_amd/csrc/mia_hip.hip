@@ -89,6 +89,7 @@ struct mia_hip_ctx {
   hipStream_t stream4 = nullptr; hipEvent_t ev_early = nullptr;
   // the band DPs in two rounds (align_all: split_dp): the first beside the plan's second and third launch, on the lists its first launch made
   hipEvent_t ev_snap = nullptr, ev_v1 = nullptr; uint32_t* d_bx_snap = nullptr; int split_dp_mode = 0;      // mode: 0 auto, 1 always (MIA_HIP_SPLIT_DP=1), -1 never (MIA_HIP_SPLIT_DP=0)
+  bool cull_with_records = true;      // k_cull_records writes the tally records of an iteration without links itself (MIA_HIP_NO_CULL_RECORDS=1: k_rec_params always)
   int64_t split_dp_steps = 0;
   // MIA_HIP_EARLY_TALLY=1 (alt build only; an experiment that measured SLOWER): the plan's reads tallied beside the band DPs
   bool use_early = false, early_queued = false;
@@ -392,6 +393,7 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* nr = alt_env("MIA_HIP_NO_TALLY_RUNS")) ctx->tally_runs = atoi(nr) == 0;
     if (const char* sd = alt_env("MIA_HIP_SPLIT_DP")) ctx->split_dp_mode = atoi(sd) != 0 ? 1 : -1;
     if (const char* ra = alt_env("MIA_HIP_NO_TALLY_RALL")) ctx->tally_rall = atoi(ra) == 0;
+    if (const char* cr = alt_env("MIA_HIP_NO_CULL_RECORDS")) ctx->cull_with_records = atoi(cr) == 0;
     if (const char* tc = alt_env("MIA_HIP_TALLY_CHUNK")) { const int c = atoi(tc); if (c == 256 || c == 512 || c == 768) ctx->tally_chunk_linear = c; }
     if (const char* ew = alt_env("MIA_HIP_EARLY_WGS")) ctx->early_wgs_per_cu = atoi(ew);
     if (const char* nf = alt_env("MIA_HIP_NO_FINE")) ctx->use_fine = atoi(nf) == 0 ? 1 : 0;
@@ -1700,7 +1702,8 @@ static int finish_params(mia_hip_ctx* ctx) {
                      ctx->n_slots, ctx->d_back_slot, ctx->ri, ctx->si, ctx->d_links_all, ctx->d_link_len, ctx->d_link_act, ctx->d_n_links_all,
                      (int32_t)ctx->links_cap_all, ctx->read_base, ctx->d_drop_f, ctx->d_drop_b, ctx->d_cull_flags, ctx->abort_if,
                      ctx->early_queued ? ctx->d_early : (const uint8_t*)nullptr, ctx->d_fix_list, ctx->d_ctrl + CTRL_FIXN,
-                     (ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax) ? ctx->d_umax : (const int32_t*)nullptr);
+                     (ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax) ? ctx->d_umax : (const int32_t*)nullptr,
+                     (ctx->cull_with_records && ctx->d_n_links_all == ctx->lk.n && !ctx->early_queued) ? 1 : 0);
   HIPCHK(hipGetLastError());
   return MIA_HIP_OK;
 }
@@ -1752,7 +1755,9 @@ extern "C" int mia_hip_cull(mia_hip_ctx* ctx, int32_t hard_cut, double slope, do
   if (!ctx->in_iterate) HIPCHK(hipMemsetAsync(ctx->lk.n, 0, 8, ctx->stream));                     // link count, cull flags (neighbours in the control block)
   hipLaunchKernelGGL(k_cull_records, dim3((unsigned)nb), dim3(256), 0, ctx->stream, ctx->rs, ctx->L, (const int64_t*)ctx->d_partial, ctx->d_slot, ctx->ri, ctx->si,
                      ctx->read_base, ctx->d_cull_flags, ctx->d_slot_dropped, ctx->n_slots, hard_cut, slope, intercept, ctx->d_back_slot,
-                     (const int64_t*)ctx->d_front_slot0, ctx->lk, ctx->dev_cut, ctx->abort_if, ctx->cull_scan ? 0 : nb, slot_base, ctx->d_total);
+                     (const int64_t*)ctx->d_front_slot0, ctx->lk, ctx->dev_cut, ctx->abort_if, ctx->cull_scan ? 0 : nb, slot_base, ctx->d_total,
+                     ctx->cull_with_records ? 1 : 0, ctx->d_drop_f, ctx->d_drop_b,
+                     (ctx->umax_valid && ctx->rs.roff == ctx->d_roff && ctx->d_rplanes && ctx->d_umax) ? ctx->d_umax : (const int32_t*)nullptr);
   HIPCHK(hipGetLastError());
   // by default the links to apply are this context's own; a sharded run replaces them with the gathered list (mia_hip_set_links)
   ctx->d_links_all = ctx->lk.rec;

@@ -32,6 +32,8 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             "MIA_HIP_STRAND_SPLIT=0", "MIA_HIP_NO_TALLY_RUNS", "MIA_HIP_SORT2_UNPACKED", "MIA_HIP_DEBUG_SKIP=4096",
             # round 5: the band DPs in two rounds, the first beside the plan's second and third launch (measured, no gain: off by default)
             "MIA_HIP_SPLIT_DP=1",
+            # round 5: the tally records written by k_rec_params in every iteration (default: by k_cull_records, k_rec_params only where a link exists)
+            "MIA_HIP_NO_CULL_RECORDS",
             # round 4, second half: every wavefront at priority 0 (default: the step's chain ahead of k_bxl_trace); smaller persistent grids
             "MIA_HIP_BX_DEBUG=128", "MIA_HIP_BX_VALUES_PCT=50", "MIA_HIP_BX_TRACE_PCT=44"]
 
