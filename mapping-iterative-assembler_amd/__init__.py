@@ -192,21 +192,26 @@ class LoopbackGroup:
     """mia_hip_loopback_*: n_ranks contexts of this process, one host thread each, exchange through host barriers and
     device copies -- the sharded path on a single GPU (RCCL refuses two ranks on one device)"""
 
-    def __init__(self, n_ranks):
+    def __init__(self, n_ranks, like=None):
+        # ADVICE r04: the release and the alt build are two libraries with two sets of static state (the loopback registry among them):
+        # the group lives in the library of the contexts it serves (`like`: one of them; default: the release build's)
+        self._l = like._l if like is not None else lib()
         self._g = C.c_void_p()
-        if lib().mia_hip_loopback_create(n_ranks, C.byref(self._g)) != 0:
+        if self._l.mia_hip_loopback_create(n_ranks, C.byref(self._g)) != 0:
             raise MiaHipError("mia_hip_loopback_create failed")
         self.n_ranks = n_ranks
 
     def attach(self, hip, rank):
+        if hip._l is not self._l:
+            raise MiaHipError("LoopbackGroup: this context comes from another build of the library than the group (pass like=<a context> when the group is made)")
         t = Collectives()
-        if lib().mia_hip_loopback_table(self._g, rank, C.byref(t)) != 0:
+        if self._l.mia_hip_loopback_table(self._g, rank, C.byref(t)) != 0:
             raise MiaHipError("mia_hip_loopback_table failed")
         hip.comm_attach(t)
 
     def close(self):
         if self._g:
-            lib().mia_hip_loopback_destroy(self._g)
+            self._l.mia_hip_loopback_destroy(self._g)
             self._g = C.c_void_p()
 
 

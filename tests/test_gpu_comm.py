@@ -338,7 +338,7 @@ def test_one_ranks_event_overflow_fails_every_rank_the_same_iteration(oracle):
             parts.append(context(mia_amd, fs, anc, dropped1, lo, hi))
         finally:
             os.environ.pop("MIA_HIP_FAKE_EVENT_OVERFLOW")
-    grp = mia_amd.LoopbackGroup(2)
+    grp = mia_amd.LoopbackGroup(2, like=parts[0])               # (the group in the contexts' own library: the alt build here)
     for k, h in enumerate(parts):
         grp.attach(h, k)
     out, err = run_ranks([lambda h=h: h.iterate(ref0, True) for h in parts])
