@@ -1235,8 +1235,7 @@ static int align_all(mia_hip_ctx* ctx) {
       // two launches, and a second round behind the last launch takes what they appended.  MEASURED, NO GAIN: first iteration of 10 M
       // solexa reads 17.13 ms with it, 16.90 without; 1 M flat reads 1.90 / 1.83 -- the plan's launches and the DPs are all bound by
       // vector issue, and what runs side by side only shares the chip.  Kept behind the switch (tests/test_gpu_switches.py runs it).
-      const bool split_dp = new_flow && ctx->deferred && split && last_phase >= 2 && !early && !(ctx->bx_dbg & (4u | 8u)) && ctx->split_dp_mode >= 0 &&
-                            ctx->split_dp_mode > 0;
+      const bool split_dp = new_flow && ctx->deferred && split && last_phase >= 2 && !early && !(ctx->bx_dbg & (4u | 8u)) && ctx->split_dp_mode > 0;
       bd.snap = nullptr;
       if (split_dp) {
         if (!ctx->d_bx_snap && dev_alloc(ctx, &ctx->d_bx_snap, (size_t)(2 * BX_NCLS))) return MIA_HIP_ERR_NOMEM;
@@ -2087,7 +2086,9 @@ static int bucket_launch(mia_hip_ctx* ctx, hipStream_t on) {
     // ... and every bucket by alignment start (k_sort2_count / k_sort2_fill: the tally's runs of equal starts)
     const int64_t words2 = (int64_t)nb * SORT2_KEYS * 2;
     if (words2 > ctx->sort2_cap) { if (dev_alloc(ctx, &ctx->d_sort2, (size_t)words2)) return MIA_HIP_ERR_NOMEM; ctx->sort2_cap = words2; }
-    if (!ctx->d_order2 && (dev_alloc(ctx, &ctx->d_order2, (size_t)n) || dev_alloc(ctx, &ctx->d_okey, (size_t)n + 64))) return MIA_HIP_ERR_NOMEM;
+    // (each on its own: a failure of the second must not leave the first behind as "both are there" -- ADVICE r05)
+    if (!ctx->d_order2 && dev_alloc(ctx, &ctx->d_order2, (size_t)n)) return MIA_HIP_ERR_NOMEM;
+    if (!ctx->d_okey && dev_alloc(ctx, &ctx->d_okey, (size_t)n + 64)) return MIA_HIP_ERR_NOMEM;
     HIPCHK(hipMemsetAsync(ctx->d_sort2, 0, (size_t)words2 * 4, on));
     const int32_t packed = (n < (1 << 24) && !alt_env("MIA_HIP_SORT2_UNPACKED")) ? 1 : 0;      // (the key in the entry's top byte, or -- 2^24 reads and more -- in a byte array beside it)
     hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), (size_t)nb * 8, on, ctx->rs, nb, (const int32_t*)d_off, d_cur, ctx->d_order, ctx->abort_if, part, 0, split, ctx->d_okey, packed);

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(MYERS_OND_THREADS) void k_myers_ond(const MyersPair
     const int la = pr.la, lb = pr.lb, mode = pr.mode;
     int maxd = pr.maxd;
     if (maxd > la + lb) maxd = la + lb;                              // src/myers_align.c:13
-    if (pr.cap <= 0 && maxd > 0) { if (tid == 0) out[p] = MYERS_BEYOND_CAP; continue; }
+    // a pair without a cap was not packed for this kernel (a_off = b_off = 0, no LDS counted for it): never touch its codes.
+    // maxd <= 0 admits no distance at all (d < maxd, src/myers_align.c:20): the answer is "none" here and now
+    if (pr.cap <= 0) { if (tid == 0) out[p] = maxd > 0 ? MYERS_BEYOND_CAP : 0xFFFFFFFFu; continue; }
     const int cap = pr.cap < maxd ? pr.cap : maxd;
     const int wa = (la + 7) / 8 + OND_PAD_WORDS, wb = (lb + 7) / 8 + OND_PAD_WORDS;
     uint32_t* A = reinterpret_cast<uint32_t*>(lds_raw);

@@ -7,9 +7,9 @@
 // around the hot path: option parsing, FASTA/FASTQ parsing (src/io.c:35-386), the
 // read store, and formatting the .maln (src/map_alignment.c:283-382).
 //
-// Options of the reference that are outside the accelerated path (SURVEY.md section 2,
-// "OUT OF SCOPE": -T -a -u -U -A -C -h -D -I -q) are rejected with a message
-// instead of being silently ignored.
+// Adapter trimming (-T, -a) runs on the GPU (mia_hip_trim).  Options of the reference that are
+// outside the accelerated path ("OUT OF SCOPE": -u -U -A -C -h -D -I -q)
+// are rejected with a message instead of being silently ignored.
 #include <ctype.h>
 #include <fcntl.h>
 #include <getopt.h>
