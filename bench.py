@@ -171,6 +171,23 @@ def cpu_baseline(w, sample_per_proc=3000, iters=2):
                       f"pop_smp+cull+consensus, matrix {w['matrix_file'] or 'flat'}), slowest process {max(secs):.2f} s"}
 
 
+def certificate(hip, cons, fixed_point=None):
+    """What the timed steps computed, in 64 bytes each: sha256 of the consensus string the last step returned
+    and of every read's (score, as, ae) after it -- int32, little endian, the three arrays one after the other.
+    tests/test_gpu_bench_workloads.py builds THIS workload with THIS seed, checks samples and subset tallies of it against the
+    oracle and pins the same digests (tests/golden/bench_certificates.json): the number and the parity evidence are about the
+    same bytes."""
+    import hashlib
+    sc, a, e = hip.alignments()
+    h = hashlib.sha256()
+    for x in (sc, a, e):
+        h.update(np.ascontiguousarray(x, dtype="<i4").tobytes())
+    c = {"consensus_sha256": hashlib.sha256(cons.encode()).hexdigest(), "alignments_sha256": h.hexdigest(), "consensus_len": len(cons)}
+    if fixed_point is not None:
+        c["consensus_is_fixed_point"] = bool(fixed_point)
+    return c
+
+
 # ---- one iteration ------------------------------------------------------------------------------------------------
 class Pipeline:
     def __init__(self, hip, w, world=1, rank=0, force_dist=False, breakdown=False, c_comm=False):
@@ -498,7 +515,10 @@ def section_converge(hip_mod, device, cfg, n, seed, peaks, no_cpu, max_iters=12,
     dom_ms, dom_launches = hip.stage_stats()[dominant]
     hip.set_timed_stages(None)
     pipe.reset_stats()
+    before = cur
     cur = run_steps(pipe, cur, K)                   # the stage table: every stage timed
+    # the converged state's digest (taken here: the iteration against the starting reference further down moves every read's window)
+    cert = dict(certificate(hip, cur, fixed_point=converged and cur == before), workload="make_workload(%d, %d, seed=%d)" % (cfg, n, seed))
     tag = f"cfg{cfg}"
     pmc, stale = load_pmc(tag)
     stages, counts = pipe.stages(K, peaks, pmc, stale)
@@ -512,13 +532,13 @@ def section_converge(hip_mod, device, cfg, n, seed, peaks, no_cpu, max_iters=12,
     hip.sync()
     first_warm_ms = (time.perf_counter() - t0) * 1e3
     _, first_counts = pipe.stages(1, None, None, True)
-    out = {"reads": n, "workload": f"configs[{cfg}]: {n} synthetic {w['read_len']} bp aDNA-damaged reads vs {w['ref_name']}, matrix {w['matrix_file']}; "
+    out = {"reads": n, "workload": f"configs[{cfg}]: {n} synthetic {w['read_len']} bp {'aDNA-damaged ' if cfg != 1 else ''}reads vs {w['ref_name']}, matrix {w['matrix_file'] or 'flat'}; "
                        "pass-1 coordinates = true positions",
            "iterations_to_convergence": rounds, "converged": converged, "ms_per_iteration": it_ms,
            "reads_per_s_per_iteration": n * rounds / (sum(it_ms) * 1e-3),
            "steady_state_ms_per_iteration": steady_ms, "steady_state_reads_per_s": n / (steady_ms * 1e-3),
            "first_iteration_again_ms": first_warm_ms, "first_iteration_over_steady": first_warm_ms / steady_ms,
-           "first_iteration_read_fate": first_counts,
+           "first_iteration_read_fate": first_counts, "certificate": cert,
            "bytes_per_read": w["bytes_per_read"], "consensus_len": len(cur), "read_fate": counts,
            "roofline": roofline(stages, peaks, tag, stale), "step_traffic": step_traffic(pmc, stale, n, w["bytes_per_read"])}
     if not no_cpu:
@@ -700,6 +720,8 @@ def headline(out, extras_path):
         cb = dict(out["cpu_baseline"])
         cb["sample"] = str(cb.get("sample", ""))[:200]
         h["cpu_baseline"] = cb
+    if "certificate" in out:
+        h["certificate"] = {k: out["certificate"].get(k) for k in ("consensus_sha256", "alignments_sha256", "consensus_is_fixed_point", "workload")}
     for k in ("value_first_iteration", "collectives", "communicator", "collectives_note", "library", "step_traffic"):
         if k in out:
             h[k] = out[k]
@@ -707,12 +729,7 @@ def headline(out, extras_path):
         h["first_iteration_ms"] = out["first_iteration"]["ms"]
         h["first_iteration_over_steady"] = out["first_iteration"]["over_steady"]
     conv = {}
-    if "first_iteration" in out:
-        # configs[1] converges in two iterations like the others: the first against mt311 itself, the second against its consensus
-        f_ms, s_ms = out["first_iteration"]["ms"], out["ms_per_step"]
-        conv["configs1"] = {"reads": out["config"].get("reads_per_gpu"), "iterations": 2, "value_to_convergence": 2 * out["config"].get("reads_per_gpu", 0) / ((f_ms + s_ms) * 1e-3),
-                            "steady_ms": s_ms, "first_ms": f_ms, "first_over_steady": f_ms / s_ms}
-    for k in ("configs2", "configs3", "configs3_share", "configs4", "configs4_share"):
+    for k in ("configs1", "configs2", "configs3", "configs3_share", "configs4", "configs4_share"):
         c = out.get(k)
         if c:
             conv[k] = {"reads": c.get("reads"), "iterations": c["iterations_to_convergence"], "value_to_convergence": c["reads_per_s_per_iteration"],
@@ -720,7 +737,8 @@ def headline(out, extras_path):
                        "first_over_steady": c["first_iteration_over_steady"], "steady_reads_per_s": c["steady_state_reads_per_s"],
                        "roofline_kernel": c["roofline"]["kernel"], "roofline_frac": c["roofline"]["frac"],
                        "traffic_over_algorithmic": (c.get("step_traffic") or {}).get("ratio"),
-                       "cpu_reads_per_s": (c.get("cpu_baseline") or {}).get("value")}
+                       "cpu_reads_per_s": (c.get("cpu_baseline") or {}).get("value"),
+                       "consensus_sha256": (c.get("certificate") or {}).get("consensus_sha256", "")[:16]}
     lb = out.get("configs3_loopback_w8")
     if lb and "error" not in lb:
         conv["configs3_loopback_w8"] = {k: lb[k] for k in ("ranks", "reads_per_rank", "steady_ms_per_step", "first_iteration_ms")}
@@ -796,6 +814,7 @@ def timed_job(a, env, cfg, reads, scaling, peaks=None):
     # one block of a.steps iterations is 16 ms of GPU time -- a.blocks such blocks, each timed EXACTLY as the
     # contract says (barrier + synchronize on both sides, the longest rank counts); `value` is the MEDIAN block, min / max ride along
     block_dt, dom_ms, dom_launches = [], 0.0, 0
+    step_in = cur
     for _blk in range(max(1, a.blocks)):
         pipe.reset_stats()
         if world > 1:
@@ -803,6 +822,7 @@ def timed_job(a, env, cfg, reads, scaling, peaks=None):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
+            step_in = cur
             cur = pipe.step(cur)
         hip.sync()
         torch.cuda.synchronize()
@@ -820,6 +840,7 @@ def timed_job(a, env, cfg, reads, scaling, peaks=None):
     if dominant and len(block_dt) > 1:             # the dominant kernel's events: the average over all blocks, as launches of ONE block
         dom_ms, dom_launches = dom_ms / len(block_dt), dom_launches // len(block_dt)
     dt = sorted(block_dt)[len(block_dt) // 2]
+    cert = certificate(hip, cur, fixed_point=(cur == step_in) if a.steps > 0 else None)      # (of this rank's reads; the consensus is every rank's)
     if world > 1:
         tot = torch.tensor([n], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -832,7 +853,10 @@ def timed_job(a, env, cfg, reads, scaling, peaks=None):
         cur = run_steps(pipe, cur, a.steps)
     job = {"value": total_reads * a.steps / dt, "ms_per_step": dt / a.steps * 1e3, "scaling": scaling, "reads_per_gpu": n, "total_reads": total_reads,
            "blocks": {"n": len(block_dt), "steps_each": a.steps, "ms_per_step_median": dt / a.steps * 1e3, "ms_per_step_min": min(block_dt) / a.steps * 1e3,
-                      "ms_per_step_max": max(block_dt) / a.steps * 1e3},
+                      "ms_per_step_max": max(block_dt) / a.steps * 1e3,
+                      # (the contract's single timed region is the FIRST block; the median is what `value` reports)
+                      "ms_per_step_first_block": block_dt[0] / a.steps * 1e3, "value_first_block": total_reads * a.steps / block_dt[0]},
+           "certificate": cert,
            "workload": "configs[%d]: %d synthetic %d bp %sreads %s vs %s, matrix %s; step = reiterate_assembly + pop_smp + cull + "
                        "consensus; pass-1 coordinates = true positions"
                        % (cfg, reads, w["read_len"], "paired (two per 300 +- 30 bp fragment, ids /1 /2) aDNA-damaged " if cfg == 3 else ("aDNA-damaged " if cfg != 1 else ""),
@@ -917,10 +941,15 @@ def main():
     if rank == 0 and world == 1 and not a.pmc_run:
         hp = mia_amd.MiaHip(local)
         gbs, ginst = hp.measure_peaks(1 << 30)
+        issue, mhz = hp.measure_issue()
         hp.close()
-        peaks = {"hbm_copy_gbs": gbs, "valu_ginst_s": ginst,
+        # the guide's issue bound (MI355X_MICROARCH.md): a SIMD issues one wave64 VALU instruction every 2 cycles at best -> SIMDs x clock / 2
+        peaks = {"hbm_copy_gbs": gbs, "valu_ginst_s": ginst, "valu_issue_ginst_s": issue, "shader_clock_mhz": mhz,
+                 "issue_bound_2cycle_ginst_s": 1024 * mhz * 1e6 / 2 / 1e9 if mhz else None,
+                 "valu_mix_over_issue": ginst / issue if issue else None,
                  "note": "k_peak_copy: 1 GiB streamed in and out (16 bytes per lane and step), best of 5; k_peak_valu: v_max3_i32/v_add_u32 chains, 8 waves "
-                         "per SIMD, wave64 instructions per second over the whole chip (csrc/mia_peak_kernels.h)"}
+                         "per SIMD, wave64 instructions per second over the whole chip; k_peak_issue: sixteen independent v_add_u32 per round (nothing waits for "
+                         "anything), shader_clock_mhz = s_memtime / s_memrealtime inside that kernel (csrc/mia_peak_kernels.h)"}
     job, live = timed_job(a, env, cfg, reads, scaling, peaks)
     pipe, hip, w, cur, n = live["pipe"], live["hip"], live["w"], live["cur"], live["n"]
     weak = None
@@ -943,6 +972,7 @@ def main():
                        "bytes_per_read": job["bytes_per_read"]},
             "roofline": roofline(stages, peaks, tag, stale),
             "read_fate": counts,
+            "certificate": dict(job["certificate"], workload="make_workload(%d, %d, seed=%d)" % (cfg, n, 1 + rank)),
             "step_traffic": step_traffic(pmc, stale, n, job["bytes_per_read"]),
             "library": {"path": os.path.relpath(hip.lib_path, ROOT), "alt_build": hip.is_alt_build, "switches": mia_amd.alt_switches_set(),
                         "source_hash": source_hash()},
@@ -1007,7 +1037,6 @@ def main():
                 p1["ancient_error"] = repr(ex)
             out["pass1"] = p1
             out["myers"] = section_myers(hip, a.no_cpu_baseline)
-            out["cli"] = section_cli(w)
         if a.pmc_run:
             hip.measure_peaks(1 << 28)           # k_peak_copy in the counter passes: the FETCH_SIZE calibration
         if not a.no_cpu_baseline and world == 1:      # the CPU comparator is timed beside the single-GPU line only
@@ -1015,6 +1044,8 @@ def main():
         if not weak:
             hip.close()
         if world == 1 and not a.no_extras and cfg == 1:
+            # configs[1] from mt311 to convergence, every iteration timed ("iterations: 2" used to be assumed)
+            out["configs1"] = section_converge(mia_amd, local, 1, n, 1, peaks, True, w=w)
             out["configs2"] = section_converge(mia_amd, local, 2, 1_000_000, 3, peaks, a.no_cpu_baseline)
             w3 = make_workload(3, 10_000_000, 4)
             out["configs3"] = section_converge(mia_amd, local, 3, 10_000_000, 4, peaks, a.no_cpu_baseline, w=w3)
@@ -1030,6 +1061,11 @@ def main():
             # GPU's share of it (625 k reads: the N = 8 point of that job as far as one GPU can show it)
             out["configs4"] = section_converge(mia_amd, local, 4, 5_000_000, 5, peaks, a.no_cpu_baseline)
             out["configs4_share"] = section_converge(mia_amd, local, 4, 625_000, 5, peaks, True)
+        if world == 1 and not a.no_extras:
+            # the host program end to end, LAST: every context of this process is closed by now.  (Rounds 4 and 5 ran it while the bench still
+            # held a context with a million reads on the same GPU: the child's first mia_hip_iterate then took 30-60 ms -- two processes
+            # taking turns on one device -- against 2.6-2.7 ms when it has the GPU to itself, which is how a user runs it.)
+            out["cli"] = section_cli(w)
         extras_path = write_extras(out)
         hl = headline(out, extras_path)
         line = json.dumps(hl, separators=(",", ":"))

@@ -388,6 +388,10 @@ int mia_hip_set_stage_mask(mia_hip_ctx *ctx, uint32_t mask);
  * copy_bytes (read + written bytes per second, GB/s) and the issue rate of the DP kernels' own instruction mix
  * (v_max3_i32 / v_add_u32 chains, 10^9 wave64 instructions per second over the whole chip).  Either may be NULL. */
 int mia_hip_measure_peaks(mia_hip_ctx *ctx, int64_t copy_bytes, double *hbm_copy_gbs, double *valu_ginst_s);
+/* The pure issue ceiling beside it: independent v_add_u32 (nothing waits for anything), 10^9 wave64 instructions per second over the
+ * whole chip, and the shader clock in MHz the kernel itself ran at (s_memtime over the constant 100 MHz s_memrealtime), so that a
+ * kernel's instruction rate can be read against the 2-cycle issue bound at the clock of the day.  Either may be NULL. */
+int mia_hip_measure_issue(mia_hip_ctx *ctx, double *add_ginst_s, double *shader_clock_mhz);
 /* milliseconds the k_pass1 kernel of the most recent mia_hip_pass1 call took (HIP events) */
 int mia_hip_pass1_time(mia_hip_ctx *ctx, double *kernel_ms);
 /* reads of the last mia_hip_pass1 call decided by the diagonal filter (csrc/diag_filter.h: flat matrix, no k-mer mask)

@@ -106,6 +106,7 @@ def _load(path=None):
     lib.mia_hip_loopback_destroy.argtypes = [vp]
     lib.mia_hip_loopback_destroy.restype = None
     lib.mia_hip_measure_peaks.argtypes = [vp, C.c_int64, P(C.c_double), P(C.c_double)]
+    lib.mia_hip_measure_issue.argtypes = [vp, P(C.c_double), P(C.c_double)]
     return lib
 
 
@@ -139,7 +140,7 @@ def exported_symbols():
             "mia_hip_get_tally", "mia_hip_consensus", "mia_hip_myers", "mia_hip_myers_packed", "mia_hip_myers_align", "mia_hip_filter_stats", "mia_hip_band_stats", "mia_hip_bx_stats", "mia_hip_bx_counters", "mia_hip_kernel_time", "mia_hip_pass1_time", "mia_hip_myers_time", "mia_hip_pass1_filtered", "mia_hip_pass1_anchored", "mia_hip_pre_cull_counts", "mia_hip_ma_tally", "mia_hip_get_ins_tally", "mia_hip_trim", "mia_hip_trim_stats", "mia_hip_set_back_slots", "mia_hip_set_pass1_state",
             "mia_hip_get_record_params", "mia_hip_set_read_base", "mia_hip_links", "mia_hip_set_links", "mia_hip_link_lengths",
             "mia_hip_finish_links", "mia_hip_plain_stats", "mia_hip_score_sums",
-            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask", "mia_hip_comm_unique_id", "mia_hip_comm_init", "mia_hip_comm_destroy",
+            "mia_hip_score_cut_from_sums", "mia_hip_stage_stats", "mia_hip_measure_peaks", "mia_hip_measure_issue", "mia_hip_set_tally", "mia_hip_iterate", "mia_hip_set_stage_mask", "mia_hip_comm_unique_id", "mia_hip_comm_init", "mia_hip_comm_destroy",
             "mia_hip_comm_attach", "mia_hip_comm_info", "mia_hip_loopback_create", "mia_hip_loopback_table", "mia_hip_loopback_destroy"]
 
 
@@ -575,6 +576,12 @@ class MiaHip:
         """(HBM copy GB/s, 10^9 wave64 VALU instructions/s) measured on this device"""
         a, b = C.c_double(0), C.c_double(0)
         self._chk(self._l.mia_hip_measure_peaks(self._h, copy_bytes, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def measure_issue(self):
+        """(10^9 independent wave64 v_add_u32 per second over the chip, shader clock in MHz during that kernel)"""
+        a, b = C.c_double(0), C.c_double(0)
+        self._chk(self._l.mia_hip_measure_issue(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def ma_tally(self, ref_len, gaps, start, revcom, col_off, seq, smp, ins_record=(), ins_pos=(), ins_off=(0,), ins_bases=b""):

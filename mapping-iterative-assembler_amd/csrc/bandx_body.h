@@ -1143,6 +1143,94 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
   out->edge = !(d0 >= 0 && len2 - 1 + d0 + wc <= len1);
 }
 
+// THE QUICK PLAN (round 6).  bx_anchors asks the table where EACH of the read's nine blocks occurs -- a walk of dependent loads through
+// the open-addressed table --, sorts the answers into diagonals and clusters them around their median: some 1 500 instructions and a few
+// trips to the L2 per read, 44 % of k_bx_plan's cycles -- to find out, for nine reads in ten of a steady-state iteration, that every
+// block sits where the read was aligned before: on diagonal d = as - s of its window.  This is the same proof with the question
+// turned round: look at diagonal d FIRST (one seek of the planes, the mismatch mask), and ask about each block's 10-mer the two
+// questions that settle its place in the pigeonhole WITHOUT knowing positions -- two bitmaps over all 4^10 10-mers (KmerBits, 256 KB,
+// made with the table): does it occur in the reference at all, does it occur more than once (start positions 0 .. L - 1 of the
+// wrapped string: the wrap's copies are the same places).
+//   * a block whose ten rows are free of loss on d carries the reference's own 10-mer of that place; if that 10-mer occurs ONCE in the
+//     reference its only place inside the window is on d (a window no longer than the reference holds a place and its wrap copy never
+//     both): the block is in the family, anchored on d and nowhere else;
+//   * a block whose 10-mer occurs NOWHERE in the reference is in the family with no anchor at all: every path breaks it (budget and
+//     s_un take its dl, exactly as bx_anchors' "nowhere");
+//   * every other block -- a repeated 10-mer, or a broken block whose 10-mer happens to exist somewhere -- is left out of the family as
+//     an overloaded 10-mer is there: no budget from it, no anchor of it, nothing is claimed about it.
+// The theorem is the one bx_finish already applies: a path that crosses no block of the family cleanly loses at least the sum of
+// their dl > B0, so every path that can win or tie crosses one -- on d, the only place there is -- and strays from it by what B0 less
+// s_un leaves.  The family is at most bx_anchors' own, so the band is at least as wide as the full plan's: the values DP may have to
+// decide where the full plan would have -- never a wrong answer.  Not for tables that spell out N columns (kh.wild: every run's first
+// iteration), not for a window longer than the reference.  false: nothing decided, the full plan (bx_anchors ...) takes the read.
+struct KmerBits { const uint32_t* present; const uint32_t* repeated; int32_t ref_len; };      // ref_len = L (the places the bitmaps count); present == nullptr: none
+constexpr int64_t KB_WORDS = (int64_t)1 << (2 * DF_K - 5);      // words per bitmap
+constexpr int BX_QUICK_MAX = 8;        // more rows with a loss on d than this: an indel, or a read that belongs elsewhere -- not worth the look-ups
+template <int NW>
+MIA_HD inline bool bx_quick(DiagScan<NW>& sc, const RefPlanes& rp, const KmerHash& kh, const KmerBits& kb, int s, int len1, int len2, int st, int d, const BxTab& T,
+                            BxPlan* out) {
+  constexpr int NB = bx_nb_max<NW>();
+  out->mode = BX_NONE; out->b0 = 0;
+  if (!kb.present || kh.wild > 0 || d < 0 || d > len1 - len2 || len1 > kb.ref_len) return false;
+  const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
+  sc.seek(rp, (int64_t)s + d);
+  uint64_t m1[NW];
+  int nm = 0;
+#pragma unroll
+  for (int j = 0; j < NW; j++) { m1[j] = bx_loss_rows<NW>(sc, j); nm += df_popc(m1[j]); }
+  if (nm > BX_QUICK_MAX) return false;
+  const int16_t* dl = T.dl + (st * (MAX_READ + 1) + len2) * BX_BLOCKS;
+  uint32_t kidx[NB], w1[NB], w2[NB];
+  int32_t dlv[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    kidx[b] = 0; dlv[b] = 0; w1[b] = 0; w2[b] = 0;
+    if (b < nb_cut) {
+      kidx[b] = bx_kmer_planes<NW>(sc, bx_block_row(b, len2, nb_cut));
+      w1[b] = kb.present[kidx[b] >> 5];
+      w2[b] = kb.repeated[kidx[b] >> 5];
+      dlv[b] = dl[b];
+    }
+  }
+  BX_LOADS_ISSUED();
+  int budget = -1, nbv = 0, s_un = 0, b_lo = -1, b_hi = -1;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (b >= nb_cut) continue;
+    const int o = bx_block_row(b, len2, nb_cut);
+    const bool clean = bx_count<NW>(m1, o, o + DF_K) == 0;
+    const bool present = ((w1[b] >> (kidx[b] & 31u)) & 1u) != 0u, repeated = ((w2[b] >> (kidx[b] & 31u)) & 1u) != 0u;
+    if (!present) {                           // occurs nowhere: every path breaks this block
+      budget += dlv[b]; s_un += dlv[b]; nbv++;
+    } else if (clean && !repeated) {          // the reference's own 10-mer of this place, and its only one: anchored on d
+      budget += dlv[b]; nbv++;
+      if (b_lo < 0) b_lo = b;
+      b_hi = b;
+    }
+  }
+  if (nbv < BX_MIN_BLOCKS || b_lo < 0) return false;
+  BxAnchors an;
+  an.fail = 0; an.a_lo = d; an.a_hi = d; an.d_first = d; an.d_last = d; an.budget = budget; an.t_lo = 1; an.t_hi = R; an.l_out = -1; an.s_un = s_un;
+  an.r_head = bx_block_row(b_lo, len2, nb_cut); an.r_tail = bx_block_row(b_hi, len2, nb_cut) + DF_K; an.rescue = 0; an.fine = 0; an.fc1 = 0; an.fc2 = 0; an.fmax = 0;
+  bx_finish<NW, 1>(sc, rp, an, s, len1, len2, st, T, out);
+  if (out->mode == BX_NONE) { out->b0 = 0; return false; }
+  return true;
+}
+// one reference place into the bitmaps (device: atomics; host: the tests)
+MIA_HD inline void kmer_bits_insert(const uint8_t* codes, int64_t n_codes, int64_t p, uint32_t* present, uint32_t* repeated) {
+  uint32_t idx;
+  uint64_t npos;
+  if (kmer_wild_at(codes, n_codes, p, &idx, &npos) != 0) return;                  // (off the end, or an N inside: no path crosses such a place cleanly)
+  const uint32_t bit = 1u << (idx & 31u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t old = atomicOr(&present[idx >> 5], bit);
+  if (old & bit) atomicOr(&repeated[idx >> 5], bit);
+#else
+  if (present[idx >> 5] & bit) repeated[idx >> 5] |= bit;
+  present[idx >> 5] |= bit;
+#endif
+}
+
 // a read the 10-mers could not vouch for (budget, or anchors set aside that l_out could not cover): the fine blocks may
 MIA_HD inline bool bx_wants_fine(const BxPlan& p) { return p.mode == BX_NONE && (p.b0 == BXF_BUDGET || p.b0 == BXF_SPAN); }
 MIA_HD inline bool a_hi_ok(const BxAnchors& an, const BxTab& T) { return an.fail == 0 && an.a_hi - an.a_lo + 2 * BX_FINE_RADIUS < T.maxw; }
@@ -1175,6 +1263,19 @@ MIA_HD inline void bx_plan_nw(const RefPlanes& rp, const KmerHash& ko, int64_t n
     const int why = out->b0;
     if (bx_fine_anchors<NW>(sc, rp, s, len1, len2, st, T, &an)) bx_finish<NW>(sc, rp, an, s, len1, len2, st, T, out);
     if (out->mode == BX_NONE && out->b0 != BXF_WIDTH) out->b0 = why;
+  }
+}
+
+// the quick plan alone, for a caller that has a diagonal to ask about (tests/emul: emu_bandx with opts & 256); false: not decided
+MIA_HD inline bool bx_plan_quick(const RefPlanes& rp, const KmerHash& ko, const KmerBits& kb, int64_t n_ref, int s, int len1, const uint8_t* read_packed, int len2, int st, int d,
+                                 const BxTab& T, BxPlan* out) {
+  out->mode = BX_NONE; out->b0 = 0;
+  if (!bx_plannable(rp, ko, n_ref, s, len1, len2)) return false;
+  switch ((len2 + 63) >> 6) {
+    case 1: { DiagScan<1> sc; return sc.load_read(read_packed, len2) && bx_quick<1>(sc, rp, ko, kb, s, len1, len2, st, d, T, out); }
+    case 2: { DiagScan<2> sc; return sc.load_read(read_packed, len2) && bx_quick<2>(sc, rp, ko, kb, s, len1, len2, st, d, T, out); }
+    case 3: { DiagScan<3> sc; return sc.load_read(read_packed, len2) && bx_quick<3>(sc, rp, ko, kb, s, len1, len2, st, d, T, out); }
+    default: { DiagScan<4> sc; return sc.load_read(read_packed, len2) && bx_quick<4>(sc, rp, ko, kb, s, len1, len2, st, d, T, out); }
   }
 }
 

@@ -23,8 +23,8 @@ namespace mia {
 
 // counters of the pipeline; each on a cache line of its own (BXC_STRIDE words apart): thousands of wavefronts add to them,
 // and atomics on one line are served one after the other
-enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_CAND = 30, BXC_CAND2 = 31, BXC_COUNTERS = 32 };     // CAND: reads handed from the plan's first launch to its second; CAND2: on to the third (fine blocks)
-static_assert(BXC_SEEN < BXC_FAIL0 && BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_CAND && BXC_CAND < BXC_COUNTERS, "counter layout");
+enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_OPEN = 29, BXC_CAND = 30, BXC_CAND2 = 31, BXC_COUNTERS = 32 };     // CAND: reads handed from the plan's first launch to its second; CAND2: on to the third (fine blocks)
+static_assert(BXC_SEEN < BXC_FAIL0 && BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_OPEN && BXC_OPEN < BXC_CAND && BXC_CAND < BXC_COUNTERS, "counter layout");     // OPEN: reads the plan leaves to the full-window kernels (BxDev::open)
 constexpr int BXC_STRIDE = 64;
 constexpr int BXC_WORDS = BXC_COUNTERS * BXC_STRIDE;
 __device__ __forceinline__ uint32_t* bxc(const uint32_t* ctr, int k) { return const_cast<uint32_t*>(ctr) + (size_t)k * BXC_STRIDE; }
@@ -58,6 +58,18 @@ struct BxDev {
   // the band DPs in two rounds (align_all: split_dp): `snap` holds the lengths of the values / trace lists as the plan's first launch left
   // them (k_bx_snap); round 1 takes the entries below, round 2 -- behind the plan's last launch -- the ones from there on
   const uint32_t* snap;
+  // round 6: the reads the plan leaves OPEN (given up on, or strand unknown) listed by the plan itself -- at steady state a few hundred per
+  // million, which k_align_open then takes one per wavefront, instead of the planner's count / scan / fill over ALL reads and a quad pass
+  // (align_all: direct_open); nullptr: the planner bins them
+  int32_t* open;
+  uint32_t* open_n;
+  // round 6: the QUICK plan (bx_quick, phase 4 of k_bx_plan) looks at every read on the diagonal it was aligned on before and finishes or
+  // lists nine in ten; what it cannot decide goes on qlist, which the plan's first launch proper then takes as its in_list.  mark_all: the
+  // reads of in_list get their marks (bin_of, the open list) from this launch -- they have none yet (in_list of the diagonal filter: 0)
+  int32_t* qlist;
+  uint32_t* qlist_n;
+  int32_t mark_all;
+  KmerBits kb;             // the two bitmaps the quick plan asks (present == nullptr: no quick plan)
 };
 // which entries of the plan's lists a launch of the band DPs takes
 enum { BX_PART_ALL = 0, BX_PART_HEAD = 1, BX_PART_TAIL = 2 };
@@ -200,6 +212,12 @@ __global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t
   kmer_hash_insert(codes, n_codes, (int64_t)blockIdx.x * 256 + threadIdx.x, slot, ovf, mask, shift, wild);
 }
 
+// the quick plan's two bitmaps (bandx_body.h: KmerBits) from the start positions 0 .. L - 1 of the wrapped reference; both cleared before
+__global__ __launch_bounds__(256) void k_kmer_bits(const uint8_t* codes, int64_t n_codes, int64_t L, uint32_t* present, uint32_t* repeated) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < L) kmer_bits_insert(codes, n_codes, p, present, repeated);
+}
+
 // bit planes of every read (diag_filter.h: DiagScan::load_read), once per read set: words lo words, then words hi words
 __global__ __launch_bounds__(256) void k_read_planes(ReadSet rs, int32_t words, uint64_t* out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -245,6 +263,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
   __shared__ int32_t n_cand;
   __shared__ uint32_t blk_cnt[SLOT_FINE + 1], blk_base[2 * BX_NCLS + 1];   // per block: list appends, finished, seen, reasons, hand-overs
   PLAN_CLK_DECL;
+  if (PH == 1 && in_list && (int64_t)blockIdx.x * 256 >= (int64_t)*n_in_p) return;      // (the grid is sized for all reads: a short list leaves most of it nothing to do)
   for (int k = threadIdx.x; k < BX_LOSS_WORDS; k += 256) loss_lds[k] = bx.tab.loss[k];
   if (threadIdx.x == 0) n_cand = 0;
   if (threadIdx.x <= SLOT_FINE) blk_cnt[threadIdx.x] = 0;
@@ -297,6 +316,8 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
       if (bp.mode == BX_VALUES || bp.mode == BX_TRACE) bx.plan[r.i] = bx_pack(bp);
       if (mark_open && bp.mode != BX_DONE) bin_of[r.i] = (bp.mode == BX_VALUES || bp.mode == BX_TRACE) ? bx.listed_mark : 0;
     }
+    // (every read is marked by exactly one launch of the plan -- the one that finishes it: so it is listed exactly once)
+    if (bx.open) bxl_append(bx.open, bx.open_n, mark_open && bp.mode != BX_DONE && bp.mode != BX_VALUES && bp.mode != BX_TRACE, r.i);
     // list appends and counters go through the block: one global atomic per block and list instead of one per wavefront
     int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? BX_NCLS + bx_class_of(bp.w) : -1);
     uint32_t rank = 0;
@@ -319,6 +340,41 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     if (threadIdx.x <= SLOT_FINE) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
   };
+  const bool marks = !in_list || bx.mark_all != 0;
+  if (PH == 4) {
+    // THE QUICK PLAN (bandx_body.h: bx_quick): the diagonal the read was aligned on before, asked first.  What it plans is emitted as by
+    // any other phase; everything else -- undecided, not plannable, strand unknown -- goes on qlist for the first launch proper.
+    DiagScan<NW> sc;
+    Rd r = fetch((int)threadIdx.x, sc);
+    BxPlan bp;
+    bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
+    BxAnchors an{};
+    bool planned = false;
+    if (r.ok && bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2) && load_planes(r, sc))
+      planned = bx_quick<NW>(sc, rp, ko, bx.kb, r.s, r.l1, r.len2, r.st, rs.as[r.i] - r.s, T, &bp);
+    if (!planned) { bp.mode = BX_NONE; bp.b0 = 0; }
+    const unsigned long long sm = __ballot(planned);
+    if ((threadIdx.x & 63) == 0 && sm) atomicAdd(&blk_cnt[2 * BX_NCLS + 1], (uint32_t)__popcll(sm));
+    Rd rr = r;
+    rr.ok = planned;
+    emit(rr, bp, planned, false, an);
+    // the undecided reads onto qlist: ONE global atomic per block (an atomic per wavefront on the one counter -- fifteen thousand of them,
+    // served one at a time -- made this launch longer than the full plan it replaces: 224 us)
+    __shared__ uint32_t q_cnt[4], q_base;
+    const bool to_q = t0 + threadIdx.x < total && !planned;
+    const unsigned long long qm = __ballot(to_q);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) q_cnt[wv] = (uint32_t)__popcll(qm);
+    __syncthreads();
+    if (threadIdx.x == 0) { const uint32_t tot = q_cnt[0] + q_cnt[1] + q_cnt[2] + q_cnt[3]; q_base = tot ? atomicAdd(bx.qlist_n, tot) : 0u; }
+    __syncthreads();
+    if (to_q) {
+      uint32_t before = 0;
+      for (int k = 0; k < wv; k++) before += q_cnt[k];
+      bx.qlist[q_base + before + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = (int32_t)(t0 + threadIdx.x);
+    }
+    return;
+  }
   if (PH < 2) {
     PLAN_CLK(0);
     DiagScan<NW> sc;
@@ -388,7 +444,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     // (a waiting read's mark is written by the launch that finishes it)
     Rd rr = r;
     if (waits) rr.ok = false;
-    emit(rr, bp, !in_list && t0 + threadIdx.x < total && !waits, to_fine, an);
+    emit(rr, bp, marks && t0 + threadIdx.x < total && !waits, to_fine, an);
     PLAN_CLK(5);
     if (bx.early && !in_list && t0 + threadIdx.x < total) bx.early[t0 + threadIdx.x] = bp.mode == BX_DONE ? 1 : 0;      // (every read passes here once)
     if (PH == 1) {                                  // hand the waiting reads over: one reservation per block
@@ -478,7 +534,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     }
     Rd rr = r;
     if (to_fine) rr.ok = false;
-    emit(rr, bp, !in_list && rr.ok, to_fine, an);
+    emit(rr, bp, marks && rr.ok, to_fine, an);
     if (bx.early && rr.ok && bp.mode == BX_DONE) bx.early[r.i] = 1;
   }
 }

@@ -35,6 +35,8 @@ static const char* const STAGE_NAMES[STG_COUNT] = {"k_align_quad", "k_align_quad
 // One device block for every small counter of an iteration (planner bins and header, filter / band-pipeline counters, link
 // count, cull and tally flags, insert-event count): one memset at the start of the alignment clears them all, and one copy
 // brings back what the host wants to see.  Offsets in 32-bit words.
+constexpr int OPEN_WGS = 1024;                                   // k_align_open's persistent grid (one read per wavefront; a steady-state list holds a few hundred)
+constexpr int64_t OPEN_SLAB_BYTES = (int64_t)MAX_READ * 64 * 12;   // its trace slab: the widest window class's
 constexpr int CTRL_BINS = 0;                                   // [count N_BINS][off N_BINS][cursor N_BINS][wide_count][retry_count]
 constexpr int CTRL_HDR = (3 * N_BINS + 2 + 1) & ~1;            // PH_* (8-byte aligned: the DP kernels fetch their range as a pair)
 constexpr int CTRL_FILTER = CTRL_HDR + PH_WORDS;               // 4 words (k_diag_filter / k_band_align)
@@ -74,6 +76,11 @@ struct mia_hip_ctx {
   int64_t spec_redone = 0;                  // iterations whose cull / tally / consensus were queued twice (reads for the exact kernel)
   bool pend_encode = false; int32_t pend_L = 0, pend_wl = 0, pend_total = 0;      // mia_hip_iterate: d_ascii holds the new reference, d_ref not yet
   uint32_t* d_prep_bar = nullptr; uint32_t prep_bar_count = 0; bool no_prep_fuse = false;   // k_ref_prep's grid barrier (MIA_HIP_NO_PREP_FUSE=1: six launches)
+  // round 6: the band plan lists the reads it leaves open itself and k_align_open takes them one per wavefront (align_all: direct_open;
+  // MIA_HIP_NO_DIRECT_OPEN=1, alt build: the planner's count / scan / fill and the quad kernels, as in every iteration with many open reads)
+  uint32_t* d_kbits = nullptr;          // the quick plan's bitmaps over all 4^10 10-mers (bandx_body.h: KmerBits), remade with the table
+  bool use_quick = true; int64_t quick_steps = 0;      // the quick plan in front of k_bx_plan's launches (MIA_HIP_NO_QUICK_PLAN=1, alt build: the full plan for every read)
+  int32_t* d_open_list = nullptr; int64_t open_cap = 0; unsigned char* d_slabs_open = nullptr; bool use_direct_open = true; int64_t direct_open_steps = 0;   // k_cons_tail's barrier counter (d_prep_bar + 1; MIA_HIP_NO_TAIL_FUSE=1: four launches)
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
   bool zero_copy = true;        // mia_hip_iterate: the last kernel writes consensus and counters into pinned host memory itself (MIA_HIP_NO_ZERO_COPY=1: two copies)
   // the launches other streams wait for signal their events themselves (launch_k) instead of a marker behind them; MIA_HIP_NO_EXT_EVENTS=1: markers
@@ -376,6 +383,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* cs = alt_env("MIA_HIP_CULL_SCAN")) ctx->cull_scan = atoi(cs) != 0;
     if (const char* sm = alt_env("MIA_HIP_STAGE_MARKERS")) ctx->stage_markers = atoi(sm) != 0;
     if (const char* ts = alt_env("MIA_HIP_TAIL_SCANS")) ctx->tail_scans = atoi(ts) != 0;
+    if (const char* dop = alt_env("MIA_HIP_NO_DIRECT_OPEN")) ctx->use_direct_open = atoi(dop) == 0;
+    if (const char* qp = alt_env("MIA_HIP_NO_QUICK_PLAN")) ctx->use_quick = atoi(qp) == 0;
     if (const char* sw = getenv("MIA_HIP_SPIN_WAIT")) ctx->spin_wait = atoi(sw) != 0;
     if (const char* em = alt_env("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
     if (const char* st2 = alt_env("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
@@ -480,6 +489,9 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (ctx->d_bx_cand2) (void)hipFree(ctx->d_bx_cand2);
   for (int k = 0; k < 3; k++) if (ctx->d_slabs_retry[k]) (void)hipFree(ctx->d_slabs_retry[k]);
   if (ctx->d_prep_bar) (void)hipFree(ctx->d_prep_bar);
+  if (ctx->d_slabs_open) (void)hipFree(ctx->d_slabs_open);
+  if (ctx->d_open_list) (void)hipFree(ctx->d_open_list);
+  if (ctx->d_kbits) (void)hipFree(ctx->d_kbits);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   delete ctx;
@@ -1052,6 +1064,7 @@ static int align_all(mia_hip_ctx* ctx) {
   uint32_t h_filter_n = 0;
   bool banded = false;
   bool planner_head_first = false;      // count / scan / fill of the planner queued in front of the band DPs (see the band launches)
+  bool direct_open = false;             // the plan lists its open reads itself, k_align_open takes them (no planner, no quad kernels: see below)
   if (filtered) {
     // reads whose alignment is provably one gap-free diagonal never reach the DP kernels (diag_filter.h)
     const int64_t words = plane_words((int64_t)wrap + 64);
@@ -1101,6 +1114,9 @@ static int align_all(mia_hip_ctx* ctx) {
         ctx->khash_cap = kslots;
       }
       const KmerHash kh{ctx->d_khash, ctx->d_khash_ovf, kslots - 1, kh_shift_for(kslots), ctx->kh_entries > 0 ? BX_WILD : 0};
+      // (the quick plan's bitmaps: made wherever the table is made for a reference without spelled-out N columns)
+      const bool want_bits = ctx->use_quick && kh.wild == 0;
+      if (want_bits && !ctx->d_kbits && dev_alloc(ctx, &ctx->d_kbits, (size_t)(2 * KB_WORDS))) return MIA_HIP_ERR_NOMEM;
       if (fused_prep) {
         RefPrep rp2;
         rp2.ascii = ctx->ascii_src; rp2.L = ctx->pend_L; rp2.wl = ctx->pend_wl; rp2.total = ctx->pend_total; rp2.codes = ctx->d_ref;
@@ -1115,6 +1131,7 @@ static int align_all(mia_hip_ctx* ctx) {
         // kernel is bounded, and a barrier given up on is reported through a pinned word the step's one wait looks at.
         rp2.bar = ctx->d_prep_bar; rp2.bar_target = ctx->prep_bar_count + grid;
         rp2.stuck = ctx->h_pin ? reinterpret_cast<uint32_t*>(ctx->h_pin + (62 << 10)) : nullptr;
+        rp2.kbits = want_bits ? ctx->d_kbits : nullptr;
         hipLaunchKernelGGL(k_ref_prep, dim3(grid), dim3(256), 0, ctx->stream, rp2);
         HIPCHK(hipGetLastError());
         ctx->prep_bar_count += grid;
@@ -1123,6 +1140,10 @@ static int align_all(mia_hip_ctx* ctx) {
       HIPCHK(hipMemsetAsync(ctx->d_khash, 0xFF, (size_t)kslots * 16, ctx->stream));
       hipLaunchKernelGGL(k_kmer_hash, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_khash, ctx->d_khash_ovf,
                          kh.mask, kh.shift, kh.wild);
+      if (want_bits) {
+        HIPCHK(hipMemsetAsync(ctx->d_kbits, 0, (size_t)(2 * KB_WORDS) * 4, ctx->stream));
+        hipLaunchKernelGGL(k_kmer_bits, dim3((unsigned)((ctx->L + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, (int64_t)ctx->L, ctx->d_kbits, ctx->d_kbits + KB_WORDS);
+      }
       }
       if (n > ctx->bx_cap) {
         if (dev_alloc(ctx, &ctx->d_bx_plan, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_expect, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_lists, (size_t)n * 3 * BX_NCLS))
@@ -1211,6 +1232,22 @@ static int align_all(mia_hip_ctx* ctx) {
         for (int k = 1; k < BXF_KINDS; k++) lr += ctx->bx_last[BXC_FAIL0 + k];
         const bool many_early = !ctx->no_auto_plain && (!ctx->ref_mostly_bases || lr * 20 > n);
         planner_head_first = new_flow && ctx->deferred && many_early && !ctx->planner_beside && !(ctx->dbg & 256u);
+        // DIRECT OPEN LIST (round 6).  At steady state the plan leaves a few hundred reads per million open.  For their sake the planner
+        // counted, scanned and filled over ALL reads (three launches beside the persistent band grids: 13 + 7 + 71 us), a quad kernel took
+        // them four to a wavefront (110 us: one quad's latency), three window-class launches and a retry launch followed -- nine launches,
+        // 270 us, the longest of the step's three DP chains.  Now the plan appends such a read to a list as it gives up on it and
+        // k_align_open takes the list, one read per wavefront (90-115 us beside the band DPs, 35 on an idle chip: off the step's chain either way).  Where the plan gives up on MANY reads (the values-only quad pass is on:
+        // every run's first iteration, N-rich references) the planner and the quad kernels stay: four reads per wavefront is what pays there.
+        const bool plain_wanted = ctx->use_plain && (ctx->plain_behind_band || many_early);      // (= use_plain below, the band pipeline being on)
+        direct_open = new_flow && ctx->deferred && ctx->use_direct_open && !plain_wanted && !planner_head_first && !run_filter && !(ctx->dbg & 256u) &&
+                      !(ctx->bx_dbg & (4u | 8u));
+      }
+      bd.open = nullptr; bd.open_n = ctx->d_bx_ctr + (size_t)BXC_OPEN * BXC_STRIDE;
+      if (direct_open) {
+        if (n > ctx->open_cap) { if (dev_alloc(ctx, &ctx->d_open_list, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->open_cap = n; }
+        if (!ctx->d_slabs_open && hipMalloc((void**)&ctx->d_slabs_open, (size_t)OPEN_SLAB_BYTES * OPEN_WGS) != hipSuccess) return MIA_HIP_ERR_NOMEM;
+        bd.open = ctx->d_open_list;
+        ctx->direct_open_steps++;
       }
       // the early tally (k_rec_early): the plan marks the reads it finishes, their tally runs on stream4 beside the band DPs.  Only in
       // mia_hip_iterate (the whole step is queued at once), for read sets small enough that the step is a chain of latencies.
@@ -1242,11 +1279,32 @@ static int align_all(mia_hip_ctx* ctx) {
         bd.snap = ctx->d_bx_snap;
         ctx->split_dp_steps++;
       }
+      // THE QUICK PLAN FIRST (round 6; bandx_body.h: bx_quick, k_bx_plan<NW, 4>): every read on the diagonal it was aligned on before -- nine
+      // in ten of a steady-state iteration are finished or listed there for a tenth of the full plan's instructions; the rest goes on a
+      // list (the diagonal filter's: d_left_list, d_filter_n[1]) that the launches below take as their in_list.  Not against a table that
+      // spells out N columns (every run's first iteration), not with the diagonal filter in front, not with the early tally's marks.
+      const bool quick = split && new_flow && !run_filter && !early && want_bits && !(ctx->bx_dbg & 32u);
+      bd.qlist = nullptr; bd.qlist_n = ctx->d_filter_n + 1; bd.mark_all = 0;
+      bd.kb = KmerBits{quick ? ctx->d_kbits : nullptr, quick ? ctx->d_kbits + KB_WORDS : nullptr, ctx->L};
+      if (quick) {
+        if (n > ctx->left_cap) { if (dev_alloc(ctx, &ctx->d_left_list, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->left_cap = n; }
+        bd.qlist = ctx->d_left_list;
+        ctx->quick_steps++;
+      }
       if (stage_begin(ctx, STG_BX_PLAN)) return MIA_HIP_ERR_NOMEM;
       {
-        const int32_t* in_list = run_filter ? ctx->d_left_list : nullptr;
+        const int32_t* in_list = (run_filter || quick) ? ctx->d_left_list : nullptr;
         const dim3 pb(256);
         const int nwords = (ctx->max_len + 63) >> 6;       // 64-row words of the longest read
+        if (quick) {
+          const dim3 pg((unsigned)((n + 255) / 256));
+          hipEvent_t done = nullptr;
+          const int32_t* in_list = nullptr;               // (this launch walks all n reads)
+#define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, 0, ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
+          switch (nwords) { case 1: MIA_PLAN(1, 4); break; case 2: MIA_PLAN(2, 4); break; case 3: MIA_PLAN(3, 4); break; default: MIA_PLAN(4, 4); break; }
+#undef MIA_PLAN
+          bd.mark_all = 1;
+        }
         for (int phase = split ? 1 : 0; phase <= last_phase; phase++) {
           const dim3 pg(phase >= 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
           // (the fork event rides on the last launch's own completion signal: no marker between the plan and the values DP)
@@ -1372,7 +1430,7 @@ static int align_all(mia_hip_ctx* ctx) {
   const bool many_rejects = bx && !ctx->no_auto_plain && (!ctx->ref_mostly_bases || last_rejects * 20 > n);
   const bool use_plain = ctx->use_plain && (!banded || ctx->plain_behind_band || many_rejects);
   hipStream_t ps = ctx->bx_planner_aside ? ctx->stream2 : ctx->stream;      // the planner's stream (see the band launches above)
-  if (!planner_head_first)
+  if (!planner_head_first && !direct_open)
   hipLaunchKernelGGL(k_plan_count, dim3(gb), dim3(tb), 0, ps, ctx->rs, ref, ctx->packs, ctx->use_quad, filtered, filtered && use_plain, ctx->d_bin_of, d_count, ctx->d_filter_n);
   if (ctx->deferred) {
     // ---- mia_hip_iterate: the same plan, but its numbers stay on the device (k_plan_scan) and every DP kernel reads its own
@@ -1382,6 +1440,17 @@ static int align_all(mia_hip_ctx* ctx) {
     auto ck = [&](const char* what) { if (dbg_steps) { hipError_t e = hipStreamSynchronize(ps); fprintf(stderr, "[align_all deferred] %s: %s\n", what, hipGetErrorString(e)); fflush(stderr); } };
     ck("plan_count");
     int32_t* d_retry_cnt = hdr + PH_RETRY + 1;
+    if (direct_open) {
+      // the planner's whole chain is this one launch (the last on its stream: it signals ev_join itself, see bx_join_and_retry)
+      const bool sig = ctx->bx_planner_aside && ctx->bx_pending_join && (ctx->ext_events & 4u);
+      if (stage_begin(ctx, STG_TRACE, ps)) return MIA_HIP_ERR_NOMEM;
+      launch_k(k_align_open, dim3(OPEN_WGS), dim3(64), 0, ps, sig ? ctx->ev_join : nullptr, ctx->rs, ref, (const int32_t*)ctx->d_pssm, ctx->packs, (const int32_t*)ctx->d_open_list,
+               (const uint32_t*)(ctx->d_bx_ctr + (size_t)BXC_OPEN * BXC_STRIDE), ctx->d_slabs_open, (int64_t)OPEN_SLAB_BYTES, ctx->d_wide_list, d_wide_count, ctx->dbg);
+      stage_end(ctx, STG_TRACE, ps);
+      HIPCHK(hipGetLastError());
+      ctx->planner_end_signalled = sig;
+      ck("open list");
+    } else {
     if (!planner_head_first) {
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 0, ctx->d_list);      // (writes the quad bins' padding itself: -1 = empty slot)
     hipLaunchKernelGGL(k_plan_fill, dim3(gb), dim3(tb), 0, ps, n, ctx->d_bin_of, d_off, d_cursor, ctx->d_list);
@@ -1448,6 +1517,7 @@ static int align_all(mia_hip_ctx* ctx) {
       }
     }
     if (!windows_done) { if (int rcw = window_classes()) return rcw; }
+    }
     ck("retry");
     if (int rcj = bx_join_and_retry(ctx)) return rcj;
     ck("band join");

@@ -445,6 +445,61 @@ __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, co
   }
 }
 
+// ---- the reads the band plan left open, straight from its own list (BxDev::open), one per wavefront: what k_plan_count would do with
+// each of them (strand unknown: ST_SKIPPED; the window's class; the exact kernel's list for what no class holds) and then the window DP
+// of that class.  One launch instead of the planner's count / scan / fill / seed, the quad kernel and four window launches -- for the
+// few hundred reads per million a steady-state iteration leaves open (align_all: direct_open).  slab_bytes: the widest class's.
+__global__ __launch_bounds__(64) void k_align_open(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackSet ps, const int32_t* list, const uint32_t* count_p,
+                                                    unsigned char* trace_slabs, int64_t slab_bytes, int32_t* wide_list, int32_t* wide_count, uint32_t dbg) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SUB_LDS_BYTES];
+  const int count = (int)*count_p;
+  __builtin_amdgcn_s_setprio(3);
+  DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
+  for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    const int i = list[w];
+    if (!rs.sk[i]) { if (wave.lane() == 0) rs.status[i] = ST_SKIPPED; continue; }      // (k_plan_count's mark for a read reiterate_assembly skips: src/mia_main.c:178)
+    AlignArgs a;
+    int s, l1;
+    const int len2 = rs.len[i];
+    read_window(ref, rs.as[i], rs.ae[i], len2, &s, &l1);
+    const int ci = classify(len2, l1, ps, 0);
+    if (ci == BIN_WIDE) {
+      if (wave.lane() == 0) { const int q = atomicAdd(wide_count, 1); wide_list[q] = i; }
+      continue;
+    }
+    a.ref_codes = ref.codes;
+    a.ref_start = s;
+    a.len1 = l1;
+    a.read_packed = rs.packed + rs.roff[i];
+    a.len2 = len2;
+    a.pssm = pssm2 + (rs.rc[i] ? PSSM_WORDS : 0);
+    a.sg5 = 1;
+    a.pk = ps.p[ci];
+    a.lds_sub = 0;
+    a.trace_stride = (uint32_t)((l1 + 3) & ~3);
+    a.cols_out = rs.cols + (int64_t)i * rs.stride;
+    a.dbg = dbg;
+    AlignResult r;
+    if (ci == 0) r = WindowAligner<DevWave, 4>::run(wave, a);
+    else if (ci == 1) r = WindowAligner<DevWave, 8>::run(wave, a);
+    else r = WindowAligner<DevWave, 12>::run(wave, a);
+    if (wave.lane() == 0) {
+      if (r.status & ST_ESCAPE) {
+        const int q = atomicAdd(wide_count, 1);
+        wide_list[q] = i;
+      } else {
+        rs.score[i] = r.score;
+        rs.refstart[i] = s;
+        rs.abr[i] = (int16_t)r.abr;
+        rs.as[i] = r.abc + s;   // src/mia_main.c:254-255
+        rs.ae[i] = r.aec + s;
+      }
+      rs.status[i] = r.status;
+    }
+    wave.lds_fence();
+  }
+}
+
 // ---- four reads per wavefront (align_body_quad.h): windows <= 208 columns, equal read lengths ----
 __global__ __launch_bounds__(64, 4) void k_align_quad(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackParams pk, const int32_t* list,
                                                     int32_t n_quads, unsigned char* trace_slabs, int64_t slab_bytes,

@@ -56,4 +56,30 @@ __global__ __launch_bounds__(256) void k_peak_valu(int32_t* out, int iters, int3
   out[(int64_t)blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
 
+// The pure issue rate (k_peak_valu's max3 / add chains are the DP kernels' mix and reach 60 % of the guide's
+// 2-cycle bound -- whether that is the instruction's cost or the clock cannot be told from outside): sixteen INDEPENDENT v_add_u32 per
+// round, nothing waits for anything, and the shader clock the kernel itself ran at -- s_memtime (shader clock) over s_memrealtime
+// (constant 100 MHz), taken by one lane per workgroup around the loop.
+constexpr int PEAK_ISSUE_OPS_PER_ITER = 16 * 4;
+__global__ __launch_bounds__(256) void k_peak_issue(int32_t* out, int iters, int32_t seed, unsigned long long* clocks) {
+  int32_t a[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) a[q] = seed + (int)threadIdx.x + q;
+  const int32_t k = 3;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[q]) : "v"(k));
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  int32_t x = 0;
+#pragma unroll
+  for (int q = 0; q < 16; q++) x ^= a[q];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = x;
+  if (threadIdx.x == 0 && clocks) { clocks[2 * (int64_t)blockIdx.x] = c1 - c0; clocks[2 * (int64_t)blockIdx.x + 1] = r1 - r0; }
+}
+
 }  // namespace mia

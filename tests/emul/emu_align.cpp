@@ -374,7 +374,18 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
     nib[(size_t)(q >> 3)] = (nib[(size_t)(q >> 3)] & ~(0xFu << (4 * (q & 7)))) | ((uint32_t)(ref_codes[p] > 4 ? 4 : ref_codes[p]) << (4 * (q & 7)));
   }
   BxPlan bp;
-  bx_plan(rp, ko, n_codes, ref_start, len1, pb, len2, strand, T, &bp);
+  // (opts >> 16 = d + 1: the QUICK plan for diagonal d alone -- bx_quick, what k_bx_plan<NW, 4> runs -- instead of the full plan)
+  const int quick_d = (opts >> 16) - 1;
+  if (quick_d >= 0) {
+    // (the reference as it stands is the unwrapped one: every start position counts; opts & 512: a circular reference whose last 256 codes
+    // are the wrap -- the places the bitmaps count are the ones in front of it)
+    const int64_t L = (opts & 512) && n_codes > 2 * 256 ? n_codes - 256 : n_codes;
+    std::vector<uint32_t> bits((size_t)(2 * KB_WORDS), 0u);
+    for (int64_t p = 0; p < L; p++) kmer_bits_insert(ref_codes, n_codes, p, bits.data(), bits.data() + KB_WORDS);
+    const KmerBits kb{bits.data(), bits.data() + KB_WORDS, (int32_t)L};
+    if (!bx_plan_quick(rp, ko, kb, n_codes, ref_start, len1, pb, len2, strand, quick_d, T, &bp)) { bp.mode = BX_NONE; bp.b0 = 0; }
+  }
+  else bx_plan(rp, ko, n_codes, ref_start, len1, pb, len2, strand, T, &bp);
   out6[5] = 0;
   if (bp.mode == BX_NONE) { plan5[3] = bp.b0; return 0; }      // (b0 = the reason, BXF_*)
   plan5[0] = bp.d0; plan5[1] = bp.w; plan5[2] = bp.dstar; plan5[3] = bp.b0; plan5[4] = bp.edge;
@@ -386,7 +397,7 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
     out6[0] = expect; out6[1] = bp.dstar; out6[2] = bp.dstar + len2 - 1; out6[3] = 0; out6[4] = 0;
     for (int r = 0; r < len2; r++) cols[r] = (int16_t)(bp.dstar + r);
   }
-  int cls = bx_class_of(bp.w) + (opts >> 4);
+  int cls = bx_class_of(bp.w) + ((opts >> 4) & 3);
   if (cls > 4) cls = 4;
   const int wc = bx_class_width(cls);
   const bool interior = bp.d0 >= 0 && len2 - 1 + bp.d0 + wc <= len1;

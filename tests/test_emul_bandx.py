@@ -43,6 +43,8 @@ def check(emul, oracle, spec, strand, ref, s, len1, read, stats, opts=None):
         k = stats["n"]
         opts = (k & 3) | (((k >> 2) % 3) << 4)          # trace forced or not, edge form or not, class widened by 0..2
     stats["n"] += 1
+    if "N" not in ref[s:s + len1] and "N" not in read:
+        check_quick(emul, oracle, spec, strand, ref, s, len1, read, stats)
     mode, out6, cols, plan = run_bandx(emul, oracle, spec, strand, ref, s, len1, read, opts)
     stats["mode%d" % mode] = stats.get("mode%d" % mode, 0) + 1
     if mode == 0:
@@ -63,6 +65,35 @@ def check(emul, oracle, spec, strand, ref, s, len1, read, stats, opts=None):
     assert all(int(cols[i]) == -2 for i in range(res.abr)) or out6[5] != 3, ctx
     assert out6[4] == len([x for x in rg.value.split(b"-") if x]) - 1 + len([x for x in fg.value.split(b"-") if x]) - 1, ctx
     return True
+
+
+def check_quick(emul, oracle, spec, strand, ref, s, len1, read, stats):
+    """The QUICK plan (bx_quick, round 6: what k_bx_plan<NW, 4> runs with d = the read's diagonal of the iteration before) asked about
+    EVERY diagonal of the window on which the read has at most BX_QUICK_MAX mismatches -- the right one, and any wrong one a second
+    copy or a repeat offers: whenever it plans the read, the stages that plan leads to must deliver dyn_prog's alignment over the
+    whole window, exactly as for the full plan."""
+    win = ref[s:s + len1]
+    n = len(read)
+    res = None
+    for d in range(0, len1 - n + 1):
+        if sum(1 for i in range(n) if read[i] != win[d + i]) > 8:
+            continue
+        stats["quick_asked"] = stats.get("quick_asked", 0) + 1
+        k = stats["quick_asked"]
+        opts = ((d + 1) << 16) | (k & 3) | (((k >> 2) % 3) << 4)
+        mode, out6, cols, plan = run_bandx(emul, oracle, spec, strand, ref, s, len1, read, opts)
+        if mode == 0 or out6[5] == 0:
+            continue
+        stats["quick_mode%d" % mode] = stats.get("quick_mode%d" % mode, 0) + 1
+        if res is None:
+            res = oc.Aln()
+            rg = C.create_string_buffer(1100)
+            fg = C.create_string_buffer(1100)
+            assert oracle.ora_align(win.encode(), len(win), read.encode(), n, None, C.byref(_pssm(oracle, spec, strand)), 1, C.byref(res), rg, fg, None, None) == 0
+        ctx = ("quick", d, spec, strand, win, read, plan, out6, (res.best, res.abc, res.aec, res.abr))
+        assert (out6[0], out6[1], out6[2], out6[3]) == (res.best, res.abc, res.aec, res.abr), ctx
+        r, f = script_to_strings(win, read, cols, res.abr, res.aer)
+        assert r == rg.value.decode() and f == fg.value.decode(), ctx
 
 
 def window(ref, pos, length, margin=50):
@@ -501,3 +532,56 @@ def test_window_wide_n_credit(emul, oracle, spec, strand):
         check(emul, oracle, spec, strand, ref, s, l1, read, stats)
     print("n_credit", spec, strand, sorted(stats.items()), finished)
     assert stats["n"] > 550 and finished > 150, (str(sorted(stats.items())), finished)
+
+
+def test_quick_plan_on_wrapped_references(emul, oracle):
+    """bx_quick's bitmaps count the start positions 0 .. L - 1 of a circular reference ONCE (the 256 codes behind L are the wrap's copies
+    of the first ones): a window over the origin holds a place or its copy, never both -- unless the window is longer than the reference,
+    which the quick plan must refuse.  References of 300 .. 3 000 bases, wrapped; reads anywhere, many over the origin; windows in
+    wrapped coordinates; substitutions, single indels; the repeats that a short circular reference makes of itself."""
+    rnd = random.Random(2026)
+    stats = {"n": 0}
+    for spec, strand in MATS[:3]:
+        for i in range(240):
+            L = rnd.choice([300, 420, 700, 1500, 3000])
+            core = "".join(rnd.choice("ACGT") for _ in range(L))
+            if i % 5 == 0:                                            # a tandem duplication inside the circle: repeated 10-mers
+                a = rnd.randint(0, L - 80)
+                core = core[:a + 40] + core[a:a + 40] + core[a + 80:]
+            ref = core + core[:256]
+            n = rnd.choice([60, 100, 100, 130])
+            pos = rnd.choice([L - rnd.randint(1, n), L - n - rnd.randint(0, 40), rnd.randint(0, L - 1), rnd.randint(0, 50)])
+            read = ref[pos:pos + n]
+            if len(read) < n:
+                continue
+            if i % 3 == 0:
+                at = rnd.randint(5, n - 5)
+                read = read[:at] + read[at + 1:] if i % 2 else read[:at] + rnd.choice("ACGT") + read[at:]
+            read = damage(rnd, read) if spec != "flat" else read
+            read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([0, 0, 1, 2, 4])))
+            s, l1 = window(ref, pos, len(read), margin=rnd.choice([50, 50, 120]))
+            if l1 < len(read) or l1 > 760:
+                continue
+            win = ref[s:s + l1]
+            res = None
+            for d in range(0, l1 - len(read) + 1):
+                if sum(1 for k in range(len(read)) if read[k] != win[d + k]) > 8:
+                    continue
+                stats["n"] += 1
+                opts = ((d + 1) << 16) | 512 | (stats["n"] & 3)
+                mode, out6, cols, plan = run_bandx(emul, oracle, spec, strand, ref, s, l1, read, opts)
+                if l1 > L:
+                    assert mode == 0, ("a window longer than the reference", L, l1)
+                if mode == 0 or out6[5] == 0:
+                    continue
+                stats["planned"] = stats.get("planned", 0) + 1
+                if res is None:
+                    res = oc.Aln()
+                    rg = C.create_string_buffer(1100)
+                    fg = C.create_string_buffer(1100)
+                    assert oracle.ora_align(win.encode(), len(win), read.encode(), len(read), None, C.byref(_pssm(oracle, spec, strand)), 1, C.byref(res), rg, fg, None, None) == 0
+                ctx = ("quick, wrapped", L, d, spec, strand, win, read, plan, out6, (res.best, res.abc, res.aec, res.abr))
+                assert (out6[0], out6[1], out6[2], out6[3]) == (res.best, res.abc, res.aec, res.abr), ctx
+                r, f = script_to_strings(win, read, cols, res.abr, res.aer)
+                assert r == rg.value.decode() and f == fg.value.decode(), ctx
+    assert stats["n"] > 500 and stats.get("planned", 0) > 300, stats

@@ -147,3 +147,10 @@ def test_fixed_point(full):
         rounds += 1
     assert cons == ref, rounds
     assert abs(len(cons) - len(f.ref)) < 100
+    if N == 5_000_000:
+        # the digests bench.py prints for configs4 (bench.certificate; tests/test_gpu_bench_workloads.py): same generator, same seed, same size
+        import json
+        import bench
+        want = json.load(open(os.path.join(GOLDEN, "bench_certificates.json")))["cfg4"]
+        got = bench.certificate(f.hip, cons, True)
+        assert {k: got[k] for k in ("consensus_sha256", "alignments_sha256", "consensus_len")} == {k: want[k] for k in ("consensus_sha256", "alignments_sha256", "consensus_len")}

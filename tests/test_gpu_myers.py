@@ -215,3 +215,44 @@ def test_ccheck_sized_pair_rows_from_the_device_table():
             cost = sum(1 for x, y in zip(ra, rb) if x == "-" or y == "-" or not (_bits(x) & _bits(y)))
             assert cost == d
     hip.close()
+
+
+def test_rows_of_a_pair_beyond_the_dpath_kernels_cap():
+    """a long pair whose distance lies BETWEEN k_myers_ond's cap (about sqrt(64 * sweep): ~260 for 1 000 characters,
+    ~360 for 2 000) and maxd is finished by the bit-vector kernel; the device table then holds no row for it (it was sized for
+    the cap) and the rows must come from the host's D-path walk -- the same rows, the same distance, as with the D-path kernel
+    switched off altogether.  A pair below the cap rides along (rows from the device table), and one with maxd = 0 (no distance
+    is admissible: the reference returns UINT_MAX without looking at the sequences)."""
+    import mia_amd
+    rng = np.random.default_rng(77)
+    hip = mia_amd.MiaHip(0)
+    os.environ["MIA_HIP_MYERS_NO_OND"] = "1"
+    try:
+        ref = mia_amd.MiaHip(0)
+    finally:
+        os.environ.pop("MIA_HIP_MYERS_NO_OND")
+    seen_beyond = 0
+    for la, subs, dels, ins in ((1000, 260, 15, 15), (2000, 380, 25, 25), (1500, 330, 10, 10), (1200, 20, 2, 2)):
+        a = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, la)].copy()
+        b = _edited_copy(rng, a, subs, dels, ins)
+        sa, sb = a.tobytes().decode(), b.tobytes().decode()
+        for mode in (0, 1, 2):
+            maxd = la          # far above the cap
+            d, ra, rb = hip.myers_align(sa, mode, sb, maxd)
+            d2, ra2, rb2 = ref.myers_align(sa, mode, sb, maxd)
+            assert d is not None and (d, ra, rb) == (d2, ra2, rb2), (la, mode, d, d2)
+            if d > 300:
+                seen_beyond += 1
+            if len(ra) == len(rb):
+                cost = sum(1 for x, y in zip(ra, rb) if x == "-" or y == "-" or not (_bits(x) & _bits(y)))
+                assert cost == d
+    assert seen_beyond >= 3
+    # maxd = 0 beside a D-path pair in one call: the pair without a cap must not be read as if it had been packed
+    a = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 900)].copy()
+    b = _edited_copy(rng, a, 5, 1, 1)
+    sa, sb = a.tobytes().decode(), b.tobytes().decode()
+    got = hip.myers([sa, sa, sa], [sb, sb, sb], [0, 0, 0], [0, 50, -3])
+    want = ref.myers([sa, sa, sa], [sb, sb, sb], [0, 0, 0], [0, 50, -3])
+    assert got[0] == 0xFFFFFFFF and got[2] == 0xFFFFFFFF and got[1] < 50 and (got == want).all()
+    hip.close()
+    ref.close()

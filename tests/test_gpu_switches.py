@@ -35,7 +35,11 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             # round 5: the tally records written by k_rec_params in every iteration (default: by k_cull_records, k_rec_params only where a link exists)
             "MIA_HIP_NO_CULL_RECORDS",
             # round 4, second half: every wavefront at priority 0 (default: the step's chain ahead of k_bxl_trace); smaller persistent grids
-            "MIA_HIP_BX_DEBUG=128", "MIA_HIP_BX_VALUES_PCT=50", "MIA_HIP_BX_TRACE_PCT=44"]
+            "MIA_HIP_BX_DEBUG=128", "MIA_HIP_BX_VALUES_PCT=50", "MIA_HIP_BX_TRACE_PCT=44",
+            # round 6: the planner's chain (count / scan / fill, quad kernels, window classes) instead of the plan's own open list
+            "MIA_HIP_NO_DIRECT_OPEN",
+            # round 6: the full plan (bx_anchors: every block looked up) for every read instead of the quick plan on the read's old diagonal first
+            "MIA_HIP_NO_QUICK_PLAN"]
 
 
 def two_iterations(mod, w, env):
@@ -76,3 +80,115 @@ def test_every_switch_gives_the_same_iterations(config):
             for k, name in enumerate(("consensus", "score", "as", "ae", "script", "tally", "gaps")):
                 x, y = base[it][k], got[it][k]
                 assert (x == y) if isinstance(x, str) else np.array_equal(x, y), (env, it, name)
+
+
+def test_rall_tally_on_reads_with_n_and_shared_starts(oracle):
+    """the position-specific tally's instance for reads of 129-256 bases (k_tally_binned<false, *, true>: EVERY row through
+    the runs of equal starts) had only the campaigns' coverage.  60 000 reads of 150 bases against a 3 kb circular reference (twenty
+    reads per start and strand: long runs; a twentieth of the reads runs over the origin), a fifth of them carrying N (the planes_ok ==
+    false route), both strands, ancient matrix: three iterations side by side with the ORACLE (every tally word of every column), then
+    the routing switches against the default, word for word."""
+    import gen_data
+    import mia_amd
+    from oracle_sample import check_subset_iterations
+    rng = np.random.default_rng(150)
+    ref = gen_data.random_reference(3000, seed=150)
+    n = 60_000
+    d = gen_data.make_reads(ref, n, 150, seed=151, circular=True, damage=True)
+    stored = gen_data.stored_orientation(d)
+    with_n = rng.random(n) < 0.2
+    for i in np.nonzero(with_n)[0]:
+        stored[i, rng.integers(0, 150, int(rng.integers(1, 4)))] = ord("N")
+    rc = d["strand"].astype(np.uint8)
+    as0 = d["start"].astype(np.int32)
+    ae0 = (as0 + 149).astype(np.int32)
+    pssm = mia_amd.read_pssm(os.path.join(GOLDEN, "ancient.submat.txt"))
+    done, _ = check_subset_iterations(mia_amd, oracle, ref, True, "ancient.submat.txt", pssm, stored, rc, np.ones(n, np.uint8), as0, ae0, iters=3)
+    assert done >= 2
+    w = {"pssm": pssm, "n": n, "stored": stored, "offsets": np.arange(n + 1, dtype=np.int64) * 150, "rc": rc, "as_": as0, "ae": ae0, "ref": ref, "circular": True}
+    base = two_iterations(mia_amd, w, None)
+    for env in ("MIA_HIP_NO_TALLY_RALL", "MIA_HIP_NO_TALLY_RUNS", "MIA_HIP_STRAND_SPLIT=0", "MIA_HIP_NO_BINNED_TALLY", "MIA_HIP_SORT2_UNPACKED"):
+        got = two_iterations(mia_amd, w, env)
+        for it in range(2):
+            for k, name in enumerate(("consensus", "score", "as", "ae", "script", "tally", "gaps")):
+                x, y = base[it][k], got[it][k]
+                assert (x == y) if isinstance(x, str) else np.array_equal(x, y), (env, it, name)
+
+
+@pytest.mark.parametrize("config", [1, 2], ids=["flat", "ancient"])
+def test_direct_open_list(config, oracle):
+    """Round 6: where the plan gives up on FEW reads it lists them itself and k_align_open takes them one per wavefront (align_all:
+    direct_open) -- no planner, no quad kernels.  That is every steady-state iteration, but never the first two of a run from mt311
+    (ambiguity codes, then the first iteration's reject count), which is all most tests run.  Here the run starts from a reference of
+    plain bases, so iteration 1 already takes the new route, with everything the planner used to sort out on the list: 1 500 reads of
+    100 bases with 20 % substitutions (the plan gives up: windows of class 0), 300 reads of 230 bases with as many (windows of 330
+    columns: class 1).  Against the oracle (every read, every tally word, three iterations), and -- with 200 reads of unknown strand added
+    (ST_SKIPPED, never re-aligned) -- against the planner's route (MIA_HIP_NO_DIRECT_OPEN), word for word."""
+    import bench
+    import gen_data
+    import mia_amd
+    from oracle_sample import check_subset_iterations
+    w = bench.make_workload(config, 60_000, 7)
+    rng = np.random.default_rng(66)
+    n0, ref = w["n"], w["plain_ref"]
+    long_n, long_len = 300, 230
+    d = gen_data.make_reads(ref, long_n, long_len, seed=67, circular=True, damage=config != 1)
+    n = n0 + long_n
+    stored = np.full((n, long_len), ord("A"), np.uint8)
+    stored[:n0, :100] = w["stored"]
+    stored[n0:] = gen_data.stored_orientation(d)
+    lens = np.concatenate([np.full(n0, 100, np.int32), np.full(long_n, long_len, np.int32)])
+    rc = np.concatenate([w["rc"], d["strand"].astype(np.uint8)])
+    as0 = np.concatenate([w["as_"], d["start"].astype(np.int32)])
+    ae0 = (as0 + lens - 1).astype(np.int32)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    # (heavily mutated reads away from the origin: one that is split there in one iteration and not in the next makes the reference list an
+    # AlnSeq slot that holds no record -- the library refuses that corner by name, MIA_HIP_ERR_RANGE, and it is not what this test is about)
+    inner = np.nonzero((as0 > 400) & (as0 < len(ref) - 700))[0]
+    long_inner = inner[inner >= n0]
+    for i in np.concatenate([rng.choice(inner[inner < n0], 1500, replace=False), long_inner]):
+        k = int(lens[i]) // 5
+        stored[i, rng.choice(int(lens[i]), k, replace=False)] = acgt[rng.integers(0, 4, k)]
+    done, _ = check_subset_iterations(mia_amd, oracle, ref, True, w["matrix_file"], w["pssm"], stored, rc, np.ones(n, np.uint8), as0, ae0, iters=3, lens=lens)
+    assert done >= 2
+    # (strand-unknown reads only in the comparison of the two routes: the oracle's pushed read store has no pass-1 records for them to point
+    # at -- tests/test_gpu_iteration.py::fixture_lin is such a read from pass 1 on, against the oracle)
+    sk = np.ones(n, np.uint8)
+    sk[rng.choice(n0, 200, replace=False)] = 0
+    offsets = np.zeros(n + 1, np.int64)
+    offsets[1:] = np.cumsum(lens)
+    flat = np.concatenate([stored[:n0, :100].reshape(-1), stored[n0:].reshape(-1)])
+
+    def run(env):
+        name, _, val = (env or "").partition("=")
+        if env:
+            os.environ[name] = val or "1"
+        try:
+            hip = mia_amd.MiaHip(0)
+        finally:
+            if env:
+                os.environ.pop(name, None)
+        hip.set_pssm(w["pssm"])
+        hip.upload_reads(flat, offsets, rc, sk, as0, ae0)
+        out, cur = [], ref
+        for _ in range(3):
+            cons = hip.iterate(cur, True)
+            sc, a, e = hip.alignments()
+            cols, rstart = hip.scripts()
+            t, g = hip.get_tally()
+            out.append((cons, sc.copy(), a.copy(), e.copy(), np.where(cols >= 0, cols.astype(np.int32) + rstart[:, None], cols.astype(np.int32)), t.copy(), g.copy()))
+            cur = cons
+        fate = hip.bx_counters()
+        hip.close()
+        return out, fate
+
+    base, fate = run(None)
+    other, _ = run("MIA_HIP_NO_DIRECT_OPEN")
+    known = sk.astype(bool)
+    for it in range(3):
+        for k, name in enumerate(("consensus", "score", "as", "ae", "script", "tally", "gaps")):
+            x, y = base[it][k], other[it][k]
+            if name == "script":            # (a strand-unknown read is never aligned: its script is whatever the buffer held)
+                x, y = x[known], y[known]
+            assert (x == y) if isinstance(x, str) else np.array_equal(x, y), (it, name)
+    assert fate[29] >= 1500, fate[29]          # BXC_OPEN of the last iteration: the list was in use (fewer than a twentieth of the reads: more, and the planner's quad kernels take them)
