@@ -1163,15 +1163,17 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
 // s_un leaves.  The family is at most bx_anchors' own, so the band is at least as wide as the full plan's: the values DP may have to
 // decide where the full plan would have -- never a wrong answer.  Not for tables that spell out N columns (kh.wild: every run's first
 // iteration), not for a window longer than the reference.  false: nothing decided, the full plan (bx_anchors ...) takes the read.
-struct KmerBits { const uint32_t* present; const uint32_t* repeated; int32_t ref_len; };      // ref_len = L (the places the bitmaps count); present == nullptr: none
-constexpr int64_t KB_WORDS = (int64_t)1 << (2 * DF_K - 5);      // words per bitmap
+// (the two bitmaps word by word side by side: one 8-byte load answers both questions about a 10-mer)
+struct alignas(8) KbPair { uint32_t present, repeated; };
+struct KmerBits { const KbPair* w; int32_t ref_len; };      // ref_len = L (the places the bitmaps count); w == nullptr: none
+constexpr int64_t KB_WORDS = (int64_t)1 << (2 * DF_K - 5);      // pairs (32 10-mers each)
 constexpr int BX_QUICK_MAX = 8;        // more rows with a loss on d than this: an indel, or a read that belongs elsewhere -- not worth the look-ups
 template <int NW>
 MIA_HD inline bool bx_quick(DiagScan<NW>& sc, const RefPlanes& rp, const KmerHash& kh, const KmerBits& kb, int s, int len1, int len2, int st, int d, const BxTab& T,
                             BxPlan* out) {
   constexpr int NB = bx_nb_max<NW>();
   out->mode = BX_NONE; out->b0 = 0;
-  if (!kb.present || kh.wild > 0 || d < 0 || d > len1 - len2 || len1 > kb.ref_len) return false;
+  if (!kb.w || kh.wild > 0 || d < 0 || d > len1 - len2 || len1 > kb.ref_len) return false;
   const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
   sc.seek(rp, (int64_t)s + d);
   uint64_t m1[NW];
@@ -1187,8 +1189,8 @@ MIA_HD inline bool bx_quick(DiagScan<NW>& sc, const RefPlanes& rp, const KmerHas
     kidx[b] = 0; dlv[b] = 0; w1[b] = 0; w2[b] = 0;
     if (b < nb_cut) {
       kidx[b] = bx_kmer_planes<NW>(sc, bx_block_row(b, len2, nb_cut));
-      w1[b] = kb.present[kidx[b] >> 5];
-      w2[b] = kb.repeated[kidx[b] >> 5];
+      const KbPair pr = kb.w[kidx[b] >> 5];
+      w1[b] = pr.present; w2[b] = pr.repeated;
       dlv[b] = dl[b];
     }
   }
@@ -1216,18 +1218,111 @@ MIA_HD inline bool bx_quick(DiagScan<NW>& sc, const RefPlanes& rp, const KmerHas
   if (out->mode == BX_NONE) { out->b0 = 0; return false; }
   return true;
 }
+// THE QUICK PLAN, SECOND FORM: one short indel.  A read that the one-diagonal form cannot plan -- in a steady-state iteration that is a
+// read with an indel, one in ten -- leaves the read's own diagonal d behind the indel for d2 = d + shift, |shift| <= BX_QUICK_SHIFT
+// (a deletion in the read moves it up, an insertion down).  The blocks in front of the indel are clean on d, the blocks behind it on
+// d2; a 10-mer that occurs once in the reference has ONE place, so a block that is found clean on either diagonal and is unique is
+// anchored there and nowhere else -- however it was found.  The family: those blocks, and the blocks whose 10-mer occurs nowhere; the
+// anchors: d in front, d2 behind (all of d's blocks before all of d2's, or this is not one indel and the full plan takes the read);
+// bx_finish's two-diagonal form writes the path down (the switch row between the last block on d and the first on d2) and proves the
+// band [min - g, max + g] exactly as for anchors that bx_anchors found in the table.  Every shift is tried, the one with the most blocks
+// behind the indel is taken (a wrong choice costs a wider band or the budget test, never a wrong answer: the anchors are true places).
+constexpr int BX_QUICK_SHIFT = 3;
+template <int NW>
+MIA_HD inline bool bx_quick2(DiagScan<NW>& sc, const RefPlanes& rp, const KmerHash& kh, const KmerBits& kb, int s, int len1, int len2, int st, int d, const BxTab& T,
+                             BxPlan* out) {
+  constexpr int NB = bx_nb_max<NW>();
+  out->mode = BX_NONE; out->b0 = 0;
+  if (!kb.w || kh.wild > 0 || d < 0 || d > len1 - len2 || len1 > kb.ref_len) return false;
+  const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
+  const int16_t* dl = T.dl + (st * (MAX_READ + 1) + len2) * BX_BLOCKS;
+  uint32_t kidx[NB], w1[NB], w2[NB];
+  int32_t dlv[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    kidx[b] = 0; dlv[b] = 0; w1[b] = 0; w2[b] = 0;
+    if (b < nb_cut) {
+      kidx[b] = bx_kmer_planes<NW>(sc, bx_block_row(b, len2, nb_cut));
+      const KbPair pr = kb.w[kidx[b] >> 5];
+      w1[b] = pr.present; w2[b] = pr.repeated;
+      dlv[b] = dl[b];
+    }
+  }
+  BX_LOADS_ISSUED();
+  uint32_t uniq = 0, absent = 0;               // bit b: the block's 10-mer occurs once / nowhere in the reference
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (b >= nb_cut) continue;
+    const bool present = ((w1[b] >> (kidx[b] & 31u)) & 1u) != 0u, repeated = ((w2[b] >> (kidx[b] & 31u)) & 1u) != 0u;
+    if (!present) absent |= 1u << b; else if (!repeated) uniq |= 1u << b;
+  }
+  // the unique blocks that are clean on diagonal x (bit b), for x = d - SHIFT .. d + SHIFT: one seek, then a column at a time
+  uint32_t on[2 * BX_QUICK_SHIFT + 1];
+  sc.seek(rp, (int64_t)s + d - BX_QUICK_SHIFT);
+#pragma unroll
+  for (int k = 0; k <= 2 * BX_QUICK_SHIFT; k++) {
+    if (k) sc.advance(rp, (int64_t)s + d - BX_QUICK_SHIFT + k);
+    uint64_t m[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) m[j] = bx_loss_rows<NW>(sc, j);
+    uint32_t c = 0;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      if (b >= nb_cut) continue;
+      const int o = bx_block_row(b, len2, nb_cut);
+      if (bx_count<NW>(m, o, o + DF_K) == 0) c |= 1u << b;
+    }
+    const int x = d - BX_QUICK_SHIFT + k;
+    on[k] = (x >= 0 && x <= len1 - len2) ? (c & uniq) : 0u;       // (the written-down path must stay inside the window: bx_anchors' BXF_PATH)
+  }
+  const uint32_t cd = on[BX_QUICK_SHIFT];
+  if (!cd) return false;                       // no anchor on the read's own diagonal (an indel in its first rows: the full plan's end-indel rescue)
+  const int b_first = 31 - df_clz32(cd);       // the last block anchored on d
+  int best = -1, best_n = 0;
+#pragma unroll
+  for (int k = 0; k <= 2 * BX_QUICK_SHIFT; k++) {
+    if (k == BX_QUICK_SHIFT) continue;
+    const uint32_t c2 = on[k];
+    if (!c2 || (c2 & ((2u << b_first) - 1u))) continue;            // nothing there, or a block of it in front of d's last: not "d, one indel, d2"
+    const int nn = df_popc32(c2);
+    if (nn > best_n) { best_n = nn; best = k; }
+  }
+  if (best < 0) return false;
+  const uint32_t c2 = on[best];
+  const int d2 = d - BX_QUICK_SHIFT + best;
+  const uint32_t fam = cd | c2 | absent;
+  int budget = -1, s_un = 0, nbv = 0;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (!((fam >> b) & 1u)) continue;
+    budget += dlv[b]; nbv++;
+    if ((absent >> b) & 1u) s_un += dlv[b];
+  }
+  if (nbv < BX_MIN_BLOCKS) return false;
+  const int b_lo = df_ctz32(cd), b_last = df_ctz32(c2), b_hi = 31 - df_clz32(c2);
+  BxAnchors an;
+  an.fail = 0; an.a_lo = d < d2 ? d : d2; an.a_hi = d < d2 ? d2 : d; an.d_first = d; an.d_last = d2; an.budget = budget; an.l_out = -1; an.s_un = s_un;
+  an.t_lo = bx_block_row(b_first, len2, nb_cut) + DF_K; an.t_hi = bx_block_row(b_last, len2, nb_cut);
+  if (an.t_lo < 1) an.t_lo = 1;
+  an.r_head = bx_block_row(b_lo, len2, nb_cut); an.r_tail = bx_block_row(b_hi, len2, nb_cut) + DF_K; an.rescue = 0; an.fine = 0; an.fc1 = 0; an.fc2 = 0; an.fmax = 0;
+  (void)R;
+  bx_finish<NW, 2>(sc, rp, an, s, len1, len2, st, T, out);
+  if (out->mode == BX_NONE) { out->b0 = 0; return false; }
+  return true;
+}
 // one reference place into the bitmaps (device: atomics; host: the tests)
-MIA_HD inline void kmer_bits_insert(const uint8_t* codes, int64_t n_codes, int64_t p, uint32_t* present, uint32_t* repeated) {
+MIA_HD inline void kmer_bits_insert(const uint8_t* codes, int64_t n_codes, int64_t p, KbPair* w) {
   uint32_t idx;
   uint64_t npos;
   if (kmer_wild_at(codes, n_codes, p, &idx, &npos) != 0) return;                  // (off the end, or an N inside: no path crosses such a place cleanly)
   const uint32_t bit = 1u << (idx & 31u);
+  KbPair* e = w + (idx >> 5);
 #if defined(__HIP_DEVICE_COMPILE__)
-  const uint32_t old = atomicOr(&present[idx >> 5], bit);
-  if (old & bit) atomicOr(&repeated[idx >> 5], bit);
+  const uint32_t old = atomicOr(&e->present, bit);
+  if (old & bit) atomicOr(&e->repeated, bit);
 #else
-  if (present[idx >> 5] & bit) repeated[idx >> 5] |= bit;
-  present[idx >> 5] |= bit;
+  if (e->present & bit) e->repeated |= bit;
+  e->present |= bit;
 #endif
 }
 
@@ -1272,10 +1367,10 @@ MIA_HD inline bool bx_plan_quick(const RefPlanes& rp, const KmerHash& ko, const 
   out->mode = BX_NONE; out->b0 = 0;
   if (!bx_plannable(rp, ko, n_ref, s, len1, len2)) return false;
   switch ((len2 + 63) >> 6) {
-    case 1: { DiagScan<1> sc; return sc.load_read(read_packed, len2) && bx_quick<1>(sc, rp, ko, kb, s, len1, len2, st, d, T, out); }
-    case 2: { DiagScan<2> sc; return sc.load_read(read_packed, len2) && bx_quick<2>(sc, rp, ko, kb, s, len1, len2, st, d, T, out); }
-    case 3: { DiagScan<3> sc; return sc.load_read(read_packed, len2) && bx_quick<3>(sc, rp, ko, kb, s, len1, len2, st, d, T, out); }
-    default: { DiagScan<4> sc; return sc.load_read(read_packed, len2) && bx_quick<4>(sc, rp, ko, kb, s, len1, len2, st, d, T, out); }
+    case 1: { DiagScan<1> sc; return sc.load_read(read_packed, len2) && (bx_quick<1>(sc, rp, ko, kb, s, len1, len2, st, d, T, out) || bx_quick2<1>(sc, rp, ko, kb, s, len1, len2, st, d, T, out)); }
+    case 2: { DiagScan<2> sc; return sc.load_read(read_packed, len2) && (bx_quick<2>(sc, rp, ko, kb, s, len1, len2, st, d, T, out) || bx_quick2<2>(sc, rp, ko, kb, s, len1, len2, st, d, T, out)); }
+    case 3: { DiagScan<3> sc; return sc.load_read(read_packed, len2) && (bx_quick<3>(sc, rp, ko, kb, s, len1, len2, st, d, T, out) || bx_quick2<3>(sc, rp, ko, kb, s, len1, len2, st, d, T, out)); }
+    default: { DiagScan<4> sc; return sc.load_read(read_packed, len2) && (bx_quick<4>(sc, rp, ko, kb, s, len1, len2, st, d, T, out) || bx_quick2<4>(sc, rp, ko, kb, s, len1, len2, st, d, T, out)); }
   }
 }
 

@@ -69,7 +69,8 @@ struct BxDev {
   int32_t* qlist;
   uint32_t* qlist_n;
   int32_t mark_all;
-  KmerBits kb;             // the two bitmaps the quick plan asks (present == nullptr: no quick plan)
+  KmerBits kb;             // the two bitmaps the quick plan asks (w == nullptr: no quick plan)
+  int32_t plane_words;     // phase 5 (the quick plan with the reference's planes in LDS): words per plane
 };
 // which entries of the plan's lists a launch of the band DPs takes
 enum { BX_PART_ALL = 0, BX_PART_HEAD = 1, BX_PART_TAIL = 2 };
@@ -213,9 +214,9 @@ __global__ __launch_bounds__(256) void k_kmer_hash(const uint8_t* codes, int64_t
 }
 
 // the quick plan's two bitmaps (bandx_body.h: KmerBits) from the start positions 0 .. L - 1 of the wrapped reference; both cleared before
-__global__ __launch_bounds__(256) void k_kmer_bits(const uint8_t* codes, int64_t n_codes, int64_t L, uint32_t* present, uint32_t* repeated) {
+__global__ __launch_bounds__(256) void k_kmer_bits(const uint8_t* codes, int64_t n_codes, int64_t L, KbPair* w) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p < L) kmer_bits_insert(codes, n_codes, p, present, repeated);
+  if (p < L) kmer_bits_insert(codes, n_codes, p, w);
 }
 
 // bit planes of every read (diag_filter.h: DiagScan::load_read), once per read set: words lo words, then words hi words
@@ -244,18 +245,21 @@ __global__ __launch_bounds__(256) void k_read_planes(ReadSet rs, int32_t words, 
 // (the stamps stay in registers; a block adds its four wavefronts' sums to one of 64 stripes at its end: an atomic per stamp and
 // wavefront on seven words made the launch six times as long)
 __device__ unsigned long long g_plan_clk[64 * 16];
-#define PLAN_CLK(k) do { if (bx.dbg & 512u) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pacc_[k] += now_ - pclk_; pclk_ = now_; } } while (0)
-#define PLAN_CLK_DECL unsigned long long pclk_ = (bx.dbg & 512u) ? __builtin_amdgcn_s_memtime() : 0ull, pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; __shared__ unsigned long long pclk_lds_[8]; if (threadIdx.x < 8) pclk_lds_[threadIdx.x] = 0
-#define PLAN_CLK_FLUSH do { if (bx.dbg & 512u) { if ((threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 7; q_++) atomicAdd(&pclk_lds_[q_], pacc_[q_]); __syncthreads(); \
+// (with the quick plan in front -- phase 4 -- it is that launch the stamps are taken in: the first launch proper then has an in_list and stays out)
+#define PLAN_CLK(k) do { if (pclk_on_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); pacc_[k] += now_ - pclk_; pclk_ = now_; } } while (0)
+#define PLAN_CLK_DECL const bool pclk_on_ = (bx.dbg & 512u) != 0u && (PH == 4 || PH == 5 || in_list == nullptr); unsigned long long pclk_ = pclk_on_ ? __builtin_amdgcn_s_memtime() : 0ull, pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; __shared__ unsigned long long pclk_lds_[8]; if (threadIdx.x < 8) pclk_lds_[threadIdx.x] = 0
+#define PLAN_CLK_FLUSH do { if (pclk_on_) { if ((threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 7; q_++) atomicAdd(&pclk_lds_[q_], pacc_[q_]); __syncthreads(); \
     if (threadIdx.x < 7) atomicAdd(&g_plan_clk[(blockIdx.x & 63) * 16 + threadIdx.x], pclk_lds_[threadIdx.x]); if (threadIdx.x == 7) atomicAdd(&g_plan_clk[(blockIdx.x & 63) * 16 + 11], 4ull); } } while (0)
 #else
 #define PLAN_CLK(k) do { } while (0)
 #define PLAN_CLK_DECL do { } while (0)
 #define PLAN_CLK_FLUSH do { } while (0)
 #endif
+constexpr int BX_QCH = 4;          // stretches of 256 reads a workgroup of the quick plan (phase 4) takes
 template <int NW, int PH>
 __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPlanes rp, KmerHash ko, int64_t n_ref, BxDev bx, const int32_t* in_list,
                                                   const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of) {
+  // PH: 0 everything in one launch; 1 / 2 / 3 the three launches of the full plan; 4 the quick plan, 5 the same with the reference's planes in LDS
   constexpr int SLOT_FINE = 2 * BX_NCLS + 2 + BXF_KINDS;     // blk_cnt: reads handed on to the third launch
   __shared__ int16_t loss_lds[BX_LOSS_WORDS];
   __shared__ BxAnchors cand_an[PH < 2 ? 256 : 1];
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
   __shared__ int32_t n_cand;
   __shared__ uint32_t blk_cnt[SLOT_FINE + 1], blk_base[2 * BX_NCLS + 1];   // per block: list appends, finished, seen, reasons, hand-overs
   PLAN_CLK_DECL;
-  if (PH == 1 && in_list && (int64_t)blockIdx.x * 256 >= (int64_t)*n_in_p) return;      // (the grid is sized for all reads: a short list leaves most of it nothing to do)
+  if (PH < 2 && in_list && (int64_t)blockIdx.x * 256 >= (int64_t)*n_in_p) return;      // (a short list leaves most of the grid nothing to do)
   for (int k = threadIdx.x; k < BX_LOSS_WORDS; k += 256) loss_lds[k] = bx.tab.loss[k];
   if (threadIdx.x == 0) n_cand = 0;
   if (threadIdx.x <= SLOT_FINE) blk_cnt[threadIdx.x] = 0;
@@ -341,38 +345,143 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     __syncthreads();
   };
   const bool marks = !in_list || bx.mark_all != 0;
-  if (PH == 4) {
-    // THE QUICK PLAN (bandx_body.h: bx_quick): the diagonal the read was aligned on before, asked first.  What it plans is emitted as by
-    // any other phase; everything else -- undecided, not plannable, strand unknown -- goes on qlist for the first launch proper.
-    DiagScan<NW> sc;
-    Rd r = fetch((int)threadIdx.x, sc);
-    BxPlan bp;
-    bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
-    BxAnchors an{};
-    bool planned = false;
-    if (r.ok && bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2) && load_planes(r, sc))
-      planned = bx_quick<NW>(sc, rp, ko, bx.kb, r.s, r.l1, r.len2, r.st, rs.as[r.i] - r.s, T, &bp);
-    if (!planned) { bp.mode = BX_NONE; bp.b0 = 0; }
-    const unsigned long long sm = __ballot(planned);
-    if ((threadIdx.x & 63) == 0 && sm) atomicAdd(&blk_cnt[2 * BX_NCLS + 1], (uint32_t)__popcll(sm));
-    Rd rr = r;
-    rr.ok = planned;
-    emit(rr, bp, planned, false, an);
-    // the undecided reads onto qlist: ONE global atomic per block (an atomic per wavefront on the one counter -- fifteen thousand of them,
-    // served one at a time -- made this launch longer than the full plan it replaces: 224 us)
-    __shared__ uint32_t q_cnt[4], q_base;
-    const bool to_q = t0 + threadIdx.x < total && !planned;
-    const unsigned long long qm = __ballot(to_q);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) q_cnt[wv] = (uint32_t)__popcll(qm);
-    __syncthreads();
-    if (threadIdx.x == 0) { const uint32_t tot = q_cnt[0] + q_cnt[1] + q_cnt[2] + q_cnt[3]; q_base = tot ? atomicAdd(bx.qlist_n, tot) : 0u; }
-    __syncthreads();
-    if (to_q) {
-      uint32_t before = 0;
-      for (int k = 0; k < wv; k++) before += q_cnt[k];
-      bx.qlist[q_base + before + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = (int32_t)(t0 + threadIdx.x);
+  if ((PH == 4 || PH == 5)) {
+    // THE QUICK PLAN (bandx_body.h: bx_quick, bx_quick2).  A workgroup takes BX_QCH stretches of 256 reads, one read per thread and stretch,
+    // through the one-diagonal form (the diagonal the read was aligned on before, asked first); the reads that leaves undecided -- one in
+    // ten: the reads with an indel -- are collected and taken through the one-indel form by the block's first threads; then ONE round of
+    // list reservations for all of them.  What the two forms leave -- one read in a hundred -- goes on qlist, the in_list of the full plan's
+    // launch(es) behind this one; a read that is not plannable at all (strand unknown, an N in it, a window the plan does not take) is left
+    // open here and now.
+    // (The first version emitted per stretch of 256 as the other phases do -- four barriers and two returning atomics on the lists'
+    // counters per block: 41 % of a wavefront's cycles were that wait, bx_quick itself 3 % (tools/plan_clk_probe.py) -- a counter that
+    // four thousand blocks add to serves them one at a time, 20 ns each.  Tried and dropped: the full plan for the hundredth read inside
+    // this launch, by the block's first threads (+ 59 us for the launch, the fork behind it that much later); the full plan's launches
+    // beside the band DPs, their lists the late ones (the step waits as long for them there as in front of the fork).)
+    constexpr int NL = 2 * BX_NCLS + 2, LQ = 2 * BX_NCLS, LO = 2 * BX_NCLS + 1;      // the lists a read can go on: the plan's ten, qlist, the open list
+    __shared__ uint8_t q_which[256 * BX_QCH];                          // list of the block's read li; 255: none (finished here, open without a list, or no such read)
+    __shared__ uint16_t q_rank[256 * BX_QCH], q_cand[256 * BX_QCH];
+    __shared__ uint32_t q_cnt[NL], q_base[NL], q_ncand, q_fin, q_seen, q_fail[BXF_KINDS];
+    if (threadIdx.x < NL) q_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < BXF_KINDS) q_fail[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { q_ncand = 0; q_fin = 0; q_seen = 0; }
+    // PHASE 5: the reference's three planes in LDS (a mitochondrion's are 6.5 KB).  A seek is a dozen 8-byte loads at an address of the
+    // lane's own -- every one of them sixty-four trips through the compute unit's one address unit --, the quick plan seeks twice per read,
+    // and with the table walks gone those loads and the bitmaps' were what a wavefront waited for (tools/plan_clk_probe.py: half its cycles)
+    extern __shared__ uint64_t lds_planes[];
+    if ((PH == 5)) {
+      const int pw = bx.plane_words;
+      for (int k = threadIdx.x; k < pw; k += 256) { lds_planes[k] = rp.lo[k]; lds_planes[pw + k] = rp.hi[k]; lds_planes[2 * pw + k] = rp.ok[k]; }
+      rp.lo = lds_planes; rp.hi = lds_planes + pw; rp.ok = lds_planes + 2 * pw;
     }
+    __syncthreads();
+    PLAN_CLK(0);
+    const int64_t tq = (int64_t)blockIdx.x * (256 * BX_QCH);
+    auto fetch_at = [&](int64_t t) -> Rd {
+      Rd r{0, 0, 0, 0, 0, false};
+      if (t >= total) return r;
+      r.i = (int32_t)t;
+      if (!rs.sk[r.i]) return r;
+      r.len2 = rs.len[r.i];
+      r.st = rs.rc[r.i] ? 1 : 0;
+      read_window(ref, rs.as[r.i], rs.ae[r.i], r.len2, &r.s, &r.l1);
+      r.ok = true;
+      return r;
+    };
+    // what a planned read leaves behind at once: its result (finished) or its plan (listed), its mark; returns its list, 255 for none
+    auto write_plan = [&](const Rd& r, const BxPlan& bp) -> int {
+      if (bp.mode == BX_DONE || bp.mode == BX_VALUES) {
+        const int expect = bx.umax[r.i] - bp.b0;                         // (the quick plan runs on the context's own reads: umax is there)
+        if (bp.mode == BX_DONE) {
+          rs.score[r.i] = expect;
+          rs.refstart[r.i] = r.s;
+          rs.abr[r.i] = 0;
+          rs.as[r.i] = r.s + bp.dstar;                   // src/mia_main.c:254-255
+          rs.ae[r.i] = r.s + bp.dstar + r.len2 - 1;
+          rs.status[r.i] = ST_DIAG;
+          bin_of[r.i] = -4;
+          return 255;
+        }
+        bx.expect[r.i] = expect;
+      }
+      bx.plan[r.i] = bx_pack(bp);
+      bin_of[r.i] = bx.listed_mark;
+      return bp.mode == BX_VALUES ? bx_class_of(bp.w) : BX_NCLS + bx_class_of(bp.w);
+    };
+    // a read the plan leaves open (given up on, not plannable, strand unknown): its mark, its reason, the open list if there is one
+    auto leave_open = [&](int32_t i, bool counted, int why) -> int {
+      bin_of[i] = 0;
+      if (counted && why > 0 && why < BXF_KINDS) atomicAdd(&q_fail[why], 1u);
+      return bx.open ? LO : 255;
+    };
+    auto place = [&](int li, int which) {
+      q_which[li] = (uint8_t)which;
+      if (which < NL) q_rank[li] = (uint16_t)atomicAdd(&q_cnt[which], 1u);
+    };
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < BX_QCH; c++) {
+      const int li = c * 256 + (int)threadIdx.x;
+      const int64_t t = tq + li;
+      DiagScan<NW> sc;
+      Rd r = fetch_at(t);
+      BxPlan bp;
+      bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
+      bool planned = false;
+      const bool plannable = r.ok && bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2);
+      const bool can = plannable && load_planes(r, sc);
+      PLAN_CLK(1);
+      if (can) planned = bx_quick<NW>(sc, rp, ko, bx.kb, r.s, r.l1, r.len2, r.st, rs.as[r.i] - r.s, T, &bp);
+      PLAN_CLK(2);
+      int which = 255;
+      if (planned) which = write_plan(r, bp);
+      else if (can) { q_cand[atomicAdd(&q_ncand, 1u)] = (uint16_t)li; which = 254; }       // (254: the one-indel form decides)
+      else if (t < total) which = leave_open((int32_t)t, r.ok, plannable ? BXF_READ : BXF_WINDOW);
+      place(li, which);
+      const unsigned long long fm = __ballot(planned && bp.mode == BX_DONE), sm = __ballot(r.ok);
+      if (lane == 0 && fm) atomicAdd(&q_fin, (uint32_t)__popcll(fm));
+      if (lane == 0 && sm) atomicAdd(&q_seen, (uint32_t)__popcll(sm));
+      if (!bx.lazy_scripts) bx_diag_scripts(rs, fm, r.i, bp.dstar, r.len2);
+      PLAN_CLK(3);
+    }
+    __syncthreads();
+    // ... the one-indel form, by as many threads as there are undecided reads
+    for (uint32_t k = threadIdx.x; k < ((q_ncand + 63u) & ~63u); k += 256) {            // (whole wavefronts: the ballots below)
+      const bool mine = k < q_ncand;
+      const int li = mine ? (int)q_cand[k] : 0;
+      DiagScan<NW> sc;
+      Rd r{0, 0, 0, 0, 0, false};
+      BxPlan bp;
+      bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
+      bool planned = false;
+      if (mine) {
+        r = fetch_at(tq + li);
+        if (r.ok && load_planes(r, sc)) planned = bx_quick2<NW>(sc, rp, ko, bx.kb, r.s, r.l1, r.len2, r.st, rs.as[r.i] - r.s, T, &bp);
+        place(li, planned ? write_plan(r, bp) : LQ);
+      }
+      const unsigned long long fm = __ballot(planned && bp.mode == BX_DONE);
+      if (lane == 0 && fm) atomicAdd(&q_fin, (uint32_t)__popcll(fm));
+      if (!bx.lazy_scripts) bx_diag_scripts(rs, fm, r.i, bp.dstar, r.len2);
+    }
+    PLAN_CLK(4);
+    __syncthreads();
+    // one reservation per list and block, then every read to its place
+    if (threadIdx.x < NL && q_cnt[threadIdx.x])
+      q_base[threadIdx.x] = atomicAdd(threadIdx.x == LQ ? bx.qlist_n : (threadIdx.x == LO ? bx.open_n : bxc(bx.ctr, BXC_LIST0 + threadIdx.x)), q_cnt[threadIdx.x]);
+    if (threadIdx.x == NL && q_fin) atomicAdd(bxc(bx.ctr, BXC_DONE_PLAN), q_fin);
+    if (threadIdx.x == NL + 1 && q_seen) atomicAdd(bxc(bx.ctr, BXC_SEEN), q_seen);
+    if (threadIdx.x == NL + 2 && q_ncand) atomicAdd(bxc(bx.ctr, BXC_FAIL0), q_ncand);      // (statistics: reads the one-diagonal form left to the one-indel form)
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + BXF_KINDS && threadIdx.x > 32 && q_fail[threadIdx.x - 32]) atomicAdd(bxc(bx.ctr, BXC_FAIL0 + (int)threadIdx.x - 32), q_fail[threadIdx.x - 32]);
+    __syncthreads();
+    PLAN_CLK(5);
+    for (int c = 0; c < BX_QCH; c++) {
+      const int li = c * 256 + (int)threadIdx.x, which = q_which[li];
+      if (which >= NL) continue;
+      const uint32_t at = q_base[which] + q_rank[li];
+      if (which == LQ) bx.qlist[at] = (int32_t)(tq + li);
+      else if (which == LO) bx.open[at] = (int32_t)(tq + li);
+      else bx.lists[(int64_t)which * bx.list_stride + at] = (int32_t)(tq + li);
+    }
+    PLAN_CLK(6);
+    PLAN_CLK_FLUSH;
     return;
   }
   if (PH < 2) {
@@ -384,7 +493,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     BxAnchors an{};
     bool waits = false, to_fine = false;
 #ifdef MIA_HIP_ALT_PATHS
-    if (PH == 1 && (bx.dbg & 512u)) {
+    if (PH == 1 && pclk_on_) {
       // the same stretches one after the other over the whole wavefront (a clock between them): what the kernel does, in four steps
       const bool pl = r.ok && bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2);
       PLAN_CLK(1);

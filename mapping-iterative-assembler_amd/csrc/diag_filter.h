@@ -133,6 +133,10 @@ MIA_HD inline int df_clz(uint64_t x) {   // x != 0
 #endif
 }
 
+MIA_HD inline int df_popc32(uint32_t x) { return df_popc((uint64_t)x); }
+MIA_HD inline int df_ctz32(uint32_t x) { return df_ctz((uint64_t)x); }            // x != 0
+MIA_HD inline int df_clz32(uint32_t x) { return df_clz((uint64_t)x) - 32; }      // x != 0
+
 // The read against every diagonal of a range: planes of the window slide past the read one bit per step.  NW = 64-bit
 // words per read plane, a template parameter so that every array index is static (registers, not scratch).
 template <int NW>

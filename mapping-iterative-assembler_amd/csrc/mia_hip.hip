@@ -78,8 +78,9 @@ struct mia_hip_ctx {
   uint32_t* d_prep_bar = nullptr; uint32_t prep_bar_count = 0; bool no_prep_fuse = false;   // k_ref_prep's grid barrier (MIA_HIP_NO_PREP_FUSE=1: six launches)
   // round 6: the band plan lists the reads it leaves open itself and k_align_open takes them one per wavefront (align_all: direct_open;
   // MIA_HIP_NO_DIRECT_OPEN=1, alt build: the planner's count / scan / fill and the quad kernels, as in every iteration with many open reads)
-  uint32_t* d_kbits = nullptr;          // the quick plan's bitmaps over all 4^10 10-mers (bandx_body.h: KmerBits), remade with the table
+  KbPair* d_kbits = nullptr;            // the quick plan's bitmaps over all 4^10 10-mers (bandx_body.h: KmerBits), remade with the table
   bool use_quick = true; int64_t quick_steps = 0;      // the quick plan in front of k_bx_plan's launches (MIA_HIP_NO_QUICK_PLAN=1, alt build: the full plan for every read)
+  bool direct_open_now = false;        // this alignment's open reads are on d_open_list (set by align_all, read by bx_join_and_retry)
   int32_t* d_open_list = nullptr; int64_t open_cap = 0; unsigned char* d_slabs_open = nullptr; bool use_direct_open = true; int64_t direct_open_steps = 0;   // k_cons_tail's barrier counter (d_prep_bar + 1; MIA_HIP_NO_TAIL_FUSE=1: four launches)
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
   bool zero_copy = true;        // mia_hip_iterate: the last kernel writes consensus and counters into pinned host memory itself (MIA_HIP_NO_ZERO_COPY=1: two copies)
@@ -914,9 +915,23 @@ static int bx_join_and_retry(mia_hip_ctx* ctx) {
   // mia_hip_iterate's counting sort on stream2 waits for -- see queue_cull)
   hipEvent_t stop = (aside && (ctx->ext_events & 8u)) ? ctx->ev_fork : nullptr;
   ctx->align_end_signalled = stop != nullptr;
-  hipError_t e = cols <= 64 * 4 ? launch_window<4>(ctx, 0, ctx->d_retry2, 0, range, nullptr, aside, stop)
-               : cols <= 64 * 8 ? launch_window<8>(ctx, 1, ctx->d_retry2, 0, range, nullptr, aside, stop)
-                                : launch_window<12>(ctx, 2, ctx->d_retry2, 0, range, nullptr, aside, stop);
+  hipError_t e;
+  if (ctx->direct_open_now) {
+    // the plan's own open list and the band DPs' retry list in ONE launch, a read of either per wavefront (k_align_open): the planner's
+    // stream has had nothing to do in this alignment -- no kernel beside the DPs for the open reads, no wait for that stream here
+    RefInfo ref{ctx->d_ref, ctx->L, ctx->wrap, ctx->explicit_win};
+    if (stage_begin(ctx, STG_TRACE)) return MIA_HIP_ERR_NOMEM;
+    launch_k(k_align_open, dim3(OPEN_WGS), dim3(64), 0, ctx->stream, stop, ctx->rs, ref, (const int32_t*)ctx->d_pssm, ctx->packs, (const int32_t*)ctx->d_open_list,
+             (const uint32_t*)(ctx->d_bx_ctr + (size_t)BXC_OPEN * BXC_STRIDE), ctx->d_slabs_open, (int64_t)OPEN_SLAB_BYTES, ctx->d_wide_list, ctx->d_bins + 3 * N_BINS, ctx->dbg,
+             (const int32_t*)ctx->d_retry2, (const uint32_t*)(range + 1));
+    stage_end(ctx, STG_TRACE);
+    e = hipGetLastError();
+    if (e != hipSuccess) { ctx->err = std::string("k_align_open launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
+    return MIA_HIP_OK;
+  }
+  e = cols <= 64 * 4 ? launch_window<4>(ctx, 0, ctx->d_retry2, 0, range, nullptr, aside, stop)
+    : cols <= 64 * 8 ? launch_window<8>(ctx, 1, ctx->d_retry2, 0, range, nullptr, aside, stop)
+                     : launch_window<12>(ctx, 2, ctx->d_retry2, 0, range, nullptr, aside, stop);
   if (e != hipSuccess) { ctx->err = std::string("k_align_window (band retry list) launch: ") + hipGetErrorString(e); return MIA_HIP_ERR_DEVICE; }
   if (aside) {
     if (!ctx->planner_end_signalled) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));      // (the planner's chain ends here)
@@ -1029,6 +1044,7 @@ static void align_counters_collect(mia_hip_ctx* ctx, const int32_t* hb, bool fil
     }
   }
   for (int k = 0; k < BXC_COUNTERS; k++) ctx->bx_last[k] = bx ? h_bxc[k * BXC_STRIDE] : 0;
+  if (bx) ctx->bx_last[BXC_CUR_VALUES] = h_filter[1];      // (statistics: reads the quick plan left to the full plan -- the lanes kernels have no use for this slot)
   if (plain) ctx->plain_retried += h_hdr[PH_RETRIED_PLAIN];
 }
 
@@ -1037,6 +1053,7 @@ static int align_all(mia_hip_ctx* ctx) {
   const int64_t n = ctx->rs.n;
   const int wrap = ctx->wrap;
   ctx->bx_pending_join = false;
+  ctx->direct_open_now = false;
   if (!ctx->spec_ok) { ctx->spec_pending = false; ctx->abort_if = nullptr; }
   ctx->bx_planner_aside = false;
   ctx->planner_end_signalled = false; ctx->align_end_signalled = false;
@@ -1116,7 +1133,7 @@ static int align_all(mia_hip_ctx* ctx) {
       const KmerHash kh{ctx->d_khash, ctx->d_khash_ovf, kslots - 1, kh_shift_for(kslots), ctx->kh_entries > 0 ? BX_WILD : 0};
       // (the quick plan's bitmaps: made wherever the table is made for a reference without spelled-out N columns)
       const bool want_bits = ctx->use_quick && kh.wild == 0;
-      if (want_bits && !ctx->d_kbits && dev_alloc(ctx, &ctx->d_kbits, (size_t)(2 * KB_WORDS))) return MIA_HIP_ERR_NOMEM;
+      if (want_bits && !ctx->d_kbits && dev_alloc(ctx, &ctx->d_kbits, (size_t)KB_WORDS)) return MIA_HIP_ERR_NOMEM;
       if (fused_prep) {
         RefPrep rp2;
         rp2.ascii = ctx->ascii_src; rp2.L = ctx->pend_L; rp2.wl = ctx->pend_wl; rp2.total = ctx->pend_total; rp2.codes = ctx->d_ref;
@@ -1141,8 +1158,8 @@ static int align_all(mia_hip_ctx* ctx) {
       hipLaunchKernelGGL(k_kmer_hash, dim3((unsigned)((wrap + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, ctx->d_khash, ctx->d_khash_ovf,
                          kh.mask, kh.shift, kh.wild);
       if (want_bits) {
-        HIPCHK(hipMemsetAsync(ctx->d_kbits, 0, (size_t)(2 * KB_WORDS) * 4, ctx->stream));
-        hipLaunchKernelGGL(k_kmer_bits, dim3((unsigned)((ctx->L + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, (int64_t)ctx->L, ctx->d_kbits, ctx->d_kbits + KB_WORDS);
+        HIPCHK(hipMemsetAsync(ctx->d_kbits, 0, (size_t)KB_WORDS * sizeof(KbPair), ctx->stream));
+        hipLaunchKernelGGL(k_kmer_bits, dim3((unsigned)((ctx->L + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, (int64_t)wrap, (int64_t)ctx->L, ctx->d_kbits);
       }
       }
       if (n > ctx->bx_cap) {
@@ -1243,6 +1260,7 @@ static int align_all(mia_hip_ctx* ctx) {
                       !(ctx->bx_dbg & (4u | 8u));
       }
       bd.open = nullptr; bd.open_n = ctx->d_bx_ctr + (size_t)BXC_OPEN * BXC_STRIDE;
+      ctx->direct_open_now = direct_open;
       if (direct_open) {
         if (n > ctx->open_cap) { if (dev_alloc(ctx, &ctx->d_open_list, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->open_cap = n; }
         if (!ctx->d_slabs_open && hipMalloc((void**)&ctx->d_slabs_open, (size_t)OPEN_SLAB_BYTES * OPEN_WGS) != hipSuccess) return MIA_HIP_ERR_NOMEM;
@@ -1283,9 +1301,12 @@ static int align_all(mia_hip_ctx* ctx) {
       // in ten of a steady-state iteration are finished or listed there for a tenth of the full plan's instructions; the rest goes on a
       // list (the diagonal filter's: d_left_list, d_filter_n[1]) that the launches below take as their in_list.  Not against a table that
       // spells out N columns (every run's first iteration), not with the diagonal filter in front, not with the early tally's marks.
-      const bool quick = split && new_flow && !run_filter && !early && want_bits && !(ctx->bx_dbg & 32u);
+      const bool quick = split && new_flow && !run_filter && !early && want_bits && !(ctx->bx_dbg & 32u) && bd.umax != nullptr;      // (the context's own reads: their U is at hand)
       bd.qlist = nullptr; bd.qlist_n = ctx->d_filter_n + 1; bd.mark_all = 0;
-      bd.kb = KmerBits{quick ? ctx->d_kbits : nullptr, quick ? ctx->d_kbits + KB_WORDS : nullptr, ctx->L};
+      bd.kb = KmerBits{quick ? ctx->d_kbits : nullptr, ctx->L};
+      // (the reference's planes in LDS for the quick plan while they are small: 38 KB holds a hundred thousand columns)
+      const bool quick_lds = quick && words * 24 <= 38 * 1024;
+      bd.plane_words = (int32_t)(quick_lds ? words : 0);
       if (quick) {
         if (n > ctx->left_cap) { if (dev_alloc(ctx, &ctx->d_left_list, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->left_cap = n; }
         bd.qlist = ctx->d_left_list;
@@ -1296,19 +1317,24 @@ static int align_all(mia_hip_ctx* ctx) {
         const int32_t* in_list = (run_filter || quick) ? ctx->d_left_list : nullptr;
         const dim3 pb(256);
         const int nwords = (ctx->max_len + 63) >> 6;       // 64-row words of the longest read
+        // behind the quick plan the full plan has one read in a hundred left: without fine blocks ONE launch (phase 0: the reads with anchors on
+        // two diagonals by the block's first threads -- a second launch would be a second chain through the table, 40 us, for fifty workgroups)
+        const bool one_launch = quick && !fine;
         if (quick) {
-          const dim3 pg((unsigned)((n + 255) / 256));
+          const dim3 pg((unsigned)((n + 256 * BX_QCH - 1) / (256 * BX_QCH)));
           hipEvent_t done = nullptr;
           const int32_t* in_list = nullptr;               // (this launch walks all n reads)
-#define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, 0, ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
-          switch (nwords) { case 1: MIA_PLAN(1, 4); break; case 2: MIA_PLAN(2, 4); break; case 3: MIA_PLAN(3, 4); break; default: MIA_PLAN(4, 4); break; }
+#define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, (size_t)(PHV == 5 ? words * 24 : 0), ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
+          if (quick_lds) { switch (nwords) { case 1: MIA_PLAN(1, 5); break; case 2: MIA_PLAN(2, 5); break; case 3: MIA_PLAN(3, 5); break; default: MIA_PLAN(4, 5); break; } }
+          else { switch (nwords) { case 1: MIA_PLAN(1, 4); break; case 2: MIA_PLAN(2, 4); break; case 3: MIA_PLAN(3, 4); break; default: MIA_PLAN(4, 4); break; } }
 #undef MIA_PLAN
           bd.mark_all = 1;
         }
-        for (int phase = split ? 1 : 0; phase <= last_phase; phase++) {
+        const int phase_first = (split && !one_launch) ? 1 : 0, phase_last = one_launch ? 0 : last_phase;
+        for (int phase = phase_first; phase <= phase_last; phase++) {
           const dim3 pg(phase >= 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
           // (the fork event rides on the last launch's own completion signal: no marker between the plan and the values DP)
-          hipEvent_t done = (fork_by_launch && phase == last_phase && !planner_head_first) ? ctx->ev_fork : nullptr;
+          hipEvent_t done = (fork_by_launch && phase == phase_last && !planner_head_first) ? ctx->ev_fork : nullptr;
 #define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, 0, ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
 #define MIA_PLAN_NW(PHV) switch (nwords) { case 1: MIA_PLAN(1, PHV); break; case 2: MIA_PLAN(2, PHV); break; case 3: MIA_PLAN(3, PHV); break; default: MIA_PLAN(4, PHV); break; }
           switch (phase) {
@@ -1441,15 +1467,8 @@ static int align_all(mia_hip_ctx* ctx) {
     ck("plan_count");
     int32_t* d_retry_cnt = hdr + PH_RETRY + 1;
     if (direct_open) {
-      // the planner's whole chain is this one launch (the last on its stream: it signals ev_join itself, see bx_join_and_retry)
-      const bool sig = ctx->bx_planner_aside && ctx->bx_pending_join && (ctx->ext_events & 4u);
-      if (stage_begin(ctx, STG_TRACE, ps)) return MIA_HIP_ERR_NOMEM;
-      launch_k(k_align_open, dim3(OPEN_WGS), dim3(64), 0, ps, sig ? ctx->ev_join : nullptr, ctx->rs, ref, (const int32_t*)ctx->d_pssm, ctx->packs, (const int32_t*)ctx->d_open_list,
-               (const uint32_t*)(ctx->d_bx_ctr + (size_t)BXC_OPEN * BXC_STRIDE), ctx->d_slabs_open, (int64_t)OPEN_SLAB_BYTES, ctx->d_wide_list, d_wide_count, ctx->dbg);
-      stage_end(ctx, STG_TRACE, ps);
-      HIPCHK(hipGetLastError());
-      ctx->planner_end_signalled = sig;
-      ck("open list");
+      // (the plan's open list is taken by the alignment's LAST launch, together with the band DPs' retry list: bx_join_and_retry)
+      ctx->planner_end_signalled = false;
     } else {
     if (!planner_head_first) {
     hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(512), 0, ps, d_count, d_off, hdr, 0, ctx->d_list);      // (writes the quad bins' padding itself: -1 = empty slot)

@@ -37,7 +37,7 @@ struct RefPrep {
   int64_t nib_words; uint32_t* nib;
   uint32_t* bar; uint32_t bar_target;
   uint32_t* stuck;        // pinned host word: set if the barrier was given up on (a part of the grid never arrived)
-  uint32_t* kbits;        // the quick plan's bitmaps (bandx_body.h: KmerBits; 2 * KB_WORDS words: present, repeated), or nullptr
+  KbPair* kbits;          // the quick plan's bitmaps (bandx_body.h: KmerBits; KB_WORDS pairs), or nullptr
 };
 // the barrier's wait is bounded: a grid that is not wholly resident (device partitioned, compute units masked) must end in an error,
 // not in a wait for ever -- one second by the constant 100 MHz clock (s_memrealtime), a hundred thousand times what a launch of
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_ref_prep(RefPrep a) {
   uint4* ks = reinterpret_cast<uint4*>(a.kslot);
   for (int64_t k = tid; k < (int64_t)a.kslots; k += nth) ks[k] = make_uint4(KH_EMPTY, KH_EMPTY, KH_EMPTY, KH_EMPTY);
   for (int64_t k = tid; k < a.ctrl_words; k += nth) a.ctrl[k] = 0;
-  if (a.kbits) { uint4* kb4 = reinterpret_cast<uint4*>(a.kbits); for (int64_t k = tid; k < 2 * KB_WORDS / 4; k += nth) kb4[k] = make_uint4(0u, 0u, 0u, 0u); }
+  if (a.kbits) { uint4* kb4 = reinterpret_cast<uint4*>(a.kbits); for (int64_t k = tid; k < KB_WORDS / 2; k += nth) kb4[k] = make_uint4(0u, 0u, 0u, 0u); }
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_ref_prep(RefPrep a) {
   const int64_t wrap = (int64_t)a.total - 64;
   ref_planes_body(a.codes, (int64_t)a.total, a.plane_words, a.plo, a.phi, a.pok);
   for (int64_t w = tid; w < a.nib_words; w += nth) a.nib[w] = ref_nibble_word(a.codes, wrap, w);
-  if (a.kbits) for (int64_t p = tid; p < a.L; p += nth) kmer_bits_insert(a.codes, wrap, p, a.kbits, a.kbits + KB_WORDS);
+  if (a.kbits) for (int64_t p = tid; p < a.L; p += nth) kmer_bits_insert(a.codes, wrap, p, a.kbits);
   if (a.kwild > 0)        // N columns spelled out: 64 positions per workgroup and round (every thread of the block: barriers inside)
     for (int64_t p0 = (int64_t)blockIdx.x * 64; p0 < wrap; p0 += (int64_t)gridDim.x * 64) kmer_hash_insert_block(a.codes, wrap, p0, a.kslot, a.kovf, a.kmask, a.kshift, a.kwild);
   else

@@ -449,14 +449,17 @@ __global__ __launch_bounds__(64) void k_align_window(ReadSet rs, RefInfo ref, co
 // each of them (strand unknown: ST_SKIPPED; the window's class; the exact kernel's list for what no class holds) and then the window DP
 // of that class.  One launch instead of the planner's count / scan / fill / seed, the quad kernel and four window launches -- for the
 // few hundred reads per million a steady-state iteration leaves open (align_all: direct_open).  slab_bytes: the widest class's.
+// list_b / count_b_p (or nullptr): a second list behind the first -- the reads the band DPs could not finish (their retry list): the last
+// launch of the alignment takes both, a read of either kind per wavefront, in the time one of them takes.
 __global__ __launch_bounds__(64) void k_align_open(ReadSet rs, RefInfo ref, const int32_t* pssm2, PackSet ps, const int32_t* list, const uint32_t* count_p,
-                                                    unsigned char* trace_slabs, int64_t slab_bytes, int32_t* wide_list, int32_t* wide_count, uint32_t dbg) {
+                                                    unsigned char* trace_slabs, int64_t slab_bytes, int32_t* wide_list, int32_t* wide_count, uint32_t dbg,
+                                                    const int32_t* list_b, const uint32_t* count_b_p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SUB_LDS_BYTES];
-  const int count = (int)*count_p;
+  const int count_a = (int)*count_p, count = count_a + (list_b ? (int)*count_b_p : 0);
   __builtin_amdgcn_s_setprio(3);
   DevWave wave(lds_raw, trace_slabs + (int64_t)blockIdx.x * slab_bytes);
   for (int w = blockIdx.x; w < count; w += gridDim.x) {
-    const int i = list[w];
+    const int i = w < count_a ? list[w] : list_b[w - count_a];
     if (!rs.sk[i]) { if (wave.lane() == 0) rs.status[i] = ST_SKIPPED; continue; }      // (k_plan_count's mark for a read reiterate_assembly skips: src/mia_main.c:178)
     AlignArgs a;
     int s, l1;

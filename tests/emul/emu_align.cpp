@@ -380,9 +380,9 @@ extern "C" int emu_bandx(const uint8_t* ref_codes, int64_t n_codes, int ref_star
     // (the reference as it stands is the unwrapped one: every start position counts; opts & 512: a circular reference whose last 256 codes
     // are the wrap -- the places the bitmaps count are the ones in front of it)
     const int64_t L = (opts & 512) && n_codes > 2 * 256 ? n_codes - 256 : n_codes;
-    std::vector<uint32_t> bits((size_t)(2 * KB_WORDS), 0u);
-    for (int64_t p = 0; p < L; p++) kmer_bits_insert(ref_codes, n_codes, p, bits.data(), bits.data() + KB_WORDS);
-    const KmerBits kb{bits.data(), bits.data() + KB_WORDS, (int32_t)L};
+    std::vector<KbPair> bits((size_t)KB_WORDS, KbPair{0u, 0u});
+    for (int64_t p = 0; p < L; p++) kmer_bits_insert(ref_codes, n_codes, p, bits.data());
+    const KmerBits kb{bits.data(), (int32_t)L};
     if (!bx_plan_quick(rp, ko, kb, n_codes, ref_start, len1, pb, len2, strand, quick_d, T, &bp)) { bp.mode = BX_NONE; bp.b0 = 0; }
   }
   else bx_plan(rp, ko, n_codes, ref_start, len1, pb, len2, strand, T, &bp);

@@ -76,7 +76,8 @@ def check_quick(emul, oracle, spec, strand, ref, s, len1, read, stats):
     n = len(read)
     res = None
     for d in range(0, len1 - n + 1):
-        if sum(1 for i in range(n) if read[i] != win[d + i]) > 8:
+        # (the one-diagonal form wants few mismatches on d; the one-indel form -- bx_quick2 -- a clean stretch at the read's head)
+        if sum(1 for i in range(n) if read[i] != win[d + i]) > 8 and sum(1 for i in range(min(n, 24)) if read[i] != win[d + i]) > 1:
             continue
         stats["quick_asked"] = stats.get("quick_asked", 0) + 1
         k = stats["quick_asked"]
@@ -565,7 +566,7 @@ def test_quick_plan_on_wrapped_references(emul, oracle):
             win = ref[s:s + l1]
             res = None
             for d in range(0, l1 - len(read) + 1):
-                if sum(1 for k in range(len(read)) if read[k] != win[d + k]) > 8:
+                if sum(1 for k in range(len(read)) if read[k] != win[d + k]) > 8 and sum(1 for k in range(min(len(read), 24)) if read[k] != win[d + k]) > 1:
                     continue
                 stats["n"] += 1
                 opts = ((d + 1) << 16) | 512 | (stats["n"] & 3)

@@ -128,29 +128,28 @@ def test_direct_open_list(config, oracle):
     import gen_data
     import mia_amd
     from oracle_sample import check_subset_iterations
-    w = bench.make_workload(config, 60_000, 7)
+    w = bench.make_workload(config, 1000, 7)                  # (for the reference, the matrix and its file name)
     rng = np.random.default_rng(66)
-    n0, ref = w["n"], w["plain_ref"]
-    long_n, long_len = 300, 230
-    d = gen_data.make_reads(ref, long_n, long_len, seed=67, circular=True, damage=config != 1)
+    ref = w["plain_ref"]
+    # a LINEAR run (no -c): nothing is split at the origin, so no read can be split in one iteration and whole in the next -- the corner the
+    # library refuses by name (MIA_HIP_ERR_RANGE) and that is not what this test is about
+    n0, long_n, long_len = 60_000, 300, 230
+    d0 = gen_data.make_reads(ref, n0, 100, seed=68, circular=False, damage=config != 1)
+    d = gen_data.make_reads(ref, long_n, long_len, seed=67, circular=False, damage=config != 1)
     n = n0 + long_n
     stored = np.full((n, long_len), ord("A"), np.uint8)
-    stored[:n0, :100] = w["stored"]
+    stored[:n0, :100] = gen_data.stored_orientation(d0)
     stored[n0:] = gen_data.stored_orientation(d)
     lens = np.concatenate([np.full(n0, 100, np.int32), np.full(long_n, long_len, np.int32)])
-    rc = np.concatenate([w["rc"], d["strand"].astype(np.uint8)])
-    as0 = np.concatenate([w["as_"], d["start"].astype(np.int32)])
+    rc = np.concatenate([d0["strand"].astype(np.uint8), d["strand"].astype(np.uint8)])
+    as0 = np.concatenate([d0["start"].astype(np.int32), d["start"].astype(np.int32)])
     ae0 = (as0 + lens - 1).astype(np.int32)
     acgt = np.frombuffer(b"ACGT", np.uint8)
-    # (heavily mutated reads away from the origin: one that is split there in one iteration and not in the next makes the reference list an
-    # AlnSeq slot that holds no record -- the library refuses that corner by name, MIA_HIP_ERR_RANGE, and it is not what this test is about)
-    inner = np.nonzero((as0 > 400) & (as0 < len(ref) - 700))[0]
-    long_inner = inner[inner >= n0]
-    for i in np.concatenate([rng.choice(inner[inner < n0], 1500, replace=False), long_inner]):
+    for i in np.concatenate([rng.choice(n0, 1500, replace=False), np.arange(n0, n)]):
         k = int(lens[i]) // 5
         stored[i, rng.choice(int(lens[i]), k, replace=False)] = acgt[rng.integers(0, 4, k)]
-    done, _ = check_subset_iterations(mia_amd, oracle, ref, True, w["matrix_file"], w["pssm"], stored, rc, np.ones(n, np.uint8), as0, ae0, iters=3, lens=lens)
-    assert done >= 2
+    done, _ = check_subset_iterations(mia_amd, oracle, ref, False, w["matrix_file"], w["pssm"], stored, rc, np.ones(n, np.uint8), as0, ae0, iters=3, lens=lens)
+    assert done >= 1            # (the reference IS the reads' genome: the consensus may repeat it at once)
     # (strand-unknown reads only in the comparison of the two routes: the oracle's pushed read store has no pass-1 records for them to point
     # at -- tests/test_gpu_iteration.py::fixture_lin is such a read from pass 1 on, against the oracle)
     sk = np.ones(n, np.uint8)
@@ -172,7 +171,7 @@ def test_direct_open_list(config, oracle):
         hip.upload_reads(flat, offsets, rc, sk, as0, ae0)
         out, cur = [], ref
         for _ in range(3):
-            cons = hip.iterate(cur, True)
+            cons = hip.iterate(cur, False)
             sc, a, e = hip.alignments()
             cols, rstart = hip.scripts()
             t, g = hip.get_tally()
@@ -191,4 +190,4 @@ def test_direct_open_list(config, oracle):
             if name == "script":            # (a strand-unknown read is never aligned: its script is whatever the buffer held)
                 x, y = x[known], y[known]
             assert (x == y) if isinstance(x, str) else np.array_equal(x, y), (it, name)
-    assert fate[29] >= 1500, fate[29]          # BXC_OPEN of the last iteration: the list was in use (fewer than a twentieth of the reads: more, and the planner's quad kernels take them)
+    assert fate[29] >= 1500, fate              # BXC_OPEN of the last iteration: the list was in use (fewer than a twentieth of the reads: more, and the planner's quad kernels take them)

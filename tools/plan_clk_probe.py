@@ -32,6 +32,8 @@ hip.sync()
 hip._l.mia_hip_debug_plan_clk(hip._h, out)
 v = list(out)
 names = ["set-up", "fetch + window + plannable", "planes", "anchors", "finish", "emit", "hand-over"]
+if not first and not os.environ.get("MIA_HIP_NO_QUICK_PLAN"):        # the quick plan is in front (steady state): its stretches
+    names = ["set-up", "fetch + window + planes (x4)", "one diagonal, bx_quick (x4)", "results and marks (x4)", "barrier + one indel, bx_quick2", "list reservations", "list entries"]
 tot = sum(v[:7])
 waves = max(v[11], 1)
 print("config", cfg, "reads", n_reads, "first iteration" if first else "steady", "| wavefronts", waves // K, "per launch; cycles per wavefront (s_memtime, 100 MHz):")
@@ -40,3 +42,12 @@ for k, nm in enumerate(names):
 st = hip.stage_stats()
 print("  k_bx_plan stage ms per step (instrumented):", st["k_bx_plan"][0] / K)
 hip.close()
+hip2 = mia_amd.MiaHip(0)
+pipe2 = bench.Pipeline(hip2, w)
+c2 = w["ref"]
+for _ in range(4):
+    c2 = pipe2.step(c2)
+ctr = hip2.bx_counters()
+print("  last step's counters: seen %d, finished by the plan %d, values lists %s, trace lists %s, late lists %s, quick -> one-indel form %d, quick -> full plan %d, open %d" %
+      (ctr[15], ctr[12], ctr[0:5], ctr[5:10], ctr[24:29], ctr[16], ctr[10], ctr[29]))
+hip2.close()
