@@ -71,6 +71,11 @@ struct BxDev {
   int32_t mark_all;
   KmerBits kb;             // the two bitmaps the quick plan asks (w == nullptr: no quick plan)
   int32_t plane_words;     // phase 5 (the quick plan with the reference's planes in LDS): words per plane
+  // mia_hip_iterate forks behind the QUICK plan: the trace DP of its lists -- the longest kernel of the step -- starts there, and the full
+  // plan's launch for the hundredth read the quick plan left runs beside it, in front of the values DP on the context's stream.  What that
+  // launch lists goes on the LATE lists (the trace DP is reading its own by then), which the trace launch behind the values DP takes,
+  // values and trace plans alike
+  int32_t to_late;
 };
 // which entries of the plan's lists a launch of the band DPs takes
 enum { BX_PART_ALL = 0, BX_PART_HEAD = 1, BX_PART_TAIL = 2 };
@@ -323,21 +328,22 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     // (every read is marked by exactly one launch of the plan -- the one that finishes it: so it is listed exactly once)
     if (bx.open) bxl_append(bx.open, bx.open_n, mark_open && bp.mode != BX_DONE && bp.mode != BX_VALUES && bp.mode != BX_TRACE, r.i);
     // list appends and counters go through the block: one global atomic per block and list instead of one per wavefront
-    int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? BX_NCLS + bx_class_of(bp.w) : -1);
+    const bool late = bx.to_late != 0;
+    int which = bp.mode == BX_VALUES ? bx_class_of(bp.w) : (bp.mode == BX_TRACE ? (late ? 0 : BX_NCLS) + bx_class_of(bp.w) : -1);
     uint32_t rank = 0;
     if (which >= 0) rank = atomicAdd(&blk_cnt[which], 1u);
     if (to_fine) rank = atomicAdd(&blk_cnt[SLOT_FINE], 1u);
     if (bp.mode == BX_DONE) atomicAdd(&blk_cnt[2 * BX_NCLS], 1u);
     if (r.ok && bp.mode == BX_NONE && bp.b0 > 0 && bp.b0 < BXF_KINDS) atomicAdd(&blk_cnt[2 * BX_NCLS + 2 + bp.b0], 1u);
     __syncthreads();
-    if (threadIdx.x < 2 * BX_NCLS && blk_cnt[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(bxc(bx.ctr, BXC_LIST0 + threadIdx.x), blk_cnt[threadIdx.x]);
+    if (threadIdx.x < 2 * BX_NCLS && blk_cnt[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(bxc(bx.ctr, (late ? BXC_LATE0 : BXC_LIST0) + threadIdx.x), blk_cnt[threadIdx.x]);
     if (threadIdx.x == 2 * BX_NCLS && blk_cnt[2 * BX_NCLS]) atomicAdd(bxc(bx.ctr, BXC_DONE_PLAN), blk_cnt[2 * BX_NCLS]);
     if (threadIdx.x == 2 * BX_NCLS + 1 && blk_cnt[2 * BX_NCLS + 1]) atomicAdd(bxc(bx.ctr, BXC_SEEN), blk_cnt[2 * BX_NCLS + 1]);
     if (threadIdx.x > 2 * BX_NCLS + 2 && threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS && blk_cnt[threadIdx.x])
       atomicAdd(bxc(bx.ctr, BXC_FAIL0 + (int)threadIdx.x - 2 * BX_NCLS - 2), blk_cnt[threadIdx.x]);
     if (threadIdx.x == SLOT_FINE && blk_cnt[SLOT_FINE]) blk_base[2 * BX_NCLS] = atomicAdd(bx.cand2_n, blk_cnt[SLOT_FINE]);
     __syncthreads();
-    if (which >= 0) bx.lists[(int64_t)which * bx.list_stride + blk_base[which] + rank] = r.i;
+    if (which >= 0) bx.lists[(int64_t)((late ? 2 * BX_NCLS : 0) + which) * bx.list_stride + blk_base[which] + rank] = r.i;
     if (to_fine) { BxCandRec rec; rec.i = r.i; rec.an = an; bx.cand2[blk_base[2 * BX_NCLS] + rank] = rec; }
     if (!bx.lazy_scripts) bx_diag_scripts(rs, __ballot(bp.mode == BX_DONE), r.i, bp.dstar, r.len2);
     __syncthreads();

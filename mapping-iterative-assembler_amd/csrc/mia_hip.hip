@@ -1301,8 +1301,12 @@ static int align_all(mia_hip_ctx* ctx) {
       // in ten of a steady-state iteration are finished or listed there for a tenth of the full plan's instructions; the rest goes on a
       // list (the diagonal filter's: d_left_list, d_filter_n[1]) that the launches below take as their in_list.  Not against a table that
       // spells out N columns (every run's first iteration), not with the diagonal filter in front, not with the early tally's marks.
-      const bool quick = split && new_flow && !run_filter && !early && want_bits && !(ctx->bx_dbg & 32u) && bd.umax != nullptr;      // (the context's own reads: their U is at hand)
-      bd.qlist = nullptr; bd.qlist_n = ctx->d_filter_n + 1; bd.mark_all = 0;
+      const bool quick = split && new_flow && !run_filter && !early && !split_dp && want_bits && !(ctx->bx_dbg & 32u) && bd.umax != nullptr;      // (the context's own reads: their U is at hand)
+      bd.qlist = nullptr; bd.qlist_n = ctx->d_filter_n + 1; bd.mark_all = 0; bd.to_late = 0;
+      // mia_hip_iterate: the fork is behind the QUICK plan (BxDev::to_late) -- values DP and late trace are on the context's stream there, behind
+      // the full plan's launch, so no wait between streams is added; mia_hip_realign keeps every launch of the plan in front of the fork
+      // (... and only where the plan lists its open reads itself: the planner's kernels on stream2 would want every read's mark at the fork)
+      const bool fork_at_quick = quick && ctx->deferred && direct_open && !planner_head_first && !(ctx->bx_dbg & (4u | 8u));
       bd.kb = KmerBits{quick ? ctx->d_kbits : nullptr, ctx->L};
       // (the reference's planes in LDS for the quick plan while they are small: 38 KB holds a hundred thousand columns)
       const bool quick_lds = quick && words * 24 <= 38 * 1024;
@@ -1322,19 +1326,23 @@ static int align_all(mia_hip_ctx* ctx) {
         const bool one_launch = quick && !fine;
         if (quick) {
           const dim3 pg((unsigned)((n + 256 * BX_QCH - 1) / (256 * BX_QCH)));
-          hipEvent_t done = nullptr;
+          hipEvent_t done = (fork_at_quick && fork_by_launch) ? ctx->ev_fork : nullptr;
           const int32_t* in_list = nullptr;               // (this launch walks all n reads)
 #define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, (size_t)(PHV == 5 ? words * 24 : 0), ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
           if (quick_lds) { switch (nwords) { case 1: MIA_PLAN(1, 5); break; case 2: MIA_PLAN(2, 5); break; case 3: MIA_PLAN(3, 5); break; default: MIA_PLAN(4, 5); break; } }
           else { switch (nwords) { case 1: MIA_PLAN(1, 4); break; case 2: MIA_PLAN(2, 4); break; case 3: MIA_PLAN(3, 4); break; default: MIA_PLAN(4, 4); break; } }
 #undef MIA_PLAN
           bd.mark_all = 1;
+          if (fork_at_quick) {
+            if (!fork_by_launch) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+            bd.to_late = 1;
+          }
         }
         const int phase_first = (split && !one_launch) ? 1 : 0, phase_last = one_launch ? 0 : last_phase;
         for (int phase = phase_first; phase <= phase_last; phase++) {
           const dim3 pg(phase >= 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
           // (the fork event rides on the last launch's own completion signal: no marker between the plan and the values DP)
-          hipEvent_t done = (fork_by_launch && phase == phase_last && !planner_head_first) ? ctx->ev_fork : nullptr;
+          hipEvent_t done = (fork_by_launch && phase == phase_last && !planner_head_first && !fork_at_quick) ? ctx->ev_fork : nullptr;
 #define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, 0, ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
 #define MIA_PLAN_NW(PHV) switch (nwords) { case 1: MIA_PLAN(1, PHV); break; case 2: MIA_PLAN(2, PHV); break; case 3: MIA_PLAN(3, PHV); break; default: MIA_PLAN(4, PHV); break; }
           switch (phase) {
@@ -1357,6 +1365,7 @@ static int align_all(mia_hip_ctx* ctx) {
             HIPCHK(hipEventRecord(ctx->ev_v1, ctx->stream4));
           }
         }
+        bd.to_late = 0;
       }
       stage_end(ctx, STG_BX_PLAN);
       HIPCHK(hipGetLastError());
@@ -1378,7 +1387,7 @@ static int align_all(mia_hip_ctx* ctx) {
           // stay on the context's stream, right behind the plan -- a cross-stream wait costs 20-30 us each way, and it is the
           // planner with the full-window kernels (short, done long before) that moves to stream2.
           hipStream_t vs = ctx->deferred ? ctx->stream : ctx->stream2;
-          if (!fork_by_launch) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+          if (!fork_by_launch && !fork_at_quick) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
           HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
           HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
           if (early) HIPCHK(hipStreamWaitEvent(ctx->stream4, ctx->ev_fork, 0));
