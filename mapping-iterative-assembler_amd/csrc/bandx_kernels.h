@@ -23,8 +23,8 @@ namespace mia {
 
 // counters of the pipeline; each on a cache line of its own (BXC_STRIDE words apart): thousands of wavefronts add to them,
 // and atomics on one line are served one after the other
-enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_OPEN = 29, BXC_CAND = 30, BXC_CAND2 = 31, BXC_COUNTERS = 32 };     // CAND: reads handed from the plan's first launch to its second; CAND2: on to the third (fine blocks)
-static_assert(BXC_SEEN < BXC_FAIL0 && BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_OPEN && BXC_OPEN < BXC_CAND && BXC_CAND < BXC_COUNTERS, "counter layout");     // OPEN: reads the plan leaves to the full-window kernels (BxDev::open)
+enum { BXC_LIST0 = 0, BXC_CUR_VALUES = 2 * BX_NCLS, BXC_CUR_TRACE, BXC_DONE_PLAN, BXC_DONE_VALUES, BXC_DONE_TRACE, BXC_SEEN, BXC_FAIL0 = 16, BXC_LATE0 = 24, BXC_OPEN = 29, BXC_CAND = 30, BXC_CAND2 = 31, BXC_LATE2_0 = 32, BXC_COUNTERS = 40 };     // LATE2: what the full plan lists beside the DPs (BxDev::to_late); the first 32 are what mia_hip_bx_counters reports     // CAND: reads handed from the plan's first launch to its second; CAND2: on to the third (fine blocks)
+static_assert(BXC_SEEN < BXC_FAIL0 && BXC_FAIL0 + BXF_KINDS <= BXC_LATE0 && BXC_LATE0 + BX_NCLS <= BXC_OPEN && BXC_OPEN < BXC_CAND && BXC_CAND2 < BXC_LATE2_0 && BXC_LATE2_0 + BX_NCLS <= BXC_COUNTERS, "counter layout");     // OPEN: reads the plan leaves to the full-window kernels (BxDev::open)
 constexpr int BXC_STRIDE = 64;
 constexpr int BXC_WORDS = BXC_COUNTERS * BXC_STRIDE;
 __device__ __forceinline__ uint32_t* bxc(const uint32_t* ctr, int k) { return const_cast<uint32_t*>(ctr) + (size_t)k * BXC_STRIDE; }
@@ -39,7 +39,7 @@ struct BxDev {
   int32_t rplane_words;
   uint32_t* plan;          // [n] packed BxPlan of a read on a list
   int32_t* expect;         // [n] U - b0: the score of the plan's diagonal
-  int32_t* lists;          // [3 * BX_NCLS][list_stride] read indices: values lists, trace lists, late trace lists (what the values DP could not finish)
+  int32_t* lists;          // [4 * BX_NCLS][list_stride] read indices: values lists, trace lists, late trace lists (what the values DP could not finish), second late lists (what the full plan lists beside the DPs: to_late)
   int32_t* retry;          // reads no band kernel could finish (the reference's index-0 quirk ...): the one-read-per-wavefront window kernel takes them
   int32_t* retry_n;        // ... their number
   int32_t listed_mark;     // bin_of of a read on a list: -5 (the planner leaves it alone: it runs BESIDE the band kernels), or 0 (open: round 2's order)
@@ -71,10 +71,10 @@ struct BxDev {
   int32_t mark_all;
   KmerBits kb;             // the two bitmaps the quick plan asks (w == nullptr: no quick plan)
   int32_t plane_words;     // phase 5 (the quick plan with the reference's planes in LDS): words per plane
-  // mia_hip_iterate forks behind the QUICK plan: the trace DP of its lists -- the longest kernel of the step -- starts there, and the full
-  // plan's launch for the hundredth read the quick plan left runs beside it, in front of the values DP on the context's stream.  What that
-  // launch lists goes on the LATE lists (the trace DP is reading its own by then), which the trace launch behind the values DP takes,
-  // values and trace plans alike
+  // mia_hip_iterate forks behind the QUICK plan: both band DPs start there (the trace DP of its lists is the longest kernel of the step),
+  // and the full plan's launch for the hundredth read the quick plan left runs beside them on the context's stream.  What that launch
+  // lists goes on the SECOND LATE lists (the DPs are reading their own by then), values and trace plans alike; a trace launch of their
+  // own takes them (k_bxl_trace_late2), beside the one behind the values DP
   int32_t to_late;
 };
 // which entries of the plan's lists a launch of the band DPs takes
@@ -264,15 +264,20 @@ constexpr int BX_QCH = 4;          // stretches of 256 reads a workgroup of the 
 template <int NW, int PH>
 __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPlanes rp, KmerHash ko, int64_t n_ref, BxDev bx, const int32_t* in_list,
                                                   const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of) {
-  // PH: 0 everything in one launch; 1 / 2 / 3 the three launches of the full plan; 4 the quick plan, 5 the same with the reference's planes in LDS
+  // PH: 0 everything in one launch; 1 / 2 / 3 the three launches of the full plan; 4 the quick plan, 5 the same with the reference's planes in
+  // LDS; 6 = phase 0 over a list that may be LONGER than the grid (the quick plan's undecided reads, taken beside the band DPs by a grid
+  // the chip holds at once: four thousand workgroups, nearly all with nothing to do, queue for slots the persistent DP grids hold, and the
+  // launch is not over until the last of them has had one): the same code with a loop around it -- an instance of its own, the loop costs
+  // registers
+  constexpr int P = PH == 6 ? 0 : PH;
   constexpr int SLOT_FINE = 2 * BX_NCLS + 2 + BXF_KINDS;     // blk_cnt: reads handed on to the third launch
   __shared__ int16_t loss_lds[BX_LOSS_WORDS];
-  __shared__ BxAnchors cand_an[PH < 2 ? 256 : 1];
-  __shared__ uint8_t cand_tid[PH < 2 ? 256 : 1];
+  __shared__ BxAnchors cand_an[P < 2 ? 256 : 1];
+  __shared__ uint8_t cand_tid[P < 2 ? 256 : 1];
   __shared__ int32_t n_cand;
   __shared__ uint32_t blk_cnt[SLOT_FINE + 1], blk_base[2 * BX_NCLS + 1];   // per block: list appends, finished, seen, reasons, hand-overs
   PLAN_CLK_DECL;
-  if (PH < 2 && in_list && (int64_t)blockIdx.x * 256 >= (int64_t)*n_in_p) return;      // (a short list leaves most of the grid nothing to do)
+  if (P < 2 && in_list && (int64_t)blockIdx.x * 256 >= (int64_t)*n_in_p) return;      // (a short list leaves most of the grid nothing to do)
   for (int k = threadIdx.x; k < BX_LOSS_WORDS; k += 256) loss_lds[k] = bx.tab.loss[k];
   if (threadIdx.x == 0) n_cand = 0;
   if (threadIdx.x <= SLOT_FINE) blk_cnt[threadIdx.x] = 0;
@@ -280,9 +285,11 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
   BxTab T = bx.tab;
   T.loss = loss_lds;
   const int64_t total = in_list ? (int64_t)*n_in_p : n_all;
-  const int64_t t0 = (int64_t)blockIdx.x * 256;
+  int64_t t0 = (int64_t)blockIdx.x * 256;      // (PH 6: a workgroup takes every gridDim-th stretch of the list)
+  // (a launch beside the band DPs -- to_late -- is a short chain the step waits for: ahead of the DPs' wavefronts wherever a SIMD holds both)
+  if (bx.to_late) __builtin_amdgcn_s_setprio(3);
   // a read the 10-mers cannot vouch for goes on to the third launch instead of being given up
-  const bool fine_on = (PH == 1 || PH == 2) && bx.cand2 != nullptr;
+  const bool fine_on = (P == 1 || P == 2) && bx.cand2 != nullptr;
 
   struct Rd { int32_t i; int len2, s, l1, st; bool ok; };
   auto fetch = [&](int tid, DiagScan<NW>& sc) -> Rd {
@@ -336,14 +343,14 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     if (bp.mode == BX_DONE) atomicAdd(&blk_cnt[2 * BX_NCLS], 1u);
     if (r.ok && bp.mode == BX_NONE && bp.b0 > 0 && bp.b0 < BXF_KINDS) atomicAdd(&blk_cnt[2 * BX_NCLS + 2 + bp.b0], 1u);
     __syncthreads();
-    if (threadIdx.x < 2 * BX_NCLS && blk_cnt[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(bxc(bx.ctr, (late ? BXC_LATE0 : BXC_LIST0) + threadIdx.x), blk_cnt[threadIdx.x]);
+    if (threadIdx.x < 2 * BX_NCLS && blk_cnt[threadIdx.x]) blk_base[threadIdx.x] = atomicAdd(bxc(bx.ctr, (late ? BXC_LATE2_0 : BXC_LIST0) + threadIdx.x), blk_cnt[threadIdx.x]);
     if (threadIdx.x == 2 * BX_NCLS && blk_cnt[2 * BX_NCLS]) atomicAdd(bxc(bx.ctr, BXC_DONE_PLAN), blk_cnt[2 * BX_NCLS]);
     if (threadIdx.x == 2 * BX_NCLS + 1 && blk_cnt[2 * BX_NCLS + 1]) atomicAdd(bxc(bx.ctr, BXC_SEEN), blk_cnt[2 * BX_NCLS + 1]);
     if (threadIdx.x > 2 * BX_NCLS + 2 && threadIdx.x < 2 * BX_NCLS + 2 + BXF_KINDS && blk_cnt[threadIdx.x])
       atomicAdd(bxc(bx.ctr, BXC_FAIL0 + (int)threadIdx.x - 2 * BX_NCLS - 2), blk_cnt[threadIdx.x]);
     if (threadIdx.x == SLOT_FINE && blk_cnt[SLOT_FINE]) blk_base[2 * BX_NCLS] = atomicAdd(bx.cand2_n, blk_cnt[SLOT_FINE]);
     __syncthreads();
-    if (which >= 0) bx.lists[(int64_t)((late ? 2 * BX_NCLS : 0) + which) * bx.list_stride + blk_base[which] + rank] = r.i;
+    if (which >= 0) bx.lists[(int64_t)((late ? 3 * BX_NCLS : 0) + which) * bx.list_stride + blk_base[which] + rank] = r.i;
     if (to_fine) { BxCandRec rec; rec.i = r.i; rec.an = an; bx.cand2[blk_base[2 * BX_NCLS] + rank] = rec; }
     if (!bx.lazy_scripts) bx_diag_scripts(rs, __ballot(bp.mode == BX_DONE), r.i, bp.dstar, r.len2);
     __syncthreads();
@@ -490,7 +497,8 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     PLAN_CLK_FLUSH;
     return;
   }
-  if (PH < 2) {
+  for (;;) {        // (one pass -- except PH 6: a stretch of the list per pass)
+  if (P < 2) {
     PLAN_CLK(0);
     DiagScan<NW> sc;
     Rd r = fetch((int)threadIdx.x, sc);
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     BxAnchors an{};
     bool waits = false, to_fine = false;
 #ifdef MIA_HIP_ALT_PATHS
-    if (PH == 1 && pclk_on_) {
+    if (P == 1 && pclk_on_) {
       // the same stretches one after the other over the whole wavefront (a clock between them): what the kernel does, in four steps
       const bool pl = r.ok && bx_plannable(rp, ko, n_ref, r.s, r.l1, r.len2);
       PLAN_CLK(1);
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
         }
       }
     }
-    const unsigned long long sm = __ballot(r.ok);
+    const unsigned long long sm = __ballot(r.ok && !bx.mark_all);      // (mark_all: the quick plan in front has seen -- and counted -- every read of this list)
     if ((threadIdx.x & 63) == 0 && sm) atomicAdd(&blk_cnt[2 * BX_NCLS + 1], (uint32_t)__popcll(sm));
     // (a waiting read's mark is written by the launch that finishes it)
     Rd rr = r;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     emit(rr, bp, marks && t0 + threadIdx.x < total && !waits, to_fine, an);
     PLAN_CLK(5);
     if (bx.early && !in_list && t0 + threadIdx.x < total) bx.early[t0 + threadIdx.x] = bp.mode == BX_DONE ? 1 : 0;      // (every read passes here once)
-    if (PH == 1) {                                  // hand the waiting reads over: one reservation per block
+    if (P == 1) {                                  // hand the waiting reads over: one reservation per block
       __shared__ uint32_t cand_base;
       __syncthreads();
       if (threadIdx.x == 0 && n_cand) cand_base = atomicAdd(bx.cand_n, (uint32_t)n_cand);
@@ -579,19 +587,18 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     }
   }
   __syncthreads();
-  if ((PH == 0 && n_cand == 0) || (bx.dbg & 32u)) return;      // (MIA_HIP_BX_DEBUG=32, profiling only: no second phase)
-  if (PH == 3 && !bx.cand2) return;
-  // the candidates: this block's own (PH 0), or a stretch of the list per step (PH 2, 3; every thread loops alike: emit has barriers)
-  constexpr bool listed = PH >= 2;
-  const BxCandRec* const list = PH == 3 ? bx.cand2 : bx.cand;
-  const int64_t n_list = PH == 3 ? (int64_t)*bx.cand2_n : (PH == 2 ? (int64_t)*bx.cand_n : 0);
-  constexpr int per = PH == 3 ? 256 / BX_FINE_LANES : 256;            // reads per block and step
+  if (!((P == 0 && n_cand == 0) || (bx.dbg & 32u)) && !(P == 3 && !bx.cand2)) {      // (MIA_HIP_BX_DEBUG=32, profiling only: no second phase)
+  // the candidates: this block's own (P 0), or a stretch of the list per step (P 2, 3; every thread loops alike: emit has barriers)
+  constexpr bool listed = P >= 2;
+  const BxCandRec* const list = P == 3 ? bx.cand2 : bx.cand;
+  const int64_t n_list = P == 3 ? (int64_t)*bx.cand2_n : (P == 2 ? (int64_t)*bx.cand_n : 0);
+  constexpr int per = P == 3 ? 256 / BX_FINE_LANES : 256;            // reads per block and step
   for (int64_t c0 = listed ? (int64_t)blockIdx.x * per : 0; listed ? c0 < n_list : c0 == 0; c0 += listed ? (int64_t)gridDim.x * per : 1) {
     DiagScan<NW> sc;
     Rd r{0, 0, 0, 0, 0, false};
     BxPlan bp;
     bp.mode = BX_NONE; bp.d0 = 0; bp.w = 1; bp.dstar = 0; bp.b0 = 0; bp.edge = 0;
-    const int slot = PH == 3 ? (int)threadIdx.x / BX_FINE_LANES : (int)threadIdx.x, u = PH == 3 ? (int)threadIdx.x % BX_FINE_LANES : 0;
+    const int slot = P == 3 ? (int)threadIdx.x / BX_FINE_LANES : (int)threadIdx.x, u = P == 3 ? (int)threadIdx.x % BX_FINE_LANES : 0;
     const bool mine = listed ? c0 + slot < n_list : (int)threadIdx.x < n_cand;
     bool to_fine = false;
     BxAnchors an{};
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
         an = cand_an[threadIdx.x];
       }
       load_planes(r, sc);
-      if (PH == 3) {
+      if (P == 3) {
         // the fine blocks (bx_fine_anchors): more blocks, more budget; the reason the 10-mers gave stands if they do not help either
         const int why = an.rescue;
         an.rescue = 0;
@@ -651,6 +658,14 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     if (to_fine) rr.ok = false;
     emit(rr, bp, marks && rr.ok, to_fine, an);
     if (bx.early && rr.ok && bp.mode == BX_DONE) bx.early[r.i] = 1;
+  }
+  }
+  if (PH != 6) return;
+  t0 += (int64_t)gridDim.x * 256;
+  if (t0 >= total) return;
+  __syncthreads();
+  if (threadIdx.x == 0) n_cand = 0;
+  __syncthreads();
   }
 }
 
@@ -944,6 +959,10 @@ __global__ __launch_bounds__(256, 4) void k_bxl_trace(ReadSet rs, RefInfo ref, B
 __global__ __launch_bounds__(256, 4) void k_bxl_trace_late(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
   if (!(bx.dbg & 128u)) __builtin_amdgcn_s_setprio(3);
   bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, 2 * BX_NCLS, BXC_LATE0);
+}
+__global__ __launch_bounds__(256, 4) void k_bxl_trace_late2(ReadSet rs, RefInfo ref, BxDev bx, uint32_t* slabs, int64_t slab_words, int32_t* bin_of) {
+  if (!(bx.dbg & 128u)) __builtin_amdgcn_s_setprio(3);
+  bxl_trace_grid(rs, ref, bx, slabs, slab_words, bin_of, 3 * BX_NCLS, BXC_LATE2_0);
 }
 
 }  // namespace mia

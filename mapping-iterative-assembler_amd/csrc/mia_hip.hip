@@ -68,6 +68,7 @@ struct mia_hip_ctx {
   hipStream_t stream3 = nullptr; hipEvent_t ev_join3 = nullptr;                      // ... and both beside the planner and the full-window kernels of the reads the plan gave up on
   int32_t* d_retry2 = nullptr; int64_t retry2_cap = 0;                              // reads no band kernel could finish
   uint32_t* d_bx_slabs_late = nullptr; int64_t bx_slab_late_cap = 0; int bx_late_wgs = 0;
+  uint32_t* d_bx_slabs_late2 = nullptr; bool dp_aside = false;      // the second late trace's slabs; this alignment's values DP and late trace are on stream2 (align_all: fork_at_quick)
   // mia_hip_iterate without a host wait behind the alignment: cull, tally and consensus are queued at once and every one of
   // their kernels returns at its first instruction if *abort_if != 0 (reads are waiting for the exact one-read-per-thread
   // kernel: the host sees that with the consensus, runs it, and queues the chain again)
@@ -485,6 +486,7 @@ extern "C" void mia_hip_destroy(mia_hip_ctx* ctx) {
   if (ctx->d_retry2) (void)hipFree(ctx->d_retry2);
   if (ctx->d_cull_sync) (void)hipFree(ctx->d_cull_sync);
   if (ctx->d_bx_slabs_late) (void)hipFree(ctx->d_bx_slabs_late);
+  if (ctx->d_bx_slabs_late2) (void)hipFree(ctx->d_bx_slabs_late2);
   if (ctx->d_one) (void)hipFree(ctx->d_one);
   if (ctx->d_bx_cand) (void)hipFree(ctx->d_bx_cand);
   if (ctx->d_bx_cand2) (void)hipFree(ctx->d_bx_cand2);
@@ -846,7 +848,7 @@ extern "C" int mia_hip_debug_plan_clk(mia_hip_ctx* ctx, uint64_t* out12) {
 #endif
 extern "C" int mia_hip_bx_counters(mia_hip_ctx* ctx, uint32_t* out32) {
   if (!ctx || !out32) return MIA_HIP_ERR_ARG;
-  for (int k = 0; k < BXC_COUNTERS; k++) out32[k] = ctx->bx_last[k];
+  for (int k = 0; k < 32; k++) out32[k] = ctx->bx_last[k];
   return MIA_HIP_OK;
 }
 
@@ -909,7 +911,7 @@ static int bx_join_and_retry(mia_hip_ctx* ctx) {
   // mia_hip_iterate: the retry list is the band kernels' alone, so its window kernel only waits for THEM (the trace DP on
   // stream3; values and late trace are ahead of it on this stream) and runs beside the tail of the planner's chain on
   // stream2, with trace slabs of its own; the planner is waited for behind it
-  if (!aside) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  if (!aside || ctx->dp_aside) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // (dp_aside: values DP and late trace on stream2)
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
   // (this launch is the last of the alignment on the context's stream: with ext_events it signals ev_fork, which
   // mia_hip_iterate's counting sort on stream2 waits for -- see queue_cull)
@@ -1054,6 +1056,7 @@ static int align_all(mia_hip_ctx* ctx) {
   const int wrap = ctx->wrap;
   ctx->bx_pending_join = false;
   ctx->direct_open_now = false;
+  ctx->dp_aside = false;
   if (!ctx->spec_ok) { ctx->spec_pending = false; ctx->abort_if = nullptr; }
   ctx->bx_planner_aside = false;
   ctx->planner_end_signalled = false; ctx->align_end_signalled = false;
@@ -1163,7 +1166,7 @@ static int align_all(mia_hip_ctx* ctx) {
       }
       }
       if (n > ctx->bx_cap) {
-        if (dev_alloc(ctx, &ctx->d_bx_plan, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_expect, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_lists, (size_t)n * 3 * BX_NCLS))
+        if (dev_alloc(ctx, &ctx->d_bx_plan, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_expect, (size_t)n) || dev_alloc(ctx, &ctx->d_bx_lists, (size_t)n * 4 * BX_NCLS))
           return MIA_HIP_ERR_NOMEM;
         ctx->bx_cap = n;
       }
@@ -1194,7 +1197,10 @@ static int align_all(mia_hip_ctx* ctx) {
         if (n > ctx->retry2_cap) { if (dev_alloc(ctx, &ctx->d_retry2, (size_t)n)) return MIA_HIP_ERR_NOMEM; ctx->retry2_cap = n; }
         if (!ctx->bx_late_wgs) ctx->bx_late_wgs = ctx->cus;        // the values DP's left-overs are few: one workgroup per CU
         const int64_t late_words = (int64_t)((ctx->max_len + 3) & ~3) * BXL_SLAB_ROW_WORDS * ctx->bx_late_wgs * 4;
-        if (late_words > ctx->bx_slab_late_cap) { if (dev_alloc(ctx, &ctx->d_bx_slabs_late, (size_t)late_words)) return MIA_HIP_ERR_NOMEM; ctx->bx_slab_late_cap = late_words; }
+        if (late_words > ctx->bx_slab_late_cap) {
+          if (dev_alloc(ctx, &ctx->d_bx_slabs_late, (size_t)late_words) || dev_alloc(ctx, &ctx->d_bx_slabs_late2, (size_t)late_words)) return MIA_HIP_ERR_NOMEM;
+          ctx->bx_slab_late_cap = late_words;
+        }
       }
       bd.retry = ctx->d_retry2; bd.retry_n = ctx->d_plan_hdr + PH_RETRY2 + 1;
       bd.listed_mark = new_flow ? -5 : 0;
@@ -1306,7 +1312,10 @@ static int align_all(mia_hip_ctx* ctx) {
       // mia_hip_iterate: the fork is behind the QUICK plan (BxDev::to_late) -- values DP and late trace are on the context's stream there, behind
       // the full plan's launch, so no wait between streams is added; mia_hip_realign keeps every launch of the plan in front of the fork
       // (... and only where the plan lists its open reads itself: the planner's kernels on stream2 would want every read's mark at the fork)
-      const bool fork_at_quick = quick && ctx->deferred && direct_open && !planner_head_first && !(ctx->bx_dbg & (4u | 8u));
+      bool plan_launched = false;
+      // (... and not with the fine blocks: the three launches of the full plan are then a chain of their own, longer beside the DPs than
+      // both DPs together -- configs[2]: 45 + 174 + 114 us and 211 for their lists' trace against 280 for the DPs; in front of the fork)
+      const bool fork_at_quick = quick && ctx->deferred && direct_open && !fine && !planner_head_first && !(ctx->bx_dbg & (4u | 8u));
       bd.kb = KmerBits{quick ? ctx->d_kbits : nullptr, ctx->L};
       // (the reference's planes in LDS for the quick plan while they are small: 38 KB holds a hundred thousand columns)
       const bool quick_lds = quick && words * 24 <= 38 * 1024;
@@ -1339,14 +1348,16 @@ static int align_all(mia_hip_ctx* ctx) {
           }
         }
         const int phase_first = (split && !one_launch) ? 1 : 0, phase_last = one_launch ? 0 : last_phase;
+        plan_launched = true;
         for (int phase = phase_first; phase <= phase_last; phase++) {
-          const dim3 pg(phase >= 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)((n + 255) / 256));
+          // (one_launch: a grid the chip holds at once, looping over the list -- see PH 6 in bandx_kernels.h)
+          const dim3 pg(phase >= 2 ? (unsigned)std::min<int64_t>((n + 255) / 256, 1024) : (unsigned)(one_launch ? std::min<int64_t>((n + 255) / 256, 256) : (n + 255) / 256));
           // (the fork event rides on the last launch's own completion signal: no marker between the plan and the values DP)
           hipEvent_t done = (fork_by_launch && phase == phase_last && !planner_head_first && !fork_at_quick) ? ctx->ev_fork : nullptr;
 #define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, 0, ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
 #define MIA_PLAN_NW(PHV) switch (nwords) { case 1: MIA_PLAN(1, PHV); break; case 2: MIA_PLAN(2, PHV); break; case 3: MIA_PLAN(3, PHV); break; default: MIA_PLAN(4, PHV); break; }
           switch (phase) {
-            case 0: MIA_PLAN_NW(0) break;
+            case 0: if (one_launch) { MIA_PLAN_NW(6) } else { MIA_PLAN_NW(0) } break;
             case 1: MIA_PLAN_NW(1) break;
             case 2: MIA_PLAN_NW(2) break;
             default: MIA_PLAN_NW(3) break;
@@ -1386,7 +1397,15 @@ static int align_all(mia_hip_ctx* ctx) {
           // mia_hip_iterate (deferred): the values DP and the trace launch behind it ARE the step's critical path, so they
           // stay on the context's stream, right behind the plan -- a cross-stream wait costs 20-30 us each way, and it is the
           // planner with the full-window kernels (short, done long before) that moves to stream2.
-          hipStream_t vs = ctx->deferred ? ctx->stream : ctx->stream2;
+          // fork_at_quick (round 6): the context's stream holds the full plan's launch for the reads the quick plan left and the trace launch
+          // of what THAT lists (the second late lists); values DP and late trace run beside them on stream2, the trace DP on stream3 -- three
+          // chains of about the same length instead of plan -> values DP -> late trace one after the other, and the join waits for all
+          hipStream_t vs = (ctx->deferred && !fork_at_quick) ? ctx->stream : ctx->stream2;
+          ctx->dp_aside = fork_at_quick;
+          if (fork_at_quick && plan_launched) {
+            if (stage_launch(ctx, STG_BX_VALUES, k_bxl_trace_late2, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, ctx->stream, ctx->rs, ref, bd, ctx->d_bx_slabs_late2, slab_words, ctx->d_bin_of))
+              return MIA_HIP_ERR_NOMEM;
+          }
           if (!fork_by_launch && !fork_at_quick) HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
           HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
           HIPCHK(hipStreamWaitEvent(ctx->stream3, ctx->ev_fork, 0));
@@ -1404,7 +1423,7 @@ static int align_all(mia_hip_ctx* ctx) {
             if (stage_launch(ctx, STG_BX_VALUES, k_bxl_trace_late, dim3((unsigned)ctx->bx_late_wgs), dim3(256), 0, vs, ctx->rs, ref, bd, ctx->d_bx_slabs_late, slab_words, ctx->d_bin_of))
               return MIA_HIP_ERR_NOMEM;
           }
-          if (!ctx->deferred) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
+          if (!ctx->deferred || fork_at_quick) HIPCHK(hipEventRecord(ctx->ev_join, ctx->stream2));
           HIPCHK(hipGetLastError());
           ctx->bx_planner_aside = ctx->deferred;
           ctx->bx_pending_join = true;
