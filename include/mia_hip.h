@@ -372,10 +372,13 @@ int mia_hip_band_stats(mia_hip_ctx *ctx, int reset, int64_t *reads_finished, dou
  * kernel_ms3 = accumulated time of k_bx_plan, k_bx_values, k_bx_trace (HIP events on the context's stream);
  * launches = realign calls that used the pipeline.  Any pointer may be NULL. */
 int mia_hip_bx_stats(mia_hip_ctx *ctx, int reset, int64_t *reads4, double *kernel_ms3, int64_t *launches);
-/* Diagnostic: the 32 device counters of the band pipeline after the last realign -- [0..3] reads sent to the values DP by
- * band class (8, 16, 24, 32 diagonals), [4..7] to the trace DP, [10..12] finished by plan / values / trace, [13] reads
- * planned on, [17..23] reads not planned, by reason (N in the read, window, too few anchored blocks, anchors too far
- * apart, written-down path outside the window, loss over the pigeonhole budget, band wider than 32). */
+/* Diagnostic: the first 32 device counters of the band pipeline after the last realign -- [0..4] reads listed for the values DP
+ * by band class (8, 16, 24, 32, 64 diagonals), [5..9] for the trace DP, [10] reads the quick plan (round 6: every read asked on
+ * the diagonal it was aligned on before) left to the full plan, [12..14] finished by plan / values DP / trace DP, [15] reads
+ * planned on, [16] reads the quick plan's one-diagonal form handed to its one-indel form, [17..23] reads not planned, by reason
+ * (N in the read, window, too few anchored blocks, anchors too far apart, written-down path outside the window, loss over the
+ * pigeonhole budget, band wider than 64), [24..28] reads the values DP left to the late trace launch by class, [29] reads the
+ * plan listed for the full-window kernels itself (k_align_open), [30], [31] reads handed to the plan's second / third launch. */
 int mia_hip_bx_counters(mia_hip_ctx *ctx, uint32_t *out32);
 /* Every timed stage at once: names[k] (static strings: k_align_quad, k_align_quad_plain, k_diag_filter, k_band_align,
  * k_bx_plan, k_bx_values, k_bx_trace, k_tally_binned, k_pass1), accumulated milliseconds and launches since the last

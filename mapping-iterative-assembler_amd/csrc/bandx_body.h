@@ -1161,8 +1161,13 @@ MIA_HD inline void bx_finish(DiagScan<NW>& sc, const RefPlanes& rp, const BxAnch
 // The theorem is the one bx_finish already applies: a path that crosses no block of the family cleanly loses at least the sum of
 // their dl > B0, so every path that can win or tie crosses one -- on d, the only place there is -- and strays from it by what B0 less
 // s_un leaves.  The family is at most bx_anchors' own, so the band is at least as wide as the full plan's: the values DP may have to
-// decide where the full plan would have -- never a wrong answer.  Not for tables that spell out N columns (kh.wild: every run's first
-// iteration), not for a window longer than the reference.  false: nothing decided, the full plan (bx_anchors ...) takes the read.
+// decide where the full plan would have -- never a wrong answer.  A reference with N columns (kh.wild: the table spells them out): only
+// for the windows that hold NONE.  The bitmaps count the places made of plain bases alone, all over the reference; a window of plain
+// bases holds no other kind of place, so "once in the reference" and "nowhere in the reference" say about the window what they say
+// without any N, and no N credit is due.  (An assembly's consensus keeps a handful of N columns where coverage is thin -- configs[4]'s
+// has two in 100 kb -- and the whole run would go without the quick plan for their sake; a reference that is N all over, every run's
+// first iteration, is not asked: align_all.)  Not for a window longer than the reference.  false: nothing decided, the full plan
+// (bx_anchors ...) takes the read.
 // (the two bitmaps word by word side by side: one 8-byte load answers both questions about a 10-mer)
 struct alignas(8) KbPair { uint32_t present, repeated; };
 struct KmerBits { const KbPair* w; int32_t ref_len; };      // ref_len = L (the places the bitmaps count); w == nullptr: none
@@ -1173,7 +1178,8 @@ MIA_HD inline bool bx_quick(DiagScan<NW>& sc, const RefPlanes& rp, const KmerHas
                             BxPlan* out) {
   constexpr int NB = bx_nb_max<NW>();
   out->mode = BX_NONE; out->b0 = 0;
-  if (!kb.w || kh.wild > 0 || d < 0 || d > len1 - len2 || len1 > kb.ref_len) return false;
+  if (!kb.w || d < 0 || d > len1 - len2 || len1 > kb.ref_len) return false;
+  if (kh.wild > 0 && !all_bases(rp, s, (int64_t)s + len1)) return false;      // (a reference with N columns: only the windows that hold none -- see above)
   const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
   sc.seek(rp, (int64_t)s + d);
   uint64_t m1[NW];
@@ -1233,7 +1239,8 @@ MIA_HD inline bool bx_quick2(DiagScan<NW>& sc, const RefPlanes& rp, const KmerHa
                              BxPlan* out) {
   constexpr int NB = bx_nb_max<NW>();
   out->mode = BX_NONE; out->b0 = 0;
-  if (!kb.w || kh.wild > 0 || d < 0 || d > len1 - len2 || len1 > kb.ref_len) return false;
+  if (!kb.w || d < 0 || d > len1 - len2 || len1 > kb.ref_len) return false;
+  if (kh.wild > 0 && !all_bases(rp, s, (int64_t)s + len1)) return false;      // (a reference with N columns: only the windows that hold none -- see above)
   const int R = len2 - 1, nb_cut = bx_blocks_of(len2);
   const int16_t* dl = T.dl + (st * (MAX_READ + 1) + len2) * BX_BLOCKS;
   uint32_t kidx[NB], w1[NB], w2[NB];

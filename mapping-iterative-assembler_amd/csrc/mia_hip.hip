@@ -167,6 +167,7 @@ struct mia_hip_ctx {
   // the diagonal filter (diag_filter.h): flat matrix only
   bool tally_linear = false;               // MIA_HIP_NO_LINEAR_TALLY=1: the tally adds the four scores of every base
   bool ref_mostly_bases = true;            // fewer than 2 % of the reference columns are N
+  bool ref_few_n = true;                   // ... fewer than 0.2 %: four windows in five hold none (the quick plan asks those even where the table spells out N columns)
   int64_t kh_entries = 0;                  // > 0: the reference has N columns and its 10-mer table lists them (bandx_body.h, N COLUMNS)
   bool diag_scripts_missing = false;       // the last alignment left the scripts of its ST_DIAG reads unwritten (k_diag_scripts)
   int lazy_scripts = 1;                    // MIA_HIP_EAGER_SCRIPTS=1: the band pipeline writes them as it goes
@@ -961,6 +962,7 @@ extern "C" int mia_hip_realign(mia_hip_ctx* ctx, const char* new_ref, int32_t re
   for (int i = 0; i < wl; i++) codes[L + i] = codes[i];
   // a reference full of ambiguity codes (mt311 itself: every other column) leaves the diagonal filter nothing to decide
   ctx->ref_mostly_bases = n_other * 50 <= L;
+  ctx->ref_few_n = n_other * 500 <= L;
   ctx->kh_entries = 0;
   if (n_other && ctx->use_wild) {
     ctx->kh_entries = kh_wild_entries(codes.data(), wrap, BX_WILD);
@@ -1134,8 +1136,8 @@ static int align_all(mia_hip_ctx* ctx) {
         ctx->khash_cap = kslots;
       }
       const KmerHash kh{ctx->d_khash, ctx->d_khash_ovf, kslots - 1, kh_shift_for(kslots), ctx->kh_entries > 0 ? BX_WILD : 0};
-      // (the quick plan's bitmaps: made wherever the table is made for a reference without spelled-out N columns)
-      const bool want_bits = ctx->use_quick && kh.wild == 0;
+      // (the quick plan's bitmaps: made wherever the table is made, unless the reference is N all over -- hardly a window without one then)
+      const bool want_bits = ctx->use_quick && (kh.wild == 0 || ctx->ref_few_n);
       if (want_bits && !ctx->d_kbits && dev_alloc(ctx, &ctx->d_kbits, (size_t)KB_WORDS)) return MIA_HIP_ERR_NOMEM;
       if (fused_prep) {
         RefPrep rp2;
@@ -1305,8 +1307,9 @@ static int align_all(mia_hip_ctx* ctx) {
       }
       // THE QUICK PLAN FIRST (round 6; bandx_body.h: bx_quick, k_bx_plan<NW, 4>): every read on the diagonal it was aligned on before -- nine
       // in ten of a steady-state iteration are finished or listed there for a tenth of the full plan's instructions; the rest goes on a
-      // list (the diagonal filter's: d_left_list, d_filter_n[1]) that the launches below take as their in_list.  Not against a table that
-      // spells out N columns (every run's first iteration), not with the diagonal filter in front, not with the early tally's marks.
+      // list (the diagonal filter's: d_left_list, d_filter_n[1]) that the launches below take as their in_list.  Not against a reference
+      // that is N all over (every run's first iteration; one with a few N columns: the windows that hold none, want_bits above), not with the
+      // diagonal filter in front, not with the early tally's marks.
       const bool quick = split && new_flow && !run_filter && !early && !split_dp && want_bits && !(ctx->bx_dbg & 32u) && bd.umax != nullptr;      // (the context's own reads: their U is at hand)
       bd.qlist = nullptr; bd.qlist_n = ctx->d_filter_n + 1; bd.mark_all = 0; bd.to_late = 0;
       // mia_hip_iterate: the fork is behind the QUICK plan (BxDev::to_late) -- values DP and late trace are on the context's stream there, behind

@@ -586,3 +586,65 @@ def test_quick_plan_on_wrapped_references(emul, oracle):
                 r, f = script_to_strings(win, read, cols, res.abr, res.aer)
                 assert r == rg.value.decode() and f == fg.value.decode(), ctx
     assert stats["n"] > 500 and stats.get("planned", 0) > 300, stats
+
+
+def test_quick_plan_beside_n_columns(emul, oracle):
+    """A reference with a FEW N columns (an assembly's consensus where coverage is thin; configs[4]'s has two in 100 kb): the table
+    spells them out (kh.wild), and the quick plan answers for the windows that hold none -- the bitmaps count the places made of plain
+    bases, which are all the places such a window has.  Windows with an N column are refused (the full plan and its N credit take
+    them).  Adversarial part: a stretch copied elsewhere WITH an N put into the copy, so that a 10-mer that is unique among the plain
+    places has a second home under one spelling of the N -- outside every window the quick plan answers for."""
+    rnd = random.Random(606)
+    stats = {"n": 0}
+    for spec, strand in MATS[:3]:
+        for i in range(260):
+            L = rnd.choice([1200, 2000, 4000])
+            core = [rnd.choice("ACGT") for _ in range(L)]
+            a = rnd.randint(100, L // 2 - 200)
+            b = rnd.randint(L // 2 + 100, L - 300)
+            if i % 2 == 0:                                            # the copy with an N inside
+                core[b:b + 120] = core[a:a + 120]
+                core[b + rnd.randint(20, 100)] = "N"
+            for _ in range(rnd.choice([1, 2, 4])):
+                core[rnd.randint(0, L - 1)] = rnd.choice("NNRY")
+            ref = "".join(core)
+            n = rnd.choice([60, 100, 100, 130])
+            pos = rnd.choice([a + rnd.randint(-30, 60), b + rnd.randint(-30, 60), rnd.randint(0, L - n)])
+            pos = max(0, min(L - n, pos))
+            read = ref[pos:pos + n]
+            if any(c not in "ACGT" for c in read):
+                read = "".join(c if c in "ACGT" else rnd.choice("ACGT") for c in read)
+            if i % 3 == 0:
+                at = rnd.randint(5, n - 5)
+                read = read[:at] + read[at + 1:] if i % 2 else read[:at] + rnd.choice("ACGT") + read[at:]
+            read = damage(rnd, read) if spec != "flat" else read
+            read = mutate(rnd, read, rnd.sample(range(len(read)), rnd.choice([0, 0, 1, 2, 4])))
+            s, l1 = window(ref, pos, len(read), margin=rnd.choice([20, 50, 50]))
+            if l1 < len(read):
+                continue
+            win = ref[s:s + l1]
+            clear = all(c in "ACGT" for c in win)
+            res = None
+            for d in range(0, l1 - len(read) + 1):
+                if sum(1 for k in range(len(read)) if read[k] != win[d + k]) > 8 and sum(1 for k in range(min(len(read), 24)) if read[k] != win[d + k]) > 1:
+                    continue
+                stats["n"] += 1
+                opts = ((d + 1) << 16) | (stats["n"] & 3)
+                mode, out6, cols, plan = run_bandx(emul, oracle, spec, strand, ref, s, l1, read, opts)
+                if not clear:
+                    stats["refused"] = stats.get("refused", 0) + 1
+                    assert mode == 0, ("a window with an N column", win)
+                if mode == 0 or out6[5] == 0:
+                    continue
+                stats["planned"] = stats.get("planned", 0) + 1
+                if res is None:
+                    res = oc.Aln()
+                    rg = C.create_string_buffer(1100)
+                    fg = C.create_string_buffer(1100)
+                    assert oracle.ora_align(win.encode(), len(win), read.encode(), len(read), None, C.byref(_pssm(oracle, spec, strand)), 1, C.byref(res), rg, fg, None, None) == 0
+                ctx = ("quick, N columns elsewhere", L, d, spec, strand, win, read, plan, out6, (res.best, res.abc, res.aec, res.abr))
+                assert (out6[0], out6[1], out6[2], out6[3]) == (res.best, res.abc, res.aec, res.abr), ctx
+                r, f = script_to_strings(win, read, cols, res.abr, res.aer)
+                assert r == rg.value.decode() and f == fg.value.decode(), ctx
+    print("quick beside N", sorted(stats.items()))
+    assert stats["n"] > 600 and stats.get("planned", 0) > 300 and stats.get("refused", 0) > 30, stats

@@ -5,7 +5,8 @@ usage: band_campaign.py [rounds [first seed [MIA_HIP_NO_DIAG_FILTER [matrix]]]] 
 "off"; MIA_HIP_NO_DIAG_FILTER takes every shortcut out, i.e. compares the band pipeline with the full-window DP kernels;
 fourth: flat (default), ancient, solexa -- the position-specific matrices, both strands mixed, aDNA damage on the reads;
 fifth: nrich -- after the reads are drawn, 3-20 % of the reference columns (and a few stretches of 2-12) become
-ambiguity codes, as in mt311)"""
+ambiguity codes, as in mt311; fewn -- a handful of columns only (fewer than one in 500: an assembly's consensus where coverage is thin),
+the case in which the table spells out N columns AND the quick plan answers for the windows that hold none)"""
 import os
 import sys
 import time
@@ -64,7 +65,12 @@ def run(rounds=40, seed0=1000, switch="MIA_HIP_NO_BAND_DP", matrix="flat", nrich
         jitter = rng.integers(-10, 11, n) * (rng.random(n) < 0.3)
         as0 = ((start + jitter) % L).astype(np.int32)
         ae0 = (as0 + read_len - 1).astype(np.int32)
-        if nrich:
+        if nrich == "fewn":
+            ref = ref.copy()
+            codes = np.frombuffer(b"YRMWSKNNNN", np.uint8)
+            k = int(rng.integers(1, max(2, L // 500)))
+            ref[rng.integers(0, L, k)] = rng.choice(codes, k)
+        elif nrich:
             ref = ref.copy()
             codes = np.frombuffer(b"YRYRMWVHDSBKN", np.uint8)
             hit = rng.random(L) < float(rng.choice([0.03, 0.1, 0.1, 0.2]))
@@ -92,7 +98,7 @@ def run(rounds=40, seed0=1000, switch="MIA_HIP_NO_BAND_DP", matrix="flat", nrich
         reads_total += n
         if not quiet:
             print("round", k, "seed", seed, "len", read_len, "L", L, "ok", round(time.time() - t0, 1), "s", flush=True)
-    print("campaign done:", matrix, "matrix,", "N-rich references," if nrich else "", reads_total, "reads, no difference;", planned[0], "of", planned[1],
+    print("campaign done:", matrix, "matrix,", ("a few N columns," if nrich == "fewn" else "N-rich references,") if nrich else "", reads_total, "reads, no difference;", planned[0], "of", planned[1],
           "finished or placed by the band pipeline")
     return reads_total, planned[0]
 
@@ -100,4 +106,4 @@ def run(rounds=40, seed0=1000, switch="MIA_HIP_NO_BAND_DP", matrix="flat", nrich
 if __name__ == "__main__":
     run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1000,
         sys.argv[3] if len(sys.argv) > 3 else "MIA_HIP_NO_BAND_DP", sys.argv[4] if len(sys.argv) > 4 else "flat",
-        len(sys.argv) > 5 and sys.argv[5] == "nrich")
+        (len(sys.argv) > 5 and sys.argv[5] in ("nrich", "fewn")) and (sys.argv[5] if sys.argv[5] == "fewn" else True))
