@@ -52,7 +52,7 @@ def bytes_per_read(read_len):
     return (read_len + 1) // 2 + 16 + 16 + read_len
 
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 PMC_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc")
 CSRC = os.path.join(ROOT, "mapping-iterative-assembler_amd", "csrc")
 STAGES = ["k_diag_filter", "k_band_align", "k_bx_plan", "k_bx_values", "k_bx_trace", "k_align_quad_plain", "k_align_quad", "k_tally_binned"]

@@ -80,7 +80,7 @@ struct mia_hip_ctx {
   // round 6: the band plan lists the reads it leaves open itself and k_align_open takes them one per wavefront (align_all: direct_open;
   // MIA_HIP_NO_DIRECT_OPEN=1, alt build: the planner's count / scan / fill and the quad kernels, as in every iteration with many open reads)
   KbPair* d_kbits = nullptr;            // the quick plan's bitmaps over all 4^10 10-mers (bandx_body.h: KmerBits), remade with the table
-  bool use_quick = true; int64_t quick_steps = 0;      // the quick plan in front of k_bx_plan's launches (MIA_HIP_NO_QUICK_PLAN=1, alt build: the full plan for every read)
+  int use_quick = 1; int64_t quick_steps = 0;      // the quick plan in front of k_bx_plan's launches (MIA_HIP_NO_QUICK_PLAN=1, alt build: the full plan for every read)
   bool direct_open_now = false;        // this alignment's open reads are on d_open_list (set by align_all, read by bx_join_and_retry)
   int32_t* d_open_list = nullptr; int64_t open_cap = 0; unsigned char* d_slabs_open = nullptr; bool use_direct_open = true; int64_t direct_open_steps = 0;   // k_cons_tail's barrier counter (d_prep_bar + 1; MIA_HIP_NO_TAIL_FUSE=1: four launches)
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
@@ -387,7 +387,8 @@ extern "C" int mia_hip_create(mia_hip_ctx** out, int device_index) {
     if (const char* sm = alt_env("MIA_HIP_STAGE_MARKERS")) ctx->stage_markers = atoi(sm) != 0;
     if (const char* ts = alt_env("MIA_HIP_TAIL_SCANS")) ctx->tail_scans = atoi(ts) != 0;
     if (const char* dop = alt_env("MIA_HIP_NO_DIRECT_OPEN")) ctx->use_direct_open = atoi(dop) == 0;
-    if (const char* qp = alt_env("MIA_HIP_NO_QUICK_PLAN")) ctx->use_quick = atoi(qp) == 0;
+    if (const char* qp = alt_env("MIA_HIP_NO_QUICK_PLAN")) ctx->use_quick = atoi(qp) == 0 ? 1 : 0;
+    if (const char* qp = alt_env("MIA_HIP_QUICK_PLAN")) ctx->use_quick = atoi(qp);      // (2: also where the size rule below says no)
     if (const char* sw = getenv("MIA_HIP_SPIN_WAIT")) ctx->spin_wait = atoi(sw) != 0;
     if (const char* em = alt_env("MIA_HIP_EXT_EVENTS_MASK")) ctx->ext_events = (uint32_t)atoi(em);
     if (const char* st2 = alt_env("MIA_HIP_SPEC_TEST")) ctx->spec_force = atoi(st2) != 0;
@@ -1310,7 +1311,10 @@ static int align_all(mia_hip_ctx* ctx) {
       // list (the diagonal filter's: d_left_list, d_filter_n[1]) that the launches below take as their in_list.  Not against a reference
       // that is N all over (every run's first iteration; one with a few N columns: the windows that hold none, want_bits above), not with the
       // diagonal filter in front, not with the early tally's marks.
-      const bool quick = split && new_flow && !run_filter && !early && !split_dp && want_bits && !(ctx->bx_dbg & 32u) && bd.umax != nullptr;      // (the context's own reads: their U is at hand)
+      // (... and with the fine blocks on only from two million reads: the three launches of the full plan stay behind it then, each with a
+      // launch's floor of 30-90 us for the few reads it has left -- 1 M ancient reads 1.12 ms without it, 1.15 with; 10 M solexa 6.0 / 5.4)
+      const bool quick = split && new_flow && !run_filter && !early && !split_dp && want_bits && !(ctx->bx_dbg & 32u) && bd.umax != nullptr &&      // (the context's own reads: their U is at hand)
+                         (!fine || n >= 2000000 || ctx->use_quick > 1);
       bd.qlist = nullptr; bd.qlist_n = ctx->d_filter_n + 1; bd.mark_all = 0; bd.to_late = 0;
       // mia_hip_iterate: the fork is behind the QUICK plan (BxDev::to_late) -- values DP and late trace are on the context's stream there, behind
       // the full plan's launch, so no wait between streams is added; mia_hip_realign keeps every launch of the plan in front of the fork

@@ -39,7 +39,8 @@ SWITCHES = ["MIA_HIP_NO_BANDX", "MIA_HIP_NO_LANES", "MIA_HIP_BX_SERIAL", "MIA_HI
             # round 6: the planner's chain (count / scan / fill, quad kernels, window classes) instead of the plan's own open list
             "MIA_HIP_NO_DIRECT_OPEN",
             # round 6: the full plan (bx_anchors: every block looked up) for every read instead of the quick plan on the read's old diagonal first
-            "MIA_HIP_NO_QUICK_PLAN"]
+            # (... and the quick plan in front of the fine blocks' three launches below two million reads too, where the size rule leaves it out)
+            "MIA_HIP_NO_QUICK_PLAN", "MIA_HIP_QUICK_PLAN=2"]
 
 
 def two_iterations(mod, w, env):

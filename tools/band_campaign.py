@@ -36,9 +36,12 @@ def run(rounds=40, seed0=1000, switch="MIA_HIP_NO_BAND_DP", matrix="flat", nrich
         for env in (None, switch):
             if env:
                 os.environ[env] = "1"
+            elif matrix != "flat":
+                os.environ["MIA_HIP_QUICK_PLAN"] = "2"      # (with the fine blocks on, the quick plan starts at two million reads by itself: here always)
             hip = mia_amd.MiaHip(0)
             if env:
                 os.environ.pop(env)
+            os.environ.pop("MIA_HIP_QUICK_PLAN", None)
             hip.set_pssm(PSSM)
             hip.upload_reads(reads.reshape(-1), off, rc, np.ones(n, np.uint8), as0, ae0)
             hip.realign(refs, True)

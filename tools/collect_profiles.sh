@@ -1,5 +1,5 @@
 set -x
-cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; RND=${ROUND:-r05}; O=$R/gpurun_out/$RND; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; RND=${ROUND:-r06}; O=$R/gpurun_out/$RND; mkdir -p $O
 PART=${PART:-all}
 if [ $PART != pmc ]; then
 for c in 1 2 3 4; do
