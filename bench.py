@@ -310,9 +310,14 @@ class Pipeline:
             if pmc_usable(pmc, pmc_stale, n):
                 kept = pmc["_meta"].get("steps_kept", 4)
                 tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "SQ_INSTS_VALU": 0.0}
+                # (a kernel the counter passes never met -- the route a few open reads take depends on last iteration's reject count, which
+                # sits at its threshold for configs[4] and differs with the seed: no counter figures for that stage, and the line says so)
+                missing = [kn for kn in STAGE_KERNELS.get(name, [name]) if kn not in pmc or not all(c in pmc[kn] for c in tot)]
+                if missing:
+                    s["pmc_missing"] = missing
+                    out.append(s)
+                    continue
                 for kn in STAGE_KERNELS.get(name, [name]):
-                    if kn not in pmc or not all(c in pmc[kn] for c in tot):
-                        raise RuntimeError(f"PMC summary has no entry for {kn}: re-run tools/pmc_collect.sh for this build")
                     for c in tot:                   # average per dispatch x dispatches per step
                         per_step = pmc[kn][c] * pmc[kn]["dispatches_" + c] / kept
                         tot[c] += per_step if name in STAGE_KERNELS else pmc[kn][c]
@@ -732,13 +737,11 @@ def headline(out, extras_path):
     for k in ("configs1", "configs2", "configs3", "configs3_share", "configs4", "configs4_share"):
         c = out.get(k)
         if c:
+            # (what the line has room for; first_over_steady, steady reads/s, the section's roofline and CPU figure: bench_extras.json)
             conv[k] = {"reads": c.get("reads"), "iterations": c["iterations_to_convergence"], "value_to_convergence": c["reads_per_s_per_iteration"],
                        "steady_ms": c["steady_state_ms_per_iteration"], "first_ms": c["first_iteration_again_ms"],
-                       "first_over_steady": c["first_iteration_over_steady"], "steady_reads_per_s": c["steady_state_reads_per_s"],
-                       "roofline_kernel": c["roofline"]["kernel"], "roofline_frac": c["roofline"]["frac"],
                        "traffic_over_algorithmic": (c.get("step_traffic") or {}).get("ratio"),
-                       "cpu_reads_per_s": (c.get("cpu_baseline") or {}).get("value"),
-                       "consensus_sha256": (c.get("certificate") or {}).get("consensus_sha256", "")[:16]}
+                       "consensus_sha256": (c.get("certificate") or {}).get("consensus_sha256", "")[:12]}
     lb = out.get("configs3_loopback_w8")
     if lb and "error" not in lb:
         conv["configs3_loopback_w8"] = {k: lb[k] for k in ("ranks", "reads_per_rank", "steady_ms_per_step", "first_iteration_ms")}
@@ -1070,7 +1073,7 @@ def main():
         hl = headline(out, extras_path)
         line = json.dumps(hl, separators=(",", ":"))
         # never die for a long line after everything was measured -- drop optional keys (all of them are in the extras file)
-        for victim in ("collectives_note", "library", "step_traffic", "weak", "to_convergence", "cpu_baseline.sample", "roofline.pmc", "roofline.dp_phase", "roofline.valu"):
+        for victim in ("collectives_note", "library", "cpu_baseline.sample", "roofline.pmc", "roofline.dp_phase", "step_traffic", "weak", "roofline.valu", "to_convergence"):
             if len(line) < HEADLINE_MAX:
                 break
             top, _, sub = victim.partition(".")
