@@ -76,6 +76,10 @@ struct BxDev {
   // lists goes on the SECOND LATE lists (the DPs are reading their own by then), values and trace plans alike; a trace launch of their
   // own takes them (k_bxl_trace_late2), beside the one behind the values DP
   int32_t to_late;
+  // stretches of 256 reads per workgroup of the quick plan (<= BX_QCH).  Every workgroup ends with one round of reservations on the lists'
+  // counters, and a counter serves them one at a time (20 ns each): 1 M flat reads 122 us with four stretches, 148 with two (twice the
+  // workgroups), 147 with eight (two wavefronts per SIMD); 10 M solexa reads 5.44 ms per step with four, 5.33 with eight
+  int32_t qch;
 };
 // which entries of the plan's lists a launch of the band DPs takes
 enum { BX_PART_ALL = 0, BX_PART_HEAD = 1, BX_PART_TAIL = 2 };
@@ -260,7 +264,9 @@ __device__ unsigned long long g_plan_clk[64 * 16];
 #define PLAN_CLK_DECL do { } while (0)
 #define PLAN_CLK_FLUSH do { } while (0)
 #endif
-constexpr int BX_QCH = 4;          // stretches of 256 reads a workgroup of the quick plan (phase 4) takes
+// 64-bit words of dynamic LDS the quick plan's per-read arrays take (two 16-bit words and a byte per read), in front of the planes
+__host__ __device__ constexpr int bx_quick_lds_words(int qch) { return (256 * qch * 5 + 7) / 8; }
+constexpr int BX_QCH = 8;          // stretches of 256 reads a workgroup of the quick plan (phase 4) takes AT MOST (BxDev::qch: four up to four million reads, eight beyond)
 template <int NW, int PH>
 __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPlanes rp, KmerHash ko, int64_t n_ref, BxDev bx, const int32_t* in_list,
                                                   const uint32_t* n_in_p, int64_t n_all, int32_t* bin_of) {
@@ -371,8 +377,12 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     // this launch, by the block's first threads (+ 59 us for the launch, the fork behind it that much later); the full plan's launches
     // beside the band DPs, their lists the late ones (the step waits as long for them there as in front of the fork).)
     constexpr int NL = 2 * BX_NCLS + 2, LQ = 2 * BX_NCLS, LO = 2 * BX_NCLS + 1;      // the lists a read can go on: the plan's ten, qlist, the open list
-    __shared__ uint8_t q_which[256 * BX_QCH];                          // list of the block's read li; 255: none (finished here, open without a list, or no such read)
-    __shared__ uint16_t q_rank[256 * BX_QCH], q_cand[256 * BX_QCH];
+    // (per read of the block, in the launch's dynamic LDS -- its size goes with bx.qch: q_which = the list of read li; 255: none (finished
+    // here, open without a list, or no such read); q_rank = its place among the block's entries of that list; q_cand = the undecided)
+    extern __shared__ uint64_t lds_dyn[];
+    uint16_t* const q_rank = reinterpret_cast<uint16_t*>(lds_dyn);
+    uint16_t* const q_cand = q_rank + 256 * bx.qch;
+    uint8_t* const q_which = reinterpret_cast<uint8_t*>(q_cand + 256 * bx.qch);
     __shared__ uint32_t q_cnt[NL], q_base[NL], q_ncand, q_fin, q_seen, q_fail[BXF_KINDS];
     if (threadIdx.x < NL) q_cnt[threadIdx.x] = 0;
     if (threadIdx.x < BXF_KINDS) q_fail[threadIdx.x] = 0;
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     // PHASE 5: the reference's three planes in LDS (a mitochondrion's are 6.5 KB).  A seek is a dozen 8-byte loads at an address of the
     // lane's own -- every one of them sixty-four trips through the compute unit's one address unit --, the quick plan seeks twice per read,
     // and with the table walks gone those loads and the bitmaps' were what a wavefront waited for (tools/plan_clk_probe.py: half its cycles)
-    extern __shared__ uint64_t lds_planes[];
+    uint64_t* const lds_planes = lds_dyn + bx_quick_lds_words(bx.qch);
     if ((PH == 5)) {
       const int pw = bx.plane_words;
       for (int k = threadIdx.x; k < pw; k += 256) { lds_planes[k] = rp.lo[k]; lds_planes[pw + k] = rp.hi[k]; lds_planes[2 * pw + k] = rp.ok[k]; }
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     }
     __syncthreads();
     PLAN_CLK(0);
-    const int64_t tq = (int64_t)blockIdx.x * (256 * BX_QCH);
+    const int64_t tq = (int64_t)blockIdx.x * (256 * bx.qch);
     auto fetch_at = [&](int64_t t) -> Rd {
       Rd r{0, 0, 0, 0, 0, false};
       if (t >= total) return r;
@@ -431,7 +441,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
       if (which < NL) q_rank[li] = (uint16_t)atomicAdd(&q_cnt[which], 1u);
     };
     const int lane = threadIdx.x & 63;
-    for (int c = 0; c < BX_QCH; c++) {
+    for (int c = 0; c < bx.qch; c++) {
       const int li = c * 256 + (int)threadIdx.x;
       const int64_t t = tq + li;
       DiagScan<NW> sc;
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(256) void k_bx_plan(ReadSet rs, RefInfo ref, RefPla
     if (threadIdx.x >= 32 && threadIdx.x < 32 + BXF_KINDS && threadIdx.x > 32 && q_fail[threadIdx.x - 32]) atomicAdd(bxc(bx.ctr, BXC_FAIL0 + (int)threadIdx.x - 32), q_fail[threadIdx.x - 32]);
     __syncthreads();
     PLAN_CLK(5);
-    for (int c = 0; c < BX_QCH; c++) {
+    for (int c = 0; c < bx.qch; c++) {
       const int li = c * 256 + (int)threadIdx.x, which = q_which[li];
       if (which >= NL) continue;
       const uint32_t at = q_base[which] + q_rank[li];

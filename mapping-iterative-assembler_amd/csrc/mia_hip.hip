@@ -82,7 +82,7 @@ struct mia_hip_ctx {
   KbPair* d_kbits = nullptr;            // the quick plan's bitmaps over all 4^10 10-mers (bandx_body.h: KmerBits), remade with the table
   int use_quick = 1; int64_t quick_steps = 0;      // the quick plan in front of k_bx_plan's launches (MIA_HIP_NO_QUICK_PLAN=1, alt build: the full plan for every read)
   bool direct_open_now = false;        // this alignment's open reads are on d_open_list (set by align_all, read by bx_join_and_retry)
-  int32_t* d_open_list = nullptr; int64_t open_cap = 0; unsigned char* d_slabs_open = nullptr; bool use_direct_open = true; int64_t direct_open_steps = 0;   // k_cons_tail's barrier counter (d_prep_bar + 1; MIA_HIP_NO_TAIL_FUSE=1: four launches)
+  int32_t* d_open_list = nullptr; int64_t open_cap = 0; unsigned char* d_slabs_open = nullptr; bool use_direct_open = true; int64_t direct_open_steps = 0;   // the plan's own open list (n entries), k_align_open's trace slabs (one per workgroup of its grid)
   bool spec_force = false; int32_t* d_one = nullptr;      // MIA_HIP_SPEC_TEST=1 (tests): a word that holds 1
   bool zero_copy = true;        // mia_hip_iterate: the last kernel writes consensus and counters into pinned host memory itself (MIA_HIP_NO_ZERO_COPY=1: two copies)
   // the launches other streams wait for signal their events themselves (launch_k) instead of a marker behind them; MIA_HIP_NO_EXT_EVENTS=1: markers
@@ -1315,7 +1315,7 @@ static int align_all(mia_hip_ctx* ctx) {
       // launch's floor of 30-90 us for the few reads it has left -- 1 M ancient reads 1.12 ms without it, 1.15 with; 10 M solexa 6.0 / 5.4)
       const bool quick = split && new_flow && !run_filter && !early && !split_dp && want_bits && !(ctx->bx_dbg & 32u) && bd.umax != nullptr &&      // (the context's own reads: their U is at hand)
                          (!fine || n >= 2000000 || ctx->use_quick > 1);
-      bd.qlist = nullptr; bd.qlist_n = ctx->d_filter_n + 1; bd.mark_all = 0; bd.to_late = 0;
+      bd.qlist = nullptr; bd.qlist_n = ctx->d_filter_n + 1; bd.mark_all = 0; bd.to_late = 0; bd.qch = 4;
       // mia_hip_iterate: the fork is behind the QUICK plan (BxDev::to_late) -- values DP and late trace are on the context's stream there, behind
       // the full plan's launch, so no wait between streams is added; mia_hip_realign keeps every launch of the plan in front of the fork
       // (... and only where the plan lists its open reads itself: the planner's kernels on stream2 would want every read's mark at the fork)
@@ -1341,10 +1341,13 @@ static int align_all(mia_hip_ctx* ctx) {
         // two diagonals by the block's first threads -- a second launch would be a second chain through the table, 40 us, for fifty workgroups)
         const bool one_launch = quick && !fine;
         if (quick) {
-          const dim3 pg((unsigned)((n + 256 * BX_QCH - 1) / (256 * BX_QCH)));
+          // (eight stretches per workgroup where the lists' counters are the wait -- many reads -- and the planes in LDS are small: with a
+          // 100 kb reference's 37 KB of planes the larger per-read arrays cost the third workgroup per compute unit, configs[4] 7.85 -> 8.05 ms)
+          bd.qch = (n >= 4000000 && words * 24 <= 16 * 1024) ? BX_QCH : 4;
+          const dim3 pg((unsigned)((n + 256 * bd.qch - 1) / (256 * bd.qch)));
           hipEvent_t done = (fork_at_quick && fork_by_launch) ? ctx->ev_fork : nullptr;
           const int32_t* in_list = nullptr;               // (this launch walks all n reads)
-#define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, (size_t)(PHV == 5 ? words * 24 : 0), ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
+#define MIA_PLAN(NWV, PHV) launch_k(k_bx_plan<NWV, PHV>, pg, pb, (size_t)(bx_quick_lds_words(bd.qch) * 8 + (PHV == 5 ? words * 24 : 0)), ctx->stream, done, ctx->rs, ref, rp, kh, (int64_t)wrap, bd, in_list, (const uint32_t*)(ctx->d_filter_n + 1), n, ctx->d_bin_of)
           if (quick_lds) { switch (nwords) { case 1: MIA_PLAN(1, 5); break; case 2: MIA_PLAN(2, 5); break; case 3: MIA_PLAN(3, 5); break; default: MIA_PLAN(4, 5); break; } }
           else { switch (nwords) { case 1: MIA_PLAN(1, 4); break; case 2: MIA_PLAN(2, 4); break; case 3: MIA_PLAN(3, 4); break; default: MIA_PLAN(4, 4); break; } }
 #undef MIA_PLAN
