@@ -192,3 +192,39 @@ def test_direct_open_list(config, oracle):
                 x, y = x[known], y[known]
             assert (x == y) if isinstance(x, str) else np.array_equal(x, y), (it, name)
     assert max(f[29] for f in fate) >= 1500, [f[29] for f in fate]      # BXC_OPEN: the list was in use (fewer than a twentieth of the reads: more, and the planner's quad kernels take them)
+
+
+def test_quick_plan_with_eight_stretches_per_workgroup():
+    """From four million reads the quick plan's workgroups take eight stretches of 256 reads (BxDev::qch; their per-read arrays sized in the
+    launch's dynamic LDS): 4 M flat reads, two iterations, against the full plan for every read (MIA_HIP_NO_QUICK_PLAN) -- consensus, every
+    read's score / start / end, tally and gaps."""
+    import bench
+    import mia_amd
+    w = bench.make_workload(1, 4_000_000, 7)
+
+    def run(env):
+        if env:
+            os.environ[env] = "1"
+        try:
+            hip = mia_amd.MiaHip(0)
+        finally:
+            if env:
+                os.environ.pop(env, None)
+        hip.set_pssm(w["pssm"])
+        hip.upload_reads(w["stored"].reshape(-1), w["offsets"], w["rc"], np.ones(w["n"], np.uint8), w["as_"], w["ae"])
+        out, ref = [], w["ref"]
+        for _ in range(2):
+            cons = hip.iterate(ref, w["circular"])
+            sc, a, e = hip.alignments()
+            t, g = hip.get_tally()
+            out.append((cons, sc.copy(), a.copy(), e.copy(), t.copy(), g.copy(), list(hip.bx_counters())))
+            ref = cons
+        hip.close()
+        return out
+
+    base, other = run(None), run("MIA_HIP_NO_QUICK_PLAN")
+    assert base[1][6][10] > 0 and other[1][6][10] == 0        # (reads the quick plan left to the full plan: it ran / it did not)
+    for it in range(2):
+        for k, name in enumerate(("consensus", "score", "as", "ae", "tally", "gaps")):
+            x, y = base[it][k], other[it][k]
+            assert (x == y) if isinstance(x, str) else np.array_equal(x, y), (it, name)
