@@ -199,6 +199,36 @@ __device__ __forceinline__ void rec_write(const ReadSet& rs, int64_t i, int32_t*
   t4[3] = make_int4(p[4], p[5], p[6], p[7]);
 }
 
+// ... the same record as four 16-byte words in registers (k_cull_records hands a wavefront's records over through LDS: rec_store_wave)
+__device__ __forceinline__ void rec_make(const ReadSet& rs, int64_t i, uint8_t* drop_front, uint8_t* drop_back, uint8_t df, uint8_t db, const int32_t* p,
+                                         uint32_t st, int32_t actf, const int32_t* umax, int4* r4) {
+  drop_front[i] = df;
+  drop_back[i] = db;
+  const int fl = (rs.rc[i] ? TRF_RC : 0) | (df ? TRF_DF : 0) | (db ? TRF_DB : 0) | ((st & ST_DIAG) ? TRF_DIAG : 0) |
+                 ((st & ST_TOO_LONG) ? TRF_TOO_LONG : 0) | (rs.sk[i] ? TRF_SK : 0) | ((st & ST_ONEGAP) ? TRF_ONEGAP : 0) |
+                 ((umax && umax[i] >= 0) ? TRF_NO_N : 0);
+  r4[0] = make_int4(rs.as[i], rs.ae[i], (int32_t)((uint32_t)rs.len[i] | ((uint32_t)(uint16_t)rs.abr[i] << 16)), fl);
+  r4[1] = make_int4(rs.refstart[i], (int32_t)rs.roff[i], actf, (int32_t)(st >> 8));
+  r4[2] = make_int4(p[0], p[1], p[2], p[3]);
+  r4[3] = make_int4(p[4], p[5], p[6], p[7]);
+}
+// The records of the 64 reads i0 .. i0 + 63 of a wavefront, 4 KB in a row: a lane storing its own record writes four 16-byte pieces 64
+// bytes apart from its neighbours' -- every store instruction touches 64 lines and fills a quarter of each.  Through LDS (buf: this
+// wavefront's 256 words of 16 bytes) every store instruction writes 1 KB without a hole.  Every lane of the wavefront calls this.
+__device__ __forceinline__ void rec_store_wave(int32_t* trec, int64_t i0, int64_t n, const int4* r4, int lane, int4* buf) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) buf[lane * 4 + q] = r4[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int4* out = reinterpret_cast<int4*>(trec) + i0 * 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int w = k * 64 + lane;
+    if (i0 + (w >> 2) < n) out[w] = buf[w];
+  }
+}
+
 struct SlotInfo {             // per local AlnSeq slot (global slot - slot_base)
   int64_t base;               // first global slot of this context
   const int64_t* n_local_p;   // slots owned by this context in this iteration (device: the scan's total)
@@ -499,7 +529,9 @@ __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, con
     if (lane == li) { my_flen = g.ncols_f + nf; my_actf = af + nf; my_blen = g.split ? g.ncols_b + nb : 0; my_st = st_new; }        // (the counts are wave-uniform: the read's own lane keeps them for its link and its record)
   }
   // ---- own dropped marks, the persistent back slot, the links of formerly split reads (k_cull_mark)
-  if (!in) return;
+  __shared__ int4 s_rec[4][256];              // (rec_store_wave: a wavefront's 64 records)
+  int4 r4[4] = {make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0), make_int4(0, 0, 0, 0)};
+  if (in) {
   if (dev_cut) { slope = dev_cut[0]; intercept = dev_cut[1]; }
   const double min_score = hard_cut > 0 ? (double)hard_cut : (double)(intercept + (slope * (double)rs.len[me]));
   const bool low = (double)rs.score[me] < min_score;
@@ -516,9 +548,8 @@ __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, con
   if (!sk) {
     if (front_slot0[me] >= 0) add_link(front_slot0[me], 1, 0, 0);
     if (back_slot[me] >= 0) add_link(back_slot[me], 2, 0, 0);
-    if (with_records) rec_write(rs, me, ri.trec, drop_front, drop_back, 0, 0, p, my_st, 0, umax);
-    return;
-  }
+    if (with_records) rec_make(rs, me, drop_front, drop_back, 0, 0, p, my_st, 0, umax, r4);
+  } else {
   // WITH_RECORDS (round 5): the read's tally record and dropped bits as k_rec_params would write them if no link existed -- its own slot(s),
   // its own depth-code parameters, listed once.  k_rec_params then returns at once unless the iteration has a link (a formerly split read, a
   // strand-unknown read with pass-1 slots): it read every per-read array again to write 64 bytes per read that are known here.
@@ -534,8 +565,11 @@ __global__ __launch_bounds__(256) void k_cull_records(ReadSet rs, int32_t L, con
     const int64_t ls = my_slot - si.base, n_local = *si.n_local_p;
     if (ls >= 0 && ls < n_local) { p[2] = my_flen + my_blen; p[3] = 1; }
     if (g_me.split && ls + 1 < n_local) { p[4] = my_flen; p[5] = my_actf; p[6] = my_flen + my_blen; p[7] = 1; }
-    rec_write(rs, me, ri.trec, drop_front, drop_back, df, db, p, my_st, my_actf, umax);
+    rec_make(rs, me, drop_front, drop_back, df, db, p, my_st, my_actf, umax, r4);
   }
+  }
+  }
+  if (with_records) rec_store_wave(ri.trec, i0, rs.n, r4, lane, s_rec[wv]);
 }
 
 // own dropped marks, the persistent back slot, and the links of formerly split reads
