@@ -2098,6 +2098,10 @@ __global__ void k_ma_ins_events(MaRecords mr, int64_t n_ins, const int32_t* ins_
 }
 
 // ---- insert columns (find_ins_cons, src/map_align.c:444-510) ----------------------
+// The buffer of the insert tallies for `cap` slots: nine 32-bit words per slot as find_ins_cons reads them, then -- 8-byte aligned -- three
+// 64-bit words per slot that k_ins_tally adds to instead of five of the nine (ins_sc_of; call_inserts_at folds them back before it calls)
+MIA_HD inline int64_t ins_words(int64_t cap) { return ((cap * 9 + 1) & ~(int64_t)1) + cap * 6; }
+MIA_HD inline unsigned long long* ins_sc_of(int32_t* ins_tally, int64_t cap) { return reinterpret_cast<unsigned long long*>(ins_tally + ((cap * 9 + 1) & ~(int64_t)1)); }
 // ins_off[pos] = sum of gaps[0..pos-1]; slot (pos, j) -> ins_off[pos] + j; 9 words per slot:
 // A,C,G,T counts, number of reads with a base there, scoreA..scoreT
 // cap: slots the insert buffers hold.  The host launches with the capacity left from the last call and reads the real total
@@ -2111,14 +2115,18 @@ __global__ void k_ins_tally(const uint64_t* events, int32_t n_events, const int3
   const int gc = (int)(uint32_t)ev, j = (int)((ev >> 32) & 1023), code = (int)((ev >> 42) & 7), d = (int)((ev >> 45) & 31);
   const int rc = (int)((ev >> 50) & 1);
   if (gc <= 0 || gc >= L || j >= gaps[gc] || ins_off[gc] + j >= cap) continue;
-  int32_t* t = ins_tally + (int64_t)(ins_off[gc] + j) * 9;
+  // A device-scope atomic is a trip to memory of its own on this part (eight L2s: 64 bytes written per add, 12 G adds/s whatever the
+  // address), and an event used to cost six.  Three: the base's count (or "another character"); scores A and C in one 64-bit add, G and
+  // T in another -- (c << 32) + a with a sign-extended: the low half of the sum is the sum of the a's as long as that fits 32 bits (it did
+  // before: the words were 32 bits), the rest the sum of the c's, exactly.  The number of reads with a base here is the counts' sum.
+  const int64_t sl = (int64_t)(ins_off[gc] + j);
+  int32_t* t = ins_tally + sl * 9;
+  unsigned long long* sc = ins_sc_of(ins_tally, cap) + sl * 3;
   const int32_t* row = pssm2 + (rc ? PSSM_WORDS : 0) + d * 25 + code;
   if (code < 4) atomicAdd(&t[code], 1);
-  atomicAdd(&t[4], 1);
-  atomicAdd(&t[5], row[0]);
-  atomicAdd(&t[6], row[5]);
-  atomicAdd(&t[7], row[10]);
-  atomicAdd(&t[8], row[15]);
+  else atomicAdd(&sc[2], 1ull);
+  atomicAdd(&sc[0], (unsigned long long)(((long long)row[5] << 32) + (long long)row[0]));
+  atomicAdd(&sc[1], (unsigned long long)(((long long)row[15] << 32) + (long long)row[10]));
   }
 }
 
@@ -2145,15 +2153,23 @@ __global__ void k_call_columns(const int32_t* tally, int32_t Lp, int32_t L, int 
                        tally[T_SG * Lp + p], tally[T_ST * Lp + p], cons_code);
 }
 __device__ __forceinline__ void call_inserts_at(int p, const int32_t* tally, int32_t Lp, const int32_t* gaps, const int32_t* ins_off,
-                                                const int32_t* ins_tally, int cons_code, char* ins_calls, int32_t cap) {
+                                                int32_t* ins_tally, int cons_code, char* ins_calls, int32_t cap) {
   const int span = tally[T_SPAN * Lp + p];
   for (int j = 0; j < gaps[p] && ins_off[p] + j < cap; j++) {
-    const int32_t* t = ins_tally + (int64_t)(ins_off[p] + j) * 9;
+    const int64_t sl = (int64_t)(ins_off[p] + j);
+    int32_t* t = ins_tally + sl * 9;
+    // (k_ins_tally's three 64-bit words folded back into the slot's own: whoever reads the nine words after the calls -- mia_hip_get_ins_tally
+    // -- finds them as add_base's counterpart leaves them.  A slot belongs to one column, a column to one thread; folding twice changes nothing.)
+    const unsigned long long* sc = ins_sc_of(ins_tally, cap) + sl * 3;
+    const long long x0 = (long long)sc[0], x1 = (long long)sc[1];
+    const int32_t sA = (int32_t)(uint32_t)x0, sC = (int32_t)((x0 - (long long)sA) >> 32), sG = (int32_t)(uint32_t)x1, sT = (int32_t)((x1 - (long long)sG) >> 32);
+    t[4] = t[0] + t[1] + t[2] + t[3] + (int32_t)sc[2];
+    t[5] = sA; t[6] = sC; t[7] = sG; t[8] = sT;
     ins_calls[ins_off[p] + j] = call_base(t[0], t[1], t[2], t[3], span - t[4], span, t[5], t[6], t[7], t[8], cons_code);
   }
 }
 __global__ void k_call_inserts(const int32_t* tally, int32_t Lp, int32_t L, const int32_t* gaps, const int32_t* ins_off,
-                               const int32_t* ins_tally, int cons_code, char* ins_calls, int32_t cap) {
+                               int32_t* ins_tally, int cons_code, char* ins_calls, int32_t cap) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p <= 0 || p >= L) return;
   call_inserts_at(p, tally, Lp, gaps, ins_off, ins_tally, cons_code, ins_calls, cap);

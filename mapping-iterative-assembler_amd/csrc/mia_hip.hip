@@ -2458,7 +2458,7 @@ static int consensus_launch(mia_hip_ctx* ctx, int cons_code, int64_t cap, bool c
     hipLaunchKernelGGL(k_call_columns, dim3((L + 255) / 256), dim3(256), 0, ctx->stream, ctx->tb.tally, Lp, L, cons_code, ctx->d_calls);
   }
   if (cap <= 0) return MIA_HIP_OK;
-  HIPCHK(hipMemsetAsync(ctx->d_ins_tally, 0, (size_t)cap * 9 * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_ins_tally, 0, (size_t)ins_words(cap) * 4, ctx->stream));
   const int ne = ctx->n_events_host;
   if (events_on_device)
     hipLaunchKernelGGL(k_ins_tally, dim3(256), dim3(256), 0, ctx->stream, ctx->tb.events, 0, ctx->d_pssm, ctx->d_ins_off, ctx->tb.gaps, L, ctx->d_ins_tally,
@@ -2505,7 +2505,7 @@ extern "C" int mia_hip_consensus(mia_hip_ctx* ctx, int cons_code, char* out, int
   std::vector<char> ins_big;
   if (total > ctx->ins_tally_cap) {
     const int64_t cap = (int64_t)total + total / 4 + 1024;
-    if (dev_alloc(ctx, &ctx->d_ins_tally, (size_t)cap * 9) || dev_alloc(ctx, &ctx->d_ins_calls, (size_t)cap)) return MIA_HIP_ERR_NOMEM;
+    if (dev_alloc(ctx, &ctx->d_ins_tally, (size_t)ins_words(cap)) || dev_alloc(ctx, &ctx->d_ins_calls, (size_t)cap)) return MIA_HIP_ERR_NOMEM;
     ctx->ins_tally_cap = cap;
     rc0 = insert_part(cap);
     if (rc0) return rc0;

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_call_columns_z(const int32_t* tally, in
 }
 
 __global__ __launch_bounds__(256) void k_call_inserts_count(const int32_t* tally, int32_t Lp, int32_t L, const int32_t* gaps, const int32_t* ins_off,
-                                                              const int32_t* ins_tally, int cons_code, const char* calls, char* ins_calls, int32_t ins_cap,
+                                                              int32_t* ins_tally, int cons_code, const char* calls, char* ins_calls, int32_t ins_cap,
                                                               const int32_t* ins_total, int32_t* cnt, const int32_t* abort_if = nullptr) {
   if (abort_if && *abort_if != 0) return;     // (mia_hip_iterate queued this launch before the alignment's exact-kernel count was known: see iterate_body)
   const int p = blockIdx.x * 256 + threadIdx.x;
